@@ -1,0 +1,139 @@
+"""ORACLE (test infrastructure, never shipped): closed-form "jet" restatement of the fused HIP kernels, numpy fp64.
+
+The reference obtains d^k u / dx^k by k autograd graph walks (neurodiffeq.py:21-34) through
+``FCNN.forward`` (networks.py:59-70).  The HIP path instead propagates the value and the first/second
+partial derivatives ("streams") of every hidden unit forward through the MLP and reverses those recurrences
+by hand.  This file states exactly that algorithm, one numpy statement per formula,
+so the kernels can be checked stage by stage:
+
+* ``mlp_jets``      -- forward streams of the raw network output,
+* ``mlp_jets_vjp``  -- parameter gradient given the adjoint of every output stream.
+
+Parity status: PINNED via ``tests/test_oracle_golden.py`` -- streams are compared with ``ref_diff`` of
+``oracle/autograd_ref.py`` (itself pinned to the reference's golden vectors) and the VJP with torch autograd.
+
+A stream is a tuple of coordinate indices: ``()`` value, ``(a,)`` d/dx_a, ``(a, b)`` d2/dx_a dx_b (a <= b).
+"""
+import numpy as np
+
+
+def act_derivs(name, z):
+    """sigma(z) and its first three derivatives."""
+    if name == "tanh":
+        t = np.tanh(z)
+        s1 = 1 - t * t
+        return t, s1, -2 * t * s1, -2 * s1 * (1 - 3 * t * t)
+    if name == "sin":
+        s, c = np.sin(z), np.cos(z)
+        return s, c, -s, -c
+    raise KeyError(name)
+
+
+def split_params(flat, dims):
+    """flat -> [(W (out,in), b (out,)), ...] in torch order."""
+    out, off = [], 0
+    for a, b in zip(dims[:-1], dims[1:]):
+        w = flat[off:off + a * b].reshape(b, a); off += a * b
+        bias = flat[off:off + b]; off += b
+        out.append((w, bias))
+    assert off == flat.size
+    return out
+
+
+def close_streams(streams):
+    """A second-order stream needs both of its first-order streams; the value stream is always present."""
+    s = {()}
+    for m in streams:
+        m = tuple(sorted(m))
+        assert len(m) <= 2, "order > 2 is outside the fused path"
+        s.add(m)
+        for a in m:
+            s.add((a,))
+    return sorted(s, key=lambda m: (len(m), m))
+
+
+def _forward(flat, dims, act, coords, streams):
+    layers = split_params(np.asarray(flat, dtype=np.float64), dims)
+    x = np.stack([np.asarray(c, dtype=np.float64).reshape(-1) for c in coords], axis=1)   # (N, d)
+    n, d = x.shape
+    # input "activations": value = x, d/dx_a = e_a, second = 0
+    h = {m: np.zeros((n, d)) for m in streams}
+    h[()] = x
+    for m in streams:
+        if len(m) == 1:
+            h[m][:, m[0]] = 1.0
+    saved = []
+    for li, (w, b) in enumerate(layers):
+        z = {m: h[m] @ w.T for m in streams}
+        z[()] = z[()] + b
+        if li == len(layers) - 1:
+            return z, saved, layers
+        s0, s1, s2, s3 = act_derivs(act, z[()])
+        hn = {(): s0}
+        for m in streams:
+            if len(m) == 1:
+                hn[m] = s1 * z[m]
+            elif len(m) == 2:
+                hn[m] = s2 * z[(m[0],)] * z[(m[1],)] + s1 * z[m]
+        saved.append((h, z, (s1, s2, s3)))
+        h = hn
+    raise AssertionError
+
+
+def mlp_jets(flat, dims, act, coords, streams):
+    """Streams of the raw network output: dict stream -> (N, n_out)."""
+    streams = close_streams(streams)
+    z, _, _ = _forward(flat, dims, act, coords, streams)
+    return z
+
+
+def mlp_jets_vjp(flat, dims, act, coords, gbar):
+    """Parameter gradient sum_n sum_streams <gbar[stream][n], d out_stream[n] / d params>  (flat, torch order).
+
+    ``gbar``: dict stream -> (N, n_out) adjoints."""
+    streams = close_streams(list(gbar.keys()))
+    zlast, saved, layers = _forward(flat, dims, act, coords, streams)
+    n = zlast[()].shape[0]
+    zb = {m: np.asarray(gbar.get(m, np.zeros_like(zlast[()])), dtype=np.float64) for m in streams}
+    grads = [None] * len(layers)
+    # h feeding the last layer is recomputed from the last saved z
+    for li in range(len(layers) - 1, -1, -1):
+        w, _ = layers[li]
+        if li == 0:
+            x = np.stack([np.asarray(c, dtype=np.float64).reshape(-1) for c in coords], axis=1)
+            hin = {m: np.zeros_like(x) for m in streams}
+            hin[()] = x
+            for m in streams:
+                if len(m) == 1:
+                    hin[m][:, m[0]] = 1.0
+        else:
+            _, zprev, (s1, s2, _) = saved[li - 1]
+            s0 = act_derivs(act, zprev[()])[0]
+            hin = {(): s0}
+            for m in streams:
+                if len(m) == 1:
+                    hin[m] = s1 * zprev[m]
+                elif len(m) == 2:
+                    hin[m] = s2 * zprev[(m[0],)] * zprev[(m[1],)] + s1 * zprev[m]
+        dw = sum(zb[m].T @ hin[m] for m in streams)
+        db = zb[()].sum(axis=0)
+        grads[li] = (dw, db)
+        if li == 0:
+            break
+        hb = {m: zb[m] @ w for m in streams}
+        _, zprev, (s1, s2, s3) = saved[li - 1]
+        nzb = {m: np.zeros_like(hb[()]) for m in streams}
+        nzb[()] = s1 * hb[()]
+        for m in streams:
+            if len(m) == 1:
+                nzb[()] += s2 * zprev[m] * hb[m]
+                nzb[m] += s1 * hb[m]
+        for m in streams:
+            if len(m) == 2:
+                a, b = (m[0],), (m[1],)
+                nzb[()] += (s3 * zprev[a] * zprev[b] + s2 * zprev[m]) * hb[m]
+                nzb[a] += s2 * zprev[b] * hb[m]
+                nzb[b] += s2 * zprev[a] * hb[m]
+                nzb[m] += s1 * hb[m]
+        zb = nzb
+    return np.concatenate([np.concatenate([dw.reshape(-1), db]) for dw, db in grads])

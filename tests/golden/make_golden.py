@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Generate golden fixtures by running the UNMODIFIED reference (NeuroDiffGym/neurodiffeq at /root/reference).
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It writes small ``.npz`` files next to this script.  They pin, for reduced-size versions of the
+BASELINE configs C1/C2/C3/C5:
+
+* the generator samples for a fixed ``torch.manual_seed`` (bit-exact contract, north_star),
+* function values, residuals, loss and the flat parameter gradient of ONE reference training closure
+  (``solvers.py:369-395``) evaluated in fp64 and in fp32 on the same fp32-representable inputs,
+* a 3-epoch ``run_train_epoch`` trajectory (loss history + final parameters) with default Adam.
+
+Nothing here is imported by the product; ``tests/`` load the ``.npz`` files only.
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(HERE, "_refshim"), "/root/reference"]
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+import numpy as np
+import torch
+
+import neurodiffeq  # noqa: E402  (sets default dtype fp64 + default device as an import side effect)
+from neurodiffeq import diff
+from neurodiffeq.utils import set_tensor_type
+from neurodiffeq.networks import FCNN, SinActv
+from neurodiffeq.conditions import IVP, DirichletBVP2D, IBVP1D, NoCondition
+from neurodiffeq.generators import Generator1D, Generator2D
+from neurodiffeq.solvers import Solver1D, Solver2D
+
+set_tensor_type(device="cpu", float_bits=32)
+PI = np.pi
+
+
+# ----------------------------------------------------------------------------- config definitions
+def lid(x):
+    return (1 - torch.exp(-50.0 * x)) * (1 - torch.exp(50.0 * (x - 1)))
+
+
+def cfg_c1(n=64):
+    pde = lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)]
+    nets = [FCNN(1, 1, hidden_units=(32, 32), actv=SinActv) for _ in range(2)]
+    conds = [IVP(0.0, 1.5), IVP(0.0, 1.0)]
+    gen = Generator1D(n, 0.1, 12.0, "equally-spaced-noisy")
+    return dict(kind="1d", pde=pde, nets=nets, conds=conds, gen=gen)
+
+
+def cfg_c2(g=16):
+    pde = lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2)]
+    nets = [FCNN(2, 1, hidden_units=(32, 32))]
+    conds = [DirichletBVP2D(
+        x_min=0, x_min_val=lambda y: torch.sin(PI * y), x_max=1, x_max_val=lambda y: 0,
+        y_min=0, y_min_val=lambda x: 0, y_max=1, y_max_val=lambda x: 0)]
+    gen = Generator2D((g, g), (0, 0), (1, 1), "equally-spaced-noisy")
+    return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen)
+
+
+def cfg_c3(g=12):
+    nu = 0.01 / PI
+    pde = lambda u, x, t: [diff(u, t) + u * diff(u, x) - nu * diff(u, x, order=2)]
+    nets = [FCNN(2, 1, hidden_units=(64, 64, 64))]
+    conds = [IBVP1D(x_min=-1, x_max=1, t_min=0, t_min_val=lambda x: -torch.sin(PI * x),
+                    x_min_val=lambda t: 0, x_max_val=lambda t: 0)]
+    gen = Generator2D((g, g), (-1, 0), (1, 1), "equally-spaced-noisy")
+    return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen)
+
+
+def cfg_c5(g=8):
+    re = 400.0
+
+    def pde(u, v, p, x, y):
+        mx = u * diff(u, x) + v * diff(u, y) + diff(p, x) - 1 / re * (diff(u, x, order=2) + diff(u, y, order=2))
+        my = u * diff(v, x) + v * diff(v, y) + diff(p, y) - 1 / re * (diff(v, x, order=2) + diff(v, y, order=2))
+        return [mx, my, diff(u, x) + diff(v, y)]
+
+    nets = [FCNN(2, 1, hidden_units=(64, 64, 64)) for _ in range(3)]
+    zero = lambda s: 0
+    conds = [
+        DirichletBVP2D(0, zero, 1, zero, 0, zero, 1, lid),
+        DirichletBVP2D(0, zero, 1, zero, 0, zero, 1, zero),
+        NoCondition(),
+    ]
+    gen = Generator2D((g, g), (0, 0), (1, 1), "equally-spaced-noisy")
+    return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen)
+
+
+CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5}
+
+
+# ----------------------------------------------------------------------------- helpers
+def flat_params(nets):
+    return torch.cat([p.detach().reshape(-1) for n in nets for p in n.parameters()])
+
+
+def closure_once(cfg, coords32, dtype):
+    """One reference training closure (solvers.py:369-395) at the given precision."""
+    nets = [n.to(dtype) for n in cfg["nets"]]
+    for n in nets:
+        n.zero_grad()
+    batch = [c.detach().to(dtype).reshape(-1, 1).requires_grad_(True) for c in coords32]
+    funcs = [c.enforce(n, *batch) for n, c in zip(nets, cfg["conds"])]
+    res = torch.cat(cfg["pde"](*funcs, *batch), dim=1)
+    loss = (res ** 2).mean()
+    loss.backward()
+    # a parameter the loss does not depend on (e.g. the output bias of the NS pressure net, which enters
+    # the residual only through derivatives) keeps ``.grad is None`` in the reference; recorded as zeros.
+    grad = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                      for n in nets for p in n.parameters()])
+    out = dict(
+        funcs=torch.cat(funcs, dim=1).detach().numpy(),
+        residuals=res.detach().numpy(),
+        loss=np.asarray(loss.item()),
+        grad=grad.detach().numpy(),
+    )
+    for n in nets:
+        n.to(torch.float32)
+    return out
+
+
+def make(name, seed=0):
+    torch.manual_seed(seed)
+    cfg = CONFIGS[name]()
+    gen = cfg["gen"]
+    torch.manual_seed(seed + 1)
+    draw1 = gen.get_examples()
+    draw2 = gen.get_examples()
+    as_list = lambda d: [d] if isinstance(d, torch.Tensor) else list(d)
+    draw1, draw2 = as_list(draw1), as_list(draw2)
+    coords = [d.detach().clone() for d in draw1]
+
+    out = dict(
+        seed=np.asarray(seed),
+        params0=flat_params(cfg["nets"]).numpy(),
+        coords=np.stack([c.numpy() for c in coords]),
+        draw2=np.stack([c.detach().numpy() for c in draw2]),
+    )
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        r = closure_once(cfg, coords, dt)
+        for k, v in r.items():
+            out[f"{k}_{tag}"] = v
+
+    # 3-epoch trajectory with the reference solver (default Adam lr=1e-3), fp32, fresh samples per epoch
+    Solver = Solver1D if cfg["kind"] == "1d" else Solver2D
+    kw = dict(t_min=0.1, t_max=12.0) if cfg["kind"] == "1d" else dict(xy_min=(0, 0), xy_max=(1, 1))
+    pde = cfg["pde"]
+    solver = Solver(pde if cfg["kind"] != "1d" else pde, cfg["conds"], nets=cfg["nets"],
+                    train_generator=gen, valid_generator=gen, n_batches_valid=0, **kw)
+    torch.manual_seed(seed + 2)
+    for _ in range(3):
+        solver.run_train_epoch()
+    out["traj_loss"] = np.asarray(solver.metrics_history["train_loss"])
+    out["traj_params"] = flat_params(cfg["nets"]).numpy()
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, "N =", coords[0].numel(), "P =", out["params0"].size,
+          "loss64 =", float(out["loss_f64"]), "loss32 =", float(out["loss_f32"]),
+          "traj =", out["traj_loss"], "->", os.path.getsize(path), "bytes")
+
+
+def make_diff_known_answers():
+    """Known-answer vectors for diff()/operators on closed-form functions (mirrors the reference's
+    tests/test_neurodiffeq.py:87-96 and tests/test_operators_cartesian.py:62-111), fp64."""
+    from neurodiffeq.operators import grad, div, curl, laplacian
+    torch.manual_seed(7)
+    n = 32
+    x, y, z = [torch.rand(n, 1, dtype=torch.float64, requires_grad=True) for _ in range(3)]
+    u = torch.sin(x) * torch.exp(y) + x * y * z ** 3
+    v = torch.cos(x * y) + z
+    w = x ** 2 * torch.tanh(y * z)
+    out = dict(x=x, y=y, z=z, u=u, v=v, w=w)
+    out["u_x"], out["u_xx"], out["u_yz"] = diff(u, x), diff(u, x, order=2), diff(diff(u, y), z)
+    out["lap_u"] = laplacian(u, x, y, z)
+    out["div"] = div(u, v, w, x, y, z)
+    cx, cy, cz = curl(u, v, w, x, y, z)
+    out["curl_x"], out["curl_y"], out["curl_z"] = cx, cy, cz
+    gx, gy, gz = grad(w, x, y, z)
+    out["grad_w_x"], out["grad_w_y"], out["grad_w_z"] = gx, gy, gz
+    t = torch.linspace(-1, 1, n, dtype=torch.float64, requires_grad=True).reshape(-1, 1)
+    out["t"] = t
+    for k in range(1, 5):
+        out[f"exp_d{k}"] = diff(torch.exp(2 * t), t, order=k)
+        out[f"sq_d{k}"] = diff(t ** 2, t, order=k)
+    np.savez_compressed(os.path.join(HERE, "diff_known.npz"),
+                        **{k: v.detach().numpy() for k, v in out.items()})
+    print("diff_known: ok")
+
+
+if __name__ == "__main__":
+    for name in CONFIGS:
+        make(name)
+    make_diff_known_answers()

@@ -1,0 +1,136 @@
+"""Pin the oracles (oracle/*.py) to the golden vectors produced by the unmodified reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import autograd_ref as R
+from oracle import jet_ref as J
+
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8}
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"{name}.npz"))
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
+def test_generator_draws_bit_exact(golden_dir, name):
+    g = _load(golden_dir, name)
+    torch.manual_seed(int(g["seed"]))
+    cfg = R.build_config(name, SIZES[name])          # consumes the RNG exactly like the reference's net init
+    torch.manual_seed(int(g["seed"]) + 1)
+    d1 = np.stack([c.numpy() for c in cfg["sampler"]()])
+    d2 = np.stack([c.numpy() for c in cfg["sampler"]()])
+    assert np.array_equal(d1, g["coords"])
+    assert np.array_equal(d2, g["draw2"])
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
+def test_default_init_bit_exact(golden_dir, name):
+    g = _load(golden_dir, name)
+    torch.manual_seed(int(g["seed"]))
+    cfg = R.build_config(name, SIZES[name])
+    assert np.array_equal(R.get_flat(cfg["nets"]).numpy(), g["params0"])
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_closure_matches_reference(golden_dir, name, prec):
+    g = _load(golden_dir, name)
+    dt = torch.float64 if prec == "f64" else torch.float32
+    cfg = R.build_config(name, SIZES[name], dtype=dt)
+    R.set_flat(cfg["nets"], g["params0"])
+    coords = [torch.from_numpy(c).to(dt) for c in g["coords"]]
+    out = R.closure(cfg["nets"], cfg["enforcers"], cfg["pde"], coords)
+    tol = 1e-12 if prec == "f64" else 2e-6
+    assert rel_l2(out["funcs"].numpy(), g[f"funcs_{prec}"]) < tol
+    assert rel_l2(out["residuals"].numpy(), g[f"residuals_{prec}"]) < tol
+    assert abs(out["loss"].item() - float(g[f"loss_{prec}"])) <= tol * abs(float(g[f"loss_{prec}"]))
+    assert rel_l2(R.get_flat_grad(cfg["nets"]).numpy(), g[f"grad_{prec}"]) < tol
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3"])
+def test_adam_trajectory_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    torch.manual_seed(int(g["seed"]))
+    cfg = R.build_config(name, SIZES[name])
+    loop = R.TrainLoop(cfg["nets"], cfg["enforcers"], cfg["pde"], cfg["sampler"])
+    torch.manual_seed(int(g["seed"]) + 2)
+    for _ in range(3):
+        loop.epoch()
+    assert np.allclose(loop.history, g["traj_loss"], rtol=2e-5)
+    assert rel_l2(R.get_flat(cfg["nets"]).numpy(), g["traj_params"]) < 1e-5
+
+
+def test_diff_known_answers(golden_dir):
+    g = _load(golden_dir, "diff_known")
+    x, y, z = [torch.tensor(g[k], requires_grad=True) for k in "xyz"]
+    u = torch.sin(x) * torch.exp(y) + x * y * z ** 3
+    assert np.allclose(R.ref_diff(u, x).detach().numpy(), g["u_x"], rtol=1e-12)
+    assert np.allclose(R.ref_diff(u, x, 2).detach().numpy(), g["u_xx"], rtol=1e-12)
+    assert np.allclose(R.ref_diff(R.ref_diff(u, y), z).detach().numpy(), g["u_yz"], rtol=1e-12)
+    t = torch.tensor(g["t"], requires_grad=True)
+    for k in range(1, 5):
+        assert np.allclose(R.ref_diff(torch.exp(2 * t), t, k).detach().numpy(), g[f"exp_d{k}"], rtol=1e-12)
+        assert np.allclose(R.ref_diff(t ** 2, t, k).detach().numpy(), g[f"sq_d{k}"], atol=1e-12)
+    with pytest.raises(ValueError):
+        R.ref_diff(u.reshape(-1), x)
+
+
+# ---------------------------------------------------------------- jet oracle vs autograd oracle
+ARCH = {"c1": ((1, 32, 32, 1), "sin"), "c2": ((2, 32, 32, 1), "tanh"), "c3": ((2, 64, 64, 64, 1), "tanh")}
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3"])
+def test_jet_streams_match_autograd(golden_dir, name):
+    g = _load(golden_dir, name)
+    dims, act = ARCH[name]
+    npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
+    flat = g["params0"][:npar].astype(np.float64)
+    net = R.make_fcnn(dims[0], dims[-1], dims[1:-1], act, torch.float64)
+    R.set_flat([net], flat)
+    cs = [torch.tensor(c, dtype=torch.float64).reshape(-1, 1).requires_grad_(True) for c in g["coords"]]
+    out = net(torch.cat(cs, dim=1))
+    d = len(cs)
+    streams = [(a,) for a in range(d)] + [(a, b) for a in range(d) for b in range(a, d)]
+    jets = J.mlp_jets(flat, dims, act, [c.detach().numpy() for c in cs], streams)
+    assert np.allclose(jets[()], out.detach().numpy(), rtol=1e-12, atol=1e-14)
+    for m in streams:
+        ref = out
+        for a in m:
+            ref = R.ref_diff(ref, cs[a])
+        assert np.allclose(jets[m], ref.detach().numpy(), rtol=1e-10, atol=1e-12), m
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3"])
+def test_jet_vjp_matches_autograd(golden_dir, name):
+    g = _load(golden_dir, name)
+    dims, act = ARCH[name]
+    npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
+    flat = g["params0"][:npar].astype(np.float64)
+    net = R.make_fcnn(dims[0], dims[-1], dims[1:-1], act, torch.float64)
+    R.set_flat([net], flat)
+    cs = [torch.tensor(c, dtype=torch.float64).reshape(-1, 1).requires_grad_(True) for c in g["coords"]]
+    out = net(torch.cat(cs, dim=1))
+    d = len(cs)
+    streams = [()] + [(a,) for a in range(d)] + [(a, b) for a in range(d) for b in range(a, d)]
+    rng = np.random.default_rng(0)
+    gbar = {m: rng.standard_normal(out.shape) for m in streams}
+    total = 0
+    for m in streams:
+        ref = out
+        for a in m:
+            ref = R.ref_diff(ref, cs[a])
+        total = total + (ref * torch.tensor(gbar[m])).sum()
+    total.backward()
+    want = R.get_flat_grad([net]).numpy()
+    got = J.mlp_jets_vjp(flat, dims, act, [c.detach().numpy() for c in cs], gbar)
+    assert rel_l2(got, want) < 1e-11
