@@ -1,0 +1,84 @@
+/* ndq -- C-ABI of the MI355X-native PINN training core (libndq.so).
+ *
+ * The reference (NeuroDiffGym/neurodiffeq) has no FFI layer: its hot path is Python on top of torch autograd
+ * (SURVEY.md 8b).  These entry points are what a binding for that path would call; each cites the reference code it
+ * replaces.  All pointers are DEVICE pointers to fp32 unless stated; `stream` is a hipStream_t passed as void*.
+ * No entry point allocates, synchronises or touches host memory.  Return value: 0 on success, a positive hipError_t,
+ * or a negative NDQ_E* code.
+ */
+#ifndef NDQ_H
+#define NDQ_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDQ_EUNSUPPORTED (-1) /* no compiled kernel for this descriptor */
+#define NDQ_EINVAL (-2)       /* bad argument */
+
+#define NDQ_ACT_TANH 0 /* torch.nn.Tanh, default of FCNN (networks.py:27,52-53) */
+#define NDQ_ACT_SIN 1  /* neurodiffeq.networks.SinActv (networks.py:142-152) */
+
+/* Shape of one FCNN (networks.py:59-66: Linear(d,h) actv [Linear(h,h) actv]* Linear(h,n_out)) plus the set of
+ * derivative streams of its raw output that the residual needs.  Stream order in every jets/gbar array:
+ *   0: value | 1..d: d/dx_a (if first) | second-order pairs (a<=b) selected by mask2, enumerated
+ *   (0,0),(0,1),..,(0,d-1),(1,1),..  (bit k of mask2 <-> k-th pair).  */
+typedef struct ndq_mlp_desc {
+  int d;       /* number of input coordinates (1..3) */
+  int first;   /* 1: first-order streams present */
+  int mask2;   /* second-order pair mask */
+  int hidden;  /* width of every hidden layer (multiple of 16) */
+  int layers;  /* number of hidden layers */
+  int act;     /* NDQ_ACT_* */
+  int n_out;   /* output units */
+} ndq_mlp_desc;
+
+/* 1 if libndq.so carries kernels for this descriptor. */
+int ndq_mlp_supported(const ndq_mlp_desc* desc);
+/* number of streams NS, of parameters P (flat torch order W1,b1,W2,b2,...,Wout,bout) */
+int ndq_mlp_num_streams(const ndq_mlp_desc* desc);
+int ndq_mlp_num_params(const ndq_mlp_desc* desc);
+/* number of workgroups ndq_mlp_jet_bwd launches for n points == rows of `partials` it writes */
+int ndq_mlp_bwd_blocks(const ndq_mlp_desc* desc, int n);
+
+/* Fused FCNN forward with derivative streams.  Replaces FCNN.forward (networks.py:68-70) together with every
+ * diff(net_out, x_a[, order=2]) sweep over it (neurodiffeq.py:21-34).
+ *   coords [d][ldc], params [P], jets (out) [NS][n_out][ldj]  */
+int ndq_mlp_jet_fwd(const ndq_mlp_desc* desc, const float* coords, int ldc, int n, const float* params, float* jets,
+                    int ldj, void* stream);
+
+/* Adjoint of ndq_mlp_jet_fwd w.r.t. the parameters: given gbar[s][o][n] = dLoss/d jets[s][o][n] it recomputes the
+ * streams and writes per-workgroup partial sums of dLoss/dparams.  Replaces the part of loss.backward()
+ * (solvers.py:393) that walks the differentiated network graph.
+ *   partials (out) [ndq_mlp_bwd_blocks][P]  */
+int ndq_mlp_jet_bwd(const ndq_mlp_desc* desc, const float* coords, int ldc, int n, const float* params,
+                    const float* gbar, int ldj, float* partials, void* stream);
+
+/* out[i] = (accumulate ? out[i] : 0) + scale * sum_{r<nparts} partials[r*len + i], fixed summation order.
+ * Second stage of every reduction (parameter gradients: accumulate over n_batches like solvers.py:360-362;
+ * loss: mean of squared residuals, solvers.py:218). */
+int ndq_reduce_partials(const float* partials, int nparts, int len, float* out, int accumulate, float scale,
+                        void* stream);
+
+/* Fused Adam step on a flat parameter vector (torch.optim.Adam defaults, solvers.py:182); step is the 1-based
+ * step count AFTER this update.  Optional fast path for the optimizer.step() of solvers.py:331-341. */
+int ndq_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* Signature of a generated pointwise kernel launcher (one per traced PDE system, built by
+ * neurodiffeq_amd/codegen.py with hipcc).  It evaluates the condition re-parameterisation (conditions.py
+ * `parameterize`), the user's residuals (`diff_eqs`, solvers.py:380), the squared-residual partial sums
+ * (solvers.py:218) and -- when gbar != NULL -- the adjoint of the loss w.r.t. every network output stream.
+ *   coords [d][ldc]; jets/gbar: arrays of n_nets device pointers, each [NS_k][n_out_k][ldj];
+ *   funcs (opt, out) [n_funcs][ldj]; resid (opt, out) [n_eq][ldj];
+ *   loss_partials (out) [ndq_pw_blocks(n)] block sums of r^2 over all equations;
+ *   seed_scale: gbar = seed_scale * d(sum r^2)/d jets, i.e. 1/(N_global * n_eq) for the mean. */
+typedef int (*ndq_pointwise_fn)(const float* coords, int ldc, int n, const float* const* jets,
+                                float* const* gbar, int ldj, float* funcs, float* resid, float* loss_partials,
+                                float seed_scale, void* stream);
+typedef int (*ndq_pw_blocks_fn)(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

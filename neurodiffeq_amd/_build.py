@@ -1,0 +1,40 @@
+"""In-tree build of the gfx950 artefacts (no cmake, no torch headers): plain ``hipcc -shared``.
+
+``libndq.so`` = csrc/ndq_api.hip (+ ndq_mlp.h), the C-ABI declared in include/ndq.h.  The built library travels to
+the GPU box with the repository snapshot; ``ensure_built`` recompiles only when a source is newer than the library.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libndq.so")
+SOURCES = [os.path.join(CSRC, "ndq_api.hip")]
+HEADERS = [os.path.join(CSRC, "ndq_mlp.h"), os.path.join(HERE, "..", "include", "ndq.h")]
+HIPCC = os.environ.get("NDQ_HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+def is_stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [HIPCC] + FLAGS + SOURCES + ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed building libndq.so:\n" + proc.stderr[-6000:])
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

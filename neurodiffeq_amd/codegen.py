@@ -1,0 +1,374 @@
+"""HIP code generation for the traced pointwise stage (see :mod:`neurodiffeq_amd.symbolic`).
+
+One generated kernel per traced PDE system does, per collocation point, everything the reference does between the
+network forward and the parameter backward: condition re-parameterisation (conditions.py ``parameterize``), the
+user's residuals (``diff_eqs``, solvers.py:380, with every ``diff`` already resolved symbolically), the squared
+residual sum for the loss (solvers.py:218) and the adjoint of that loss w.r.t. every network output stream -- the
+seed of ``loss.backward()`` (solvers.py:393).  It is the HBM-bound kernel of the path: it reads the coordinates and
+the streams, writes the adjoint streams (+ optionally function values / residuals) and one partial sum per block.
+
+The launcher it exports has the ``ndq_pointwise_fn`` signature of include/ndq.h.
+"""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+from .symbolic import Graph
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+JIT_DIR = os.path.join(HERE, "_jit")
+HIPCC = os.environ.get("NDQ_HIPCC", "/opt/rocm/bin/hipcc")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+# ----------------------------------------------------------------------------------------------- stream layout
+def pair_list(d):
+    return [(a, b) for a in range(d) for b in range(a, d)]
+
+
+class NetStreams:
+    """Which derivative streams of net ``k`` the residual needs, closed to a set the MLP kernels provide.
+
+    deps: global coordinate indices fed to the net (in order).  Stream slots follow include/ndq.h."""
+
+    def __init__(self, deps, n_out):
+        self.deps = tuple(deps)
+        self.d = len(deps)
+        self.n_out = n_out
+        self.first = 0
+        self.mask2 = 0
+
+    def need(self, mi):
+        """mi: multi-index of GLOBAL coordinate indices."""
+        loc = tuple(sorted(self.deps.index(c) for c in mi))
+        if len(loc) >= 1:
+            self.first = 1
+        if len(loc) == 2:
+            self.mask2 |= 1 << pair_list(self.d).index(loc)
+
+    @property
+    def n_streams(self):
+        return 1 + self.first * self.d + bin(self.mask2).count("1")
+
+    def slot(self, mi):
+        loc = tuple(sorted(self.deps.index(c) for c in mi))
+        if len(loc) == 0:
+            return 0
+        if len(loc) == 1:
+            return 1 + loc[0]
+        k = pair_list(self.d).index(loc)
+        assert (self.mask2 >> k) & 1
+        return 1 + self.d + bin(self.mask2 & ((1 << k) - 1)).count("1")
+
+
+# ----------------------------------------------------------------------------------------------- expression emission
+def _lit(v):
+    if v != v or v in (float("inf"), float("-inf")):
+        raise ValueError("non-finite constant in traced expression")
+    s = "%.9g" % v
+    if "." not in s and "e" not in s and "n" not in s:
+        s += ".0"
+    return s + "f"
+
+
+def _powi_expr(x, n):
+    if n == 0:
+        return "1.0f"
+    if n == 1:
+        return x
+    if n <= 8:
+        return "(" + "*".join([x] * n) + ")"
+    return f"powf({x}, {float(n)}f)"
+
+
+_UN_FWD = {
+    "neg": "-{a}", "sin": "sinf({a})", "cos": "cosf({a})", "tan": "tanf({a})", "exp": "expf({a})",
+    "log": "logf({a})", "tanh": "tanhf({a})", "sqrt": "sqrtf({a})", "abs": "fabsf({a})", "sinh": "sinhf({a})",
+    "cosh": "coshf({a})", "sigmoid": "(1.0f/(1.0f+expf(-{a})))", "recip": "(1.0f/{a})",
+    "sign": "(({a}>0.0f)-({a}<0.0f))",
+}
+# adjoint factor of the single child: child_adj += b * factor ; {a} child value, {v} node value
+_UN_ADJ = {
+    "neg": "-{b}", "sin": "{b}*cosf({a})", "cos": "-{b}*sinf({a})", "tan": "{b}*(1.0f+{v}*{v})",
+    "exp": "{b}*{v}", "log": "{b}/{a}", "tanh": "{b}*(1.0f-{v}*{v})", "sqrt": "{b}/(2.0f*{v})",
+    "abs": "{b}*(({a}>0.0f)-({a}<0.0f))", "sinh": "{b}*coshf({a})", "cosh": "{b}*sinhf({a})",
+    "sigmoid": "{b}*{v}*(1.0f-{v})", "recip": "-{b}*{v}*{v}", "sign": None,
+}
+
+
+class PointwiseProgram:
+    """A traced system lowered to straight-line fp32 code.
+
+    graph      : symbolic.Graph
+    residuals  : node ids, one per equation (columns of the reference's (N, n_eq) residual, solvers.py:381)
+    funcs      : node ids of the re-parameterised function values (one per condition, solvers.py:373-375)
+    streams    : {net_idx: NetStreams}
+    """
+
+    def __init__(self, graph: Graph, residuals, funcs, n_nets):
+        self.g = graph
+        self.residuals = list(residuals)
+        self.funcs = list(funcs)
+        self.n_nets = n_nets
+        self.n_coords = graph.n_coords
+        self.order = graph.reachable(self.residuals + self.funcs)
+        self.streams = {}
+        for k in range(n_nets):
+            deps = graph.net_deps.get(k)
+            if deps is None:
+                continue
+            self.streams[k] = NetStreams(deps, graph.net_nout[k])
+        self.symbols = []          # net nodes in use, in order
+        for i in self.order:
+            n = graph.nodes[i]
+            if n[0] == "net":
+                self.streams[n[1]].need(n[3])
+                self.symbols.append(i)
+        # nets referenced by no symbol still need a (value-only) layout entry
+        self.source = self._emit()
+        self.key = hashlib.sha1(self.source.encode()).hexdigest()[:16]
+
+    # ---- helpers
+    def _val(self, i):
+        n = self.g.nodes[i]
+        if n[0] == "const":
+            return _lit(n[1])
+        if n[0] == "coord":
+            return f"c{n[1]}"
+        return f"v{i}"
+
+    def sym_location(self, i):
+        _, k, o, mi = self.g.nodes[i]
+        st = self.streams[k]
+        return k, st.slot(mi) * st.n_out + o
+
+    def _emit_point_fn(self):
+        g = self.g
+        L = []
+        # which nodes depend on a network symbol (only those carry adjoints)
+        dep = {}
+        for i in self.order:
+            n = g.nodes[i]
+            dep[i] = n[0] == "net" or any(dep[c] for c in g.children(i))
+        res_order = g.reachable(self.residuals)
+        res_set = set(res_order)
+        L.append("// ---- forward")
+        for i in self.order:
+            n = g.nodes[i]
+            op = n[0]
+            if op in ("const", "coord"):
+                continue
+            if op == "net":
+                L.append(f"  const float v{i} = s[{self.symbols.index(i)}];")
+                continue
+            if op in ("add", "sub", "mul", "div"):
+                sym = {"add": "+", "sub": "-", "mul": "*", "div": "/"}[op]
+                e = f"{self._val(n[1])} {sym} {self._val(n[2])}"
+            elif op == "powi":
+                e = _powi_expr(self._val(n[1]), n[2])
+            elif op == "powc":
+                e = f"powf({self._val(n[1])}, {_lit(n[2])})"
+            else:
+                e = _UN_FWD[op].format(a=self._val(n[1]))
+            L.append(f"  const float v{i} = {e};")
+        for e, i in enumerate(self.residuals):
+            L.append(f"  r[{e}] = {self._val(i)};")
+        for m, i in enumerate(self.funcs):
+            L.append(f"  f[{m}] = {self._val(i)};")
+        L.append("  if (!want_adj) return;")
+        L.append("// ---- adjoint of sum_e r_e^2 (scaled by seed) w.r.t. the network streams")
+        terms = {}
+        for e, i in enumerate(self.residuals):
+            if dep.get(i):
+                terms.setdefault(i, []).append(f"(2.0f*seed)*{self._val(i)}")
+        for i in reversed(res_order):
+            if i not in terms or not dep[i]:
+                continue
+            n = g.nodes[i]
+            op = n[0]
+            L.append(f"  const float b{i} = {' + '.join(terms[i])};")
+            b = f"b{i}"
+            if op == "net":
+                continue
+
+            def push(child, expr):
+                if dep[child]:
+                    terms.setdefault(child, []).append(expr)
+
+            if op == "add":
+                push(n[1], b); push(n[2], b)
+            elif op == "sub":
+                push(n[1], b); push(n[2], f"-{b}")
+            elif op == "mul":
+                push(n[1], f"{b}*{self._val(n[2])}"); push(n[2], f"{b}*{self._val(n[1])}")
+            elif op == "div":
+                push(n[1], f"{b}/{self._val(n[2])}")
+                push(n[2], f"-{b}*v{i}/{self._val(n[2])}")
+            elif op == "powi":
+                push(n[1], f"{b}*{float(n[2])}f*{_powi_expr(self._val(n[1]), n[2] - 1)}")
+            elif op == "powc":
+                push(n[1], f"{b}*{_lit(n[2])}*powf({self._val(n[1])}, {_lit(n[2] - 1.0)})")
+            else:
+                t = _UN_ADJ[op]
+                if t is not None:
+                    push(n[1], t.format(b=b, a=self._val(n[1]), v=f"v{i}"))
+        for idx, i in enumerate(self.symbols):
+            L.append(f"  g[{idx}] = {'b%d' % i if (i in terms and i in res_set) else '0.0f'};")
+        return "\n".join(L)
+
+    def _emit(self):
+        nsym = max(len(self.symbols), 1)
+        neq, nf, nc, nn = len(self.residuals), len(self.funcs), self.n_coords, self.n_nets
+        body = self._emit_point_fn()
+        loads, stores = [], []
+        for idx, i in enumerate(self.symbols):
+            k, loc = self.sym_location(i)
+            loads.append(f"    s[{idx}] = a.jets[{k}][(size_t){loc} * a.ldj + n];")
+        # adjoint stores: every slot of every net is written (unused streams get 0 so the backward kernel can read them)
+        for k, st in sorted(self.streams.items()):
+            used = {}
+            for idx, i in enumerate(self.symbols):
+                kk, loc = self.sym_location(i)
+                if kk == k:
+                    used[loc] = idx
+            for loc in range(st.n_streams * st.n_out):
+                val = f"g[{used[loc]}]" if loc in used else "0.0f"
+                stores.append(f"      a.gbar[{k}][(size_t){loc} * a.ldj + n] = {val};")
+        src = f"""// GENERATED by neurodiffeq_amd/codegen.py -- fused pointwise stage of one traced PDE system (gfx950).
+// per point: {nc} coords + {len(self.symbols)} stream symbols in, {neq} residual(s), {nf} function value(s), adjoints out.
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#define NDQ_PW_INLINE __device__ __forceinline__
+#else
+#include <math.h>
+#include <stddef.h>
+#define NDQ_PW_INLINE static inline
+#endif
+
+#define NDQ_PW_NC {nc}
+#define NDQ_PW_NSYM {len(self.symbols)}
+#define NDQ_PW_NEQ {neq}
+#define NDQ_PW_NF {nf}
+#define NDQ_PW_NNETS {nn}
+
+NDQ_PW_INLINE void ndq_pw_point(const float* c, const float* s, float seed, int want_adj, float* r, float* f, float* g) {{
+{chr(10).join(f"  const float c{i} = c[{i}];" for i in range(nc))}
+{body}
+}}
+
+#ifdef __HIPCC__
+struct PwArgs {{
+  const float* coords;
+  const float* jets[NDQ_PW_NNETS];
+  float* gbar[NDQ_PW_NNETS];
+  float* funcs;
+  float* resid;
+  float* loss_partials;
+  int n, ldc, ldj, want_adj;
+  float seed;
+}};
+
+extern "C" __global__ __launch_bounds__(256) void ndq_pw_kernel(PwArgs a) {{
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  float sq = 0.f;
+  if (n < a.n) {{
+    float c[NDQ_PW_NC], s[{nsym}], r[{max(neq, 1)}], f[{max(nf, 1)}], g[{nsym}];
+#pragma unroll
+    for (int i = 0; i < NDQ_PW_NC; ++i) c[i] = a.coords[(size_t)i * a.ldc + n];
+{chr(10).join(loads)}
+    ndq_pw_point(c, s, a.seed, a.want_adj, r, f, g);
+#pragma unroll
+    for (int e = 0; e < NDQ_PW_NEQ; ++e) sq = fmaf(r[e], r[e], sq);
+    if (a.resid) {{
+#pragma unroll
+      for (int e = 0; e < NDQ_PW_NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];
+    }}
+    if (a.funcs) {{
+#pragma unroll
+      for (int m = 0; m < NDQ_PW_NF; ++m) a.funcs[(size_t)m * a.ldj + n] = f[m];
+    }}
+    if (a.want_adj) {{
+{chr(10).join(stores)}
+    }}
+  }}
+  // fixed-order block reduction of the squared residuals: wave shuffle tree, then the 4 waves in order
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
+  __shared__ float wsum[4];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}}
+
+extern "C" int ndq_pw_blocks(int n) {{ return (n + 255) / 256; }}
+
+extern "C" int ndq_pw_launch(const float* coords, int ldc, int n, const float* const* jets, float* const* gbar, int ldj,
+                             float* funcs, float* resid, float* loss_partials, float seed_scale, void* stream) {{
+  if (!coords || !jets || !loss_partials || n <= 0) return -2;
+  PwArgs a;
+  a.coords = coords;
+  for (int k = 0; k < NDQ_PW_NNETS; ++k) {{
+    a.jets[k] = jets[k];
+    a.gbar[k] = gbar ? gbar[k] : nullptr;
+  }}
+  a.funcs = funcs; a.resid = resid; a.loss_partials = loss_partials;
+  a.n = n; a.ldc = ldc; a.ldj = ldj; a.want_adj = gbar ? 1 : 0; a.seed = seed_scale;
+  hipLaunchKernelGGL(ndq_pw_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}}
+#endif
+"""
+        return src
+
+    # ---- algorithmic HBM traffic per point (bytes), for the roofline report
+    def bytes_per_point(self, train=True, write_resid=False, write_funcs=False):
+        b = 4 * self.n_coords + 4 * len(self.symbols)
+        if train:
+            b += 4 * sum(st.n_streams * st.n_out for st in self.streams.values())
+        if write_resid:
+            b += 4 * len(self.residuals)
+        if write_funcs:
+            b += 4 * len(self.funcs)
+        return b
+
+
+# ----------------------------------------------------------------------------------------------- build / load
+class PointwiseKernel:
+    def __init__(self, so_path):
+        self.path = so_path
+        self.lib = ctypes.CDLL(so_path)
+        self.lib.ndq_pw_launch.restype = ctypes.c_int
+        self.lib.ndq_pw_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_float, ctypes.c_void_p]
+        self.lib.ndq_pw_blocks.restype = ctypes.c_int
+        self.lib.ndq_pw_blocks.argtypes = [ctypes.c_int]
+
+    def blocks(self, n):
+        return self.lib.ndq_pw_blocks(n)
+
+
+def so_path_for(program: PointwiseProgram):
+    return os.path.join(JIT_DIR, f"pw_{program.key}.so")
+
+
+def build(program: PointwiseProgram, force=False):
+    """Compile the generated source for gfx950 (in-tree cache keyed by the source hash) and return the .so path."""
+    os.makedirs(JIT_DIR, exist_ok=True)
+    so = so_path_for(program)
+    src = os.path.join(JIT_DIR, f"pw_{program.key}.hip")
+    if os.path.exists(so) and not force:
+        return so
+    with open(src, "w") as fh:
+        fh.write(program.source)
+    tmp = so + f".tmp{os.getpid()}"
+    cmd = [HIPCC] + HIPCC_FLAGS + [src, "-o", tmp]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed for generated pointwise kernel {src}:\n{proc.stderr[-4000:]}")
+    os.replace(tmp, so)
+    return so
+
+
+def load(program: PointwiseProgram):
+    return PointwiseKernel(build(program))

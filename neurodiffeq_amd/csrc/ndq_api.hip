@@ -1,0 +1,200 @@
+// C-ABI of libndq.so (declared in include/ndq.h): descriptor dispatch onto the templated gfx950 kernels of
+// ndq_mlp.h, the second-stage reduction and the fused Adam step.
+#include "ndq_mlp.h"
+#include "../../include/ndq.h"
+
+namespace ndq {
+
+// ---------------------------------------------------------------------------------------------- kernel table
+// X(D, FIRST, MASK2, NB, L, ACT)  -- n_out = 1.  Stream sets are closed under "second order needs first order".
+// BASELINE configs: C1 (1,1,0,2,2,SIN) | C2 (2,1,0b101,2,2,TANH) | C3 (2,1,0b001,4,3,TANH) | C5 u,v (2,1,0b101,4,3,TANH),
+// p (2,1,0,4,3,TANH); value-only variants serve solution evaluation (solvers.py:682-720).
+#ifndef NDQ_CFG_TABLE
+#define NDQ_CFG_TABLE(X)      \
+  X(1, 0, 0, 2, 2, ACT_SIN)   \
+  X(1, 1, 0, 2, 2, ACT_SIN)   \
+  X(1, 1, 1, 2, 2, ACT_SIN)   \
+  X(1, 0, 0, 2, 2, ACT_TANH)  \
+  X(1, 1, 0, 2, 2, ACT_TANH)  \
+  X(1, 1, 1, 2, 2, ACT_TANH)  \
+  X(2, 0, 0, 2, 2, ACT_TANH)  \
+  X(2, 1, 0, 2, 2, ACT_TANH)  \
+  X(2, 1, 1, 2, 2, ACT_TANH)  \
+  X(2, 1, 5, 2, 2, ACT_TANH)  \
+  X(2, 1, 7, 2, 2, ACT_TANH)  \
+  X(2, 0, 0, 4, 3, ACT_TANH)  \
+  X(2, 1, 0, 4, 3, ACT_TANH)  \
+  X(2, 1, 1, 4, 3, ACT_TANH)  \
+  X(2, 1, 5, 4, 3, ACT_TANH)
+#endif
+
+struct Entry {
+  int d, first, mask2, nb, layers, act;
+  int ns, p;
+  int (*fwd)(const MlpArgs&, hipStream_t);
+  int (*bwd)(const MlpArgs&, int blocks, hipStream_t);
+  size_t fwd_lds, bwd_lds;
+};
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+template <class C>
+int launch_fwd(const MlpArgs& a, hipStream_t s) {
+  static bool attr = false;
+  const size_t lds = fwd_lds_bytes<C>();
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_jet_fwd_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  const int tiles = (a.n + 15) / 16;
+  int blocks = (tiles + kWaves - 1) / kWaves;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(mlp_jet_fwd_kernel<C>, dim3(blocks), dim3(kThreads), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+template <class C>
+int launch_bwd(const MlpArgs& a, int blocks, hipStream_t s) {
+  static bool attr = false;
+  const size_t lds = bwd_lds_bytes<C>(kWaves);
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_jet_bwd_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(mlp_jet_bwd_kernel<C>, dim3(blocks), dim3(kThreads), lds, s, a);
+  return (int)hipGetLastError();
+}
+
+#define NDQ_ENTRY(D, F, M, NB, L, A)                                                                      \
+  Entry{D, F, M, NB, L, A, Cfg<D, F, M, NB, L, A>::NS, Cfg<D, F, M, NB, L, A>::P,                         \
+        &launch_fwd<Cfg<D, F, M, NB, L, A>>, &launch_bwd<Cfg<D, F, M, NB, L, A>>,                         \
+        fwd_lds_bytes<Cfg<D, F, M, NB, L, A>>(), bwd_lds_bytes<Cfg<D, F, M, NB, L, A>>(kWaves)},
+
+static const Entry kTable[] = {NDQ_CFG_TABLE(NDQ_ENTRY)};
+
+static const Entry* find(const ndq_mlp_desc* d) {
+  if (!d || d->n_out != 1 || d->hidden % 16) return nullptr;
+  for (const Entry& e : kTable)
+    if (e.d == d->d && e.first == d->first && e.mask2 == d->mask2 && e.nb * 16 == d->hidden && e.layers == d->layers &&
+        e.act == d->act)
+      return &e;
+  return nullptr;
+}
+
+static int bwd_blocks(int n) {
+  const int tiles = (n + 15) / 16;
+  int blocks = (tiles + kWaves - 1) / kWaves;
+  if (blocks > 512) blocks = 512;  // <= 2 workgroups per CU: each wave amortises its epilogue over several tiles
+  if (blocks < 1) blocks = 1;
+  return blocks;
+}
+
+// ---------------------------------------------------------------------------------------------- reduction
+// out[i] = (acc ? out[i] : 0) + scale * sum_r partials[r*len + i];  one thread per 4 columns, rows in fixed order,
+// 4 independent row chains per thread for memory-level parallelism (combined in a fixed order).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nparts, int len,
+                                                              float* __restrict__ out, int accumulate, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 3 < nparts; r += 4) {
+    s0 += part[(size_t)r * len + i];
+    s1 += part[(size_t)(r + 1) * len + i];
+    s2 += part[(size_t)(r + 2) * len + i];
+    s3 += part[(size_t)(r + 3) * len + i];
+  }
+  for (; r < nparts; ++r) s0 += part[(size_t)r * len + i];
+  const float s = ((s0 + s1) + (s2 + s3)) * scale;
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------- Adam
+// torch.optim.Adam (amsgrad=False, maximize=False) single-tensor formula:
+//   g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int len, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  float gi = g[i];
+  const float pi = p[i];
+  if (wd != 0.f) gi = fmaf(wd, pi, gi);
+  const float mi = fmaf(b1, m[i], (1.f - b1) * gi);       // lerp(m, g, 1-b1)
+  const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2s + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+}  // namespace ndq
+
+using namespace ndq;
+
+extern "C" {
+
+int ndq_mlp_supported(const ndq_mlp_desc* desc) { return find(desc) ? 1 : 0; }
+
+int ndq_mlp_num_streams(const ndq_mlp_desc* desc) {
+  const Entry* e = find(desc);
+  return e ? e->ns : NDQ_EUNSUPPORTED;
+}
+
+int ndq_mlp_num_params(const ndq_mlp_desc* desc) {
+  const Entry* e = find(desc);
+  return e ? e->p : NDQ_EUNSUPPORTED;
+}
+
+int ndq_mlp_bwd_blocks(const ndq_mlp_desc* desc, int n) {
+  const Entry* e = find(desc);
+  if (!e) return NDQ_EUNSUPPORTED;
+  if (n <= 0) return NDQ_EINVAL;
+  return bwd_blocks(n);
+}
+
+int ndq_mlp_jet_fwd(const ndq_mlp_desc* desc, const float* coords, int ldc, int n, const float* params, float* jets,
+                    int ldj, void* stream) {
+  const Entry* e = find(desc);
+  if (!e) return NDQ_EUNSUPPORTED;
+  if (!coords || !params || !jets || n <= 0 || ldc < n || ldj < n) return NDQ_EINVAL;
+  MlpArgs a{};
+  a.coords = coords; a.params = params; a.jets = jets; a.n = n; a.ldc = ldc; a.ldj = ldj;
+  return e->fwd(a, static_cast<hipStream_t>(stream));
+}
+
+int ndq_mlp_jet_bwd(const ndq_mlp_desc* desc, const float* coords, int ldc, int n, const float* params,
+                    const float* gbar, int ldj, float* partials, void* stream) {
+  const Entry* e = find(desc);
+  if (!e) return NDQ_EUNSUPPORTED;
+  if (!coords || !params || !gbar || !partials || n <= 0 || ldc < n || ldj < n) return NDQ_EINVAL;
+  MlpArgs a{};
+  a.coords = coords; a.params = params; a.gbar = gbar; a.partials = partials; a.n = n; a.ldc = ldc; a.ldj = ldj;
+  return e->bwd(a, bwd_blocks(n), static_cast<hipStream_t>(stream));
+}
+
+int ndq_reduce_partials(const float* partials, int nparts, int len, float* out, int accumulate, float scale,
+                        void* stream) {
+  if (!partials || !out || nparts <= 0 || len <= 0) return NDQ_EINVAL;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     partials, nparts, len, out, accumulate, scale);
+  return (int)hipGetLastError();
+}
+
+int ndq_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || len <= 0 || step <= 0) return NDQ_EINVAL;
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), params, grad,
+                     exp_avg, exp_avg_sq, len, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,601 @@
+// MI355X (gfx950) device code for the PINN training hot path: fused FCNN "jet" forward and its hand-written
+// adjoint.  Replaces, for one collocation batch, what the reference does with
+//   FCNN.forward                      (neurodiffeq/networks.py:59-70)
+//   k reverse sweeps per diff() call  (neurodiffeq/neurodiffeq.py:21-34, operators.py:15-33)
+//   loss.backward() through that twice-differentiated graph (solvers.py:393)
+// by ONE forward kernel that propagates value / first / second partial-derivative "streams" of every hidden
+// unit through the MLP, and ONE backward kernel that recomputes the streams and reverses the recurrences
+// (math: SURVEY.md App. A.1/A.2; numpy statement of the same recurrences: oracle/jet_ref.py).
+//
+// Execution model (CDNA4):
+//  * a wave (64 lanes) owns a tile of 16 collocation points; lane = (p = lane&15 : point, q = lane>>4).
+//  * a "fragment" f32x4 frag[NB] holds, for point p, hidden units 16*b + 4*q + r (b < NB, r < 4) -- exactly the
+//    C/D layout of v_mfma_f32_16x16x4_f32 with units as rows and points as columns.  Register r of block kb is
+//    ALSO a valid B operand (k = q) of the next layer's MFMA if the contraction index is taken in the order
+//    k_t = 16*kb + 4*q + t, so hidden activations never leave registers between layers: the weights are
+//    pre-permuted into "fragment order" in LDS once per workgroup and read back as the A operand with one
+//    conflict-free ds_read_b32 per MFMA.
+//  * f32-in/f32-acc MFMA is bitwise an fmaf chain (exact fp32), so parity with the reference's fp32 ATen path is
+//    a re-association question only.
+//  * weight gradients of hidden layers are themselves MFMA GEMMs contracted over points; the operands need the
+//    point index on the MFMA k axis, i.e. a transpose of the fragments, which goes through a padded (ld = H+4)
+//    per-wave LDS staging tile (conflict-free b128 writes / b32 reads).
+//  * all reductions are fixed-order: lane shuffles -> per-wave -> per-workgroup (sequential over waves in LDS) ->
+//    partials[block][P] in HBM -> ndq_reduce kernel.  No float atomics anywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <utility>
+#include <type_traits>
+
+namespace ndq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ static for
+template <class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// ------------------------------------------------------------------------------------------------ streams
+// A derivative stream is () value, (a) d/dx_a, (a,b) d2/dx_a dx_b with a <= b.  Stream order:
+//   0 | 1..D (if FIRST) | the second-order pairs selected by M2 in the order (0,0),(0,1)..(0,D-1),(1,1)...
+template <int D_, int FIRST_, unsigned M2_>
+struct Streams {
+  static constexpr int D = D_;
+  static constexpr int FIRST = FIRST_;
+  static constexpr unsigned M2 = M2_;
+  static constexpr int NPAIR = D * (D + 1) / 2;
+  static constexpr int count2() {
+    int c = 0;
+    for (int k = 0; k < NPAIR; ++k) c += (M2 >> k) & 1u;
+    return c;
+  }
+  static constexpr int N2 = count2();
+  static constexpr int NS = 1 + FIRST * D + N2;
+  static constexpr int S2 = 1 + FIRST * D;  // index of the first second-order stream
+  static_assert(FIRST == 1 || M2 == 0, "second-order streams need the first-order ones");
+  static constexpr int pair_of(int s) {  // s >= S2 -> pair index
+    int c = S2;
+    for (int k = 0; k < NPAIR; ++k)
+      if ((M2 >> k) & 1u) {
+        if (c == s) return k;
+        ++c;
+      }
+    return -1;
+  }
+  static constexpr int pair_a(int k) {
+    int idx = 0;
+    for (int a = 0; a < D; ++a)
+      for (int b = a; b < D; ++b) {
+        if (idx == k) return a;
+        ++idx;
+      }
+    return -1;
+  }
+  static constexpr int pair_b(int k) {
+    int idx = 0;
+    for (int a = 0; a < D; ++a)
+      for (int b = a; b < D; ++b) {
+        if (idx == k) return b;
+        ++idx;
+      }
+    return -1;
+  }
+  static constexpr int A(int s) { return pair_a(pair_of(s)); }  // coordinate indices of second-order stream s
+  static constexpr int B(int s) { return pair_b(pair_of(s)); }
+};
+
+// ------------------------------------------------------------------------------------------------ activations
+// state kept per hidden unit: t = sigma(z) and c (only where sigma' is not a function of t).
+enum { ACT_TANH = 0, ACT_SIN = 1 };
+
+template <int ACT> struct Act;
+template <> struct Act<ACT_TANH> {  // nn.Tanh, networks.py:27 default
+  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { t = tanhf(z); c = 0.f; }
+  static __device__ __forceinline__ float s1(float t, float) { return fmaf(-t, t, 1.f); }
+  static __device__ __forceinline__ float s2(float t, float, float s1v) { return -2.f * t * s1v; }
+  static __device__ __forceinline__ float s3(float t, float, float s1v) { return -2.f * s1v * fmaf(-3.f * t, t, 1.f); }
+};
+template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
+  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { sincosf(z, &t, &c); }
+  static __device__ __forceinline__ float s1(float, float c) { return c; }
+  static __device__ __forceinline__ float s2(float t, float, float) { return -t; }
+  static __device__ __forceinline__ float s3(float, float c, float) { return -c; }
+};
+
+// ------------------------------------------------------------------------------------------------ config
+template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_>
+struct Cfg {
+  using SS = Streams<D_, FIRST_, M2_>;
+  static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
+  static constexpr int HP = H + 4;  // padded leading dimension of the transpose staging tiles
+  // flat parameter offsets, torch order: W1 (H,D) b1 (H) | W_l (H,H) b_l (H), l = 2..L | Wout (1,H) bout (1)
+  static constexpr int offW1 = 0, offb1 = H * D;
+  static constexpr int offW(int l) { return H * D + H + (l - 2) * (H * H + H); }  // l in 2..L
+  static constexpr int offb(int l) { return offW(l) + H * H; }
+  static constexpr int offWout = H * D + H + (L - 1) * (H * H + H);
+  static constexpr int offbout = offWout + H;
+  static constexpr int P = offbout + 1;
+  // LDS carve (floats): W1T [D][H] | b1 [H] | per hidden-hidden layer: Wf [H*H] (+ Wt [H*H] for bwd) | b_l | Wout | bout
+  static constexpr int ldsW1T = 0, ldsb1 = D * H;
+  static constexpr int ldsLayer0 = D * H + H;
+  static constexpr int layerStride(bool bwd) { return (bwd ? 2 : 1) * H * H + H; }
+  static constexpr int ldsWf(int l, bool bwd) { return ldsLayer0 + (l - 2) * layerStride(bwd); }
+  static constexpr int ldsWt(int l) { return ldsWf(l, true) + H * H; }
+  static constexpr int ldsb(int l, bool bwd) { return ldsWf(l, bwd) + (bwd ? 2 : 1) * H * H; }
+  static constexpr int ldsWout(bool bwd) { return ldsLayer0 + (L - 1) * layerStride(bwd); }
+  static constexpr int ldsbout(bool bwd) { return ldsWout(bwd) + H; }
+  static constexpr int ldsWeightsEnd(bool bwd) { return (ldsbout(bwd) + 1 + 3) & ~3; }
+  static constexpr int stageFloatsPerWave = 2 * 16 * HP;  // Zt and Ht tiles of one stream
+};
+
+struct MlpArgs {
+  const float* coords;   // [D][ldc]  SoA collocation coordinates
+  const float* params;   // [P] flat, torch parameter order
+  const float* gbar;     // bwd: [NS][ldj] adjoint of every output stream
+  float* jets;           // fwd: [NS][ldj] output streams of the raw network
+  float* partials;       // bwd: [gridDim.x][P] per-workgroup parameter-gradient partial sums
+  int n;                 // number of points
+  int ldc;               // leading dimension of coords
+  int ldj;               // leading dimension of jets / gbar
+};
+
+// ------------------------------------------------------------------------------------------------ weight staging
+template <class C, bool BWD>
+__device__ __forceinline__ void stage_weights(float* lds, const float* __restrict__ prm) {
+  constexpr int H = C::H, D = C::D, NB = C::NB;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < D * H; i += nt) {  // W1T[a][j] = W1[j][a]
+    const int a = i / H, j = i - a * H;
+    lds[C::ldsW1T + i] = prm[C::offW1 + j * D + a];
+  }
+  for (int i = tid; i < H; i += nt) {
+    lds[C::ldsb1 + i] = prm[C::offb1 + i];
+    lds[C::ldsWout(BWD) + i] = prm[C::offWout + i];
+  }
+  if (tid == 0) lds[C::ldsbout(BWD)] = prm[C::offbout];
+#pragma unroll
+  for (int l = 2; l <= C::L; ++l) {
+    const float* W = prm + C::offW(l);
+    for (int i = tid; i < H * H; i += nt) {
+      const int lane = i & 63, t = (i >> 6) & 3, blk = i >> 8;  // blk = first*NB + second
+      const int b0 = blk / NB, b1 = blk - b0 * NB;
+      // forward A operand of block (ib=b0, kb=b1), step t:  A[i'][k=q'] = W[16 ib + i'][16 kb + 4 q' + t]
+      lds[C::ldsWf(l, BWD) + i] = W[(16 * b0 + (lane & 15)) * H + 16 * b1 + 4 * (lane >> 4) + t];
+      if (BWD)  // transposed A operand of block (kb=b0, ib=b1): A[i'][k=q'] = W[16 ib + 4 q' + t][16 kb + i']
+        lds[C::ldsWt(l) + i] = W[(16 * b1 + 4 * (lane >> 4) + t) * H + 16 * b0 + (lane & 15)];
+    }
+    for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = prm[C::offb(l) + i];
+  }
+}
+
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// ------------------------------------------------------------------------------------------------ per-layer pieces
+// hidden-unit state of one layer for one tile
+template <class C>
+struct LayerState {
+  float t[C::NB][4];                 // sigma(z)
+  float c[C::NB][4];                 // cos(z) for sin; unused (dead) for tanh
+  f32x4 z[C::NS][C::NB];             // pre-activation derivative streams (index 0 unused: value is in t)
+};
+
+// streams of h = sigma(z) from the layer state:  h0 = t, h_a = s1 z_a, h_ab = s2 z_a z_b + s1 z_ab
+template <class C>
+__device__ __forceinline__ void act_forward(const LayerState<C>& st, f32x4 (&h)[C::NS][C::NB]) {
+  using SS = typename C::SS;
+  using A = Act<C::ACT>;
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = st.t[b][r], c = st.c[b][r];
+      const float s1 = A::s1(t, c);
+      h[0][b][r] = t;
+      if constexpr (SS::FIRST) {
+        sfor<C::D>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
+          h[1 + a][b][r] = s1 * st.z[1 + a][b][r];
+        });
+        if constexpr (SS::N2 > 0) {
+          const float s2 = A::s2(t, c, s1);
+          sfor<SS::N2>([&](auto k_) {
+            constexpr int s = SS::S2 + decltype(k_)::value;
+            constexpr int a = SS::A(s), bb = SS::B(s);
+            h[s][b][r] = fmaf(s2 * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[s][b][r]);
+          });
+        }
+      }
+    }
+}
+
+// adjoint of act_forward: given hbar (overwritten in place with zbar)
+template <class C>
+__device__ __forceinline__ void act_backward(const LayerState<C>& st, f32x4 (&g)[C::NS][C::NB]) {
+  using SS = typename C::SS;
+  using A = Act<C::ACT>;
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = st.t[b][r], c = st.c[b][r];
+      const float s1 = A::s1(t, c);
+      float z0 = s1 * g[0][b][r];
+      if constexpr (SS::FIRST) {
+        const float s2 = A::s2(t, c, s1);
+        float za[C::D];
+        sfor<C::D>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
+          z0 = fmaf(s2 * st.z[1 + a][b][r], g[1 + a][b][r], z0);
+          za[a] = s1 * g[1 + a][b][r];
+        });
+        if constexpr (SS::N2 > 0) {
+          const float s3 = A::s3(t, c, s1);
+          sfor<SS::N2>([&](auto k_) {
+            constexpr int s = SS::S2 + decltype(k_)::value;
+            constexpr int a = SS::A(s), bb = SS::B(s);
+            const float hb = g[s][b][r];
+            const float zA = st.z[1 + a][b][r], zB = st.z[1 + bb][b][r];
+            z0 = fmaf(fmaf(s3 * zA, zB, s2 * st.z[s][b][r]), hb, z0);
+            za[a] = fmaf(s2 * zB, hb, za[a]);
+            za[bb] = fmaf(s2 * zA, hb, za[bb]);
+            g[s][b][r] = s1 * hb;
+          });
+        }
+        sfor<C::D>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
+          g[1 + a][b][r] = za[a];
+        });
+      }
+      g[0][b][r] = z0;
+    }
+}
+
+// z[s][ib] (+)= sum_kb sum_t A(w[(ib*NB+kb)*4+t]) * B(h[s][kb][t]);  w points at a fragment-ordered H x H matrix
+template <class C>
+__device__ __forceinline__ void gemm_frag(const float* __restrict__ w, int lane, const f32x4 (&h)[C::NS][C::NB],
+                                          f32x4 (&z)[C::NS][C::NB]) {
+#pragma unroll
+  for (int ib = 0; ib < C::NB; ++ib)
+#pragma unroll
+    for (int kb = 0; kb < C::NB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float a = w[((ib * C::NB + kb) * 4 + t) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) z[s][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, h[s][kb][t], z[s][ib], 0, 0, 0);
+      }
+}
+
+template <class C>
+__device__ __forceinline__ void zero_frag(f32x4 (&z)[C::NS][C::NB]) {
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) z[s][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// first layer (VALU): z = W1 x + b1; derivative streams of z are columns of W1 (second order: zero)
+template <class C, bool BWD>
+__device__ __forceinline__ void first_layer(const float* lds, int q, const float (&x)[C::D], LayerState<C>& st) {
+  using SS = typename C::SS;
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b) {
+    const int j0 = 16 * b + 4 * q;
+    f32x4 z = lds4(lds + C::ldsb1 + j0);
+    f32x4 w[C::D];
+#pragma unroll
+    for (int a = 0; a < C::D; ++a) {
+      w[a] = lds4(lds + C::ldsW1T + a * C::H + j0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[r] = fmaf(w[a][r], x[a], z[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[r], st.t[b][r], st.c[b][r]);
+    if constexpr (SS::FIRST) {
+#pragma unroll
+      for (int a = 0; a < C::D; ++a) st.z[1 + a][b] = w[a];
+#pragma unroll
+      for (int s = SS::S2; s < C::NS; ++s) st.z[s][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+// hidden layer l (2..L): z = W_l h + b_l on every stream, then activation state
+template <class C, bool BWD>
+__device__ __forceinline__ void hidden_layer(const float* lds, int l, int lane, int q, const f32x4 (&h)[C::NS][C::NB],
+                                             LayerState<C>& st) {
+  f32x4 z[C::NS][C::NB];
+  zero_frag<C>(z);
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
+  gemm_frag<C>(lds + C::ldsWf(l, BWD), lane, h, z);
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[0][b][r], st.t[b][r], st.c[b][r]);
+#pragma unroll
+    for (int s = 1; s < C::NS; ++s) st.z[s][b] = z[s][b];
+  }
+}
+
+__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lane groups q (lanes p, p+16, p+32, p+48)
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float point_sum(float v) {  // sum over the 16 points of the tile (lanes with equal q)
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ forward kernel
+template <class C>
+__global__ __launch_bounds__(256) void mlp_jet_fwd_kernel(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<C, false>(lds, a.params);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  const int wavesPerBlock = blockDim.x >> 6;
+  const int ntiles = (a.n + 15) >> 4;
+  for (int tile = blockIdx.x * wavesPerBlock + wave; tile < ntiles; tile += gridDim.x * wavesPerBlock) {
+    const int n = tile * 16 + p;
+    const int nn = n < a.n ? n : a.n - 1;
+    float x[C::D];
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    LayerState<C> st;
+    first_layer<C, false>(lds, q, x, st);
+    f32x4 h[C::NS][C::NB];
+#pragma unroll
+    for (int l = 2; l <= C::L; ++l) {
+      act_forward<C>(st, h);
+      hidden_layer<C, false>(lds, l, lane, q, h, st);
+    }
+    act_forward<C>(st, h);
+    float out[C::NS];
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) out[s] = 0.f;
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) {
+      const f32x4 wo = lds4(lds + C::ldsWout(false) + 16 * b + 4 * q);
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[s] = fmaf(wo[r], h[s][b][r], out[s]);
+    }
+    const float bout = lds[C::ldsbout(false)];
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+      float v = quad_sum(out[s]);
+      if (s == 0) v += bout;
+      if (q == 0 && n < a.n) a.jets[(size_t)s * a.ldj + n] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward kernel
+// per-wave gradient accumulators (registers), summed over all tiles the wave processes
+template <class C>
+struct GradAcc {
+  float w1[C::D][C::NB][4];          // dW1[j][a], j = 16b+4q+r   (needs point_sum)
+  float b1[C::NB][4];                // db1[j]                    (needs point_sum)
+  f32x4 w[C::L > 1 ? C::L - 1 : 1][C::NB][C::NB];  // dW_l[16jb+4q+r][16kb+p], MFMA accumulators (already summed)
+  float b[C::L > 1 ? C::L - 1 : 1][C::NB][4];      // db_l[j]     (needs point_sum)
+  float wout[C::NB][4];              // dWout[j]                  (needs point_sum)
+  float bout;                        // dbout                     (needs full wave sum)
+};
+
+// dW_l += sum_s Zbar[s] H[s]^T over the 16 points of the tile, stream by stream through the LDS transpose tile.
+// stage: per-wave region of 2*16*HP floats.  Point <-> MFMA k mapping: k = q at step st  <->  point 4*q + st,
+// which makes both the b128 writes (8-lane groups: bank stride 4*(HP mod 8) ... HP = H+4 -> 16 B apart) and the b32
+// reads (32-lane groups: q*4*HP = 16 banks apart) conflict-free.
+template <class C>
+__device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q, const f32x4 (&zb)[C::NS][C::NB],
+                                            const f32x4 (&h)[C::NS][C::NB], f32x4 (&acc)[C::NB][C::NB]) {
+  constexpr int HP = C::HP;
+  float* Zt = stage;
+  float* Ht = stage + 16 * HP;
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) {
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) {
+      *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
+      *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = h[s][b];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float av[C::NB], bv[C::NB];
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b) {
+        av[b] = Zt[(4 * q + st) * HP + 16 * b + p];
+        bv[b] = Ht[(4 * q + st) * HP + 16 * b + p];
+      }
+#pragma unroll
+      for (int jb = 0; jb < C::NB; ++jb)
+#pragma unroll
+        for (int kb = 0; kb < C::NB; ++kb)
+          acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jb], bv[kb], acc[jb][kb], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void mlp_jet_bwd_kernel(MlpArgs a) {
+  using SS = typename C::SS;
+  using A = Act<C::ACT>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<C, true>(lds, a.params);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  const int wavesPerBlock = blockDim.x >> 6;
+  const int ntiles = (a.n + 15) >> 4;
+  float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
+
+  GradAcc<C> acc;
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) acc.w1[d][b][r] = 0.f;
+      acc.b1[b][r] = 0.f;
+      acc.wout[b][r] = 0.f;
+#pragma unroll
+      for (int l = 0; l < C::L - 1; ++l) acc.b[l][b][r] = 0.f;
+    }
+#pragma unroll
+  for (int l = 0; l < C::L - 1; ++l)
+#pragma unroll
+    for (int jb = 0; jb < C::NB; ++jb)
+#pragma unroll
+      for (int kb = 0; kb < C::NB; ++kb) acc.w[l][jb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc.bout = 0.f;
+
+  for (int tile = blockIdx.x * wavesPerBlock + wave; tile < ntiles; tile += gridDim.x * wavesPerBlock) {
+    const int n = tile * 16 + p;
+    const bool valid = n < a.n;
+    const int nn = valid ? n : a.n - 1;
+    float x[C::D], gout[C::NS];
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) gout[s] = valid ? a.gbar[(size_t)s * a.ldj + nn] : 0.f;
+
+    // ---------------- forward recompute, keeping every layer's state
+    LayerState<C> st[C::L];
+    first_layer<C, true>(lds, q, x, st[0]);
+    f32x4 h[C::NS][C::NB];
+    sfor<C::L - 1>([&](auto li_) {
+      constexpr int li = decltype(li_)::value;  // computes layer l = li + 2 from layer li + 1
+      act_forward<C>(st[li], h);
+      hidden_layer<C, true>(lds, li + 2, lane, q, h, st[li + 1]);
+    });
+    act_forward<C>(st[C::L - 1], h);  // h_L streams
+
+    // ---------------- output layer adjoint (n_out = 1): hbar = Wout * gout; dWout += sum_s gout_s h_s; dbout += gout_0
+    f32x4 g[C::NS][C::NB];
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) {
+      const f32x4 wo = lds4(lds + C::ldsWout(true) + 16 * b + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float dw = 0.f;
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+          g[s][b][r] = wo[r] * gout[s];
+          dw = fmaf(gout[s], h[s][b][r], dw);
+        }
+        acc.wout[b][r] += dw;
+      }
+    }
+    acc.bout += (q == 0) ? gout[0] : 0.f;
+
+    // ---------------- hidden layers L .. 2
+    sfor<C::L - 1>([&](auto k_) {
+      constexpr int l = C::L - decltype(k_)::value;          // layer whose weights W_l (H x H) map h_{l-1} -> z_l
+      constexpr int li = l - 1;             // state index of layer l
+      act_backward<C>(st[li], g);           // g: hbar_l -> zbar_l
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc.b[l - 2][b][r] += g[0][b][r];
+      act_forward<C>(st[li - 1], h);        // h_{l-1} streams (inputs of layer l)
+      weight_grad<C>(stage, lane, p, q, g, h, acc.w[l - 2]);
+      f32x4 hb[C::NS][C::NB];
+      zero_frag<C>(hb);
+      gemm_frag<C>(lds + C::ldsWt(l), lane, g, hb);   // hbar_{l-1} = W_l^T zbar_l
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+        for (int b = 0; b < C::NB; ++b) g[s][b] = hb[s][b];
+    });
+
+    // ---------------- first layer: z_a = W1[:,a] (constant), z_ab = 0
+    act_backward<C>(st[0], g);  // g[0] = zbar, g[1+a] = zbar_a
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z0 = g[0][b][r];
+        acc.b1[b][r] += z0;
+#pragma unroll
+        for (int d = 0; d < C::D; ++d) {
+          float v = z0 * x[d];
+          if constexpr (SS::FIRST) v += g[1 + d][b][r];
+          acc.w1[d][b][r] += v;
+        }
+      }
+  }
+
+  // ---------------- reduce: lanes -> wave -> workgroup (fixed order) -> partials[block][P]
+  float* red = lds + C::ldsWeightsEnd(true) + wavesPerBlock * C::stageFloatsPerWave;
+  const float bsum = point_sum(quad_sum(acc.bout));
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc.b1[b][r] = point_sum(acc.b1[b][r]);
+      acc.wout[b][r] = point_sum(acc.wout[b][r]);
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) acc.w1[d][b][r] = point_sum(acc.w1[d][b][r]);
+#pragma unroll
+      for (int l = 0; l < C::L - 1; ++l) acc.b[l][b][r] = point_sum(acc.b[l][b][r]);
+    }
+  for (int w = 0; w < wavesPerBlock; ++w) {
+    if (wave == w) {
+      auto put = [&](int idx, float v) {
+        if (w == 0) red[idx] = v; else red[idx] += v;
+      };
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * b + 4 * q + r;
+          if (p == 0) {
+            put(C::offb1 + j, acc.b1[b][r]);
+            put(C::offWout + j, acc.wout[b][r]);
+#pragma unroll
+            for (int d = 0; d < C::D; ++d) put(C::offW1 + j * C::D + d, acc.w1[d][b][r]);
+#pragma unroll
+            for (int l = 0; l < C::L - 1; ++l) put(C::offb(l + 2) + j, acc.b[l][b][r]);
+          }
+        }
+#pragma unroll
+      for (int l = 0; l < C::L - 1; ++l)
+#pragma unroll
+        for (int jb = 0; jb < C::NB; ++jb)
+#pragma unroll
+          for (int kb = 0; kb < C::NB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              put(C::offW(l + 2) + (16 * jb + 4 * q + r) * C::H + 16 * kb + p, acc.w[l][jb][kb][r]);
+      if (lane == 0) put(C::offbout, bsum);
+    }
+    __syncthreads();
+  }
+  float* out = a.partials + (size_t)blockIdx.x * C::P;
+  for (int i = threadIdx.x; i < C::P; i += blockDim.x) out[i] = red[i];
+}
+
+// ------------------------------------------------------------------------------------------------ host-side sizes
+template <class C> constexpr size_t fwd_lds_bytes() { return sizeof(float) * C::ldsWeightsEnd(false); }
+template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock) {
+  return sizeof(float) * (C::ldsWeightsEnd(true) + wavesPerBlock * C::stageFloatsPerWave + ((C::P + 3) & ~3));
+}
+
+}  // namespace ndq

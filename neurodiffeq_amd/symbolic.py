@@ -1,0 +1,502 @@
+"""Symbolic tracing of the pointwise part of the PINN hot path.
+
+The reference evaluates ``cond.parameterize`` (conditions.py:41-57), the user's ``diff_eqs`` (solvers.py:380) and
+every ``diff()`` inside them (neurodiffeq.py:21-34) as graphs of ATen ops that autograd walks ``order`` times.
+Here the same Python callables are run ONCE on :class:`Sym` proxies.  A network output is an opaque function of
+the coordinates whose partial derivatives are named symbols ("streams") that the fused HIP forward kernel
+(csrc/ndq_mlp.h) provides; ``diff`` therefore becomes plain symbolic differentiation of a hash-consed expression
+DAG, and the DAG (residuals + function values + reverse-mode adjoint w.r.t. the stream symbols) is emitted as one
+fused HIP kernel by :mod:`neurodiffeq_amd.codegen`.
+
+Every traced value has the reference's ``(N, 1)`` column semantics.
+"""
+import math
+import numbers
+
+import torch
+
+__all__ = ["Sym", "Graph", "TraceUnsupported", "is_sym", "sym_diff"]
+
+
+class TraceUnsupported(Exception):
+    """Raised when user code does something the tracer cannot express; the solver then uses the composite path."""
+
+
+# op -> (arity).  Unary elementwise functions are listed in UNARY.
+UNARY = ("neg", "sin", "cos", "tan", "exp", "log", "tanh", "sqrt", "abs", "sinh", "cosh", "sigmoid", "recip", "sign")
+
+
+class Graph:
+    """Hash-consed expression DAG.  Node = (op, args...) with integer ids; leaves:
+    ('const', value) | ('coord', i) | ('net', net_idx, out_idx, multiindex)."""
+
+    def __init__(self, n_coords):
+        self.n_coords = n_coords
+        self.nodes = []
+        self._ids = {}
+        self._dcache = {}
+        self.net_deps = {}       # net_idx -> tuple of coordinate indices in the order fed to the net
+        self.net_nout = {}       # net_idx -> number of output units
+
+    # -------------------------------------------------------------- construction
+    def _mk(self, key):
+        i = self._ids.get(key)
+        if i is None:
+            i = len(self.nodes)
+            self.nodes.append(key)
+            self._ids[key] = i
+        return i
+
+    def const(self, v):
+        v = float(v)
+        if v == 0.0:
+            v = 0.0  # normalise -0.0
+        return self._mk(("const", v))
+
+    def coord(self, i):
+        return self._mk(("coord", int(i)))
+
+    def net(self, net_idx, out_idx, mi=()):
+        return self._mk(("net", int(net_idx), int(out_idx), tuple(sorted(mi))))
+
+    def cval(self, i):
+        n = self.nodes[i]
+        return n[1] if n[0] == "const" else None
+
+    def add(self, a, b):
+        ca, cb = self.cval(a), self.cval(b)
+        if ca is not None and cb is not None:
+            return self.const(ca + cb)
+        if ca == 0.0:
+            return b
+        if cb == 0.0:
+            return a
+        if a > b:
+            a, b = b, a
+        return self._mk(("add", a, b))
+
+    def sub(self, a, b):
+        ca, cb = self.cval(a), self.cval(b)
+        if ca is not None and cb is not None:
+            return self.const(ca - cb)
+        if cb == 0.0:
+            return a
+        if ca == 0.0:
+            return self.unary("neg", b)
+        if a == b:
+            return self.const(0.0)
+        return self._mk(("sub", a, b))
+
+    def mul(self, a, b):
+        ca, cb = self.cval(a), self.cval(b)
+        if ca is not None and cb is not None:
+            return self.const(ca * cb)
+        if ca == 0.0 or cb == 0.0:
+            return self.const(0.0)
+        if ca == 1.0:
+            return b
+        if cb == 1.0:
+            return a
+        if ca == -1.0:
+            return self.unary("neg", b)
+        if cb == -1.0:
+            return self.unary("neg", a)
+        if a > b:
+            a, b = b, a
+        return self._mk(("mul", a, b))
+
+    def div(self, a, b):
+        ca, cb = self.cval(a), self.cval(b)
+        if ca is not None and cb is not None:
+            return self.const(ca / cb)
+        if ca == 0.0:
+            return self.const(0.0)
+        if cb == 1.0:
+            return a
+        return self._mk(("div", a, b))
+
+    def powi(self, a, n):
+        n = int(n)
+        if n == 0:
+            return self.const(1.0)
+        if n == 1:
+            return a
+        ca = self.cval(a)
+        if ca is not None:
+            return self.const(ca ** n)
+        if n < 0:
+            return self.div(self.const(1.0), self.powi(a, -n))
+        return self._mk(("powi", a, n))
+
+    def powc(self, a, c):
+        c = float(c)
+        if c == int(c) and abs(c) <= 64:
+            return self.powi(a, int(c))
+        ca = self.cval(a)
+        if ca is not None:
+            return self.const(ca ** c)
+        if c == 0.5:
+            return self.unary("sqrt", a)
+        return self._mk(("powc", a, c))
+
+    _FOLD = {
+        "neg": lambda v: -v, "sin": math.sin, "cos": math.cos, "tan": math.tan, "exp": math.exp, "log": math.log,
+        "tanh": math.tanh, "sqrt": math.sqrt, "abs": abs, "sinh": math.sinh, "cosh": math.cosh,
+        "sigmoid": lambda v: 1.0 / (1.0 + math.exp(-v)), "recip": lambda v: 1.0 / v,
+        "sign": lambda v: (v > 0) - (v < 0),
+    }
+
+    def unary(self, op, a):
+        ca = self.cval(a)
+        if ca is not None:
+            return self.const(self._FOLD[op](ca))
+        if op == "neg" and self.nodes[a][0] == "neg":
+            return self.nodes[a][1]
+        return self._mk((op, a))
+
+    # -------------------------------------------------------------- differentiation
+    def diff(self, e, ci):
+        """d node e / d coordinate ci (symbolic, memoised)."""
+        key = (e, ci)
+        r = self._dcache.get(key)
+        if r is not None:
+            return r
+        n = self.nodes[e]
+        op = n[0]
+        D = lambda x: self.diff(x, ci)
+        if op == "const":
+            r = self.const(0.0)
+        elif op == "coord":
+            r = self.const(1.0 if n[1] == ci else 0.0)
+        elif op == "net":
+            _, k, o, mi = n
+            if ci not in self.net_deps[k]:
+                r = self.const(0.0)
+            else:
+                if len(mi) >= 2:
+                    raise TraceUnsupported("derivatives of network outputs beyond second order are outside the fused path")
+                r = self.net(k, o, mi + (ci,))
+        elif op == "add":
+            r = self.add(D(n[1]), D(n[2]))
+        elif op == "sub":
+            r = self.sub(D(n[1]), D(n[2]))
+        elif op == "mul":
+            a, b = n[1], n[2]
+            r = self.add(self.mul(D(a), b), self.mul(a, D(b)))
+        elif op == "div":
+            a, b = n[1], n[2]
+            # (a/b)' = a'/b - (a/b) b'/b
+            r = self.sub(self.div(D(a), b), self.mul(e, self.div(D(b), b)))
+        elif op == "powi":
+            a, k = n[1], n[2]
+            r = self.mul(self.mul(self.const(k), self.powi(a, k - 1)), D(a))
+        elif op == "powc":
+            a, c = n[1], n[2]
+            r = self.mul(self.mul(self.const(c), self.powc(a, c - 1.0)), D(a))
+        else:
+            a = n[1]
+            da = D(a)
+            if op == "neg":
+                r = self.unary("neg", da)
+            elif op == "sin":
+                r = self.mul(self.unary("cos", a), da)
+            elif op == "cos":
+                r = self.unary("neg", self.mul(self.unary("sin", a), da))
+            elif op == "tan":
+                r = self.mul(self.add(self.const(1.0), self.mul(e, e)), da)
+            elif op == "exp":
+                r = self.mul(e, da)
+            elif op == "log":
+                r = self.div(da, a)
+            elif op == "tanh":
+                r = self.mul(self.sub(self.const(1.0), self.mul(e, e)), da)
+            elif op == "sqrt":
+                r = self.div(da, self.mul(self.const(2.0), e))
+            elif op == "abs":
+                r = self.mul(self.unary("sign", a), da)
+            elif op == "sign":
+                r = self.const(0.0)
+            elif op == "sinh":
+                r = self.mul(self.unary("cosh", a), da)
+            elif op == "cosh":
+                r = self.mul(self.unary("sinh", a), da)
+            elif op == "sigmoid":
+                r = self.mul(self.mul(e, self.sub(self.const(1.0), e)), da)
+            elif op == "recip":
+                r = self.unary("neg", self.mul(self.mul(e, e), da))
+            else:  # pragma: no cover
+                raise TraceUnsupported(f"no derivative rule for {op}")
+        self._dcache[key] = r
+        return r
+
+    # -------------------------------------------------------------- queries
+    def reachable(self, roots):
+        seen, order = set(), []
+        stack = [(r, False) for r in roots]
+        while stack:
+            i, done = stack.pop()
+            if done:
+                order.append(i)
+                continue
+            if i in seen:
+                continue
+            seen.add(i)
+            stack.append((i, True))
+            n = self.nodes[i]
+            if n[0] in ("const", "coord", "net"):
+                continue
+            for a in self.children(i):
+                if a not in seen:
+                    stack.append((a, False))
+        return order  # topological (children first)
+
+    def children(self, i):
+        n = self.nodes[i]
+        op = n[0]
+        if op in ("const", "coord", "net"):
+            return ()
+        if op in ("add", "sub", "mul", "div"):
+            return (n[1], n[2])
+        return (n[1],)
+
+
+_CURRENT = []
+
+
+def current_graph():
+    if not _CURRENT:
+        raise TraceUnsupported("no active trace")
+    return _CURRENT[-1]
+
+
+class trace_scope:
+    def __init__(self, graph):
+        self.graph = graph
+
+    def __enter__(self):
+        _CURRENT.append(self.graph)
+        return self.graph
+
+    def __exit__(self, *exc):
+        _CURRENT.pop()
+
+
+def _as_node(g, v):
+    if isinstance(v, Sym):
+        if v.g is not g:
+            raise TraceUnsupported("mixing symbols of different traces")
+        return v.i
+    if isinstance(v, numbers.Number):
+        return g.const(float(v))
+    if isinstance(v, torch.Tensor) and v.numel() == 1:
+        return g.const(float(v.item()))
+    try:
+        import numpy as np
+        if isinstance(v, np.ndarray) and v.size == 1:
+            return g.const(float(v.reshape(-1)[0]))
+    except Exception:  # pragma: no cover
+        pass
+    raise TraceUnsupported(f"cannot mix a traced value with {type(v).__name__} of more than one element")
+
+
+class _Shape(tuple):
+    pass
+
+
+class Sym:
+    """Proxy for an ``(N, 1)`` column of the batch inside a trace."""
+    __array_priority__ = 10000
+    __array_ufunc__ = None
+
+    def __init__(self, g, i):
+        self.g, self.i = g, i
+
+    # ---- tensor-ish surface used by reference-style code
+    @property
+    def shape(self):
+        return torch.Size([self.g.n_points if hasattr(self.g, "n_points") else 1, 1])
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 2
+
+    @property
+    def requires_grad(self):
+        return True
+
+    def requires_grad_(self, flag=True):
+        return self
+
+    def view(self, *shape):
+        return self._reshape(shape)
+
+    def reshape(self, *shape):
+        return self._reshape(shape)
+
+    def _reshape(self, shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        if tuple(shape) in ((-1, 1), (self.shape[0], 1)):
+            return self
+        raise TraceUnsupported(f"reshape to {shape} inside the fused path")
+
+    def clone(self):
+        return self
+
+    def detach(self):
+        raise TraceUnsupported("detach() inside the traced region")
+
+    def __getitem__(self, idx):
+        raise TraceUnsupported("indexing a traced column")
+
+    def __bool__(self):
+        raise TraceUnsupported("data-dependent control flow on a traced value")
+
+    def __len__(self):
+        return self.shape[0]
+
+    # ---- arithmetic
+    def _bin(self, other, op, rev=False):
+        g = self.g
+        try:
+            o = _as_node(g, other)
+        except TraceUnsupported:
+            return NotImplemented
+        a, b = (o, self.i) if rev else (self.i, o)
+        return Sym(g, getattr(g, op)(a, b))
+
+    def __add__(self, o): return self._bin(o, "add")
+    def __radd__(self, o): return self._bin(o, "add", True)
+    def __sub__(self, o): return self._bin(o, "sub")
+    def __rsub__(self, o): return self._bin(o, "sub", True)
+    def __mul__(self, o): return self._bin(o, "mul")
+    def __rmul__(self, o): return self._bin(o, "mul", True)
+    def __truediv__(self, o): return self._bin(o, "div")
+    def __rtruediv__(self, o): return self._bin(o, "div", True)
+    def __neg__(self): return Sym(self.g, self.g.unary("neg", self.i))
+    def __pos__(self): return self
+    def __abs__(self): return Sym(self.g, self.g.unary("abs", self.i))
+
+    def __pow__(self, e):
+        if isinstance(e, Sym):
+            # a ** b = exp(b log a)
+            g = self.g
+            return Sym(g, g.unary("exp", g.mul(e.i, g.unary("log", self.i))))
+        c = self.g.cval(_as_node(self.g, e))
+        return Sym(self.g, self.g.powc(self.i, c))
+
+    def __rpow__(self, base):
+        g = self.g
+        c = g.cval(_as_node(g, base))
+        return Sym(g, g.unary("exp", g.mul(self.i, g.const(math.log(c)))))
+
+    # methods mirroring torch.Tensor
+    def _un(self, op):
+        return Sym(self.g, self.g.unary(op, self.i))
+
+    def sin(self): return self._un("sin")
+    def cos(self): return self._un("cos")
+    def tan(self): return self._un("tan")
+    def exp(self): return self._un("exp")
+    def log(self): return self._un("log")
+    def tanh(self): return self._un("tanh")
+    def sqrt(self): return self._un("sqrt")
+    def abs(self): return self._un("abs")
+    def sinh(self): return self._un("sinh")
+    def cosh(self): return self._un("cosh")
+    def sigmoid(self): return self._un("sigmoid")
+    def reciprocal(self): return self._un("recip")
+    def square(self): return self * self
+    def pow(self, e): return self ** e
+
+    # ---- torch.* functions
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", str(func))
+        h = _TORCH_FUNCS.get(name)
+        if h is None:
+            raise TraceUnsupported(f"torch.{name} is not supported inside the fused path")
+        return h(*args, **kwargs)
+
+    def __repr__(self):
+        return f"Sym#{self.i}{self.g.nodes[self.i]}"
+
+
+def _first_sym(*args):
+    for a in args:
+        if isinstance(a, Sym):
+            return a
+    raise TraceUnsupported("no traced operand")
+
+
+def _tf_unary(op):
+    def f(x, *a, **k):
+        return x._un(op)
+    return f
+
+
+def _tf_bin(op):
+    def f(a, b, *rest, alpha=None, **k):
+        s = _first_sym(a, b)
+        g = s.g
+        nb = _as_node(g, b)
+        if alpha is not None:
+            nb = g.mul(g.const(alpha), nb)
+        return Sym(g, getattr(g, op)(_as_node(g, a), nb))
+    return f
+
+
+def _tf_like(value):
+    def f(x, *a, **k):
+        return Sym(x.g, x.g.const(value))
+    return f
+
+
+def _tf_full_like(x, fill_value, **k):
+    return Sym(x.g, x.g.const(fill_value))
+
+
+def _tf_pow(a, b):
+    if isinstance(a, Sym):
+        return a ** b
+    return b.__rpow__(a)
+
+
+_TORCH_FUNCS = {
+    "sin": _tf_unary("sin"), "cos": _tf_unary("cos"), "tan": _tf_unary("tan"), "exp": _tf_unary("exp"),
+    "log": _tf_unary("log"), "tanh": _tf_unary("tanh"), "sqrt": _tf_unary("sqrt"), "abs": _tf_unary("abs"),
+    "sinh": _tf_unary("sinh"), "cosh": _tf_unary("cosh"), "sigmoid": _tf_unary("sigmoid"),
+    "reciprocal": _tf_unary("recip"), "neg": _tf_unary("neg"), "negative": _tf_unary("neg"),
+    "absolute": _tf_unary("abs"),
+    "square": lambda x: x * x,
+    "add": _tf_bin("add"), "sub": _tf_bin("sub"), "subtract": _tf_bin("sub"), "mul": _tf_bin("mul"),
+    "multiply": _tf_bin("mul"), "div": _tf_bin("div"), "divide": _tf_bin("div"), "true_divide": _tf_bin("div"),
+    "pow": _tf_pow,
+    "ones_like": _tf_like(1.0), "zeros_like": _tf_like(0.0), "full_like": _tf_full_like,
+    "clone": lambda x, **k: x,
+}
+
+
+def is_sym(x):
+    return isinstance(x, Sym)
+
+
+def sym_diff(u, t, order=1):
+    """``diff`` on traced values: symbolic d^order u / dt^order.  ``t`` must be one of the batch coordinates
+    (the reference differentiates w.r.t. the sampled coordinate tensors, neurodiffeq.py:22)."""
+    if not isinstance(t, Sym):
+        raise TraceUnsupported("diff(u, t): t must be a traced coordinate")
+    g = t.g
+    nt = g.nodes[t.i]
+    if nt[0] != "coord":
+        raise TraceUnsupported("diff(u, t): t must be a batch coordinate, not an expression")
+    if not isinstance(u, Sym):
+        # a python scalar / constant: derivative is zero, like the reference's "unused" branch (neurodiffeq.py:23-24)
+        return Sym(g, g.const(0.0))
+    e = u.i
+    for _ in range(int(order)):
+        e = g.diff(e, nt[1])
+    return Sym(g, e)
