@@ -106,7 +106,9 @@ class PointwiseProgram:
     streams    : {net_idx: NetStreams}
     """
 
-    def __init__(self, graph: Graph, residuals, funcs, n_nets):
+    def __init__(self, graph: Graph, residuals, funcs, n_nets, widen=None):
+        """widen(net_idx, NetStreams): optional hook that may enlarge ``first`` / ``mask2`` of a net to the nearest
+        stream set libndq.so has kernels for (slots are assigned after it ran)."""
         self.g = graph
         self.residuals = list(residuals)
         self.funcs = list(funcs)
@@ -125,7 +127,9 @@ class PointwiseProgram:
             if n[0] == "net":
                 self.streams[n[1]].need(n[3])
                 self.symbols.append(i)
-        # nets referenced by no symbol still need a (value-only) layout entry
+        if widen is not None:
+            for k, st in self.streams.items():
+                widen(k, st)
         self.source = self._emit()
         self.key = hashlib.sha1(self.source.encode()).hexdigest()[:16]
 

@@ -1,0 +1,200 @@
+"""Conditions (re-parameterisations that make initial/boundary conditions hold exactly) with the reference's class
+names, constructor arguments and ``enforce`` / ``parameterize`` protocol (neurodiffeq/conditions.py:8-57).
+
+``parameterize`` bodies are plain arithmetic on their arguments, so the SAME code runs
+  * on torch tensors (composite path, solution evaluation), and
+  * on :class:`neurodiffeq_amd.symbolic.Sym` proxies while a solver traces the system for the fused gfx950 path --
+    there the network output is a symbol and ``enforce`` asks the active trace for it instead of calling the net.
+User-defined subclasses that only override ``parameterize`` with ordinary arithmetic are traced the same way.
+"""
+import warnings
+
+import torch
+
+from .neurodiffeq import safe_diff as diff
+from .symbolic import Sym, TraceUnsupported, current_graph
+
+
+def _const_like(ref, value):
+    """A column filled with ``value`` shaped like ``ref`` (a traced constant inside a trace)."""
+    if isinstance(ref, Sym):
+        return Sym(ref.g, ref.g.const(value))
+    return torch.full_like(ref, float(value))
+
+
+def _exp(x):
+    return x.exp() if isinstance(x, Sym) else torch.exp(x)
+
+
+def _raw_output(net, coordinates, ith_unit):
+    """Network output on cat(coords, 1) (conditions.py:52-55), or its symbol while tracing."""
+    if any(isinstance(c, Sym) for c in coordinates):
+        return current_graph().net_symbol(net, coordinates, ith_unit)
+    out = net(torch.cat(coordinates, dim=1))
+    if ith_unit is not None:
+        out = out[:, ith_unit].view(-1, 1)
+    return out
+
+
+class BaseCondition:
+    """Base class: ``enforce(net, *coords)`` = ``parameterize(net(cat(coords)), *coords)``."""
+
+    def __init__(self):
+        self.ith_unit = None
+
+    def parameterize(self, output_tensor, *input_tensors):
+        raise ValueError(f"Abstract {self.__class__.__name__} cannot be parameterized")
+
+    def enforce(self, net, *coordinates):
+        return self.parameterize(_raw_output(net, coordinates, self.ith_unit), *coordinates)
+
+    def set_impose_on(self, ith_unit):
+        warnings.warn(f"`{self.__class__.__name__}.set_impose_on` is deprecated and will be removed in the future",
+                      DeprecationWarning)
+        self.ith_unit = ith_unit
+
+
+class NoCondition(BaseCondition):
+    """Identity re-parameterisation (conditions.py:205-222)."""
+
+    def parameterize(self, output_tensor, *input_tensors):
+        return output_tensor
+
+
+class EnsembleCondition(BaseCondition):
+    """One sub-condition per output unit of a multi-output network (conditions.py:157-202)."""
+
+    def __init__(self, *sub_conditions, force=False):
+        super().__init__()
+        for i, c in enumerate(sub_conditions):
+            if c.__class__.enforce != BaseCondition.enforce:
+                msg = (f"{c.__class__.__name__} (index={i})'s overrides BaseCondition's `.enforce` method. "
+                       f"Ensembl'ing is likely not going to work.")
+                if not force:
+                    raise ValueError(msg + "\nTry with `force=True` if you know what you are doing.")
+                warnings.warn(msg)
+        self.conditions = sub_conditions
+
+    def parameterize(self, output_tensor, *input_tensors):
+        if isinstance(output_tensor, Sym):
+            raise TraceUnsupported("EnsembleCondition on a multi-output network")
+        if output_tensor.shape[1] != len(self.conditions):
+            raise ValueError(f"number of output units ({output_tensor.shape[1]}) "
+                             f"differs from number of conditions ({len(self.conditions)})")
+        cols = [c.parameterize(output_tensor[:, i].view(-1, 1), *input_tensors) for i, c in enumerate(self.conditions)]
+        return torch.cat(cols, dim=1)
+
+
+class IVP(BaseCondition):
+    """u(t0) = u0, optionally u'(t0) = u0'  (conditions.py:225-267)."""
+
+    def __init__(self, t_0, u_0=None, u_0_prime=None, **deprecated):
+        super().__init__()
+        if "x_0" in deprecated:
+            warnings.warn("`x_0` is deprecated; use `u_0`", FutureWarning)
+            u_0 = deprecated.pop("x_0")
+        if "x_0_prime" in deprecated:
+            warnings.warn("`x_0_prime` is deprecated; use `u_0_prime`", FutureWarning)
+            u_0_prime = deprecated.pop("x_0_prime")
+        if deprecated:
+            raise TypeError(f"unexpected arguments {list(deprecated)}")
+        self.t_0, self.u_0, self.u_0_prime = t_0, u_0, u_0_prime
+
+    def parameterize(self, output_tensor, t):
+        decay = 1 - _exp(-t + self.t_0)
+        if self.u_0_prime is None:
+            return self.u_0 + decay * output_tensor
+        return self.u_0 + (t - self.t_0) * self.u_0_prime + (decay ** 2) * output_tensor
+
+
+class DirichletBVP(BaseCondition):
+    """u(t0) = u0, u(t1) = u1  (conditions.py:398-435)."""
+
+    def __init__(self, t_0, u_0, t_1, u_1):
+        super().__init__()
+        self.t_0, self.u_0, self.t_1, self.u_1 = t_0, u_0, t_1, u_1
+
+    def parameterize(self, output_tensor, t):
+        s = (t - self.t_0) / (self.t_1 - self.t_0)
+        return self.u_0 * (1 - s) + self.u_1 * s + (1 - _exp((1 - s) * s)) * output_tensor
+
+
+class DirichletBVP2D(BaseCondition):
+    """Dirichlet data on the four edges of [x0,x1] x [y0,y1]  (conditions.py:438-509):
+    u = A(x,y) + xt (1-xt) yt (1-yt) N, with A the transfinite interpolant of f0, f1 (x edges) and g0, g1 (y edges)."""
+
+    def __init__(self, x_min, x_min_val, x_max, x_max_val, y_min, y_min_val, y_max, y_max_val):
+        super().__init__()
+        self.x0, self.f0 = x_min, x_min_val
+        self.x1, self.f1 = x_max, x_max_val
+        self.y0, self.g0 = y_min, y_min_val
+        self.y1, self.g1 = y_max, y_max_val
+
+    def parameterize(self, output_tensor, x, y):
+        xt = (x - self.x0) / (self.x1 - self.x0)
+        yt = (y - self.y0) / (self.y1 - self.y0)
+        xa, xb = _const_like(x, self.x0), _const_like(x, self.x1)
+
+        def edge_minus_corners(g):          # g(x) minus the linear blend of its corner values
+            return g(x) - ((1 - xt) * g(xa) + xt * g(xb))
+
+        a = (1 - xt) * self.f0(y) + xt * self.f1(y) \
+            + (1 - yt) * edge_minus_corners(self.g0) + yt * edge_minus_corners(self.g1)
+        return a + xt * (1 - xt) * yt * (1 - yt) * output_tensor
+
+
+class IBVP1D(BaseCondition):
+    """Initial condition u(x,t0) = u0(x) plus a Dirichlet or Neumann condition at each end of [x0, x1]
+    (conditions.py:512-712).  The Dirichlet-Dirichlet form is traceable (fused path); the Neumann forms evaluate the
+    network at boundary points and differentiate it there, which runs on the composite path."""
+
+    def __init__(self, x_min, x_max, t_min, t_min_val, x_min_val=None, x_min_prime=None, x_max_val=None,
+                 x_max_prime=None):
+        super().__init__()
+        given = [c is not None for c in (x_min_val, x_min_prime, x_max_val, x_max_prime)]
+        if sum(given) != 2 or (x_min_val and x_min_prime) or (x_max_val and x_max_prime):
+            raise NotImplementedError("Sorry, this boundary condition is not implemented.")
+        self.x_min, self.x_min_val, self.x_min_prime = x_min, x_min_val, x_min_prime
+        self.x_max, self.x_max_val, self.x_max_prime = x_max, x_max_val, x_max_prime
+        self.t_min, self.t_min_val = t_min, t_min_val
+
+    def _kind(self):
+        return ("d" if self.x_min_val else "n") + ("d" if self.x_max_val else "n")
+
+    def enforce(self, net, x, t):
+        kind = self._kind()
+        u = _raw_output(net, (x, t), self.ith_unit)
+        if kind == "dd":
+            return self.parameterize(u, x, t)
+        if isinstance(x, Sym):
+            raise TraceUnsupported("Neumann IBVP1D evaluates the network at boundary points")
+        extra = []
+        for need, xb in ((kind[0] == "n", self.x_min), (kind[1] == "n", self.x_max)):
+            if need:
+                xe = xb * torch.ones_like(x, requires_grad=True)
+                extra += [_raw_output(net, (xe, t), self.ith_unit), xe]
+        return self.parameterize(u, x, t, *extra)
+
+    def parameterize(self, u, x, t, *additional_tensors):
+        kind = self._kind()
+        w = self.x_max - self.x_min
+        xt = (x - self.x_min) / w
+        tc = _const_like(t, self.t_min)
+        grow = 1 - _exp(-(t - self.t_min))
+        delta = lambda fn: fn(t) - fn(tc)          # boundary datum minus its value at t0
+        if kind == "dd":
+            a = self.t_min_val(x) + xt * delta(self.x_max_val) + (1 - xt) * delta(self.x_min_val)
+            return a + xt * (1 - xt) * grow * u
+        if kind == "dn":
+            u1, x1 = additional_tensors
+            a = delta(self.x_min_val) + self.t_min_val(x) + xt * w * delta(self.x_max_prime)
+            return a + xt * grow * (u - w * diff(u1, x1) - u1)
+        if kind == "nd":
+            u0, x0 = additional_tensors
+            a = delta(self.x_max_val) + self.t_min_val(x) + (xt - 1) * w * delta(self.x_min_prime)
+            return a + (1 - xt) * grow * (u + w * diff(u0, x0) - u0)
+        u0, x0, u1, x1 = additional_tensors
+        a = self.t_min_val(x) - 0.5 * (1 - xt) ** 2 * w * delta(self.x_min_prime) \
+            + 0.5 * xt ** 2 * w * delta(self.x_max_prime)
+        d0 = diff(u0, x0)
+        return a + grow * (u - xt * w * d0 + 0.5 * xt ** 2 * w * (d0 - diff(u1, x1)))

@@ -1,0 +1,182 @@
+"""The fused train / evaluation step of one PDE system on one MI355X.
+
+This is the compute core of ``BaseSolver._run_epoch``'s closure (reference: solvers.py:369-395) re-expressed as a
+fixed launch sequence on one HIP stream, per batch:
+
+    H2D (one SoA block)  ->  ndq_mlp_jet_fwd  x n_nets          FCNN.forward + every diff() over it
+                         ->  generated pointwise kernel          parameterize + diff_eqs + sum r^2 + adjoint seeds
+                         ->  ndq_mlp_jet_bwd  x n_nets           loss.backward() through the networks
+                         ->  ndq_reduce_partials                 .grad accumulation (+ the loss scalar)
+
+No host synchronisation happens inside a step; the loss stays in HBM until the caller reads it.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, codegen
+from .networks import FlatParams, describe
+from .symbolic import Graph, Sym, TraceUnsupported, trace_scope
+
+_c_vp = ctypes.c_void_p
+
+
+def _ptr(t):
+    return _c_vp(t.data_ptr())
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class FusedSystem:
+    def __init__(self, nets, conditions, diff_eqs, n_coords, device, compute_func_val=None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.NdqError("the fused path needs an MI355X (device 'cuda'); no CPU fallback exists for it")
+        self.L = _lib.lib()
+        self.nets, self.conditions, self.n_coords = list(nets), list(conditions), n_coords
+        infos = [describe(n) for n in self.nets]
+        if any(i is None for i in infos):
+            raise TraceUnsupported("a network is not an FCNN the gfx950 kernels support")
+        g = Graph(n_coords)
+        g.register_nets(self.nets, [i["n_out"] for i in infos])
+        cfv = compute_func_val or (lambda net, cond, *coords: cond.enforce(net, *coords))
+        with trace_scope(g):
+            coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
+            funcs = [cfv(n, c, *coords) for n, c in zip(self.nets, self.conditions)]
+            res = diff_eqs(*funcs, *coords)
+            if isinstance(res, Sym):
+                res = [res]
+            res = [r if isinstance(r, Sym) else Sym(g, g.const(float(r))) for r in res]
+        if not all(isinstance(f, Sym) for f in funcs):
+            raise TraceUnsupported("a condition returned something that is not a traced column")
+        self.n_eq, self.n_funcs = len(res), len(funcs)
+        for k, info in enumerate(infos):       # a net that never appears in an equation still needs a layout
+            g.net_deps.setdefault(k, tuple(range(info["d"])))
+            g.net_nout.setdefault(k, info["n_out"])
+
+        self.descs = {}
+
+        def widen(k, st):
+            info = infos[k]
+            if st.d != info["d"]:
+                raise TraceUnsupported("network input width differs from the number of coordinates fed to it")
+            if list(st.deps) != list(range(st.deps[0], st.deps[0] + st.d)):
+                raise TraceUnsupported("network fed a non-contiguous subset of the coordinates")
+            npair = st.d * (st.d + 1) // 2
+            best = None
+            for first in ((1,) if st.first else (0, 1)):
+                for mask2 in range(1 << npair):
+                    if (mask2 & st.mask2) != st.mask2 or (mask2 and not first):
+                        continue
+                    d = _lib.MlpDesc(st.d, first, mask2, info["hidden"], info["layers"], info["act"], info["n_out"])
+                    if self.L.ndq_mlp_supported(ctypes.byref(d)):
+                        cost = first * st.d + bin(mask2).count("1")
+                        if best is None or cost < best[0]:
+                            best = (cost, d)
+            if best is None:
+                raise TraceUnsupported(f"no gfx950 kernel for FCNN d={st.d} hidden={info['hidden']} layers="
+                                       f"{info['layers']} streams(first={st.first}, mask2={st.mask2:#b})")
+            st.first, st.mask2 = best[1].first, best[1].mask2
+            self.descs[k] = best[1]
+
+        self.program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(self.nets), widen=widen)
+        self.kernel = codegen.load(self.program)
+        self.flat = [FlatParams(n, self.device) for n in self.nets]
+        self.ns = [self.program.streams[k].n_streams for k in range(len(self.nets))]
+        self.coord0 = [self.program.streams[k].deps[0] for k in range(len(self.nets))]
+        for k, fp in enumerate(self.flat):
+            assert self.L.ndq_mlp_num_params(ctypes.byref(self.descs[k])) == fp.numel
+        self._bufs = {}
+        self.loss_buf = torch.zeros(64, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def buffers(self, n):
+        b = self._bufs.get(n)
+        if b is not None:
+            return b
+        ld = _round_up(n, 64)
+        dev, f32 = self.device, torch.float32
+        b = dict(ld=ld,
+                 coords=torch.zeros(self.n_coords, ld, dtype=f32, device=dev),
+                 pinned=torch.zeros(self.n_coords, ld, dtype=f32).pin_memory(),
+                 jets=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
+                 gbar=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
+                 funcs=torch.zeros(self.n_funcs, ld, dtype=f32, device=dev),
+                 resid=torch.zeros(self.n_eq, ld, dtype=f32, device=dev),
+                 pw_blocks=self.kernel.blocks(n))
+        b["loss_partials"] = torch.zeros(b["pw_blocks"], dtype=f32, device=dev)
+        b["bwd_blocks"] = [self.L.ndq_mlp_bwd_blocks(ctypes.byref(self.descs[k]), n) for k in range(len(self.nets))]
+        b["partials"] = [torch.empty(nb, fp.numel, dtype=f32, device=dev) for nb, fp in zip(b["bwd_blocks"], self.flat)]
+        b["jets_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["jets"]])
+        b["gbar_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["gbar"]])
+        self._bufs[n] = b
+        return b
+
+    def upload(self, batch, lo=0, hi=None):
+        """Copy rows [lo, hi) of the sampled batch (list of (N, 1) or (N,) tensors) into the SoA device block."""
+        n_all = batch[0].numel()
+        hi = n_all if hi is None else hi
+        n = hi - lo
+        b = self.buffers(n)
+        if batch[0].device.type == "cuda":
+            for i, c in enumerate(batch):
+                b["coords"][i, :n].copy_(c.detach().reshape(-1)[lo:hi])
+        else:
+            for i, c in enumerate(batch):
+                b["pinned"][i, :n].copy_(c.detach().reshape(-1)[lo:hi])
+            b["coords"].copy_(b["pinned"], non_blocking=True)
+        return b, n
+
+    def coord_columns(self, b, n):
+        return [b["coords"][i, :n].view(-1, 1) for i in range(self.n_coords)]
+
+    def func_columns(self, b, n):
+        return [b["funcs"][i, :n].view(-1, 1) for i in range(self.n_funcs)]
+
+    # ------------------------------------------------------------------------------------------ launches
+    def forward(self, b, n, stream):
+        for k, fp in enumerate(self.flat):
+            fp.sync()
+            rc = self.L.ndq_mlp_jet_fwd(ctypes.byref(self.descs[k]), _ptr(b["coords"][self.coord0[k]]), b["ld"], n,
+                                        _ptr(fp.flat), _ptr(b["jets"][k]), b["ld"], stream)
+            _lib.check(rc, "ndq_mlp_jet_fwd")
+
+    def pointwise(self, b, n, stream, train, n_global, want_funcs=False, want_resid=False):
+        seed = 1.0 / (float(n_global) * self.n_eq)
+        rc = self.kernel.lib.ndq_pw_launch(_ptr(b["coords"]), b["ld"], n, b["jets_pp"],
+                                           b["gbar_pp"] if train else None, b["ld"],
+                                           _ptr(b["funcs"]) if want_funcs else None,
+                                           _ptr(b["resid"]) if want_resid else None,
+                                           _ptr(b["loss_partials"]), seed, stream)
+        _lib.check(rc, "ndq_pw_launch")
+        return seed
+
+    def backward(self, b, n, stream, accumulate):
+        for k, fp in enumerate(self.flat):
+            rc = self.L.ndq_mlp_jet_bwd(ctypes.byref(self.descs[k]), _ptr(b["coords"][self.coord0[k]]), b["ld"], n,
+                                        _ptr(fp.flat), _ptr(b["gbar"][k]), b["ld"], _ptr(b["partials"][k]), stream)
+            _lib.check(rc, "ndq_mlp_jet_bwd")
+            rc = self.L.ndq_reduce_partials(_ptr(b["partials"][k]), b["bwd_blocks"][k], fp.numel, _ptr(fp.grad),
+                                            1 if accumulate else 0, 1.0, stream)
+            _lib.check(rc, "ndq_reduce_partials")
+
+    def reduce_loss(self, b, stream, seed, slot):
+        rc = self.L.ndq_reduce_partials(_ptr(b["loss_partials"]), b["pw_blocks"], 1,
+                                        _c_vp(self.loss_buf.data_ptr() + 4 * slot), 0, seed, stream)
+        _lib.check(rc, "ndq_reduce_partials(loss)")
+
+    def step(self, batch, train, slot=0, accumulate=False, n_global=None, lo=0, hi=None, want_funcs=False,
+             want_resid=False):
+        """One closure evaluation (solvers.py:369-395) on rows [lo, hi) of ``batch``; the (shard of the) mean squared
+        residual lands in ``loss_buf[slot]`` and, when ``train``, parameter gradients in every ``FlatParams.grad``."""
+        b, n = self.upload(batch, lo, hi)
+        n_global = n if n_global is None else n_global
+        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        self.forward(b, n, stream)
+        seed = self.pointwise(b, n, stream, train, n_global, want_funcs, want_resid)
+        if train:
+            self.backward(b, n, stream, accumulate)
+        self.reduce_loss(b, stream, seed, slot)
+        return b, n

@@ -1,0 +1,237 @@
+"""Collocation-point generators with the reference's names, arguments and draw order
+(neurodiffeq/generators.py:107-316, 1046-1064).
+
+Generators are the *input producer* of the hot path, not part of it: they always sample on the host with torch's
+global CPU generator, in the same call sequence as the reference, so that a given ``torch.manual_seed`` yields
+bit-identical points (the north-star parity contract); the solver uploads each batch to HBM as one SoA block."""
+import numpy as np
+import torch
+
+_CPU = torch.device("cpu")
+
+
+def _chebyshev_first(a, b, n):
+    nodes = torch.cos(((torch.arange(n, device=_CPU) + 0.5) / n) * np.pi)
+    return (((a + b) + (b - a) * nodes) / 2).requires_grad_(True)
+
+
+def _chebyshev_second(a, b, n):
+    nodes = torch.cos(torch.arange(n, device=_CPU) / float(n - 1) * np.pi)
+    return (((a + b) + (b - a) * nodes) / 2).requires_grad_(True)
+
+
+def _chebyshev_second_noisy(a, b, n):
+    nodes = torch.cos((torch.arange(n, device=_CPU) + (torch.rand(n, device=_CPU) * 2 - 1)) / float(n - 1) * np.pi)
+    return (((a + b) + (b - a) * nodes) / 2).requires_grad_(True)
+
+
+def _latin_hypercube(a, b, n):
+    edges = torch.linspace(a, b, steps=n + 1, device=_CPU)
+    pts = torch.rand(n, device=_CPU) * (edges[1] - edges[0])
+    pts += edges[:-1]
+    pts = pts[torch.randperm(n, device=_CPU)]
+    return pts.requires_grad_(True)
+
+
+def _log_bounds(t_min, t_max, whence):
+    if t_min <= 0 or t_max <= 0:
+        raise ValueError(f"the interval [{t_min}, {t_max}] cannot be used for log-sampling in {whence}; "
+                         f"if you meant [10^{t_min}, 10^{t_max}], pass {10 ** t_min} and {10 ** t_max}")
+    return np.log10(t_min), np.log10(t_max)
+
+
+class BaseGenerator:
+    def __init__(self):
+        self.size = None
+
+    def get_examples(self):
+        pass  # pragma: no cover
+
+    @staticmethod
+    def check_generator(obj):
+        if not isinstance(obj, BaseGenerator):
+            raise ValueError(f"{obj} is not a generator")
+
+    def __add__(self, other):
+        self.check_generator(other)
+        return ConcatGenerator(self, other)
+
+    def __mul__(self, other):
+        self.check_generator(other)
+        return EnsembleGenerator(self, other)
+
+    def _internal_vars(self):
+        return dict(size=self.size)
+
+    def __repr__(self):
+        d = self._internal_vars()
+        return f"{self.__class__.__name__}({', '.join(f'{k}={d[k]!r}' for k in d)})"
+
+
+class Generator1D(BaseGenerator):
+    """1-D points on [t_min, t_max] (generators.py:107-191); ``method`` as in the reference."""
+
+    def __init__(self, size, t_min=0.0, t_max=1.0, method="uniform", noise_std=None):
+        super().__init__()
+        self.size, self.t_min, self.t_max, self.method = size, t_min, t_max, method
+        self.noise_std = noise_std if noise_std else ((t_max - t_min) / size) / 4.0
+        fixed = None
+        if method == "uniform":
+            self.examples = torch.zeros(size, requires_grad=True, device=_CPU)
+            self.getter = lambda: self.examples + torch.rand(size, device=_CPU) * (t_max - t_min) + t_min
+        elif method in ("equally-spaced", "equally-spaced-noisy"):
+            fixed = torch.linspace(t_min, t_max, size, requires_grad=True, device=_CPU)
+        elif method in ("log-spaced", "log-spaced-noisy"):
+            lo, hi = _log_bounds(t_min, t_max, self.__class__)
+            fixed = torch.logspace(lo, hi, size, requires_grad=True, device=_CPU)
+        elif method in ("chebyshev", "chebyshev1"):
+            fixed = _chebyshev_first(t_min, t_max, size)
+        elif method == "chebyshev2":
+            fixed = _chebyshev_second(t_min, t_max, size)
+        elif method == "chebyshev2-noisy":
+            self.getter = lambda: _chebyshev_second_noisy(t_min, t_max, size)
+        elif method == "latin-hypercube":
+            self.getter = lambda: _latin_hypercube(t_min, t_max, size)
+        else:
+            raise ValueError(f"Unknown method: {method}")
+        if fixed is not None:
+            self.examples = fixed
+            if method.endswith("-noisy"):
+                self.getter = lambda: torch.normal(mean=self.examples, std=self.noise_std)
+            else:
+                self.getter = lambda: self.examples
+
+    def get_examples(self):
+        return self.getter()
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(t_min=self.t_min, t_max=self.t_max, method=self.method, noise_std=self.noise_std)
+        return d
+
+
+class Generator2D(BaseGenerator):
+    """Points on a (possibly noisy) m x n grid over [x0,x1] x [y0,y1] (generators.py:194-314).  For the noisy grid
+    the x noise is drawn before the y noise, each with one ``torch.normal`` over the flattened ij-meshgrid."""
+
+    def __init__(self, grid=(10, 10), xy_min=(0.0, 0.0), xy_max=(1.0, 1.0), method="equally-spaced-noisy",
+                 xy_noise_std=None):
+        super().__init__()
+        self.grid, self.size = grid, grid[0] * grid[1]
+        self.xy_min, self.xy_max, self.method, self.xy_noise_std = xy_min, xy_max, method, xy_noise_std
+        axes = None
+        if method in ("equally-spaced", "equally-spaced-noisy"):
+            axes = [torch.linspace(xy_min[i], xy_max[i], grid[i], requires_grad=True, device=_CPU) for i in (0, 1)]
+        elif method in ("chebyshev", "chebyshev1"):
+            axes = [_chebyshev_first(xy_min[i], xy_max[i], grid[i]) for i in (0, 1)]
+        elif method == "chebyshev2":
+            axes = [_chebyshev_second(xy_min[i], xy_max[i], grid[i]) for i in (0, 1)]
+        elif method == "latin-hypercube":
+            axes = [_latin_hypercube(xy_min[i], xy_max[i], grid[i]) for i in (0, 1)]
+        elif method == "chebyshev2-noisy":
+            def draw():
+                ax = [_chebyshev_second_noisy(xy_min[i], xy_max[i], grid[i]) for i in (0, 1)]
+                gx, gy = torch.meshgrid(ax[0], ax[1], indexing="ij")
+                return gx.flatten(), gy.flatten()
+            self.getter = draw
+        else:
+            raise ValueError(f"Unknown method: {method}")
+        if axes is not None:
+            gx, gy = torch.meshgrid(axes[0], axes[1], indexing="ij")
+            self.grid_x, self.grid_y = gx.flatten(), gy.flatten()
+            if method == "equally-spaced-noisy":
+                if xy_noise_std:
+                    self.noise_xstd, self.noise_ystd = xy_noise_std
+                else:
+                    self.noise_xstd = ((xy_max[0] - xy_min[0]) / grid[0]) / 4.0
+                    self.noise_ystd = ((xy_max[1] - xy_min[1]) / grid[1]) / 4.0
+                self.getter = lambda: (torch.normal(mean=self.grid_x, std=self.noise_xstd),
+                                       torch.normal(mean=self.grid_y, std=self.noise_ystd))
+            else:
+                self.getter = lambda: (self.grid_x, self.grid_y)
+
+    def get_examples(self):
+        return self.getter()
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(grid=self.grid, xy_min=self.xy_min, xy_max=self.xy_max, method=self.method,
+                 xy_noise_std=self.xy_noise_std)
+        return d
+
+
+class ConcatGenerator(BaseGenerator):
+    """``g1 + g2``: concatenated samples (generators.py:658-691)."""
+
+    def __init__(self, *generators):
+        super().__init__()
+        self.generators = generators
+        self.size = sum(g.size for g in generators)
+
+    def get_examples(self):
+        draws = [g.get_examples() for g in self.generators]
+        if isinstance(draws[0], torch.Tensor):
+            return torch.cat(draws)
+        return tuple(torch.cat(parts) for parts in zip(*draws))
+
+
+class EnsembleGenerator(BaseGenerator):
+    """``g1 * g2``: same number of points, more dimensions (generators.py:826-876)."""
+
+    def __init__(self, *generators):
+        super().__init__()
+        self.size = generators[0].size
+        for i, g in enumerate(generators):
+            if g.size != self.size:
+                raise ValueError(f"gens[{i}].size ({g.size}) != gens[0].size ({self.size})")
+        self.generators = generators
+
+    def get_examples(self):
+        out = ()
+        for g in self.generators:
+            ex = g.get_examples()
+            out += (ex,) if isinstance(ex, torch.Tensor) else tuple(ex)
+        return out[0] if len(out) == 1 else out
+
+
+class StaticGenerator(BaseGenerator):
+    """Draw once, return the same points forever (generators.py:694-720)."""
+
+    def __init__(self, generator):
+        super().__init__()
+        self.generator, self.size = generator, generator.size
+        self.examples = generator.get_examples()
+
+    def get_examples(self):
+        return self.examples
+
+
+class PredefinedGenerator(BaseGenerator):
+    """Fixed user-supplied points (generators.py:723-756)."""
+
+    def __init__(self, *xs):
+        super().__init__()
+        self.xs = [x if isinstance(x, torch.Tensor) else torch.tensor(x, device=_CPU) for x in xs]
+        self.xs = [x.detach().clone().reshape(-1).requires_grad_(True) for x in self.xs]
+        self.size = len(self.xs[0])
+        if any(len(x) != self.size for x in self.xs):
+            raise ValueError("tensors of different lengths encountered")
+        if len(self.xs) == 1:
+            self.xs = self.xs[0]
+
+    def get_examples(self):
+        return self.xs
+
+
+class SamplerGenerator(BaseGenerator):
+    """Solver-side wrapper: always returns a list of ``(N, 1)`` columns that require grad (generators.py:1046-1064)."""
+
+    def __init__(self, generator):
+        super().__init__()
+        self.generator, self.size = generator, generator.size
+
+    def get_examples(self):
+        samples = self.generator.get_examples()
+        if isinstance(samples, torch.Tensor):
+            samples = [samples]
+        return [s.reshape(-1, 1).detach().requires_grad_(True) for s in samples]

@@ -1,0 +1,30 @@
+"""Loss functions ``loss_fn(residual (N, n_eq), funcs, coords) -> scalar`` (reference: neurodiffeq/losses.py:5-35).
+
+``l2`` (= the solver default, solvers.py:218) is what the fused gfx950 path computes in-kernel; the others run on the
+composite autograd path."""
+import torch
+
+from .operators import grad
+
+
+def _l1_norm(residual, funcs, coords):
+    return residual.abs().mean()
+
+
+def _l2_norm(residual, funcs, coords):
+    return (residual ** 2).mean()
+
+
+def _infinity_norm(residual, funcs, coords):
+    return residual.abs().max(dim=1)[0].mean()
+
+
+def _h1_norm(residual, funcs, coords):
+    return (torch.cat([residual, *grad(residual, *coords)], dim=1) ** 2).mean()
+
+
+def _h1_semi_norm(residual, funcs, coords):
+    return (torch.cat(grad(residual, *coords), dim=1) ** 2).mean()
+
+
+_losses = {"l1": _l1_norm, "l2": _l2_norm, "infinity": _infinity_norm, "h1": _h1_norm, "h1 semi": _h1_semi_norm}

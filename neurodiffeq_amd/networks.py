@@ -1,0 +1,160 @@
+"""Networks of the PINN hot path -- same constructor surface as the reference (neurodiffeq/networks.py:6-70,
+142-209) so existing scripts keep working; ``FCNN`` is a real ``nn.Module`` (``.NN`` is the ``Sequential``; its
+parameters are ordinary ``nn.Parameter`` objects, which the optimiser, ``deepcopy`` and checkpoints rely on).
+
+What is new is :func:`describe`: it recognises FCNN-shaped modules the gfx950 kernels can run (uniform hidden width
+multiple of 16, tanh / sin, one output unit) and :class:`FlatParams`, which re-homes the parameters as views of one
+flat fp32 buffer in torch parameter order -- the layout ``ndq_mlp_jet_fwd/bwd`` and ``ndq_adam_step`` consume.
+"""
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class SinActv(nn.Module):
+    """sin activation (reference: networks.py:142-152)."""
+
+    def forward(self, input_):
+        return torch.sin(input_)
+
+
+class Swish(nn.Module):
+    """x * sigmoid(beta x) (reference: networks.py:155-174)."""
+
+    def __init__(self, beta=1.0, trainable=False):
+        super().__init__()
+        self.trainable = trainable
+        self.beta = nn.Parameter(torch.tensor(float(beta))) if trainable else float(beta)
+
+    def forward(self, x):
+        return x * torch.sigmoid(self.beta * x)
+
+
+class APTx(nn.Module):
+    """(alpha + tanh(beta x)) * gamma * x (reference: networks.py:177-209)."""
+
+    def __init__(self, alpha=1.0, beta=1.0, gamma=0.5, trainable=False):
+        super().__init__()
+        self.trainable = trainable
+        mk = (lambda v: nn.Parameter(torch.tensor(float(v)))) if trainable else float
+        self.alpha, self.beta, self.gamma = mk(alpha), mk(beta), mk(gamma)
+
+    def forward(self, x):
+        return (self.alpha + torch.tanh(self.beta * x)) * self.gamma * x
+
+
+class FCNN(nn.Module):
+    """Fully connected network ``Linear -> actv -> ... -> Linear`` (reference: networks.py:26-70).
+
+    Same arguments and defaults: ``hidden_units=(32, 32)``, ``actv=nn.Tanh``; the deprecated
+    ``n_hidden_units`` / ``n_hidden_layers`` pair is still understood (with the reference's FutureWarning)."""
+
+    def __init__(self, n_input_units=1, n_output_units=1, n_hidden_units=None, n_hidden_layers=None,
+                 actv=nn.Tanh, hidden_units=None):
+        super().__init__()
+        if n_hidden_units is None and n_hidden_layers is not None:
+            n_hidden_units = 32
+        elif n_hidden_units is not None and n_hidden_layers is None:
+            n_hidden_layers = 1
+        if n_hidden_units is not None or n_hidden_layers is not None:
+            if hidden_units is None:
+                hidden_units = tuple(n_hidden_units for _ in range(n_hidden_layers + 1))
+                warnings.warn(f"`n_hidden_units` and `n_hidden_layers` are deprecated, "
+                              f"pass `hidden_units={hidden_units}` instead", FutureWarning)
+            else:
+                warnings.warn(f"Ignoring `n_hidden_units` and `n_hidden_layers` in favor of "
+                              f"`hidden_units={hidden_units}`", FutureWarning)
+        if hidden_units is None:
+            hidden_units = (32, 32)
+        hidden_units = tuple(hidden_units)
+        widths = (n_input_units,) + hidden_units
+        mods = []
+        for fan_in, fan_out in zip(widths[:-1], widths[1:]):
+            mods += [nn.Linear(fan_in, fan_out), actv()]
+        mods.append(nn.Linear(widths[-1], n_output_units))
+        self.NN = nn.Sequential(*mods)
+
+    def forward(self, t):
+        return self.NN(t)
+
+
+# ------------------------------------------------------------------------------------------- kernel-side description
+_ACT_IDS = {nn.Tanh: _lib.NDQ_ACT_TANH, SinActv: _lib.NDQ_ACT_SIN}
+
+
+def describe(net):
+    """Return ``dict(d, hidden, layers, act, n_out, linears)`` if ``net`` is an FCNN the HIP kernels can run,
+    else ``None`` (the solver then uses the composite autograd path for the whole system)."""
+    seq = getattr(net, "NN", net)
+    if not isinstance(seq, nn.Sequential):
+        return None
+    mods = list(seq)
+    if len(mods) < 3 or len(mods) % 2 == 0:
+        return None
+    linears, acts = mods[0::2], mods[1::2]
+    if not all(isinstance(m, nn.Linear) and m.bias is not None for m in linears):
+        return None
+    act_types = {type(a) for a in acts}
+    if len(act_types) != 1 or next(iter(act_types)) not in _ACT_IDS:
+        return None
+    hidden = linears[0].out_features
+    if hidden % 16 or any(l.in_features != hidden or l.out_features != hidden for l in linears[1:-1]):
+        return None
+    if linears[-1].in_features != hidden:
+        return None
+    if any(p.dtype != torch.float32 for l in linears for p in l.parameters()):
+        return None
+    return dict(d=linears[0].in_features, hidden=hidden, layers=len(acts), act=_ACT_IDS[next(iter(act_types))],
+                n_out=linears[-1].out_features, linears=linears)
+
+
+class FlatParams:
+    """Parameters of one network as views of a single flat fp32 device buffer (torch order: W1, b1, W2, b2, ...).
+
+    ``sync()`` is called before every launch: if something re-homed a parameter (``net.to(...)``, ``load_state_dict``
+    on a copy, ...) the flat buffer is rebuilt from the current values, so the kernels always see what torch sees."""
+
+    def __init__(self, net, device):
+        self.net = net
+        self.device = torch.device(device)
+        self.params = [p for l in describe(net)["linears"] for p in (l.weight, l.bias)]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self._offsets = []
+        off = 0
+        for p in self.params:
+            self._offsets.append(off)
+            off += p.numel()
+        self.sync()
+
+    def _is_flat(self):
+        if self.flat is None:
+            return False
+        base = self.flat.data_ptr()
+        return all(p.data.data_ptr() == base + 4 * off and p.data.device == self.flat.device
+                   for p, off in zip(self.params, self._offsets))
+
+    def sync(self):
+        if self._is_flat():
+            return
+        with torch.no_grad():
+            flat = torch.cat([p.detach().to(self.device, torch.float32).reshape(-1) for p in self.params]).contiguous()
+            for p, off in zip(self.params, self._offsets):
+                p.data = flat[off:off + p.numel()].view(p.shape)
+        self.flat = flat
+
+    def attach_grads(self):
+        """Expose the flat gradient buffer as ``p.grad`` views (what ``loss.backward()`` leaves behind, solvers.py:393)."""
+        for p, off in zip(self.params, self._offsets):
+            g = self.grad[off:off + p.numel()].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def grads_attached(self):
+        base = self.grad.data_ptr()
+        return all(p.grad is not None and p.grad.data_ptr() == base + 4 * off
+                   for p, off in zip(self.params, self._offsets))

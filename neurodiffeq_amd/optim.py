@@ -1,0 +1,83 @@
+"""Fused Adam for flat network parameters (``ndq_adam_step``, include/ndq.h).
+
+The reference's default optimiser is ``torch.optim.Adam(params)`` stepped once per epoch (solvers.py:182,331-341).
+:class:`FusedAdam` IS a ``torch.optim.Adam`` (same hyper-parameters, same ``state_dict`` layout: per-parameter
+``step`` / ``exp_avg`` / ``exp_avg_sq``) whose state tensors are views of flat buffers once a solver has bound its
+:class:`~neurodiffeq_amd.networks.FlatParams`; ``step()`` then costs one kernel launch per network instead of a
+foreach chain.  Parameters that are not bound fall back to the stock implementation."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self._bound = []            # [(FlatParams, exp_avg_flat, exp_avg_sq_flat, group)]
+        self._bound_ids = set()
+        self._steps = {}
+
+    def bind(self, flat_params):
+        """Adopt the flat buffers of ``flat_params`` (list of FlatParams) for every parameter this optimiser owns."""
+        if [id(fp) for fp, *_ in self._bound] == [id(fp) for fp in flat_params]:
+            return
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        self._bound, self._bound_ids = [], set()
+        for fp in flat_params:
+            groups = {id(group_of.get(id(p))) for p in fp.params}
+            if len(groups) != 1 or None in [group_of.get(id(p)) for p in fp.params]:
+                continue                        # not (entirely) ours, or split across groups: leave to torch
+            group = group_of[id(fp.params[0])]
+            m = torch.zeros_like(fp.grad)
+            v = torch.zeros_like(fp.grad)
+            steps = set()
+            for p, off in zip(fp.params, fp._offsets):
+                st = self.state[p]
+                mv, vv = m[off:off + p.numel()].view(p.shape), v[off:off + p.numel()].view(p.shape)
+                if "exp_avg" in st:
+                    mv.copy_(st["exp_avg"]); vv.copy_(st["exp_avg_sq"])
+                    steps.add(int(st["step"]))
+                else:
+                    steps.add(0)
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"], st["exp_avg_sq"] = mv, vv
+            if len(steps) != 1:
+                continue
+            self._steps[id(fp)] = steps.pop()
+            self._bound.append((fp, m, v, group))
+            self._bound_ids.update(id(p) for p in fp.params)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib() if self._bound else None
+        fused = set()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if self._bound else None
+        for fp, m, v, group in self._bound:
+            if not (fp._is_flat() and fp.grads_attached()) or group.get("amsgrad") or group.get("maximize"):
+                continue
+            self._steps[id(fp)] += 1
+            step = self._steps[id(fp)]
+            b1, b2 = group["betas"]
+            rc = L.ndq_adam_step(fp.flat.data_ptr(), fp.grad.data_ptr(), m.data_ptr(), v.data_ptr(), fp.numel,
+                                 float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], step, stream)
+            _lib.check(rc, "ndq_adam_step")
+            for p in fp.params:
+                self.state[p]["step"] += 1
+            fused.update(id(p) for p in fp.params)
+        if len(fused) < sum(len(g["params"]) for g in self.param_groups):
+            # anything not handled above: stock Adam on the remaining parameters
+            saved = [g["params"] for g in self.param_groups]
+            try:
+                for g in self.param_groups:
+                    g["params"] = [p for p in g["params"] if id(p) not in fused]
+                super().step()
+            finally:
+                for g, ps in zip(self.param_groups, saved):
+                    g["params"] = ps
+        return loss

@@ -1,0 +1,576 @@
+"""Solvers with the reference's public surface (neurodiffeq/solvers.py): ``BaseSolver`` / ``Solver1D`` /
+``Solver2D`` / ``GenericSolver``, ``fit`` / ``run_train_epoch`` / ``run_valid_epoch`` / ``get_solution`` /
+``get_residuals`` / ``get_internals``, the hooks ``compute_func_val`` / ``additional_loss`` /
+``_do_optimizer_step`` and the ``metrics_history`` / ``best_nets`` / ``lowest_loss`` bookkeeping that callbacks read.
+
+The epoch control flow is the reference's (``_run_epoch``, solvers.py:343-424: zero_grad once, accumulate gradients
+over ``n_batches`` generator draws, one optimizer step, history, best-network snapshot).  What differs is the
+per-batch compute:
+
+* **fused path** (nets on an MI355X, FCNN nets the kernels support, default / ``'l2'`` loss): the closure is the
+  launch sequence of :class:`neurodiffeq_amd.engine.FusedSystem`; nothing is synchronised until the epoch's loss is
+  read once.  A missing/broken ``libndq.so`` raises -- it is never papered over.
+* **composite path**: the reference's closure on torch autograd, for everything outside the fused scope (custom
+  loss functions / ``additional_loss`` overrides, closure optimisers such as LBFGS, Neumann ``IBVP1D``, non-FCNN
+  networks, fp64, or a host without a GPU).
+"""
+import inspect
+import sys
+import warnings
+from abc import ABC, abstractmethod
+from copy import deepcopy
+from itertools import chain
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .conditions import BaseCondition
+from .generators import Generator1D, Generator2D, SamplerGenerator
+from .losses import _losses
+from .networks import FCNN
+from .optim import FusedAdam
+from .symbolic import TraceUnsupported
+
+
+def _requires_closure(optimizer):
+    p = inspect.signature(optimizer.step).parameters.get("closure")
+    return bool(p) and p.default == inspect._empty
+
+
+def _unique_params(nets):
+    seen, out = set(), []
+    for p in chain.from_iterable(n.parameters() for n in nets):
+        if id(p) not in seen:
+            seen.add(id(p))
+            out.append(p)
+    return out
+
+
+def _default_l2(residual, funcs, coords):
+    return (residual ** 2).mean()
+
+
+class BaseSolver(ABC):
+    """See the module docstring; constructor arguments are the reference's (solvers.py:36-140)."""
+
+    #: 'auto' -> fused when possible, composite otherwise (with a warning on a GPU); 'require' -> raise if the fused
+    #: path cannot be used; 'off' -> always composite.
+    fused = "auto"
+
+    def __init__(self, diff_eqs, conditions, nets=None, train_generator=None, valid_generator=None,
+                 analytic_solutions=None, optimizer=None, loss_fn=None, n_batches_train=1, n_batches_valid=4,
+                 metrics=None, n_input_units=None, n_output_units=None, shuffle=None, batch_size=None,
+                 criterion=None):
+        if criterion is not None:
+            warnings.warn("`criterion` is deprecated; use `loss_fn`", FutureWarning)
+            loss_fn = criterion if loss_fn is None else loss_fn
+        if shuffle:
+            warnings.warn("param `shuffle` is deprecated and ignored; shuffling should be performed by generators",
+                          FutureWarning)
+        if batch_size is not None:
+            warnings.warn("param `batch_size` is deprecated and ignored; specify n_batches_train and "
+                          "n_batches_valid instead", FutureWarning)
+        self.diff_eqs = diff_eqs
+        self.conditions = conditions
+        self.n_funcs = len(conditions)
+        if nets is None:
+            self.nets = [FCNN(n_input_units=n_input_units, n_output_units=n_output_units, hidden_units=(32, 32),
+                              actv=nn.Tanh) for _ in range(self.n_funcs)]
+        else:
+            self.nets = nets
+        if train_generator is None:
+            raise ValueError("train_generator must be specified")
+        if valid_generator is None:
+            raise ValueError("valid_generator must be specified")
+
+        # the reference runs on "cuda if available" (its import selects it, README FAQ); same here for the networks
+        self.device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        if self.device.type == "cuda":
+            for n in self.nets:
+                n.to(self.device)
+
+        self.metrics_fn = metrics if metrics else {}
+        if analytic_solutions:
+            warnings.warn("The `analytic_solutions` argument is deprecated and could lead to unstable behavior. "
+                          "Pass a `metrics` dict instead.", FutureWarning)
+
+            def analytic_mse(*args):
+                x = args[-n_input_units:]
+                u_hat = analytic_solutions(*x)
+                u = args[:-n_input_units]
+                u, u_hat = torch.stack(u), torch.stack(u_hat)
+                return ((u - u_hat) ** 2).mean()
+
+            if "analytic_mse" in self.metrics_fn:
+                warnings.warn("Ignoring `analytic_solutions` in presence of key 'analytic_mse' in `metrics`",
+                              FutureWarning)
+            else:
+                self.metrics_fn["analytic_mse"] = analytic_mse
+
+        self.metrics_history = {"train_loss": [], "valid_loss": []}
+        self.metrics_history.update({"train__" + name: [] for name in self.metrics_fn})
+        self.metrics_history.update({"valid__" + name: [] for name in self.metrics_fn})
+
+        self.optimizer = optimizer if optimizer else FusedAdam(_unique_params(self.nets))
+        self._set_loss_fn(loss_fn)
+        self.generator = {"train": SamplerGenerator(train_generator), "valid": SamplerGenerator(valid_generator)}
+        self.n_batches = {"train": n_batches_train, "valid": n_batches_valid}
+        self._batch = {"train": None, "valid": None}
+        if self.n_batches["valid"] == 0 and _requires_closure(self.optimizer):
+            warnings.warn(f"Setting n_batches_valid=0 will update lowest_loss and best_net with training loss "
+                          f"instead of validation loss. This is a problem for {self.optimizer.__class__} optimizer "
+                          f"because it updates the parameters before the training loss computed. "
+                          f"This leads to potentially worse solution in `best_net`!", RuntimeWarning)
+        self._best_nets = None
+        self._best_flat = None          # device snapshots of the flat parameters (fused path)
+        self.lowest_loss = None
+        self.local_epoch = 0
+        self._max_local_epoch = 0
+        self._stop_training = False
+        self._phase = None
+        self._fused_sys = None
+        self._fused_key = None
+        self._fused_failed = None
+        self.dist = None                # optional neurodiffeq_amd.parallel.BatchSharding
+
+    # ------------------------------------------------------------------------------------------ loss function
+    def _set_loss_fn(self, criterion):
+        if criterion is None:
+            self.loss_fn = _default_l2
+        elif isinstance(criterion, nn.modules.loss._Loss):
+            self.loss_fn = lambda r, f, x: criterion(r, torch.zeros_like(r))
+        elif isinstance(criterion, str):
+            self.loss_fn = _losses[criterion.lower()]
+        elif callable(criterion):
+            self.loss_fn = criterion
+        else:
+            raise TypeError(f"Unknown type of criterion {type(criterion)}")
+
+    # ------------------------------------------------------------------------------------------ small properties
+    @property
+    def global_epoch(self):
+        return len(self.metrics_history["train_loss"])
+
+    @property
+    def batch(self):
+        return self._batch
+
+    @property
+    def _batch_examples(self):
+        warnings.warn("`._batch_examples` has been deprecated in favor of `._batch` and will be removed in a future "
+                      "version", FutureWarning)
+        return self._batch
+
+    @property
+    def criterion(self):
+        warnings.warn(f"`{self.__class__.__name__}`.criterion is a deprecated alias for `.loss_fn`")
+        return self.loss_fn
+
+    @criterion.setter
+    def criterion(self, loss_fn):
+        warnings.warn(f"`{self.__class__.__name__}`.criterion is a deprecated alias for `.loss_fn`")
+        self.loss_fn = loss_fn
+
+    @property
+    def best_nets(self):
+        """Networks of the epoch with the lowest loss (solvers.py:434-441).  On the fused path the snapshot is a flat
+        device copy taken without a host round trip; module copies are materialised on first access."""
+        if self._best_flat is not None:
+            nets = deepcopy(self.nets)
+            with torch.no_grad():
+                for net, flat in zip(nets, self._best_flat):
+                    off = 0
+                    for p in net.parameters():
+                        p.copy_(flat[off:off + p.numel()].view(p.shape))
+                        off += p.numel()
+            self._best_nets, self._best_flat = nets, None
+        return self._best_nets
+
+    @best_nets.setter
+    def best_nets(self, nets):
+        self._best_nets, self._best_flat = nets, None
+
+    # ------------------------------------------------------------------------------------------ hooks
+    def compute_func_val(self, net, cond, *coordinates):
+        return cond.enforce(net, *coordinates)
+
+    def additional_loss(self, residual, funcs, coords):
+        return 0.0
+
+    def _do_optimizer_step(self, closure=None):
+        if closure is None:
+            self.optimizer.step()
+        else:
+            self.optimizer.step(closure=closure)
+
+    # ------------------------------------------------------------------------------------------ history
+    def _update_history(self, value, metric_type, key):
+        self._phase = key
+        if metric_type == "loss":
+            self.metrics_history[f"{key}_{metric_type}"].append(value)
+        elif metric_type in self.metrics_fn:
+            self.metrics_history[f"{key}__{metric_type}"].append(value)
+        else:
+            raise KeyError(f"metric '{metric_type}' not specified")
+
+    def _update_train_history(self, value, metric_type):
+        self._update_history(value, metric_type, key="train")
+
+    def _update_valid_history(self, value, metric_type):
+        self._update_history(value, metric_type, key="valid")
+
+    def _generate_batch(self, key):
+        self._phase = key
+        self._batch[key] = [v.reshape(-1, 1) for v in self.generator[key].get_examples()]
+        return self._batch[key]
+
+    def _generate_train_batch(self):
+        return self._generate_batch("train")
+
+    def _generate_valid_batch(self):
+        return self._generate_batch("valid")
+
+    # ------------------------------------------------------------------------------------------ fused system
+    def _fused_system(self, n_coords):
+        """The compiled fused step for the current (diff_eqs, nets, conditions, loss), or None -> composite path.
+        Re-keyed every epoch because callbacks may swap any of these between epochs (solvers.py:496-497)."""
+        if self.fused == "off" or self.device.type != "cuda":
+            if self.fused == "require":
+                raise _lib.NdqError("fused='require' but no MI355X is visible")
+            return None
+        reason = None
+        if self.loss_fn is not _default_l2 and self.loss_fn is not _losses["l2"]:
+            reason = "custom loss function"
+        elif type(self).additional_loss is not BaseSolver.additional_loss:
+            reason = "additional_loss override"
+        elif _requires_closure(self.optimizer):
+            reason = "closure-based optimizer"
+        key = (id(self.diff_eqs), tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions),
+               getattr(self.compute_func_val, "__func__", self.compute_func_val), reason)
+        if key == self._fused_key:
+            return self._fused_sys
+        self._fused_key, self._fused_sys = key, None
+        if reason is None:
+            try:
+                from .engine import FusedSystem
+                self._fused_sys = FusedSystem(self.nets, self.conditions, self.diff_eqs, n_coords, self.device,
+                                              compute_func_val=self.compute_func_val)
+                if isinstance(self.optimizer, FusedAdam):
+                    self.optimizer.bind(self._fused_sys.flat)
+            except TraceUnsupported as e:
+                reason = str(e)
+        if self._fused_sys is None:
+            if self.fused == "require":
+                raise _lib.NdqError(f"fused='require' but the system is outside the fused path: {reason}")
+            warnings.warn(f"neurodiffeq_amd: using the composite autograd path ({reason})", RuntimeWarning)
+        return self._fused_sys
+
+    @property
+    def fused_active(self):
+        return self._fused_sys is not None
+
+    # ------------------------------------------------------------------------------------------ epoch
+    def _run_epoch(self, key):
+        """One epoch on train/valid points (solvers.py:343-424)."""
+        if self.n_batches[key] <= 0:
+            return
+        self._phase = key
+        first_batch = self._generate_batch(key)
+        system = self._fused_system(len(first_batch))
+        if system is None:
+            return self._run_epoch_composite(key, first_batch)
+        nb = self.n_batches[key]
+        metric_values = {name: 0.0 for name in self.metrics_fn}
+        if system.loss_buf.numel() < nb:
+            system.loss_buf = torch.zeros(nb, dtype=torch.float32, device=self.device)
+        if key == "train":
+            self.optimizer.zero_grad()
+        shard = self.dist
+        for batch_id in range(nb):
+            batch = first_batch if batch_id == 0 else self._generate_batch(key)
+            n_all = batch[0].shape[0]
+            lo, hi = shard.bounds(n_all) if shard else (0, n_all)
+            b, n = system.step(batch, train=(key == "train"), slot=batch_id, accumulate=(batch_id > 0),
+                               n_global=n_all, lo=lo, hi=hi, want_funcs=bool(self.metrics_fn))
+            if self.metrics_fn:
+                funcs, coords = system.func_columns(b, n), system.coord_columns(b, n)
+                for name, fn in self.metrics_fn.items():
+                    metric_values[name] += fn(*funcs, *coords).item()
+        if key == "train":
+            for fp in system.flat:
+                fp.attach_grads()
+        if shard:
+            shard.all_reduce(system, nb, train=(key == "train"))
+        epoch_loss = system.loss_buf[:nb].sum().item() / nb           # the epoch's only host synchronisation
+        self._update_history(epoch_loss, "loss", key)
+        if key == "valid" or self.n_batches["valid"] == 0:
+            self._update_best(key)
+        if key == "train":
+            self._do_optimizer_step()
+        for name in self.metrics_fn:
+            self._update_history(metric_values[name] / nb, name, key)
+
+    def _run_epoch_composite(self, key, first_batch):
+        """The reference's closure on torch autograd, for systems outside the fused scope."""
+        epoch_loss, batch_loss = 0.0, 0.0
+        metric_values = {name: 0.0 for name in self.metrics_fn}
+        closure_opt = _requires_closure(self.optimizer)
+        if key == "train" and not closure_opt:
+            self.optimizer.zero_grad()
+        dev = self.device
+        for batch_id in range(self.n_batches[key]):
+            batch = first_batch if batch_id == 0 else self._generate_batch(key)
+            if batch[0].device != dev:
+                batch = [c.detach().to(dev).requires_grad_(True) for c in batch]
+                self._batch[key] = batch
+
+            def closure(zero_grad=True):
+                nonlocal batch_loss
+                if key == "train" and zero_grad:
+                    self.optimizer.zero_grad()
+                funcs = [self.compute_func_val(n, c, *batch) for n, c in zip(self.nets, self.conditions)]
+                for name in self.metrics_fn:
+                    metric_values[name] += self.metrics_fn[name](*funcs, *batch).item()
+                residuals = torch.cat(self.diff_eqs(*funcs, *batch), dim=1)
+                try:
+                    loss = self.loss_fn(residuals, funcs, batch) + self.additional_loss(residuals, funcs, batch)
+                except TypeError as e:
+                    warnings.warn("You might need to update your code. Since v0.4.0; both `criterion` and "
+                                  "`additional_loss` requires three inputs: `residual`, `funcs`, and `coords`.",
+                                  FutureWarning)
+                    raise e
+                if key == "train":
+                    loss.backward()
+                    batch_loss = loss.item()
+                return loss
+
+            if key == "train":
+                if closure_opt:
+                    self._do_optimizer_step(closure=closure)
+                else:
+                    closure(zero_grad=False)
+                epoch_loss += batch_loss
+            else:
+                epoch_loss += closure().item()
+        self._update_history(epoch_loss / self.n_batches[key], "loss", key)
+        if key == "valid" or self.n_batches["valid"] == 0:
+            self._update_best(key)
+        if key == "train" and not closure_opt:
+            self._do_optimizer_step()
+        for name in self.metrics_fn:
+            self._update_history(metric_values[name] / self.n_batches[key], name, key)
+
+    def run_train_epoch(self):
+        self._run_epoch("train")
+
+    def run_valid_epoch(self):
+        self._run_epoch("valid")
+
+    def _update_best(self, key):
+        current_loss = self.metrics_history[key + "_loss"][-1]
+        if (self.lowest_loss is None) or current_loss < self.lowest_loss:
+            self.lowest_loss = current_loss
+            if self._fused_sys is not None:
+                for fp in self._fused_sys.flat:
+                    fp.sync()
+                self._best_flat = [fp.flat.clone() for fp in self._fused_sys.flat]
+                self._best_nets = None
+            else:
+                self.best_nets = deepcopy(self.nets)
+
+    def fit(self, max_epochs, callbacks=(), tqdm_file=sys.stderr, **kwargs):
+        """Run ``max_epochs`` epochs of (train, valid, callbacks) -- solvers.py:443-497."""
+        self._stop_training = False
+        self._max_local_epoch = max_epochs
+        monitor = kwargs.pop("monitor", None)
+        if monitor:
+            warnings.warn("Passing `monitor` is deprecated, use a MonitorCallback and pass a list of callbacks instead")
+            callbacks = [monitor.to_callback()] + list(callbacks)
+        if kwargs:
+            raise ValueError(f"Unknown keyword argument(s): {list(kwargs.keys())}")
+        loop = range(max_epochs)
+        if tqdm_file is not None:
+            try:
+                from tqdm.auto import tqdm
+                loop = tqdm(loop, desc="Training Progress", colour="blue", file=tqdm_file, dynamic_ncols=True)
+            except ImportError:  # pragma: no cover
+                pass
+        for local_epoch in loop:
+            if self._stop_training:
+                break
+            self.local_epoch = local_epoch + 1
+            self.run_train_epoch()
+            self.run_valid_epoch()
+            for cb in callbacks:
+                cb(self)
+
+    # ------------------------------------------------------------------------------------------ results
+    @abstractmethod
+    def get_solution(self, copy=True, best=True):
+        pass  # pragma: no cover
+
+    def _solution(self, cls, copy, best):
+        nets = self.best_nets if best else self.nets
+        conditions = self.conditions
+        if copy:
+            nets, conditions = deepcopy(nets), deepcopy(conditions)
+        return cls(nets, conditions)
+
+    def _get_internal_variables(self):
+        return {
+            "metrics": self.metrics_fn, "n_batches": self.n_batches, "best_nets": self.best_nets,
+            "criterion": self.loss_fn, "loss_fn": self.loss_fn, "conditions": self.conditions,
+            "global_epoch": self.global_epoch, "lowest_loss": self.lowest_loss, "n_funcs": self.n_funcs,
+            "nets": self.nets, "optimizer": self.optimizer, "diff_eqs": self.diff_eqs, "generator": self.generator,
+            "train_generator": self.generator["train"], "valid_generator": self.generator["valid"],
+        }
+
+    def get_internals(self, var_names=None, return_type="list", param_names=None):
+        if param_names is not None:
+            warnings.warn("`param_names` is deprecated; use `var_names`", FutureWarning)
+            var_names = param_names
+        available = self._get_internal_variables()
+        if var_names == "all" or var_names is None:
+            return available
+        if isinstance(var_names, str):
+            return available[var_names]
+        if return_type == "list":
+            return [available[name] for name in var_names]
+        if return_type == "dict":
+            return {name: available[name] for name in var_names}
+        raise ValueError(f"unrecognized return_type = {return_type}")
+
+    def get_residuals(self, *coords, to_numpy=False, best=True, no_reshape=False):
+        """Residuals of ``diff_eqs`` at given points (solvers.py:606-646)."""
+        coords = [c if isinstance(c, torch.Tensor) else torch.tensor(c) for c in coords]
+        original_shape = coords[0].shape
+        coords = [c.detach().to(self.device).reshape(-1, 1).requires_grad_() for c in coords]
+        solution = self.get_solution(copy=False, best=best)
+        funcs = solution(*coords, to_numpy=False, no_reshape=no_reshape)
+        if isinstance(funcs, torch.Tensor):
+            funcs = [funcs]
+        residuals = self.diff_eqs(*funcs, *coords)
+        if not no_reshape:
+            residuals = [r.reshape(*original_shape) for r in residuals]
+        if to_numpy:
+            residuals = [r.detach().cpu().numpy() for r in residuals]
+        return residuals if len(residuals) > 1 else residuals[0]
+
+
+class BaseSolution(ABC):
+    """Callable solution object (solvers.py:649-720)."""
+
+    def __init__(self, nets, conditions):
+        if nets is None:
+            raise RuntimeError("The nets cannot be None, check if you disabled validation and used `best`=True with "
+                               "`get_solution` / `get_residual`")
+        self.nets = [nets] * len(conditions) if isinstance(nets, nn.Module) else nets
+        self.conditions = conditions
+
+    @abstractmethod
+    def _compute_u(self, net, condition, *coords):
+        pass  # pragma: no cover
+
+    def __call__(self, *coords, to_numpy=False, no_reshape=False, as_type=None):
+        if as_type is not None:
+            warnings.warn("`as_type` is deprecated; use `to_numpy`", FutureWarning)
+            to_numpy = as_type
+        coords = [c if isinstance(c, torch.Tensor) else torch.tensor(c) for c in coords]
+        original_shape = coords[0].shape
+        try:
+            dev = next(self.nets[0].parameters()).device
+        except StopIteration:  # pragma: no cover
+            dev = coords[0].device
+        coords = [c.to(dev).reshape(-1, 1) for c in coords]
+        if isinstance(to_numpy, str):
+            if to_numpy in ("tf", "torch"):
+                to_numpy = False
+            elif to_numpy == "np":
+                to_numpy = True
+            else:
+                raise ValueError(f"Unrecognized `as_type` option: '{to_numpy}'")
+        us = [self._compute_u(net, con, *coords) for con, net in zip(self.conditions, self.nets)]
+        if not no_reshape:
+            us = [u.reshape(*original_shape) for u in us]
+        if to_numpy:
+            us = [u.detach().cpu().numpy() for u in us]
+        return us if len(self.nets) > 1 else us[0]
+
+
+class GenericSolution(BaseSolution):
+    def _compute_u(self, net, condition, *coords):
+        return condition.enforce(net, *coords)
+
+
+class Solution1D(GenericSolution):
+    pass
+
+
+class Solution2D(GenericSolution):
+    pass
+
+
+class GenericSolver(BaseSolver):
+    def get_solution(self, copy=True, best=True):
+        return self._solution(GenericSolution, copy, best)
+
+
+class Solver1D(BaseSolver):
+    """ODE systems in one independent variable (solvers.py:1020-1186)."""
+
+    def __init__(self, ode_system, conditions, t_min=None, t_max=None, nets=None, train_generator=None,
+                 valid_generator=None, analytic_solutions=None, optimizer=None, loss_fn=None, n_batches_train=1,
+                 n_batches_valid=4, metrics=None, n_output_units=1, batch_size=None, shuffle=None):
+        if (train_generator is None or valid_generator is None) and (t_min is None or t_max is None):
+            raise ValueError(f"Either generator is not provided, t_min and t_max should be both provided: \n"
+                             f"got t_min={t_min}, t_max={t_max}, train_generator={train_generator}, "
+                             f"valid_generator={valid_generator}")
+        if train_generator is None:
+            train_generator = Generator1D(32, t_min=t_min, t_max=t_max, method="equally-spaced-noisy")
+        if valid_generator is None:
+            valid_generator = Generator1D(32, t_min=t_min, t_max=t_max, method="equally-spaced")
+        self.t_min, self.t_max = t_min, t_max
+        super().__init__(diff_eqs=ode_system, conditions=conditions, nets=nets, train_generator=train_generator,
+                         valid_generator=valid_generator, analytic_solutions=analytic_solutions, optimizer=optimizer,
+                         loss_fn=loss_fn, n_batches_train=n_batches_train, n_batches_valid=n_batches_valid,
+                         metrics=metrics, n_input_units=1, n_output_units=n_output_units, shuffle=shuffle,
+                         batch_size=batch_size)
+
+    def get_solution(self, copy=True, best=True):
+        return self._solution(Solution1D, copy, best)
+
+    def _get_internal_variables(self):
+        d = super()._get_internal_variables()
+        d.update(t_min=self.t_min, t_max=self.t_max)
+        return d
+
+
+class Solver2D(BaseSolver):
+    """PDE systems in two independent variables (solvers.py:1427-1593)."""
+
+    def __init__(self, pde_system, conditions, xy_min=None, xy_max=None, nets=None, train_generator=None,
+                 valid_generator=None, analytic_solutions=None, optimizer=None, loss_fn=None, n_batches_train=1,
+                 n_batches_valid=4, metrics=None, n_output_units=1, batch_size=None, shuffle=None):
+        if (train_generator is None or valid_generator is None) and (xy_min is None or xy_max is None):
+            raise ValueError(f"Either generator is not provided, xy_min and xy_max should be both provided: \n"
+                             f"got xy_min={xy_min}, xy_max={xy_max}, train_generator={train_generator}, "
+                             f"valid_generator={valid_generator}")
+        if train_generator is None:
+            train_generator = Generator2D((32, 32), xy_min=xy_min, xy_max=xy_max, method="equally-spaced-noisy")
+        if valid_generator is None:
+            valid_generator = Generator2D((32, 32), xy_min=xy_min, xy_max=xy_max, method="equally-spaced")
+        self.xy_min, self.xy_max = xy_min, xy_max
+        super().__init__(diff_eqs=pde_system, conditions=conditions, nets=nets, train_generator=train_generator,
+                         valid_generator=valid_generator, analytic_solutions=analytic_solutions, optimizer=optimizer,
+                         loss_fn=loss_fn, n_batches_train=n_batches_train, n_batches_valid=n_batches_valid,
+                         metrics=metrics, n_input_units=2, n_output_units=n_output_units, shuffle=shuffle,
+                         batch_size=batch_size)
+
+    def get_solution(self, copy=True, best=True):
+        return self._solution(Solution2D, copy, best)
+
+    def _get_internal_variables(self):
+        d = super()._get_internal_variables()
+        d.update(xy_min=self.xy_min, xy_max=self.xy_max)
+        return d

@@ -38,6 +38,32 @@ class Graph:
         self.net_deps = {}       # net_idx -> tuple of coordinate indices in the order fed to the net
         self.net_nout = {}       # net_idx -> number of output units
 
+    # -------------------------------------------------------------- networks
+    def register_nets(self, nets, n_outs):
+        self._net_ids = {id(n): k for k, n in enumerate(nets)}
+        self._net_nouts = list(n_outs)
+
+    def net_symbol(self, net, coords, ith_unit=None):
+        """Symbol for ``net(cat(coords, 1))`` (conditions.py:52-55) -- only for the solver's own networks, evaluated at
+        the batch coordinates themselves."""
+        k = getattr(self, "_net_ids", {}).get(id(net))
+        if k is None:
+            raise TraceUnsupported("a network that does not belong to the solver was called inside the traced region")
+        deps = []
+        for c in coords:
+            node = self.nodes[c.i] if isinstance(c, Sym) else None
+            if node is None or node[0] != "coord":
+                raise TraceUnsupported("network evaluated at something other than the batch coordinates")
+            deps.append(node[1])
+        deps = tuple(deps)
+        if self.net_deps.setdefault(k, deps) != deps:
+            raise TraceUnsupported("network evaluated at two different coordinate tuples")
+        n_out = self._net_nouts[k]
+        self.net_nout[k] = n_out
+        if n_out != 1:
+            raise TraceUnsupported("multi-output networks are not on the fused path yet")
+        return Sym(self, self.net(k, 0 if ith_unit is None else ith_unit))
+
     # -------------------------------------------------------------- construction
     def _mk(self, key):
         i = self._ids.get(key)

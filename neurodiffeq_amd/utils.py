@@ -1,0 +1,39 @@
+"""Global dtype / device helpers with the reference's names (neurodiffeq/utils.py:10-68).
+
+Difference from the reference, on purpose: importing :mod:`neurodiffeq_amd` does NOT flip the process-wide default
+dtype to fp64 / device to cuda (reference ``__init__.py:22``).  The fused gfx950 path is fp32; call
+``set_tensor_type(float_bits=64)`` explicitly to get the reference's fp64 default, which runs on the composite
+(torch autograd) path."""
+import random
+import re
+
+import numpy as np
+import torch
+
+
+def set_tensor_type(device=None, float_bits=32):
+    if not isinstance(float_bits, int):
+        raise ValueError(f"float_bits must be int, got {type(float_bits)}")
+    if float_bits == 32:
+        torch.set_default_dtype(torch.float32)
+    elif float_bits == 64:
+        torch.set_default_dtype(torch.float64)
+    else:
+        raise ValueError(f"float_bits must be 32 or 64, got {float_bits}")
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    if device != "cpu" and not re.fullmatch(r"cuda(?::\d+)?", device):
+        raise ValueError(f"Unknown device '{device}'; device must be either 'cuda', 'cuda:x' where x is the device "
+                         f"number, 'cpu'")
+    torch.set_default_device(device)
+
+
+def set_seed(seed_value, ignore_numpy=False, ignore_torch=False, ignore_random=False):
+    if not ignore_numpy:
+        np.random.seed(seed_value)
+    if not ignore_torch:
+        torch.manual_seed(seed_value)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed_value)
+    if not ignore_random:
+        random.seed(seed_value)

@@ -1,0 +1,72 @@
+"""The BASELINE.json configs written against the neurodiffeq_amd API -- exactly what a user script
+for the reference looks like with the import changed.  Shared by the tests, bench.py and __graft_entry__.py."""
+import math
+
+import torch
+
+from neurodiffeq_amd import diff
+from neurodiffeq_amd.conditions import IVP, DirichletBVP2D, IBVP1D, NoCondition
+from neurodiffeq_amd.generators import Generator1D, Generator2D
+from neurodiffeq_amd.networks import FCNN, SinActv
+
+PI = math.pi
+DEFAULT_SIZE = {"c1": 1024, "c2": 256, "c3": 512, "c5": 1024}
+
+
+def lid(x):
+    return (1 - torch.exp(-50.0 * x)) * (1 - torch.exp(50.0 * (x - 1)))
+
+
+def make(name, size=None):
+    """Returns dict(kind, pde, nets, conds, gen, n_points); nets use torch's default init (consumes the global RNG
+    like the reference's constructors)."""
+    size = size or DEFAULT_SIZE[name]
+    zero = lambda s: 0
+    if name == "c1":
+        pde = lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)]
+        nets = [FCNN(1, 1, hidden_units=(32, 32), actv=SinActv) for _ in range(2)]
+        conds = [IVP(0.0, 1.5), IVP(0.0, 1.0)]
+        gen = Generator1D(size, 0.1, 12.0, "equally-spaced-noisy")
+        return dict(kind="1d", pde=pde, nets=nets, conds=conds, gen=gen, n_points=size, dom=(0.1, 12.0))
+    if name == "c2":
+        pde = lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2)]
+        nets = [FCNN(2, 1, hidden_units=(32, 32))]
+        conds = [DirichletBVP2D(x_min=0, x_min_val=lambda y: torch.sin(PI * y), x_max=1, x_max_val=zero,
+                                y_min=0, y_min_val=zero, y_max=1, y_max_val=zero)]
+        gen = Generator2D((size, size), (0, 0), (1, 1), "equally-spaced-noisy")
+        return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen, n_points=size * size, dom=((0, 0), (1, 1)))
+    if name == "c3":
+        nu = 0.01 / PI
+        pde = lambda u, x, t: [diff(u, t) + u * diff(u, x) - nu * diff(u, x, order=2)]
+        nets = [FCNN(2, 1, hidden_units=(64, 64, 64))]
+        conds = [IBVP1D(x_min=-1, x_max=1, t_min=0, t_min_val=lambda x: -torch.sin(PI * x), x_min_val=zero,
+                        x_max_val=zero)]
+        gen = Generator2D((size, size), (-1, 0), (1, 1), "equally-spaced-noisy")
+        return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen, n_points=size * size, dom=((-1, 0), (1, 1)))
+    if name == "c5":
+        re = 400.0
+
+        def pde(u, v, p, x, y):
+            mx = u * diff(u, x) + v * diff(u, y) + diff(p, x) - 1 / re * (diff(u, x, order=2) + diff(u, y, order=2))
+            my = u * diff(v, x) + v * diff(v, y) + diff(p, y) - 1 / re * (diff(v, x, order=2) + diff(v, y, order=2))
+            return [mx, my, diff(u, x) + diff(v, y)]
+
+        nets = [FCNN(2, 1, hidden_units=(64, 64, 64)) for _ in range(3)]
+        conds = [DirichletBVP2D(0, zero, 1, zero, 0, zero, 1, lid), DirichletBVP2D(0, zero, 1, zero, 0, zero, 1, zero),
+                 NoCondition()]
+        gen = Generator2D((size, size), (0, 0), (1, 1), "equally-spaced-noisy")
+        return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen, n_points=size * size, dom=((0, 0), (1, 1)))
+    raise KeyError(name)
+
+
+def make_solver(name, size=None, **kw):
+    from neurodiffeq_amd.solvers import Solver1D, Solver2D
+    cfg = make(name, size)
+    kw.setdefault("n_batches_valid", 0)
+    if cfg["kind"] == "1d":
+        s = Solver1D(cfg["pde"], cfg["conds"], t_min=cfg["dom"][0], t_max=cfg["dom"][1], nets=cfg["nets"],
+                     train_generator=cfg["gen"], valid_generator=cfg["gen"], **kw)
+    else:
+        s = Solver2D(cfg["pde"], cfg["conds"], xy_min=cfg["dom"][0], xy_max=cfg["dom"][1], nets=cfg["nets"],
+                     train_generator=cfg["gen"], valid_generator=cfg["gen"], **kw)
+    return s, cfg

@@ -1,0 +1,58 @@
+"""Test infrastructure: compile the per-point function of a generated pointwise kernel (neurodiffeq_amd/codegen.py)
+with gcc and run it over a batch on the host, so tracer + symbolic differentiation + adjoint code generation can be
+checked against the oracle without a GPU.  The product never loads this."""
+import ctypes
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+_DRIVER = r"""
+void pw_cpu_run(const float* coords, const float* syms, int n, float seed, int want_adj,
+                float* resid, float* funcs, float* gbar) {
+  for (int i = 0; i < n; ++i) {
+    float c[NDQ_PW_NC > 0 ? NDQ_PW_NC : 1], s[NDQ_PW_NSYM > 0 ? NDQ_PW_NSYM : 1];
+    float r[NDQ_PW_NEQ > 0 ? NDQ_PW_NEQ : 1], f[NDQ_PW_NF > 0 ? NDQ_PW_NF : 1], g[NDQ_PW_NSYM > 0 ? NDQ_PW_NSYM : 1];
+    for (int k = 0; k < NDQ_PW_NC; ++k) c[k] = coords[(size_t)k * n + i];
+    for (int k = 0; k < NDQ_PW_NSYM; ++k) s[k] = syms[(size_t)k * n + i];
+    ndq_pw_point(c, s, seed, want_adj, r, f, g);
+    for (int k = 0; k < NDQ_PW_NEQ; ++k) resid[(size_t)k * n + i] = r[k];
+    for (int k = 0; k < NDQ_PW_NF; ++k) funcs[(size_t)k * n + i] = f[k];
+    if (want_adj) for (int k = 0; k < NDQ_PW_NSYM; ++k) gbar[(size_t)k * n + i] = g[k];
+  }
+}
+"""
+
+
+def compile_cpu(program):
+    src = program.source + _DRIVER
+    key = hashlib.sha1(src.encode()).hexdigest()[:16]
+    d = os.path.join(tempfile.gettempdir(), "ndq_pw_cpu")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, f"pw_{key}.so")
+    if not os.path.exists(so):
+        c = os.path.join(d, f"pw_{key}.c")
+        with open(c, "w") as fh:
+            fh.write(src)
+        subprocess.run(["gcc", "-O2", "-std=c99", "-fno-fast-math", "-ffp-contract=off", "-shared", "-fPIC", c, "-o", so,
+                        "-lm"], check=True)
+    lib = ctypes.CDLL(so)
+    return lib
+
+
+def run_cpu(program, coords, syms, seed, want_adj=True):
+    """coords [nc][n] fp32, syms [nsym][n] fp32 (order = program.symbols) -> resid [neq][n], funcs [nf][n], gbar [nsym][n]"""
+    lib = compile_cpu(program)
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    syms = np.ascontiguousarray(syms, dtype=np.float32)
+    n = coords.shape[1]
+    resid = np.zeros((len(program.residuals), n), np.float32)
+    funcs = np.zeros((len(program.funcs), n), np.float32)
+    gbar = np.zeros((max(len(program.symbols), 1), n), np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.pw_cpu_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.pw_cpu_run(p(coords), p(syms), n, seed, int(want_adj), p(resid), p(funcs), p(gbar))
+    return resid, funcs, gbar

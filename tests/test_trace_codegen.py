@@ -1,0 +1,98 @@
+"""Tracer + symbolic diff + generated pointwise code (compiled for the host with gcc) + the jet oracle's VJP,
+chained into a full closure and compared with the reference's golden vectors: everything on the fused path except
+the HIP MLP kernels themselves (those are modelled lane-by-lane in test_wave_model.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from neurodiffeq_amd import codegen
+from neurodiffeq_amd.networks import describe
+from neurodiffeq_amd.symbolic import Graph, Sym, trace_scope
+from oracle import jet_ref as J
+from tests import configs
+from tests.pw_cpu import run_cpu
+
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8}
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def trace(cfg, n_coords):
+    nets, conds = cfg["nets"], cfg["conds"]
+    g = Graph(n_coords)
+    g.register_nets(nets, [describe(n)["n_out"] for n in nets])
+    with trace_scope(g):
+        coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
+        funcs = [c.enforce(n, *coords) for n, c in zip(nets, conds)]
+        res = cfg["pde"](*funcs, *coords)
+    for k, n in enumerate(nets):
+        g.net_deps.setdefault(k, tuple(range(describe(n)["d"])))
+        g.net_nout.setdefault(k, 1)
+    return codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets))
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
+def test_fused_pipeline_on_host_matches_reference(golden_dir, name):
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(0)
+    cfg = configs.make(name, SIZES[name])
+    coords = gold["coords"].astype(np.float32)
+    n_coords, n = coords.shape
+    prog = trace(cfg, n_coords)
+    # network streams from the jet oracle (fp64 -> fp32), laid out like program.symbols
+    dims_act, flats, off = [], [], 0
+    for net in cfg["nets"]:
+        info = describe(net)
+        dims = (info["d"],) + (info["hidden"],) * info["layers"] + (1,)
+        npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
+        dims_act.append((dims, "tanh" if info["act"] == 0 else "sin"))
+        flats.append(gold["params0"][off:off + npar].astype(np.float64))
+        off += npar
+    needed = {k: set() for k in range(len(cfg["nets"]))}
+    for i in prog.symbols:
+        _, k, o, mi = prog.g.nodes[i]
+        needed[k].add(mi)
+    jets = {}
+    for k, (dims, act) in enumerate(dims_act):
+        deps = prog.streams[k].deps
+        local = lambda mi: tuple(deps.index(c) for c in mi)
+        js = J.mlp_jets(flats[k], dims, act, [coords[c] for c in deps], [local(mi) for mi in needed[k]] or [()])
+        jets[k] = {mi: js[tuple(sorted(local(mi)))][:, 0] for mi in needed[k]}
+    syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]] for i in prog.symbols]).astype(np.float32)
+    n_eq = len(prog.residuals)
+    seed = 1.0 / (n * n_eq)
+    resid, funcs, gbar = run_cpu(prog, coords, syms, seed)
+    assert rel_l2(funcs.T, gold["funcs_f64"]) < 1e-5
+    assert rel_l2(resid.T, gold["residuals_f64"]) < 1e-5
+    loss = float((resid.astype(np.float64) ** 2).sum() * seed)
+    assert abs(loss - float(gold["loss_f64"])) <= 1e-5 * abs(float(gold["loss_f64"]))
+    # parameter gradient: adjoint streams through the jet oracle's VJP
+    grads = []
+    for k, (dims, act) in enumerate(dims_act):
+        deps = prog.streams[k].deps
+        gb = {}
+        for idx, i in enumerate(prog.symbols):
+            _, kk, o, mi = prog.g.nodes[i]
+            if kk == k:
+                gb[tuple(sorted(deps.index(c) for c in mi))] = gbar[idx].astype(np.float64)[:, None]
+        grads.append(J.mlp_jets_vjp(flats[k], dims, act, [coords[c] for c in deps], gb))
+    assert rel_l2(np.concatenate(grads), gold["grad_f64"]) < 1e-5
+
+
+def test_unsupported_constructs_raise_trace_unsupported():
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.symbolic import TraceUnsupported
+    g = Graph(1)
+    with trace_scope(g):
+        t = Sym(g, g.coord(0))
+        with pytest.raises(TraceUnsupported):
+            torch.cumsum(t, 0)
+        with pytest.raises(TraceUnsupported):
+            bool(t > 0) if hasattr(t, "__gt__") else bool(t)
+        assert g.cval(diff(3.0 * t * t, t, order=3).i) == 0.0
+        assert g.cval(diff(t ** 2, t, order=2).i) == 2.0
