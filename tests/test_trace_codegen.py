@@ -93,6 +93,6 @@ def test_unsupported_constructs_raise_trace_unsupported():
         with pytest.raises(TraceUnsupported):
             torch.cumsum(t, 0)
         with pytest.raises(TraceUnsupported):
-            bool(t > 0) if hasattr(t, "__gt__") else bool(t)
+            bool(t)
         assert g.cval(diff(3.0 * t * t, t, order=3).i) == 0.0
         assert g.cval(diff(t ** 2, t, order=2).i) == 2.0
