@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""Headline benchmark: collocation-points/sec of one training step (forward + residual + loss + backward + Adam)
+of the 2D Laplace system -- BASELINE.json config C2: Solver2D, FCNN(2-32-32-1, tanh), DirichletBVP2D,
+Generator2D 256x256 = 65 536 noisy-grid points per batch per GPU, fp32 -- through ``Solver2D.run_train_epoch()``.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver with torch.distributed.run (one rank per MI355X, RCCL); scaling is WEAK: every rank
+trains on its own 65 536-point shard of a global N*65 536-point batch and joins one all-reduce of the flat
+[gradients | loss] vector per step.  A "step" is one ``run_train_epoch()`` with ``n_batches_train=1``,
+``n_batches_valid=0``: fused forward, generated pointwise residual/loss kernel, fused backward, reductions, one host
+read of the loss, best-network snapshot, fused Adam step.  Inputs are pre-sampled (reference RNG order) and resident
+in HBM before the timed region (``ResidentBatchGenerator``); the figure with host sampling + PCIe upload inside the
+step is reported separately as ``with_host_sampling``.
+
+Rank 0 prints ONE JSON line (contract in the task description) including
+  roofline     -- dominant kernel (mlp_jet_bwd): algorithmic GEMM flops / HIP-event launch time vs the fp32 MFMA peak,
+  kernels      -- the same for the forward kernel and achieved HBM GB/s of the pointwise residual kernel,
+  cpu_baseline -- the oracle's port of the reference step (torch CPU autograd) timed on this host.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GRID = 256
+N_POINTS = GRID * GRID
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+# algorithmic GEMM flops per point, C2: forward 10 688, adjoint = 2 x forward
+FWD_FLOP_PER_PT = 2 * (32 * 2 * 1 + 32 * 32 * 5 + 32 * 1 * 5)
+BWD_FLOP_PER_PT = 2 * FWD_FLOP_PER_PT
+
+
+def time_launches(fn, iters=200, warm=20):
+    """Average duration (seconds) of one launch of ``fn`` on torch's current stream, by HIP events."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def kernel_breakdown(system, batch):
+    """Per-kernel launch time of the step's kernels on a resident batch -> roofline figures."""
+    from neurodiffeq_amd.engine import _c_vp
+    b, n = system.upload(batch)
+    stream = _c_vp(torch.cuda.current_stream().cuda_stream)
+    system.step(batch, train=True)
+    t_fwd = time_launches(lambda: system.forward(b, n, stream))
+    t_pw = time_launches(lambda: system.pointwise(b, n, stream, True, n))
+    L, k, fp = system.L, 0, system.flat[0]
+    d = system.descs[0]
+    coords = system._coord_ptr(b, system.coord0[0])
+
+    def bwd_only():
+        L.ndq_mlp_jet_bwd(ctypes.byref(d), coords, b["ld"], n, fp.flat.data_ptr(), b["gbar"][0].data_ptr(), b["ld"],
+                          b["partials"][0].data_ptr(), stream)
+
+    def reduce_only():
+        L.ndq_reduce_partials(b["partials"][0].data_ptr(), b["bwd_blocks"][0], fp.numel, fp.grad.data_ptr(), 0, 1.0, stream)
+
+    t_bwd = time_launches(bwd_only)
+    t_red = time_launches(reduce_only)
+    pw_bytes = system.program.bytes_per_point(train=True) * n
+    return dict(
+        mlp_jet_fwd=dict(us=t_fwd * 1e6, tflops=FWD_FLOP_PER_PT * n / t_fwd / 1e12),
+        pointwise=dict(us=t_pw * 1e6, gbs=pw_bytes / t_pw / 1e9, bytes_per_point=pw_bytes // n),
+        mlp_jet_bwd=dict(us=t_bwd * 1e6, tflops=BWD_FLOP_PER_PT * n / t_bwd / 1e12),
+        reduce_partials=dict(us=t_red * 1e6),
+    )
+
+
+def cpu_baseline(budget_s=20.0):
+    """The reference's training step restated on torch CPU autograd (oracle/autograd_ref.py, pinned to the
+    reference's golden vectors), same config, timed on this host's cores."""
+    from oracle import autograd_ref as R
+    torch.manual_seed(0)
+    cfg = R.build_config("c2", GRID)
+    loop = R.TrainLoop(cfg["nets"], cfg["enforcers"], cfg["pde"], cfg["sampler"])
+    for _ in range(2):
+        loop.epoch()
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 8 or (time.perf_counter() - t_start < budget_s and len(times) < 200):
+        t0 = time.perf_counter()
+        loop.epoch()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > 3 * budget_s:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=N_POINTS / med, unit="collocation-points/s", cores=torch.get_num_threads(), kind="port",
+                ms_per_step=med * 1e3,
+                sample=f"{len(times)} timed run_train_epoch-equivalent steps (sample+fwd+diff+loss+bwd+Adam) of the "
+                       f"same C2 config, fp32, torch {torch.__version__} CPU, {os.cpu_count()} logical cpus")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from neurodiffeq_amd.generators import Generator2D, ResidentBatchGenerator
+    from neurodiffeq_amd.parallel import BatchSharding
+    from tests import configs
+
+    # identical weights on every rank (same seed); the global batch is a (256*world) x 256 noisy grid of which each
+    # rank keeps its contiguous 65 536-point shard resident.
+    torch.manual_seed(0)
+    solver, cfg = configs.make_solver("c2", GRID)
+    solver.fused = "require"
+    torch.manual_seed(1)
+    global_gen = Generator2D((GRID * world, GRID), (0, 0), (1, 1), "equally-spaced-noisy")
+    n_pool = 8
+    resident = ResidentBatchGenerator.presample(global_gen, n_pool, "cuda", lo=rank * N_POINTS, hi=(rank + 1) * N_POINTS)
+    from neurodiffeq_amd.generators import SamplerGenerator
+    solver.generator["train"] = SamplerGenerator(resident)
+    if world > 1:
+        solver.dist = BatchSharding(presharded=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.run_train_epoch()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.run_train_epoch()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert solver.fused_active
+    ms = dt / args.steps * 1e3
+    value = N_POINTS * world / (dt / args.steps)
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "collocation-points/sec (residual+bwd), 2D Laplace 65k pts, 1/2/4/8 GPU",
+            "value": value, "unit": "collocation-points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: Solver2D 2D Laplace, DirichletBVP2D, FCNN(2-32-32-1, tanh), Generator2D "
+                                   "256x256 = 65536 noisy-grid points per GPU per step, Adam(1e-3), "
+                                   "run_train_epoch() with n_batches_train=1, n_batches_valid=0",
+                       "points_per_gpu": N_POINTS, "global_batch": N_POINTS * world,
+                       "parallelism": f"dp{world} (shard-by-batch, one all-reduce of [P+1] fp32 per step)",
+                       "inputs": "pre-sampled in the reference's RNG order, resident in HBM"},
+            "final_loss": solver.metrics_history["train_loss"][-1],
+        }
+    if rank == 0 and world == 1:
+        system = solver._fused_sys
+        batch = solver._generate_batch("train")
+        kb = kernel_breakdown(system, batch)
+        out["kernels"] = kb
+        out["roofline"] = {"kernel": "mlp_jet_bwd_kernel<Cfg<2,1,5,2,2,tanh>>", "bound": "mfma",
+                           "achieved": kb["mlp_jet_bwd"]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": kb["mlp_jet_bwd"]["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "algorithmic_flop_per_point": BWD_FLOP_PER_PT, "avg_launch_us": kb["mlp_jet_bwd"]["us"]}
+        out["roofline_pointwise"] = {"kernel": "ndq_pw_kernel (generated)", "bound": "hbm",
+                                     "achieved": kb["pointwise"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": kb["pointwise"]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                                     "algorithmic_bytes_per_point": kb["pointwise"]["bytes_per_point"]}
+        # the same step with host sampling (CPU RNG, bit-exact with the reference) + PCIe upload inside it
+        torch.manual_seed(2)
+        solver.generator["train"] = SamplerGenerator(cfg["gen"])
+        for _ in range(3):
+            solver.run_train_epoch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k2 = max(10, args.steps // 10)
+        for _ in range(k2):
+            solver.run_train_epoch()
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / k2
+        out["with_host_sampling"] = {"value": N_POINTS / dt2, "ms_per_step": dt2 * 1e3}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,61 @@ def _round_up(n, m):
     return (n + m - 1) // m * m
 
 
+def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
+    """Trace (conditions, diff_eqs) once on symbolic columns and lower them to a pointwise program.
+
+    Needs no GPU (used by ``__graft_entry__.build`` to pre-compile the generated kernels); raises
+    :class:`TraceUnsupported` when the system is outside the fused scope.  Returns ``(program, descs)`` with
+    ``descs[k]`` the ``ndq_mlp_desc`` of network k (stream set widened to one libndq.so has kernels for)."""
+    L = _lib.lib()
+    nets, conditions = list(nets), list(conditions)
+    infos = [describe(n) for n in nets]
+    if any(i is None for i in infos):
+        raise TraceUnsupported("a network is not an FCNN the gfx950 kernels support")
+    g = Graph(n_coords)
+    g.register_nets(nets, [i["n_out"] for i in infos])
+    cfv = compute_func_val or (lambda net, cond, *coords: cond.enforce(net, *coords))
+    with trace_scope(g):
+        coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
+        funcs = [cfv(n, c, *coords) for n, c in zip(nets, conditions)]
+        res = diff_eqs(*funcs, *coords)
+        if isinstance(res, Sym):
+            res = [res]
+        res = [r if isinstance(r, Sym) else Sym(g, g.const(float(r))) for r in res]
+    if not all(isinstance(f, Sym) for f in funcs):
+        raise TraceUnsupported("a condition returned something that is not a traced column")
+    for k, info in enumerate(infos):       # a net that never appears in an equation still needs a layout
+        g.net_deps.setdefault(k, tuple(range(info["d"])))
+        g.net_nout.setdefault(k, info["n_out"])
+    descs = {}
+
+    def widen(k, st):
+        info = infos[k]
+        if st.d != info["d"]:
+            raise TraceUnsupported("network input width differs from the number of coordinates fed to it")
+        if list(st.deps) != list(range(st.deps[0], st.deps[0] + st.d)):
+            raise TraceUnsupported("network fed a non-contiguous subset of the coordinates")
+        npair = st.d * (st.d + 1) // 2
+        best = None
+        for first in ((1,) if st.first else (0, 1)):
+            for mask2 in range(1 << npair):
+                if (mask2 & st.mask2) != st.mask2 or (mask2 and not first):
+                    continue
+                d = _lib.MlpDesc(st.d, first, mask2, info["hidden"], info["layers"], info["act"], info["n_out"])
+                if L.ndq_mlp_supported(ctypes.byref(d)):
+                    cost = first * st.d + bin(mask2).count("1")
+                    if best is None or cost < best[0]:
+                        best = (cost, d)
+        if best is None:
+            raise TraceUnsupported(f"no gfx950 kernel for FCNN d={st.d} hidden={info['hidden']} layers="
+                                   f"{info['layers']} streams(first={st.first}, mask2={st.mask2:#b})")
+        st.first, st.mask2 = best[1].first, best[1].mask2
+        descs[k] = best[1]
+
+    program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets), widen=widen)
+    return program, descs
+
+
 class FusedSystem:
     def __init__(self, nets, conditions, diff_eqs, n_coords, device, compute_func_val=None):
         self.device = torch.device(device)
@@ -36,52 +91,8 @@ class FusedSystem:
             raise _lib.NdqError("the fused path needs an MI355X (device 'cuda'); no CPU fallback exists for it")
         self.L = _lib.lib()
         self.nets, self.conditions, self.n_coords = list(nets), list(conditions), n_coords
-        infos = [describe(n) for n in self.nets]
-        if any(i is None for i in infos):
-            raise TraceUnsupported("a network is not an FCNN the gfx950 kernels support")
-        g = Graph(n_coords)
-        g.register_nets(self.nets, [i["n_out"] for i in infos])
-        cfv = compute_func_val or (lambda net, cond, *coords: cond.enforce(net, *coords))
-        with trace_scope(g):
-            coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
-            funcs = [cfv(n, c, *coords) for n, c in zip(self.nets, self.conditions)]
-            res = diff_eqs(*funcs, *coords)
-            if isinstance(res, Sym):
-                res = [res]
-            res = [r if isinstance(r, Sym) else Sym(g, g.const(float(r))) for r in res]
-        if not all(isinstance(f, Sym) for f in funcs):
-            raise TraceUnsupported("a condition returned something that is not a traced column")
-        self.n_eq, self.n_funcs = len(res), len(funcs)
-        for k, info in enumerate(infos):       # a net that never appears in an equation still needs a layout
-            g.net_deps.setdefault(k, tuple(range(info["d"])))
-            g.net_nout.setdefault(k, info["n_out"])
-
-        self.descs = {}
-
-        def widen(k, st):
-            info = infos[k]
-            if st.d != info["d"]:
-                raise TraceUnsupported("network input width differs from the number of coordinates fed to it")
-            if list(st.deps) != list(range(st.deps[0], st.deps[0] + st.d)):
-                raise TraceUnsupported("network fed a non-contiguous subset of the coordinates")
-            npair = st.d * (st.d + 1) // 2
-            best = None
-            for first in ((1,) if st.first else (0, 1)):
-                for mask2 in range(1 << npair):
-                    if (mask2 & st.mask2) != st.mask2 or (mask2 and not first):
-                        continue
-                    d = _lib.MlpDesc(st.d, first, mask2, info["hidden"], info["layers"], info["act"], info["n_out"])
-                    if self.L.ndq_mlp_supported(ctypes.byref(d)):
-                        cost = first * st.d + bin(mask2).count("1")
-                        if best is None or cost < best[0]:
-                            best = (cost, d)
-            if best is None:
-                raise TraceUnsupported(f"no gfx950 kernel for FCNN d={st.d} hidden={info['hidden']} layers="
-                                       f"{info['layers']} streams(first={st.first}, mask2={st.mask2:#b})")
-            st.first, st.mask2 = best[1].first, best[1].mask2
-            self.descs[k] = best[1]
-
-        self.program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(self.nets), widen=widen)
+        self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val)
+        self.n_eq, self.n_funcs = len(self.program.residuals), len(self.program.funcs)
         self.kernel = codegen.load(self.program)
         self.flat = [FlatParams(n, self.device) for n in self.nets]
         self.ns = [self.program.streams[k].n_streams for k in range(len(self.nets))]
@@ -92,14 +103,29 @@ class FusedSystem:
         self.loss_buf = torch.zeros(64, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------------------------------ buffers
-    def buffers(self, n):
-        b = self._bufs.get(n)
+    def _resident_ld(self, batch):
+        """Leading dimension if ``batch`` is rows of ONE contiguous fp32 SoA block (ResidentBatchGenerator), else 0."""
+        if any(c.dtype != torch.float32 or not c.is_contiguous() for c in batch):
+            return 0
+        p0 = batch[0].data_ptr()
+        if len(batch) == 1:
+            return _round_up(batch[0].numel(), 64) if p0 % 16 == 0 else 0
+        step = batch[1].data_ptr() - p0
+        if step <= 0 or step % 4 or step // 4 < batch[0].numel():
+            return 0
+        if any(c.data_ptr() != p0 + i * step for i, c in enumerate(batch)):
+            return 0
+        return step // 4
+
+    def buffers(self, n, ld=None):
+        key = (n, ld)
+        b = self._bufs.get(key)
         if b is not None:
             return b
-        ld = _round_up(n, 64)
+        ld = ld or _round_up(n, 64)
         dev, f32 = self.device, torch.float32
         b = dict(ld=ld,
-                 coords=torch.zeros(self.n_coords, ld, dtype=f32, device=dev),
+                 coords_own=torch.zeros(self.n_coords, ld, dtype=f32, device=dev),
                  pinned=torch.zeros(self.n_coords, ld, dtype=f32).pin_memory(),
                  jets=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
                  gbar=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
@@ -111,7 +137,8 @@ class FusedSystem:
         b["partials"] = [torch.empty(nb, fp.numel, dtype=f32, device=dev) for nb, fp in zip(b["bwd_blocks"], self.flat)]
         b["jets_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["jets"]])
         b["gbar_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["gbar"]])
-        self._bufs[n] = b
+        b["coords"], b["coords_rows"] = b["coords_own"], None
+        self._bufs[key] = b
         return b
 
     def upload(self, batch, lo=0, hi=None):
@@ -119,18 +146,33 @@ class FusedSystem:
         n_all = batch[0].numel()
         hi = n_all if hi is None else hi
         n = hi - lo
+        if batch[0].device.type == "cuda" and lo == 0 and hi == n_all:
+            ld = self._resident_ld(batch)
+            if ld:
+                b = self.buffers(n, ld=ld)
+                b["coords"] = batch[0].reshape(-1)          # row 0 of the resident SoA block; rows are ld apart
+                b["coords_rows"] = [c.reshape(-1) for c in batch]
+                return b, n
         b = self.buffers(n)
+        b["coords"], b["coords_rows"] = b["coords_own"], None
         if batch[0].device.type == "cuda":
             for i, c in enumerate(batch):
-                b["coords"][i, :n].copy_(c.detach().reshape(-1)[lo:hi])
+                b["coords_own"][i, :n].copy_(c.detach().reshape(-1)[lo:hi])
         else:
             for i, c in enumerate(batch):
                 b["pinned"][i, :n].copy_(c.detach().reshape(-1)[lo:hi])
-            b["coords"].copy_(b["pinned"], non_blocking=True)
+            b["coords_own"].copy_(b["pinned"], non_blocking=True)
         return b, n
 
+    def _coord_ptr(self, b, row):
+        if b["coords_rows"] is not None:
+            return _c_vp(b["coords_rows"][row].data_ptr())
+        return _c_vp(b["coords_own"][row].data_ptr())
+
     def coord_columns(self, b, n):
-        return [b["coords"][i, :n].view(-1, 1) for i in range(self.n_coords)]
+        if b["coords_rows"] is not None:
+            return [c[:n].view(-1, 1) for c in b["coords_rows"]]
+        return [b["coords_own"][i, :n].view(-1, 1) for i in range(self.n_coords)]
 
     def func_columns(self, b, n):
         return [b["funcs"][i, :n].view(-1, 1) for i in range(self.n_funcs)]
@@ -139,13 +181,13 @@ class FusedSystem:
     def forward(self, b, n, stream):
         for k, fp in enumerate(self.flat):
             fp.sync()
-            rc = self.L.ndq_mlp_jet_fwd(ctypes.byref(self.descs[k]), _ptr(b["coords"][self.coord0[k]]), b["ld"], n,
+            rc = self.L.ndq_mlp_jet_fwd(ctypes.byref(self.descs[k]), self._coord_ptr(b, self.coord0[k]), b["ld"], n,
                                         _ptr(fp.flat), _ptr(b["jets"][k]), b["ld"], stream)
             _lib.check(rc, "ndq_mlp_jet_fwd")
 
     def pointwise(self, b, n, stream, train, n_global, want_funcs=False, want_resid=False):
         seed = 1.0 / (float(n_global) * self.n_eq)
-        rc = self.kernel.lib.ndq_pw_launch(_ptr(b["coords"]), b["ld"], n, b["jets_pp"],
+        rc = self.kernel.lib.ndq_pw_launch(self._coord_ptr(b, 0), b["ld"], n, b["jets_pp"],
                                            b["gbar_pp"] if train else None, b["ld"],
                                            _ptr(b["funcs"]) if want_funcs else None,
                                            _ptr(b["resid"]) if want_resid else None,
@@ -155,7 +197,7 @@ class FusedSystem:
 
     def backward(self, b, n, stream, accumulate):
         for k, fp in enumerate(self.flat):
-            rc = self.L.ndq_mlp_jet_bwd(ctypes.byref(self.descs[k]), _ptr(b["coords"][self.coord0[k]]), b["ld"], n,
+            rc = self.L.ndq_mlp_jet_bwd(ctypes.byref(self.descs[k]), self._coord_ptr(b, self.coord0[k]), b["ld"], n,
                                         _ptr(fp.flat), _ptr(b["gbar"][k]), b["ld"], _ptr(b["partials"][k]), stream)
             _lib.check(rc, "ndq_mlp_jet_bwd")
             rc = self.L.ndq_reduce_partials(_ptr(b["partials"][k]), b["bwd_blocks"][k], fp.numel, _ptr(fp.grad),

@@ -234,4 +234,38 @@ class SamplerGenerator(BaseGenerator):
         samples = self.generator.get_examples()
         if isinstance(samples, torch.Tensor):
             samples = [samples]
+        if samples[0].device.type == "cuda" and not samples[0].requires_grad:
+            return [s.reshape(-1, 1) for s in samples]       # resident batch: keep the views (zero-copy hand-off)
         return [s.reshape(-1, 1).detach().requires_grad_(True) for s in samples]
+
+
+class ResidentBatchGenerator(BaseGenerator):
+    """Pre-sampled batches kept resident in HBM as SoA blocks ``[n_batches][d][ld]`` and served round-robin.
+
+    New (no reference counterpart): it removes the host sampling + PCIe hand-off from a training step when the
+    points can be drawn ahead of time -- ``ResidentBatchGenerator.presample(gen, k, device)`` draws ``k`` batches from
+    any generator in the reference's RNG order (so they are the same points the reference would train on) and
+    uploads them once.  ``get_examples`` returns views into the current block; the fused engine recognises them and
+    reads the block in place (no copy)."""
+
+    def __init__(self, blocks, size):
+        super().__init__()
+        self.blocks, self.size, self._next = blocks, size, 0
+
+    @classmethod
+    def presample(cls, generator, n_batches, device, lo=0, hi=None):
+        draws = []
+        for _ in range(n_batches):
+            ex = generator.get_examples()
+            ex = [ex] if isinstance(ex, torch.Tensor) else list(ex)
+            draws.append(torch.stack([e.detach().reshape(-1)[lo:hi] for e in ex]))
+        n = draws[0].shape[1]
+        ld = (n + 63) // 64 * 64
+        blocks = torch.zeros(n_batches, draws[0].shape[0], ld, dtype=torch.float32, device=device)
+        blocks[:, :, :n] = torch.stack(draws).to(device)
+        return cls(blocks, n)
+
+    def get_examples(self):
+        blk = self.blocks[self._next % self.blocks.shape[0]]
+        self._next += 1
+        return tuple(blk[i, :self.size] for i in range(blk.shape[0]))

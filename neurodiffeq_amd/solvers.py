@@ -292,7 +292,8 @@ class BaseSolver(ABC):
             n_all = batch[0].shape[0]
             lo, hi = shard.bounds(n_all) if shard else (0, n_all)
             b, n = system.step(batch, train=(key == "train"), slot=batch_id, accumulate=(batch_id > 0),
-                               n_global=n_all, lo=lo, hi=hi, want_funcs=bool(self.metrics_fn))
+                               n_global=shard.global_n(n_all) if shard else n_all, lo=lo, hi=hi,
+                               want_funcs=bool(self.metrics_fn))
             if self.metrics_fn:
                 funcs, coords = system.func_columns(b, n), system.coord_columns(b, n)
                 for name, fn in self.metrics_fn.items():

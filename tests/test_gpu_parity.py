@@ -1,0 +1,316 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X).  Everything goes through the C-ABI of libndq.so /
+the generated pointwise kernels; the checker is the oracle (oracle/*.py) and the reference's golden vectors
+(tests/golden/*.npz).  Tolerance: rel-L2 <= 1e-5 against the fp64 reference (north_star).
+
+Each test also dumps its error figures into gpurun_out/diag/ so a failing run can be diagnosed from one call."""
+import ctypes
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import autograd_ref as R
+from oracle import jet_ref as J
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG = os.path.join(ROOT, "gpurun_out", "diag")
+TOL = 1e-5
+
+# name -> (dims, act name, act id, (d, first, mask2) of the config's stream set, streams in kernel order)
+ARCH = {
+    "c1": ((1, 32, 32, 1), "sin", 1, (1, 1, 0), [(), (0,)]),
+    "c2": ((2, 32, 32, 1), "tanh", 0, (2, 1, 5), [(), (0,), (1,), (0, 0), (1, 1)]),
+    "c2full": ((2, 32, 32, 1), "tanh", 0, (2, 1, 7), [(), (0,), (1,), (0, 0), (0, 1), (1, 1)]),
+    "c3": ((2, 64, 64, 64, 1), "tanh", 0, (2, 1, 1), [(), (0,), (1,), (0, 0)]),
+    "c5": ((2, 64, 64, 64, 1), "tanh", 0, (2, 1, 5), [(), (0,), (1,), (0, 0), (1, 1)]),
+    "c5p": ((2, 64, 64, 64, 1), "tanh", 0, (2, 1, 0), [(), (0,), (1,)]),
+    "c2val": ((2, 32, 32, 1), "tanh", 0, (2, 0, 0), [()]),
+}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8}
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def diag(name, payload):
+    os.makedirs(DIAG, exist_ok=True)
+    with open(os.path.join(DIAG, name + ".json"), "w") as fh:
+        json.dump(payload, fh, indent=1, default=float)
+
+
+@pytest.fixture(scope="module")
+def L():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from neurodiffeq_amd import _lib
+    return _lib.lib()
+
+
+def _desc(name):
+    from neurodiffeq_amd import _lib
+    dims, _, act, (d, first, mask2), _ = ARCH[name]
+    return _lib.MlpDesc(d, first, mask2, dims[1], len(dims) - 2, act, 1)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _params(name, rng, scale=1.0):
+    dims = ARCH[name][0]
+    parts = []
+    for a, b in zip(dims[:-1], dims[1:]):
+        k = 1.0 / np.sqrt(a)
+        parts += [rng.uniform(-k, k, a * b) * scale, rng.uniform(-k, k, b) * scale]
+    return np.concatenate(parts).astype(np.float32)
+
+
+def _fwd(L, name, coords, flat):
+    dims, _, _, _, streams = ARCH[name]
+    n = coords.shape[1]
+    ld = (n + 63) // 64 * 64
+    c = torch.zeros(dims[0], ld, device="cuda"); c[:, :n] = torch.from_numpy(coords)
+    p = torch.from_numpy(flat).cuda()
+    jets = torch.full((len(streams), ld), float("nan"), device="cuda")
+    d = _desc(name)
+    rc = L.ndq_mlp_jet_fwd(ctypes.byref(d), c.data_ptr(), ld, n, p.data_ptr(), jets.data_ptr(), ld, _stream())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return jets[:, :n].cpu().numpy()
+
+
+def _bwd(L, name, coords, flat, gbar):
+    dims, _, _, _, streams = ARCH[name]
+    n = coords.shape[1]
+    ld = (n + 63) // 64 * 64
+    c = torch.zeros(dims[0], ld, device="cuda"); c[:, :n] = torch.from_numpy(coords)
+    g = torch.zeros(len(streams), ld, device="cuda"); g[:, :n] = torch.from_numpy(gbar)
+    p = torch.from_numpy(flat).cuda()
+    d = _desc(name)
+    nb = L.ndq_mlp_bwd_blocks(ctypes.byref(d), n)
+    P = L.ndq_mlp_num_params(ctypes.byref(d))
+    assert P == flat.size
+    part = torch.full((nb, P), float("nan"), device="cuda")
+    out = torch.zeros(P, device="cuda")
+    rc = L.ndq_mlp_jet_bwd(ctypes.byref(d), c.data_ptr(), ld, n, p.data_ptr(), g.data_ptr(), ld, part.data_ptr(), _stream())
+    assert rc == 0, rc
+    rc = L.ndq_reduce_partials(part.data_ptr(), nb, P, out.data_ptr(), 0, 1.0, _stream())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _groups(name):
+    dims = ARCH[name][0]
+    out, off = [], 0
+    for li, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        out.append((f"W{li + 1}", off, off + a * b)); off += a * b
+        out.append((f"b{li + 1}", off, off + b)); off += b
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ MLP kernels
+@pytest.mark.parametrize("name", list(ARCH))
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4099])
+def test_mlp_jet_fwd_matches_jet_oracle(L, name, n):
+    dims, act, _, _, streams = ARCH[name]
+    rng = np.random.default_rng(zlib.crc32(f"{name}/{n}".encode()))
+    flat = _params(name, rng)
+    coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
+    got = _fwd(L, name, coords, flat)
+    want = J.mlp_jets(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)), streams)
+    errs = {str(m): rel_l2(got[s], want[m][:, 0]) for s, m in enumerate(streams)}
+    diag(f"fwd_{name}_{n}", errs)
+    assert np.isfinite(got).all()
+    assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("name", [k for k in ARCH if k != "c2val"] + ["c2val"])
+@pytest.mark.parametrize("n", [1, 17, 1000, 4099])
+def test_mlp_jet_bwd_matches_jet_oracle(L, name, n):
+    dims, act, _, _, streams = ARCH[name]
+    rng = np.random.default_rng(zlib.crc32(f"{name}/{n}/b".encode()))
+    flat = _params(name, rng)
+    coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
+    gbar = rng.standard_normal((len(streams), n)).astype(np.float32)
+    got = _bwd(L, name, coords, flat, gbar)
+    want = J.mlp_jets_vjp(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)),
+                          {m: gbar[s].astype(np.float64)[:, None] for s, m in enumerate(streams)})
+    errs = {g: rel_l2(got[a:b], want[a:b]) for g, a, b in _groups(name)}
+    errs["all"] = rel_l2(got, want)
+    diag(f"bwd_{name}_{n}", errs)
+    assert np.isfinite(got).all()
+    assert errs["all"] < TOL, errs
+
+
+def test_bwd_is_linear_in_gbar_and_deterministic(L):
+    """Size-independent properties at the full C2 size (65 536 points): linearity of the adjoint in its seed,
+    run-to-run bit-exactness (fixed-order reductions, no float atomics), shard additivity."""
+    name, n = "c2", 65536
+    dims, act, _, _, streams = ARCH[name]
+    rng = np.random.default_rng(5)
+    flat = _params(name, rng)
+    coords = rng.uniform(0, 1, (2, n)).astype(np.float32)
+    g1 = rng.standard_normal((len(streams), n)).astype(np.float32)
+    g2 = rng.standard_normal((len(streams), n)).astype(np.float32)
+    a, b = _bwd(L, name, coords, flat, g1), _bwd(L, name, coords, flat, g2)
+    ab = _bwd(L, name, coords, flat, (2.0 * g1 - 0.5 * g2).astype(np.float32))
+    again = _bwd(L, name, coords, flat, g1)
+    h = n // 2
+    halves = _bwd(L, name, coords[:, :h], flat, g1[:, :h]) + _bwd(L, name, coords[:, h:], flat, g1[:, h:])
+    res = dict(linearity=rel_l2(ab, 2.0 * a - 0.5 * b), shard_additivity=rel_l2(halves, a),
+               bit_exact_rerun=bool(np.array_equal(a, again)))
+    diag("bwd_properties_c2_full", res)
+    assert res["bit_exact_rerun"]
+    assert res["linearity"] < 5e-6 and res["shard_additivity"] < 5e-6, res
+
+
+def test_bad_arguments_are_rejected(L):
+    from neurodiffeq_amd import _lib
+    d = _desc("c2")
+    t = torch.zeros(64, device="cuda")
+    assert L.ndq_mlp_jet_fwd(ctypes.byref(d), t.data_ptr(), 64, 0, t.data_ptr(), t.data_ptr(), 64, _stream()) == -2
+    assert L.ndq_mlp_jet_fwd(ctypes.byref(d), t.data_ptr(), 8, 16, t.data_ptr(), t.data_ptr(), 64, _stream()) == -2
+    bad = _lib.MlpDesc(2, 1, 5, 40, 2, 0, 1)
+    assert L.ndq_mlp_supported(ctypes.byref(bad)) == 0
+    assert L.ndq_mlp_jet_fwd(ctypes.byref(bad), t.data_ptr(), 64, 16, t.data_ptr(), t.data_ptr(), 64, _stream()) == -1
+
+
+# ------------------------------------------------------------------------------------------------ reduce / adam
+def test_reduce_partials(L):
+    rng = np.random.default_rng(0)
+    for nparts, length in [(1, 1), (3, 7), (512, 1185), (257, 8577)]:
+        part = rng.standard_normal((nparts, length)).astype(np.float32)
+        base = rng.standard_normal(length).astype(np.float32)
+        p, o = torch.from_numpy(part).cuda(), torch.from_numpy(base).cuda()
+        assert L.ndq_reduce_partials(p.data_ptr(), nparts, length, o.data_ptr(), 1, 0.5, _stream()) == 0
+        torch.cuda.synchronize()
+        want = base.astype(np.float64) + 0.5 * part.astype(np.float64).sum(0)
+        assert rel_l2(o.cpu().numpy(), want) < 1e-6
+
+
+def test_adam_step_matches_torch(L):
+    rng = np.random.default_rng(1)
+    n = 1185
+    p0 = rng.standard_normal(n).astype(np.float32)
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = torch.from_numpy(p0.copy()).cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        g = rng.standard_normal(n).astype(np.float32)
+        ref.grad = torch.from_numpy(g.copy())
+        opt.step()
+        gg = torch.from_numpy(g).cuda()
+        assert L.ndq_adam_step(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 0.0,
+                               step, _stream()) == 0
+    torch.cuda.synchronize()
+    assert rel_l2(p.cpu().numpy(), ref.detach().numpy()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ whole closure
+def _load_system(name, size):
+    from tests import configs
+    from neurodiffeq_amd.engine import FusedSystem
+    torch.manual_seed(0)
+    cfg = configs.make(name, size)
+    for net in cfg["nets"]:
+        net.to("cuda")
+    n_coords = 1 if cfg["kind"] == "1d" else 2
+    return cfg, FusedSystem(cfg["nets"], cfg["conds"], cfg["pde"], n_coords, "cuda")
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
+def test_fused_closure_matches_reference_golden(golden_dir, name):
+    """funcs / residuals / loss / flat gradient of ONE closure (solvers.py:369-395) on the reference's own inputs."""
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    cfg, system = _load_system(name, SIZES[name])
+    R.set_flat(cfg["nets"], gold["params0"])
+    coords = [torch.from_numpy(c) for c in gold["coords"]]
+    b, n = system.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    funcs = b["funcs"][:, :n].T.cpu().numpy()
+    resid = b["resid"][:, :n].T.cpu().numpy()
+    loss = float(system.loss_buf[0].item())
+    grad = np.concatenate([fp.grad.cpu().numpy() for fp in system.flat])
+    errs = dict(funcs=rel_l2(funcs, gold["funcs_f64"]), residuals=rel_l2(resid, gold["residuals_f64"]),
+                loss=abs(loss - float(gold["loss_f64"])) / abs(float(gold["loss_f64"])),
+                grad=rel_l2(grad, gold["grad_f64"]))
+    off = 0
+    for k, fp in enumerate(system.flat):
+        errs[f"grad_net{k}"] = rel_l2(grad[off:off + fp.numel], gold["grad_f64"][off:off + fp.numel])
+        off += fp.numel
+    diag(f"closure_{name}", errs)
+    assert max(errs["funcs"], errs["residuals"], errs["loss"], errs["grad"]) < TOL, errs
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3"])
+def test_solver_trajectory_matches_reference_golden(golden_dir, name):
+    """Three epochs of Solver.run_train_epoch (sampling on the CPU RNG, fused step, fused Adam) against the
+    reference solver's loss history and final parameters."""
+    from tests import configs
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    solver, cfg = configs.make_solver(name, SIZES[name])
+    solver.fused = "require"
+    assert np.array_equal(R.get_flat(cfg["nets"]).cpu().numpy(), gold["params0"])
+    torch.manual_seed(int(gold["seed"]) + 2)
+    for _ in range(3):
+        solver.run_train_epoch()
+    assert solver.fused_active
+    hist = np.array(solver.metrics_history["train_loss"])
+    params = R.get_flat(cfg["nets"]).cpu().numpy()
+    errs = dict(loss=float(np.max(np.abs(hist - gold["traj_loss"]) / np.abs(gold["traj_loss"]))),
+                params=rel_l2(params, gold["traj_params"]))
+    diag(f"trajectory_{name}", dict(errs, hist=hist.tolist(), want=gold["traj_loss"].tolist()))
+    assert errs["loss"] < 2e-5 and errs["params"] < 1e-5, errs
+
+
+@pytest.mark.parametrize("name,size", [("c2", 256), ("c3", 96), ("c1", 1024)])
+def test_fused_closure_matches_oracle_at_size(name, size):
+    """Full-size C2 (65 536 points) and larger C1/C3 batches against the autograd oracle in fp64."""
+    cfg, system = _load_system(name, size)
+    torch.manual_seed(0)
+    ocfg = R.build_config(name, size, dtype=torch.float64)
+    flat = R.get_flat(cfg["nets"]).cpu()
+    R.set_flat(ocfg["nets"], flat.double())
+    torch.manual_seed(3)
+    coords = [c.detach() for c in cfg["gen"].get_examples()] if cfg["kind"] != "1d" else [cfg["gen"].get_examples().detach()]
+    out = R.closure(ocfg["nets"], ocfg["enforcers"], ocfg["pde"], [c.double() for c in coords])
+    want_grad = R.get_flat_grad(ocfg["nets"]).numpy()
+    b, n = system.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), out["funcs"].numpy()),
+                residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy(), out["residuals"].numpy()),
+                loss=abs(system.loss_buf[0].item() - out["loss"].item()) / abs(out["loss"].item()),
+                grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in system.flat]), want_grad))
+    diag(f"closure_full_{name}_{size}", errs)
+    assert max(errs.values()) < TOL, errs
+
+
+def test_gradient_accumulation_and_validation_mode():
+    """n_batches_train = 2 accumulates gradients before one step (solvers.py:360-419); a validation epoch leaves
+    parameters and gradients untouched."""
+    from tests import configs
+    torch.manual_seed(0)
+    solver, cfg = configs.make_solver("c2", 16, n_batches_train=2, n_batches_valid=1)
+    solver.fused = "require"
+    torch.manual_seed(0)
+    ocfg = R.build_config("c2", 16)
+    loop = R.TrainLoop(ocfg["nets"], ocfg["enforcers"], ocfg["pde"], ocfg["sampler"], n_batches=2)
+    torch.manual_seed(7)
+    loop.epoch()
+    torch.manual_seed(7)
+    solver.run_train_epoch()
+    before = R.get_flat(cfg["nets"]).cpu().numpy().copy()
+    solver.run_valid_epoch()
+    assert np.array_equal(before, R.get_flat(cfg["nets"]).cpu().numpy())
+    assert len(solver.metrics_history["valid_loss"]) == 1
+    assert abs(solver.metrics_history["train_loss"][0] - loop.history[0]) <= 2e-5 * abs(loop.history[0])
+    assert rel_l2(before, R.get_flat(ocfg["nets"]).numpy()) < 1e-5

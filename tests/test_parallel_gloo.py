@@ -1,0 +1,72 @@
+"""world_size-2 gloo test (CPU) of the data-parallel contract: shard bounds, GLOBAL-N normalisation and the single
+fused all-reduce reproduce the unsharded loss and gradient.  Per-shard compute here is the oracle closure (tests
+only) standing in for the HIP kernels, which have their own parity tests."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from neurodiffeq_amd.parallel import BatchSharding
+
+
+class _FP:
+    def __init__(self, g):
+        self.grad = g
+
+
+class _System:
+    def __init__(self, grads, n_slots):
+        self.flat = [_FP(g) for g in grads]
+        self.loss_buf = torch.zeros(n_slots, dtype=torch.float32)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import autograd_ref as R
+    torch.manual_seed(0)
+    cfg = R.build_config("c2", 12)
+    torch.manual_seed(1)
+    coords = cfg["sampler"]()
+    n = coords[0].numel()
+    sh = BatchSharding()
+    lo, hi = sh.bounds(n)
+    # shard closure with GLOBAL normalisation: loss_shard = sum r^2 / (N * n_eq)
+    batch = [c[lo:hi].reshape(-1, 1).requires_grad_(True) for c in coords]
+    funcs = [e(net, *batch) for net, e in zip(cfg["nets"], cfg["enforcers"])]
+    res = torch.cat(cfg["pde"](*funcs, *batch), dim=1)
+    loss = (res ** 2).sum() / (n * res.shape[1])
+    loss.backward()
+    sys_ = _System([R.get_flat_grad(cfg["nets"]).clone()], 1)
+    sys_.loss_buf[0] = loss.detach()
+    sh.all_reduce(sys_, 1, train=True)
+    if rank == 0:
+        for net in cfg["nets"]:
+            net.zero_grad()
+        full = R.closure(cfg["nets"], cfg["enforcers"], cfg["pde"], coords)
+        np.savez(out, grad=sys_.flat[0].grad.numpy(), loss=sys_.loss_buf.numpy(),
+                 grad_full=R.get_flat_grad(cfg["nets"]).numpy(), loss_full=full["loss"].numpy(), bounds=np.array([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_all_reduce_equals_unsharded(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r = np.load(out)
+    assert np.allclose(r["loss"][0], r["loss_full"], rtol=1e-5)
+    assert np.linalg.norm(r["grad"] - r["grad_full"]) <= 1e-5 * np.linalg.norm(r["grad_full"])
+
+
+def test_bounds_partition():
+    for n in (1, 7, 64, 65536, 1000):
+        for world in (1, 2, 3, 8):
+            edges = [BatchSharding(rank=r, world_size=world).bounds(n) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges[:-1], edges[1:]))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
