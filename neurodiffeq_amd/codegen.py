@@ -221,10 +221,89 @@ class PointwiseProgram:
             L.append(f"  g[{idx}] = {'b%d' % i if (i in terms and i in res_set) else '0.0f'};")
         return "\n".join(L)
 
+    def point_fn_source(self):
+        nc = self.n_coords
+        body = self._emit_point_fn()
+        return f"""NDQ_PW_INLINE void ndq_pw_point(const float* c, const float* s, float seed, int want_adj, float* r, float* f, float* g) {{
+{chr(10).join(f"  const float c{i} = c[{i}];" for i in range(nc))}
+{body}
+}}
+"""
+
+    def fused_source(self, desc):
+        """Source of the single-network fused closure kernel (csrc/ndq_mlp.h: fused_closure_kernel) specialised with
+        this program's per-point function.  desc: the network's ndq_mlp_desc."""
+        assert self.n_nets == 1 and tuple(self.streams[0].deps) == tuple(range(self.n_coords))
+        st = self.streams[0]
+        ns = st.n_streams
+        nsym = max(len(self.symbols), 1)
+        loads, stores = [], []
+        used = {}
+        for idx, i in enumerate(self.symbols):
+            _, loc = self.sym_location(i)
+            used[loc] = idx
+            loads.append(f"    s[{idx}] = jets[{loc}];")
+        for loc in range(ns):
+            stores.append(f"    gj[{loc}] = {'g[%d]' % used[loc] if loc in used else '0.0f'};")
+        header = os.path.join(HERE, "csrc", "ndq_mlp.h")
+        neq, nf = len(self.residuals), len(self.funcs)
+        return f"""// GENERATED by neurodiffeq_amd/codegen.py -- fused closure kernel (forward streams + pointwise stage + reverse pass)
+// of one single-network PDE system, gfx950.
+#include "{header}"
+#define NDQ_PW_INLINE __device__ __forceinline__
+{self.point_fn_source()}
+namespace {{
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}>;
+struct PW {{
+  static constexpr int NEQ = {neq}, NF = {nf};
+  static __device__ __forceinline__ void apply(const float (&x)[CFG::D], const float (&jets)[CFG::NS], float seed,
+                                               int want_adj, float (&r)[{max(neq, 1)}], float (&f)[{max(nf, 1)}],
+                                               float (&gj)[CFG::NS]) {{
+    float s[{nsym}], g[{nsym}];
+{chr(10).join(loads)}
+    ndq_pw_point(x, s, seed, want_adj, r, f, g);
+{chr(10).join(stores)}
+  }}
+}};
+constexpr int kWaves = CFG::BWD_THREADS / 64;
+int fused_blocks(int n) {{
+  const int tiles = (n + 15) / 16;
+  int b = (tiles + kWaves - 1) / kWaves;
+  return b > 256 ? 256 : (b < 1 ? 1 : b);
+}}
+}}  // namespace
+
+extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
+extern "C" int ndq_fused_num_params() {{ return CFG::P; }}
+
+extern "C" int ndq_fused_launch(const float* coords, int ldc, int n, const float* params, float* partials,
+                                float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,
+                                void* stream) {{
+  if (!coords || !params || !loss_partials || n <= 0 || ldc < n || (train && !partials)) return -2;
+  ndq::FusedArgs a;
+  a.coords = coords; a.params = params; a.partials = partials; a.loss_partials = loss_partials;
+  a.funcs = funcs; a.resid = resid; a.n = n; a.ldc = ldc; a.ldj = ldj; a.seed = seed;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr = false;
+  if (!attr) {{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ndq::fused_closure_kernel<CFG, PW, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ndq::fused_lds_bytes<CFG>(true));
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }}
+  if (train)
+    hipLaunchKernelGGL((ndq::fused_closure_kernel<CFG, PW, true>), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS),
+                       ndq::fused_lds_bytes<CFG>(true), s, a);
+  else
+    hipLaunchKernelGGL((ndq::fused_closure_kernel<CFG, PW, false>), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS),
+                       ndq::fused_lds_bytes<CFG>(false), s, a);
+  return (int)hipGetLastError();
+}}
+"""
+
     def _emit(self):
         nsym = max(len(self.symbols), 1)
         neq, nf, nc, nn = len(self.residuals), len(self.funcs), self.n_coords, self.n_nets
-        body = self._emit_point_fn()
         loads, stores = [], []
         for idx, i in enumerate(self.symbols):
             k, loc = self.sym_location(i)
@@ -256,11 +335,7 @@ class PointwiseProgram:
 #define NDQ_PW_NF {nf}
 #define NDQ_PW_NNETS {nn}
 
-NDQ_PW_INLINE void ndq_pw_point(const float* c, const float* s, float seed, int want_adj, float* r, float* f, float* g) {{
-{chr(10).join(f"  const float c{i} = c[{i}];" for i in range(nc))}
-{body}
-}}
-
+{self.point_fn_source()}
 #ifdef __HIPCC__
 struct PwArgs {{
   const float* coords;
@@ -376,3 +451,49 @@ def build(program: PointwiseProgram, force=False):
 
 def load(program: PointwiseProgram):
     return PointwiseKernel(build(program))
+
+
+# ----------------------------------------------------------------------------------------------- fused closure kernel
+class FusedKernel:
+    def __init__(self, so_path):
+        self.path = so_path
+        self.lib = ctypes.CDLL(so_path)
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        self.lib.ndq_fused_launch.restype = ci
+        self.lib.ndq_fused_launch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
+        self.lib.ndq_fused_blocks.restype = ci
+        self.lib.ndq_fused_blocks.argtypes = [ci]
+        self.lib.ndq_fused_num_params.restype = ci
+
+    def blocks(self, n):
+        return self.lib.ndq_fused_blocks(n)
+
+
+def _header_digest():
+    with open(os.path.join(HERE, "csrc", "ndq_mlp.h"), "rb") as fh:
+        return hashlib.sha1(fh.read()).hexdigest()
+
+
+def build_fused(program: PointwiseProgram, desc, force=False):
+    """Compile the fused closure kernel of a single-network system for gfx950 (in-tree cache keyed by the generated
+    source AND the kernel header it instantiates)."""
+    os.makedirs(JIT_DIR, exist_ok=True)
+    source = program.fused_source(desc)
+    key = hashlib.sha1((source + _header_digest()).encode()).hexdigest()[:16]
+    so = os.path.join(JIT_DIR, f"fused_{key}.so")
+    src = os.path.join(JIT_DIR, f"fused_{key}.hip")
+    if os.path.exists(so) and not force:
+        return so
+    with open(src, "w") as fh:
+        fh.write(source)
+    tmp = so + f".tmp{os.getpid()}"
+    proc = subprocess.run([HIPCC] + HIPCC_FLAGS + [src, "-o", tmp], capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed for generated fused kernel {src}:\n{proc.stderr[-4000:]}")
+    os.replace(tmp, so)
+    return so
+
+
+def can_fuse(program: PointwiseProgram):
+    return program.n_nets == 1 and 0 in program.streams and \
+        tuple(program.streams[0].deps) == tuple(range(program.n_coords))

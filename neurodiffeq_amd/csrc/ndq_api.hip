@@ -30,14 +30,18 @@ namespace ndq {
 
 struct Entry {
   int d, first, mask2, nb, layers, act;
-  int ns, p;
+  int ns, p, bwd_waves;
   int (*fwd)(const MlpArgs&, hipStream_t);
   int (*bwd)(const MlpArgs&, int blocks, hipStream_t);
   size_t fwd_lds, bwd_lds;
 };
 
-constexpr int kThreads = 256;
-constexpr int kWaves = kThreads / 64;
+#ifndef NDQ_FWD_MAX_BLOCKS
+#define NDQ_FWD_MAX_BLOCKS 768   // persistent-style grid: up to 3 workgroups per CU, waves loop over tiles
+#endif
+#ifndef NDQ_BWD_MAX_BLOCKS
+#define NDQ_BWD_MAX_BLOCKS 256   // one workgroup per CU; every wave amortises its epilogue over several tiles
+#endif
 
 template <class C>
 int launch_fwd(const MlpArgs& a, hipStream_t s) {
@@ -49,32 +53,34 @@ int launch_fwd(const MlpArgs& a, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
+  constexpr int waves = C::FWD_THREADS / 64;
   const int tiles = (a.n + 15) / 16;
-  int blocks = (tiles + kWaves - 1) / kWaves;
-  if (blocks > 2048) blocks = 2048;
+  int blocks = (tiles + waves - 1) / waves;
+  if (blocks > NDQ_FWD_MAX_BLOCKS) blocks = NDQ_FWD_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(mlp_jet_fwd_kernel<C>, dim3(blocks), dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL(mlp_jet_fwd_kernel<C>, dim3(blocks), dim3(C::FWD_THREADS), lds, s, a);
   return (int)hipGetLastError();
 }
 
 template <class C>
 int launch_bwd(const MlpArgs& a, int blocks, hipStream_t s) {
   static bool attr = false;
-  const size_t lds = bwd_lds_bytes<C>(kWaves);
+  const size_t lds = bwd_lds_bytes<C>(C::BWD_THREADS / 64);
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_jet_bwd_kernel<C>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(mlp_jet_bwd_kernel<C>, dim3(blocks), dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL(mlp_jet_bwd_kernel<C>, dim3(blocks), dim3(C::BWD_THREADS), lds, s, a);
   return (int)hipGetLastError();
 }
 
 #define NDQ_ENTRY(D, F, M, NB, L, A)                                                                      \
   Entry{D, F, M, NB, L, A, Cfg<D, F, M, NB, L, A>::NS, Cfg<D, F, M, NB, L, A>::P,                         \
+        Cfg<D, F, M, NB, L, A>::BWD_THREADS / 64,                                                         \
         &launch_fwd<Cfg<D, F, M, NB, L, A>>, &launch_bwd<Cfg<D, F, M, NB, L, A>>,                         \
-        fwd_lds_bytes<Cfg<D, F, M, NB, L, A>>(), bwd_lds_bytes<Cfg<D, F, M, NB, L, A>>(kWaves)},
+        fwd_lds_bytes<Cfg<D, F, M, NB, L, A>>(), bwd_lds_bytes<Cfg<D, F, M, NB, L, A>>(Cfg<D, F, M, NB, L, A>::BWD_THREADS / 64)},
 
 static const Entry kTable[] = {NDQ_CFG_TABLE(NDQ_ENTRY)};
 
@@ -87,10 +93,10 @@ static const Entry* find(const ndq_mlp_desc* d) {
   return nullptr;
 }
 
-static int bwd_blocks(int n) {
+static int bwd_blocks(const Entry* e, int n) {
   const int tiles = (n + 15) / 16;
-  int blocks = (tiles + kWaves - 1) / kWaves;
-  if (blocks > 512) blocks = 512;  // <= 2 workgroups per CU: each wave amortises its epilogue over several tiles
+  int blocks = (tiles + e->bwd_waves - 1) / e->bwd_waves;
+  if (blocks > NDQ_BWD_MAX_BLOCKS) blocks = NDQ_BWD_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
   return blocks;
 }
@@ -156,7 +162,7 @@ int ndq_mlp_bwd_blocks(const ndq_mlp_desc* desc, int n) {
   const Entry* e = find(desc);
   if (!e) return NDQ_EUNSUPPORTED;
   if (n <= 0) return NDQ_EINVAL;
-  return bwd_blocks(n);
+  return bwd_blocks(e, n);
 }
 
 int ndq_mlp_jet_fwd(const ndq_mlp_desc* desc, const float* coords, int ldc, int n, const float* params, float* jets,
@@ -176,7 +182,7 @@ int ndq_mlp_jet_bwd(const ndq_mlp_desc* desc, const float* coords, int ldc, int 
   if (!coords || !params || !gbar || !partials || n <= 0 || ldc < n || ldj < n) return NDQ_EINVAL;
   MlpArgs a{};
   a.coords = coords; a.params = params; a.gbar = gbar; a.partials = partials; a.n = n; a.ldc = ldc; a.ldj = ldj;
-  return e->bwd(a, bwd_blocks(n), static_cast<hipStream_t>(stream));
+  return e->bwd(a, bwd_blocks(e, n), static_cast<hipStream_t>(stream));
 }
 
 int ndq_reduce_partials(const float* partials, int nparts, int len, float* out, int accumulate, float scale,

@@ -94,9 +94,34 @@ struct Streams {
 // state kept per hidden unit: t = sigma(z) and c (only where sigma' is not a function of t).
 enum { ACT_TANH = 0, ACT_SIN = 1 };
 
+#ifndef NDQ_FAST_TANH
+#define NDQ_FAST_TANH 1
+#endif
+#ifndef NDQ_BWD_THREADS
+#define NDQ_BWD_THREADS 512
+#endif
+#ifndef NDQ_FWD_THREADS
+#define NDQ_FWD_THREADS 256
+#endif
+
+// tanh z = 1 - 2 / (2^(2 z log2 e) + 1): one v_exp_f32 + one v_rcp_f32 (both ~1 ulp).  Absolute error <= ~1.5e-7
+// over the whole range (saturates correctly: e -> inf gives 1, e -> 0 gives -1); the libm tanhf costs ~10x the
+// VALU issue slots, and the VALU is what competes with the MFMA pipe in these kernels.
+__device__ __forceinline__ float tanh_fast(float z) {
+  const float e = __builtin_amdgcn_exp2f(z * 2.88539008177792681472f);
+  return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+}
+
 template <int ACT> struct Act;
 template <> struct Act<ACT_TANH> {  // nn.Tanh, networks.py:27 default
-  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { t = tanhf(z); c = 0.f; }
+  static __device__ __forceinline__ void fwd(float z, float& t, float& c) {
+#if NDQ_FAST_TANH
+    t = tanh_fast(z);
+#else
+    t = tanhf(z);
+#endif
+    c = 0.f;
+  }
   static __device__ __forceinline__ float s1(float t, float) { return fmaf(-t, t, 1.f); }
   static __device__ __forceinline__ float s2(float t, float, float s1v) { return -2.f * t * s1v; }
   static __device__ __forceinline__ float s3(float t, float, float s1v) { return -2.f * s1v * fmaf(-3.f * t, t, 1.f); }
@@ -114,6 +139,10 @@ struct Cfg {
   using SS = Streams<D_, FIRST_, M2_>;
   static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
   static constexpr int HP = H + 4;  // padded leading dimension of the transpose staging tiles
+  // workgroup sizes: 8 waves (2 per SIMD, <= 256 registers each) when the per-wave state fits, else 4 waves with the
+  // whole 512-entry register file per wave
+  static constexpr int BWD_THREADS = (NB_ * NB_ * (L_ - 1) + NB_ * SS::NS * L_ > 40) ? 256 : NDQ_BWD_THREADS;
+  static constexpr int FWD_THREADS = (NB_ >= 4) ? 256 : NDQ_FWD_THREADS;
   // flat parameter offsets, torch order: W1 (H,D) b1 (H) | W_l (H,H) b_l (H), l = 2..L | Wout (1,H) bout (1)
   static constexpr int offW1 = 0, offb1 = H * D;
   static constexpr int offW(int l) { return H * D + H + (l - 2) * (H * H + H); }  // l in 2..L
@@ -339,7 +368,7 @@ __device__ __forceinline__ float point_sum(float v) {  // sum over the 16 points
 
 // ------------------------------------------------------------------------------------------------ forward kernel
 template <class C>
-__global__ __launch_bounds__(256) void mlp_jet_fwd_kernel(MlpArgs a) {
+__global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_weights<C, false>(lds, a.params);
   __syncthreads();
@@ -383,6 +412,16 @@ __global__ __launch_bounds__(256) void mlp_jet_fwd_kernel(MlpArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward kernel
+// number of per-wave LDS reduction regions that fit next to the weights (workgroup LDS budget 160 KiB - margin)
+template <class C>
+constexpr int bwd_regions(int waves) {
+  const int pp = (C::P + 3) & ~3;
+  const int budget = 38 * 1024 - C::ldsWeightsEnd(true);   // floats
+  int r = budget / pp;
+  if (r < 1) r = 1;
+  return r > waves ? waves : r;
+}
+
 // per-wave gradient accumulators (registers), summed over all tiles the wave processes
 template <class C>
 struct GradAcc {
@@ -435,18 +474,7 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
 }
 
 template <class C>
-__global__ __launch_bounds__(256) void mlp_jet_bwd_kernel(MlpArgs a) {
-  using SS = typename C::SS;
-  using A = Act<C::ACT>;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_weights<C, true>(lds, a.params);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
-  const int wavesPerBlock = blockDim.x >> 6;
-  const int ntiles = (a.n + 15) >> 4;
-  float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
-
-  GradAcc<C> acc;
+__device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
 #pragma unroll
   for (int b = 0; b < C::NB; ++b)
 #pragma unroll
@@ -465,85 +493,111 @@ __global__ __launch_bounds__(256) void mlp_jet_bwd_kernel(MlpArgs a) {
 #pragma unroll
       for (int kb = 0; kb < C::NB; ++kb) acc.w[l][jb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
   acc.bout = 0.f;
+}
 
-  for (int tile = blockIdx.x * wavesPerBlock + wave; tile < ntiles; tile += gridDim.x * wavesPerBlock) {
-    const int n = tile * 16 + p;
-    const bool valid = n < a.n;
-    const int nn = valid ? n : a.n - 1;
-    float x[C::D], gout[C::NS];
-#pragma unroll
-    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
-#pragma unroll
-    for (int s = 0; s < C::NS; ++s) gout[s] = valid ? a.gbar[(size_t)s * a.ldj + nn] : 0.f;
+// forward pass of one tile keeping every layer's state; h = streams of the last hidden layer's activations
+template <class C, bool BWD>
+__device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, const float (&x)[C::D],
+                                             LayerState<C> (&st)[C::L], f32x4 (&h)[C::NS][C::NB]) {
+  first_layer<C, BWD>(lds, q, x, st[0]);
+  sfor<C::L - 1>([&](auto li_) {
+    constexpr int li = decltype(li_)::value;  // computes layer l = li + 2 from layer li + 1
+    act_forward<C>(st[li], h);
+    hidden_layer<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
+  });
+  act_forward<C>(st[C::L - 1], h);
+}
 
-    // ---------------- forward recompute, keeping every layer's state
-    LayerState<C> st[C::L];
-    first_layer<C, true>(lds, q, x, st[0]);
-    f32x4 h[C::NS][C::NB];
-    sfor<C::L - 1>([&](auto li_) {
-      constexpr int li = decltype(li_)::value;  // computes layer l = li + 2 from layer li + 1
-      act_forward<C>(st[li], h);
-      hidden_layer<C, true>(lds, li + 2, lane, q, h, st[li + 1]);
-    });
-    act_forward<C>(st[C::L - 1], h);  // h_L streams
+// output layer (n_out = 1) on the VALU: out[s] = Wout . h[s] (+ bout on the value stream), identical in all 4 lane groups
+template <class C, bool BWD>
+__device__ __forceinline__ void tile_output(const float* lds, int q, const f32x4 (&h)[C::NS][C::NB], float (&out)[C::NS]) {
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) out[s] = 0.f;
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b) {
+    const f32x4 wo = lds4(lds + C::ldsWout(BWD) + 16 * b + 4 * q);
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[s] = fmaf(wo[r], h[s][b][r], out[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) out[s] = quad_sum(out[s]);
+  out[0] += lds[C::ldsbout(BWD)];
+}
 
-    // ---------------- output layer adjoint (n_out = 1): hbar = Wout * gout; dWout += sum_s gout_s h_s; dbout += gout_0
-    f32x4 g[C::NS][C::NB];
+// reverse pass of one tile: gout[s] = dLoss/d out[s] for the tile's points (0 for padding lanes)
+template <class C>
+__device__ __forceinline__ void tile_backward(const float* lds, float* stage, int lane, int p, int q,
+                                              const float (&x)[C::D], const float (&gout)[C::NS],
+                                              LayerState<C> (&st)[C::L], f32x4 (&h)[C::NS][C::NB], GradAcc<C>& acc) {
+  using SS = typename C::SS;
+  // ---------------- output layer adjoint (n_out = 1): hbar = Wout * gout; dWout += sum_s gout_s h_s; dbout += gout_0
+  f32x4 g[C::NS][C::NB];
 #pragma unroll
-    for (int b = 0; b < C::NB; ++b) {
-      const f32x4 wo = lds4(lds + C::ldsWout(true) + 16 * b + 4 * q);
+  for (int b = 0; b < C::NB; ++b) {
+    const f32x4 wo = lds4(lds + C::ldsWout(true) + 16 * b + 4 * q);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float dw = 0.f;
+    for (int r = 0; r < 4; ++r) {
+      float dw = 0.f;
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) {
-          g[s][b][r] = wo[r] * gout[s];
-          dw = fmaf(gout[s], h[s][b][r], dw);
-        }
-        acc.wout[b][r] += dw;
+      for (int s = 0; s < C::NS; ++s) {
+        g[s][b][r] = wo[r] * gout[s];
+        dw = fmaf(gout[s], h[s][b][r], dw);
       }
+      acc.wout[b][r] += dw;
     }
-    acc.bout += (q == 0) ? gout[0] : 0.f;
+  }
+  acc.bout += (q == 0) ? gout[0] : 0.f;
 
-    // ---------------- hidden layers L .. 2
-    sfor<C::L - 1>([&](auto k_) {
-      constexpr int l = C::L - decltype(k_)::value;          // layer whose weights W_l (H x H) map h_{l-1} -> z_l
-      constexpr int li = l - 1;             // state index of layer l
-      act_backward<C>(st[li], g);           // g: hbar_l -> zbar_l
-#pragma unroll
-      for (int b = 0; b < C::NB; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc.b[l - 2][b][r] += g[0][b][r];
-      act_forward<C>(st[li - 1], h);        // h_{l-1} streams (inputs of layer l)
-      weight_grad<C>(stage, lane, p, q, g, h, acc.w[l - 2]);
-      f32x4 hb[C::NS][C::NB];
-      zero_frag<C>(hb);
-      gemm_frag<C>(lds + C::ldsWt(l), lane, g, hb);   // hbar_{l-1} = W_l^T zbar_l
-#pragma unroll
-      for (int s = 0; s < C::NS; ++s)
-#pragma unroll
-        for (int b = 0; b < C::NB; ++b) g[s][b] = hb[s][b];
-    });
-
-    // ---------------- first layer: z_a = W1[:,a] (constant), z_ab = 0
-    act_backward<C>(st[0], g);  // g[0] = zbar, g[1+a] = zbar_a
+  // ---------------- hidden layers L .. 2
+  sfor<C::L - 1>([&](auto k_) {
+    constexpr int l = C::L - decltype(k_)::value;          // layer whose weights W_l (H x H) map h_{l-1} -> z_l
+    constexpr int li = l - 1;             // state index of layer l
+    act_backward<C>(st[li], g);           // g: hbar_l -> zbar_l
 #pragma unroll
     for (int b = 0; b < C::NB; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float z0 = g[0][b][r];
-        acc.b1[b][r] += z0;
+      for (int r = 0; r < 4; ++r) acc.b[l - 2][b][r] += g[0][b][r];
+    act_forward<C>(st[li - 1], h);        // h_{l-1} streams (inputs of layer l)
+    weight_grad<C>(stage, lane, p, q, g, h, acc.w[l - 2]);
+    f32x4 hb[C::NS][C::NB];
+    zero_frag<C>(hb);
+    gemm_frag<C>(lds + C::ldsWt(l), lane, g, hb);   // hbar_{l-1} = W_l^T zbar_l
 #pragma unroll
-        for (int d = 0; d < C::D; ++d) {
-          float v = z0 * x[d];
-          if constexpr (SS::FIRST) v += g[1 + d][b][r];
-          acc.w1[d][b][r] += v;
-        }
-      }
-  }
+    for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b) g[s][b] = hb[s][b];
+  });
 
-  // ---------------- reduce: lanes -> wave -> workgroup (fixed order) -> partials[block][P]
-  float* red = lds + C::ldsWeightsEnd(true) + wavesPerBlock * C::stageFloatsPerWave;
+  // ---------------- first layer: z_a = W1[:,a] (constant), z_ab = 0
+  act_backward<C>(st[0], g);  // g[0] = zbar, g[1+a] = zbar_a
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float z0 = g[0][b][r];
+      acc.b1[b][r] += z0;
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) {
+        float v = z0 * x[d];
+        if constexpr (SS::FIRST) v += g[1 + d][b][r];
+        acc.w1[d][b][r] += v;
+      }
+    }
+}
+
+// lanes -> wave -> workgroup (fixed order) -> out_row[P].
+// Waves deposit their sums into R per-wave LDS regions (R = as many as fit; they overlay the transpose staging).
+// Round k handles waves [k*R, (k+1)*R): round 0 stores, later rounds use no-return ds_add_f32 (each address is
+// touched once per wave and rounds are separated by barriers, so the summation order is fixed); finally every thread
+// adds the R regions in order and writes the workgroup's row of partials.
+template <class C, int WAVES>
+__device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, int wave, int lane, int p, int q,
+                                                   float* __restrict__ out) {
+  constexpr int PP = (C::P + 3) & ~3;
+  constexpr int R = bwd_regions<C>(WAVES);
+  float* red0 = lds + C::ldsWeightsEnd(true);
   const float bsum = point_sum(quad_sum(acc.bout));
 #pragma unroll
   for (int b = 0; b < C::NB; ++b)
@@ -556,10 +610,13 @@ __global__ __launch_bounds__(256) void mlp_jet_bwd_kernel(MlpArgs a) {
 #pragma unroll
       for (int l = 0; l < C::L - 1; ++l) acc.b[l][b][r] = point_sum(acc.b[l][b][r]);
     }
-  for (int w = 0; w < wavesPerBlock; ++w) {
-    if (wave == w) {
+  __syncthreads();  // every wave is done with its staging tile
+  float* red = red0 + (wave % R) * PP;
+  for (int k = 0; k * R < WAVES; ++k) {
+    if (wave / R == k) {
       auto put = [&](int idx, float v) {
-        if (w == 0) red[idx] = v; else red[idx] += v;
+        if (k == 0) red[idx] = v;
+        else __hip_atomic_fetch_add(&red[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
 #pragma unroll
       for (int b = 0; b < C::NB; ++b)
@@ -588,14 +645,126 @@ __global__ __launch_bounds__(256) void mlp_jet_bwd_kernel(MlpArgs a) {
     }
     __syncthreads();
   }
-  float* out = a.partials + (size_t)blockIdx.x * C::P;
-  for (int i = threadIdx.x; i < C::P; i += blockDim.x) out[i] = red[i];
+  for (int i = threadIdx.x; i < C::P; i += blockDim.x) {
+    float v = red0[i];
+#pragma unroll
+    for (int r = 1; r < R; ++r) v += red0[r * PP + i];
+    out[i] = v;
+  }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<C, true>(lds, a.params);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  constexpr int WAVES = C::BWD_THREADS / 64;
+  const int ntiles = (a.n + 15) >> 4;
+  float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
+  GradAcc<C> acc;
+  acc_zero<C>(acc);
+  for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
+    const int n = tile * 16 + p;
+    const bool valid = n < a.n;
+    const int nn = valid ? n : a.n - 1;
+    float x[C::D], gout[C::NS];
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) gout[s] = valid ? a.gbar[(size_t)s * a.ldj + nn] : 0.f;
+    LayerState<C> st[C::L];
+    f32x4 h[C::NS][C::NB];
+    tile_forward<C, true>(lds, lane, q, x, st, h);
+    tile_backward<C>(lds, stage, lane, p, q, x, gout, st, h, acc);
+  }
+  block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
+}
+
+// ------------------------------------------------------------------------------------------------ fused train / eval kernel
+// One kernel for the whole closure of a single-network system (solvers.py:369-395): forward streams -> generated
+// pointwise stage PW (conditions + residuals + loss seeds, neurodiffeq_amd/codegen.py) -> reverse pass, with the
+// layer states kept in registers in between: no forward recompute, no stream round trip through HBM, one launch.
+// PW::apply(x, jets, seed, r, f, gj): per-point function; PW::NEQ / PW::NF = number of residuals / function values.
+struct FusedArgs {
+  const float* coords;     // [D][ldc]
+  const float* params;     // [P]
+  float* partials;         // TRAIN: [gridDim.x][P]
+  float* loss_partials;    // [gridDim.x] block sums of sum_e r_e^2
+  float* funcs;            // optional [NF][ldj]
+  float* resid;            // optional [NEQ][ldj]
+  int n, ldc, ldj;
+  float seed;              // adjoint seed scale 1 / (N_global * n_eq)
+};
+
+template <class C, class PW, bool TRAIN>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<C, TRAIN>(lds, a.params);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  constexpr int WAVES = C::BWD_THREADS / 64;
+  const int ntiles = (a.n + 15) >> 4;
+  float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
+  GradAcc<C> acc;
+  if constexpr (TRAIN) acc_zero<C>(acc);
+  float lsum = 0.f;
+  for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
+    const int n = tile * 16 + p;
+    const bool valid = n < a.n;
+    const int nn = valid ? n : a.n - 1;
+    float x[C::D];
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    LayerState<C> st[C::L];
+    f32x4 h[C::NS][C::NB];
+    tile_forward<C, TRAIN>(lds, lane, q, x, st, h);
+    float jets[C::NS], gout[C::NS], r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
+    tile_output<C, TRAIN>(lds, q, h, jets);
+    PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
+    if (valid && q == 0) {
+#pragma unroll
+      for (int e = 0; e < PW::NEQ; ++e) lsum = fmaf(r[e], r[e], lsum);
+      if (a.resid) {
+#pragma unroll
+        for (int e = 0; e < PW::NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];
+      }
+      if (a.funcs) {
+#pragma unroll
+        for (int m = 0; m < PW::NF; ++m) a.funcs[(size_t)m * a.ldj + n] = f[m];
+      }
+    }
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s) gout[s] = valid ? gout[s] : 0.f;
+      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, h, acc);
+    }
+  }
+  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
+  // loss: lanes (only q == 0 lanes are non-zero) -> wave -> workgroup, fixed order
+  lsum = point_sum(quad_sum(lsum));
+  __syncthreads();
+  float* wl = lds + C::ldsWeightsEnd(TRAIN);
+  if (lane == 0) wl[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int w = 0; w < WAVES; ++w) v += wl[w];
+    a.loss_partials[blockIdx.x] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host-side sizes
 template <class C> constexpr size_t fwd_lds_bytes() { return sizeof(float) * C::ldsWeightsEnd(false); }
+template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock);
+template <class C> constexpr size_t fused_lds_bytes(bool train) {
+  return train ? bwd_lds_bytes<C>(C::BWD_THREADS / 64) : sizeof(float) * (C::ldsWeightsEnd(false) + 16);
+}
 template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock) {
-  return sizeof(float) * (C::ldsWeightsEnd(true) + wavesPerBlock * C::stageFloatsPerWave + ((C::P + 3) & ~3));
+  const int pp = (C::P + 3) & ~3;
+  const int stage = wavesPerBlock * C::stageFloatsPerWave;
+  const int red = bwd_regions<C>(wavesPerBlock) * pp;
+  return sizeof(float) * (C::ldsWeightsEnd(true) + (stage > red ? stage : red));
 }
 
 }  // namespace ndq

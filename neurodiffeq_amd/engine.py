@@ -85,7 +85,10 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
 
 
 class FusedSystem:
-    def __init__(self, nets, conditions, diff_eqs, n_coords, device, compute_func_val=None):
+    def __init__(self, nets, conditions, diff_eqs, n_coords, device, compute_func_val=None, single_kernel=True):
+        """single_kernel: for single-network systems use the one-launch fused closure kernel (forward + pointwise +
+        reverse, csrc/ndq_mlp.h: fused_closure_kernel); otherwise (and for multi-network systems) the three-kernel
+        pipeline through HBM streams."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.NdqError("the fused path needs an MI355X (device 'cuda'); no CPU fallback exists for it")
@@ -94,6 +97,9 @@ class FusedSystem:
         self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val)
         self.n_eq, self.n_funcs = len(self.program.residuals), len(self.program.funcs)
         self.kernel = codegen.load(self.program)
+        self.fusedk = None
+        if single_kernel and codegen.can_fuse(self.program):
+            self.fusedk = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0]))
         self.flat = [FlatParams(n, self.device) for n in self.nets]
         self.ns = [self.program.streams[k].n_streams for k in range(len(self.nets))]
         self.coord0 = [self.program.streams[k].deps[0] for k in range(len(self.nets))]
@@ -135,6 +141,10 @@ class FusedSystem:
         b["loss_partials"] = torch.zeros(b["pw_blocks"], dtype=f32, device=dev)
         b["bwd_blocks"] = [self.L.ndq_mlp_bwd_blocks(ctypes.byref(self.descs[k]), n) for k in range(len(self.nets))]
         b["partials"] = [torch.empty(nb, fp.numel, dtype=f32, device=dev) for nb, fp in zip(b["bwd_blocks"], self.flat)]
+        if self.fusedk is not None:
+            b["fused_blocks"] = self.fusedk.blocks(n)
+            b["fused_partials"] = torch.empty(b["fused_blocks"], self.flat[0].numel, dtype=f32, device=dev)
+            b["fused_loss_partials"] = torch.zeros(b["fused_blocks"], dtype=f32, device=dev)
         b["jets_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["jets"]])
         b["gbar_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["gbar"]])
         b["coords"], b["coords_rows"] = b["coords_own"], None
@@ -209,6 +219,25 @@ class FusedSystem:
                                         _c_vp(self.loss_buf.data_ptr() + 4 * slot), 0, seed, stream)
         _lib.check(rc, "ndq_reduce_partials(loss)")
 
+    def fused_closure(self, b, n, stream, train, n_global, slot, accumulate, want_funcs=False, want_resid=False):
+        """Single-network systems: the whole closure in ONE launch, then the two fixed-order second-stage sums."""
+        fp = self.flat[0]
+        fp.sync()
+        seed = 1.0 / (float(n_global) * self.n_eq)
+        rc = self.fusedk.lib.ndq_fused_launch(self._coord_ptr(b, 0), b["ld"], n, _ptr(fp.flat),
+                                              _ptr(b["fused_partials"]), _ptr(b["fused_loss_partials"]),
+                                              _ptr(b["funcs"]) if want_funcs else None,
+                                              _ptr(b["resid"]) if want_resid else None, b["ld"], seed,
+                                              1 if train else 0, stream)
+        _lib.check(rc, "ndq_fused_launch")
+        if train:
+            rc = self.L.ndq_reduce_partials(_ptr(b["fused_partials"]), b["fused_blocks"], fp.numel, _ptr(fp.grad),
+                                            1 if accumulate else 0, 1.0, stream)
+            _lib.check(rc, "ndq_reduce_partials")
+        rc = self.L.ndq_reduce_partials(_ptr(b["fused_loss_partials"]), b["fused_blocks"], 1,
+                                        _c_vp(self.loss_buf.data_ptr() + 4 * slot), 0, seed, stream)
+        _lib.check(rc, "ndq_reduce_partials(loss)")
+
     def step(self, batch, train, slot=0, accumulate=False, n_global=None, lo=0, hi=None, want_funcs=False,
              want_resid=False):
         """One closure evaluation (solvers.py:369-395) on rows [lo, hi) of ``batch``; the (shard of the) mean squared
@@ -216,6 +245,9 @@ class FusedSystem:
         b, n = self.upload(batch, lo, hi)
         n_global = n if n_global is None else n_global
         stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        if self.fusedk is not None:
+            self.fused_closure(b, n, stream, train, n_global, slot, accumulate, want_funcs, want_resid)
+            return b, n
         self.forward(b, n, stream)
         seed = self.pointwise(b, n, stream, train, n_global, want_funcs, want_resid)
         if train:

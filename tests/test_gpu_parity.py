@@ -125,7 +125,11 @@ def test_mlp_jet_fwd_matches_jet_oracle(L, name, n):
     coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
     got = _fwd(L, name, coords, flat)
     want = J.mlp_jets(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)), streams)
-    errs = {str(m): rel_l2(got[s], want[m][:, 0]) for s, m in enumerate(streams)}
+    # rel-L2 per stream; for tiny batches a single stream value can be a near-cancellation, so the denominator is
+    # floored at 1 % of the largest stream's RMS (absolute fp32 noise is what matters there)
+    floor = 1e-2 * np.sqrt(n) * max(np.sqrt(np.mean(want[m] ** 2)) for m in streams)
+    errs = {str(m): float(np.linalg.norm(got[s] - want[m][:, 0]) / max(np.linalg.norm(want[m][:, 0]), floor))
+            for s, m in enumerate(streams)}
     diag(f"fwd_{name}_{n}", errs)
     assert np.isfinite(got).all()
     assert max(errs.values()) < TOL, errs
@@ -215,7 +219,7 @@ def test_adam_step_matches_torch(L):
 
 
 # ------------------------------------------------------------------------------------------------ whole closure
-def _load_system(name, size):
+def _load_system(name, size, single_kernel=True):
     from tests import configs
     from neurodiffeq_amd.engine import FusedSystem
     torch.manual_seed(0)
@@ -223,14 +227,16 @@ def _load_system(name, size):
     for net in cfg["nets"]:
         net.to("cuda")
     n_coords = 1 if cfg["kind"] == "1d" else 2
-    return cfg, FusedSystem(cfg["nets"], cfg["conds"], cfg["pde"], n_coords, "cuda")
+    return cfg, FusedSystem(cfg["nets"], cfg["conds"], cfg["pde"], n_coords, "cuda", single_kernel=single_kernel)
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
-def test_fused_closure_matches_reference_golden(golden_dir, name):
+# "1k" = single-launch fused closure kernel (single-network systems), "3k" = forward / pointwise / backward pipeline
+@pytest.mark.parametrize("name,mode", [("c1", "3k"), ("c2", "1k"), ("c2", "3k"), ("c3", "1k"), ("c3", "3k"), ("c5", "3k")])
+def test_fused_closure_matches_reference_golden(golden_dir, name, mode):
     """funcs / residuals / loss / flat gradient of ONE closure (solvers.py:369-395) on the reference's own inputs."""
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
-    cfg, system = _load_system(name, SIZES[name])
+    cfg, system = _load_system(name, SIZES[name], single_kernel=(mode == "1k"))
+    assert (system.fusedk is not None) == (mode == "1k")
     R.set_flat(cfg["nets"], gold["params0"])
     coords = [torch.from_numpy(c) for c in gold["coords"]]
     b, n = system.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)
@@ -246,7 +252,7 @@ def test_fused_closure_matches_reference_golden(golden_dir, name):
     for k, fp in enumerate(system.flat):
         errs[f"grad_net{k}"] = rel_l2(grad[off:off + fp.numel], gold["grad_f64"][off:off + fp.numel])
         off += fp.numel
-    diag(f"closure_{name}", errs)
+    diag(f"closure_{name}_{mode}", errs)
     assert max(errs["funcs"], errs["residuals"], errs["loss"], errs["grad"]) < TOL, errs
 
 
@@ -272,10 +278,11 @@ def test_solver_trajectory_matches_reference_golden(golden_dir, name):
     assert errs["loss"] < 2e-5 and errs["params"] < 1e-5, errs
 
 
-@pytest.mark.parametrize("name,size", [("c2", 256), ("c3", 96), ("c1", 1024)])
-def test_fused_closure_matches_oracle_at_size(name, size):
-    """Full-size C2 (65 536 points) and larger C1/C3 batches against the autograd oracle in fp64."""
-    cfg, system = _load_system(name, size)
+@pytest.mark.parametrize("name,size,mode", [("c2", 256, "1k"), ("c2", 256, "3k"), ("c3", 96, "1k"), ("c3", 97, "3k"),
+                                            ("c1", 1024, "3k"), ("c2", 37, "1k")])
+def test_fused_closure_matches_oracle_at_size(name, size, mode):
+    """Full-size C2 (65 536 points) and larger / ragged C1/C3 batches against the autograd oracle in fp64."""
+    cfg, system = _load_system(name, size, single_kernel=(mode == "1k"))
     torch.manual_seed(0)
     ocfg = R.build_config(name, size, dtype=torch.float64)
     flat = R.get_flat(cfg["nets"]).cpu()
@@ -290,7 +297,7 @@ def test_fused_closure_matches_oracle_at_size(name, size):
                 residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy(), out["residuals"].numpy()),
                 loss=abs(system.loss_buf[0].item() - out["loss"].item()) / abs(out["loss"].item()),
                 grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in system.flat]), want_grad))
-    diag(f"closure_full_{name}_{size}", errs)
+    diag(f"closure_full_{name}_{size}_{mode}", errs)
     assert max(errs.values()) < TOL, errs
 
 
