@@ -65,6 +65,47 @@ int ndq_reduce_partials(const float* partials, int nparts, int len, float* out, 
 int ndq_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* One fused launch for the two second-stage sums of a batch: out[i] = (accumulate ? out[i] : 0) + sum_r partials[r*len+i]
+ * (parameter gradients) and *loss_out = loss_scale * sum_r loss_partials[r] (mean squared residual of the batch). */
+int ndq_reduce_grad_loss(const float* partials, int nparts, int len, float* out, int accumulate,
+                         const float* loss_partials, int n_loss_parts, float* loss_out, float loss_scale, void* stream);
+
+/* Device-side end of a training epoch (solvers.py:407-419 without a host round trip): epoch loss = mean of the
+ * n_batches loss slots -> loss_hist[hist_index]; best-network snapshot (solvers.py:434-441): if the epoch loss is
+ * below best_loss[parity] the PRE-step parameters are copied to best_flat and best_loss[parity^1] is updated
+ * (best_loss is a 2-slot ping-pong so no workgroup reads what another writes); then the fused Adam update.
+ * write_scalars: only one network of a multi-network system records loss_hist / best_loss. */
+int ndq_epoch_tail(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, const float* loss_slots, int n_batches,
+                   float* loss_hist, int hist_index, float* best_loss, int parity, float* best_flat, int write_scalars,
+                   void* stream);
+
+/* Launcher exported by a generated single-network fused closure kernel (codegen.py: fused_source). */
+typedef int (*ndq_fused_launch_fn)(const float* coords, int ldc, int n, const float* params, float* partials,
+                                   float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,
+                                   void* stream);
+
+/* Everything one training epoch of a single-network system with n_batches_train = 1 needs, prepared once by the host:
+ * closure kernel -> ndq_reduce_grad_loss -> ndq_epoch_tail, issued back to back on `stream` by ONE native call. */
+typedef struct ndq_fused_step {
+  ndq_fused_launch_fn launch;
+  int n, ldc, ldj, blocks, n_params;
+  float seed;                 /* 1 / (N_global * n_eq) */
+  float* params;              /* [P] */
+  float* partials;            /* [blocks][P] */
+  float* loss_partials;       /* [blocks] */
+  float* grad;                /* [P] */
+  float* loss_slot;           /* [1] */
+  float* adam_m;              /* [P]  (NULL: stop after the reductions) */
+  float* adam_v;              /* [P] */
+  float lr, beta1, beta2, eps, weight_decay;
+  float* loss_hist;           /* ring of epoch losses */
+  float* best_loss;           /* [2] */
+  float* best_flat;           /* [P] */
+} ndq_fused_step;
+int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_step, int hist_index, int parity,
+                       void* stream);
+
 /* Signature of a generated pointwise kernel launcher (one per traced PDE system, built by
  * neurodiffeq_amd/codegen.py with hipcc).  It evaluates the condition re-parameterisation (conditions.py
  * `parameterize`), the user's residuals (`diff_eqs`, solvers.py:380), the squared-residual partial sums

@@ -16,6 +16,24 @@ class MlpDesc(ctypes.Structure):
         return (self.d, self.first, self.mask2, self.hidden, self.layers, self.act, self.n_out)
 
 
+FUSED_LAUNCH_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                   ctypes.c_float, ctypes.c_int, ctypes.c_void_p)
+
+
+class FusedStep(ctypes.Structure):
+    """ndq_fused_step of include/ndq.h"""
+    _fields_ = [("launch", ctypes.c_void_p),
+                ("n", ctypes.c_int), ("ldc", ctypes.c_int), ("ldj", ctypes.c_int), ("blocks", ctypes.c_int),
+                ("n_params", ctypes.c_int), ("seed", ctypes.c_float),
+                ("params", ctypes.c_void_p), ("partials", ctypes.c_void_p), ("loss_partials", ctypes.c_void_p),
+                ("grad", ctypes.c_void_p), ("loss_slot", ctypes.c_void_p), ("adam_m", ctypes.c_void_p),
+                ("adam_v", ctypes.c_void_p),
+                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("weight_decay", ctypes.c_float),
+                ("loss_hist", ctypes.c_void_p), ("best_loss", ctypes.c_void_p), ("best_flat", ctypes.c_void_p)]
+
+
 class NdqError(RuntimeError):
     pass
 
@@ -46,15 +64,20 @@ def lib():
     L.ndq_mlp_jet_bwd.argtypes = [dp, vp, ci, ci, vp, vp, ci, vp, vp]
     L.ndq_reduce_partials.argtypes = [vp, ci, ci, vp, ci, cf, vp]
     L.ndq_adam_step.argtypes = [vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, vp]
+    L.ndq_reduce_grad_loss.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, cf, vp]
+    L.ndq_epoch_tail.argtypes = [vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp]
+    L.ndq_fused_step_run.argtypes = [ctypes.POINTER(FusedStep), vp, ci, ci, ci, vp]
     for name in ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks",
-                 "ndq_mlp_jet_fwd", "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step"):
+                 "ndq_mlp_jet_fwd", "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss",
+                 "ndq_epoch_tail", "ndq_fused_step_run"):
         getattr(L, name).restype = ci
     _LIB = L
     return L
 
 
 EXPORTS = ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks", "ndq_mlp_jet_fwd",
-           "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step")
+           "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss", "ndq_epoch_tail",
+           "ndq_fused_step_run")
 
 
 def check(rc, what):

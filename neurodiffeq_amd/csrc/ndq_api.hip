@@ -121,6 +121,75 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// both second-stage sums of one batch in one launch: blocks [0, gridDim.x-1) reduce 64 gradient columns each with 4
+// row groups per column (fixed order: row groups sequentially, then the 4 group sums in order); the last block sums
+// the loss partials (wave shuffle tree + the 4 waves in order).
+struct Reduce2Args {
+  const float* part; int nparts, len; float* out; int accumulate;
+  const float* lpart; int nlparts; float* lout; float lscale;
+};
+__global__ __launch_bounds__(256) void reduce_grad_loss_kernel(Reduce2Args a) {
+  __shared__ float sm[256];
+  const int tid = threadIdx.x;
+  if (blockIdx.x + 1 < gridDim.x) {
+    const int c = tid & 63, rg = tid >> 6;
+    const int i = blockIdx.x * 64 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < a.len) {
+      int r = rg;
+      for (; r + 4 < a.nparts; r += 8) {
+        s0 += a.part[(size_t)r * a.len + i];
+        s1 += a.part[(size_t)(r + 4) * a.len + i];
+      }
+      if (r < a.nparts) s0 += a.part[(size_t)r * a.len + i];
+    }
+    sm[tid] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && i < a.len) {
+      const float s = (sm[c] + sm[64 + c]) + (sm[128 + c] + sm[192 + c]);
+      a.out[i] = a.accumulate ? a.out[i] + s : s;
+    }
+  } else {
+    float v = 0.f;
+    for (int r = tid; r < a.nlparts; r += 256) v += a.lpart[r];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) *a.lout = ((sm[0] + sm[1]) + (sm[2] + sm[3])) * a.lscale;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- epoch tail
+struct TailArgs {
+  float* p; const float* g; float* m; float* v; int len;
+  float lr, b1, b2, eps, wd, bc1, bc2s;
+  const float* loss_slots; int nb; float* loss_hist; int hist_index; float* best_loss; int parity; float* best_flat;
+  int write_scalars;
+};
+__global__ __launch_bounds__(256) void epoch_tail_kernel(TailArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float loss = 0.f;
+  for (int k = 0; k < a.nb; ++k) loss += a.loss_slots[k];
+  loss /= (float)a.nb;
+  const float best = a.best_loss[a.parity];
+  const bool better = loss < best;              // false for NaN, like the reference's comparison
+  if (i < a.len) {
+    const float pi = a.p[i];
+    if (better && a.best_flat) a.best_flat[i] = pi;
+    float gi = a.g[i];
+    if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+    const float mi = fmaf(a.b1, a.m[i], (1.f - a.b1) * gi);
+    const float vi = fmaf(a.b2, a.v[i], (1.f - a.b2) * gi * gi);
+    a.m[i] = mi;
+    a.v[i] = vi;
+    a.p[i] = pi - (a.lr / a.bc1) * (mi / (sqrtf(vi) / a.bc2s + a.eps));
+  }
+  if (i == 0 && a.write_scalars) {
+    a.loss_hist[a.hist_index] = loss;
+    a.best_loss[a.parity ^ 1] = better ? loss : best;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- Adam
 // torch.optim.Adam (amsgrad=False, maximize=False) single-tensor formula:
 //   g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
@@ -191,6 +260,46 @@ int ndq_reduce_partials(const float* partials, int nparts, int len, float* out, 
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                      partials, nparts, len, out, accumulate, scale);
   return (int)hipGetLastError();
+}
+
+int ndq_reduce_grad_loss(const float* partials, int nparts, int len, float* out, int accumulate,
+                         const float* loss_partials, int n_loss_parts, float* loss_out, float loss_scale, void* stream) {
+  if (!partials || !out || !loss_partials || !loss_out || nparts <= 0 || len <= 0 || n_loss_parts <= 0) return NDQ_EINVAL;
+  Reduce2Args a{partials, nparts, len, out, accumulate, loss_partials, n_loss_parts, loss_out, loss_scale};
+  hipLaunchKernelGGL(reduce_grad_loss_kernel, dim3((len + 63) / 64 + 1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}
+
+int ndq_epoch_tail(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, const float* loss_slots, int n_batches,
+                   float* loss_hist, int hist_index, float* best_loss, int parity, float* best_flat, int write_scalars,
+                   void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || len <= 0 || step <= 0 || !loss_slots || n_batches <= 0 ||
+      !loss_hist || !best_loss || hist_index < 0 || (parity != 0 && parity != 1))
+    return NDQ_EINVAL;
+  TailArgs a;
+  a.p = params; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.len = len;
+  a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.loss_slots = loss_slots; a.nb = n_batches; a.loss_hist = loss_hist; a.hist_index = hist_index;
+  a.best_loss = best_loss; a.parity = parity; a.best_flat = best_flat; a.write_scalars = write_scalars;
+  hipLaunchKernelGGL(epoch_tail_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}
+
+int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_step, int hist_index, int parity,
+                       void* stream) {
+  if (!s || !s->launch || !coords) return NDQ_EINVAL;
+  int rc = s->launch(coords, s->ldc, s->n, s->params, s->partials, s->loss_partials, nullptr, nullptr, s->ldj, s->seed,
+                     1, stream);
+  if (rc) return rc;
+  rc = ndq_reduce_grad_loss(s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks, s->loss_slot,
+                            s->seed, stream);
+  if (rc || !s->adam_m) return rc;
+  return ndq_epoch_tail(s->params, s->grad, s->adam_m, s->adam_v, s->n_params, s->lr, s->beta1, s->beta2, s->eps,
+                        s->weight_decay, adam_step, s->loss_slot, 1, s->loss_hist, hist_index, s->best_loss, parity,
+                        s->best_flat, 1, stream);
 }
 
 int ndq_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,

@@ -238,6 +238,77 @@ class FusedSystem:
                                         _c_vp(self.loss_buf.data_ptr() + 4 * slot), 0, seed, stream)
         _lib.check(rc, "ndq_reduce_partials(loss)")
 
+    # ------------------------------------------------------------------------------------------ native epoch
+    HIST = 8192
+
+    def fast_ready(self):
+        return self.fusedk is not None
+
+    def fast_state(self):
+        """Device-side epoch bookkeeping of the native fast path: loss ring, best-loss ping-pong, best snapshot."""
+        if getattr(self, "_fast", None) is None:
+            dev, f32 = self.device, torch.float32
+            self._fast = dict(loss_hist=torch.zeros(self.HIST, dtype=f32, device=dev),
+                              best_loss=torch.full((2,), float("inf"), dtype=f32, device=dev),
+                              best_flat=torch.zeros_like(self.flat[0].grad), parity=0, pending=0, structs={},
+                              launch=ctypes.cast(self.fusedk.lib.ndq_fused_launch, ctypes.c_void_p).value)
+        return self._fast
+
+    def fast_train_epoch(self, batch, optimizer, adam_slot, track_best, n_global=None, dist=None):
+        """One whole training epoch (n_batches = 1) of a single-network system with zero host synchronisation:
+        closure kernel -> fused second-stage sums [-> all-reduce] -> device-side epoch tail (loss history, best
+        snapshot, Adam).  ``adam_slot`` = (exp_avg, exp_avg_sq, group dict, step count AFTER this update)."""
+        fs = self.fast_state()
+        b, n = self.upload(batch)
+        fp = self.flat[0]
+        fp.sync()
+        m, v, group, step = adam_slot
+        key = (n, b["ld"], id(b))
+        st = fs["structs"].get(key)
+        if st is None:
+            st = _lib.FusedStep()
+            st.launch = fs["launch"]
+            st.n, st.ldc, st.ldj, st.blocks, st.n_params = n, b["ld"], b["ld"], b["fused_blocks"], fp.numel
+            st.partials, st.loss_partials = b["fused_partials"].data_ptr(), b["fused_loss_partials"].data_ptr()
+            st.grad, st.loss_slot = fp.grad.data_ptr(), fp.grad_loss.data_ptr() + 4 * fp.numel
+            st.loss_hist, st.best_loss = fs["loss_hist"].data_ptr(), fs["best_loss"].data_ptr()
+            fs["structs"][key] = st
+        n_global = n if n_global is None else n_global
+        st.params = fp.flat.data_ptr()
+        st.seed = 1.0 / (float(n_global) * self.n_eq)
+        st.best_flat = fs["best_flat"].data_ptr() if track_best else None
+        b1, b2 = group["betas"]
+        st.lr, st.beta1, st.beta2, st.eps, st.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]
+        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        coords = self._coord_ptr(b, 0)
+        hist_index, parity = fs["pending"], fs["parity"]
+        if dist is None:
+            st.adam_m, st.adam_v = m.data_ptr(), v.data_ptr()
+            rc = self.L.ndq_fused_step_run(ctypes.byref(st), coords, step, hist_index, parity, stream)
+            _lib.check(rc, "ndq_fused_step_run")
+        else:
+            st.adam_m = st.adam_v = None
+            rc = self.L.ndq_fused_step_run(ctypes.byref(st), coords, step, hist_index, parity, stream)
+            _lib.check(rc, "ndq_fused_step_run")
+            dist.all_reduce_flat(fp.grad_loss)
+            rc = self.L.ndq_epoch_tail(_ptr(fp.flat), _ptr(fp.grad), _ptr(m), _ptr(v), fp.numel, group["lr"], b1, b2,
+                                       group["eps"], group["weight_decay"], step, _c_vp(st.loss_slot), 1,
+                                       _ptr(fs["loss_hist"]), hist_index, _ptr(fs["best_loss"]), parity,
+                                       _ptr(fs["best_flat"]) if track_best else None, 1, stream)
+            _lib.check(rc, "ndq_epoch_tail")
+        fs["pending"] += 1
+        fs["parity"] ^= 1
+
+    def fast_flush(self):
+        """Read back (ONE synchronising copy) the epoch losses recorded since the last flush and the best loss."""
+        fs = getattr(self, "_fast", None)
+        if fs is None or fs["pending"] == 0:
+            return [], None
+        k = fs["pending"]
+        vals = torch.cat([fs["loss_hist"][:k], fs["best_loss"][fs["parity"]:fs["parity"] + 1]]).tolist()
+        fs["pending"] = 0
+        return vals[:k], vals[k]
+
     def step(self, batch, train, slot=0, accumulate=False, n_global=None, lo=0, hi=None, want_funcs=False,
              want_resid=False):
         """One closure evaluation (solvers.py:369-395) on rows [lo, hi) of ``batch``; the (shard of the) mean squared

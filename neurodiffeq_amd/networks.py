@@ -123,7 +123,10 @@ class FlatParams:
         self.params = [p for l in describe(net)["linears"] for p in (l.weight, l.bias)]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
-        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        # gradient buffer with one spare trailing slot: single-network systems keep the batch loss there so that
+        # [gradient | loss] is ONE contiguous all-reduce message (parallel.py)
+        self.grad_loss = torch.zeros(self.numel + 1, dtype=torch.float32, device=self.device)
+        self.grad = self.grad_loss[:self.numel]
         self._offsets = []
         off = 0
         for p in self.params:

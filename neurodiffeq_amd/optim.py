@@ -49,8 +49,30 @@ class FusedAdam(torch.optim.Adam):
             self._bound.append((fp, m, v, group))
             self._bound_ids.update(id(p) for p in fp.params)
 
+    def fast_slot(self, fp):
+        """(exp_avg, exp_avg_sq, group, step AFTER the next update) for the solver's native epoch path, which performs
+        the Adam update on the device itself (ndq_epoch_tail); None if ``fp`` is not bound / not eligible."""
+        for f, m, v, group in self._bound:
+            if f is fp and not group.get("amsgrad") and not group.get("maximize"):
+                self._steps[id(fp)] += 1
+                self._dirty_steps = True
+                return m, v, group, self._steps[id(fp)]
+        return None
+
+    def _sync_step_tensors(self):
+        if getattr(self, "_dirty_steps", False):
+            for fp, _, _, _ in self._bound:
+                for p in fp.params:
+                    self.state[p]["step"].fill_(float(self._steps[id(fp)]))
+            self._dirty_steps = False
+
+    def state_dict(self):
+        self._sync_step_tensors()
+        return super().state_dict()
+
     @torch.no_grad()
     def step(self, closure=None):
+        self._sync_step_tensors()
         loss = None
         if closure is not None:
             with torch.enable_grad():

@@ -32,6 +32,10 @@ class BatchSharding:
     def global_n(self, n):
         return n * self.world_size if self.presharded else n
 
+    def all_reduce_flat(self, flat):
+        """In-place sum of one contiguous fp32 vector ([gradient | loss] of a single-network system)."""
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+
     def all_reduce(self, system, n_batches, train=True):
         """Sum gradients (``system.flat[k].grad``) and the first ``n_batches`` loss slots over all ranks, in place."""
         grads = [fp.grad for fp in system.flat] if train else []

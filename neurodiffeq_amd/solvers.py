@@ -108,9 +108,9 @@ class BaseSolver(ABC):
             else:
                 self.metrics_fn["analytic_mse"] = analytic_mse
 
-        self.metrics_history = {"train_loss": [], "valid_loss": []}
-        self.metrics_history.update({"train__" + name: [] for name in self.metrics_fn})
-        self.metrics_history.update({"valid__" + name: [] for name in self.metrics_fn})
+        self._history = {"train_loss": [], "valid_loss": []}
+        self._history.update({"train__" + name: [] for name in self.metrics_fn})
+        self._history.update({"valid__" + name: [] for name in self.metrics_fn})
 
         self.optimizer = optimizer if optimizer else FusedAdam(_unique_params(self.nets))
         self._set_loss_fn(loss_fn)
@@ -124,14 +124,14 @@ class BaseSolver(ABC):
                           f"This leads to potentially worse solution in `best_net`!", RuntimeWarning)
         self._best_nets = None
         self._best_flat = None          # device snapshots of the flat parameters (fused path)
-        self.lowest_loss = None
+        self._lowest_loss = None
         self.local_epoch = 0
         self._max_local_epoch = 0
         self._stop_training = False
         self._phase = None
         self._fused_sys = None
         self._fused_key = None
-        self._fused_failed = None
+        self._fast_tracks_best = False
         self.dist = None                # optional neurodiffeq_amd.parallel.BatchSharding
 
     # ------------------------------------------------------------------------------------------ loss function
@@ -149,8 +149,46 @@ class BaseSolver(ABC):
 
     # ------------------------------------------------------------------------------------------ small properties
     @property
+    def metrics_history(self):
+        """Dict of history lists (solvers.py:174-180).  On the native fast path epoch losses are recorded on the
+        device; reading this property (callbacks, user code, ``fit``'s end) pulls them over in one copy."""
+        self._flush_device_history()
+        return self._history
+
+    @metrics_history.setter
+    def metrics_history(self, value):
+        self._flush_device_history()
+        self._history = value
+
+    @property
+    def lowest_loss(self):
+        self._flush_device_history()
+        return self._lowest_loss
+
+    @lowest_loss.setter
+    def lowest_loss(self, value):
+        self._flush_device_history()
+        self._lowest_loss = value
+        if self._fused_sys is not None and getattr(self._fused_sys, "_fast", None) is not None:
+            self._fused_sys._fast["best_loss"].fill_(float("inf") if value is None else float(value))
+
+    def _flush_device_history(self):
+        system = self._fused_sys
+        if system is None or getattr(system, "_fast", None) is None or system._fast["pending"] == 0:
+            return
+        losses, best = system.fast_flush()
+        self._history["train_loss"].extend(losses)
+        if self._fast_tracks_best and best < float("inf") and (self._lowest_loss is None or best < self._lowest_loss):
+            self._lowest_loss = best
+            self._best_flat = [system._fast["best_flat"]]     # device snapshot written by ndq_epoch_tail
+            self._best_nets = None
+
+    @property
     def global_epoch(self):
-        return len(self.metrics_history["train_loss"])
+        pending = 0
+        if self._fused_sys is not None and getattr(self._fused_sys, "_fast", None) is not None:
+            pending = self._fused_sys._fast["pending"]
+        return len(self._history["train_loss"]) + pending
 
     @property
     def batch(self):
@@ -176,6 +214,7 @@ class BaseSolver(ABC):
     def best_nets(self):
         """Networks of the epoch with the lowest loss (solvers.py:434-441).  On the fused path the snapshot is a flat
         device copy taken without a host round trip; module copies are materialised on first access."""
+        self._flush_device_history()
         if self._best_flat is not None:
             nets = deepcopy(self.nets)
             with torch.no_grad():
@@ -184,7 +223,9 @@ class BaseSolver(ABC):
                     for p in net.parameters():
                         p.copy_(flat[off:off + p.numel()].view(p.shape))
                         off += p.numel()
-            self._best_nets, self._best_flat = nets, None
+            self._best_nets = nets
+            self._best_flat = None
+            self._best_nets_from_device = True
         return self._best_nets
 
     @best_nets.setter
@@ -207,10 +248,11 @@ class BaseSolver(ABC):
     # ------------------------------------------------------------------------------------------ history
     def _update_history(self, value, metric_type, key):
         self._phase = key
+        self._flush_device_history()
         if metric_type == "loss":
-            self.metrics_history[f"{key}_{metric_type}"].append(value)
+            self._history[f"{key}_{metric_type}"].append(value)
         elif metric_type in self.metrics_fn:
-            self.metrics_history[f"{key}__{metric_type}"].append(value)
+            self._history[f"{key}__{metric_type}"].append(value)
         else:
             raise KeyError(f"metric '{metric_type}' not specified")
 
@@ -281,6 +323,8 @@ class BaseSolver(ABC):
         if system is None:
             return self._run_epoch_composite(key, first_batch)
         nb = self.n_batches[key]
+        if key == "train" and self._run_train_epoch_native(system, first_batch):
+            return
         metric_values = {name: 0.0 for name in self.metrics_fn}
         if system.loss_buf.numel() < nb:
             system.loss_buf = torch.zeros(nb, dtype=torch.float32, device=self.device)
@@ -311,6 +355,42 @@ class BaseSolver(ABC):
             self._do_optimizer_step()
         for name in self.metrics_fn:
             self._update_history(metric_values[name] / nb, name, key)
+
+    def _run_train_epoch_native(self, system, batch):
+        """Whole training epoch as ONE native call with no host synchronisation (engine.fast_train_epoch), when the
+        epoch has the default shape: single-network fused system, one batch per epoch, FusedAdam, no metrics, and none
+        of the step hooks overridden.  Returns False if the general path must run instead."""
+        cls = type(self)
+        if not (system.fast_ready() and self.n_batches["train"] == 1 and not self.metrics_fn
+                and isinstance(self.optimizer, FusedAdam)
+                and cls._do_optimizer_step is BaseSolver._do_optimizer_step
+                and cls._update_best is BaseSolver._update_best
+                and cls._update_history is BaseSolver._update_history):
+            return False
+        track_best = self.n_batches["valid"] == 0
+        fs = system.fast_state()
+        if fs["pending"] >= system.HIST or (fs["pending"] and track_best != self._fast_tracks_best):
+            self._flush_device_history()
+        # a best loss found on the host path (or set by the user) must be what the device compares against
+        if fs["pending"] == 0:
+            fs["best_loss"].fill_(float("inf") if self._lowest_loss is None else float(self._lowest_loss))
+        slot = self.optimizer.fast_slot(system.flat[0])
+        if slot is None:
+            return False
+        self._fast_tracks_best = track_best
+        shard = self.dist
+        n_all = batch[0].shape[0]
+        if shard is not None:
+            lo, hi = shard.bounds(n_all)
+            if (lo, hi) != (0, n_all):
+                batch = [c[lo:hi] for c in batch]
+        system.fast_train_epoch(batch, self.optimizer, slot, track_best,
+                                n_global=shard.global_n(n_all) if shard else n_all, dist=shard)
+        for fp in system.flat:
+            if not fp.grads_attached():
+                fp.attach_grads()
+        self._phase = "train"
+        return True
 
     def _run_epoch_composite(self, key, first_batch):
         """The reference's closure on torch autograd, for systems outside the fused scope."""
@@ -370,8 +450,8 @@ class BaseSolver(ABC):
 
     def _update_best(self, key):
         current_loss = self.metrics_history[key + "_loss"][-1]
-        if (self.lowest_loss is None) or current_loss < self.lowest_loss:
-            self.lowest_loss = current_loss
+        if (self._lowest_loss is None) or current_loss < self._lowest_loss:
+            self._lowest_loss = current_loss
             if self._fused_sys is not None:
                 for fp in self._fused_sys.flat:
                     fp.sync()
@@ -405,6 +485,7 @@ class BaseSolver(ABC):
             self.run_valid_epoch()
             for cb in callbacks:
                 cb(self)
+        self._flush_device_history()
 
     # ------------------------------------------------------------------------------------------ results
     @abstractmethod

@@ -125,9 +125,9 @@ def test_mlp_jet_fwd_matches_jet_oracle(L, name, n):
     coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
     got = _fwd(L, name, coords, flat)
     want = J.mlp_jets(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)), streams)
-    # rel-L2 per stream; for tiny batches a single stream value can be a near-cancellation, so the denominator is
-    # floored at 1 % of the largest stream's RMS (absolute fp32 noise is what matters there)
-    floor = 1e-2 * np.sqrt(n) * max(np.sqrt(np.mean(want[m] ** 2)) for m in streams)
+    # rel-L2 per stream; for tiny batches a single stream value can be a near-cancellation of O(1) terms, so there
+    # the denominator is floored at 10 % of the largest stream's RMS (absolute fp32 noise is what matters)
+    floor = (0.1 if n < 64 else 0.0) * np.sqrt(n) * max(np.sqrt(np.mean(want[m] ** 2)) for m in streams)
     errs = {str(m): float(np.linalg.norm(got[s] - want[m][:, 0]) / max(np.linalg.norm(want[m][:, 0]), floor))
             for s, m in enumerate(streams)}
     diag(f"fwd_{name}_{n}", errs)
@@ -321,3 +321,32 @@ def test_gradient_accumulation_and_validation_mode():
     assert len(solver.metrics_history["valid_loss"]) == 1
     assert abs(solver.metrics_history["train_loss"][0] - loop.history[0]) <= 2e-5 * abs(loop.history[0])
     assert rel_l2(before, R.get_flat(ocfg["nets"]).numpy()) < 1e-5
+
+
+def test_native_epoch_path_bookkeeping_matches_general_path():
+    """The zero-sync native epoch (closure -> fused sums -> device-side tail) against the general path on the same
+    seeds: loss history, lowest_loss, best_nets snapshot (pre-step parameters of the best epoch), final parameters,
+    optimizer step count."""
+    from tests import configs
+
+    def run(native):
+        torch.manual_seed(0)
+        # a (no-op) metric forces the general path
+        solver, cfg = configs.make_solver("c2", 16, metrics=None if native else {"zero": lambda u, x, y: (u * 0).mean()})
+        solver.fused = "require"
+        torch.manual_seed(5)
+        for _ in range(6):
+            solver.run_train_epoch()
+        assert solver.fused_active
+        hist = list(solver.metrics_history["train_loss"])
+        best = R.get_flat(solver.best_nets).cpu().numpy()
+        return solver, hist, solver.lowest_loss, best, R.get_flat(cfg["nets"]).cpu().numpy()
+
+    s1, h1, l1, b1, p1 = run(True)
+    s2, h2, l2, b2, p2 = run(False)
+    assert s1._fused_sys._fast is not None and getattr(s2._fused_sys, "_fast", None) is None
+    assert len(h1) == len(h2) == 6 and s1.global_epoch == 6
+    assert np.allclose(h1, h2, rtol=2e-5)
+    assert abs(l1 - min(h1)) <= 1e-7 * abs(l1) and abs(l1 - l2) <= 2e-5 * abs(l2)
+    assert rel_l2(b1, b2) < 1e-5 and rel_l2(p1, p2) < 1e-5
+    assert int(s1.optimizer.state_dict()["state"][0]["step"]) == 6
