@@ -160,7 +160,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL path is exercised even for a single rank, so that the 1-GPU box
+    # can validate exactly the code the multi-GPU scaling runs use
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -180,12 +183,12 @@ def main():
     resident = ResidentBatchGenerator.presample(global_gen, n_pool, "cuda", lo=rank * N_POINTS, hi=(rank + 1) * N_POINTS)
     from neurodiffeq_amd.generators import SamplerGenerator
     solver.generator["train"] = SamplerGenerator(resident)
-    if world > 1:
+    if use_dist:
         solver.dist = BatchSharding(presharded=True)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +200,7 @@ def main():
         solver.run_train_epoch()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -220,7 +223,7 @@ def main():
                        "inputs": "pre-sampled in the reference's RNG order, resident in HBM"},
             "final_loss": solver.metrics_history["train_loss"][-1],
         }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not use_dist:
         system = solver._fused_sys
         batch = solver._generate_batch("train")
         from neurodiffeq_amd.engine import FusedSystem
@@ -263,7 +266,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

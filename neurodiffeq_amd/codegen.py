@@ -22,6 +22,11 @@ HIPCC = os.environ.get("NDQ_HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 
+def _extra_flags():
+    """Tuning knobs for experiments: NDQ_JIT_FLAGS="-DNDQ_X=1 ..." is appended to hipcc and hashed into the cache key."""
+    return os.environ.get("NDQ_JIT_FLAGS", "").split()
+
+
 # ----------------------------------------------------------------------------------------------- stream layout
 def pair_list(d):
     return [(a, b) for a in range(d) for b in range(a, d)]
@@ -479,7 +484,7 @@ def build_fused(program: PointwiseProgram, desc, force=False):
     source AND the kernel header it instantiates)."""
     os.makedirs(JIT_DIR, exist_ok=True)
     source = program.fused_source(desc)
-    key = hashlib.sha1((source + _header_digest()).encode()).hexdigest()[:16]
+    key = hashlib.sha1((source + _header_digest() + " ".join(_extra_flags())).encode()).hexdigest()[:16]
     so = os.path.join(JIT_DIR, f"fused_{key}.so")
     src = os.path.join(JIT_DIR, f"fused_{key}.hip")
     if os.path.exists(so) and not force:
@@ -487,7 +492,7 @@ def build_fused(program: PointwiseProgram, desc, force=False):
     with open(src, "w") as fh:
         fh.write(source)
     tmp = so + f".tmp{os.getpid()}"
-    proc = subprocess.run([HIPCC] + HIPCC_FLAGS + [src, "-o", tmp], capture_output=True, text=True)
+    proc = subprocess.run([HIPCC] + HIPCC_FLAGS + _extra_flags() + [src, "-o", tmp], capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc failed for generated fused kernel {src}:\n{proc.stderr[-4000:]}")
     os.replace(tmp, so)

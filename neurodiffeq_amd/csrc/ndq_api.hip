@@ -128,34 +128,56 @@ struct Reduce2Args {
   const float* part; int nparts, len; float* out; int accumulate;
   const float* lpart; int nlparts; float* lout; float lscale;
 };
-__global__ __launch_bounds__(256) void reduce_grad_loss_kernel(Reduce2Args a) {
-  __shared__ float sm[256];
-  const int tid = threadIdx.x;
+
+// column sums of partials[nparts][len] for the 64 columns of this workgroup: 16 row groups x 64 columns, every thread
+// keeps 4 independent chains (rows rg, rg+16, ...), then the 16 group sums are added in fixed order.  Returns the
+// column total in the threads of row group 0 (valid where col < len).
+__device__ __forceinline__ float column_sum_1024(const float* __restrict__ part, int nparts, int len, int col, int rg,
+                                                 float* sm /* [16*64] */) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < len) {
+    int r = rg;
+    for (; r + 48 < nparts; r += 64) {
+      s0 += part[(size_t)r * len + col];
+      s1 += part[(size_t)(r + 16) * len + col];
+      s2 += part[(size_t)(r + 32) * len + col];
+      s3 += part[(size_t)(r + 48) * len + col];
+    }
+    for (; r < nparts; r += 16) s0 += part[(size_t)r * len + col];
+  }
+  sm[rg * 64 + (threadIdx.x & 63)] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  float s = 0.f;
+  if (rg == 0) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += sm[g * 64 + (threadIdx.x & 63)];
+  }
+  return s;
+}
+
+// sum of n floats by one 1024-thread workgroup, fixed order; result valid in thread 0
+__device__ __forceinline__ float block_sum_1024(const float* __restrict__ v, int n, float* sm16) {
+  float x = 0.f;
+  for (int r = threadIdx.x; r < n; r += 1024) x += v[r];
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+  if ((threadIdx.x & 63) == 0) sm16[threadIdx.x >> 6] = x;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < 16; ++w) s += sm16[w];
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void reduce_grad_loss_kernel(Reduce2Args a) {
+  __shared__ float sm[16 * 64];
   if (blockIdx.x + 1 < gridDim.x) {
-    const int c = tid & 63, rg = tid >> 6;
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + c;
-    float s0 = 0.f, s1 = 0.f;
-    if (i < a.len) {
-      int r = rg;
-      for (; r + 4 < a.nparts; r += 8) {
-        s0 += a.part[(size_t)r * a.len + i];
-        s1 += a.part[(size_t)(r + 4) * a.len + i];
-      }
-      if (r < a.nparts) s0 += a.part[(size_t)r * a.len + i];
-    }
-    sm[tid] = s0 + s1;
-    __syncthreads();
-    if (rg == 0 && i < a.len) {
-      const float s = (sm[c] + sm[64 + c]) + (sm[128 + c] + sm[192 + c]);
-      a.out[i] = a.accumulate ? a.out[i] + s : s;
-    }
+    const float s = column_sum_1024(a.part, a.nparts, a.len, i, rg, sm);
+    if (rg == 0 && i < a.len) a.out[i] = a.accumulate ? a.out[i] + s : s;
   } else {
-    float v = 0.f;
-    for (int r = tid; r < a.nlparts; r += 256) v += a.lpart[r];
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if ((tid & 63) == 0) sm[tid >> 6] = v;
-    __syncthreads();
-    if (tid == 0) *a.lout = ((sm[0] + sm[1]) + (sm[2] + sm[3])) * a.lscale;
+    const float s = block_sum_1024(a.lpart, a.nlparts, sm);
+    if (threadIdx.x == 0) *a.lout = s * a.lscale;
   }
 }
 
@@ -172,10 +194,10 @@ __global__ __launch_bounds__(256) void epoch_tail_kernel(TailArgs a) {
   for (int k = 0; k < a.nb; ++k) loss += a.loss_slots[k];
   loss /= (float)a.nb;
   const float best = a.best_loss[a.parity];
-  const bool better = loss < best;              // false for NaN, like the reference's comparison
+  const bool better = (a.best_flat != nullptr) && (loss < best);   // false for NaN, like the reference's comparison
   if (i < a.len) {
     const float pi = a.p[i];
-    if (better && a.best_flat) a.best_flat[i] = pi;
+    if (better) a.best_flat[i] = pi;
     float gi = a.g[i];
     if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
     const float mi = fmaf(a.b1, a.m[i], (1.f - a.b1) * gi);
@@ -187,6 +209,44 @@ __global__ __launch_bounds__(256) void epoch_tail_kernel(TailArgs a) {
   if (i == 0 && a.write_scalars) {
     a.loss_hist[a.hist_index] = loss;
     a.best_loss[a.parity ^ 1] = better ? loss : best;
+  }
+}
+
+// second-stage sums AND the epoch tail in one launch (single batch per epoch, no all-reduce in between): every
+// workgroup first adds up the loss partials itself (nlparts <= a few hundred floats), then reduces its 64 gradient
+// columns and applies best-snapshot + Adam to them.
+struct ReduceTailArgs {
+  Reduce2Args r;
+  TailArgs t;
+};
+__global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) {
+  __shared__ float sm[16 * 64];
+  __shared__ float sloss;
+  const float ls = block_sum_1024(a.r.lpart, a.r.nlparts, sm);
+  if (threadIdx.x == 0) sloss = ls * a.r.lscale;
+  __syncthreads();
+  const float loss = sloss;
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  const float g = column_sum_1024(a.r.part, a.r.nparts, a.r.len, i, rg, sm);
+  const float best = a.t.best_loss[a.t.parity];
+  const bool better = (a.t.best_flat != nullptr) && (loss < best);
+  if (rg == 0 && i < a.r.len) {
+    a.r.out[i] = g;
+    const float pi = a.t.p[i];
+    if (better) a.t.best_flat[i] = pi;
+    float gi = g;
+    if (a.t.wd != 0.f) gi = fmaf(a.t.wd, pi, gi);
+    const float mi = fmaf(a.t.b1, a.t.m[i], (1.f - a.t.b1) * gi);
+    const float vi = fmaf(a.t.b2, a.t.v[i], (1.f - a.t.b2) * gi * gi);
+    a.t.m[i] = mi;
+    a.t.v[i] = vi;
+    a.t.p[i] = pi - (a.t.lr / a.t.bc1) * (mi / (sqrtf(vi) / a.t.bc2s + a.t.eps));
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *a.r.lout = loss;
+    a.t.loss_hist[a.t.hist_index] = loss;
+    a.t.best_loss[a.t.parity ^ 1] = better ? loss : best;
   }
 }
 
@@ -266,7 +326,7 @@ int ndq_reduce_grad_loss(const float* partials, int nparts, int len, float* out,
                          const float* loss_partials, int n_loss_parts, float* loss_out, float loss_scale, void* stream) {
   if (!partials || !out || !loss_partials || !loss_out || nparts <= 0 || len <= 0 || n_loss_parts <= 0) return NDQ_EINVAL;
   Reduce2Args a{partials, nparts, len, out, accumulate, loss_partials, n_loss_parts, loss_out, loss_scale};
-  hipLaunchKernelGGL(reduce_grad_loss_kernel, dim3((len + 63) / 64 + 1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(reduce_grad_loss_kernel, dim3((len + 63) / 64 + 1), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }
 
@@ -294,12 +354,20 @@ int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_st
   int rc = s->launch(coords, s->ldc, s->n, s->params, s->partials, s->loss_partials, nullptr, nullptr, s->ldj, s->seed,
                      1, stream);
   if (rc) return rc;
-  rc = ndq_reduce_grad_loss(s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks, s->loss_slot,
-                            s->seed, stream);
-  if (rc || !s->adam_m) return rc;
-  return ndq_epoch_tail(s->params, s->grad, s->adam_m, s->adam_v, s->n_params, s->lr, s->beta1, s->beta2, s->eps,
-                        s->weight_decay, adam_step, s->loss_slot, 1, s->loss_hist, hist_index, s->best_loss, parity,
-                        s->best_flat, 1, stream);
+  if (!s->adam_m)
+    return ndq_reduce_grad_loss(s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks,
+                                s->loss_slot, s->seed, stream);
+  if (adam_step <= 0 || hist_index < 0 || (parity != 0 && parity != 1) || !s->loss_hist || !s->best_loss) return NDQ_EINVAL;
+  ReduceTailArgs a;
+  a.r = Reduce2Args{s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks, s->loss_slot, s->seed};
+  a.t.p = s->params; a.t.g = s->grad; a.t.m = s->adam_m; a.t.v = s->adam_v; a.t.len = s->n_params;
+  a.t.lr = s->lr; a.t.b1 = s->beta1; a.t.b2 = s->beta2; a.t.eps = s->eps; a.t.wd = s->weight_decay;
+  a.t.bc1 = (float)(1.0 - pow((double)s->beta1, (double)adam_step));
+  a.t.bc2s = (float)sqrt(1.0 - pow((double)s->beta2, (double)adam_step));
+  a.t.loss_slots = s->loss_slot; a.t.nb = 1; a.t.loss_hist = s->loss_hist; a.t.hist_index = hist_index;
+  a.t.best_loss = s->best_loss; a.t.parity = parity; a.t.best_flat = s->best_flat; a.t.write_scalars = 1;
+  hipLaunchKernelGGL(reduce_tail_kernel, dim3((s->n_params + 63) / 64), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
 }
 
 int ndq_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,

@@ -98,7 +98,10 @@ enum { ACT_TANH = 0, ACT_SIN = 1 };
 #define NDQ_FAST_TANH 1
 #endif
 #ifndef NDQ_BWD_THREADS
-#define NDQ_BWD_THREADS 512
+#define NDQ_BWD_THREADS 256
+#endif
+#ifndef NDQ_HBAR_INPLACE
+#define NDQ_HBAR_INPLACE 1
 #endif
 #ifndef NDQ_FWD_THREADS
 #define NDQ_FWD_THREADS 256
@@ -239,6 +242,28 @@ __device__ __forceinline__ void act_forward(const LayerState<C>& st, f32x4 (&h)[
             h[s][b][r] = fmaf(s2 * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[s][b][r]);
           });
         }
+      }
+    }
+}
+
+// one stream of act_forward (compile-time stream index S)
+template <class C, int S>
+__device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, f32x4 (&hs)[C::NB]) {
+  using SS = typename C::SS;
+  using A = Act<C::ACT>;
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = st.t[b][r], c = st.c[b][r];
+      if constexpr (S == 0) {
+        hs[b][r] = t;
+      } else if constexpr (S < SS::S2) {
+        hs[b][r] = A::s1(t, c) * st.z[S][b][r];
+      } else {
+        constexpr int a = SS::A(S), bb = SS::B(S);
+        const float s1 = A::s1(t, c);
+        hs[b][r] = fmaf(A::s2(t, c, s1) * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[S][b][r]);
       }
     }
 }
@@ -439,16 +464,18 @@ struct GradAcc {
 // reads (32-lane groups: q*4*HP = 16 banks apart) conflict-free.
 template <class C>
 __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q, const f32x4 (&zb)[C::NS][C::NB],
-                                            const f32x4 (&h)[C::NS][C::NB], f32x4 (&acc)[C::NB][C::NB]) {
+                                            const LayerState<C>& st_in, f32x4 (&acc)[C::NB][C::NB]) {
   constexpr int HP = C::HP;
   float* Zt = stage;
   float* Ht = stage + 16 * HP;
-#pragma unroll
-  for (int s = 0; s < C::NS; ++s) {
+  sfor<C::NS>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    f32x4 hs[C::NB];
+    act_forward_stream<C, s>(st_in, hs);    // stream s of the layer's input activations, recomputed from its state
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
       *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
-      *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = h[s][b];
+      *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = hs[b];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -470,6 +497,27 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  });
+}
+
+// one stream of hbar = W^T zbar in place: g[s] <- sum over (ib, t) of A(w) * B(g[s][ib][t]); stream by stream so that only
+// one extra fragment is live (the two output blocks alternate as MFMA accumulators, 64 cycles apart > 40 latency)
+template <class C>
+__device__ __forceinline__ void gemm_frag_inplace(const float* __restrict__ w, int lane, f32x4 (&g)[C::NS][C::NB]) {
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) {
+    f32x4 o[C::NB];
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < C::NB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ib = 0; ib < C::NB; ++ib)
+          o[ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[((ib * C::NB + kb) * 4 + t) * 64 + lane], g[s][kb][t], o[ib], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) g[s][b] = o[b];
   }
 }
 
@@ -530,22 +578,33 @@ __device__ __forceinline__ void tile_output(const float* lds, int q, const f32x4
 template <class C>
 __device__ __forceinline__ void tile_backward(const float* lds, float* stage, int lane, int p, int q,
                                               const float (&x)[C::D], const float (&gout)[C::NS],
-                                              LayerState<C> (&st)[C::L], f32x4 (&h)[C::NS][C::NB], GradAcc<C>& acc) {
+                                              LayerState<C> (&st)[C::L], GradAcc<C>& acc) {
   using SS = typename C::SS;
   // ---------------- output layer adjoint (n_out = 1): hbar = Wout * gout; dWout += sum_s gout_s h_s; dbout += gout_0
+  // (h_s of the last hidden layer is recomputed per stream from its state instead of being kept live)
   f32x4 g[C::NS][C::NB];
+  {
+    f32x4 dw[C::NB];
 #pragma unroll
-  for (int b = 0; b < C::NB; ++b) {
-    const f32x4 wo = lds4(lds + C::ldsWout(true) + 16 * b + 4 * q);
+    for (int b = 0; b < C::NB; ++b) dw[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    sfor<C::NS>([&](auto s_) {
+      constexpr int s = decltype(s_)::value;
+      f32x4 hs[C::NB];
+      act_forward_stream<C, s>(st[C::L - 1], hs);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float dw = 0.f;
+      for (int b = 0; b < C::NB; ++b)
 #pragma unroll
-      for (int s = 0; s < C::NS; ++s) {
-        g[s][b][r] = wo[r] * gout[s];
-        dw = fmaf(gout[s], h[s][b][r], dw);
+        for (int r = 0; r < 4; ++r) dw[b][r] = fmaf(gout[s], hs[b][r], dw[b][r]);
+    });
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) {
+      const f32x4 wo = lds4(lds + C::ldsWout(true) + 16 * b + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc.wout[b][r] += dw[b][r];
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) g[s][b][r] = wo[r] * gout[s];
       }
-      acc.wout[b][r] += dw;
     }
   }
   acc.bout += (q == 0) ? gout[0] : 0.f;
@@ -559,15 +618,18 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
     for (int b = 0; b < C::NB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc.b[l - 2][b][r] += g[0][b][r];
-    act_forward<C>(st[li - 1], h);        // h_{l-1} streams (inputs of layer l)
-    weight_grad<C>(stage, lane, p, q, g, h, acc.w[l - 2]);
+    weight_grad<C>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2]);   // inputs of layer l = activations of layer l-1
+#if NDQ_HBAR_INPLACE
+    gemm_frag_inplace<C>(lds + C::ldsWt(l), lane, g);                 // hbar_{l-1} = W_l^T zbar_l
+#else
     f32x4 hb[C::NS][C::NB];
     zero_frag<C>(hb);
-    gemm_frag<C>(lds + C::ldsWt(l), lane, g, hb);   // hbar_{l-1} = W_l^T zbar_l
+    gemm_frag<C>(lds + C::ldsWt(l), lane, g, hb);
 #pragma unroll
     for (int s = 0; s < C::NS; ++s)
 #pragma unroll
       for (int b = 0; b < C::NB; ++b) g[s][b] = hb[s][b];
+#endif
   });
 
   // ---------------- first layer: z_a = W1[:,a] (constant), z_ab = 0
@@ -676,7 +738,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
     LayerState<C> st[C::L];
     f32x4 h[C::NS][C::NB];
     tile_forward<C, true>(lds, lane, q, x, st, h);
-    tile_backward<C>(lds, stage, lane, p, q, x, gout, st, h, acc);
+    tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc);
   }
   block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
 }
@@ -737,7 +799,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     if constexpr (TRAIN) {
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) gout[s] = valid ? gout[s] : 0.f;
-      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, h, acc);
+      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc);
     }
   }
   if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
