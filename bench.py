@@ -159,6 +159,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))   # host-side torch ops (sampling leg); ATen's default of one
+    # thread per logical cpu is far past the sweet spot for 65k-element ops
     import torch.distributed as dist
     # under torch.distributed.run (RANK set) the RCCL path is exercised even for a single rank, so that the 1-GPU box
     # can validate exactly the code the multi-GPU scaling runs use
