@@ -245,6 +245,14 @@ def main():
                                "unit": "TFLOP/s", "frac": kb["mlp_jet_bwd"]["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                                "traffic": None, "algorithmic_flop_per_point": BWD_FLOP_PER_PT,
                                "avg_launch_us": kb["mlp_jet_bwd"]["us"]}
+        tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
+        if os.path.exists(tpath):      # HBM bytes per launch from the last committed rocprofv3 --pmc pass
+            tr = json.load(open(tpath))
+            key = "fused_closure" if system.fusedk is not None else None
+            if key and key in tr["kernels"]:
+                out["roofline"]["traffic"] = tr["kernels"][key]["hbm_bytes"]
+                out["roofline"]["traffic_note"] = tr["source"]
+            out["roofline_pointwise"]["traffic"] = tr["kernels"]["pointwise"]["hbm_bytes"]
         out["kernels"] = kb
         out["roofline_pointwise"] = {"kernel": "ndq_pw_kernel (generated)", "bound": "hbm",
                                      "achieved": kb["pointwise"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -11,7 +11,9 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row.get("Kernel_Name", "?")
-        short = "bwd" if "jet_bwd" in k else "fwd" if "jet_fwd" in k else "reduce" if "reduce_partials" in k else None
+        short = ("fused_closure" if "fused_closure" in k else "bwd" if "jet_bwd" in k else "fwd" if "jet_fwd" in k
+                 else "reduce_tail" if "reduce_tail" in k else "pointwise" if "ndq_pw" in k
+                 else "reduce" if "reduce_partials" in k else None)
         if short is None:
             continue
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
