@@ -245,6 +245,11 @@ def main():
                                "unit": "TFLOP/s", "frac": kb["mlp_jet_bwd"]["tflops"] / FP32_MFMA_PEAK_TFLOPS,
                                "traffic": None, "algorithmic_flop_per_point": BWD_FLOP_PER_PT,
                                "avg_launch_us": kb["mlp_jet_bwd"]["us"]}
+        out["kernels"] = kb
+        out["roofline_pointwise"] = {"kernel": "ndq_pw_kernel (generated)", "bound": "hbm",
+                                     "achieved": kb["pointwise"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": kb["pointwise"]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                                     "algorithmic_bytes_per_point": kb["pointwise"]["bytes_per_point"]}
         tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
         if os.path.exists(tpath):      # HBM bytes per launch from the last committed rocprofv3 --pmc pass
             tr = json.load(open(tpath))
@@ -253,11 +258,6 @@ def main():
                 out["roofline"]["traffic"] = tr["kernels"][key]["hbm_bytes"]
                 out["roofline"]["traffic_note"] = tr["source"]
             out["roofline_pointwise"]["traffic"] = tr["kernels"]["pointwise"]["hbm_bytes"]
-        out["kernels"] = kb
-        out["roofline_pointwise"] = {"kernel": "ndq_pw_kernel (generated)", "bound": "hbm",
-                                     "achieved": kb["pointwise"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": kb["pointwise"]["gbs"] / HBM_PEAK_GBS, "traffic": None,
-                                     "algorithmic_bytes_per_point": kb["pointwise"]["bytes_per_point"]}
         # the same step with host sampling (CPU RNG, bit-exact with the reference) + PCIe upload inside it
         torch.manual_seed(2)
         solver.generator["train"] = SamplerGenerator(cfg["gen"])

@@ -137,22 +137,26 @@ template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
 };
 
 // ------------------------------------------------------------------------------------------------ config
-template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_>
+template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1>
 struct Cfg {
   using SS = Streams<D_, FIRST_, M2_>;
   static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
-  static constexpr int HP = H + 4;  // padded leading dimension of the transpose staging tiles
+  static constexpr int NOUT = NOUT_;               // output units; > 1: the output layer is an MFMA layer too
+  static constexpr int NBO = (NOUT_ + 15) / 16;    // 16-row blocks of the (zero-padded) output layer
+  static constexpr int HO = 16 * NBO;
+  static constexpr int HP = (H > HO ? H : HO) + 4;  // padded leading dimension of the transpose staging tiles
   // workgroup sizes: 8 waves (2 per SIMD, <= 256 registers each) when the per-wave state fits, else 4 waves with the
   // whole 512-entry register file per wave
-  static constexpr int BWD_THREADS = (NB_ * NB_ * (L_ - 1) + NB_ * SS::NS * L_ > 40) ? 256 : NDQ_BWD_THREADS;
+  static constexpr int BWD_THREADS =
+      (NB_ * NB_ * (L_ - 1) + NB_ * SS::NS * L_ + (NOUT_ > 1 ? NB_ * NBO : 0) > 40) ? 256 : NDQ_BWD_THREADS;
   static constexpr int FWD_THREADS = (NB_ >= 4) ? 256 : NDQ_FWD_THREADS;
   // flat parameter offsets, torch order: W1 (H,D) b1 (H) | W_l (H,H) b_l (H), l = 2..L | Wout (1,H) bout (1)
   static constexpr int offW1 = 0, offb1 = H * D;
   static constexpr int offW(int l) { return H * D + H + (l - 2) * (H * H + H); }  // l in 2..L
   static constexpr int offb(int l) { return offW(l) + H * H; }
   static constexpr int offWout = H * D + H + (L - 1) * (H * H + H);
-  static constexpr int offbout = offWout + H;
-  static constexpr int P = offbout + 1;
+  static constexpr int offbout = offWout + NOUT * H;
+  static constexpr int P = offbout + NOUT;
   // LDS carve (floats): W1T [D][H] | b1 [H] | per hidden-hidden layer: Wf [H*H] (+ Wt [H*H] for bwd) | b_l | Wout | bout
   static constexpr int ldsW1T = 0, ldsb1 = D * H;
   static constexpr int ldsLayer0 = D * H + H;
@@ -160,17 +164,19 @@ struct Cfg {
   static constexpr int ldsWf(int l, bool bwd) { return ldsLayer0 + (l - 2) * layerStride(bwd); }
   static constexpr int ldsWt(int l) { return ldsWf(l, true) + H * H; }
   static constexpr int ldsb(int l, bool bwd) { return ldsWf(l, bwd) + (bwd ? 2 : 1) * H * H; }
+  // output layer: NOUT == 1: Wout [H] | bout [1];  NOUT > 1: fragment-ordered Wo [HO*H] (+ transposed [HO*H]) | bout [HO]
   static constexpr int ldsWout(bool bwd) { return ldsLayer0 + (L - 1) * layerStride(bwd); }
-  static constexpr int ldsbout(bool bwd) { return ldsWout(bwd) + H; }
-  static constexpr int ldsWeightsEnd(bool bwd) { return (ldsbout(bwd) + 1 + 3) & ~3; }
+  static constexpr int ldsWoutT() { return ldsWout(true) + HO * H; }
+  static constexpr int ldsbout(bool bwd) { return ldsWout(bwd) + (NOUT == 1 ? H : (bwd ? 2 : 1) * HO * H); }
+  static constexpr int ldsWeightsEnd(bool bwd) { return (ldsbout(bwd) + (NOUT == 1 ? 1 : HO) + 3) & ~3; }
   static constexpr int stageFloatsPerWave = 2 * 16 * HP;  // Zt and Ht tiles of one stream
 };
 
 struct MlpArgs {
   const float* coords;   // [D][ldc]  SoA collocation coordinates
   const float* params;   // [P] flat, torch parameter order
-  const float* gbar;     // bwd: [NS][ldj] adjoint of every output stream
-  float* jets;           // fwd: [NS][ldj] output streams of the raw network
+  const float* gbar;     // bwd: [NS][NOUT][ldj] adjoint of every output stream
+  float* jets;           // fwd: [NS][NOUT][ldj] output streams of the raw network
   float* partials;       // bwd: [gridDim.x][P] per-workgroup parameter-gradient partial sums
   int n;                 // number of points
   int ldc;               // leading dimension of coords
@@ -186,11 +192,28 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
     const int a = i / H, j = i - a * H;
     lds[C::ldsW1T + i] = prm[C::offW1 + j * D + a];
   }
-  for (int i = tid; i < H; i += nt) {
-    lds[C::ldsb1 + i] = prm[C::offb1 + i];
-    lds[C::ldsWout(BWD) + i] = prm[C::offWout + i];
+  for (int i = tid; i < H; i += nt) lds[C::ldsb1 + i] = prm[C::offb1 + i];
+  if constexpr (C::NOUT == 1) {
+    for (int i = tid; i < H; i += nt) lds[C::ldsWout(BWD) + i] = prm[C::offWout + i];
+    if (tid == 0) lds[C::ldsbout(BWD)] = prm[C::offbout];
+  } else {
+    constexpr int NBO = C::NBO;
+    const float* Wo = prm + C::offWout;  // [NOUT][H], rows >= NOUT are zero padding
+    for (int i = tid; i < C::HO * H; i += nt) {
+      const int lane = i & 63, t = (i >> 6) & 3, blk = i >> 8;
+      {  // forward A operand of block (ob, kb): blk = ob*NB + kb:  A[i'][q'] = Wo[16 ob + i'][16 kb + 4 q' + t]
+        const int ob = blk / NB, kb = blk - ob * NB;
+        const int o = 16 * ob + (lane & 15);
+        lds[C::ldsWout(BWD) + i] = o < C::NOUT ? Wo[o * H + 16 * kb + 4 * (lane >> 4) + t] : 0.f;
+      }
+      if (BWD) {  // transposed A operand of block (kb, ob): blk = kb*NBO + ob:  A[i'][q'] = Wo[16 ob + 4 q' + t][16 kb + i']
+        const int kb = blk / NBO, ob = blk - kb * NBO;
+        const int o = 16 * ob + 4 * (lane >> 4) + t;
+        lds[C::ldsWoutT() + i] = o < C::NOUT ? Wo[o * H + 16 * kb + (lane & 15)] : 0.f;
+      }
+    }
+    for (int i = tid; i < C::HO; i += nt) lds[C::ldsbout(BWD) + i] = i < C::NOUT ? prm[C::offbout + i] : 0.f;
   }
-  if (tid == 0) lds[C::ldsbout(BWD)] = prm[C::offbout];
 #pragma unroll
   for (int l = 2; l <= C::L; ++l) {
     const float* W = prm + C::offW(l);
@@ -391,6 +414,47 @@ __device__ __forceinline__ float point_sum(float v) {  // sum over the 16 points
   return v;
 }
 
+// output layer (n_out = 1) on the VALU: out[s] = Wout . h[s] (+ bout on the value stream), identical in all 4 lane groups
+template <class C, bool BWD>
+__device__ __forceinline__ void tile_output(const float* lds, int q, const f32x4 (&h)[C::NS][C::NB], float (&out)[C::NS]) {
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) out[s] = 0.f;
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b) {
+    const f32x4 wo = lds4(lds + C::ldsWout(BWD) + 16 * b + 4 * q);
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[s] = fmaf(wo[r], h[s][b][r], out[s]);
+  }
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) out[s] = quad_sum(out[s]);
+  out[0] += lds[C::ldsbout(BWD)];
+}
+
+// output layer with NOUT > 1 as an MFMA layer: o[s][ob] = Wo h[s] (+ bout on the value stream); rows >= NOUT are zero
+template <class C, bool BWD>
+__device__ __forceinline__ void output_layer_mfma(const float* lds, int lane, int q, const f32x4 (&h)[C::NS][C::NB],
+                                                  f32x4 (&o)[C::NS][C::NBO]) {
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+    for (int ob = 0; ob < C::NBO; ++ob) o[s][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ob = 0; ob < C::NBO; ++ob) o[0][ob] = lds4(lds + C::ldsbout(BWD) + 16 * ob + 4 * q);
+  const float* w = lds + C::ldsWout(BWD);
+#pragma unroll
+  for (int ob = 0; ob < C::NBO; ++ob)
+#pragma unroll
+    for (int kb = 0; kb < C::NB; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float a = w[((ob * C::NB + kb) * 4 + t) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, h[s][kb][t], o[s][ob], 0, 0, 0);
+      }
+}
+
 // ------------------------------------------------------------------------------------------------ forward kernel
 template <class C>
 __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) {
@@ -415,23 +479,27 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
       hidden_layer<C, false>(lds, l, lane, q, h, st);
     }
     act_forward<C>(st, h);
-    float out[C::NS];
+    if constexpr (C::NOUT == 1) {
+      float out[C::NS];
+      tile_output<C, false>(lds, q, h, out);
+      if (q == 0 && n < a.n) {
 #pragma unroll
-    for (int s = 0; s < C::NS; ++s) out[s] = 0.f;
+        for (int s = 0; s < C::NS; ++s) a.jets[(size_t)s * a.ldj + n] = out[s];
+      }
+    } else {
+      f32x4 o[C::NS][C::NBO];
+      output_layer_mfma<C, false>(lds, lane, q, h, o);
+      if (n < a.n) {
 #pragma unroll
-    for (int b = 0; b < C::NB; ++b) {
-      const f32x4 wo = lds4(lds + C::ldsWout(false) + 16 * b + 4 * q);
+        for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-      for (int s = 0; s < C::NS; ++s)
+          for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[s] = fmaf(wo[r], h[s][b][r], out[s]);
-    }
-    const float bout = lds[C::ldsbout(false)];
-#pragma unroll
-    for (int s = 0; s < C::NS; ++s) {
-      float v = quad_sum(out[s]);
-      if (s == 0) v += bout;
-      if (q == 0 && n < a.n) a.jets[(size_t)s * a.ldj + n] = v;
+            for (int r = 0; r < 4; ++r) {
+              const int u = 16 * ob + 4 * q + r;
+              if (u < C::NOUT) a.jets[((size_t)s * C::NOUT + u) * a.ldj + n] = o[s][ob][r];
+            }
+      }
     }
   }
 }
@@ -454,17 +522,19 @@ struct GradAcc {
   float b1[C::NB][4];                // db1[j]                    (needs point_sum)
   f32x4 w[C::L > 1 ? C::L - 1 : 1][C::NB][C::NB];  // dW_l[16jb+4q+r][16kb+p], MFMA accumulators (already summed)
   float b[C::L > 1 ? C::L - 1 : 1][C::NB][4];      // db_l[j]     (needs point_sum)
-  float wout[C::NB][4];              // dWout[j]                  (needs point_sum)
-  float bout;                        // dbout                     (needs full wave sum)
+  float wout[C::NB][4];              // NOUT == 1: dWout[j]       (needs point_sum)
+  float bout;                        // NOUT == 1: dbout          (needs full wave sum)
+  f32x4 wo[C::NBO][C::NB];           // NOUT > 1: dWout[16ob+4q+r][16kb+p], MFMA accumulators
+  float bo[C::NBO][4];               // NOUT > 1: dbout[16ob+4q+r] (needs point_sum)
 };
 
 // dW_l += sum_s Zbar[s] H[s]^T over the 16 points of the tile, stream by stream through the LDS transpose tile.
 // stage: per-wave region of 2*16*HP floats.  Point <-> MFMA k mapping: k = q at step st  <->  point 4*q + st,
 // which makes both the b128 writes (8-lane groups: bank stride 4*(HP mod 8) ... HP = H+4 -> 16 B apart) and the b32
 // reads (32-lane groups: q*4*HP = 16 banks apart) conflict-free.
-template <class C>
-__device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q, const f32x4 (&zb)[C::NS][C::NB],
-                                            const LayerState<C>& st_in, f32x4 (&acc)[C::NB][C::NB]) {
+template <class C, int NBA>
+__device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q, const f32x4 (&zb)[C::NS][NBA],
+                                            const LayerState<C>& st_in, f32x4 (&acc)[NBA][C::NB]) {
   constexpr int HP = C::HP;
   float* Zt = stage;
   float* Ht = stage + 16 * HP;
@@ -473,23 +543,21 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
     f32x4 hs[C::NB];
     act_forward_stream<C, s>(st_in, hs);    // stream s of the layer's input activations, recomputed from its state
 #pragma unroll
-    for (int b = 0; b < C::NB; ++b) {
-      *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
-      *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = hs[b];
-    }
+    for (int b = 0; b < NBA; ++b) *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = hs[b];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-      float av[C::NB], bv[C::NB];
+      float av[NBA], bv[C::NB];
 #pragma unroll
-      for (int b = 0; b < C::NB; ++b) {
-        av[b] = Zt[(4 * q + st) * HP + 16 * b + p];
-        bv[b] = Ht[(4 * q + st) * HP + 16 * b + p];
-      }
+      for (int b = 0; b < NBA; ++b) av[b] = Zt[(4 * q + st) * HP + 16 * b + p];
 #pragma unroll
-      for (int jb = 0; jb < C::NB; ++jb)
+      for (int b = 0; b < C::NB; ++b) bv[b] = Ht[(4 * q + st) * HP + 16 * b + p];
+#pragma unroll
+      for (int jb = 0; jb < NBA; ++jb)
 #pragma unroll
         for (int kb = 0; kb < C::NB; ++kb)
           acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jb], bv[kb], acc[jb][kb], 0, 0, 0);
@@ -541,6 +609,13 @@ __device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
 #pragma unroll
       for (int kb = 0; kb < C::NB; ++kb) acc.w[l][jb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
   acc.bout = 0.f;
+#pragma unroll
+  for (int ob = 0; ob < C::NBO; ++ob) {
+#pragma unroll
+    for (int kb = 0; kb < C::NB; ++kb) acc.wo[ob][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc.bo[ob][r] = 0.f;
+  }
 }
 
 // forward pass of one tile keeping every layer's state; h = streams of the last hidden layer's activations
@@ -556,22 +631,35 @@ __device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, 
   act_forward<C>(st[C::L - 1], h);
 }
 
-// output layer (n_out = 1) on the VALU: out[s] = Wout . h[s] (+ bout on the value stream), identical in all 4 lane groups
-template <class C, bool BWD>
-__device__ __forceinline__ void tile_output(const float* lds, int q, const f32x4 (&h)[C::NS][C::NB], float (&out)[C::NS]) {
+template <class C>
+__device__ __forceinline__ void tile_backward_hidden(const float* lds, float* stage, int lane, int p, int q,
+                                                     const float (&x)[C::D], LayerState<C> (&st)[C::L],
+                                                     f32x4 (&g)[C::NS][C::NB], GradAcc<C>& acc);
+
+// reverse pass of one tile, multi-output network: go[s][ob] = dLoss/d out[s][16ob+4q+r] for the tile's points
+template <class C>
+__device__ __forceinline__ void tile_backward_multi(const float* lds, float* stage, int lane, int p, int q,
+                                                    const float (&x)[C::D], const f32x4 (&go)[C::NS][C::NBO],
+                                                    LayerState<C> (&st)[C::L], GradAcc<C>& acc) {
 #pragma unroll
-  for (int s = 0; s < C::NS; ++s) out[s] = 0.f;
+  for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
-  for (int b = 0; b < C::NB; ++b) {
-    const f32x4 wo = lds4(lds + C::ldsWout(BWD) + 16 * b + 4 * q);
+    for (int r = 0; r < 4; ++r) acc.bo[ob][r] += go[0][ob][r];
+  weight_grad<C, C::NBO>(stage, lane, p, q, go, st[C::L - 1], acc.wo);   // dWout += sum_s Gout[s] H_L[s]^T
+  f32x4 g[C::NS][C::NB];
+  zero_frag<C>(g);
+  const float* w = lds + C::ldsWoutT();
 #pragma unroll
-    for (int s = 0; s < C::NS; ++s)
+  for (int kb = 0; kb < C::NB; ++kb)                                       // hbar_L = Wout^T gout
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[s] = fmaf(wo[r], h[s][b][r], out[s]);
-  }
+    for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
-  for (int s = 0; s < C::NS; ++s) out[s] = quad_sum(out[s]);
-  out[0] += lds[C::ldsbout(BWD)];
+      for (int t = 0; t < 4; ++t) {
+        const float a = w[((kb * C::NBO + ob) * 4 + t) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) g[s][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, go[s][ob][t], g[s][kb], 0, 0, 0);
+      }
+  tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc);
 }
 
 // reverse pass of one tile: gout[s] = dLoss/d out[s] for the tile's points (0 for padding lanes)
@@ -579,7 +667,6 @@ template <class C>
 __device__ __forceinline__ void tile_backward(const float* lds, float* stage, int lane, int p, int q,
                                               const float (&x)[C::D], const float (&gout)[C::NS],
                                               LayerState<C> (&st)[C::L], GradAcc<C>& acc) {
-  using SS = typename C::SS;
   // ---------------- output layer adjoint (n_out = 1): hbar = Wout * gout; dWout += sum_s gout_s h_s; dbout += gout_0
   // (h_s of the last hidden layer is recomputed per stream from its state instead of being kept live)
   f32x4 g[C::NS][C::NB];
@@ -608,7 +695,15 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
     }
   }
   acc.bout += (q == 0) ? gout[0] : 0.f;
+  tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc);
+}
 
+// hidden layers L .. 2 and the first layer, given g = hbar of the last hidden layer
+template <class C>
+__device__ __forceinline__ void tile_backward_hidden(const float* lds, float* stage, int lane, int p, int q,
+                                                     const float (&x)[C::D], LayerState<C> (&st)[C::L],
+                                                     f32x4 (&g)[C::NS][C::NB], GradAcc<C>& acc) {
+  using SS = typename C::SS;
   // ---------------- hidden layers L .. 2
   sfor<C::L - 1>([&](auto k_) {
     constexpr int l = C::L - decltype(k_)::value;          // layer whose weights W_l (H x H) map h_{l-1} -> z_l
@@ -618,7 +713,7 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
     for (int b = 0; b < C::NB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc.b[l - 2][b][r] += g[0][b][r];
-    weight_grad<C>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2]);   // inputs of layer l = activations of layer l-1
+    weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2]);   // inputs of layer l = activations of layer l-1
 #if NDQ_HBAR_INPLACE
     gemm_frag_inplace<C>(lds + C::ldsWt(l), lane, g);                 // hbar_{l-1} = W_l^T zbar_l
 #else
@@ -666,12 +761,18 @@ __device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       acc.b1[b][r] = point_sum(acc.b1[b][r]);
-      acc.wout[b][r] = point_sum(acc.wout[b][r]);
+      if constexpr (C::NOUT == 1) acc.wout[b][r] = point_sum(acc.wout[b][r]);
 #pragma unroll
       for (int d = 0; d < C::D; ++d) acc.w1[d][b][r] = point_sum(acc.w1[d][b][r]);
 #pragma unroll
       for (int l = 0; l < C::L - 1; ++l) acc.b[l][b][r] = point_sum(acc.b[l][b][r]);
     }
+  if constexpr (C::NOUT > 1) {
+#pragma unroll
+    for (int ob = 0; ob < C::NBO; ++ob)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc.bo[ob][r] = point_sum(acc.bo[ob][r]);
+  }
   __syncthreads();  // every wave is done with its staging tile
   float* red = red0 + (wave % R) * PP;
   for (int k = 0; k * R < WAVES; ++k) {
@@ -687,7 +788,7 @@ __device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, 
           const int j = 16 * b + 4 * q + r;
           if (p == 0) {
             put(C::offb1 + j, acc.b1[b][r]);
-            put(C::offWout + j, acc.wout[b][r]);
+            if constexpr (C::NOUT == 1) put(C::offWout + j, acc.wout[b][r]);
 #pragma unroll
             for (int d = 0; d < C::D; ++d) put(C::offW1 + j * C::D + d, acc.w1[d][b][r]);
 #pragma unroll
@@ -703,7 +804,21 @@ __device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, 
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               put(C::offW(l + 2) + (16 * jb + 4 * q + r) * C::H + 16 * kb + p, acc.w[l][jb][kb][r]);
-      if (lane == 0) put(C::offbout, bsum);
+      if constexpr (C::NOUT == 1) {
+        if (lane == 0) put(C::offbout, bsum);
+      } else {
+#pragma unroll
+        for (int ob = 0; ob < C::NBO; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = 16 * ob + 4 * q + r;
+            if (u < C::NOUT) {
+              if (p == 0) put(C::offbout + u, acc.bo[ob][r]);
+#pragma unroll
+              for (int kb = 0; kb < C::NB; ++kb) put(C::offWout + u * C::H + 16 * kb + p, acc.wo[ob][kb][r]);
+            }
+          }
+      }
     }
     __syncthreads();
   }
@@ -730,15 +845,30 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
     const int nn = valid ? n : a.n - 1;
-    float x[C::D], gout[C::NS];
+    float x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
-#pragma unroll
-    for (int s = 0; s < C::NS; ++s) gout[s] = valid ? a.gbar[(size_t)s * a.ldj + nn] : 0.f;
     LayerState<C> st[C::L];
     f32x4 h[C::NS][C::NB];
     tile_forward<C, true>(lds, lane, q, x, st, h);
-    tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc);
+    if constexpr (C::NOUT == 1) {
+      float gout[C::NS];
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s) gout[s] = valid ? a.gbar[(size_t)s * a.ldj + nn] : 0.f;
+      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc);
+    } else {
+      f32x4 go[C::NS][C::NBO];
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+        for (int ob = 0; ob < C::NBO; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = 16 * ob + 4 * q + r;
+            go[s][ob][r] = (valid && u < C::NOUT) ? a.gbar[((size_t)s * C::NOUT + u) * a.ldj + nn] : 0.f;
+          }
+      tile_backward_multi<C>(lds, stage, lane, p, q, x, go, st, acc);
+    }
   }
   block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
 }
@@ -761,6 +891,7 @@ struct FusedArgs {
 
 template <class C, class PW, bool TRAIN>
 __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs a) {
+  static_assert(C::NOUT == 1, "the single-launch closure kernel needs a single-output network");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   stage_weights<C, TRAIN>(lds, a.params);
   __syncthreads();

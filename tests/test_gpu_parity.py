@@ -30,6 +30,10 @@ ARCH = {
     "c5": ((2, 64, 64, 64, 1), "tanh", 0, (2, 1, 5), [(), (0,), (1,), (0, 0), (1, 1)]),
     "c5p": ((2, 64, 64, 64, 1), "tanh", 0, (2, 1, 0), [(), (0,), (1,)]),
     "c2val": ((2, 32, 32, 1), "tanh", 0, (2, 0, 0), [()]),
+    # multi-output networks: C4's radial coefficient net (25 harmonics) and a 3-output 2-D net
+    "c4": ((1, 32, 32, 25), "tanh", 0, (1, 1, 1), [(), (0,), (0, 0)]),
+    "c4val": ((1, 32, 32, 25), "tanh", 0, (1, 0, 0), [()]),
+    "m3": ((2, 32, 32, 3), "tanh", 0, (2, 1, 5), [(), (0,), (1,), (0, 0), (1, 1)]),
 }
 SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8}
 
@@ -55,7 +59,7 @@ def L():
 def _desc(name):
     from neurodiffeq_amd import _lib
     dims, _, act, (d, first, mask2), _ = ARCH[name]
-    return _lib.MlpDesc(d, first, mask2, dims[1], len(dims) - 2, act, 1)
+    return _lib.MlpDesc(d, first, mask2, dims[1], len(dims) - 2, act, dims[-1])
 
 
 def _stream():
@@ -77,12 +81,12 @@ def _fwd(L, name, coords, flat):
     ld = (n + 63) // 64 * 64
     c = torch.zeros(dims[0], ld, device="cuda"); c[:, :n] = torch.from_numpy(coords)
     p = torch.from_numpy(flat).cuda()
-    jets = torch.full((len(streams), ld), float("nan"), device="cuda")
+    jets = torch.full((len(streams), dims[-1], ld), float("nan"), device="cuda")
     d = _desc(name)
     rc = L.ndq_mlp_jet_fwd(ctypes.byref(d), c.data_ptr(), ld, n, p.data_ptr(), jets.data_ptr(), ld, _stream())
     assert rc == 0, rc
     torch.cuda.synchronize()
-    return jets[:, :n].cpu().numpy()
+    return jets[:, :, :n].cpu().numpy()          # [NS][n_out][n]
 
 
 def _bwd(L, name, coords, flat, gbar):
@@ -90,7 +94,7 @@ def _bwd(L, name, coords, flat, gbar):
     n = coords.shape[1]
     ld = (n + 63) // 64 * 64
     c = torch.zeros(dims[0], ld, device="cuda"); c[:, :n] = torch.from_numpy(coords)
-    g = torch.zeros(len(streams), ld, device="cuda"); g[:, :n] = torch.from_numpy(gbar)
+    g = torch.zeros(len(streams), dims[-1], ld, device="cuda"); g[:, :, :n] = torch.from_numpy(gbar)
     p = torch.from_numpy(flat).cuda()
     d = _desc(name)
     nb = L.ndq_mlp_bwd_blocks(ctypes.byref(d), n)
@@ -127,25 +131,25 @@ def test_mlp_jet_fwd_matches_jet_oracle(L, name, n):
     want = J.mlp_jets(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)), streams)
     # rel-L2 per stream; for tiny batches a single stream value can be a near-cancellation of O(1) terms, so there
     # the denominator is floored at 10 % of the largest stream's RMS (absolute fp32 noise is what matters)
-    floor = (0.1 if n < 64 else 0.0) * np.sqrt(n) * max(np.sqrt(np.mean(want[m] ** 2)) for m in streams)
-    errs = {str(m): float(np.linalg.norm(got[s] - want[m][:, 0]) / max(np.linalg.norm(want[m][:, 0]), floor))
+    floor = (0.1 if n < 64 else 0.0) * np.sqrt(n * dims[-1]) * max(np.sqrt(np.mean(want[m] ** 2)) for m in streams)
+    errs = {str(m): float(np.linalg.norm(got[s].T - want[m]) / max(np.linalg.norm(want[m]), floor))
             for s, m in enumerate(streams)}
     diag(f"fwd_{name}_{n}", errs)
     assert np.isfinite(got).all()
     assert max(errs.values()) < TOL, errs
 
 
-@pytest.mark.parametrize("name", [k for k in ARCH if k != "c2val"] + ["c2val"])
+@pytest.mark.parametrize("name", list(ARCH))
 @pytest.mark.parametrize("n", [1, 17, 1000, 4099])
 def test_mlp_jet_bwd_matches_jet_oracle(L, name, n):
     dims, act, _, _, streams = ARCH[name]
     rng = np.random.default_rng(zlib.crc32(f"{name}/{n}/b".encode()))
     flat = _params(name, rng)
     coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
-    gbar = rng.standard_normal((len(streams), n)).astype(np.float32)
+    gbar = rng.standard_normal((len(streams), dims[-1], n)).astype(np.float32)
     got = _bwd(L, name, coords, flat, gbar)
     want = J.mlp_jets_vjp(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)),
-                          {m: gbar[s].astype(np.float64)[:, None] for s, m in enumerate(streams)})
+                          {m: gbar[s].astype(np.float64).T for s, m in enumerate(streams)})
     errs = {g: rel_l2(got[a:b], want[a:b]) for g, a, b in _groups(name)}
     errs["all"] = rel_l2(got, want)
     diag(f"bwd_{name}_{n}", errs)
@@ -161,13 +165,13 @@ def test_bwd_is_linear_in_gbar_and_deterministic(L):
     rng = np.random.default_rng(5)
     flat = _params(name, rng)
     coords = rng.uniform(0, 1, (2, n)).astype(np.float32)
-    g1 = rng.standard_normal((len(streams), n)).astype(np.float32)
-    g2 = rng.standard_normal((len(streams), n)).astype(np.float32)
+    g1 = rng.standard_normal((len(streams), 1, n)).astype(np.float32)
+    g2 = rng.standard_normal((len(streams), 1, n)).astype(np.float32)
     a, b = _bwd(L, name, coords, flat, g1), _bwd(L, name, coords, flat, g2)
     ab = _bwd(L, name, coords, flat, (2.0 * g1 - 0.5 * g2).astype(np.float32))
     again = _bwd(L, name, coords, flat, g1)
     h = n // 2
-    halves = _bwd(L, name, coords[:, :h], flat, g1[:, :h]) + _bwd(L, name, coords[:, h:], flat, g1[:, h:])
+    halves = _bwd(L, name, coords[:, :h], flat, g1[:, :, :h]) + _bwd(L, name, coords[:, h:], flat, g1[:, :, h:])
     res = dict(linearity=rel_l2(ab, 2.0 * a - 0.5 * b), shard_additivity=rel_l2(halves, a),
                bit_exact_rerun=bool(np.array_equal(a, again)))
     diag("bwd_properties_c2_full", res)
