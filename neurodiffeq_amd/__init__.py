@@ -7,6 +7,6 @@ Same names as the reference package (``diff``, ``operators``, ``networks.FCNN``,
 Unlike the reference (``__init__.py:22``) importing this package does not change torch's global default dtype or
 device; the fused path is fp32 and puts the networks on the GPU itself."""
 from .neurodiffeq import diff, safe_diff, unsafe_diff  # noqa: F401
-from . import operators, networks, conditions, generators, solvers, losses, utils  # noqa: F401
+from . import operators, networks, conditions, generators, solvers, losses, utils, function_basis  # noqa: F401
 
 __version__ = "0.1.0"

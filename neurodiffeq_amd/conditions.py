@@ -12,7 +12,7 @@ import warnings
 import torch
 
 from .neurodiffeq import safe_diff as diff
-from .symbolic import Sym, TraceUnsupported, current_graph
+from .symbolic import Sym, SymMat, TraceUnsupported, current_graph
 
 
 def _const_like(ref, value):
@@ -23,7 +23,7 @@ def _const_like(ref, value):
 
 
 def _exp(x):
-    return x.exp() if isinstance(x, Sym) else torch.exp(x)
+    return x._un("exp") if isinstance(x, (Sym, SymMat)) else torch.exp(x)
 
 
 def _raw_output(net, coordinates, ith_unit):
@@ -77,7 +77,7 @@ class EnsembleCondition(BaseCondition):
 
     def parameterize(self, output_tensor, *input_tensors):
         if isinstance(output_tensor, Sym):
-            raise TraceUnsupported("EnsembleCondition on a multi-output network")
+            output_tensor = SymMat([output_tensor])
         if output_tensor.shape[1] != len(self.conditions):
             raise ValueError(f"number of output units ({output_tensor.shape[1]}) "
                              f"differs from number of conditions ({len(self.conditions)})")
@@ -198,3 +198,75 @@ class IBVP1D(BaseCondition):
             + 0.5 * xt ** 2 * w * delta(self.x_max_prime)
         d0 = diff(u0, x0)
         return a + grow * (u - xt * w * d0 + 0.5 * xt ** 2 * w * (d0 - diff(u1, x1)))
+
+
+# ------------------------------------------------------------------------------------------------- spherical shells
+def _abs(x):
+    return x._un("abs") if isinstance(x, (Sym, SymMat)) else torch.abs(x)
+
+
+def _tanh(x):
+    return x._un("tanh") if isinstance(x, (Sym, SymMat)) else torch.tanh(x)
+
+
+class DirichletBVPSpherical(BaseCondition):
+    """u(r0,θ,φ) = f(θ,φ) and optionally u(r1,θ,φ) = g(θ,φ) on a spherical shell (conditions.py:887-945)."""
+
+    def __init__(self, r_0, f, r_1=None, g=None):
+        super().__init__()
+        if (r_1 is None) ^ (g is None):
+            raise ValueError(f"r_1 and g must be both/neither set to None; got r_1={r_1}, g={g}")
+        self.r_0, self.r_1, self.f, self.g = r_0, r_1, f, g
+
+    def parameterize(self, output_tensor, r, theta, phi):
+        if self.r_1 is None:
+            return (1 - _exp(-_abs(r - self.r_0))) * output_tensor + self.f(theta, phi)
+        s = (r - self.r_0) / (self.r_1 - self.r_0)
+        return self.f(theta, phi) * (1 - s) + self.g(theta, phi) * s + (1. - _exp((1 - s) * s)) * output_tensor
+
+
+class InfDirichletBVPSpherical(BaseCondition):
+    """u(r0) = f, u(r→∞) = g (conditions.py:948-1001)."""
+
+    def __init__(self, r_0, f, g, order=1):
+        super().__init__()
+        self.r_0, self.f, self.g, self.order = r_0, f, g, order
+
+    def parameterize(self, output_tensor, r, theta, phi):
+        dr = r - self.r_0
+        decay, rise = _exp(-self.order * dr), _tanh(dr)
+        return self.f(theta, phi) * decay + self.g(theta, phi) * rise + decay * rise * output_tensor
+
+
+class DirichletBVPSphericalBasis(BaseCondition):
+    """Dirichlet data for the vector of harmonic coefficients R(r) (one network output per basis function) on one or
+    two spherical boundaries (conditions.py:1004-1096); ``R_0`` / ``R_1`` are scalars or length-k rows."""
+
+    def __init__(self, r_0, R_0, r_1=None, R_1=None, max_degree=None):
+        super().__init__()
+        if (r_1 is None) ^ (R_1 is None):
+            raise ValueError(f"r_1 and R_1 must be both/neither set to None; got r_1={r_1}, R_1={R_1}")
+        if max_degree is not None:
+            warnings.warn("`max_degree` is deprecated and ignored", FutureWarning)
+        self.r_0, self.r_1, self.R_0, self.R_1 = r_0, r_1, R_0, R_1
+
+    def parameterize(self, output_tensor, r):
+        if self.r_1 is None:
+            return (1 - _exp(-r + self.r_0)) * output_tensor + self.R_0
+        s = (r - self.r_0) / (self.r_1 - self.r_0)
+        return self.R_0 * (1 - s) + self.R_1 * s + (1. - _exp((1 - s) * s)) * output_tensor
+
+
+class InfDirichletBVPSphericalBasis(BaseCondition):
+    """Coefficient-vector version of :class:`InfDirichletBVPSpherical` (conditions.py:1099-1166)."""
+
+    def __init__(self, r_0, R_0, R_inf, order=1, max_degree=None):
+        super().__init__()
+        if max_degree is not None:
+            warnings.warn("`max_degree` is deprecated and ignored", FutureWarning)
+        self.r_0, self.R_0, self.R_inf, self.order = r_0, R_0, R_inf, order
+
+    def parameterize(self, output_tensor, r):
+        dr = r - self.r_0
+        decay, rise = _exp(-self.order * dr), _tanh(dr)
+        return self.R_0 * decay + self.R_inf * rise + decay * rise * output_tensor

@@ -160,6 +160,72 @@ class Generator2D(BaseGenerator):
         return d
 
 
+class GeneratorSpherical(BaseGenerator):
+    """Points (r, theta, phi) with directions uniform-ish on the sphere (generators.py:572-655); same draw order as the
+    reference: three ``rand`` for the direction, three ``randint`` signs, then the radius."""
+
+    def __init__(self, size, r_min=0., r_max=1., method="equally-spaced-noisy"):
+        super().__init__()
+        if r_min < 0 or r_max < r_min:
+            raise ValueError(f"Illegal range [{r_min}, {r_max}]")
+        if method == "equally-spaced-noisy":        # r^2 ~ U[r_min^2, r_max^2]
+            lo, span = r_min ** 2, r_max ** 2 - r_min ** 2
+            self.get_r = lambda: torch.sqrt(span * torch.rand(self.shape, device=_CPU) + lo)
+        elif method == "equally-radius-noisy":      # r ~ U[r_min, r_max]
+            lo, span = r_min, r_max - r_min
+            self.get_r = lambda: span * torch.rand(self.shape, device=_CPU) + lo
+        else:
+            raise ValueError(f"Unknown method: {method}")
+        self.size, self.r_min, self.r_max, self.method = size, r_min, r_max, method
+        self.shape = (size,)
+
+    def get_examples(self):
+        a, b, c = (torch.rand(self.shape, device=_CPU) for _ in range(3))
+        denom = a + b + c
+        eps = 1e-6
+        x, y, z = (torch.sqrt(v / denom) + eps for v in (a, b, c))
+        sx, sy, sz = (torch.randint(0, 2, self.shape, dtype=x.dtype, device=_CPU) * 2 - 1 for _ in range(3))
+        x, y, z = x * sx, y * sy, z * sz
+        theta = torch.acos(z).requires_grad_(True)
+        phi = (-torch.atan2(y, x) + np.pi).requires_grad_(True)   # atan2 ranges (-pi, pi]; shift to [0, 2pi)
+        r = self.get_r().requires_grad_(True)
+        return r, theta, phi
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(r_min=self.r_min, r_max=self.r_max, method=self.method)
+        return d
+
+
+class Generator3D(BaseGenerator):
+    """Points on a (noisy) 3-D grid (generators.py:317-416)."""
+
+    def __init__(self, grid=(10, 10, 10), xyz_min=(0.0, 0.0, 0.0), xyz_max=(1.0, 1.0, 1.0),
+                 method="equally-spaced-noisy"):
+        super().__init__()
+        self.grid, self.size = grid, grid[0] * grid[1] * grid[2]
+        self.xyz_min, self.xyz_max, self.method = xyz_min, xyz_max, method
+        if method in ("equally-spaced", "equally-spaced-noisy"):
+            axes = [torch.linspace(xyz_min[i], xyz_max[i], grid[i], requires_grad=True, device=_CPU) for i in range(3)]
+        elif method in ("chebyshev", "chebyshev1"):
+            axes = [_chebyshev_first(xyz_min[i], xyz_max[i], grid[i]) for i in range(3)]
+        elif method == "chebyshev2":
+            axes = [_chebyshev_second(xyz_min[i], xyz_max[i], grid[i]) for i in range(3)]
+        else:
+            raise ValueError(f"Unknown method: {method}")
+        gx, gy, gz = torch.meshgrid(*axes, indexing="ij")
+        self.grid_x, self.grid_y, self.grid_z = gx.flatten(), gy.flatten(), gz.flatten()
+        if method == "equally-spaced-noisy":
+            self.noise_std = [((xyz_max[i] - xyz_min[i]) / grid[i]) / 4.0 for i in range(3)]
+            self.getter = lambda: tuple(torch.normal(mean=m, std=s) for m, s in
+                                        zip((self.grid_x, self.grid_y, self.grid_z), self.noise_std))
+        else:
+            self.getter = lambda: (self.grid_x, self.grid_y, self.grid_z)
+
+    def get_examples(self):
+        return self.getter()
+
+
 class ConcatGenerator(BaseGenerator):
     """``g1 + g2``: concatenated samples (generators.py:658-691)."""
 

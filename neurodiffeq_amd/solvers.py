@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from . import _lib
 from .conditions import BaseCondition
-from .generators import Generator1D, Generator2D, SamplerGenerator
+from .generators import Generator1D, Generator2D, GeneratorSpherical, SamplerGenerator
 from .losses import _losses
 from .networks import FCNN
 from .optim import FusedAdam
@@ -591,6 +591,79 @@ class Solution1D(GenericSolution):
 
 class Solution2D(GenericSolution):
     pass
+
+
+class SolutionSpherical(GenericSolution):
+    """u(r, theta, phi) of a network that takes all three coordinates (solvers.py:971-980)."""
+
+
+class SolutionSphericalHarmonics(SolutionSpherical):
+    """u = sum_k R_k(r) Y_k(theta, phi) with the network producing the coefficient vector R (solvers.py:983-1018)."""
+
+    def __init__(self, nets, conditions, max_degree=None, harmonics_fn=None):
+        super().__init__(nets, conditions)
+        if harmonics_fn is None and max_degree is None:
+            raise ValueError("harmonics_fn should be specified")
+        if max_degree is not None:
+            warnings.warn("`max_degree` is DEPRECATED; pass `harmonics_fn` instead, which takes precedence",
+                          FutureWarning)
+            from .function_basis import RealSphericalHarmonics
+            self.harmonics_fn = RealSphericalHarmonics(max_degree=max_degree)
+        if harmonics_fn is not None:
+            self.harmonics_fn = harmonics_fn
+
+    def _compute_u(self, net, condition, rs, thetas, phis):
+        return torch.sum(condition.enforce(net, rs) * self.harmonics_fn(thetas, phis), dim=1)
+
+
+class SolverSpherical(BaseSolver):
+    """PDE systems in spherical coordinates (r, theta, phi) (solvers.py:761-968).  ``enforcer(net, cond, coords)``
+    replaces ``cond.enforce(net, *coords)`` -- e.g. the harmonic expansion
+    ``(cond.enforce(net, r) * Y(theta, phi)).sum(1, keepdim=True)`` of pde_spherical.py:253-254."""
+
+    def __init__(self, pde_system, conditions, r_min=None, r_max=None, nets=None, train_generator=None,
+                 valid_generator=None, analytic_solutions=None, optimizer=None, loss_fn=None, n_batches_train=1,
+                 n_batches_valid=4, metrics=None, enforcer=None, n_output_units=1, shuffle=None, batch_size=None):
+        if (train_generator is None or valid_generator is None) and (r_min is None or r_max is None):
+            raise ValueError(f"Either generator is not provided, r_min and r_max should be both provided: "
+                             f"got r_min={r_min}, r_max={r_max}, train_generator={train_generator}, "
+                             f"valid_generator={valid_generator}")
+        if train_generator is None:
+            train_generator = GeneratorSpherical(512, r_min, r_max, method="equally-spaced-noisy")
+        if valid_generator is None:
+            valid_generator = GeneratorSpherical(512, r_min, r_max, method="equally-spaced-noisy")
+        self.r_min, self.r_max = r_min, r_max
+        self.enforcer = enforcer
+        super().__init__(diff_eqs=pde_system, conditions=conditions, nets=nets, train_generator=train_generator,
+                         valid_generator=valid_generator, analytic_solutions=analytic_solutions, optimizer=optimizer,
+                         loss_fn=loss_fn, n_batches_train=n_batches_train, n_batches_valid=n_batches_valid,
+                         metrics=metrics, n_input_units=3, n_output_units=n_output_units, shuffle=shuffle,
+                         batch_size=batch_size)
+
+    def _auto_enforce(self, net, cond, *coordinates):
+        if self.enforcer:
+            return self.enforcer(net, cond, coordinates)
+        # fill cond.enforce with as many leading coordinates as its parameterisation takes
+        fn = cond.parameterize if cond.__class__.enforce == BaseCondition.enforce else cond.enforce
+        n_params = len(inspect.signature(fn).parameters)
+        return cond.enforce(net, *coordinates[:n_params - 1])
+
+    def compute_func_val(self, net, cond, *coordinates):
+        return self._auto_enforce(net, cond, *coordinates)
+
+    def get_solution(self, copy=True, best=True, harmonics_fn=None):
+        nets = self.best_nets if best else self.nets
+        conditions = self.conditions
+        if copy:
+            nets, conditions = deepcopy(nets), deepcopy(conditions)
+        if harmonics_fn:
+            return SolutionSphericalHarmonics(nets, conditions, harmonics_fn=harmonics_fn)
+        return SolutionSpherical(nets, conditions)
+
+    def _get_internal_variables(self):
+        d = super()._get_internal_variables()
+        d.update(r_min=self.r_min, r_max=self.r_max, enforcer=self.enforcer)
+        return d
 
 
 class GenericSolver(BaseSolver):

@@ -15,7 +15,7 @@ import numbers
 
 import torch
 
-__all__ = ["Sym", "Graph", "TraceUnsupported", "is_sym", "sym_diff"]
+__all__ = ["Sym", "SymMat", "Graph", "TraceUnsupported", "is_sym", "sym_diff"]
 
 
 class TraceUnsupported(Exception):
@@ -60,9 +60,11 @@ class Graph:
             raise TraceUnsupported("network evaluated at two different coordinate tuples")
         n_out = self._net_nouts[k]
         self.net_nout[k] = n_out
-        if n_out != 1:
-            raise TraceUnsupported("multi-output networks are not on the fused path yet")
-        return Sym(self, self.net(k, 0 if ith_unit is None else ith_unit))
+        if ith_unit is not None:
+            return Sym(self, self.net(k, ith_unit))
+        if n_out == 1:
+            return Sym(self, self.net(k, 0))
+        return SymMat([Sym(self, self.net(k, o)) for o in range(n_out)])
 
     # -------------------------------------------------------------- construction
     def _mk(self, key):
@@ -307,6 +309,21 @@ class trace_scope:
         _CURRENT.pop()
 
 
+def _row_values(v):
+    """A constant row vector (tensor / ndarray / list with more than one element) as a list of floats, else None."""
+    if isinstance(v, torch.Tensor) and v.numel() > 1:
+        return [float(x) for x in v.detach().reshape(-1).tolist()]
+    try:
+        import numpy as np
+        if isinstance(v, np.ndarray) and v.size > 1:
+            return [float(x) for x in v.reshape(-1)]
+    except Exception:  # pragma: no cover
+        pass
+    if isinstance(v, (list, tuple)) and len(v) > 1 and all(isinstance(x, numbers.Number) for x in v):
+        return [float(x) for x in v]
+    return None
+
+
 def _as_node(g, v):
     if isinstance(v, Sym):
         if v.g is not g:
@@ -386,6 +403,11 @@ class Sym:
     # ---- arithmetic
     def _bin(self, other, op, rev=False):
         g = self.g
+        if isinstance(other, SymMat):
+            return other._bin(self, op, rev=not rev)
+        row = _row_values(other)
+        if row is not None:          # column (N,1) with a constant row (k,) broadcasts to an (N,k) matrix
+            return SymMat([self] * len(row))._bin(other, op, rev)
         try:
             o = _as_node(g, other)
         except TraceUnsupported:
@@ -451,9 +473,106 @@ class Sym:
         return f"Sym#{self.i}{self.g.nodes[self.i]}"
 
 
+class SymMat:
+    """Proxy for an ``(N, k)`` matrix inside a trace: k traced columns (multi-output networks, function bases)."""
+    __array_priority__ = 10000
+    __array_ufunc__ = None
+
+    def __init__(self, cols):
+        self.cols = list(cols)
+        self.g = self.cols[0].g
+
+    @property
+    def shape(self):
+        return torch.Size([self.cols[0].shape[0], len(self.cols)])
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 2
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        if isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None):
+            j = idx[1]
+            if isinstance(j, int):
+                return self.cols[j]                     # caller reshapes with .view(-1, 1), a no-op here
+            if isinstance(j, slice):
+                sub = self.cols[j]
+                return sub[0] if len(sub) == 1 else SymMat(sub)
+        raise TraceUnsupported("only column selection is supported on a traced matrix")
+
+    def _operand_cols(self, other):
+        k = len(self.cols)
+        if isinstance(other, SymMat):
+            if len(other.cols) != k:
+                raise TraceUnsupported("traced matrices of different widths")
+            return [c.i for c in other.cols]
+        row = _row_values(other)
+        if row is not None:
+            if len(row) != k:
+                raise TraceUnsupported("constant row of the wrong width")
+            return [self.g.const(v) for v in row]
+        n = _as_node(self.g, other)
+        return [n] * k
+
+    def _bin(self, other, op, rev=False):
+        try:
+            oc = self._operand_cols(other)
+        except TraceUnsupported:
+            return NotImplemented
+        g = self.g
+        f = getattr(g, op)
+        return SymMat([Sym(g, f(o, c.i) if rev else f(c.i, o)) for c, o in zip(self.cols, oc)])
+
+    def __add__(self, o): return self._bin(o, "add")
+    def __radd__(self, o): return self._bin(o, "add", True)
+    def __sub__(self, o): return self._bin(o, "sub")
+    def __rsub__(self, o): return self._bin(o, "sub", True)
+    def __mul__(self, o): return self._bin(o, "mul")
+    def __rmul__(self, o): return self._bin(o, "mul", True)
+    def __truediv__(self, o): return self._bin(o, "div")
+    def __rtruediv__(self, o): return self._bin(o, "div", True)
+    def __neg__(self): return SymMat([-c for c in self.cols])
+    def __pow__(self, e): return SymMat([c ** e for c in self.cols])
+
+    def _un(self, op):
+        return SymMat([c._un(op) for c in self.cols])
+
+    def sum(self, dim=None, keepdim=False, keepdims=None, **kw):
+        if keepdims is not None:
+            keepdim = keepdims
+        if dim not in (1, -1):
+            raise TraceUnsupported("only row sums (dim=1) of a traced matrix are supported")
+        acc = self.cols[0]
+        for c in self.cols[1:]:
+            acc = acc + c
+        return acc                                      # (N,) and (N,1) are the same traced column
+
+    def view(self, *shape):
+        return self.reshape(*shape)
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        if tuple(shape) in ((-1, len(self.cols)), (self.shape[0], len(self.cols))):
+            return self
+        raise TraceUnsupported(f"reshape of a traced matrix to {shape}")
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return Sym.__torch_function__(func, types, args, kwargs)
+
+    def __repr__(self):
+        return f"SymMat[{len(self.cols)} cols]"
+
+
 def _first_sym(*args):
     for a in args:
-        if isinstance(a, Sym):
+        if isinstance(a, (Sym, SymMat)):
             return a
     raise TraceUnsupported("no traced operand")
 
@@ -464,9 +583,16 @@ def _tf_unary(op):
     return f
 
 
+_PY_OPS = {"add": lambda a, b: a + b, "sub": lambda a, b: a - b, "mul": lambda a, b: a * b, "div": lambda a, b: a / b}
+
+
 def _tf_bin(op):
     def f(a, b, *rest, alpha=None, **k):
         s = _first_sym(a, b)
+        if isinstance(a, SymMat) or isinstance(b, SymMat) or _row_values(a) is not None or _row_values(b) is not None:
+            if alpha is not None:
+                b = b * alpha
+            return s._bin(b, op) if s is a else s._bin(a, op, True)
         g = s.g
         nb = _as_node(g, b)
         if alpha is not None:
@@ -477,8 +603,32 @@ def _tf_bin(op):
 
 def _tf_like(value):
     def f(x, *a, **k):
+        if isinstance(x, SymMat):
+            return SymMat([Sym(x.g, x.g.const(value)) for _ in x.cols])
         return Sym(x.g, x.g.const(value))
     return f
+
+
+def _tf_cat(tensors, dim=0, **k):
+    if dim not in (1, -1):
+        raise TraceUnsupported("torch.cat of traced columns along dim 0")
+    cols = []
+    for t in tensors:
+        if isinstance(t, SymMat):
+            cols += t.cols
+        elif isinstance(t, Sym):
+            cols.append(t)
+        else:
+            raise TraceUnsupported("torch.cat mixing traced and concrete tensors")
+    return SymMat(cols)
+
+
+def _tf_sum(x, dim=None, keepdim=False, **k):
+    if isinstance(x, SymMat):
+        return x.sum(dim=dim, keepdim=keepdim)
+    if dim in (1, -1):
+        return x
+    raise TraceUnsupported("reductions over the batch inside the traced region")
 
 
 def _tf_full_like(x, fill_value, **k):
@@ -503,11 +653,12 @@ _TORCH_FUNCS = {
     "pow": _tf_pow,
     "ones_like": _tf_like(1.0), "zeros_like": _tf_like(0.0), "full_like": _tf_full_like,
     "clone": lambda x, **k: x,
+    "cat": _tf_cat, "concat": _tf_cat, "sum": _tf_sum,
 }
 
 
 def is_sym(x):
-    return isinstance(x, Sym)
+    return isinstance(x, (Sym, SymMat))
 
 
 def sym_diff(u, t, order=1):

@@ -131,6 +131,45 @@ def ibvp1d_dd(x0, x1, t0, u_init, g_left, h_right):
     return enforce
 
 
+def dirichlet_bvp_spherical_basis(r0, R0, r1, R1):
+    """Coefficient-vector Dirichlet condition on a spherical shell (conditions.py:1089-1096):
+    R = R0 (1 - rt) + R1 rt + (1 - exp((1 - rt) rt)) N(r),  rt = (r - r0)/(r1 - r0); the net sees r only."""
+    def enforce(net, r):
+        rt = (r - r0) / (r1 - r0)
+        return R0 * (1 - rt) + R1 * rt + (1. - torch.exp((1 - rt) * rt)) * net(r)
+    return enforce
+
+
+def real_spherical_harmonics(theta, phi, max_degree=4):
+    """(N,1),(N,1) -> (N,(max_degree+1)^2): real harmonics l <= 4 in the reference's normalisation
+    (function_basis.py:200-229; textbook closed forms)."""
+    s, c, sp, cp, c2p = torch.sin(theta), torch.cos(theta), torch.sin(phi), torch.cos(phi), torch.cos(2 * phi)
+    bands = [
+        [torch.ones_like(theta) * 0.5],
+        [s * sp * 0.866025404, c * 0.866025404, s * cp * 0.866025404],
+        [s ** 2 * sp * cp * 1.936491673, s * c * sp * 1.936491673, (2 * c ** 2 - s ** 2) * 0.559016994,
+         s * c * cp * 1.936491673, s ** 2 * c2p * 0.968245837],
+        [s ** 3 * (3 * cp ** 2 * sp - sp ** 3) * 1.045825033, s ** 2 * c * cp * sp * 5.123475383,
+         s * (4 * c ** 2 - s ** 2) * sp * 0.810092587, (2 * c ** 3 - 3 * c * s ** 2) * 0.661437828,
+         s * (4 * c ** 2 - s ** 2) * cp * 0.810092587, c * s ** 2 * c2p * 2.561737691,
+         s ** 3 * (cp ** 3 - 3 * sp ** 2 * cp) * 1.045825033],
+        [s ** 4 * (sp * cp * c2p) * 4.437059837, s ** 3 * c * (3 * cp ** 2 * sp - sp ** 3) * 3.1374751,
+         s ** 2 * (sp * cp) * (7 * c ** 2 - 1) * 1.677050983, s * c * sp * (7 * c ** 2 - 3) * 1.185854123,
+         (35 * c ** 4 - 30 * c ** 2 + 3) * 0.1875, s * c * cp * (7 * c ** 2 - 3) * 1.185854123,
+         s ** 2 * c2p * (7 * c ** 2 - 1) * 0.838525492, s ** 3 * c * (cp ** 3 - 3 * cp * sp ** 2) * 3.1374751,
+         s ** 4 * (cp ** 4 - 6 * cp ** 2 * sp ** 2 + sp ** 4) * 1.109264959],
+    ]
+    return torch.cat([y for band in bands[:max_degree + 1] for y in band], dim=1)
+
+
+def spherical_laplacian(u, r, theta, phi):
+    """operators.py:203-207 with ref_diff."""
+    u_r, u_t, u_p = ref_diff(u, r), ref_diff(u, theta), ref_diff(u, phi)
+    st = torch.sin(theta)
+    r2 = r ** 2
+    return (ref_diff(r2 * u_r, r) + ref_diff(st * u_t, theta) / st + ref_diff(u_p, phi) / st ** 2) / r2
+
+
 # ------------------------------------------------------------------------------------------- generators
 def sample_1d(n, t_min, t_max, dtype=torch.float32):
     """'equally-spaced-noisy' Generator1D (generators.py:139-158): normal(mean=linspace, std=(range/n)/4)."""
@@ -149,6 +188,23 @@ def sample_2d(grid, xy_min, xy_max, dtype=torch.float32):
     sx = ((xy_max[0] - xy_min[0]) / grid[0]) / 4.0
     sy = ((xy_max[1] - xy_min[1]) / grid[1]) / 4.0
     return lambda: (torch.normal(mean=mx, std=sx), torch.normal(mean=my, std=sy))
+
+
+def sample_spherical(n, r_min, r_max, dtype=torch.float32):
+    """GeneratorSpherical 'equally-spaced-noisy' (generators.py:622-646): 3 rand + 3 randint + 1 rand, in that order."""
+    def draw():
+        a, b, c = torch.rand(n, dtype=dtype), torch.rand(n, dtype=dtype), torch.rand(n, dtype=dtype)
+        denom = a + b + c
+        x, y, z = torch.sqrt(a / denom) + 1e-6, torch.sqrt(b / denom) + 1e-6, torch.sqrt(c / denom) + 1e-6
+        sx = torch.randint(0, 2, (n,), dtype=dtype) * 2 - 1
+        sy = torch.randint(0, 2, (n,), dtype=dtype) * 2 - 1
+        sz = torch.randint(0, 2, (n,), dtype=dtype) * 2 - 1
+        x, y, z = x * sx, y * sy, z * sz
+        theta = torch.acos(z)
+        phi = -torch.atan2(y, x) + PI
+        r = torch.sqrt((r_max ** 2 - r_min ** 2) * torch.rand(n, dtype=dtype) + r_min ** 2)
+        return r, theta, phi
+    return draw
 
 
 # ------------------------------------------------------------------------------------------- closure / loop
@@ -231,4 +287,19 @@ def build_config(name, size=None, dtype=torch.float32):
             return [mx, my, d(u, x) + d(v, y)]
         return dict(nets=nets, enforcers=enf, pde=pde, sampler=sample_2d((g, g), (0, 0), (1, 1), dtype),
                     n_points=g * g)
+    if name == "c4":      # Poisson in a spherical shell, harmonic expansion (tests/test_pde_spherical.py:103-175 shape)
+        n = size or 131072
+        r0, r1 = 0.1, 3.0
+        gauss = 1.0 / (2 * PI) ** 1.5
+        kq = 1.0 / (4 * PI)
+        v0 = kq / r0 * math.erf(r0 / math.sqrt(2.0))
+        v1 = kq / r1 * math.erf(r1 / math.sqrt(2.0))
+        # boundary coefficient rows are fp32 data (as a user script under set_tensor_type(float_bits=32) makes them)
+        R0 = torch.zeros(25, dtype=torch.float32); R0[0] = 2 * v0; R0 = R0.to(dtype)
+        R1 = torch.zeros(25, dtype=torch.float32); R1[0] = 2 * v1; R1 = R1.to(dtype)
+        nets = [make_fcnn(1, 25, (32, 32), "tanh", dtype)]
+        cond = dirichlet_bvp_spherical_basis(r0, R0, r1, R1)
+        enf = [lambda net, r, th, ph: (cond(net, r) * real_spherical_harmonics(th, ph)).sum(dim=1, keepdim=True)]
+        pde = lambda u, r, th, ph: [spherical_laplacian(u, r, th, ph) + gauss * torch.exp(-r ** 2 / 2)]
+        return dict(nets=nets, enforcers=enf, pde=pde, sampler=sample_spherical(n, r0, r1, dtype), n_points=n)
     raise KeyError(name)

@@ -29,9 +29,11 @@ import neurodiffeq  # noqa: E402  (sets default dtype fp64 + default device as a
 from neurodiffeq import diff
 from neurodiffeq.utils import set_tensor_type
 from neurodiffeq.networks import FCNN, SinActv
-from neurodiffeq.conditions import IVP, DirichletBVP2D, IBVP1D, NoCondition
-from neurodiffeq.generators import Generator1D, Generator2D
-from neurodiffeq.solvers import Solver1D, Solver2D
+from neurodiffeq.conditions import IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis
+from neurodiffeq.generators import Generator1D, Generator2D, GeneratorSpherical
+from neurodiffeq.solvers import Solver1D, Solver2D, SolverSpherical
+from neurodiffeq.function_basis import RealSphericalHarmonics
+from neurodiffeq.operators import spherical_laplacian
 
 set_tensor_type(device="cpu", float_bits=32)
 PI = np.pi
@@ -89,7 +91,25 @@ def cfg_c5(g=8):
     return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen)
 
 
-CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5}
+def cfg_c4(n=96):
+    import math
+    r0, r1 = 0.1, 3.0
+    gauss = 1.0 / (2 * PI) ** 1.5
+    kq = 1.0 / (4 * PI)
+    v0 = kq / r0 * math.erf(r0 / math.sqrt(2.0))
+    v1 = kq / r1 * math.erf(r1 / math.sqrt(2.0))
+    R0 = torch.zeros(25); R0[0] = 2 * v0
+    R1 = torch.zeros(25); R1[0] = 2 * v1
+    Y = RealSphericalHarmonics(max_degree=4)
+    pde = lambda u, r, th, ph: [spherical_laplacian(u, r, th, ph) + gauss * torch.exp(-r ** 2 / 2)]
+    nets = [FCNN(1, 25, hidden_units=(32, 32))]
+    conds = [DirichletBVPSphericalBasis(r_0=r0, R_0=R0, r_1=r1, R_1=R1)]
+    gen = GeneratorSpherical(n, r0, r1)
+    enforcer = lambda net, cond, coords: (cond.enforce(net, coords[0]) * Y(*coords[1:])).sum(dim=1, keepdim=True)
+    return dict(kind="sph", pde=pde, nets=nets, conds=conds, gen=gen, enforcer=enforcer, r=(r0, r1))
+
+
+CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4}
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -103,7 +123,12 @@ def closure_once(cfg, coords32, dtype):
     for n in nets:
         n.zero_grad()
     batch = [c.detach().to(dtype).reshape(-1, 1).requires_grad_(True) for c in coords32]
-    funcs = [c.enforce(n, *batch) for n, c in zip(nets, cfg["conds"])]
+    if "enforcer" in cfg:
+        for c in cfg["conds"]:     # boundary coefficient rows follow the working precision
+            c.R_0, c.R_1 = c.R_0.to(dtype), c.R_1.to(dtype)
+        funcs = [cfg["enforcer"](n, c, batch) for n, c in zip(nets, cfg["conds"])]
+    else:
+        funcs = [c.enforce(n, *batch) for n, c in zip(nets, cfg["conds"])]
     res = torch.cat(cfg["pde"](*funcs, *batch), dim=1)
     loss = (res ** 2).mean()
     loss.backward()
@@ -145,11 +170,15 @@ def make(name, seed=0):
             out[f"{k}_{tag}"] = v
 
     # 3-epoch trajectory with the reference solver (default Adam lr=1e-3), fp32, fresh samples per epoch
-    Solver = Solver1D if cfg["kind"] == "1d" else Solver2D
-    kw = dict(t_min=0.1, t_max=12.0) if cfg["kind"] == "1d" else dict(xy_min=(0, 0), xy_max=(1, 1))
     pde = cfg["pde"]
-    solver = Solver(pde if cfg["kind"] != "1d" else pde, cfg["conds"], nets=cfg["nets"],
-                    train_generator=gen, valid_generator=gen, n_batches_valid=0, **kw)
+    if cfg["kind"] == "sph":
+        solver = SolverSpherical(pde, cfg["conds"], r_min=cfg["r"][0], r_max=cfg["r"][1], nets=cfg["nets"],
+                                 train_generator=gen, valid_generator=gen, n_batches_valid=0, enforcer=cfg["enforcer"])
+    else:
+        Solver = Solver1D if cfg["kind"] == "1d" else Solver2D
+        kw = dict(t_min=0.1, t_max=12.0) if cfg["kind"] == "1d" else dict(xy_min=(0, 0), xy_max=(1, 1))
+        solver = Solver(pde, cfg["conds"], nets=cfg["nets"], train_generator=gen, valid_generator=gen,
+                        n_batches_valid=0, **kw)
     torch.manual_seed(seed + 2)
     for _ in range(3):
         solver.run_train_epoch()
@@ -191,6 +220,9 @@ def make_diff_known_answers():
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for name in CONFIGS:
-        make(name)
-    make_diff_known_answers()
+        if not only or name in only:
+            make(name)
+    if not only:
+        make_diff_known_answers()

@@ -35,7 +35,7 @@ ARCH = {
     "c4val": ((1, 32, 32, 25), "tanh", 0, (1, 0, 0), [()]),
     "m3": ((2, 32, 32, 3), "tanh", 0, (2, 1, 5), [(), (0,), (1,), (0, 0), (1, 1)]),
 }
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96}
 
 
 def rel_l2(a, b):
@@ -230,12 +230,13 @@ def _load_system(name, size, single_kernel=True):
     cfg = configs.make(name, size)
     for net in cfg["nets"]:
         net.to("cuda")
-    n_coords = 1 if cfg["kind"] == "1d" else 2
-    return cfg, FusedSystem(cfg["nets"], cfg["conds"], cfg["pde"], n_coords, "cuda", single_kernel=single_kernel)
+    return cfg, FusedSystem(cfg["nets"], cfg["conds"], cfg["pde"], configs.n_coords(cfg), "cuda",
+                            compute_func_val=configs.func_val(cfg), single_kernel=single_kernel)
 
 
 # "1k" = single-launch fused closure kernel (single-network systems), "3k" = forward / pointwise / backward pipeline
-@pytest.mark.parametrize("name,mode", [("c1", "3k"), ("c2", "1k"), ("c2", "3k"), ("c3", "1k"), ("c3", "3k"), ("c5", "3k")])
+@pytest.mark.parametrize("name,mode", [("c1", "3k"), ("c2", "1k"), ("c2", "3k"), ("c3", "1k"), ("c3", "3k"), ("c5", "3k"),
+                                       ("c4", "3k")])
 def test_fused_closure_matches_reference_golden(golden_dir, name, mode):
     """funcs / residuals / loss / flat gradient of ONE closure (solvers.py:369-395) on the reference's own inputs."""
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
@@ -260,7 +261,7 @@ def test_fused_closure_matches_reference_golden(golden_dir, name, mode):
     assert max(errs["funcs"], errs["residuals"], errs["loss"], errs["grad"]) < TOL, errs
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4"])
 def test_solver_trajectory_matches_reference_golden(golden_dir, name):
     """Three epochs of Solver.run_train_epoch (sampling on the CPU RNG, fused step, fused Adam) against the
     reference solver's loss history and final parameters."""
@@ -283,7 +284,7 @@ def test_solver_trajectory_matches_reference_golden(golden_dir, name):
 
 
 @pytest.mark.parametrize("name,size,mode", [("c2", 256, "1k"), ("c2", 256, "3k"), ("c3", 96, "1k"), ("c3", 97, "3k"),
-                                            ("c1", 1024, "3k"), ("c2", 37, "1k")])
+                                            ("c1", 1024, "3k"), ("c2", 37, "1k"), ("c4", 5000, "3k")])
 def test_fused_closure_matches_oracle_at_size(name, size, mode):
     """Full-size C2 (65 536 points) and larger / ragged C1/C3 batches against the autograd oracle in fp64."""
     cfg, system = _load_system(name, size, single_kernel=(mode == "1k"))
@@ -292,7 +293,8 @@ def test_fused_closure_matches_oracle_at_size(name, size, mode):
     flat = R.get_flat(cfg["nets"]).cpu()
     R.set_flat(ocfg["nets"], flat.double())
     torch.manual_seed(3)
-    coords = [c.detach() for c in cfg["gen"].get_examples()] if cfg["kind"] != "1d" else [cfg["gen"].get_examples().detach()]
+    ex = cfg["gen"].get_examples()
+    coords = [ex.detach()] if isinstance(ex, torch.Tensor) else [c.detach() for c in ex]
     out = R.closure(ocfg["nets"], ocfg["enforcers"], ocfg["pde"], [c.double() for c in coords])
     want_grad = R.get_flat_grad(ocfg["nets"]).numpy()
     b, n = system.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)

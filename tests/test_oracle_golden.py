@@ -9,7 +9,7 @@ import torch
 from oracle import autograd_ref as R
 from oracle import jet_ref as J
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96}
 
 
 def _load(golden_dir, name):
@@ -21,7 +21,7 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5", "c4"])
 def test_generator_draws_bit_exact(golden_dir, name):
     g = _load(golden_dir, name)
     torch.manual_seed(int(g["seed"]))
@@ -33,7 +33,7 @@ def test_generator_draws_bit_exact(golden_dir, name):
     assert np.array_equal(d2, g["draw2"])
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5", "c4"])
 def test_default_init_bit_exact(golden_dir, name):
     g = _load(golden_dir, name)
     torch.manual_seed(int(g["seed"]))
@@ -41,7 +41,7 @@ def test_default_init_bit_exact(golden_dir, name):
     assert np.array_equal(R.get_flat(cfg["nets"]).numpy(), g["params0"])
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5", "c4"])
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_closure_matches_reference(golden_dir, name, prec):
     g = _load(golden_dir, name)
@@ -57,7 +57,7 @@ def test_closure_matches_reference(golden_dir, name, prec):
     assert rel_l2(R.get_flat_grad(cfg["nets"]).numpy(), g[f"grad_{prec}"]) < tol
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4"])
 def test_adam_trajectory_matches_reference(golden_dir, name):
     g = _load(golden_dir, name)
     torch.manual_seed(int(g["seed"]))

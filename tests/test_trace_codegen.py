@@ -14,7 +14,7 @@ from oracle import jet_ref as J
 from tests import configs
 from tests.pw_cpu import run_cpu
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96}
 
 
 def rel_l2(a, b):
@@ -26,17 +26,18 @@ def trace(cfg, n_coords):
     nets, conds = cfg["nets"], cfg["conds"]
     g = Graph(n_coords)
     g.register_nets(nets, [describe(n)["n_out"] for n in nets])
+    cfv = configs.func_val(cfg) or (lambda net, cond, *coords: cond.enforce(net, *coords))
     with trace_scope(g):
         coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
-        funcs = [c.enforce(n, *coords) for n, c in zip(nets, conds)]
+        funcs = [cfv(n, c, *coords) for n, c in zip(nets, conds)]
         res = cfg["pde"](*funcs, *coords)
     for k, n in enumerate(nets):
         g.net_deps.setdefault(k, tuple(range(describe(n)["d"])))
-        g.net_nout.setdefault(k, 1)
+        g.net_nout.setdefault(k, describe(n)["n_out"])
     return codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets))
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5", "c4"])
 def test_fused_pipeline_on_host_matches_reference(golden_dir, name):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
@@ -48,7 +49,7 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name):
     dims_act, flats, off = [], [], 0
     for net in cfg["nets"]:
         info = describe(net)
-        dims = (info["d"],) + (info["hidden"],) * info["layers"] + (1,)
+        dims = (info["d"],) + (info["hidden"],) * info["layers"] + (info["n_out"],)
         npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
         dims_act.append((dims, "tanh" if info["act"] == 0 else "sin"))
         flats.append(gold["params0"][off:off + npar].astype(np.float64))
@@ -62,8 +63,9 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name):
         deps = prog.streams[k].deps
         local = lambda mi: tuple(deps.index(c) for c in mi)
         js = J.mlp_jets(flats[k], dims, act, [coords[c] for c in deps], [local(mi) for mi in needed[k]] or [()])
-        jets[k] = {mi: js[tuple(sorted(local(mi)))][:, 0] for mi in needed[k]}
-    syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]] for i in prog.symbols]).astype(np.float32)
+        jets[k] = {mi: js[tuple(sorted(local(mi)))] for mi in needed[k]}               # (N, n_out)
+    syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]][:, prog.g.nodes[i][2]]
+                     for i in prog.symbols]).astype(np.float32)
     n_eq = len(prog.residuals)
     seed = 1.0 / (n * n_eq)
     resid, funcs, gbar = run_cpu(prog, coords, syms, seed)
@@ -79,7 +81,8 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name):
         for idx, i in enumerate(prog.symbols):
             _, kk, o, mi = prog.g.nodes[i]
             if kk == k:
-                gb[tuple(sorted(deps.index(c) for c in mi))] = gbar[idx].astype(np.float64)[:, None]
+                m = gb.setdefault(tuple(sorted(deps.index(c) for c in mi)), np.zeros((n, dims[-1])))
+                m[:, o] = gbar[idx].astype(np.float64)
         grads.append(J.mlp_jets_vjp(flats[k], dims, act, [coords[c] for c in deps], gb))
     assert rel_l2(np.concatenate(grads), gold["grad_f64"]) < 1e-5
 
