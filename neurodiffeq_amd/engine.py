@@ -101,7 +101,8 @@ class FusedSystem:
         if single_kernel and codegen.can_fuse(self.program):
             self.fusedk = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0]))
         self.flat = [FlatParams(n, self.device) for n in self.nets]
-        self.ns = [self.program.streams[k].n_streams for k in range(len(self.nets))]
+        # rows of the stream / adjoint-stream arrays of net k: [n_streams][n_out]
+        self.ns = [self.program.streams[k].n_streams * self.program.streams[k].n_out for k in range(len(self.nets))]
         self.coord0 = [self.program.streams[k].deps[0] for k in range(len(self.nets))]
         for k, fp in enumerate(self.flat):
             assert self.L.ndq_mlp_num_params(ctypes.byref(self.descs[k])) == fp.numel
