@@ -100,6 +100,13 @@ enum { ACT_TANH = 0, ACT_SIN = 1 };
 #ifndef NDQ_BWD_THREADS
 #define NDQ_BWD_THREADS 256
 #endif
+// Two co-resident waves per SIMD run the same program from the same start, so they stay phase-locked (both in a
+// VALU phase, then both in an MFMA phase) and do not fill each other's idle pipe.  Raising the issue priority of the
+// second wave of every SIMD (waves WAVES/2.. of an 8-wave workgroup) lets it win every arbitration, which pushes the
+// pair out of phase after the first contended segment.
+#ifndef NDQ_STAGGER_PRIO
+#define NDQ_STAGGER_PRIO 1
+#endif
 #ifndef NDQ_HBAR_INPLACE
 #define NDQ_HBAR_INPLACE 1
 #endif
@@ -839,6 +846,9 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
   constexpr int WAVES = C::BWD_THREADS / 64;
   const int ntiles = (a.n + 15) >> 4;
   float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
+#if NDQ_STAGGER_PRIO
+  if (WAVES > 4 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(NDQ_STAGGER_PRIO);
+#endif
   GradAcc<C> acc;
   acc_zero<C>(acc);
   for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
@@ -899,6 +909,9 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   constexpr int WAVES = C::BWD_THREADS / 64;
   const int ntiles = (a.n + 15) >> 4;
   float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
+#if NDQ_STAGGER_PRIO
+  if (WAVES > 4 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(NDQ_STAGGER_PRIO);
+#endif
   GradAcc<C> acc;
   if constexpr (TRAIN) acc_zero<C>(acc);
   float lsum = 0.f;
