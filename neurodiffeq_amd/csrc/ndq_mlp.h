@@ -107,6 +107,14 @@ enum { ACT_TANH = 0, ACT_SIN = 1 };
 #ifndef NDQ_STAGGER_PRIO
 #define NDQ_STAGGER_PRIO 1
 #endif
+// Hidden-layer GEMMs on the bf16 matrix core with 3-way split operands ("bf16x3"): x = x0 + x1 + x2 (three bf16
+// chunks = 24 mantissa bits), products a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1 accumulated in fp32 -> relative error
+// ~2^-23, i.e. fp32-class accuracy.  Why: the f32-input MFMA shares the VALU datapath on gfx950 (it does NOT overlap
+// with VALU work -- scripts/ubench_mfma_valu.hip, profiles/r01e_ubench_*), while v_mfma_f32_16x16x32_bf16 runs on the
+// real matrix core, 6 of them replace 8 f32 MFMAs at ~1/3 of the cycles, and they overlap with the activation math.
+#ifndef NDQ_BF16X3
+#define NDQ_BF16X3 1
+#endif
 #ifndef NDQ_HBAR_INPLACE
 #define NDQ_HBAR_INPLACE 1
 #endif
@@ -167,10 +175,14 @@ struct Cfg {
   // LDS carve (floats): W1T [D][H] | b1 [H] | per hidden-hidden layer: Wf [H*H] (+ Wt [H*H] for bwd) | b_l | Wout | bout
   static constexpr int ldsW1T = 0, ldsb1 = D * H;
   static constexpr int ldsLayer0 = D * H + H;
-  static constexpr int layerStride(bool bwd) { return (bwd ? 2 : 1) * H * H + H; }
+  // hidden GEMM operand format: bf16x3 planes (3 x 2 B per weight) when the width is a multiple of 32, else f32
+  static constexpr bool BF16 = (NDQ_BF16X3 != 0) && (NB_ % 2 == 0);
+  static constexpr int NC = NB_ / 2;                       // K-chunks of 32 contraction slots (bf16 path)
+  static constexpr int WEL = BF16 ? (H * H * 3) / 2 : H * H;   // floats of LDS per weight matrix image
+  static constexpr int layerStride(bool bwd) { return (bwd ? 2 : 1) * WEL + H; }
   static constexpr int ldsWf(int l, bool bwd) { return ldsLayer0 + (l - 2) * layerStride(bwd); }
-  static constexpr int ldsWt(int l) { return ldsWf(l, true) + H * H; }
-  static constexpr int ldsb(int l, bool bwd) { return ldsWf(l, bwd) + (bwd ? 2 : 1) * H * H; }
+  static constexpr int ldsWt(int l) { return ldsWf(l, true) + WEL; }
+  static constexpr int ldsb(int l, bool bwd) { return ldsWf(l, bwd) + (bwd ? 2 : 1) * WEL; }
   // output layer: NOUT == 1: Wout [H] | bout [1];  NOUT > 1: fragment-ordered Wo [HO*H] (+ transposed [HO*H]) | bout [HO]
   static constexpr int ldsWout(bool bwd) { return ldsLayer0 + (L - 1) * layerStride(bwd); }
   static constexpr int ldsWoutT() { return ldsWout(true) + HO * H; }
@@ -221,6 +233,38 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
     }
     for (int i = tid; i < C::HO; i += nt) lds[C::ldsbout(BWD) + i] = i < C::NOUT ? prm[C::offbout + i] : 0.f;
   }
+  if constexpr (C::BF16) {
+    // bf16x3 planes in "bf16 fragment order": A operand of (ob = 16-row output block, c = chunk of 32 contraction
+    // slots), plane pl: lane (i = lane&15, kg = lane>>4) holds 8 bf16, slot e <-> unit 16*(2c + (e>>2)) + 4*kg + (e&3).
+    // index in bf16 units: ((((ob*NC + c)*3 + pl)*64 + lane)*8 + e
+#pragma unroll
+    for (int l = 2; l <= C::L; ++l) {
+      const float* W = prm + C::offW(l);
+      __bf16* wf = reinterpret_cast<__bf16*>(lds + C::ldsWf(l, BWD));
+      __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWt(l));
+      for (int i = tid; i < H * H; i += nt) {
+        const int e = i & 7, lane = (i >> 3) & 63, blk = i >> 9;   // blk = ob*NC + c
+        const int ob = blk / C::NC, c = blk - ob * C::NC;
+        const int unit = 16 * (2 * c + (e >> 2)) + 4 * (lane >> 4) + (e & 3);
+        const int row = 16 * ob + (lane & 15);
+        {
+          const float w = W[row * H + unit];                       // forward: out = row, in = unit
+          const __bf16 w0 = (__bf16)w; const float r1 = w - (float)w0;
+          const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (float)w1);
+          const int base = ((blk * 3) * 64 + lane) * 8 + e;
+          wf[base] = w0; wf[base + 512] = w1; wf[base + 1024] = w2;
+        }
+        if (BWD) {
+          const float w = W[unit * H + row];                       // transposed: out = in-unit row, contraction over out-units
+          const __bf16 w0 = (__bf16)w; const float r1 = w - (float)w0;
+          const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (float)w1);
+          const int base = ((blk * 3) * 64 + lane) * 8 + e;
+          wt[base] = w0; wt[base + 512] = w1; wt[base + 1024] = w2;
+        }
+      }
+      for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = prm[C::offb(l) + i];
+    }
+  } else
 #pragma unroll
   for (int l = 2; l <= C::L; ++l) {
     const float* W = prm + C::offW(l);
@@ -340,6 +384,59 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, f32x4 (&g)
     }
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <class C> __device__ __forceinline__ void zero_frag(f32x4 (&z)[C::NS][C::NB]);
+
+// split the 8 fp32 values a lane holds for one K-chunk (blocks 2c, 2c+1) into three bf16x8 operands
+__device__ __forceinline__ void split3(const f32x4 a, const f32x4 b, bf16x8 (&pl)[3]) {
+  const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h0 = (__bf16)x[e];
+    const float r1 = x[e] - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    const __bf16 h2 = (__bf16)(r1 - (float)h1);
+    pl[0][e] = h0; pl[1][e] = h1; pl[2][e] = h2;
+  }
+}
+
+// bf16x3 GEMM on fragments: z[s][ob] += W h[s] with W given as bf16 planes (stage_weights) and h split on the fly.
+// The six partial products are issued smallest first; consecutive MFMAs go to different accumulators (streams).
+template <class C>
+__device__ __forceinline__ void gemm_bf16x3(const float* __restrict__ wl, int lane, const f32x4 (&h)[C::NS][C::NB],
+                                            f32x4 (&z)[C::NS][C::NB]) {
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+#pragma unroll
+  for (int c = 0; c < C::NC; ++c) {
+    bf16x8 hp[C::NS][3];
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) split3(h[s][2 * c], h[s][2 * c + 1], hp[s]);
+#pragma unroll
+    for (int ob = 0; ob < C::NB; ++ob) {
+      const bf16x8 a0 = w[((ob * C::NC + c) * 3 + 0) * 64 + lane];
+      const bf16x8 a1 = w[((ob * C::NC + c) * 3 + 1) * 64 + lane];
+      const bf16x8 a2 = w[((ob * C::NC + c) * 3 + 2) * 64 + lane];
+#define NDQ_T(A, P)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
+      z[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, hp[s][P], z[s][ob], 0, 0, 0);
+      NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+    }
+  }
+}
+
+// in-place variant for hbar = W^T zbar (all streams are split first, then overwritten)
+template <class C>
+__device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl, int lane, f32x4 (&g)[C::NS][C::NB]) {
+  f32x4 o[C::NS][C::NB];
+  zero_frag<C>(o);
+  gemm_bf16x3<C>(wl, lane, g, o);
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) g[s][b] = o[s][b];
+}
+
 // z[s][ib] (+)= sum_kb sum_t A(w[(ib*NB+kb)*4+t]) * B(h[s][kb][t]);  w points at a fragment-ordered H x H matrix
 template <class C>
 __device__ __forceinline__ void gemm_frag(const float* __restrict__ w, int lane, const f32x4 (&h)[C::NS][C::NB],
@@ -398,7 +495,8 @@ __device__ __forceinline__ void hidden_layer(const float* lds, int l, int lane, 
   zero_frag<C>(z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
-  gemm_frag<C>(lds + C::ldsWf(l, BWD), lane, h, z);
+  if constexpr (C::BF16) gemm_bf16x3<C>(lds + C::ldsWf(l, BWD), lane, h, z);
+  else gemm_frag<C>(lds + C::ldsWf(l, BWD), lane, h, z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
 #pragma unroll
@@ -721,17 +819,21 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc.b[l - 2][b][r] += g[0][b][r];
     weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2]);   // inputs of layer l = activations of layer l-1
+    if constexpr (C::BF16) {
+      gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);             // hbar_{l-1} = W_l^T zbar_l
+    } else {
 #if NDQ_HBAR_INPLACE
-    gemm_frag_inplace<C>(lds + C::ldsWt(l), lane, g);                 // hbar_{l-1} = W_l^T zbar_l
+      gemm_frag_inplace<C>(lds + C::ldsWt(l), lane, g);
 #else
-    f32x4 hb[C::NS][C::NB];
-    zero_frag<C>(hb);
-    gemm_frag<C>(lds + C::ldsWt(l), lane, g, hb);
+      f32x4 hb[C::NS][C::NB];
+      zero_frag<C>(hb);
+      gemm_frag<C>(lds + C::ldsWt(l), lane, g, hb);
 #pragma unroll
-    for (int s = 0; s < C::NS; ++s)
+      for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-      for (int b = 0; b < C::NB; ++b) g[s][b] = hb[s][b];
+        for (int b = 0; b < C::NB; ++b) g[s][b] = hb[s][b];
 #endif
+    }
   });
 
   // ---------------- first layer: z_a = W1[:,a] (constant), z_ab = 0

@@ -107,6 +107,7 @@ class FusedSystem:
         for k, fp in enumerate(self.flat):
             assert self.L.ndq_mlp_num_params(ctypes.byref(self.descs[k])) == fp.numel
         self._bufs = {}
+        self._resident_cache = {}
         self.loss_buf = torch.zeros(64, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------------------------------ buffers
@@ -133,7 +134,10 @@ class FusedSystem:
         dev, f32 = self.device, torch.float32
         b = dict(ld=ld,
                  coords_own=torch.zeros(self.n_coords, ld, dtype=f32, device=dev),
-                 pinned=torch.zeros(self.n_coords, ld, dtype=f32).pin_memory(),
+                 # host staging ring: a pinned block may only be rewritten once its async H2D copy has completed
+                 # (the native epoch path never synchronises, so the host can run several epochs ahead)
+                 pinned=[torch.zeros(self.n_coords, ld, dtype=f32).pin_memory() for _ in range(4)],
+                 pin_events=[None] * 4, pin_next=0,
                  jets=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
                  gbar=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
                  funcs=torch.zeros(self.n_funcs, ld, dtype=f32, device=dev),
@@ -158,11 +162,18 @@ class FusedSystem:
         hi = n_all if hi is None else hi
         n = hi - lo
         if batch[0].device.type == "cuda" and lo == 0 and hi == n_all:
+            hit = self._resident_cache.get(id(batch))        # same list object served again by a resident generator
+            if hit is not None and hit[0] is batch:
+                b = hit[1]
+                b["coords_rows"] = hit[2]
+                return b, n
             ld = self._resident_ld(batch)
             if ld:
                 b = self.buffers(n, ld=ld)
                 b["coords"] = batch[0].reshape(-1)          # row 0 of the resident SoA block; rows are ld apart
                 b["coords_rows"] = [c.reshape(-1) for c in batch]
+                if len(self._resident_cache) < 64:
+                    self._resident_cache[id(batch)] = (batch, b, b["coords_rows"])
                 return b, n
         b = self.buffers(n)
         b["coords"], b["coords_rows"] = b["coords_own"], None
@@ -170,9 +181,17 @@ class FusedSystem:
             for i, c in enumerate(batch):
                 b["coords_own"][i, :n].copy_(c.detach().reshape(-1)[lo:hi])
         else:
+            k = b["pin_next"]
+            b["pin_next"] = (k + 1) % len(b["pinned"])
+            if b["pin_events"][k] is not None:
+                b["pin_events"][k].synchronize()
+            pinned = b["pinned"][k]
             for i, c in enumerate(batch):
-                b["pinned"][i, :n].copy_(c.detach().reshape(-1)[lo:hi])
-            b["coords_own"].copy_(b["pinned"], non_blocking=True)
+                pinned[i, :n].copy_(c.detach().reshape(-1)[lo:hi])
+            b["coords_own"].copy_(pinned, non_blocking=True)
+            ev = b["pin_events"][k] or torch.cuda.Event()
+            ev.record()
+            b["pin_events"][k] = ev
         return b, n
 
     def _coord_ptr(self, b, row):

@@ -301,7 +301,9 @@ class SamplerGenerator(BaseGenerator):
         if isinstance(samples, torch.Tensor):
             samples = [samples]
         if samples[0].device.type == "cuda" and not samples[0].requires_grad:
-            return [s.reshape(-1, 1) for s in samples]       # resident batch: keep the views (zero-copy hand-off)
+            if samples[0].dim() == 2:
+                return samples                                   # resident batch: already (N, 1) views, zero-copy
+            return [s.reshape(-1, 1) for s in samples]
         return [s.reshape(-1, 1).detach().requires_grad_(True) for s in samples]
 
 
@@ -317,6 +319,7 @@ class ResidentBatchGenerator(BaseGenerator):
     def __init__(self, blocks, size):
         super().__init__()
         self.blocks, self.size, self._next = blocks, size, 0
+        self._views = {}
 
     @classmethod
     def presample(cls, generator, n_batches, device, lo=0, hi=None):
@@ -332,6 +335,10 @@ class ResidentBatchGenerator(BaseGenerator):
         return cls(blocks, n)
 
     def get_examples(self):
-        blk = self.blocks[self._next % self.blocks.shape[0]]
+        k = self._next % self.blocks.shape[0]
         self._next += 1
-        return tuple(blk[i, :self.size] for i in range(blk.shape[0]))
+        views = self._views.get(k)
+        if views is None:         # (N, 1) column views of the block's rows, built once per block
+            blk = self.blocks[k]
+            views = self._views[k] = [blk[i, :self.size].reshape(-1, 1) for i in range(blk.shape[0])]
+        return views

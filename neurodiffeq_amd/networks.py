@@ -128,6 +128,7 @@ class FlatParams:
         self.grad_loss = torch.zeros(self.numel + 1, dtype=torch.float32, device=self.device)
         self.grad = self.grad_loss[:self.numel]
         self._offsets = []
+        self._grad_views = None
         off = 0
         for p in self.params:
             self._offsets.append(off)
@@ -135,11 +136,13 @@ class FlatParams:
         self.sync()
 
     def _is_flat(self):
+        """Do all parameters still alias the flat buffer?  (cheap: one data_ptr() per parameter, called every epoch)"""
         if self.flat is None:
             return False
-        base = self.flat.data_ptr()
-        return all(p.data.data_ptr() == base + 4 * off and p.data.device == self.flat.device
-                   for p, off in zip(self.params, self._offsets))
+        for p, ptr in zip(self.params, self._ptrs):
+            if p.data_ptr() != ptr:
+                return False
+        return True
 
     def sync(self):
         if self._is_flat():
@@ -149,15 +152,20 @@ class FlatParams:
             for p, off in zip(self.params, self._offsets):
                 p.data = flat[off:off + p.numel()].view(p.shape)
         self.flat = flat
+        self._ptrs = [flat.data_ptr() + 4 * off for off in self._offsets]
 
     def attach_grads(self):
         """Expose the flat gradient buffer as ``p.grad`` views (what ``loss.backward()`` leaves behind, solvers.py:393)."""
-        for p, off in zip(self.params, self._offsets):
-            g = self.grad[off:off + p.numel()].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+        if self._grad_views is None:
+            self._grad_views = [self.grad[off:off + p.numel()].view(p.shape) for p, off in zip(self.params, self._offsets)]
+        for p, g in zip(self.params, self._grad_views):
+            if p.grad is not g:
                 p.grad = g
 
     def grads_attached(self):
-        base = self.grad.data_ptr()
-        return all(p.grad is not None and p.grad.data_ptr() == base + 4 * off
-                   for p, off in zip(self.params, self._offsets))
+        if self._grad_views is None:
+            return False
+        for p, g in zip(self.params, self._grad_views):
+            if p.grad is not g:
+                return False
+        return True

@@ -33,9 +33,18 @@ from .optim import FusedAdam
 from .symbolic import TraceUnsupported
 
 
+_CLOSURE_CACHE = {}
+
+
 def _requires_closure(optimizer):
-    p = inspect.signature(optimizer.step).parameters.get("closure")
-    return bool(p) and p.default == inspect._empty
+    """True for optimisers whose ``step`` needs a closure (LBFGS-style, solvers.py:29-32); cached per optimiser class
+    because ``inspect.signature`` costs more than a whole fused training epoch."""
+    cls = type(optimizer)
+    r = _CLOSURE_CACHE.get(cls)
+    if r is None:
+        p = inspect.signature(optimizer.step).parameters.get("closure")
+        r = _CLOSURE_CACHE[cls] = bool(p) and p.default == inspect._empty
+    return r
 
 
 def _unique_params(nets):
@@ -264,8 +273,11 @@ class BaseSolver(ABC):
 
     def _generate_batch(self, key):
         self._phase = key
-        self._batch[key] = [v.reshape(-1, 1) for v in self.generator[key].get_examples()]
-        return self._batch[key]
+        ex = self.generator[key].get_examples()
+        if not (len(ex) and ex[0].dim() == 2 and ex[0].shape[1] == 1):
+            ex = [v.reshape(-1, 1) for v in ex]
+        self._batch[key] = ex
+        return ex
 
     def _generate_train_batch(self):
         return self._generate_batch("train")
