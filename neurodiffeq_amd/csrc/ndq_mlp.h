@@ -115,6 +115,17 @@ enum { ACT_TANH = 0, ACT_SIN = 1 };
 #ifndef NDQ_BF16X3
 #define NDQ_BF16X3 1
 #endif
+// Weight gradients on the matrix core as well (weight_grad_mm): implemented, measured, REJECTED -- default off.
+// dW = sum over points of zbar * h cancels heavily (|sum| << sum |terms|), and the bf16 matrix core's internal fp32
+// accumulation of its 32 products is visibly less precise than an fmaf chain: with real PDE adjoints the gradient came
+// out 9e-5 off (rel-L2, C2 closure) although every factor was an exact bf16x3 split, versus 2e-7 with the exact-f32
+// MFMA.  The per-point forward / hbar GEMMs do not accumulate across points and stay at fp32-class error (4e-7).
+#ifndef NDQ_DW_MM
+#define NDQ_DW_MM 0
+#endif
+#ifndef NDQ_KEEP_PLANES
+#define NDQ_KEEP_PLANES 1
+#endif
 #ifndef NDQ_HBAR_INPLACE
 #define NDQ_HBAR_INPLACE 1
 #endif
@@ -179,6 +190,11 @@ struct Cfg {
   static constexpr bool BF16 = (NDQ_BF16X3 != 0) && (NB_ % 2 == 0);
   static constexpr int NC = NB_ / 2;                       // K-chunks of 32 contraction slots (bf16 path)
   static constexpr int WEL = BF16 ? (H * H * 3) / 2 : H * H;   // floats of LDS per weight matrix image
+  // weight gradients of hidden layers on the matrix core too (fragments transposed by MFMAs against 0/1 selection
+  // operands instead of through LDS); the forward's bf16 planes of the layer inputs are kept when they fit
+  static constexpr bool DW_MM = BF16 && (NDQ_DW_MM != 0) && (NB_ == 2);   // wider nets: register budget, keep the LDS path
+  static constexpr bool KEEP_PLANES = DW_MM && (NB_ == 2) && (L_ == 2) && (NDQ_KEEP_PLANES != 0);
+  static constexpr int NCH = (SS::NS + 1) / 2;             // stream pairs = K-chunks of the weight-gradient MFMAs
   static constexpr int layerStride(bool bwd) { return (bwd ? 2 : 1) * WEL + H; }
   static constexpr int ldsWf(int l, bool bwd) { return ldsLayer0 + (l - 2) * layerStride(bwd); }
   static constexpr int ldsWt(int l) { return ldsWf(l, true) + WEL; }
@@ -291,6 +307,13 @@ struct LayerState {
   f32x4 z[C::NS][C::NB];             // pre-activation derivative streams (index 0 unused: value is in t)
 };
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// bf16x3 planes of all streams of one fragment set: pl[s][c][k], k = 0 (high) .. 2 (low)
+template <class C>
+struct Planes {
+  bf16x8 pl[C::NS][C::NC > 0 ? C::NC : 1][3];
+};
+
 // streams of h = sigma(z) from the layer state:  h0 = t, h_a = s1 z_a, h_ab = s2 z_a z_b + s1 z_ab
 template <class C>
 __device__ __forceinline__ void act_forward(const LayerState<C>& st, f32x4 (&h)[C::NS][C::NB]) {
@@ -384,7 +407,6 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, f32x4 (&g)
     }
 }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <class C> __device__ __forceinline__ void zero_frag(f32x4 (&z)[C::NS][C::NB]);
 
 // split the 8 fp32 values a lane holds for one K-chunk (blocks 2c, 2c+1) into three bf16x8 operands
@@ -423,6 +445,99 @@ __device__ __forceinline__ void gemm_bf16x3(const float* __restrict__ wl, int la
 #undef NDQ_T
     }
   }
+}
+
+template <class C>
+__device__ __forceinline__ void split_all(const f32x4 (&h)[C::NS][C::NB], Planes<C>& P) {
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) split3(h[s][2 * c], h[s][2 * c + 1], P.pl[s][c]);
+}
+
+// z[s][ob] += W h[s] with h given as bf16x3 planes
+template <class C>
+__device__ __forceinline__ void gemm_planes(const float* __restrict__ wl, int lane, const Planes<C>& P,
+                                            f32x4 (&z)[C::NS][C::NB]) {
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+#pragma unroll
+  for (int c = 0; c < C::NC; ++c)
+#pragma unroll
+    for (int ob = 0; ob < C::NB; ++ob) {
+      const bf16x8 a0 = w[((ob * C::NC + c) * 3 + 0) * 64 + lane];
+      const bf16x8 a1 = w[((ob * C::NC + c) * 3 + 1) * 64 + lane];
+      const bf16x8 a2 = w[((ob * C::NC + c) * 3 + 2) * 64 + lane];
+#define NDQ_T(A, K)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
+      z[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, P.pl[s][c][K], z[s][ob], 0, 0, 0);
+      NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+    }
+}
+
+// 0/1 selection operand: as the B operand of an MFMA whose A operand is a plane set of K-chunk c, it extracts
+// 16-unit block (2c + half) TRANSPOSED: D[point][unit] -> lane (unit, q') holds points 4q'..4q'+3.
+// lane (j = lane&15, kg = lane>>4): slot (kg, e) <-> unit 16*half + 4*kg + (e&3) with e>>2 == half.
+__device__ __forceinline__ bf16x8 sel_operand(int lane, int half) {
+  bf16x8 v;
+  const int j = lane & 15, kg = lane >> 4;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (__bf16)((kg == (j >> 2) && e == 4 * half + (j & 3)) ? 1.0f : 0.0f);
+  return v;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = (__bf16)a[e]; v[4 + e] = (__bf16)b[e]; }
+  return v;
+}
+
+// dW += sum_s Zbar[s] H[s]^T over the tile's 16 points, entirely on the matrix core: every bf16 plane of Zbar / H is
+// transposed exactly by one MFMA against a selection operand, two streams are packed into one K = 32 chunk
+// (slot (kg, e) <-> stream 2ch + (e>>2), point 4kg + (e&3)), then the six bf16x3 partial products accumulate into the
+// same D-layout accumulators the f32 path used (acc[jb][kb][r] at lane (c, q) = dW[16jb+4q+r][16kb+c]).
+template <class C>
+__device__ __forceinline__ void weight_grad_mm(int lane, const Planes<C>& Z, const Planes<C>& Hh,
+                                               f32x4 (&acc)[C::NB][C::NB]) {
+  const bf16x8 sel[2] = {sel_operand(lane, 0), sel_operand(lane, 1)};
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+  // The tile's contribution is formed in fresh accumulators and then added to the running sums on the VALU (RNE):
+  // the matrix core's fp32 accumulation truncates, and chaining it across all tiles of a wave produced a drift that
+  // grew linearly with the number of tiles (2e-5 at 1 M points); per tile it is ~1e-7 and does not accumulate.
+  f32x4 d[C::NB][C::NB];
+#pragma unroll
+  for (int jb = 0; jb < C::NB; ++jb)
+#pragma unroll
+    for (int kb = 0; kb < C::NB; ++kb) d[jb][kb] = zero;
+  sfor<C::NCH>([&](auto ch_) {
+    constexpr int ch = decltype(ch_)::value;
+    constexpr int s0 = 2 * ch, s1 = 2 * ch + 1;
+    bf16x8 za[C::NB][3], hb[C::NB][3];
+#pragma unroll
+    for (int jb = 0; jb < C::NB; ++jb)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        f32x4 tz0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Z.pl[s0][jb >> 1][k], sel[jb & 1], zero, 0, 0, 0);
+        f32x4 th0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Hh.pl[s0][jb >> 1][k], sel[jb & 1], zero, 0, 0, 0);
+        f32x4 tz1 = zero, th1 = zero;
+        if constexpr (s1 < C::NS) {
+          tz1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Z.pl[s1][jb >> 1][k], sel[jb & 1], zero, 0, 0, 0);
+          th1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Hh.pl[s1][jb >> 1][k], sel[jb & 1], zero, 0, 0, 0);
+        }
+        za[jb][k] = pack8(tz0, tz1);
+        hb[jb][k] = pack8(th0, th1);
+      }
+#define NDQ_T(KA, KB)                                                                                        \
+  _Pragma("unroll") for (int jb = 0; jb < C::NB; ++jb) _Pragma("unroll") for (int kb = 0; kb < C::NB; ++kb)  \
+      d[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[jb][KA], hb[kb][KB], d[jb][kb], 0, 0, 0);
+    NDQ_T(1, 1) NDQ_T(2, 0) NDQ_T(0, 2) NDQ_T(1, 0) NDQ_T(0, 1) NDQ_T(0, 0)
+#undef NDQ_T
+  });
+#pragma unroll
+  for (int jb = 0; jb < C::NB; ++jb)
+#pragma unroll
+    for (int kb = 0; kb < C::NB; ++kb) acc[jb][kb] += d[jb][kb];
 }
 
 // in-place variant for hbar = W^T zbar (all streams are split first, then overwritten)
@@ -506,6 +621,24 @@ __device__ __forceinline__ void hidden_layer(const float* lds, int l, int lane, 
   }
 }
 
+// same with the layer input given as bf16x3 planes
+template <class C, bool BWD>
+__device__ __forceinline__ void hidden_layer_planes(const float* lds, int l, int lane, int q, const Planes<C>& P,
+                                                    LayerState<C>& st) {
+  f32x4 z[C::NS][C::NB];
+  zero_frag<C>(z);
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
+  gemm_planes<C>(lds + C::ldsWf(l, BWD), lane, P, z);
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[0][b][r], st.t[b][r], st.c[b][r]);
+#pragma unroll
+    for (int s = 1; s < C::NS; ++s) st.z[s][b] = z[s][b];
+  }
+}
+
 __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lane groups q (lanes p, p+16, p+32, p+48)
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
@@ -560,6 +693,41 @@ __device__ __forceinline__ void output_layer_mfma(const float* lds, int lane, in
       }
 }
 
+// forward pass of one tile keeping every layer's state; h = streams of the last hidden layer's activations
+// forward-only hidden layer on the bf16x3 path (planes are transient)
+template <class C>
+__device__ __forceinline__ void gemm_layer_bf16(const float* lds, int l, int lane, int q, const f32x4 (&h)[C::NS][C::NB],
+                                                LayerState<C>& st) {
+  Planes<C> P;
+  split_all<C>(h, P);
+  hidden_layer_planes<C, false>(lds, l, lane, q, P, st);
+}
+
+template <class C> struct KeptPlanes { Planes<C> hk[(C::KEEP_PLANES && C::L > 1) ? C::L - 1 : 1]; };
+
+template <class C, bool BWD>
+__device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, const float (&x)[C::D],
+                                             LayerState<C> (&st)[C::L], f32x4 (&h)[C::NS][C::NB], KeptPlanes<C>& kp) {
+  first_layer<C, BWD>(lds, q, x, st[0]);
+  sfor<C::L - 1>([&](auto li_) {
+    constexpr int li = decltype(li_)::value;  // computes layer l = li + 2 from layer li + 1
+    act_forward<C>(st[li], h);
+    if constexpr (C::BF16) {
+      if constexpr (BWD && C::KEEP_PLANES) {   // the weight-gradient GEMM of layer l reuses these planes
+        split_all<C>(h, kp.hk[li]);
+        hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, kp.hk[li], st[li + 1]);
+      } else {
+        Planes<C> P;
+        split_all<C>(h, P);
+        hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, P, st[li + 1]);
+      }
+    } else {
+      hidden_layer<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
+    }
+  });
+  act_forward<C>(st[C::L - 1], h);
+}
+
 // ------------------------------------------------------------------------------------------------ forward kernel
 template <class C>
 __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) {
@@ -575,13 +743,14 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
     float x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
-    LayerState<C> st;
+    LayerState<C> st;                      // one state, reused layer after layer (nothing is kept for a reverse pass)
     first_layer<C, false>(lds, q, x, st);
     f32x4 h[C::NS][C::NB];
 #pragma unroll
     for (int l = 2; l <= C::L; ++l) {
       act_forward<C>(st, h);
-      hidden_layer<C, false>(lds, l, lane, q, h, st);
+      if constexpr (C::BF16) gemm_layer_bf16<C>(lds, l, lane, q, h, st);
+      else hidden_layer<C, false>(lds, l, lane, q, h, st);
     }
     act_forward<C>(st, h);
     if constexpr (C::NOUT == 1) {
@@ -723,29 +892,16 @@ __device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
   }
 }
 
-// forward pass of one tile keeping every layer's state; h = streams of the last hidden layer's activations
-template <class C, bool BWD>
-__device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, const float (&x)[C::D],
-                                             LayerState<C> (&st)[C::L], f32x4 (&h)[C::NS][C::NB]) {
-  first_layer<C, BWD>(lds, q, x, st[0]);
-  sfor<C::L - 1>([&](auto li_) {
-    constexpr int li = decltype(li_)::value;  // computes layer l = li + 2 from layer li + 1
-    act_forward<C>(st[li], h);
-    hidden_layer<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
-  });
-  act_forward<C>(st[C::L - 1], h);
-}
-
 template <class C>
 __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* stage, int lane, int p, int q,
                                                      const float (&x)[C::D], LayerState<C> (&st)[C::L],
-                                                     f32x4 (&g)[C::NS][C::NB], GradAcc<C>& acc);
+                                                     f32x4 (&g)[C::NS][C::NB], GradAcc<C>& acc, KeptPlanes<C>& kp);
 
 // reverse pass of one tile, multi-output network: go[s][ob] = dLoss/d out[s][16ob+4q+r] for the tile's points
 template <class C>
 __device__ __forceinline__ void tile_backward_multi(const float* lds, float* stage, int lane, int p, int q,
                                                     const float (&x)[C::D], const f32x4 (&go)[C::NS][C::NBO],
-                                                    LayerState<C> (&st)[C::L], GradAcc<C>& acc) {
+                                                    LayerState<C> (&st)[C::L], GradAcc<C>& acc, KeptPlanes<C>& kp) {
 #pragma unroll
   for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
@@ -764,14 +920,14 @@ __device__ __forceinline__ void tile_backward_multi(const float* lds, float* sta
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) g[s][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, go[s][ob][t], g[s][kb], 0, 0, 0);
       }
-  tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc);
+  tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc, kp);
 }
 
 // reverse pass of one tile: gout[s] = dLoss/d out[s] for the tile's points (0 for padding lanes)
 template <class C>
 __device__ __forceinline__ void tile_backward(const float* lds, float* stage, int lane, int p, int q,
                                               const float (&x)[C::D], const float (&gout)[C::NS],
-                                              LayerState<C> (&st)[C::L], GradAcc<C>& acc) {
+                                              LayerState<C> (&st)[C::L], GradAcc<C>& acc, KeptPlanes<C>& kp) {
   // ---------------- output layer adjoint (n_out = 1): hbar = Wout * gout; dWout += sum_s gout_s h_s; dbout += gout_0
   // (h_s of the last hidden layer is recomputed per stream from its state instead of being kept live)
   f32x4 g[C::NS][C::NB];
@@ -800,14 +956,14 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
     }
   }
   acc.bout += (q == 0) ? gout[0] : 0.f;
-  tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc);
+  tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc, kp);
 }
 
 // hidden layers L .. 2 and the first layer, given g = hbar of the last hidden layer
 template <class C>
 __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* stage, int lane, int p, int q,
                                                      const float (&x)[C::D], LayerState<C> (&st)[C::L],
-                                                     f32x4 (&g)[C::NS][C::NB], GradAcc<C>& acc) {
+                                                     f32x4 (&g)[C::NS][C::NB], GradAcc<C>& acc, KeptPlanes<C>& kp) {
   using SS = typename C::SS;
   // ---------------- hidden layers L .. 2
   sfor<C::L - 1>([&](auto k_) {
@@ -818,10 +974,30 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
     for (int b = 0; b < C::NB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc.b[l - 2][b][r] += g[0][b][r];
-    weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2]);   // inputs of layer l = activations of layer l-1
-    if constexpr (C::BF16) {
-      gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);             // hbar_{l-1} = W_l^T zbar_l
+    if constexpr (C::DW_MM) {
+      Planes<C> Z;
+      split_all<C>(g, Z);                                             // zbar_l planes: used by BOTH GEMMs below
+      if constexpr (C::KEEP_PLANES) {
+        weight_grad_mm<C>(lane, Z, kp.hk[li - 1], acc.w[l - 2]);       // inputs of layer l: planes kept by the forward
+      } else {
+        f32x4 hin[C::NS][C::NB];
+        Planes<C> Hh;
+        act_forward<C>(st[li - 1], hin);
+        split_all<C>(hin, Hh);
+        weight_grad_mm<C>(lane, Z, Hh, acc.w[l - 2]);
+      }
+      f32x4 o[C::NS][C::NB];
+      zero_frag<C>(o);
+      gemm_planes<C>(lds + C::ldsWt(l), lane, Z, o);                  // hbar_{l-1} = W_l^T zbar_l
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+        for (int b = 0; b < C::NB; ++b) g[s][b] = o[s][b];
+    } else if constexpr (C::BF16) {
+      weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2]);
+      gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);
     } else {
+      weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2]);   // inputs of layer l = activations of layer l-1
 #if NDQ_HBAR_INPLACE
       gemm_frag_inplace<C>(lds + C::ldsWt(l), lane, g);
 #else
@@ -962,12 +1138,13 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
     LayerState<C> st[C::L];
     f32x4 h[C::NS][C::NB];
-    tile_forward<C, true>(lds, lane, q, x, st, h);
+    KeptPlanes<C> kp;
+    tile_forward<C, true>(lds, lane, q, x, st, h, kp);
     if constexpr (C::NOUT == 1) {
       float gout[C::NS];
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) gout[s] = valid ? a.gbar[(size_t)s * a.ldj + nn] : 0.f;
-      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc);
+      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc, kp);
     } else {
       f32x4 go[C::NS][C::NBO];
 #pragma unroll
@@ -979,7 +1156,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
             const int u = 16 * ob + 4 * q + r;
             go[s][ob][r] = (valid && u < C::NOUT) ? a.gbar[((size_t)s * C::NOUT + u) * a.ldj + nn] : 0.f;
           }
-      tile_backward_multi<C>(lds, stage, lane, p, q, x, go, st, acc);
+      tile_backward_multi<C>(lds, stage, lane, p, q, x, go, st, acc, kp);
     }
   }
   block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
@@ -1026,7 +1203,8 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
     LayerState<C> st[C::L];
     f32x4 h[C::NS][C::NB];
-    tile_forward<C, TRAIN>(lds, lane, q, x, st, h);
+    KeptPlanes<C> kp;
+    tile_forward<C, TRAIN>(lds, lane, q, x, st, h, kp);
     float jets[C::NS], gout[C::NS], r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
     tile_output<C, TRAIN>(lds, q, h, jets);
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
@@ -1045,7 +1223,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     if constexpr (TRAIN) {
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) gout[s] = valid ? gout[s] : 0.f;
-      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc);
+      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc, kp);
     }
   }
   if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);

@@ -47,7 +47,7 @@ def main():
                 parts += [rng.uniform(-k, k, a * b), rng.uniform(-k, k, b)]
             flat = np.concatenate(parts).astype(np.float32)
             coords = rng.uniform(0, 1, (dims[0], N)).astype(np.float32)
-            gbar = rng.standard_normal((len(streams), N)).astype(np.float32)
+            gbar = (rng.standard_normal((len(streams), N)) * float(os.environ.get("KBENCH_GSCALE", "1"))).astype(np.float32)
             c, p, g = torch.from_numpy(coords).cuda(), torch.from_numpy(flat).cuda(), torch.from_numpy(gbar).cuda()
             jets = torch.zeros(len(streams), N, device="cuda")
             nb = L.ndq_mlp_bwd_blocks(ctypes.byref(d), N)
