@@ -22,7 +22,8 @@ extern "C" {
 /* Shape of one FCNN (networks.py:59-66: Linear(d,h) actv [Linear(h,h) actv]* Linear(h,n_out)) plus the set of
  * derivative streams of its raw output that the residual needs.  Stream order in every jets/gbar array:
  *   0: value | 1..d: d/dx_a (if first) | second-order pairs (a<=b) selected by mask2, enumerated
- *   (0,0),(0,1),..,(0,d-1),(1,1),..  (bit k of mask2 <-> k-th pair).  */
+ *   (0,0),(0,1),..,(0,d-1),(1,1),..  (bit k of mask2 <-> k-th pair).
+ *   With lap = 1 the second-order part is a single stream: sum over the diagonal pairs in mask2 of d2/dx_a^2.  */
 typedef struct ndq_mlp_desc {
   int d;       /* number of input coordinates (1..3) */
   int first;   /* 1: first-order streams present */
@@ -31,6 +32,7 @@ typedef struct ndq_mlp_desc {
   int layers;  /* number of hidden layers */
   int act;     /* NDQ_ACT_* */
   int n_out;   /* output units */
+  int lap;     /* 1: "Laplacian stream" -- the diagonal pairs of mask2 are carried as ONE stream holding their sum */
 } ndq_mlp_desc;
 
 /* 1 if libndq.so carries kernels for this descriptor. */

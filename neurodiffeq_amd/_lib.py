@@ -10,10 +10,10 @@ NDQ_ACT_TANH, NDQ_ACT_SIN = 0, 1
 
 class MlpDesc(ctypes.Structure):
     _fields_ = [("d", ctypes.c_int), ("first", ctypes.c_int), ("mask2", ctypes.c_int), ("hidden", ctypes.c_int),
-                ("layers", ctypes.c_int), ("act", ctypes.c_int), ("n_out", ctypes.c_int)]
+                ("layers", ctypes.c_int), ("act", ctypes.c_int), ("n_out", ctypes.c_int), ("lap", ctypes.c_int)]
 
     def key(self):
-        return (self.d, self.first, self.mask2, self.hidden, self.layers, self.act, self.n_out)
+        return (self.d, self.first, self.mask2, self.hidden, self.layers, self.act, self.n_out, self.lap)
 
 
 FUSED_LAUNCH_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,

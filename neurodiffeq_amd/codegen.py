@@ -43,9 +43,16 @@ class NetStreams:
         self.n_out = n_out
         self.first = 0
         self.mask2 = 0
+        self.lap = 0            # 1: the diagonal pairs of mask2 travel as ONE stream holding their sum
 
     def need(self, mi):
-        """mi: multi-index of GLOBAL coordinate indices."""
+        """mi: multi-index of GLOBAL coordinate indices, or ("L", a, b, ..) for the Laplacian stream."""
+        if mi and mi[0] == "L":
+            self.first, self.lap = 1, 1
+            for c in mi[1:]:
+                a = self.deps.index(c)
+                self.mask2 |= 1 << pair_list(self.d).index((a, a))
+            return
         loc = tuple(sorted(self.deps.index(c) for c in mi))
         if len(loc) >= 1:
             self.first = 1
@@ -54,9 +61,12 @@ class NetStreams:
 
     @property
     def n_streams(self):
-        return 1 + self.first * self.d + bin(self.mask2).count("1")
+        return 1 + self.first * self.d + (1 if self.lap else bin(self.mask2).count("1"))
 
     def slot(self, mi):
+        if mi and mi[0] == "L":
+            return 1 + self.d
+        assert not (self.lap and len(mi) == 2)
         loc = tuple(sorted(self.deps.index(c) for c in mi))
         if len(loc) == 0:
             return 0
@@ -111,12 +121,16 @@ class PointwiseProgram:
     streams    : {net_idx: NetStreams}
     """
 
-    def __init__(self, graph: Graph, residuals, funcs, n_nets, widen=None):
+    def __init__(self, graph: Graph, residuals, funcs, n_nets, widen=None, allow_lap=None):
         """widen(net_idx, NetStreams): optional hook that may enlarge ``first`` / ``mask2`` of a net to the nearest
-        stream set libndq.so has kernels for (slots are assigned after it ran)."""
+        stream set libndq.so has kernels for (slots are assigned after it ran).
+        allow_lap(net_idx, coords) -> bool: may the second derivatives of net k w.r.t. ``coords`` be merged into one
+        Laplacian stream (asked only after the merge has been proven valid symbolically)."""
         self.g = graph
         self.residuals = list(residuals)
         self.funcs = list(funcs)
+        if allow_lap is not None:
+            self.residuals = self._merge_laplacian(self.residuals, self.funcs, n_nets, allow_lap)
         self.n_nets = n_nets
         self.n_coords = graph.n_coords
         self.order = graph.reachable(self.residuals + self.funcs)
@@ -137,6 +151,50 @@ class PointwiseProgram:
                 widen(k, st)
         self.source = self._emit()
         self.key = hashlib.sha1(self.source.encode()).hexdigest()[:16]
+
+    # ---- Laplacian-stream rewrite
+    def _merge_laplacian(self, residuals, funcs, n_nets, allow_lap):
+        """If every residual depends on the pure second derivatives N_aa of a network output only through their SUM
+        (d r / d N_aa is the same expression for all a, and free of the N_bb), replace them by one symbol
+        L = sum_a N_aa: r(N_xx, N_yy, ..) = r0 + c (N_xx + N_yy + ..) = r(L, 0, ..).  Proven on the DAG, per network."""
+        g = self.g
+        order = g.reachable(list(residuals) + list(funcs))
+        second = {}
+        for i in order:
+            n = g.nodes[i]
+            if n[0] == "net" and len(n[3]) == 2 and n[3][0] != "L":
+                second.setdefault(n[1], []).append(i)
+        func_set = set(g.reachable(list(funcs)))
+        out = list(residuals)
+        for k, leaves in second.items():
+            mis = [g.nodes[i][3] for i in leaves]
+            if any(a != b for a, b in mis) or len(leaves) < 2:
+                continue                                     # mixed partials present, or nothing to merge
+            if any(i in func_set for i in leaves):
+                continue
+            by_out = {}
+            for i in leaves:
+                by_out.setdefault(g.nodes[i][2], []).append(i)
+            coords = sorted({mi[0] for mi in mis})
+            if any(sorted(g.nodes[i][3][0] for i in ls) != coords for ls in by_out.values()):
+                continue                                     # every output must use the same coordinate set
+            leafset = set(leaves)
+            ok = True
+            for r in out:
+                for o, ls in by_out.items():
+                    ds = [g.diff(r, ("n", i)) for i in ls]
+                    if any(d != ds[0] for d in ds) or any(j in leafset for j in g.reachable([ds[0]])):
+                        ok = False
+            if not ok or not allow_lap(k, tuple(coords)):
+                continue
+            mapping = {}
+            for o, ls in by_out.items():
+                lap = g.net(k, o, ("L",) + tuple(coords))
+                for j, i in enumerate(sorted(ls, key=lambda i: g.nodes[i][3])):
+                    mapping[i] = lap if j == 0 else g.const(0.0)
+            memo = {}
+            out = [g.subst(r, mapping, memo) for r in out]
+        return out
 
     # ---- helpers
     def _val(self, i):
@@ -258,7 +316,7 @@ class PointwiseProgram:
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}>;
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf};
   static __device__ __forceinline__ void apply(const float (&x)[CFG::D], const float (&jets)[CFG::NS], float seed,

@@ -6,33 +6,35 @@
 namespace ndq {
 
 // ---------------------------------------------------------------------------------------------- kernel table
-// X(D, FIRST, MASK2, NB, L, ACT, NOUT).  Stream sets are closed under "second order needs first order".
+// X(D, FIRST, MASK2, NB, L, ACT, NOUT, LAP).  Stream sets are closed under "second order needs first order".
 // BASELINE configs: C1 (1,1,0,2,2,SIN) | C2 (2,1,0b101,2,2,TANH) | C3 (2,1,0b001,4,3,TANH) | C5 u,v (2,1,0b101,4,3,TANH),
 // p (2,1,0,4,3,TANH); value-only variants serve solution evaluation (solvers.py:682-720).
 #ifndef NDQ_CFG_TABLE
 #define NDQ_CFG_TABLE(X)      \
-  X(1, 0, 0, 2, 2, ACT_SIN, 1)   \
-  X(1, 1, 0, 2, 2, ACT_SIN, 1)   \
-  X(1, 1, 1, 2, 2, ACT_SIN, 1)   \
-  X(1, 0, 0, 2, 2, ACT_TANH, 1)  \
-  X(1, 1, 0, 2, 2, ACT_TANH, 1)  \
-  X(1, 1, 1, 2, 2, ACT_TANH, 1)  \
-  X(2, 0, 0, 2, 2, ACT_TANH, 1)  \
-  X(2, 1, 0, 2, 2, ACT_TANH, 1)  \
-  X(2, 1, 1, 2, 2, ACT_TANH, 1)  \
-  X(2, 1, 5, 2, 2, ACT_TANH, 1)  \
-  X(2, 1, 7, 2, 2, ACT_TANH, 1)  \
-  X(2, 0, 0, 4, 3, ACT_TANH, 1)  \
-  X(2, 1, 0, 4, 3, ACT_TANH, 1)  \
-  X(2, 1, 1, 4, 3, ACT_TANH, 1)  \
-  X(2, 1, 5, 4, 3, ACT_TANH, 1)  \
-  X(1, 0, 0, 2, 2, ACT_TANH, 25) \
-  X(1, 1, 1, 2, 2, ACT_TANH, 25) \
-  X(2, 1, 5, 2, 2, ACT_TANH, 3)
+  X(1, 0, 0, 2, 2, ACT_SIN, 1, 0)   \
+  X(1, 1, 0, 2, 2, ACT_SIN, 1, 0)   \
+  X(1, 1, 1, 2, 2, ACT_SIN, 1, 0)   \
+  X(1, 0, 0, 2, 2, ACT_TANH, 1, 0)  \
+  X(1, 1, 0, 2, 2, ACT_TANH, 1, 0)  \
+  X(1, 1, 1, 2, 2, ACT_TANH, 1, 0)  \
+  X(2, 0, 0, 2, 2, ACT_TANH, 1, 0)  \
+  X(2, 1, 0, 2, 2, ACT_TANH, 1, 0)  \
+  X(2, 1, 1, 2, 2, ACT_TANH, 1, 0)  \
+  X(2, 1, 5, 2, 2, ACT_TANH, 1, 0)  \
+  X(2, 1, 7, 2, 2, ACT_TANH, 1, 0)  \
+  X(2, 0, 0, 4, 3, ACT_TANH, 1, 0)  \
+  X(2, 1, 0, 4, 3, ACT_TANH, 1, 0)  \
+  X(2, 1, 1, 4, 3, ACT_TANH, 1, 0)  \
+  X(2, 1, 5, 4, 3, ACT_TANH, 1, 0)  \
+  X(1, 0, 0, 2, 2, ACT_TANH, 25, 0) \
+  X(1, 1, 1, 2, 2, ACT_TANH, 25, 0) \
+  X(2, 1, 5, 2, 2, ACT_TANH, 3, 0)  \
+  X(2, 1, 5, 2, 2, ACT_TANH, 1, 1)  \
+  X(2, 1, 5, 4, 3, ACT_TANH, 1, 1)
 #endif
 
 struct Entry {
-  int d, first, mask2, nb, layers, act, nout;
+  int d, first, mask2, nb, layers, act, nout, lap;
   int ns, p, bwd_waves;
   int (*fwd)(const MlpArgs&, hipStream_t);
   int (*bwd)(const MlpArgs&, int blocks, hipStream_t);
@@ -79,12 +81,12 @@ int launch_bwd(const MlpArgs& a, int blocks, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-#define NDQ_ENTRY(D, F, M, NB, L, A, O)                                                                   \
-  Entry{D, F, M, NB, L, A, O, Cfg<D, F, M, NB, L, A, O>::NS, Cfg<D, F, M, NB, L, A, O>::P,                \
-        Cfg<D, F, M, NB, L, A, O>::BWD_THREADS / 64,                                                      \
-        &launch_fwd<Cfg<D, F, M, NB, L, A, O>>, &launch_bwd<Cfg<D, F, M, NB, L, A, O>>,                   \
-        fwd_lds_bytes<Cfg<D, F, M, NB, L, A, O>>(),                                                       \
-        bwd_lds_bytes<Cfg<D, F, M, NB, L, A, O>>(Cfg<D, F, M, NB, L, A, O>::BWD_THREADS / 64)},
+#define NDQ_ENTRY(D, F, M, NB, L, A, O, LP)                                                               \
+  Entry{D, F, M, NB, L, A, O, LP, Cfg<D, F, M, NB, L, A, O, LP>::NS, Cfg<D, F, M, NB, L, A, O, LP>::P,    \
+        Cfg<D, F, M, NB, L, A, O, LP>::BWD_THREADS / 64,                                                  \
+        &launch_fwd<Cfg<D, F, M, NB, L, A, O, LP>>, &launch_bwd<Cfg<D, F, M, NB, L, A, O, LP>>,           \
+        fwd_lds_bytes<Cfg<D, F, M, NB, L, A, O, LP>>(),                                                   \
+        bwd_lds_bytes<Cfg<D, F, M, NB, L, A, O, LP>>(Cfg<D, F, M, NB, L, A, O, LP>::BWD_THREADS / 64)},
 
 static const Entry kTable[] = {NDQ_CFG_TABLE(NDQ_ENTRY)};
 
@@ -92,7 +94,7 @@ static const Entry* find(const ndq_mlp_desc* d) {
   if (!d || d->hidden % 16) return nullptr;
   for (const Entry& e : kTable)
     if (e.d == d->d && e.first == d->first && e.mask2 == d->mask2 && e.nb * 16 == d->hidden && e.layers == d->layers &&
-        e.act == d->act && e.nout == d->n_out)
+        e.act == d->act && e.nout == d->n_out && e.lap == d->lap)
       return &e;
   return nullptr;
 }

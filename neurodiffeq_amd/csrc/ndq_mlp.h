@@ -44,18 +44,32 @@ __device__ __forceinline__ void sfor(F&& f) {
 // ------------------------------------------------------------------------------------------------ streams
 // A derivative stream is () value, (a) d/dx_a, (a,b) d2/dx_a dx_b with a <= b.  Stream order:
 //   0 | 1..D (if FIRST) | the second-order pairs selected by M2 in the order (0,0),(0,1)..(0,D-1),(1,1)...
-template <int D_, int FIRST_, unsigned M2_>
+// LAP = 1 ("Laplacian stream"): the diagonal pairs (a,a) selected by M2 are NOT propagated separately; ONE stream
+// carries their sum  L = sum_a d2/dx_a^2  (closed under the recurrences: h_L = s2 sum_a z_a^2 + s1 z_L, z_L = W h_L).
+// Usable whenever the residual depends on those second derivatives only through that sum (Laplace, Poisson, heat,
+// Navier-Stokes ...); the pointwise code generator proves this symbolically before asking for it.
+template <int D_, int FIRST_, unsigned M2_, int LAP_ = 0>
 struct Streams {
   static constexpr int D = D_;
   static constexpr int FIRST = FIRST_;
   static constexpr unsigned M2 = M2_;
+  static constexpr int LAP = LAP_;
   static constexpr int NPAIR = D * (D + 1) / 2;
   static constexpr int count2() {
     int c = 0;
     for (int k = 0; k < NPAIR; ++k) c += (M2 >> k) & 1u;
     return c;
   }
-  static constexpr int N2 = count2();
+  static constexpr int N2 = LAP ? 1 : count2();   // number of second-order streams
+  static constexpr bool in_lap(int a) {           // coordinate a contributes to the Laplacian stream
+    int idx = 0;
+    for (int x = 0; x < D; ++x)
+      for (int y = x; y < D; ++y) {
+        if (x == a && y == a) return (M2 >> idx) & 1u;
+        ++idx;
+      }
+    return false;
+  }
   static constexpr int NS = 1 + FIRST * D + N2;
   static constexpr int S2 = 1 + FIRST * D;  // index of the first second-order stream
   static_assert(FIRST == 1 || M2 == 0, "second-order streams need the first-order ones");
@@ -163,9 +177,9 @@ template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
 };
 
 // ------------------------------------------------------------------------------------------------ config
-template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1>
+template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0>
 struct Cfg {
-  using SS = Streams<D_, FIRST_, M2_>;
+  using SS = Streams<D_, FIRST_, M2_, LAP_>;
   static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
   static constexpr int NOUT = NOUT_;               // output units; > 1: the output layer is an MFMA layer too
   static constexpr int NBO = (NOUT_ + 15) / 16;    // 16-row blocks of the (zero-padded) output layer
@@ -331,7 +345,15 @@ __device__ __forceinline__ void act_forward(const LayerState<C>& st, f32x4 (&h)[
           constexpr int a = decltype(a_)::value;
           h[1 + a][b][r] = s1 * st.z[1 + a][b][r];
         });
-        if constexpr (SS::N2 > 0) {
+        if constexpr (SS::LAP) {
+          const float s2 = A::s2(t, c, s1);
+          float q2 = 0.f;
+          sfor<C::D>([&](auto a_) {
+            constexpr int a = decltype(a_)::value;
+            if constexpr (SS::in_lap(a)) q2 = fmaf(st.z[1 + a][b][r], st.z[1 + a][b][r], q2);
+          });
+          h[SS::S2][b][r] = fmaf(s2, q2, s1 * st.z[SS::S2][b][r]);
+        } else if constexpr (SS::N2 > 0) {
           const float s2 = A::s2(t, c, s1);
           sfor<SS::N2>([&](auto k_) {
             constexpr int s = SS::S2 + decltype(k_)::value;
@@ -357,6 +379,14 @@ __device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, f32x
         hs[b][r] = t;
       } else if constexpr (S < SS::S2) {
         hs[b][r] = A::s1(t, c) * st.z[S][b][r];
+      } else if constexpr (SS::LAP) {
+        const float s1 = A::s1(t, c);
+        float q2 = 0.f;
+        sfor<C::D>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
+          if constexpr (SS::in_lap(a)) q2 = fmaf(st.z[1 + a][b][r], st.z[1 + a][b][r], q2);
+        });
+        hs[b][r] = fmaf(A::s2(t, c, s1), q2, s1 * st.z[S][b][r]);
       } else {
         constexpr int a = SS::A(S), bb = SS::B(S);
         const float s1 = A::s1(t, c);
@@ -385,7 +415,22 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, f32x4 (&g)
           z0 = fmaf(s2 * st.z[1 + a][b][r], g[1 + a][b][r], z0);
           za[a] = s1 * g[1 + a][b][r];
         });
-        if constexpr (SS::N2 > 0) {
+        if constexpr (SS::LAP) {
+          // h_L = s2 * sum_a z_a^2 + s1 * z_L
+          const float s3 = A::s3(t, c, s1);
+          const float hb = g[SS::S2][b][r];
+          float q2 = 0.f;
+          sfor<C::D>([&](auto a_) {
+            constexpr int a = decltype(a_)::value;
+            if constexpr (SS::in_lap(a)) {
+              const float zA = st.z[1 + a][b][r];
+              q2 = fmaf(zA, zA, q2);
+              za[a] = fmaf(2.f * s2 * zA, hb, za[a]);
+            }
+          });
+          z0 = fmaf(fmaf(s3, q2, s2 * st.z[SS::S2][b][r]), hb, z0);
+          g[SS::S2][b][r] = s1 * hb;
+        } else if constexpr (SS::N2 > 0) {
           const float s3 = A::s3(t, c, s1);
           sfor<SS::N2>([&](auto k_) {
             constexpr int s = SS::S2 + decltype(k_)::value;

@@ -11,6 +11,7 @@ fixed launch sequence on one HIP stream, per batch:
 No host synchronisation happens inside a step; the loss stays in HBM until the caller reads it.
 """
 import ctypes
+import os
 
 import torch
 
@@ -57,12 +58,28 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
         g.net_nout.setdefault(k, info["n_out"])
     descs = {}
 
+    def allow_lap(k, coords):
+        """Is there a kernel for net k with the second derivatives w.r.t. ``coords`` merged into one Laplacian stream?"""
+        info = infos[k]
+        deps = g.net_deps[k]
+        if os.environ.get("NDQ_NO_LAP") or any(c not in deps for c in coords):
+            return False
+        mask2 = 0
+        for c in coords:
+            a = deps.index(c)
+            mask2 |= 1 << codegen.pair_list(len(deps)).index((a, a))
+        d = _lib.MlpDesc(len(deps), 1, mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1)
+        return bool(L.ndq_mlp_supported(ctypes.byref(d)))
+
     def widen(k, st):
         info = infos[k]
         if st.d != info["d"]:
             raise TraceUnsupported("network input width differs from the number of coordinates fed to it")
         if list(st.deps) != list(range(st.deps[0], st.deps[0] + st.d)):
             raise TraceUnsupported("network fed a non-contiguous subset of the coordinates")
+        if st.lap:                      # allow_lap already checked that this exact kernel exists
+            descs[k] = _lib.MlpDesc(st.d, 1, st.mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1)
+            return
         npair = st.d * (st.d + 1) // 2
         best = None
         for first in ((1,) if st.first else (0, 1)):
@@ -80,7 +97,8 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
         st.first, st.mask2 = best[1].first, best[1].mask2
         descs[k] = best[1]
 
-    program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets), widen=widen)
+    program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets), widen=widen,
+                                       allow_lap=allow_lap)
     return program, descs
 
 

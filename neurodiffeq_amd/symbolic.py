@@ -85,7 +85,10 @@ class Graph:
         return self._mk(("coord", int(i)))
 
     def net(self, net_idx, out_idx, mi=()):
-        return self._mk(("net", int(net_idx), int(out_idx), tuple(sorted(mi))))
+        mi = tuple(mi)
+        if not (mi and mi[0] == "L"):       # ("L", a, b, ..) = Laplacian stream: sum over a of d2/dx_a^2
+            mi = tuple(sorted(mi))
+        return self._mk(("net", int(net_idx), int(out_idx), mi))
 
     def cval(self, i):
         n = self.nodes[i]
@@ -194,6 +197,8 @@ class Graph:
         D = lambda x: self.diff(x, ci)
         if op == "const":
             r = self.const(0.0)
+        elif isinstance(ci, tuple) and op in ("coord", "net"):   # d/d(leaf node ("n", id)): other leaves independent
+            r = self.const(1.0 if e == ci[1] else 0.0)
         elif op == "coord":
             r = self.const(1.0 if n[1] == ci else 0.0)
         elif op == "net":
@@ -255,6 +260,30 @@ class Graph:
             else:  # pragma: no cover
                 raise TraceUnsupported(f"no derivative rule for {op}")
         self._dcache[key] = r
+        return r
+
+    def subst(self, e, mapping, _memo=None):
+        """Rebuild node e with leaves replaced according to mapping {leaf node id: node id} (simplifying on the way)."""
+        memo = {} if _memo is None else _memo
+        if e in mapping:
+            return mapping[e]
+        r = memo.get(e)
+        if r is not None:
+            return r
+        n = self.nodes[e]
+        op = n[0]
+        S = lambda x: self.subst(x, mapping, memo)
+        if op in ("const", "coord", "net"):
+            r = e
+        elif op in ("add", "sub", "mul", "div"):
+            r = getattr(self, op)(S(n[1]), S(n[2]))
+        elif op == "powi":
+            r = self.powi(S(n[1]), n[2])
+        elif op == "powc":
+            r = self.powc(S(n[1]), n[2])
+        else:
+            r = self.unary(op, S(n[1]))
+        memo[e] = r
         return r
 
     # -------------------------------------------------------------- queries

@@ -14,7 +14,7 @@ from neurodiffeq_amd._lib import MlpDesc  # noqa: E402
 from oracle import jet_ref as J  # noqa: E402
 
 N = int(os.environ.get("KBENCH_N", 65536))
-CFGS = {"c2": ((2, 32, 32, 1), "tanh", MlpDesc(2, 1, 5, 32, 2, 0, 1), [(), (0,), (1,), (0, 0), (1, 1)], 10688)}
+CFGS = {"c2": ((2, 32, 32, 1), "tanh", MlpDesc(2, 1, 5, 32, 2, 0, 1, 0), [(), (0,), (1,), (0, 0), (1, 1)], 10688)}
 
 
 def rel(a, b):

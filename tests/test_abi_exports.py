@@ -19,14 +19,16 @@ def test_every_declared_symbol_is_exported():
 
 def test_descriptor_queries_without_gpu():
     L = _lib.lib()
-    c2 = _lib.MlpDesc(2, 1, 5, 32, 2, _lib.NDQ_ACT_TANH, 1)
+    c2 = _lib.MlpDesc(2, 1, 5, 32, 2, _lib.NDQ_ACT_TANH, 1, 0)
     assert L.ndq_mlp_supported(ctypes.byref(c2)) == 1
     assert L.ndq_mlp_num_streams(ctypes.byref(c2)) == 5
     assert L.ndq_mlp_num_params(ctypes.byref(c2)) == 2 * 32 + 32 + 32 * 32 + 32 + 32 + 1 == 1185
     assert L.ndq_mlp_bwd_blocks(ctypes.byref(c2), 65536) >= 1
-    c3 = _lib.MlpDesc(2, 1, 1, 64, 3, _lib.NDQ_ACT_TANH, 1)
+    c2lap = _lib.MlpDesc(2, 1, 5, 32, 2, _lib.NDQ_ACT_TANH, 1, 1)        # Laplacian stream: value, x, y, xx+yy
+    assert L.ndq_mlp_supported(ctypes.byref(c2lap)) == 1 and L.ndq_mlp_num_streams(ctypes.byref(c2lap)) == 4
+    c3 = _lib.MlpDesc(2, 1, 1, 64, 3, _lib.NDQ_ACT_TANH, 1, 0)
     assert L.ndq_mlp_num_params(ctypes.byref(c3)) == 8577
-    bad = _lib.MlpDesc(2, 1, 5, 40, 2, 0, 1)
+    bad = _lib.MlpDesc(2, 1, 5, 40, 2, 0, 1, 0)
     assert L.ndq_mlp_supported(ctypes.byref(bad)) == 0
     assert L.ndq_mlp_num_params(ctypes.byref(bad)) == -1
 

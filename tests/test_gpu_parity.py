@@ -34,7 +34,29 @@ ARCH = {
     "c4": ((1, 32, 32, 25), "tanh", 0, (1, 1, 1), [(), (0,), (0, 0)]),
     "c4val": ((1, 32, 32, 25), "tanh", 0, (1, 0, 0), [()]),
     "m3": ((2, 32, 32, 3), "tanh", 0, (2, 1, 5), [(), (0,), (1,), (0, 0), (1, 1)]),
+    # Laplacian stream: the two pure second derivatives travel as ONE stream holding their sum
+    "c2lap": ((2, 32, 32, 1), "tanh", 0, (2, 1, 5), [(), (0,), (1,), ("L", 0, 1)]),
+    "c5lap": ((2, 64, 64, 64, 1), "tanh", 0, (2, 1, 5), [(), (0,), (1,), ("L", 0, 1)]),
 }
+
+
+def _parts(m):
+    """oracle streams making up kernel stream m"""
+    return [(c, c) for c in m[1:]] if (m and m[0] == "L") else [m]
+
+
+def _oracle_jets(flat, dims, act, coords, streams):
+    want = sorted({p for m in streams for p in _parts(m)}, key=lambda t: (len(t), t))
+    js = J.mlp_jets(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)), want)
+    return {m: sum(js[p] for p in _parts(m)) for m in streams}
+
+
+def _oracle_vjp(flat, dims, act, coords, streams, gbar):
+    gb = {}
+    for s, m in enumerate(streams):
+        for p in _parts(m):
+            gb[p] = gb.get(p, 0) + gbar[s].astype(np.float64).T
+    return J.mlp_jets_vjp(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)), gb)
 SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96}
 
 
@@ -59,7 +81,8 @@ def L():
 def _desc(name):
     from neurodiffeq_amd import _lib
     dims, _, act, (d, first, mask2), _ = ARCH[name]
-    return _lib.MlpDesc(d, first, mask2, dims[1], len(dims) - 2, act, dims[-1])
+    lap = int(any(m and m[0] == "L" for m in ARCH[name][4]))
+    return _lib.MlpDesc(d, first, mask2, dims[1], len(dims) - 2, act, dims[-1], lap)
 
 
 def _stream():
@@ -128,7 +151,7 @@ def test_mlp_jet_fwd_matches_jet_oracle(L, name, n):
     flat = _params(name, rng)
     coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
     got = _fwd(L, name, coords, flat)
-    want = J.mlp_jets(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)), streams)
+    want = _oracle_jets(flat, dims, act, coords, streams)
     # rel-L2 per stream; for tiny batches a single stream value can be a near-cancellation of O(1) terms, so there
     # the denominator is floored at 10 % of the largest stream's RMS (absolute fp32 noise is what matters)
     floor = (0.1 if n < 64 else 0.0) * np.sqrt(n * dims[-1]) * max(np.sqrt(np.mean(want[m] ** 2)) for m in streams)
@@ -148,8 +171,7 @@ def test_mlp_jet_bwd_matches_jet_oracle(L, name, n):
     coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
     gbar = rng.standard_normal((len(streams), dims[-1], n)).astype(np.float32)
     got = _bwd(L, name, coords, flat, gbar)
-    want = J.mlp_jets_vjp(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)),
-                          {m: gbar[s].astype(np.float64).T for s, m in enumerate(streams)})
+    want = _oracle_vjp(flat, dims, act, coords, streams, gbar)
     errs = {g: rel_l2(got[a:b], want[a:b]) for g, a, b in _groups(name)}
     errs["all"] = rel_l2(got, want)
     diag(f"bwd_{name}_{n}", errs)
@@ -185,7 +207,7 @@ def test_bad_arguments_are_rejected(L):
     t = torch.zeros(64, device="cuda")
     assert L.ndq_mlp_jet_fwd(ctypes.byref(d), t.data_ptr(), 64, 0, t.data_ptr(), t.data_ptr(), 64, _stream()) == -2
     assert L.ndq_mlp_jet_fwd(ctypes.byref(d), t.data_ptr(), 8, 16, t.data_ptr(), t.data_ptr(), 64, _stream()) == -2
-    bad = _lib.MlpDesc(2, 1, 5, 40, 2, 0, 1)
+    bad = _lib.MlpDesc(2, 1, 5, 40, 2, 0, 1, 0)
     assert L.ndq_mlp_supported(ctypes.byref(bad)) == 0
     assert L.ndq_mlp_jet_fwd(ctypes.byref(bad), t.data_ptr(), 64, 16, t.data_ptr(), t.data_ptr(), 64, _stream()) == -1
 

@@ -22,7 +22,7 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def trace(cfg, n_coords):
+def trace(cfg, n_coords, lap=True):
     nets, conds = cfg["nets"], cfg["conds"]
     g = Graph(n_coords)
     g.register_nets(nets, [describe(n)["n_out"] for n in nets])
@@ -34,17 +34,21 @@ def trace(cfg, n_coords):
     for k, n in enumerate(nets):
         g.net_deps.setdefault(k, tuple(range(describe(n)["d"])))
         g.net_nout.setdefault(k, describe(n)["n_out"])
-    return codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets))
+    return codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets),
+                                    allow_lap=(lambda k, coords: True) if lap else None)
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c5", "c4"])
-def test_fused_pipeline_on_host_matches_reference(golden_dir, name):
+@pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
+                                      ("c4", True)])
+def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
     cfg = configs.make(name, SIZES[name])
     coords = gold["coords"].astype(np.float32)
     n_coords, n = coords.shape
-    prog = trace(cfg, n_coords)
+    prog = trace(cfg, n_coords, lap)
+    if name in ("c2", "c5"):     # Laplace / Navier-Stokes use u_xx + u_yy only: the merge must be found when allowed
+        assert any(prog.g.nodes[i][3][:1] == ("L",) for i in prog.symbols) == lap
     # network streams from the jet oracle (fp64 -> fp32), laid out like program.symbols
     dims_act, flats, off = [], [], 0
     for net in cfg["nets"]:
@@ -54,6 +58,8 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name):
         dims_act.append((dims, "tanh" if info["act"] == 0 else "sin"))
         flats.append(gold["params0"][off:off + npar].astype(np.float64))
         off += npar
+    # a ("L", a, b, ..) symbol is the Laplacian stream = sum of the pure second derivatives (a,a), (b,b), ..
+    parts = lambda mi: [(c, c) for c in mi[1:]] if (mi and mi[0] == "L") else [mi]
     needed = {k: set() for k in range(len(cfg["nets"]))}
     for i in prog.symbols:
         _, k, o, mi = prog.g.nodes[i]
@@ -61,9 +67,10 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name):
     jets = {}
     for k, (dims, act) in enumerate(dims_act):
         deps = prog.streams[k].deps
-        local = lambda mi: tuple(deps.index(c) for c in mi)
-        js = J.mlp_jets(flats[k], dims, act, [coords[c] for c in deps], [local(mi) for mi in needed[k]] or [()])
-        jets[k] = {mi: js[tuple(sorted(local(mi)))] for mi in needed[k]}               # (N, n_out)
+        local = lambda mi: tuple(sorted(deps.index(c) for c in mi))
+        want = sorted({local(m) for mi in needed[k] for m in parts(mi)})
+        js = J.mlp_jets(flats[k], dims, act, [coords[c] for c in deps], want or [()])
+        jets[k] = {mi: sum(js[local(m)] for m in parts(mi)) for mi in needed[k]}       # (N, n_out)
     syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]][:, prog.g.nodes[i][2]]
                      for i in prog.symbols]).astype(np.float32)
     n_eq = len(prog.residuals)
@@ -81,8 +88,9 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name):
         for idx, i in enumerate(prog.symbols):
             _, kk, o, mi = prog.g.nodes[i]
             if kk == k:
-                m = gb.setdefault(tuple(sorted(deps.index(c) for c in mi)), np.zeros((n, dims[-1])))
-                m[:, o] = gbar[idx].astype(np.float64)
+                for part in parts(mi):
+                    m = gb.setdefault(tuple(sorted(deps.index(c) for c in part)), np.zeros((n, dims[-1])))
+                    m[:, o] += gbar[idx].astype(np.float64)
         grads.append(J.mlp_jets_vjp(flats[k], dims, act, [coords[c] for c in deps], gb))
     assert rel_l2(np.concatenate(grads), gold["grad_f64"]) < 1e-5
 
