@@ -137,6 +137,9 @@ enum { ACT_TANH = 0, ACT_SIN = 1 };
 #ifndef NDQ_DW_MM
 #define NDQ_DW_MM 0
 #endif
+#ifndef NDQ_KEEP_H
+#define NDQ_KEEP_H 1
+#endif
 #ifndef NDQ_KEEP_PLANES
 #define NDQ_KEEP_PLANES 1
 #endif
@@ -209,6 +212,7 @@ struct Cfg {
   static constexpr bool DW_MM = BF16 && (NDQ_DW_MM != 0) && (NB_ == 2);   // wider nets: register budget, keep the LDS path
   static constexpr bool KEEP_PLANES = DW_MM && (NB_ == 2) && (L_ == 2) && (NDQ_KEEP_PLANES != 0);
   static constexpr int NCH = (SS::NS + 1) / 2;             // stream pairs = K-chunks of the weight-gradient MFMAs
+  static constexpr bool KEEP_H = (NB_ == 2) && (NDQ_KEEP_H != 0);
   static constexpr int layerStride(bool bwd) { return (bwd ? 2 : 1) * WEL + H; }
   static constexpr int ldsWf(int l, bool bwd) { return ldsLayer0 + (l - 2) * layerStride(bwd); }
   static constexpr int ldsWt(int l) { return ldsWf(l, true) + WEL; }
@@ -272,23 +276,19 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
       const float* W = prm + C::offW(l);
       __bf16* wf = reinterpret_cast<__bf16*>(lds + C::ldsWf(l, BWD));
       __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWt(l));
-      for (int i = tid; i < H * H; i += nt) {
-        const int e = i & 7, lane = (i >> 3) & 63, blk = i >> 9;   // blk = ob*NC + c
-        const int ob = blk / C::NC, c = blk - ob * C::NC;
-        const int unit = 16 * (2 * c + (e >> 2)) + 4 * (lane >> 4) + (e & 3);
-        const int row = 16 * ob + (lane & 15);
-        {
-          const float w = W[row * H + unit];                       // forward: out = row, in = unit
-          const __bf16 w0 = (__bf16)w; const float r1 = w - (float)w0;
-          const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (float)w1);
-          const int base = ((blk * 3) * 64 + lane) * 8 + e;
+      for (int i = tid; i < H * H; i += nt) {   // one coalesced pass over W[j][k] (out j, in k): split once, scatter twice
+        const int j = i / H, k = i - j * H;
+        const float w = W[i];
+        const __bf16 w0 = (__bf16)w; const float r1 = w - (float)w0;
+        const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (float)w1);
+        {  // forward image: block (ob = j/16, c = k/32), lane (j%16, kg = (k%16)/4), slot e = 4*((k%32)/16) + k%4
+          const int blk = (j >> 4) * C::NC + (k >> 5);
+          const int base = ((blk * 3) * 64 + (j & 15) + 16 * ((k & 15) >> 2)) * 8 + 4 * ((k & 31) >> 4) + (k & 3);
           wf[base] = w0; wf[base + 512] = w1; wf[base + 1024] = w2;
         }
-        if (BWD) {
-          const float w = W[unit * H + row];                       // transposed: out = in-unit row, contraction over out-units
-          const __bf16 w0 = (__bf16)w; const float r1 = w - (float)w0;
-          const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (float)w1);
-          const int base = ((blk * 3) * 64 + lane) * 8 + e;
+        if (BWD) {  // transposed image: block (ob = k/16, c = j/32), lane (k%16, kg = (j%16)/4), slot e = 4*((j%32)/16) + j%4
+          const int blk = (k >> 4) * C::NC + (j >> 5);
+          const int base = ((blk * 3) * 64 + (k & 15) + 16 * ((j & 15) >> 2)) * 8 + 4 * ((j & 31) >> 4) + (j & 3);
           wt[base] = w0; wt[base + 512] = w1; wt[base + 1024] = w2;
         }
       }
@@ -684,16 +684,23 @@ __device__ __forceinline__ void hidden_layer_planes(const float* lds, int l, int
   }
 }
 
+// cross-lane sums: the 4 lane groups are combined through ds_bpermute (v_permlane16/32_swap with both operands equal
+// did not produce the expected exchange on this toolchain and was dropped), the 16 points of a tile -- exactly one DPP
+// row -- by DPP row rotations fused into the adds.  Every lane ends up with the total.
 __device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lane groups q (lanes p, p+16, p+32, p+48)
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float point_sum(float v) {  // sum over the 16 points of the tile (lanes with equal q)
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+  v = dpp_add<0x128>(v);  // row_ror:8
+  v = dpp_add<0x124>(v);  // row_ror:4
+  v = dpp_add<0x122>(v);  // row_ror:2
+  v = dpp_add<0x121>(v);  // row_ror:1
   return v;
 }
 
@@ -748,7 +755,12 @@ __device__ __forceinline__ void gemm_layer_bf16(const float* lds, int l, int lan
   hidden_layer_planes<C, false>(lds, l, lane, q, P, st);
 }
 
-template <class C> struct KeptPlanes { Planes<C> hk[(C::KEEP_PLANES && C::L > 1) ? C::L - 1 : 1]; };
+template <class C> struct KeptPlanes {
+  Planes<C> hk[(C::KEEP_PLANES && C::L > 1) ? C::L - 1 : 1];
+  // with one wave per SIMD there are registers to spare: the activation streams of every layer are kept from the
+  // forward pass instead of being recomputed for the weight-gradient GEMMs and the output-layer gradient
+  f32x4 h[C::KEEP_H ? C::L : 1][C::NS][C::NB];
+};
 
 template <class C, bool BWD>
 __device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, const float (&x)[C::D],
@@ -757,6 +769,12 @@ __device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, 
   sfor<C::L - 1>([&](auto li_) {
     constexpr int li = decltype(li_)::value;  // computes layer l = li + 2 from layer li + 1
     act_forward<C>(st[li], h);
+    if constexpr (BWD && C::KEEP_H) {
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+        for (int b = 0; b < C::NB; ++b) kp.h[li][s][b] = h[s][b];
+    }
     if constexpr (C::BF16) {
       if constexpr (BWD && C::KEEP_PLANES) {   // the weight-gradient GEMM of layer l reuses these planes
         split_all<C>(h, kp.hk[li]);
@@ -771,6 +789,12 @@ __device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, 
     }
   });
   act_forward<C>(st[C::L - 1], h);
+  if constexpr (BWD && C::KEEP_H) {
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b) kp.h[C::L - 1][s][b] = h[s][b];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ forward kernel
@@ -853,14 +877,20 @@ struct GradAcc {
 // reads (32-lane groups: q*4*HP = 16 banks apart) conflict-free.
 template <class C, int NBA>
 __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q, const f32x4 (&zb)[C::NS][NBA],
-                                            const LayerState<C>& st_in, f32x4 (&acc)[NBA][C::NB]) {
+                                            const LayerState<C>& st_in, f32x4 (&acc)[NBA][C::NB],
+                                            const f32x4 (*hkept)[C::NB] = nullptr) {
   constexpr int HP = C::HP;
   float* Zt = stage;
   float* Ht = stage + 16 * HP;
   sfor<C::NS>([&](auto s_) {
     constexpr int s = decltype(s_)::value;
     f32x4 hs[C::NB];
-    act_forward_stream<C, s>(st_in, hs);    // stream s of the layer's input activations, recomputed from its state
+    if constexpr (C::KEEP_H) {              // stream s of the layer's input activations: kept by the forward pass ...
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b) hs[b] = hkept[s][b];
+    } else {
+      act_forward_stream<C, s>(st_in, hs);  // ... or recomputed from the layer state
+    }
 #pragma unroll
     for (int b = 0; b < NBA; ++b) *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
 #pragma unroll
@@ -951,7 +981,7 @@ __device__ __forceinline__ void tile_backward_multi(const float* lds, float* sta
   for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc.bo[ob][r] += go[0][ob][r];
-  weight_grad<C, C::NBO>(stage, lane, p, q, go, st[C::L - 1], acc.wo);   // dWout += sum_s Gout[s] H_L[s]^T
+  weight_grad<C, C::NBO>(stage, lane, p, q, go, st[C::L - 1], acc.wo, kp.h[C::KEEP_H ? C::L - 1 : 0]);   // dWout += sum_s Gout[s] H_L[s]^T
   f32x4 g[C::NS][C::NB];
   zero_frag<C>(g);
   const float* w = lds + C::ldsWoutT();
@@ -983,7 +1013,12 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
     sfor<C::NS>([&](auto s_) {
       constexpr int s = decltype(s_)::value;
       f32x4 hs[C::NB];
-      act_forward_stream<C, s>(st[C::L - 1], hs);
+      if constexpr (C::KEEP_H) {
+#pragma unroll
+        for (int b = 0; b < C::NB; ++b) hs[b] = kp.h[C::L - 1][s][b];
+      } else {
+        act_forward_stream<C, s>(st[C::L - 1], hs);
+      }
 #pragma unroll
       for (int b = 0; b < C::NB; ++b)
 #pragma unroll
@@ -1039,10 +1074,10 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
 #pragma unroll
         for (int b = 0; b < C::NB; ++b) g[s][b] = o[s][b];
     } else if constexpr (C::BF16) {
-      weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2]);
+      weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);
       gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);
     } else {
-      weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2]);   // inputs of layer l = activations of layer l-1
+      weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);   // inputs of layer l
 #if NDQ_HBAR_INPLACE
       gemm_frag_inplace<C>(lds + C::ldsWt(l), lane, g);
 #else
