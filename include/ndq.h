@@ -76,7 +76,8 @@ int ndq_reduce_grad_loss(const float* partials, int nparts, int len, float* out,
  * n_batches loss slots -> loss_hist[hist_index]; best-network snapshot (solvers.py:434-441): if the epoch loss is
  * below best_loss[parity] the PRE-step parameters are copied to best_flat and best_loss[parity^1] is updated
  * (best_loss is a 2-slot ping-pong so no workgroup reads what another writes); then the fused Adam update.
- * write_scalars: only one network of a multi-network system records loss_hist / best_loss. */
+ * write_scalars: only one network of a multi-network system records loss_hist / best_loss.
+ * exp_avg == NULL (validation epoch): no Adam update, only the loss / best-snapshot bookkeeping. */
 int ndq_epoch_tail(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, const float* loss_slots, int n_batches,
                    float* loss_hist, int hist_index, float* best_loss, int parity, float* best_flat, int write_scalars,

@@ -204,13 +204,15 @@ __global__ __launch_bounds__(256) void epoch_tail_kernel(TailArgs a) {
   if (i < a.len) {
     const float pi = a.p[i];
     if (better) a.best_flat[i] = pi;
-    float gi = a.g[i];
-    if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
-    const float mi = fmaf(a.b1, a.m[i], (1.f - a.b1) * gi);
-    const float vi = fmaf(a.b2, a.v[i], (1.f - a.b2) * gi * gi);
-    a.m[i] = mi;
-    a.v[i] = vi;
-    a.p[i] = pi - (a.lr / a.bc1) * (mi / (sqrtf(vi) / a.bc2s + a.eps));
+    if (a.m != nullptr) {             // validation epochs pass no optimiser state: bookkeeping only
+      float gi = a.g[i];
+      if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+      const float mi = fmaf(a.b1, a.m[i], (1.f - a.b1) * gi);
+      const float vi = fmaf(a.b2, a.v[i], (1.f - a.b2) * gi * gi);
+      a.m[i] = mi;
+      a.v[i] = vi;
+      a.p[i] = pi - (a.lr / a.bc1) * (mi / (sqrtf(vi) / a.bc2s + a.eps));
+    }
   }
   if (i == 0 && a.write_scalars) {
     a.loss_hist[a.hist_index] = loss;
@@ -340,14 +342,15 @@ int ndq_epoch_tail(float* params, const float* grad, float* exp_avg, float* exp_
                    float beta2, float eps, float weight_decay, int step, const float* loss_slots, int n_batches,
                    float* loss_hist, int hist_index, float* best_loss, int parity, float* best_flat, int write_scalars,
                    void* stream) {
-  if (!params || !grad || !exp_avg || !exp_avg_sq || len <= 0 || step <= 0 || !loss_slots || n_batches <= 0 ||
-      !loss_hist || !best_loss || hist_index < 0 || (parity != 0 && parity != 1))
+  const bool adam = exp_avg != nullptr;
+  if (!params || len <= 0 || !loss_slots || n_batches <= 0 || !loss_hist || !best_loss || hist_index < 0 ||
+      (parity != 0 && parity != 1) || (adam && (!grad || !exp_avg_sq || step <= 0)))
     return NDQ_EINVAL;
   TailArgs a;
   a.p = params; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.len = len;
   a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
-  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-  a.bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.bc1 = adam ? (float)(1.0 - pow((double)beta1, (double)step)) : 1.f;
+  a.bc2s = adam ? (float)sqrt(1.0 - pow((double)beta2, (double)step)) : 1.f;
   a.loss_slots = loss_slots; a.nb = n_batches; a.loss_hist = loss_hist; a.hist_index = hist_index;
   a.best_loss = best_loss; a.parity = parity; a.best_flat = best_flat; a.write_scalars = write_scalars;
   hipLaunchKernelGGL(epoch_tail_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);

@@ -287,10 +287,43 @@ class FusedSystem:
         if getattr(self, "_fast", None) is None:
             dev, f32 = self.device, torch.float32
             self._fast = dict(loss_hist=torch.zeros(self.HIST, dtype=f32, device=dev),
+                              valid_hist=torch.zeros(self.HIST, dtype=f32, device=dev),
                               best_loss=torch.full((2,), float("inf"), dtype=f32, device=dev),
-                              best_flat=torch.zeros_like(self.flat[0].grad), parity=0, pending=0, structs={},
-                              launch=ctypes.cast(self.fusedk.lib.ndq_fused_launch, ctypes.c_void_p).value)
+                              best_flat=[torch.zeros_like(fp.grad) for fp in self.flat], parity=0, pending=0,
+                              pending_valid=0, structs={},
+                              launch=(ctypes.cast(self.fusedk.lib.ndq_fused_launch, ctypes.c_void_p).value
+                                      if self.fusedk is not None else None))
         return self._fast
+
+    def epoch_tail(self, kind, n_batches, track_best, adam_slots=None):
+        """Device-side end of an epoch for ANY fused system (pipeline or single-launch), after the per-batch
+        ``step()`` calls filled ``loss_buf[:n_batches]`` and the gradient buffers: mean loss -> history ring, best
+        snapshot of every network when ``track_best``, and -- training epochs -- the fused Adam update of every
+        network (adam_slots[k] = FusedAdam.fast_slot(flat[k])).  No host synchronisation."""
+        fs = self.fast_state()
+        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        train = kind == "train"
+        hist = fs["loss_hist"] if train else fs["valid_hist"]
+        idx = fs["pending"] if train else fs["pending_valid"]
+        parity = fs["parity"]
+        for k, fp in enumerate(self.flat):
+            fp.sync()
+            if train:
+                m, v, group, step = adam_slots[k]
+                b1, b2 = group["betas"]
+                args = (_ptr(fp.flat), _ptr(fp.grad), _ptr(m), _ptr(v), fp.numel, group["lr"], b1, b2, group["eps"],
+                        group["weight_decay"], step)
+            else:
+                args = (_ptr(fp.flat), None, None, None, fp.numel, 0.0, 0.0, 0.0, 0.0, 0.0, 1)
+            rc = self.L.ndq_epoch_tail(*args, _ptr(self.loss_buf), n_batches, _ptr(hist), idx, _ptr(fs["best_loss"]),
+                                       parity, _ptr(fs["best_flat"][k]) if track_best else None, 1 if k == 0 else 0,
+                                       stream)
+            _lib.check(rc, "ndq_epoch_tail")
+        if train:
+            fs["pending"] += 1
+        else:
+            fs["pending_valid"] += 1
+        fs["parity"] ^= 1
 
     def fast_train_epoch(self, batch, optimizer, adam_slot, track_best, n_global=None, dist=None):
         """One whole training epoch (n_batches = 1) of a single-network system with zero host synchronisation:
@@ -314,7 +347,7 @@ class FusedSystem:
         n_global = n if n_global is None else n_global
         st.params = fp.flat.data_ptr()
         st.seed = 1.0 / (float(n_global) * self.n_eq)
-        st.best_flat = fs["best_flat"].data_ptr() if track_best else None
+        st.best_flat = fs["best_flat"][0].data_ptr() if track_best else None
         b1, b2 = group["betas"]
         st.lr, st.beta1, st.beta2, st.eps, st.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]
         stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
@@ -332,20 +365,22 @@ class FusedSystem:
             rc = self.L.ndq_epoch_tail(_ptr(fp.flat), _ptr(fp.grad), _ptr(m), _ptr(v), fp.numel, group["lr"], b1, b2,
                                        group["eps"], group["weight_decay"], step, _c_vp(st.loss_slot), 1,
                                        _ptr(fs["loss_hist"]), hist_index, _ptr(fs["best_loss"]), parity,
-                                       _ptr(fs["best_flat"]) if track_best else None, 1, stream)
+                                       _ptr(fs["best_flat"][0]) if track_best else None, 1, stream)
             _lib.check(rc, "ndq_epoch_tail")
         fs["pending"] += 1
         fs["parity"] ^= 1
 
     def fast_flush(self):
-        """Read back (ONE synchronising copy) the epoch losses recorded since the last flush and the best loss."""
+        """Read back (ONE synchronising copy) the train / valid epoch losses recorded since the last flush and the
+        best loss: returns (train_losses, valid_losses, best_loss)."""
         fs = getattr(self, "_fast", None)
-        if fs is None or fs["pending"] == 0:
-            return [], None
-        k = fs["pending"]
-        vals = torch.cat([fs["loss_hist"][:k], fs["best_loss"][fs["parity"]:fs["parity"] + 1]]).tolist()
-        fs["pending"] = 0
-        return vals[:k], vals[k]
+        if fs is None or (fs["pending"] == 0 and fs["pending_valid"] == 0):
+            return [], [], None
+        k, kv = fs["pending"], fs["pending_valid"]
+        vals = torch.cat([fs["loss_hist"][:k], fs["valid_hist"][:kv],
+                          fs["best_loss"][fs["parity"]:fs["parity"] + 1]]).tolist()
+        fs["pending"] = fs["pending_valid"] = 0
+        return vals[:k], vals[k:k + kv], vals[k + kv]
 
     def step(self, batch, train, slot=0, accumulate=False, n_global=None, lo=0, hi=None, want_funcs=False,
              want_resid=False):

@@ -49,6 +49,9 @@ class FusedAdam(torch.optim.Adam):
             self._bound.append((fp, m, v, group))
             self._bound_ids.update(id(p) for p in fp.params)
 
+    def bound(self, fp):
+        return any(f is fp and not g.get("amsgrad") and not g.get("maximize") for f, _, _, g in self._bound)
+
     def fast_slot(self, fp):
         """(exp_avg, exp_avg_sq, group, step AFTER the next update) for the solver's native epoch path, which performs
         the Adam update on the device itself (ndq_epoch_tail); None if ``fp`` is not bound / not eligible."""

@@ -183,13 +183,15 @@ class BaseSolver(ABC):
 
     def _flush_device_history(self):
         system = self._fused_sys
-        if system is None or getattr(system, "_fast", None) is None or system._fast["pending"] == 0:
+        fs = getattr(system, "_fast", None) if system is not None else None
+        if fs is None or (fs["pending"] == 0 and fs["pending_valid"] == 0):
             return
-        losses, best = system.fast_flush()
+        losses, vlosses, best = system.fast_flush()
         self._history["train_loss"].extend(losses)
-        if self._fast_tracks_best and best < float("inf") and (self._lowest_loss is None or best < self._lowest_loss):
+        self._history["valid_loss"].extend(vlosses)
+        if best < float("inf") and (self._lowest_loss is None or best < self._lowest_loss):
             self._lowest_loss = best
-            self._best_flat = [system._fast["best_flat"]]     # device snapshot written by ndq_epoch_tail
+            self._best_flat = list(fs["best_flat"])            # device snapshots written by ndq_epoch_tail
             self._best_nets = None
 
     @property
@@ -335,7 +337,7 @@ class BaseSolver(ABC):
         if system is None:
             return self._run_epoch_composite(key, first_batch)
         nb = self.n_batches[key]
-        if key == "train" and self._run_train_epoch_native(system, first_batch):
+        if self._run_epoch_native(key, system, first_batch):
             return
         metric_values = {name: 0.0 for name in self.metrics_fn}
         if system.loss_buf.numel() < nb:
@@ -368,40 +370,62 @@ class BaseSolver(ABC):
         for name in self.metrics_fn:
             self._update_history(metric_values[name] / nb, name, key)
 
-    def _run_train_epoch_native(self, system, batch):
-        """Whole training epoch as ONE native call with no host synchronisation (engine.fast_train_epoch), when the
-        epoch has the default shape: single-network fused system, one batch per epoch, FusedAdam, no metrics, and none
-        of the step hooks overridden.  Returns False if the general path must run instead."""
+    def _native_ok(self):
+        """May the epoch's bookkeeping stay on the device?  (default hooks, FusedAdam, no metrics)"""
         cls = type(self)
-        if not (system.fast_ready() and self.n_batches["train"] == 1 and not self.metrics_fn
-                and isinstance(self.optimizer, FusedAdam)
+        return (not self.metrics_fn and isinstance(self.optimizer, FusedAdam)
                 and cls._do_optimizer_step is BaseSolver._do_optimizer_step
                 and cls._update_best is BaseSolver._update_best
-                and cls._update_history is BaseSolver._update_history):
+                and cls._update_history is BaseSolver._update_history)
+
+    def _run_epoch_native(self, key, system, first_batch):
+        """Whole epoch with no host synchronisation.  Single-network systems with one batch per training epoch go
+        through ONE native call (engine.fast_train_epoch: closure kernel + fused sums/tail kernel); every other fused
+        system runs its per-batch launch sequence and then the device-side epoch tail (loss history ring, best
+        snapshot, fused Adam per network).  Returns False if the general (host-synchronising) path must run."""
+        if not self._native_ok():
             return False
-        track_best = self.n_batches["valid"] == 0
+        train = key == "train"
+        nb = self.n_batches[key]
+        track_best = (not train) or self.n_batches["valid"] == 0
         fs = system.fast_state()
-        if fs["pending"] >= system.HIST or (fs["pending"] and track_best != self._fast_tracks_best):
+        if max(fs["pending"], fs["pending_valid"]) >= system.HIST:
             self._flush_device_history()
         # a best loss found on the host path (or set by the user) must be what the device compares against
-        if fs["pending"] == 0:
+        if fs["pending"] == 0 and fs["pending_valid"] == 0:
             fs["best_loss"].fill_(float("inf") if self._lowest_loss is None else float(self._lowest_loss))
-        slot = self.optimizer.fast_slot(system.flat[0])
-        if slot is None:
-            return False
-        self._fast_tracks_best = track_best
+        slots = None
+        if train:
+            if not all(self.optimizer.bound(fp) for fp in system.flat):
+                return False
+            slots = [self.optimizer.fast_slot(fp) for fp in system.flat]
         shard = self.dist
-        n_all = batch[0].shape[0]
-        if shard is not None:
-            lo, hi = shard.bounds(n_all)
-            if (lo, hi) != (0, n_all):
-                batch = [c[lo:hi] for c in batch]
-        system.fast_train_epoch(batch, self.optimizer, slot, track_best,
-                                n_global=shard.global_n(n_all) if shard else n_all, dist=shard)
-        for fp in system.flat:
-            if not fp.grads_attached():
-                fp.attach_grads()
-        self._phase = "train"
+        if train and nb == 1 and system.fast_ready():
+            batch = first_batch
+            n_all = batch[0].shape[0]
+            if shard is not None:
+                lo, hi = shard.bounds(n_all)
+                if (lo, hi) != (0, n_all):
+                    batch = [c[lo:hi] for c in batch]
+            system.fast_train_epoch(batch, self.optimizer, slots[0], track_best,
+                                    n_global=shard.global_n(n_all) if shard else n_all, dist=shard)
+        else:
+            if system.loss_buf.numel() < nb:
+                system.loss_buf = torch.zeros(nb, dtype=torch.float32, device=self.device)
+            for batch_id in range(nb):
+                batch = first_batch if batch_id == 0 else self._generate_batch(key)
+                n_all = batch[0].shape[0]
+                lo, hi = shard.bounds(n_all) if shard else (0, n_all)
+                system.step(batch, train=train, slot=batch_id, accumulate=(batch_id > 0),
+                            n_global=shard.global_n(n_all) if shard else n_all, lo=lo, hi=hi)
+            if shard:
+                shard.all_reduce(system, nb, train=train)
+            system.epoch_tail(key, nb, track_best, slots)
+        if train:
+            for fp in system.flat:
+                if not fp.grads_attached():
+                    fp.attach_grads()
+        self._phase = key
         return True
 
     def _run_epoch_composite(self, key, first_batch):

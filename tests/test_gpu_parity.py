@@ -378,3 +378,29 @@ def test_native_epoch_path_bookkeeping_matches_general_path():
     assert abs(l1 - min(h1)) <= 1e-7 * abs(l1) and abs(l1 - l2) <= 2e-5 * abs(l2)
     assert rel_l2(b1, b2) < 1e-5 and rel_l2(p1, p2) < 1e-5
     assert int(s1.optimizer.state_dict()["state"][0]["step"]) == 6
+
+
+@pytest.mark.parametrize("name", ["c2", "c1"])
+def test_native_fit_with_validation_matches_general_path(name):
+    """fit() with validation epochs (best network chosen by the validation loss, solvers.py:414-415) on the zero-sync
+    path -- single-launch (c2) and multi-network pipeline (c1) -- against the general host-synchronising path."""
+    from tests import configs
+
+    def run(native):
+        torch.manual_seed(0)
+        solver, cfg = configs.make_solver(name, SIZES[name], n_batches_train=2, n_batches_valid=2,
+                                          metrics=None if native else {"zero": lambda *a: (a[0] * 0).mean()})
+        solver.fused = "require"
+        torch.manual_seed(5)
+        solver.fit(4, tqdm_file=None)
+        h = solver.metrics_history
+        return (solver, list(h["train_loss"]), list(h["valid_loss"]), solver.lowest_loss,
+                R.get_flat(solver.best_nets).cpu().numpy(), R.get_flat(cfg["nets"]).cpu().numpy())
+
+    s1, t1, v1, l1, b1, p1 = run(True)
+    s2, t2, v2, l2, b2, p2 = run(False)
+    assert getattr(s1._fused_sys, "_fast", None) is not None and getattr(s2._fused_sys, "_fast", None) is None
+    assert len(t1) == len(v1) == 4
+    assert np.allclose(t1, t2, rtol=3e-5) and np.allclose(v1, v2, rtol=3e-5)
+    assert abs(l1 - min(v1)) <= 1e-6 * abs(l1) and abs(l1 - l2) <= 3e-5 * abs(l2)
+    assert rel_l2(b1, b2) < 2e-5 and rel_l2(p1, p2) < 2e-5
