@@ -47,7 +47,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
     with trace_scope(g):
         coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
         funcs = [cfv(n, c, *coords) for n, c in zip(nets, conditions)]
-        res = diff_eqs(*funcs, *coords)
+        res = diff_eqs(*funcs, *coords) if diff_eqs is not None else []     # None: evaluation of the functions only
         if isinstance(res, Sym):
             res = [res]
         res = [r if isinstance(r, Sym) else Sym(g, g.const(float(r))) for r in res]
@@ -159,7 +159,7 @@ class FusedSystem:
                  jets=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
                  gbar=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
                  funcs=torch.zeros(self.n_funcs, ld, dtype=f32, device=dev),
-                 resid=torch.zeros(self.n_eq, ld, dtype=f32, device=dev),
+                 resid=torch.zeros(max(self.n_eq, 1), ld, dtype=f32, device=dev),
                  pw_blocks=self.kernel.blocks(n))
         b["loss_partials"] = torch.zeros(b["pw_blocks"], dtype=f32, device=dev)
         b["bwd_blocks"] = [self.L.ndq_mlp_bwd_blocks(ctypes.byref(self.descs[k]), n) for k in range(len(self.nets))]
@@ -233,8 +233,27 @@ class FusedSystem:
                                         _ptr(fp.flat), _ptr(b["jets"][k]), b["ld"], stream)
             _lib.check(rc, "ndq_mlp_jet_fwd")
 
+    def evaluate(self, coords):
+        """Function values u_i(coords) through the forward-only kernels: list of n_coords tensors (any device, n
+        elements each) -> device tensor [n_funcs][n].  Replaces BaseSolution._compute_u's torch forward
+        (solvers.py:682-725)."""
+        b, n = self.upload([c.reshape(-1) for c in coords])
+        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        self.forward(b, n, stream)
+        self.pointwise(b, n, stream, False, n, want_funcs=True)
+        return b["funcs"][:, :n]
+
+    def residuals(self, coords):
+        """Residual columns r_e(coords) of the traced PDE system: device tensor [n_eq][n] (get_residuals,
+        solvers.py:606-646, without building an autograd graph)."""
+        b, n = self.upload([c.reshape(-1) for c in coords])
+        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        self.forward(b, n, stream)
+        self.pointwise(b, n, stream, False, n, want_resid=True)
+        return b["resid"][:, :n]
+
     def pointwise(self, b, n, stream, train, n_global, want_funcs=False, want_resid=False):
-        seed = 1.0 / (float(n_global) * self.n_eq)
+        seed = 1.0 / (float(n_global) * max(self.n_eq, 1))
         rc = self.kernel.lib.ndq_pw_launch(self._coord_ptr(b, 0), b["ld"], n, b["jets_pp"],
                                            b["gbar_pp"] if train else None, b["ld"],
                                            _ptr(b["funcs"]) if want_funcs else None,

@@ -559,10 +559,38 @@ class BaseSolver(ABC):
             return {name: available[name] for name in var_names}
         raise ValueError(f"unrecognized return_type = {return_type}")
 
+    def _fused_residuals(self, coords, best):
+        """Residual columns through the forward + generated pointwise kernels (no autograd graph); None -> composite."""
+        if self.device.type != "cuda" or self.fused == "off" or any(c.dtype not in (torch.float32, torch.float64)
+                                                                    for c in coords):
+            return None
+        nets = self.best_nets if best else self.nets
+        if nets is None:
+            return None
+        key = (tuple(id(n) for n in nets), id(self.diff_eqs), tuple(id(c) for c in self.conditions), len(coords))
+        if getattr(self, "_resid_key", None) != key:
+            self._resid_key, self._resid_sys = key, None
+            try:
+                from .engine import FusedSystem
+                self._resid_sys = FusedSystem(nets, self.conditions, self.diff_eqs, len(coords), self.device,
+                                              compute_func_val=self.compute_func_val, single_kernel=False)
+            except TraceUnsupported:
+                pass
+        if self._resid_sys is None:
+            return None
+        res = self._resid_sys.residuals([c.detach().to(torch.float32) for c in coords])
+        return [res[e].clone() for e in range(res.shape[0])]
+
     def get_residuals(self, *coords, to_numpy=False, best=True, no_reshape=False):
         """Residuals of ``diff_eqs`` at given points (solvers.py:606-646)."""
         coords = [c if isinstance(c, torch.Tensor) else torch.tensor(c) for c in coords]
         original_shape = coords[0].shape
+        fused = self._fused_residuals(coords, best)
+        if fused is not None:
+            residuals = [r.reshape(-1, 1) if no_reshape else r.reshape(*original_shape) for r in fused]
+            if to_numpy:
+                residuals = [r.cpu().numpy() for r in residuals]
+            return residuals if len(residuals) > 1 else residuals[0]
         coords = [c.detach().to(self.device).reshape(-1, 1).requires_grad_() for c in coords]
         solution = self.get_solution(copy=False, best=best)
         funcs = solution(*coords, to_numpy=False, no_reshape=no_reshape)
@@ -608,12 +636,36 @@ class BaseSolution(ABC):
                 to_numpy = True
             else:
                 raise ValueError(f"Unrecognized `as_type` option: '{to_numpy}'")
-        us = [self._compute_u(net, con, *coords) for con, net in zip(self.conditions, self.nets)]
+        us = self._fused_values(coords)
+        if us is None:      # composite (torch) evaluation: anything the tracer / kernels do not cover
+            us = [self._compute_u(net, con, *coords) for con, net in zip(self.conditions, self.nets)]
         if not no_reshape:
             us = [u.reshape(*original_shape) for u in us]
         if to_numpy:
             us = [u.detach().cpu().numpy() for u in us]
         return us if len(self.nets) > 1 else us[0]
+
+
+    def _fused_values(self, coords):
+        """u_i at the given (N, 1) coordinate columns through the forward-only gfx950 kernels, or None when the
+        solution cannot be traced / the networks are not on an MI355X.  ``_compute_u`` itself is what gets traced, so
+        subclasses (harmonic expansions, ...) are covered without extra code."""
+        if coords[0].device.type != "cuda" or coords[0].dtype != torch.float32 or coords[0].requires_grad \
+                or len(set(id(n) for n in self.nets)) != len(self.nets):
+            return None
+        key = (tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions), len(coords))
+        if getattr(self, "_eval_key", None) != key:
+            self._eval_key, self._eval_sys = key, None
+            try:
+                from .engine import FusedSystem
+                self._eval_sys = FusedSystem(self.nets, self.conditions, None, len(coords), coords[0].device,
+                                             compute_func_val=self._compute_u, single_kernel=False)
+            except (TraceUnsupported, _lib.NdqError):
+                pass
+        if self._eval_sys is None:
+            return None
+        vals = self._eval_sys.evaluate(coords)
+        return [vals[i].clone().reshape(-1, 1) for i in range(len(self.nets))]
 
 
 class GenericSolution(BaseSolution):

@@ -404,3 +404,31 @@ def test_native_fit_with_validation_matches_general_path(name):
     assert np.allclose(t1, t2, rtol=3e-5) and np.allclose(v1, v2, rtol=3e-5)
     assert abs(l1 - min(v1)) <= 1e-6 * abs(l1) and abs(l1 - l2) <= 3e-5 * abs(l2)
     assert rel_l2(b1, b2) < 2e-5 and rel_l2(p1, p2) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c4"])
+def test_solution_and_residuals_on_forward_kernels(name):
+    """solver.get_solution()(coords) and solver.get_residuals(coords) (solvers.py:606-646, 682-720) run on the
+    forward-only kernels + generated pointwise kernel and agree with the autograd oracle in fp64."""
+    from tests import configs
+    torch.manual_seed(0)
+    solver, cfg = configs.make_solver(name, SIZES[name])
+    solver.fused = "require"
+    torch.manual_seed(0)
+    ocfg = R.build_config(name, SIZES[name], dtype=torch.float64)
+    R.set_flat(ocfg["nets"], R.get_flat(cfg["nets"]).cpu().double())
+    torch.manual_seed(9)
+    ex = cfg["gen"].get_examples()
+    coords = [ex.detach()] if isinstance(ex, torch.Tensor) else [c.detach() for c in ex]
+    out = R.closure(ocfg["nets"], ocfg["enforcers"], ocfg["pde"], [c.double() for c in coords], backward=False)
+    kw = dict(harmonics_fn=configs.RealSphericalHarmonics(4)) if name == "c4" else {}
+    sol = solver.get_solution(best=False, **kw)
+    us = sol(*[c.cuda() for c in coords], to_numpy=True)
+    us = us if isinstance(us, list) else [us]
+    assert getattr(sol, "_eval_sys", None) is not None, "solution evaluation did not take the fused path"
+    assert rel_l2(np.stack([u.reshape(-1) for u in us], axis=1), out["funcs"].numpy()) < TOL
+    rs = solver.get_residuals(*coords, best=False, to_numpy=True)
+    rs = rs if isinstance(rs, list) else [rs]
+    assert getattr(solver, "_resid_sys", None) is not None
+    assert rel_l2(np.stack([r.reshape(-1) for r in rs], axis=1), out["residuals"].numpy()) < TOL
+    assert us[0].shape == tuple(coords[0].shape)
