@@ -8,14 +8,17 @@ Generator2D 256x256 = 65 536 noisy-grid points per batch per GPU, fp32 -- throug
 N > 1 is launched by the driver with torch.distributed.run (one rank per MI355X, RCCL); scaling is WEAK: every rank
 trains on its own 65 536-point shard of a global N*65 536-point batch and joins one all-reduce of the flat
 [gradients | loss] vector per step.  A "step" is one ``run_train_epoch()`` with ``n_batches_train=1``,
-``n_batches_valid=0``: fused forward, generated pointwise residual/loss kernel, fused backward, reductions, one host
-read of the loss, best-network snapshot, fused Adam step.  Inputs are pre-sampled (reference RNG order) and resident
-in HBM before the timed region (``ResidentBatchGenerator``); the figure with host sampling + PCIe upload inside the
-step is reported separately as ``with_host_sampling``.
+``n_batches_valid=0``: two kernel launches -- the single-launch closure kernel (forward streams + traced pointwise
+stage + reverse pass) and the second-stage sums / device-side epoch tail (loss history, best-network snapshot, fused
+Adam) -- and no host synchronisation.  Inputs are pre-sampled (reference RNG order) and resident in HBM before the
+timed region (``ResidentBatchGenerator``); the figure with host sampling + PCIe upload inside the step is reported
+separately as ``with_host_sampling``.
 
 Rank 0 prints ONE JSON line (contract in the task description) including
-  roofline     -- dominant kernel (mlp_jet_bwd): algorithmic GEMM flops / HIP-event launch time vs the fp32 MFMA peak,
-  kernels      -- the same for the forward kernel and achieved HBM GB/s of the pointwise residual kernel,
+  roofline     -- dominant kernel (fused closure kernel): algorithmic GEMM flops / HIP-event launch time vs the fp32
+                  MFMA peak, plus the HBM bytes per launch measured by rocprofv3 --pmc (profiles/traffic_c2.json),
+  kernels      -- the three-kernel pipeline (forward / pointwise / backward) timed the same way, incl. the achieved
+                  HBM GB/s of the standalone pointwise residual kernel,
   cpu_baseline -- the oracle's port of the reference step (torch CPU autograd) timed on this host.
 """
 import argparse

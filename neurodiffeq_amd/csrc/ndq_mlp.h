@@ -7,21 +7,25 @@
 // unit through the MLP, and ONE backward kernel that recomputes the streams and reverses the recurrences
 // (math: SURVEY.md App. A.1/A.2; numpy statement of the same recurrences: oracle/jet_ref.py).
 //
-// Execution model (CDNA4):
-//  * a wave (64 lanes) owns a tile of 16 collocation points; lane = (p = lane&15 : point, q = lane>>4).
-//  * a "fragment" f32x4 frag[NB] holds, for point p, hidden units 16*b + 4*q + r (b < NB, r < 4) -- exactly the
-//    C/D layout of v_mfma_f32_16x16x4_f32 with units as rows and points as columns.  Register r of block kb is
-//    ALSO a valid B operand (k = q) of the next layer's MFMA if the contraction index is taken in the order
-//    k_t = 16*kb + 4*q + t, so hidden activations never leave registers between layers: the weights are
-//    pre-permuted into "fragment order" in LDS once per workgroup and read back as the A operand with one
-//    conflict-free ds_read_b32 per MFMA.
-//  * f32-in/f32-acc MFMA is bitwise an fmaf chain (exact fp32), so parity with the reference's fp32 ATen path is
-//    a re-association question only.
-//  * weight gradients of hidden layers are themselves MFMA GEMMs contracted over points; the operands need the
-//    point index on the MFMA k axis, i.e. a transpose of the fragments, which goes through a padded (ld = H+4)
-//    per-wave LDS staging tile (conflict-free b128 writes / b32 reads).
-//  * all reductions are fixed-order: lane shuffles -> per-wave -> per-workgroup (sequential over waves in LDS) ->
-//    partials[block][P] in HBM -> ndq_reduce kernel.  No float atomics anywhere.
+// Execution model (CDNA4), details in DESIGN.md section 4:
+//  * a wave (64 lanes) owns a tile of 16 collocation points; lane = (p = lane&15 : point, q = lane>>4); ONE wave per
+//    SIMD with the whole 512-entry register file (the f32 MFMA shares the VALU datapath on gfx950, so a second wave
+//    per SIMD buys nothing -- scripts/ubench_mfma_valu.hip).
+//  * a "fragment" f32x4 frag[NB] holds, for point p, hidden units 16*b + 4*q + r (b < NB, r < 4) -- exactly the C/D
+//    layout of the 16x16 MFMAs with units as rows and points as columns.  The 8 values a lane holds per 32 units are
+//    ALSO a valid B operand of the next layer's MFMA if the contraction runs in the permuted order
+//    slot(kg, e) <-> unit 16*(2c + (e>>2)) + 4*kg + (e&3), so hidden activations never leave registers between
+//    layers: the weights are pre-permuted into that "fragment order" in LDS once per workgroup.
+//  * per-point GEMMs (z = W h, hbar = W^T zbar; K = H) run on the bf16 matrix core with 3-way split operands
+//    ("bf16x3", fp32-class accuracy, overlaps with the activation math); widths that are not a multiple of 32 fall
+//    back to the exact f32 MFMA.
+//  * weight gradients of hidden layers contract over points with heavy cancellation and stay on the exact f32 MFMA
+//    (bitwise an fmaf chain); the operands need the point index on the MFMA k axis, i.e. a transpose of the
+//    fragments, which goes through a padded (ld = H+4) per-wave LDS tile (conflict-free b128 writes / b32 reads).
+//  * "Laplacian stream" (LAP = 1): when the residual needs second derivatives only through their sum, ONE stream
+//    carries sum_a d2/dx_a^2 instead of one stream per coordinate.
+//  * all reductions are fixed-order: DPP row rotations / lane shuffles -> per-wave LDS regions -> workgroup ->
+//    partials[block][P] in HBM -> second-stage kernel.  No float atomics across waves.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
@@ -114,13 +118,6 @@ enum { ACT_TANH = 0, ACT_SIN = 1 };
 #ifndef NDQ_BWD_THREADS
 #define NDQ_BWD_THREADS 256
 #endif
-// Two co-resident waves per SIMD run the same program from the same start, so they stay phase-locked (both in a
-// VALU phase, then both in an MFMA phase) and do not fill each other's idle pipe.  Raising the issue priority of the
-// second wave of every SIMD (waves WAVES/2.. of an 8-wave workgroup) lets it win every arbitration, which pushes the
-// pair out of phase after the first contended segment.
-#ifndef NDQ_STAGGER_PRIO
-#define NDQ_STAGGER_PRIO 1
-#endif
 // Hidden-layer GEMMs on the bf16 matrix core with 3-way split operands ("bf16x3"): x = x0 + x1 + x2 (three bf16
 // chunks = 24 mantissa bits), products a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1 accumulated in fp32 -> relative error
 // ~2^-23, i.e. fp32-class accuracy.  Why: the f32-input MFMA shares the VALU datapath on gfx950 (it does NOT overlap
@@ -142,9 +139,6 @@ enum { ACT_TANH = 0, ACT_SIN = 1 };
 #endif
 #ifndef NDQ_KEEP_PLANES
 #define NDQ_KEEP_PLANES 1
-#endif
-#ifndef NDQ_HBAR_INPLACE
-#define NDQ_HBAR_INPLACE 1
 #endif
 #ifndef NDQ_FWD_THREADS
 #define NDQ_FWD_THREADS 256
@@ -467,31 +461,6 @@ __device__ __forceinline__ void split3(const f32x4 a, const f32x4 b, bf16x8 (&pl
   }
 }
 
-// bf16x3 GEMM on fragments: z[s][ob] += W h[s] with W given as bf16 planes (stage_weights) and h split on the fly.
-// The six partial products are issued smallest first; consecutive MFMAs go to different accumulators (streams).
-template <class C>
-__device__ __forceinline__ void gemm_bf16x3(const float* __restrict__ wl, int lane, const f32x4 (&h)[C::NS][C::NB],
-                                            f32x4 (&z)[C::NS][C::NB]) {
-  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
-#pragma unroll
-  for (int c = 0; c < C::NC; ++c) {
-    bf16x8 hp[C::NS][3];
-#pragma unroll
-    for (int s = 0; s < C::NS; ++s) split3(h[s][2 * c], h[s][2 * c + 1], hp[s]);
-#pragma unroll
-    for (int ob = 0; ob < C::NB; ++ob) {
-      const bf16x8 a0 = w[((ob * C::NC + c) * 3 + 0) * 64 + lane];
-      const bf16x8 a1 = w[((ob * C::NC + c) * 3 + 1) * 64 + lane];
-      const bf16x8 a2 = w[((ob * C::NC + c) * 3 + 2) * 64 + lane];
-#define NDQ_T(A, P)                                                                                          \
-  _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
-      z[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, hp[s][P], z[s][ob], 0, 0, 0);
-      NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
-#undef NDQ_T
-    }
-  }
-}
-
 template <class C>
 __device__ __forceinline__ void split_all(const f32x4 (&h)[C::NS][C::NB], Planes<C>& P) {
 #pragma unroll
@@ -585,12 +554,14 @@ __device__ __forceinline__ void weight_grad_mm(int lane, const Planes<C>& Z, con
     for (int kb = 0; kb < C::NB; ++kb) acc[jb][kb] += d[jb][kb];
 }
 
-// in-place variant for hbar = W^T zbar (all streams are split first, then overwritten)
+// hbar = W^T zbar in place (all streams are split first, then overwritten)
 template <class C>
 __device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl, int lane, f32x4 (&g)[C::NS][C::NB]) {
   f32x4 o[C::NS][C::NB];
   zero_frag<C>(o);
-  gemm_bf16x3<C>(wl, lane, g, o);
+  Planes<C> P;
+  split_all<C>(g, P);
+  gemm_planes<C>(wl, lane, P, o);
 #pragma unroll
   for (int s = 0; s < C::NS; ++s)
 #pragma unroll
@@ -655,8 +626,7 @@ __device__ __forceinline__ void hidden_layer(const float* lds, int l, int lane, 
   zero_frag<C>(z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
-  if constexpr (C::BF16) gemm_bf16x3<C>(lds + C::ldsWf(l, BWD), lane, h, z);
-  else gemm_frag<C>(lds + C::ldsWf(l, BWD), lane, h, z);
+  gemm_frag<C>(lds + C::ldsWf(l, BWD), lane, h, z);   // exact-f32 MFMA path (widths that are not a multiple of 32)
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
 #pragma unroll
@@ -1078,17 +1048,7 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
       gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);
     } else {
       weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);   // inputs of layer l
-#if NDQ_HBAR_INPLACE
       gemm_frag_inplace<C>(lds + C::ldsWt(l), lane, g);
-#else
-      f32x4 hb[C::NS][C::NB];
-      zero_frag<C>(hb);
-      gemm_frag<C>(lds + C::ldsWt(l), lane, g, hb);
-#pragma unroll
-      for (int s = 0; s < C::NS; ++s)
-#pragma unroll
-        for (int b = 0; b < C::NB; ++b) g[s][b] = hb[s][b];
-#endif
     }
   });
 
@@ -1204,9 +1164,6 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
   constexpr int WAVES = C::BWD_THREADS / 64;
   const int ntiles = (a.n + 15) >> 4;
   float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
-#if NDQ_STAGGER_PRIO
-  if (WAVES > 4 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(NDQ_STAGGER_PRIO);
-#endif
   GradAcc<C> acc;
   acc_zero<C>(acc);
   for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
@@ -1268,9 +1225,6 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   constexpr int WAVES = C::BWD_THREADS / 64;
   const int ntiles = (a.n + 15) >> 4;
   float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
-#if NDQ_STAGGER_PRIO
-  if (WAVES > 4 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(NDQ_STAGGER_PRIO);
-#endif
   GradAcc<C> acc;
   if constexpr (TRAIN) acc_zero<C>(acc);
   float lsum = 0.f;
