@@ -37,6 +37,13 @@ ARCH = {
     # Laplacian stream: the two pure second derivatives travel as ONE stream holding their sum
     "c2lap": ((2, 32, 32, 1), "tanh", 0, (2, 1, 5), [(), (0,), (1,), ("L", 0, 1)]),
     "c5lap": ((2, 64, 64, 64, 1), "tanh", 0, (2, 1, 5), [(), (0,), (1,), ("L", 0, 1)]),
+    # three input coordinates (SolverSpherical's default FCNN(3, 1)): diagonal, Laplacian-merged and full Hessian
+    "s3": ((3, 32, 32, 1), "tanh", 0, (3, 1, 41), [(), (0,), (1,), (2,), (0, 0), (1, 1), (2, 2)]),
+    "s3lap": ((3, 32, 32, 1), "tanh", 0, (3, 1, 41), [(), (0,), (1,), (2,), ("L", 0, 1, 2)]),
+    "s3full": ((3, 32, 32, 1), "tanh", 0, (3, 1, 63),
+               [(), (0,), (1,), (2,), (0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]),
+    "s3first": ((3, 32, 32, 1), "tanh", 0, (3, 1, 0), [(), (0,), (1,), (2,)]),
+    "s3val": ((3, 32, 32, 1), "tanh", 0, (3, 0, 0), [()]),
 }
 
 
@@ -327,6 +334,57 @@ def test_fused_closure_matches_oracle_at_size(name, size, mode):
                 grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in system.flat]), want_grad))
     diag(f"closure_full_{name}_{size}_{mode}", errs)
     assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("mode", ["1k", "3k"])
+@pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide",
+                                  "stokes_like", "poisson3d", "hessian3d", "shell"])
+def test_zoo_closure_matches_autograd_oracle(name, mode):
+    """Systems outside the BASELINE set (tests/zoo.py): second-order IVP, sin networks, mixed second derivatives, first
+    order only, three coordinates (Laplacian-merged, diagonal and full Hessian stream sets), three networks."""
+    from tests import zoo
+    from neurodiffeq_amd.engine import FusedSystem
+    torch.manual_seed(11)
+    system = zoo.build(name)
+    nets, conds, pde = system.product()
+    single = len(nets) == 1
+    if mode == "1k" and not single:
+        pytest.skip("the single-launch closure kernel serves single-network systems")
+    flat = R.get_flat(nets)
+    coords = system.sample(3001, seed=5)
+    onets, enforcers, opde = system.oracle(flat)
+    want = R.closure(onets, enforcers, opde, coords)
+    want_grad = R.get_flat_grad(onets).numpy()
+    for net in nets:
+        net.to("cuda")
+    fs = FusedSystem(nets, conds, pde, system.n_coords, "cuda", single_kernel=(mode == "1k"))
+    assert (fs.fusedk is not None) == (mode == "1k")
+    b, n = fs.step([c.float() for c in coords], train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), want["funcs"].numpy()),
+                residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy(), want["residuals"].numpy()),
+                loss=abs(fs.loss_buf[0].item() - want["loss"].item()) / abs(want["loss"].item()),
+                grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in fs.flat]), want_grad))
+    diag(f"zoo_{name}_{mode}", errs)
+    assert max(errs.values()) < TOL, errs
+
+
+def test_spherical_solver_with_default_network_runs_fused():
+    """SolverSpherical with its default FCNN(3, 1) (solvers.py:761-976 of the reference) trains on the d = 3 kernels."""
+    from tests import zoo
+    from neurodiffeq_amd.solvers import SolverSpherical
+    torch.manual_seed(0)
+    pde, conds = zoo.spherical_solver_problem()
+    solver = SolverSpherical(pde, conds, 0.5, 2.0, n_batches_valid=1)
+    solver.fused = "require"
+    solver.fit(200, tqdm_file=None)
+    assert solver.fused_active
+    h = solver.metrics_history
+    assert len(h["train_loss"]) == 200 and len(h["valid_loss"]) == 200
+    assert h["train_loss"][-1] < 0.5 * h["train_loss"][0]
+    r = torch.full((5,), 0.5)
+    th, ph = torch.linspace(0.3, 2.8, 5), torch.zeros(5)
+    assert torch.allclose(solver.get_solution()(r, th, ph).cpu(), torch.cos(th), atol=1e-6)      # inner boundary exact
 
 
 def test_gradient_accumulation_and_validation_mode():

@@ -11,7 +11,7 @@ from neurodiffeq_amd import codegen
 from neurodiffeq_amd.networks import describe
 from neurodiffeq_amd.symbolic import Graph, Sym, trace_scope
 from oracle import jet_ref as J
-from tests import configs
+from tests import configs, zoo
 from tests.pw_cpu import run_cpu
 
 SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96}
@@ -22,15 +22,14 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def trace(cfg, n_coords, lap=True):
-    nets, conds = cfg["nets"], cfg["conds"]
+def trace(nets, conds, pde, n_coords, lap=True, cfv=None):
     g = Graph(n_coords)
     g.register_nets(nets, [describe(n)["n_out"] for n in nets])
-    cfv = configs.func_val(cfg) or (lambda net, cond, *coords: cond.enforce(net, *coords))
+    cfv = cfv or (lambda net, cond, *coords: cond.enforce(net, *coords))
     with trace_scope(g):
         coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
         funcs = [cfv(n, c, *coords) for n, c in zip(nets, conds)]
-        res = cfg["pde"](*funcs, *coords)
+        res = pde(*funcs, *coords)
     for k, n in enumerate(nets):
         g.net_deps.setdefault(k, tuple(range(describe(n)["d"])))
         g.net_nout.setdefault(k, describe(n)["n_out"])
@@ -38,29 +37,23 @@ def trace(cfg, n_coords, lap=True):
                                     allow_lap=(lambda k, coords: True) if lap else None)
 
 
-@pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
-                                      ("c4", True)])
-def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
-    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
-    torch.manual_seed(0)
-    cfg = configs.make(name, SIZES[name])
-    coords = gold["coords"].astype(np.float32)
+def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None):
+    """One training closure on the host: traced + generated pointwise code (gcc) around the jet oracle's network
+    streams and VJP.  coords [d][n] fp32, params flat fp64.  Returns (program, funcs [n][nf], resid [n][neq], loss, grad)."""
+    coords = np.ascontiguousarray(coords, np.float32)
     n_coords, n = coords.shape
-    prog = trace(cfg, n_coords, lap)
-    if name in ("c2", "c5"):     # Laplace / Navier-Stokes use u_xx + u_yy only: the merge must be found when allowed
-        assert any(prog.g.nodes[i][3][:1] == ("L",) for i in prog.symbols) == lap
-    # network streams from the jet oracle (fp64 -> fp32), laid out like program.symbols
+    prog = trace(nets, conds, pde, n_coords, lap, cfv)
     dims_act, flats, off = [], [], 0
-    for net in cfg["nets"]:
+    for net in nets:
         info = describe(net)
         dims = (info["d"],) + (info["hidden"],) * info["layers"] + (info["n_out"],)
         npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
         dims_act.append((dims, "tanh" if info["act"] == 0 else "sin"))
-        flats.append(gold["params0"][off:off + npar].astype(np.float64))
+        flats.append(np.asarray(params[off:off + npar], np.float64))
         off += npar
     # a ("L", a, b, ..) symbol is the Laplacian stream = sum of the pure second derivatives (a,a), (b,b), ..
     parts = lambda mi: [(c, c) for c in mi[1:]] if (mi and mi[0] == "L") else [mi]
-    needed = {k: set() for k in range(len(cfg["nets"]))}
+    needed = {k: set() for k in range(len(nets))}
     for i in prog.symbols:
         _, k, o, mi = prog.g.nodes[i]
         needed[k].add(mi)
@@ -76,10 +69,7 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
     n_eq = len(prog.residuals)
     seed = 1.0 / (n * n_eq)
     resid, funcs, gbar = run_cpu(prog, coords, syms, seed)
-    assert rel_l2(funcs.T, gold["funcs_f64"]) < 1e-5
-    assert rel_l2(resid.T, gold["residuals_f64"]) < 1e-5
     loss = float((resid.astype(np.float64) ** 2).sum() * seed)
-    assert abs(loss - float(gold["loss_f64"])) <= 1e-5 * abs(float(gold["loss_f64"]))
     # parameter gradient: adjoint streams through the jet oracle's VJP
     grads = []
     for k, (dims, act) in enumerate(dims_act):
@@ -92,7 +82,53 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
                     m = gb.setdefault(tuple(sorted(deps.index(c) for c in part)), np.zeros((n, dims[-1])))
                     m[:, o] += gbar[idx].astype(np.float64)
         grads.append(J.mlp_jets_vjp(flats[k], dims, act, [coords[c] for c in deps], gb))
-    assert rel_l2(np.concatenate(grads), gold["grad_f64"]) < 1e-5
+    return prog, funcs.T, resid.T, loss, np.concatenate(grads)
+
+
+@pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
+                                      ("c4", True)])
+def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(0)
+    cfg = configs.make(name, SIZES[name])
+    prog, funcs, resid, loss, grad = host_closure(cfg["nets"], cfg["conds"], cfg["pde"], gold["coords"], gold["params0"], lap,
+                                                  configs.func_val(cfg))
+    if name in ("c2", "c5"):     # Laplace / Navier-Stokes use u_xx + u_yy only: the merge must be found when allowed
+        assert any(prog.g.nodes[i][3][:1] == ("L",) for i in prog.symbols) == lap
+    assert rel_l2(funcs, gold["funcs_f64"]) < 1e-5
+    assert rel_l2(resid, gold["residuals_f64"]) < 1e-5
+    assert abs(loss - float(gold["loss_f64"])) <= 1e-5 * abs(float(gold["loss_f64"]))
+    assert rel_l2(grad, gold["grad_f64"]) < 1e-5
+
+
+# stream set the tracer must arrive at for each zoo system: per network (first, mask2, lap)
+ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tanh": [(1, 1, 0)], "helmholtz_xy": [(1, 7, 0)],
+               "advection": [(1, 0, 0)], "heat_wide": [(1, 1, 0)], "stokes_like": [(1, 5, 1), (1, 5, 1), (1, 0, 0)],
+               "poisson3d": [(1, 41, 1)], "hessian3d": [(1, 63, 0)], "shell": [(1, 41, 0)]}
+
+
+@pytest.mark.parametrize("name", zoo.NAMES)
+def test_zoo_on_host_matches_autograd_oracle(name):
+    """Systems outside the BASELINE set: tracer + generated code + jet oracle against the fp64 autograd oracle built from
+    independently written re-parameterisations (tests/zoo.py)."""
+    from oracle import autograd_ref as R
+    torch.manual_seed(11)
+    system = zoo.build(name)
+    nets, conds, pde = system.product()
+    flat = R.get_flat(nets)
+    coords = system.sample(40, seed=5)
+    onets, enforcers, opde = system.oracle(flat)
+    want = R.closure(onets, enforcers, opde, coords)
+    want_grad = R.get_flat_grad(onets).numpy()
+    prog, funcs, resid, loss, grad = host_closure(nets, conds, pde, np.stack([c.numpy() for c in coords]).astype(np.float32),
+                                                  flat.double().numpy())
+    got_streams = [(int(st.first), int(st.mask2), int(st.lap)) for st in (prog.streams[k] for k in range(len(nets)))]
+    assert got_streams == ZOO_STREAMS[name]
+    # the oracle ran on the fp64 coordinates, the host pipeline on their fp32 rounding: tolerance 1e-5 covers it
+    assert rel_l2(funcs, want["funcs"].numpy()) < 1e-5
+    assert rel_l2(resid, want["residuals"].numpy()) < 1e-5
+    assert abs(loss - want["loss"].item()) <= 1e-5 * abs(want["loss"].item())
+    assert rel_l2(grad, want_grad) < 1e-5
 
 
 def test_unsupported_constructs_raise_trace_unsupported():

@@ -1,0 +1,142 @@
+"""A zoo of small ODE / PDE systems beyond the five BASELINE configs, used to exercise the tracer, the symbolic
+differentiation, the generated pointwise code and every stream-set kernel (first order only, mixed second derivatives,
+three coordinates, multi-network, sin activations ...).  Each system is stated twice from the same maths:
+
+* ``product``: against the neurodiffeq_amd API (conditions classes + ``diff``), i.e. what a user writes;
+* ``oracle``:  plain closures over ``oracle.autograd_ref.ref_diff`` with hand-written re-parameterisations
+  (conditions.py of the reference: IVP 247-267, DirichletBVP 373-394, DirichletBVP2D 473-509, IBVP1D 669-681,
+  DirichletBVPSpherical 920-958), so the checker shares no code with the thing checked.
+"""
+import math
+
+import torch
+
+PI = math.pi
+
+
+class System:
+    def __init__(self, name, n_coords, nets, box, pde, conds, enforcers):
+        self.name, self.n_coords, self.net_specs, self.box = name, n_coords, nets, box
+        self.pde, self.conds, self.enforcers = pde, conds, enforcers
+
+    def sample(self, n, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        return [lo + (hi - lo) * torch.rand(n, generator=g, dtype=torch.float64) for lo, hi in self.box]
+
+    def product(self):
+        """(nets fp32, conditions, diff_eqs) on the neurodiffeq_amd API"""
+        from neurodiffeq_amd import diff
+        from neurodiffeq_amd.networks import FCNN, SinActv
+        nets = [FCNN(i, o, hidden_units=h, actv=SinActv if a == "sin" else torch.nn.Tanh) for i, o, h, a in self.net_specs]
+        return nets, self.conds(), self.pde(diff)
+
+    def oracle(self, flat):
+        """(nets fp64 carrying ``flat``, enforcers, pde) on the oracle"""
+        from oracle import autograd_ref as R
+        nets = [R.make_fcnn(i, o, h, a, dtype=torch.float64) for i, o, h, a in self.net_specs]
+        R.set_flat(nets, flat.double())
+        return nets, self.enforcers(R.ref_diff), self.pde(R.ref_diff)
+
+
+def _R():
+    from oracle import autograd_ref
+    return autograd_ref
+
+
+def _cat(*cols):
+    return torch.cat(cols, dim=1)
+
+
+def build(name):
+    from neurodiffeq_amd import conditions as C
+    zero = lambda s: 0 * s
+    if name == "pendulum":            # u'' + sin u = 0, u(0) = 1, u'(0) = 0.5  -> second-order IVP, 1-D mask 0b1
+        pde = lambda D: (lambda u, t: [D(u, t, order=2) + torch.sin(u)])
+        conds = lambda: [C.IVP(0.0, 1.0, u_0_prime=0.5)]
+        enf = lambda D: [lambda net, t: 1.0 + t * 0.5 + (1 - torch.exp(-t)) ** 2 * net(t)]
+        return System(name, 1, [(1, 1, (32, 32), "tanh")], [(0.0, 2.0)], pde, conds, enf)
+    if name == "coupled_sin":         # two sin networks, non-polynomial coefficients (division, exp, sqrt)
+        pde = lambda D: (lambda u, v, t: [D(u, t) - v / (1 + t ** 2), D(v, t) + u * torch.exp(-t) - torch.sqrt(t + 1)])
+        conds = lambda: [C.IVP(0.0, 0.0), C.IVP(0.0, 1.0)]
+        enf = lambda D: [lambda net, t: 0.0 + (1 - torch.exp(-t)) * net(t), lambda net, t: 1.0 + (1 - torch.exp(-t)) * net(t)]
+        return System(name, 1, [(1, 1, (32, 32), "sin")] * 2, [(0.0, 3.0)], pde, conds, enf)
+    if name == "bvp_tanh":            # u'' - tanh(u) u' = cos t between two Dirichlet ends
+        pde = lambda D: (lambda u, t: [D(u, t, order=2) - torch.tanh(u) * D(u, t) - torch.cos(t)])
+        conds = lambda: [C.DirichletBVP(0.0, 1.0, 2.0, -1.0)]
+
+        def e(net, t):
+            s = t / 2.0
+            return 1.0 * (1 - s) - 1.0 * s + (1 - torch.exp((1 - s) * s)) * net(t)
+        return System(name, 1, [(1, 1, (32, 32), "tanh")], [(0.0, 2.0)], pde, conds, lambda D: [e])
+    if name == "helmholtz_xy":        # all three second derivatives -> 2-D mask 0b111
+        f0 = lambda y: torch.sin(PI * y)
+        g1 = lambda x: x * (1 - x)
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + 0.5 * D(D(u, x), y) + 4.0 * u
+                                          - torch.sin(PI * x) * torch.cos(PI * y)])
+        conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, g1)]
+
+        return System(name, 2, [(2, 1, (32, 32), "tanh")], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, g1)])
+    if name == "advection":           # first order only (2-D, mask 0), raw network
+        pde = lambda D: (lambda u, x, y: [D(u, x) + 2.0 * D(u, y) - u ** 2 + torch.exp(-x * y)])
+        conds = lambda: [C.NoCondition()]
+        return System(name, 2, [(2, 1, (32, 32), "tanh")], [(-1.0, 1.0), (-1.0, 1.0)], pde, conds,
+                      lambda D: [lambda net, x, y: net(_cat(x, y))])
+    if name == "heat_wide":           # three hidden layers of 64, IBVP1D Dirichlet-Dirichlet
+        u0 = lambda x: torch.sin(PI * x)
+        pde = lambda D: (lambda u, x, t: [D(u, t) - 0.1 * D(u, x, order=2) + u ** 3])
+        conds = lambda: [C.IBVP1D(0.0, 1.0, 0.0, u0, x_min_val=zero, x_max_val=zero)]
+
+        return System(name, 2, [(2, 1, (64, 64, 64), "tanh")], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().ibvp1d_dd(0.0, 1.0, 0.0, u0, zero, zero)])
+    if name == "stokes_like":         # three networks sharing two coordinates, mixed stream sets (Laplacian + first order)
+        def pde(D):
+            def f(u, v, p, x, y):
+                return [D(u, x, order=2) + D(u, y, order=2) - D(p, x) + torch.sin(PI * y),
+                        D(v, x, order=2) + D(v, y, order=2) - D(p, y), D(u, x) + D(v, y)]
+            return f
+        conds = lambda: [C.NoCondition()] * 3
+        raw = lambda net, x, y: net(_cat(x, y))
+        return System(name, 2, [(2, 1, (32, 32), "tanh")] * 3, [(0.0, 1.0), (0.0, 1.0)], pde, conds, lambda D: [raw] * 3)
+    if name == "poisson3d":           # three coordinates, Laplacian -> one merged second-order stream
+        pde = lambda D: (lambda u, x, y, z: [D(u, x, order=2) + D(u, y, order=2) + D(u, z, order=2)
+                                             + torch.exp(-(x ** 2 + y ** 2 + z ** 2))])
+        conds = lambda: [C.NoCondition()]
+        return System(name, 3, [(3, 1, (32, 32), "tanh")], [(-1.0, 1.0)] * 3, pde, conds,
+                      lambda D: [lambda net, x, y, z: net(_cat(x, y, z))])
+    if name == "hessian3d":           # every entry of the 3-D Hessian with different weights -> mask 0b111111
+        pde = lambda D: (lambda u, x, y, z: [D(u, x, order=2) + 2.0 * D(u, y, order=2) + 3.0 * D(u, z, order=2)
+                                             + D(D(u, x), y) - D(D(u, y), z) + 0.5 * D(D(u, z), x) + u * D(u, z)])
+        conds = lambda: [C.NoCondition()]
+        return System(name, 3, [(3, 1, (32, 32), "tanh")], [(-1.0, 1.0)] * 3, pde, conds,
+                      lambda D: [lambda net, x, y, z: net(_cat(x, y, z))])
+    if name == "shell":               # Laplace in a spherical shell, SolverSpherical's setting: diagonal second derivatives
+        f = lambda th, ph: torch.cos(th)
+        g = lambda th, ph: torch.sin(th) * torch.cos(ph)
+        r0, r1 = 0.5, 2.0
+
+        def pde(D):
+            def lap(u, r, th, ph):             # operators.py spherical_laplacian, expanded form
+                return [D(u, r, order=2) + 2.0 / r * D(u, r) + (D(u, th, order=2) + D(u, th) / torch.tan(th)) / r ** 2
+                        + D(u, ph, order=2) / (r * torch.sin(th)) ** 2]
+            return lap
+        conds = lambda: [C.DirichletBVPSpherical(r0, f, r1, g)]
+
+        def e(net, r, th, ph):
+            s = (r - r0) / (r1 - r0)
+            return f(th, ph) * (1 - s) + g(th, ph) * s + (1 - torch.exp((1 - s) * s)) * net(_cat(r, th, ph))
+        return System(name, 3, [(3, 1, (32, 32), "tanh")], [(r0, r1), (0.3, 2.8), (0.0, 2 * PI)], pde, conds, lambda D: [e])
+    raise KeyError(name)
+
+
+NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "poisson3d",
+         "hessian3d", "shell"]
+
+
+def spherical_solver_problem():
+    """(diff_eqs, conditions) of the SolverSpherical end-to-end test: Laplace between two spheres through
+    operators.spherical_laplacian, default FCNN(3, 1) network."""
+    from neurodiffeq_amd.conditions import DirichletBVPSpherical
+    from neurodiffeq_amd.operators import spherical_laplacian
+    cond = DirichletBVPSpherical(0.5, lambda th, ph: torch.cos(th), 2.0, lambda th, ph: 0.25 * torch.cos(th))
+    return (lambda u, r, th, ph: [spherical_laplacian(u, r, th, ph)]), [cond]
