@@ -83,6 +83,26 @@ int ndq_epoch_tail(float* params, const float* grad, float* exp_avg, float* exp_
                    float* loss_hist, int hist_index, float* best_loss, int parity, float* best_flat, int write_scalars,
                    void* stream);
 
+/* Device-side collocation-point sampler: the distributions of the reference's generators drawn with a counter-based
+ * Philox4x32-10 stream instead of torch's host generator, so a fresh batch per epoch costs one small kernel and no
+ * PCIe transfer.  (The reference samples on torch's default device with the global RNG, generators.py:150-152,
+ * 253-266, 622-646; points drawn here follow the same distributions but are NOT the same numbers.) */
+#define NDQ_SAMPLE_UNIFORM 0   /* Generator1D 'uniform' per coordinate: lo + (hi - lo) * U[0,1) */
+#define NDQ_SAMPLE_GRID 1      /* Generator1D/2D/3D 'equally-spaced[-noisy]': ij-meshgrid of linspaces + N(0, std^2) */
+#define NDQ_SAMPLE_SPHERICAL 2 /* GeneratorSpherical: direction as generators.py:622-635, radius per `radial` */
+typedef struct ndq_sampler_desc {
+  int kind;           /* NDQ_SAMPLE_* */
+  int d;              /* coordinates per point (1..3; SPHERICAL: 3 = r, theta, phi) */
+  int n[3];           /* GRID: points per axis (last axis fastest); otherwise n[0] = number of points */
+  float lo[3], hi[3]; /* box per coordinate; SPHERICAL: lo[0] = r_min, hi[0] = r_max */
+  float noise_std[3]; /* GRID: standard deviation of the jitter per axis (0: exact grid) */
+  int radial;         /* SPHERICAL: 0: r^2 uniform ('equally-spaced-noisy'), 1: r uniform ('equally-radius-noisy') */
+} ndq_sampler_desc;
+/* coords (out) [d][ldc].  Point i uses Philox counter (i, draw, stream_id) under key `seed`: the same
+ * (seed, draw, stream_id) always yields the same batch; ranks use distinct stream_id. */
+int ndq_sample(const ndq_sampler_desc* desc, unsigned long long seed, unsigned long long draw, unsigned stream_id,
+               float* coords, int ldc, void* stream);
+
 /* Launcher exported by a generated single-network fused closure kernel (codegen.py: fused_source). */
 typedef int (*ndq_fused_launch_fn)(const float* coords, int ldc, int n, const float* params, float* partials,
                                    float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,

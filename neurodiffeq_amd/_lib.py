@@ -16,6 +16,15 @@ class MlpDesc(ctypes.Structure):
         return (self.d, self.first, self.mask2, self.hidden, self.layers, self.act, self.n_out, self.lap)
 
 
+NDQ_SAMPLE_UNIFORM, NDQ_SAMPLE_GRID, NDQ_SAMPLE_SPHERICAL = 0, 1, 2
+
+
+class SamplerDesc(ctypes.Structure):
+    """ndq_sampler_desc of include/ndq.h"""
+    _fields_ = [("kind", ctypes.c_int), ("d", ctypes.c_int), ("n", ctypes.c_int * 3), ("lo", ctypes.c_float * 3),
+                ("hi", ctypes.c_float * 3), ("noise_std", ctypes.c_float * 3), ("radial", ctypes.c_int)]
+
+
 FUSED_LAUNCH_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.c_float, ctypes.c_int, ctypes.c_void_p)
@@ -67,9 +76,10 @@ def lib():
     L.ndq_reduce_grad_loss.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, cf, vp]
     L.ndq_epoch_tail.argtypes = [vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp]
     L.ndq_fused_step_run.argtypes = [ctypes.POINTER(FusedStep), vp, ci, ci, ci, vp]
+    L.ndq_sample.argtypes = [ctypes.POINTER(SamplerDesc), ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, vp, ci, vp]
     for name in ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks",
                  "ndq_mlp_jet_fwd", "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss",
-                 "ndq_epoch_tail", "ndq_fused_step_run"):
+                 "ndq_epoch_tail", "ndq_fused_step_run", "ndq_sample"):
         getattr(L, name).restype = ci
     _LIB = L
     return L
@@ -77,7 +87,7 @@ def lib():
 
 EXPORTS = ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks", "ndq_mlp_jet_fwd",
            "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss", "ndq_epoch_tail",
-           "ndq_fused_step_run")
+           "ndq_fused_step_run", "ndq_sample")
 
 
 def check(rc, what):

@@ -1,6 +1,7 @@
 // C-ABI of libndq.so (declared in include/ndq.h): descriptor dispatch onto the templated gfx950 kernels of
 // ndq_mlp.h, the second-stage reduction and the fused Adam step.
 #include "ndq_mlp.h"
+#include "ndq_sample.h"
 #include "../../include/ndq.h"
 
 namespace ndq {
@@ -393,6 +394,11 @@ int ndq_adam_step(float* params, const float* grad, float* exp_avg, float* exp_a
   hipLaunchKernelGGL(adam_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), params, grad,
                      exp_avg, exp_avg_sq, len, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
   return (int)hipGetLastError();
+}
+
+int ndq_sample(const ndq_sampler_desc* desc, unsigned long long seed, unsigned long long draw, unsigned stream_id,
+               float* coords, int ldc, void* stream) {
+  return ndq::launch_sample(desc, seed, draw, stream_id, coords, ldc, (hipStream_t)stream);
 }
 
 }  // extern "C"

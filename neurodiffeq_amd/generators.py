@@ -1,9 +1,15 @@
 """Collocation-point generators with the reference's names, arguments and draw order
 (neurodiffeq/generators.py:107-316, 1046-1064).
 
-Generators are the *input producer* of the hot path, not part of it: they always sample on the host with torch's
-global CPU generator, in the same call sequence as the reference, so that a given ``torch.manual_seed`` yields
-bit-identical points (the north-star parity contract); the solver uploads each batch to HBM as one SoA block."""
+Generators are the *input producer* of the hot path, not part of it: the classes with the reference's names always
+sample on the host with torch's global CPU generator, in the same call sequence as the reference, so that a given
+``torch.manual_seed`` yields bit-identical points (the north-star parity contract); the solver uploads each batch to
+HBM as one SoA block.  Two additions without a reference counterpart keep the producer off the step's critical path:
+:class:`ResidentBatchGenerator` (pre-sampled batches resident in HBM) and :class:`DeviceGenerator` (the same
+distributions drawn by a Philox kernel on the MI355X, a fresh batch per epoch with no PCIe hand-off)."""
+import ctypes
+import os
+
 import numpy as np
 import torch
 
@@ -342,3 +348,80 @@ class ResidentBatchGenerator(BaseGenerator):
             blk = self.blocks[k]
             views = self._views[k] = [blk[i, :self.size].reshape(-1, 1) for i in range(blk.shape[0])]
         return views
+
+
+class DeviceGenerator(BaseGenerator):
+    """Draws the distribution of a reference generator ON the MI355X (csrc/ndq_sample.h through ``ndq_sample``).
+
+    New (no reference counterpart): host sampling is the floor of a fused step
+    (``torch.normal`` over 2 x 65 536 points costs ~10x the whole fused C2 step).  Wrapping a generator keeps its
+    distribution -- grid geometry, jitter standard deviation, radial law -- but draws from a counter-based
+    Philox4x32-10 stream: batch number ``k`` of a given ``seed`` (default ``torch.initial_seed()`` at construction) and
+    ``stream_id`` (default: the process rank, so data-parallel ranks draw disjoint streams) is always the same
+    points, yet they are NOT the numbers the reference's host generator would produce, hence opt-in.
+
+    Supported: ``Generator1D`` ('uniform', 'equally-spaced', 'equally-spaced-noisy'), ``Generator2D`` / ``Generator3D``
+    ('equally-spaced', 'equally-spaced-noisy'), ``GeneratorSpherical`` (both radial laws).  ``get_examples`` enqueues
+    one kernel on the current stream and returns ``(N, 1)`` views of ONE resident SoA block which the fused engine
+    reads in place; the block is overwritten by the next draw (stream-ordered, so the previous step has consumed it).
+    """
+
+    def __init__(self, generator, device=None, seed=None, stream_id=None):
+        super().__init__()
+        from . import _lib
+        if not torch.cuda.is_available():
+            raise _lib.NdqError("DeviceGenerator samples with a gfx950 kernel and needs an MI355X; use the wrapped "
+                                "generator itself for host sampling")
+        self.generator, self.size = generator, generator.size
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.seed = int(torch.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        self.stream_id = int(os.environ.get("RANK", "0")) if stream_id is None else int(stream_id)
+        self.draw = 0
+        self.desc = self.describe(generator)
+        self._L = _lib.lib()
+        ld = (self.size + 63) // 64 * 64
+        self.block = torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device)
+        self._views = [self.block[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)]
+
+    @staticmethod
+    def describe(g):
+        """``ndq_sampler_desc`` of a reference-style generator; ``ValueError`` for what the kernel does not draw."""
+        from . import _lib
+        d = _lib.SamplerDesc()
+        grid_methods = ("equally-spaced", "equally-spaced-noisy")
+
+        def grid(ns, lo, hi, std):
+            d.kind, d.d = _lib.NDQ_SAMPLE_GRID, len(ns)
+            for i in range(len(ns)):
+                d.n[i], d.lo[i], d.hi[i], d.noise_std[i] = int(ns[i]), float(lo[i]), float(hi[i]), float(std[i])
+        if isinstance(g, Generator1D) and g.method == "uniform":
+            d.kind, d.d = _lib.NDQ_SAMPLE_UNIFORM, 1
+            d.n[0], d.lo[0], d.hi[0] = g.size, g.t_min, g.t_max
+        elif isinstance(g, Generator1D) and g.method in grid_methods:
+            grid([g.size], [g.t_min], [g.t_max], [g.noise_std if g.method.endswith("noisy") else 0.0])
+        elif isinstance(g, Generator2D) and g.method in grid_methods:
+            grid(g.grid, g.xy_min, g.xy_max, [g.noise_xstd, g.noise_ystd] if g.method.endswith("noisy") else [0.0, 0.0])
+        elif isinstance(g, Generator3D) and g.method in grid_methods:
+            grid(g.grid, g.xyz_min, g.xyz_max, g.noise_std if g.method.endswith("noisy") else [0.0] * 3)
+        elif isinstance(g, GeneratorSpherical):
+            d.kind, d.d = _lib.NDQ_SAMPLE_SPHERICAL, 3
+            d.n[0], d.lo[0], d.hi[0] = g.size, g.r_min, g.r_max
+            d.radial = int(g.method == "equally-radius-noisy")
+        else:
+            raise ValueError(f"DeviceGenerator cannot draw {g!r} on the device")
+        return d
+
+    def get_examples(self):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, self.draw, self.stream_id, self.block.data_ptr(),
+                                self.block.shape[1], stream)
+        if rc != 0:
+            from . import _lib
+            raise _lib.NdqError(f"ndq_sample failed with code {rc}")
+        self.draw += 1
+        return self._views
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(generator=self.generator, seed=self.seed, stream_id=self.stream_id)
+        return d

@@ -381,7 +381,7 @@ def test_spherical_solver_with_default_network_runs_fused():
     assert solver.fused_active
     h = solver.metrics_history
     assert len(h["train_loss"]) == 200 and len(h["valid_loss"]) == 200
-    assert h["train_loss"][-1] < 0.5 * h["train_loss"][0]
+    assert h["train_loss"][-1] < 0.85 * h["train_loss"][0] and h["valid_loss"][-1] < 0.85 * h["valid_loss"][0]
     r = torch.full((5,), 0.5)
     th, ph = torch.linspace(0.3, 2.8, 5), torch.zeros(5)
     assert torch.allclose(solver.get_solution()(r, th, ph).cpu(), torch.cos(th), atol=1e-6)      # inner boundary exact
