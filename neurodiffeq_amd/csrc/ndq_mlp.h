@@ -134,6 +134,9 @@ enum { ACT_TANH = 0, ACT_SIN = 1 };
 #ifndef NDQ_DW_MM
 #define NDQ_DW_MM 0
 #endif
+#ifndef NDQ_WIDE_LOWREG
+#define NDQ_WIDE_LOWREG 1
+#endif
 #ifndef NDQ_KEEP_H
 #define NDQ_KEEP_H 1
 #endif
@@ -207,6 +210,15 @@ struct Cfg {
   static constexpr bool KEEP_PLANES = DW_MM && (NB_ == 2) && (L_ == 2) && (NDQ_KEEP_PLANES != 0);
   static constexpr int NCH = (SS::NS + 1) / 2;             // stream pairs = K-chunks of the weight-gradient MFMAs
   static constexpr bool KEEP_H = (NB_ == 2) && (NDQ_KEEP_H != 0);
+  // wide nets (H >= 64): the reverse pass is register-bound, so (a) the per-point GEMMs go through their bf16 planes
+  // SG streams at a time instead of all at once, (b) the bias-type gradient sums (db_l, dW1, dWout: one value per
+  // unit) live in a per-wave LDS region instead of registers, (c) the first layer's derivative streams (columns of
+  // W1) are re-read from LDS for the reverse pass instead of being kept
+  static constexpr bool WIDE = (NB_ >= 4) && (NDQ_WIDE_LOWREG != 0);
+  static constexpr int SG = WIDE ? 2 : SS::NS;
+  static constexpr bool ACC_LDS = WIDE && (NOUT_ == 1);
+  static constexpr int biasFloats = ACC_LDS ? H * (D_ + L_ + 1) : 0;      // b1 | W1 [D] | b_2..b_L | Wout
+  static constexpr int biasB1 = 0, biasW1 = H, biasBl = H * (1 + D_), biasWout = H * (D_ + L_);
   static constexpr int layerStride(bool bwd) { return (bwd ? 2 : 1) * WEL + H; }
   static constexpr int ldsWf(int l, bool bwd) { return ldsLayer0 + (l - 2) * layerStride(bwd); }
   static constexpr int ldsWt(int l) { return ldsWf(l, true) + WEL; }
@@ -489,6 +501,43 @@ __device__ __forceinline__ void gemm_planes(const float* __restrict__ wl, int la
     }
 }
 
+// the same for streams [S0, S0 + SN) only: planes of SN streams live at a time (wide nets)
+template <class C, int S0, int SN>
+__device__ __forceinline__ void gemm_group(const float* __restrict__ wl, int lane, const f32x4 (&h)[C::NS][C::NB],
+                                           f32x4 (&z)[C::NS][C::NB]) {
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+  bf16x8 pl[SN][C::NC][3];
+#pragma unroll
+  for (int s = 0; s < SN; ++s)
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c) split3(h[S0 + s][2 * c], h[S0 + s][2 * c + 1], pl[s][c]);
+#pragma unroll
+  for (int c = 0; c < C::NC; ++c)
+#pragma unroll
+    for (int ob = 0; ob < C::NB; ++ob) {
+      const bf16x8 a0 = w[((ob * C::NC + c) * 3 + 0) * 64 + lane];
+      const bf16x8 a1 = w[((ob * C::NC + c) * 3 + 1) * 64 + lane];
+      const bf16x8 a2 = w[((ob * C::NC + c) * 3 + 2) * 64 + lane];
+#define NDQ_T(A, K)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < SN; ++s)                                                             \
+      z[S0 + s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], z[S0 + s][ob], 0, 0, 0);
+      NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+    }
+}
+
+// z[s] += W h[s] for all streams, C::SG streams at a time
+template <class C>
+__device__ __forceinline__ void gemm_grouped(const float* __restrict__ wl, int lane, const f32x4 (&h)[C::NS][C::NB],
+                                             f32x4 (&z)[C::NS][C::NB]) {
+  constexpr int NG = (C::NS + C::SG - 1) / C::SG;
+  sfor<NG>([&](auto g_) {
+    constexpr int s0 = decltype(g_)::value * C::SG;
+    constexpr int sn = (C::NS - s0 < C::SG) ? C::NS - s0 : C::SG;
+    gemm_group<C, s0, sn>(wl, lane, h, z);
+  });
+}
+
 // 0/1 selection operand: as the B operand of an MFMA whose A operand is a plane set of K-chunk c, it extracts
 // 16-unit block (2c + half) TRANSPOSED: D[point][unit] -> lane (unit, q') holds points 4q'..4q'+3.
 // lane (j = lane&15, kg = lane>>4): slot (kg, e) <-> unit 16*half + 4*kg + (e&3) with e>>2 == half.
@@ -557,6 +606,41 @@ __device__ __forceinline__ void weight_grad_mm(int lane, const Planes<C>& Z, con
 // hbar = W^T zbar in place (all streams are split first, then overwritten)
 template <class C>
 __device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl, int lane, f32x4 (&g)[C::NS][C::NB]) {
+  if constexpr (C::WIDE) {           // group by group: planes and outputs of SG streams live at a time
+    constexpr int NG = (C::NS + C::SG - 1) / C::SG;
+    sfor<NG>([&](auto g_) {
+      constexpr int s0 = decltype(g_)::value * C::SG;
+      constexpr int sn = (C::NS - s0 < C::SG) ? C::NS - s0 : C::SG;
+      const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+      bf16x8 pl[sn][C::NC][3];
+      f32x4 o[sn][C::NB];
+#pragma unroll
+      for (int s = 0; s < sn; ++s) {
+#pragma unroll
+        for (int c = 0; c < C::NC; ++c) split3(g[s0 + s][2 * c], g[s0 + s][2 * c + 1], pl[s][c]);
+#pragma unroll
+        for (int b = 0; b < C::NB; ++b) o[s][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int c = 0; c < C::NC; ++c)
+#pragma unroll
+        for (int ob = 0; ob < C::NB; ++ob) {
+          const bf16x8 a0 = w[((ob * C::NC + c) * 3 + 0) * 64 + lane];
+          const bf16x8 a1 = w[((ob * C::NC + c) * 3 + 1) * 64 + lane];
+          const bf16x8 a2 = w[((ob * C::NC + c) * 3 + 2) * 64 + lane];
+#define NDQ_T(A, K)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
+      o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], o[s][ob], 0, 0, 0);
+          NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+        }
+#pragma unroll
+      for (int s = 0; s < sn; ++s)
+#pragma unroll
+        for (int b = 0; b < C::NB; ++b) g[s0 + s][b] = o[s][b];
+    });
+    return;
+  }
   f32x4 o[C::NS][C::NB];
   zero_frag<C>(o);
   Planes<C> P;
@@ -725,6 +809,24 @@ __device__ __forceinline__ void gemm_layer_bf16(const float* lds, int l, int lan
   hidden_layer_planes<C, false>(lds, l, lane, q, P, st);
 }
 
+// hidden layer on the bf16x3 path with the planes built SG streams at a time (wide nets); st_out may not alias h's source
+template <class C, bool BWD>
+__device__ __forceinline__ void hidden_layer_grouped(const float* lds, int l, int lane, int q,
+                                                     const f32x4 (&h)[C::NS][C::NB], LayerState<C>& st) {
+  f32x4 z[C::NS][C::NB];
+  zero_frag<C>(z);
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
+  gemm_grouped<C>(lds + C::ldsWf(l, BWD), lane, h, z);
+#pragma unroll
+  for (int b = 0; b < C::NB; ++b) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[0][b][r], st.t[b][r], st.c[b][r]);
+#pragma unroll
+    for (int s = 1; s < C::NS; ++s) st.z[s][b] = z[s][b];
+  }
+}
+
 template <class C> struct KeptPlanes {
   Planes<C> hk[(C::KEEP_PLANES && C::L > 1) ? C::L - 1 : 1];
   // with one wave per SIMD there are registers to spare: the activation streams of every layer are kept from the
@@ -745,7 +847,9 @@ __device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, 
 #pragma unroll
         for (int b = 0; b < C::NB; ++b) kp.h[li][s][b] = h[s][b];
     }
-    if constexpr (C::BF16) {
+    if constexpr (C::BF16 && C::WIDE) {
+      hidden_layer_grouped<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
+    } else if constexpr (C::BF16) {
       if constexpr (BWD && C::KEEP_PLANES) {   // the weight-gradient GEMM of layer l reuses these planes
         split_all<C>(h, kp.hk[li]);
         hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, kp.hk[li], st[li + 1]);
@@ -788,7 +892,8 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
 #pragma unroll
     for (int l = 2; l <= C::L; ++l) {
       act_forward<C>(st, h);
-      if constexpr (C::BF16) gemm_layer_bf16<C>(lds, l, lane, q, h, st);
+      if constexpr (C::BF16 && C::WIDE) hidden_layer_grouped<C, false>(lds, l, lane, q, h, st);
+      else if constexpr (C::BF16) gemm_layer_bf16<C>(lds, l, lane, q, h, st);
       else hidden_layer<C, false>(lds, l, lane, q, h, st);
     }
     act_forward<C>(st, h);
@@ -822,7 +927,7 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
 template <class C>
 constexpr int bwd_regions(int waves) {
   const int pp = (C::P + 3) & ~3;
-  const int budget = 38 * 1024 - C::ldsWeightsEnd(true);   // floats
+  const int budget = 38 * 1024 - C::ldsWeightsEnd(true) - waves * C::biasFloats;   // floats
   int r = budget / pp;
   if (r < 1) r = 1;
   return r > waves ? waves : r;
@@ -839,7 +944,34 @@ struct GradAcc {
   float bout;                        // NOUT == 1: dbout          (needs full wave sum)
   f32x4 wo[C::NBO][C::NB];           // NOUT > 1: dWout[16ob+4q+r][16kb+p], MFMA accumulators
   float bo[C::NBO][4];               // NOUT > 1: dbout[16ob+4q+r] (needs point_sum)
+  float* bias;                       // ACC_LDS: this wave's LDS region holding b1 / w1 / b / wout instead (already point-summed)
 };
+
+// ACC_LDS: add the tile's point-sum of v (one value per unit j = 16b+4q+r, per lane group) to this wave's LDS sums.
+// Only this wave touches its region and LDS operations of a wave are issued in order, so the order of additions --
+// tile after tile -- is fixed.
+template <class C>
+__device__ __forceinline__ void bias_accum(GradAcc<C>& acc, int off, int p, int q, int b, const float (&v)[4]) {
+  float s[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) s[r] = point_sum(v[r]);
+  if (p == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __hip_atomic_fetch_add(acc.bias + off + 16 * b + 4 * q + r, s[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+}
+
+// first-layer derivative streams (columns of W1) re-read from LDS
+template <class C>
+__device__ __forceinline__ void reload_first_layer_streams(const float* lds, int q, LayerState<C>& st) {
+  if constexpr (C::SS::FIRST) {
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+      for (int a = 0; a < C::D; ++a) st.z[1 + a][b] = lds4(lds + C::ldsW1T + a * C::H + 16 * b + 4 * q);
+  }
+}
 
 // dW_l += sum_s Zbar[s] H[s]^T over the 16 points of the tile, stream by stream through the LDS transpose tile.
 // stage: per-wave region of 2*16*HP floats.  Point <-> MFMA k mapping: k = q at step st  <->  point 4*q + st,
@@ -937,6 +1069,23 @@ __device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
   }
 }
 
+// start of the per-wave bias-sum regions (ACC_LDS), behind the staging tiles / reduction regions
+template <class C> __device__ __forceinline__ float* bias_region(float* lds, int waves, int wave) {
+  const int pp = (C::P + 3) & ~3;
+  const int stage = waves * C::stageFloatsPerWave;
+  const int red = bwd_regions<C>(waves) * pp;
+  return lds + C::ldsWeightsEnd(true) + (stage > red ? stage : red) + wave * C::biasFloats;
+}
+template <class C> __device__ __forceinline__ void acc_init(GradAcc<C>& acc, float* lds, int waves, int wave, int lane) {
+  acc_zero<C>(acc);
+  acc.bias = nullptr;
+  if constexpr (C::ACC_LDS) {
+    acc.bias = bias_region<C>(lds, waves, wave);
+    for (int i = lane; i < C::biasFloats; i += 64) acc.bias[i] = 0.f;
+  }
+}
+
+
 template <class C>
 __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* stage, int lane, int p, int q,
                                                      const float (&x)[C::D], LayerState<C> (&st)[C::L],
@@ -997,9 +1146,13 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
       const f32x4 wo = lds4(lds + C::ldsWout(true) + 16 * b + 4 * q);
+      if constexpr (C::ACC_LDS) {
+        const float v[4] = {dw[b][0], dw[b][1], dw[b][2], dw[b][3]};
+        bias_accum<C>(acc, C::biasWout, p, q, b, v);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc.wout[b][r] += dw[b][r];
+        if constexpr (!C::ACC_LDS) acc.wout[b][r] += dw[b][r];
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) g[s][b][r] = wo[r] * gout[s];
       }
@@ -1021,9 +1174,16 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
     constexpr int li = l - 1;             // state index of layer l
     act_backward<C>(st[li], g);           // g: hbar_l -> zbar_l
 #pragma unroll
-    for (int b = 0; b < C::NB; ++b)
+    for (int b = 0; b < C::NB; ++b) {
+      if constexpr (C::ACC_LDS) {
+        const float v[4] = {g[0][b][0], g[0][b][1], g[0][b][2], g[0][b][3]};
+        bias_accum<C>(acc, C::biasBl + (l - 2) * C::H, p, q, b, v);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc.b[l - 2][b][r] += g[0][b][r];
+        for (int r = 0; r < 4; ++r) acc.b[l - 2][b][r] += g[0][b][r];
+      }
+    }
+    if constexpr (C::WIDE && li == 1) reload_first_layer_streams<C>(lds, q, st[0]);   // needed from here on again
     if constexpr (C::DW_MM) {
       Planes<C> Z;
       split_all<C>(g, Z);                                             // zbar_l planes: used by BOTH GEMMs below
@@ -1053,20 +1213,39 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
   });
 
   // ---------------- first layer: z_a = W1[:,a] (constant), z_ab = 0
+  if constexpr (C::WIDE && C::L == 1) reload_first_layer_streams<C>(lds, q, st[0]);
   act_backward<C>(st[0], g);  // g[0] = zbar, g[1+a] = zbar_a
+  if constexpr (C::ACC_LDS) {
 #pragma unroll
-  for (int b = 0; b < C::NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float z0 = g[0][b][r];
-      acc.b1[b][r] += z0;
+    for (int b = 0; b < C::NB; ++b) {
+      const float v0[4] = {g[0][b][0], g[0][b][1], g[0][b][2], g[0][b][3]};
+      bias_accum<C>(acc, C::biasB1, p, q, b, v0);
 #pragma unroll
       for (int d = 0; d < C::D; ++d) {
-        float v = z0 * x[d];
-        if constexpr (SS::FIRST) v += g[1 + d][b][r];
-        acc.w1[d][b][r] += v;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = g[0][b][r] * x[d];
+          if constexpr (SS::FIRST) v[r] += g[1 + d][b][r];
+        }
+        bias_accum<C>(acc, C::biasW1 + d * C::H, p, q, b, v);
       }
     }
+  } else {
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float z0 = g[0][b][r];
+        acc.b1[b][r] += z0;
+#pragma unroll
+        for (int d = 0; d < C::D; ++d) {
+          float v = z0 * x[d];
+          if constexpr (SS::FIRST) v += g[1 + d][b][r];
+          acc.w1[d][b][r] += v;
+        }
+      }
+  }
 }
 
 // lanes -> wave -> workgroup (fixed order) -> out_row[P].
@@ -1085,6 +1264,16 @@ __device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, 
   for (int b = 0; b < C::NB; ++b)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      if constexpr (C::ACC_LDS) {             // the per-unit sums were kept in this wave's LDS region
+        const int j = 16 * b + 4 * q + r;
+        acc.b1[b][r] = acc.bias[C::biasB1 + j];
+        acc.wout[b][r] = acc.bias[C::biasWout + j];
+#pragma unroll
+        for (int d = 0; d < C::D; ++d) acc.w1[d][b][r] = acc.bias[C::biasW1 + d * C::H + j];
+#pragma unroll
+        for (int l = 0; l < C::L - 1; ++l) acc.b[l][b][r] = acc.bias[C::biasBl + l * C::H + j];
+        continue;
+      }
       acc.b1[b][r] = point_sum(acc.b1[b][r]);
       if constexpr (C::NOUT == 1) acc.wout[b][r] = point_sum(acc.wout[b][r]);
 #pragma unroll
@@ -1165,7 +1354,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
   const int ntiles = (a.n + 15) >> 4;
   float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
   GradAcc<C> acc;
-  acc_zero<C>(acc);
+  acc_init<C>(acc, lds, WAVES, wave, lane);
   for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
@@ -1226,7 +1415,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   const int ntiles = (a.n + 15) >> 4;
   float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
   GradAcc<C> acc;
-  if constexpr (TRAIN) acc_zero<C>(acc);
+  if constexpr (TRAIN) acc_init<C>(acc, lds, WAVES, wave, lane);
   float lsum = 0.f;
   for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
     const int n = tile * 16 + p;
@@ -1284,7 +1473,6 @@ template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock) {
   const int pp = (C::P + 3) & ~3;
   const int stage = wavesPerBlock * C::stageFloatsPerWave;
   const int red = bwd_regions<C>(wavesPerBlock) * pp;
-  return sizeof(float) * (C::ldsWeightsEnd(true) + (stage > red ? stage : red));
+  return sizeof(float) * (C::ldsWeightsEnd(true) + (stage > red ? stage : red) + wavesPerBlock * C::biasFloats);
 }
-
 }  // namespace ndq
