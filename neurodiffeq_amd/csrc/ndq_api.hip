@@ -10,7 +10,7 @@ namespace ndq {
 // X(D, FIRST, MASK2, NB, L, ACT, NOUT, LAP).  Stream sets are closed under "second order needs first order".
 // BASELINE configs: C1 (1,1,0,2,2,SIN) | C2 (2,1,0b101,2,2,TANH) | C3 (2,1,0b001,4,3,TANH) | C5 u,v (2,1,0b101,4,3,TANH),
 // p (2,1,0,4,3,TANH); value-only variants serve solution evaluation (solvers.py:682-720).
-// d = 3: SolverSpherical's default FCNN(3,1,(32,32)) (solvers_spherical.py) -- diagonal (0b101001), Laplacian-merged and full Hessian.
+// sigmoid / swish: 1-D and 2-D stream sets at the default width.  d = 3: SolverSpherical's default FCNN(3,1,(32,32)) (solvers_spherical.py) -- diagonal (0b101001), Laplacian-merged and full Hessian.
 #ifndef NDQ_CFG_TABLE
 #define NDQ_CFG_TABLE(X)      \
   X(1, 0, 0, 2, 2, ACT_SIN, 1, 0)   \
@@ -37,7 +37,25 @@ namespace ndq {
   X(3, 1, 0, 2, 2, ACT_TANH, 1, 0)  \
   X(3, 1, 41, 2, 2, ACT_TANH, 1, 0) \
   X(3, 1, 41, 2, 2, ACT_TANH, 1, 1) \
-  X(3, 1, 63, 2, 2, ACT_TANH, 1, 0)
+  X(3, 1, 63, 2, 2, ACT_TANH, 1, 0)  \
+  X(1, 0, 0, 2, 2, ACT_SIGMOID, 1, 0) \
+  X(1, 1, 0, 2, 2, ACT_SIGMOID, 1, 0) \
+  X(1, 1, 1, 2, 2, ACT_SIGMOID, 1, 0) \
+  X(2, 0, 0, 2, 2, ACT_SIGMOID, 1, 0) \
+  X(2, 1, 0, 2, 2, ACT_SIGMOID, 1, 0) \
+  X(2, 1, 1, 2, 2, ACT_SIGMOID, 1, 0) \
+  X(2, 1, 5, 2, 2, ACT_SIGMOID, 1, 0) \
+  X(2, 1, 7, 2, 2, ACT_SIGMOID, 1, 0) \
+  X(2, 1, 5, 2, 2, ACT_SIGMOID, 1, 1) \
+  X(1, 0, 0, 2, 2, ACT_SWISH, 1, 0) \
+  X(1, 1, 0, 2, 2, ACT_SWISH, 1, 0) \
+  X(1, 1, 1, 2, 2, ACT_SWISH, 1, 0) \
+  X(2, 0, 0, 2, 2, ACT_SWISH, 1, 0) \
+  X(2, 1, 0, 2, 2, ACT_SWISH, 1, 0) \
+  X(2, 1, 1, 2, 2, ACT_SWISH, 1, 0) \
+  X(2, 1, 5, 2, 2, ACT_SWISH, 1, 0) \
+  X(2, 1, 7, 2, 2, ACT_SWISH, 1, 0) \
+  X(2, 1, 5, 2, 2, ACT_SWISH, 1, 1)
 #endif
 
 struct Entry {

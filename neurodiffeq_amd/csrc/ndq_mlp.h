@@ -110,7 +110,7 @@ struct Streams {
 
 // ------------------------------------------------------------------------------------------------ activations
 // state kept per hidden unit: t = sigma(z) and c (only where sigma' is not a function of t).
-enum { ACT_TANH = 0, ACT_SIN = 1 };
+enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3 };
 
 #ifndef NDQ_FAST_TANH
 #define NDQ_FAST_TANH 1
@@ -174,6 +174,28 @@ template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
   static __device__ __forceinline__ float s1(float, float c) { return c; }
   static __device__ __forceinline__ float s2(float t, float, float) { return -t; }
   static __device__ __forceinline__ float s3(float, float c, float) { return -c; }
+};
+
+__device__ __forceinline__ float sigmoid_fast(float z) {   // 1 / (1 + 2^(-z log2 e)); saturates cleanly to 0 / 1
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
+template <> struct Act<ACT_SIGMOID> {  // torch.nn.Sigmoid as FCNN(actv=nn.Sigmoid): everything is a polynomial in t
+  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { t = sigmoid_fast(z); c = 0.f; }
+  static __device__ __forceinline__ float s1(float t, float) { return t * (1.f - t); }
+  static __device__ __forceinline__ float s2(float t, float, float s1v) { return s1v * fmaf(-2.f, t, 1.f); }
+  static __device__ __forceinline__ float s3(float, float, float s1v) { return s1v * fmaf(-6.f, s1v, 1.f); }
+};
+// Swish with the default fixed beta = 1 (networks.py:155-175): f = z sigma(z).  State: t = f, c = sigma(z); since
+// z sigma = t the derivatives need no z:  f1 = c + t(1-c),  f2 = (1-c)(2c + t(1-2c)),  f3 = (1-c)(3c(1-2c) + t(1-6c+6c^2))
+template <> struct Act<ACT_SWISH> {
+  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { c = sigmoid_fast(z); t = z * c; }
+  static __device__ __forceinline__ float s1(float t, float c) { return fmaf(t, 1.f - c, c); }
+  static __device__ __forceinline__ float s2(float t, float c, float) {
+    return (1.f - c) * fmaf(t, fmaf(-2.f, c, 1.f), 2.f * c);
+  }
+  static __device__ __forceinline__ float s3(float t, float c, float) {
+    return (1.f - c) * fmaf(t, fmaf(6.f * c, c - 1.f, 1.f), 3.f * c * fmaf(-2.f, c, 1.f));
+  }
 };
 
 // ------------------------------------------------------------------------------------------------ config
@@ -323,7 +345,7 @@ __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast
 template <class C>
 struct LayerState {
   float t[C::NB][4];                 // sigma(z)
-  float c[C::NB][4];                 // cos(z) for sin; unused (dead) for tanh
+  float c[C::NB][4];                 // second state value: cos(z) for sin, sigma(z) for swish; unused (dead) otherwise
   f32x4 z[C::NS][C::NB];             // pre-activation derivative streams (index 0 unused: value is in t)
 };
 

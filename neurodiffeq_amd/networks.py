@@ -82,7 +82,8 @@ class FCNN(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------- kernel-side description
-_ACT_IDS = {nn.Tanh: _lib.NDQ_ACT_TANH, SinActv: _lib.NDQ_ACT_SIN}
+_ACT_IDS = {nn.Tanh: _lib.NDQ_ACT_TANH, SinActv: _lib.NDQ_ACT_SIN, nn.Sigmoid: _lib.NDQ_ACT_SIGMOID,
+            Swish: _lib.NDQ_ACT_SWISH}
 
 
 def describe(net):
@@ -100,6 +101,8 @@ def describe(net):
     act_types = {type(a) for a in acts}
     if len(act_types) != 1 or next(iter(act_types)) not in _ACT_IDS:
         return None
+    if any(isinstance(a, Swish) and (a.trainable or a.beta != 1.0) for a in acts):
+        return None          # the kernels carry Swish with its default fixed beta = 1 only
     hidden = linears[0].out_features
     if hidden % 16 or any(l.in_features != hidden or l.out_features != hidden for l in linears[1:-1]):
         return None

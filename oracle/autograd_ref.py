@@ -53,7 +53,14 @@ class Sin(nn.Module):
         return torch.sin(z)
 
 
-ACTIVATIONS = {"tanh": nn.Tanh, "sin": Sin}
+class SwishRef(nn.Module):
+    """x * sigmoid(beta x) with the default beta = 1 (networks.py:155-175)."""
+
+    def forward(self, x):
+        return x * torch.sigmoid(x)
+
+
+ACTIVATIONS = {"tanh": nn.Tanh, "sin": Sin, "sigmoid": nn.Sigmoid, "swish": SwishRef}
 
 
 def make_fcnn(n_in, n_out, hidden, act="tanh", dtype=torch.float32):

@@ -26,6 +26,15 @@ def act_derivs(name, z):
     if name == "sin":
         s, c = np.sin(z), np.cos(z)
         return s, c, -s, -c
+    if name in ("sigmoid", "swish"):
+        s = 1.0 / (1.0 + np.exp(-z))
+        d1 = s * (1 - s)
+        d2 = d1 * (1 - 2 * s)
+        d3 = d1 * (1 - 6 * d1)
+        if name == "sigmoid":
+            return s, d1, d2, d3
+        # Leibniz on z * s(z)  (Swish, beta = 1: networks.py:155-175)
+        return z * s, s + z * d1, 2 * d1 + z * d2, 3 * d2 + z * d3
     raise KeyError(name)
 
 

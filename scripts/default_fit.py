@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Wall time of solver.fit() in the reference's default configuration (README-style script: default networks, default
+generators -- 32 noisy points for training, 4 static validation batches per epoch).  usage: scripts/default_fit.py [epochs]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neurodiffeq_amd import diff  # noqa: E402
+from neurodiffeq_amd.conditions import IVP, DirichletBVP2D  # noqa: E402
+from neurodiffeq_amd.solvers import Solver1D, Solver2D  # noqa: E402
+
+epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+out = {}
+for fused in ("auto", "off"):
+    torch.manual_seed(0)
+    s = Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], t_min=0.0, t_max=2.0)
+    s.fused = fused
+    s.fit(20, tqdm_file=None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.fit(epochs, tqdm_file=None)
+    _ = s.metrics_history["valid_loss"][-1]
+    torch.cuda.synchronize()
+    out[f"ode_{fused}_us_per_epoch"] = round((time.perf_counter() - t0) / epochs * 1e6, 1)
+    out[f"ode_{fused}_final_valid_loss"] = s.metrics_history["valid_loss"][-1]
+    torch.manual_seed(0)
+    zero = lambda v: 0 * v
+    s = Solver2D(lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2)],
+                 [DirichletBVP2D(0, lambda y: torch.sin(3.14159265 * y), 1, zero, 0, zero, 1, zero)], xy_min=(0, 0), xy_max=(1, 1))
+    s.fused = fused
+    s.fit(20, tqdm_file=None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.fit(epochs // 2, tqdm_file=None)
+    _ = s.metrics_history["valid_loss"][-1]
+    torch.cuda.synchronize()
+    out[f"pde_{fused}_us_per_epoch"] = round((time.perf_counter() - t0) / (epochs // 2) * 1e6, 1)
+    out[f"pde_{fused}_final_valid_loss"] = s.metrics_history["valid_loss"][-1]
+print(json.dumps(out))

@@ -44,6 +44,11 @@ ARCH = {
                [(), (0,), (1,), (2,), (0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]),
     "s3first": ((3, 32, 32, 1), "tanh", 0, (3, 1, 0), [(), (0,), (1,), (2,)]),
     "s3val": ((3, 32, 32, 1), "tanh", 0, (3, 0, 0), [()]),
+    # sigmoid and Swish (beta = 1) activations
+    "sg2": ((2, 32, 32, 1), "sigmoid", 2, (2, 1, 7), [(), (0,), (1,), (0, 0), (0, 1), (1, 1)]),
+    "sw2lap": ((2, 32, 32, 1), "swish", 3, (2, 1, 5), [(), (0,), (1,), ("L", 0, 1)]),
+    "sw1": ((1, 32, 32, 1), "swish", 3, (1, 1, 1), [(), (0,), (0, 0)]),
+    "sg1": ((1, 32, 32, 1), "sigmoid", 2, (1, 1, 0), [(), (0,)]),
 }
 
 
@@ -338,7 +343,8 @@ def test_fused_closure_matches_oracle_at_size(name, size, mode):
 
 @pytest.mark.parametrize("mode", ["1k", "3k"])
 @pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide",
-                                  "stokes_like", "poisson3d", "hessian3d", "shell"])
+                                  "stokes_like", "poisson3d", "hessian3d", "shell", "swish_laplace", "sigmoid_mixed",
+                                  "swish_ode"])
 def test_zoo_closure_matches_autograd_oracle(name, mode):
     """Systems outside the BASELINE set (tests/zoo.py): second-order IVP, sin networks, mixed second derivatives, first
     order only, three coordinates (Laplacian-merged, diagonal and full Hessian stream sets), three networks."""

@@ -48,7 +48,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None):
         info = describe(net)
         dims = (info["d"],) + (info["hidden"],) * info["layers"] + (info["n_out"],)
         npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
-        dims_act.append((dims, "tanh" if info["act"] == 0 else "sin"))
+        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish")[info["act"]]))
         flats.append(np.asarray(params[off:off + npar], np.float64))
         off += npar
     # a ("L", a, b, ..) symbol is the Laplacian stream = sum of the pure second derivatives (a,a), (b,b), ..
@@ -104,7 +104,8 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
 # stream set the tracer must arrive at for each zoo system: per network (first, mask2, lap)
 ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tanh": [(1, 1, 0)], "helmholtz_xy": [(1, 7, 0)],
                "advection": [(1, 0, 0)], "heat_wide": [(1, 1, 0)], "stokes_like": [(1, 5, 1), (1, 5, 1), (1, 0, 0)],
-               "poisson3d": [(1, 41, 1)], "hessian3d": [(1, 63, 0)], "shell": [(1, 41, 0)]}
+               "poisson3d": [(1, 41, 1)], "hessian3d": [(1, 63, 0)], "shell": [(1, 41, 0)],
+               "swish_laplace": [(1, 5, 1)], "sigmoid_mixed": [(1, 7, 0)], "swish_ode": [(1, 1, 0), (1, 0, 0)]}
 
 
 @pytest.mark.parametrize("name", zoo.NAMES)

@@ -27,6 +27,13 @@ def act_derivs(act, z):
     if act == "tanh":
         t = np.tanh(z); s1 = 1 - t * t
         return t, s1, -2 * t * s1, -2 * s1 * (1 - 3 * t * t)
+    if act in ("sigmoid", "swish"):        # the kernel's closed forms in (t, c), csrc/ndq_mlp.h: Act<ACT_SIGMOID / ACT_SWISH>
+        c = 1.0 / (1.0 + np.exp(-z))
+        if act == "sigmoid":
+            s1 = c * (1 - c)
+            return c, s1, s1 * (1 - 2 * c), s1 * (1 - 6 * s1)
+        t = z * c
+        return t, c + t * (1 - c), (1 - c) * (2 * c + t * (1 - 2 * c)), (1 - c) * (3 * c * (1 - 2 * c) + t * (1 - 6 * c + 6 * c * c))
     s, c = np.sin(z), np.cos(z)
     return s, c, -s, -c
 

@@ -26,8 +26,9 @@ class System:
     def product(self):
         """(nets fp32, conditions, diff_eqs) on the neurodiffeq_amd API"""
         from neurodiffeq_amd import diff
-        from neurodiffeq_amd.networks import FCNN, SinActv
-        nets = [FCNN(i, o, hidden_units=h, actv=SinActv if a == "sin" else torch.nn.Tanh) for i, o, h, a in self.net_specs]
+        from neurodiffeq_amd.networks import FCNN, SinActv, Swish
+        actv = {"tanh": torch.nn.Tanh, "sin": SinActv, "sigmoid": torch.nn.Sigmoid, "swish": Swish}
+        nets = [FCNN(i, o, hidden_units=h, actv=actv[a]) for i, o, h, a in self.net_specs]
         return nets, self.conds(), self.pde(diff)
 
     def oracle(self, flat):
@@ -98,6 +99,23 @@ def build(name):
         conds = lambda: [C.NoCondition()] * 3
         raw = lambda net, x, y: net(_cat(x, y))
         return System(name, 2, [(2, 1, (32, 32), "tanh")] * 3, [(0.0, 1.0), (0.0, 1.0)], pde, conds, lambda D: [raw] * 3)
+    if name == "swish_laplace":       # Swish network (beta = 1) on the C2 problem: Laplacian stream + DirichletBVP2D
+        f0 = lambda y: torch.sin(PI * y)
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2)])
+        conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
+        return System(name, 2, [(2, 1, (32, 32), "swish")], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, zero)])
+    if name == "sigmoid_mixed":       # sigmoid network, full 2-D Hessian, nonlinear in u
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=2) - 2.0 * D(D(u, x), y) + 3.0 * D(u, y, order=2) + u * D(u, x)
+                                          - torch.cos(x + y)])
+        conds = lambda: [C.NoCondition()]
+        return System(name, 2, [(2, 1, (32, 32), "sigmoid")], [(-1.0, 1.0), (-1.0, 1.0)], pde, conds,
+                      lambda D: [lambda net, x, y: net(_cat(x, y))])
+    if name == "swish_ode":           # second-order ODE on a Swish network coupled to a first-order one on a sigmoid network
+        pde = lambda D: (lambda u, v, t: [D(u, t, order=2) + v * D(u, t) + u, D(v, t) - u * v + torch.sin(t)])
+        conds = lambda: [C.IVP(0.0, 1.0, u_0_prime=0.0), C.IVP(0.0, 0.5)]
+        enf = lambda D: [lambda net, t: 1.0 + t * 0.0 + (1 - torch.exp(-t)) ** 2 * net(t), _R().ivp(0.0, 0.5)]
+        return System(name, 1, [(1, 1, (32, 32), "swish"), (1, 1, (32, 32), "sigmoid")], [(0.0, 2.0)], pde, conds, enf)
     if name == "poisson3d":           # three coordinates, Laplacian -> one merged second-order stream
         pde = lambda D: (lambda u, x, y, z: [D(u, x, order=2) + D(u, y, order=2) + D(u, z, order=2)
                                              + torch.exp(-(x ** 2 + y ** 2 + z ** 2))])
@@ -130,7 +148,7 @@ def build(name):
 
 
 NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "poisson3d",
-         "hessian3d", "shell"]
+         "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode"]
 
 
 def spherical_solver_problem():
