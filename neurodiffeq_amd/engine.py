@@ -126,6 +126,7 @@ class FusedSystem:
             assert self.L.ndq_mlp_num_params(ctypes.byref(self.descs[k])) == fp.numel
         self._bufs = {}
         self._resident_cache = {}
+        self._static, self._static_seen = {}, {}
         self.loss_buf = torch.zeros(64, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------------------------------ buffers
@@ -193,6 +194,10 @@ class FusedSystem:
                 if len(self._resident_cache) < 64:
                     self._resident_cache[id(batch)] = (batch, b, b["coords_rows"])
                 return b, n
+        if batch[0].device.type != "cuda":
+            hit = self._static_batch(batch, lo, hi, n)
+            if hit is not None:
+                return hit, n
         b = self.buffers(n)
         b["coords"], b["coords_rows"] = b["coords_own"], None
         if batch[0].device.type == "cuda":
@@ -211,6 +216,32 @@ class FusedSystem:
             ev.record()
             b["pin_events"][k] = ev
         return b, n
+
+    def _static_batch(self, batch, lo, hi, n):
+        """Host batches that come back unchanged (static generators: 'equally-spaced' grids, StaticGenerator,
+        PredefinedGenerator -- the default validation sets) are uploaded once and then read in place.  Identity =
+        same storage, offset, length and torch version counter; the tensors of cached entries and of the last few
+        candidates are kept alive, so an address can never come back with different contents."""
+        key = tuple((c.untyped_storage().data_ptr(), c.storage_offset(), c.numel(), c._version) for c in batch) + (lo, hi)
+        hit = self._static.get(key)
+        if hit is not None:
+            b = self.buffers(n, ld=hit[1].shape[1])
+            b["coords"], b["coords_rows"] = hit[2][0], hit[2]
+            return b
+        if key in self._static_seen and len(self._static) < 16:      # second sighting: promote to a resident block
+            ld = _round_up(n, 64)
+            block = torch.zeros(self.n_coords, ld, dtype=torch.float32, device=self.device)
+            host = torch.stack([c.detach().reshape(-1)[lo:hi].to(torch.float32) for c in batch])
+            block[:, :n].copy_(host)
+            rows = [block[i] for i in range(self.n_coords)]
+            self._static[key] = (list(batch), block, rows)
+            b = self.buffers(n, ld=ld)
+            b["coords"], b["coords_rows"] = rows[0], rows
+            return b
+        self._static_seen[key] = list(batch)
+        while len(self._static_seen) > 8:
+            self._static_seen.pop(next(iter(self._static_seen)))
+        return None
 
     def _coord_ptr(self, b, row):
         if b["coords_rows"] is not None:

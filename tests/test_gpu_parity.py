@@ -393,6 +393,27 @@ def test_spherical_solver_with_default_network_runs_fused():
     assert torch.allclose(solver.get_solution()(r, th, ph).cpu(), torch.cos(th), atol=1e-6)      # inner boundary exact
 
 
+def test_static_host_batches_are_cached_and_invalidated():
+    """A host batch that comes back unchanged (static validation sets) is uploaded once and read in place; an
+    in-place change (torch version counter) or a new tensor is seen."""
+    cfg, system = _load_system("c2", 16)
+    torch.manual_seed(3)
+    x, y = torch.rand(256), torch.rand(256)
+
+    def loss_of(sysm, batch):
+        sysm.step(batch, train=False, slot=0)
+        return sysm.loss_buf[0].item()
+    first = [loss_of(system, [x, y]) for _ in range(4)]
+    assert len(system._static) == 1 and len(set(first)) == 1
+    other = [torch.rand(256), torch.rand(256)]                  # a different batch of the same size in between
+    l_other = loss_of(system, other)
+    assert loss_of(system, [x, y]) == first[0] and l_other != first[0]
+    x.mul_(0.5)                                                 # in-place edit: must be uploaded again
+    edited = loss_of(system, [x, y])
+    _, fresh = _load_system("c2", 16)
+    assert edited != first[0] and edited == loss_of(fresh, [x.clone(), y.clone()])
+
+
 def test_gradient_accumulation_and_validation_mode():
     """n_batches_train = 2 accumulates gradients before one step (solvers.py:360-419); a validation epoch leaves
     parameters and gradients untouched."""
