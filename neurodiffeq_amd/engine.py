@@ -217,12 +217,19 @@ class FusedSystem:
             b["pin_events"][k] = ev
         return b, n
 
+    @staticmethod
+    def static_key(batch):
+        """Identity of a host batch's contents (storage, offset, length, version counter); None for device batches."""
+        if batch[0].device.type == "cuda":
+            return None
+        return tuple((c.untyped_storage().data_ptr(), c.storage_offset(), c.numel(), c._version) for c in batch)
+
     def _static_batch(self, batch, lo, hi, n):
         """Host batches that come back unchanged (static generators: 'equally-spaced' grids, StaticGenerator,
         PredefinedGenerator -- the default validation sets) are uploaded once and then read in place.  Identity =
         same storage, offset, length and torch version counter; the tensors of cached entries and of the last few
         candidates are kept alive, so an address can never come back with different contents."""
-        key = tuple((c.untyped_storage().data_ptr(), c.storage_offset(), c.numel(), c._version) for c in batch) + (lo, hi)
+        key = self.static_key(batch) + (lo, hi)
         hit = self._static.get(key)
         if hit is not None:
             b = self.buffers(n, ld=hit[1].shape[1])

@@ -412,15 +412,21 @@ class BaseSolver(ABC):
         else:
             if system.loss_buf.numel() < nb:
                 system.loss_buf = torch.zeros(nb, dtype=torch.float32, device=self.device)
-            for batch_id in range(nb):
-                batch = first_batch if batch_id == 0 else self._generate_batch(key)
+            batches = [first_batch] + [self._generate_batch(key) for _ in range(nb - 1)]
+            if not train and nb > 1:
+                # a static validation set served nb times (the default: 4 x the same 'equally-spaced' grid) gives nb
+                # identical losses under unchanged parameters: evaluate it once, the mean is that value
+                k0 = system.static_key(batches[0])
+                if k0 is not None and all(system.static_key(b) == k0 for b in batches[1:]):
+                    batches = batches[:1]
+            for batch_id, batch in enumerate(batches):
                 n_all = batch[0].shape[0]
                 lo, hi = shard.bounds(n_all) if shard else (0, n_all)
                 system.step(batch, train=train, slot=batch_id, accumulate=(batch_id > 0),
                             n_global=shard.global_n(n_all) if shard else n_all, lo=lo, hi=hi)
             if shard:
-                shard.all_reduce(system, nb, train=train)
-            system.epoch_tail(key, nb, track_best, slots)
+                shard.all_reduce(system, len(batches), train=train)
+            system.epoch_tail(key, len(batches), track_best, slots)
         if train:
             for fp in system.flat:
                 if not fp.grads_attached():

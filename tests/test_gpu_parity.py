@@ -491,6 +491,30 @@ def test_native_fit_with_validation_matches_general_path(name):
     assert rel_l2(b1, b2) < 2e-5 and rel_l2(p1, p2) < 2e-5
 
 
+def test_default_configuration_fit_matches_general_path():
+    """The reference's default set-up (Solver1D: 32 noisy training points, the SAME 'equally-spaced' validation grid
+    served n_batches_valid = 4 times per epoch): the zero-sync path evaluates the static grid once per epoch and must
+    report what the general path reports after evaluating it four times."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.solvers import Solver1D
+
+    def run(native):
+        torch.manual_seed(0)
+        solver = Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], t_min=0.0, t_max=2.0,
+                          metrics=None if native else {"zero": lambda u, t: (u * 0).mean()})
+        solver.fused = "require"
+        solver.fit(30, tqdm_file=None)
+        h = solver.metrics_history
+        return solver, list(h["train_loss"]), list(h["valid_loss"]), solver.lowest_loss
+
+    s1, t1, v1, l1 = run(True)
+    s2, t2, v2, l2 = run(False)
+    assert getattr(s1._fused_sys, "_fast", None) is not None and getattr(s2._fused_sys, "_fast", None) is None
+    assert len(s1._fused_sys._static) == 1 and len(v1) == 30
+    assert np.allclose(t1, t2, rtol=3e-5) and np.allclose(v1, v2, rtol=3e-5) and abs(l1 - l2) <= 3e-5 * abs(l2)
+
+
 @pytest.mark.parametrize("name", ["c1", "c2", "c4"])
 def test_solution_and_residuals_on_forward_kernels(name):
     """solver.get_solution()(coords) and solver.get_residuals(coords) (solvers.py:606-646, 682-720) run on the
