@@ -26,6 +26,10 @@ def _ptr(t):
     return _c_vp(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or \
+    (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
+
 def _round_up(n, m):
     return (n + m - 1) // m * m
 
@@ -127,6 +131,7 @@ class FusedSystem:
         self._bufs = {}
         self._resident_cache = {}
         self._static, self._static_seen = {}, {}
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.loss_buf = torch.zeros(64, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------------------------------ buffers
@@ -217,6 +222,11 @@ class FusedSystem:
             b["pin_events"][k] = ev
         return b, n
 
+    def _stream(self):
+        """hipStream_t of torch's current stream on this device as a ctypes pointer (the raw getter is ~10x cheaper
+        than building a torch.cuda.Stream object, and this runs several times per epoch)."""
+        return _c_vp(_raw_stream(self._dev_index))
+
     @staticmethod
     def static_key(batch):
         """Identity of a host batch's contents (storage, offset, length, version counter); None for device batches."""
@@ -276,7 +286,7 @@ class FusedSystem:
         elements each) -> device tensor [n_funcs][n].  Replaces BaseSolution._compute_u's torch forward
         (solvers.py:682-725)."""
         b, n = self.upload([c.reshape(-1) for c in coords])
-        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = self._stream()
         self.forward(b, n, stream)
         self.pointwise(b, n, stream, False, n, want_funcs=True)
         return b["funcs"][:, :n]
@@ -285,7 +295,7 @@ class FusedSystem:
         """Residual columns r_e(coords) of the traced PDE system: device tensor [n_eq][n] (get_residuals,
         solvers.py:606-646, without building an autograd graph)."""
         b, n = self.upload([c.reshape(-1) for c in coords])
-        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = self._stream()
         self.forward(b, n, stream)
         self.pointwise(b, n, stream, False, n, want_resid=True)
         return b["resid"][:, :n]
@@ -358,7 +368,7 @@ class FusedSystem:
         snapshot of every network when ``track_best``, and -- training epochs -- the fused Adam update of every
         network (adam_slots[k] = FusedAdam.fast_slot(flat[k])).  No host synchronisation."""
         fs = self.fast_state()
-        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = self._stream()
         train = kind == "train"
         hist = fs["loss_hist"] if train else fs["valid_hist"]
         idx = fs["pending"] if train else fs["pending_valid"]
@@ -407,7 +417,7 @@ class FusedSystem:
         st.best_flat = fs["best_flat"][0].data_ptr() if track_best else None
         b1, b2 = group["betas"]
         st.lr, st.beta1, st.beta2, st.eps, st.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]
-        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = self._stream()
         coords = self._coord_ptr(b, 0)
         hist_index, parity = fs["pending"], fs["parity"]
         if dist is None:
@@ -445,7 +455,7 @@ class FusedSystem:
         residual lands in ``loss_buf[slot]`` and, when ``train``, parameter gradients in every ``FlatParams.grad``."""
         b, n = self.upload(batch, lo, hi)
         n_global = n if n_global is None else n_global
-        stream = _c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = self._stream()
         if self.fusedk is not None:
             self.fused_closure(b, n, stream, train, n_global, slot, accumulate, want_funcs, want_resid)
             return b, n

@@ -416,9 +416,12 @@ class BaseSolver(ABC):
             if not train and nb > 1:
                 # a static validation set served nb times (the default: 4 x the same 'equally-spaced' grid) gives nb
                 # identical losses under unchanged parameters: evaluate it once, the mean is that value
-                k0 = system.static_key(batches[0])
-                if k0 is not None and all(system.static_key(b) == k0 for b in batches[1:]):
-                    batches = batches[:1]
+                if all(b is batches[0] for b in batches[1:]) and batches[0][0].device.type != "cuda":
+                    batches = batches[:1]          # SamplerGenerator served the same unchanged columns again
+                else:
+                    k0 = system.static_key(batches[0])
+                    if k0 is not None and all(system.static_key(b) == k0 for b in batches[1:]):
+                        batches = batches[:1]
             for batch_id, batch in enumerate(batches):
                 n_all = batch[0].shape[0]
                 lo, hi = shard.bounds(n_all) if shard else (0, n_all)
