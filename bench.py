@@ -226,6 +226,9 @@ def main():
                                    "run_train_epoch() with n_batches_train=1, n_batches_valid=0",
                        "points_per_gpu": N_POINTS, "global_batch": N_POINTS * world,
                        "parallelism": f"dp{world} (shard-by-batch, one all-reduce of [P+1] fp32 per step)",
+                       "allreduce": ("none (single process)" if not use_dist else
+                                     "RCCL, enqueued by the native step on the compute stream"
+                                     if solver.dist.direct("cuda") is not None else "torch.distributed (RCCL)"),
                        "inputs": "pre-sampled in the reference's RNG order, resident in HBM"},
             "final_loss": solver.metrics_history["train_loss"][-1],
         }
@@ -301,6 +304,7 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
+        solver.dist.close()
         dist.destroy_process_group()
 
 

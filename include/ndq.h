@@ -110,8 +110,15 @@ typedef int (*ndq_fused_launch_fn)(const float* coords, int ldc, int n, const fl
                                    float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,
                                    void* stream);
 
+/* Sum-all-reduce of `count` fp32 values in place over the data-parallel ranks, enqueued on `stream`: the signature of
+ * ncclAllReduce (RCCL) with dtype = ncclFloat32 (7) and op = ncclSum (0).  libndq.so does not link RCCL; the host
+ * passes the function and its communicator in (parallel.py). */
+typedef int (*ndq_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op, void* comm,
+                                void* stream);
+
 /* Everything one training epoch of a single-network system with n_batches_train = 1 needs, prepared once by the host:
- * closure kernel -> ndq_reduce_grad_loss -> ndq_epoch_tail, issued back to back on `stream` by ONE native call. */
+ * closure kernel -> ndq_reduce_grad_loss [-> all-reduce of grad|loss] -> ndq_epoch_tail, issued back to back on
+ * `stream` by ONE native call. */
 typedef struct ndq_fused_step {
   ndq_fused_launch_fn launch;
   int n, ldc, ldj, blocks, n_params;
@@ -127,6 +134,8 @@ typedef struct ndq_fused_step {
   float* loss_hist;           /* ring of epoch losses */
   float* best_loss;           /* [2] */
   float* best_flat;           /* [P] */
+  ndq_allreduce_fn allreduce; /* data parallel: sums grad[0..P) and the loss slot, which must be grad[P] (one message) */
+  void* comm;                 /* ncclComm_t for `allreduce` */
 } ndq_fused_step;
 int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_step, int hist_index, int parity,
                        void* stream);

@@ -392,6 +392,18 @@ int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_st
     return ndq_reduce_grad_loss(s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks,
                                 s->loss_slot, s->seed, stream);
   if (adam_step <= 0 || hist_index < 0 || (parity != 0 && parity != 1) || !s->loss_hist || !s->best_loss) return NDQ_EINVAL;
+  if (s->allreduce) {
+    // data parallel: local second-stage sums -> ONE all-reduce of [grad | loss] -> tail on the reduced vector
+    if (s->loss_slot != s->grad + s->n_params) return NDQ_EINVAL;
+    rc = ndq_reduce_grad_loss(s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks, s->loss_slot,
+                              s->seed, stream);
+    if (rc) return rc;
+    rc = s->allreduce(s->grad, s->grad, (size_t)s->n_params + 1, /*ncclFloat32*/ 7, /*ncclSum*/ 0, s->comm, stream);
+    if (rc) return 1000 + rc;   // ncclResult_t, offset so that it cannot be taken for a hipError_t
+    return ndq_epoch_tail(s->params, s->grad, s->adam_m, s->adam_v, s->n_params, s->lr, s->beta1, s->beta2, s->eps,
+                          s->weight_decay, adam_step, s->loss_slot, 1, s->loss_hist, hist_index, s->best_loss, parity,
+                          s->best_flat, 1, stream);
+  }
   ReduceTailArgs a;
   a.r = Reduce2Args{s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks, s->loss_slot, s->seed};
   a.t.p = s->params; a.t.g = s->grad; a.t.m = s->adam_m; a.t.v = s->adam_v; a.t.len = s->n_params;

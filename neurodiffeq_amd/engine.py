@@ -420,12 +420,17 @@ class FusedSystem:
         stream = self._stream()
         coords = self._coord_ptr(b, 0)
         hist_index, parity = fs["pending"], fs["parity"]
-        if dist is None:
+        direct = dist.direct(self.device) if dist is not None else None
+        if dist is None or direct is not None:
+            # one native call; with data parallelism the RCCL all-reduce of [grad | loss] is enqueued by it, on the
+            # same stream, between the local sums and the tail
             st.adam_m, st.adam_v = m.data_ptr(), v.data_ptr()
+            st.allreduce, st.comm = direct if direct is not None else (None, None)
             rc = self.L.ndq_fused_step_run(ctypes.byref(st), coords, step, hist_index, parity, stream)
             _lib.check(rc, "ndq_fused_step_run")
         else:
             st.adam_m = st.adam_v = None
+            st.allreduce = st.comm = None
             rc = self.L.ndq_fused_step_run(ctypes.byref(st), coords, step, hist_index, parity, stream)
             _lib.check(rc, "ndq_fused_step_run")
             dist.all_reduce_flat(fp.grad_loss)
