@@ -253,30 +253,57 @@ struct ReduceTailArgs {
   TailArgs t;
 };
 __global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) {
+  // Latency-bound (19 workgroups at C2): every global load -- loss partials, this thread's rows of the gradient
+  // partials, the parameter / moment values it will update -- is issued before the first reduction step, and there is
+  // ONE barrier.  Summation orders are fixed (per-thread chains, then LDS slots added in index order).
   __shared__ float sm[16 * 64];
-  __shared__ float sloss;
-  const float ls = block_sum_1024(a.r.lpart, a.r.nlparts, sm);
-  if (threadIdx.x == 0) sloss = ls * a.r.lscale;
-  __syncthreads();
-  const float loss = sloss;
-  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  __shared__ float smw[16];
+  const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;
   const int i = blockIdx.x * 64 + c;
-  const float g = column_sum_1024(a.r.part, a.r.nparts, a.r.len, i, rg, sm);
+  const bool col = i < a.r.len;
+  float lp = 0.f;
+  for (int r = tid; r < a.r.nlparts; r += 1024) lp += a.r.lpart[r];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col) {
+    const float* __restrict__ part = a.r.part;
+    const int len = a.r.len, nparts = a.r.nparts;
+    int r = rg;
+    for (; r + 48 < nparts; r += 64) {
+      s0 += part[(size_t)r * len + i];
+      s1 += part[(size_t)(r + 16) * len + i];
+      s2 += part[(size_t)(r + 32) * len + i];
+      s3 += part[(size_t)(r + 48) * len + i];
+    }
+    for (; r < nparts; r += 16) s0 += part[(size_t)r * len + i];
+  }
+  const bool upd = (rg == 0) && col;
+  float pi = 0.f, m0 = 0.f, v0 = 0.f;
+  if (upd) { pi = a.t.p[i]; m0 = a.t.m[i]; v0 = a.t.v[i]; }
   const float best = a.t.best_loss[a.t.parity];
+  for (int off = 32; off > 0; off >>= 1) lp += __shfl_down(lp, off);
+  if (c == 0) smw[rg] = lp;
+  sm[rg * 64 + c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  float loss = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) loss += smw[w];
+  loss *= a.r.lscale;
   const bool better = (a.t.best_flat != nullptr) && (loss < best);
-  if (rg == 0 && i < a.r.len) {
+  if (upd) {
+    float g = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g += sm[k * 64 + c];
     a.r.out[i] = g;
-    const float pi = a.t.p[i];
     if (better) a.t.best_flat[i] = pi;
     float gi = g;
     if (a.t.wd != 0.f) gi = fmaf(a.t.wd, pi, gi);
-    const float mi = fmaf(a.t.b1, a.t.m[i], (1.f - a.t.b1) * gi);
-    const float vi = fmaf(a.t.b2, a.t.v[i], (1.f - a.t.b2) * gi * gi);
+    const float mi = fmaf(a.t.b1, m0, (1.f - a.t.b1) * gi);
+    const float vi = fmaf(a.t.b2, v0, (1.f - a.t.b2) * gi * gi);
     a.t.m[i] = mi;
     a.t.v[i] = vi;
     a.t.p[i] = pi - (a.t.lr / a.t.bc1) * (mi / (sqrtf(vi) / a.t.bc2s + a.t.eps));
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && tid == 0) {
     *a.r.lout = loss;
     a.t.loss_hist[a.t.hist_index] = loss;
     a.t.best_loss[a.t.parity ^ 1] = better ? loss : best;
