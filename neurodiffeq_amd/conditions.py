@@ -107,6 +107,77 @@ class IVP(BaseCondition):
         return self.u_0 + (t - self.t_0) * self.u_0_prime + (decay ** 2) * output_tensor
 
 
+class _BundleConditionMixin:
+    """Conditions whose parameters (t_0, u_0, ...) may be *inputs* sampled by the generator instead of constants
+    (conditions.py:78-135): ``bundle_param_lookup`` maps a parameter name to its position among the extra coordinates
+    ``theta`` handed to ``parameterize(output, t, *theta)``."""
+
+    def __init__(self, bundle_param_lookup=None, allowed_params=None):
+        self.bundle_param_lookup = bundle_param_lookup or {}
+        if isinstance(allowed_params, str):
+            allowed_params = set(allowed_params)
+        if allowed_params:
+            illegal = set(self.bundle_param_lookup) - set(allowed_params)
+            if illegal:
+                raise ValueError(f"The following parameter(s) are not allowed in `bundle_parameters_lookup`: {illegal}.\n"
+                                 f"Supported parameter name(s) are: {allowed_params}.")
+
+    def _get_parameter(self, param_name, thetas, override_name=None):
+        if param_name in self.bundle_param_lookup:
+            return thetas[self.bundle_param_lookup[param_name]]
+        return getattr(self, override_name or param_name)
+
+
+def _bundle_kwargs(kw, names):
+    """deprecated keyword aliases of the bundle conditions (conditions.py:293, 365)"""
+    out = {}
+    for old, new_name in names.items():
+        if old in kw:
+            warnings.warn(f"`{old}` is deprecated; use `{new_name}`", FutureWarning)
+            out[new_name] = kw.pop(old)
+    if kw:
+        raise TypeError(f"unexpected arguments {list(kw)}")
+    return out
+
+
+class BundleIVP(BaseCondition, _BundleConditionMixin):
+    """IVP whose t_0 / u_0 / u_0' may be bundle inputs (conditions.py:270-345)."""
+
+    def __init__(self, t_0=None, u_0=None, u_0_prime=None, bundle_param_lookup=None, **deprecated):
+        alias = _bundle_kwargs(deprecated, {"x_0": "u_0", "x_0_prime": "u_0_prime", "bundle_conditions": "bundle_param_lookup"})
+        u_0, u_0_prime = alias.get("u_0", u_0), alias.get("u_0_prime", u_0_prime)
+        bundle_param_lookup = alias.get("bundle_param_lookup", bundle_param_lookup)
+        BaseCondition.__init__(self)
+        _BundleConditionMixin.__init__(self, bundle_param_lookup, allowed_params=["t_0", "u_0", "u_0_prime"])
+        self.t_0, self.u_0, self.u_0_prime = t_0, u_0, u_0_prime
+
+    def parameterize(self, output_tensor, t, *theta):
+        t_0 = self._get_parameter("t_0", theta)
+        u_0 = self._get_parameter("u_0", theta)
+        u_0_prime = self._get_parameter("u_0_prime", theta)
+        decay = 1 - _exp(-t + t_0)
+        if u_0_prime is None:
+            return u_0 + decay * output_tensor
+        return u_0 + (t - t_0) * u_0_prime + (decay ** 2) * output_tensor
+
+
+class BundleDirichletBVP(BaseCondition, _BundleConditionMixin):
+    """Two-point Dirichlet condition whose ends / end values may be bundle inputs (conditions.py:348-395)."""
+
+    def __init__(self, t_0, u_0, t_1, u_1, bundle_param_lookup=None, **deprecated):
+        alias = _bundle_kwargs(deprecated, {"bundle_conditions": "bundle_param_lookup"})
+        bundle_param_lookup = alias.get("bundle_param_lookup", bundle_param_lookup)
+        BaseCondition.__init__(self)
+        _BundleConditionMixin.__init__(self, bundle_param_lookup, allowed_params=["t_0", "u_0", "t_1", "u_1"])
+        self.t_0, self.u_0, self.t_1, self.u_1 = t_0, u_0, t_1, u_1
+
+    def parameterize(self, output_tensor, t, *theta):
+        u_0, u_1 = self._get_parameter("u_0", theta), self._get_parameter("u_1", theta)
+        t_0, t_1 = self._get_parameter("t_0", theta), self._get_parameter("t_1", theta)
+        s = (t - t_0) / (t_1 - t_0)
+        return u_0 * (1 - s) + u_1 * s + (1 - _exp((1 - s) * s)) * output_tensor
+
+
 class DirichletBVP(BaseCondition):
     """u(t0) = u0, u(t1) = u1  (conditions.py:398-435)."""
 

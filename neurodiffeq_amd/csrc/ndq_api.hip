@@ -35,6 +35,7 @@ namespace ndq {
   X(2, 1, 5, 4, 3, ACT_TANH, 1, 1)  \
   X(3, 0, 0, 2, 2, ACT_TANH, 1, 0)  \
   X(3, 1, 0, 2, 2, ACT_TANH, 1, 0)  \
+  X(3, 1, 1, 2, 2, ACT_TANH, 1, 0)  \
   X(3, 1, 41, 2, 2, ACT_TANH, 1, 0) \
   X(3, 1, 41, 2, 2, ACT_TANH, 1, 1) \
   X(3, 1, 63, 2, 2, ACT_TANH, 1, 0)  \

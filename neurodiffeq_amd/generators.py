@@ -66,6 +66,10 @@ class BaseGenerator:
         self.check_generator(other)
         return EnsembleGenerator(self, other)
 
+    def __xor__(self, other):
+        self.check_generator(other)
+        return MeshGenerator(self, other)
+
     def _internal_vars(self):
         return dict(size=self.size)
 
@@ -264,6 +268,32 @@ class EnsembleGenerator(BaseGenerator):
             ex = g.get_examples()
             out += (ex,) if isinstance(ex, torch.Tensor) else tuple(ex)
         return out[0] if len(out) == 1 else out
+
+
+class MeshGenerator(BaseGenerator):
+    """``g1 ^ g2``: ij-meshgrid of the sub-generators' samples, flattened (generators.py:848-901); nested meshes are
+    flattened into one (``(g1 ^ g2) ^ g3 == MeshGenerator(g1, g2, g3)``)."""
+
+    def __init__(self, *generators):
+        super().__init__()
+        self.generators = []
+        for g in generators:
+            self.generators += list(g.generators) if isinstance(g, MeshGenerator) else [g]
+        self.size = int(np.prod([g.size for g in self.generators]))
+
+    def get_examples(self):
+        parts = ()
+        for g in self.generators:
+            ex = g.get_examples()
+            parts += (ex,) if isinstance(ex, torch.Tensor) else tuple(ex)
+        if len(parts) == 1:
+            return parts[0]
+        return tuple(m.flatten() for m in torch.meshgrid(*parts, indexing="ij"))
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(generators=self.generators)
+        return d
 
 
 class StaticGenerator(BaseGenerator):

@@ -798,6 +798,61 @@ class Solver1D(BaseSolver):
         return d
 
 
+class BundleSolution1D(GenericSolution):
+    pass
+
+
+class BundleSolver1D(BaseSolver):
+    """A bundle of ODE solutions: the networks take ``(t, *theta)`` where ``theta`` are equation parameters and / or
+    condition parameters sampled next to ``t`` (solvers.py:1189-1420).  ``eq_param_index`` selects which of the bundle
+    inputs the ODE callable receives after ``(*funcs, t)``.  On the fused path the extra inputs are ordinary input
+    coordinates of the network whose derivative streams are simply not requested."""
+
+    def __init__(self, ode_system, conditions, t_min=None, t_max=None, theta_min=None, theta_max=None,
+                 eq_param_index=(), nets=None, train_generator=None, valid_generator=None, analytic_solutions=None,
+                 optimizer=None, loss_fn=None, n_batches_train=1, n_batches_valid=4, metrics=None, n_output_units=1,
+                 batch_size=None, shuffle=None):
+        if (train_generator is None or valid_generator is None) and (t_min is None or t_max is None):
+            raise ValueError(f"Either generator is not provided, t_min and t_max should be both provided: \n"
+                             f"got t_min={t_min}, t_max={t_max}, train_generator={train_generator}, "
+                             f"valid_generator={valid_generator}")
+        theta_min = (theta_min,) if isinstance(theta_min, (float, int)) else tuple(theta_min or ())
+        theta_max = (theta_max,) if isinstance(theta_max, (float, int)) else tuple(theta_max or ())
+        if len(theta_min) != len(theta_max):
+            raise ValueError(f"length of theta_min and theta_max must be equal, got {len(theta_min)} != {len(theta_max)}")
+        r_min, r_max = (t_min,) + theta_min, (t_max,) + theta_max
+        n_input_units = len(r_min)
+        if train_generator is None:
+            train_generator = Generator1D(32, t_min=t_min, t_max=t_max, method="equally-spaced-noisy")
+            for lo, hi in zip(theta_min, theta_max):
+                train_generator ^= Generator1D(32, t_min=lo, t_max=hi, method="equally-spaced-noisy")
+        if valid_generator is None:
+            valid_generator = Generator1D(32, t_min=t_min, t_max=t_max, method="equally-spaced")
+            for lo, hi in zip(theta_min, theta_max):
+                valid_generator ^= Generator1D(32, t_min=lo, t_max=hi, method="equally-spaced")
+        self.r_min, self.r_max = r_min, r_max
+        n_funcs, n_coords = len(conditions), 1
+        picked = tuple(n_funcs + n_coords + idx for idx in eq_param_index)
+        self.eq_param_index = picked
+
+        def bundle_eqs(*variables):
+            return ode_system(*variables[:n_funcs + n_coords], *(variables[i] for i in picked))
+
+        super().__init__(diff_eqs=bundle_eqs, conditions=conditions, nets=nets, train_generator=train_generator,
+                         valid_generator=valid_generator, analytic_solutions=analytic_solutions, optimizer=optimizer,
+                         loss_fn=loss_fn, n_batches_train=n_batches_train, n_batches_valid=n_batches_valid,
+                         metrics=metrics, n_input_units=n_input_units, n_output_units=n_output_units, shuffle=shuffle,
+                         batch_size=batch_size)
+
+    def get_solution(self, copy=True, best=True):
+        return self._solution(BundleSolution1D, copy, best)
+
+    def _get_internal_variables(self):
+        d = super()._get_internal_variables()
+        d.update(r_min=self.r_min, r_max=self.r_max, eq_param_index=self.eq_param_index)
+        return d
+
+
 class Solver2D(BaseSolver):
     """PDE systems in two independent variables (solvers.py:1427-1593)."""
 

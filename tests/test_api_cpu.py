@@ -12,13 +12,13 @@ import torch.nn as nn
 from neurodiffeq_amd import diff, safe_diff, unsafe_diff
 from neurodiffeq_amd import operators as ops
 from neurodiffeq_amd.conditions import (IVP, DirichletBVP, DirichletBVP2D, IBVP1D, NoCondition, EnsembleCondition,
-                                        DirichletBVPSpherical, DirichletBVPSphericalBasis)
+                                        DirichletBVPSpherical, DirichletBVPSphericalBasis, BundleIVP, BundleDirichletBVP)
 from neurodiffeq_amd.function_basis import RealSphericalHarmonics, HarmonicsLaplacian
 from neurodiffeq_amd.generators import (Generator1D, Generator2D, Generator3D, GeneratorSpherical, ConcatGenerator,
                                         EnsembleGenerator, StaticGenerator, PredefinedGenerator, SamplerGenerator)
 from neurodiffeq_amd.losses import _losses
 from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx
-from neurodiffeq_amd.solvers import Solver1D, Solver2D, SolverSpherical
+from neurodiffeq_amd.solvers import Solver1D, Solver2D, SolverSpherical, BundleSolver1D
 
 F64 = torch.float64
 
@@ -166,6 +166,42 @@ def test_ensemble_and_spherical_conditions():
     assert torch.allclose(cb.enforce(netr, torch.full((4, 1), 2.0, dtype=F64)), R1.expand(4, 9))
     with pytest.raises(ValueError):
         DirichletBVPSphericalBasis(0.5, R0, r_1=2.0)
+
+
+def test_bundle_conditions_and_solver():
+    """tests/test_conditions.py:165-260 and test_solvers.py (bundle) of the reference, re-stated."""
+    torch.manual_seed(5)
+    net = FCNN(3, 1).double()
+    t0 = torch.zeros(9, 1, dtype=F64, requires_grad=True)
+    u0, v0 = torch.rand(9, 1, dtype=F64), torch.rand(9, 1, dtype=F64)
+    c = BundleIVP(t_0=0.0, bundle_param_lookup={"u_0": 0, "u_0_prime": 1})
+    u = c.enforce(net, t0, u0, v0)
+    assert torch.allclose(u, u0) and torch.allclose(diff(u, t0), v0)
+    c = BundleIVP(u_0=1.5, bundle_param_lookup={"t_0": 1})             # t_0 itself sampled (second bundle input)
+    ts = torch.rand(9, 1, dtype=F64)
+    assert torch.allclose(c.enforce(net, ts, u0, ts), torch.full_like(ts, 1.5))
+    b = BundleDirichletBVP(0.0, None, 2.0, -1.0, bundle_param_lookup={"u_0": 0})
+    net2 = FCNN(2, 1).double()
+    assert torch.allclose(b.enforce(net2, torch.zeros_like(u0), u0), u0)
+    assert torch.allclose(b.enforce(net2, torch.full_like(u0, 2.0), u0), torch.full_like(u0, -1.0))
+    with pytest.raises(ValueError):
+        BundleIVP(0.0, 1.0, bundle_param_lookup={"bogus": 0})
+    with pytest.warns(FutureWarning):
+        BundleIVP(0.0, x_0=1.0)
+    mesh = Generator1D(4) ^ Generator1D(5) ^ Generator1D(6)
+    assert mesh.size == 120 and len(mesh.generators) == 3 and all(x.shape == (120,) for x in mesh.get_examples())
+    s = BundleSolver1D(lambda u, t, lam: [diff(u, t) + lam * u], [BundleIVP(t_0=0.0, bundle_param_lookup={"u_0": 0})],
+                       t_min=0.0, t_max=1.0, theta_min=(0.5, 0.5), theta_max=(2.0, 2.0), eq_param_index=(1,), n_batches_valid=1)
+    assert s.generator["train"].size == 32 ** 3 and s.nets[0].NN[0].in_features == 3
+    s.generator["train"] = SamplerGenerator(Generator1D(8) ^ Generator1D(4, 0.5, 2.0) ^ Generator1D(4, 0.5, 2.0))
+    s.generator["valid"] = SamplerGenerator(Generator1D(8) ^ Generator1D(4, 0.5, 2.0) ^ Generator1D(4, 0.5, 2.0))
+    s.fit(2, tqdm_file=None)
+    assert len(s.metrics_history["train_loss"]) == 2
+    sol = s.get_solution()(torch.zeros(5), torch.linspace(0.5, 2, 5), torch.ones(5))
+    assert torch.allclose(sol.cpu(), torch.linspace(0.5, 2, 5), atol=1e-6)
+    assert set(s.get_internals(["r_min", "eq_param_index"], return_type="dict")) == {"r_min", "eq_param_index"}
+    with pytest.raises(ValueError):
+        BundleSolver1D(lambda u, t: [u], [IVP(0, 1)], t_min=0, t_max=1, theta_min=(0,), theta_max=())
 
 
 # ----------------------------------------------------------------------------------------------- harmonics

@@ -344,7 +344,7 @@ def test_fused_closure_matches_oracle_at_size(name, size, mode):
 @pytest.mark.parametrize("mode", ["1k", "3k"])
 @pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide",
                                   "stokes_like", "poisson3d", "hessian3d", "shell", "swish_laplace", "sigmoid_mixed",
-                                  "swish_ode"])
+                                  "swish_ode", "bundle_decay", "bundle_bvp"])
 def test_zoo_closure_matches_autograd_oracle(name, mode):
     """Systems outside the BASELINE set (tests/zoo.py): second-order IVP, sin networks, mixed second derivatives, first
     order only, three coordinates (Laplacian-merged, diagonal and full Hessian stream sets), three networks."""
@@ -412,6 +412,32 @@ def test_static_host_batches_are_cached_and_invalidated():
     edited = loss_of(system, [x, y])
     _, fresh = _load_system("c2", 16)
     assert edited != first[0] and edited == loss_of(fresh, [x.clone(), y.clone()])
+
+
+def test_bundle_solver_trains_fused_and_matches_autograd_path():
+    """BundleSolver1D (solvers.py:1189-1420): bundle inputs are extra network coordinates without derivative streams.
+    The fused zero-sync fit and the reference's autograd closure (fused='off', same GPU) walk the same trajectory."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import BundleIVP
+    from neurodiffeq_amd.solvers import BundleSolver1D
+
+    def run(mode):
+        torch.manual_seed(0)
+        solver = BundleSolver1D(lambda u, t, lam: [diff(u, t) + lam * u],
+                                [BundleIVP(t_0=0.0, bundle_param_lookup={"u_0": 0})], t_min=0.0, t_max=1.0,
+                                theta_min=(0.5, 0.5), theta_max=(2.0, 2.0), eq_param_index=(1,), n_batches_valid=1)
+        solver.fused = mode
+        solver.fit(40, tqdm_file=None)
+        return solver
+
+    a, b = run("require"), run("off")
+    assert a.fused_active and not b.fused_active
+    ha, hb = a.metrics_history, b.metrics_history
+    assert np.allclose(ha["train_loss"], hb["train_loss"], rtol=2e-4) and np.allclose(ha["valid_loss"], hb["valid_loss"], rtol=2e-4)
+    t, u0, lam = torch.rand(50), 0.5 + 1.5 * torch.rand(50), 0.5 + 1.5 * torch.rand(50)
+    ua, ub = a.get_solution()(t, u0, lam).cpu(), b.get_solution()(t, u0, lam).cpu()
+    assert torch.allclose(ua, ub, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(a.get_solution()(torch.zeros(50), u0, lam).cpu(), u0, atol=1e-6)        # u(0; u0, lam) = u0
 
 
 def test_gradient_accumulation_and_validation_mode():

@@ -105,7 +105,8 @@ def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
 ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tanh": [(1, 1, 0)], "helmholtz_xy": [(1, 7, 0)],
                "advection": [(1, 0, 0)], "heat_wide": [(1, 1, 0)], "stokes_like": [(1, 5, 1), (1, 5, 1), (1, 0, 0)],
                "poisson3d": [(1, 41, 1)], "hessian3d": [(1, 63, 0)], "shell": [(1, 41, 0)],
-               "swish_laplace": [(1, 5, 1)], "sigmoid_mixed": [(1, 7, 0)], "swish_ode": [(1, 1, 0), (1, 0, 0)]}
+               "swish_laplace": [(1, 5, 1)], "sigmoid_mixed": [(1, 7, 0)], "swish_ode": [(1, 1, 0), (1, 0, 0)],
+               "bundle_decay": [(1, 0, 0)], "bundle_bvp": [(1, 1, 0)]}
 
 
 @pytest.mark.parametrize("name", zoo.NAMES)

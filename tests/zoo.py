@@ -116,6 +116,19 @@ def build(name):
         conds = lambda: [C.IVP(0.0, 1.0, u_0_prime=0.0), C.IVP(0.0, 0.5)]
         enf = lambda D: [lambda net, t: 1.0 + t * 0.0 + (1 - torch.exp(-t)) ** 2 * net(t), _R().ivp(0.0, 0.5)]
         return System(name, 1, [(1, 1, (32, 32), "swish"), (1, 1, (32, 32), "sigmoid")], [(0.0, 2.0)], pde, conds, enf)
+    if name == "bundle_decay":        # bundle of IVPs: u' + lam u = 0, u(0) = u0 with (u0, lam) as extra network inputs
+        pde = lambda D: (lambda u, t, u0, lam: [D(u, t) + lam * u])
+        conds = lambda: [C.BundleIVP(t_0=0.0, bundle_param_lookup={"u_0": 0})]
+        enf = lambda D: [lambda net, t, u0, lam: u0 + (1 - torch.exp(-t)) * net(_cat(t, u0, lam))]
+        return System(name, 3, [(3, 1, (32, 32), "tanh")], [(0.0, 1.0), (0.5, 2.0), (0.5, 2.0)], pde, conds, enf)
+    if name == "bundle_bvp":          # bundle of two-point problems: u'' + u = 0, u(0) = 0, u(1) = u1 sampled
+        pde = lambda D: (lambda u, t, u1: [D(u, t, order=2) + u])
+        conds = lambda: [C.BundleDirichletBVP(0.0, 0.0, 1.0, None, bundle_param_lookup={"u_1": 0})]
+
+        def e(net, t, u1):
+            s = (t - 0.0) / (1.0 - 0.0)
+            return 0.0 * (1 - s) + u1 * s + (1 - torch.exp((1 - s) * s)) * net(_cat(t, u1))
+        return System(name, 2, [(2, 1, (32, 32), "tanh")], [(0.0, 1.0), (-1.0, 1.0)], pde, conds, lambda D: [e])
     if name == "poisson3d":           # three coordinates, Laplacian -> one merged second-order stream
         pde = lambda D: (lambda u, x, y, z: [D(u, x, order=2) + D(u, y, order=2) + D(u, z, order=2)
                                              + torch.exp(-(x ** 2 + y ** 2 + z ** 2))])
@@ -148,7 +161,7 @@ def build(name):
 
 
 NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "poisson3d",
-         "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode"]
+         "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp"]
 
 
 def spherical_solver_problem():
