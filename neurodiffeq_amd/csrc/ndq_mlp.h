@@ -126,22 +126,17 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3 };
 #ifndef NDQ_BF16X3
 #define NDQ_BF16X3 1
 #endif
-// Weight gradients on the matrix core as well (weight_grad_mm): implemented, measured, REJECTED -- default off.
-// dW = sum over points of zbar * h cancels heavily (|sum| << sum |terms|), and the bf16 matrix core's internal fp32
-// accumulation of its 32 products is visibly less precise than an fmaf chain: with real PDE adjoints the gradient came
-// out 9e-5 off (rel-L2, C2 closure) although every factor was an exact bf16x3 split, versus 2e-7 with the exact-f32
-// MFMA.  The per-point forward / hbar GEMMs do not accumulate across points and stay at fp32-class error (4e-7).
-#ifndef NDQ_DW_MM
-#define NDQ_DW_MM 0
-#endif
+// The weight gradients stay on the exact-f32 MFMA: a bf16x3 variant (fragments transposed by MFMAs against 0/1
+// selection operands, six split products) was implemented, measured and REJECTED.  dW = sum over points of zbar * h
+// cancels heavily (|sum| << sum |terms|) and the bf16 matrix core's internal fp32 accumulation of its 32 products is
+// visibly less precise than an fmaf chain: with real PDE adjoints the gradient came out 9e-5 off (rel-L2, C2 closure)
+// although every factor was an exact bf16x3 split, versus 2e-7 with the f32 MFMA.  The per-point forward / hbar
+// GEMMs do not accumulate across points and stay at fp32-class error (4e-7).
 #ifndef NDQ_WIDE_LOWREG
 #define NDQ_WIDE_LOWREG 1
 #endif
 #ifndef NDQ_KEEP_H
 #define NDQ_KEEP_H 1
-#endif
-#ifndef NDQ_KEEP_PLANES
-#define NDQ_KEEP_PLANES 1
 #endif
 #ifndef NDQ_FWD_THREADS
 #define NDQ_FWD_THREADS 256
@@ -226,11 +221,6 @@ struct Cfg {
   static constexpr bool BF16 = (NDQ_BF16X3 != 0) && (NB_ % 2 == 0);
   static constexpr int NC = NB_ / 2;                       // K-chunks of 32 contraction slots (bf16 path)
   static constexpr int WEL = BF16 ? (H * H * 3) / 2 : H * H;   // floats of LDS per weight matrix image
-  // weight gradients of hidden layers on the matrix core too (fragments transposed by MFMAs against 0/1 selection
-  // operands instead of through LDS); the forward's bf16 planes of the layer inputs are kept when they fit
-  static constexpr bool DW_MM = BF16 && (NDQ_DW_MM != 0) && (NB_ == 2);   // wider nets: register budget, keep the LDS path
-  static constexpr bool KEEP_PLANES = DW_MM && (NB_ == 2) && (L_ == 2) && (NDQ_KEEP_PLANES != 0);
-  static constexpr int NCH = (SS::NS + 1) / 2;             // stream pairs = K-chunks of the weight-gradient MFMAs
   static constexpr bool KEEP_H = (NB_ == 2) && (NDQ_KEEP_H != 0);
   // wide nets (H >= 64): the reverse pass is register-bound, so (a) the per-point GEMMs go through their bf16 planes
   // SG streams at a time instead of all at once, (b) the bias-type gradient sums (db_l, dW1, dWout: one value per
@@ -560,71 +550,6 @@ __device__ __forceinline__ void gemm_grouped(const float* __restrict__ wl, int l
   });
 }
 
-// 0/1 selection operand: as the B operand of an MFMA whose A operand is a plane set of K-chunk c, it extracts
-// 16-unit block (2c + half) TRANSPOSED: D[point][unit] -> lane (unit, q') holds points 4q'..4q'+3.
-// lane (j = lane&15, kg = lane>>4): slot (kg, e) <-> unit 16*half + 4*kg + (e&3) with e>>2 == half.
-__device__ __forceinline__ bf16x8 sel_operand(int lane, int half) {
-  bf16x8 v;
-  const int j = lane & 15, kg = lane >> 4;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (__bf16)((kg == (j >> 2) && e == 4 * half + (j & 3)) ? 1.0f : 0.0f);
-  return v;
-}
-
-__device__ __forceinline__ bf16x8 pack8(const f32x4 a, const f32x4 b) {
-  bf16x8 v;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { v[e] = (__bf16)a[e]; v[4 + e] = (__bf16)b[e]; }
-  return v;
-}
-
-// dW += sum_s Zbar[s] H[s]^T over the tile's 16 points, entirely on the matrix core: every bf16 plane of Zbar / H is
-// transposed exactly by one MFMA against a selection operand, two streams are packed into one K = 32 chunk
-// (slot (kg, e) <-> stream 2ch + (e>>2), point 4kg + (e&3)), then the six bf16x3 partial products accumulate into the
-// same D-layout accumulators the f32 path used (acc[jb][kb][r] at lane (c, q) = dW[16jb+4q+r][16kb+c]).
-template <class C>
-__device__ __forceinline__ void weight_grad_mm(int lane, const Planes<C>& Z, const Planes<C>& Hh,
-                                               f32x4 (&acc)[C::NB][C::NB]) {
-  const bf16x8 sel[2] = {sel_operand(lane, 0), sel_operand(lane, 1)};
-  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-  // The tile's contribution is formed in fresh accumulators and then added to the running sums on the VALU (RNE):
-  // the matrix core's fp32 accumulation truncates, and chaining it across all tiles of a wave produced a drift that
-  // grew linearly with the number of tiles (2e-5 at 1 M points); per tile it is ~1e-7 and does not accumulate.
-  f32x4 d[C::NB][C::NB];
-#pragma unroll
-  for (int jb = 0; jb < C::NB; ++jb)
-#pragma unroll
-    for (int kb = 0; kb < C::NB; ++kb) d[jb][kb] = zero;
-  sfor<C::NCH>([&](auto ch_) {
-    constexpr int ch = decltype(ch_)::value;
-    constexpr int s0 = 2 * ch, s1 = 2 * ch + 1;
-    bf16x8 za[C::NB][3], hb[C::NB][3];
-#pragma unroll
-    for (int jb = 0; jb < C::NB; ++jb)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        f32x4 tz0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Z.pl[s0][jb >> 1][k], sel[jb & 1], zero, 0, 0, 0);
-        f32x4 th0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Hh.pl[s0][jb >> 1][k], sel[jb & 1], zero, 0, 0, 0);
-        f32x4 tz1 = zero, th1 = zero;
-        if constexpr (s1 < C::NS) {
-          tz1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Z.pl[s1][jb >> 1][k], sel[jb & 1], zero, 0, 0, 0);
-          th1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Hh.pl[s1][jb >> 1][k], sel[jb & 1], zero, 0, 0, 0);
-        }
-        za[jb][k] = pack8(tz0, tz1);
-        hb[jb][k] = pack8(th0, th1);
-      }
-#define NDQ_T(KA, KB)                                                                                        \
-  _Pragma("unroll") for (int jb = 0; jb < C::NB; ++jb) _Pragma("unroll") for (int kb = 0; kb < C::NB; ++kb)  \
-      d[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(za[jb][KA], hb[kb][KB], d[jb][kb], 0, 0, 0);
-    NDQ_T(1, 1) NDQ_T(2, 0) NDQ_T(0, 2) NDQ_T(1, 0) NDQ_T(0, 1) NDQ_T(0, 0)
-#undef NDQ_T
-  });
-#pragma unroll
-  for (int jb = 0; jb < C::NB; ++jb)
-#pragma unroll
-    for (int kb = 0; kb < C::NB; ++kb) acc[jb][kb] += d[jb][kb];
-}
-
 // hbar = W^T zbar in place (all streams are split first, then overwritten)
 template <class C>
 __device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl, int lane, f32x4 (&g)[C::NS][C::NB]) {
@@ -850,7 +775,6 @@ __device__ __forceinline__ void hidden_layer_grouped(const float* lds, int l, in
 }
 
 template <class C> struct KeptPlanes {
-  Planes<C> hk[(C::KEEP_PLANES && C::L > 1) ? C::L - 1 : 1];
   // with one wave per SIMD there are registers to spare: the activation streams of every layer are kept from the
   // forward pass instead of being recomputed for the weight-gradient GEMMs and the output-layer gradient
   f32x4 h[C::KEEP_H ? C::L : 1][C::NS][C::NB];
@@ -872,14 +796,9 @@ __device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, 
     if constexpr (C::BF16 && C::WIDE) {
       hidden_layer_grouped<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
     } else if constexpr (C::BF16) {
-      if constexpr (BWD && C::KEEP_PLANES) {   // the weight-gradient GEMM of layer l reuses these planes
-        split_all<C>(h, kp.hk[li]);
-        hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, kp.hk[li], st[li + 1]);
-      } else {
-        Planes<C> P;
-        split_all<C>(h, P);
-        hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, P, st[li + 1]);
-      }
+      Planes<C> P;
+      split_all<C>(h, P);
+      hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, P, st[li + 1]);
     } else {
       hidden_layer<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
     }
@@ -1206,26 +1125,7 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
       }
     }
     if constexpr (C::WIDE && li == 1) reload_first_layer_streams<C>(lds, q, st[0]);   // needed from here on again
-    if constexpr (C::DW_MM) {
-      Planes<C> Z;
-      split_all<C>(g, Z);                                             // zbar_l planes: used by BOTH GEMMs below
-      if constexpr (C::KEEP_PLANES) {
-        weight_grad_mm<C>(lane, Z, kp.hk[li - 1], acc.w[l - 2]);       // inputs of layer l: planes kept by the forward
-      } else {
-        f32x4 hin[C::NS][C::NB];
-        Planes<C> Hh;
-        act_forward<C>(st[li - 1], hin);
-        split_all<C>(hin, Hh);
-        weight_grad_mm<C>(lane, Z, Hh, acc.w[l - 2]);
-      }
-      f32x4 o[C::NS][C::NB];
-      zero_frag<C>(o);
-      gemm_planes<C>(lds + C::ldsWt(l), lane, Z, o);                  // hbar_{l-1} = W_l^T zbar_l
-#pragma unroll
-      for (int s = 0; s < C::NS; ++s)
-#pragma unroll
-        for (int b = 0; b < C::NB; ++b) g[s][b] = o[s][b];
-    } else if constexpr (C::BF16) {
+    if constexpr (C::BF16) {
       weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);
       gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);
     } else {
