@@ -37,7 +37,23 @@ typedef struct ndq_mlp_desc {
   int lap;     /* 1: "Laplacian stream" -- the diagonal pairs of mask2 are carried as ONE stream holding their sum */
 } ndq_mlp_desc;
 
-/* 1 if libndq.so carries kernels for this descriptor. */
+/* One compiled kernel pair (forward streams / parameter-gradient adjoint) for ONE descriptor.  libndq.so carries a
+ * table of them (csrc/ndq_api.hip); extension modules built at run time for other network shapes or stream sets
+ * (neurodiffeq_amd/codegen.py: hipcc on csrc/ndq_launch.h with one Cfg) add theirs through ndq_mlp_register, after
+ * which every entry point below serves that descriptor too. */
+typedef struct ndq_mlp_kernels {
+  ndq_mlp_desc desc;
+  int n_streams, n_params;
+  int bwd_waves;  /* waves per workgroup of the adjoint kernel (one 16-point tile per wave and iteration) */
+  int lds_bytes;  /* dynamic LDS the larger of the two kernels asks for (a workgroup has 160 KiB) */
+  int (*fwd)(const float* coords, int ldc, int n, const float* params, float* jets, int ldj, void* stream);
+  int (*bwd)(const float* coords, int ldc, int n, const float* params, const float* gbar, int ldj, float* partials,
+             int blocks, void* stream);
+} ndq_mlp_kernels;
+/* The record must stay valid for the life of the process.  Registering a descriptor twice is a no-op. */
+int ndq_mlp_register(const ndq_mlp_kernels* kernels);
+
+/* 1 if kernels for this descriptor are available (built in or registered). */
 int ndq_mlp_supported(const ndq_mlp_desc* desc);
 /* number of streams NS, of parameters P (flat torch order W1,b1,W2,b2,...,Wout,bout) */
 int ndq_mlp_num_streams(const ndq_mlp_desc* desc);

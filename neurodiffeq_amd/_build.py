@@ -1,6 +1,6 @@
 """In-tree build of the gfx950 artefacts (no cmake, no torch headers): plain ``hipcc -shared``.
 
-``libndq.so`` = csrc/ndq_api.hip (+ ndq_mlp.h), the C-ABI declared in include/ndq.h.  The built library travels to
+``libndq.so`` = csrc/ndq_api.hip (+ ndq_mlp.h, ndq_launch.h, ndq_sample.h), the C-ABI declared in include/ndq.h.  The built library travels to
 the GPU box with the repository snapshot; ``ensure_built`` recompiles only when a source is newer than the library.
 """
 import os
@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libndq.so")
 SOURCES = [os.path.join(CSRC, "ndq_api.hip")]
-HEADERS = [os.path.join(CSRC, "ndq_mlp.h"), os.path.join(HERE, "..", "include", "ndq.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("ndq_mlp.h", "ndq_launch.h", "ndq_sample.h")] + \
+    [os.path.join(HERE, "..", "include", "ndq.h")]
 HIPCC = os.environ.get("NDQ_HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 

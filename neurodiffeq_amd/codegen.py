@@ -533,8 +533,83 @@ class FusedKernel:
 
 
 def _header_digest():
-    with open(os.path.join(HERE, "csrc", "ndq_mlp.h"), "rb") as fh:
-        return hashlib.sha1(fh.read()).hexdigest()
+    h = hashlib.sha1()
+    for name in ("csrc/ndq_mlp.h", "csrc/ndq_launch.h", "../include/ndq.h"):
+        with open(os.path.join(HERE, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+# ----------------------------------------------------------------------------------------------- MLP kernel extensions
+# libndq.so carries a table of (shape, stream set) kernel pairs; anything else the templates can express is compiled
+# on first use as a tiny extension module (one Cfg: forward + adjoint kernel) and registered with libndq.so, after
+# which the ordinary C-ABI entry points serve it.  Cached in-tree like the generated pointwise kernels.
+_MLP_EXT = {}
+
+
+def mlp_ext_allowed(desc):
+    """Can ndq_mlp.h express this descriptor?  (H = 16..64, 1..4 hidden layers, d <= 3; the LDS footprint is checked
+    by ndq_mlp_register once the module is built.)"""
+    if os.environ.get("NDQ_JIT_MLP", "1") == "0":
+        return False
+    npair = desc.d * (desc.d + 1) // 2
+    diag = 0
+    for a in range(desc.d):
+        diag |= 1 << pair_list(desc.d).index((a, a))
+    return (1 <= desc.d <= 3 and desc.hidden % 16 == 0 and 16 <= desc.hidden <= 64 and 1 <= desc.layers <= 4
+            and desc.act in (0, 1, 2, 3) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
+            and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
+            and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0)))
+
+
+def mlp_ext_source(desc):
+    header = os.path.join(HERE, "csrc", "ndq_launch.h")
+    return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
+#include "{header}"
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}>;
+extern "C" const ndq_mlp_kernels* ndq_ext_kernels(void) {{
+  static const ndq_mlp_kernels k = ndq::make_kernels<CFG>();
+  return &k;
+}}
+"""
+
+
+def build_mlp_ext(desc, force=False):
+    os.makedirs(JIT_DIR, exist_ok=True)
+    source = mlp_ext_source(desc)
+    key = hashlib.sha1((source + _header_digest() + " ".join(_extra_flags())).encode()).hexdigest()[:16]
+    so = os.path.join(JIT_DIR, f"mlp_{key}.so")
+    src = os.path.join(JIT_DIR, f"mlp_{key}.hip")
+    if os.path.exists(so) and not force:
+        return so
+    with open(src, "w") as fh:
+        fh.write(source)
+    tmp = so + f".tmp{os.getpid()}"
+    proc = subprocess.run([HIPCC] + HIPCC_FLAGS + _extra_flags() + [src, "-o", tmp], capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed for MLP kernel extension {src}:\n{proc.stderr[-4000:]}")
+    os.replace(tmp, so)
+    return so
+
+
+def ensure_mlp_kernels(desc):
+    """True if libndq.so can serve ``desc`` -- from its table, or after building + registering an extension module."""
+    from . import _lib
+    L = _lib.lib()
+    if L.ndq_mlp_supported(ctypes.byref(desc)):
+        return True
+    if not mlp_ext_allowed(desc):
+        return False
+    key = desc.key()
+    if key in _MLP_EXT:
+        return _MLP_EXT[key] is not None
+    _MLP_EXT[key] = None
+    ext = ctypes.CDLL(build_mlp_ext(desc))
+    ext.ndq_ext_kernels.restype = ctypes.c_void_p
+    if L.ndq_mlp_register(ctypes.c_void_p(ext.ndq_ext_kernels())) != 0:
+        return False                              # e.g. the shape needs more LDS than a workgroup has
+    _MLP_EXT[key] = ext                           # keep the module (and its record) alive
+    return bool(L.ndq_mlp_supported(ctypes.byref(desc)))
 
 
 def build_fused(program: PointwiseProgram, desc, force=False):

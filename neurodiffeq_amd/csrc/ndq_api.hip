@@ -1,8 +1,8 @@
 // C-ABI of libndq.so (declared in include/ndq.h): descriptor dispatch onto the templated gfx950 kernels of
 // ndq_mlp.h, the second-stage reduction and the fused Adam step.
-#include "ndq_mlp.h"
+#include <vector>
+#include "ndq_launch.h"
 #include "ndq_sample.h"
-#include "../../include/ndq.h"
 
 namespace ndq {
 
@@ -59,73 +59,26 @@ namespace ndq {
   X(2, 1, 5, 2, 2, ACT_SWISH, 1, 1)
 #endif
 
-struct Entry {
-  int d, first, mask2, nb, layers, act, nout, lap;
-  int ns, p, bwd_waves;
-  int (*fwd)(const MlpArgs&, hipStream_t);
-  int (*bwd)(const MlpArgs&, int blocks, hipStream_t);
-  size_t fwd_lds, bwd_lds;
-};
+#define NDQ_ENTRY(D, F, M, NB, L, A, O, LP) make_kernels<Cfg<D, F, M, NB, L, A, O, LP>>(),
 
-#ifndef NDQ_FWD_MAX_BLOCKS
-#define NDQ_FWD_MAX_BLOCKS 768   // persistent-style grid: up to 3 workgroups per CU, waves loop over tiles
-#endif
-#ifndef NDQ_BWD_MAX_BLOCKS
-#define NDQ_BWD_MAX_BLOCKS 256   // one workgroup per CU; every wave amortises its epilogue over several tiles
-#endif
+static const ndq_mlp_kernels kTable[] = {NDQ_CFG_TABLE(NDQ_ENTRY)};
+static std::vector<const ndq_mlp_kernels*> g_registered;     // extension modules (ndq_mlp_register)
 
-template <class C>
-int launch_fwd(const MlpArgs& a, hipStream_t s) {
-  static bool attr = false;
-  const size_t lds = fwd_lds_bytes<C>();
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_jet_fwd_kernel<C>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  constexpr int waves = C::FWD_THREADS / 64;
-  const int tiles = (a.n + 15) / 16;
-  int blocks = (tiles + waves - 1) / waves;
-  if (blocks > NDQ_FWD_MAX_BLOCKS) blocks = NDQ_FWD_MAX_BLOCKS;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(mlp_jet_fwd_kernel<C>, dim3(blocks), dim3(C::FWD_THREADS), lds, s, a);
-  return (int)hipGetLastError();
+static bool same_desc(const ndq_mlp_desc& a, const ndq_mlp_desc& b) {
+  return a.d == b.d && a.first == b.first && a.mask2 == b.mask2 && a.hidden == b.hidden && a.layers == b.layers &&
+         a.act == b.act && a.n_out == b.n_out && a.lap == b.lap;
 }
 
-template <class C>
-int launch_bwd(const MlpArgs& a, int blocks, hipStream_t s) {
-  static bool attr = false;
-  const size_t lds = bwd_lds_bytes<C>(C::BWD_THREADS / 64);
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_jet_bwd_kernel<C>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  hipLaunchKernelGGL(mlp_jet_bwd_kernel<C>, dim3(blocks), dim3(C::BWD_THREADS), lds, s, a);
-  return (int)hipGetLastError();
-}
-
-#define NDQ_ENTRY(D, F, M, NB, L, A, O, LP)                                                               \
-  Entry{D, F, M, NB, L, A, O, LP, Cfg<D, F, M, NB, L, A, O, LP>::NS, Cfg<D, F, M, NB, L, A, O, LP>::P,    \
-        Cfg<D, F, M, NB, L, A, O, LP>::BWD_THREADS / 64,                                                  \
-        &launch_fwd<Cfg<D, F, M, NB, L, A, O, LP>>, &launch_bwd<Cfg<D, F, M, NB, L, A, O, LP>>,           \
-        fwd_lds_bytes<Cfg<D, F, M, NB, L, A, O, LP>>(),                                                   \
-        bwd_lds_bytes<Cfg<D, F, M, NB, L, A, O, LP>>(Cfg<D, F, M, NB, L, A, O, LP>::BWD_THREADS / 64)},
-
-static const Entry kTable[] = {NDQ_CFG_TABLE(NDQ_ENTRY)};
-
-static const Entry* find(const ndq_mlp_desc* d) {
+static const ndq_mlp_kernels* find(const ndq_mlp_desc* d) {
   if (!d || d->hidden % 16) return nullptr;
-  for (const Entry& e : kTable)
-    if (e.d == d->d && e.first == d->first && e.mask2 == d->mask2 && e.nb * 16 == d->hidden && e.layers == d->layers &&
-        e.act == d->act && e.nout == d->n_out && e.lap == d->lap)
-      return &e;
+  for (const ndq_mlp_kernels& e : kTable)
+    if (same_desc(e.desc, *d)) return &e;
+  for (const ndq_mlp_kernels* e : g_registered)
+    if (same_desc(e->desc, *d)) return e;
   return nullptr;
 }
 
-static int bwd_blocks(const Entry* e, int n) {
+static int bwd_blocks(const ndq_mlp_kernels* e, int n) {
   const int tiles = (n + 15) / 16;
   int blocks = (tiles + e->bwd_waves - 1) / e->bwd_waves;
   if (blocks > NDQ_BWD_MAX_BLOCKS) blocks = NDQ_BWD_MAX_BLOCKS;
@@ -338,18 +291,26 @@ extern "C" {
 
 int ndq_mlp_supported(const ndq_mlp_desc* desc) { return find(desc) ? 1 : 0; }
 
+int ndq_mlp_register(const ndq_mlp_kernels* k) {
+  if (!k || !k->fwd || !k->bwd || k->desc.hidden % 16 || k->n_streams < 1 || k->n_params < 1 || k->bwd_waves < 1 ||
+      k->lds_bytes > 160 * 1024)
+    return NDQ_EINVAL;
+  if (!find(&k->desc)) g_registered.push_back(k);
+  return 0;
+}
+
 int ndq_mlp_num_streams(const ndq_mlp_desc* desc) {
-  const Entry* e = find(desc);
-  return e ? e->ns : NDQ_EUNSUPPORTED;
+  const ndq_mlp_kernels* e = find(desc);
+  return e ? e->n_streams : NDQ_EUNSUPPORTED;
 }
 
 int ndq_mlp_num_params(const ndq_mlp_desc* desc) {
-  const Entry* e = find(desc);
-  return e ? e->p : NDQ_EUNSUPPORTED;
+  const ndq_mlp_kernels* e = find(desc);
+  return e ? e->n_params : NDQ_EUNSUPPORTED;
 }
 
 int ndq_mlp_bwd_blocks(const ndq_mlp_desc* desc, int n) {
-  const Entry* e = find(desc);
+  const ndq_mlp_kernels* e = find(desc);
   if (!e) return NDQ_EUNSUPPORTED;
   if (n <= 0) return NDQ_EINVAL;
   return bwd_blocks(e, n);
@@ -357,22 +318,18 @@ int ndq_mlp_bwd_blocks(const ndq_mlp_desc* desc, int n) {
 
 int ndq_mlp_jet_fwd(const ndq_mlp_desc* desc, const float* coords, int ldc, int n, const float* params, float* jets,
                     int ldj, void* stream) {
-  const Entry* e = find(desc);
+  const ndq_mlp_kernels* e = find(desc);
   if (!e) return NDQ_EUNSUPPORTED;
   if (!coords || !params || !jets || n <= 0 || ldc < n || ldj < n) return NDQ_EINVAL;
-  MlpArgs a{};
-  a.coords = coords; a.params = params; a.jets = jets; a.n = n; a.ldc = ldc; a.ldj = ldj;
-  return e->fwd(a, static_cast<hipStream_t>(stream));
+  return e->fwd(coords, ldc, n, params, jets, ldj, stream);
 }
 
 int ndq_mlp_jet_bwd(const ndq_mlp_desc* desc, const float* coords, int ldc, int n, const float* params,
                     const float* gbar, int ldj, float* partials, void* stream) {
-  const Entry* e = find(desc);
+  const ndq_mlp_kernels* e = find(desc);
   if (!e) return NDQ_EUNSUPPORTED;
   if (!coords || !params || !gbar || !partials || n <= 0 || ldc < n || ldj < n) return NDQ_EINVAL;
-  MlpArgs a{};
-  a.coords = coords; a.params = params; a.gbar = gbar; a.partials = partials; a.n = n; a.ldc = ldc; a.ldj = ldj;
-  return e->bwd(a, bwd_blocks(e, n), static_cast<hipStream_t>(stream));
+  return e->bwd(coords, ldc, n, params, gbar, ldj, partials, bwd_blocks(e, n), stream);
 }
 
 int ndq_reduce_partials(const float* partials, int nparts, int len, float* out, int accumulate, float scale,

@@ -66,14 +66,14 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
         """Is there a kernel for net k with the second derivatives w.r.t. ``coords`` merged into one Laplacian stream?"""
         info = infos[k]
         deps = g.net_deps[k]
-        if os.environ.get("NDQ_NO_LAP") or any(c not in deps for c in coords):
+        if os.environ.get("NDQ_NO_LAP") or any(c not in deps for c in coords) or info["n_out"] != 1:
             return False
         mask2 = 0
         for c in coords:
             a = deps.index(c)
             mask2 |= 1 << codegen.pair_list(len(deps)).index((a, a))
         d = _lib.MlpDesc(len(deps), 1, mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1)
-        return bool(L.ndq_mlp_supported(ctypes.byref(d)))
+        return codegen.ensure_mlp_kernels(d)
 
     def widen(k, st):
         info = infos[k]
@@ -83,7 +83,16 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
             raise TraceUnsupported("network fed a non-contiguous subset of the coordinates")
         if st.lap:                      # allow_lap already checked that this exact kernel exists
             descs[k] = _lib.MlpDesc(st.d, 1, st.mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1)
+            codegen.ensure_mlp_kernels(descs[k])
             return
+        # exact stream set: from libndq.so's table, else compiled on first use as an extension module ...
+        exact = _lib.MlpDesc(st.d, 1 if (st.first or st.mask2) else 0, st.mask2, info["hidden"], info["layers"],
+                             info["act"], info["n_out"])
+        if codegen.ensure_mlp_kernels(exact):
+            st.first, st.mask2 = exact.first, exact.mask2
+            descs[k] = exact
+            return
+        # ... else the cheapest superset the table has (NDQ_JIT_MLP=0, or a shape the templates cannot express)
         npair = st.d * (st.d + 1) // 2
         best = None
         for first in ((1,) if st.first else (0, 1)):

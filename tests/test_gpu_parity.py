@@ -344,7 +344,8 @@ def test_fused_closure_matches_oracle_at_size(name, size, mode):
 @pytest.mark.parametrize("mode", ["1k", "3k"])
 @pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide",
                                   "stokes_like", "poisson3d", "hessian3d", "shell", "swish_laplace", "sigmoid_mixed",
-                                  "swish_ode", "bundle_decay", "bundle_bvp"])
+                                  "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
+                                  "shape_16x2_sin", "shape_32x1"])
 def test_zoo_closure_matches_autograd_oracle(name, mode):
     """Systems outside the BASELINE set (tests/zoo.py): second-order IVP, sin networks, mixed second derivatives, first
     order only, three coordinates (Laplacian-merged, diagonal and full Hessian stream sets), three networks."""

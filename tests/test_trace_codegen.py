@@ -106,7 +106,8 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "advection": [(1, 0, 0)], "heat_wide": [(1, 1, 0)], "stokes_like": [(1, 5, 1), (1, 5, 1), (1, 0, 0)],
                "poisson3d": [(1, 41, 1)], "hessian3d": [(1, 63, 0)], "shell": [(1, 41, 0)],
                "swish_laplace": [(1, 5, 1)], "sigmoid_mixed": [(1, 7, 0)], "swish_ode": [(1, 1, 0), (1, 0, 0)],
-               "bundle_decay": [(1, 0, 0)], "bundle_bvp": [(1, 1, 0)]}
+               "bundle_decay": [(1, 0, 0)], "bundle_bvp": [(1, 1, 0)], "shape_64x2": [(1, 5, 1)], "shape_32x3": [(1, 5, 1)],
+               "shape_48x2": [(1, 5, 1)], "shape_16x2_sin": [(1, 5, 1)], "shape_32x1": [(1, 5, 1)]}
 
 
 @pytest.mark.parametrize("name", zoo.NAMES)

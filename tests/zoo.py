@@ -129,6 +129,16 @@ def build(name):
             s = (t - 0.0) / (1.0 - 0.0)
             return 0.0 * (1 - s) + u1 * s + (1 - torch.exp((1 - s) * s)) * net(_cat(t, u1))
         return System(name, 2, [(2, 1, (32, 32), "tanh")], [(0.0, 1.0), (-1.0, 1.0)], pde, conds, lambda D: [e])
+    # ---- network shapes outside libndq.so's table: compiled on first use as extension modules (codegen.ensure_mlp_kernels)
+    if name in ("shape_64x2", "shape_32x3", "shape_48x2", "shape_16x2_sin", "shape_32x1"):
+        hidden, act = {"shape_64x2": ((64, 64), "tanh"), "shape_32x3": ((32, 32, 32), "tanh"),
+                       "shape_48x2": ((48, 48), "tanh"), "shape_16x2_sin": ((16, 16), "sin"),
+                       "shape_32x1": ((32,), "tanh")}[name]
+        f0 = lambda y: torch.sin(PI * y)
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + u * D(u, x) - torch.exp(-x * y)])
+        conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
+        return System(name, 2, [(2, 1, hidden, act)], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, zero)])
     if name == "poisson3d":           # three coordinates, Laplacian -> one merged second-order stream
         pde = lambda D: (lambda u, x, y, z: [D(u, x, order=2) + D(u, y, order=2) + D(u, z, order=2)
                                              + torch.exp(-(x ** 2 + y ** 2 + z ** 2))])
@@ -161,7 +171,8 @@ def build(name):
 
 
 NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "poisson3d",
-         "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp"]
+         "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
+         "shape_16x2_sin", "shape_32x1"]
 
 
 def spherical_solver_problem():
