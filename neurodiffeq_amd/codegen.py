@@ -604,7 +604,12 @@ def ensure_mlp_kernels(desc):
     if key in _MLP_EXT:
         return _MLP_EXT[key] is not None
     _MLP_EXT[key] = None
-    ext = ctypes.CDLL(build_mlp_ext(desc))
+    try:
+        ext = ctypes.CDLL(build_mlp_ext(desc))
+    except (RuntimeError, OSError) as e:          # no hipcc on this host / compile error: not a supported shape then
+        import warnings
+        warnings.warn(f"could not build an MLP kernel extension for {key}: {str(e)[:400]}")
+        return False
     ext.ndq_ext_kernels.restype = ctypes.c_void_p
     if L.ndq_mlp_register(ctypes.c_void_p(ext.ndq_ext_kernels())) != 0:
         return False                              # e.g. the shape needs more LDS than a workgroup has
