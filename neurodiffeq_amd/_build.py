@@ -14,6 +14,11 @@ HEADERS = [os.path.join(CSRC, h) for h in ("ndq_mlp.h", "ndq_launch.h", "ndq_sam
     [os.path.join(HERE, "..", "include", "ndq.h")]
 HIPCC = os.environ.get("NDQ_HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+_EXTRA = os.environ.get("NDQ_LIB_FLAGS", "").split()      # tuning experiments: built to a library of their own
+if _EXTRA:
+    import hashlib
+    LIB = os.path.join(HERE, "libndq_" + hashlib.sha1(" ".join(_EXTRA).encode()).hexdigest()[:8] + ".so")
+    FLAGS = FLAGS + _EXTRA
 
 
 def is_stale():

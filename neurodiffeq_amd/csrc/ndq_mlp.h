@@ -135,6 +135,12 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3 };
 #ifndef NDQ_WIDE_LOWREG
 #define NDQ_WIDE_LOWREG 1
 #endif
+#ifndef NDQ_PIN_WEIGHT_READS
+#define NDQ_PIN_WEIGHT_READS 1
+#endif
+#ifndef NDQ_WIDE_SG
+#define NDQ_WIDE_SG 2    // streams whose bf16 planes are live at a time in the wide-net GEMMs
+#endif
 #ifndef NDQ_KEEP_H
 #define NDQ_KEEP_H 1
 #endif
@@ -225,9 +231,10 @@ struct Cfg {
   // wide nets (H >= 64): the reverse pass is register-bound, so (a) the per-point GEMMs go through their bf16 planes
   // SG streams at a time instead of all at once, (b) the bias-type gradient sums (db_l, dW1, dWout: one value per
   // unit) live in a per-wave LDS region instead of registers, (c) the first layer's derivative streams (columns of
-  // W1) are re-read from LDS for the reverse pass instead of being kept
+  // W1) are re-read from LDS for the reverse pass instead of being kept.  (Recomputing the middle layer's state in
+  // the reverse pass instead of keeping it was tried too: no fewer spills, 16 % slower -- rejected.)
   static constexpr bool WIDE = (NB_ >= 4) && (NDQ_WIDE_LOWREG != 0);
-  static constexpr int SG = WIDE ? 2 : SS::NS;
+  static constexpr int SG = WIDE ? NDQ_WIDE_SG : SS::NS;
   static constexpr bool ACC_LDS = WIDE && (NOUT_ == 1);
   static constexpr int biasFloats = ACC_LDS ? H * (D_ + L_ + 1) : 0;      // b1 | W1 [D] | b_2..b_L | Wout
   static constexpr int biasB1 = 0, biasW1 = H, biasBl = H * (1 + D_), biasWout = H * (D_ + L_);
@@ -329,6 +336,16 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
 }
 
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// An offset of zero the optimiser cannot see through.  Added to the LDS base once per tile it keeps the (loop-invariant)
+// weight reads inside the tile loop.  Wide nets only: there the hoisted reads would occupy hundreds of registers for
+// the whole kernel (C3 closure kernel: 548 -> 483 us with the reads pinned); at H = 32 hoisting is harmless (+-1 %).
+template <class C>
+__device__ __forceinline__ int opaque_zero() {
+  int z = 0;
+  if constexpr (C::WIDE && (NDQ_PIN_WEIGHT_READS != 0)) asm volatile("" : "+v"(z));
+  return z;
+}
 
 // ------------------------------------------------------------------------------------------------ per-layer pieces
 // hidden-unit state of one layer for one tile
@@ -756,15 +773,43 @@ __device__ __forceinline__ void gemm_layer_bf16(const float* lds, int l, int lan
   hidden_layer_planes<C, false>(lds, l, lane, q, P, st);
 }
 
-// hidden layer on the bf16x3 path with the planes built SG streams at a time (wide nets); st_out may not alias h's source
+// hidden layer on the bf16x3 path for wide nets: SG streams at a time, each group's activations h[s] computed from the
+// input layer's state right before they are split into planes (never more than SG streams of h and of planes live)
 template <class C, bool BWD>
-__device__ __forceinline__ void hidden_layer_grouped(const float* lds, int l, int lane, int q,
-                                                     const f32x4 (&h)[C::NS][C::NB], LayerState<C>& st) {
+__device__ __forceinline__ void hidden_layer_grouped(const float* lds, int l, int lane, int q, const LayerState<C>& st_in,
+                                                     LayerState<C>& st) {
   f32x4 z[C::NS][C::NB];
   zero_frag<C>(z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
-  gemm_grouped<C>(lds + C::ldsWf(l, BWD), lane, h, z);
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(lds + C::ldsWf(l, BWD));
+  constexpr int NG = (C::NS + C::SG - 1) / C::SG;
+  sfor<NG>([&](auto g_) {
+    constexpr int s0 = decltype(g_)::value * C::SG;
+    constexpr int sn = (C::NS - s0 < C::SG) ? C::NS - s0 : C::SG;
+    bf16x8 pl[sn][C::NC][3];
+    sfor<sn>([&](auto s_) {
+      constexpr int s = decltype(s_)::value;
+      f32x4 hs[C::NB];
+      act_forward_stream<C, s0 + s>(st_in, hs);
+#pragma unroll
+      for (int c = 0; c < C::NC; ++c) split3(hs[2 * c], hs[2 * c + 1], pl[s][c]);
+    });
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c)
+#pragma unroll
+      for (int ob = 0; ob < C::NB; ++ob) {
+        const bf16x8 a0 = w[((ob * C::NC + c) * 3 + 0) * 64 + lane];
+        const bf16x8 a1 = w[((ob * C::NC + c) * 3 + 1) * 64 + lane];
+        const bf16x8 a2 = w[((ob * C::NC + c) * 3 + 2) * 64 + lane];
+#define NDQ_T(A, K)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
+      z[s0 + s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], z[s0 + s][ob], 0, 0, 0);
+        NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+      }
+  });
+  // st may alias st_in (forward-only kernel): everything read from st_in is consumed above
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
 #pragma unroll
@@ -786,21 +831,23 @@ __device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, 
   first_layer<C, BWD>(lds, q, x, st[0]);
   sfor<C::L - 1>([&](auto li_) {
     constexpr int li = decltype(li_)::value;  // computes layer l = li + 2 from layer li + 1
-    act_forward<C>(st[li], h);
-    if constexpr (BWD && C::KEEP_H) {
-#pragma unroll
-      for (int s = 0; s < C::NS; ++s)
-#pragma unroll
-        for (int b = 0; b < C::NB; ++b) kp.h[li][s][b] = h[s][b];
-    }
     if constexpr (C::BF16 && C::WIDE) {
-      hidden_layer_grouped<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
-    } else if constexpr (C::BF16) {
-      Planes<C> P;
-      split_all<C>(h, P);
-      hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, P, st[li + 1]);
+      hidden_layer_grouped<C, BWD>(lds, li + 2, lane, q, st[li], st[li + 1]);
     } else {
-      hidden_layer<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
+      act_forward<C>(st[li], h);
+      if constexpr (BWD && C::KEEP_H) {
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+          for (int b = 0; b < C::NB; ++b) kp.h[li][s][b] = h[s][b];
+      }
+      if constexpr (C::BF16) {
+        Planes<C> P;
+        split_all<C>(h, P);
+        hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, P, st[li + 1]);
+      } else {
+        hidden_layer<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
+      }
     }
   });
   act_forward<C>(st[C::L - 1], h);
@@ -827,27 +874,31 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
     float x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    const float* ldsw = lds + opaque_zero<C>();
     LayerState<C> st;                      // one state, reused layer after layer (nothing is kept for a reverse pass)
-    first_layer<C, false>(lds, q, x, st);
+    first_layer<C, false>(ldsw, q, x, st);
     f32x4 h[C::NS][C::NB];
 #pragma unroll
     for (int l = 2; l <= C::L; ++l) {
-      act_forward<C>(st, h);
-      if constexpr (C::BF16 && C::WIDE) hidden_layer_grouped<C, false>(lds, l, lane, q, h, st);
-      else if constexpr (C::BF16) gemm_layer_bf16<C>(lds, l, lane, q, h, st);
-      else hidden_layer<C, false>(lds, l, lane, q, h, st);
+      if constexpr (C::BF16 && C::WIDE) {
+        hidden_layer_grouped<C, false>(ldsw, l, lane, q, st, st);
+      } else {
+        act_forward<C>(st, h);
+        if constexpr (C::BF16) gemm_layer_bf16<C>(ldsw, l, lane, q, h, st);
+        else hidden_layer<C, false>(ldsw, l, lane, q, h, st);
+      }
     }
     act_forward<C>(st, h);
     if constexpr (C::NOUT == 1) {
       float out[C::NS];
-      tile_output<C, false>(lds, q, h, out);
+      tile_output<C, false>(ldsw, q, h, out);
       if (q == 0 && n < a.n) {
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) a.jets[(size_t)s * a.ldj + n] = out[s];
       }
     } else {
       f32x4 o[C::NS][C::NBO];
-      output_layer_mfma<C, false>(lds, lane, q, h, o);
+      output_layer_mfma<C, false>(ldsw, lane, q, h, o);
       if (n < a.n) {
 #pragma unroll
         for (int s = 0; s < C::NS; ++s)
@@ -1284,15 +1335,16 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
     float x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    const float* ldsw = lds + opaque_zero<C>();
     LayerState<C> st[C::L];
     f32x4 h[C::NS][C::NB];
     KeptPlanes<C> kp;
-    tile_forward<C, true>(lds, lane, q, x, st, h, kp);
+    tile_forward<C, true>(ldsw, lane, q, x, st, h, kp);
     if constexpr (C::NOUT == 1) {
       float gout[C::NS];
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) gout[s] = valid ? a.gbar[(size_t)s * a.ldj + nn] : 0.f;
-      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc, kp);
+      tile_backward<C>(ldsw, stage, lane, p, q, x, gout, st, acc, kp);
     } else {
       f32x4 go[C::NS][C::NBO];
 #pragma unroll
@@ -1304,7 +1356,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
             const int u = 16 * ob + 4 * q + r;
             go[s][ob][r] = (valid && u < C::NOUT) ? a.gbar[((size_t)s * C::NOUT + u) * a.ldj + nn] : 0.f;
           }
-      tile_backward_multi<C>(lds, stage, lane, p, q, x, go, st, acc, kp);
+      tile_backward_multi<C>(ldsw, stage, lane, p, q, x, go, st, acc, kp);
     }
   }
   block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
@@ -1346,12 +1398,13 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     float x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    const float* ldsw = lds + opaque_zero<C>();
     LayerState<C> st[C::L];
     f32x4 h[C::NS][C::NB];
     KeptPlanes<C> kp;
-    tile_forward<C, TRAIN>(lds, lane, q, x, st, h, kp);
+    tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp);
     float jets[C::NS], gout[C::NS], r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
-    tile_output<C, TRAIN>(lds, q, h, jets);
+    tile_output<C, TRAIN>(ldsw, q, h, jets);
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
     if (valid && q == 0) {
 #pragma unroll
@@ -1368,7 +1421,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     if constexpr (TRAIN) {
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) gout[s] = valid ? gout[s] : 0.f;
-      tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc, kp);
+      tile_backward<C>(ldsw, stage, lane, p, q, x, gout, st, acc, kp);
     }
   }
   if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);

@@ -17,9 +17,11 @@ from neurodiffeq_amd.engine import FusedSystem, trace_system, _c_vp, _ptr  # noq
 
 build_only = "--build" in sys.argv
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-grid = int(args[0]) if args else 256
+name = os.environ.get("FBENCH_CFG", "c2")
+grid = int(args[0]) if args else {"c2": 256, "c3": 512}[name]
+FLOP = {"c2": 32064, "c3": 198912}[name]
 torch.manual_seed(0)
-cfg = configs.make("c2", grid)
+cfg = configs.make(name, grid)
 if build_only:
     prog, descs = trace_system(cfg["nets"], cfg["conds"], cfg["pde"], 2)
     print(codegen.build_fused(prog, descs[0]))
@@ -43,14 +45,15 @@ def closure():
                                      _ptr(b["fused_loss_partials"]), None, None, b["ld"], 1.0 / n, 1, stream)
 
 
+ITERS = 200 if name == "c2" else 60
 for _ in range(20):
     closure()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()
-for _ in range(200):
+for _ in range(ITERS):
     closure()
 e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) * 1e3 / 200
-print(json.dumps(dict(flags=os.environ.get("NDQ_JIT_FLAGS", ""), n=n, us=round(us, 2), tflops=round(32064 * n / us / 1e6, 1),
+us = e0.elapsed_time(e1) * 1e3 / ITERS
+print(json.dumps(dict(flags=os.environ.get("NDQ_JIT_FLAGS", ""), n=n, us=round(us, 2), tflops=round(FLOP * n / us / 1e6, 1),
                       grad_rel=float(np.linalg.norm(g - g_ref) / np.linalg.norm(g_ref)), loss_rel=abs(l - l_ref) / abs(l_ref),
                       blocks=b["fused_blocks"])))
