@@ -62,6 +62,48 @@ def test_shard_and_all_reduce_equals_unsharded(tmp_path):
     assert np.linalg.norm(r["grad"] - r["grad_full"]) <= 1e-5 * np.linalg.norm(r["grad_full"])
 
 
+def _worker_presharded(rank, world, port, out):
+    """Weak scaling as bench.py runs it: every rank owns a batch of its own (presharded), seeds are normalised by the
+    GLOBAL point count world * n; the reduced [gradient | loss] equals one closure over the concatenated batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import autograd_ref as R
+    torch.manual_seed(0)
+    cfg = R.build_config("c2", 8)
+    shards = []
+    for r in range(world):
+        torch.manual_seed(10 + r)
+        shards.append(cfg["sampler"]())
+    mine = shards[rank]
+    n = mine[0].numel()
+    sh = BatchSharding(presharded=True)
+    assert sh.bounds(n) == (0, n) and sh.global_n(n) == world * n and sh.direct("cpu") is None
+    batch = [c.reshape(-1, 1).requires_grad_(True) for c in mine]
+    funcs = [e(net, *batch) for net, e in zip(cfg["nets"], cfg["enforcers"])]
+    res = torch.cat(cfg["pde"](*funcs, *batch), dim=1)
+    loss = (res ** 2).sum() / (sh.global_n(n) * res.shape[1])
+    loss.backward()
+    flat = torch.cat([R.get_flat_grad(cfg["nets"]), loss.detach().reshape(1)])     # [grad | loss]: ONE message
+    sh.all_reduce_flat(flat)
+    if rank == 0:
+        for net in cfg["nets"]:
+            net.zero_grad()
+        whole = [torch.cat([s[i] for s in shards]) for i in range(len(mine))]
+        full = R.closure(cfg["nets"], cfg["enforcers"], cfg["pde"], whole)
+        np.savez(out, flat=flat.numpy(), grad_full=R.get_flat_grad(cfg["nets"]).numpy(), loss_full=full["loss"].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_presharded_weak_scaling_equals_one_big_batch(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "res2.npz")
+    mp.spawn(_worker_presharded, args=(2, port, out), nprocs=2, join=True)
+    r = np.load(out)
+    assert np.allclose(r["flat"][-1], r["loss_full"], rtol=1e-5)
+    assert np.linalg.norm(r["flat"][:-1] - r["grad_full"]) <= 1e-5 * np.linalg.norm(r["grad_full"])
+
+
 def test_bounds_partition():
     for n in (1, 7, 64, 65536, 1000):
         for world in (1, 2, 3, 8):
