@@ -9,8 +9,9 @@
 //
 // Execution model (CDNA4), details in DESIGN.md section 4:
 //  * a wave (64 lanes) owns a tile of 16 collocation points; lane = (p = lane&15 : point, q = lane>>4); ONE wave per
-//    SIMD with the whole 512-entry register file (the f32 MFMA shares the VALU datapath on gfx950, so a second wave
-//    per SIMD buys nothing -- scripts/ubench_mfma_valu.hip).
+//    SIMD with the whole 512-entry register file (the f32 MFMA shares the VALU datapath on gfx950 --
+//    scripts/ubench_mfma_valu.hip -- so a second wave per SIMD only buys the overlap of its bf16 MFMAs and stalls with
+//    the other's VALU work: ~3 % where the state fits twice, see NDQ_BWD_THREADS).
 //  * a "fragment" f32x4 frag[NB] holds, for point p, hidden units 16*b + 4*q + r (b < NB, r < 4) -- exactly the C/D
 //    layout of the 16x16 MFMAs with units as rows and points as columns.  The 8 values a lane holds per 32 units are
 //    ALSO a valid B operand of the next layer's MFMA if the contraction runs in the permuted order
@@ -116,8 +117,9 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3 };
 #define NDQ_FAST_TANH 1
 #endif
 #ifndef NDQ_BWD_THREADS
-#define NDQ_BWD_THREADS 256
-#endif
+#define NDQ_BWD_THREADS 256   // 512 (2 waves per SIMD) measured ~3 % faster on the C2 closure kernel but produced a wrong
+#endif                        // dW1 in mlp_jet_bwd<2,1,7,...> at n = 4099 (not understood) -- stays at one wave per SIMD
+
 // Hidden-layer GEMMs on the bf16 matrix core with 3-way split operands ("bf16x3"): x = x0 + x1 + x2 (three bf16
 // chunks = 24 mantissa bits), products a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1 accumulated in fp32 -> relative error
 // ~2^-23, i.e. fp32-class accuracy.  Why: the f32-input MFMA shares the VALU datapath on gfx950 (it does NOT overlap
