@@ -152,6 +152,8 @@ typedef struct ndq_fused_step {
   float* best_flat;           /* [P] */
   ndq_allreduce_fn allreduce; /* data parallel: sums grad[0..P) and the loss slot, which must be grad[P] (one message) */
   void* comm;                 /* ncclComm_t for `allreduce` */
+  void* ev_start;             /* optional hipEvent_t recorded on `stream` right before the closure kernel ... */
+  void* ev_stop;              /* ... and right after it (in-situ kernel timing, bench.py); NULL: nothing recorded */
 } ndq_fused_step;
 int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_step, int hist_index, int parity,
                        void* stream);

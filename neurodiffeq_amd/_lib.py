@@ -41,7 +41,8 @@ class FusedStep(ctypes.Structure):
                 ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
                 ("weight_decay", ctypes.c_float),
                 ("loss_hist", ctypes.c_void_p), ("best_loss", ctypes.c_void_p), ("best_flat", ctypes.c_void_p),
-                ("allreduce", ctypes.c_void_p), ("comm", ctypes.c_void_p)]
+                ("allreduce", ctypes.c_void_p), ("comm", ctypes.c_void_p),
+                ("ev_start", ctypes.c_void_p), ("ev_stop", ctypes.c_void_p)]
 
 
 class NdqError(RuntimeError):

@@ -140,6 +140,7 @@ class FusedSystem:
         self._bufs = {}
         self._resident_cache = {}
         self._static, self._static_seen = {}, {}
+        self.closure_events = []        # bench.py: (hipEvent_t start, stop) pairs, one consumed per native training step
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.loss_buf = torch.zeros(64, dtype=torch.float32, device=self.device)
 
@@ -429,6 +430,7 @@ class FusedSystem:
         stream = self._stream()
         coords = self._coord_ptr(b, 0)
         hist_index, parity = fs["pending"], fs["parity"]
+        st.ev_start, st.ev_stop = self.closure_events.pop() if self.closure_events else (None, None)
         direct = dist.direct(self.device) if dist is not None else None
         if dist is None or direct is not None:
             # one native call; with data parallelism the RCCL all-reduce of [grad | loss] is enqueued by it, on the
