@@ -70,18 +70,31 @@ def closure_in_situ(solver, system, steps):
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
         assert hip.hipEventCreate(ctypes.byref(a)) == 0 and hip.hipEventCreate(ctypes.byref(b)) == 0
         pairs.append((a.value, b.value))
+    def elapsed(a, b):
+        ms = ctypes.c_float()
+        assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
+        return ms.value * 1e-3
+
+    # what an event pair costs by itself on a busy stream (two records with nothing in between)
+    hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scratch = torch.zeros(1024, device="cuda")
+    empty = []
+    for a, b in pairs[:min(50, steps)]:
+        scratch.add_(1.0)
+        hip.hipEventRecord(a, stream), hip.hipEventRecord(b, stream)
+    torch.cuda.synchronize()
+    empty = sorted(elapsed(a, b) for a, b in pairs[:min(50, steps)])
+    overhead = empty[len(empty) // 2]
     system.closure_events = list(pairs)
     for _ in range(steps):
         solver.run_train_epoch()
     torch.cuda.synchronize()
     assert not system.closure_events
-    total = 0.0
+    raw = sum(elapsed(a, b) for a, b in pairs) / steps
     for a, b in pairs:
-        ms = ctypes.c_float()
-        assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
-        total += ms.value
         hip.hipEventDestroy(a), hip.hipEventDestroy(b)
-    return total * 1e-3 / steps
+    return raw - overhead, raw, overhead
 
 
 def fused_breakdown(system, batch):
@@ -267,7 +280,7 @@ def main():
         if system.fusedk is not None:
             kb.update(fused_breakdown(system, batch))
             kb["fused_closure"]["back_to_back_us"] = kb["fused_closure"]["us"]
-            t_situ = closure_in_situ(solver, system, args.steps)
+            t_situ, t_raw, t_ev = closure_in_situ(solver, system, args.steps)
             flop = (FWD_FLOP_PER_PT + BWD_FLOP_PER_PT) * N_POINTS
             kb["fused_closure"].update(us=t_situ * 1e6, tflops=flop / t_situ / 1e12)
             out["roofline"] = {"kernel": "fused_closure_kernel<Cfg<2,1,5,2,2,tanh>, PW, train> (fwd + pointwise + bwd)",
@@ -276,9 +289,11 @@ def main():
                                "frac": kb["fused_closure"]["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                                "algorithmic_flop_per_point": FWD_FLOP_PER_PT + BWD_FLOP_PER_PT,
                                # HIP events around the kernel inside real training steps (closure -> tail -> closure
-                               # ...), as rocprofv3 sees it; launched back to back on its own it averages less
+                               # ...) minus what an empty event pair measures on the same stream; launched back to
+                               # back on its own the kernel averages less (launch ramps overlap)
                                "avg_launch_us": kb["fused_closure"]["us"],
                                "back_to_back_us": kb["fused_closure"]["back_to_back_us"],
+                               "event_pair_us": {"raw": t_raw * 1e6, "empty_pair": t_ev * 1e6},
                                # the kernel carries u_xx + u_yy as ONE "Laplacian" stream when the tracer proves the
                                # residual only needs the sum, i.e. it executes 4 streams instead of SURVEY's 5
                                "executed_streams": system.program.streams[0].n_streams,
