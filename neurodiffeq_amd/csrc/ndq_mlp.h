@@ -117,8 +117,13 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3 };
 #define NDQ_FAST_TANH 1
 #endif
 #ifndef NDQ_BWD_THREADS
-#define NDQ_BWD_THREADS 256   // 512 (2 waves per SIMD) measured ~3 % faster on the C2 closure kernel but produced a wrong
-#endif                        // dW1 in mlp_jet_bwd<2,1,7,...> at n = 4099 (not understood) -- stays at one wave per SIMD
+// 512 threads (2 waves per SIMD, 256 registers each) measured ~3 % faster on the C2 closure kernel, but every kernel
+// that then spills to scratch (mlp_jet_bwd<2,1,5,..>: 28 VGPRs, <2,1,7,..>: 64) came back with a few corrupted
+// workgroup rows per launch, different ones each time (scripts/stress_bwd.py; the spill-free 1-D kernels and all
+// one-wave-per-SIMD kernels, spilling or not, are bit-reproducible over thousands of launches).  Cause not found --
+// two scratch-using waves on one SIMD is the common factor -- so: one wave per SIMD.
+#define NDQ_BWD_THREADS 256
+#endif
 
 // Hidden-layer GEMMs on the bf16 matrix core with 3-way split operands ("bf16x3"): x = x0 + x1 + x2 (three bf16
 // chunks = 24 mantissa bits), products a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1 accumulated in fp32 -> relative error
