@@ -29,38 +29,51 @@ class DirectRccl:
     ALL ranks fall back to ``torch.distributed`` (the decision itself is an all-reduce over the regular group)."""
 
     def __init__(self, rank, world_size, group, device):
-        self.ok, self.comm, self.fn = False, None, None
+        self.ok, self.comm, self.fn, self.lib = False, None, None, None
         err = None
+        uid = _UniqueId()
+        # phase 1 (local): load the library, rank 0 draws the unique id.  Nothing here may skip the collectives below.
         try:
             lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
             lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
             lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
             lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p]
-            uid = _UniqueId()
+            lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
             if rank == 0 and lib.ncclGetUniqueId(ctypes.byref(uid)) != 0:
                 raise RuntimeError("ncclGetUniqueId failed")
-            payload = [bytes(uid) if rank == 0 else None]
-            src = dist.get_global_rank(group, 0) if group is not None else 0
-            dist.broadcast_object_list(payload, src=src, group=group, device=device)
-            ctypes.memmove(ctypes.byref(uid), payload[0], 128)
-            comm = ctypes.c_void_p()
-            with torch.cuda.device(device):
-                rc = lib.ncclCommInitRank(ctypes.byref(comm), world_size, uid, rank)
-                if rc != 0:
-                    raise RuntimeError(f"ncclCommInitRank returned {rc}")
-                probe = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
-                stream = torch.cuda.current_stream(device).cuda_stream
-                rc = lib.ncclAllReduce(probe.data_ptr(), probe.data_ptr(), 8, 7, 0, comm, ctypes.c_void_p(stream))
-                torch.cuda.synchronize(device)
-                want = world_size * (world_size + 1) / 2.0
-                if rc != 0 or not bool((probe == want).all()):
-                    raise RuntimeError(f"self-test all-reduce failed (rc={rc}, got {probe[0].item()}, want {want})")
-            self.lib, self.comm = lib, comm
-            self.fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
-        except Exception as e:                      # noqa: BLE001 -- any failure means: use torch.distributed
-            err = e
-        flag = torch.tensor([0.0 if err is not None else 1.0], device=device)
+        except Exception as e:                      # noqa: BLE001
+            err, lib = e, None
+        # phase 2 (collective, unconditional): the id -- or None if rank 0 could not produce one -- reaches every rank
+        payload = [bytes(uid) if (rank == 0 and err is None) else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(payload, src=src, group=group, device=device)
+        # phase 3 (collective inside RCCL, entered only if EVERY rank can): agree first
+        ready = torch.tensor([1.0 if (err is None and payload[0] is not None) else 0.0], device=device)
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN, group=group)
+        if ready.item() == 1.0:
+            try:
+                ctypes.memmove(ctypes.byref(uid), payload[0], 128)
+                comm = ctypes.c_void_p()
+                with torch.cuda.device(device):
+                    rc = lib.ncclCommInitRank(ctypes.byref(comm), world_size, uid, rank)
+                    if rc != 0:
+                        raise RuntimeError(f"ncclCommInitRank returned {rc}")
+                    probe = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
+                    stream = torch.cuda.current_stream(device).cuda_stream
+                    rc = lib.ncclAllReduce(probe.data_ptr(), probe.data_ptr(), 8, 7, 0, comm, ctypes.c_void_p(stream))
+                    torch.cuda.synchronize(device)
+                    want = world_size * (world_size + 1) / 2.0
+                    if rc != 0 or not bool((probe == want).all()):
+                        raise RuntimeError(f"self-test all-reduce failed (rc={rc}, got {probe[0].item()}, want {want})")
+                self.lib, self.comm = lib, comm
+                self.fn = ctypes.cast(lib.ncclAllReduce, ctypes.c_void_p).value
+            except Exception as e:                  # noqa: BLE001
+                err = e
+        elif err is None:
+            err = RuntimeError("another rank could not set up the communicator")
+        # phase 4 (collective, unconditional): use it only if the self-test passed everywhere
+        flag = torch.tensor([0.0 if (err is not None or self.comm is None) else 1.0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         self.ok = bool(flag.item() == 1.0)
         if not self.ok and err is not None:
@@ -69,7 +82,6 @@ class DirectRccl:
     def close(self):
         if self.comm is not None:
             torch.cuda.synchronize()
-            self.lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
             self.lib.ncclCommDestroy(self.comm)
             self.comm, self.ok = None, False
 
