@@ -537,43 +537,6 @@ __device__ __forceinline__ void gemm_planes(const float* __restrict__ wl, int la
     }
 }
 
-// the same for streams [S0, S0 + SN) only: planes of SN streams live at a time (wide nets)
-template <class C, int S0, int SN>
-__device__ __forceinline__ void gemm_group(const float* __restrict__ wl, int lane, const f32x4 (&h)[C::NS][C::NB],
-                                           f32x4 (&z)[C::NS][C::NB]) {
-  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
-  bf16x8 pl[SN][C::NC][3];
-#pragma unroll
-  for (int s = 0; s < SN; ++s)
-#pragma unroll
-    for (int c = 0; c < C::NC; ++c) split3(h[S0 + s][2 * c], h[S0 + s][2 * c + 1], pl[s][c]);
-#pragma unroll
-  for (int c = 0; c < C::NC; ++c)
-#pragma unroll
-    for (int ob = 0; ob < C::NB; ++ob) {
-      const bf16x8 a0 = w[((ob * C::NC + c) * 3 + 0) * 64 + lane];
-      const bf16x8 a1 = w[((ob * C::NC + c) * 3 + 1) * 64 + lane];
-      const bf16x8 a2 = w[((ob * C::NC + c) * 3 + 2) * 64 + lane];
-#define NDQ_T(A, K)                                                                                          \
-  _Pragma("unroll") for (int s = 0; s < SN; ++s)                                                             \
-      z[S0 + s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], z[S0 + s][ob], 0, 0, 0);
-      NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
-#undef NDQ_T
-    }
-}
-
-// z[s] += W h[s] for all streams, C::SG streams at a time
-template <class C>
-__device__ __forceinline__ void gemm_grouped(const float* __restrict__ wl, int lane, const f32x4 (&h)[C::NS][C::NB],
-                                             f32x4 (&z)[C::NS][C::NB]) {
-  constexpr int NG = (C::NS + C::SG - 1) / C::SG;
-  sfor<NG>([&](auto g_) {
-    constexpr int s0 = decltype(g_)::value * C::SG;
-    constexpr int sn = (C::NS - s0 < C::SG) ? C::NS - s0 : C::SG;
-    gemm_group<C, s0, sn>(wl, lane, h, z);
-  });
-}
-
 // hbar = W^T zbar in place (all streams are split first, then overwritten)
 template <class C>
 __device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl, int lane, f32x4 (&g)[C::NS][C::NB]) {
