@@ -606,10 +606,12 @@ def ensure_mlp_kernels(desc):
     _MLP_EXT[key] = None
     try:
         ext = ctypes.CDLL(build_mlp_ext(desc))
-    except (RuntimeError, OSError) as e:          # no hipcc on this host / compile error: not a supported shape then
+    except RuntimeError as e:                     # the templates reject this combination: not a supported shape
         import warnings
         warnings.warn(f"could not build an MLP kernel extension for {key}: {str(e)[:400]}")
         return False
+    except OSError as e:                          # no hipcc / unreadable module: the native path is broken, say so
+        raise _lib.NdqError(f"cannot build or load the MLP kernel extension for {key}: {e}") from e
     ext.ndq_ext_kernels.restype = ctypes.c_void_p
     if L.ndq_mlp_register(ctypes.c_void_p(ext.ndq_ext_kernels())) != 0:
         return False                              # e.g. the shape needs more LDS than a workgroup has
