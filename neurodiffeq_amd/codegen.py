@@ -294,24 +294,40 @@ class PointwiseProgram:
 """
 
     def fused_source(self, desc):
-        """Source of the single-network fused closure kernel (csrc/ndq_mlp.h: fused_closure_kernel) specialised with
-        this program's per-point function.  desc: the network's ndq_mlp_desc."""
-        assert self.n_nets == 1 and tuple(self.streams[0].deps) == tuple(range(self.n_coords))
-        st = self.streams[0]
-        ns = st.n_streams
+        """Source of the single-launch closure kernel (csrc/ndq_mlp.h: fused_closure_kernel for one network,
+        fused_multi_closure_kernel for 2..4 networks of one shape and stream set) specialised with this program's
+        per-point function.  desc: the ndq_mlp_desc shared by all networks."""
+        K = self.n_nets
+        assert can_fuse(self, {k: desc for k in range(K)})
+        ns = self.streams[0].n_streams
         nsym = max(len(self.symbols), 1)
+        jet = (lambda k, loc: f"jets[{loc}]") if K == 1 else (lambda k, loc: f"jets[{k}][{loc}]")
+        gj = (lambda k, loc: f"gj[{loc}]") if K == 1 else (lambda k, loc: f"gj[{k}][{loc}]")
         loads, stores = [], []
         used = {}
         for idx, i in enumerate(self.symbols):
-            _, loc = self.sym_location(i)
-            used[loc] = idx
-            loads.append(f"    s[{idx}] = jets[{loc}];")
-        for loc in range(ns):
-            stores.append(f"    gj[{loc}] = {'g[%d]' % used[loc] if loc in used else '0.0f'};")
+            k, loc = self.sym_location(i)
+            used[(k, loc)] = idx
+            loads.append(f"    s[{idx}] = {jet(k, loc)};")
+        for k in range(K):
+            for loc in range(ns):
+                stores.append(f"    {gj(k, loc)} = {'g[%d]' % used[(k, loc)] if (k, loc) in used else '0.0f'};")
         header = os.path.join(HERE, "csrc", "ndq_mlp.h")
         neq, nf = len(self.residuals), len(self.funcs)
-        return f"""// GENERATED by neurodiffeq_amd/codegen.py -- fused closure kernel (forward streams + pointwise stage + reverse pass)
-// of one single-network PDE system, gfx950.
+        jets_t = "const float (&jets)[CFG::NS]" if K == 1 else f"const float (&jets)[{K}][CFG::NS]"
+        gj_t = "float (&gj)[CFG::NS]" if K == 1 else f"float (&gj)[{K}][CFG::NS]"
+        kern = (lambda train: f"ndq::fused_closure_kernel<CFG, PW, {train}>") if K == 1 else \
+            (lambda train: f"ndq::fused_multi_closure_kernel<CFG, {K}, PW, {train}>")
+        lds = (lambda train: f"ndq::fused_lds_bytes<CFG>({train})") if K == 1 else \
+            (lambda train: f"ndq::fused_multi_lds_bytes<CFG>({K}, {train})")
+        if K == 1:
+            args_t = "ndq::FusedArgs"
+            fill = "a.params = params[0]; a.partials = partials ? partials[0] : nullptr;"
+        else:
+            args_t = "ndq::FusedMultiArgs"
+            fill = f"for (int k = 0; k < {K}; ++k) {{ a.params[k] = params[k]; a.partials[k] = partials ? partials[k] : nullptr; }}"
+        return f"""// GENERATED by neurodiffeq_amd/codegen.py -- single-launch closure kernel (forward streams + pointwise stage +
+// reverse pass) of one PDE system with {K} network(s), gfx950.
 #include "{header}"
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
@@ -319,9 +335,9 @@ namespace {{
 using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}>;
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf};
-  static __device__ __forceinline__ void apply(const float (&x)[CFG::D], const float (&jets)[CFG::NS], float seed,
+  static __device__ __forceinline__ void apply(const float (&x)[CFG::D], {jets_t}, float seed,
                                                int want_adj, float (&r)[{max(neq, 1)}], float (&f)[{max(nf, 1)}],
-                                               float (&gj)[CFG::NS]) {{
+                                               {gj_t}) {{
     float s[{nsym}], g[{nsym}];
 {chr(10).join(loads)}
     ndq_pw_point(x, s, seed, want_adj, r, f, g);
@@ -334,33 +350,54 @@ int fused_blocks(int n) {{
   int b = (tiles + kWaves - 1) / kWaves;
   return b > 256 ? 256 : (b < 1 ? 1 : b);
 }}
-}}  // namespace
 
-extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
-extern "C" int ndq_fused_num_params() {{ return CFG::P; }}
-
-extern "C" int ndq_fused_launch(const float* coords, int ldc, int n, const float* params, float* partials,
-                                float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,
-                                void* stream) {{
+// params / partials: host arrays of {K} device pointers (one per network)
+int launch(const float* coords, int ldc, int n, const float* const* params, float* const* partials, float* loss_partials,
+           float* funcs, float* resid, int ldj, float seed, int train, void* stream) {{
   if (!coords || !params || !loss_partials || n <= 0 || ldc < n || (train && !partials)) return -2;
-  ndq::FusedArgs a;
-  a.coords = coords; a.params = params; a.partials = partials; a.loss_partials = loss_partials;
+  {args_t} a;
+  a.coords = coords; a.loss_partials = loss_partials;
+  {fill}
   a.funcs = funcs; a.resid = resid; a.n = n; a.ldc = ldc; a.ldj = ldj; a.seed = seed;
   hipStream_t s = static_cast<hipStream_t>(stream);
   static bool attr = false;
   if (!attr) {{
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ndq::fused_closure_kernel<CFG, PW, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ndq::fused_lds_bytes<CFG>(true));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&{kern('true')}),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int){lds('true')});
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&{kern('false')}),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int){lds('false')});
     if (e != hipSuccess) return (int)e;
     attr = true;
   }}
   if (train)
-    hipLaunchKernelGGL((ndq::fused_closure_kernel<CFG, PW, true>), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS),
-                       ndq::fused_lds_bytes<CFG>(true), s, a);
+    hipLaunchKernelGGL(({kern('true')}), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS), {lds('true')}, s, a);
   else
-    hipLaunchKernelGGL((ndq::fused_closure_kernel<CFG, PW, false>), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS),
-                       ndq::fused_lds_bytes<CFG>(false), s, a);
+    hipLaunchKernelGGL(({kern('false')}), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS), {lds('false')}, s, a);
   return (int)hipGetLastError();
+}}
+}}  // namespace
+
+extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
+extern "C" int ndq_fused_num_params() {{ return CFG::P; }}
+extern "C" int ndq_fused_num_nets() {{ return {K}; }}
+extern "C" unsigned long ndq_fused_lds_bytes() {{ return (unsigned long){lds('true')}; }}
+
+// one network: the ndq_fused_launch_fn of include/ndq.h
+extern "C" int ndq_fused_launch(const float* coords, int ldc, int n, const float* params, float* partials,
+                                float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,
+                                void* stream) {{
+  if ({K} != 1) return -2;
+  const float* pp[1] = {{params}};
+  float* qq[1] = {{partials}};
+  return launch(coords, ldc, n, pp, partials ? qq : nullptr, loss_partials, funcs, resid, ldj, seed, train, stream);
+}}
+
+// any number of networks: params / partials are host arrays of device pointers
+extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const float* const* params,
+                                      float* const* partials, float* loss_partials, float* funcs, float* resid, int ldj,
+                                      float seed, int train, void* stream) {{
+  return launch(coords, ldc, n, params, partials, loss_partials, funcs, resid, ldj, seed, train, stream);
 }}
 """
 
@@ -524,9 +561,14 @@ class FusedKernel:
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         self.lib.ndq_fused_launch.restype = ci
         self.lib.ndq_fused_launch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
+        self.lib.ndq_fused_launch_multi.restype = ci
+        self.lib.ndq_fused_launch_multi.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
         self.lib.ndq_fused_blocks.restype = ci
         self.lib.ndq_fused_blocks.argtypes = [ci]
         self.lib.ndq_fused_num_params.restype = ci
+        self.lib.ndq_fused_num_nets.restype = ci
+        self.lib.ndq_fused_lds_bytes.restype = ctypes.c_ulong
+        self.n_nets = self.lib.ndq_fused_num_nets()
 
     def blocks(self, n):
         return self.lib.ndq_fused_blocks(n)
@@ -639,6 +681,18 @@ def build_fused(program: PointwiseProgram, desc, force=False):
     return so
 
 
-def can_fuse(program: PointwiseProgram):
-    return program.n_nets == 1 and 0 in program.streams and \
-        tuple(program.streams[0].deps) == tuple(range(program.n_coords))
+def can_fuse(program: PointwiseProgram, descs=None):
+    """Single-launch closure: one network, or 2..4 networks of ONE shape and stream set (H <= 48), every network
+    reading all coordinates and producing one output."""
+    K = program.n_nets
+    if K < 1 or K > 4 or any(k not in program.streams for k in range(K)):
+        return False
+    if any(tuple(program.streams[k].deps) != tuple(range(program.n_coords)) or program.streams[k].n_out != 1
+           for k in range(K)):
+        return False
+    if K > 1:
+        if descs is None or len({descs[k].key() for k in range(K)}) != 1 or descs[0].hidden > 48:
+            return False
+        if os.environ.get("NDQ_NO_MULTI_FUSE"):
+            return False
+    return True

@@ -1408,11 +1408,111 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   }
 }
 
+// ------------------------------------------------------------------------------------------------ multi-network closure
+// The same single launch for K networks of ONE shape and stream set (systems of ODEs / PDEs with one network per
+// unknown, the reference's default: solvers.py:136-140): all K weight images sit in LDS, each tile runs the K forward
+// passes, the pointwise stage on all K stream sets, then -- network by network -- a second forward pass that keeps
+// the layer states and the reverse pass (keeping K sets of states live at once would not fit the register file; the
+// systems this serves are small and launch-bound, the extra per-point GEMMs are noise).  H = 32 class nets only.
+constexpr int kMaxFusedNets = 4;
+struct FusedMultiArgs {
+  const float* coords;                    // [D][ldc]
+  const float* params[kMaxFusedNets];     // K x [P]
+  float* partials[kMaxFusedNets];         // TRAIN: K x [gridDim.x][P]
+  float* loss_partials;                   // [gridDim.x]
+  float* funcs;                           // optional [NF][ldj]
+  float* resid;                           // optional [NEQ][ldj]
+  int n, ldc, ldj;
+  float seed;
+};
+
+template <class C, int K, class PW, bool TRAIN>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(FusedMultiArgs a) {
+  static_assert(C::NOUT == 1 && !C::WIDE && K >= 2 && K <= kMaxFusedNets, "multi-network closure: n_out = 1, H <= 48, 2..4 nets");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WS = C::ldsWeightsEnd(TRAIN);          // LDS floats per weight image
+#pragma unroll
+  for (int k = 0; k < K; ++k) stage_weights<C, TRAIN>(lds + k * WS, a.params[k]);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  constexpr int WAVES = C::BWD_THREADS / 64;
+  const int ntiles = (a.n + 15) >> 4;
+  float* stage = lds + K * WS + wave * C::stageFloatsPerWave;
+  GradAcc<C> acc[K];
+  if constexpr (TRAIN) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) { acc_zero<C>(acc[k]); acc[k].bias = nullptr; }
+  }
+  float lsum = 0.f;
+  for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
+    const int n = tile * 16 + p;
+    const bool valid = n < a.n;
+    const int nn = valid ? n : a.n - 1;
+    float x[C::D];
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    float jets[K][C::NS], gout[K][C::NS], r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
+    sfor<K>([&](auto k_) {
+      constexpr int k = decltype(k_)::value;
+      LayerState<C> st[C::L];
+      f32x4 h[C::NS][C::NB];
+      KeptPlanes<C> kp;
+      tile_forward<C, TRAIN>(lds + k * WS, lane, q, x, st, h, kp);
+      tile_output<C, TRAIN>(lds + k * WS, q, h, jets[k]);
+    });
+    PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
+    if (valid && q == 0) {
+#pragma unroll
+      for (int e = 0; e < PW::NEQ; ++e) lsum = fmaf(r[e], r[e], lsum);
+      if (a.resid) {
+#pragma unroll
+        for (int e = 0; e < PW::NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];
+      }
+      if (a.funcs) {
+#pragma unroll
+        for (int m = 0; m < PW::NF; ++m) a.funcs[(size_t)m * a.ldj + n] = f[m];
+      }
+    }
+    if constexpr (TRAIN) {
+      sfor<K>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) gout[k][s] = valid ? gout[k][s] : 0.f;
+        LayerState<C> st[C::L];
+        f32x4 h[C::NS][C::NB];
+        KeptPlanes<C> kp;
+        tile_forward<C, true>(lds + k * WS, lane, q, x, st, h, kp);
+        tile_backward<C>(lds + k * WS, stage, lane, p, q, x, gout[k], st, acc[k], kp);
+      });
+    }
+  }
+  if constexpr (TRAIN) {
+    // block_reduce_store puts its regions right behind "the" weight image of the base it is given: hand it the last one
+    sfor<K>([&](auto k_) {
+      constexpr int k = decltype(k_)::value;
+      block_reduce_store<C, WAVES>(lds + (K - 1) * WS, acc[k], wave, lane, p, q, a.partials[k] + (size_t)blockIdx.x * C::P);
+    });
+  }
+  lsum = point_sum(quad_sum(lsum));
+  __syncthreads();
+  float* wl = lds + K * WS;
+  if (lane == 0) wl[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int w = 0; w < WAVES; ++w) v += wl[w];
+    a.loss_partials[blockIdx.x] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host-side sizes
 template <class C> constexpr size_t fwd_lds_bytes() { return sizeof(float) * C::ldsWeightsEnd(false); }
 template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock);
 template <class C> constexpr size_t fused_lds_bytes(bool train) {
   return train ? bwd_lds_bytes<C>(C::BWD_THREADS / 64) : sizeof(float) * (C::ldsWeightsEnd(false) + 16);
+}
+template <class C> constexpr size_t fused_multi_lds_bytes(int nets, bool train) {
+  return fused_lds_bytes<C>(train) + sizeof(float) * (size_t)(nets - 1) * C::ldsWeightsEnd(train);
 }
 template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock) {
   const int pp = (C::P + 3) & ~3;

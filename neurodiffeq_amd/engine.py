@@ -129,8 +129,10 @@ class FusedSystem:
         self.n_eq, self.n_funcs = len(self.program.residuals), len(self.program.funcs)
         self.kernel = codegen.load(self.program)
         self.fusedk = None
-        if single_kernel and codegen.can_fuse(self.program):
-            self.fusedk = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0]))
+        if single_kernel and codegen.can_fuse(self.program, self.descs):
+            fk = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0]))
+            if fk.lib.ndq_fused_lds_bytes() <= 160 * 1024:       # K weight images + staging must fit one workgroup's LDS
+                self.fusedk = fk
         self.flat = [FlatParams(n, self.device) for n in self.nets]
         # rows of the stream / adjoint-stream arrays of net k: [n_streams][n_out]
         self.ns = [self.program.streams[k].n_streams * self.program.streams[k].n_out for k in range(len(self.nets))]
@@ -182,7 +184,9 @@ class FusedSystem:
         b["partials"] = [torch.empty(nb, fp.numel, dtype=f32, device=dev) for nb, fp in zip(b["bwd_blocks"], self.flat)]
         if self.fusedk is not None:
             b["fused_blocks"] = self.fusedk.blocks(n)
-            b["fused_partials"] = torch.empty(b["fused_blocks"], self.flat[0].numel, dtype=f32, device=dev)
+            b["fused_partials_all"] = [torch.empty(b["fused_blocks"], fp.numel, dtype=f32, device=dev) for fp in self.flat]
+            b["fused_partials"] = b["fused_partials_all"][0]
+            b["fused_partials_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["fused_partials_all"]])
             b["fused_loss_partials"] = torch.zeros(b["fused_blocks"], dtype=f32, device=dev)
         b["jets_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["jets"]])
         b["gbar_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["gbar"]])
@@ -335,20 +339,24 @@ class FusedSystem:
         _lib.check(rc, "ndq_reduce_partials(loss)")
 
     def fused_closure(self, b, n, stream, train, n_global, slot, accumulate, want_funcs=False, want_resid=False):
-        """Single-network systems: the whole closure in ONE launch, then the two fixed-order second-stage sums."""
-        fp = self.flat[0]
-        fp.sync()
+        """The whole closure in ONE launch (one network, or 2..4 networks of one shape), then the fixed-order
+        second-stage sums."""
+        for fp in self.flat:
+            fp.sync()
         seed = 1.0 / (float(n_global) * self.n_eq)
-        rc = self.fusedk.lib.ndq_fused_launch(self._coord_ptr(b, 0), b["ld"], n, _ptr(fp.flat),
-                                              _ptr(b["fused_partials"]), _ptr(b["fused_loss_partials"]),
-                                              _ptr(b["funcs"]) if want_funcs else None,
-                                              _ptr(b["resid"]) if want_resid else None, b["ld"], seed,
-                                              1 if train else 0, stream)
-        _lib.check(rc, "ndq_fused_launch")
+        params_pp = (_c_vp * len(self.flat))(*[fp.flat.data_ptr() for fp in self.flat])
+        rc = self.fusedk.lib.ndq_fused_launch_multi(self._coord_ptr(b, 0), b["ld"], n, params_pp,
+                                                    b["fused_partials_pp"] if train else None,
+                                                    _ptr(b["fused_loss_partials"]),
+                                                    _ptr(b["funcs"]) if want_funcs else None,
+                                                    _ptr(b["resid"]) if want_resid else None, b["ld"], seed,
+                                                    1 if train else 0, stream)
+        _lib.check(rc, "ndq_fused_launch_multi")
         if train:
-            rc = self.L.ndq_reduce_partials(_ptr(b["fused_partials"]), b["fused_blocks"], fp.numel, _ptr(fp.grad),
-                                            1 if accumulate else 0, 1.0, stream)
-            _lib.check(rc, "ndq_reduce_partials")
+            for fp, part in zip(self.flat, b["fused_partials_all"]):
+                rc = self.L.ndq_reduce_partials(_ptr(part), b["fused_blocks"], fp.numel, _ptr(fp.grad),
+                                                1 if accumulate else 0, 1.0, stream)
+                _lib.check(rc, "ndq_reduce_partials")
         rc = self.L.ndq_reduce_partials(_ptr(b["fused_loss_partials"]), b["fused_blocks"], 1,
                                         _c_vp(self.loss_buf.data_ptr() + 4 * slot), 0, seed, stream)
         _lib.check(rc, "ndq_reduce_partials(loss)")
@@ -357,7 +365,7 @@ class FusedSystem:
     HIST = 8192
 
     def fast_ready(self):
-        return self.fusedk is not None
+        return self.fusedk is not None and len(self.nets) == 1
 
     def fast_state(self):
         """Device-side epoch bookkeeping of the native fast path: loss ring, best-loss ping-pong, best snapshot."""
@@ -369,7 +377,7 @@ class FusedSystem:
                               best_flat=[torch.zeros_like(fp.grad) for fp in self.flat], parity=0, pending=0,
                               pending_valid=0, structs={},
                               launch=(ctypes.cast(self.fusedk.lib.ndq_fused_launch, ctypes.c_void_p).value
-                                      if self.fusedk is not None else None))
+                                      if self.fast_ready() else None))
         return self._fast
 
     def epoch_tail(self, kind, n_batches, track_best, adam_slots=None):
