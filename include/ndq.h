@@ -158,6 +158,16 @@ typedef struct ndq_fused_step {
 int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_step, int hist_index, int parity,
                        void* stream);
 
+/* The same for a system of 2..4 networks of one shape served by ONE closure launch (generated launcher taking host
+ * arrays of per-network device pointers): steps[k] describes network k (params, partials, grad, Adam state, best
+ * snapshot; n / ld / blocks / seed / loss_partials / loss_hist / best_loss are read from steps[0]); after the closure
+ * kernel every network gets its fused second-stage-sums + tail kernel.  No data-parallel hook on this entry point. */
+typedef int (*ndq_fused_launch_multi_fn)(const float* coords, int ldc, int n, const float* const* params,
+                                         float* const* partials, float* loss_partials, float* funcs, float* resid,
+                                         int ldj, float seed, int train, void* stream);
+int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_launch_multi_fn launch,
+                             const float* coords, int adam_step, int hist_index, int parity, void* stream);
+
 /* Signature of a generated pointwise kernel launcher (one per traced PDE system, built by
  * neurodiffeq_amd/codegen.py with hipcc).  It evaluates the condition re-parameterisation (conditions.py
  * `parameterize`), the user's residuals (`diff_eqs`, solvers.py:380), the squared-residual partial sums

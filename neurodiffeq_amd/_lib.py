@@ -78,11 +78,12 @@ def lib():
     L.ndq_reduce_grad_loss.argtypes = [vp, ci, ci, vp, ci, vp, ci, vp, cf, vp]
     L.ndq_epoch_tail.argtypes = [vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp]
     L.ndq_fused_step_run.argtypes = [ctypes.POINTER(FusedStep), vp, ci, ci, ci, vp]
+    L.ndq_fused_multi_step_run.argtypes = [ctypes.POINTER(FusedStep), ci, vp, vp, ci, ci, ci, vp]
     L.ndq_mlp_register.argtypes = [vp]
     L.ndq_sample.argtypes = [ctypes.POINTER(SamplerDesc), ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, vp, ci, vp]
     for name in ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks",
                  "ndq_mlp_jet_fwd", "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss",
-                 "ndq_epoch_tail", "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register"):
+                 "ndq_epoch_tail", "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run"):
         getattr(L, name).restype = ci
     _LIB = L
     return L
@@ -90,7 +91,7 @@ def lib():
 
 EXPORTS = ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks", "ndq_mlp_jet_fwd",
            "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss", "ndq_epoch_tail",
-           "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register")
+           "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run")
 
 
 def check(rc, what):

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) {
     a.t.v[i] = vi;
     a.t.p[i] = pi - (a.t.lr / a.t.bc1) * (mi / (sqrtf(vi) / a.t.bc2s + a.t.eps));
   }
-  if (blockIdx.x == 0 && tid == 0) {
+  if (blockIdx.x == 0 && tid == 0 && a.t.write_scalars) {
     *a.r.lout = loss;
     a.t.loss_hist[a.t.hist_index] = loss;
     a.t.best_loss[a.t.parity ^ 1] = better ? loss : best;
@@ -401,6 +401,46 @@ int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_st
   a.t.best_loss = s->best_loss; a.t.parity = parity; a.t.best_flat = s->best_flat; a.t.write_scalars = 1;
   hipLaunchKernelGGL(reduce_tail_kernel, dim3((s->n_params + 63) / 64), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
+}
+
+static int launch_reduce_tail(const ndq_fused_step* s, const float* loss_partials, int blocks, float seed, float* loss_hist,
+                              float* best_loss, int adam_step, int hist_index, int parity, int write_scalars, void* stream) {
+  ReduceTailArgs a;
+  a.r = Reduce2Args{s->partials, blocks, s->n_params, s->grad, 0, loss_partials, blocks, s->loss_slot, seed};
+  a.t.p = s->params; a.t.g = s->grad; a.t.m = s->adam_m; a.t.v = s->adam_v; a.t.len = s->n_params;
+  a.t.lr = s->lr; a.t.b1 = s->beta1; a.t.b2 = s->beta2; a.t.eps = s->eps; a.t.wd = s->weight_decay;
+  a.t.bc1 = (float)(1.0 - pow((double)s->beta1, (double)adam_step));
+  a.t.bc2s = (float)sqrt(1.0 - pow((double)s->beta2, (double)adam_step));
+  a.t.loss_slots = s->loss_slot; a.t.nb = 1; a.t.loss_hist = loss_hist; a.t.hist_index = hist_index;
+  a.t.best_loss = best_loss; a.t.parity = parity; a.t.best_flat = s->best_flat; a.t.write_scalars = write_scalars;
+  hipLaunchKernelGGL(reduce_tail_kernel, dim3((s->n_params + 63) / 64), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}
+
+int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_launch_multi_fn launch,
+                             const float* coords, int adam_step, int hist_index, int parity, void* stream) {
+  if (!steps || !launch || !coords || n_nets < 1 || n_nets > 4 || adam_step <= 0 || hist_index < 0 ||
+      (parity != 0 && parity != 1))
+    return NDQ_EINVAL;
+  const ndq_fused_step& s0 = steps[0];
+  if (!s0.loss_hist || !s0.best_loss || !s0.loss_partials) return NDQ_EINVAL;
+  const float* params[4];
+  float* partials[4];
+  for (int k = 0; k < n_nets; ++k) {
+    if (!steps[k].params || !steps[k].partials || !steps[k].grad || !steps[k].adam_m || !steps[k].adam_v ||
+        !steps[k].loss_slot)
+      return NDQ_EINVAL;
+    params[k] = steps[k].params;
+    partials[k] = steps[k].partials;
+  }
+  int rc = launch(coords, s0.ldc, s0.n, params, partials, s0.loss_partials, nullptr, nullptr, s0.ldj, s0.seed, 1, stream);
+  if (rc) return rc;
+  for (int k = 0; k < n_nets; ++k) {
+    rc = launch_reduce_tail(&steps[k], s0.loss_partials, s0.blocks, s0.seed, s0.loss_hist, s0.best_loss, adam_step,
+                            hist_index, parity, k == 0 ? 1 : 0, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int ndq_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,

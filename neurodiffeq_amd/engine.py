@@ -364,8 +364,10 @@ class FusedSystem:
     # ------------------------------------------------------------------------------------------ native epoch
     HIST = 8192
 
-    def fast_ready(self):
-        return self.fusedk is not None and len(self.nets) == 1
+    def fast_ready(self, dist=None):
+        """Can a whole training epoch go through one native call?  (single-launch closure; the data-parallel hook exists
+        for one network only)"""
+        return self.fusedk is not None and (len(self.nets) == 1 or dist is None)
 
     def fast_state(self):
         """Device-side epoch bookkeeping of the native fast path: loss ring, best-loss ping-pong, best snapshot."""
@@ -377,7 +379,9 @@ class FusedSystem:
                               best_flat=[torch.zeros_like(fp.grad) for fp in self.flat], parity=0, pending=0,
                               pending_valid=0, structs={},
                               launch=(ctypes.cast(self.fusedk.lib.ndq_fused_launch, ctypes.c_void_p).value
-                                      if self.fast_ready() else None))
+                                      if self.fusedk is not None else None),
+                              launch_multi=(ctypes.cast(self.fusedk.lib.ndq_fused_launch_multi, ctypes.c_void_p).value
+                                            if self.fusedk is not None else None))
         return self._fast
 
     def epoch_tail(self, kind, n_batches, track_best, adam_slots=None):
@@ -408,6 +412,41 @@ class FusedSystem:
             fs["pending"] += 1
         else:
             fs["pending_valid"] += 1
+        fs["parity"] ^= 1
+
+    def fast_train_epoch_multi(self, batch, adam_slots, track_best):
+        """fast_train_epoch for 2..4 networks behind ONE closure launch: closure kernel, then one fused sums + tail
+        kernel per network, all from one native call (ndq_fused_multi_step_run)."""
+        fs = self.fast_state()
+        b, n = self.upload(batch)
+        K = len(self.flat)
+        key = (n, b["ld"], id(b), "multi")
+        arr = fs["structs"].get(key)
+        if arr is None:
+            arr = (_lib.FusedStep * K)()
+            for k, fp in enumerate(self.flat):
+                st = arr[k]
+                st.n, st.ldc, st.ldj, st.blocks, st.n_params = n, b["ld"], b["ld"], b["fused_blocks"], fp.numel
+                st.partials, st.loss_partials = b["fused_partials_all"][k].data_ptr(), b["fused_loss_partials"].data_ptr()
+                st.grad, st.loss_slot = fp.grad.data_ptr(), fp.grad_loss.data_ptr() + 4 * fp.numel
+                st.loss_hist, st.best_loss = fs["loss_hist"].data_ptr(), fs["best_loss"].data_ptr()
+            fs["structs"][key] = arr
+        step = None
+        for k, fp in enumerate(self.flat):
+            fp.sync()
+            m, v, group, step_k = adam_slots[k]
+            step = step_k if step is None else step
+            st = arr[k]
+            st.params = fp.flat.data_ptr()
+            st.seed = 1.0 / (float(n) * self.n_eq)
+            st.best_flat = fs["best_flat"][k].data_ptr() if track_best else None
+            st.adam_m, st.adam_v = m.data_ptr(), v.data_ptr()
+            b1, b2 = group["betas"]
+            st.lr, st.beta1, st.beta2, st.eps, st.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]
+        rc = self.L.ndq_fused_multi_step_run(arr, K, _c_vp(fs["launch_multi"]), self._coord_ptr(b, 0), step,
+                                             fs["pending"], fs["parity"], self._stream())
+        _lib.check(rc, "ndq_fused_multi_step_run")
+        fs["pending"] += 1
         fs["parity"] ^= 1
 
     def fast_train_epoch(self, batch, optimizer, adam_slot, track_best, n_global=None, dist=None):

@@ -400,7 +400,10 @@ class BaseSolver(ABC):
                 return False
             slots = [self.optimizer.fast_slot(fp) for fp in system.flat]
         shard = self.dist
-        if train and nb == 1 and system.fast_ready():
+        if train and nb == 1 and len(system.flat) > 1 and system.fast_ready(shard) and len({s[3] for s in slots}) == 1:
+            # several networks behind one closure launch, all at the same Adam step (always, unless states were edited)
+            system.fast_train_epoch_multi(first_batch, slots, track_best)
+        elif train and nb == 1 and len(system.flat) == 1 and system.fast_ready(shard):
             batch = first_batch
             n_all = batch[0].shape[0]
             if shard is not None:
