@@ -121,9 +121,11 @@ class PointwiseProgram:
     streams    : {net_idx: NetStreams}
     """
 
-    def __init__(self, graph: Graph, residuals, funcs, n_nets, widen=None, allow_lap=None):
+    def __init__(self, graph: Graph, residuals, funcs, n_nets, widen=None, allow_lap=None, unify=None):
         """widen(net_idx, NetStreams): optional hook that may enlarge ``first`` / ``mask2`` of a net to the nearest
         stream set libndq.so has kernels for (slots are assigned after it ran).
+        unify(streams dict): optional hook run before ``widen`` that may give several networks one common stream set
+        (so that one multi-network closure kernel can serve them).
         allow_lap(net_idx, coords) -> bool: may the second derivatives of net k w.r.t. ``coords`` be merged into one
         Laplacian stream (asked only after the merge has been proven valid symbolically)."""
         self.g = graph
@@ -146,6 +148,8 @@ class PointwiseProgram:
             if n[0] == "net":
                 self.streams[n[1]].need(n[3])
                 self.symbols.append(i)
+        if unify is not None:
+            unify(self.streams)
         if widen is not None:
             for k, st in self.streams.items():
                 widen(k, st)

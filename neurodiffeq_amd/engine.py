@@ -110,8 +110,32 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
         st.first, st.mask2 = best[1].first, best[1].mask2
         descs[k] = best[1]
 
+    def unify(streams):
+        """2..4 networks of ONE shape reading all coordinates: give them the union of their stream sets, so that the
+        multi-network closure kernel (one launch for the whole system) can serve them; a network then carries at most
+        a few streams it does not need -- these systems are launch-bound, not compute-bound."""
+        K = len(nets)
+        if not (2 <= K <= 4) or len(streams) != K or os.environ.get("NDQ_NO_MULTI_FUSE"):
+            return
+        shape = {(i["d"], i["hidden"], i["layers"], i["act"], i["n_out"]) for i in infos}
+        if len(shape) != 1 or infos[0]["n_out"] != 1 or infos[0]["hidden"] > 48:
+            return
+        if any(tuple(st.deps) != tuple(range(n_coords)) for st in streams.values()):
+            return
+        sts = list(streams.values())
+        if len({(st.first, st.mask2, st.lap) for st in sts}) == 1:
+            return
+        lap = max(st.lap for st in sts)
+        if lap and any((not st.lap) and st.mask2 for st in sts):
+            return              # some network needs its second derivatives one by one, another only their sum
+        first, mask2 = max(st.first for st in sts), 0
+        for st in sts:
+            mask2 |= st.mask2
+        for st in sts:
+            st.first, st.mask2, st.lap = first, mask2, lap
+
     program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets), widen=widen,
-                                       allow_lap=allow_lap)
+                                       allow_lap=allow_lap, unify=unify)
     return program, descs
 
 

@@ -365,7 +365,7 @@ def test_zoo_closure_matches_autograd_oracle(name, mode):
     if mode == "1k" and fs.fusedk is None:
         pytest.skip("no single-launch closure for this system (networks of different shapes / stream sets)")
     assert (fs.fusedk is not None) == (mode == "1k")
-    assert mode == "3k" or len(nets) == 1 or name in ("coupled_sin",)         # the multi-network closure kernel
+    assert mode == "3k" or len(nets) == 1 or name in ("coupled_sin", "stokes_like")   # the multi-network closure kernel
     b, n = fs.step([c.float() for c in coords], train=True, slot=0, want_funcs=True, want_resid=True)
     torch.cuda.synchronize()
     errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), want["funcs"].numpy()),
