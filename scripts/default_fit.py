@@ -40,4 +40,16 @@ for fused in ("auto", "off"):
     torch.cuda.synchronize()
     out[f"pde_{fused}_us_per_epoch"] = round((time.perf_counter() - t0) / (epochs // 2) * 1e6, 1)
     out[f"pde_{fused}_final_valid_loss"] = s.metrics_history["valid_loss"][-1]
+    torch.manual_seed(0)          # the README's Lotka-Volterra system: two default networks, one per unknown
+    s = Solver1D(lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)], [IVP(0.0, 1.5), IVP(0.0, 1.0)],
+                 t_min=0.1, t_max=12.0)
+    s.fused = fused
+    s.fit(20, tqdm_file=None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s.fit(epochs // 2, tqdm_file=None)
+    _ = s.metrics_history["valid_loss"][-1]
+    torch.cuda.synchronize()
+    out[f"system_{fused}_us_per_epoch"] = round((time.perf_counter() - t0) / (epochs // 2) * 1e6, 1)
+    out[f"system_{fused}_final_valid_loss"] = s.metrics_history["valid_loss"][-1]
 print(json.dumps(out))
