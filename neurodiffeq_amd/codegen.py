@@ -578,6 +578,13 @@ class FusedKernel:
         return self.lib.ndq_fused_blocks(n)
 
 
+def _cache_key(source):
+    """Cache key of a generated module: its source (with the package location factored out, so a relocated checkout
+    keeps its cache), the kernel headers it instantiates and the extra compile flags."""
+    text = source.replace(HERE, "<neurodiffeq_amd>")
+    return hashlib.sha1((text + _header_digest() + " ".join(_extra_flags())).encode()).hexdigest()[:16]
+
+
 def _header_digest():
     h = hashlib.sha1()
     for name in ("csrc/ndq_mlp.h", "csrc/ndq_launch.h", "../include/ndq.h"):
@@ -623,7 +630,7 @@ extern "C" const ndq_mlp_kernels* ndq_ext_kernels(void) {{
 def build_mlp_ext(desc, force=False):
     os.makedirs(JIT_DIR, exist_ok=True)
     source = mlp_ext_source(desc)
-    key = hashlib.sha1((source + _header_digest() + " ".join(_extra_flags())).encode()).hexdigest()[:16]
+    key = _cache_key(source)
     so = os.path.join(JIT_DIR, f"mlp_{key}.so")
     src = os.path.join(JIT_DIR, f"mlp_{key}.hip")
     if os.path.exists(so) and not force:
@@ -670,7 +677,7 @@ def build_fused(program: PointwiseProgram, desc, force=False):
     source AND the kernel header it instantiates)."""
     os.makedirs(JIT_DIR, exist_ok=True)
     source = program.fused_source(desc)
-    key = hashlib.sha1((source + _header_digest() + " ".join(_extra_flags())).encode()).hexdigest()[:16]
+    key = _cache_key(source)
     so = os.path.join(JIT_DIR, f"fused_{key}.so")
     src = os.path.join(JIT_DIR, f"fused_{key}.hip")
     if os.path.exists(so) and not force:
