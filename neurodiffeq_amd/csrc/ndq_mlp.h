@@ -119,7 +119,7 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3 };
 #ifndef NDQ_BWD_THREADS
 // 512 threads (2 waves per SIMD, 256 registers each) measured ~3 % faster on the C2 closure kernel, but every kernel
 // that then spills to scratch (mlp_jet_bwd<2,1,5,..>: 28 VGPRs, <2,1,7,..>: 64) came back with a few corrupted
-// workgroup rows per launch, different ones each time (scripts/stress_bwd.py; the spill-free 1-D kernels and all
+// workgroup rows per launch, different ones each time (tests: test_bwd_launches_are_bit_reproducible; the spill-free 1-D kernels and all
 // one-wave-per-SIMD kernels, spilling or not, are bit-reproducible over thousands of launches).  Cause not found --
 // two scratch-using waves on one SIMD is the common factor -- so: one wave per SIMD.
 #define NDQ_BWD_THREADS 256

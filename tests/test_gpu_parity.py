@@ -213,6 +213,29 @@ def test_bwd_is_linear_in_gbar_and_deterministic(L):
     assert res["linearity"] < 5e-6 and res["shard_additivity"] < 5e-6, res
 
 
+@pytest.mark.parametrize("name,n", [("c2", 8195), ("c2full", 4099), ("c3", 8195), ("c1", 4099)])
+def test_bwd_launches_are_bit_reproducible(L, name, n):
+    """100 launches of the adjoint kernel on identical inputs give 100 bit-identical partial-sum blocks (a build with
+    two scratch-using waves per SIMD failed exactly this: a few corrupted workgroup rows per launch)."""
+    dims, act, _, _, streams = ARCH[name]
+    rng = np.random.default_rng(7)
+    flat = _params(name, rng)
+    coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
+    gbar = rng.standard_normal((len(streams), dims[-1], n)).astype(np.float32)
+    ld = (n + 63) // 64 * 64
+    c = torch.zeros(dims[0], ld, device="cuda"); c[:, :n] = torch.from_numpy(coords)
+    g = torch.zeros(len(streams), dims[-1], ld, device="cuda"); g[:, :, :n] = torch.from_numpy(gbar)
+    p = torch.from_numpy(flat).cuda()
+    d = _desc(name)
+    nb, P, reps = L.ndq_mlp_bwd_blocks(ctypes.byref(d), n), L.ndq_mlp_num_params(ctypes.byref(d)), 100
+    parts = torch.zeros(reps, nb, P, device="cuda")
+    for r in range(reps):
+        assert L.ndq_mlp_jet_bwd(ctypes.byref(d), c.data_ptr(), ld, n, p.data_ptr(), g.data_ptr(), ld, parts[r].data_ptr(),
+                                 _stream()) == 0
+    torch.cuda.synchronize()
+    assert int((parts != parts[0:1]).any(dim=2).any(dim=1).sum().item()) == 0
+
+
 def test_bad_arguments_are_rejected(L):
     from neurodiffeq_amd import _lib
     d = _desc("c2")
