@@ -20,6 +20,7 @@ extern "C" {
 #define NDQ_ACT_SIN 1  /* neurodiffeq.networks.SinActv (networks.py:142-152) */
 #define NDQ_ACT_SIGMOID 2 /* torch.nn.Sigmoid passed as FCNN(actv=...) (networks.py:52-53) */
 #define NDQ_ACT_SWISH 3   /* neurodiffeq.networks.Swish with its default fixed beta = 1 (networks.py:155-175) */
+#define NDQ_ACT_APTX 4    /* neurodiffeq.networks.APTx with its default fixed alpha = 1, beta = 1, gamma = 0.5 (networks.py:177-209) */
 
 /* Shape of one FCNN (networks.py:59-66: Linear(d,h) actv [Linear(h,h) actv]* Linear(h,n_out)) plus the set of
  * derivative streams of its raw output that the residual needs.  Stream order in every jets/gbar array:

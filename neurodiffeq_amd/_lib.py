@@ -5,7 +5,7 @@ import os
 
 from . import _build
 
-NDQ_ACT_TANH, NDQ_ACT_SIN, NDQ_ACT_SIGMOID, NDQ_ACT_SWISH = 0, 1, 2, 3
+NDQ_ACT_TANH, NDQ_ACT_SIN, NDQ_ACT_SIGMOID, NDQ_ACT_SWISH, NDQ_ACT_APTX = 0, 1, 2, 3, 4
 
 
 class MlpDesc(ctypes.Structure):

@@ -610,7 +610,7 @@ def mlp_ext_allowed(desc):
     for a in range(desc.d):
         diag |= 1 << pair_list(desc.d).index((a, a))
     return (1 <= desc.d <= 3 and desc.hidden % 16 == 0 and 16 <= desc.hidden <= 64 and 1 <= desc.layers <= 4
-            and desc.act in (0, 1, 2, 3) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
+            and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
             and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0)))
 

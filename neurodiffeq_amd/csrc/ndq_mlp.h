@@ -111,7 +111,7 @@ struct Streams {
 
 // ------------------------------------------------------------------------------------------------ activations
 // state kept per hidden unit: t = sigma(z) and c (only where sigma' is not a function of t).
-enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3 };
+enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 };
 
 #ifndef NDQ_FAST_TANH
 #define NDQ_FAST_TANH 1
@@ -203,6 +203,25 @@ template <> struct Act<ACT_SWISH> {
   }
   static __device__ __forceinline__ float s3(float t, float c, float) {
     return (1.f - c) * fmaf(t, fmaf(6.f * c, c - 1.f, 1.f), 3.f * c * fmaf(-2.f, c, 1.f));
+  }
+};
+
+// APTx with its default fixed parameters alpha = 1, beta = 1, gamma = 1/2 (networks.py:177-209): f = z (1 + tanh z) / 2.
+// State: t = f, c = z (z cannot be recovered from f and tanh z where 1 + tanh z underflows); with T = tanh z
+//   f1 = (1 + T)/2 + z (1 - T^2)/2,  f2 = (1 - T^2)(1 - z T),  f3 = (1 - T^2)(3 z T^2 - 3 T - z)
+template <> struct Act<ACT_APTX> {
+  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { c = z; t = 0.5f * z * (1.f + tanh_fast(z)); }
+  static __device__ __forceinline__ float s1(float, float z) {
+    const float T = tanh_fast(z);
+    return 0.5f * fmaf(z, fmaf(-T, T, 1.f), 1.f + T);
+  }
+  static __device__ __forceinline__ float s2(float, float z, float) {
+    const float T = tanh_fast(z);
+    return fmaf(-T, T, 1.f) * fmaf(-z, T, 1.f);
+  }
+  static __device__ __forceinline__ float s3(float, float z, float) {
+    const float T = tanh_fast(z);
+    return fmaf(-T, T, 1.f) * fmaf(3.f * z * T, T, fmaf(-3.f, T, -z));
   }
 };
 
@@ -359,7 +378,7 @@ __device__ __forceinline__ int opaque_zero() {
 template <class C>
 struct LayerState {
   float t[C::NB][4];                 // sigma(z)
-  float c[C::NB][4];                 // second state value: cos(z) for sin, sigma(z) for swish; unused (dead) otherwise
+  float c[C::NB][4];                 // second state value: cos(z) for sin, sigma(z) for swish, z for aptx; unused (dead) otherwise
   f32x4 z[C::NS][C::NB];             // pre-activation derivative streams (index 0 unused: value is in t)
 };
 

@@ -83,7 +83,7 @@ class FCNN(nn.Module):
 
 # ------------------------------------------------------------------------------------------- kernel-side description
 _ACT_IDS = {nn.Tanh: _lib.NDQ_ACT_TANH, SinActv: _lib.NDQ_ACT_SIN, nn.Sigmoid: _lib.NDQ_ACT_SIGMOID,
-            Swish: _lib.NDQ_ACT_SWISH}
+            Swish: _lib.NDQ_ACT_SWISH, APTx: _lib.NDQ_ACT_APTX}
 
 
 def describe(net):
@@ -103,6 +103,8 @@ def describe(net):
         return None
     if any(isinstance(a, Swish) and (a.trainable or a.beta != 1.0) for a in acts):
         return None          # the kernels carry Swish with its default fixed beta = 1 only
+    if any(isinstance(a, APTx) and (a.trainable or (a.alpha, a.beta, a.gamma) != (1.0, 1.0, 0.5)) for a in acts):
+        return None          # ... and APTx with its default fixed parameters
     hidden = linears[0].out_features
     if hidden % 16 or any(l.in_features != hidden or l.out_features != hidden for l in linears[1:-1]):
         return None

@@ -60,7 +60,14 @@ class SwishRef(nn.Module):
         return x * torch.sigmoid(x)
 
 
-ACTIVATIONS = {"tanh": nn.Tanh, "sin": Sin, "sigmoid": nn.Sigmoid, "swish": SwishRef}
+class APTxRef(nn.Module):
+    """(alpha + tanh(beta x)) * gamma * x with the defaults alpha = 1, beta = 1, gamma = 0.5 (networks.py:177-209)."""
+
+    def forward(self, x):
+        return (1.0 + torch.tanh(x)) * 0.5 * x
+
+
+ACTIVATIONS = {"tanh": nn.Tanh, "sin": Sin, "sigmoid": nn.Sigmoid, "swish": SwishRef, "aptx": APTxRef}
 
 
 def make_fcnn(n_in, n_out, hidden, act="tanh", dtype=torch.float32):

@@ -35,6 +35,11 @@ def act_derivs(name, z):
             return s, d1, d2, d3
         # Leibniz on z * s(z)  (Swish, beta = 1: networks.py:155-175)
         return z * s, s + z * d1, 2 * d1 + z * d2, 3 * d2 + z * d3
+    if name == "aptx":        # z (1 + tanh z) / 2: APTx with alpha = 1, beta = 1, gamma = 1/2 (networks.py:177-209); Leibniz
+        t = np.tanh(z)
+        u, u1 = 1 + t, 1 - t * t
+        u2, u3 = -2 * t * u1, -2 * u1 * (1 - 3 * t * t)
+        return 0.5 * z * u, 0.5 * (u + z * u1), 0.5 * (2 * u1 + z * u2), 0.5 * (3 * u2 + z * u3)
     raise KeyError(name)
 
 

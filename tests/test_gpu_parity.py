@@ -50,6 +50,8 @@ ARCH = {
     "sw1": ((1, 32, 32, 1), "swish", 3, (1, 1, 1), [(), (0,), (0, 0)]),
     "sg1": ((1, 32, 32, 1), "sigmoid", 2, (1, 1, 0), [(), (0,)]),
 }
+# APTx has no kernels in libndq.so's table: the descriptor is served by an extension module compiled on first use
+ARCH_EXT = {"ap2": ((2, 32, 32, 1), "aptx", 4, (2, 1, 5), [(), (0,), (1,), (0, 0), (1, 1)])}
 
 
 def _parts(m):
@@ -155,6 +157,29 @@ def _groups(name):
 
 
 # ------------------------------------------------------------------------------------------------ MLP kernels
+def test_extension_module_kernels_match_jet_oracle(L):
+    """A descriptor outside libndq.so's table (APTx activation): codegen.ensure_mlp_kernels builds + registers it, then
+    the ordinary C-ABI entry points serve it."""
+    from neurodiffeq_amd import codegen
+    ARCH.update(ARCH_EXT)
+    try:
+        d = _desc("ap2")
+        assert codegen.ensure_mlp_kernels(d) and L.ndq_mlp_supported(ctypes.byref(d)) == 1
+        dims, act, _, _, streams = ARCH["ap2"]
+        rng = np.random.default_rng(11)
+        flat = _params("ap2", rng)
+        n = 1000
+        coords = rng.uniform(-1.0, 1.0, (2, n)).astype(np.float32)
+        got = _fwd(L, "ap2", coords, flat)
+        want = _oracle_jets(flat, dims, act, coords, streams)
+        assert max(float(np.linalg.norm(got[s].T - want[m]) / np.linalg.norm(want[m])) for s, m in enumerate(streams)) < TOL
+        gbar = rng.standard_normal((len(streams), 1, n)).astype(np.float32)
+        assert rel_l2(_bwd(L, "ap2", coords, flat, gbar), _oracle_vjp(flat, dims, act, coords, streams, gbar)) < TOL
+    finally:
+        for k in ARCH_EXT:
+            ARCH.pop(k, None)
+
+
 @pytest.mark.parametrize("name", list(ARCH))
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4099])
 def test_mlp_jet_fwd_matches_jet_oracle(L, name, n):
@@ -368,7 +393,7 @@ def test_fused_closure_matches_oracle_at_size(name, size, mode):
 @pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide",
                                   "stokes_like", "poisson3d", "hessian3d", "shell", "swish_laplace", "sigmoid_mixed",
                                   "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
-                                  "shape_16x2_sin", "shape_32x1"])
+                                  "shape_16x2_sin", "shape_32x1", "aptx_burgers"])
 def test_zoo_closure_matches_autograd_oracle(name, mode):
     """Systems outside the BASELINE set (tests/zoo.py): second-order IVP, sin networks, mixed second derivatives, first
     order only, three coordinates (Laplacian-merged, diagonal and full Hessian stream sets), three networks."""

@@ -48,7 +48,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None):
         info = describe(net)
         dims = (info["d"],) + (info["hidden"],) * info["layers"] + (info["n_out"],)
         npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
-        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish")[info["act"]]))
+        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx")[info["act"]]))
         flats.append(np.asarray(params[off:off + npar], np.float64))
         off += npar
     # a ("L", a, b, ..) symbol is the Laplacian stream = sum of the pure second derivatives (a,a), (b,b), ..
@@ -107,7 +107,8 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "poisson3d": [(1, 41, 1)], "hessian3d": [(1, 63, 0)], "shell": [(1, 41, 0)],
                "swish_laplace": [(1, 5, 1)], "sigmoid_mixed": [(1, 7, 0)], "swish_ode": [(1, 1, 0), (1, 0, 0)],
                "bundle_decay": [(1, 0, 0)], "bundle_bvp": [(1, 1, 0)], "shape_64x2": [(1, 5, 1)], "shape_32x3": [(1, 5, 1)],
-               "shape_48x2": [(1, 5, 1)], "shape_16x2_sin": [(1, 5, 1)], "shape_32x1": [(1, 5, 1)]}
+               "shape_48x2": [(1, 5, 1)], "shape_16x2_sin": [(1, 5, 1)], "shape_32x1": [(1, 5, 1)],
+               "aptx_burgers": [(1, 1, 0)]}
 
 
 @pytest.mark.parametrize("name", zoo.NAMES)

@@ -14,6 +14,7 @@ CASES = [
     (2, 64, 3, "tanh", [(0, 0)]),
     (2, 32, 2, "swish", [(0, 0), (0, 1), (1, 1)]),     # the kernels' closed forms in (t, c) vs Leibniz on z * sigma(z)
     (1, 32, 2, "sigmoid", [(0, 0)]),
+    (2, 32, 2, "aptx", [(0, 0), (1, 1)]),
 ]
 
 

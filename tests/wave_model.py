@@ -34,6 +34,9 @@ def act_derivs(act, z):
             return c, s1, s1 * (1 - 2 * c), s1 * (1 - 6 * s1)
         t = z * c
         return t, c + t * (1 - c), (1 - c) * (2 * c + t * (1 - 2 * c)), (1 - c) * (3 * c * (1 - 2 * c) + t * (1 - 6 * c + 6 * c * c))
+    if act == "aptx":                      # the kernel's closed forms in (z, T = tanh z), Act<ACT_APTX>
+        T = np.tanh(z)
+        return 0.5 * z * (1 + T), 0.5 * ((1 + T) + z * (1 - T * T)), (1 - T * T) * (1 - z * T), (1 - T * T) * (3 * z * T * T - 3 * T - z)
     s, c = np.sin(z), np.cos(z)
     return s, c, -s, -c
 

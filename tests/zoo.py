@@ -26,8 +26,8 @@ class System:
     def product(self):
         """(nets fp32, conditions, diff_eqs) on the neurodiffeq_amd API"""
         from neurodiffeq_amd import diff
-        from neurodiffeq_amd.networks import FCNN, SinActv, Swish
-        actv = {"tanh": torch.nn.Tanh, "sin": SinActv, "sigmoid": torch.nn.Sigmoid, "swish": Swish}
+        from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx
+        actv = {"tanh": torch.nn.Tanh, "sin": SinActv, "sigmoid": torch.nn.Sigmoid, "swish": Swish, "aptx": APTx}
         nets = [FCNN(i, o, hidden_units=h, actv=actv[a]) for i, o, h, a in self.net_specs]
         return nets, self.conds(), self.pde(diff)
 
@@ -139,6 +139,12 @@ def build(name):
         conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
         return System(name, 2, [(2, 1, hidden, act)], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
                       lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, zero)])
+    if name == "aptx_burgers":        # APTx network (default parameters) on a Burgers-type problem; kernels built on first use
+        u0 = lambda x: -torch.sin(PI * x)
+        pde = lambda D: (lambda u, x, t: [D(u, t) + u * D(u, x) - 0.05 * D(u, x, order=2)])
+        conds = lambda: [C.IBVP1D(-1.0, 1.0, 0.0, u0, x_min_val=zero, x_max_val=zero)]
+        return System(name, 2, [(2, 1, (32, 32), "aptx")], [(-1.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().ibvp1d_dd(-1.0, 1.0, 0.0, u0, zero, zero)])
     if name == "poisson3d":           # three coordinates, Laplacian -> one merged second-order stream
         pde = lambda D: (lambda u, x, y, z: [D(u, x, order=2) + D(u, y, order=2) + D(u, z, order=2)
                                              + torch.exp(-(x ** 2 + y ** 2 + z ** 2))])
@@ -172,7 +178,7 @@ def build(name):
 
 NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "poisson3d",
          "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
-         "shape_16x2_sin", "shape_32x1"]
+         "shape_16x2_sin", "shape_32x1", "aptx_burgers"]
 
 
 def spherical_solver_problem():
