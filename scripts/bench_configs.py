@@ -14,8 +14,11 @@ from neurodiffeq_amd.generators import ResidentBatchGenerator, SamplerGenerator 
 
 names = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c5"]
 for name in names:
+    size = None
+    if ":" in name:                                   # "c2:2048": the config at another batch size (grid side / point count)
+        name, size = name.split(":")[0], int(name.split(":")[1])
     torch.manual_seed(0)
-    solver, cfg = configs.make_solver(name)
+    solver, cfg = configs.make_solver(name, size)
     solver.fused = "require"
     torch.manual_seed(1)
     solver.generator["train"] = SamplerGenerator(ResidentBatchGenerator.presample(cfg["gen"], 4, "cuda"))
