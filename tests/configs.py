@@ -5,11 +5,12 @@ import math
 import torch
 
 from neurodiffeq_amd import diff
-from neurodiffeq_amd.conditions import IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis
+from neurodiffeq_amd.conditions import (IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis, BundleIVP,
+                                        DirichletBVPSpherical)
 from neurodiffeq_amd.function_basis import RealSphericalHarmonics
 from neurodiffeq_amd.generators import Generator1D, Generator2D, GeneratorSpherical
 from neurodiffeq_amd.operators import spherical_laplacian
-from neurodiffeq_amd.networks import FCNN, SinActv
+from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx
 
 PI = math.pi
 DEFAULT_SIZE = {"c1": 1024, "c2": 256, "c3": 512, "c5": 1024, "c4": 131072}
@@ -22,7 +23,7 @@ def lid(x):
 def make(name, size=None):
     """Returns dict(kind, pde, nets, conds, gen, n_points); nets use torch's default init (consumes the global RNG
     like the reference's constructors)."""
-    size = size or DEFAULT_SIZE[name]
+    size = size or DEFAULT_SIZE.get(name)
     zero = lambda s: 0
     if name == "c1":
         pde = lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)]
@@ -73,11 +74,36 @@ def make(name, size=None):
         gen = GeneratorSpherical(size, r0, r1)
         enforcer = lambda net, cond, coords: (cond.enforce(net, coords[0]) * Y(*coords[1:])).sum(dim=1, keepdim=True)
         return dict(kind="sph", pde=pde, nets=nets, conds=conds, gen=gen, n_points=size, dom=(r0, r1), enforcer=enforcer)
+    # ---- rows widened into after the BASELINE configs; fixed small sizes, goldens in tests/golden/w*.npz
+    if name == "w1":      # BundleSolver1D: u' + lam u = 0, u(0) = u0, bundle inputs (u0, lam)
+        ode = lambda u, t, lam: [diff(u, t) + lam * u]
+        nets = [FCNN(3, 1, hidden_units=(32, 32))]
+        conds = [BundleIVP(t_0=0.0, bundle_param_lookup={"u_0": 0})]
+        gen = Generator1D(8, 0.0, 1.0, "equally-spaced-noisy") ^ Generator1D(4, 0.5, 2.0, "equally-spaced-noisy") \
+            ^ Generator1D(4, 0.5, 2.0, "equally-spaced-noisy")
+        return dict(kind="bundle", ode=ode, pde=lambda u, t, u0, lam: ode(u, t, lam), nets=nets, conds=conds, gen=gen,
+                    n_points=128, dom=(0.0, 1.0), theta=((0.5, 0.5), (2.0, 2.0)), eq_param_index=(1,))
+    if name == "w2":      # SolverSpherical with its default FCNN(3, 1) and DirichletBVPSpherical
+        pde = lambda u, r, th, ph: [spherical_laplacian(u, r, th, ph)]
+        nets = [FCNN(3, 1, hidden_units=(32, 32))]
+        conds = [DirichletBVPSpherical(0.5, lambda th, ph: torch.cos(th), 2.0, lambda th, ph: 0.25 * torch.cos(th))]
+        return dict(kind="sph", pde=pde, nets=nets, conds=conds, gen=GeneratorSpherical(96, 0.5, 2.0), n_points=96,
+                    dom=(0.5, 2.0))
+    if name == "w3":      # Swish network on the C2 problem
+        c = make("c2", 12)
+        c["nets"] = [FCNN(2, 1, hidden_units=(32, 32), actv=Swish)]
+        return c
+    if name == "w4":      # APTx networks: second-order ODE with a Neumann-form IVP coupled to a first-order one
+        pde = lambda u, v, t: [diff(u, t, order=2) + v * diff(u, t) + u, diff(v, t) - u * v + torch.sin(t)]
+        nets = [FCNN(1, 1, hidden_units=(32, 32), actv=APTx) for _ in range(2)]
+        conds = [IVP(0.0, 1.0, u_0_prime=0.0), IVP(0.0, 0.5)]
+        return dict(kind="1d", pde=pde, nets=nets, conds=conds, gen=Generator1D(64, 0.0, 2.0, "equally-spaced-noisy"),
+                    n_points=64, dom=(0.0, 2.0))
     raise KeyError(name)
 
 
 def n_coords(cfg):
-    return {"1d": 1, "2d": 2, "sph": 3}[cfg["kind"]]
+    return {"1d": 1, "2d": 2, "sph": 3, "bundle": 3}[cfg["kind"]]
 
 
 def func_val(cfg):
@@ -88,12 +114,16 @@ def func_val(cfg):
 
 
 def make_solver(name, size=None, **kw):
-    from neurodiffeq_amd.solvers import Solver1D, Solver2D, SolverSpherical
+    from neurodiffeq_amd.solvers import Solver1D, Solver2D, SolverSpherical, BundleSolver1D
     cfg = make(name, size)
     kw.setdefault("n_batches_valid", 0)
     if cfg["kind"] == "sph":
         s = SolverSpherical(cfg["pde"], cfg["conds"], r_min=cfg["dom"][0], r_max=cfg["dom"][1], nets=cfg["nets"],
-                            train_generator=cfg["gen"], valid_generator=cfg["gen"], enforcer=cfg["enforcer"], **kw)
+                            train_generator=cfg["gen"], valid_generator=cfg["gen"], enforcer=cfg.get("enforcer"), **kw)
+    elif cfg["kind"] == "bundle":
+        s = BundleSolver1D(cfg["ode"], cfg["conds"], t_min=cfg["dom"][0], t_max=cfg["dom"][1], theta_min=cfg["theta"][0],
+                           theta_max=cfg["theta"][1], eq_param_index=cfg["eq_param_index"], nets=cfg["nets"],
+                           train_generator=cfg["gen"], valid_generator=cfg["gen"], **kw)
     elif cfg["kind"] == "1d":
         s = Solver1D(cfg["pde"], cfg["conds"], t_min=cfg["dom"][0], t_max=cfg["dom"][1], nets=cfg["nets"],
                      train_generator=cfg["gen"], valid_generator=cfg["gen"], **kw)

@@ -28,10 +28,11 @@ import torch
 import neurodiffeq  # noqa: E402  (sets default dtype fp64 + default device as an import side effect)
 from neurodiffeq import diff
 from neurodiffeq.utils import set_tensor_type
-from neurodiffeq.networks import FCNN, SinActv
-from neurodiffeq.conditions import IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis
+from neurodiffeq.networks import FCNN, SinActv, Swish, APTx
+from neurodiffeq.conditions import (IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis, BundleIVP,
+                                    DirichletBVPSpherical)
 from neurodiffeq.generators import Generator1D, Generator2D, GeneratorSpherical
-from neurodiffeq.solvers import Solver1D, Solver2D, SolverSpherical
+from neurodiffeq.solvers import Solver1D, Solver2D, SolverSpherical, BundleSolver1D
 from neurodiffeq.function_basis import RealSphericalHarmonics
 from neurodiffeq.operators import spherical_laplacian
 
@@ -109,7 +110,46 @@ def cfg_c4(n=96):
     return dict(kind="sph", pde=pde, nets=nets, conds=conds, gen=gen, enforcer=enforcer, r=(r0, r1))
 
 
-CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4}
+# ---- the rows the port widened into after the BASELINE configs: bundle solver, SolverSpherical with its
+# default 3-input network, Swish and APTx networks
+def cfg_w1():
+    """BundleSolver1D: u' + lam u = 0, u(0) = u0 with (u0, lam) sampled next to t (solvers.py:1189-1420)."""
+    ode = lambda u, t, lam: [diff(u, t) + lam * u]
+    nets = [FCNN(3, 1, hidden_units=(32, 32))]
+    conds = [BundleIVP(t_0=0.0, bundle_param_lookup={"u_0": 0})]
+    gen = Generator1D(8, 0.0, 1.0, "equally-spaced-noisy") ^ Generator1D(4, 0.5, 2.0, "equally-spaced-noisy") \
+        ^ Generator1D(4, 0.5, 2.0, "equally-spaced-noisy")
+    return dict(kind="bundle", pde=ode, nets=nets, conds=conds, gen=gen, t=(0.0, 1.0), theta=((0.5, 0.5), (2.0, 2.0)),
+                eq_param_index=(1,))
+
+
+def cfg_w2():
+    """SolverSpherical with its default network shape FCNN(3, 1) and DirichletBVPSpherical: Laplace in a shell."""
+    pde = lambda u, r, th, ph: [spherical_laplacian(u, r, th, ph)]
+    nets = [FCNN(3, 1, hidden_units=(32, 32))]
+    conds = [DirichletBVPSpherical(0.5, lambda th, ph: torch.cos(th), 2.0, lambda th, ph: 0.25 * torch.cos(th))]
+    gen = GeneratorSpherical(96, 0.5, 2.0)
+    return dict(kind="sph", pde=pde, nets=nets, conds=conds, gen=gen, r=(0.5, 2.0))
+
+
+def cfg_w3():
+    """Swish network (default beta) on the C2 problem."""
+    c = cfg_c2(12)
+    c["nets"] = [FCNN(2, 1, hidden_units=(32, 32), actv=Swish)]
+    return c
+
+
+def cfg_w4():
+    """APTx networks (default parameters) on a second-order ODE with a Neumann-form IVP, and a coupled first-order one."""
+    ode = lambda u, v, t: [diff(u, t, order=2) + v * diff(u, t) + u, diff(v, t) - u * v + torch.sin(t)]
+    nets = [FCNN(1, 1, hidden_units=(32, 32), actv=APTx) for _ in range(2)]
+    conds = [IVP(0.0, 1.0, u_0_prime=0.0), IVP(0.0, 0.5)]
+    gen = Generator1D(64, 0.0, 2.0, "equally-spaced-noisy")
+    return dict(kind="1d", pde=ode, nets=nets, conds=conds, gen=gen, t=(0.0, 2.0))
+
+
+CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
+           "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4}
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -123,13 +163,17 @@ def closure_once(cfg, coords32, dtype):
     for n in nets:
         n.zero_grad()
     batch = [c.detach().to(dtype).reshape(-1, 1).requires_grad_(True) for c in coords32]
-    if "enforcer" in cfg:
+    if cfg.get("enforcer") is not None:
         for c in cfg["conds"]:     # boundary coefficient rows follow the working precision
             c.R_0, c.R_1 = c.R_0.to(dtype), c.R_1.to(dtype)
         funcs = [cfg["enforcer"](n, c, batch) for n, c in zip(nets, cfg["conds"])]
     else:
         funcs = [c.enforce(n, *batch) for n, c in zip(nets, cfg["conds"])]
-    res = torch.cat(cfg["pde"](*funcs, *batch), dim=1)
+    if cfg["kind"] == "bundle":    # BundleSolver1D hands the ODE (funcs, t) and the bundle inputs picked by eq_param_index
+        picked = [batch[1 + i] for i in cfg["eq_param_index"]]
+        res = torch.cat(cfg["pde"](*funcs, batch[0], *picked), dim=1)
+    else:
+        res = torch.cat(cfg["pde"](*funcs, *batch), dim=1)
     loss = (res ** 2).mean()
     loss.backward()
     # a parameter the loss does not depend on (e.g. the output bias of the NS pressure net, which enters
@@ -173,10 +217,15 @@ def make(name, seed=0):
     pde = cfg["pde"]
     if cfg["kind"] == "sph":
         solver = SolverSpherical(pde, cfg["conds"], r_min=cfg["r"][0], r_max=cfg["r"][1], nets=cfg["nets"],
-                                 train_generator=gen, valid_generator=gen, n_batches_valid=0, enforcer=cfg["enforcer"])
+                                 train_generator=gen, valid_generator=gen, n_batches_valid=0, enforcer=cfg.get("enforcer"))
+    elif cfg["kind"] == "bundle":
+        solver = BundleSolver1D(pde, cfg["conds"], t_min=cfg["t"][0], t_max=cfg["t"][1], theta_min=cfg["theta"][0],
+                                theta_max=cfg["theta"][1], eq_param_index=cfg["eq_param_index"], nets=cfg["nets"],
+                                train_generator=gen, valid_generator=gen, n_batches_valid=0)
     else:
         Solver = Solver1D if cfg["kind"] == "1d" else Solver2D
-        kw = dict(t_min=0.1, t_max=12.0) if cfg["kind"] == "1d" else dict(xy_min=(0, 0), xy_max=(1, 1))
+        kw = dict(t_min=cfg.get("t", (0.1, 12.0))[0], t_max=cfg.get("t", (0.1, 12.0))[1]) if cfg["kind"] == "1d" \
+            else dict(xy_min=(0, 0), xy_max=(1, 1))
         solver = Solver(pde, cfg["conds"], nets=cfg["nets"], train_generator=gen, valid_generator=gen,
                         n_batches_valid=0, **kw)
     torch.manual_seed(seed + 2)

@@ -14,7 +14,7 @@ from oracle import jet_ref as J
 from tests import configs, zoo
 from tests.pw_cpu import run_cpu
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None}
 
 
 def rel_l2(a, b):
@@ -86,7 +86,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None):
 
 
 @pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
-                                      ("c4", True)])
+                                      ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True)])
 def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
