@@ -121,13 +121,17 @@ class PointwiseProgram:
     streams    : {net_idx: NetStreams}
     """
 
-    def __init__(self, graph: Graph, residuals, funcs, n_nets, widen=None, allow_lap=None, unify=None):
+    LOSS_KINDS = ("l2", "l1", "infinity")
+
+    def __init__(self, graph: Graph, residuals, funcs, n_nets, widen=None, allow_lap=None, unify=None, loss="l2"):
         """widen(net_idx, NetStreams): optional hook that may enlarge ``first`` / ``mask2`` of a net to the nearest
         stream set libndq.so has kernels for (slots are assigned after it ran).
         unify(streams dict): optional hook run before ``widen`` that may give several networks one common stream set
         (so that one multi-network closure kernel can serve them).
         allow_lap(net_idx, coords) -> bool: may the second derivatives of net k w.r.t. ``coords`` be merged into one
         Laplacian stream (asked only after the merge has been proven valid symbolically)."""
+        assert loss in self.LOSS_KINDS
+        self.loss = loss       # per-point loss term (losses.py:4-12): sum r^2 | sum |r| | max |r|, averaged by the host
         self.g = graph
         self.residuals = list(residuals)
         self.funcs = list(funcs)
@@ -248,11 +252,23 @@ class PointwiseProgram:
         for m, i in enumerate(self.funcs):
             L.append(f"  f[{m}] = {self._val(i)};")
         L.append("  if (!want_adj) return;")
-        L.append("// ---- adjoint of sum_e r_e^2 (scaled by seed) w.r.t. the network streams")
+        L.append(f"// ---- adjoint of the per-point loss term ({self.loss}, scaled by seed) w.r.t. the network streams")
         terms = {}
+        neq = len(self.residuals)
+        if self.loss == "infinity" and neq > 1:      # d max_e |r_e|: the first maximal entry carries the seed
+            L.append("  int amax = 0; float vmax = fabsf(r[0]);")
+            L.append(f"  for (int e = 1; e < {neq}; ++e) if (fabsf(r[e]) > vmax) {{ vmax = fabsf(r[e]); amax = e; }}")
         for e, i in enumerate(self.residuals):
             if dep.get(i):
-                terms.setdefault(i, []).append(f"(2.0f*seed)*{self._val(i)}")
+                v = self._val(i)
+                sign = f"(({v}) > 0.0f ? seed : (({v}) < 0.0f ? -seed : 0.0f))"
+                if self.loss == "l2":
+                    t = f"(2.0f*seed)*{v}"
+                elif self.loss == "l1" or neq == 1:
+                    t = sign
+                else:
+                    t = f"(amax == {e} ? {sign} : 0.0f)"
+                terms.setdefault(i, []).append(t)
         for i in reversed(res_order):
             if i not in terms or not dep[i]:
                 continue
@@ -291,11 +307,27 @@ class PointwiseProgram:
     def point_fn_source(self):
         nc = self.n_coords
         body = self._emit_point_fn()
+        neq = len(self.residuals)
+        if self.loss == "l2":
+            term = " + ".join(f"r[{e}]*r[{e}]" for e in range(neq)) or "0.0f"
+        elif self.loss == "l1":
+            term = " + ".join(f"fabsf(r[{e}])" for e in range(neq)) or "0.0f"
+        else:
+            term = "0.0f"
+            for e in range(neq):
+                term = f"fmaxf({term}, fabsf(r[{e}]))"
         return f"""NDQ_PW_INLINE void ndq_pw_point(const float* c, const float* s, float seed, int want_adj, float* r, float* f, float* g) {{
 {chr(10).join(f"  const float c{i} = c[{i}];" for i in range(nc))}
 {body}
 }}
+// per-point loss term ({self.loss}); the host averages it: seed = 1 / (N * n_eq) for l2 / l1, 1 / N for infinity
+NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
 """
+
+    @property
+    def loss_norm(self):
+        """what the sum over points of the per-point loss term is divided by, per point"""
+        return 1 if self.loss == "infinity" else max(len(self.residuals), 1)
 
     def fused_source(self, desc):
         """Source of the single-launch closure kernel (csrc/ndq_mlp.h: fused_closure_kernel for one network,
@@ -339,6 +371,7 @@ namespace {{
 using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}>;
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf};
+  static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
   static __device__ __forceinline__ void apply(const float (&x)[CFG::D], {jets_t}, float seed,
                                                int want_adj, float (&r)[{max(neq, 1)}], float (&f)[{max(nf, 1)}],
                                                {gj_t}) {{
@@ -461,8 +494,7 @@ extern "C" __global__ __launch_bounds__(256) void ndq_pw_kernel(PwArgs a) {{
     for (int i = 0; i < NDQ_PW_NC; ++i) c[i] = a.coords[(size_t)i * a.ldc + n];
 {chr(10).join(loads)}
     ndq_pw_point(c, s, a.seed, a.want_adj, r, f, g);
-#pragma unroll
-    for (int e = 0; e < NDQ_PW_NEQ; ++e) sq = fmaf(r[e], r[e], sq);
+    sq += ndq_pw_loss(r);
     if (a.resid) {{
 #pragma unroll
       for (int e = 0; e < NDQ_PW_NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];

@@ -1355,7 +1355,8 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
 // One kernel for the whole closure of a single-network system (solvers.py:369-395): forward streams -> generated
 // pointwise stage PW (conditions + residuals + loss seeds, neurodiffeq_amd/codegen.py) -> reverse pass, with the
 // layer states kept in registers in between: no forward recompute, no stream round trip through HBM, one launch.
-// PW::apply(x, jets, seed, r, f, gj): per-point function; PW::NEQ / PW::NF = number of residuals / function values.
+// PW::apply(x, jets, seed, r, f, gj): per-point function; PW::loss(r): per-point loss term; PW::NEQ / PW::NF = number of
+// residuals / function values.
 struct FusedArgs {
   const float* coords;     // [D][ldc]
   const float* params;     // [P]
@@ -1396,8 +1397,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     tile_output<C, TRAIN>(ldsw, q, h, jets);
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
     if (valid && q == 0) {
-#pragma unroll
-      for (int e = 0; e < PW::NEQ; ++e) lsum = fmaf(r[e], r[e], lsum);
+      lsum += PW::loss(r);
       if (a.resid) {
 #pragma unroll
         for (int e = 0; e < PW::NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];
@@ -1481,8 +1481,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
     });
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
     if (valid && q == 0) {
-#pragma unroll
-      for (int e = 0; e < PW::NEQ; ++e) lsum = fmaf(r[e], r[e], lsum);
+      lsum += PW::loss(r);
       if (a.resid) {
 #pragma unroll
         for (int e = 0; e < PW::NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];

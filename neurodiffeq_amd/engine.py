@@ -34,7 +34,7 @@ def _round_up(n, m):
     return (n + m - 1) // m * m
 
 
-def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
+def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, loss="l2"):
     """Trace (conditions, diff_eqs) once on symbolic columns and lower them to a pointwise program.
 
     Needs no GPU (used by ``__graft_entry__.build`` to pre-compile the generated kernels); raises
@@ -135,12 +135,13 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None):
             st.first, st.mask2, st.lap = first, mask2, lap
 
     program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets), widen=widen,
-                                       allow_lap=allow_lap, unify=unify)
+                                       allow_lap=allow_lap, unify=unify, loss=loss)
     return program, descs
 
 
 class FusedSystem:
-    def __init__(self, nets, conditions, diff_eqs, n_coords, device, compute_func_val=None, single_kernel=True):
+    def __init__(self, nets, conditions, diff_eqs, n_coords, device, compute_func_val=None, single_kernel=True,
+                 loss="l2"):
         """single_kernel: for single-network systems use the one-launch fused closure kernel (forward + pointwise +
         reverse, csrc/ndq_mlp.h: fused_closure_kernel); otherwise (and for multi-network systems) the three-kernel
         pipeline through HBM streams."""
@@ -149,8 +150,9 @@ class FusedSystem:
             raise _lib.NdqError("the fused path needs an MI355X (device 'cuda'); no CPU fallback exists for it")
         self.L = _lib.lib()
         self.nets, self.conditions, self.n_coords = list(nets), list(conditions), n_coords
-        self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val)
+        self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val, loss)
         self.n_eq, self.n_funcs = len(self.program.residuals), len(self.program.funcs)
+        self.loss_norm = self.program.loss_norm      # loss = sum over points of the per-point term / (N * loss_norm)
         self.kernel = codegen.load(self.program)
         self.fusedk = None
         if single_kernel and codegen.can_fuse(self.program, self.descs):
@@ -339,7 +341,7 @@ class FusedSystem:
         return b["resid"][:, :n]
 
     def pointwise(self, b, n, stream, train, n_global, want_funcs=False, want_resid=False):
-        seed = 1.0 / (float(n_global) * max(self.n_eq, 1))
+        seed = 1.0 / (float(n_global) * self.loss_norm)
         rc = self.kernel.lib.ndq_pw_launch(self._coord_ptr(b, 0), b["ld"], n, b["jets_pp"],
                                            b["gbar_pp"] if train else None, b["ld"],
                                            _ptr(b["funcs"]) if want_funcs else None,
@@ -367,7 +369,7 @@ class FusedSystem:
         second-stage sums."""
         for fp in self.flat:
             fp.sync()
-        seed = 1.0 / (float(n_global) * self.n_eq)
+        seed = 1.0 / (float(n_global) * self.loss_norm)
         params_pp = (_c_vp * len(self.flat))(*[fp.flat.data_ptr() for fp in self.flat])
         rc = self.fusedk.lib.ndq_fused_launch_multi(self._coord_ptr(b, 0), b["ld"], n, params_pp,
                                                     b["fused_partials_pp"] if train else None,
@@ -462,7 +464,7 @@ class FusedSystem:
             step = step_k if step is None else step
             st = arr[k]
             st.params = fp.flat.data_ptr()
-            st.seed = 1.0 / (float(n) * self.n_eq)
+            st.seed = 1.0 / (float(n) * self.loss_norm)
             st.best_flat = fs["best_flat"][k].data_ptr() if track_best else None
             st.adam_m, st.adam_v = m.data_ptr(), v.data_ptr()
             b1, b2 = group["betas"]
@@ -494,7 +496,7 @@ class FusedSystem:
             fs["structs"][key] = st
         n_global = n if n_global is None else n_global
         st.params = fp.flat.data_ptr()
-        st.seed = 1.0 / (float(n_global) * self.n_eq)
+        st.seed = 1.0 / (float(n_global) * self.loss_norm)
         st.best_flat = fs["best_flat"][0].data_ptr() if track_best else None
         b1, b2 = group["betas"]
         st.lr, st.beta1, st.beta2, st.eps, st.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]

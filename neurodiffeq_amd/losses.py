@@ -1,7 +1,8 @@
 """Loss functions ``loss_fn(residual (N, n_eq), funcs, coords) -> scalar`` (reference: neurodiffeq/losses.py:5-35).
 
-``l2`` (= the solver default, solvers.py:218) is what the fused gfx950 path computes in-kernel; the others run on the
-composite autograd path."""
+``l2`` (= the solver default, solvers.py:218), ``l1`` and ``infinity`` are per-point terms averaged over the batch: the
+fused gfx950 path evaluates them (and their adjoint seeds) inside the generated pointwise code; the Sobolev norms need
+derivatives of the residual itself and run on the composite autograd path."""
 import torch
 
 from .operators import grad

@@ -296,14 +296,16 @@ class BaseSolver(ABC):
                 raise _lib.NdqError("fused='require' but no MI355X is visible")
             return None
         reason = None
-        if self.loss_fn is not _default_l2 and self.loss_fn is not _losses["l2"]:
+        loss_kind = "l2" if self.loss_fn is _default_l2 else \
+            next((k for k in ("l2", "l1", "infinity") if self.loss_fn is _losses[k]), None)
+        if loss_kind is None:
             reason = "custom loss function"
         elif type(self).additional_loss is not BaseSolver.additional_loss:
             reason = "additional_loss override"
         elif _requires_closure(self.optimizer):
             reason = "closure-based optimizer"
         key = (id(self.diff_eqs), tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions),
-               getattr(self.compute_func_val, "__func__", self.compute_func_val), reason)
+               getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind)
         if key == self._fused_key:
             return self._fused_sys
         self._fused_key, self._fused_sys = key, None
@@ -311,7 +313,7 @@ class BaseSolver(ABC):
             try:
                 from .engine import FusedSystem
                 self._fused_sys = FusedSystem(self.nets, self.conditions, self.diff_eqs, n_coords, self.device,
-                                              compute_func_val=self.compute_func_val)
+                                              compute_func_val=self.compute_func_val, loss=loss_kind)
                 if isinstance(self.optimizer, FusedAdam):
                     self.optimizer.bind(self._fused_sys.flat)
             except TraceUnsupported as e:

@@ -222,7 +222,14 @@ def sample_spherical(n, r_min, r_max, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------- closure / loop
-def closure(nets, enforcers, pde, coords, backward=True):
+LOSSES = {   # losses.py:4-12
+    "l2": lambda r: (r ** 2).mean(),
+    "l1": lambda r: torch.abs(r).mean(),
+    "infinity": lambda r: r.abs().max(dim=1)[0].mean(),
+}
+
+
+def closure(nets, enforcers, pde, coords, backward=True, loss="l2"):
     """One training closure (solvers.py:369-395) on given coordinates.
 
     ``coords``: list of 1-D (or (N,1)) tensors.  Returns dict(funcs (N,n_funcs), residuals (N,n_eq), loss 0-d)
@@ -230,7 +237,7 @@ def closure(nets, enforcers, pde, coords, backward=True):
     batch = [c.detach().reshape(-1, 1).requires_grad_(True) for c in coords]
     funcs = [e(n, *batch) for n, e in zip(nets, enforcers)]
     res = torch.cat(pde(*funcs, *batch), dim=1)
-    loss = (res ** 2).mean()
+    loss = LOSSES[loss](res)
     if backward:
         loss.backward()
     return dict(funcs=torch.cat(funcs, dim=1).detach(), residuals=res.detach(), loss=loss.detach())

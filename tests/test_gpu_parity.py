@@ -425,6 +425,49 @@ def test_zoo_closure_matches_autograd_oracle(name, mode):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("name,kind,mode", [("helmholtz_xy", "l1", "1k"), ("stokes_like", "l1", "1k"), ("stokes_like", "infinity", "1k"),
+                                            ("stokes_like", "infinity", "3k"), ("pendulum", "infinity", "1k")])
+def test_l1_and_infinity_losses_match_autograd_oracle(name, kind, mode):
+    """loss_fn = 'l1' / 'infinity' (losses.py:4-12) on the fused path: per-point loss terms and their adjoint seeds come
+    out of the generated pointwise code."""
+    from tests import zoo
+    from neurodiffeq_amd.engine import FusedSystem
+    torch.manual_seed(11)
+    system = zoo.build(name)
+    nets, conds, pde = system.product()
+    flat = R.get_flat(nets)
+    coords = system.sample(3001, seed=5)
+    onets, enforcers, opde = system.oracle(flat)
+    want = R.closure(onets, enforcers, opde, coords, loss=kind)
+    want_grad = R.get_flat_grad(onets).numpy()
+    for net in nets:
+        net.to("cuda")
+    fs = FusedSystem(nets, conds, pde, system.n_coords, "cuda", single_kernel=(mode == "1k"), loss=kind)
+    b, n = fs.step([c.float() for c in coords], train=True, slot=0)
+    torch.cuda.synchronize()
+    errs = dict(loss=abs(fs.loss_buf[0].item() - want["loss"].item()) / abs(want["loss"].item()),
+                grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in fs.flat]), want_grad))
+    diag(f"loss_{kind}_{name}_{mode}", errs)
+    assert max(errs.values()) < TOL, errs
+
+
+def test_solver_with_l1_loss_stays_on_the_fused_path():
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.solvers import Solver1D
+
+    def run(mode):
+        torch.manual_seed(0)
+        s = Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], t_min=0.0, t_max=2.0, loss_fn="l1", n_batches_valid=1)
+        s.fused = mode
+        s.fit(30, tqdm_file=None)
+        return s
+    a, b = run("require"), run("off")
+    assert a.fused_active and not b.fused_active
+    assert np.allclose(a.metrics_history["train_loss"], b.metrics_history["train_loss"], rtol=2e-4)
+    assert np.allclose(a.metrics_history["valid_loss"], b.metrics_history["valid_loss"], rtol=2e-4)
+
+
 def test_spherical_solver_with_default_network_runs_fused():
     """SolverSpherical with its default FCNN(3, 1) (solvers.py:761-976 of the reference) trains on the d = 3 kernels."""
     from tests import zoo

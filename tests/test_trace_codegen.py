@@ -22,7 +22,7 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def trace(nets, conds, pde, n_coords, lap=True, cfv=None):
+def trace(nets, conds, pde, n_coords, lap=True, cfv=None, loss="l2"):
     g = Graph(n_coords)
     g.register_nets(nets, [describe(n)["n_out"] for n in nets])
     cfv = cfv or (lambda net, cond, *coords: cond.enforce(net, *coords))
@@ -34,15 +34,15 @@ def trace(nets, conds, pde, n_coords, lap=True, cfv=None):
         g.net_deps.setdefault(k, tuple(range(describe(n)["d"])))
         g.net_nout.setdefault(k, describe(n)["n_out"])
     return codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets),
-                                    allow_lap=(lambda k, coords: True) if lap else None)
+                                    allow_lap=(lambda k, coords: True) if lap else None, loss=loss)
 
 
-def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None):
+def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"):
     """One training closure on the host: traced + generated pointwise code (gcc) around the jet oracle's network
     streams and VJP.  coords [d][n] fp32, params flat fp64.  Returns (program, funcs [n][nf], resid [n][neq], loss, grad)."""
     coords = np.ascontiguousarray(coords, np.float32)
     n_coords, n = coords.shape
-    prog = trace(nets, conds, pde, n_coords, lap, cfv)
+    prog = trace(nets, conds, pde, n_coords, lap, cfv, loss)
     dims_act, flats, off = [], [], 0
     for net in nets:
         info = describe(net)
@@ -67,9 +67,11 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None):
     syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]][:, prog.g.nodes[i][2]]
                      for i in prog.symbols]).astype(np.float32)
     n_eq = len(prog.residuals)
-    seed = 1.0 / (n * n_eq)
+    seed = 1.0 / (n * prog.loss_norm)
     resid, funcs, gbar = run_cpu(prog, coords, syms, seed)
-    loss = float((resid.astype(np.float64) ** 2).sum() * seed)
+    r64 = resid.astype(np.float64)
+    term = {"l2": lambda r: (r ** 2).sum(), "l1": lambda r: np.abs(r).sum(), "infinity": lambda r: np.abs(r).max(axis=0).sum()}
+    loss = float(term[loss](r64) * seed)
     # parameter gradient: adjoint streams through the jet oracle's VJP
     grads = []
     for k, (dims, act) in enumerate(dims_act):
@@ -131,6 +133,25 @@ def test_zoo_on_host_matches_autograd_oracle(name):
     # the oracle ran on the fp64 coordinates, the host pipeline on their fp32 rounding: tolerance 1e-5 covers it
     assert rel_l2(funcs, want["funcs"].numpy()) < 1e-5
     assert rel_l2(resid, want["residuals"].numpy()) < 1e-5
+    assert abs(loss - want["loss"].item()) <= 1e-5 * abs(want["loss"].item())
+    assert rel_l2(grad, want_grad) < 1e-5
+
+
+@pytest.mark.parametrize("name,kind", [("helmholtz_xy", "l1"), ("stokes_like", "l1"), ("stokes_like", "infinity"),
+                                       ("pendulum", "infinity")])
+def test_l1_and_infinity_losses_on_host_match_autograd_oracle(name, kind):
+    """losses.py:4-12: mean |r| and mean over points of max_e |r_e| as per-point terms of the generated code."""
+    from oracle import autograd_ref as R
+    torch.manual_seed(11)
+    system = zoo.build(name)
+    nets, conds, pde = system.product()
+    flat = R.get_flat(nets)
+    coords = system.sample(40, seed=5)
+    onets, enforcers, opde = system.oracle(flat)
+    want = R.closure(onets, enforcers, opde, coords, loss=kind)
+    want_grad = R.get_flat_grad(onets).numpy()
+    prog, funcs, resid, loss, grad = host_closure(nets, conds, pde, np.stack([c.numpy() for c in coords]).astype(np.float32),
+                                                  flat.double().numpy(), loss=kind)
     assert abs(loss - want["loss"].item()) <= 1e-5 * abs(want["loss"].item())
     assert rel_l2(grad, want_grad) < 1e-5
 
