@@ -1,5 +1,5 @@
 """Collocation-point generators with the reference's names, arguments and draw order
-(neurodiffeq/generators.py:107-316, 1046-1064).
+(neurodiffeq/generators.py:107-1064).
 
 Generators are the *input producer* of the hot path, not part of it: the classes with the reference's names always
 sample on the host with torch's global CPU generator, in the same call sequence as the reference, so that a given
@@ -323,6 +323,178 @@ class PredefinedGenerator(BaseGenerator):
 
     def get_examples(self):
         return self.xs
+
+
+class GeneratorND(BaseGenerator):
+    """Points on an N-dimensional (noisy) grid with a sampling method per axis (generators.py:419-569):
+    'equally-spaced', 'uniform', 'log-spaced', 'exp-spaced' (keyword ``base``), 'chebyshev' / 'chebyshev1', 'chebyshev2';
+    keyword ``cut`` slices each axis, ``abs_value`` folds the jittered samples to non-negative values.  The jitter is
+    one ``torch.normal`` per axis over the flattened ij-meshgrid, in axis order."""
+
+    def __init__(self, grid=(10, 10), r_min=(0.0, 0.0), r_max=(1.0, 1.0), methods=("equally-spaced", "equally-spaced"),
+                 noisy=True, r_noise_std=None, **kwargs):
+        super().__init__()
+        self.size = int(np.prod(grid))
+        self.grid, self.r_min, self.r_max = grid, r_min, r_max
+        self.methods, self.noisy, self.r_noise_std = methods, noisy, r_noise_std
+        tup = lambda v: (v,) if isinstance(v, (int, float)) else v
+        methods = [methods] if isinstance(methods, str) else methods
+        grid, r_min, r_max = tup(grid), tup(r_min), tup(r_max)
+        r_noise_std = tup(r_noise_std) if r_noise_std is not None else None
+        n_dim = len(grid)
+        cut = kwargs.pop("cut", tuple((None, None) for _ in range(n_dim)))
+        base = tup(kwargs.pop("base", tuple(10 for _ in range(n_dim))))
+        abs_value = kwargs.pop("abs_value", False)
+        if kwargs:
+            raise ValueError(f"Unknown keyword argument(s): {list(kwargs.keys())}")
+        if cut[0] is None or isinstance(cut[0], (int, float)):
+            cut = (cut,)
+        axes, stds = [], []
+        for i in range(n_dim):
+            lo, hi, n, method = r_min[i], r_max[i], grid[i], methods[i]
+            std = r_noise_std[i] if r_noise_std else ((hi - lo) / n) / 4.0
+            if method == "equally-spaced":
+                x = torch.linspace(lo, hi, n, requires_grad=True, device=_CPU)
+                sd = std * torch.ones(n)
+            elif method == "uniform":
+                x = torch.zeros(n, requires_grad=True, device=_CPU) + torch.rand(n, device=_CPU) * (hi - lo) + lo
+                sd = torch.zeros(n)
+            elif method == "log-spaced":
+                a, b = np.log10(lo), np.log10(hi)
+                x = torch.logspace(a, b, n, requires_grad=True, device=_CPU)
+                sd = std * torch.logspace(a, b, n, device=_CPU)
+            elif method == "exp-spaced":
+                x = torch.linspace(base[i] ** lo, base[i] ** hi, n, device=_CPU)
+                x = (torch.log(x) / np.log(base[i])).clone().detach().requires_grad_(True)
+                sd = (std * x).clone().detach()
+            elif method in ("chebyshev", "chebyshev1"):
+                x, sd = _chebyshev_first(lo, hi, n), std * torch.ones(n)
+            elif method == "chebyshev2":
+                x, sd = _chebyshev_second(lo, hi, n), std * torch.ones(n)
+            else:
+                raise ValueError(f"Unknown method: {method}")
+            axes.append(x[cut[i][0]:cut[i][1]])
+            stds.append(sd[cut[i][0]:cut[i][1]])
+        self.grid_r = [m.flatten() for m in torch.meshgrid(*axes, indexing="ij")]
+        self.grid_std = [m.flatten() for m in torch.meshgrid(*stds, indexing="ij")]
+        if not noisy:
+            self.getter = lambda: tuple(self.grid_r)
+        elif abs_value:
+            self.getter = lambda: tuple(torch.abs(torch.normal(m, s)) for m, s in zip(self.grid_r, self.grid_std))
+        else:
+            self.getter = lambda: tuple(torch.normal(m, s) for m, s in zip(self.grid_r, self.grid_std))
+
+    def get_examples(self):
+        return self.getter()
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(grid=self.grid, r_min=self.r_min, r_max=self.r_max, methods=self.methods, noisy=self.noisy,
+                 r_noise_std=self.r_noise_std)
+        return d
+
+
+class TransformGenerator(BaseGenerator):
+    """Applies ``transforms[i]`` to the i-th sample vector (``None`` = identity), or one ``transform`` to all of them
+    at once (generators.py:752-801)."""
+
+    def __init__(self, generator, transforms=None, transform=None):
+        super().__init__()
+        self.generator, self.size = generator, generator.size
+        if transforms is not None and transform is not None:
+            raise ValueError("transform and transforms cannot be both specified")
+        if transforms is not None:
+            self.trans = [(lambda x: x) if t is None else t for t in transforms]
+        else:
+            self.trans = transform if transform is not None else (lambda x: x)
+
+    def get_examples(self):
+        xs = self.generator.get_examples()
+        if isinstance(xs, torch.Tensor):
+            return self.trans(xs) if callable(self.trans) else self.trans[0](xs)
+        if callable(self.trans):
+            return self.trans(*xs)
+        return tuple(t(x) for t, x in zip(self.trans, xs))
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(generator=self.generator, trans=self.trans)
+        return d
+
+
+class FilterGenerator(BaseGenerator):
+    """Keeps the samples where ``filter_fn(list of sample vectors)`` (a boolean mask) holds (generators.py:904-952)."""
+
+    def __init__(self, generator, filter_fn, size=None, update_size=True):
+        super().__init__()
+        self.generator, self.filter_fn = generator, filter_fn
+        self.size = generator.size if size is None else size
+        self.update_size = update_size
+
+    def get_examples(self):
+        xs = self.generator.get_examples()
+        xs = [xs] if isinstance(xs, torch.Tensor) else xs
+        mask = self.filter_fn(xs)
+        xs = [x[mask] for x in xs]
+        if self.update_size:
+            self.size = len(xs[0])
+        return xs[0] if len(xs) == 1 else xs
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(generator=self.generator, filter_fn=self.filter_fn)
+        return d
+
+
+class ResampleGenerator(BaseGenerator):
+    """Shuffled sub-sample of another generator's output, with or without replacement (generators.py:955-993); the index
+    draw (``randint`` / ``randperm``) precedes the inner generator's own draw, like in the reference."""
+
+    def __init__(self, generator, size=None, replacement=False):
+        super().__init__()
+        self.generator = generator
+        self.size = generator.size if size is None else size
+        self.replacement = replacement
+
+    def get_examples(self):
+        if self.replacement:
+            idx = torch.randint(self.generator.size, (self.size,), device=_CPU)
+        else:
+            idx = torch.randperm(self.generator.size, device=_CPU)[:self.size]
+        xs = self.generator.get_examples()
+        return xs[idx] if isinstance(xs, torch.Tensor) else [x[idx] for x in xs]
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(generator=self.generator, replacement=self.replacement)
+        return d
+
+
+class BatchGenerator(BaseGenerator):
+    """Serves another generator's samples ``batch_size`` at a time from a cache that is refilled when it runs short
+    (generators.py:996-1043)."""
+
+    def __init__(self, generator, batch_size):
+        super().__init__()
+        if generator.size <= 0:
+            raise ValueError(f"generator has size {generator.size} <= 0")
+        self.generator, self.size = generator, batch_size
+        first = generator.get_examples()
+        self.cached_xs = [first] if isinstance(first, torch.Tensor) else list(first)
+
+    def get_examples(self):
+        while len(self.cached_xs[0]) < self.size:
+            more = self.generator.get_examples()
+            more = [more] if isinstance(more, torch.Tensor) else more
+            self.cached_xs = [torch.cat([x, m]) for x, m in zip(self.cached_xs, more)]
+        batch = [x[:self.size] for x in self.cached_xs]
+        self.cached_xs = [x[self.size:] for x in self.cached_xs]
+        return batch[0] if len(batch) == 1 else batch
+
+    def _internal_vars(self):
+        d = super()._internal_vars()
+        d.update(generator=self.generator)
+        return d
 
 
 class SamplerGenerator(BaseGenerator):

@@ -268,6 +268,23 @@ def make_diff_known_answers():
     print("diff_known: ok")
 
 
+def make_generator_goldens():
+    """Three draws of every generator construction in tests/generator_specs.py from the reference's module."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import neurodiffeq.generators as RG
+    from tests import generator_specs as S
+    out = {}
+    for name in S.SPECS:
+        drs, size = S.draws(RG, name)
+        out[f"{name}/size"] = np.asarray(size)
+        out[f"{name}/n_vectors"] = np.asarray(len(drs[0]))
+        for d, vectors in enumerate(drs):
+            for v, arr in enumerate(vectors):
+                out[f"{name}/{d}/{v}"] = arr
+    np.savez_compressed(os.path.join(HERE, "generators.npz"), **out)
+    print("generators:", len(S.SPECS), "constructions")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name in CONFIGS:
@@ -275,3 +292,5 @@ if __name__ == "__main__":
             make(name)
     if not only:
         make_diff_known_answers()
+    if not only or "generators" in only:
+        make_generator_goldens()
