@@ -271,6 +271,64 @@ class IBVP1D(BaseCondition):
         return a + grow * (u - xt * w * d0 + 0.5 * xt ** 2 * w * (d0 - diff(u1, x1)))
 
 
+class DoubleEndedBVP1D(BaseCondition):
+    """Two-point boundary conditions in one variable, each end either Dirichlet (``x_*_val``) or Neumann
+    (``x_*_prime``) (conditions.py:715-884).  A Neumann end needs the network and its derivative AT that end, so
+    ``enforce`` is overridden to evaluate the network there as well (composite path only)."""
+
+    def __init__(self, x_min, x_max, x_min_val=None, x_min_prime=None, x_max_val=None, x_max_prime=None):
+        super().__init__()
+        given = sum(c is not None for c in (x_min_val, x_min_prime, x_max_val, x_max_prime))
+        if given != 2 or (x_min_val and x_min_prime) or (x_max_val and x_max_prime):
+            raise NotImplementedError("Sorry, this boundary condition is not implemented.")
+        self.x_min, self.x_min_val, self.x_min_prime = x_min, x_min_val, x_min_prime
+        self.x_max, self.x_max_val, self.x_max_prime = x_max, x_max_val, x_max_prime
+
+    def _kind(self):
+        return ("d" if self.x_min_val is not None else "n") + ("d" if self.x_max_val is not None else "n")
+
+    def enforce(self, net, x):
+        kind = self._kind()
+        u = _raw_output(net, (x,), self.ith_unit)
+        if kind == "dd":
+            return self.parameterize(u, x)
+        if isinstance(x, Sym):
+            raise TraceUnsupported("Neumann DoubleEndedBVP1D evaluates the network at boundary points")
+        extra = []
+        for need, xb in ((kind[0] == "n", self.x_min), (kind[1] == "n", self.x_max)):
+            if need:
+                xe = xb * torch.ones_like(x, requires_grad=True)
+                extra += [_raw_output(net, (xe,), self.ith_unit), xe]
+        return self.parameterize(u, x, *extra)
+
+    def parameterize(self, u, x, *additional_tensors):
+        kind = self._kind()
+        w = self.x_max - self.x_min
+        xt = (x - self.x_min) / w
+        if kind == "dd":
+            return self.x_min_val * (1 - xt) + self.x_max_val * xt + xt * (1 - xt) * u
+        if kind == "dn":
+            u1, x1 = additional_tensors
+            a = (1 - xt) * self.x_min_val + 0.5 * xt ** 2 * self.x_max_prime * w
+            return a + xt * (u - u1 + self.x_min_val - diff(u1, x1) * w)
+        if kind == "nd":
+            u0, x0 = additional_tensors
+            a = xt * self.x_max_val - 0.5 * (1 - xt) ** 2 * self.x_min_prime * w
+            return a + (1 - xt) * (u - u0 + self.x_max_val + diff(u0, x0) * w)
+        u0, x0, u1, x1 = additional_tensors
+        a = -0.5 * (1 - xt) ** 2 * w * self.x_min_prime + 0.5 * xt ** 2 * w * self.x_max_prime
+        return a + 0.5 * xt ** 2 * (u - u1 - 0.5 * diff(u1, x1) * w) + 0.5 * (1 - xt) ** 2 * (u - u0 + 0.5 * diff(u0, x0) * w)
+
+
+class IrregularBoundaryCondition(BaseCondition):
+    """Base class of conditions on irregular domains (conditions.py:138-154): ``in_domain`` tells monitors which points
+    to draw; every point by default."""
+
+    def in_domain(self, *coordinates):
+        import numpy as np
+        return np.ones_like(coordinates[0], dtype=bool)
+
+
 # ------------------------------------------------------------------------------------------------- spherical shells
 def _abs(x):
     return x._un("abs") if isinstance(x, (Sym, SymMat)) else torch.abs(x)

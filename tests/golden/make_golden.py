@@ -285,6 +285,32 @@ def make_generator_goldens():
     print("generators:", len(S.SPECS), "constructions")
 
 
+def make_condition_goldens():
+    """enforce() of every condition construction in tests/condition_specs.py from the reference's modules, fp64."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import neurodiffeq.conditions as RC
+    import neurodiffeq.networks as RN
+    from tests import condition_specs as S
+    set_tensor_type(device="cpu", float_bits=64)
+    out = {name: S.SPECS[name](RC, RN).detach().numpy() for name in S.SPECS}
+    set_tensor_type(device="cpu", float_bits=32)
+    np.savez_compressed(os.path.join(HERE, "conditions.npz"), **out)
+    print("conditions:", len(out), "constructions")
+
+
+def make_operator_goldens():
+    """Every operator / function basis of tests/operator_specs.py from the reference's modules, fp64."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import neurodiffeq.operators as RO
+    import neurodiffeq.function_basis as RB
+    from tests import operator_specs as S
+    set_tensor_type(device="cpu", float_bits=64)
+    out = {name: S.SPECS[name](RO, RB).detach().numpy() for name in S.SPECS}
+    set_tensor_type(device="cpu", float_bits=32)
+    np.savez_compressed(os.path.join(HERE, "operators.npz"), **out)
+    print("operators:", len(out), "evaluations")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     for name in CONFIGS:
@@ -294,3 +320,7 @@ if __name__ == "__main__":
         make_diff_known_answers()
     if not only or "generators" in only:
         make_generator_goldens()
+    if not only or "conditions" in only:
+        make_condition_goldens()
+    if not only or "operators" in only:
+        make_operator_goldens()
