@@ -81,6 +81,47 @@ class FCNN(nn.Module):
         return self.NN(t)
 
 
+class Resnet(nn.Module):
+    """``FCNN(x) + W x``: a fully connected residual branch plus a trainable bias-free linear skip from input to output
+    (reference: networks.py:73-106; attribute names ``residual`` / ``skip_connection`` as there, the residual branch is
+    built first).  Runs on the composite path."""
+
+    def __init__(self, n_input_units=1, n_output_units=1, n_hidden_units=None, n_hidden_layers=None, actv=nn.Tanh,
+                 hidden_units=(32, 32)):
+        super().__init__()
+        self.residual = FCNN(n_input_units=n_input_units, n_output_units=n_output_units, n_hidden_units=n_hidden_units,
+                             n_hidden_layers=n_hidden_layers, actv=actv, hidden_units=hidden_units)
+        self.skip_connection = nn.Linear(n_input_units, n_output_units, bias=False)
+
+    def forward(self, t):
+        return self.skip_connection(t) + self.residual(t)
+
+
+class MonomialNN(nn.Module):
+    """Parameter-free feature map ``x -> [x^d for d in degrees]`` along dim 1 (reference: networks.py:109-139);
+    an int ``degrees = k`` means 1..k."""
+
+    def __init__(self, degrees):
+        super().__init__()
+        if isinstance(degrees, int):
+            degrees = list(range(1, degrees + 1))
+        self.degrees = tuple(degrees)
+        if len(self.degrees) == 0:
+            raise ValueError("No degrees used, check `degrees` argument again")
+        if 0 in degrees:
+            warnings.warn("One of the degrees is 0 which might introduce redundant features")
+        if len(set(self.degrees)) < len(self.degrees):
+            warnings.warn(f"Duplicate degrees found: {self.degrees}")
+
+    def forward(self, x):
+        return torch.cat([x ** d for d in self.degrees], dim=1)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(degrees={self.degrees})"
+
+    __str__ = __repr__
+
+
 # ------------------------------------------------------------------------------------------- kernel-side description
 _ACT_IDS = {nn.Tanh: _lib.NDQ_ACT_TANH, SinActv: _lib.NDQ_ACT_SIN, nn.Sigmoid: _lib.NDQ_ACT_SIGMOID,
             Swish: _lib.NDQ_ACT_SWISH, APTx: _lib.NDQ_ACT_APTX}
