@@ -201,6 +201,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    local_rank = int(os.environ.get("NDQ_BENCH_DEVICE", local_rank))     # debugging aid: several ranks on one device
     torch.cuda.set_device(local_rank)
     torch.set_num_threads(min(16, os.cpu_count() or 1))   # host-side torch ops (sampling leg); ATen's default of one
     # thread per logical cpu is far past the sweet spot for 65k-element ops
