@@ -1,8 +1,9 @@
 """Loss functions ``loss_fn(residual (N, n_eq), funcs, coords) -> scalar`` (reference: neurodiffeq/losses.py:5-35).
 
 ``l2`` (= the solver default, solvers.py:218), ``l1`` and ``infinity`` are per-point terms averaged over the batch: the
-fused gfx950 path evaluates them (and their adjoint seeds) inside the generated pointwise code; the Sobolev norms need
-derivatives of the residual itself and run on the composite autograd path."""
+fused gfx950 path evaluates them (and their adjoint seeds) inside the generated pointwise code.  The Sobolev norms are
+the l2 loss of the residual list extended by d(sum_e r_e)/dx_a; the solver traces them that way when that extra
+derivative stays within second-order network streams (first-order systems), else they run on the composite path."""
 import torch
 
 from .operators import grad

@@ -29,6 +29,7 @@ from .conditions import BaseCondition
 from .generators import Generator1D, Generator2D, GeneratorSpherical, SamplerGenerator
 from .losses import _losses
 from .networks import FCNN
+from .neurodiffeq import safe_diff as diff
 from .optim import FusedAdam
 from .symbolic import TraceUnsupported
 
@@ -54,6 +55,21 @@ def _unique_params(nets):
             seen.add(id(p))
             out.append(p)
     return out
+
+
+def sobolev_equations(diff_eqs, n_funcs, semi=False):
+    """The Sobolev norms of the reference (losses.py:17-26) are the mean square over the columns
+    [r_1 .. r_neq, d(sum_e r_e)/dx_1 .. d(sum_e r_e)/dx_d] (``semi``: the derivative columns alone), i.e. the l2 loss
+    of this extended residual list.  It traces only when the extra derivative stays within second-order network
+    streams (first-order systems); otherwise the tracer raises and the composite path takes over."""
+    def extended(*variables):
+        res = list(diff_eqs(*variables))
+        total = res[0]
+        for r in res[1:]:
+            total = total + r
+        grads = [diff(total, x) for x in variables[n_funcs:]]
+        return grads if semi else res + grads
+    return extended
 
 
 def _default_l2(residual, funcs, coords):
@@ -297,7 +313,7 @@ class BaseSolver(ABC):
             return None
         reason = None
         loss_kind = "l2" if self.loss_fn is _default_l2 else \
-            next((k for k in ("l2", "l1", "infinity") if self.loss_fn is _losses[k]), None)
+            next((k for k in ("l2", "l1", "infinity", "h1", "h1 semi") if self.loss_fn is _losses[k]), None)
         if loss_kind is None:
             reason = "custom loss function"
         elif type(self).additional_loss is not BaseSolver.additional_loss:
@@ -312,8 +328,11 @@ class BaseSolver(ABC):
         if reason is None:
             try:
                 from .engine import FusedSystem
-                self._fused_sys = FusedSystem(self.nets, self.conditions, self.diff_eqs, n_coords, self.device,
-                                              compute_func_val=self.compute_func_val, loss=loss_kind)
+                eqs, kind = self.diff_eqs, loss_kind
+                if loss_kind in ("h1", "h1 semi"):
+                    eqs, kind = sobolev_equations(self.diff_eqs, len(self.nets), semi=(loss_kind == "h1 semi")), "l2"
+                self._fused_sys = FusedSystem(self.nets, self.conditions, eqs, n_coords, self.device,
+                                              compute_func_val=self.compute_func_val, loss=kind)
                 if isinstance(self.optimizer, FusedAdam):
                     self.optimizer.bind(self._fused_sys.flat)
             except TraceUnsupported as e:

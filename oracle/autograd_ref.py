@@ -229,6 +229,14 @@ LOSSES = {   # losses.py:4-12
 }
 
 
+def sobolev_loss(res, batch, semi=False):
+    """losses.py:17-26: g_a = d(sum_e r_e)/dx_a by one reverse sweep each (operators.grad, operators.py:15-33 with
+    grad_outputs = ones over the whole (N, n_eq) residual); h1 = mean([r, g]^2), h1 semi = mean(g^2)."""
+    g = [torch.autograd.grad(res, x, grad_outputs=torch.ones_like(res), create_graph=True)[0] for x in batch]
+    cols = g if semi else [res] + g
+    return (torch.cat(cols, dim=1) ** 2).mean()
+
+
 def closure(nets, enforcers, pde, coords, backward=True, loss="l2"):
     """One training closure (solvers.py:369-395) on given coordinates.
 
@@ -237,7 +245,7 @@ def closure(nets, enforcers, pde, coords, backward=True, loss="l2"):
     batch = [c.detach().reshape(-1, 1).requires_grad_(True) for c in coords]
     funcs = [e(n, *batch) for n, e in zip(nets, enforcers)]
     res = torch.cat(pde(*funcs, *batch), dim=1)
-    loss = LOSSES[loss](res)
+    loss = sobolev_loss(res, batch, semi=(loss == "h1 semi")) if loss in ("h1", "h1 semi") else LOSSES[loss](res)
     if backward:
         loss.backward()
     return dict(funcs=torch.cat(funcs, dim=1).detach(), residuals=res.detach(), loss=loss.detach())

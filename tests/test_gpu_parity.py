@@ -451,6 +451,38 @@ def test_l1_and_infinity_losses_match_autograd_oracle(name, kind, mode):
     assert max(errs.values()) < TOL, errs
 
 
+def test_sobolev_loss_fused_for_first_order_systems_composite_otherwise():
+    """loss_fn = 'h1' (losses.py:17-26): first-order systems trace (the extra d r/dx needs second-order streams at most) and
+    follow the autograd path's trajectory; a second-order PDE would need third-order streams and is refused."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP, NoCondition
+    from neurodiffeq_amd.solvers import Solver1D, Solver2D
+
+    def run(mode, kind):
+        torch.manual_seed(0)
+        s = Solver1D(lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)], [IVP(0.0, 1.5), IVP(0.0, 1.0)],
+                     t_min=0.1, t_max=4.0, loss_fn=kind, n_batches_valid=1)
+        s.fused = mode
+        s.fit(25, tqdm_file=None)
+        return s
+    for kind in ("h1", "h1 semi"):
+        a, b = run("require", kind), run("off", kind)
+        assert a.fused_active and not b.fused_active
+        assert np.allclose(a.metrics_history["train_loss"], b.metrics_history["train_loss"], rtol=3e-4), kind
+        assert np.allclose(a.metrics_history["valid_loss"], b.metrics_history["valid_loss"], rtol=3e-4), kind
+    torch.manual_seed(0)
+    s2 = Solver2D(lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2)], [NoCondition()], xy_min=(0, 0), xy_max=(1, 1),
+                  loss_fn="h1", n_batches_valid=0)
+    s2.fused = "require"
+    with pytest.raises(_lib_error()):
+        s2.fit(1, tqdm_file=None)
+
+
+def _lib_error():
+    from neurodiffeq_amd import _lib
+    return _lib.NdqError
+
+
 def test_solver_with_l1_loss_stays_on_the_fused_path():
     from neurodiffeq_amd import diff
     from neurodiffeq_amd.conditions import IVP

@@ -156,6 +156,35 @@ def test_l1_and_infinity_losses_on_host_match_autograd_oracle(name, kind):
     assert rel_l2(grad, want_grad) < 1e-5
 
 
+@pytest.mark.parametrize("name,kind", [("coupled_sin", "h1"), ("advection", "h1"), ("advection", "h1 semi")])
+def test_sobolev_losses_on_host_match_autograd_oracle(name, kind):
+    """losses.py:17-26 on first-order systems: the h1 norms are the l2 loss of the residual list extended by
+    d(sum_e r_e)/dx_a (what solvers.BaseSolver._fused_system traces)."""
+    from neurodiffeq_amd import diff
+    from oracle import autograd_ref as R
+    torch.manual_seed(11)
+    system = zoo.build(name)
+    nets, conds, pde = system.product()
+    n_funcs = len(nets)
+
+    def extended(*variables):
+        res = list(pde(*variables))
+        total = res[0]
+        for r in res[1:]:
+            total = total + r
+        grads = [diff(total, x) for x in variables[n_funcs:]]
+        return grads if kind == "h1 semi" else res + grads
+    flat = R.get_flat(nets)
+    coords = system.sample(40, seed=5)
+    onets, enforcers, opde = system.oracle(flat)
+    want = R.closure(onets, enforcers, opde, coords, loss=kind)
+    want_grad = R.get_flat_grad(onets).numpy()
+    prog, funcs, resid, loss, grad = host_closure(nets, conds, extended, np.stack([c.numpy() for c in coords]).astype(np.float32),
+                                                  flat.double().numpy())
+    assert abs(loss - want["loss"].item()) <= 1e-5 * abs(want["loss"].item())
+    assert rel_l2(grad, want_grad) < 1e-5
+
+
 def test_unsupported_constructs_raise_trace_unsupported():
     from neurodiffeq_amd import diff
     from neurodiffeq_amd.symbolic import TraceUnsupported
