@@ -36,6 +36,8 @@ typedef struct ndq_mlp_desc {
   int act;     /* NDQ_ACT_* */
   int n_out;   /* output units */
   int lap;     /* 1: "Laplacian stream" -- the diagonal pairs of mask2 are carried as ONE stream holding their sum */
+  int skip;    /* 1: Resnet (networks.py:73-106): out += S x with a trainable bias-free S (n_out x d) that follows the
+                  output bias in the flat parameter vector; n_out = 1 only */
 } ndq_mlp_desc;
 
 /* One compiled kernel pair (forward streams / parameter-gradient adjoint) for ONE descriptor.  libndq.so carries a
@@ -56,7 +58,7 @@ int ndq_mlp_register(const ndq_mlp_kernels* kernels);
 
 /* 1 if kernels for this descriptor are available (built in or registered). */
 int ndq_mlp_supported(const ndq_mlp_desc* desc);
-/* number of streams NS, of parameters P (flat torch order W1,b1,W2,b2,...,Wout,bout) */
+/* number of streams NS, of parameters P (flat torch order W1,b1,W2,b2,...,Wout,bout[,S]) */
 int ndq_mlp_num_streams(const ndq_mlp_desc* desc);
 int ndq_mlp_num_params(const ndq_mlp_desc* desc);
 /* number of workgroups ndq_mlp_jet_bwd launches for n points == rows of `partials` it writes */

@@ -368,7 +368,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}>;
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf};
   static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
@@ -644,14 +644,15 @@ def mlp_ext_allowed(desc):
     return (1 <= desc.d <= 3 and desc.hidden % 16 == 0 and 16 <= desc.hidden <= 64 and 1 <= desc.layers <= 4
             and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
-            and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0)))
+            and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0))
+            and desc.skip in (0, 1) and (desc.skip == 0 or desc.n_out == 1))
 
 
 def mlp_ext_source(desc):
     header = os.path.join(HERE, "csrc", "ndq_launch.h")
     return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
 #include "{header}"
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}>;
 extern "C" const ndq_mlp_kernels* ndq_ext_kernels(void) {{
   static const ndq_mlp_kernels k = ndq::make_kernels<CFG>();
   return &k;

@@ -226,7 +226,7 @@ template <> struct Act<ACT_APTX> {
 };
 
 // ------------------------------------------------------------------------------------------------ config
-template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0>
+template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0, int SKIP_ = 0>
 struct Cfg {
   using SS = Streams<D_, FIRST_, M2_, LAP_>;
   static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
@@ -245,7 +245,12 @@ struct Cfg {
   static constexpr int offb(int l) { return offW(l) + H * H; }
   static constexpr int offWout = H * D + H + (L - 1) * (H * H + H);
   static constexpr int offbout = offWout + NOUT * H;
-  static constexpr int P = offbout + NOUT;
+  // SKIP: a trainable bias-free linear map from the inputs straight to the output, out += S x (networks.Resnet,
+  // networks.py:73-106); its weights S (n_out x d) follow the output bias in the flat parameter vector
+  static constexpr int SKIP = SKIP_;
+  static_assert(SKIP_ == 0 || NOUT_ == 1, "the skip connection is implemented for single-output networks");
+  static constexpr int offS = offbout + NOUT;
+  static constexpr int P = offS + SKIP * NOUT * D;
   // LDS carve (floats): W1T [D][H] | b1 [H] | per hidden-hidden layer: Wf [H*H] (+ Wt [H*H] for bwd) | b_l | Wout | bout
   static constexpr int ldsW1T = 0, ldsb1 = D * H;
   static constexpr int ldsLayer0 = D * H + H;
@@ -272,7 +277,8 @@ struct Cfg {
   static constexpr int ldsWout(bool bwd) { return ldsLayer0 + (L - 1) * layerStride(bwd); }
   static constexpr int ldsWoutT() { return ldsWout(true) + HO * H; }
   static constexpr int ldsbout(bool bwd) { return ldsWout(bwd) + (NOUT == 1 ? H : (bwd ? 2 : 1) * HO * H); }
-  static constexpr int ldsWeightsEnd(bool bwd) { return (ldsbout(bwd) + (NOUT == 1 ? 1 : HO) + 3) & ~3; }
+  static constexpr int ldsSkip(bool bwd) { return ldsbout(bwd) + (NOUT == 1 ? 1 : HO); }
+  static constexpr int ldsWeightsEnd(bool bwd) { return (ldsSkip(bwd) + SKIP * NOUT * D + 3) & ~3; }
   static constexpr int stageFloatsPerWave = 2 * 16 * HP;  // Zt and Ht tiles of one stream
 };
 
@@ -300,6 +306,9 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
   if constexpr (C::NOUT == 1) {
     for (int i = tid; i < H; i += nt) lds[C::ldsWout(BWD) + i] = prm[C::offWout + i];
     if (tid == 0) lds[C::ldsbout(BWD)] = prm[C::offbout];
+    if constexpr (C::SKIP != 0) {
+      if (tid < D) lds[C::ldsSkip(BWD) + tid] = prm[C::offS + tid];
+    }
   } else {
     constexpr int NBO = C::NBO;
     const float* Wo = prm + C::offWout;  // [NOUT][H], rows >= NOUT are zero padding
@@ -713,7 +722,8 @@ __device__ __forceinline__ float point_sum(float v) {  // sum over the 16 points
 
 // output layer (n_out = 1) on the VALU: out[s] = Wout . h[s] (+ bout on the value stream), identical in all 4 lane groups
 template <class C, bool BWD>
-__device__ __forceinline__ void tile_output(const float* lds, int q, const f32x4 (&h)[C::NS][C::NB], float (&out)[C::NS]) {
+__device__ __forceinline__ void tile_output(const float* lds, int q, const float (&x)[C::D], const f32x4 (&h)[C::NS][C::NB],
+                                            float (&out)[C::NS]) {
 #pragma unroll
   for (int s = 0; s < C::NS; ++s) out[s] = 0.f;
 #pragma unroll
@@ -727,6 +737,14 @@ __device__ __forceinline__ void tile_output(const float* lds, int q, const f32x4
 #pragma unroll
   for (int s = 0; s < C::NS; ++s) out[s] = quad_sum(out[s]);
   out[0] += lds[C::ldsbout(BWD)];
+  if constexpr (C::SKIP != 0) {            // + S x: value and first-order streams (second order: nothing)
+#pragma unroll
+    for (int a = 0; a < C::D; ++a) {
+      const float sa = lds[C::ldsSkip(BWD) + a];
+      out[0] = fmaf(sa, x[a], out[0]);
+      if constexpr (C::SS::FIRST) out[1 + a] += sa;
+    }
+  }
 }
 
 // output layer with NOUT > 1 as an MFMA layer: o[s][ob] = Wo h[s] (+ bout on the value stream); rows >= NOUT are zero
@@ -880,7 +898,7 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
     act_forward<C>(st, h);
     if constexpr (C::NOUT == 1) {
       float out[C::NS];
-      tile_output<C, false>(ldsw, q, h, out);
+      tile_output<C, false>(ldsw, q, x, h, out);
       if (q == 0 && n < a.n) {
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) a.jets[(size_t)s * a.ldj + n] = out[s];
@@ -923,6 +941,7 @@ struct GradAcc {
   float b[C::L > 1 ? C::L - 1 : 1][C::NB][4];      // db_l[j]     (needs point_sum)
   float wout[C::NB][4];              // NOUT == 1: dWout[j]       (needs point_sum)
   float bout;                        // NOUT == 1: dbout          (needs full wave sum)
+  float skip[C::D];                  // SKIP: dS[a]               (needs full wave sum)
   f32x4 wo[C::NBO][C::NB];           // NOUT > 1: dWout[16ob+4q+r][16kb+p], MFMA accumulators
   float bo[C::NBO][4];               // NOUT > 1: dbout[16ob+4q+r] (needs point_sum)
   float* bias;                       // ACC_LDS: this wave's LDS region holding b1 / w1 / b / wout instead (already point-summed)
@@ -1042,6 +1061,8 @@ __device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
       for (int kb = 0; kb < C::NB; ++kb) acc.w[l][jb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
   acc.bout = 0.f;
 #pragma unroll
+  for (int d = 0; d < C::D; ++d) acc.skip[d] = 0.f;
+#pragma unroll
   for (int ob = 0; ob < C::NBO; ++ob) {
 #pragma unroll
     for (int kb = 0; kb < C::NB; ++kb) acc.wo[ob][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1140,6 +1161,14 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
     }
   }
   acc.bout += (q == 0) ? gout[0] : 0.f;
+  if constexpr (C::SKIP != 0) {
+#pragma unroll
+    for (int a = 0; a < C::D; ++a) {
+      float v = gout[0] * x[a];
+      if constexpr (C::SS::FIRST) v += gout[1 + a];
+      acc.skip[a] += (q == 0) ? v : 0.f;
+    }
+  }
   tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc, kp);
 }
 
@@ -1222,6 +1251,9 @@ __device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, 
   constexpr int R = bwd_regions<C>(WAVES);
   float* red0 = lds + C::ldsWeightsEnd(true);
   const float bsum = point_sum(quad_sum(acc.bout));
+  float ssum[C::D];
+#pragma unroll
+  for (int a = 0; a < C::D; ++a) ssum[a] = (C::SKIP != 0) ? point_sum(quad_sum(acc.skip[a])) : 0.f;
 #pragma unroll
   for (int b = 0; b < C::NB; ++b)
 #pragma unroll
@@ -1281,7 +1313,13 @@ __device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, 
             for (int r = 0; r < 4; ++r)
               put(C::offW(l + 2) + (16 * jb + 4 * q + r) * C::H + 16 * kb + p, acc.w[l][jb][kb][r]);
       if constexpr (C::NOUT == 1) {
-        if (lane == 0) put(C::offbout, bsum);
+        if (lane == 0) {
+          put(C::offbout, bsum);
+          if constexpr (C::SKIP != 0) {
+#pragma unroll
+            for (int a = 0; a < C::D; ++a) put(C::offS + a, ssum[a]);
+          }
+        }
       } else {
 #pragma unroll
         for (int ob = 0; ob < C::NBO; ++ob)
@@ -1394,7 +1432,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     KeptPlanes<C> kp;
     tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp);
     float jets[C::NS], gout[C::NS], r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
-    tile_output<C, TRAIN>(ldsw, q, h, jets);
+    tile_output<C, TRAIN>(ldsw, q, x, h, jets);
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
     if (valid && q == 0) {
       lsum += PW::loss(r);
@@ -1477,7 +1515,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
       f32x4 h[C::NS][C::NB];
       KeptPlanes<C> kp;
       tile_forward<C, TRAIN>(lds + k * WS, lane, q, x, st, h, kp);
-      tile_output<C, TRAIN>(lds + k * WS, q, h, jets[k]);
+      tile_output<C, TRAIN>(lds + k * WS, q, x, h, jets[k]);
     });
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
     if (valid && q == 0) {

@@ -72,7 +72,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         for c in coords:
             a = deps.index(c)
             mask2 |= 1 << codegen.pair_list(len(deps)).index((a, a))
-        d = _lib.MlpDesc(len(deps), 1, mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1)
+        d = _lib.MlpDesc(len(deps), 1, mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1, info["skip"])
         return codegen.ensure_mlp_kernels(d)
 
     def widen(k, st):
@@ -82,12 +82,12 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         if list(st.deps) != list(range(st.deps[0], st.deps[0] + st.d)):
             raise TraceUnsupported("network fed a non-contiguous subset of the coordinates")
         if st.lap:                      # allow_lap already checked that this exact kernel exists
-            descs[k] = _lib.MlpDesc(st.d, 1, st.mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1)
+            descs[k] = _lib.MlpDesc(st.d, 1, st.mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1, info["skip"])
             codegen.ensure_mlp_kernels(descs[k])
             return
         # exact stream set: from libndq.so's table, else compiled on first use as an extension module ...
         exact = _lib.MlpDesc(st.d, 1 if (st.first or st.mask2) else 0, st.mask2, info["hidden"], info["layers"],
-                             info["act"], info["n_out"])
+                             info["act"], info["n_out"], 0, info["skip"])
         if codegen.ensure_mlp_kernels(exact):
             st.first, st.mask2 = exact.first, exact.mask2
             descs[k] = exact
@@ -99,7 +99,8 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             for mask2 in range(1 << npair):
                 if (mask2 & st.mask2) != st.mask2 or (mask2 and not first):
                     continue
-                d = _lib.MlpDesc(st.d, first, mask2, info["hidden"], info["layers"], info["act"], info["n_out"])
+                d = _lib.MlpDesc(st.d, first, mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 0,
+                                 info["skip"])
                 if L.ndq_mlp_supported(ctypes.byref(d)):
                     cost = first * st.d + bin(mask2).count("1")
                     if best is None or cost < best[0]:
@@ -117,7 +118,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         K = len(nets)
         if not (2 <= K <= 4) or len(streams) != K or os.environ.get("NDQ_NO_MULTI_FUSE"):
             return
-        shape = {(i["d"], i["hidden"], i["layers"], i["act"], i["n_out"]) for i in infos}
+        shape = {(i["d"], i["hidden"], i["layers"], i["act"], i["n_out"], i["skip"]) for i in infos}
         if len(shape) != 1 or infos[0]["n_out"] != 1 or infos[0]["hidden"] > 48:
             return
         if any(tuple(st.deps) != tuple(range(n_coords)) for st in streams.values()):

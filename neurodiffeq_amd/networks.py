@@ -130,6 +130,11 @@ _ACT_IDS = {nn.Tanh: _lib.NDQ_ACT_TANH, SinActv: _lib.NDQ_ACT_SIN, nn.Sigmoid: _
 def describe(net):
     """Return ``dict(d, hidden, layers, act, n_out, linears)`` if ``net`` is an FCNN the HIP kernels can run,
     else ``None`` (the solver then uses the composite autograd path for the whole system)."""
+    skip = None
+    if isinstance(net, Resnet):                  # FCNN branch + bias-free linear skip: out += S x, handled in-kernel
+        skip, net = net.skip_connection, net.residual
+        if skip.bias is not None or skip.weight.dtype != torch.float32:
+            return None
     seq = getattr(net, "NN", net)
     if not isinstance(seq, nn.Sequential):
         return None
@@ -153,8 +158,11 @@ def describe(net):
         return None
     if any(p.dtype != torch.float32 for l in linears for p in l.parameters()):
         return None
+    if skip is not None and (linears[-1].out_features != 1 or tuple(skip.weight.shape) != (1, linears[0].in_features)):
+        return None          # the in-kernel skip connection serves single-output networks
+    params = [p for l in linears for p in (l.weight, l.bias)] + ([skip.weight] if skip is not None else [])
     return dict(d=linears[0].in_features, hidden=hidden, layers=len(acts), act=_ACT_IDS[next(iter(act_types))],
-                n_out=linears[-1].out_features, linears=linears)
+                n_out=linears[-1].out_features, linears=linears, skip=int(skip is not None), params=params)
 
 
 class FlatParams:
@@ -166,7 +174,7 @@ class FlatParams:
     def __init__(self, net, device):
         self.net = net
         self.device = torch.device(device)
-        self.params = [p for l in describe(net)["linears"] for p in (l.weight, l.bias)]
+        self.params = describe(net)["params"]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
         # gradient buffer with one spare trailing slot: single-network systems keep the batch loss there so that

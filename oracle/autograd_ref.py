@@ -80,6 +80,19 @@ def make_fcnn(n_in, n_out, hidden, act="tanh", dtype=torch.float32):
     return nn.Sequential(*mods).to(dtype)
 
 
+class ResnetRef(nn.Module):
+    """FCNN branch + trainable bias-free linear skip from input to output (networks.py:73-106); the branch is built
+    first, so ``parameters()`` lists its weights before the skip matrix."""
+
+    def __init__(self, n_in, n_out, hidden, act="tanh", dtype=torch.float32):
+        super().__init__()
+        self.residual = make_fcnn(n_in, n_out, hidden, act, dtype)
+        self.skip_connection = nn.Linear(n_in, n_out, bias=False).to(dtype)
+
+    def forward(self, t):
+        return self.skip_connection(t) + self.residual(t)
+
+
 def get_flat(nets):
     return torch.cat([p.detach().reshape(-1) for p in chain.from_iterable(n.parameters() for n in nets)])
 

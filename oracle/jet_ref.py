@@ -94,17 +94,41 @@ def _forward(flat, dims, act, coords, streams):
     raise AssertionError
 
 
-def mlp_jets(flat, dims, act, coords, streams):
-    """Streams of the raw network output: dict stream -> (N, n_out)."""
+def _n_fcnn_params(dims):
+    return sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
+
+
+def mlp_jets(flat, dims, act, coords, streams, skip=False):
+    """Streams of the raw network output: dict stream -> (N, n_out).  ``skip``: Resnet (networks.py:73-106) -- the flat
+    vector ends with the bias-free skip matrix S (n_out, d) and the output gains S x (value) / S[:, a] (d/dx_a)."""
     streams = close_streams(streams)
-    z, _, _ = _forward(flat, dims, act, coords, streams)
+    flat = np.asarray(flat, dtype=np.float64)
+    z, _, _ = _forward(flat[:_n_fcnn_params(dims)], dims, act, coords, streams)
+    if skip:
+        S = flat[_n_fcnn_params(dims):].reshape(dims[-1], dims[0])
+        x = np.stack([np.asarray(c, dtype=np.float64).reshape(-1) for c in coords], axis=1)
+        z = dict(z)
+        z[()] = z[()] + x @ S.T
+        for m in streams:
+            if len(m) == 1:
+                z[m] = z[m] + S[:, m[0]]
     return z
 
 
-def mlp_jets_vjp(flat, dims, act, coords, gbar):
-    """Parameter gradient sum_n sum_streams <gbar[stream][n], d out_stream[n] / d params>  (flat, torch order).
+def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False):
+    """Parameter gradient sum_n sum_streams <gbar[stream][n], d out_stream[n] / d params>  (flat, torch order; with
+    ``skip`` the gradient of the skip matrix follows).
 
     ``gbar``: dict stream -> (N, n_out) adjoints."""
+    if skip:
+        flat = np.asarray(flat, dtype=np.float64)
+        base = mlp_jets_vjp(flat[:_n_fcnn_params(dims)], dims, act, coords, gbar)
+        x = np.stack([np.asarray(c, dtype=np.float64).reshape(-1) for c in coords], axis=1)
+        dS = np.asarray(gbar.get((), np.zeros((x.shape[0], dims[-1]))), dtype=np.float64).T @ x      # (n_out, d)
+        for m, g in gbar.items():
+            if len(m) == 1:
+                dS[:, m[0]] += np.asarray(g, dtype=np.float64).sum(axis=0)
+        return np.concatenate([base, dS.reshape(-1)])
     streams = close_streams(list(gbar.keys()))
     zlast, saved, layers = _forward(flat, dims, act, coords, streams)
     n = zlast[()].shape[0]

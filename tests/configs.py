@@ -10,7 +10,7 @@ from neurodiffeq_amd.conditions import (IVP, DirichletBVP2D, IBVP1D, NoCondition
 from neurodiffeq_amd.function_basis import RealSphericalHarmonics
 from neurodiffeq_amd.generators import Generator1D, Generator2D, GeneratorSpherical
 from neurodiffeq_amd.operators import spherical_laplacian
-from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx
+from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx, Resnet
 
 PI = math.pi
 DEFAULT_SIZE = {"c1": 1024, "c2": 256, "c3": 512, "c5": 1024, "c4": 131072}
@@ -92,6 +92,10 @@ def make(name, size=None):
     if name == "w3":      # Swish network on the C2 problem
         c = make("c2", 12)
         c["nets"] = [FCNN(2, 1, hidden_units=(32, 32), actv=Swish)]
+        return c
+    if name == "w5":      # Resnet on the C2 problem
+        c = make("c2", 12)
+        c["nets"] = [Resnet(2, 1, hidden_units=(32, 32))]
         return c
     if name == "w4":      # APTx networks: second-order ODE with a Neumann-form IVP coupled to a first-order one
         pde = lambda u, v, t: [diff(u, t, order=2) + v * diff(u, t) + u, diff(v, t) - u * v + torch.sin(t)]

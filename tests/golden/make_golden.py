@@ -28,7 +28,7 @@ import torch
 import neurodiffeq  # noqa: E402  (sets default dtype fp64 + default device as an import side effect)
 from neurodiffeq import diff
 from neurodiffeq.utils import set_tensor_type
-from neurodiffeq.networks import FCNN, SinActv, Swish, APTx
+from neurodiffeq.networks import FCNN, SinActv, Swish, APTx, Resnet
 from neurodiffeq.conditions import (IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis, BundleIVP,
                                     DirichletBVPSpherical)
 from neurodiffeq.generators import Generator1D, Generator2D, GeneratorSpherical
@@ -148,8 +148,15 @@ def cfg_w4():
     return dict(kind="1d", pde=ode, nets=nets, conds=conds, gen=gen, t=(0.0, 2.0))
 
 
+def cfg_w5():
+    """Resnet (FCNN branch + trainable linear skip, networks.py:73-106) on the C2 problem."""
+    c = cfg_c2(12)
+    c["nets"] = [Resnet(2, 1, hidden_units=(32, 32))]
+    return c
+
+
 CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
-           "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4}
+           "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5}
 
 
 # ----------------------------------------------------------------------------- helpers

@@ -14,7 +14,7 @@ from oracle import jet_ref as J
 from tests import configs, zoo
 from tests.pw_cpu import run_cpu
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None}
 
 
 def rel_l2(a, b):
@@ -47,8 +47,8 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     for net in nets:
         info = describe(net)
         dims = (info["d"],) + (info["hidden"],) * info["layers"] + (info["n_out"],)
-        npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
-        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx")[info["act"]]))
+        npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:])) + info["skip"] * info["n_out"] * info["d"]
+        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx")[info["act"]], bool(info["skip"])))
         flats.append(np.asarray(params[off:off + npar], np.float64))
         off += npar
     # a ("L", a, b, ..) symbol is the Laplacian stream = sum of the pure second derivatives (a,a), (b,b), ..
@@ -58,11 +58,11 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
         _, k, o, mi = prog.g.nodes[i]
         needed[k].add(mi)
     jets = {}
-    for k, (dims, act) in enumerate(dims_act):
+    for k, (dims, act, skip) in enumerate(dims_act):
         deps = prog.streams[k].deps
         local = lambda mi: tuple(sorted(deps.index(c) for c in mi))
         want = sorted({local(m) for mi in needed[k] for m in parts(mi)})
-        js = J.mlp_jets(flats[k], dims, act, [coords[c] for c in deps], want or [()])
+        js = J.mlp_jets(flats[k], dims, act, [coords[c] for c in deps], want or [()], skip=skip)
         jets[k] = {mi: sum(js[local(m)] for m in parts(mi)) for mi in needed[k]}       # (N, n_out)
     syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]][:, prog.g.nodes[i][2]]
                      for i in prog.symbols]).astype(np.float32)
@@ -74,7 +74,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     loss = float(term[loss](r64) * seed)
     # parameter gradient: adjoint streams through the jet oracle's VJP
     grads = []
-    for k, (dims, act) in enumerate(dims_act):
+    for k, (dims, act, skip) in enumerate(dims_act):
         deps = prog.streams[k].deps
         gb = {}
         for idx, i in enumerate(prog.symbols):
@@ -83,12 +83,12 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
                 for part in parts(mi):
                     m = gb.setdefault(tuple(sorted(deps.index(c) for c in part)), np.zeros((n, dims[-1])))
                     m[:, o] += gbar[idx].astype(np.float64)
-        grads.append(J.mlp_jets_vjp(flats[k], dims, act, [coords[c] for c in deps], gb))
+        grads.append(J.mlp_jets_vjp(flats[k], dims, act, [coords[c] for c in deps], gb, skip=skip))
     return prog, funcs.T, resid.T, loss, np.concatenate(grads)
 
 
 @pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
-                                      ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True)])
+                                      ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True), ("w5", True)])
 def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
@@ -110,7 +110,7 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "swish_laplace": [(1, 5, 1)], "sigmoid_mixed": [(1, 7, 0)], "swish_ode": [(1, 1, 0), (1, 0, 0)],
                "bundle_decay": [(1, 0, 0)], "bundle_bvp": [(1, 1, 0)], "shape_64x2": [(1, 5, 1)], "shape_32x3": [(1, 5, 1)],
                "shape_48x2": [(1, 5, 1)], "shape_16x2_sin": [(1, 5, 1)], "shape_32x1": [(1, 5, 1)],
-               "aptx_burgers": [(1, 1, 0)]}
+               "aptx_burgers": [(1, 1, 0)], "resnet_laplace": [(1, 5, 1)], "resnet_ode": [(1, 1, 0)]}
 
 
 @pytest.mark.parametrize("name", zoo.NAMES)

@@ -26,15 +26,17 @@ class System:
     def product(self):
         """(nets fp32, conditions, diff_eqs) on the neurodiffeq_amd API"""
         from neurodiffeq_amd import diff
-        from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx
+        from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx, Resnet
         actv = {"tanh": torch.nn.Tanh, "sin": SinActv, "sigmoid": torch.nn.Sigmoid, "swish": Swish, "aptx": APTx}
-        nets = [FCNN(i, o, hidden_units=h, actv=actv[a]) for i, o, h, a in self.net_specs]
+        nets = [(Resnet if a.startswith("resnet-") else FCNN)(i, o, hidden_units=h, actv=actv[a.replace("resnet-", "")])
+                for i, o, h, a in self.net_specs]
         return nets, self.conds(), self.pde(diff)
 
     def oracle(self, flat):
         """(nets fp64 carrying ``flat``, enforcers, pde) on the oracle"""
         from oracle import autograd_ref as R
-        nets = [R.make_fcnn(i, o, h, a, dtype=torch.float64) for i, o, h, a in self.net_specs]
+        nets = [R.ResnetRef(i, o, h, a[7:], dtype=torch.float64) if a.startswith("resnet-")
+                else R.make_fcnn(i, o, h, a, dtype=torch.float64) for i, o, h, a in self.net_specs]
         R.set_flat(nets, flat.double())
         return nets, self.enforcers(R.ref_diff), self.pde(R.ref_diff)
 
@@ -139,6 +141,17 @@ def build(name):
         conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
         return System(name, 2, [(2, 1, hidden, act)], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
                       lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, zero)])
+    if name == "resnet_laplace":      # Resnet (networks.py:73-106): FCNN + trainable linear skip, on the C2 problem
+        f0 = lambda y: torch.sin(PI * y)
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2)])
+        conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
+        return System(name, 2, [(2, 1, (32, 32), "resnet-tanh")], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, zero)])
+    if name == "resnet_ode":          # Resnet on a second-order ODE with a Neumann-form IVP (the skip feeds value and u')
+        pde = lambda D: (lambda u, t: [D(u, t, order=2) + 0.5 * D(u, t) + u - torch.cos(t)])
+        conds = lambda: [C.IVP(0.0, 1.0, u_0_prime=0.5)]
+        enf = lambda D: [lambda net, t: 1.0 + t * 0.5 + (1 - torch.exp(-t)) ** 2 * net(t)]
+        return System(name, 1, [(1, 1, (32, 32), "resnet-tanh")], [(0.0, 2.0)], pde, conds, enf)
     if name == "aptx_burgers":        # APTx network (default parameters) on a Burgers-type problem; kernels built on first use
         u0 = lambda x: -torch.sin(PI * x)
         pde = lambda D: (lambda u, x, t: [D(u, t) + u * D(u, x) - 0.05 * D(u, x, order=2)])
@@ -178,7 +191,7 @@ def build(name):
 
 NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "poisson3d",
          "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
-         "shape_16x2_sin", "shape_32x1", "aptx_burgers"]
+         "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode"]
 
 
 def spherical_solver_problem():
