@@ -137,11 +137,13 @@ class PointwiseProgram:
         self.funcs = list(funcs)
         if allow_lap is not None:
             self.residuals = self._merge_laplacian(self.residuals, self.funcs, n_nets, allow_lap)
-        self.n_nets = n_nets
+        self.n_nets = n_nets                    # parameter sets
+        self.site_net = list(getattr(graph, "site_net", None) or range(n_nets))
+        self.n_sites = len(self.site_net)       # (network, coordinate tuple) pairs: stream arrays are per site
         self.n_coords = graph.n_coords
         self.order = graph.reachable(self.residuals + self.funcs)
         self.streams = {}
-        for k in range(n_nets):
+        for k in range(self.n_sites):
             deps = graph.net_deps.get(k)
             if deps is None:
                 continue
@@ -318,6 +320,7 @@ class PointwiseProgram:
                 term = f"fmaxf({term}, fabsf(r[{e}]))"
         return f"""NDQ_PW_INLINE void ndq_pw_point(const float* c, const float* s, float seed, int want_adj, float* r, float* f, float* g) {{
 {chr(10).join(f"  const float c{i} = c[{i}];" for i in range(nc))}
+{chr(10).join(f"  const float c{i} = {_lit(v)};   // virtual coordinate (boundary value)" for i, v in sorted(self.g.vcoords.items()))}
 {body}
 }}
 // per-point loss term ({self.loss}); the host averages it: seed = 1 / (N * n_eq) for l2 / l1, 1 / N for infinity
@@ -440,7 +443,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 
     def _emit(self):
         nsym = max(len(self.symbols), 1)
-        neq, nf, nc, nn = len(self.residuals), len(self.funcs), self.n_coords, self.n_nets
+        neq, nf, nc, nn = len(self.residuals), len(self.funcs), self.n_coords, self.n_sites
         loads, stores = [], []
         for idx, i in enumerate(self.symbols):
             k, loc = self.sym_location(i)
@@ -729,7 +732,7 @@ def can_fuse(program: PointwiseProgram, descs=None):
     """Single-launch closure: one network, or 2..4 networks of ONE shape and stream set (H <= 48), every network
     reading all coordinates and producing one output."""
     K = program.n_nets
-    if K < 1 or K > 4 or any(k not in program.streams for k in range(K)):
+    if K < 1 or K > 4 or program.n_sites != K or any(k not in program.streams for k in range(K)):
         return False
     if any(tuple(program.streams[k].deps) != tuple(range(program.n_coords)) or program.streams[k].n_out != 1
            for k in range(K)):

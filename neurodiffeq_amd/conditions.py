@@ -26,6 +26,15 @@ def _exp(x):
     return x._un("exp") if isinstance(x, (Sym, SymMat)) else torch.exp(x)
 
 
+def _boundary_column(x, value):
+    """A column holding the boundary coordinate ``value`` at every point, differentiable like a coordinate: a fresh
+    leaf tensor (conditions.py:577-579), or -- while tracing -- a virtual coordinate of the graph, which makes the
+    network call on it a further evaluation site of the same parameters."""
+    if isinstance(x, Sym):
+        return Sym(x.g, x.g.vcoord(value))
+    return value * torch.ones_like(x, requires_grad=True)
+
+
 def _raw_output(net, coordinates, ith_unit):
     """Network output on cat(coords, 1) (conditions.py:52-55), or its symbol while tracing."""
     if any(isinstance(c, Sym) for c in coordinates):
@@ -237,12 +246,10 @@ class IBVP1D(BaseCondition):
         u = _raw_output(net, (x, t), self.ith_unit)
         if kind == "dd":
             return self.parameterize(u, x, t)
-        if isinstance(x, Sym):
-            raise TraceUnsupported("Neumann IBVP1D evaluates the network at boundary points")
         extra = []
         for need, xb in ((kind[0] == "n", self.x_min), (kind[1] == "n", self.x_max)):
             if need:
-                xe = xb * torch.ones_like(x, requires_grad=True)
+                xe = _boundary_column(x, xb)
                 extra += [_raw_output(net, (xe, t), self.ith_unit), xe]
         return self.parameterize(u, x, t, *extra)
 
@@ -292,12 +299,10 @@ class DoubleEndedBVP1D(BaseCondition):
         u = _raw_output(net, (x,), self.ith_unit)
         if kind == "dd":
             return self.parameterize(u, x)
-        if isinstance(x, Sym):
-            raise TraceUnsupported("Neumann DoubleEndedBVP1D evaluates the network at boundary points")
         extra = []
         for need, xb in ((kind[0] == "n", self.x_min), (kind[1] == "n", self.x_max)):
             if need:
-                xe = xb * torch.ones_like(x, requires_grad=True)
+                xe = _boundary_column(x, xb)
                 extra += [_raw_output(net, (xe,), self.ith_unit), xe]
         return self.parameterize(u, x, *extra)
 

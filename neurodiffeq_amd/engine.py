@@ -63,8 +63,8 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     descs = {}
 
     def allow_lap(k, coords):
-        """Is there a kernel for net k with the second derivatives w.r.t. ``coords`` merged into one Laplacian stream?"""
-        info = infos[k]
+        """Is there a kernel for site k with the second derivatives w.r.t. ``coords`` merged into one Laplacian stream?"""
+        info = infos[g.site_net[k]]
         deps = g.net_deps[k]
         if os.environ.get("NDQ_NO_LAP") or any(c not in deps for c in coords) or info["n_out"] != 1:
             return False
@@ -76,11 +76,9 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         return codegen.ensure_mlp_kernels(d)
 
     def widen(k, st):
-        info = infos[k]
+        info = infos[g.site_net[k]]
         if st.d != info["d"]:
             raise TraceUnsupported("network input width differs from the number of coordinates fed to it")
-        if list(st.deps) != list(range(st.deps[0], st.deps[0] + st.d)):
-            raise TraceUnsupported("network fed a non-contiguous subset of the coordinates")
         if st.lap:                      # allow_lap already checked that this exact kernel exists
             descs[k] = _lib.MlpDesc(st.d, 1, st.mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1, info["skip"])
             codegen.ensure_mlp_kernels(descs[k])
@@ -116,7 +114,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         multi-network closure kernel (one launch for the whole system) can serve them; a network then carries at most
         a few streams it does not need -- these systems are launch-bound, not compute-bound."""
         K = len(nets)
-        if not (2 <= K <= 4) or len(streams) != K or os.environ.get("NDQ_NO_MULTI_FUSE"):
+        if not (2 <= K <= 4) or len(streams) != K or len(g.site_net) != K or os.environ.get("NDQ_NO_MULTI_FUSE"):
             return
         shape = {(i["d"], i["hidden"], i["layers"], i["act"], i["n_out"], i["skip"]) for i in infos}
         if len(shape) != 1 or infos[0]["n_out"] != 1 or infos[0]["hidden"] > 48:
@@ -161,11 +159,19 @@ class FusedSystem:
             if fk.lib.ndq_fused_lds_bytes() <= 160 * 1024:       # K weight images + staging must fit one workgroup's LDS
                 self.fusedk = fk
         self.flat = [FlatParams(n, self.device) for n in self.nets]
-        # rows of the stream / adjoint-stream arrays of net k: [n_streams][n_out]
-        self.ns = [self.program.streams[k].n_streams * self.program.streams[k].n_out for k in range(len(self.nets))]
-        self.coord0 = [self.program.streams[k].deps[0] for k in range(len(self.nets))]
-        for k, fp in enumerate(self.flat):
-            assert self.L.ndq_mlp_num_params(ctypes.byref(self.descs[k])) == fp.numel
+        # evaluation sites: (network, coordinate tuple) pairs; site k < n_nets is network k at its first tuple, further
+        # sites (networks evaluated on a boundary as well: Neumann conditions) follow.  Stream arrays are per site.
+        self.site_net = list(self.program.site_net)
+        self.n_sites = len(self.site_net)
+        self.vcoords = dict(self.program.g.vcoords)
+        # rows of the stream / adjoint-stream arrays of site k: [n_streams][n_out]
+        self.ns = [self.program.streams[k].n_streams * self.program.streams[k].n_out for k in range(self.n_sites)]
+        self.site_deps = [tuple(self.program.streams[k].deps) for k in range(self.n_sites)]
+        # a site whose inputs are a run of consecutive batch coordinates reads the batch block in place ...
+        self.coord0 = [d[0] if all(c < n_coords for c in d) and list(d) == list(range(d[0], d[0] + len(d))) else None
+                       for d in self.site_deps]                     # ... any other gets a gathered block of its own
+        for k in range(self.n_sites):
+            assert self.L.ndq_mlp_num_params(ctypes.byref(self.descs[k])) == self.flat[self.site_net[k]].numel
         self._bufs = {}
         self._resident_cache = {}
         self._static, self._static_seen = {}, {}
@@ -207,16 +213,27 @@ class FusedSystem:
                  resid=torch.zeros(max(self.n_eq, 1), ld, dtype=f32, device=dev),
                  pw_blocks=self.kernel.blocks(n))
         b["loss_partials"] = torch.zeros(b["pw_blocks"], dtype=f32, device=dev)
-        b["bwd_blocks"] = [self.L.ndq_mlp_bwd_blocks(ctypes.byref(self.descs[k]), n) for k in range(len(self.nets))]
-        b["partials"] = [torch.empty(nb, fp.numel, dtype=f32, device=dev) for nb, fp in zip(b["bwd_blocks"], self.flat)]
+        b["bwd_blocks"] = [self.L.ndq_mlp_bwd_blocks(ctypes.byref(self.descs[k]), n) for k in range(self.n_sites)]
+        b["partials"] = [torch.empty(nb, self.flat[self.site_net[k]].numel, dtype=f32, device=dev)
+                         for k, nb in enumerate(b["bwd_blocks"])]
+        # gathered coordinate blocks of the sites that do not read the batch block in place: virtual coordinates are
+        # constant rows (filled here, once), real ones are copied in before every forward pass
+        b["site_coords"] = {}
+        for k, deps in enumerate(self.site_deps):
+            if self.coord0[k] is None:
+                blk = torch.zeros(len(deps), ld, dtype=f32, device=dev)
+                for row, c in enumerate(deps):
+                    if c in self.vcoords:
+                        blk[row].fill_(self.vcoords[c])
+                b["site_coords"][k] = blk
         if self.fusedk is not None:
             b["fused_blocks"] = self.fusedk.blocks(n)
             b["fused_partials_all"] = [torch.empty(b["fused_blocks"], fp.numel, dtype=f32, device=dev) for fp in self.flat]
             b["fused_partials"] = b["fused_partials_all"][0]
             b["fused_partials_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["fused_partials_all"]])
             b["fused_loss_partials"] = torch.zeros(b["fused_blocks"], dtype=f32, device=dev)
-        b["jets_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["jets"]])
-        b["gbar_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["gbar"]])
+        b["jets_pp"] = (_c_vp * self.n_sites)(*[t.data_ptr() for t in b["jets"]])
+        b["gbar_pp"] = (_c_vp * self.n_sites)(*[t.data_ptr() for t in b["gbar"]])
         b["coords"], b["coords_rows"] = b["coords_own"], None
         self._bufs[key] = b
         return b
@@ -315,10 +332,25 @@ class FusedSystem:
         return [b["funcs"][i, :n].view(-1, 1) for i in range(self.n_funcs)]
 
     # ------------------------------------------------------------------------------------------ launches
+    def _site_coords(self, b, k, n, refresh):
+        """Device pointer of site k's coordinate block [d][ld]: the batch block itself, or the site's gathered block
+        (``refresh``: copy the real coordinate rows of the current batch in first)."""
+        if self.coord0[k] is not None:
+            return self._coord_ptr(b, self.coord0[k])
+        blk = b["site_coords"][k]
+        if refresh:
+            for row, c in enumerate(self.site_deps[k]):
+                if c not in self.vcoords:
+                    src = b["coords_rows"][c] if b["coords_rows"] is not None else b["coords_own"][c]
+                    blk[row, :n].copy_(src[:n])
+        return _c_vp(blk.data_ptr())
+
     def forward(self, b, n, stream):
-        for k, fp in enumerate(self.flat):
+        for fp in self.flat:
             fp.sync()
-            rc = self.L.ndq_mlp_jet_fwd(ctypes.byref(self.descs[k]), self._coord_ptr(b, self.coord0[k]), b["ld"], n,
+        for k in range(self.n_sites):
+            fp = self.flat[self.site_net[k]]
+            rc = self.L.ndq_mlp_jet_fwd(ctypes.byref(self.descs[k]), self._site_coords(b, k, n, True), b["ld"], n,
                                         _ptr(fp.flat), _ptr(b["jets"][k]), b["ld"], stream)
             _lib.check(rc, "ndq_mlp_jet_fwd")
 
@@ -352,13 +384,18 @@ class FusedSystem:
         return seed
 
     def backward(self, b, n, stream, accumulate):
-        for k, fp in enumerate(self.flat):
-            rc = self.L.ndq_mlp_jet_bwd(ctypes.byref(self.descs[k]), self._coord_ptr(b, self.coord0[k]), b["ld"], n,
+        seen = set()
+        for k in range(self.n_sites):
+            net = self.site_net[k]
+            fp = self.flat[net]
+            rc = self.L.ndq_mlp_jet_bwd(ctypes.byref(self.descs[k]), self._site_coords(b, k, n, False), b["ld"], n,
                                         _ptr(fp.flat), _ptr(b["gbar"][k]), b["ld"], _ptr(b["partials"][k]), stream)
             _lib.check(rc, "ndq_mlp_jet_bwd")
+            # every site of a network adds into that network's gradient (the first one overwrites unless accumulating)
             rc = self.L.ndq_reduce_partials(_ptr(b["partials"][k]), b["bwd_blocks"][k], fp.numel, _ptr(fp.grad),
-                                            1 if accumulate else 0, 1.0, stream)
+                                            1 if (accumulate or net in seen) else 0, 1.0, stream)
             _lib.check(rc, "ndq_reduce_partials")
+            seen.add(net)
 
     def reduce_loss(self, b, stream, seed, slot):
         rc = self.L.ndq_reduce_partials(_ptr(b["loss_partials"]), b["pw_blocks"], 1,

@@ -28,24 +28,39 @@ UNARY = ("neg", "sin", "cos", "tan", "exp", "log", "tanh", "sqrt", "abs", "sinh"
 
 class Graph:
     """Hash-consed expression DAG.  Node = (op, args...) with integer ids; leaves:
-    ('const', value) | ('coord', i) | ('net', net_idx, out_idx, multiindex)."""
+    ('const', value) | ('coord', i) | ('net', site, out_idx, multiindex).
+
+    A *site* is one (network, coordinate tuple) pair the system evaluates: normally one per network, at the batch
+    coordinates; conditions with Neumann ends also evaluate their network on the boundary, i.e. at a tuple in which
+    one entry is a *virtual coordinate* (index >= n_coords, a constant column).  Site k < n_nets is network k's first
+    site, further sites of any network follow; ``site_net[site]`` maps back to the parameter set."""
 
     def __init__(self, n_coords):
         self.n_coords = n_coords
         self.nodes = []
         self._ids = {}
         self._dcache = {}
-        self.net_deps = {}       # net_idx -> tuple of coordinate indices in the order fed to the net
-        self.net_nout = {}       # net_idx -> number of output units
+        self.net_deps = {}       # site -> tuple of coordinate indices in the order fed to the net
+        self.net_nout = {}       # site -> number of output units
+        self.vcoords = {}        # virtual coordinate index (>= n_coords) -> its constant value
+        self.site_net = []       # site -> network index (filled by register_nets / net_symbol)
 
     # -------------------------------------------------------------- networks
     def register_nets(self, nets, n_outs):
         self._net_ids = {id(n): k for k, n in enumerate(nets)}
         self._net_nouts = list(n_outs)
+        self.site_net = list(range(len(nets)))
+        self._sites = {}         # (network index, deps) -> site
+
+    def vcoord(self, value):
+        """A new virtual coordinate: a column that holds ``value`` at every point (node id)."""
+        idx = self.n_coords + len(self.vcoords)
+        self.vcoords[idx] = float(value)
+        return self.coord(idx)
 
     def net_symbol(self, net, coords, ith_unit=None):
         """Symbol for ``net(cat(coords, 1))`` (conditions.py:52-55) -- only for the solver's own networks, evaluated at
-        the batch coordinates themselves."""
+        (real or virtual) coordinate columns."""
         k = getattr(self, "_net_ids", {}).get(id(net))
         if k is None:
             raise TraceUnsupported("a network that does not belong to the solver was called inside the traced region")
@@ -53,13 +68,21 @@ class Graph:
         for c in coords:
             node = self.nodes[c.i] if isinstance(c, Sym) else None
             if node is None or node[0] != "coord":
-                raise TraceUnsupported("network evaluated at something other than the batch coordinates")
+                raise TraceUnsupported("network evaluated at something other than coordinate columns")
             deps.append(node[1])
         deps = tuple(deps)
-        if self.net_deps.setdefault(k, deps) != deps:
-            raise TraceUnsupported("network evaluated at two different coordinate tuples")
+        site = self._sites.get((k, deps))
+        if site is None:
+            if k not in self.net_deps:           # the network's first site keeps the network's own index
+                site = k
+            else:
+                site = len(self.site_net)
+                self.site_net.append(k)
+            self._sites[(k, deps)] = site
+            self.net_deps[site] = deps
         n_out = self._net_nouts[k]
-        self.net_nout[k] = n_out
+        self.net_nout[site] = n_out
+        k = site
         if ith_unit is not None:
             return Sym(self, self.net(k, ith_unit))
         if n_out == 1:

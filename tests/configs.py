@@ -6,7 +6,7 @@ import torch
 
 from neurodiffeq_amd import diff
 from neurodiffeq_amd.conditions import (IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis, BundleIVP,
-                                        DirichletBVPSpherical)
+                                        DirichletBVPSpherical, DoubleEndedBVP1D)
 from neurodiffeq_amd.function_basis import RealSphericalHarmonics
 from neurodiffeq_amd.generators import Generator1D, Generator2D, GeneratorSpherical
 from neurodiffeq_amd.operators import spherical_laplacian
@@ -93,6 +93,24 @@ def make(name, size=None):
         c = make("c2", 12)
         c["nets"] = [FCNN(2, 1, hidden_units=(32, 32), actv=Swish)]
         return c
+    if name in ("w6", "w7"):      # IBVP1D with Neumann ends: the network is evaluated on the boundary as well
+        if name == "w6":
+            pde = lambda u, x, t: [diff(u, t) - 0.1 * diff(u, x, order=2)]
+            cond = IBVP1D(x_min=0.0, x_max=1.0, t_min=0.0, t_min_val=lambda x: torch.cos(PI * x),
+                          x_min_prime=lambda t: 0.0 * t, x_max_prime=lambda t: 0.2 * t)
+        else:
+            pde = lambda u, x, t: [diff(u, t) - 0.1 * diff(u, x, order=2) + u ** 2]
+            cond = IBVP1D(x_min=0.0, x_max=1.0, t_min=0.0, t_min_val=lambda x: torch.sin(PI * x / 2),
+                          x_min_val=lambda t: 0.0 * t, x_max_prime=lambda t: torch.sin(t))
+        return dict(kind="2d", pde=pde, nets=[FCNN(2, 1, hidden_units=(32, 32))], conds=[cond],
+                    gen=Generator2D((10, 10), (0, 0), (1, 1), "equally-spaced-noisy"), n_points=100, dom=((0, 0), (1, 1)))
+    if name == "w8":      # DoubleEndedBVP1D: Neumann-Dirichlet and Dirichlet-Neumann, one network each
+        pde = lambda u, v, x: [diff(u, x, order=2) + u - v, diff(v, x, order=2) - v + torch.sin(x)]
+        nets = [FCNN(1, 1, hidden_units=(32, 32)) for _ in range(2)]
+        conds = [DoubleEndedBVP1D(0.0, 1.0, x_min_prime=-0.5, x_max_val=2.0),
+                 DoubleEndedBVP1D(0.0, 1.0, x_min_val=1.0, x_max_prime=0.5)]
+        return dict(kind="1d", pde=pde, nets=nets, conds=conds, gen=Generator1D(48, 0.0, 1.0, "equally-spaced-noisy"),
+                    n_points=48, dom=(0.0, 1.0))
     if name == "w5":      # Resnet on the C2 problem
         c = make("c2", 12)
         c["nets"] = [Resnet(2, 1, hidden_units=(32, 32))]

@@ -30,7 +30,7 @@ from neurodiffeq import diff
 from neurodiffeq.utils import set_tensor_type
 from neurodiffeq.networks import FCNN, SinActv, Swish, APTx, Resnet
 from neurodiffeq.conditions import (IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis, BundleIVP,
-                                    DirichletBVPSpherical)
+                                    DirichletBVPSpherical, DoubleEndedBVP1D)
 from neurodiffeq.generators import Generator1D, Generator2D, GeneratorSpherical
 from neurodiffeq.solvers import Solver1D, Solver2D, SolverSpherical, BundleSolver1D
 from neurodiffeq.function_basis import RealSphericalHarmonics
@@ -155,8 +155,39 @@ def cfg_w5():
     return c
 
 
+def cfg_w6():
+    """Heat equation with Neumann conditions on both ends (IBVP1D, conditions.py:685-712): the network is evaluated on
+    the two boundaries as well."""
+    pde = lambda u, x, t: [diff(u, t) - 0.1 * diff(u, x, order=2)]
+    nets = [FCNN(2, 1, hidden_units=(32, 32))]
+    conds = [IBVP1D(x_min=0.0, x_max=1.0, t_min=0.0, t_min_val=lambda x: torch.cos(PI * x),
+                    x_min_prime=lambda t: 0.0 * t, x_max_prime=lambda t: 0.2 * t)]
+    gen = Generator2D((10, 10), (0, 0), (1, 1), "equally-spaced-noisy")
+    return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen)
+
+
+def cfg_w7():
+    """Mixed Dirichlet / Neumann IBVP1D (left value, right flux)."""
+    pde = lambda u, x, t: [diff(u, t) - 0.1 * diff(u, x, order=2) + u ** 2]
+    nets = [FCNN(2, 1, hidden_units=(32, 32))]
+    conds = [IBVP1D(x_min=0.0, x_max=1.0, t_min=0.0, t_min_val=lambda x: torch.sin(PI * x / 2),
+                    x_min_val=lambda t: 0.0 * t, x_max_prime=lambda t: torch.sin(t))]
+    gen = Generator2D((10, 10), (0, 0), (1, 1), "equally-spaced-noisy")
+    return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen)
+
+
+def cfg_w8():
+    """Two-point boundary value problems with DoubleEndedBVP1D (conditions.py:715-884): Neumann-Dirichlet and
+    Dirichlet-Neumann, one network each."""
+    ode = lambda u, v, x: [diff(u, x, order=2) + u - v, diff(v, x, order=2) - v + torch.sin(x)]
+    nets = [FCNN(1, 1, hidden_units=(32, 32)) for _ in range(2)]
+    conds = [DoubleEndedBVP1D(0.0, 1.0, x_min_prime=-0.5, x_max_val=2.0), DoubleEndedBVP1D(0.0, 1.0, x_min_val=1.0, x_max_prime=0.5)]
+    gen = Generator1D(48, 0.0, 1.0, "equally-spaced-noisy")
+    return dict(kind="1d", pde=ode, nets=nets, conds=conds, gen=gen, t=(0.0, 1.0))
+
+
 CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
-           "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5}
+           "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5, "w6": cfg_w6, "w7": cfg_w7, "w8": cfg_w8}
 
 
 # ----------------------------------------------------------------------------- helpers

@@ -71,7 +71,7 @@ def _oracle_vjp(flat, dims, act, coords, streams, gbar):
         for p in _parts(m):
             gb[p] = gb.get(p, 0) + gbar[s].astype(np.float64).T
     return J.mlp_jets_vjp(flat.astype(np.float64), dims, act, list(coords.astype(np.float64)), gb)
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None}
 
 
 def rel_l2(a, b):
@@ -319,7 +319,7 @@ def _load_system(name, size, single_kernel=True):
 # "1k" = single-launch fused closure kernel (single-network systems), "3k" = forward / pointwise / backward pipeline
 @pytest.mark.parametrize("name,mode", [("c1", "3k"), ("c1", "1k"), ("c2", "1k"), ("c2", "3k"), ("c3", "1k"), ("c3", "3k"), ("c5", "3k"),
                                        ("c4", "3k"), ("w1", "1k"), ("w1", "3k"), ("w2", "1k"), ("w2", "3k"), ("w3", "1k"),
-                                       ("w4", "1k"), ("w4", "3k"), ("w5", "1k"), ("w5", "3k")])
+                                       ("w4", "1k"), ("w4", "3k"), ("w5", "1k"), ("w5", "3k"), ("w6", "3k"), ("w7", "3k"), ("w8", "3k")])
 def test_fused_closure_matches_reference_golden(golden_dir, name, mode):
     """funcs / residuals / loss / flat gradient of ONE closure (solvers.py:369-395) on the reference's own inputs."""
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
@@ -344,7 +344,7 @@ def test_fused_closure_matches_reference_golden(golden_dir, name, mode):
     assert max(errs["funcs"], errs["residuals"], errs["loss"], errs["grad"]) < TOL, errs
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "w1", "w2", "w3", "w4", "w5"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "w1", "w2", "w3", "w4", "w5", "w6", "w7", "w8"])
 def test_solver_trajectory_matches_reference_golden(golden_dir, name):
     """Three epochs of Solver.run_train_epoch (sampling on the CPU RNG, fused step, fused Adam) against the
     reference solver's loss history and final parameters."""

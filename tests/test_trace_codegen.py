@@ -14,7 +14,7 @@ from oracle import jet_ref as J
 from tests import configs, zoo
 from tests.pw_cpu import run_cpu
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None}
 
 
 def rel_l2(a, b):
@@ -53,16 +53,20 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
         off += npar
     # a ("L", a, b, ..) symbol is the Laplacian stream = sum of the pure second derivatives (a,a), (b,b), ..
     parts = lambda mi: [(c, c) for c in mi[1:]] if (mi and mi[0] == "L") else [mi]
-    needed = {k: set() for k in range(len(nets))}
+    # evaluation sites: (network, coordinate tuple) pairs; a virtual coordinate is a constant column
+    site_net = prog.site_net
+    column = lambda c: coords[c] if c < n_coords else np.full(n, prog.g.vcoords[c], np.float32)
+    needed = {k: set() for k in range(prog.n_sites)}
     for i in prog.symbols:
         _, k, o, mi = prog.g.nodes[i]
         needed[k].add(mi)
     jets = {}
-    for k, (dims, act, skip) in enumerate(dims_act):
+    for k in range(prog.n_sites):
+        dims, act, skip = dims_act[site_net[k]]
         deps = prog.streams[k].deps
         local = lambda mi: tuple(sorted(deps.index(c) for c in mi))
         want = sorted({local(m) for mi in needed[k] for m in parts(mi)})
-        js = J.mlp_jets(flats[k], dims, act, [coords[c] for c in deps], want or [()], skip=skip)
+        js = J.mlp_jets(flats[site_net[k]], dims, act, [column(c) for c in deps], want or [()], skip=skip)
         jets[k] = {mi: sum(js[local(m)] for m in parts(mi)) for mi in needed[k]}       # (N, n_out)
     syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]][:, prog.g.nodes[i][2]]
                      for i in prog.symbols]).astype(np.float32)
@@ -73,8 +77,9 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     term = {"l2": lambda r: (r ** 2).sum(), "l1": lambda r: np.abs(r).sum(), "infinity": lambda r: np.abs(r).max(axis=0).sum()}
     loss = float(term[loss](r64) * seed)
     # parameter gradient: adjoint streams through the jet oracle's VJP
-    grads = []
-    for k, (dims, act, skip) in enumerate(dims_act):
+    grads = [0.0] * len(nets)
+    for k in range(prog.n_sites):                       # every site of a network adds into that network's gradient
+        dims, act, skip = dims_act[site_net[k]]
         deps = prog.streams[k].deps
         gb = {}
         for idx, i in enumerate(prog.symbols):
@@ -83,12 +88,15 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
                 for part in parts(mi):
                     m = gb.setdefault(tuple(sorted(deps.index(c) for c in part)), np.zeros((n, dims[-1])))
                     m[:, o] += gbar[idx].astype(np.float64)
-        grads.append(J.mlp_jets_vjp(flats[k], dims, act, [coords[c] for c in deps], gb, skip=skip))
+        if not gb:
+            gb = {(): np.zeros((n, dims[-1]))}
+        grads[site_net[k]] = grads[site_net[k]] + J.mlp_jets_vjp(flats[site_net[k]], dims, act, [column(c) for c in deps], gb,
+                                                               skip=skip)
     return prog, funcs.T, resid.T, loss, np.concatenate(grads)
 
 
 @pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
-                                      ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True), ("w5", True)])
+                                      ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True), ("w5", True), ("w6", True), ("w7", True), ("w8", True)])
 def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
