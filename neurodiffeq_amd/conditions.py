@@ -225,8 +225,9 @@ class DirichletBVP2D(BaseCondition):
 
 class IBVP1D(BaseCondition):
     """Initial condition u(x,t0) = u0(x) plus a Dirichlet or Neumann condition at each end of [x0, x1]
-    (conditions.py:512-712).  The Dirichlet-Dirichlet form is traceable (fused path); the Neumann forms evaluate the
-    network at boundary points and differentiate it there, which runs on the composite path."""
+    (conditions.py:512-712).  The Neumann forms evaluate the network at boundary points as well and differentiate
+    it there; while tracing, such a boundary column is a virtual coordinate of the graph and the call on it a further
+    evaluation site of the same parameters (engine.FusedSystem runs the MLP kernels once per site)."""
 
     def __init__(self, x_min, x_max, t_min, t_min_val, x_min_val=None, x_min_prime=None, x_max_val=None,
                  x_max_prime=None):
@@ -281,7 +282,7 @@ class IBVP1D(BaseCondition):
 class DoubleEndedBVP1D(BaseCondition):
     """Two-point boundary conditions in one variable, each end either Dirichlet (``x_*_val``) or Neumann
     (``x_*_prime``) (conditions.py:715-884).  A Neumann end needs the network and its derivative AT that end, so
-    ``enforce`` is overridden to evaluate the network there as well (composite path only)."""
+    ``enforce`` is overridden to evaluate the network there as well (a further evaluation site on the fused path)."""
 
     def __init__(self, x_min, x_max, x_min_val=None, x_min_prime=None, x_max_val=None, x_max_prime=None):
         super().__init__()
