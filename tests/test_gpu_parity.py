@@ -565,6 +565,41 @@ def test_bundle_solver_trains_fused_and_matches_autograd_path():
     assert torch.allclose(a.get_solution()(torch.zeros(50), u0, lam).cpu(), u0, atol=1e-6)        # u(0; u0, lam) = u0
 
 
+def test_checkpoint_and_resume_of_a_fused_solver():
+    """The reference's resume recipe (README: dill the internals, rebuild a solver around the loaded networks and
+    optimiser; callbacks.py:129-155, solvers_utils.py:281-398): the fused path's flat parameters, device-side Adam
+    moments and step counts must survive the round trip -- resumed training continues the uninterrupted trajectory."""
+    import dill
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.generators import Generator1D
+    from neurodiffeq_amd.solvers import Solver1D
+    ode = lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)]
+    conds = [IVP(0.0, 1.5), IVP(0.0, 1.0)]
+
+    def make(nets=None, optimizer=None):
+        s = Solver1D(ode, conds, t_min=0.1, t_max=4.0, nets=nets, optimizer=optimizer, n_batches_valid=1,
+                     train_generator=Generator1D(64, 0.1, 4.0, "equally-spaced"), valid_generator=Generator1D(64, 0.1, 4.0, "equally-spaced"))
+        s.fused = "require"
+        return s
+    torch.manual_seed(0)
+    whole = make()
+    whole.fit(20, tqdm_file=None)
+    torch.manual_seed(0)
+    first = make()
+    first.fit(10, tqdm_file=None)
+    blob = dill.dumps(first.get_internals(["nets", "optimizer", "global_epoch", "lowest_loss"], return_type="dict"))
+    state = dill.loads(blob)
+    resumed = make(nets=state["nets"], optimizer=state["optimizer"])
+    resumed.fit(10, tqdm_file=None)
+    assert resumed.fused_active
+    a = np.array(whole.metrics_history["train_loss"][10:])
+    b = np.array(resumed.metrics_history["train_loss"])
+    assert np.allclose(a, b, rtol=1e-5), (a, b)
+    pa, pb = R.get_flat(whole.nets).cpu().numpy(), R.get_flat(resumed.nets).cpu().numpy()
+    assert rel_l2(pb, pa) < 1e-5
+
+
 def test_gradient_accumulation_and_validation_mode():
     """n_batches_train = 2 accumulates gradients before one step (solvers.py:360-419); a validation epoch leaves
     parameters and gradients untouched."""
