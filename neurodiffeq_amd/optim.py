@@ -18,6 +18,19 @@ class FusedAdam(torch.optim.Adam):
         self._bound = []            # [(FlatParams, exp_avg_flat, exp_avg_sq_flat, group)]
         self._bound_ids = set()
         self._steps = {}
+        self._dirty_steps = False
+
+    # pickling / deepcopy (checkpoints: callbacks.py:129-155, solvers_utils.py:281-398): torch serialises defaults,
+    # state and param_groups only, so the per-parameter ``step`` tensors are brought up to date first and the
+    # binding to a solver's flat buffers -- device pointers -- is dropped; the next solver binds afresh and adopts the
+    # moments / step counts from ``state``.
+    def __getstate__(self):
+        self._sync_step_tensors()
+        return super().__getstate__()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._bound, self._bound_ids, self._steps, self._dirty_steps = [], set(), {}, False
 
     def bind(self, flat_params):
         """Adopt the flat buffers of ``flat_params`` (list of FlatParams) for every parameter this optimiser owns."""
