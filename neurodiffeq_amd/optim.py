@@ -32,6 +32,12 @@ class FusedAdam(torch.optim.Adam):
         super().__setstate__(state)
         self._bound, self._bound_ids, self._steps, self._dirty_steps = [], set(), {}, False
 
+    def load_state_dict(self, state_dict):
+        """Loaded moments / step counts live in fresh tensors: drop the binding, the solver binds again before its next
+        native epoch and ``bind`` adopts them."""
+        super().load_state_dict(state_dict)
+        self._bound, self._bound_ids, self._steps, self._dirty_steps = [], set(), {}, False
+
     def bind(self, flat_params):
         """Adopt the flat buffers of ``flat_params`` (list of FlatParams) for every parameter this optimiser owns."""
         if [id(fp) for fp, *_ in self._bound] == [id(fp) for fp in flat_params]:

@@ -418,7 +418,9 @@ class BaseSolver(ABC):
         slots = None
         if train:
             if not all(self.optimizer.bound(fp) for fp in system.flat):
-                return False
+                self.optimizer.bind(system.flat)     # a new / unpickled / re-loaded optimiser: adopt its state first
+                if not all(self.optimizer.bound(fp) for fp in system.flat):
+                    return False
             slots = [self.optimizer.fast_slot(fp) for fp in system.flat]
         shard = self.dist
         if train and nb == 1 and len(system.flat) > 1 and system.fast_ready(shard) and len({s[3] for s in slots}) == 1:

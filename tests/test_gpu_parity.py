@@ -598,6 +598,15 @@ def test_checkpoint_and_resume_of_a_fused_solver():
     assert np.allclose(a, b, rtol=1e-5), (a, b)
     pa, pb = R.get_flat(whole.nets).cpu().numpy(), R.get_flat(resumed.nets).cpu().numpy()
     assert rel_l2(pb, pa) < 1e-5
+    # the other route: state_dict round trip into a live solver (torch idiom), then keep training natively
+    torch.manual_seed(0)
+    again = make()
+    again.fit(10, tqdm_file=None)
+    sd = dill.loads(dill.dumps(again.optimizer.state_dict()))
+    again.optimizer.load_state_dict(sd)
+    again.fit(10, tqdm_file=None)
+    assert getattr(again._fused_sys, "_fast", None) is not None
+    assert np.allclose(np.array(again.metrics_history["train_loss"][10:]), a, rtol=1e-5)
 
 
 def test_gradient_accumulation_and_validation_mode():
