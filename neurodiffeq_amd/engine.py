@@ -194,11 +194,23 @@ class FusedSystem:
             return 0
         return step // 4
 
+    MAX_BUFFER_SETS = 8
+
     def buffers(self, n, ld=None):
         key = (n, ld)
         b = self._bufs.get(key)
         if b is not None:
+            self._bufs[key] = self._bufs.pop(key)           # most recently used last
             return b
+        # batch sizes that change every epoch (FilterGenerator, ...) must not pile up buffer sets: keep the most
+        # recently used few; an evicted set is freed once the launches that use it have drained (stream-ordered)
+        while len(self._bufs) >= self.MAX_BUFFER_SETS:
+            old = self._bufs.pop(next(iter(self._bufs)))
+            fs = getattr(self, "_fast", None)
+            if fs is not None:
+                for k in [k for k in fs["structs"] if k[2] == id(old)]:
+                    del fs["structs"][k]
+            self._resident_cache = {k: v for k, v in self._resident_cache.items() if v[1] is not old}
         ld = ld or _round_up(n, 64)
         dev, f32 = self.device, torch.float32
         b = dict(ld=ld,

@@ -609,6 +609,29 @@ def test_checkpoint_and_resume_of_a_fused_solver():
     assert np.allclose(np.array(again.metrics_history["train_loss"][10:]), a, rtol=1e-5)
 
 
+def test_batch_size_that_changes_every_epoch():
+    """FilterGenerator (generators.py:904-952) keeps a different number of points each draw: the engine's per-size
+    buffer sets are capped, and every epoch's loss is the loss of that epoch's points (checked through the composite path)."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import NoCondition
+    from neurodiffeq_amd.generators import FilterGenerator, Generator2D
+    from neurodiffeq_amd.solvers import Solver2D
+
+    def run(mode):
+        torch.manual_seed(0)
+        gen = FilterGenerator(Generator2D((24, 24), (0, 0), (1, 1), "equally-spaced-noisy"),
+                              lambda xs: (xs[0] - 0.5) ** 2 + (xs[1] - 0.5) ** 2 < 0.2)
+        s = Solver2D(lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2) - u], [NoCondition()], xy_min=(0, 0),
+                     xy_max=(1, 1), train_generator=gen, valid_generator=gen, n_batches_valid=0)
+        s.fused = mode
+        torch.manual_seed(1)
+        s.fit(30, tqdm_file=None)
+        return s
+    a, b = run("require"), run("off")
+    assert a.fused_active and len(a._fused_sys._bufs) <= a._fused_sys.MAX_BUFFER_SETS
+    assert np.allclose(a.metrics_history["train_loss"], b.metrics_history["train_loss"], rtol=3e-4)
+
+
 def test_gradient_accumulation_and_validation_mode():
     """n_batches_train = 2 accumulates gradients before one step (solvers.py:360-419); a validation epoch leaves
     parameters and gradients untouched."""
