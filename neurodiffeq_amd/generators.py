@@ -575,11 +575,13 @@ class DeviceGenerator(BaseGenerator):
 
     Supported: ``Generator1D`` ('uniform', 'equally-spaced', 'equally-spaced-noisy'), ``Generator2D`` / ``Generator3D``
     ('equally-spaced', 'equally-spaced-noisy'), ``GeneratorSpherical`` (both radial laws).  ``get_examples`` enqueues
-    one kernel on the current stream and returns ``(N, 1)`` views of ONE resident SoA block which the fused engine
-    reads in place; the block is overwritten by the next draw (stream-ordered, so the previous step has consumed it).
+    one kernel and returns ``(N, 1)`` views of a resident SoA block which the fused engine reads in place.  With
+    ``prefetch`` (default) there are two blocks: the batch returned now was drawn during the previous step on a side
+    stream and the next one is being drawn while this one trains; a returned batch stays valid until the call after
+    the next.  Without it there is one block, drawn on the current stream and overwritten by the next call.
     """
 
-    def __init__(self, generator, device=None, seed=None, stream_id=None):
+    def __init__(self, generator, device=None, seed=None, stream_id=None, prefetch=True):
         super().__init__()
         from . import _lib
         if not torch.cuda.is_available():
@@ -593,8 +595,27 @@ class DeviceGenerator(BaseGenerator):
         self.desc = self.describe(generator)
         self._L = _lib.lib()
         ld = (self.size + 63) // 64 * 64
-        self.block = torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device)
-        self._views = [self.block[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)]
+        # prefetch: two blocks; while a training step consumes one, the next batch is drawn into the other on a side
+        # stream (the closure kernel leaves most of every CU's wave slots free), so the sampler's ~5 us leave the
+        # critical path.  Ordering is by HIP events only -- no host synchronisation.
+        self.prefetch = bool(prefetch)
+        nbuf = 2 if self.prefetch else 1
+        self.blocks = [torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
+        self.block = self.blocks[0]
+        self._views_of = [[blk[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)] for blk in self.blocks]
+        self._views = self._views_of[0]
+        if self.prefetch:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._sampled = [torch.cuda.Event() for _ in range(2)]     # recorded on the side stream after a draw
+            self._consumed = torch.cuda.Event()                       # recorded on the consumer's stream
+            self._ahead = None                                         # index of the block that holds draw `self.draw`
+
+    def _launch(self, block, draw, stream_ptr):
+        rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, draw, self.stream_id, block.data_ptr(),
+                                block.shape[1], ctypes.c_void_p(stream_ptr))
+        if rc != 0:
+            from . import _lib
+            raise _lib.NdqError(f"ndq_sample failed with code {rc}")
 
     @staticmethod
     def describe(g):
@@ -625,13 +646,27 @@ class DeviceGenerator(BaseGenerator):
         return d
 
     def get_examples(self):
-        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, self.draw, self.stream_id, self.block.data_ptr(),
-                                self.block.shape[1], stream)
-        if rc != 0:
-            from . import _lib
-            raise _lib.NdqError(f"ndq_sample failed with code {rc}")
+        cur = torch.cuda.current_stream(self.device)
+        if not self.prefetch:
+            self._launch(self.block, self.draw, cur.cuda_stream)
+            self.draw += 1
+            return self._views
+        if self._ahead is None:                          # first call: draw synchronously with the consumer's stream
+            b = 0
+            self._launch(self.blocks[b], self.draw, cur.cuda_stream)
+        else:                                            # this draw was prefetched: the consumer waits for it
+            b = self._ahead
+            cur.wait_event(self._sampled[b])
+        # draw the next batch into the other block, once everything already enqueued on the consumer's stream (the
+        # last reader of that block is the training step before this call) has drained
+        nxt = b ^ 1
+        self._consumed.record(cur)
+        self._side.wait_event(self._consumed)
+        self._launch(self.blocks[nxt], self.draw + 1, self._side.cuda_stream)
+        self._sampled[nxt].record(self._side)
+        self._ahead = nxt
         self.draw += 1
+        self.block, self._views = self.blocks[b], self._views_of[b]
         return self._views
 
     def _internal_vars(self):
