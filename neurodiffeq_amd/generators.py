@@ -605,10 +605,26 @@ class DeviceGenerator(BaseGenerator):
         self._views_of = [[blk[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)] for blk in self.blocks]
         self._views = self._views_of[0]
         if self.prefetch:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._sampled = [torch.cuda.Event() for _ in range(2)]     # recorded on the side stream after a draw
-            self._consumed = torch.cuda.Event()                       # recorded on the consumer's stream
-            self._ahead = None                                         # index of the block that holds draw `self.draw`
+            # raw HIP events / waits through ctypes: the torch wrappers cost ~5 us of host time apiece, more than the
+            # kernel they are meant to hide
+            self._hip = hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+            hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+
+            def event():
+                e = ctypes.c_void_p()
+                if hip.hipEventCreateWithFlags(ctypes.byref(e), 2) != 0:          # hipEventDisableTiming
+                    raise _lib.NdqError("hipEventCreateWithFlags failed")
+                return e
+            self._side_stream = torch.cuda.Stream(device=self.device)     # kept alive; only its handle is used
+            self._side = ctypes.c_void_p(self._side_stream.cuda_stream)
+            self._sampled = [event(), event()]        # recorded on the side stream after a draw
+            self._consumed = event()                  # recorded on the consumer's stream
+            self._ahead = None                        # index of the block that holds draw `self.draw`
+            self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or \
+                (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
 
     def _launch(self, block, draw, stream_ptr):
         rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, draw, self.stream_id, block.data_ptr(),
@@ -646,24 +662,25 @@ class DeviceGenerator(BaseGenerator):
         return d
 
     def get_examples(self):
-        cur = torch.cuda.current_stream(self.device)
         if not self.prefetch:
-            self._launch(self.block, self.draw, cur.cuda_stream)
+            self._launch(self.block, self.draw, torch.cuda.current_stream(self.device).cuda_stream)
             self.draw += 1
             return self._views
+        hip = self._hip
+        cur = ctypes.c_void_p(self._raw_stream(self._dev_index))
         if self._ahead is None:                          # first call: draw synchronously with the consumer's stream
             b = 0
-            self._launch(self.blocks[b], self.draw, cur.cuda_stream)
+            self._launch(self.blocks[b], self.draw, cur.value)
         else:                                            # this draw was prefetched: the consumer waits for it
             b = self._ahead
-            cur.wait_event(self._sampled[b])
+            hip.hipStreamWaitEvent(cur, self._sampled[b], 0)
         # draw the next batch into the other block, once everything already enqueued on the consumer's stream (the
         # last reader of that block is the training step before this call) has drained
         nxt = b ^ 1
-        self._consumed.record(cur)
-        self._side.wait_event(self._consumed)
-        self._launch(self.blocks[nxt], self.draw + 1, self._side.cuda_stream)
-        self._sampled[nxt].record(self._side)
+        hip.hipEventRecord(self._consumed, cur)
+        hip.hipStreamWaitEvent(self._side, self._consumed, 0)
+        self._launch(self.blocks[nxt], self.draw + 1, self._side.value)
+        hip.hipEventRecord(self._sampled[nxt], self._side)
         self._ahead = nxt
         self.draw += 1
         self.block, self._views = self.blocks[b], self._views_of[b]
