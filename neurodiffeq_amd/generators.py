@@ -575,13 +575,13 @@ class DeviceGenerator(BaseGenerator):
 
     Supported: ``Generator1D`` ('uniform', 'equally-spaced', 'equally-spaced-noisy'), ``Generator2D`` / ``Generator3D``
     ('equally-spaced', 'equally-spaced-noisy'), ``GeneratorSpherical`` (both radial laws).  ``get_examples`` enqueues
-    one kernel and returns ``(N, 1)`` views of a resident SoA block which the fused engine reads in place.  With
-    ``prefetch`` (default) there are two blocks: the batch returned now was drawn during the previous step on a side
-    stream and the next one is being drawn while this one trains; a returned batch stays valid until the call after
-    the next.  Without it there is one block, drawn on the current stream and overwritten by the next call.
+    one kernel on the current stream and returns ``(N, 1)`` views of ONE resident SoA block which the fused engine
+    reads in place; the block is overwritten by the next draw (stream-ordered, so the previous step has consumed it).
+    (Drawing the next batch on a side stream while the current one trains was tried: the event waits between the two
+    streams cost more than the 4 us kernel they hide -- 41 us per step instead of 33 -- and it was dropped.)
     """
 
-    def __init__(self, generator, device=None, seed=None, stream_id=None, prefetch=True):
+    def __init__(self, generator, device=None, seed=None, stream_id=None):
         super().__init__()
         from . import _lib
         if not torch.cuda.is_available():
@@ -595,43 +595,8 @@ class DeviceGenerator(BaseGenerator):
         self.desc = self.describe(generator)
         self._L = _lib.lib()
         ld = (self.size + 63) // 64 * 64
-        # prefetch: two blocks; while a training step consumes one, the next batch is drawn into the other on a side
-        # stream (the closure kernel leaves most of every CU's wave slots free), so the sampler's ~5 us leave the
-        # critical path.  Ordering is by HIP events only -- no host synchronisation.
-        self.prefetch = bool(prefetch)
-        nbuf = 2 if self.prefetch else 1
-        self.blocks = [torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device) for _ in range(nbuf)]
-        self.block = self.blocks[0]
-        self._views_of = [[blk[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)] for blk in self.blocks]
-        self._views = self._views_of[0]
-        if self.prefetch:
-            # raw HIP events / waits through ctypes: the torch wrappers cost ~5 us of host time apiece, more than the
-            # kernel they are meant to hide
-            self._hip = hip = ctypes.CDLL("libamdhip64.so")
-            hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
-            hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-            hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
-
-            def event():
-                e = ctypes.c_void_p()
-                if hip.hipEventCreateWithFlags(ctypes.byref(e), 2) != 0:          # hipEventDisableTiming
-                    raise _lib.NdqError("hipEventCreateWithFlags failed")
-                return e
-            self._side_stream = torch.cuda.Stream(device=self.device)     # kept alive; only its handle is used
-            self._side = ctypes.c_void_p(self._side_stream.cuda_stream)
-            self._sampled = [event(), event()]        # recorded on the side stream after a draw
-            self._consumed = event()                  # recorded on the consumer's stream
-            self._ahead = None                        # index of the block that holds draw `self.draw`
-            self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-            self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or \
-                (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
-
-    def _launch(self, block, draw, stream_ptr):
-        rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, draw, self.stream_id, block.data_ptr(),
-                                block.shape[1], ctypes.c_void_p(stream_ptr))
-        if rc != 0:
-            from . import _lib
-            raise _lib.NdqError(f"ndq_sample failed with code {rc}")
+        self.block = torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device)
+        self._views = [self.block[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)]
 
     @staticmethod
     def describe(g):
@@ -662,28 +627,13 @@ class DeviceGenerator(BaseGenerator):
         return d
 
     def get_examples(self):
-        if not self.prefetch:
-            self._launch(self.block, self.draw, torch.cuda.current_stream(self.device).cuda_stream)
-            self.draw += 1
-            return self._views
-        hip = self._hip
-        cur = ctypes.c_void_p(self._raw_stream(self._dev_index))
-        if self._ahead is None:                          # first call: draw synchronously with the consumer's stream
-            b = 0
-            self._launch(self.blocks[b], self.draw, cur.value)
-        else:                                            # this draw was prefetched: the consumer waits for it
-            b = self._ahead
-            hip.hipStreamWaitEvent(cur, self._sampled[b], 0)
-        # draw the next batch into the other block, once everything already enqueued on the consumer's stream (the
-        # last reader of that block is the training step before this call) has drained
-        nxt = b ^ 1
-        hip.hipEventRecord(self._consumed, cur)
-        hip.hipStreamWaitEvent(self._side, self._consumed, 0)
-        self._launch(self.blocks[nxt], self.draw + 1, self._side.value)
-        hip.hipEventRecord(self._sampled[nxt], self._side)
-        self._ahead = nxt
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, self.draw, self.stream_id, self.block.data_ptr(),
+                                self.block.shape[1], stream)
+        if rc != 0:
+            from . import _lib
+            raise _lib.NdqError(f"ndq_sample failed with code {rc}")
         self.draw += 1
-        self.block, self._views = self.blocks[b], self._views_of[b]
         return self._views
 
     def _internal_vars(self):
