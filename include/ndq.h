@@ -135,16 +135,6 @@ typedef int (*ndq_fused_launch_fn)(const float* coords, int ldc, int n, const fl
 typedef int (*ndq_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op, void* comm,
                                 void* stream);
 
-/* The same launcher drawing the batch INSIDE the kernel (ndq_sampler_desc below; the Philox block of point i under
- * (sample_seed, sample_draw, sample_stream), exactly what ndq_sample would write): `coords` is an OUTPUT here -- the
- * kernel stores what it drew -- and the sampler launch plus the coordinate read disappear from the step. */
-struct ndq_sampler_desc;
-typedef int (*ndq_fused_launch_sampled_fn)(float* coords, int ldc, int n, const float* params, float* partials,
-                                           float* loss_partials, float* funcs, float* resid, int ldj, float seed,
-                                           int train, const struct ndq_sampler_desc* sampler,
-                                           unsigned long long sample_seed, unsigned long long sample_draw,
-                                           unsigned sample_stream, void* stream);
-
 /* Everything one training epoch of a single-network system with n_batches_train = 1 needs, prepared once by the host:
  * closure kernel -> ndq_reduce_grad_loss [-> all-reduce of grad|loss] -> ndq_epoch_tail, issued back to back on
  * `stream` by ONE native call. */
@@ -167,10 +157,6 @@ typedef struct ndq_fused_step {
   void* comm;                 /* ncclComm_t for `allreduce` */
   void* ev_start;             /* optional hipEvent_t recorded on `stream` right before the closure kernel ... */
   void* ev_stop;              /* ... and right after it (in-situ kernel timing, bench.py); NULL: nothing recorded */
-  ndq_fused_launch_sampled_fn launch_sampled;  /* with `sampler`: the closure kernel draws its batch (coords = output) */
-  const struct ndq_sampler_desc* sampler;      /* NULL: `coords` holds the batch */
-  unsigned long long sample_seed, sample_draw;
-  unsigned sample_stream;
 } ndq_fused_step;
 int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_step, int hist_index, int parity,
                        void* stream);

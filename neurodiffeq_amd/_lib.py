@@ -43,9 +43,7 @@ class FusedStep(ctypes.Structure):
                 ("weight_decay", ctypes.c_float),
                 ("loss_hist", ctypes.c_void_p), ("best_loss", ctypes.c_void_p), ("best_flat", ctypes.c_void_p),
                 ("allreduce", ctypes.c_void_p), ("comm", ctypes.c_void_p),
-                ("ev_start", ctypes.c_void_p), ("ev_stop", ctypes.c_void_p),
-                ("launch_sampled", ctypes.c_void_p), ("sampler", ctypes.c_void_p),
-                ("sample_seed", ctypes.c_ulonglong), ("sample_draw", ctypes.c_ulonglong), ("sample_stream", ctypes.c_uint)]
+                ("ev_start", ctypes.c_void_p), ("ev_stop", ctypes.c_void_p)]
 
 
 class NdqError(RuntimeError):

@@ -362,13 +362,9 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         if K == 1:
             args_t = "ndq::FusedArgs"
             fill = "a.params = params[0]; a.partials = partials ? partials[0] : nullptr;"
-            sample_fill = ("a.sample = smp ? 1 : 0; a.coords_out = const_cast<float*>(coords);\n"
-                           "  if (smp) { if (ndq::sample_total(smp) != n || smp->d != CFG::D) return -2; a.smp = *smp; "
-                           "a.key = ndq::make_sample_key(sseed, draw, stream_id); }")
         else:
             args_t = "ndq::FusedMultiArgs"
             fill = f"for (int k = 0; k < {K}; ++k) {{ a.params[k] = params[k]; a.partials[k] = partials ? partials[k] : nullptr; }}"
-            sample_fill = "if (smp) return -2;      // in-kernel sampling: single-network closure only"
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- single-launch closure kernel (forward streams + pointwise stage +
 // reverse pass) of one PDE system with {K} network(s), gfx950.
 #include "{header}"
@@ -395,16 +391,12 @@ int fused_blocks(int n) {{
   return b > 256 ? 256 : (b < 1 ? 1 : b);
 }}
 
-// params / partials: host arrays of {K} device pointers (one per network); smp != NULL: the kernel draws the batch
-// itself and WRITES it to coords
+// params / partials: host arrays of {K} device pointers (one per network)
 int launch(const float* coords, int ldc, int n, const float* const* params, float* const* partials, float* loss_partials,
-           float* funcs, float* resid, int ldj, float seed, int train, void* stream,
-           const ndq_sampler_desc* smp = nullptr, unsigned long long sseed = 0, unsigned long long draw = 0,
-           unsigned stream_id = 0) {{
+           float* funcs, float* resid, int ldj, float seed, int train, void* stream) {{
   if (!coords || !params || !loss_partials || n <= 0 || ldc < n || (train && !partials)) return -2;
   {args_t} a;
   a.coords = coords; a.loss_partials = loss_partials;
-  {sample_fill}
   {fill}
   a.funcs = funcs; a.resid = resid; a.n = n; a.ldc = ldc; a.ldj = ldj; a.seed = seed;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -439,18 +431,6 @@ extern "C" int ndq_fused_launch(const float* coords, int ldc, int n, const float
   const float* pp[1] = {{params}};
   float* qq[1] = {{partials}};
   return launch(coords, ldc, n, pp, partials ? qq : nullptr, loss_partials, funcs, resid, ldj, seed, train, stream);
-}}
-
-// one network, the batch drawn inside the kernel (ndq_fused_launch_sampled_fn of include/ndq.h): coords is written
-extern "C" int ndq_fused_launch_sampled(float* coords, int ldc, int n, const float* params, float* partials,
-                                        float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,
-                                        const ndq_sampler_desc* smp, unsigned long long sample_seed,
-                                        unsigned long long sample_draw, unsigned sample_stream, void* stream) {{
-  if ({K} != 1 || !smp) return -2;
-  const float* pp[1] = {{params}};
-  float* qq[1] = {{partials}};
-  return launch(coords, ldc, n, pp, partials ? qq : nullptr, loss_partials, funcs, resid, ldj, seed, train, stream, smp,
-                sample_seed, sample_draw, sample_stream);
 }}
 
 // any number of networks: params / partials are host arrays of device pointers
@@ -620,7 +600,6 @@ class FusedKernel:
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         self.lib.ndq_fused_launch.restype = ci
         self.lib.ndq_fused_launch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
-        self.lib.ndq_fused_launch_sampled.restype = ci
         self.lib.ndq_fused_launch_multi.restype = ci
         self.lib.ndq_fused_launch_multi.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
         self.lib.ndq_fused_blocks.restype = ci

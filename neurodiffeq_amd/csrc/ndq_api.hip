@@ -2,6 +2,7 @@
 // ndq_mlp.h, the second-stage reduction and the fused Adam step.
 #include <vector>
 #include "ndq_launch.h"
+#include "ndq_sample.h"
 
 namespace ndq {
 
@@ -370,16 +371,8 @@ int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_st
                        void* stream) {
   if (!s || !s->launch || !coords) return NDQ_EINVAL;
   if (s->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(s->ev_start), static_cast<hipStream_t>(stream));
-  int rc;
-  if (s->sampler) {          // the closure kernel draws the batch itself and stores it to `coords`
-    if (!s->launch_sampled) return NDQ_EINVAL;
-    rc = s->launch_sampled(const_cast<float*>(coords), s->ldc, s->n, s->params, s->partials, s->loss_partials, nullptr,
-                           nullptr, s->ldj, s->seed, 1, s->sampler, s->sample_seed, s->sample_draw, s->sample_stream,
-                           stream);
-  } else {
-    rc = s->launch(coords, s->ldc, s->n, s->params, s->partials, s->loss_partials, nullptr, nullptr, s->ldj, s->seed, 1,
-                   stream);
-  }
+  int rc = s->launch(coords, s->ldc, s->n, s->params, s->partials, s->loss_partials, nullptr, nullptr, s->ldj, s->seed,
+                     1, stream);
   if (rc) return rc;
   if (s->ev_stop) (void)hipEventRecord(static_cast<hipEvent_t>(s->ev_stop), static_cast<hipStream_t>(stream));
   if (!s->adam_m)

@@ -29,7 +29,6 @@
 //    partials[block][P] in HBM -> second-stage kernel.  No float atomics across waves.
 #pragma once
 #include <hip/hip_runtime.h>
-#include "ndq_sample.h"
 #include <utility>
 #include <type_traits>
 
@@ -1405,12 +1404,6 @@ struct FusedArgs {
   float* resid;            // optional [NEQ][ldj]
   int n, ldc, ldj;
   float seed;              // adjoint seed scale 1 / (N_global * n_eq)
-  // sample != 0: the kernel DRAWS the batch itself (sample_point, csrc/ndq_sample.h) instead of reading it, and
-  // writes the coordinates to coords_out [D][ldc] so that the block the generator handed out holds them afterwards
-  int sample;
-  ndq_sampler_desc smp;
-  SampleKey key;
-  float* coords_out;
 };
 
 template <class C, class PW, bool TRAIN>
@@ -1431,19 +1424,8 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     const bool valid = n < a.n;
     const int nn = valid ? n : a.n - 1;
     float x[C::D];
-    if (a.sample) {                                          // wave-uniform branch
-      float xs[3];
-      sample_point(a.smp, a.key, nn, xs);
 #pragma unroll
-      for (int d = 0; d < C::D; ++d) x[d] = xs[d];
-      if (valid && q == 0) {
-#pragma unroll
-        for (int d = 0; d < C::D; ++d) a.coords_out[(size_t)d * a.ldc + n] = x[d];
-      }
-    } else {
-#pragma unroll
-      for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
-    }
+    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
     const float* ldsw = lds + opaque_zero<C>();
     LayerState<C> st[C::L];
     f32x4 h[C::NS][C::NB];

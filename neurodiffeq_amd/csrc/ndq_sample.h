@@ -37,20 +37,21 @@ __device__ inline float linspace_at(float lo, float hi, int n, int i) {
   return (i < n / 2) ? fmaf(step, (float)i, lo) : fmaf(-step, (float)(n - 1 - i), hi);
 }
 
-// which draw: Philox key (k0, k1) = seed, counter words 1..3 = (draw lo, draw hi, stream id); word 0 = point index
-struct SampleKey { unsigned k0, k1, c1, c2, c3; };
+struct SampleArgs {
+  ndq_sampler_desc s;
+  unsigned k0, k1, c1, c2, c3;
+  float* coords;
+  int ldc, total;
+};
 
-inline SampleKey make_sample_key(unsigned long long seed, unsigned long long draw, unsigned stream_id) {
-  return SampleKey{(unsigned)seed, (unsigned)(seed >> 32), (unsigned)draw, (unsigned)(draw >> 32), stream_id};
-}
-
-// the coordinates of point i of the draw `key` (x[0..d)); shared by the stand-alone sampler kernel and by the closure
-// kernel when it draws its own batch
-__device__ __forceinline__ void sample_point(const ndq_sampler_desc& s, const SampleKey& key, int i, float* x) {
-  const U4 r = philox4x32_10(U4{(unsigned)i, key.c1, key.c2, key.c3}, key.k0, key.k1);
+__global__ void __launch_bounds__(256) sample_kernel(SampleArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.total) return;
+  const U4 r = philox4x32_10(U4{(unsigned)i, a.c1, a.c2, a.c3}, a.k0, a.k1);
   const unsigned w[4] = {r.x, r.y, r.z, r.w};
+  const ndq_sampler_desc& s = a.s;
   if (s.kind == NDQ_SAMPLE_UNIFORM) {                       // generators.py:150-152 (Generator1D 'uniform')
-    for (int c = 0; c < s.d; ++c) x[c] = s.lo[c] + (s.hi[c] - s.lo[c]) * u01(w[c]);
+    for (int c = 0; c < s.d; ++c) a.coords[(size_t)c * a.ldc + i] = s.lo[c] + (s.hi[c] - s.lo[c]) * u01(w[c]);
   } else if (s.kind == NDQ_SAMPLE_GRID) {                   // generators.py:253-266: ij-meshgrid + N(0, std^2) jitter
     // Box-Muller: (w0, w1) -> two normals, (w2, w3) -> two more
     const float r0 = sqrtf(-2.0f * __logf(u01_open(w[0]))), t0 = 6.283185307179586f * u01(w[1]);
@@ -62,60 +63,45 @@ __device__ __forceinline__ void sample_point(const ndq_sampler_desc& s, const Sa
     for (int c = 0; c < s.d; ++c) {
       float v = linspace_at(s.lo[c], s.hi[c], s.n[c], idx[c]);
       if (s.noise_std[c] != 0.0f) v = fmaf(s.noise_std[c], z[c], v);
-      x[c] = v;
+      a.coords[(size_t)c * a.ldc + i] = v;
     }
   } else {                                                  // generators.py:622-646 (GeneratorSpherical)
     const float p = u01_open(w[0]), q = u01_open(w[1]), t = u01_open(w[2]);
     const float inv = 1.0f / (p + q + t);
-    float cx = sqrtf(p * inv) + 1e-6f, cy = sqrtf(q * inv) + 1e-6f, cz = fminf(sqrtf(t * inv) + 1e-6f, 1.0f);
-    if (w[0] & 1u) cx = -cx;                                // the low 8 bits of each word are not used by u01
-    if (w[1] & 1u) cy = -cy;
-    if (w[2] & 1u) cz = -cz;
+    float x = sqrtf(p * inv) + 1e-6f, y = sqrtf(q * inv) + 1e-6f, z = fminf(sqrtf(t * inv) + 1e-6f, 1.0f);
+    if (w[0] & 1u) x = -x;                                  // the low 8 bits of each word are not used by u01
+    if (w[1] & 1u) y = -y;
+    if (w[2] & 1u) z = -z;
     const float u = u01(w[3]);
     const float lo = s.lo[0], hi = s.hi[0];
-    x[0] = s.radial ? lo + (hi - lo) * u : sqrtf((hi * hi - lo * lo) * u + lo * lo);
-    x[1] = acosf(cz);
-    x[2] = 3.14159265358979f - atan2f(cy, cx);
+    const float rad = s.radial ? lo + (hi - lo) * u : sqrtf((hi * hi - lo * lo) * u + lo * lo);
+    a.coords[i] = rad;
+    a.coords[(size_t)a.ldc + i] = acosf(z);
+    a.coords[(size_t)2 * a.ldc + i] = 3.14159265358979f - atan2f(y, x);
   }
-}
-
-struct SampleArgs {
-  ndq_sampler_desc s;
-  SampleKey key;
-  float* coords;
-  int ldc, total;
-};
-
-__global__ void __launch_bounds__(256) sample_kernel(SampleArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.total) return;
-  float x[3];
-  sample_point(a.s, a.key, i, x);
-  for (int c = 0; c < a.s.d; ++c) a.coords[(size_t)c * a.ldc + i] = x[c];
-}
-
-inline long long sample_total(const ndq_sampler_desc* s) {
-  if (!s || s->d < 1 || s->d > 3) return -1;
-  if (s->kind == NDQ_SAMPLE_GRID) {
-    long long total = 1;
-    for (int c = 0; c < s->d; ++c) {
-      if (s->n[c] < 1) return -1;
-      total *= s->n[c];
-    }
-    return total;
-  }
-  if (s->kind == NDQ_SAMPLE_UNIFORM) return s->n[0];
-  if (s->kind == NDQ_SAMPLE_SPHERICAL) return s->d == 3 ? s->n[0] : -1;
-  return -1;
 }
 
 inline int launch_sample(const ndq_sampler_desc* s, unsigned long long seed, unsigned long long draw, unsigned stream_id,
                          float* coords, int ldc, hipStream_t stream) {
-  const long long total = sample_total(s);
-  if (!coords || total < 1 || total > 0x7fffffffLL || ldc < total) return NDQ_EINVAL;
+  if (!s || !coords || s->d < 1 || s->d > 3) return NDQ_EINVAL;
+  long long total = 0;
+  if (s->kind == NDQ_SAMPLE_GRID) {
+    total = 1;
+    for (int c = 0; c < s->d; ++c) {
+      if (s->n[c] < 1) return NDQ_EINVAL;
+      total *= s->n[c];
+    }
+  } else if (s->kind == NDQ_SAMPLE_UNIFORM || s->kind == NDQ_SAMPLE_SPHERICAL) {
+    total = s->n[0];
+    if (s->kind == NDQ_SAMPLE_SPHERICAL && s->d != 3) return NDQ_EINVAL;
+  } else {
+    return NDQ_EINVAL;
+  }
+  if (total < 1 || total > 0x7fffffffLL || ldc < total) return NDQ_EINVAL;
   SampleArgs a;
   a.s = *s;
-  a.key = make_sample_key(seed, draw, stream_id);
+  a.k0 = (unsigned)seed; a.k1 = (unsigned)(seed >> 32);
+  a.c1 = (unsigned)draw; a.c2 = (unsigned)(draw >> 32); a.c3 = stream_id;
   a.coords = coords; a.ldc = ldc; a.total = (int)total;
   hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
   return (int)hipGetLastError();

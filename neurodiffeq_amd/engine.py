@@ -16,7 +16,6 @@ import os
 import torch
 
 from . import _lib, codegen
-from . import generators
 from .networks import FlatParams, describe
 from .symbolic import Graph, Sym, TraceUnsupported, trace_scope
 
@@ -256,8 +255,6 @@ class FusedSystem:
         n_all = batch[0].numel()
         hi = n_all if hi is None else hi
         n = hi - lo
-        if batch[0].device.type == "cuda":
-            generators.materialize(batch)        # a draw deferred to a sampling closure kernel that is not going to run
         if batch[0].device.type == "cuda" and lo == 0 and hi == n_all:
             hit = self._resident_cache.get(id(batch))        # same list object served again by a resident generator
             if hit is not None and hit[0] is batch:
@@ -460,9 +457,7 @@ class FusedSystem:
                               launch=(ctypes.cast(self.fusedk.lib.ndq_fused_launch, ctypes.c_void_p).value
                                       if self.fusedk is not None else None),
                               launch_multi=(ctypes.cast(self.fusedk.lib.ndq_fused_launch_multi, ctypes.c_void_p).value
-                                            if self.fusedk is not None else None),
-                              launch_sampled=(ctypes.cast(self.fusedk.lib.ndq_fused_launch_sampled, ctypes.c_void_p).value
-                                              if self.fusedk is not None else None))
+                                            if self.fusedk is not None else None))
         return self._fast
 
     def epoch_tail(self, kind, n_batches, track_best, adam_slots=None):
@@ -535,13 +530,7 @@ class FusedSystem:
         closure kernel -> fused second-stage sums [-> all-reduce] -> device-side epoch tail (loss history, best
         snapshot, Adam).  ``adam_slot`` = (exp_avg, exp_avg_sq, group dict, step count AFTER this update)."""
         fs = self.fast_state()
-        gen = generators.deferred_draw(batch) if dist is None else None
-        if gen is not None:                      # the closure kernel draws this batch itself
-            draw, gen.pending = gen.pending, None
-            b, n = self.upload(batch)
-            gen.pending = draw
-        else:
-            b, n = self.upload(batch)
+        b, n = self.upload(batch)
         fp = self.flat[0]
         fp.sync()
         m, v, group, step = adam_slot
@@ -565,15 +554,6 @@ class FusedSystem:
         coords = self._coord_ptr(b, 0)
         hist_index, parity = fs["pending"], fs["parity"]
         st.ev_start, st.ev_stop = self.closure_events.pop() if self.closure_events else (None, None)
-        if gen is not None and b["coords_rows"] is not None:
-            st.launch_sampled = fs["launch_sampled"]
-            st.sampler = ctypes.addressof(gen.desc)
-            st.sample_seed, st.sample_draw, st.sample_stream = gen.seed, gen.pending, gen.stream_id
-            gen.pending = None
-        else:
-            st.sampler = None
-            if gen is not None:
-                generators.materialize(batch)
         direct = dist.direct(self.device) if dist is not None else None
         if dist is None or direct is not None:
             # one native call; with data parallelism the RCCL all-reduce of [grad | loss] is enqueued by it, on the

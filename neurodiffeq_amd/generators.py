@@ -563,24 +563,6 @@ class ResidentBatchGenerator(BaseGenerator):
         return views
 
 
-# views handed out by DeviceGenerators whose draw has been DEFERRED to the consuming closure kernel: id(views) -> generator
-_DEFERRED = {}
-
-
-def deferred_draw(batch):
-    """The DeviceGenerator whose deferred (not yet materialised) draw ``batch`` is, or None."""
-    g = _DEFERRED.get(id(batch))
-    return g if (g is not None and g._views is batch and g.pending is not None) else None
-
-
-def materialize(batch):
-    """Run the sampler kernel now for a deferred draw (any consumer other than the sampling closure kernel)."""
-    g = deferred_draw(batch)
-    if g is not None:
-        g._launch(g.pending)
-        g.pending = None
-
-
 class DeviceGenerator(BaseGenerator):
     """Draws the distribution of a reference generator ON the MI355X (csrc/ndq_sample.h through ``ndq_sample``).
 
@@ -615,23 +597,6 @@ class DeviceGenerator(BaseGenerator):
         ld = (self.size + 63) // 64 * 64
         self.block = torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device)
         self._views = [self.block[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)]
-        # a solver about to run its single-launch native step may ask for the NEXT draw to be deferred: the closure
-        # kernel then draws the batch itself (and stores it into the block), the sampler launch disappears.  Anything
-        # else that touches a deferred batch first calls ``materialize`` (engine.upload, the composite path).
-        self._defer_next = False
-        self.pending = None          # draw number of a deferred, not yet materialised draw
-        _DEFERRED[id(self._views)] = self
-
-    def defer_next(self):
-        self._defer_next = True
-
-    def _launch(self, draw):
-        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, draw, self.stream_id, self.block.data_ptr(),
-                                self.block.shape[1], stream)
-        if rc != 0:
-            from . import _lib
-            raise _lib.NdqError(f"ndq_sample failed with code {rc}")
 
     @staticmethod
     def describe(g):
@@ -662,13 +627,12 @@ class DeviceGenerator(BaseGenerator):
         return d
 
     def get_examples(self):
-        if self.pending is not None:         # a deferred draw nobody consumed: it must still exist before the next one
-            self._launch(self.pending)
-            self.pending = None
-        if self._defer_next:
-            self._defer_next, self.pending = False, self.draw
-        else:
-            self._launch(self.draw)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, self.draw, self.stream_id, self.block.data_ptr(),
+                                self.block.shape[1], stream)
+        if rc != 0:
+            from . import _lib
+            raise _lib.NdqError(f"ndq_sample failed with code {rc}")
         self.draw += 1
         return self._views
 

@@ -26,8 +26,7 @@ import torch.nn as nn
 
 from . import _lib
 from .conditions import BaseCondition
-from . import generators as _generators
-from .generators import DeviceGenerator, Generator1D, Generator2D, GeneratorSpherical, SamplerGenerator
+from .generators import Generator1D, Generator2D, GeneratorSpherical, SamplerGenerator
 from .losses import _losses
 from .networks import FCNN
 from .neurodiffeq import safe_diff as diff
@@ -354,7 +353,6 @@ class BaseSolver(ABC):
         if self.n_batches[key] <= 0:
             return
         self._phase = key
-        self._maybe_defer_sampling(key)
         first_batch = self._generate_batch(key)
         system = self._fused_system(len(first_batch))
         if system is None:
@@ -392,19 +390,6 @@ class BaseSolver(ABC):
             self._do_optimizer_step()
         for name in self.metrics_fn:
             self._update_history(metric_values[name] / nb, name, key)
-
-    def _maybe_defer_sampling(self, key):
-        """A DeviceGenerator feeding a system whose whole training epoch is ONE native call (single network, single
-        batch, zero-sync path) need not launch its sampler: the closure kernel draws the batch itself.  Whatever else
-        ends up consuming the batch materialises it first (engine.upload / the composite path)."""
-        if key != "train" or self.n_batches["train"] != 1 or self.dist is not None:
-            return
-        system = self._fused_sys
-        if system is None or len(system.flat) != 1 or not system.fast_ready() or not self._native_ok():
-            return
-        gen = getattr(self.generator["train"], "generator", None)
-        if isinstance(gen, DeviceGenerator):
-            gen.defer_next()
 
     def _native_ok(self):
         """May the epoch's bookkeeping stay on the device?  (default hooks, FusedAdam, no metrics)"""
@@ -488,7 +473,6 @@ class BaseSolver(ABC):
         dev = self.device
         for batch_id in range(self.n_batches[key]):
             batch = first_batch if batch_id == 0 else self._generate_batch(key)
-            _generators.materialize(batch)
             if batch[0].device != dev:
                 batch = [c.detach().to(dev).requires_grad_(True) for c in batch]
                 self._batch[key] = batch
