@@ -1,19 +1,20 @@
-"""In-tree build of the gfx950 artefacts (no cmake, no torch headers): plain ``hipcc -shared``.
+"""In-tree build of the gfx950 artefacts (no cmake, no torch headers): hipcc through ``_hipcc.compile_shared`` (device
+assembly fix-up pass included).
 
 ``libndq.so`` = csrc/ndq_api.hip (+ ndq_mlp.h, ndq_launch.h, ndq_sample.h), the C-ABI declared in include/ndq.h.  The built library travels to
 the GPU box with the repository snapshot; ``ensure_built`` recompiles only when a source is newer than the library.
 """
 import os
-import subprocess
+
+from . import _hipcc
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libndq.so")
 SOURCES = [os.path.join(CSRC, "ndq_api.hip")]
 HEADERS = [os.path.join(CSRC, h) for h in ("ndq_mlp.h", "ndq_launch.h", "ndq_sample.h")] + \
-    [os.path.join(HERE, "..", "include", "ndq.h")]
-HIPCC = os.environ.get("NDQ_HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+    [os.path.join(HERE, "..", "include", "ndq.h"), os.path.join(HERE, "_hipcc.py")]
+FLAGS = []
 _EXTRA = os.environ.get("NDQ_LIB_FLAGS", "").split()      # tuning experiments: built to a library of their own
 if _EXTRA:
     import hashlib
@@ -31,14 +32,7 @@ def is_stale():
 def build_lib(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    tmp = LIB + f".tmp{os.getpid()}"
-    cmd = [HIPCC] + FLAGS + SOURCES + ["-o", tmp]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError("hipcc failed building libndq.so:\n" + proc.stderr[-6000:])
-    os.replace(tmp, LIB)
+    _hipcc.compile_shared(SOURCES, LIB, FLAGS, verbose=verbose)
     return LIB
 
 

@@ -1,0 +1,107 @@
+"""hipcc driver for every gfx950 artefact of this package (libndq.so and the generated kernels), with one extra step
+between code generation and assembly: a fix-up pass over the device assembly.
+
+Why: on gfx950 (MI355X, ROCm 7.2 / clang 22) a packed-fp32 VALU instruction (``v_pk_mul_f32`` / ``v_pk_fma_f32`` / ...)
+that is IMMEDIATELY followed by a bf16 MFMA can deliver a wrong low-half result in lanes 48..63 (the last quarter of the
+wave): the lanes get the value of the preceding packed instruction's operand.  Found as a non-deterministic dW1 entry of
+one closure kernel, bisected at the assembly level, and reproduced in isolation by ``scripts/ubench_pk_war.hip``
+(``profiles/r01u_pk_mfma_hazard.txt``: ~11 % of the executions wrong; one wait state -- ``s_nop 0`` or any other
+instruction -- between the two makes it exact; scalar ``v_mul_f32`` instead of the packed form is exact).  The compiler's
+hazard recogniser does not know the pair, so ``fix_pk_mfma`` inserts the wait state itself: ~20 sites per kernel, one
+cycle each.
+
+Pipeline (what ``hipcc -shared`` does internally, split so that the assembly can be edited):
+  1. hipcc --cuda-device-only -S          -> device assembly
+  2. fix_pk_mfma
+  3. clang (assembler) -> lld -> clang-offload-bundler   -> fat binary
+  4. hipcc --cuda-host-only -fcuda-include-gpubinary     -> shared library
+"""
+import os
+import re
+import shutil
+import subprocess
+
+HIPCC = os.environ.get("NDQ_HIPCC", "/opt/rocm/bin/hipcc")
+LLVM_BIN = os.environ.get("NDQ_LLVM_BIN", os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))),
+                                                       "lib", "llvm", "bin"))
+ARCH = "gfx950"
+BASE_FLAGS = ["-O3", "-std=c++17", "-fPIC"]
+# part of every cache key: bump when the fix-up rules change so that cached kernels are rebuilt
+FIXUP_VERSION = "pk-mfma-nop-1"
+
+_PK = re.compile(r"^\s*v_pk_\w+")
+_MFMA = re.compile(r"^\s*v_s?mfmac?_\w+")
+
+
+def _is_instruction(line):
+    s = line.strip()
+    return bool(s) and not s.startswith((";", "//", ".")) and not s.endswith(":")
+
+
+def fix_pk_mfma(asm_text):
+    """Insert ``s_nop 0`` between a packed VALU instruction and an MFMA that directly follows it (labels, comments and
+    directives in between do not separate them at run time).  Returns (patched text, number of sites)."""
+    out, sites, prev_pk = [], 0, False
+    for line in asm_text.split("\n"):
+        if _is_instruction(line):
+            if prev_pk and _MFMA.match(line):
+                out.append("\ts_nop 0")
+                sites += 1
+            prev_pk = bool(_PK.match(line))
+        out.append(line)
+    return "\n".join(out), sites
+
+
+def fixup_enabled():
+    return os.environ.get("NDQ_NO_PK_MFMA_FIX", "0") != "1"
+
+
+def _run(cmd, what):
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"{what} failed:\n{' '.join(cmd)}\n{proc.stderr[-6000:]}")
+
+
+def compile_shared(sources, out, extra_flags=(), verbose=False):
+    """Build ``out`` (a shared library holding host code + the gfx950 code object) from HIP sources.  Returns the number
+    of pk->mfma sites the fix-up pass separated.  Atomic: ``out`` is replaced only when everything succeeded."""
+    sources = [sources] if isinstance(sources, str) else list(sources)
+    flags = BASE_FLAGS + list(extra_flags)
+    work = f"{out}.build{os.getpid()}"
+    os.makedirs(work, exist_ok=True)
+    try:
+        if not fixup_enabled():                       # experiments: the compiler's own output, one step
+            tmp = os.path.join(work, "out.so")
+            _run([HIPCC, f"--offload-arch={ARCH}"] + flags + ["-shared"] + sources + ["-o", tmp], "hipcc")
+            os.replace(tmp, out)
+            return 0
+        sites, objs = 0, []
+        for i, src in enumerate(sources):
+            asm = os.path.join(work, f"dev{i}.s")
+            _run([HIPCC, f"--offload-arch={ARCH}", "--cuda-device-only", "-S"] + flags + [src, "-o", asm],
+                 "hipcc (device code generation)")
+            with open(asm) as fh:
+                text, n = fix_pk_mfma(fh.read())
+            sites += n
+            with open(asm, "w") as fh:
+                fh.write(text)
+            obj, co, fb = (os.path.join(work, f"dev{i}.{e}") for e in ("o", "out", "hipfb"))
+            _run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}",
+                  "-c", asm, "-o", obj], "assembling the device code")
+            _run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared",
+                  obj, "-o", co], "linking the device code")
+            _run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+                  f"-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--{ARCH}", "-input=/dev/null",
+                  f"-input={co}", f"-output={fb}"], "bundling the device code")
+            host = os.path.join(work, f"host{i}.o")
+            _run([HIPCC, f"--offload-arch={ARCH}", "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb]
+                 + flags + ["-c", src, "-o", host], "hipcc (host code)")
+            objs.append(host)
+        tmp = os.path.join(work, "out.so")
+        _run([HIPCC, "-shared", "-fPIC"] + objs + ["-o", tmp], "linking the shared library")
+        os.replace(tmp, out)
+        if verbose:
+            print(f"built {out}: {sites} pk->mfma site(s) separated", flush=True)
+        return sites
+    finally:
+        shutil.rmtree(work, ignore_errors=True)

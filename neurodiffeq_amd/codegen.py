@@ -12,14 +12,12 @@ The launcher it exports has the ``ndq_pointwise_fn`` signature of include/ndq.h.
 import ctypes
 import hashlib
 import os
-import subprocess
 
 from .symbolic import Graph
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 JIT_DIR = os.path.join(HERE, "_jit")
-HIPCC = os.environ.get("NDQ_HIPCC", "/opt/rocm/bin/hipcc")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+from . import _hipcc        # noqa: E402  (hipcc + the device-assembly fix-up pass; see _hipcc.py)
 
 
 def _extra_flags():
@@ -160,7 +158,7 @@ class PointwiseProgram:
             for k, st in self.streams.items():
                 widen(k, st)
         self.source = self._emit()
-        self.key = hashlib.sha1(self.source.encode()).hexdigest()[:16]
+        self.key = hashlib.sha1((self.source + _build_tag()).encode()).hexdigest()[:16]
 
     # ---- Laplacian-stream rewrite
     def _merge_laplacian(self, residuals, funcs, n_nets, allow_lap):
@@ -579,12 +577,10 @@ def build(program: PointwiseProgram, force=False):
         return so
     with open(src, "w") as fh:
         fh.write(program.source)
-    tmp = so + f".tmp{os.getpid()}"
-    cmd = [HIPCC] + HIPCC_FLAGS + [src, "-o", tmp]
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed for generated pointwise kernel {src}:\n{proc.stderr[-4000:]}")
-    os.replace(tmp, so)
+    try:
+        _hipcc.compile_shared(src, so)
+    except RuntimeError as e:
+        raise RuntimeError(f"hipcc failed for generated pointwise kernel {src}:\n{str(e)[-4000:]}") from e
     return so
 
 
@@ -617,7 +613,12 @@ def _cache_key(source):
     """Cache key of a generated module: its source (with the package location factored out, so a relocated checkout
     keeps its cache), the kernel headers it instantiates and the extra compile flags."""
     text = source.replace(HERE, "<neurodiffeq_amd>")
-    return hashlib.sha1((text + _header_digest() + " ".join(_extra_flags())).encode()).hexdigest()[:16]
+    return hashlib.sha1((text + _header_digest() + " ".join(_extra_flags()) + _build_tag()).encode()).hexdigest()[:16]
+
+
+def _build_tag():
+    """What the build pipeline itself contributes to a cache key (the assembly fix-up pass and its version)."""
+    return _hipcc.FIXUP_VERSION if _hipcc.fixup_enabled() else "no-fixup"
 
 
 def _header_digest():
@@ -673,11 +674,10 @@ def build_mlp_ext(desc, force=False):
         return so
     with open(src, "w") as fh:
         fh.write(source)
-    tmp = so + f".tmp{os.getpid()}"
-    proc = subprocess.run([HIPCC] + HIPCC_FLAGS + _extra_flags() + [src, "-o", tmp], capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed for MLP kernel extension {src}:\n{proc.stderr[-4000:]}")
-    os.replace(tmp, so)
+    try:
+        _hipcc.compile_shared(src, so, _extra_flags())
+    except RuntimeError as e:
+        raise RuntimeError(f"hipcc failed for MLP kernel extension {src}:\n{str(e)[-4000:]}") from e
     return so
 
 
@@ -720,11 +720,10 @@ def build_fused(program: PointwiseProgram, desc, force=False):
         return so
     with open(src, "w") as fh:
         fh.write(source)
-    tmp = so + f".tmp{os.getpid()}"
-    proc = subprocess.run([HIPCC] + HIPCC_FLAGS + _extra_flags() + [src, "-o", tmp], capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed for generated fused kernel {src}:\n{proc.stderr[-4000:]}")
-    os.replace(tmp, so)
+    try:
+        _hipcc.compile_shared(src, so, _extra_flags())
+    except RuntimeError as e:
+        raise RuntimeError(f"hipcc failed for generated fused kernel {src}:\n{str(e)[-4000:]}") from e
     return so
 
 

@@ -759,3 +759,30 @@ def test_solution_and_residuals_on_forward_kernels(name):
     assert getattr(solver, "_resid_sys", None) is not None
     assert rel_l2(np.stack([r.reshape(-1) for r in rs], axis=1), out["residuals"].numpy()) < TOL
     assert us[0].shape == tuple(coords[0].shape)
+
+
+def test_pk_mfma_hazard_is_fixed_up_by_the_build():
+    """scripts/ubench_pk_war.hip replays, with hard-coded registers, the instruction sequence that made one closure
+    kernel's dW1 non-deterministic on gfx950 (packed-fp32 VALU op directly followed by a bf16 MFMA: lanes 48..63 of the
+    packed op's low half come out wrong).  Built through the package's own pipeline (_hipcc.compile_shared: the
+    assembly fix-up pass separates the pair) it must be exact; built with the pass switched off it documents whether
+    this machine shows the hazard (recorded, not asserted)."""
+    import ctypes, os, tempfile
+    from neurodiffeq_amd import _hipcc
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "ubench_pk_war.hip")
+    counts = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for label, off in (("fixed", "0"), ("raw", "1")):
+            os.environ["NDQ_NO_PK_MFMA_FIX"] = off
+            try:
+                so = os.path.join(tmp, f"pk_war_{label}.so")
+                sites = _hipcc.compile_shared(src, so, ["-DNDQ_PK_WAR_LIB=1", "-Wno-unused-value"])
+            finally:
+                os.environ.pop("NDQ_NO_PK_MFMA_FIX", None)
+            lib = ctypes.CDLL(so)
+            lib.ndq_pk_war_count.restype = ctypes.c_long
+            counts[label] = int(lib.ndq_pk_war_count(200))
+            counts[label + "_sites"] = sites
+    diag("pk_mfma_hazard", counts)
+    assert counts["fixed_sites"] > 0
+    assert counts["fixed"] == 0, counts

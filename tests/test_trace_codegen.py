@@ -205,3 +205,43 @@ def test_unsupported_constructs_raise_trace_unsupported():
             bool(t)
         assert g.cval(diff(3.0 * t * t, t, order=3).i) == 0.0
         assert g.cval(diff(t ** 2, t, order=2).i) == 2.0
+
+
+def test_assembly_fixup_separates_packed_valu_from_mfma():
+    """_hipcc.fix_pk_mfma: one wait state between a packed-fp32 VALU instruction and a directly following MFMA (labels
+    and comments in between do not count), nothing anywhere else, idempotent."""
+    from neurodiffeq_amd import _hipcc
+    asm = "\n".join([
+        "\tv_pk_mul_f32 v[2:3], v[10:11], v[58:59] op_sel:[0,1]",
+        "\tv_mfma_f32_16x16x32_bf16 a[52:55], v[116:119], v[82:85], a[52:55]",
+        "\tv_pk_fma_f32 v[4:5], v[6:7], v[8:9], v[4:5]",
+        "; a comment",
+        ".LBB0_3:",
+        "\tv_mfma_f32_16x16x4_f32 a[0:3], v1, v2, a[0:3]",
+        "\tv_pk_add_f32 v[4:5], v[6:7], v[8:9]",
+        "\ts_waitcnt lgkmcnt(0)",
+        "\tv_mfma_f32_16x16x4_f32 a[0:3], v1, v2, a[0:3]",
+        "\tv_mul_f32_e32 v1, v2, v3",
+        "\tv_mfma_f32_16x16x4_f32 a[0:3], v1, v2, a[0:3]",
+    ])
+    out, sites = _hipcc.fix_pk_mfma(asm)
+    assert sites == 2
+    lines = out.split("\n")
+    assert lines[1].strip() == "s_nop 0" and lines[2].startswith("\tv_mfma")
+    assert lines[6].strip() == "s_nop 0" and lines[5] == ".LBB0_3:" and lines[7].startswith("\tv_mfma_f32_16x16x4")
+    assert out.count("s_nop 0") == 2
+    again, more = _hipcc.fix_pk_mfma(out)
+    assert more == 0 and again == out
+
+
+def test_build_pipeline_produces_a_loadable_library(tmp_path):
+    """The split hipcc pipeline (device assembly -> fix-up -> assembler -> bundle -> host compile) yields a shared library
+    that loads and exports its host symbols (no GPU needed: hipcc cross-compiles)."""
+    import ctypes
+    from neurodiffeq_amd import _hipcc
+    src = tmp_path / "k.hip"
+    src.write_text('#include <hip/hip_runtime.h>\n__global__ void k(float* x) { x[threadIdx.x] += 1.f; }\n'
+                   'extern "C" int answer() { return 42; }\n')
+    so = str(tmp_path / "k.so")
+    assert _hipcc.compile_shared(str(src), so) == 0
+    assert ctypes.CDLL(so).answer() == 42
