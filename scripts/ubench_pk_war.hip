@@ -71,6 +71,47 @@ KERNEL(k_indep_mfma, PK "v_mfma_f32_16x16x32_bf16 a[40:43], v[116:119], v[82:85]
 KERNEL(k_very_late, PK MFMA "s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7\n" RD)
 KERNEL(k_opsel_hi_only, "v_pk_mul_f32 v[2:3], v[10:11], v[58:59] op_sel_hi:[1,0]\n v_mul_f32 v2, v10, v59\n v_mul_f32 v3, v11, v59\n" "v_pk_mul_f32 v[60:61], v[10:11], v[58:59] op_sel_hi:[1,0]\n" MFMA)
 
+
+// Cross-wave variant: 512 threads = 8 waves = 2 per SIMD.  Waves 0..3 run ONLY the packed multiplies (with one wait state
+// after each -- the intra-wave fix), waves 4..7 ONLY bf16 MFMAs: if the hazard is about what the SIMD issues next, no
+// matter from which wave, the packed results still go wrong.
+__global__ __launch_bounds__(512) void k_cross_wave(const float* in, int* bad, int iters, float* dbg) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wave = threadIdx.x >> 6;
+  int wrong = 0;
+  if (wave < 4) {
+    for (int it = 0; it < iters; ++it) {
+      const float x0 = in[(t + it) & 1023] + 1.0f, x1 = x0 + 0.25f, y0 = 0.5f + 0.001f * (it & 7), y1 = y0 + 0.125f;
+      float o0, o1;
+      asm volatile("v_mov_b32 v10, %[x0]\n v_mov_b32 v11, %[x1]\n v_mov_b32 v102, %[y0]\n v_mov_b32 v103, %[y1]\n"
+                   "v_add_f32_e64 v58, v102, v102\n v_add_f32_e64 v59, v103, v103\n s_nop 1\n"
+                   "v_pk_mul_f32 v[60:61], v[102:103], 0 op_sel_hi:[1,0]\n"
+                   "v_pk_mul_f32 v[2:3], v[10:11], v[58:59] op_sel:[0,1]\n"
+                   "s_nop 0\n"
+                   "v_pk_mul_f32 v[60:61], v[102:103], 0 op_sel_hi:[1,0]\n"
+                   "v_pk_mul_f32 v[4:5], v[10:11], v[58:59] op_sel:[0,1]\n"
+                   "s_nop 7\n"
+                   "v_mov_b32 %[o0], v2\n v_mov_b32 %[o1], v4\n"
+                   : [o0] "=&v"(o0), [o1] "=&v"(o1)
+                   : [x0] "v"(x0), [x1] "v"(x1), [y0] "v"(y0), [y1] "v"(y1)
+                   : "v2", "v3", "v4", "v5", "v10", "v11", "v58", "v59", "v60", "v61", "v102", "v103");
+      const float want = x0 * (2.0f * y1);
+      if (o0 != want || o1 != want) ++wrong;
+    }
+  } else {
+    for (int it = 0; it < iters; ++it)
+      asm volatile("v_mov_b32 v116, 0\n v_mov_b32 v117, 0\n v_mov_b32 v118, 0\n v_mov_b32 v119, 0\n"
+                   "v_mov_b32 v82, 0\n v_mov_b32 v83, 0\n v_mov_b32 v84, 0\n v_mov_b32 v85, 0\n s_nop 1\n"
+                   "v_mfma_f32_16x16x32_bf16 a[40:43], v[116:119], v[82:85], 0\n"
+                   "v_mfma_f32_16x16x32_bf16 a[52:55], v[116:119], v[82:85], 0\n"
+                   "v_mfma_f32_16x16x32_bf16 a[40:43], v[116:119], v[82:85], a[40:43]\n"
+                   "v_mfma_f32_16x16x32_bf16 a[52:55], v[116:119], v[82:85], a[52:55]\n"
+                   ::: "v82", "v83", "v84", "v85", "v116", "v117", "v118", "v119", "a40", "a41", "a42", "a43", "a52",
+                       "a53", "a54", "a55");
+  }
+  if (wrong) atomicAdd(&bad[threadIdx.x & 63], wrong);
+}
+
 // library mode (tests/test_gpu_parity.py builds this file through neurodiffeq_amd._hipcc.compile_shared, i.e. WITH the
 // assembly fix-up pass, and expects zero): wrong results of the sequence as the compiler emitted it
 extern "C" long ndq_pk_war_count(int iters) {
@@ -89,7 +130,8 @@ extern "C" long ndq_pk_war_count(int iters) {
 }
 
 #ifndef NDQ_PK_WAR_LIB
-int main() {
+int main(int argc, char** argv) {
+  const bool only_cross = argc > 1 && argv[1][0] == 'c';
   const int blocks = 1024, threads = 256, iters = 2000;
   std::vector<float> h(1024);
   for (int i = 0; i < 1024; ++i) h[i] = (float)((i * 37) % 101) / 101.0f;
@@ -108,6 +150,7 @@ int main() {
       {"no overwrite at all", k_no_overwrite}, {"independent mfma (srcC = 0)", k_indep_mfma},
       {"128 wait states between mfma and overwrite", k_very_late}};
   for (auto& e : ks) {
+    if (only_cross) break;
     for (int rep = 0; rep < 3; ++rep) {
       hipMemset(bad, 0, 256); hipMemset(dbg, 0, 64);
       hipLaunchKernelGGL(e.k, dim3(blocks), dim3(threads), 0, 0, in, bad, iters, dbg);
@@ -118,6 +161,15 @@ int main() {
              (long)blocks * threads * iters, hi);
       if (rep == 0 && tot) { float d[7]; hipMemcpy(d, dbg, 28, hipMemcpyDeviceToHost); printf("      sample (block 7 lane 50, iteration %g): got lo %.9g want %.9g  [x0*2*y0 = %.9g, previous iteration want = %.9g]  got hi %.9g want %.9g\n", d[6], d[0], d[1], d[2], d[3], d[4], d[5]); }
     }
+  }
+  for (int rep = 0; rep < 3; ++rep) {
+    hipMemset(bad, 0, 256);
+    hipLaunchKernelGGL(k_cross_wave, dim3(blocks), dim3(512), 0, 0, in, bad, iters, dbg);
+    hipDeviceSynchronize();
+    int hb[64]; hipMemcpy(hb, bad, 256, hipMemcpyDeviceToHost);
+    long tot = 0, hi = 0; for (int l = 0; l < 64; ++l) { tot += hb[l]; if (l >= 48) hi += hb[l]; }
+    printf("%-44s rep %d: wrong results %ld of %ld (lanes 48..63: %ld)\n", "cross-wave: pk waves + mfma waves, 2 per SIMD", rep, tot,
+           (long)blocks * 256 * iters, hi);
   }
   return 0;
 }
