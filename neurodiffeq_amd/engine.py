@@ -154,6 +154,7 @@ class FusedSystem:
         self.loss_norm = self.program.loss_norm      # loss = sum over points of the per-point term / (N * loss_norm)
         self.kernel = codegen.load(self.program)
         self.fusedk = None
+        self._fused_verified = os.environ.get("NDQ_SELF_CHECK", "1") == "0"
         if single_kernel and codegen.can_fuse(self.program, self.descs):
             fk = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0]))
             if fk.lib.ndq_fused_lds_bytes() <= 160 * 1024:       # K weight images + staging must fit one workgroup's LDS
@@ -414,6 +415,60 @@ class FusedSystem:
                                         _c_vp(self.loss_buf.data_ptr() + 4 * slot), 0, seed, stream)
         _lib.check(rc, "ndq_reduce_partials(loss)")
 
+    def verify_fused(self, b, n, n_global=None):
+        """First use of this system's single-launch closure kernel: run it twice and the three-kernel pipeline once on
+        the batch at hand and compare the gradients.  The closure kernel is generated and compiled per system, its
+        register allocation differs from build to build, and gfx950 has shown hazards the compiler does not know
+         -- a kernel that is not bit-reproducible, or that disagrees with the independently compiled
+        forward / pointwise / adjoint kernels, is not used: the system continues on the three-kernel pipeline (still
+        all-HIP) with a warning.  One host synchronisation, once per system; NDQ_SELF_CHECK=0 skips it."""
+        if self._fused_verified or self.fusedk is None:
+            return True
+        self._fused_verified = True
+        n_global = n if n_global is None else n_global
+        stream = self._stream()
+        keep = [fp.grad_loss.clone() for fp in self.flat], self.loss_buf[:1].clone()
+
+        def grads():
+            return torch.cat([fp.grad for fp in self.flat]).clone(), self.loss_buf[:1].clone()
+        runs = []
+        for _ in range(2):
+            self.fused_closure(b, n, stream, True, n_global, 0, False)
+            runs.append(grads())
+        pipe = []
+        for _ in range(2):
+            self.forward(b, n, stream)
+            seed = self.pointwise(b, n, stream, True, n_global, False, False)
+            self.backward(b, n, stream, False)
+            self.reduce_loss(b, stream, seed, 0)
+            pipe.append(grads())
+        for fp, g in zip(self.flat, keep[0]):
+            fp.grad_loss.copy_(g)
+        self.loss_buf[:1].copy_(keep[1])
+        same = bool(torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]))
+        pipe_same = bool(torch.equal(pipe[0][0], pipe[1][0]) and torch.equal(pipe[0][1], pipe[1][1]))
+        ref = pipe[0][0].double()
+        err = float((runs[0][0].double() - ref).norm() / ref.norm().clamp_min(1e-30))
+        lerr = float((runs[0][1] - pipe[0][1]).abs() / pipe[0][1].abs().clamp_min(1e-30))
+        self.fused_check = dict(reproducible=same, pipeline_reproducible=pipe_same, grad_rel_l2=err, loss_rel=lerr)
+        if not pipe_same:
+            raise _lib.NdqError(f"the three-kernel pipeline of this system is not bit-reproducible ({self.fused_check}); "
+                                "refusing to train on it")
+        if same and err < self.SELF_CHECK_TOL and lerr < self.SELF_CHECK_TOL:
+            return True
+        import warnings
+        warnings.warn(f"single-launch closure kernel rejected by its self-check ({self.fused_check}); this system "
+                      "continues on the three-kernel pipeline", RuntimeWarning)
+        self.fusedk = None
+        self._fast = None
+        return False
+
+    SELF_CHECK_TOL = 1e-4
+
+    def verify_on(self, batch, n_global=None, lo=0, hi=None):
+        b, n = self.upload(batch, lo, hi)
+        return self.verify_fused(b, n, n_global)
+
     def fused_closure(self, b, n, stream, train, n_global, slot, accumulate, want_funcs=False, want_resid=False):
         """The whole closure in ONE launch (one network, or 2..4 networks of one shape), then the fixed-order
         second-stage sums."""
@@ -595,6 +650,8 @@ class FusedSystem:
         b, n = self.upload(batch, lo, hi)
         n_global = n if n_global is None else n_global
         stream = self._stream()
+        if self.fusedk is not None and train and not self._fused_verified and not accumulate:
+            self.verify_fused(b, n, n_global)
         if self.fusedk is not None:
             self.fused_closure(b, n, stream, train, n_global, slot, accumulate, want_funcs, want_resid)
             return b, n

@@ -786,3 +786,46 @@ def test_pk_mfma_hazard_is_fixed_up_by_the_build():
     diag("pk_mfma_hazard", counts)
     assert counts["fixed_sites"] > 0
     assert counts["fixed"] == 0, counts
+
+
+def test_closure_kernel_self_check_accepts_good_and_rejects_bad_kernels():
+    """engine.verify_fused: the first training use of a system's single-launch closure kernel runs it twice plus the
+    three-kernel pipeline; a healthy kernel is accepted (bit-reproducible, gradients equal to ~1e-6), one whose
+    gradients change from launch to launch is rejected with a warning and the system carries on, correctly, on the
+    pipeline."""
+    from tests import zoo
+    from neurodiffeq_amd.engine import FusedSystem
+    torch.manual_seed(11)
+    system = zoo.build("helmholtz_xy")
+    nets, conds, pde = system.product()
+    flat = R.get_flat(nets)
+    coords = system.sample(3001, seed=5)
+    onets, enforcers, opde = system.oracle(flat)
+    want = R.closure(onets, enforcers, opde, coords)
+    want_grad = R.get_flat_grad(onets).numpy()
+    for net in nets:
+        net.to("cuda")
+    good = FusedSystem(nets, conds, pde, system.n_coords, "cuda", single_kernel=True)
+    good.step([c.float() for c in coords], train=True, slot=0)
+    torch.cuda.synchronize()
+    assert good.fusedk is not None and good.fused_check["reproducible"] and good.fused_check["pipeline_reproducible"]
+    assert good.fused_check["grad_rel_l2"] < 1e-5 and good.fused_check["loss_rel"] < 1e-5, good.fused_check
+
+    bad = FusedSystem(nets, conds, pde, system.n_coords, "cuda", single_kernel=True)
+    healthy = bad.fused_closure
+    calls = [0]
+
+    def flaky(b, n, stream, train, *a, **k):          # a kernel whose dW1[13][0] differs from launch to launch
+        healthy(b, n, stream, train, *a, **k)
+        calls[0] += 1
+        if train:
+            bad.flat[0].grad[39] += 1e-3 * calls[0]
+    bad.fused_closure = flaky
+    with pytest.warns(RuntimeWarning, match="self-check"):
+        b, n = bad.step([c.float() for c in coords], train=True, slot=0)
+    torch.cuda.synchronize()
+    assert bad.fusedk is None and not bad.fused_check["reproducible"]
+    errs = dict(loss=abs(bad.loss_buf[0].item() - want["loss"].item()) / abs(want["loss"].item()),
+                grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in bad.flat]), want_grad))
+    diag("self_check", dict(good=good.fused_check, bad=bad.fused_check, after=errs))
+    assert max(errs.values()) < TOL, errs
