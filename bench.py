@@ -251,6 +251,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert solver.fused_active
+    # the headline is the single-launch closure kernel: if its first-use self-check (engine.verify_fused) rejected it,
+    # the numbers below would silently be the three-kernel pipeline's -- refuse instead
+    assert solver._fused_sys is not None and solver._fused_sys.fusedk is not None, \
+        f"single-launch closure kernel not in use: {getattr(solver._fused_sys, 'fused_check', None)}"
     ms = dt / args.steps * 1e3
     value = N_POINTS * world / (dt / args.steps)
 

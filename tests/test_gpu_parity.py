@@ -417,6 +417,7 @@ def test_zoo_closure_matches_autograd_oracle(name, mode):
     assert mode == "3k" or len(nets) == 1 or name in ("coupled_sin", "stokes_like")   # the multi-network closure kernel
     b, n = fs.step([c.float() for c in coords], train=True, slot=0, want_funcs=True, want_resid=True)
     torch.cuda.synchronize()
+    assert mode != "1k" or (fs.fusedk is not None and fs.fused_check["reproducible"]), getattr(fs, "fused_check", None)
     errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), want["funcs"].numpy()),
                 residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy(), want["residuals"].numpy()),
                 loss=abs(fs.loss_buf[0].item() - want["loss"].item()) / abs(want["loss"].item()),
