@@ -104,6 +104,12 @@ class BatchSharding:
         self._flat = None
         self._direct = None         # DirectRccl, created on first use on a GPU under the nccl backend
 
+    def agree(self, flag, device):
+        """True iff ``flag`` is true on every rank (one tiny MIN all-reduce over the regular group)."""
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item() == 1.0)
+
     def direct(self, device):
         """(address of ncclAllReduce, ncclComm_t) for the native step, or None (CPU / gloo / NDQ_RCCL_DIRECT=0 /
         communicator unavailable -> ``torch.distributed``)."""

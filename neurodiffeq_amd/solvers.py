@@ -414,7 +414,9 @@ class BaseSolver(ABC):
             # three-kernel pipeline (engine.verify_fused) before any parameter is updated with its gradients
             n_all = first_batch[0].shape[0]
             lo, hi = self.dist.bounds(n_all) if self.dist else (0, n_all)
-            system.verify_on(first_batch, self.dist.global_n(n_all) if self.dist else n_all, lo, hi)
+            ok = system.verify_on(first_batch, self.dist.global_n(n_all) if self.dist else n_all, lo, hi)
+            if self.dist and not self.dist.agree(ok, self.device) and system.fusedk is not None:
+                system.fusedk, system._fast = None, None      # ranks must take the same path: another rank rejected its kernel
         fs = system.fast_state()
         if max(fs["pending"], fs["pending_valid"]) >= system.HIST:
             self._flush_device_history()
