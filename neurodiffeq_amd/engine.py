@@ -467,7 +467,10 @@ class FusedSystem:
 
     def verify_on(self, batch, n_global=None, lo=0, hi=None):
         b, n = self.upload(batch, lo, hi)
-        return self.verify_fused(b, n, n_global)
+        ok = self.verify_fused(b, n, n_global)
+        if batch[0].device.type != "cuda":       # the epoch uploads this batch again: not a sign of a static generator
+            self._static_seen.pop(self.static_key(batch) + (lo, batch[0].numel() if hi is None else hi), None)
+        return ok
 
     def fused_closure(self, b, n, stream, train, n_global, slot, accumulate, want_funcs=False, want_resid=False):
         """The whole closure in ONE launch (one network, or 2..4 networks of one shape), then the fixed-order
