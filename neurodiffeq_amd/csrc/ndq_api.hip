@@ -206,7 +206,7 @@ struct ReduceTailArgs {
   Reduce2Args r;
   TailArgs t;
 };
-__global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) {
+__device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
   // Latency-bound (19 workgroups at C2): every global load -- loss partials, this thread's rows of the gradient
   // partials, the parameter / moment values it will update -- is issued before the first reduction step, and there is
   // ONE barrier.  Summation orders are fixed (per-thread chains, then LDS slots added in index order).
@@ -262,6 +262,17 @@ __global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) {
     a.t.loss_hist[a.t.hist_index] = loss;
     a.t.best_loss[a.t.parity ^ 1] = better ? loss : best;
   }
+}
+__global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) { reduce_tail_body(a); }
+
+// the same for the 2..4 networks behind one multi-network closure launch, in ONE launch: blockIdx.y = network
+struct ReduceTailMultiArgs {
+  ReduceTailArgs net[4];
+};
+__global__ __launch_bounds__(1024) void reduce_tail_multi_kernel(ReduceTailMultiArgs a) {
+  const ReduceTailArgs& mine = a.net[blockIdx.y];
+  if ((int)blockIdx.x * 64 >= mine.r.len) return;          // networks of one shape: never taken, kept for safety
+  reduce_tail_body(mine);
 }
 
 // ---------------------------------------------------------------------------------------------- Adam
@@ -403,9 +414,9 @@ int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_st
   return (int)hipGetLastError();
 }
 
-static int launch_reduce_tail(const ndq_fused_step* s, const float* loss_partials, int blocks, float seed, float* loss_hist,
-                              float* best_loss, int adam_step, int hist_index, int parity, int write_scalars, void* stream) {
-  ReduceTailArgs a;
+static void fill_reduce_tail(ReduceTailArgs& a, const ndq_fused_step* s, const float* loss_partials, int blocks, float seed,
+                             float* loss_hist, float* best_loss, int adam_step, int hist_index, int parity,
+                             int write_scalars) {
   a.r = Reduce2Args{s->partials, blocks, s->n_params, s->grad, 0, loss_partials, blocks, s->loss_slot, seed};
   a.t.p = s->params; a.t.g = s->grad; a.t.m = s->adam_m; a.t.v = s->adam_v; a.t.len = s->n_params;
   a.t.lr = s->lr; a.t.b1 = s->beta1; a.t.b2 = s->beta2; a.t.eps = s->eps; a.t.wd = s->weight_decay;
@@ -413,8 +424,6 @@ static int launch_reduce_tail(const ndq_fused_step* s, const float* loss_partial
   a.t.bc2s = (float)sqrt(1.0 - pow((double)s->beta2, (double)adam_step));
   a.t.loss_slots = s->loss_slot; a.t.nb = 1; a.t.loss_hist = loss_hist; a.t.hist_index = hist_index;
   a.t.best_loss = best_loss; a.t.parity = parity; a.t.best_flat = s->best_flat; a.t.write_scalars = write_scalars;
-  hipLaunchKernelGGL(reduce_tail_kernel, dim3((s->n_params + 63) / 64), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
-  return (int)hipGetLastError();
 }
 
 int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_launch_multi_fn launch,
@@ -435,12 +444,17 @@ int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_
   }
   int rc = launch(coords, s0.ldc, s0.n, params, partials, s0.loss_partials, nullptr, nullptr, s0.ldj, s0.seed, 1, stream);
   if (rc) return rc;
+  ReduceTailMultiArgs a;
+  int max_params = 0;
   for (int k = 0; k < n_nets; ++k) {
-    rc = launch_reduce_tail(&steps[k], s0.loss_partials, s0.blocks, s0.seed, s0.loss_hist, s0.best_loss, adam_step,
-                            hist_index, parity, k == 0 ? 1 : 0, stream);
-    if (rc) return rc;
+    fill_reduce_tail(a.net[k], &steps[k], s0.loss_partials, s0.blocks, s0.seed, s0.loss_hist, s0.best_loss, adam_step,
+                     hist_index, parity, k == 0 ? 1 : 0);
+    if (steps[k].n_params > max_params) max_params = steps[k].n_params;
   }
-  return 0;
+  for (int k = n_nets; k < 4; ++k) a.net[k] = a.net[0];
+  hipLaunchKernelGGL(reduce_tail_multi_kernel, dim3((max_params + 63) / 64, n_nets), dim3(1024), 0,
+                     static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
 }
 
 int ndq_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,

@@ -830,3 +830,29 @@ def test_closure_kernel_self_check_accepts_good_and_rejects_bad_kernels():
                 grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in bad.flat]), want_grad))
     diag("self_check", dict(good=good.fused_check, bad=bad.fused_check, after=errs))
     assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("name", ["poisson3d", "helmholtz_xy", "heat_wide", "coupled_sin", "swish_laplace"])
+def test_closure_kernel_launches_are_bit_reproducible(name):
+    """50 launches of a system's single-launch closure kernel on identical inputs: 50 bit-identical blocks of partial
+    sums and loss partials (poisson3d is the kernel in which the packed-VALU -> MFMA hazard of DESIGN 4.6 surfaced as one
+    non-deterministic dW1 entry)."""
+    from tests import zoo
+    from neurodiffeq_amd.engine import FusedSystem
+    torch.manual_seed(11)
+    system = zoo.build(name)
+    nets, conds, pde = system.product()
+    coords = [c.float() for c in system.sample(3001, seed=5)]
+    for net in nets:
+        net.to("cuda")
+    fs = FusedSystem(nets, conds, pde, system.n_coords, "cuda", single_kernel=True)
+    assert fs.fusedk is not None
+    first = None
+    for rep in range(50):
+        b, n = fs.step(coords, train=True, slot=0)
+        snap = torch.cat([p.reshape(-1) for p in b["fused_partials_all"]] + [b["fused_loss_partials"].reshape(-1)]).clone()
+        if first is None:
+            first = snap
+        else:
+            assert torch.equal(snap, first), f"launch {rep} differs in {(snap != first).sum().item()} entries"
+    assert fs.fusedk is not None and fs.fused_check["reproducible"]
