@@ -287,16 +287,19 @@ def main():
             kb["fused_closure"]["back_to_back_us"] = kb["fused_closure"]["us"]
             t_situ, t_raw, t_ev = closure_in_situ(solver, system, args.steps)
             flop = (FWD_FLOP_PER_PT + BWD_FLOP_PER_PT) * N_POINTS
-            kb["fused_closure"].update(us=t_situ * 1e6, tflops=flop / t_situ / 1e12)
+            # two HIP-event measurements of the same kernel: inside real steps (event pair minus what an empty pair
+            # costs: the calibration moves by ~1 us between boxes) and 200 launches back to back between two events.
+            # The roofline is priced with the LARGER of the two.
+            t_kernel = max(t_situ, kb["fused_closure"]["back_to_back_us"] * 1e-6)
+            kb["fused_closure"].update(us=t_kernel * 1e6, tflops=flop / t_kernel / 1e12, in_situ_us=t_situ * 1e6)
             out["roofline"] = {"kernel": "fused_closure_kernel<Cfg<2,1,5,2,2,tanh>, PW, train> (fwd + pointwise + bwd)",
                                "bound": "mfma", "achieved": kb["fused_closure"]["tflops"],
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": kb["fused_closure"]["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                                "algorithmic_flop_per_point": FWD_FLOP_PER_PT + BWD_FLOP_PER_PT,
-                               # HIP events around the kernel inside real training steps (closure -> tail -> closure
-                               # ...) minus what an empty event pair measures on the same stream; launched back to
-                               # back on its own the kernel averages less (launch ramps overlap)
+                               # max(in situ, back to back), see above
                                "avg_launch_us": kb["fused_closure"]["us"],
+                               "in_situ_us": kb["fused_closure"]["in_situ_us"],
                                "back_to_back_us": kb["fused_closure"]["back_to_back_us"],
                                "event_pair_us": {"raw": t_raw * 1e6, "empty_pair": t_ev * 1e6},
                                # the kernel carries u_xx + u_yy as ONE "Laplacian" stream when the tracer proves the
