@@ -856,3 +856,61 @@ def test_closure_kernel_launches_are_bit_reproducible(name):
         else:
             assert torch.equal(snap, first), f"launch {rep} differs in {(snap != first).sum().item()} entries"
     assert fs.fusedk is not None and fs.fused_check["reproducible"]
+
+
+@pytest.mark.parametrize("kind", ["sgd_momentum", "rmsprop", "adamw", "adam_clipped"])
+def test_torch_optimizers_and_step_overrides_on_the_fused_path(kind):
+    """a10 of SURVEY 8(a): ``optimizer=`` may be any torch.optim optimiser over the networks' parameters and users
+    override ``_do_optimizer_step`` (gradient clipping, solvers.py:331-341).  The fused closure leaves ordinary ``.grad``
+    tensors behind (views of the flat gradient buffer), so all of that keeps working: five epochs against the autograd
+    restatement driven by the same optimiser."""
+    from itertools import chain
+    from tests import configs
+    from neurodiffeq_amd.solvers import Solver2D
+
+    def make_opt(params):
+        params = list(params)
+        if kind == "sgd_momentum":
+            return torch.optim.SGD(params, lr=1e-2, momentum=0.9, nesterov=True)
+        if kind == "rmsprop":
+            return torch.optim.RMSprop(params, lr=1e-3, alpha=0.9)
+        if kind == "adamw":
+            return torch.optim.AdamW(params, lr=2e-3, weight_decay=0.05)
+        return torch.optim.Adam(params, lr=1e-3)
+
+    class Clipped(Solver2D):
+        def _do_optimizer_step(self, closure=None):
+            torch.nn.utils.clip_grad_norm_(list(chain.from_iterable(n.parameters() for n in self.nets)), 0.05)
+            self.optimizer.step()
+
+    torch.manual_seed(0)
+    cfg = configs.make("c2", 16)
+    for net in cfg["nets"]:
+        net.to("cuda")
+    cls = Clipped if kind == "adam_clipped" else Solver2D
+    solver = cls(cfg["pde"], cfg["conds"], xy_min=cfg["dom"][0], xy_max=cfg["dom"][1], nets=cfg["nets"],
+                 train_generator=cfg["gen"], valid_generator=cfg["gen"], n_batches_valid=0,
+                 optimizer=make_opt(chain.from_iterable(n.parameters() for n in cfg["nets"])))
+    solver.fused = "require"
+    torch.manual_seed(0)
+    ocfg = R.build_config("c2", 16)
+    loop = R.TrainLoop(ocfg["nets"], ocfg["enforcers"], ocfg["pde"], ocfg["sampler"])
+    loop.opt = make_opt(chain.from_iterable(n.parameters() for n in ocfg["nets"]))
+    if kind == "adam_clipped":
+        plain_step = loop.opt.step
+
+        def clipped_step():
+            torch.nn.utils.clip_grad_norm_(list(chain.from_iterable(n.parameters() for n in ocfg["nets"])), 0.05)
+            plain_step()
+        loop.opt.step = clipped_step
+    torch.manual_seed(7)
+    for _ in range(5):
+        loop.epoch()
+    torch.manual_seed(7)
+    for _ in range(5):
+        solver.run_train_epoch()
+    assert solver.fused_active
+    errs = dict(params=rel_l2(R.get_flat(cfg["nets"]).cpu().numpy(), R.get_flat(ocfg["nets"]).numpy()),
+                loss=max(abs(a - b) / abs(b) for a, b in zip(solver.metrics_history["train_loss"], loop.history)))
+    diag(f"optimizer_{kind}", errs)
+    assert errs["params"] < 1e-5 and errs["loss"] < 2e-5, errs
