@@ -341,9 +341,10 @@ def main():
         dt2 = (time.perf_counter() - t0) / k2
         out["with_host_sampling"] = {"value": N_POINTS / dt2, "ms_per_step": dt2 * 1e3}
         # ... and with a fresh batch drawn ON the device every step (generators.DeviceGenerator: same distribution,
-        # Philox stream instead of the host RNG -> not the reference's numbers, hence not the headline)
+        # Philox stream instead of the host RNG -> not the reference's numbers, hence not the headline); prefetch=True:
+        # the next batch is drawn by extra workgroups of the step's own sums + tail kernel, no sampler launch
         from neurodiffeq_amd.generators import DeviceGenerator
-        solver.generator["train"] = SamplerGenerator(DeviceGenerator(cfg["gen"], seed=2))
+        solver.generator["train"] = SamplerGenerator(DeviceGenerator(cfg["gen"], seed=2, prefetch=True))
         for _ in range(10):
             solver.run_train_epoch()
         torch.cuda.synchronize()

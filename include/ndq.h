@@ -157,6 +157,14 @@ typedef struct ndq_fused_step {
   void* comm;                 /* ncclComm_t for `allreduce` */
   void* ev_start;             /* optional hipEvent_t recorded on `stream` right before the closure kernel ... */
   void* ev_stop;              /* ... and right after it (in-situ kernel timing, bench.py); NULL: nothing recorded */
+  /* optional prefetch of the NEXT batch of a device generator: extra workgroups of the sums + tail kernel draw
+   * (next_sampler, next_seed, next_draw, next_stream) into next_coords [d][next_ldc] -- the block this step's closure
+   * kernel has just finished reading -- so the sampler launch leaves the step.  NULL: nothing drawn. */
+  const struct ndq_sampler_desc* next_sampler;
+  unsigned long long next_seed, next_draw;
+  unsigned next_stream;
+  float* next_coords;
+  int next_ldc;
 } ndq_fused_step;
 int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_step, int hist_index, int parity,
                        void* stream);

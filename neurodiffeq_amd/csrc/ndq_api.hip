@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256) void epoch_tail_kernel(TailArgs a) {
 struct ReduceTailArgs {
   Reduce2Args r;
   TailArgs t;
+  int tail_blocks;            // workgroups [tail_blocks, gridDim.x) draw the next batch (smp), if any
+  ndq::SampleArgs smp;
 };
 __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
   // Latency-bound (19 workgroups at C2): every global load -- loss partials, this thread's rows of the gradient
@@ -263,7 +265,13 @@ __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
     a.t.best_loss[a.t.parity ^ 1] = better ? loss : best;
   }
 }
-__global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) { reduce_tail_body(a); }
+__global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) {
+  if ((int)blockIdx.x >= a.tail_blocks) {                  // prefetch of the next batch (ndq_fused_step.next_sampler)
+    ndq::sample_point_store(a.smp, ((int)blockIdx.x - a.tail_blocks) * 1024 + (int)threadIdx.x);
+    return;
+  }
+  reduce_tail_body(a);
+}
 
 // the same for the 2..4 networks behind one multi-network closure launch, in ONE launch: blockIdx.y = network
 struct ReduceTailMultiArgs {
@@ -410,7 +418,15 @@ int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_st
   a.t.bc2s = (float)sqrt(1.0 - pow((double)s->beta2, (double)adam_step));
   a.t.loss_slots = s->loss_slot; a.t.nb = 1; a.t.loss_hist = s->loss_hist; a.t.hist_index = hist_index;
   a.t.best_loss = s->best_loss; a.t.parity = parity; a.t.best_flat = s->best_flat; a.t.write_scalars = 1;
-  hipLaunchKernelGGL(reduce_tail_kernel, dim3((s->n_params + 63) / 64), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
+  a.tail_blocks = (s->n_params + 63) / 64;
+  int blocks = a.tail_blocks;
+  if (s->next_sampler) {
+    rc = ndq::fill_sample_args(a.smp, s->next_sampler, s->next_seed, s->next_draw, s->next_stream, s->next_coords,
+                               s->next_ldc);
+    if (rc) return rc;
+    blocks += (a.smp.total + 1023) / 1024;
+  }
+  hipLaunchKernelGGL(reduce_tail_kernel, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }
 
@@ -424,6 +440,7 @@ static void fill_reduce_tail(ReduceTailArgs& a, const ndq_fused_step* s, const f
   a.t.bc2s = (float)sqrt(1.0 - pow((double)s->beta2, (double)adam_step));
   a.t.loss_slots = s->loss_slot; a.t.nb = 1; a.t.loss_hist = loss_hist; a.t.hist_index = hist_index;
   a.t.best_loss = best_loss; a.t.parity = parity; a.t.best_flat = s->best_flat; a.t.write_scalars = write_scalars;
+  a.tail_blocks = 0x7fffffff;
 }
 
 int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_launch_multi_fn launch,

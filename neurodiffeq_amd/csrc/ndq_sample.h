@@ -44,8 +44,9 @@ struct SampleArgs {
   int ldc, total;
 };
 
-__global__ void __launch_bounds__(256) sample_kernel(SampleArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+// point i of the batch described by a (one thread per point; also called from the epoch tail kernel's extra
+// workgroups, which draw the NEXT batch while the optimiser step is applied: csrc/ndq_api.hip)
+__device__ __forceinline__ void sample_point_store(const SampleArgs& a, int i) {
   if (i >= a.total) return;
   const U4 r = philox4x32_10(U4{(unsigned)i, a.c1, a.c2, a.c3}, a.k0, a.k1);
   const unsigned w[4] = {r.x, r.y, r.z, r.w};
@@ -81,8 +82,11 @@ __global__ void __launch_bounds__(256) sample_kernel(SampleArgs a) {
   }
 }
 
-inline int launch_sample(const ndq_sampler_desc* s, unsigned long long seed, unsigned long long draw, unsigned stream_id,
-                         float* coords, int ldc, hipStream_t stream) {
+__global__ void __launch_bounds__(256) sample_kernel(SampleArgs a) { sample_point_store(a, blockIdx.x * 256 + threadIdx.x); }
+
+// validated launch arguments of one draw; returns 0 or NDQ_EINVAL
+inline int fill_sample_args(SampleArgs& a, const ndq_sampler_desc* s, unsigned long long seed, unsigned long long draw,
+                            unsigned stream_id, float* coords, int ldc) {
   if (!s || !coords || s->d < 1 || s->d > 3) return NDQ_EINVAL;
   long long total = 0;
   if (s->kind == NDQ_SAMPLE_GRID) {
@@ -98,12 +102,19 @@ inline int launch_sample(const ndq_sampler_desc* s, unsigned long long seed, uns
     return NDQ_EINVAL;
   }
   if (total < 1 || total > 0x7fffffffLL || ldc < total) return NDQ_EINVAL;
-  SampleArgs a;
   a.s = *s;
   a.k0 = (unsigned)seed; a.k1 = (unsigned)(seed >> 32);
   a.c1 = (unsigned)draw; a.c2 = (unsigned)(draw >> 32); a.c3 = stream_id;
   a.coords = coords; a.ldc = ldc; a.total = (int)total;
-  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+  return 0;
+}
+
+inline int launch_sample(const ndq_sampler_desc* s, unsigned long long seed, unsigned long long draw, unsigned stream_id,
+                         float* coords, int ldc, hipStream_t stream) {
+  SampleArgs a;
+  const int rc = fill_sample_args(a, s, seed, draw, stream_id, coords, ldc);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }
 

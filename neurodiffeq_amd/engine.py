@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import _lib, codegen
+from . import _lib, codegen, generators
 from .networks import FlatParams, describe
 from .symbolic import Graph, Sym, TraceUnsupported, trace_scope
 
@@ -612,6 +612,15 @@ class FusedSystem:
         coords = self._coord_ptr(b, 0)
         hist_index, parity = fs["pending"], fs["parity"]
         st.ev_start, st.ev_stop = self.closure_events.pop() if self.closure_events else (None, None)
+        # a prefetching DeviceGenerator: the tail kernel's extra workgroups draw the next batch into the block this
+        # step's closure kernel has just read (single GPU only: the data-parallel tail is a different kernel)
+        src = generators.device_source(batch) if dist is None else None
+        if src is not None and src.prefetch and b["coords_rows"] is not None:
+            st.next_sampler = ctypes.addressof(src.desc)
+            st.next_seed, st.next_draw, st.next_stream = src.seed, src.draw, src.stream_id
+            st.next_coords, st.next_ldc = src.block.data_ptr(), src.block.shape[1]
+        else:
+            src, st.next_sampler = None, None
         direct = dist.direct(self.device) if dist is not None else None
         if dist is None or direct is not None:
             # one native call; with data parallelism the RCCL all-reduce of [grad | loss] is enqueued by it, on the
@@ -620,6 +629,8 @@ class FusedSystem:
             st.allreduce, st.comm = direct if direct is not None else (None, None)
             rc = self.L.ndq_fused_step_run(ctypes.byref(st), coords, step, hist_index, parity, stream)
             _lib.check(rc, "ndq_fused_step_run")
+            if src is not None:
+                src.prefetched = src.draw
         else:
             st.adam_m = st.adam_v = None
             st.allreduce = st.comm = None

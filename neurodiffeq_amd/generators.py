@@ -563,6 +563,16 @@ class ResidentBatchGenerator(BaseGenerator):
         return views
 
 
+# (N, 1) view lists handed out by DeviceGenerators -> the generator (engine.fast_train_epoch asks for a prefetch)
+_DEVICE_SOURCES = {}
+
+
+def device_source(batch):
+    """The DeviceGenerator that handed out ``batch`` (its own list of views), or None."""
+    g = _DEVICE_SOURCES.get(id(batch))
+    return g if (g is not None and g._views is batch) else None
+
+
 class DeviceGenerator(BaseGenerator):
     """Draws the distribution of a reference generator ON the MI355X (csrc/ndq_sample.h through ``ndq_sample``).
 
@@ -581,7 +591,7 @@ class DeviceGenerator(BaseGenerator):
     streams cost more than the 4 us kernel they hide -- 41 us per step instead of 33 -- and it was dropped.)
     """
 
-    def __init__(self, generator, device=None, seed=None, stream_id=None):
+    def __init__(self, generator, device=None, seed=None, stream_id=None, prefetch=False):
         super().__init__()
         from . import _lib
         if not torch.cuda.is_available():
@@ -597,6 +607,14 @@ class DeviceGenerator(BaseGenerator):
         ld = (self.size + 63) // 64 * 64
         self.block = torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device)
         self._views = [self.block[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)]
+        # prefetch=True: a solver on the single-launch native path lets the extra workgroups of its sums + tail kernel
+        # draw the NEXT batch (ndq_fused_step.next_sampler) -- the sampler launch leaves the step.  The points are the
+        # same (draw k is a function of (seed, k, stream_id) only); the one visible difference: once an epoch has run,
+        # the tensors handed out for it already hold the next batch.
+        self.prefetch = bool(prefetch)
+        self.prefetched = None       # draw number already sitting in the block, drawn ahead by a tail kernel
+        self.launches = 0            # sampler kernels this generator launched itself (diagnostics / tests)
+        _DEVICE_SOURCES[id(self._views)] = self
 
     @staticmethod
     def describe(g):
@@ -627,12 +645,16 @@ class DeviceGenerator(BaseGenerator):
         return d
 
     def get_examples(self):
-        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, self.draw, self.stream_id, self.block.data_ptr(),
-                                self.block.shape[1], stream)
-        if rc != 0:
-            from . import _lib
-            raise _lib.NdqError(f"ndq_sample failed with code {rc}")
+        if self.prefetched == self.draw:          # a tail kernel has drawn this batch already
+            self.prefetched = None
+        else:
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, self.draw, self.stream_id, self.block.data_ptr(),
+                                    self.block.shape[1], stream)
+            if rc != 0:
+                from . import _lib
+                raise _lib.NdqError(f"ndq_sample failed with code {rc}")
+            self.launches += 1
         self.draw += 1
         return self._views
 

@@ -914,3 +914,34 @@ def test_torch_optimizers_and_step_overrides_on_the_fused_path(kind):
                 loss=max(abs(a - b) / abs(b) for a, b in zip(solver.metrics_history["train_loss"], loop.history)))
     diag(f"optimizer_{kind}", errs)
     assert errs["params"] < 1e-5 and errs["loss"] < 2e-5, errs
+
+
+def test_device_generator_prefetch_draws_the_same_batches_without_sampler_launches():
+    """DeviceGenerator(prefetch=True): the next batch is drawn by extra workgroups of the epoch's sums + tail kernel.
+    Same seed -> the same batches -> bit-identical training as with its own sampler launches; after the first epoch the
+    generator launches nothing any more; whoever else asks for a batch still gets the right one."""
+    from tests import configs
+    from neurodiffeq_amd.generators import DeviceGenerator, SamplerGenerator
+
+    def run(prefetch):
+        torch.manual_seed(0)
+        solver, cfg = configs.make_solver("c2", 32)
+        solver.fused = "require"
+        gen = DeviceGenerator(cfg["gen"], seed=11, prefetch=prefetch)
+        solver.generator["train"] = SamplerGenerator(gen)
+        for _ in range(8):
+            solver.run_train_epoch()
+        nxt = [c.clone() for c in gen.get_examples()]           # draw 8, asked for from outside the solver
+        return solver, gen, list(solver.metrics_history["train_loss"]), R.get_flat(cfg["nets"]).cpu().numpy(), nxt
+
+    s0, g0, h0, p0, n0 = run(False)
+    s1, g1, h1, p1, n1 = run(True)
+    assert s1._fused_sys._fast is not None
+    assert g0.launches == 9 and g1.launches == 1, (g0.launches, g1.launches)
+    assert h0 == h1 and np.array_equal(p0, p1)
+    assert all(torch.equal(a, b) for a, b in zip(n0, n1))
+    # the prefetched block is the generator's own: a second consumer in between simply re-draws what it needs
+    ref = DeviceGenerator(configs.make("c2", 32)["gen"], seed=11)
+    for _ in range(9):
+        want = [c.clone() for c in ref.get_examples()]
+    assert all(torch.equal(a, b) for a, b in zip(n1, want))
