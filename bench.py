@@ -107,7 +107,7 @@ def fused_breakdown(system, batch):
     seed = 1.0 / n
 
     def closure_only():
-        system.fusedk.lib.ndq_fused_launch(system._coord_ptr(b, 0), b["ld"], n, _ptr(fp.flat), _ptr(b["fused_partials"]),
+        b["fusedk"].lib.ndq_fused_launch(system._coord_ptr(b, 0), b["ld"], n, _ptr(fp.flat), _ptr(b["fused_partials"]),
                                            _ptr(b["fused_loss_partials"]), None, None, b["ld"], seed, 1, stream)
 
     def reduce_only():
@@ -292,7 +292,9 @@ def main():
             # The roofline is priced with the LARGER of the two.
             t_kernel = max(t_situ, kb["fused_closure"]["back_to_back_us"] * 1e-6)
             kb["fused_closure"].update(us=t_kernel * 1e6, tflops=flop / t_kernel / 1e12, in_situ_us=t_situ * 1e6)
-            out["roofline"] = {"kernel": "fused_closure_kernel<Cfg<2,1,5,2,2,tanh>, PW, train> (fwd + pointwise + bwd)",
+            threads = system.fused_variant(N_POINTS).threads
+            out["roofline"] = {"kernel": "fused_closure_kernel<Cfg<2,1,5,2,2,tanh>, PW, train> (fwd + pointwise + bwd), "
+                                         f"{threads} threads per workgroup",
                                "bound": "mfma", "achieved": kb["fused_closure"]["tflops"],
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": kb["fused_closure"]["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,

@@ -27,7 +27,7 @@ LLVM_BIN = os.environ.get("NDQ_LLVM_BIN", os.path.join(os.path.dirname(os.path.d
 ARCH = "gfx950"
 BASE_FLAGS = ["-O3", "-std=c++17", "-fPIC"]
 # part of every cache key: bump when the fix-up rules change so that cached kernels are rebuilt
-FIXUP_VERSION = "pk-mfma-nop-1"
+FIXUP_VERSION = "pk-opsel-scalar+mfma-nop-2"
 
 _PK = re.compile(r"^\s*v_pk_\w+")
 _MFMA = re.compile(r"^\s*v_s?mfmac?_\w+")
@@ -61,6 +61,65 @@ def fix_pk_mfma(asm_text, rule="mfma"):
     return "\n".join(out), sites
 
 
+_PK_F32 = re.compile(r"^(\s*)v_pk_(mul|add|fma)_f32\s+(.*)$")
+_MOD = re.compile(r"\b(op_sel|op_sel_hi|neg_lo|neg_hi):\[([01,]+)\]")
+
+
+def _half(operand, hi):
+    """Register / constant that the low (hi = 0) or high (hi = 1) half of a packed operand names."""
+    m = re.fullmatch(r"([vs])\[(\d+):(\d+)\]", operand)
+    if m:
+        return f"{m.group(1)}{int(m.group(2)) + hi}"
+    return operand                                   # inline constant / literal: the same value in both halves
+
+
+def scalarize_pk(asm_text, which="opsel"):
+    """Rewrite packed-fp32 VALU instructions as two scalar VOP3 instructions (experiments / hazard work-arounds).
+    ``which``: "opsel" -- only instructions whose LOW half selects a high source half (op_sel with a 1 in it);
+    "opsel_hi" -- additionally those whose high half selects the low half of a REGISTER pair; "all" -- every one.
+    Instructions whose halves would clobber each other's sources are left alone.  Returns (text, rewritten, skipped)."""
+    out, done, skipped = [], 0, 0
+    for line in asm_text.split("\n"):
+        m = _PK_F32.match(line)
+        if not m:
+            out.append(line)
+            continue
+        indent, op, rest = m.groups()
+        rest = rest.split(";")[0].strip()
+        mods = {k: [int(x) for x in v.split(",")] for k, v in _MOD.findall(rest)}
+        ops = [o.strip() for o in _MOD.sub("", rest).strip().rstrip(",").split(",")]
+        ops = [o for o in ops if o]
+        nsrc = 3 if op == "fma" else 2
+        if len(ops) != nsrc + 1 or not re.fullmatch(r"v\[\d+:\d+\]", ops[0]):
+            out.append(line)
+            continue
+        sel = mods.get("op_sel", [0] * nsrc) + [0] * nsrc
+        sel_hi = mods.get("op_sel_hi", [1] * nsrc) + [1] * nsrc
+        neg_lo = mods.get("neg_lo", [0] * nsrc) + [0] * nsrc
+        neg_hi = mods.get("neg_hi", [0] * nsrc) + [0] * nsrc
+        is_pair = [bool(re.fullmatch(r"[vs]\[\d+:\d+\]", o)) for o in ops[1:]]
+        has_opsel = any(sel[i] for i in range(nsrc))
+        has_hi = any(is_pair[i] and not sel_hi[i] for i in range(nsrc))
+        if not (which == "all" or (which == "opsel" and has_opsel) or (which == "opsel_hi" and (has_opsel or has_hi))):
+            out.append(line)
+            continue
+        d_lo, d_hi = _half(ops[0], 0), _half(ops[0], 1)
+        src_lo = [("-" if neg_lo[i] else "") + _half(ops[1 + i], sel[i] if is_pair[i] else 0) for i in range(nsrc)]
+        src_hi = [("-" if neg_hi[i] else "") + _half(ops[1 + i], sel_hi[i] if is_pair[i] else 0) for i in range(nsrc)]
+        mnem = {"mul": "v_mul_f32_e64", "add": "v_add_f32_e64", "fma": "v_fma_f32"}[op]
+        lo = f"{indent}{mnem} {d_lo}, " + ", ".join(src_lo)
+        hi = f"{indent}{mnem} {d_hi}, " + ", ".join(src_hi)
+        lo_clobbers_hi = any(x.lstrip("-") == d_lo for x in src_hi)
+        hi_clobbers_lo = any(x.lstrip("-") == d_hi for x in src_lo)
+        if lo_clobbers_hi and hi_clobbers_lo:
+            out.append(line)
+            skipped += 1
+            continue
+        out += [hi, lo] if lo_clobbers_hi else [lo, hi]
+        done += 1
+    return "\n".join(out), done, skipped
+
+
 def fixup_enabled():
     return os.environ.get("NDQ_NO_PK_MFMA_FIX", "0") != "1"
 
@@ -91,7 +150,13 @@ def compile_shared(sources, out, extra_flags=(), verbose=False):
                  "hipcc (device code generation)")
             rule = next((f.split("=", 1)[1] for f in flags if f.startswith("-DNDQ_FIXUP_RULE=")), "mfma")
             with open(asm) as fh:
-                text, n = fix_pk_mfma(fh.read(), rule)
+                text = fh.read()
+            split = next((f.split("=", 1)[1] for f in flags if f.startswith("-DNDQ_FIXUP_SPLIT=")), "opsel")
+            if split != "none":
+                text, n_split, n_skip = scalarize_pk(text, split)
+                if verbose:
+                    print(f"scalarized {n_split} packed op(s) ({split}), left {n_skip} alone", flush=True)
+            text, n = fix_pk_mfma(text, rule)
             sites += n
             with open(asm, "w") as fh:
                 fh.write(text)

@@ -419,6 +419,7 @@ int launch(const float* coords, int ldc, int n, const float* const* params, floa
 extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
 extern "C" int ndq_fused_num_params() {{ return CFG::P; }}
 extern "C" int ndq_fused_num_nets() {{ return {K}; }}
+extern "C" int ndq_fused_threads() {{ return CFG::BWD_THREADS; }}
 extern "C" unsigned long ndq_fused_lds_bytes() {{ return (unsigned long){lds('true')}; }}
 
 // one network: the ndq_fused_launch_fn of include/ndq.h
@@ -602,6 +603,8 @@ class FusedKernel:
         self.lib.ndq_fused_blocks.argtypes = [ci]
         self.lib.ndq_fused_num_params.restype = ci
         self.lib.ndq_fused_num_nets.restype = ci
+        self.lib.ndq_fused_threads.restype = ci
+        self.threads = self.lib.ndq_fused_threads()
         self.lib.ndq_fused_lds_bytes.restype = ctypes.c_ulong
         self.n_nets = self.lib.ndq_fused_num_nets()
 
@@ -708,12 +711,14 @@ def ensure_mlp_kernels(desc):
     return bool(L.ndq_mlp_supported(ctypes.byref(desc)))
 
 
-def build_fused(program: PointwiseProgram, desc, force=False):
+def build_fused(program: PointwiseProgram, desc, force=False, threads=None):
     """Compile the fused closure kernel of a single-network system for gfx950 (in-tree cache keyed by the generated
-    source AND the kernel header it instantiates)."""
+    source AND the kernel header it instantiates).  ``threads=512``: the 8-wave build (two waves per SIMD where the
+    per-wave state fits 256 registers; csrc/ndq_mlp.h NDQ_BWD_THREADS) the engine uses for large batches."""
     os.makedirs(JIT_DIR, exist_ok=True)
     source = program.fused_source(desc)
-    key = _cache_key(source)
+    flags = _extra_flags() + ([f"-DNDQ_BWD_THREADS={int(threads)}"] if threads else [])
+    key = _cache_key(source + (f"|threads={int(threads)}" if threads else ""))
     so = os.path.join(JIT_DIR, f"fused_{key}.so")
     src = os.path.join(JIT_DIR, f"fused_{key}.hip")
     if os.path.exists(so) and not force:
@@ -721,7 +726,7 @@ def build_fused(program: PointwiseProgram, desc, force=False):
     with open(src, "w") as fh:
         fh.write(source)
     try:
-        _hipcc.compile_shared(src, so, _extra_flags())
+        _hipcc.compile_shared(src, so, flags)
     except RuntimeError as e:
         raise RuntimeError(f"hipcc failed for generated fused kernel {src}:\n{str(e)[-4000:]}") from e
     return so

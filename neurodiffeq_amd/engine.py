@@ -154,7 +154,11 @@ class FusedSystem:
         self.loss_norm = self.program.loss_norm      # loss = sum over points of the per-point term / (N * loss_norm)
         self.kernel = codegen.load(self.program)
         self.fusedk = None
-        self._fused_verified = os.environ.get("NDQ_SELF_CHECK", "1") == "0"
+        # the 8-wave build of the closure kernel (two waves per SIMD), built on first use for batches of at least
+        # WIDE_MIN_POINTS points: None = not tried yet, False = not available / rejected
+        self.fusedk_wide = None if os.environ.get("NDQ_FUSED_WIDE", "1") != "0" else False
+        self._self_check = os.environ.get("NDQ_SELF_CHECK", "1") != "0"
+        self._verified = set()                       # id() of the closure-kernel variants that passed verify_fused
         if single_kernel and codegen.can_fuse(self.program, self.descs):
             fk = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0]))
             if fk.lib.ndq_fused_lds_bytes() <= 160 * 1024:       # K weight images + staging must fit one workgroup's LDS
@@ -196,6 +200,28 @@ class FusedSystem:
         return step // 4
 
     MAX_BUFFER_SETS = 8
+    # Two waves per SIMD pay once every wave has at least one tile with all 256 workgroups of 8 waves in flight
+    # (measured at C2: 28.3 vs 29.6 us per step); smaller batches keep the 4-wave build, which spreads over more CUs.
+    WIDE_MIN_POINTS = int(os.environ.get("NDQ_FUSED_WIDE_MIN", 32768))
+
+    def needs_check(self, n):
+        """Has the closure-kernel build serving batches of ``n`` points still to pass verify_fused?"""
+        fk = self.fused_variant(n) if self._self_check else None
+        return fk is not None and id(fk) not in self._verified
+
+    def fused_variant(self, n):
+        """The closure-kernel build that serves a batch of ``n`` points (None: three-kernel pipeline)."""
+        if self.fusedk is None:
+            return None
+        if n >= self.WIDE_MIN_POINTS and self.fusedk_wide is not False:
+            if self.fusedk_wide is None:
+                wide = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0], threads=512))
+                # shapes whose per-wave state needs the whole register file compile to the same 4-wave kernel
+                ok = wide.threads > self.fusedk.threads and wide.lib.ndq_fused_lds_bytes() <= 160 * 1024
+                self.fusedk_wide = wide if ok else False
+            if self.fusedk_wide is not False:
+                return self.fusedk_wide
+        return self.fusedk
 
     def buffers(self, n, ld=None):
         key = (n, ld)
@@ -239,8 +265,11 @@ class FusedSystem:
                     if c in self.vcoords:
                         blk[row].fill_(self.vcoords[c])
                 b["site_coords"][k] = blk
-        if self.fusedk is not None:
-            b["fused_blocks"] = self.fusedk.blocks(n)
+        fk = b["fusedk"] = self.fused_variant(n)
+        if fk is not None:
+            b["fused_launch"] = ctypes.cast(fk.lib.ndq_fused_launch, ctypes.c_void_p).value
+            b["fused_launch_multi"] = ctypes.cast(fk.lib.ndq_fused_launch_multi, ctypes.c_void_p).value
+            b["fused_blocks"] = fk.blocks(n)
             b["fused_partials_all"] = [torch.empty(b["fused_blocks"], fp.numel, dtype=f32, device=dev) for fp in self.flat]
             b["fused_partials"] = b["fused_partials_all"][0]
             b["fused_partials_pp"] = (_c_vp * len(self.nets))(*[t.data_ptr() for t in b["fused_partials_all"]])
@@ -421,10 +450,13 @@ class FusedSystem:
         register allocation differs from build to build, and gfx950 has shown hazards the compiler does not know
          -- a kernel that is not bit-reproducible, or that disagrees with the independently compiled
         forward / pointwise / adjoint kernels, is not used: the system continues on the three-kernel pipeline (still
-        all-HIP) with a warning.  One host synchronisation, once per system; NDQ_SELF_CHECK=0 skips it."""
-        if self._fused_verified or self.fusedk is None:
+        all-HIP) with a warning.  One host synchronisation, once per system and kernel build (the 8-wave build for
+        large batches is checked when it is first used; if only that one fails, the 4-wave build takes over);
+        NDQ_SELF_CHECK=0 skips it.  Returns False if a build was rejected: ``b`` is then stale, upload again."""
+        fk = b.get("fusedk")
+        if fk is None or not self._self_check or id(fk) in self._verified:
             return True
-        self._fused_verified = True
+        self._verified.add(id(fk))
         n_global = n if n_global is None else n_global
         stream = self._stream()
         keep = [fp.grad_loss.clone() for fp in self.flat], self.loss_buf[:1].clone()
@@ -457,13 +489,27 @@ class FusedSystem:
         if same and err < self.SELF_CHECK_TOL and lerr < self.SELF_CHECK_TOL:
             return True
         import warnings
-        warnings.warn(f"single-launch closure kernel rejected by its self-check ({self.fused_check}); this system "
-                      "continues on the three-kernel pipeline", RuntimeWarning)
-        self.fusedk = None
+        if fk is self.fusedk_wide:
+            warnings.warn(f"8-wave closure kernel rejected by its self-check ({self.fused_check}); large batches of this "
+                          "system use the 4-wave build as well", RuntimeWarning)
+        else:
+            warnings.warn(f"single-launch closure kernel rejected by its self-check ({self.fused_check}); this system "
+                          "continues on the three-kernel pipeline", RuntimeWarning)
+            self.fusedk = None
+        self.fusedk_wide = False
+        # buffer sets carry the build they were made for (block counts, partial-sum rows, launchers): start over
+        self._bufs.clear()
+        self._resident_cache.clear()
         self._fast = None
         return False
 
     SELF_CHECK_TOL = 1e-4
+
+    def reject_fused(self):
+        """Give up the single-launch closure kernel of this system (all builds): three-kernel pipeline from here on."""
+        self.fusedk, self.fusedk_wide, self._fast = None, False, None
+        self._bufs.clear()
+        self._resident_cache.clear()
 
     def verify_on(self, batch, n_global=None, lo=0, hi=None):
         b, n = self.upload(batch, lo, hi)
@@ -479,7 +525,7 @@ class FusedSystem:
             fp.sync()
         seed = 1.0 / (float(n_global) * self.loss_norm)
         params_pp = (_c_vp * len(self.flat))(*[fp.flat.data_ptr() for fp in self.flat])
-        rc = self.fusedk.lib.ndq_fused_launch_multi(self._coord_ptr(b, 0), b["ld"], n, params_pp,
+        rc = b["fusedk"].lib.ndq_fused_launch_multi(self._coord_ptr(b, 0), b["ld"], n, params_pp,
                                                     b["fused_partials_pp"] if train else None,
                                                     _ptr(b["fused_loss_partials"]),
                                                     _ptr(b["funcs"]) if want_funcs else None,
@@ -511,11 +557,7 @@ class FusedSystem:
                               valid_hist=torch.zeros(self.HIST, dtype=f32, device=dev),
                               best_loss=torch.full((2,), float("inf"), dtype=f32, device=dev),
                               best_flat=[torch.zeros_like(fp.grad) for fp in self.flat], parity=0, pending=0,
-                              pending_valid=0, structs={},
-                              launch=(ctypes.cast(self.fusedk.lib.ndq_fused_launch, ctypes.c_void_p).value
-                                      if self.fusedk is not None else None),
-                              launch_multi=(ctypes.cast(self.fusedk.lib.ndq_fused_launch_multi, ctypes.c_void_p).value
-                                            if self.fusedk is not None else None))
+                              pending_valid=0, structs={})
         return self._fast
 
     def epoch_tail(self, kind, n_batches, track_best, adam_slots=None):
@@ -577,7 +619,7 @@ class FusedSystem:
             st.adam_m, st.adam_v = m.data_ptr(), v.data_ptr()
             b1, b2 = group["betas"]
             st.lr, st.beta1, st.beta2, st.eps, st.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]
-        rc = self.L.ndq_fused_multi_step_run(arr, K, _c_vp(fs["launch_multi"]), self._coord_ptr(b, 0), step,
+        rc = self.L.ndq_fused_multi_step_run(arr, K, _c_vp(b["fused_launch_multi"]), self._coord_ptr(b, 0), step,
                                              fs["pending"], fs["parity"], self._stream())
         _lib.check(rc, "ndq_fused_multi_step_run")
         fs["pending"] += 1
@@ -596,7 +638,7 @@ class FusedSystem:
         st = fs["structs"].get(key)
         if st is None:
             st = _lib.FusedStep()
-            st.launch = fs["launch"]
+            st.launch = b["fused_launch"]
             st.n, st.ldc, st.ldj, st.blocks, st.n_params = n, b["ld"], b["ld"], b["fused_blocks"], fp.numel
             st.partials, st.loss_partials = b["fused_partials"].data_ptr(), b["fused_loss_partials"].data_ptr()
             st.grad, st.loss_slot = fp.grad.data_ptr(), fp.grad_loss.data_ptr() + 4 * fp.numel
@@ -664,9 +706,9 @@ class FusedSystem:
         b, n = self.upload(batch, lo, hi)
         n_global = n if n_global is None else n_global
         stream = self._stream()
-        if self.fusedk is not None and train and not self._fused_verified and not accumulate:
-            self.verify_fused(b, n, n_global)
-        if self.fusedk is not None:
+        if train and not accumulate and not self.verify_fused(b, n, n_global):
+            b, n = self.upload(batch, lo, hi)            # a closure-kernel build was rejected: fresh buffer set
+        if b["fusedk"] is not None:
             self.fused_closure(b, n, stream, train, n_global, slot, accumulate, want_funcs, want_resid)
             return b, n
         self.forward(b, n, stream)

@@ -409,14 +409,15 @@ class BaseSolver(ABC):
         train = key == "train"
         nb = self.n_batches[key]
         track_best = (not train) or self.n_batches["valid"] == 0
-        if train and system.fusedk is not None and not system._fused_verified:
-            # first training batch of this system: the single-launch closure kernel proves itself against the
-            # three-kernel pipeline (engine.verify_fused) before any parameter is updated with its gradients
+        if train and system.fusedk is not None:
             n_all = first_batch[0].shape[0]
             lo, hi = self.dist.bounds(n_all) if self.dist else (0, n_all)
-            ok = system.verify_on(first_batch, self.dist.global_n(n_all) if self.dist else n_all, lo, hi)
-            if self.dist and not self.dist.agree(ok, self.device) and system.fusedk is not None:
-                system.fusedk, system._fast = None, None      # ranks must take the same path: another rank rejected its kernel
+            if system.needs_check(hi - lo):
+                # first training batch served by this build of the single-launch closure kernel: it proves itself against
+                # the three-kernel pipeline (engine.verify_fused) before any parameter is updated with its gradients
+                ok = system.verify_on(first_batch, self.dist.global_n(n_all) if self.dist else n_all, lo, hi)
+                if self.dist and not self.dist.agree(ok, self.device) and ok:
+                    system.reject_fused()                 # ranks must take the same path: another rank rejected its kernel
         fs = system.fast_state()
         if max(fs["pending"], fs["pending_valid"]) >= system.HIST:
             self._flush_device_history()

@@ -41,7 +41,7 @@ stream = _c_vp(torch.cuda.current_stream().cuda_stream)
 
 
 def closure():
-    sysm.fusedk.lib.ndq_fused_launch(sysm._coord_ptr(b, 0), b["ld"], n, _ptr(fp.flat), _ptr(b["fused_partials"]),
+    b["fusedk"].lib.ndq_fused_launch(sysm._coord_ptr(b, 0), b["ld"], n, _ptr(fp.flat), _ptr(b["fused_partials"]),
                                      _ptr(b["fused_loss_partials"]), None, None, b["ld"], 1.0 / n, 1, stream)
 
 
