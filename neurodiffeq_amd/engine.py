@@ -200,9 +200,10 @@ class FusedSystem:
         return step // 4
 
     MAX_BUFFER_SETS = 8
-    # Two waves per SIMD pay once every wave has at least one tile with all 256 workgroups of 8 waves in flight
-    # (measured at C2: 28.3 vs 29.6 us per step); smaller batches keep the 4-wave build, which spreads over more CUs.
-    WIDE_MIN_POINTS = int(os.environ.get("NDQ_FUSED_WIDE_MIN", 32768))
+    # Two waves per SIMD pay once every wave of 256 workgroups x 8 waves has two tiles (measured, C2 step: 65 536 points
+    # 28.7 vs 29.8 us, 262 144 points 66 vs 76 us, 1 M points 231 vs 279 us; but 33 124 points 25.4 vs 23.6 us);
+    # smaller batches keep the 4-wave build, which spreads over more CUs.
+    WIDE_MIN_POINTS = int(os.environ.get("NDQ_FUSED_WIDE_MIN", 65536))
 
     def needs_check(self, n):
         """Has the closure-kernel build serving batches of ``n`` points still to pass verify_fused?"""
