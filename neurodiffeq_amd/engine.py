@@ -200,10 +200,18 @@ class FusedSystem:
         return step // 4
 
     MAX_BUFFER_SETS = 8
-    # Two waves per SIMD pay once every wave of 256 workgroups x 8 waves has two tiles (measured, C2 step: 65 536 points
-    # 28.7 vs 29.8 us, 262 144 points 66 vs 76 us, 1 M points 231 vs 279 us; but 33 124 points 25.4 vs 23.6 us);
-    # smaller batches keep the 4-wave build, which spreads over more CUs.
-    WIDE_MIN_POINTS = int(os.environ.get("NDQ_FUSED_WIDE_MIN", 65536))
+    # Which build serves a batch: both run "rounds" of one 16-point tile per wave over 256 workgroups -- 1 024 waves
+    # (4-wave build, one per SIMD) or 2 048 (8-wave build, two per SIMD).  Measured on the C2 step: 4-wave
+    # 11.3 + 4.1 us per round (15.4 / 23.6 / 27.6 us at 1 / 3 / 4 rounds), 8-wave 12.8 + 6.7 us per round (26.2 us at 2
+    # rounds for anything from 32 769 to 65 536 points, 66 us at 8).  So 65 536 points (4 vs 2 rounds) and everything from
+    # ~115 k points up go to the 8-wave build, 33 k - 49 k and 66 k - 82 k points (3 vs 2, 5 vs 3 rounds) do not.
+    WIDE_MIN_POINTS = int(os.environ.get("NDQ_FUSED_WIDE_MIN", 0))
+
+    @staticmethod
+    def prefers_wide(n):
+        tiles = (n + 15) // 16
+        r4, r8 = -(-tiles // 1024), -(-tiles // 2048)
+        return 0.37 + 1.63 * r8 < r4
 
     def needs_check(self, n):
         """Has the closure-kernel build serving batches of ``n`` points still to pass verify_fused?"""
@@ -214,7 +222,7 @@ class FusedSystem:
         """The closure-kernel build that serves a batch of ``n`` points (None: three-kernel pipeline)."""
         if self.fusedk is None:
             return None
-        if n >= self.WIDE_MIN_POINTS and self.fusedk_wide is not False:
+        if n >= self.WIDE_MIN_POINTS and self.prefers_wide(n) and self.fusedk_wide is not False:
             if self.fusedk_wide is None:
                 wide = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0], threads=512))
                 # shapes whose per-wave state needs the whole register file compile to the same 4-wave kernel
