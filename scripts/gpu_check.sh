@@ -23,4 +23,4 @@ find "$OUT/prof" -name "*stats*" | head; f=$(find "$OUT/prof" -name "*kernel_sta
 find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
 du -sh "$OUT"
 echo "== bench under torch.distributed.run (1 rank, RCCL path) =="
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 100 --warmup 10 > "$OUT/bench_dist1.json" 2> "$OUT/bench_dist1.err"; echo "dist bench rc=$?"; tail -n 1 "$OUT/bench_dist1.json" | cut -c1-400; tail -n 3 "$OUT/bench_dist1.err"
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5000 --warmup 500 > "$OUT/bench_dist1.json" 2> "$OUT/bench_dist1.err"; echo "dist bench rc=$?"; tail -n 1 "$OUT/bench_dist1.json" | cut -c1-400; tail -n 3 "$OUT/bench_dist1.err"
