@@ -17,7 +17,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log
 echo "== bench =="
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; cat "$OUT/bench.json"; tail -n 5 "$OUT/bench.err"
 echo "== rocprofv3 kernel trace =="
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/$OUT/prof" -o trace -- python "$REPO/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$REPO/$OUT/prof_bench.json" 2> "$REPO/$OUT/prof.err"); echo "rocprof rc=$?"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/$OUT/prof" -o trace -- python "$REPO/bench.py" --steps 3000 --warmup 300 --no-cpu-baseline > "$REPO/$OUT/prof_bench.json" 2> "$REPO/$OUT/prof.err"); echo "rocprof rc=$?"
 find "$OUT/prof" -name "*stats*" | head; f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 "$f"
 # keep the merge-back small: drop the raw per-dispatch trace if it is large
 find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
