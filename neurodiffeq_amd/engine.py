@@ -207,6 +207,14 @@ class FusedSystem:
     # ~115 k points up go to the 8-wave build, 33 k - 49 k and 66 k - 82 k points (3 vs 2, 5 vs 3 rounds) do not.
     WIDE_MIN_POINTS = int(os.environ.get("NDQ_FUSED_WIDE_MIN", 0))
 
+    def _wide_possible(self):
+        """Does csrc/ndq_mlp.h give this shape an 8-wave build at all?  (Cfg::BWD_THREADS: per-wave state of more than 40
+        fragment blocks keeps the whole register file, i.e. 4 waves -- no point compiling to find that out)"""
+        d = self.descs[0]
+        nb, layers = d.hidden // 16, d.layers
+        ns = self.L.ndq_mlp_num_streams(ctypes.byref(d))
+        return nb * nb * (layers - 1) + nb * ns * layers <= 40
+
     @staticmethod
     def prefers_wide(n):
         tiles = (n + 15) // 16
@@ -223,6 +231,8 @@ class FusedSystem:
         if self.fusedk is None:
             return None
         if n >= self.WIDE_MIN_POINTS and self.prefers_wide(n) and self.fusedk_wide is not False:
+            if self.fusedk_wide is None and not self._wide_possible():
+                self.fusedk_wide = False
             if self.fusedk_wide is None:
                 wide = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0], threads=512))
                 # shapes whose per-wave state needs the whole register file compile to the same 4-wave kernel
