@@ -240,15 +240,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed spin-up, whatever W is: ~0.3 s of the workload itself, so that the W warm-up steps and the K timed ones
-    # find the device at its sustained clocks, every buffer set of the batch pool allocated, the closure kernel
-    # self-checked and the host path warm (a 50-step run measured 31 us per step without it, 26 us sustained)
-    SPIN_UP_S = 0.3
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < SPIN_UP_S:
-        for _ in range(50):
-            solver.run_train_epoch()
-        torch.cuda.synchronize()
+    # untimed spin-up, whatever W is: 10 000 steps (~0.3 s) of the workload itself, so that the W warm-up steps and the
+    # K timed ones find the device at its sustained clocks, every buffer set of the batch pool allocated, the closure
+    # kernel self-checked and the host path warm (a 50-step run measured 31 us per step without it, 26 us sustained).
+    # A fixed COUNT, not a wall-time loop: under data parallelism every epoch is a collective, all ranks must run the same
+    # number of them.
+    SPIN_UP_STEPS = 10000
+    for _ in range(SPIN_UP_STEPS):
+        solver.run_train_epoch()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         solver.run_train_epoch()
     barrier()
@@ -274,7 +274,7 @@ def main():
         out = {
             "metric": "collocation-points/sec (residual+bwd), 2D Laplace 65k pts, 1/2/4/8 GPU",
             "value": value, "unit": "collocation-points/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "spin_up_s": SPIN_UP_S, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "spin_up_steps": SPIN_UP_STEPS, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: Solver2D 2D Laplace, DirichletBVP2D, FCNN(2-32-32-1, tanh), Generator2D "
                                    "256x256 = 65536 noisy-grid points per GPU per step, Adam(1e-3), "
