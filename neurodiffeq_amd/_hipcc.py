@@ -98,6 +98,12 @@ def scalarize_pk(asm_text, which="opsel"):
         neg_lo = mods.get("neg_lo", [0] * nsrc) + [0] * nsrc
         neg_hi = mods.get("neg_hi", [0] * nsrc) + [0] * nsrc
         is_pair = [bool(re.fullmatch(r"[vs]\[\d+:\d+\]", o)) for o in ops[1:]]
+        # anything that is neither a 64-bit register pair nor a plain numeric constant (clamp / omod suffixes, special
+        # registers, symbols ...): not an instruction this rewrite understands -- leave it alone
+        if not all(p or re.fullmatch(r"-?(\d+(\.\d+)?|0x[0-9a-fA-F]+)", o) for p, o in zip(is_pair, ops[1:])):
+            out.append(line)
+            skipped += 1
+            continue
         has_opsel = any(sel[i] for i in range(nsrc))
         has_hi = any(is_pair[i] and not sel_hi[i] for i in range(nsrc))
         if not (which == "all" or (which == "opsel" and has_opsel) or (which == "opsel_hi" and (has_opsel or has_hi))):

@@ -272,3 +272,7 @@ def test_assembly_fixup_scalarizes_packed_ops_that_cross_halves():
     assert lines[10].startswith("v_pk_mul_f32 v[2:3], v[2:3], v[2:3]")      # halves would clobber each other: untouched
     every, n_all, _ = _hipcc.scalarize_pk(asm, "all")
     assert n_all == 6 and every.count("v_pk_") == 1
+    # operands the rewrite does not understand (output modifiers, special registers) are never touched
+    odd = "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0] clamp\n\tv_pk_add_f32 v[0:1], v[2:3], vcc op_sel:[0,1]"
+    same, n_odd, n_skip = _hipcc.scalarize_pk(odd, "opsel")
+    assert same == odd and n_odd == 0 and n_skip == 2
