@@ -276,3 +276,13 @@ def test_assembly_fixup_scalarizes_packed_ops_that_cross_halves():
     odd = "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0] clamp\n\tv_pk_add_f32 v[0:1], v[2:3], vcc op_sel:[0,1]"
     same, n_odd, n_skip = _hipcc.scalarize_pk(odd, "opsel")
     assert same == odd and n_odd == 0 and n_skip == 2
+
+
+def test_closure_kernel_build_is_chosen_from_the_tile_round_count():
+    """engine.FusedSystem.prefers_wide: 8-wave workgroups (2 048 waves per round at 6.7 us) against 4-wave ones (1 024 at
+    4.1 us), measured on MI355X: the BASELINE headline size and every large batch go to the 8-wave build,
+    small batches and the sizes where it would need as many rounds for more money do not."""
+    from neurodiffeq_amd.engine import FusedSystem
+    wide = FusedSystem.prefers_wide
+    assert not any(wide(n) for n in (32, 1024, 16384, 32768, 33124, 40000, 81920))
+    assert all(wide(n) for n in (49284, 57600, 65536, 98304, 131072, 262144, 1 << 20, 1 << 22))
