@@ -286,3 +286,69 @@ def test_closure_kernel_build_is_chosen_from_the_tile_round_count():
     wide = FusedSystem.prefers_wide
     assert not any(wide(n) for n in (32, 1024, 16384, 32768, 33124, 40000, 81920))
     assert all(wide(n) for n in (49284, 57600, 65536, 98304, 131072, 262144, 1 << 20, 1 << 22))
+
+
+def test_scalarized_packed_ops_compute_what_the_packed_ones_do():
+    """Property test of _hipcc.scalarize_pk on random instructions: a small interpreter executes the packed form (ISA
+    semantics: per half, source i is the low or high register of its pair as op_sel / op_sel_hi say, negated as neg_lo /
+    neg_hi say, all sources read before the destination pair is written) and the rewritten scalar sequence (executed in
+    order) on the same random register file -- the register files must end up identical, including when the destination
+    overlaps the sources."""
+    import random
+    import re
+    import numpy as np
+    from neurodiffeq_amd import _hipcc
+    rng = random.Random(7)
+    f32 = np.float32
+
+    def fma(op, a, b, c=None):
+        return f32(a * b) if op == "mul" else f32(a + b) if op == "add" else f32(np.float32(np.float64(a) * np.float64(b) + np.float64(c)))
+
+    def run_packed(regs, op, dst, srcs, sel, sel_hi, neg_lo, neg_hi):
+        def val(s, which, neg):
+            v = regs[s + which] if isinstance(s, int) else f32(s)
+            return f32(-v) if neg else v
+        lo = fma(op, *[val(s, sel[i] if isinstance(s, int) else 0, neg_lo[i]) for i, s in enumerate(srcs)])
+        hi = fma(op, *[val(s, sel_hi[i] if isinstance(s, int) else 0, neg_hi[i]) for i, s in enumerate(srcs)])
+        regs[dst], regs[dst + 1] = lo, hi
+
+    def run_scalar(regs, line):
+        m = re.match(r"\s*v_(mul|add|fma)_f32(?:_e64)?\s+v(\d+),\s*(.*)$", line)
+        op, d, rest = m.group(1), int(m.group(2)), [t.strip() for t in m.group(3).split(",")]
+        vals = []
+        for t in rest:
+            neg = t.startswith("-") and t[1:].startswith("v")
+            t2 = t[1:] if neg else t
+            v = regs[int(t2[1:])] if t2.startswith("v") else f32(float(t2))
+            vals.append(f32(-v) if neg else v)
+        regs[d] = fma(op, *vals)
+
+    checked = 0
+    for _ in range(3000):
+        op = rng.choice(["mul", "add", "fma"])
+        nsrc = 3 if op == "fma" else 2
+        dst = rng.randrange(0, 12, 1)
+        srcs = [rng.choice([rng.randrange(0, 12), rng.choice([0.5, 2.0, -1.0, 4.0])]) if rng.random() < 0.15
+                else rng.randrange(0, 12) for _ in range(nsrc)]
+        sel = [rng.randint(0, 1) for _ in range(nsrc)]
+        sel_hi = [rng.randint(0, 1) for _ in range(nsrc)]
+        neg_lo = [int(rng.random() < 0.2) for _ in range(nsrc)]
+        neg_hi = [int(rng.random() < 0.2) for _ in range(nsrc)]
+        for i, s in enumerate(srcs):                     # constants: encoded the way the compiler does (no selects, no neg)
+            if not isinstance(s, int):
+                sel[i], sel_hi[i], neg_lo[i], neg_hi[i] = 0, 0, 0, 0
+        text = f"\tv_pk_{op}_f32 v[{dst}:{dst + 1}], " + ", ".join(f"v[{s}:{s + 1}]" if isinstance(s, int) else repr(s) for s in srcs)
+        text += f" op_sel:[{','.join(map(str, sel))}] op_sel_hi:[{','.join(map(str, sel_hi))}]"
+        text += f" neg_lo:[{','.join(map(str, neg_lo))}] neg_hi:[{','.join(map(str, neg_hi))}]"
+        out, done, skipped = _hipcc.scalarize_pk(text, "all")
+        if not done:
+            assert skipped == 1 and out == text
+            continue
+        base = [f32(rng.uniform(-3, 3)) for _ in range(14)]
+        a, b = list(base), list(base)
+        run_packed(a, op, dst, srcs, sel, sel_hi, neg_lo, neg_hi)
+        for line in out.split("\n"):
+            run_scalar(b, line)
+        assert all(x == y or (np.isnan(x) and np.isnan(y)) for x, y in zip(a, b)), (text, out)
+        checked += 1
+    assert checked > 2000
