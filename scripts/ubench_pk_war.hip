@@ -1,12 +1,20 @@
-// Reproducer for a write-after-read hazard seen on gfx950 (MI355X) in compiler-generated code (ROCm 7.2 clang 22):
+// Reproducer for wrong results of a packed-fp32 instruction with op_sel on gfx950 (MI355X), seen in compiler-generated
+// code (ROCm 7.2, clang 22):
 //
-//     v_pk_mul_f32  v[2:3], v[10:11], v[58:59] op_sel:[0,1]     ; reads v10
+//     v_pk_mul_f32  v[60:61], v[202:203], 0 op_sel_hi:[1,0]
+//     v_pk_mul_f32  v[2:3], v[10:11], v[58:59] op_sel:[0,1]     ; low half = v10 * v59  (src1's HIGH half)
 //     v_mfma_f32_16x16x32_bf16 a[52:55], v[116:119], v[82:85], a[52:55]
-//     v_accvgpr_read_b32 v10, a16                               ; overwrites v10
 //
-// In the fused closure kernel of one stream set, lanes 48..63 of the packed multiply's LOW result intermittently saw
-// the NEW v10 (found by assembly-level bisection: one s_nop after the v_pk_mul makes the kernel bit-exact again).
-// This program replays the sequence with hard-coded registers and counts wrong lanes for several variants.
+// In the fused closure kernel of one stream set, lanes 48..63 of the second packed multiply's LOW result intermittently
+// came back as v10 * 0 -- the operand of the packed instruction before it -- which surfaced as one non-deterministic
+// gradient entry.  Found by assembly-level bisection (one s_nop after that v_pk_mul makes the kernel bit-exact again);
+// the file started life as a suspected write-after-read hazard, hence its name, but the result is wrong whether or not
+// anything overwrites the sources afterwards.  This program replays the sequence with hard-coded registers and counts
+// wrong lanes for several variants (profiles/r01u_pk_mfma_hazard.txt): ~11 % of the executions wrong as found; exact
+// with one wait state or any non-MFMA instruction between the packed op and the MFMA, with scalar multiplies instead,
+// or with the f32 MFMA as the follower.  Rewriting every packed-fp32 instruction that carries op_sel as two scalar
+// instructions (neurodiffeq_amd/_hipcc.py) also cured a second, older corruption that only showed with two waves per
+// SIMD.
 //   hipcc --offload-arch=gfx950 -O2 scripts/ubench_pk_war.hip -o /tmp/pk_war && /tmp/pk_war
 #include <hip/hip_runtime.h>
 #include <cstdio>
