@@ -112,3 +112,23 @@ def test_bounds_partition():
             assert all(a[1] == b[0] for a, b in zip(edges[:-1], edges[1:]))
             sizes = [hi - lo for lo, hi in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _agree_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = BatchSharding()
+    res = [sh.agree(True, "cpu"), sh.agree(rank == 0, "cpu"), sh.agree(False, "cpu")]
+    if rank == 1:
+        np.save(out, np.array(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_a_flag_only_if_all_do(tmp_path):
+    """BatchSharding.agree (the closure kernel's self-check outcome must send every rank down the same launch path):
+    true only when true everywhere."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "agree.npy")
+    mp.spawn(_agree_worker, args=(2, port, out), nprocs=2, join=True)
+    assert np.load(out).tolist() == [True, False, False]
