@@ -149,9 +149,34 @@ def kernel_breakdown(system, batch):
     )
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median_time(fn, min_runs, budget_s, max_runs=200):
+    times, t_start = [], time.perf_counter()
+    while len(times) < min_runs or (time.perf_counter() - t_start < budget_s and len(times) < max_runs):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > 3 * budget_s:
+            break
+    times.sort()
+    return times[len(times) // 2], len(times)
+
+
+def cpu_baseline(budget_s=8.0):
     """The reference's training step restated on torch CPU autograd (oracle/autograd_ref.py, pinned to the
-    reference's golden vectors), same config, timed on this host's cores."""
+    reference's golden vectors; kind = "port": the unmodified reference cannot travel to the GPU box), same C2 config,
+    timed on this host's cores three ways: the step as BASELINE.md section 2.3 defines it (sample + fwd + diff + loss +
+    bwd + Adam; ``value``), the same step on a pre-sampled batch (``presampled``: what the GPU headline times), and the
+    library-default fp64 (``fp64``)."""
     from oracle import autograd_ref as R
     torch.manual_seed(0)
     cfg = R.build_config("c2", GRID)
@@ -173,30 +198,115 @@ def cpu_baseline(budget_s=20.0):
     torch.set_num_threads(best[1])
     for _ in range(2):
         loop.epoch()
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 8 or (time.perf_counter() - t_start < budget_s and len(times) < 200):
-        t0 = time.perf_counter()
-        loop.epoch()
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_start > 3 * budget_s:
-            break
-    times.sort()
-    med = times[len(times) // 2]
+    med, runs = _median_time(loop.epoch, 8, budget_s)
+    fixed = cfg["sampler"]()
+    pre = R.TrainLoop(cfg["nets"], cfg["enforcers"], cfg["pde"], lambda: fixed)
+    pre.epoch()
+    med_pre, runs_pre = _median_time(pre.epoch, 5, budget_s / 2)
+    torch.manual_seed(0)
+    cfg64 = R.build_config("c2", GRID, dtype=torch.float64)
+    samp64 = cfg64["sampler"]
+    loop64 = R.TrainLoop(cfg64["nets"], cfg64["enforcers"], cfg64["pde"], samp64)
+    loop64.epoch()
+    med64, runs64 = _median_time(loop64.epoch, 3, budget_s / 2)
     return dict(value=N_POINTS / med, unit="collocation-points/s", cores=torch.get_num_threads(), kind="port",
-                ms_per_step=med * 1e3,
-                sample=f"{len(times)} timed run_train_epoch-equivalent steps (sample+fwd+diff+loss+bwd+Adam) of the "
-                       f"same C2 config, fp32, torch {torch.__version__} CPU, {os.cpu_count()} logical cpus")
+                ms_per_step=med * 1e3, cpu_model=cpu_model(), logical_cpus=os.cpu_count(),
+                presampled=dict(value=N_POINTS / med_pre, ms_per_step=med_pre * 1e3, runs=runs_pre,
+                                note="same step without the generator draw: what the GPU headline `value` times"),
+                fp64=dict(value=N_POINTS / med64, ms_per_step=med64 * 1e3, runs=runs64,
+                          note="library default precision (neurodiffeq/__init__.py:22), with sampling"),
+                sample=f"{runs} timed run_train_epoch-equivalent steps (sample+fwd+diff+loss+bwd+Adam) of the "
+                       f"same C2 config, fp32, torch {torch.__version__} CPU, {os.cpu_count()} logical cpus, "
+                       f"{torch.get_num_threads()} threads (fastest of 1/4/8/16/32/64/128)")
+
+
+# algorithmic GEMM flop per point of a training step, SURVEY.md 8(d) table
+ALGO_FLOP_PER_PT = {"c1": 25728, "c2": 32064, "c3": 198912, "c4": 33024, "c5": 646272}
+
+
+def timed_windows(step, k, barrier, reduce_max=None, min_total_s=0.25, max_windows=2000):
+    """Time windows of EXACTLY ``k`` steps, each bracketed by barrier + synchronize on both sides, until at least
+    ``min_total_s`` of timed work has been seen (a 20-step window of the headline is 0.5 ms: one of them is noise);
+    every rank runs the same number of windows (decided from the first one, maximum over ranks).  Returns the sorted
+    per-window times (seconds; max over ranks)."""
+    def window():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        barrier()
+        return time.perf_counter() - t0
+    first = window()
+    n = int(min(max_windows, max(1, -(-min_total_s // max(first, 1e-9)))))
+    if reduce_max is not None:
+        n = int(reduce_max([float(n)])[0])
+    times = [first] + [window() for _ in range(n - 1)]
+    if reduce_max is not None:
+        times = reduce_max(times)
+    return sorted(times)
+
+
+def config_record(name):
+    """One other BASELINE config at its stated size through run_train_epoch() on resident pre-sampled batches:
+    ms per step (median of >= 0.25 s of windows), points/s, algorithmic TFLOP/s and fraction of the fp32 MFMA peak."""
+    from tests import configs
+    from neurodiffeq_amd.generators import ResidentBatchGenerator, SamplerGenerator
+    torch.manual_seed(0)
+    solver, cfg = configs.make_solver(name)
+    solver.fused = "require"
+    torch.manual_seed(1)
+    solver.generator["train"] = SamplerGenerator(ResidentBatchGenerator.presample(cfg["gen"], 2, "cuda"))
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:
+        for _ in range(5):
+            solver.run_train_epoch()
+        torch.cuda.synchronize()
+    k = 5 if name == "c5" else 50
+    times = timed_windows(solver.run_train_epoch, k, torch.cuda.synchronize)
+    dt = times[len(times) // 2] / k
+    n = cfg["n_points"]
+    tf = ALGO_FLOP_PER_PT[name] * n / dt / 1e12
+    sysm = solver._fused_sys
+    return dict(points=n, ms_per_step=dt * 1e3, points_per_s=n / dt, algorithmic_flop_per_point=ALGO_FLOP_PER_PT[name],
+                algorithmic_tflops=tf, frac_of_fp32_mfma_peak=tf / FP32_MFMA_PEAK_TFLOPS, windows=len(times), steps_per_window=k,
+                single_launch=sysm.fusedk is not None, launches_per_step=sysm.launches_per_step(),
+                final_loss=solver.metrics_history["train_loss"][-1])
+
+
+def pointwise_large():
+    """The standalone generated pointwise residual kernel (HBM-bound: reads coordinates + network streams, writes the
+    adjoint streams) at sizes where HBM speed, not launch latency, decides: C2's at 1 M and 4 M points, C5's at 1 M."""
+    from tests import configs
+    from neurodiffeq_amd.engine import FusedSystem
+    out = {}
+    for name, size in (("c2", 1024), ("c2", 2048), ("c5", 1024)):
+        torch.manual_seed(0)
+        cfg = configs.make(name, size)
+        for net in cfg["nets"]:
+            net.to("cuda")
+        system = FusedSystem(cfg["nets"], cfg["conds"], cfg["pde"], 2, "cuda", single_kernel=False)
+        torch.manual_seed(1)
+        batch = [c.detach().cuda() for c in cfg["gen"].get_examples()]
+        b, n = system.upload(batch)
+        stream = system._stream()
+        system.step(batch, train=True)
+        t = time_launches(lambda: system.pointwise(b, n, stream, True, n), iters=200, warm=50)
+        bpp = system.program.bytes_per_point(train=True)
+        out[f"{name}_{n}"] = dict(points=n, us=t * 1e6, bytes_per_point=bpp, gbs=bpp * n / t / 1e9,
+                                  frac=bpp * n / t / 1e9 / HBM_PEAK_GBS)
+        del system, b
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: ~0.6 s of sustained work in the timed region.  An MI355X needs sustained load to reach and hold its
-    # clocks: the same step measures 26.5 us in a 20 000-step run and 28.7 us in a 200-step (6 ms) burst.
+    # defaults: ~0.5 s of sustained work in one timed window (smaller K: the window is repeated, see timed_windows)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config sub-records (C1, C3, C4, C5)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,27 +350,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed spin-up, whatever W is: 10 000 steps (~0.3 s) of the workload itself, so that the W warm-up steps and the
-    # K timed ones find the device at its sustained clocks, every buffer set of the batch pool allocated, the closure
-    # kernel self-checked and the host path warm (a 50-step run measured 31 us per step without it, 26 us sustained).
-    # A fixed COUNT, not a wall-time loop: under data parallelism every epoch is a collective, all ranks must run the same
-    # number of them.
-    SPIN_UP_STEPS = 10000
-    for _ in range(SPIN_UP_STEPS):
-        solver.run_train_epoch()
-    torch.cuda.synchronize()
+    # W untimed warm-up steps (the closure kernel's first-use self-check, buffer allocation and the host path warm up
+    # here), then windows of EXACTLY K steps, each bracketed by barrier + synchronize; a window of the driver's K = 20
+    # is 0.5 ms, so windows are repeated until >= 0.25 s has been timed and the MEDIAN window is reported (an MI355X
+    # also needs tens of ms of sustained work to reach its clocks: the first windows of a cold box are slower).
     for _ in range(args.warmup):
         solver.run_train_epoch()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        solver.run_train_epoch()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+
+    def reduce_max(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return t.tolist()
+    windows = timed_windows(solver.run_train_epoch, args.steps, barrier, reduce_max if use_dist else None)
+    dt = windows[len(windows) // 2]
     assert solver.fused_active
     # the headline is the single-launch closure kernel: if its first-use self-check (engine.verify_fused) rejected it,
     # the numbers below would silently be the three-kernel pipeline's -- refuse instead
@@ -274,7 +376,10 @@ def main():
         out = {
             "metric": "collocation-points/sec (residual+bwd), 2D Laplace 65k pts, 1/2/4/8 GPU",
             "value": value, "unit": "collocation-points/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "spin_up_steps": SPIN_UP_STEPS, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms,
+            "timing": {"windows": len(windows), "steps_per_window": args.steps, "statistic": "median window",
+                       "window_ms_min": windows[0] * 1e3, "window_ms_median": dt * 1e3, "window_ms_max": windows[-1] * 1e3,
+                       "timed_total_s": sum(windows)}, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2: Solver2D 2D Laplace, DirichletBVP2D, FCNN(2-32-32-1, tanh), Generator2D "
                                    "256x256 = 65536 noisy-grid points per GPU per step, Adam(1e-3), "
@@ -367,9 +472,22 @@ def main():
         torch.cuda.synchronize()
         dt3 = (time.perf_counter() - t0) / args.steps
         out["with_device_sampling"] = {"value": N_POINTS / dt3, "ms_per_step": dt3 * 1e3}
+        if not args.no_configs:
+            # the other BASELINE configs at their stated sizes (parity-tested at those sizes in tests/test_gpu_parity.py)
+            del pipeline
+            solver.generator["train"] = None
+            torch.cuda.empty_cache()
+            out["configs"] = {name: config_record(name) for name in ("c1", "c3", "c4", "c5")}
+            out["roofline_pointwise_large"] = pointwise_large()
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            cb = out["cpu_baseline"] = cpu_baseline()
+            # like for like: resident inputs on both sides / generator draw inside the step on both sides (the host draw +
+            # PCIe upload is then what the GPU step waits for; its numbers are the reference's bit for bit)
+            out["speedup_vs_cpu_baseline"] = {
+                "presampled_inputs_both_sides": value / cb["presampled"]["value"],
+                "host_sampling_both_sides": out["with_host_sampling"]["value"] / cb["value"],
+                "note": "headline `value` (inputs resident in HBM) vs the CPU port on a pre-sampled batch; "
+                        "`with_host_sampling` (reference RNG draw + upload inside the step) vs the CPU port's full step"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

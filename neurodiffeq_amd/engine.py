@@ -54,7 +54,14 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         res = diff_eqs(*funcs, *coords) if diff_eqs is not None else []     # None: evaluation of the functions only
         if isinstance(res, Sym):
             res = [res]
-        res = [r if isinstance(r, Sym) else Sym(g, g.const(float(r))) for r in res]
+        def column(r):
+            if isinstance(r, Sym):
+                return r
+            try:
+                return Sym(g, g.const(float(r)))
+            except (TypeError, ValueError, RuntimeError):
+                raise TraceUnsupported(f"an equation returned {type(r).__name__}, not a traced (N, 1) column or a scalar")
+        res = [column(r) for r in res]
     if not all(isinstance(f, Sym) for f in funcs):
         raise TraceUnsupported("a condition returned something that is not a traced column")
     for k, info in enumerate(infos):       # a net that never appears in an equation still needs a layout
@@ -567,6 +574,13 @@ class FusedSystem:
         """Can a whole training epoch go through one native call?  (single-launch closure; the data-parallel hook exists
         for one network only)"""
         return self.fusedk is not None and (len(self.nets) == 1 or dist is None)
+
+    def launches_per_step(self):
+        """Kernel launches of one native training epoch with one batch (bench.py reports it per config)."""
+        if self.fusedk is not None:
+            return 2                                     # closure kernel + ONE sums/tail kernel (all networks)
+        # pipeline: forward per site, pointwise, (adjoint + sums) per site, loss sum, epoch tail per network
+        return self.n_sites + 1 + 2 * self.n_sites + 1 + len(self.flat)
 
     def fast_state(self):
         """Device-side epoch bookkeeping of the native fast path: loss ring, best-loss ping-pong, best snapshot."""

@@ -323,7 +323,11 @@ class BaseSolver(ABC):
         key = (id(self.diff_eqs), tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions),
                getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind)
         if key == self._fused_key:
-            return self._fused_sys
+            sysm = self._fused_sys
+            # scalar tensors captured by the equations are constants of the generated kernel: re-trace when one of them
+            # was modified in place since (callbacks annealing a coefficient between epochs)
+            if sysm is None or all(t._version == v for t, v in sysm.program.g.captured):
+                return sysm
         self._fused_key, self._fused_sys = key, None
         if reason is None:
             try:
@@ -337,10 +341,18 @@ class BaseSolver(ABC):
                     self.optimizer.bind(self._fused_sys.flat)
             except TraceUnsupported as e:
                 reason = str(e)
+            except _lib.NdqError:
+                raise
+            except Exception as e:       # user code that does something a traced column cannot (tensor methods, ...)
+                if self.fused == "require":
+                    raise
+                reason = f"tracing the equations failed with {type(e).__name__}: {e}"
         if self._fused_sys is None:
             if self.fused == "require":
                 raise _lib.NdqError(f"fused='require' but the system is outside the fused path: {reason}")
-            warnings.warn(f"neurodiffeq_amd: using the composite autograd path ({reason})", RuntimeWarning)
+            warnings.warn(f"neurodiffeq_amd: this solver is NOT on the fused MI355X path ({reason}); it runs the "
+                          "reference's closure on torch autograd instead -- same results, typically 10-100x slower per "
+                          "step.  Pass fused='require' to make this an error.", RuntimeWarning)
         return self._fused_sys
 
     @property

@@ -44,6 +44,7 @@ class Graph:
         self.net_nout = {}       # site -> number of output units
         self.vcoords = {}        # virtual coordinate index (>= n_coords) -> its constant value
         self.site_net = []       # site -> network index (filled by register_nets / net_symbol)
+        self.captured = []       # (1-element tensor baked in as a constant, its version counter at trace time)
 
     # -------------------------------------------------------------- networks
     def register_nets(self, nets, n_outs):
@@ -364,6 +365,13 @@ class trace_scope:
 def _row_values(v):
     """A constant row vector (tensor / ndarray / list with more than one element) as a list of floats, else None."""
     if isinstance(v, torch.Tensor) and v.numel() > 1:
+        if v.requires_grad:
+            raise TraceUnsupported("a trainable tensor inside the equations (the traced kernel would read it once and "
+                                   "give it no gradient)")
+        if not (v.dim() == 1 or (v.dim() == 2 and v.shape[0] == 1)):
+            # (N, 1) per-point data columns, matrices ...: a column is NOT a constant row
+            raise TraceUnsupported(f"a concrete tensor of shape {tuple(v.shape)} inside the equations (only scalars and "
+                                   "constant rows (k,) / (1, k) can be baked into the traced kernel)")
         return [float(x) for x in v.detach().reshape(-1).tolist()]
     try:
         import numpy as np
@@ -384,6 +392,11 @@ def _as_node(g, v):
     if isinstance(v, numbers.Number):
         return g.const(float(v))
     if isinstance(v, torch.Tensor) and v.numel() == 1:
+        if v.requires_grad:
+            raise TraceUnsupported("a trainable scalar (nn.Parameter / requires_grad tensor) inside the equations: the "
+                                   "traced kernel would bake its value in and give it no gradient")
+        # baked in at trace time like a Python float; the solver re-traces when the tensor is modified in place
+        g.captured.append((v, v._version))
         return g.const(float(v.item()))
     try:
         import numpy as np

@@ -264,6 +264,33 @@ def closure(nets, enforcers, pde, coords, backward=True, loss="l2"):
     return dict(funcs=torch.cat(funcs, dim=1).detach(), residuals=res.detach(), loss=loss.detach())
 
 
+def closure_chunked(nets, enforcers, pde, coords, chunk=65536, backward=True, keep=False):
+    """``closure`` for batches too large to differentiate in one piece on the CPU (C5 at 1 048 576 points is ~43 GB
+    of autograd graph).  The default loss (solvers.py:218) is a mean over points and the
+    gradient a sum over points, so the batch is walked in chunks of ``chunk`` points, each contributing
+    ``sum(r^2) / (N * n_eq)`` -- mathematically the closure above, evaluated piecewise; summation in fp64.
+    Returns dict(loss, and -- with ``keep`` -- funcs / residuals of the whole batch)."""
+    n = coords[0].numel()
+    total, funcs, resid = 0.0, [], []
+    n_eq = None
+    for lo in range(0, n, chunk):
+        batch = [c.detach().reshape(-1)[lo:lo + chunk].reshape(-1, 1).requires_grad_(True) for c in coords]
+        f = [e(net, *batch) for net, e in zip(nets, enforcers)]
+        res = torch.cat(pde(*f, *batch), dim=1)
+        n_eq = res.shape[1]
+        part = (res ** 2).sum() / (n * n_eq)
+        if backward:
+            part.backward()
+        total += float(part.detach())
+        if keep:
+            funcs.append(torch.cat(f, dim=1).detach())
+            resid.append(res.detach())
+    out = dict(loss=torch.tensor(total, dtype=torch.float64))
+    if keep:
+        out.update(funcs=torch.cat(funcs), residuals=torch.cat(resid))
+    return out
+
+
 class TrainLoop:
     """The compute core of ``_run_epoch('train')`` (solvers.py:343-424) with the default optimiser
     ``Adam(lr=1e-3)`` (solvers.py:182): zero_grad once, accumulate over ``n_batches`` draws, one step."""

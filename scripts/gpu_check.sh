@@ -10,15 +10,15 @@ cd "$(dirname "$0")/.."
 REPO=$(pwd)
 echo "== rocminfo ==" > "$OUT/env.log"; (rocminfo | grep -E "Marketing|gfx|Compute Unit" | head -8; nproc; lscpu | grep "Model name") >> "$OUT/env.log" 2>&1
 echo "== pytest -m gpu ==" 
-timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"
+timeout 1800 python -m pytest tests -m gpu -x -q --durations=8 -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"
 tail -n 15 "$OUT/pytest_gpu.log"
 echo "== smoke =="
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?" | tee -a "$OUT/smoke.log"; tail -n 3 "$OUT/smoke.log"
 echo "== bench =="
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"; cat "$OUT/bench.json"; tail -n 5 "$OUT/bench.err"
 echo "== rocprofv3 kernel trace =="
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/$OUT/prof" -o trace -- python "$REPO/bench.py" --steps 3000 --warmup 300 --no-cpu-baseline > "$REPO/$OUT/prof_bench.json" 2> "$REPO/$OUT/prof.err"); echo "rocprof rc=$?"
-find "$OUT/prof" -name "*stats*" | head; f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 "$f"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/$OUT/prof" -o trace -- python "$REPO/bench.py" --steps 2000 --warmup 200 --no-cpu-baseline > "$REPO/$OUT/prof_bench.json" 2> "$REPO/$OUT/prof.err"); echo "rocprof rc=$?"
+find "$OUT/prof" -name "*stats*" | head; f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 25 "$f"
 # keep the merge-back small: drop the raw per-dispatch trace if it is large
 find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
 du -sh "$OUT"

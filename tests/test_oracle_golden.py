@@ -57,7 +57,7 @@ def test_closure_matches_reference(golden_dir, name, prec):
     assert rel_l2(R.get_flat_grad(cfg["nets"]).numpy(), g[f"grad_{prec}"]) < tol
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
 def test_adam_trajectory_matches_reference(golden_dir, name):
     g = _load(golden_dir, name)
     torch.manual_seed(int(g["seed"]))

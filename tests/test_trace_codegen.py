@@ -207,6 +207,31 @@ def test_unsupported_constructs_raise_trace_unsupported():
         assert g.cval(diff(t ** 2, t, order=2).i) == 2.0
 
 
+def test_trainable_and_per_point_tensors_are_not_baked_into_the_kernel():
+    """an nn.Parameter coefficient (inverse problems) or an (N, 1) data column inside ``diff_eqs`` must send
+    the system to the composite path, not be frozen into / mis-broadcast by the generated kernel; a plain scalar
+    tensor is a constant of the trace and its in-place modification is visible through the version counter."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.engine import trace_system
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.symbolic import TraceUnsupported
+    net, cond = FCNN(1, 1, hidden_units=(32, 32)), IVP(0.0, 1.0)
+    k = torch.nn.Parameter(torch.tensor(2.0))
+    with pytest.raises(TraceUnsupported, match="trainable"):
+        trace_system([net], [cond], lambda u, t: [diff(u, t) + k * u], 1)
+    data = torch.linspace(0, 1, 7).reshape(-1, 1)
+    with pytest.raises(TraceUnsupported, match="shape"):
+        trace_system([net], [cond], lambda u, t: [diff(u, t) - data], 1)
+    with pytest.raises(TraceUnsupported):
+        trace_system([net], [cond], lambda u, t: [torch.cat([u, u], dim=1)], 1)
+    c = torch.tensor(3.0)
+    prog, _ = trace_system([net], [cond], lambda u, t: [diff(u, t) + c * u], 1)
+    assert [(t is c, v) for t, v in prog.g.captured] == [(True, c._version)]
+    c.mul_(2.0)
+    assert prog.g.captured[0][1] != c._version
+
+
 def test_assembly_fixup_separates_packed_valu_from_mfma():
     """_hipcc.fix_pk_mfma: one wait state between a packed-fp32 VALU instruction and a directly following MFMA (labels
     and comments in between do not count), nothing anywhere else, idempotent."""
