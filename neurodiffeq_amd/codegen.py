@@ -335,7 +335,10 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         fused_multi_closure_kernel for 2..4 networks of one shape and stream set) specialised with this program's
         per-point function.  desc: the ndq_mlp_desc shared by all networks."""
         K = self.n_nets
-        assert can_fuse(self, {k: desc for k in range(K)})
+        mode = fuse_mode(self, {k: desc for k in range(K)})
+        assert mode is not None
+        if mode == "group":
+            return self._group_source(desc)
         ns = self.streams[0].n_streams
         nsym = max(len(self.symbols), 1)
         jet = (lambda k, loc: f"jets[{loc}]") if K == 1 else (lambda k, loc: f"jets[{k}][{loc}]")
@@ -433,6 +436,101 @@ extern "C" int ndq_fused_launch(const float* coords, int ldc, int n, const float
 }}
 
 // any number of networks: params / partials are host arrays of device pointers
+extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const float* const* params,
+                                      float* const* partials, float* loss_partials, float* funcs, float* resid, int ldj,
+                                      float seed, int train, void* stream) {{
+  return launch(coords, ldc, n, params, partials, loss_partials, funcs, resid, ldj, seed, train, stream);
+}}
+"""
+
+    def _group_source(self, desc):
+        """Source of the grouped single-launch closure kernel (csrc/ndq_mlp.h: fused_group_closure_kernel): one network
+        with any number of outputs, reading any subset of the batch coordinates; the per-point function runs on one
+        point per lane, stream values and adjoint seeds are exchanged through an LDS tile."""
+        st = self.streams[0]
+        width = st.n_streams * st.n_out
+        nsym = max(len(self.symbols), 1)
+        used = {}
+        loads = []
+        for idx, i in enumerate(self.symbols):
+            k, loc = self.sym_location(i)
+            used[loc] = idx
+            loads.append(f"    s[{idx}] = srow[{loc}];")
+        stores = [f"    grow[{loc}] = {'g[%d]' % used[loc] if loc in used else '0.0f'};" for loc in range(width)]
+        deps = list(st.deps)
+        dep_fn = " : ".join(f"d == {d} ? {c}" for d, c in enumerate(deps)) + " : 0"
+        header = os.path.join(HERE, "csrc", "ndq_mlp.h")
+        neq, nf = len(self.residuals), len(self.funcs)
+        kern = lambda train: f"ndq::fused_group_closure_kernel<CFG, PW, {train}>"
+        lds = lambda train: f"ndq::group_lds_bytes<CFG>({train})"
+        return f"""// GENERATED by neurodiffeq_amd/codegen.py -- grouped single-launch closure kernel (forward streams -> LDS exchange ->
+// per-point stage, one point per lane -> reverse pass) of one PDE system, gfx950.
+#include "{header}"
+#define NDQ_PW_INLINE __device__ __forceinline__
+{self.point_fn_source()}
+namespace {{
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}>;
+static_assert(CFG::NS * CFG::NOUT == {width}, "stream layout of the traced program and of the kernel disagree");
+struct PW {{
+  static constexpr int NEQ = {neq}, NF = {nf}, NC = {self.n_coords};
+  static constexpr int dep(int d) {{ return {dep_fn}; }}     // batch coordinate fed to network input d
+  static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
+  static __device__ __forceinline__ void apply(const float (&c)[NC], const float* srow, float seed, int want_adj,
+                                               float (&r)[{max(neq, 1)}], float (&f)[{max(nf, 1)}], float* grow) {{
+    float s[{nsym}], g[{nsym}];
+{chr(10).join(loads)}
+    ndq_pw_point(c, s, seed, want_adj, r, f, g);
+    if (!want_adj) return;
+{chr(10).join(stores)}
+  }}
+}};
+constexpr int kWaves = CFG::BWD_THREADS / 64;
+int fused_blocks(int n) {{
+  const int groups = (n + 63) / 64;
+  int b = (groups + kWaves - 1) / kWaves;
+  return b > 256 ? 256 : (b < 1 ? 1 : b);
+}}
+
+int launch(const float* coords, int ldc, int n, const float* const* params, float* const* partials, float* loss_partials,
+           float* funcs, float* resid, int ldj, float seed, int train, void* stream) {{
+  if (!coords || !params || !loss_partials || n <= 0 || ldc < n || (train && !partials)) return -2;
+  ndq::FusedArgs a;
+  a.coords = coords; a.loss_partials = loss_partials;
+  a.params = params[0]; a.partials = partials ? partials[0] : nullptr;
+  a.funcs = funcs; a.resid = resid; a.n = n; a.ldc = ldc; a.ldj = ldj; a.seed = seed;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  static bool attr = false;
+  if (!attr) {{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&{kern('true')}),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int){lds('true')});
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&{kern('false')}),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int){lds('false')});
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }}
+  if (train)
+    hipLaunchKernelGGL(({kern('true')}), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS), {lds('true')}, s, a);
+  else
+    hipLaunchKernelGGL(({kern('false')}), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS), {lds('false')}, s, a);
+  return (int)hipGetLastError();
+}}
+}}  // namespace
+
+extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
+extern "C" int ndq_fused_num_params() {{ return CFG::P; }}
+extern "C" int ndq_fused_num_nets() {{ return 1; }}
+extern "C" int ndq_fused_threads() {{ return CFG::BWD_THREADS; }}
+extern "C" unsigned long ndq_fused_lds_bytes() {{ return (unsigned long){lds('true')}; }}
+
+extern "C" int ndq_fused_launch(const float* coords, int ldc, int n, const float* params, float* partials,
+                                float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,
+                                void* stream) {{
+  const float* pp[1] = {{params}};
+  float* qq[1] = {{partials}};
+  return launch(coords, ldc, n, pp, partials ? qq : nullptr, loss_partials, funcs, resid, ldj, seed, train, stream);
+}}
+
 extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const float* const* params,
                                       float* const* partials, float* loss_partials, float* funcs, float* resid, int ldj,
                                       float seed, int train, void* stream) {{
@@ -732,18 +830,35 @@ def build_fused(program: PointwiseProgram, desc, force=False, threads=None):
     return so
 
 
-def can_fuse(program: PointwiseProgram, descs=None):
-    """Single-launch closure: one network, or 2..4 networks of ONE shape and stream set (H <= 48), every network
-    reading all coordinates and producing one output."""
+def fuse_mode(program: PointwiseProgram, descs=None):
+    """Which single-launch closure kernel serves the system, if any:
+    "tile"   one single-output network reading all coordinates (fused_closure_kernel),
+    "multi"  2..4 such networks of ONE shape and stream set, H <= 48 (fused_multi_closure_kernel),
+    "group"  one network with several outputs and / or reading only some of the batch coordinates, H <= 48
+             (fused_group_closure_kernel: per-point stage on one point per lane through an LDS exchange tile);
+             NDQ_FUSE_GROUP=1 sends every eligible single-network system there.
+    None     three-kernel pipeline."""
     K = program.n_nets
     if K < 1 or K > 4 or program.n_sites != K or any(k not in program.streams for k in range(K)):
-        return False
-    if any(tuple(program.streams[k].deps) != tuple(range(program.n_coords)) or program.streams[k].n_out != 1
-           for k in range(K)):
-        return False
-    if K > 1:
-        if descs is None or len({descs[k].key() for k in range(K)}) != 1 or descs[0].hidden > 48:
-            return False
-        if os.environ.get("NDQ_NO_MULTI_FUSE"):
-            return False
-    return True
+        return None
+    plain = all(tuple(program.streams[k].deps) == tuple(range(program.n_coords)) and program.streams[k].n_out == 1
+                for k in range(K))
+    if K == 1:
+        st = program.streams[0]
+        d0 = descs[0] if descs is not None and 0 in descs else None
+        group_ok = (d0 is not None and d0.hidden <= 48 and d0.skip == 0 and all(c < program.n_coords for c in st.deps)
+                    and not os.environ.get("NDQ_NO_GROUP_FUSE"))
+        if plain and not (group_ok and os.environ.get("NDQ_FUSE_GROUP") == "1"):
+            return "tile"
+        return "group" if group_ok else None
+    if not plain:
+        return None
+    if descs is None or len({descs[k].key() for k in range(K)}) != 1 or descs[0].hidden > 48:
+        return None
+    if os.environ.get("NDQ_NO_MULTI_FUSE"):
+        return None
+    return "multi"
+
+
+def can_fuse(program: PointwiseProgram, descs=None):
+    return fuse_mode(program, descs) is not None

@@ -1561,7 +1561,178 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
   }
 }
 
+// ------------------------------------------------------------------------------------------------ grouped closure
+// Single-launch closure for systems whose pointwise stage is too heavy to run 4x redundantly on the (p, q) lanes of a
+// 16-point tile, or whose network has several outputs / reads only some of the batch coordinates (C4: FCNN(1 -> 25)
+// coefficient network of a spherical-harmonics expansion, pde_spherical.py:253-254, conditions.py:1063-1096 -- 75
+// stream values per point feed ~1 500 per-point operations).  A wave works on GROUPS of 64 points = 4 tiles:
+//   phase 1  per tile: forward streams -> the tile's outputs go to this wave's LDS exchange tile X[64 points][XS]
+//   phase 2  ONE point per lane: PW::apply reads its row of X (all streams of all outputs), leaves the adjoint seeds
+//            in the same row                                    -- no redundancy, all 64 lanes carry distinct points
+//   phase 3  per tile: forward again, this time keeping the layer states, seeds from X, reverse pass
+// The second forward pass costs one extra forward (+1/3 of the per-point GEMMs); keeping 4 tiles of layer states in
+// registers instead would not leave room for the per-point program.  Nothing crosses HBM except coordinates in and
+// the workgroup's gradient partials out.  Row stride XS is odd: the per-lane row accesses of phase 2 (address =
+// lane * XS + j) hit 64 distinct banks.
+//   PW::NC          number of batch coordinates (rows of a.coords)
+//   PW::dep(d)      batch coordinate fed to network input d
+//   PW::apply(c, srow, seed, want_adj, r, f, grow): per-point function on the LDS row (srow == grow)
+template <class C> constexpr int group_xs() {
+  const int w = C::NS * C::NOUT;
+  return (w & 1) ? w : w + 1;
+}
+
+template <class C, class PW, bool TRAIN>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(FusedArgs a) {
+  static_assert(!C::ACC_LDS && C::SKIP == 0, "grouped closure: H <= 48, no skip connection");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  stage_weights<C, TRAIN>(lds, a.params);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
+  constexpr int WAVES = C::BWD_THREADS / 64;
+  constexpr int XS = group_xs<C>();
+  const int ngroups = (a.n + 63) >> 6;
+  float* stage = lds + C::ldsWeightsEnd(TRAIN) + wave * C::stageFloatsPerWave;
+  float* X = lds + C::ldsWeightsEnd(TRAIN) + WAVES * C::stageFloatsPerWave + wave * (64 * XS);
+  GradAcc<C> acc;
+  if constexpr (TRAIN) { acc_zero<C>(acc); acc.bias = nullptr; }
+  float lsum = 0.f;
+  for (int grp = blockIdx.x * WAVES + wave; grp < ngroups; grp += gridDim.x * WAVES) {
+    const int n = grp * 64 + lane;                       // this lane's point in phase 2
+    const bool valid = n < a.n;
+    const int nn = valid ? n : a.n - 1;
+    float c[PW::NC];
+#pragma unroll
+    for (int d = 0; d < PW::NC; ++d) c[d] = a.coords[(size_t)d * a.ldc + nn];
+    // ---- phase 1: forward streams of the 4 tiles -> X
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      float x[C::D];
+      sfor<C::D>([&](auto d_) {
+        constexpr int d = decltype(d_)::value;
+        x[d] = __shfl(c[PW::dep(d)], 16 * t + p);
+      });
+      LayerState<C> st;
+      first_layer<C, TRAIN>(lds, q, x, st);
+      f32x4 h[C::NS][C::NB];
+#pragma unroll
+      for (int l = 2; l <= C::L; ++l) {
+        act_forward<C>(st, h);
+        if constexpr (C::BF16) {
+          Planes<C> P;
+          split_all<C>(h, P);
+          hidden_layer_planes<C, TRAIN>(lds, l, lane, q, P, st);
+        } else {
+          hidden_layer<C, TRAIN>(lds, l, lane, q, h, st);
+        }
+      }
+      act_forward<C>(st, h);
+      float* row = X + (16 * t + p) * XS;
+      if constexpr (C::NOUT == 1) {
+        float out[C::NS];
+        tile_output<C, TRAIN>(lds, q, x, h, out);
+        if (q == 0) {
+#pragma unroll
+          for (int s = 0; s < C::NS; ++s) row[s] = out[s];
+        }
+      } else {
+        f32x4 o[C::NS][C::NBO];
+        output_layer_mfma<C, TRAIN>(lds, lane, q, h, o);
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+          for (int ob = 0; ob < C::NBO; ++ob)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int u = 16 * ob + 4 * q + r;
+              if (u < C::NOUT) row[s * C::NOUT + u] = o[s][ob][r];
+            }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- phase 2: the per-point program, one point per lane
+    {
+      float r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
+      float* row = X + lane * XS;
+      PW::apply(c, row, valid ? a.seed : 0.f, TRAIN ? 1 : 0, r, f, row);
+      if (valid) {
+        lsum += PW::loss(r);
+        if (a.resid) {
+#pragma unroll
+          for (int e = 0; e < PW::NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];
+        }
+        if (a.funcs) {
+#pragma unroll
+          for (int m = 0; m < PW::NF; ++m) a.funcs[(size_t)m * a.ldj + n] = f[m];
+        }
+      }
+    }
+    if constexpr (TRAIN) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- phase 3: forward with kept states + reverse pass, tile by tile (seed = 0 for padding points: their rows
+      // hold zero adjoints)
+#pragma unroll 1
+      for (int t = 0; t < 4; ++t) {
+        if ((grp * 4 + t) * 16 >= a.n) break;            // whole tile is padding (uniform over the wave)
+        float x[C::D];
+        sfor<C::D>([&](auto d_) {
+          constexpr int d = decltype(d_)::value;
+          x[d] = __shfl(c[PW::dep(d)], 16 * t + p);
+        });
+        LayerState<C> st[C::L];
+        f32x4 h[C::NS][C::NB];
+        KeptPlanes<C> kp;
+        tile_forward<C, true>(lds, lane, q, x, st, h, kp);
+        const float* row = X + (16 * t + p) * XS;
+        if constexpr (C::NOUT == 1) {
+          float gout[C::NS];
+#pragma unroll
+          for (int s = 0; s < C::NS; ++s) gout[s] = row[s];
+          tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc, kp);
+        } else {
+          f32x4 go[C::NS][C::NBO];
+#pragma unroll
+          for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+            for (int ob = 0; ob < C::NBO; ++ob)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int u = 16 * ob + 4 * q + r;
+                go[s][ob][r] = (u < C::NOUT) ? row[s * C::NOUT + u] : 0.f;
+              }
+          tile_backward_multi<C>(lds, stage, lane, p, q, x, go, st, acc, kp);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
+  lsum = point_sum(quad_sum(lsum));                      // all 64 lanes carry a point here
+  __syncthreads();
+  float* wl = lds + C::ldsWeightsEnd(TRAIN);
+  if (lane == 0) wl[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float v = 0.f;
+    for (int w = 0; w < WAVES; ++w) v += wl[w];
+    a.loss_partials[blockIdx.x] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host-side sizes
+template <class C> constexpr size_t group_lds_bytes(bool train) {
+  const int waves = C::BWD_THREADS / 64;
+  const int pp = (C::P + 3) & ~3;
+  const int work = waves * (C::stageFloatsPerWave + 64 * group_xs<C>());
+  const int red = train ? bwd_regions<C>(waves) * pp : 0;          // overlays the staging + exchange tiles at the end
+  return sizeof(float) * (C::ldsWeightsEnd(train) + (work > red ? work : red) + 16);
+}
 template <class C> constexpr size_t fwd_lds_bytes() { return sizeof(float) * C::ldsWeightsEnd(false); }
 template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock);
 template <class C> constexpr size_t fused_lds_bytes(bool train) {

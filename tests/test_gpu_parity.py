@@ -318,7 +318,7 @@ def _load_system(name, size, single_kernel=True):
 
 # "1k" = single-launch fused closure kernel (single-network systems), "3k" = forward / pointwise / backward pipeline
 @pytest.mark.parametrize("name,mode", [("c1", "3k"), ("c1", "1k"), ("c2", "1k"), ("c2", "3k"), ("c3", "1k"), ("c3", "3k"), ("c5", "3k"),
-                                       ("c4", "3k"), ("w1", "1k"), ("w1", "3k"), ("w2", "1k"), ("w2", "3k"), ("w3", "1k"),
+                                       ("c4", "3k"), ("c4", "1k"), ("w1", "1k"), ("w1", "3k"), ("w2", "1k"), ("w2", "3k"), ("w3", "1k"),
                                        ("w4", "1k"), ("w4", "3k"), ("w5", "1k"), ("w5", "3k"), ("w6", "3k"), ("w7", "3k"), ("w8", "3k")])
 def test_fused_closure_matches_reference_golden(golden_dir, name, mode):
     """funcs / residuals / loss / flat gradient of ONE closure (solvers.py:369-395) on the reference's own inputs."""
@@ -467,6 +467,44 @@ def test_l1_and_infinity_losses_match_autograd_oracle(name, kind, mode):
                 grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in fs.flat]), want_grad))
     diag(f"loss_{kind}_{name}_{mode}", errs)
     assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("name", ["shell", "poisson3d", "hessian3d", "pendulum", "shape_48x2", "shape_32x3"])
+def test_grouped_closure_kernel_on_single_output_systems(monkeypatch, name):
+    """The grouped closure kernel (csrc/ndq_mlp.h: fused_group_closure_kernel -- per-point stage on one point per lane
+    through an LDS exchange tile; built for multi-output networks such as C4's) serves single-output networks too when
+    asked to (NDQ_FUSE_GROUP=1): same results as the autograd oracle, ragged batch (3001 points: a partial group, a
+    partial tile), bit-reproducible, and accepted by its first-use self-check against the three-kernel pipeline."""
+    from tests import zoo
+    from neurodiffeq_amd import codegen
+    from neurodiffeq_amd.engine import FusedSystem
+    monkeypatch.setenv("NDQ_FUSE_GROUP", "1")
+    torch.manual_seed(11)
+    system = zoo.build(name)
+    nets, conds, pde = system.product()
+    flat = R.get_flat(nets)
+    coords = system.sample(3001, seed=5)
+    onets, enforcers, opde = system.oracle(flat)
+    want = R.closure(onets, enforcers, opde, coords)
+    want_grad = R.get_flat_grad(onets).numpy()
+    for net in nets:
+        net.to("cuda")
+    fs = FusedSystem(nets, conds, pde, system.n_coords, "cuda")
+    assert fs.fusedk is not None and codegen.fuse_mode(fs.program, fs.descs) == "group"
+    b, n = fs.step([c.float() for c in coords], train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    assert fs.fusedk is not None and fs.fused_check["reproducible"], getattr(fs, "fused_check", None)
+    errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), want["funcs"].numpy()),
+                residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy(), want["residuals"].numpy()),
+                loss=abs(fs.loss_buf[0].item() - want["loss"].item()) / abs(want["loss"].item()),
+                grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in fs.flat]), want_grad))
+    diag(f"group_{name}", dict(errs, check=fs.fused_check))
+    assert max(errs.values()) < TOL, errs
+    # evaluation-only launch (validation epochs, Solution objects): no adjoint, same values
+    b2, n2 = fs.step([c.float() for c in coords], train=False, slot=1, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    assert abs(fs.loss_buf[1].item() - fs.loss_buf[0].item()) <= 1e-6 * abs(fs.loss_buf[0].item())
+    assert rel_l2(b2["resid"][:, :n].T.cpu().numpy(), want["residuals"].numpy()) < TOL
 
 
 def test_sobolev_loss_fused_for_first_order_systems_composite_otherwise():
