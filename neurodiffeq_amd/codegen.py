@@ -425,6 +425,15 @@ extern "C" int ndq_fused_num_nets() {{ return {K}; }}
 extern "C" int ndq_fused_threads() {{ return CFG::BWD_THREADS; }}
 extern "C" unsigned long ndq_fused_lds_bytes() {{ return (unsigned long){lds('true')}; }}
 
+#ifdef NDQ_PHASE_TS
+extern "C" int ndq_fused_phase_ts(unsigned long long* out) {{    // experiments: scripts/phase_ts.py
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ndq::ndq_phase_ts), sizeof(unsigned long long) * 256 * 8);
+}}
+extern "C" int ndq_fused_tile_ts(unsigned long long* out) {{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ndq::ndq_tile_ts), sizeof(unsigned long long) * 48);
+}}
+#endif
+
 // one network: the ndq_fused_launch_fn of include/ndq.h
 extern "C" int ndq_fused_launch(const float* coords, int ldc, int n, const float* params, float* partials,
                                 float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,
@@ -449,14 +458,16 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
         point per lane, stream values and adjoint seeds are exchanged through an LDS tile."""
         st = self.streams[0]
         width = st.n_streams * st.n_out
+        gw = 1 if st.n_out == 1 else (st.n_out + 15) // 16 * 16      # row layout [n_streams][gw] (ndq::group_w)
+        row = lambda loc: (loc // st.n_out) * gw + loc % st.n_out
         nsym = max(len(self.symbols), 1)
         used = {}
         loads = []
         for idx, i in enumerate(self.symbols):
             k, loc = self.sym_location(i)
             used[loc] = idx
-            loads.append(f"    s[{idx}] = srow[{loc}];")
-        stores = [f"    grow[{loc}] = {'g[%d]' % used[loc] if loc in used else '0.0f'};" for loc in range(width)]
+            loads.append(f"    s[{idx}] = srow[{row(loc)}];")
+        stores = [f"    grow[{row(loc)}] = {'g[%d]' % used[loc] if loc in used else '0.0f'};" for loc in range(width)]
         deps = list(st.deps)
         dep_fn = " : ".join(f"d == {d} ? {c}" for d, c in enumerate(deps)) + " : 0"
         header = os.path.join(HERE, "csrc", "ndq_mlp.h")

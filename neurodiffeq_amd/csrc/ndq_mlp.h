@@ -36,6 +36,31 @@ namespace ndq {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ------------------------------------------------------------------------------------------------ phase timestamps
+// Experiments only (-DNDQ_PHASE_TS via NDQ_JIT_FLAGS; scripts/phase_ts.py): thread 0 of every workgroup records the
+// shader clock (s_memtime) and the 100 MHz wall clock (s_memrealtime) at up to 4 points of a closure kernel.
+#ifdef NDQ_PHASE_TS
+__device__ unsigned long long ndq_phase_ts[256 * 8];
+#define NDQ_TS(k)                                                            \
+  do {                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 256) {                              \
+      ndq_phase_ts[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter();     \
+      ndq_phase_ts[blockIdx.x * 8 + 4 + (k)] = wall_clock64();               \
+    }                                                                        \
+  } while (0)
+// NDQ_TT(k): shader clock of wave 0 of workgroup 0 at point k (< 24) inside a tile (the last tile's stamps survive)
+__device__ unsigned long long ndq_tile_ts[48];
+__device__ int ndq_tile_iter;      // 0 while wave 0 of workgroup 0 is in its first tile, 1 afterwards
+#define NDQ_TT(k)                                                                                   \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x == 0)                                                        \
+      ndq_tile_ts[24 * ndq_tile_iter + (k)] = __builtin_readcyclecounter();                         \
+  } while (0)
+#else
+#define NDQ_TS(k)
+#define NDQ_TT(k)
+#endif
+
 // ------------------------------------------------------------------------------------------------ static for
 template <class F, int... I>
 __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -154,6 +179,9 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 #ifndef NDQ_FWD_THREADS
 #define NDQ_FWD_THREADS 256
 #endif
+#ifndef NDQ_WG_SCHED_BARRIER
+#define NDQ_WG_SCHED_BARRIER 1
+#endif
 
 // tanh z = 1 - 2 / (2^(2 z log2 e) + 1): one v_exp_f32 + one v_rcp_f32 (both ~1 ulp).  Absolute error <= ~1.5e-7
 // over the whole range (saturates correctly: e -> inf gives 1, e -> 0 gives -1); the libm tanhf costs ~10x the
@@ -258,6 +286,11 @@ struct Cfg {
   static constexpr bool BF16 = (NDQ_BF16X3 != 0) && (NB_ % 2 == 0);
   static constexpr int NC = NB_ / 2;                       // K-chunks of 32 contraction slots (bf16 path)
   static constexpr int WEL = BF16 ? (H * H * 3) / 2 : H * H;   // floats of LDS per weight matrix image
+  // multi-output networks: the output layer (HO x H, zero-padded rows) runs on the bf16 matrix core as well when its
+  // padded height is a multiple of 32 (its rows are the contraction axis of hbar = Wout^T gout)
+  static constexpr bool BF16O = BF16 && (NOUT_ > 1) && (NBO % 2 == 0);
+  static constexpr int NCO = NBO / 2;
+  static constexpr int WOEL = BF16O ? (HO * H * 3) / 2 : HO * H;   // floats of LDS per output-layer image
   static constexpr bool KEEP_H = (NB_ == 2) && (NDQ_KEEP_H != 0);
   // wide nets (H >= 64): the reverse pass is register-bound, so (a) the per-point GEMMs go through their bf16 planes
   // SG streams at a time instead of all at once, (b) the bias-type gradient sums (db_l, dW1, dWout: one value per
@@ -275,11 +308,14 @@ struct Cfg {
   static constexpr int ldsb(int l, bool bwd) { return ldsWf(l, bwd) + (bwd ? 2 : 1) * WEL; }
   // output layer: NOUT == 1: Wout [H] | bout [1];  NOUT > 1: fragment-ordered Wo [HO*H] (+ transposed [HO*H]) | bout [HO]
   static constexpr int ldsWout(bool bwd) { return ldsLayer0 + (L - 1) * layerStride(bwd); }
-  static constexpr int ldsWoutT() { return ldsWout(true) + HO * H; }
-  static constexpr int ldsbout(bool bwd) { return ldsWout(bwd) + (NOUT == 1 ? H : (bwd ? 2 : 1) * HO * H); }
+  static constexpr int ldsWoutT() { return ldsWout(true) + WOEL; }
+  static constexpr int ldsbout(bool bwd) { return ldsWout(bwd) + (NOUT == 1 ? H : (bwd ? 2 : 1) * WOEL); }
   static constexpr int ldsSkip(bool bwd) { return ldsbout(bwd) + (NOUT == 1 ? 1 : HO); }
   static constexpr int ldsWeightsEnd(bool bwd) { return (ldsSkip(bwd) + SKIP * NOUT * D + 3) & ~3; }
-  static constexpr int stageFloatsPerWave = 2 * 16 * HP;  // Zt and Ht tiles of one stream
+  // weight-gradient transposes: streams staged per barrier round (narrow nets: two at a time, so that the LDS round
+  // trip of one stream hides behind the MFMAs of the other; wide nets: no LDS to spare)
+  static constexpr int WG_SB = (NB_ <= 2 && SS::NS >= 2 && BWD_THREADS == 256) ? 2 : 1;
+  static constexpr int stageFloatsPerWave = WG_SB * 2 * 16 * HP;  // Zt and Ht tiles of WG_SB streams
 };
 
 struct MlpArgs {
@@ -309,6 +345,30 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
     if constexpr (C::SKIP != 0) {
       if (tid < D) lds[C::ldsSkip(BWD) + tid] = prm[C::offS + tid];
     }
+  } else if constexpr (C::BF16O) {
+    // bf16x3 planes of the zero-padded output matrix Wo [HO][H] in bf16 fragment order (same index scheme as the
+    // hidden layers below): forward image = A operand of (ob = 16-row output block, c = chunk of 32 hidden units),
+    // transposed image = A operand of (kb = 16 hidden units, c = chunk of 32 output rows)
+    const float* Wo = prm + C::offWout;
+    __bf16* wf = reinterpret_cast<__bf16*>(lds + C::ldsWout(BWD));
+    __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWoutT());
+    for (int i = tid; i < C::HO * H; i += nt) {
+      const int j = i / H, k = i - j * H;
+      const float w = j < C::NOUT ? Wo[i] : 0.f;
+      const __bf16 w0 = (__bf16)w; const float r1 = w - (float)w0;
+      const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (float)w1);
+      {
+        const int blk = (j >> 4) * C::NC + (k >> 5);
+        const int base = ((blk * 3) * 64 + (j & 15) + 16 * ((k & 15) >> 2)) * 8 + 4 * ((k & 31) >> 4) + (k & 3);
+        wf[base] = w0; wf[base + 512] = w1; wf[base + 1024] = w2;
+      }
+      if (BWD) {
+        const int blk = (k >> 4) * C::NCO + (j >> 5);
+        const int base = ((blk * 3) * 64 + (k & 15) + 16 * ((j & 15) >> 2)) * 8 + 4 * ((j & 31) >> 4) + (j & 3);
+        wt[base] = w0; wt[base + 512] = w1; wt[base + 1024] = w2;
+      }
+    }
+    for (int i = tid; i < C::HO; i += nt) lds[C::ldsbout(BWD) + i] = i < C::NOUT ? prm[C::offbout + i] : 0.f;
   } else {
     constexpr int NBO = C::NBO;
     const float* Wo = prm + C::offWout;  // [NOUT][H], rows >= NOUT are zero padding
@@ -757,6 +817,25 @@ __device__ __forceinline__ void output_layer_mfma(const float* lds, int lane, in
     for (int ob = 0; ob < C::NBO; ++ob) o[s][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ob = 0; ob < C::NBO; ++ob) o[0][ob] = lds4(lds + C::ldsbout(BWD) + 16 * ob + 4 * q);
+  if constexpr (C::BF16O) {
+    Planes<C> P;
+    split_all<C>(h, P);
+    const bf16x8* wb = reinterpret_cast<const bf16x8*>(lds + C::ldsWout(BWD));
+#pragma unroll
+    for (int c = 0; c < C::NC; ++c)
+#pragma unroll
+      for (int ob = 0; ob < C::NBO; ++ob) {
+        const bf16x8 a0 = wb[((ob * C::NC + c) * 3 + 0) * 64 + lane];
+        const bf16x8 a1 = wb[((ob * C::NC + c) * 3 + 1) * 64 + lane];
+        const bf16x8 a2 = wb[((ob * C::NC + c) * 3 + 2) * 64 + lane];
+#define NDQ_T(A, K)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
+      o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, P.pl[s][c][K], o[s][ob], 0, 0, 0);
+        NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+      }
+    return;
+  }
   const float* w = lds + C::ldsWout(BWD);
 #pragma unroll
   for (int ob = 0; ob < C::NBO; ++ob)
@@ -981,38 +1060,58 @@ template <class C, int NBA>
 __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q, const f32x4 (&zb)[C::NS][NBA],
                                             const LayerState<C>& st_in, f32x4 (&acc)[NBA][C::NB],
                                             const f32x4 (*hkept)[C::NB] = nullptr) {
-  constexpr int HP = C::HP;
-  float* Zt = stage;
-  float* Ht = stage + 16 * HP;
-  sfor<C::NS>([&](auto s_) {
-    constexpr int s = decltype(s_)::value;
-    f32x4 hs[C::NB];
-    if constexpr (C::KEEP_H) {              // stream s of the layer's input activations: kept by the forward pass ...
+  constexpr int HP = C::HP, SB = C::WG_SB;
+  constexpr int NR = (C::NS + SB - 1) / SB;           // barrier rounds
+  sfor<NR>([&](auto r_) {
+    constexpr int s0 = decltype(r_)::value * SB;
+    constexpr int sn = (C::NS - s0 < SB) ? C::NS - s0 : SB;
+    sfor<sn>([&](auto k_) {
+      constexpr int s = s0 + decltype(k_)::value;
+      float* Zt = stage + decltype(k_)::value * 2 * 16 * HP;
+      float* Ht = Zt + 16 * HP;
+      f32x4 hs[C::NB];
+      if constexpr (C::KEEP_H) {              // stream s of the layer's input activations: kept by the forward pass ...
 #pragma unroll
-      for (int b = 0; b < C::NB; ++b) hs[b] = hkept[s][b];
-    } else {
-      act_forward_stream<C, s>(st_in, hs);  // ... or recomputed from the layer state
-    }
+        for (int b = 0; b < C::NB; ++b) hs[b] = hkept[s][b];
+      } else {
+        act_forward_stream<C, s>(st_in, hs);  // ... or recomputed from the layer state
+      }
 #pragma unroll
-    for (int b = 0; b < NBA; ++b) *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
+      for (int b = 0; b < NBA; ++b) *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
 #pragma unroll
-    for (int b = 0; b < C::NB; ++b) *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = hs[b];
+      for (int b = 0; b < C::NB; ++b) *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = hs[b];
+    });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // all operands of the round are read into registers of their own BEFORE the first MFMA: one LDS round trip per
+    // round instead of one per k-step (the compiler otherwise recycles four registers and waits 16 times per stream)
+    float av[sn][4][NBA], bv[sn][4][C::NB];
+    sfor<sn>([&](auto k_) {
+      constexpr int k = decltype(k_)::value;
+      const float* Zt = stage + k * 2 * 16 * HP;
+      const float* Ht = Zt + 16 * HP;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      float av[NBA], bv[C::NB];
+      for (int st = 0; st < 4; ++st) {
 #pragma unroll
-      for (int b = 0; b < NBA; ++b) av[b] = Zt[(4 * q + st) * HP + 16 * b + p];
+        for (int b = 0; b < NBA; ++b) av[k][st][b] = Zt[(4 * q + st) * HP + 16 * b + p];
 #pragma unroll
-      for (int b = 0; b < C::NB; ++b) bv[b] = Ht[(4 * q + st) * HP + 16 * b + p];
+        for (int b = 0; b < C::NB; ++b) bv[k][st][b] = Ht[(4 * q + st) * HP + 16 * b + p];
+      }
+    });
+#if NDQ_WG_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);          // keep the reads above the MFMAs
+#endif
+    sfor<sn>([&](auto k_) {
+      constexpr int k = decltype(k_)::value;
 #pragma unroll
-      for (int jb = 0; jb < NBA; ++jb)
+      for (int st = 0; st < 4; ++st)
 #pragma unroll
-        for (int kb = 0; kb < C::NB; ++kb)
-          acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jb], bv[kb], acc[jb][kb], 0, 0, 0);
-    }
+        for (int jb = 0; jb < NBA; ++jb)
+#pragma unroll
+          for (int kb = 0; kb < C::NB; ++kb)
+            acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][st][jb], bv[k][st][kb], acc[jb][kb], 0, 0, 0);
+    });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1105,6 +1204,29 @@ __device__ __forceinline__ void tile_backward_multi(const float* lds, float* sta
   weight_grad<C, C::NBO>(stage, lane, p, q, go, st[C::L - 1], acc.wo, kp.h[C::KEEP_H ? C::L - 1 : 0]);   // dWout += sum_s Gout[s] H_L[s]^T
   f32x4 g[C::NS][C::NB];
   zero_frag<C>(g);
+  if constexpr (C::BF16O) {                                                // hbar_L = Wout^T gout on the bf16 matrix core
+    bf16x8 pl[C::NS][C::NCO][3];
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+      for (int c = 0; c < C::NCO; ++c) split3(go[s][2 * c], go[s][2 * c + 1], pl[s][c]);
+    const bf16x8* wb = reinterpret_cast<const bf16x8*>(lds + C::ldsWoutT());
+#pragma unroll
+    for (int c = 0; c < C::NCO; ++c)
+#pragma unroll
+      for (int kb = 0; kb < C::NB; ++kb) {
+        const bf16x8 a0 = wb[((kb * C::NCO + c) * 3 + 0) * 64 + lane];
+        const bf16x8 a1 = wb[((kb * C::NCO + c) * 3 + 1) * 64 + lane];
+        const bf16x8 a2 = wb[((kb * C::NCO + c) * 3 + 2) * 64 + lane];
+#define NDQ_T(A, K)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
+      g[s][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], g[s][kb], 0, 0, 0);
+        NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+      }
+    tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc, kp);
+    return;
+  }
   const float* w = lds + C::ldsWoutT();
 #pragma unroll
   for (int kb = 0; kb < C::NB; ++kb)                                       // hbar_L = Wout^T gout
@@ -1161,6 +1283,7 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
     }
   }
   acc.bout += (q == 0) ? gout[0] : 0.f;
+  NDQ_TT(4);
   if constexpr (C::SKIP != 0) {
 #pragma unroll
     for (int a = 0; a < C::D; ++a) {
@@ -1183,6 +1306,7 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
     constexpr int l = C::L - decltype(k_)::value;          // layer whose weights W_l (H x H) map h_{l-1} -> z_l
     constexpr int li = l - 1;             // state index of layer l
     act_backward<C>(st[li], g);           // g: hbar_l -> zbar_l
+    NDQ_TT(5 + 3 * (C::L - l));
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
       if constexpr (C::ACC_LDS) {
@@ -1196,7 +1320,9 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
     if constexpr (C::WIDE && li == 1) reload_first_layer_streams<C>(lds, q, st[0]);   // needed from here on again
     if constexpr (C::BF16) {
       weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);
+      NDQ_TT(6 + 3 * (C::L - l));
       gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);
+      NDQ_TT(7 + 3 * (C::L - l));
     } else {
       weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);   // inputs of layer l
       gemm_frag_inplace<C>(lds + C::ldsWt(l), lane, g);
@@ -1410,11 +1536,25 @@ template <class C, class PW, bool TRAIN>
 __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs a) {
   static_assert(C::NOUT == 1, "the single-launch closure kernel needs a single-output network");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  stage_weights<C, TRAIN>(lds, a.params);
-  __syncthreads();
+  NDQ_TS(0);
+#ifdef NDQ_PHASE_TS
+  if (threadIdx.x == 0 && blockIdx.x == 0) ndq_tile_iter = 0;
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   constexpr int WAVES = C::BWD_THREADS / 64;
   const int ntiles = (a.n + 15) >> 4;
+  // coordinates of a tile are fetched one tile ahead: the first tile's before the weights are staged (both global
+  // latencies overlap), the next tile's while the current one is computed
+  float xn[C::D];
+  {
+    const int n0 = (blockIdx.x * WAVES + wave) * 16 + p;
+    const int nn0 = n0 < a.n ? n0 : a.n - 1;
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn0];
+  }
+  stage_weights<C, TRAIN>(lds, a.params);
+  __syncthreads();
+  NDQ_TS(1);
   float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
   GradAcc<C> acc;
   if constexpr (TRAIN) acc_init<C>(acc, lds, WAVES, wave, lane);
@@ -1422,18 +1562,27 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
-    const int nn = valid ? n : a.n - 1;
     float x[C::D];
 #pragma unroll
-    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    for (int d = 0; d < C::D; ++d) x[d] = xn[d];
+    {
+      const int n1 = n + gridDim.x * WAVES * 16;
+      const int nn1 = n1 < a.n ? n1 : a.n - 1;
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn1];
+    }
     const float* ldsw = lds + opaque_zero<C>();
     LayerState<C> st[C::L];
     f32x4 h[C::NS][C::NB];
     KeptPlanes<C> kp;
+    NDQ_TT(0);
     tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp);
+    NDQ_TT(1);
     float jets[C::NS], gout[C::NS], r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
     tile_output<C, TRAIN>(ldsw, q, x, h, jets);
+    NDQ_TT(2);
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
+    NDQ_TT(3);
     if (valid && q == 0) {
       lsum += PW::loss(r);
       if (a.resid) {
@@ -1450,7 +1599,15 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
       for (int s = 0; s < C::NS; ++s) gout[s] = valid ? gout[s] : 0.f;
       tile_backward<C>(ldsw, stage, lane, p, q, x, gout, st, acc, kp);
     }
+    NDQ_TT(12);
+#ifdef NDQ_PHASE_TS
+    if (threadIdx.x == 0 && blockIdx.x == 0) ndq_tile_iter = 1;
+#endif
   }
+#ifdef NDQ_PHASE_TS
+  __syncthreads();
+  NDQ_TS(2);
+#endif
   if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
   // loss: lanes (only q == 0 lanes are non-zero) -> wave -> workgroup, fixed order
   lsum = point_sum(quad_sum(lsum));
@@ -1463,6 +1620,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     for (int w = 0; w < WAVES; ++w) v += wl[w];
     a.loss_partials[blockIdx.x] = v;
   }
+  NDQ_TS(3);
 }
 
 // ------------------------------------------------------------------------------------------------ multi-network closure
@@ -1577,10 +1735,23 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
 //   PW::NC          number of batch coordinates (rows of a.coords)
 //   PW::dep(d)      batch coordinate fed to network input d
 //   PW::apply(c, srow, seed, want_adj, r, f, grow): per-point function on the LDS row (srow == grow)
+// Rows hold [NS][GW] values, GW = 1 for single-output networks, else the output count padded to whole 16-unit blocks
+// (HO): every lane then stores / loads its 4 units of a block unconditionally (the padding entries are exact zeros:
+// zero weight rows and zero bias on the way in, never written by the per-point stage, zero weight rows on the way back).
+template <class C> constexpr int group_w() { return C::NOUT == 1 ? 1 : C::HO; }
 template <class C> constexpr int group_xs() {
-  const int w = C::NS * C::NOUT;
+  const int w = C::NS * group_w<C>();
   return (w & 1) ? w : w + 1;
 }
+
+#ifndef NDQ_GROUP_U1
+#define NDQ_GROUP_U1 1      // tiles of a group whose phase-1 / phase-3 bodies the compiler may interleave (unroll factor)
+#endif
+#ifndef NDQ_GROUP_U3
+#define NDQ_GROUP_U3 1
+#endif
+#define NDQ_PRAGMA(x) _Pragma(#x)
+#define NDQ_UNROLL(n) NDQ_PRAGMA(unroll n)
 
 template <class C, class PW, bool TRAIN>
 __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(FusedArgs a) {
@@ -1605,7 +1776,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
 #pragma unroll
     for (int d = 0; d < PW::NC; ++d) c[d] = a.coords[(size_t)d * a.ldc + nn];
     // ---- phase 1: forward streams of the 4 tiles -> X
-#pragma unroll 1
+    NDQ_UNROLL(NDQ_GROUP_U1)
     for (int t = 0; t < 4; ++t) {
       float x[C::D];
       sfor<C::D>([&](auto d_) {
@@ -1643,10 +1814,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
 #pragma unroll
           for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int u = 16 * ob + 4 * q + r;
-              if (u < C::NOUT) row[s * C::NOUT + u] = o[s][ob][r];
-            }
+            for (int r = 0; r < 4; ++r) row[s * C::HO + 16 * ob + 4 * q + r] = o[s][ob][r];
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1675,7 +1843,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       // ---- phase 3: forward with kept states + reverse pass, tile by tile (seed = 0 for padding points: their rows
       // hold zero adjoints)
-#pragma unroll 1
+      NDQ_UNROLL(NDQ_GROUP_U3)
       for (int t = 0; t < 4; ++t) {
         if ((grp * 4 + t) * 16 >= a.n) break;            // whole tile is padding (uniform over the wave)
         float x[C::D];
@@ -1700,10 +1868,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
 #pragma unroll
             for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int u = 16 * ob + 4 * q + r;
-                go[s][ob][r] = (u < C::NOUT) ? row[s * C::NOUT + u] : 0.f;
-              }
+              for (int r = 0; r < 4; ++r) go[s][ob][r] = row[s * C::HO + 16 * ob + 4 * q + r];
           tile_backward_multi<C>(lds, stage, lane, p, q, x, go, st, acc, kp);
         }
       }

@@ -19,7 +19,7 @@ for blk in md.split("  - .agpr_count:")[1:]:
     print(f"{nm[:90]:90s} vgpr={g('vgpr_count')} agpr={g('agpr_count')} sgpr={g('sgpr_count')} "
           f"spill={g('vgpr_spill_count')} scratch={g('private_segment_fixed_size')} lds={g('group_segment_fixed_size')}")
 # instruction mix per function body
-for fn in re.finditer(r"^(\w+):\s*\n(.*?)^\s*s_endpgm", text, re.S | re.M):
+for fn in re.finditer(r"^(\w+):[^\n]*\n(.*?)^\s*s_endpgm", text, re.S | re.M):
     body = fn.group(2)
     ins = [l.split()[0] for l in body.split("\n") if l.strip() and not l.strip().startswith((";", ".", "//")) and not l.strip().endswith(":")]
     c = lambda pat: sum(1 for i in ins if re.match(pat, i))

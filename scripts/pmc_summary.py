@@ -1,24 +1,38 @@
 #!/usr/bin/env python
-"""Average rocprofv3 --pmc counter values per kernel from the counter_collection csv files under a directory."""
+"""Average rocprofv3 --pmc counter values per kernel from the counter_collection csv files under a directory.
+Kernels of this package are listed by a short name that keeps the template arguments (Cfg<...>) apart."""
 import csv
 import collections
 import glob
 import os
+import re
 import sys
 
 root = sys.argv[1]
+
+
+def short(k):
+    m = re.search(r"(fused_group_closure|fused_multi_closure|fused_closure|mlp_jet_bwd|mlp_jet_fwd)_kernel<ndq::Cfg<([^>]*)>", k)
+    if m:
+        return f"{m.group(1)}<{m.group(2).replace(' ', '')}>"
+    for name in ("reduce_tail_multi", "reduce_tail", "reduce_partials", "reduce_grad_loss", "epoch_tail", "ndq_pw_kernel",
+                 "sample_kernel", "calib_read4", "calib_read16", "calib_write4"):
+        if name in k:
+            return name
+    return None
+
+
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+grid = {}
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row.get("Kernel_Name", "?")
-        short = ("fused_closure" if "fused_closure" in k else "bwd" if "jet_bwd" in k else "fwd" if "jet_fwd" in k
-                 else "reduce_tail" if "reduce_tail" in k else "pointwise" if "ndq_pw" in k
-                 else "reduce" if "reduce_partials" in k else None)
-        if short is None:
+        s = short(row.get("Kernel_Name", "?"))
+        if s is None:
             continue
-        acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
-for k, d in acc.items():
-    print(k)
+        acc[s][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        grid[s] = (row.get("Grid_Size"), row.get("Workgroup_Size"))
+for k, d in sorted(acc.items()):
+    print(k, "grid/wg =", grid.get(k))
     for name, vals in sorted(d.items()):
         vals = vals[len(vals) // 4:]          # skip warm-up dispatches
-        print(f"   {name:28s} n={len(vals):4d} mean={sum(vals) / len(vals):14.1f}")
+        print(f"   {name:28s} n={len(vals):5d} mean={sum(vals) / len(vals):16.1f}")
