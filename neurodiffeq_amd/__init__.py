@@ -8,5 +8,7 @@ Unlike the reference (``__init__.py:22``) importing this package does not change
 device; the fused path is fp32 and puts the networks on the GPU itself."""
 from .neurodiffeq import diff, safe_diff, unsafe_diff  # noqa: F401
 from . import operators, networks, conditions, generators, solvers, losses, utils, function_basis  # noqa: F401
+from . import autograd_ops  # noqa: F401  (registers torch.ops.ndq.*)
+from .autograd_ops import set_native_autograd  # noqa: F401
 
 __version__ = "0.1.0"

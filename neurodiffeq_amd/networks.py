@@ -78,7 +78,12 @@ class FCNN(nn.Module):
         self.NN = nn.Sequential(*mods)
 
     def forward(self, t):
-        return self.NN(t)
+        # CUDA fp32 inputs go through the gfx950 stream kernels (autograd_ops.MlpJet: the output comes back together
+        # with its input derivatives, so diff() / operators / loss.backward() of ANY caller run on the HIP path);
+        # everything else -- CPU, fp64, shapes the kernels do not cover -- is the reference's plain Sequential
+        from .autograd_ops import try_jet_forward
+        out = try_jet_forward(self, t)
+        return self.NN(t) if out is None else out
 
 
 class Resnet(nn.Module):
