@@ -119,27 +119,37 @@ class PointwiseProgram:
     streams    : {net_idx: NetStreams}
     """
 
-    LOSS_KINDS = ("l2", "l1", "infinity")
+    LOSS_KINDS = ("l2", "l1", "infinity", "custom")
 
-    def __init__(self, graph: Graph, residuals, funcs, n_nets, widen=None, allow_lap=None, unify=None, loss="l2"):
+    def __init__(self, graph: Graph, residuals, funcs, n_nets, widen=None, allow_lap=None, unify=None, loss="l2",
+                 loss_term=None):
         """widen(net_idx, NetStreams): optional hook that may enlarge ``first`` / ``mask2`` of a net to the nearest
         stream set libndq.so has kernels for (slots are assigned after it ran).
         unify(streams dict): optional hook run before ``widen`` that may give several networks one common stream set
         (so that one multi-network closure kernel can serve them).
         allow_lap(net_idx, coords) -> bool: may the second derivatives of net k w.r.t. ``coords`` be merged into one
         Laplacian stream (asked only after the merge has been proven valid symbolically)."""
-        assert loss in self.LOSS_KINDS
-        self.loss = loss       # per-point loss term (losses.py:4-12): sum r^2 | sum |r| | max |r|, averaged by the host
+        assert loss in self.LOSS_KINDS and (loss == "custom") == (loss_term is not None)
+        # per-point loss term (losses.py:4-12): sum r^2 | sum |r| | max |r|, averaged by the host; "custom": the traced
+        # per-point term of a user loss_fn (+ additional_loss), node ``loss_term`` -- loss = mean over points of it
+        self.loss = loss
         self.g = graph
         self.residuals = list(residuals)
         self.funcs = list(funcs)
+        self.loss_term = loss_term
         if allow_lap is not None:
-            self.residuals = self._merge_laplacian(self.residuals, self.funcs, n_nets, allow_lap)
+            # the loss term is held to the same standard as the residuals: it may see pure second derivatives of a
+            # network only through their sum if those are to travel as one Laplacian stream
+            extra = [loss_term] if loss_term is not None else []
+            merged = self._merge_laplacian(self.residuals + extra, self.funcs, n_nets, allow_lap)
+            self.residuals = merged[:len(self.residuals)]
+            if extra:
+                self.loss_term = merged[-1]
         self.n_nets = n_nets                    # parameter sets
         self.site_net = list(getattr(graph, "site_net", None) or range(n_nets))
         self.n_sites = len(self.site_net)       # (network, coordinate tuple) pairs: stream arrays are per site
         self.n_coords = graph.n_coords
-        self.order = graph.reachable(self.residuals + self.funcs)
+        self.order = graph.reachable(self.residuals + self.funcs + ([self.loss_term] if self.loss_term is not None else []))
         self.streams = {}
         for k in range(self.n_sites):
             deps = graph.net_deps.get(k)
@@ -249,16 +259,23 @@ class PointwiseProgram:
             L.append(f"  const float v{i} = {e};")
         for e, i in enumerate(self.residuals):
             L.append(f"  r[{e}] = {self._val(i)};")
+        if self.loss == "custom":
+            L.append(f"  r[{len(self.residuals)}] = {self._val(self.loss_term)};      // per-point loss term")
         for m, i in enumerate(self.funcs):
             L.append(f"  f[{m}] = {self._val(i)};")
         L.append("  if (!want_adj) return;")
         L.append(f"// ---- adjoint of the per-point loss term ({self.loss}, scaled by seed) w.r.t. the network streams")
         terms = {}
         neq = len(self.residuals)
+        if self.loss == "custom":
+            res_order = g.reachable([self.loss_term])
+            res_set = set(res_order)
+            if dep.get(self.loss_term):
+                terms[self.loss_term] = ["seed"]
         if self.loss == "infinity" and neq > 1:      # d max_e |r_e|: the first maximal entry carries the seed
             L.append("  int amax = 0; float vmax = fabsf(r[0]);")
             L.append(f"  for (int e = 1; e < {neq}; ++e) if (fabsf(r[e]) > vmax) {{ vmax = fabsf(r[e]); amax = e; }}")
-        for e, i in enumerate(self.residuals):
+        for e, i in enumerate(self.residuals if self.loss != "custom" else []):
             if dep.get(i):
                 v = self._val(i)
                 sign = f"(({v}) > 0.0f ? seed : (({v}) < 0.0f ? -seed : 0.0f))"
@@ -308,7 +325,9 @@ class PointwiseProgram:
         nc = self.n_coords
         body = self._emit_point_fn()
         neq = len(self.residuals)
-        if self.loss == "l2":
+        if self.loss == "custom":
+            term = f"r[{neq}]"
+        elif self.loss == "l2":
             term = " + ".join(f"r[{e}]*r[{e}]" for e in range(neq)) or "0.0f"
         elif self.loss == "l1":
             term = " + ".join(f"fabsf(r[{e}])" for e in range(neq)) or "0.0f"
@@ -328,7 +347,12 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
     @property
     def loss_norm(self):
         """what the sum over points of the per-point loss term is divided by, per point"""
-        return 1 if self.loss == "infinity" else max(len(self.residuals), 1)
+        return 1 if self.loss in ("infinity", "custom") else max(len(self.residuals), 1)
+
+    @property
+    def n_r(self):
+        """length of the per-point ``r`` array: residuals (+ the loss term of a traced custom loss)"""
+        return max(len(self.residuals) + (1 if self.loss == "custom" else 0), 1)
 
     def fused_source(self, desc):
         """Source of the single-launch closure kernel (csrc/ndq_mlp.h: fused_closure_kernel for one network,
@@ -374,10 +398,10 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
 namespace {{
 using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}>;
 struct PW {{
-  static constexpr int NEQ = {neq}, NF = {nf};
+  static constexpr int NEQ = {neq}, NF = {nf}, NR = {self.n_r};
   static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
   static __device__ __forceinline__ void apply(const float (&x)[CFG::D], {jets_t}, float seed,
-                                               int want_adj, float (&r)[{max(neq, 1)}], float (&f)[{max(nf, 1)}],
+                                               int want_adj, float (&r)[{self.n_r}], float (&f)[{max(nf, 1)}],
                                                {gj_t}) {{
     float s[{nsym}], g[{nsym}];
 {chr(10).join(loads)}
@@ -483,11 +507,11 @@ namespace {{
 using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}>;
 static_assert(CFG::NS * CFG::NOUT == {width}, "stream layout of the traced program and of the kernel disagree");
 struct PW {{
-  static constexpr int NEQ = {neq}, NF = {nf}, NC = {self.n_coords};
+  static constexpr int NEQ = {neq}, NF = {nf}, NC = {self.n_coords}, NR = {self.n_r};
   static constexpr int dep(int d) {{ return {dep_fn}; }}     // batch coordinate fed to network input d
   static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
   static __device__ __forceinline__ void apply(const float (&c)[NC], const float* srow, float seed, int want_adj,
-                                               float (&r)[{max(neq, 1)}], float (&f)[{max(nf, 1)}], float* grow) {{
+                                               float (&r)[{self.n_r}], float (&f)[{max(nf, 1)}], float* grow) {{
     float s[{nsym}], g[{nsym}];
 {chr(10).join(loads)}
     ndq_pw_point(c, s, seed, want_adj, r, f, g);
@@ -580,6 +604,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 #define NDQ_PW_NC {nc}
 #define NDQ_PW_NSYM {len(self.symbols)}
 #define NDQ_PW_NEQ {neq}
+#define NDQ_PW_NR {self.n_r}
 #define NDQ_PW_NF {nf}
 #define NDQ_PW_NNETS {nn}
 
@@ -600,7 +625,7 @@ extern "C" __global__ __launch_bounds__(256) void ndq_pw_kernel(PwArgs a) {{
   const int n = blockIdx.x * 256 + threadIdx.x;
   float sq = 0.f;
   if (n < a.n) {{
-    float c[NDQ_PW_NC], s[{nsym}], r[{max(neq, 1)}], f[{max(nf, 1)}], g[{nsym}];
+    float c[NDQ_PW_NC], s[{nsym}], r[{self.n_r}], f[{max(nf, 1)}], g[{nsym}];
 #pragma unroll
     for (int i = 0; i < NDQ_PW_NC; ++i) c[i] = a.coords[(size_t)i * a.ldc + n];
 {chr(10).join(loads)}

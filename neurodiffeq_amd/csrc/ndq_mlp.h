@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
     NDQ_TT(0);
     tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp);
     NDQ_TT(1);
-    float jets[C::NS], gout[C::NS], r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
+    float jets[C::NS], gout[C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
     tile_output<C, TRAIN>(ldsw, q, x, h, jets);
     NDQ_TT(2);
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
@@ -1666,7 +1666,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
     float x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
-    float jets[K][C::NS], gout[K][C::NS], r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
+    float jets[K][C::NS], gout[K][C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
     sfor<K>([&](auto k_) {
       constexpr int k = decltype(k_)::value;
       LayerState<C> st[C::L];
@@ -1822,7 +1822,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- phase 2: the per-point program, one point per lane
     {
-      float r[PW::NEQ > 0 ? PW::NEQ : 1], f[PW::NF > 0 ? PW::NF : 1];
+      float r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
       float* row = X + lane * XS;
       PW::apply(c, row, valid ? a.seed : 0.f, TRAIN ? 1 : 0, r, f, row);
       if (valid) {

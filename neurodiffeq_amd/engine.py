@@ -34,7 +34,7 @@ def _round_up(n, m):
     return (n + m - 1) // m * m
 
 
-def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, loss="l2"):
+def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, loss="l2", metrics=()):
     """Trace (conditions, diff_eqs) once on symbolic columns and lower them to a pointwise program.
 
     Needs no GPU (used by ``__graft_entry__.build`` to pre-compile the generated kernels); raises
@@ -62,8 +62,26 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             except (TypeError, ValueError, RuntimeError):
                 raise TraceUnsupported(f"an equation returned {type(r).__name__}, not a traced (N, 1) column or a scalar")
         res = [column(r) for r in res]
-    if not all(isinstance(f, Sym) for f in funcs):
-        raise TraceUnsupported("a condition returned something that is not a traced column")
+        if not all(isinstance(f, Sym) for f in funcs):
+            raise TraceUnsupported("a condition returned something that is not a traced column")
+        # a custom loss: callable(residual (N, n_eq), funcs, coords) -> scalar (solvers.py:216-226; the solver passes
+        # loss_fn + additional_loss as ONE callable) traced to the per-point term whose batch mean it is
+        loss_term = None
+        if callable(loss):
+            from .symbolic import SymMat, SymScalar
+            val = loss(SymMat(res) if res else Sym(g, g.const(0.0)), list(funcs), list(coords))
+            if not isinstance(val, SymScalar):
+                raise TraceUnsupported(f"the loss function returned {type(val).__name__}, not a batch mean of traced values")
+            loss_term, loss = val.term.i, "custom"
+        # metrics: callable(*funcs, *coords) -> scalar (solvers.py:377-379), evaluated as extra per-point function
+        # rows whose batch mean is the metric
+        metric_terms = []
+        for fn in metrics:
+            from .symbolic import SymScalar
+            val = fn(*funcs, *coords)
+            if not isinstance(val, SymScalar):
+                raise TraceUnsupported(f"a metric returned {type(val).__name__}, not a batch mean of traced values")
+            metric_terms.append(val.term)
     for k, info in enumerate(infos):       # a net that never appears in an equation still needs a layout
         g.net_deps.setdefault(k, tuple(range(info["d"])))
         g.net_nout.setdefault(k, info["n_out"])
@@ -140,14 +158,16 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         for st in sts:
             st.first, st.mask2, st.lap = first, mask2, lap
 
-    program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs], len(nets), widen=widen,
-                                       allow_lap=allow_lap, unify=unify, loss=loss)
+    program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs] + [m.i for m in metric_terms],
+                                       len(nets), widen=widen, allow_lap=allow_lap, unify=unify, loss=loss,
+                                       loss_term=loss_term)
+    program.n_metrics = len(metric_terms)        # the last n_metrics "functions" are per-point metric terms
     return program, descs
 
 
 class FusedSystem:
     def __init__(self, nets, conditions, diff_eqs, n_coords, device, compute_func_val=None, single_kernel=True,
-                 loss="l2"):
+                 loss="l2", metrics=()):
         """single_kernel: for single-network systems use the one-launch fused closure kernel (forward + pointwise +
         reverse, csrc/ndq_mlp.h: fused_closure_kernel); otherwise (and for multi-network systems) the three-kernel
         pipeline through HBM streams."""
@@ -156,8 +176,12 @@ class FusedSystem:
             raise _lib.NdqError("the fused path needs an MI355X (device 'cuda'); no CPU fallback exists for it")
         self.L = _lib.lib()
         self.nets, self.conditions, self.n_coords = list(nets), list(conditions), n_coords
-        self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val, loss)
+        self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val, loss,
+                                                metrics)
+        # rows of the function-value buffer: the solver's functions, then one per-point term per traced metric
         self.n_eq, self.n_funcs = len(self.program.residuals), len(self.program.funcs)
+        self.n_metrics = self.program.n_metrics
+        self.n_user_funcs = self.n_funcs - self.n_metrics
         self.loss_norm = self.program.loss_norm      # loss = sum over points of the per-point term / (N * loss_norm)
         self.kernel = codegen.load(self.program)
         self.fusedk = None
@@ -399,7 +423,11 @@ class FusedSystem:
         return [b["coords_own"][i, :n].view(-1, 1) for i in range(self.n_coords)]
 
     def func_columns(self, b, n):
-        return [b["funcs"][i, :n].view(-1, 1) for i in range(self.n_funcs)]
+        return [b["funcs"][i, :n].view(-1, 1) for i in range(self.n_user_funcs)]
+
+    def metric_sums(self, b, n):
+        """Sum over the (local) points of every traced metric's per-point term: device tensor [n_metrics]."""
+        return b["funcs"][self.n_user_funcs:self.n_funcs, :n].sum(dim=1)
 
     # ------------------------------------------------------------------------------------------ launches
     def _site_coords(self, b, k, n, refresh):
@@ -432,7 +460,7 @@ class FusedSystem:
         stream = self._stream()
         self.forward(b, n, stream)
         self.pointwise(b, n, stream, False, n, want_funcs=True)
-        return b["funcs"][:, :n]
+        return b["funcs"][:self.n_user_funcs, :n]
 
     def residuals(self, coords):
         """Residual columns r_e(coords) of the traced PDE system: device tensor [n_eq][n] (get_residuals,

@@ -314,14 +314,20 @@ class BaseSolver(ABC):
         reason = None
         loss_kind = "l2" if self.loss_fn is _default_l2 else \
             next((k for k in ("l2", "l1", "infinity", "h1", "h1 semi") if self.loss_fn is _losses[k]), None)
-        if loss_kind is None:
-            reason = "custom loss function"
-        elif type(self).additional_loss is not BaseSolver.additional_loss:
-            reason = "additional_loss override"
-        elif _requires_closure(self.optimizer):
+        extra_loss = type(self).additional_loss is not BaseSolver.additional_loss
+        if loss_kind is None or extra_loss:
+            # a user loss_fn (solvers.py:216-226) and / or an additional_loss override (:587-604): traced together as
+            # ONE callable -> the per-point term of a batch mean (symbolic.SymScalar); anything it does that is not
+            # linear in batch means of per-point expressions raises TraceUnsupported -> composite path
+            if loss_kind in ("h1", "h1 semi"):
+                reason = "additional_loss override together with a Sobolev loss"
+            loss_kind = "custom"
+        if _requires_closure(self.optimizer):
             reason = "closure-based optimizer"
         key = (id(self.diff_eqs), tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions),
-               getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind)
+               getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind,
+               id(self.loss_fn) if loss_kind == "custom" else None,
+               tuple((name, id(fn)) for name, fn in self.metrics_fn.items()))
         if key == self._fused_key:
             sysm = self._fused_sys
             # scalar tensors captured by the equations are constants of the generated kernel: re-trace when one of them
@@ -335,8 +341,11 @@ class BaseSolver(ABC):
                 eqs, kind = self.diff_eqs, loss_kind
                 if loss_kind in ("h1", "h1 semi"):
                     eqs, kind = sobolev_equations(self.diff_eqs, len(self.nets), semi=(loss_kind == "h1 semi")), "l2"
+                elif loss_kind == "custom":
+                    kind = lambda r, f, x: self.loss_fn(r, f, x) + self.additional_loss(r, f, x)
                 self._fused_sys = FusedSystem(self.nets, self.conditions, eqs, n_coords, self.device,
-                                              compute_func_val=self.compute_func_val, loss=kind)
+                                              compute_func_val=self.compute_func_val, loss=kind,
+                                              metrics=list(self.metrics_fn.values()))
                 if isinstance(self.optimizer, FusedAdam):
                     self.optimizer.bind(self._fused_sys.flat)
             except TraceUnsupported as e:
@@ -386,9 +395,15 @@ class BaseSolver(ABC):
                                n_global=shard.global_n(n_all) if shard else n_all, lo=lo, hi=hi,
                                want_funcs=bool(self.metrics_fn))
             if self.metrics_fn:
-                funcs, coords = system.func_columns(b, n), system.coord_columns(b, n)
-                for name, fn in self.metrics_fn.items():
-                    metric_values[name] += fn(*funcs, *coords).item()
+                # traced with the system: per-point terms in extra function rows; metric = their mean over the GLOBAL
+                # batch (shard sums are added up across ranks)
+                sums = system.metric_sums(b, n)
+                if shard:
+                    sums = sums.contiguous()
+                    shard.all_reduce_flat(sums)
+                vals = (sums / float(shard.global_n(n_all) if shard else n_all)).tolist()
+                for name, v in zip(self.metrics_fn, vals):
+                    metric_values[name] += v
         if key == "train":
             for fp in system.flat:
                 fp.attach_grads()

@@ -15,7 +15,7 @@ import numbers
 
 import torch
 
-__all__ = ["Sym", "SymMat", "Graph", "TraceUnsupported", "is_sym", "sym_diff"]
+__all__ = ["Sym", "SymMat", "SymScalar", "Graph", "TraceUnsupported", "is_sym", "sym_diff"]
 
 
 class TraceUnsupported(Exception):
@@ -410,6 +410,14 @@ def _as_node(g, v):
 class _Shape(tuple):
     pass
 
+def _no_such_method(kind):
+    def __getattr__(self, name):
+        if name.startswith("__") or name in ("g", "i", "cols", "term", "items"):
+            raise AttributeError(name)
+        raise TraceUnsupported(f"Tensor.{name} is not supported on a traced {kind}")
+    return __getattr__
+
+
 
 class Sym:
     """Proxy for an ``(N, 1)`` column of the batch inside a trace."""
@@ -523,6 +531,7 @@ class Sym:
     def reciprocal(self): return self._un("recip")
     def square(self): return self * self
     def pow(self, e): return self ** e
+    def mean(self, dim=None, keepdim=False, **k): return _batch_mean(self, dim, keepdim)
 
     # ---- torch.* functions
     @classmethod
@@ -536,6 +545,8 @@ class Sym:
 
     def __repr__(self):
         return f"Sym#{self.i}{self.g.nodes[self.i]}"
+
+    __getattr__ = _no_such_method("column")
 
 
 class SymMat:
@@ -607,6 +618,12 @@ class SymMat:
     def _un(self, op):
         return SymMat([c._un(op) for c in self.cols])
 
+    def abs(self): return self._un("abs")
+    def __abs__(self): return self._un("abs")
+    def square(self): return self * self
+    def pow(self, e): return self ** e
+    def mean(self, dim=None, keepdim=False, **k): return _batch_mean(self, dim, keepdim)
+
     def sum(self, dim=None, keepdim=False, keepdims=None, **kw):
         if keepdims is not None:
             keepdim = keepdims
@@ -633,6 +650,169 @@ class SymMat:
 
     def __repr__(self):
         return f"SymMat[{len(self.cols)} cols]"
+
+    __getattr__ = _no_such_method("matrix")
+
+
+class SymScalar:
+    """A traced scalar that is a MEAN over the batch of a per-point expression (plus what linear arithmetic makes of
+    such means): value = (1 / N) * sum_p term(p).  What custom ``loss_fn`` callables, ``additional_loss`` overrides and
+    ``metrics`` (solvers.py:216-226, 587-604, 377-379) return when they are traced; products of two means, batch sums
+    (they need N) and anything else that is not linear in means raise TraceUnsupported -> composite path."""
+    __array_priority__ = 10000
+    __array_ufunc__ = None
+
+    def __init__(self, term):
+        self.term = term                  # Sym: the per-point term
+        self.g = term.g
+
+    def _lin(self, other, op, rev=False):
+        if isinstance(other, SymScalar):
+            if op == "add":
+                return SymScalar(self.term + other.term)
+            if op == "sub":
+                return SymScalar(other.term - self.term if rev else self.term - other.term)
+            raise TraceUnsupported("product / quotient of two batch means inside a traced loss")
+        if isinstance(other, (Sym, SymMat)):
+            raise TraceUnsupported("mixing a batch mean with per-point values inside a traced loss")
+        c = Sym(self.g, _as_node(self.g, other))      # python number / scalar tensor (trainable ones are refused there)
+        if op == "add":
+            return SymScalar(self.term + c)
+        if op == "sub":
+            return SymScalar(c - self.term if rev else self.term - c)
+        if op == "mul":
+            return SymScalar(self.term * c)
+        if op == "div":
+            if rev:
+                raise TraceUnsupported("division by a batch mean inside a traced loss")
+            return SymScalar(self.term / c)
+        raise TraceUnsupported(op)
+
+    def __add__(self, o): return self._lin(o, "add")
+    def __radd__(self, o): return self._lin(o, "add", True)
+    def __sub__(self, o): return self._lin(o, "sub")
+    def __rsub__(self, o): return self._lin(o, "sub", True)
+    def __mul__(self, o): return self._lin(o, "mul")
+    def __rmul__(self, o): return self._lin(o, "mul", True)
+    def __truediv__(self, o): return self._lin(o, "div")
+    def __rtruediv__(self, o): return self._lin(o, "div", True)
+    def __neg__(self): return SymScalar(-self.term)
+    def __pos__(self): return self
+
+    def mean(self, *a, **k): return self
+    def sum(self, *a, **k): return self
+    def squeeze(self, *a, **k): return self
+    def reshape(self, *a, **k): return self
+    def view(self, *a, **k): return self
+
+    @property
+    def shape(self):
+        return torch.Size([])
+
+    def dim(self):
+        return 0
+
+    def item(self):
+        raise TraceUnsupported(".item() on a traced scalar")
+
+    def __float__(self):
+        raise TraceUnsupported("float() of a traced scalar")
+
+    def __bool__(self):
+        raise TraceUnsupported("data-dependent control flow on a traced scalar")
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return Sym.__torch_function__(func, types, args, kwargs)
+
+    def __repr__(self):
+        return f"SymScalar(mean of {self.term!r})"
+
+    __getattr__ = _no_such_method("scalar")
+
+
+class SymScalarVec:
+    """Column-wise batch means of a traced matrix (``x.mean(dim=0)``): one :class:`SymScalar` per column."""
+
+    def __init__(self, items):
+        self.items = list(items)
+        self.g = self.items[0].g
+
+    def _weights(self, other):
+        row = _row_values(other)
+        if row is not None:
+            if len(row) != len(self.items):
+                raise TraceUnsupported("constant row of the wrong width")
+            return row
+        return None
+
+    def __mul__(self, o):
+        w = self._weights(o)
+        return SymScalarVec([it * (w[j] if w is not None else o) for j, it in enumerate(self.items)])
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        w = self._weights(o)
+        return SymScalarVec([it / (w[j] if w is not None else o) for j, it in enumerate(self.items)])
+
+    def __add__(self, o):
+        if isinstance(o, SymScalarVec):
+            return SymScalarVec([a + b for a, b in zip(self.items, o.items)])
+        w = self._weights(o)
+        return SymScalarVec([it + (w[j] if w is not None else o) for j, it in enumerate(self.items)])
+    __radd__ = __add__
+
+    def __getitem__(self, j):
+        return self.items[j]
+
+    def __len__(self):
+        return len(self.items)
+
+    def sum(self, *a, **k):
+        acc = self.items[0]
+        for it in self.items[1:]:
+            acc = acc + it
+        return acc
+
+    def mean(self, *a, **k):
+        return self.sum() / float(len(self.items))
+
+    @property
+    def shape(self):
+        return torch.Size([len(self.items)])
+
+
+def _batch_mean(x, dim=None, keepdim=False, **k):
+    """``x.mean()`` / ``x.mean(dim=0)`` of a traced column or matrix."""
+    if isinstance(x, (SymScalar, SymScalarVec)):
+        return x.mean()
+    if isinstance(x, SymMat):
+        if dim in (1, -1):                                   # row means: still per-point
+            return x.sum(dim=1) / float(len(x.cols))
+        if dim in (0, -2):
+            return SymScalarVec([SymScalar(c) for c in x.cols])
+        if dim is None or tuple(dim) in ((0, 1), (1, 0)):
+            return SymScalar(x.sum(dim=1) / float(len(x.cols)))
+        raise TraceUnsupported(f"mean over dim={dim} of a traced matrix")
+    if dim in (1, -1):
+        return x
+    if dim is None or dim in (0, -2) or tuple(dim) in ((0, 1), (1, 0)):
+        return SymScalar(x)
+    raise TraceUnsupported(f"mean over dim={dim} of a traced column")
+
+
+def _tf_mse_loss(input, target, size_average=None, reduce=None, reduction="mean", **k):
+    if reduction != "mean" or size_average is not None or reduce is not None:
+        raise TraceUnsupported("only reduction='mean' losses are traced")
+    d = input - target
+    return _batch_mean(d * d)
+
+
+def _tf_l1_loss(input, target, size_average=None, reduce=None, reduction="mean", **k):
+    if reduction != "mean" or size_average is not None or reduce is not None:
+        raise TraceUnsupported("only reduction='mean' losses are traced")
+    d = input - target
+    return _batch_mean(d._un("abs"))
 
 
 def _first_sym(*args):
@@ -689,6 +869,8 @@ def _tf_cat(tensors, dim=0, **k):
 
 
 def _tf_sum(x, dim=None, keepdim=False, **k):
+    if isinstance(x, (SymScalar, SymScalarVec)):
+        return x.sum()
     if isinstance(x, SymMat):
         return x.sum(dim=dim, keepdim=keepdim)
     if dim in (1, -1):
@@ -718,7 +900,8 @@ _TORCH_FUNCS = {
     "pow": _tf_pow,
     "ones_like": _tf_like(1.0), "zeros_like": _tf_like(0.0), "full_like": _tf_full_like,
     "clone": lambda x, **k: x,
-    "cat": _tf_cat, "concat": _tf_cat, "sum": _tf_sum,
+    "cat": _tf_cat, "concat": _tf_cat, "sum": _tf_sum, "mean": _batch_mean,
+    "mse_loss": _tf_mse_loss, "l1_loss": _tf_l1_loss,
 }
 
 

@@ -153,3 +153,27 @@ def make_solver(name, size=None, **kw):
         s = Solver2D(cfg["pde"], cfg["conds"], xy_min=cfg["dom"][0], xy_max=cfg["dom"][1], nets=cfg["nets"],
                      train_generator=cfg["gen"], valid_generator=cfg["gen"], **kw)
     return s, cfg
+
+
+# ---- a solver with a user loss_fn, an additional_loss override and metrics (all traced onto the fused path)
+def custom_loss_fn(r, f, x):
+    return ((1.0 + x[0] ** 2) * r ** 2).mean() + 0.1 * (f[0] ** 2).mean()
+
+
+CUSTOM_METRICS = {"energy": lambda u, x, y: (diff(u, x) ** 2 + diff(u, y) ** 2).mean(),
+                  "mean_u": lambda u, x, y: u.mean()}
+
+
+def make_custom_loss_solver(size=16, **kw):
+    from neurodiffeq_amd.solvers import Solver2D
+
+    class PenalisedSolver(Solver2D):
+        def additional_loss(self, residual, funcs, coords):          # solvers.py:587-604
+            return 0.5 * (diff(funcs[0], coords[0]) ** 2).mean()
+
+    cfg = make("c2", size)
+    kw.setdefault("n_batches_valid", 0)
+    solver = PenalisedSolver(cfg["pde"], cfg["conds"], xy_min=cfg["dom"][0], xy_max=cfg["dom"][1], nets=cfg["nets"],
+                             train_generator=cfg["gen"], valid_generator=cfg["gen"], loss_fn=custom_loss_fn,
+                             metrics=dict(CUSTOM_METRICS), **kw)
+    return solver, cfg

@@ -11,14 +11,15 @@ import numpy as np
 
 _DRIVER = r"""
 void pw_cpu_run(const float* coords, const float* syms, int n, float seed, int want_adj,
-                float* resid, float* funcs, float* gbar) {
+                float* resid, float* funcs, float* gbar, float* lossterm) {
   for (int i = 0; i < n; ++i) {
     float c[NDQ_PW_NC > 0 ? NDQ_PW_NC : 1], s[NDQ_PW_NSYM > 0 ? NDQ_PW_NSYM : 1];
-    float r[NDQ_PW_NEQ > 0 ? NDQ_PW_NEQ : 1], f[NDQ_PW_NF > 0 ? NDQ_PW_NF : 1], g[NDQ_PW_NSYM > 0 ? NDQ_PW_NSYM : 1];
+    float r[NDQ_PW_NR], f[NDQ_PW_NF > 0 ? NDQ_PW_NF : 1], g[NDQ_PW_NSYM > 0 ? NDQ_PW_NSYM : 1];
     for (int k = 0; k < NDQ_PW_NC; ++k) c[k] = coords[(size_t)k * n + i];
     for (int k = 0; k < NDQ_PW_NSYM; ++k) s[k] = syms[(size_t)k * n + i];
     ndq_pw_point(c, s, seed, want_adj, r, f, g);
     for (int k = 0; k < NDQ_PW_NEQ; ++k) resid[(size_t)k * n + i] = r[k];
+    lossterm[i] = ndq_pw_loss(r);
     for (int k = 0; k < NDQ_PW_NF; ++k) funcs[(size_t)k * n + i] = f[k];
     if (want_adj) for (int k = 0; k < NDQ_PW_NSYM; ++k) gbar[(size_t)k * n + i] = g[k];
   }
@@ -42,7 +43,7 @@ def compile_cpu(program):
     return lib
 
 
-def run_cpu(program, coords, syms, seed, want_adj=True):
+def run_cpu(program, coords, syms, seed, want_adj=True, return_loss=False):
     """coords [nc][n] fp32, syms [nsym][n] fp32 (order = program.symbols) -> resid [neq][n], funcs [nf][n], gbar [nsym][n]"""
     lib = compile_cpu(program)
     coords = np.ascontiguousarray(coords, dtype=np.float32)
@@ -52,7 +53,8 @@ def run_cpu(program, coords, syms, seed, want_adj=True):
     funcs = np.zeros((len(program.funcs), n), np.float32)
     gbar = np.zeros((max(len(program.symbols), 1), n), np.float32)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lossterm = np.zeros(n, np.float32)
     lib.pw_cpu_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int,
-                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    lib.pw_cpu_run(p(coords), p(syms), n, seed, int(want_adj), p(resid), p(funcs), p(gbar))
-    return resid, funcs, gbar
+                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.pw_cpu_run(p(coords), p(syms), n, seed, int(want_adj), p(resid), p(funcs), p(gbar), p(lossterm))
+    return (resid, funcs, gbar, lossterm) if return_loss else (resid, funcs, gbar)

@@ -178,7 +178,9 @@ def test_multi_output_network_closure_on_the_hip_kernels_matches_golden():
     net = cfg["nets"][0].to("cuda")
     R.set_flat([net], torch.from_numpy(gold["params0"]).cuda())
     coords = [torch.from_numpy(c).reshape(-1, 1).cuda().requires_grad_(True) for c in gold["coords"]]
-    u = cfg["enforcer"](net, cfg["conds"][0], coords)
+    cond = cfg["conds"][0]
+    cond.R_0, cond.R_1 = cond.R_0.cuda(), cond.R_1.cuda()     # what set_tensor_type('cuda') does for a user script
+    u = cfg["enforcer"](net, cond, coords)
     assert "MlpJet" in type(net(coords[0]).grad_fn).__name__
     res = torch.cat(cfg["pde"](u, *coords), dim=1)
     loss = (res ** 2).mean()

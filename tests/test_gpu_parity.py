@@ -507,6 +507,61 @@ def test_grouped_closure_kernel_on_single_output_systems(monkeypatch, name):
     assert rel_l2(b2["resid"][:, :n].T.cpu().numpy(), want["residuals"].numpy()) < TOL
 
 
+def test_custom_loss_additional_loss_and_metrics_stay_on_the_fused_path():
+    """VERDICT r1 missing #3 / ADVICE: a criterion callable, an ``additional_loss`` override and ``metrics`` (one of them
+    differentiating the solution) are traced with the system -- the solver stays on the HIP path (``fused='require'``)
+    and follows the trajectory of the reference's closure on plain torch autograd (``fused='off'``, native autograd
+    seam switched off so that leg is ATen only)."""
+    from tests import configs
+    from neurodiffeq_amd import autograd_ops
+    runs = {}
+    for mode in ("require", "off"):
+        torch.manual_seed(0)
+        solver, cfg = configs.make_custom_loss_solver(16)
+        solver.fused = mode
+        autograd_ops.set_native_autograd(mode == "require")
+        try:
+            torch.manual_seed(7)
+            for _ in range(3):
+                solver.run_train_epoch()
+        finally:
+            autograd_ops.set_native_autograd(True)
+        assert solver.fused_active == (mode == "require")
+        if mode == "require":
+            assert solver._fused_sys.program.loss == "custom" and solver._fused_sys.n_metrics == 2
+        runs[mode] = (np.array(solver.metrics_history["train_loss"]), np.array(solver.metrics_history["train__energy"]),
+                      np.array(solver.metrics_history["train__mean_u"]), R.get_flat(cfg["nets"]).cpu().numpy())
+    got, want = runs["require"], runs["off"]
+    errs = dict(loss=float(np.max(np.abs(got[0] - want[0]) / np.abs(want[0]))),
+                energy=float(np.max(np.abs(got[1] - want[1]) / np.abs(want[1]))),
+                mean_u=float(np.max(np.abs(got[2] - want[2]) / np.abs(want[2]))), params=rel_l2(got[3], want[3]))
+    diag("custom_loss_solver", dict(errs, loss_hist=got[0].tolist()))
+    assert errs["loss"] < 2e-5 and errs["energy"] < 2e-5 and errs["mean_u"] < 2e-5 and errs["params"] < 1e-5, errs
+
+
+def test_loss_outside_the_traced_family_falls_back_loudly():
+    """A loss the tracer cannot express (batch sum) or user code that does something a traced column cannot: under
+    fused='auto' the solver takes the composite path with a RuntimeWarning that names the cost; 'require' raises."""
+    from tests import configs
+    from neurodiffeq_amd import _lib
+    torch.manual_seed(0)
+    solver, cfg = configs.make_solver("c2", 8, loss_fn=lambda r, f, x: (r ** 2).sum() / r.shape[0])
+    with pytest.warns(RuntimeWarning, match="NOT on the fused MI355X path"):
+        solver.run_train_epoch()
+    assert not solver.fused_active and len(solver.metrics_history["train_loss"]) == 1
+    torch.manual_seed(0)
+    data = torch.linspace(0, 1, 64, device="cuda").reshape(-1, 1)
+    solver, cfg = configs.make_solver("c2", 8)
+    solver.diff_eqs = lambda u, x, y: [configs.diff(u, x, order=2) + configs.diff(u, y, order=2) - data]   # per-point data column
+    with pytest.warns(RuntimeWarning, match="NOT on the fused MI355X path"):
+        solver.run_train_epoch()
+    assert not solver.fused_active
+    solver.fused = "require"
+    solver._fused_key = None
+    with pytest.raises(_lib.NdqError):
+        solver.run_train_epoch()
+
+
 def test_sobolev_loss_fused_for_first_order_systems_composite_otherwise():
     """loss_fn = 'h1' (losses.py:17-26): first-order systems trace (the extra d r/dx needs second-order streams at most) and
     follow the autograd path's trajectory; a second-order PDE would need third-order streams and is refused."""
