@@ -322,8 +322,8 @@ class BaseSolver(ABC):
             if loss_kind in ("h1", "h1 semi"):
                 reason = "additional_loss override together with a Sobolev loss"
             loss_kind = "custom"
-        if _requires_closure(self.optimizer):
-            reason = "closure-based optimizer"
+        if _requires_closure(self.optimizer) and self.dist is not None:
+            reason = "closure-based optimizer under data parallelism"
         key = (id(self.diff_eqs), tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions),
                getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind,
                id(self.loss_fn) if loss_kind == "custom" else None,
@@ -384,16 +384,31 @@ class BaseSolver(ABC):
         metric_values = {name: 0.0 for name in self.metrics_fn}
         if system.loss_buf.numel() < nb:
             system.loss_buf = torch.zeros(nb, dtype=torch.float32, device=self.device)
-        if key == "train":
+        closure_opt = key == "train" and _requires_closure(self.optimizer)
+        if key == "train" and not closure_opt:
             self.optimizer.zero_grad()
         shard = self.dist
         for batch_id in range(nb):
             batch = first_batch if batch_id == 0 else self._generate_batch(key)
             n_all = batch[0].shape[0]
             lo, hi = shard.bounds(n_all) if shard else (0, n_all)
-            b, n = system.step(batch, train=(key == "train"), slot=batch_id, accumulate=(batch_id > 0),
-                               n_global=shard.global_n(n_all) if shard else n_all, lo=lo, hi=hi,
-                               want_funcs=bool(self.metrics_fn))
+            if closure_opt:
+                # LBFGS-style optimisers (solvers.py:397-400): one optimizer.step(closure) per batch; every call of the
+                # closure is one fused closure evaluation that overwrites the gradients and returns the batch loss
+                last = {}
+
+                def closure():
+                    last["bn"] = system.step(batch, train=True, slot=batch_id, accumulate=False, n_global=n_all,
+                                             want_funcs=bool(self.metrics_fn))
+                    for fp in system.flat:
+                        fp.attach_grads()
+                    return system.loss_buf[batch_id].clone()
+                self._do_optimizer_step(closure=closure)
+                b, n = last["bn"]
+            else:
+                b, n = system.step(batch, train=(key == "train"), slot=batch_id, accumulate=(batch_id > 0),
+                                   n_global=shard.global_n(n_all) if shard else n_all, lo=lo, hi=hi,
+                                   want_funcs=bool(self.metrics_fn))
             if self.metrics_fn:
                 # traced with the system: per-point terms in extra function rows; metric = their mean over the GLOBAL
                 # batch (shard sums are added up across ranks)
@@ -413,7 +428,7 @@ class BaseSolver(ABC):
         self._update_history(epoch_loss, "loss", key)
         if key == "valid" or self.n_batches["valid"] == 0:
             self._update_best(key)
-        if key == "train":
+        if key == "train" and not closure_opt:
             self._do_optimizer_step()
         for name in self.metrics_fn:
             self._update_history(metric_values[name] / nb, name, key)

@@ -562,6 +562,36 @@ def test_loss_outside_the_traced_family_falls_back_loudly():
         solver.run_train_epoch()
 
 
+def test_closure_based_optimizer_runs_on_the_fused_path():
+    """LBFGS-style optimisers (solvers.py:397-400: ``optimizer.step(closure)`` once per batch) on the fused path: every
+    closure call is one fused evaluation; same loss history as the reference's closure on torch autograd."""
+    from tests import configs
+    from neurodiffeq_amd import autograd_ops
+    runs = {}
+    for mode in ("require", "off"):
+        torch.manual_seed(0)
+        cfg = configs.make("c2", 16)
+        nets = [n.to("cuda") for n in cfg["nets"]]
+        opt = torch.optim.LBFGS([p for n in nets for p in n.parameters()], lr=0.5, max_iter=4, history_size=5)
+        from neurodiffeq_amd.solvers import Solver2D
+        with pytest.warns(RuntimeWarning):          # the reference's warning about n_batches_valid = 0 with LBFGS
+            solver = Solver2D(cfg["pde"], cfg["conds"], xy_min=(0, 0), xy_max=(1, 1), nets=nets, optimizer=opt,
+                              train_generator=cfg["gen"], valid_generator=cfg["gen"], n_batches_valid=0)
+        solver.fused = mode
+        autograd_ops.set_native_autograd(mode == "require")
+        try:
+            torch.manual_seed(7)
+            for _ in range(3):
+                solver.run_train_epoch()
+        finally:
+            autograd_ops.set_native_autograd(True)
+        assert solver.fused_active == (mode == "require")
+        runs[mode] = np.array(solver.metrics_history["train_loss"])
+    err = float(np.max(np.abs(runs["require"] - runs["off"]) / np.abs(runs["off"])))
+    diag("lbfgs", dict(err=err, fused=runs["require"].tolist(), autograd=runs["off"].tolist()))
+    assert err < 1e-3 and runs["require"][-1] < runs["require"][0]
+
+
 def test_sobolev_loss_fused_for_first_order_systems_composite_otherwise():
     """loss_fn = 'h1' (losses.py:17-26): first-order systems trace (the extra d r/dx needs second-order streams at most) and
     follow the autograd path's trajectory; a second-order PDE would need third-order streams and is refused."""
