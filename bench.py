@@ -299,6 +299,69 @@ def pointwise_large():
     return out
 
 
+def scaling_run(args, world, rank, use_dist, dist):
+    """``--config cX [--scaling strong|weak]``: one BASELINE config through run_train_epoch() on resident pre-sampled
+    batches, data-parallel over the ranks.  strong: the config's batch (C3 262 144, C5 1 048 576 points ...) is cut into
+    ``world`` contiguous shards, one per rank; weak: every rank keeps the whole batch of its own draw.  One all-reduce
+    of [gradients | loss] per step either way.  Same JSON contract as the headline; no roofline / CPU legs here."""
+    from neurodiffeq_amd.generators import ResidentBatchGenerator, SamplerGenerator
+    from neurodiffeq_amd.parallel import BatchSharding
+    from tests import configs
+    name = args.config
+    torch.manual_seed(0)
+    solver, cfg = configs.make_solver(name)
+    solver.fused = "require"
+    n_all = cfg["n_points"]
+    if args.scaling == "strong":
+        base, rem = divmod(n_all, world)
+        assert rem == 0, f"{n_all} points do not split evenly over {world} ranks"
+        lo, hi = rank * base, (rank + 1) * base
+        torch.manual_seed(1)                       # every rank draws the SAME global batches and keeps its shard
+    else:
+        lo, hi = 0, n_all
+        torch.manual_seed(1 + rank)
+    solver.generator["train"] = SamplerGenerator(ResidentBatchGenerator.presample(cfg["gen"], 2, "cuda", lo=lo, hi=hi))
+    if use_dist:
+        solver.dist = BatchSharding(presharded=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+    for _ in range(args.warmup):
+        solver.run_train_epoch()
+    windows = timed_windows(solver.run_train_epoch, args.steps, barrier, reduce_max if use_dist else None)
+    dt = windows[len(windows) // 2]
+    per_rank = hi - lo
+    total = per_rank * world
+    if rank == 0:
+        step_s = dt / args.steps
+        tf = ALGO_FLOP_PER_PT[name] * total / step_s / 1e12
+        print(json.dumps({
+            "metric": f"collocation-points/sec (residual+bwd), config {name.upper()}, {args.scaling} scaling",
+            "value": total / step_s, "unit": "collocation-points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": step_s * 1e3,
+            "timing": {"windows": len(windows), "steps_per_window": args.steps, "statistic": "median window"},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name.upper()} of BASELINE.json at its stated size through run_train_epoch()",
+                       "points_per_gpu": per_rank, "global_batch": total,
+                       "parallelism": f"dp{world} (shard-by-batch, one all-reduce of [P+1] fp32 per step)",
+                       "inputs": "pre-sampled in the reference's RNG order, resident in HBM"},
+            "algorithmic_tflops": tf, "frac_of_fp32_mfma_peak_per_gpu": tf / world / FP32_MFMA_PEAK_TFLOPS,
+            "single_launch": solver._fused_sys.fusedk is not None,
+            "final_loss": solver.metrics_history["train_loss"][-1]}), flush=True)
+    if use_dist:
+        dist.barrier()
+        solver.dist.close()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +370,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config sub-records (C1, C3, C4, C5)")
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="BASELINE config to run (the driver's headline is c2; c3 / c5 are the sizes where strong scaling "
+                         "has work to share: SURVEY.md 8e)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank trains the config's full batch (global batch = N x that); strong: the "
+                         "config's batch is split over the ranks")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -329,6 +398,9 @@ def main():
     from neurodiffeq_amd.generators import Generator2D, ResidentBatchGenerator
     from neurodiffeq_amd.parallel import BatchSharding
     from tests import configs
+
+    if args.config != "c2" or args.scaling != "weak":
+        return scaling_run(args, world, rank, use_dist, dist)
 
     # identical weights on every rank (same seed); the global batch is a (256*world) x 256 noisy grid of which each
     # rank keeps its contiguous 65 536-point shard resident.

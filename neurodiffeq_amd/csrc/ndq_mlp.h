@@ -182,6 +182,15 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 #ifndef NDQ_WG_SCHED_BARRIER
 #define NDQ_WG_SCHED_BARRIER 1
 #endif
+// Ablation switches (experiments only, wrong results by design): NDQ_ABL bit 0 = no weight-gradient GEMMs, bit 1 = no
+// hbar GEMM, bit 2 = no forward hidden GEMM, bit 3 = no act_backward, bit 4 = no LDS transposes (MFMAs on stale data),
+// bit 5 = no operand splitting (planes reused).  scripts/ablate.py times the closure kernel with each of them.
+#ifndef NDQ_ABL
+#define NDQ_ABL 0
+#endif
+#ifndef NDQ_STAGGER
+#define NDQ_STAGGER 0       // s_sleep argument (x 64 cycles) by which waves WAVES/2.. start their tile loop late
+#endif
 
 // tanh z = 1 - 2 / (2^(2 z log2 e) + 1): one v_exp_f32 + one v_rcp_f32 (both ~1 ulp).  Absolute error <= ~1.5e-7
 // over the whole range (saturates correctly: e -> inf gives 1, e -> 0 gives -1); the libm tanhf costs ~10x the
@@ -587,6 +596,11 @@ template <class C> __device__ __forceinline__ void zero_frag(f32x4 (&z)[C::NS][C
 // split the 8 fp32 values a lane holds for one K-chunk (blocks 2c, 2c+1) into three bf16x8 operands
 __device__ __forceinline__ void split3(const f32x4 a, const f32x4 b, bf16x8 (&pl)[3]) {
   const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  if constexpr ((NDQ_ABL & 32) != 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pl[0][e] = (__bf16)x[e]; pl[1][e] = pl[0][e]; pl[2][e] = pl[0][e]; }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const __bf16 h0 = (__bf16)x[e];
@@ -750,7 +764,7 @@ __device__ __forceinline__ void hidden_layer_planes(const float* lds, int l, int
   zero_frag<C>(z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
-  gemm_planes<C>(lds + C::ldsWf(l, BWD), lane, P, z);
+  if constexpr ((NDQ_ABL & 4) == 0) gemm_planes<C>(lds + C::ldsWf(l, BWD), lane, P, z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
 #pragma unroll
@@ -1062,6 +1076,7 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
                                             const f32x4 (*hkept)[C::NB] = nullptr) {
   constexpr int HP = C::HP, SB = C::WG_SB;
   constexpr int NR = (C::NS + SB - 1) / SB;           // barrier rounds
+  if constexpr ((NDQ_ABL & 1) != 0) return;
   sfor<NR>([&](auto r_) {
     constexpr int s0 = decltype(r_)::value * SB;
     constexpr int sn = (C::NS - s0 < SB) ? C::NS - s0 : SB;
@@ -1076,10 +1091,12 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
       } else {
         act_forward_stream<C, s>(st_in, hs);  // ... or recomputed from the layer state
       }
+      if constexpr ((NDQ_ABL & 16) == 0) {
 #pragma unroll
-      for (int b = 0; b < NBA; ++b) *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
+        for (int b = 0; b < NBA; ++b) *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
 #pragma unroll
-      for (int b = 0; b < C::NB; ++b) *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = hs[b];
+        for (int b = 0; b < C::NB; ++b) *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = hs[b];
+      }
     });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1305,7 +1322,7 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
   sfor<C::L - 1>([&](auto k_) {
     constexpr int l = C::L - decltype(k_)::value;          // layer whose weights W_l (H x H) map h_{l-1} -> z_l
     constexpr int li = l - 1;             // state index of layer l
-    act_backward<C>(st[li], g);           // g: hbar_l -> zbar_l
+    if constexpr ((NDQ_ABL & 8) == 0) act_backward<C>(st[li], g);           // g: hbar_l -> zbar_l
     NDQ_TT(5 + 3 * (C::L - l));
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
@@ -1321,7 +1338,7 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
     if constexpr (C::BF16) {
       weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);
       NDQ_TT(6 + 3 * (C::L - l));
-      gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);
+      if constexpr ((NDQ_ABL & 2) == 0) gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);
       NDQ_TT(7 + 3 * (C::L - l));
     } else {
       weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);   // inputs of layer l
@@ -1559,6 +1576,12 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   GradAcc<C> acc;
   if constexpr (TRAIN) acc_init<C>(acc, lds, WAVES, wave, lane);
   float lsum = 0.f;
+#if NDQ_STAGGER > 0
+  // two waves per SIMD run the same phases (VALU-heavy activation math, MFMA-heavy GEMMs) in lockstep and then compete for
+  // the same pipe; delaying the second wave of every SIMD by a fraction of a tile lets one's MFMAs run under the
+  // other's VALU work
+  if (WAVES > 4 && wave >= WAVES / 2) __builtin_amdgcn_s_sleep(NDQ_STAGGER);
+#endif
   for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
