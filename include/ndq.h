@@ -38,6 +38,9 @@ typedef struct ndq_mlp_desc {
   int lap;     /* 1: "Laplacian stream" -- the diagonal pairs of mask2 are carried as ONE stream holding their sum */
   int skip;    /* 1: Resnet (networks.py:73-106): out += S x with a trainable bias-free S (n_out x d) that follows the
                   output bias in the flat parameter vector; n_out = 1 only */
+  int mask3;   /* third-order triple mask: bit k <-> k-th triple a <= b <= c in lexicographic order; those streams follow
+                  the second-order ones.  A triple needs its three pairs in mask2; lap must be 0.  (Sobolev losses of
+                  second-order PDEs, losses.py:17-26; diff(u, t, order=3), neurodiffeq.py:21-34) */
 } ndq_mlp_desc;
 
 /* One compiled kernel pair (forward streams / parameter-gradient adjoint) for ONE descriptor.  libndq.so carries a

@@ -37,13 +37,34 @@ _MAX_ORDER = 2
 _DEVICE_TYPES = ("cuda",)       # tests add "cpu" after registering oracle-backed CPU kernels for the two ops
 
 
+class JetOrderError(RuntimeError):
+    """A derivative of the network output beyond what the HIP forward launch provided was requested."""
+
+
 def set_native_autograd(enabled=True, max_order=2):
-    """Switch the HIP path of plain ``net(x)`` calls on / off; ``max_order`` in {0, 1, 2}: highest derivative of the
-    network output w.r.t. its inputs the forward launch provides (lower = fewer streams = less work per call)."""
+    """Switch the HIP path of plain ``net(x)`` calls on / off; ``max_order`` in {0, 1, 2, 3}: highest derivative of the
+    network output w.r.t. its inputs the forward launch provides (lower = fewer streams = less work per call; 3 --
+    tanh / sin / sigmoid networks -- carries every third-order partial: 10 streams for two inputs, 20 for three)."""
     global _ENABLED, _MAX_ORDER
-    if max_order not in (0, 1, 2):
-        raise ValueError("max_order must be 0, 1 or 2")
+    if max_order not in (0, 1, 2, 3):
+        raise ValueError("max_order must be 0, 1, 2 or 3")
     _ENABLED, _MAX_ORDER = bool(enabled), int(max_order)
+
+
+class native_autograd:
+    """Context manager: ``with native_autograd(False): ...`` runs plain torch forwards inside."""
+
+    def __init__(self, enabled=True, max_order=None):
+        self.want = (bool(enabled), _MAX_ORDER if max_order is None else int(max_order))
+
+    def __enter__(self):
+        global _ENABLED, _MAX_ORDER
+        self.keep = (_ENABLED, _MAX_ORDER)
+        _ENABLED, _MAX_ORDER = self.want
+
+    def __exit__(self, *exc):
+        global _ENABLED, _MAX_ORDER
+        _ENABLED, _MAX_ORDER = self.keep
 
 
 def _pairs(d):
@@ -57,6 +78,8 @@ def _streams(d, order):
         s += [(a,) for a in range(d)]
     if order >= 2:
         s += _pairs(d)
+    if order >= 3:
+        s += [(a, b, c) for a in range(d) for b in range(a, d) for c in range(b, d)]
     return s
 
 
@@ -70,7 +93,8 @@ def _stream_ptr(device):
 
 def _desc(d, order, hidden, layers, act, n_out, skip=0):
     mask2 = (1 << (d * (d + 1) // 2)) - 1 if order >= 2 else 0
-    return _lib.MlpDesc(d, 1 if order >= 1 else 0, mask2, hidden, layers, act, n_out, 0, skip)
+    mask3 = (1 << (d * (d + 1) * (d + 2) // 6)) - 1 if order >= 3 else 0
+    return _lib.MlpDesc(d, 1 if order >= 1 else 0, mask2, hidden, layers, act, n_out, 0, skip, mask3)
 
 
 # ------------------------------------------------------------------------------------------------ dispatcher ops
@@ -151,7 +175,7 @@ class MlpJet(torch.autograd.Function):
         streams = _streams(d, order)
         index = {mi: k for k, mi in enumerate(streams)}
         n, ld = ctx.n, ctx.ld
-        second = any(g is not None and len(streams[s]) == 2 for s, g in enumerate(gouts))
+        second = any(g is not None and len(streams[s]) == order and order >= 2 for s, g in enumerate(gouts))
 
         def input_grad():
             """sum_s g_s * d(stream s)/dx_a for every input a, from the node's own outputs"""
@@ -163,10 +187,10 @@ class MlpJet(torch.autograd.Function):
                         continue
                     mi = tuple(sorted(streams[s] + (a,)))
                     if mi not in index:
-                        raise RuntimeError(
+                        raise JetOrderError(
                             f"derivative of order {len(mi)} of a network output w.r.t. its inputs requested, but the HIP "
-                            f"forward provides orders <= {order} (neurodiffeq_amd.autograd_ops.set_native_autograd(False) "
-                            "restores the plain torch forward)")
+                            f"forward provides orders <= {order}: call neurodiffeq_amd.set_native_autograd(max_order=3) "
+                            "for third order, or set_native_autograd(False) for the plain torch forward")
                     t = g * outs[index[mi]]
                     if n_out > 1:
                         t = t.sum(dim=1, keepdim=True)

@@ -13,7 +13,7 @@ import ctypes
 import hashlib
 import os
 
-from .symbolic import Graph
+from .symbolic import Graph, TraceUnsupported
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 JIT_DIR = os.path.join(HERE, "_jit")
@@ -30,6 +30,10 @@ def pair_list(d):
     return [(a, b) for a in range(d) for b in range(a, d)]
 
 
+def triple_list(d):
+    return [(a, b, c) for a in range(d) for b in range(a, d) for c in range(b, d)]
+
+
 class NetStreams:
     """Which derivative streams of net ``k`` the residual needs, closed to a set the MLP kernels provide.
 
@@ -41,6 +45,7 @@ class NetStreams:
         self.n_out = n_out
         self.first = 0
         self.mask2 = 0
+        self.mask3 = 0          # third-order triples (include/ndq.h: ndq_mlp_desc.mask3)
         self.lap = 0            # 1: the diagonal pairs of mask2 travel as ONE stream holding their sum
 
     def need(self, mi):
@@ -56,10 +61,16 @@ class NetStreams:
             self.first = 1
         if len(loc) == 2:
             self.mask2 |= 1 << pair_list(self.d).index(loc)
+        if len(loc) == 3:               # a triple travels with its three pairs (the recurrence needs them)
+            self.mask3 |= 1 << triple_list(self.d).index(loc)
+            for pair in ((loc[0], loc[1]), (loc[0], loc[2]), (loc[1], loc[2])):
+                self.mask2 |= 1 << pair_list(self.d).index(pair)
+        if len(loc) > 3:
+            raise TraceUnsupported("derivatives of network outputs beyond third order are outside the fused path")
 
     @property
     def n_streams(self):
-        return 1 + self.first * self.d + (1 if self.lap else bin(self.mask2).count("1"))
+        return 1 + self.first * self.d + (1 if self.lap else bin(self.mask2).count("1")) + bin(self.mask3).count("1")
 
     def slot(self, mi):
         if mi and mi[0] == "L":
@@ -70,6 +81,10 @@ class NetStreams:
             return 0
         if len(loc) == 1:
             return 1 + loc[0]
+        if len(loc) == 3:
+            k = triple_list(self.d).index(loc)
+            assert (self.mask3 >> k) & 1 and not self.lap
+            return 1 + self.d + bin(self.mask2).count("1") + bin(self.mask3 & ((1 << k) - 1)).count("1")
         k = pair_list(self.d).index(loc)
         assert (self.mask2 >> k) & 1
         return 1 + self.d + bin(self.mask2 & ((1 << k) - 1)).count("1")
@@ -178,10 +193,15 @@ class PointwiseProgram:
         g = self.g
         order = g.reachable(list(residuals) + list(funcs))
         second = {}
+        third = set()
         for i in order:
             n = g.nodes[i]
             if n[0] == "net" and len(n[3]) == 2 and n[3][0] != "L":
                 second.setdefault(n[1], []).append(i)
+            if n[0] == "net" and len(n[3]) >= 3 and n[3][0] != "L":
+                third.add(n[1])          # third-order streams need every pair on its own: no Laplacian stream
+        for k in third:
+            second.pop(k, None)
         func_set = set(g.reachable(list(funcs)))
         out = list(residuals)
         for k, leaves in second.items():
@@ -396,7 +416,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u>;
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf}, NR = {self.n_r};
   static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
@@ -504,7 +524,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u>;
 static_assert(CFG::NS * CFG::NOUT == {width}, "stream layout of the traced program and of the kernel disagree");
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf}, NC = {self.n_coords}, NR = {self.n_r};
@@ -782,6 +802,13 @@ def mlp_ext_allowed(desc):
     diag = 0
     for a in range(desc.d):
         diag |= 1 << pair_list(desc.d).index((a, a))
+    if desc.mask3:              # third order: tanh / sin / sigmoid, every triple with its three pairs, no Laplacian stream
+        if desc.lap or desc.act not in (0, 1, 2) or desc.mask3 >> len(triple_list(desc.d)):
+            return False
+        for k, (a, b, c) in enumerate(triple_list(desc.d)):
+            if (desc.mask3 >> k) & 1 and not all((desc.mask2 >> pair_list(desc.d).index(p)) & 1
+                                                   for p in ((a, b), (a, c), (b, c))):
+                return False
     return (1 <= desc.d <= 3 and desc.hidden % 16 == 0 and 16 <= desc.hidden <= 64 and 1 <= desc.layers <= 4
             and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
@@ -793,7 +820,7 @@ def mlp_ext_source(desc):
     header = os.path.join(HERE, "csrc", "ndq_launch.h")
     return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
 #include "{header}"
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u>;
 extern "C" const ndq_mlp_kernels* ndq_ext_kernels(void) {{
   static const ndq_mlp_kernels k = ndq::make_kernels<CFG>();
   return &k;

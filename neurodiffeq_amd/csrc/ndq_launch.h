@@ -66,7 +66,8 @@ int kernels_bwd(const float* coords, int ldc, int n, const float* params, const 
 template <class C>
 ndq_mlp_kernels make_kernels() {
   ndq_mlp_kernels k{};
-  k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::H, C::L, C::ACT, C::NOUT, C::SS::LAP, C::SKIP};
+  k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::H, C::L, C::ACT, C::NOUT, C::SS::LAP, C::SKIP,
+                        (int)C::SS::M3};
   k.n_streams = C::NS;
   k.n_params = C::P;
   k.bwd_waves = C::BWD_THREADS / 64;

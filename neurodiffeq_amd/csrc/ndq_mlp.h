@@ -78,13 +78,35 @@ __device__ __forceinline__ void sfor(F&& f) {
 // carries their sum  L = sum_a d2/dx_a^2  (closed under the recurrences: h_L = s2 sum_a z_a^2 + s1 z_L, z_L = W h_L).
 // Usable whenever the residual depends on those second derivatives only through that sum (Laplace, Poisson, heat,
 // Navier-Stokes ...); the pointwise code generator proves this symbolically before asking for it.
-template <int D_, int FIRST_, unsigned M2_, int LAP_ = 0>
+// Third order (M3, bit k <-> k-th triple a <= b <= c in lexicographic order): d3/dx_a dx_b dx_c, needed by the Sobolev
+// losses of second-order PDEs (losses.py:17-26) and by diff(u, t, order=3).  Recurrence (Faa di Bruno):
+//   h_abc = s3 z_a z_b z_c + s2 (z_ab z_c + z_ac z_b + z_bc z_a) + s1 z_abc,   z_abc = W h_abc
+// so a triple needs its three pairs in M2.
+template <int D_, int FIRST_, unsigned M2_, int LAP_ = 0, unsigned M3_ = 0>
 struct Streams {
   static constexpr int D = D_;
   static constexpr int FIRST = FIRST_;
   static constexpr unsigned M2 = M2_;
+  static constexpr unsigned M3 = M3_;
   static constexpr int LAP = LAP_;
   static constexpr int NPAIR = D * (D + 1) / 2;
+  static constexpr int NTRIP = D * (D + 1) * (D + 2) / 6;
+  static constexpr int count3() {
+    int c = 0;
+    for (int k = 0; k < NTRIP; ++k) c += (M3 >> k) & 1u;
+    return c;
+  }
+  static constexpr int N3 = count3();
+  static constexpr int tri_x(int k, int pos) {      // pos-th index of the k-th triple
+    int idx = 0;
+    for (int a = 0; a < D; ++a)
+      for (int b = a; b < D; ++b)
+        for (int c = b; c < D; ++c) {
+          if (idx == k) return pos == 0 ? a : (pos == 1 ? b : c);
+          ++idx;
+        }
+    return -1;
+  }
   static constexpr int count2() {
     int c = 0;
     for (int k = 0; k < NPAIR; ++k) c += (M2 >> k) & 1u;
@@ -100,9 +122,11 @@ struct Streams {
       }
     return false;
   }
-  static constexpr int NS = 1 + FIRST * D + N2;
+  static constexpr int NS = 1 + FIRST * D + N2 + N3;
   static constexpr int S2 = 1 + FIRST * D;  // index of the first second-order stream
+  static constexpr int S3 = S2 + N2;        // index of the first third-order stream
   static_assert(FIRST == 1 || M2 == 0, "second-order streams need the first-order ones");
+  static_assert(M3 == 0 || LAP == 0, "third-order streams and the Laplacian stream do not combine");
   static constexpr int pair_of(int s) {  // s >= S2 -> pair index
     int c = S2;
     for (int k = 0; k < NPAIR; ++k)
@@ -132,6 +156,38 @@ struct Streams {
   }
   static constexpr int A(int s) { return pair_a(pair_of(s)); }  // coordinate indices of second-order stream s
   static constexpr int B(int s) { return pair_b(pair_of(s)); }
+  static constexpr int tri_of(int s) {      // s >= S3 -> triple index
+    int c = S3;
+    for (int k = 0; k < NTRIP; ++k)
+      if ((M3 >> k) & 1u) {
+        if (c == s) return k;
+        ++c;
+      }
+    return -1;
+  }
+  static constexpr int T(int s, int pos) { return tri_x(tri_of(s), pos); }   // coordinate indices of third-order stream s
+  static constexpr int pair_stream(int a, int b) {   // stream index of d2/dx_a dx_b, -1 if not carried
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    int idx = 0, c = S2;
+    for (int x = 0; x < D; ++x)
+      for (int y = x; y < D; ++y) {
+        if ((M2 >> idx) & 1u) {
+          if (x == lo && y == hi) return c;
+          ++c;
+        }
+        ++idx;
+      }
+    return -1;
+  }
+  static constexpr bool closed3() {
+    for (int k = 0; k < NTRIP; ++k)
+      if ((M3 >> k) & 1u) {
+        const int a = tri_x(k, 0), b = tri_x(k, 1), c = tri_x(k, 2);
+        if (pair_stream(a, b) < 0 || pair_stream(a, c) < 0 || pair_stream(b, c) < 0) return false;
+      }
+    return true;
+  }
+  static_assert(closed3(), "a third-order stream needs its three second-order sub-streams");
 };
 
 // ------------------------------------------------------------------------------------------------ activations
@@ -213,12 +269,17 @@ template <> struct Act<ACT_TANH> {  // nn.Tanh, networks.py:27 default
   static __device__ __forceinline__ float s1(float t, float) { return fmaf(-t, t, 1.f); }
   static __device__ __forceinline__ float s2(float t, float, float s1v) { return -2.f * t * s1v; }
   static __device__ __forceinline__ float s3(float t, float, float s1v) { return -2.f * s1v * fmaf(-3.f * t, t, 1.f); }
+  // fourth derivative: -2 s2 (1 - 3 t^2) + 12 t s1^2 with s2 = -2 t s1
+  static __device__ __forceinline__ float s4(float t, float, float s1v) {
+    return 4.f * t * s1v * fmaf(-3.f * t, t, 1.f) + 12.f * t * s1v * s1v;
+  }
 };
 template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
   static __device__ __forceinline__ void fwd(float z, float& t, float& c) { sincosf(z, &t, &c); }
   static __device__ __forceinline__ float s1(float, float c) { return c; }
   static __device__ __forceinline__ float s2(float t, float, float) { return -t; }
   static __device__ __forceinline__ float s3(float, float c, float) { return -c; }
+  static __device__ __forceinline__ float s4(float t, float, float) { return t; }
 };
 
 __device__ __forceinline__ float sigmoid_fast(float z) {   // 1 / (1 + 2^(-z log2 e)); saturates cleanly to 0 / 1
@@ -229,6 +290,9 @@ template <> struct Act<ACT_SIGMOID> {  // torch.nn.Sigmoid as FCNN(actv=nn.Sigmo
   static __device__ __forceinline__ float s1(float t, float) { return t * (1.f - t); }
   static __device__ __forceinline__ float s2(float t, float, float s1v) { return s1v * fmaf(-2.f, t, 1.f); }
   static __device__ __forceinline__ float s3(float, float, float s1v) { return s1v * fmaf(-6.f, s1v, 1.f); }
+  static __device__ __forceinline__ float s4(float t, float, float s1v) {      // s2 (1 - 12 s1)
+    return s1v * fmaf(-2.f, t, 1.f) * fmaf(-12.f, s1v, 1.f);
+  }
 };
 // Swish with the default fixed beta = 1 (networks.py:155-175): f = z sigma(z).  State: t = f, c = sigma(z); since
 // z sigma = t the derivatives need no z:  f1 = c + t(1-c),  f2 = (1-c)(2c + t(1-2c)),  f3 = (1-c)(3c(1-2c) + t(1-6c+6c^2))
@@ -263,9 +327,12 @@ template <> struct Act<ACT_APTX> {
 };
 
 // ------------------------------------------------------------------------------------------------ config
-template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0, int SKIP_ = 0>
+template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0, int SKIP_ = 0,
+          unsigned M3_ = 0>
 struct Cfg {
-  using SS = Streams<D_, FIRST_, M2_, LAP_>;
+  using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
+  static_assert(M3_ == 0 || ACT_ == ACT_TANH || ACT_ == ACT_SIN || ACT_ == ACT_SIGMOID,
+                "third-order streams: tanh / sin / sigmoid networks");
   static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
   static constexpr int NOUT = NOUT_;               // output units; > 1: the output layer is an MFMA layer too
   static constexpr int NBO = (NOUT_ + 15) / 16;    // 16-row blocks of the (zero-padded) output layer
@@ -300,7 +367,7 @@ struct Cfg {
   static constexpr bool BF16O = BF16 && (NOUT_ > 1) && (NBO % 2 == 0);
   static constexpr int NCO = NBO / 2;
   static constexpr int WOEL = BF16O ? (HO * H * 3) / 2 : HO * H;   // floats of LDS per output-layer image
-  static constexpr bool KEEP_H = (NB_ == 2) && (NDQ_KEEP_H != 0);
+  static constexpr bool KEEP_H = (NB_ == 2) && (NDQ_KEEP_H != 0) && (SS::NS <= 6);
   // wide nets (H >= 64): the reverse pass is register-bound, so (a) the per-point GEMMs go through their bf16 planes
   // SG streams at a time instead of all at once, (b) the bias-type gradient sums (db_l, dW1, dWout: one value per
   // unit) live in a per-wave LDS region instead of registers, (c) the first layer's derivative streams (columns of
@@ -499,6 +566,17 @@ __device__ __forceinline__ void act_forward(const LayerState<C>& st, f32x4 (&h)[
             constexpr int a = SS::A(s), bb = SS::B(s);
             h[s][b][r] = fmaf(s2 * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[s][b][r]);
           });
+          if constexpr (SS::N3 > 0) {
+            const float s3 = A::s3(t, c, s1);
+            sfor<SS::N3>([&](auto k_) {
+              constexpr int s = SS::S3 + decltype(k_)::value;
+              constexpr int a = SS::T(s, 0), bb = SS::T(s, 1), cc = SS::T(s, 2);
+              constexpr int sab = SS::pair_stream(a, bb), sac = SS::pair_stream(a, cc), sbc = SS::pair_stream(bb, cc);
+              const float za = st.z[1 + a][b][r], zb = st.z[1 + bb][b][r], zc = st.z[1 + cc][b][r];
+              const float mix = fmaf(st.z[sab][b][r], zc, fmaf(st.z[sac][b][r], zb, st.z[sbc][b][r] * za));
+              h[s][b][r] = fmaf(s3 * za, zb * zc, fmaf(s2, mix, s1 * st.z[s][b][r]));
+            });
+          }
         }
       }
     }
@@ -526,10 +604,17 @@ __device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, f32x
           if constexpr (SS::in_lap(a)) q2 = fmaf(st.z[1 + a][b][r], st.z[1 + a][b][r], q2);
         });
         hs[b][r] = fmaf(A::s2(t, c, s1), q2, s1 * st.z[S][b][r]);
-      } else {
+      } else if constexpr (S < SS::S3) {
         constexpr int a = SS::A(S), bb = SS::B(S);
         const float s1 = A::s1(t, c);
         hs[b][r] = fmaf(A::s2(t, c, s1) * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[S][b][r]);
+      } else {
+        constexpr int a = SS::T(S, 0), bb = SS::T(S, 1), cc = SS::T(S, 2);
+        constexpr int sab = SS::pair_stream(a, bb), sac = SS::pair_stream(a, cc), sbc = SS::pair_stream(bb, cc);
+        const float s1 = A::s1(t, c), s2 = A::s2(t, c, s1), s3 = A::s3(t, c, s1);
+        const float za = st.z[1 + a][b][r], zb = st.z[1 + bb][b][r], zc = st.z[1 + cc][b][r];
+        const float mix = fmaf(st.z[sab][b][r], zc, fmaf(st.z[sac][b][r], zb, st.z[sbc][b][r] * za));
+        hs[b][r] = fmaf(s3 * za, zb * zc, fmaf(s2, mix, s1 * st.z[S][b][r]));
       }
     }
 }
@@ -571,6 +656,29 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, f32x4 (&g)
           g[SS::S2][b][r] = s1 * hb;
         } else if constexpr (SS::N2 > 0) {
           const float s3 = A::s3(t, c, s1);
+          float zb2[SS::N2];                 // what the third-order streams add to the second-order adjoints
+#pragma unroll
+          for (int k = 0; k < SS::N2; ++k) zb2[k] = 0.f;
+          if constexpr (SS::N3 > 0) {
+            const float s4 = A::s4(t, c, s1);
+            sfor<SS::N3>([&](auto k_) {
+              constexpr int s = SS::S3 + decltype(k_)::value;
+              constexpr int a = SS::T(s, 0), bb = SS::T(s, 1), cc = SS::T(s, 2);
+              constexpr int sab = SS::pair_stream(a, bb), sac = SS::pair_stream(a, cc), sbc = SS::pair_stream(bb, cc);
+              const float hb = g[s][b][r];
+              const float zA = st.z[1 + a][b][r], zB = st.z[1 + bb][b][r], zC = st.z[1 + cc][b][r];
+              const float zab = st.z[sab][b][r], zac = st.z[sac][b][r], zbc = st.z[sbc][b][r];
+              const float mix = fmaf(zab, zC, fmaf(zac, zB, zbc * zA));
+              z0 = fmaf(fmaf(s4 * zA, zB * zC, fmaf(s3, mix, s2 * st.z[s][b][r])), hb, z0);
+              za[a] = fmaf(fmaf(s3 * zB, zC, s2 * zbc), hb, za[a]);
+              za[bb] = fmaf(fmaf(s3 * zA, zC, s2 * zac), hb, za[bb]);
+              za[cc] = fmaf(fmaf(s3 * zA, zB, s2 * zab), hb, za[cc]);
+              zb2[sab - SS::S2] = fmaf(s2 * zC, hb, zb2[sab - SS::S2]);
+              zb2[sac - SS::S2] = fmaf(s2 * zB, hb, zb2[sac - SS::S2]);
+              zb2[sbc - SS::S2] = fmaf(s2 * zA, hb, zb2[sbc - SS::S2]);
+              g[s][b][r] = s1 * hb;
+            });
+          }
           sfor<SS::N2>([&](auto k_) {
             constexpr int s = SS::S2 + decltype(k_)::value;
             constexpr int a = SS::A(s), bb = SS::B(s);
@@ -579,7 +687,7 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, f32x4 (&g)
             z0 = fmaf(fmaf(s3 * zA, zB, s2 * st.z[s][b][r]), hb, z0);
             za[a] = fmaf(s2 * zB, hb, za[a]);
             za[bb] = fmaf(s2 * zA, hb, za[bb]);
-            g[s][b][r] = s1 * hb;
+            g[s][b][r] = fmaf(s1, hb, zb2[decltype(k_)::value]);
           });
         }
         sfor<C::D>([&](auto a_) {

@@ -27,6 +27,7 @@ import torch.nn as nn
 from . import _lib
 from .conditions import BaseCondition
 from .generators import Generator1D, Generator2D, GeneratorSpherical, SamplerGenerator
+from . import autograd_ops
 from .losses import _losses
 from .networks import FCNN
 from .neurodiffeq import safe_diff as diff
@@ -155,6 +156,7 @@ class BaseSolver(ABC):
         self._stop_training = False
         self._phase = None
         self._fused_sys = None
+        self._composite_plain = False   # composite path: plain torch forwards (set when an equation needs order > 2)
         self._fused_key = None
         self._fast_tracks_best = False
         self.dist = None                # optional neurodiffeq_amd.parallel.BatchSharding
@@ -529,6 +531,19 @@ class BaseSolver(ABC):
                 self._batch[key] = batch
 
             def closure(zero_grad=True):
+                # the networks' forward passes go through the HIP stream kernels (autograd_ops.MlpJet, derivatives up to
+                # second order); equations / losses that differentiate further re-run on the plain torch forward
+                if self._composite_plain:
+                    with autograd_ops.native_autograd(False):
+                        return closure_body(zero_grad)
+                try:
+                    return closure_body(zero_grad)
+                except autograd_ops.JetOrderError:
+                    self._composite_plain = True
+                    with autograd_ops.native_autograd(False):
+                        return closure_body(zero_grad)
+
+            def closure_body(zero_grad=True):
                 nonlocal batch_loss
                 if key == "train" and zero_grad:
                     self.optimizer.zero_grad()

@@ -17,6 +17,21 @@ A stream is a tuple of coordinate indices: ``()`` value, ``(a,)`` d/dx_a, ``(a, 
 import numpy as np
 
 
+def act_deriv4(name, z):
+    """Fourth derivative of the activation (the adjoint of a third-order stream needs it)."""
+    if name == "tanh":
+        t = np.tanh(z)
+        s1 = 1 - t * t
+        return 4 * t * s1 * (1 - 3 * t * t) + 12 * t * s1 * s1
+    if name == "sin":
+        return np.sin(z)
+    if name == "sigmoid":
+        s = 1.0 / (1.0 + np.exp(-z))
+        d1 = s * (1 - s)
+        return d1 * (1 - 2 * s) * (1 - 12 * d1)
+    raise KeyError(f"no fourth derivative stated for {name}")
+
+
 def act_derivs(name, z):
     """sigma(z) and its first three derivatives."""
     if name == "tanh":
@@ -54,15 +69,22 @@ def split_params(flat, dims):
     return out
 
 
+def _pairs_of(m):
+    return [(m[0], m[1]), (m[0], m[2]), (m[1], m[2])]
+
+
 def close_streams(streams):
-    """A second-order stream needs both of its first-order streams; the value stream is always present."""
+    """A second-order stream needs both of its first-order streams, a third-order one also its three second-order
+    sub-streams (Faa di Bruno); the value stream is always present."""
     s = {()}
     for m in streams:
         m = tuple(sorted(m))
-        assert len(m) <= 2, "order > 2 is outside the fused path"
+        assert len(m) <= 3, "order > 3 is outside the fused path"
         s.add(m)
         for a in m:
             s.add((a,))
+        if len(m) == 3:
+            s.update(_pairs_of(m))
     return sorted(s, key=lambda m: (len(m), m))
 
 
@@ -89,6 +111,10 @@ def _forward(flat, dims, act, coords, streams):
                 hn[m] = s1 * z[m]
             elif len(m) == 2:
                 hn[m] = s2 * z[(m[0],)] * z[(m[1],)] + s1 * z[m]
+            elif len(m) == 3:       # h_abc = s3 z_a z_b z_c + s2 (z_ab z_c + z_ac z_b + z_bc z_a) + s1 z_abc
+                a, b, c = (m[0],), (m[1],), (m[2],)
+                pab, pac, pbc = _pairs_of(m)
+                hn[m] = s3 * z[a] * z[b] * z[c] + s2 * (z[pab] * z[c] + z[pac] * z[b] + z[pbc] * z[a]) + s1 * z[m]
         saved.append((h, z, (s1, s2, s3)))
         h = hn
     raise AssertionError
@@ -145,7 +171,7 @@ def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False):
                 if len(m) == 1:
                     hin[m][:, m[0]] = 1.0
         else:
-            _, zprev, (s1, s2, _) = saved[li - 1]
+            _, zprev, (s1, s2, s3) = saved[li - 1]
             s0 = act_derivs(act, zprev[()])[0]
             hin = {(): s0}
             for m in streams:
@@ -153,6 +179,11 @@ def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False):
                     hin[m] = s1 * zprev[m]
                 elif len(m) == 2:
                     hin[m] = s2 * zprev[(m[0],)] * zprev[(m[1],)] + s1 * zprev[m]
+                elif len(m) == 3:
+                    a, b, c = (m[0],), (m[1],), (m[2],)
+                    pab, pac, pbc = _pairs_of(m)
+                    hin[m] = s3 * zprev[a] * zprev[b] * zprev[c] \
+                        + s2 * (zprev[pab] * zprev[c] + zprev[pac] * zprev[b] + zprev[pbc] * zprev[a]) + s1 * zprev[m]
         dw = sum(zb[m].T @ hin[m] for m in streams)
         db = zb[()].sum(axis=0)
         grads[li] = (dw, db)
@@ -172,6 +203,22 @@ def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False):
                 nzb[()] += (s3 * zprev[a] * zprev[b] + s2 * zprev[m]) * hb[m]
                 nzb[a] += s2 * zprev[b] * hb[m]
                 nzb[b] += s2 * zprev[a] * hb[m]
+                nzb[m] += s1 * hb[m]
+        if any(len(m) == 3 for m in streams):
+            s4 = act_deriv4(act, zprev[()])
+        for m in streams:
+            if len(m) == 3:         # adjoint of the third-order recurrence, position by position
+                a, b, c = (m[0],), (m[1],), (m[2],)
+                pab, pac, pbc = _pairs_of(m)
+                za, zb_, zc = zprev[a], zprev[b], zprev[c]
+                mix = zprev[pab] * zc + zprev[pac] * zb_ + zprev[pbc] * za
+                nzb[()] += (s4 * za * zb_ * zc + s3 * mix + s2 * zprev[m]) * hb[m]
+                nzb[a] += (s3 * zb_ * zc + s2 * zprev[pbc]) * hb[m]
+                nzb[b] += (s3 * za * zc + s2 * zprev[pac]) * hb[m]
+                nzb[c] += (s3 * za * zb_ + s2 * zprev[pab]) * hb[m]
+                nzb[pab] += s2 * zc * hb[m]
+                nzb[pac] += s2 * zb_ * hb[m]
+                nzb[pbc] += s2 * za * hb[m]
                 nzb[m] += s1 * hb[m]
         zb = nzb
     return np.concatenate([np.concatenate([dw.reshape(-1), db]) for dw, db in grads])

@@ -115,6 +115,15 @@ def make(name, size=None):
         c = make("c2", 12)
         c["nets"] = [Resnet(2, 1, hidden_units=(32, 32))]
         return c
+    if name == "w9":      # Sobolev loss on a second-order PDE: third-order network streams (losses.py:17-26)
+        c = make("c2", 10)
+        c["pde"] = lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2) + u * diff(u, x) - torch.sin(PI * x)]
+        c["loss"] = "h1"
+        return c
+    if name == "w10":     # third-order ODE, sin network
+        pde = lambda u, t: [diff(u, t, order=3) + diff(u, t, order=2) * diff(u, t) + u - torch.sin(t)]
+        return dict(kind="1d", pde=pde, nets=[FCNN(1, 1, hidden_units=(32, 32), actv=SinActv)], conds=[IVP(0.0, 1.0)],
+                    gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"), n_points=48, dom=(0.0, 2.0))
     if name == "w4":      # APTx networks: second-order ODE with a Neumann-form IVP coupled to a first-order one
         pde = lambda u, v, t: [diff(u, t, order=2) + v * diff(u, t) + u, diff(v, t) - u * v + torch.sin(t)]
         nets = [FCNN(1, 1, hidden_units=(32, 32), actv=APTx) for _ in range(2)]
@@ -139,6 +148,8 @@ def make_solver(name, size=None, **kw):
     from neurodiffeq_amd.solvers import Solver1D, Solver2D, SolverSpherical, BundleSolver1D
     cfg = make(name, size)
     kw.setdefault("n_batches_valid", 0)
+    if cfg.get("loss"):
+        kw.setdefault("loss_fn", cfg["loss"])
     if cfg["kind"] == "sph":
         s = SolverSpherical(cfg["pde"], cfg["conds"], r_min=cfg["dom"][0], r_max=cfg["dom"][1], nets=cfg["nets"],
                             train_generator=cfg["gen"], valid_generator=cfg["gen"], enforcer=cfg.get("enforcer"), **kw)
@@ -177,3 +188,12 @@ def make_custom_loss_solver(size=16, **kw):
                              train_generator=cfg["gen"], valid_generator=cfg["gen"], loss_fn=custom_loss_fn,
                              metrics=dict(CUSTOM_METRICS), **kw)
     return solver, cfg
+
+
+def fused_equations(cfg):
+    """The residual list the fused path traces for a config: the PDE itself, or -- Sobolev losses -- the PDE extended by
+    the gradient of the summed residual (solvers.sobolev_equations; its l2 loss is the h1 loss)."""
+    if cfg.get("loss") in ("h1", "h1 semi"):
+        from neurodiffeq_amd.solvers import sobolev_equations
+        return sobolev_equations(cfg["pde"], len(cfg["nets"]), semi=(cfg["loss"] == "h1 semi"))
+    return cfg["pde"]

@@ -186,8 +186,26 @@ def cfg_w8():
     return dict(kind="1d", pde=ode, nets=nets, conds=conds, gen=gen, t=(0.0, 1.0))
 
 
+def cfg_w9():
+    """Sobolev loss (losses.py:17-26, ``loss_fn='h1'``) on a SECOND-order PDE: the loss differentiates the residual once
+    more, i.e. third-order derivatives of the network (Poisson-type problem on the C2 domain)."""
+    cfg = cfg_c2(10)
+    cfg["pde"] = lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2) + u * diff(u, x) - torch.sin(PI * x)]
+    cfg["loss"] = "h1"
+    return cfg
+
+
+def cfg_w10():
+    """Third-order ODE (``diff(u, t, order=3)``, neurodiffeq.py:21-34) with a sin network."""
+    ode = lambda u, t: [diff(u, t, order=3) + diff(u, t, order=2) * diff(u, t) + u - torch.sin(t)]
+    nets = [FCNN(1, 1, hidden_units=(32, 32), actv=SinActv)]
+    return dict(kind="1d", pde=ode, nets=nets, conds=[IVP(0.0, 1.0)], gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"),
+                t=(0.0, 2.0))
+
+
 CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
-           "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5, "w6": cfg_w6, "w7": cfg_w7, "w8": cfg_w8}
+           "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5, "w6": cfg_w6, "w7": cfg_w7, "w8": cfg_w8,
+           "w9": cfg_w9, "w10": cfg_w10}
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -212,7 +230,11 @@ def closure_once(cfg, coords32, dtype):
         res = torch.cat(cfg["pde"](*funcs, batch[0], *picked), dim=1)
     else:
         res = torch.cat(cfg["pde"](*funcs, *batch), dim=1)
-    loss = (res ** 2).mean()
+    if cfg.get("loss"):            # a named loss of the reference (neurodiffeq/losses.py)
+        from neurodiffeq.losses import _losses
+        loss = _losses[cfg["loss"]](res, funcs, batch)
+    else:
+        loss = (res ** 2).mean()
     loss.backward()
     # a parameter the loss does not depend on (e.g. the output bias of the NS pressure net, which enters
     # the residual only through derivatives) keeps ``.grad is None`` in the reference; recorded as zeros.
@@ -265,7 +287,7 @@ def make(name, seed=0):
         kw = dict(t_min=cfg.get("t", (0.1, 12.0))[0], t_max=cfg.get("t", (0.1, 12.0))[1]) if cfg["kind"] == "1d" \
             else dict(xy_min=(0, 0), xy_max=(1, 1))
         solver = Solver(pde, cfg["conds"], nets=cfg["nets"], train_generator=gen, valid_generator=gen,
-                        n_batches_valid=0, **kw)
+                        n_batches_valid=0, loss_fn=cfg.get("loss"), **kw)
     torch.manual_seed(seed + 2)
     for _ in range(3):
         solver.run_train_epoch()

@@ -140,6 +140,27 @@ def test_third_order_request_raises_and_plain_inputs_fall_back(cpu_ops):
     assert "MlpJet" not in type(out.grad_fn).__name__
 
 
+def test_third_order_on_request(cpu_ops):
+    """set_native_autograd(max_order=3): every third-order partial travels with the forward launch; diff(order=3) and
+    the parameter gradient of a loss built on it equal torch autograd through the plain Sequential."""
+    torch.manual_seed(5)
+    net = FCNN(2, 1, hidden_units=(32, 32))
+    x, y = [torch.rand(9, 1, requires_grad=True) for _ in range(2)]
+
+    def build():
+        u = net(torch.cat([x, y], dim=1)) * (1.0 + x * y)
+        return diff(u, x, order=3) + diff(diff(u, y, order=2), x) + u
+    with autograd_ops.native_autograd(True, max_order=3):
+        r = build()
+        assert "MlpJet" in type(net(torch.cat([x, y], dim=1)).grad_fn).__name__
+        g1 = torch.autograd.grad((r ** 2).mean(), list(net.parameters()))
+    with autograd_ops.native_autograd(False):
+        r2 = build()
+        g2 = torch.autograd.grad((r2 ** 2).mean(), list(net.parameters()))
+    assert rel_l2(r.detach().numpy(), r2.detach().numpy()) < 2e-6
+    assert rel_l2(torch.cat([g.reshape(-1) for g in g1]).numpy(), torch.cat([g.reshape(-1) for g in g2]).numpy()) < 2e-6
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,size", [("c2", 16), ("c1", 64), ("c3", 12), ("c4", 96)])
 def test_hand_written_loop_on_the_hip_kernels_matches_reference_trajectory(name, size):

@@ -134,3 +134,30 @@ def test_jet_vjp_matches_autograd(golden_dir, name):
     want = R.get_flat_grad([net]).numpy()
     got = J.mlp_jets_vjp(flat, dims, act, [c.detach().numpy() for c in cs], gbar)
     assert rel_l2(got, want) < 1e-11
+
+
+@pytest.mark.parametrize("act", ["tanh", "sin", "sigmoid"])
+def test_third_order_jets_match_nested_autograd(act):
+    """The jet oracle's third-order recurrences (forward AND the adjoint with the fourth activation derivative) against
+    three nested autograd sweeps (ref_diff, neurodiffeq.py:21-34) in fp64."""
+    from oracle import jet_ref as J
+    torch.manual_seed(0)
+    net = R.make_fcnn(2, 2, (16, 16), act, torch.float64)
+    flat = R.get_flat([net]).numpy()
+    x, y = [torch.rand(7, 1, dtype=torch.float64, requires_grad=True) for _ in range(2)]
+    out = net(torch.cat([x, y], 1))
+    d = R.ref_diff
+    z = J.mlp_jets(flat, (2, 16, 16, 2), act, [x.detach().numpy(), y.detach().numpy()], [(0, 0, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1)])
+    rng = np.random.default_rng(0)
+    gb = {m: rng.standard_normal((7, 2)) for m in z}
+    loss = 0
+    for o in range(2):
+        u = out[:, o:o + 1]
+        cols = {(): u, (0,): d(u, x), (1,): d(u, y), (0, 0): d(u, x, 2), (0, 1): d(d(u, x), y), (1, 1): d(u, y, 2),
+                (0, 0, 0): d(u, x, 3), (0, 0, 1): d(d(u, x, 2), y), (0, 1, 1): d(d(u, y, 2), x), (1, 1, 1): d(u, y, 3)}
+        for m in z:
+            assert rel_l2(z[m][:, o], cols[m].detach().numpy()) < 1e-10, (act, m)
+            loss = loss + (torch.from_numpy(gb[m][:, o:o + 1]) * cols[m]).sum()
+    loss.backward()
+    got = J.mlp_jets_vjp(flat, (2, 16, 16, 2), act, [x.detach().numpy(), y.detach().numpy()], gb)
+    assert rel_l2(got, R.get_flat_grad([net]).numpy()) < 1e-12

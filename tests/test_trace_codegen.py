@@ -14,7 +14,7 @@ from oracle import jet_ref as J
 from tests import configs, zoo
 from tests.pw_cpu import run_cpu
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w9": None, "w10": None}
 
 
 def rel_l2(a, b):
@@ -101,13 +101,15 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
 
 
 @pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
-                                      ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True), ("w5", True), ("w6", True), ("w7", True), ("w8", True)])
+                                      ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True), ("w5", True), ("w6", True), ("w7", True), ("w8", True),
+                                      ("w9", True), ("w10", True)])
 def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
     cfg = configs.make(name, SIZES[name])
-    prog, funcs, resid, loss, grad = host_closure(cfg["nets"], cfg["conds"], cfg["pde"], gold["coords"], gold["params0"], lap,
-                                                  configs.func_val(cfg))
+    prog, funcs, resid, loss, grad = host_closure(cfg["nets"], cfg["conds"], configs.fused_equations(cfg), gold["coords"],
+                                                  gold["params0"], lap, configs.func_val(cfg))
+    resid = resid[:, :gold["residuals_f64"].shape[1]]      # Sobolev losses trace extra gradient columns behind the residuals
     if name in ("c2", "c5"):     # Laplace / Navier-Stokes use u_xx + u_yy only: the merge must be found when allowed
         assert any(prog.g.nodes[i][3][:1] == ("L",) for i in prog.symbols) == lap
     assert rel_l2(funcs, gold["funcs_f64"]) < 1e-5
@@ -123,7 +125,9 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "swish_laplace": [(1, 5, 1)], "sigmoid_mixed": [(1, 7, 0)], "swish_ode": [(1, 1, 0), (1, 0, 0)],
                "bundle_decay": [(1, 0, 0)], "bundle_bvp": [(1, 1, 0)], "shape_64x2": [(1, 5, 1)], "shape_32x3": [(1, 5, 1)],
                "shape_48x2": [(1, 5, 1)], "shape_16x2_sin": [(1, 5, 1)], "shape_32x1": [(1, 5, 1)],
-               "aptx_burgers": [(1, 1, 0)], "resnet_laplace": [(1, 5, 1)], "resnet_ode": [(1, 1, 0)]}
+               "aptx_burgers": [(1, 1, 0)], "resnet_laplace": [(1, 5, 1)], "resnet_ode": [(1, 1, 0)],
+               # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along
+               "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)]}
 
 
 @pytest.mark.parametrize("name", zoo.NAMES)
@@ -141,7 +145,8 @@ def test_zoo_on_host_matches_autograd_oracle(name):
     want_grad = R.get_flat_grad(onets).numpy()
     prog, funcs, resid, loss, grad = host_closure(nets, conds, pde, np.stack([c.numpy() for c in coords]).astype(np.float32),
                                                   flat.double().numpy())
-    got_streams = [(int(st.first), int(st.mask2), int(st.lap)) for st in (prog.streams[k] for k in range(len(nets)))]
+    got_streams = [(int(st.first), int(st.mask2), int(st.lap)) + ((int(st.mask3),) if st.mask3 else ())
+                   for st in (prog.streams[k] for k in range(len(nets)))]
     assert got_streams == ZOO_STREAMS[name]
     # the oracle ran on the fp64 coordinates, the host pipeline on their fp32 rounding: tolerance 1e-5 covers it
     assert rel_l2(funcs, want["funcs"].numpy()) < 1e-5
@@ -169,10 +174,13 @@ def test_l1_and_infinity_losses_on_host_match_autograd_oracle(name, kind):
     assert rel_l2(grad, want_grad) < 1e-5
 
 
-@pytest.mark.parametrize("name,kind", [("coupled_sin", "h1"), ("advection", "h1"), ("advection", "h1 semi")])
+@pytest.mark.parametrize("name,kind", [("coupled_sin", "h1"), ("advection", "h1"), ("advection", "h1 semi"),
+                                       # second-order systems: the extra d r/dx needs THIRD-order network streams
+                                       ("helmholtz_xy", "h1"), ("pendulum", "h1"), ("pendulum", "h1 semi"),
+                                       ("bvp_tanh", "h1"), ("poisson3d", "h1 semi")])
 def test_sobolev_losses_on_host_match_autograd_oracle(name, kind):
-    """losses.py:17-26 on first-order systems: the h1 norms are the l2 loss of the residual list extended by
-    d(sum_e r_e)/dx_a (what solvers.BaseSolver._fused_system traces)."""
+    """losses.py:17-26: the h1 norms are the l2 loss of the residual list extended by d(sum_e r_e)/dx_a (what
+    solvers.BaseSolver._fused_system traces); on second-order systems that asks for third-order streams."""
     from neurodiffeq_amd import diff
     from oracle import autograd_ref as R
     torch.manual_seed(11)

@@ -158,6 +158,16 @@ def build(name):
         conds = lambda: [C.IBVP1D(-1.0, 1.0, 0.0, u0, x_min_val=zero, x_max_val=zero)]
         return System(name, 2, [(2, 1, (32, 32), "aptx")], [(-1.0, 1.0), (0.0, 1.0)], pde, conds,
                       lambda D: [_R().ibvp1d_dd(-1.0, 1.0, 0.0, u0, zero, zero)])
+    if name == "kdv":                 # Korteweg-de Vries: a third-order derivative in x (diff(u, x, order=3), neurodiffeq.py:21-34)
+        u0 = lambda x: 0.5 / torch.cosh(0.5 * x) ** 2
+        pde = lambda D: (lambda u, x, t: [D(u, t) + 6.0 * u * D(u, x) + D(u, x, order=3)])
+        conds = lambda: [C.IBVP1D(-1.0, 1.0, 0.0, u0, x_min_val=zero, x_max_val=zero)]
+        return System(name, 2, [(2, 1, (32, 32), "tanh")], [(-1.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().ibvp1d_dd(-1.0, 1.0, 0.0, u0, zero, zero)])
+    if name == "ode3":                # third-order ODE with a sin network and a mixed product of derivatives
+        pde = lambda D: (lambda u, t: [D(u, t, order=3) + D(u, t, order=2) * D(u, t) + u - torch.sin(t)])
+        conds = lambda: [C.IVP(0.0, 1.0)]
+        return System(name, 1, [(1, 1, (32, 32), "sin")], [(0.0, 2.0)], pde, conds, lambda D: [_R().ivp(0.0, 1.0)])
     if name == "poisson3d":           # three coordinates, Laplacian -> one merged second-order stream
         pde = lambda D: (lambda u, x, y, z: [D(u, x, order=2) + D(u, y, order=2) + D(u, z, order=2)
                                              + torch.exp(-(x ** 2 + y ** 2 + z ** 2))])
@@ -189,7 +199,7 @@ def build(name):
     raise KeyError(name)
 
 
-NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "poisson3d",
+NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "kdv", "ode3", "poisson3d",
          "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
          "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode"]
 
