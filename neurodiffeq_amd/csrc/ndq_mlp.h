@@ -367,14 +367,19 @@ struct Cfg {
   static constexpr bool BF16O = BF16 && (NOUT_ > 1) && (NBO % 2 == 0);
   static constexpr int NCO = NBO / 2;
   static constexpr int WOEL = BF16O ? (HO * H * 3) / 2 : HO * H;   // floats of LDS per output-layer image
-  static constexpr bool KEEP_H = (NB_ == 2) && (NDQ_KEEP_H != 0) && (SS::NS <= 6);
+  // (two-waves-per-SIMD builds have no registers to keep them in: they recompute, and tile_backward hides the layer states
+  // behind an opaque copy so that the compiler does not quietly keep the forward pass's values alive instead)
+  static constexpr bool KEEP_H = (NB_ == 2) && (NDQ_KEEP_H != 0) && (SS::NS <= 6) && (BWD_THREADS == 256);
+  static constexpr bool LAUNDER = (NB_ == 2) && (BWD_THREADS != 256);
   // wide nets (H >= 64): the reverse pass is register-bound, so (a) the per-point GEMMs go through their bf16 planes
   // SG streams at a time instead of all at once, (b) the bias-type gradient sums (db_l, dW1, dWout: one value per
   // unit) live in a per-wave LDS region instead of registers, (c) the first layer's derivative streams (columns of
   // W1) are re-read from LDS for the reverse pass instead of being kept.  (Recomputing the middle layer's state in
   // the reverse pass instead of keeping it was tried too: no fewer spills, 16 % slower -- rejected.)
   static constexpr bool WIDE = (NB_ >= 4) && (NDQ_WIDE_LOWREG != 0);
-  static constexpr int SG = WIDE ? NDQ_WIDE_SG : SS::NS;
+  // ... and the 8-wave builds of narrow nets (256 registers per wave) run the reverse GEMM two streams at a time as well
+  static constexpr bool GROUP_HBAR = WIDE || (BWD_THREADS != 256 && SS::NS > 2);
+  static constexpr int SG = GROUP_HBAR ? NDQ_WIDE_SG : SS::NS;
   static constexpr bool ACC_LDS = WIDE && (NOUT_ == 1);
   static constexpr int biasFloats = ACC_LDS ? H * (D_ + L_ + 1) : 0;      // b1 | W1 [D] | b_2..b_L | Wout
   static constexpr int biasB1 = 0, biasW1 = H, biasBl = H * (1 + D_), biasWout = H * (D_ + L_);
@@ -514,7 +519,7 @@ __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast
 template <class C>
 __device__ __forceinline__ int opaque_zero() {
   int z = 0;
-  if constexpr (C::WIDE && (NDQ_PIN_WEIGHT_READS != 0)) asm volatile("" : "+v"(z));
+  if constexpr ((C::WIDE || C::BWD_THREADS != 256) && (NDQ_PIN_WEIGHT_READS != 0)) asm volatile("" : "+v"(z));
   return z;
 }
 
@@ -750,7 +755,7 @@ __device__ __forceinline__ void gemm_planes(const float* __restrict__ wl, int la
 // hbar = W^T zbar in place (all streams are split first, then overwritten)
 template <class C>
 __device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl, int lane, f32x4 (&g)[C::NS][C::NB]) {
-  if constexpr (C::WIDE) {           // group by group: planes and outputs of SG streams live at a time
+  if constexpr (C::GROUP_HBAR) {     // group by group: planes and outputs of SG streams live at a time
     constexpr int NG = (C::NS + C::SG - 1) / C::SG;
     sfor<NG>([&](auto g_) {
       constexpr int s0 = decltype(g_)::value * C::SG;
@@ -1211,6 +1216,30 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // all operands of the round are read into registers of their own BEFORE the first MFMA: one LDS round trip per
     // round instead of one per k-step (the compiler otherwise recycles four registers and waits 16 times per stream)
+    if constexpr (C::BWD_THREADS != 256) {
+      // two waves per SIMD, 256 registers each: no room for a round's operands at once -- step by step
+      sfor<sn>([&](auto k_) {
+        const float* Zt = stage + decltype(k_)::value * 2 * 16 * HP;
+        const float* Ht = Zt + 16 * HP;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          float a1[NBA], b1[C::NB];
+#pragma unroll
+          for (int b = 0; b < NBA; ++b) a1[b] = Zt[(4 * q + st) * HP + 16 * b + p];
+#pragma unroll
+          for (int b = 0; b < C::NB; ++b) b1[b] = Ht[(4 * q + st) * HP + 16 * b + p];
+#pragma unroll
+          for (int jb = 0; jb < NBA; ++jb)
+#pragma unroll
+            for (int kb = 0; kb < C::NB; ++kb)
+              acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[jb], b1[kb], acc[jb][kb], 0, 0, 0);
+        }
+      });
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      return;
+    }
     float av[sn][4][NBA], bv[sn][4][C::NB];
     sfor<sn>([&](auto k_) {
       constexpr int k = decltype(k_)::value;
@@ -1373,6 +1402,14 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
                                               LayerState<C> (&st)[C::L], GradAcc<C>& acc, KeptPlanes<C>& kp) {
   // ---------------- output layer adjoint (n_out = 1): hbar = Wout * gout; dWout += sum_s gout_s h_s; dbout += gout_0
   // (h_s of the last hidden layer is recomputed per stream from its state instead of being kept live)
+  if constexpr (C::LAUNDER) {
+#pragma unroll
+    for (int l = 0; l < C::L; ++l)
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(st[l].t[b][r]));
+  }
   f32x4 g[C::NS][C::NB];
   {
     f32x4 dw[C::NB];
