@@ -241,6 +241,9 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 // Ablation switches (experiments only, wrong results by design): NDQ_ABL bit 0 = no weight-gradient GEMMs, bit 1 = no
 // hbar GEMM, bit 2 = no forward hidden GEMM, bit 3 = no act_backward, bit 4 = no LDS transposes (MFMAs on stale data),
 // bit 5 = no operand splitting (planes reused).  scripts/ablate.py times the closure kernel with each of them.
+#ifndef NDQ_WIDE_LAUNDER
+#define NDQ_WIDE_LAUNDER 1
+#endif
 #ifndef NDQ_ABL
 #define NDQ_ABL 0
 #endif
@@ -370,7 +373,7 @@ struct Cfg {
   // (two-waves-per-SIMD builds have no registers to keep them in: they recompute, and tile_backward hides the layer states
   // behind an opaque copy so that the compiler does not quietly keep the forward pass's values alive instead)
   static constexpr bool KEEP_H = (NB_ == 2) && (NDQ_KEEP_H != 0) && (SS::NS <= 6) && (BWD_THREADS == 256);
-  static constexpr bool LAUNDER = (NB_ == 2) && (BWD_THREADS != 256);
+  static constexpr bool LAUNDER = ((NB_ == 2) && (BWD_THREADS != 256)) || (NB_ >= 4 && NDQ_WIDE_LAUNDER);
   // wide nets (H >= 64): the reverse pass is register-bound, so (a) the per-point GEMMs go through their bf16 planes
   // SG streams at a time instead of all at once, (b) the bias-type gradient sums (db_l, dW1, dWout: one value per
   // unit) live in a per-wave LDS region instead of registers, (c) the first layer's derivative streams (columns of
