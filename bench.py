@@ -458,12 +458,12 @@ def main():
                                    "run_train_epoch() with n_batches_train=1, n_batches_valid=0",
                        "points_per_gpu": N_POINTS, "global_batch": N_POINTS * world,
                        "parallelism": f"dp{world} (shard-by-batch, one all-reduce of [P+1] fp32 per step)",
-                       "allreduce": ("none (single process)" if not use_dist else
-                                     "RCCL, enqueued by the native step on the compute stream"
-                                     if solver.dist.direct("cuda") is not None else "torch.distributed (RCCL)"),
+                       "allreduce": ("none (single process)" if not use_dist else solver.dist.allreduce_kind("cuda")),
                        "inputs": "pre-sampled in the reference's RNG order, resident in HBM"},
             "final_loss": solver.metrics_history["train_loss"][-1],
         }
+        if use_dist and hasattr(solver.dist._direct, "status"):
+            out["allreduce_flag_timeouts"] = solver.dist._direct.status()      # one-shot exchange: must be 0
     if rank == 0 and world == 1 and not use_dist:
         system = solver._fused_sys
         batch = solver._generate_batch("train")

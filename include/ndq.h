@@ -195,6 +195,21 @@ typedef int (*ndq_pointwise_fn)(const float* coords, int ldc, int n, const float
                                 float seed_scale, void* stream);
 typedef int (*ndq_pw_blocks_fn)(int n);
 
+/* ---- one-shot all-reduce of the small [gradient | loss] message (data-parallel training) ------------
+ * Every rank writes its vector straight into every peer's inbox (fine-grained device memory shared through HIP IPC; on
+ * MI355X one xGMI hop to each of the 7 peers) and adds up the world_size vectors it received, in rank order: ONE
+ * kernel launch per call, bit-identical results on all ranks.  ndq_oneshot_allreduce has ncclAllReduce's signature
+ * (fp32 sum only) so that ndq_fused_step.allreduce / .comm can point at it; replaces, for this message size, the RCCL
+ * ring / tree behind solvers.py:393's gradient in a data-parallel run.
+ *   create:  allocates this rank's inbox for vectors of up to max_len floats, returns its 64-byte IPC handle
+ *   connect: handles = world_size x 64 bytes in rank order (every rank's own handle included), opens the peers' inboxes
+ *   status:  number of peer-flag waits that hit their spin limit so far (synchronises); 0 = healthy */
+int ndq_oneshot_create(int rank, int world_size, int max_len, void** ctx, unsigned char* handle64);
+int ndq_oneshot_connect(void* ctx, const unsigned char* handles);
+int ndq_oneshot_allreduce(const void* send, void* recv, size_t count, int dtype, int op, void* ctx, void* stream);
+int ndq_oneshot_status(void* ctx);
+int ndq_oneshot_destroy(void* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,9 +85,16 @@ def lib():
     L.ndq_fused_multi_step_run.argtypes = [ctypes.POINTER(FusedStep), ci, vp, vp, ci, ci, ci, vp]
     L.ndq_mlp_register.argtypes = [vp]
     L.ndq_sample.argtypes = [ctypes.POINTER(SamplerDesc), ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, vp, ci, vp]
+    L.ndq_oneshot_create.argtypes = [ci, ci, ci, ctypes.POINTER(vp), ctypes.c_char_p]
+    L.ndq_oneshot_connect.argtypes = [vp, ctypes.c_char_p]
+    L.ndq_oneshot_allreduce.argtypes = [vp, vp, ctypes.c_size_t, ci, ci, vp, vp]
+    L.ndq_oneshot_status.argtypes = [vp]
+    L.ndq_oneshot_destroy.argtypes = [vp]
     for name in ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks",
                  "ndq_mlp_jet_fwd", "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss",
-                 "ndq_epoch_tail", "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run"):
+                 "ndq_epoch_tail", "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run",
+                 "ndq_oneshot_create", "ndq_oneshot_connect", "ndq_oneshot_allreduce", "ndq_oneshot_status",
+                 "ndq_oneshot_destroy"):
         getattr(L, name).restype = ci
     _LIB = L
     return L
@@ -95,7 +102,8 @@ def lib():
 
 EXPORTS = ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks", "ndq_mlp_jet_fwd",
            "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss", "ndq_epoch_tail",
-           "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run")
+           "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run", "ndq_oneshot_create",
+           "ndq_oneshot_connect", "ndq_oneshot_allreduce", "ndq_oneshot_status", "ndq_oneshot_destroy")
 
 
 def check(rc, what):

@@ -490,3 +490,88 @@ int ndq_sample(const ndq_sampler_desc* desc, unsigned long long seed, unsigned l
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- one-shot all-reduce
+#include "ndq_oneshot.h"
+
+extern "C" {
+
+int ndq_oneshot_create(int rank, int world, int max_len, void** out, unsigned char* handle64) {
+  if (!out || !handle64 || world < 1 || world > ndq::kOneshotMaxRanks || rank < 0 || rank >= world || max_len < 1)
+    return NDQ_EINVAL;
+  ndq::Oneshot* c = new (std::nothrow) ndq::Oneshot();
+  if (!c) return NDQ_EINVAL;
+  std::memset(c, 0, sizeof(*c));
+  int max_blocks = 0;
+  const size_t bytes = ndq::oneshot_layout(world, max_len, &c->inbox_bytes, &c->flag_bytes, &max_blocks);
+  // fine-grained (uncached) device memory: remote stores of the peers become visible to this device's loads without a
+  // kernel boundary
+  hipError_t e = hipExtMallocWithFlags(&c->base, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) e = hipExtMallocWithFlags(&c->base, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) { delete c; return (int)e; }
+  e = hipMemset(c->base, 0, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, c->base);
+  if (e != hipSuccess) { (void)hipFree(c->base); delete c; return (int)e; }
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handles are 64 bytes");
+  std::memcpy(handle64, &h, 64);
+  c->dev.rank = rank; c->dev.world = world; c->dev.max_len = max_len; c->dev.max_blocks = max_blocks;
+  c->dev.status = reinterpret_cast<unsigned*>(static_cast<char*>(c->base) + c->inbox_bytes + c->flag_bytes);
+  c->step = 0;
+  *out = c;
+  return 0;
+}
+
+// handles: world x 64 bytes, rank-major (every rank's ndq_oneshot_create handle, its own included)
+int ndq_oneshot_connect(void* ctx, const unsigned char* handles) {
+  ndq::Oneshot* c = static_cast<ndq::Oneshot*>(ctx);
+  if (!c || !handles) return NDQ_EINVAL;
+  for (int q = 0; q < c->dev.world; ++q) {
+    void* p = c->base;
+    if (q != c->dev.rank) {
+      hipIpcMemHandle_t h;
+      std::memcpy(&h, handles + 64 * q, 64);
+      hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) return (int)e;
+      c->peer_base[q] = p;
+    }
+    c->dev.inbox[q] = static_cast<float*>(p);
+    c->dev.flags[q] = reinterpret_cast<unsigned*>(static_cast<char*>(p) + c->inbox_bytes);
+  }
+  return 0;
+}
+
+// ncclAllReduce's signature (sum of fp32 only): what ndq_fused_step.allreduce points at, with .comm = the context
+int ndq_oneshot_allreduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, void* stream) {
+  ndq::Oneshot* c = static_cast<ndq::Oneshot*>(comm);
+  if (!c || !send || !recv || dtype != 7 || op != 0 || count == 0 || (long)count > c->dev.max_len) return NDQ_EINVAL;
+  const unsigned step = ++c->step;
+  const int blocks = ((int)count + ndq::kOneshotChunk - 1) / ndq::kOneshotChunk;
+  hipLaunchKernelGGL(ndq::oneshot_allreduce_kernel, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), c->dev,
+                     static_cast<const float*>(send), static_cast<float*>(recv), (int)count, step);
+  return (int)hipGetLastError();
+}
+
+// number of flag waits that ran into their spin limit since creation (synchronises the device); 0 = healthy
+int ndq_oneshot_status(void* ctx) {
+  ndq::Oneshot* c = static_cast<ndq::Oneshot*>(ctx);
+  if (!c) return NDQ_EINVAL;
+  unsigned v = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(&v, c->dev.status, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)v;
+}
+
+int ndq_oneshot_destroy(void* ctx) {
+  ndq::Oneshot* c = static_cast<ndq::Oneshot*>(ctx);
+  if (!c) return NDQ_EINVAL;
+  (void)hipDeviceSynchronize();
+  for (int q = 0; q < c->dev.world; ++q)
+    if (q != c->dev.rank && c->peer_base[q]) (void)hipIpcCloseMemHandle(c->peer_base[q]);
+  (void)hipFree(c->base);
+  delete c;
+  return 0;
+}
+
+}  // extern "C"

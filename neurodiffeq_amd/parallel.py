@@ -93,6 +93,91 @@ class DirectRccl:
             raise RuntimeError(f"ncclAllReduce returned {rc}")
 
 
+class OneShot:
+    """The one-shot all-reduce of csrc/ndq_oneshot.h (C-ABI ``ndq_oneshot_*``): every rank writes its [gradient | loss]
+    vector into every peer's HIP-IPC-shared inbox and sums what it received in rank order -- one launch, one xGMI hop,
+    bit-identical on all ranks.  Set up like :class:`DirectRccl`: handles travel through the existing process group,
+    every rank verifies a few all-reduces against the known answer, and the ranks AGREE (MIN all-reduce over the
+    regular group) before anyone uses it; otherwise all fall back to RCCL.  ``fn`` / ``comm`` plug into
+    ``ndq_fused_step.allreduce`` / ``.comm`` exactly like ``ncclAllReduce`` and its communicator."""
+
+    MAX_LEN = 1 << 16            # floats: covers [gradients | losses] of every BASELINE system (C5: 25 732)
+
+    def __init__(self, rank, world_size, group, device, max_len=None):
+        from . import _lib
+        self.ok, self.ctx, self.fn = False, None, None
+        self.L = _lib.lib()
+        self.device = torch.device(device)
+        err = None
+        handle = ctypes.create_string_buffer(64)
+        ctx = ctypes.c_void_p()
+        try:
+            if world_size > 16:
+                raise RuntimeError("more than 16 ranks")
+            with torch.cuda.device(self.device):
+                rc = self.L.ndq_oneshot_create(rank, world_size, max_len or self.MAX_LEN, ctypes.byref(ctx), handle)
+            if rc != 0:
+                raise RuntimeError(f"ndq_oneshot_create returned {rc}")
+        except Exception as e:                      # noqa: BLE001
+            err = e
+        # collective, unconditional: every rank's handle (or None) reaches every rank
+        mine = [bytes(handle.raw) if err is None else None]
+        everyone = [None] * world_size
+        dist.all_gather_object(everyone, mine[0], group=group)
+        if err is None and all(h is not None for h in everyone):
+            try:
+                with torch.cuda.device(self.device):
+                    rc = self.L.ndq_oneshot_connect(ctx, b"".join(everyone))
+                if rc != 0:
+                    raise RuntimeError(f"ndq_oneshot_connect returned {rc} (hipIpcOpenMemHandle)")
+                self.ctx = ctx
+            except Exception as e:                  # noqa: BLE001
+                err = e
+        elif err is None:
+            err = RuntimeError("another rank could not allocate its inbox")
+        # every rank that is connected must take part in the same number of self-test calls: agree on connectivity first
+        flag = torch.tensor([1.0 if (err is None and self.ctx is not None) else 0.0], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if flag.item() == 1.0:
+            try:
+                want = world_size * (world_size + 1) / 2.0
+                stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                for n in (8, 1186, 25732, 8):
+                    probe = torch.full((n,), float(rank + 1), dtype=torch.float32, device=self.device)
+                    probe[n - 1] = float(rank + 1) * 0.5
+                    rc = self.L.ndq_oneshot_allreduce(probe.data_ptr(), probe.data_ptr(), n, 7, 0, self.ctx, stream)
+                    torch.cuda.synchronize(self.device)
+                    if rc != 0 or not bool((probe[:n - 1] == want).all()) or float(probe[n - 1]) != want * 0.5:
+                        raise RuntimeError(f"self-test all-reduce of {n} floats failed (rc={rc})")
+                if self.L.ndq_oneshot_status(self.ctx) != 0:
+                    raise RuntimeError("a peer flag was never seen (spin limit)")
+            except Exception as e:                  # noqa: BLE001
+                err = e
+        flag = torch.tensor([0.0 if (err is not None or self.ctx is None) else 1.0], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        self.ok = bool(flag.item() == 1.0)
+        if self.ok:
+            self.fn = ctypes.cast(self.L.ndq_oneshot_allreduce, ctypes.c_void_p).value
+            self.comm = self.ctx
+        elif err is not None:
+            warnings.warn(f"one-shot all-reduce unavailable ({err}); using RCCL")
+
+    def all_reduce(self, tensor):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+        rc = self.L.ndq_oneshot_allreduce(tensor.data_ptr(), tensor.data_ptr(), tensor.numel(), 7, 0, self.ctx, stream)
+        if rc != 0:
+            raise RuntimeError(f"ndq_oneshot_allreduce returned {rc}")
+
+    def status(self):
+        """Peer-flag waits that ran into their spin limit so far (synchronises); 0 = healthy."""
+        return self.L.ndq_oneshot_status(self.ctx) if self.ctx is not None else 0
+
+    def close(self):
+        if self.ctx is not None:
+            self.L.ndq_oneshot_destroy(self.ctx)
+            self.ctx, self.ok = None, False
+
+
 class BatchSharding:
     def __init__(self, rank=None, world_size=None, group=None, presharded=False):
         """presharded: every rank's generator already yields only its own shard (weak-scaling runs with resident
@@ -102,7 +187,7 @@ class BatchSharding:
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world_size = dist.get_world_size(group) if world_size is None else world_size
         self._flat = None
-        self._direct = None         # DirectRccl, created on first use on a GPU under the nccl backend
+        self._direct = None         # OneShot / DirectRccl, created on first use on a GPU
 
     def agree(self, flag, device):
         """True iff ``flag`` is true on every rank (one tiny MIN all-reduce over the regular group)."""
@@ -115,11 +200,31 @@ class BatchSharding:
         communicator unavailable -> ``torch.distributed``)."""
         if self._direct is None:
             device = torch.device(device)
-            usable = (device.type == "cuda" and dist.is_initialized() and dist.get_backend(self.group) == "nccl"
-                      and os.environ.get("NDQ_RCCL_DIRECT", "1") != "0")
-            self._direct = DirectRccl(self.rank, self.world_size, self.group, device) if usable else False
+            on_gpu = device.type == "cuda" and dist.is_initialized()
+            self._direct = False
+            # the [gradient | loss] message is a few KB: first choice is the one-shot exchange through IPC-shared inboxes
+            # (NDQ_ONESHOT_ALLREDUCE=0 skips it; up to 16 ranks of one node; works under gloo as well as nccl), then a RCCL
+            # communicator of our own driven from the native step, else torch.distributed
+            if on_gpu and os.environ.get("NDQ_ONESHOT_ALLREDUCE", "1") != "0" and 1 < self.world_size <= 16:
+                one = OneShot(self.rank, self.world_size, self.group, device)
+                if one.ok:
+                    self._direct = one
+            if self._direct is False and on_gpu and dist.get_backend(self.group) == "nccl" \
+                    and os.environ.get("NDQ_RCCL_DIRECT", "1") != "0":
+                self._direct = DirectRccl(self.rank, self.world_size, self.group, device)
         d = self._direct
-        return (d.fn, d.comm.value) if d and d.ok else None
+        if not (d and d.ok):
+            return None
+        return (d.fn, d.comm.value if hasattr(d.comm, "value") else d.comm)
+
+    def allreduce_kind(self, device):
+        """What carries the per-step all-reduce: "one-shot IPC exchange", "RCCL (direct)" or "torch.distributed"."""
+        self.direct(device)
+        d = self._direct
+        if d and d.ok:
+            return "one-shot exchange through HIP-IPC inboxes (ndq_oneshot_allreduce)" if isinstance(d, OneShot) \
+                else "RCCL, enqueued by the native step on the compute stream"
+        return "torch.distributed"
 
     def bounds(self, n):
         """Row range of this rank's shard of an n-point batch (contiguous, sizes differ by at most one)."""
