@@ -41,7 +41,14 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     :class:`TraceUnsupported` when the system is outside the fused scope.  Returns ``(program, descs)`` with
     ``descs[k]`` the ``ndq_mlp_desc`` of network k (stream set widened to one libndq.so has kernels for)."""
     L = _lib.lib()
-    nets, conditions = list(nets), list(conditions)
+    all_nets, conditions = list(nets), list(conditions)
+    # one parameter set per DISTINCT module: the reference's single_net / ith_unit mode (ode.py:276-280, pde.py:301-305)
+    # and EnsembleCondition share one multi-output network between several functions -- its symbols are output units
+    # of ONE network (one stream array, one gradient), not copies
+    nets = []
+    for n in all_nets:
+        if not any(n is m for m in nets):
+            nets.append(n)
     infos = [describe(n) for n in nets]
     if any(i is None for i in infos):
         raise TraceUnsupported("a network is not an FCNN the gfx950 kernels support")
@@ -50,7 +57,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     cfv = compute_func_val or (lambda net, cond, *coords: cond.enforce(net, *coords))
     with trace_scope(g):
         coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
-        funcs = [cfv(n, c, *coords) for n, c in zip(nets, conditions)]
+        funcs = [cfv(n, c, *coords) for n, c in zip(all_nets, conditions)]
         res = diff_eqs(*funcs, *coords) if diff_eqs is not None else []     # None: evaluation of the functions only
         if isinstance(res, Sym):
             res = [res]
@@ -63,7 +70,8 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
                 raise TraceUnsupported(f"an equation returned {type(r).__name__}, not a traced (N, 1) column or a scalar")
         res = [column(r) for r in res]
         if not all(isinstance(f, Sym) for f in funcs):
-            raise TraceUnsupported("a condition returned something that is not a traced column")
+            raise TraceUnsupported("a condition returned something that is not a traced (N, 1) column (a multi-column "
+                                   "function, e.g. EnsembleCondition as a solver function, runs on the composite path)")
         # a custom loss: callable(residual (N, n_eq), funcs, coords) -> scalar (solvers.py:216-226; the solver passes
         # loss_fn + additional_loss as ONE callable) traced to the per-point term whose batch mean it is
         loss_term = None
@@ -167,6 +175,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
                                        len(nets), widen=widen, allow_lap=allow_lap, unify=unify, loss=loss,
                                        loss_term=loss_term)
     program.n_metrics = len(metric_terms)        # the last n_metrics "functions" are per-point metric terms
+    program.unique_nets = nets                   # distinct modules, in first-appearance order: one parameter set each
     return program, descs
 
 
@@ -183,6 +192,7 @@ class FusedSystem:
         self.nets, self.conditions, self.n_coords = list(nets), list(conditions), n_coords
         self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val, loss,
                                                 metrics)
+        self.nets = list(self.program.unique_nets)      # a module shared by several functions is ONE parameter set
         # rows of the function-value buffer: the solver's functions, then one per-point term per traced metric
         self.n_eq, self.n_funcs = len(self.program.residuals), len(self.program.funcs)
         self.n_metrics = self.program.n_metrics
@@ -264,10 +274,14 @@ class FusedSystem:
         fk = self.fused_variant(n) if self._self_check else None
         return fk is not None and id(fk) not in self._verified
 
+    select_n = None     # data parallel: the LARGEST shard size of the current batch, identical on every rank, so that all
+    #                     ranks choose -- and verify -- the same closure-kernel build (shard sizes may differ by one point)
+
     def fused_variant(self, n):
         """The closure-kernel build that serves a batch of ``n`` points (None: three-kernel pipeline)."""
         if self.fusedk is None:
             return None
+        n = self.select_n or n
         if n >= self.WIDE_MIN_POINTS and self.prefers_wide(n) and self.fusedk_wide is not False:
             if self.fusedk_wide is None and not self._wide_possible():
                 self.fusedk_wide = False

@@ -380,6 +380,12 @@ class BaseSolver(ABC):
         system = self._fused_system(len(first_batch))
         if system is None:
             return self._run_epoch_composite(key, first_batch)
+        if self.dist is not None:
+            n_all = first_batch[0].shape[0]
+            if n_all < self.dist.world_size and not self.dist.presharded:
+                raise ValueError(f"a batch of {n_all} points cannot be sharded over {self.dist.world_size} ranks")
+            # the largest shard decides which closure-kernel build serves the batch: the same on every rank
+            system.select_n = n_all if self.dist.presharded else -(-n_all // self.dist.world_size)
         nb = self.n_batches[key]
         if self._run_epoch_native(key, system, first_batch):
             return

@@ -635,6 +635,45 @@ def test_closure_based_optimizer_runs_on_the_fused_path():
     assert err < 1e-3 and runs["require"][-1] < runs["require"][0]
 
 
+def test_one_multi_output_network_shared_by_several_conditions():
+    """The reference's single_net / ith_unit mode (ode.py:276-280, conditions.py:54-55): ``nets=[net, net]`` with
+    ``set_impose_on`` -- ONE parameter set, one stream array, one gradient on the fused path (shared networks
+    were treated as two), also under weight decay, where a duplicated parameter set would decay twice."""
+    from neurodiffeq_amd import diff, autograd_ops
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.optim import FusedAdam
+    from neurodiffeq_amd.solvers import Solver1D
+    runs = {}
+    for mode in ("require", "off"):
+        torch.manual_seed(0)
+        net = FCNN(1, 2, hidden_units=(32, 32)).to("cuda")
+        conds = [IVP(0.0, 1.5), IVP(0.0, 1.0)]
+        with pytest.warns(DeprecationWarning):
+            conds[0].set_impose_on(0)
+            conds[1].set_impose_on(1)
+        opt = FusedAdam(net.parameters(), lr=1e-3, weight_decay=1e-2) if mode == "require" else \
+            torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-2)
+        solver = Solver1D(lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)], conds, t_min=0.1, t_max=4.0,
+                          nets=[net, net], optimizer=opt, n_batches_valid=0)
+        solver.fused = mode
+        autograd_ops.set_native_autograd(mode == "require")
+        try:
+            torch.manual_seed(3)
+            for _ in range(5):
+                solver.run_train_epoch()
+        finally:
+            autograd_ops.set_native_autograd(True)
+        assert solver.fused_active == (mode == "require")
+        if mode == "require":
+            assert len(solver._fused_sys.flat) == 1 and solver._fused_sys.descs[0].n_out == 2
+        runs[mode] = (np.array(solver.metrics_history["train_loss"]), R.get_flat([net]).cpu().numpy())
+    errs = dict(loss=float(np.max(np.abs(runs["require"][0] - runs["off"][0]) / np.abs(runs["off"][0]))),
+                params=rel_l2(runs["require"][1], runs["off"][1]))
+    diag("shared_net", errs)
+    assert errs["loss"] < 2e-5 and errs["params"] < 1e-5, errs
+
+
 def test_sobolev_loss_fused_for_first_and_second_order_systems():
     """loss_fn = 'h1' (losses.py:17-26): first-order systems trace with second-order streams, second-order PDEs with
     third-order streams (ndq_mlp_desc.mask3); both follow the autograd path's trajectory.  A fourth-order requirement
