@@ -392,7 +392,11 @@ def main():
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("NDQ_BENCH_BACKEND", "nccl")   # "gloo": dry runs of the N > 1 path with several ranks on ONE GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from neurodiffeq_amd.generators import Generator2D, ResidentBatchGenerator
