@@ -3,6 +3,9 @@
 #include <vector>
 #include "ndq_launch.h"
 #include "ndq_sample.h"
+#include "ndq_oneshot.h"
+
+extern "C" int ndq_oneshot_allreduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, void* stream);
 
 namespace ndq {
 
@@ -275,6 +278,107 @@ __global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) {
   reduce_tail_body(a);
 }
 
+// Data parallel with the one-shot exchange (ndq_oneshot.h): the SAME launch also carries the all-reduce.  Every
+// workgroup reduces its 64 gradient columns (and the loss) locally, pushes that slice [64 gradients | loss] into every
+// rank's inbox, waits for the slices of all ranks, adds them in rank order and applies best-snapshot + Adam to its
+// columns -- a data-parallel training epoch is two launches, like a single-GPU one.  Inbox slice of workgroup b:
+// floats [65 b, 65 b + 65) of the parity's per-rank vector; flag (parity, source rank, b).
+__global__ __launch_bounds__(1024) void reduce_tail_dp_kernel(ReduceTailArgs a, ndq::OneshotDev c, unsigned step) {
+  __shared__ float sm[16 * 64];
+  __shared__ float smw[16];
+  __shared__ float sloss;
+  const int tid = threadIdx.x, col = tid & 63, rg = tid >> 6, blk = blockIdx.x;
+  const int i = blk * 64 + col;
+  const bool incol = i < a.r.len;
+  float lp = 0.f;
+  for (int r = tid; r < a.r.nlparts; r += 1024) lp += a.r.lpart[r];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (incol) {
+    const float* __restrict__ part = a.r.part;
+    const int len = a.r.len, nparts = a.r.nparts;
+    int r = rg;
+    for (; r + 48 < nparts; r += 64) {
+      s0 += part[(size_t)r * len + i];
+      s1 += part[(size_t)(r + 16) * len + i];
+      s2 += part[(size_t)(r + 32) * len + i];
+      s3 += part[(size_t)(r + 48) * len + i];
+    }
+    for (; r < nparts; r += 16) s0 += part[(size_t)r * len + i];
+  }
+  const bool upd = (rg == 0) && incol;
+  float pi = 0.f, m0 = 0.f, v0 = 0.f;
+  if (upd) { pi = a.t.p[i]; m0 = a.t.m[i]; v0 = a.t.v[i]; }
+  const float best = a.t.best_loss[a.t.parity];
+  for (int off = 32; off > 0; off >>= 1) lp += __shfl_down(lp, off);
+  if (col == 0) smw[rg] = lp;
+  sm[rg * 64 + col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  // ---- push this workgroup's slice [64 local column sums | local loss] to every rank
+  const int parity = step & 1u;
+  const size_t slot = ((size_t)parity * c.world + c.rank) * c.max_len + (size_t)blk * 65;
+  if (rg == 0) {
+    float g = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g += sm[k * 64 + col];
+    for (int q = 0; q < c.world; ++q)
+      __hip_atomic_store(c.inbox[q] + slot + col, incol ? g : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (col == 0) {
+      float loss = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) loss += smw[w];
+      loss *= a.r.lscale;
+      for (int q = 0; q < c.world; ++q)
+        __hip_atomic_store(c.inbox[q] + slot + 64, loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < c.world) {
+    unsigned* f = c.flags[tid] + ((size_t)parity * c.world + c.rank) * c.max_blocks + blk;
+    __hip_atomic_store(f, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned* mine = c.flags[c.rank] + ((size_t)parity * c.world + tid) * c.max_blocks + blk;
+    unsigned spins = 0;
+    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != step) {
+      if (++spins > ndq::kOneshotSpinLimit) {
+        atomicAdd(c.status, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  // ---- fixed-order sum over the ranks, then the tail on the global values
+  const float* inbox = c.inbox[c.rank] + (size_t)parity * c.world * c.max_len + (size_t)blk * 65;
+  if (tid == 0) {
+    float loss = 0.f;
+    for (int q = 0; q < c.world; ++q)
+      loss += __hip_atomic_load(inbox + (size_t)q * c.max_len + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    sloss = loss;
+  }
+  __syncthreads();
+  const float loss = sloss;
+  const bool better = (a.t.best_flat != nullptr) && (loss < best);
+  if (upd) {
+    float g = 0.f;
+    for (int q = 0; q < c.world; ++q)
+      g += __hip_atomic_load(inbox + (size_t)q * c.max_len + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    a.r.out[i] = g;
+    if (better) a.t.best_flat[i] = pi;
+    float gi = g;
+    if (a.t.wd != 0.f) gi = fmaf(a.t.wd, pi, gi);
+    const float mi = fmaf(a.t.b1, m0, (1.f - a.t.b1) * gi);
+    const float vi = fmaf(a.t.b2, v0, (1.f - a.t.b2) * gi * gi);
+    a.t.m[i] = mi;
+    a.t.v[i] = vi;
+    a.t.p[i] = pi - (a.t.lr / a.t.bc1) * (mi / (sqrtf(vi) / a.t.bc2s + a.t.eps));
+  }
+  if (blk == 0 && tid == 0 && a.t.write_scalars) {
+    *a.r.lout = loss;
+    a.t.loss_hist[a.t.hist_index] = loss;
+    a.t.best_loss[a.t.parity ^ 1] = better ? loss : best;
+  }
+}
+
 // the same for the 2..4 networks behind one multi-network closure launch, in ONE launch: blockIdx.y = network
 struct ReduceTailMultiArgs {
   ReduceTailArgs net[4];
@@ -388,6 +492,10 @@ int ndq_epoch_tail(float* params, const float* grad, float* exp_avg, float* exp_
   return (int)hipGetLastError();
 }
 
+static void fill_reduce_tail(ReduceTailArgs& a, const ndq_fused_step* s, const float* loss_partials, int blocks, float seed,
+                             float* loss_hist, float* best_loss, int adam_step, int hist_index, int parity,
+                             int write_scalars);
+
 int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_step, int hist_index, int parity,
                        void* stream) {
   if (!s || !s->launch || !coords) return NDQ_EINVAL;
@@ -400,6 +508,18 @@ int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_st
     return ndq_reduce_grad_loss(s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks,
                                 s->loss_slot, s->seed, stream);
   if (adam_step <= 0 || hist_index < 0 || (parity != 0 && parity != 1) || !s->loss_hist || !s->best_loss) return NDQ_EINVAL;
+  if (s->allreduce == reinterpret_cast<ndq_allreduce_fn>(&ndq_oneshot_allreduce) && s->comm &&
+      ((s->n_params + 63) / 64) * 65 <= static_cast<ndq::Oneshot*>(s->comm)->dev.max_len &&
+      (s->n_params + 63) / 64 <= static_cast<ndq::Oneshot*>(s->comm)->dev.max_blocks) {
+    // data parallel over the one-shot exchange: local sums + exchange + tail in ONE launch (reduce_tail_dp_kernel)
+    ndq::Oneshot* c = static_cast<ndq::Oneshot*>(s->comm);
+    ReduceTailArgs a;
+    fill_reduce_tail(a, s, s->loss_partials, s->blocks, s->seed, s->loss_hist, s->best_loss, adam_step, hist_index, parity, 1);
+    const unsigned step = ++c->step;
+    hipLaunchKernelGGL(reduce_tail_dp_kernel, dim3((s->n_params + 63) / 64), dim3(1024), 0, static_cast<hipStream_t>(stream), a,
+                       c->dev, step);
+    return (int)hipGetLastError();
+  }
   if (s->allreduce) {
     // data parallel: local second-stage sums -> ONE all-reduce of [grad | loss] -> tail on the reduced vector
     if (s->loss_slot != s->grad + s->n_params) return NDQ_EINVAL;
@@ -494,8 +614,6 @@ int ndq_sample(const ndq_sampler_desc* desc, unsigned long long seed, unsigned l
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------- one-shot all-reduce
-#include "ndq_oneshot.h"
-
 extern "C" {
 
 int ndq_oneshot_create(int rank, int world, int max_len, void** out, unsigned char* handle64) {

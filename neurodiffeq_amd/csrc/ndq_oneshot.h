@@ -77,7 +77,9 @@ struct Oneshot {
 };
 
 inline size_t oneshot_layout(int world, int max_len, size_t* inbox_bytes, size_t* flag_bytes, int* max_blocks) {
-  *max_blocks = (max_len + kOneshotChunk - 1) / kOneshotChunk;
+  *max_blocks = 1024;      // flags per (parity, source rank): the stand-alone call uses ceil(len / 4096) of them, the fused
+                           // data-parallel tail kernel (ndq_api.hip: reduce_tail_dp_kernel) one per 64 gradient columns
+  if ((max_len + kOneshotChunk - 1) / kOneshotChunk > *max_blocks) *max_blocks = (max_len + kOneshotChunk - 1) / kOneshotChunk;
   *inbox_bytes = ((size_t)2 * world * max_len * sizeof(float) + 255) & ~(size_t)255;
   *flag_bytes = ((size_t)2 * world * *max_blocks * sizeof(unsigned) + 255) & ~(size_t)255;
   return *inbox_bytes + *flag_bytes + 256;
