@@ -3,24 +3,30 @@
 of the 2D Laplace system -- BASELINE.json config C2: Solver2D, FCNN(2-32-32-1, tanh), DirichletBVP2D,
 Generator2D 256x256 = 65 536 noisy-grid points per batch per GPU, fp32 -- through ``Solver2D.run_train_epoch()``.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cX] [--scaling weak|strong]
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per MI355X, RCCL); scaling is WEAK: every rank
+N > 1 is launched by the driver with torch.distributed.run (one rank per MI355X); scaling is WEAK by default: every rank
 trains on its own 65 536-point shard of a global N*65 536-point batch and joins one all-reduce of the flat
-[gradients | loss] vector per step.  A "step" is one ``run_train_epoch()`` with ``n_batches_train=1``,
-``n_batches_valid=0``: two kernel launches -- the single-launch closure kernel (forward streams + traced pointwise
-stage + reverse pass) and the second-stage sums / device-side epoch tail (loss history, best-network snapshot, fused
-Adam) -- and no host synchronisation.  Inputs are pre-sampled (reference RNG order) and resident in HBM before the
-timed region (``ResidentBatchGenerator``); the figure with host sampling + PCIe upload inside the step is reported
-separately as ``with_host_sampling``, and the one with a fresh batch drawn by the device-side Philox sampler every
-step as ``with_device_sampling``.
+[gradients | loss] vector per step (one-shot exchange through HIP-IPC inboxes, RCCL fallback).  A "step" is one
+``run_train_epoch()`` with ``n_batches_train=1``, ``n_batches_valid=0``: two kernel launches -- the single-launch closure
+kernel (forward streams + traced pointwise stage + reverse pass) and the second-stage sums / [exchange] / device-side
+epoch tail (loss history, best-network snapshot, fused Adam) -- and no host synchronisation.
+
+Timing: W untimed warm-up steps, then windows of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize()
+on both sides (max over ranks), repeated until >= 0.25 s and >= 3 windows have been timed; the MEDIAN window is reported.
+Inputs of the headline ``value`` are pre-sampled (reference RNG order) and resident in HBM before the timed region
+(``ResidentBatchGenerator``); the figure with host sampling + PCIe upload inside the step is reported separately as
+``with_host_sampling`` (like for like with the CPU baseline's full step), the one with a fresh batch drawn by the
+device-side Philox sampler every step as ``with_device_sampling``.
 
 Rank 0 prints ONE JSON line (contract in the task description) including
-  roofline     -- dominant kernel (fused closure kernel): algorithmic GEMM flops / HIP-event launch time vs the fp32
-                  MFMA peak, plus the HBM bytes per launch measured by rocprofv3 --pmc (profiles/traffic_c2.json),
-  kernels      -- the three-kernel pipeline (forward / pointwise / backward) timed the same way, incl. the achieved
-                  HBM GB/s of the standalone pointwise residual kernel,
-  cpu_baseline -- the oracle's port of the reference step (torch CPU autograd) timed on this host.
+  roofline      -- dominant kernel (fused closure kernel): algorithmic GEMM flops / HIP-event launch time vs the fp32
+                   MFMA peak, plus the HBM bytes per launch from calibrated rocprofv3 --pmc passes (profiles/traffic_c2.json),
+  kernels       -- the three-kernel pipeline (forward / pointwise / backward) timed the same way,
+  configs       -- C1, C3, C4, C5 at their BASELINE sizes: ms per step, algorithmic TFLOP/s, fraction of the peak,
+  roofline_pointwise_large -- the standalone pointwise residual kernel at 1 M / 4 M points vs the HBM roofline,
+  cpu_baseline  -- the oracle's port of the reference step (torch CPU autograd) timed on this host: with sampling
+                   (``value``), on a pre-sampled batch, and in fp64; ``speedup_vs_cpu_baseline`` pairs like with like.
 """
 import argparse
 import ctypes

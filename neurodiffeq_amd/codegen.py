@@ -541,7 +541,8 @@ struct PW {{
 }};
 constexpr int kWaves = CFG::BWD_THREADS / 64;
 int fused_blocks(int n) {{
-  const int groups = (n + 63) / 64;
+  constexpr int gp = 16 * ndq::group_tiles<CFG>();
+  const int groups = (n + gp - 1) / gp;
   int b = (groups + kWaves - 1) / kWaves;
   return b > 256 ? 256 : (b < 1 ? 1 : b);
 }}

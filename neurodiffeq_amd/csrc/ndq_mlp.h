@@ -1909,6 +1909,10 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
 // Rows hold [NS][GW] values, GW = 1 for single-output networks, else the output count padded to whole 16-unit blocks
 // (HO): every lane then stores / loads its 4 units of a block unconditionally (the padding entries are exact zeros:
 // zero weight rows and zero bias on the way in, never written by the per-point stage, zero weight rows on the way back).
+// tiles per group: 4 (64 points, every lane of phase 2 carries a point) with one wave per SIMD; the 8-wave build halves the
+// exchange tile to fit the LDS (2 tiles = 32 points: phase 2 runs on half the lanes, but two waves per SIMD issue VALU
+// instructions at about twice the rate of one)
+template <class C> constexpr int group_tiles() { return C::BWD_THREADS == 256 ? 4 : 2; }
 template <class C> constexpr int group_w() { return C::NOUT == 1 ? 1 : C::HO; }
 template <class C> constexpr int group_xs() {
   const int w = C::NS * group_w<C>();
@@ -1933,22 +1937,23 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   constexpr int WAVES = C::BWD_THREADS / 64;
   constexpr int XS = group_xs<C>();
-  const int ngroups = (a.n + 63) >> 6;
+  constexpr int G = group_tiles<C>(), GP = 16 * G;      // tiles / points per group
+  const int ngroups = (a.n + GP - 1) / GP;
   float* stage = lds + C::ldsWeightsEnd(TRAIN) + wave * C::stageFloatsPerWave;
-  float* X = lds + C::ldsWeightsEnd(TRAIN) + WAVES * C::stageFloatsPerWave + wave * (64 * XS);
+  float* X = lds + C::ldsWeightsEnd(TRAIN) + WAVES * C::stageFloatsPerWave + wave * (GP * XS);
   GradAcc<C> acc;
   if constexpr (TRAIN) { acc_zero<C>(acc); acc.bias = nullptr; }
   float lsum = 0.f;
   for (int grp = blockIdx.x * WAVES + wave; grp < ngroups; grp += gridDim.x * WAVES) {
-    const int n = grp * 64 + lane;                       // this lane's point in phase 2
-    const bool valid = n < a.n;
+    const int n = grp * GP + lane;                       // this lane's point in phase 2 (lanes >= GP idle there)
+    const bool valid = n < a.n && lane < GP;
     const int nn = valid ? n : a.n - 1;
     float c[PW::NC];
 #pragma unroll
     for (int d = 0; d < PW::NC; ++d) c[d] = a.coords[(size_t)d * a.ldc + nn];
     // ---- phase 1: forward streams of the 4 tiles -> X
     NDQ_UNROLL(NDQ_GROUP_U1)
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < G; ++t) {
       float x[C::D];
       sfor<C::D>([&](auto d_) {
         constexpr int d = decltype(d_)::value;
@@ -1994,8 +1999,8 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
     // ---- phase 2: the per-point program, one point per lane
     {
       float r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
-      float* row = X + lane * XS;
-      PW::apply(c, row, valid ? a.seed : 0.f, TRAIN ? 1 : 0, r, f, row);
+      float* row = X + (lane < GP ? lane : 0) * XS;
+      if (lane < GP) PW::apply(c, row, valid ? a.seed : 0.f, TRAIN ? 1 : 0, r, f, row);
       if (valid) {
         lsum += PW::loss(r);
         if (a.resid) {
@@ -2015,8 +2020,8 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
       // ---- phase 3: forward with kept states + reverse pass, tile by tile (seed = 0 for padding points: their rows
       // hold zero adjoints)
       NDQ_UNROLL(NDQ_GROUP_U3)
-      for (int t = 0; t < 4; ++t) {
-        if ((grp * 4 + t) * 16 >= a.n) break;            // whole tile is padding (uniform over the wave)
+      for (int t = 0; t < G; ++t) {
+        if ((grp * G + t) * 16 >= a.n) break;            // whole tile is padding (uniform over the wave)
         float x[C::D];
         sfor<C::D>([&](auto d_) {
           constexpr int d = decltype(d_)::value;
@@ -2065,7 +2070,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
 template <class C> constexpr size_t group_lds_bytes(bool train) {
   const int waves = C::BWD_THREADS / 64;
   const int pp = (C::P + 3) & ~3;
-  const int work = waves * (C::stageFloatsPerWave + 64 * group_xs<C>());
+  const int work = waves * (C::stageFloatsPerWave + 16 * group_tiles<C>() * group_xs<C>());
   const int red = train ? bwd_regions<C>(waves) * pp : 0;          // overlays the staging + exchange tiles at the end
   return sizeof(float) * (C::ldsWeightsEnd(train) + (work > red ? work : red) + 16);
 }

@@ -257,7 +257,7 @@ class FusedSystem:
         """Does csrc/ndq_mlp.h give this shape an 8-wave build at all?  (Cfg::BWD_THREADS: per-wave state of more than 40
         fragment blocks keeps the whole register file, i.e. 4 waves -- no point compiling to find that out)"""
         if codegen.fuse_mode(self.program, self.descs) == "group":
-            return False                   # its LDS exchange tiles (64 points x all streams per wave) fit 4 waves only
+            return os.environ.get("NDQ_GROUP_WIDE", "0") == "1"     # experiment: 8 waves with 32-point groups
         d = self.descs[0]
         nb, layers = d.hidden // 16, d.layers
         ns = self.L.ndq_mlp_num_streams(ctypes.byref(d))
