@@ -75,12 +75,22 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         # a custom loss: callable(residual (N, n_eq), funcs, coords) -> scalar (solvers.py:216-226; the solver passes
         # loss_fn + additional_loss as ONE callable) traced to the per-point term whose batch mean it is
         loss_term = None
+        loss_probe = None
         if callable(loss):
             from .symbolic import SymMat, SymScalar
+            loss_callable = loss
             val = loss(SymMat(res) if res else Sym(g, g.const(0.0)), list(funcs), list(coords))
             if not isinstance(val, SymScalar):
                 raise TraceUnsupported(f"the loss function returned {type(val).__name__}, not a batch mean of traced values")
             loss_term, loss = val.term.i, "custom"
+
+            def loss_probe():
+                """Run the loss callable again on the same traced columns: the node it returns (the graph is hash-consed)
+                differs from the compiled term iff the callable now computes something else -- e.g. a weight that follows
+                ``solver.global_epoch``; such a value is a CONSTANT of the generated kernel."""
+                with trace_scope(g):
+                    again = loss_callable(SymMat(res) if res else Sym(g, g.const(0.0)), list(funcs), list(coords))
+                return isinstance(again, SymScalar) and again.term.i == loss_term
         # metrics: callable(*funcs, *coords) -> scalar (solvers.py:377-379), evaluated as extra per-point function
         # rows whose batch mean is the metric
         metric_terms = []
@@ -175,6 +185,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
                                        len(nets), widen=widen, allow_lap=allow_lap, unify=unify, loss=loss,
                                        loss_term=loss_term)
     program.n_metrics = len(metric_terms)        # the last n_metrics "functions" are per-point metric terms
+    program.loss_probe = loss_probe              # custom losses: "does the callable still trace to the compiled term?"
     program.unique_nets = nets                   # distinct modules, in first-appearance order: one parameter set each
     return program, descs
 

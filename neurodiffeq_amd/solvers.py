@@ -78,6 +78,8 @@ def _default_l2(residual, funcs, coords):
 
 
 class BaseSolver(ABC):
+    LOSS_PROBE_EVERY = 128      # epochs between re-probes of a traced custom loss (see _fused_system)
+
     """See the module docstring; constructor arguments are the reference's (solvers.py:36-140)."""
 
     #: 'auto' -> fused when possible, composite otherwise (with a warning on a GPU); 'require' -> raise if the fused
@@ -157,6 +159,8 @@ class BaseSolver(ABC):
         self._phase = None
         self._fused_sys = None
         self._composite_plain = False   # composite path: plain torch forwards (set when an equation needs order > 2)
+        self._loss_probe_count = 0
+        self._loss_time_dependent = False
         self._fused_key = None
         self._fast_tracks_best = False
         self.dist = None                # optional neurodiffeq_amd.parallel.BatchSharding
@@ -326,6 +330,8 @@ class BaseSolver(ABC):
             loss_kind = "custom"
         if _requires_closure(self.optimizer) and self.dist is not None:
             reason = "closure-based optimizer under data parallelism"
+        if self._loss_time_dependent:
+            reason = "epoch-dependent loss function"
         key = (id(self.diff_eqs), tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions),
                getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind,
                id(self.loss_fn) if loss_kind == "custom" else None,
@@ -335,7 +341,31 @@ class BaseSolver(ABC):
             # scalar tensors captured by the equations are constants of the generated kernel: re-trace when one of them
             # was modified in place since (callbacks annealing a coefficient between epochs)
             if sysm is None or all(t._version == v for t, v in sysm.program.g.captured):
-                return sysm
+                # a traced loss_fn / additional_loss is frozen into the generated kernel; callables that follow solver
+                # state (a penalty weight annealed with self.global_epoch, ...) are re-probed on their second use and
+                # then every LOSS_PROBE_EVERY epochs: if they now trace to a different term, the solver leaves the fused
+                # path (loudly) rather than train on a stale loss
+                probe = getattr(sysm.program, "loss_probe", None) if sysm is not None else None
+                if probe is None:
+                    return sysm
+                self._loss_probe_count += 1
+                if self._loss_probe_count != 1 and self._loss_probe_count % self.LOSS_PROBE_EVERY:
+                    return sysm
+                try:
+                    same = probe()
+                except Exception:       # noqa: BLE001 -- whatever the callable does now, it is not what was compiled
+                    same = False
+                if same:
+                    return sysm
+                self._fused_key, self._fused_sys = key, None
+                reason = ("the loss function / additional_loss changed between epochs (it depends on solver or Python state, "
+                          "which a traced kernel freezes)")
+                if self.fused == "require":
+                    raise _lib.NdqError(f"fused='require' but the system is outside the fused path: {reason}")
+                warnings.warn(f"neurodiffeq_amd: this solver is NOT on the fused MI355X path any more ({reason}); it runs "
+                              "the reference's closure on torch autograd instead.", RuntimeWarning)
+                self._loss_time_dependent = True
+                return None
         self._fused_key, self._fused_sys = key, None
         if reason is None:
             try:

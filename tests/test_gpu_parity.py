@@ -582,6 +582,32 @@ def test_custom_loss_additional_loss_and_metrics_stay_on_the_fused_path():
     assert errs["loss"] < 2e-5 and errs["energy"] < 2e-5 and errs["mean_u"] < 2e-5 and errs["params"] < 1e-5, errs
 
 
+def test_epoch_dependent_custom_loss_leaves_the_fused_path_loudly():
+    """A traced loss is frozen into the generated kernel.  A callable that follows solver state (here: a penalty weight
+    that grows with ``solver.global_epoch``) is re-probed on its second use and periodically afterwards; when it traces
+    to a different term the solver warns and continues on the reference's closure -- and therefore matches a run that
+    never used the fused path."""
+    from tests import configs
+
+    def run(mode):
+        torch.manual_seed(0)
+        solver, cfg = configs.make_solver("c2", 8)
+        solver.loss_fn = lambda r, f, x: (r ** 2).mean() * (1.0 + 0.5 * solver.global_epoch)
+        solver.fused = mode
+        torch.manual_seed(4)
+        if mode == "auto":
+            with pytest.warns(RuntimeWarning, match="changed between epochs"):
+                for _ in range(4):
+                    solver.run_train_epoch()
+            assert not solver.fused_active
+        else:
+            for _ in range(4):
+                solver.run_train_epoch()
+        return np.array(solver.metrics_history["train_loss"])
+    got, want = run("auto"), run("off")
+    assert np.allclose(got, want, rtol=2e-5), (got, want)
+
+
 def test_loss_outside_the_traced_family_falls_back_loudly():
     """A loss the tracer cannot express (batch sum) or user code that does something a traced column cannot: under
     fused='auto' the solver takes the composite path with a RuntimeWarning that names the cost; 'require' raises."""
