@@ -195,6 +195,33 @@ typedef int (*ndq_pointwise_fn)(const float* coords, int ldc, int n, const float
                                 float seed_scale, void* stream);
 typedef int (*ndq_pw_blocks_fn)(int n);
 
+/* ---- fp64 variants (libndq64.so) ------------------------------------------------------------------------------------
+ * The reference's default precision is fp64 (neurodiffeq/__init__.py:22, utils.py:10-41).  libndq64.so carries the SAME
+ * stream kernels compiled for double (csrc/ndq_mlp.h with NDQ_F64: per-point GEMMs on v_mfma_f64_16x16x4_f64, no bf16
+ * splitting, libm transcendentals) behind entry points of the same meaning; every float buffer is a double buffer.  It
+ * serves the torch custom-op seam (neurodiffeq_amd/autograd_ops.py) for fp64 networks: FCNN.forward `networks.py:68-70`
+ * + the diff() sweeps `neurodiffeq.py:21-34` + the parameter part of loss.backward() `solvers.py:393`. */
+typedef struct ndq64_mlp_kernels {
+  ndq_mlp_desc desc;
+  int n_streams, n_params;
+  int bwd_waves;
+  int lds_bytes;
+  int (*fwd)(const double* coords, int ldc, int n, const double* params, double* jets, int ldj, void* stream);
+  int (*bwd)(const double* coords, int ldc, int n, const double* params, const double* gbar, int ldj, double* partials,
+             int blocks, void* stream);
+} ndq64_mlp_kernels;
+int ndq64_mlp_register(const ndq64_mlp_kernels* kernels);
+int ndq64_mlp_supported(const ndq_mlp_desc* desc);
+int ndq64_mlp_num_streams(const ndq_mlp_desc* desc);
+int ndq64_mlp_num_params(const ndq_mlp_desc* desc);
+int ndq64_mlp_bwd_blocks(const ndq_mlp_desc* desc, int n);
+int ndq64_mlp_jet_fwd(const ndq_mlp_desc* desc, const double* coords, int ldc, int n, const double* params, double* jets,
+                      int ldj, void* stream);
+int ndq64_mlp_jet_bwd(const ndq_mlp_desc* desc, const double* coords, int ldc, int n, const double* params,
+                      const double* gbar, int ldj, double* partials, void* stream);
+int ndq64_reduce_partials(const double* partials, int nparts, int len, double* out, int accumulate, double scale,
+                          void* stream);
+
 /* ---- one-shot all-reduce of the small [gradient | loss] message (data-parallel training) ------------
  * Every rank writes its vector straight into every peer's inbox (fine-grained device memory shared through HIP IPC; on
  * MI355X one xGMI hop to each of the 7 peers) and adds up the world_size vectors it received, in rank order: ONE

@@ -100,6 +100,40 @@ def lib():
     return L
 
 
+_LIB64 = None
+
+
+def lib64():
+    """Load libndq64.so (the fp64 build of the stream kernels: ndq64_* of include/ndq.h), building it first if needed."""
+    global _LIB64
+    if _LIB64 is not None:
+        return _LIB64
+    if _build.is_stale64():
+        try:
+            _build.build_lib64()
+        except Exception as e:  # no hipcc / compile error
+            if not os.path.exists(_build.LIB64):
+                raise NdqError(f"libndq64.so is missing and could not be built: {e}") from e
+    L = ctypes.CDLL(_build.LIB64)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    dp = ctypes.POINTER(MlpDesc)
+    L.ndq64_mlp_supported.argtypes = [dp]
+    L.ndq64_mlp_num_streams.argtypes = [dp]
+    L.ndq64_mlp_num_params.argtypes = [dp]
+    L.ndq64_mlp_bwd_blocks.argtypes = [dp, ci]
+    L.ndq64_mlp_jet_fwd.argtypes = [dp, vp, ci, ci, vp, vp, ci, vp]
+    L.ndq64_mlp_jet_bwd.argtypes = [dp, vp, ci, ci, vp, vp, ci, vp, vp]
+    L.ndq64_reduce_partials.argtypes = [vp, ci, ci, vp, ci, ctypes.c_double, vp]
+    L.ndq64_mlp_register.argtypes = [vp]
+    for name in EXPORTS64:
+        getattr(L, name).restype = ci
+    _LIB64 = L
+    return L
+
+
+EXPORTS64 = ("ndq64_mlp_register", "ndq64_mlp_supported", "ndq64_mlp_num_streams", "ndq64_mlp_num_params",
+             "ndq64_mlp_bwd_blocks", "ndq64_mlp_jet_fwd", "ndq64_mlp_jet_bwd", "ndq64_reduce_partials")
+
 EXPORTS = ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks", "ndq_mlp_jet_fwd",
            "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss", "ndq_epoch_tail",
            "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run", "ndq_oneshot_create",

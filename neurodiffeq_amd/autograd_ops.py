@@ -91,6 +91,13 @@ def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _entry(dtype):
+    """(library, prefix) serving ``dtype``: libndq.so / ``ndq_`` for fp32, libndq64.so / ``ndq64_`` for fp64."""
+    if dtype == torch.float64:
+        return _lib.lib64(), "ndq64_"
+    return _lib.lib(), "ndq_"
+
+
 def _desc(d, order, hidden, layers, act, n_out, skip=0):
     mask2 = (1 << (d * (d + 1) // 2)) - 1 if order >= 2 else 0
     mask3 = (1 << (d * (d + 1) * (d + 2) // 6)) - 1 if order >= 3 else 0
@@ -105,13 +112,13 @@ def mlp_jet_fwd(coords: torch.Tensor, params: torch.Tensor, n: int, order: int, 
     (C-ABI: ndq_mlp_jet_fwd, include/ndq.h)."""
     d, ld = coords.shape
     desc = _desc(d, order, hidden, layers, act, n_out)
-    L = _lib.lib()
-    ns = L.ndq_mlp_num_streams(ctypes.byref(desc))
+    L, pre = _entry(coords.dtype)
+    ns = getattr(L, pre + "mlp_num_streams")(ctypes.byref(desc))
     if ns <= 0:
-        raise _lib.NdqError(f"no gfx950 kernel for {desc.key()}")
-    jets = torch.empty(ns * n_out, ld, dtype=torch.float32, device=coords.device)
-    _lib.check(L.ndq_mlp_jet_fwd(ctypes.byref(desc), coords.data_ptr(), ld, n, params.data_ptr(), jets.data_ptr(), ld,
-                                 _stream_ptr(coords.device)), "ndq_mlp_jet_fwd")
+        raise _lib.NdqError(f"no gfx950 kernel for {desc.key()} ({coords.dtype})")
+    jets = torch.empty(ns * n_out, ld, dtype=coords.dtype, device=coords.device)
+    _lib.check(getattr(L, pre + "mlp_jet_fwd")(ctypes.byref(desc), coords.data_ptr(), ld, n, params.data_ptr(),
+                                               jets.data_ptr(), ld, _stream_ptr(coords.device)), pre + "mlp_jet_fwd")
     return jets
 
 
@@ -128,18 +135,18 @@ def mlp_jet_bwd(coords: torch.Tensor, params: torch.Tensor, gbar: torch.Tensor, 
     (C-ABI: ndq_mlp_jet_bwd + ndq_reduce_partials; fixed summation order, run-to-run bit-identical)."""
     d, ld = coords.shape
     desc = _desc(d, order, hidden, layers, act, n_out)
-    L = _lib.lib()
-    blocks = L.ndq_mlp_bwd_blocks(ctypes.byref(desc), n)
-    P = L.ndq_mlp_num_params(ctypes.byref(desc))
+    L, pre = _entry(coords.dtype)
+    blocks = getattr(L, pre + "mlp_bwd_blocks")(ctypes.byref(desc), n)
+    P = getattr(L, pre + "mlp_num_params")(ctypes.byref(desc))
     if blocks <= 0 or P != params.numel():
         raise _lib.NdqError(f"no gfx950 kernel for {desc.key()} / parameter count mismatch ({P} vs {params.numel()})")
     stream = _stream_ptr(coords.device)
-    partials = torch.empty(blocks, P, dtype=torch.float32, device=coords.device)
-    _lib.check(L.ndq_mlp_jet_bwd(ctypes.byref(desc), coords.data_ptr(), ld, n, params.data_ptr(), gbar.data_ptr(), ld,
-                                 partials.data_ptr(), stream), "ndq_mlp_jet_bwd")
-    grad = torch.empty(P, dtype=torch.float32, device=coords.device)
-    _lib.check(L.ndq_reduce_partials(partials.data_ptr(), blocks, P, grad.data_ptr(), 0, 1.0, stream),
-               "ndq_reduce_partials")
+    partials = torch.empty(blocks, P, dtype=coords.dtype, device=coords.device)
+    _lib.check(getattr(L, pre + "mlp_jet_bwd")(ctypes.byref(desc), coords.data_ptr(), ld, n, params.data_ptr(),
+                                               gbar.data_ptr(), ld, partials.data_ptr(), stream), pre + "mlp_jet_bwd")
+    grad = torch.empty(P, dtype=coords.dtype, device=coords.device)
+    _lib.check(getattr(L, pre + "reduce_partials")(partials.data_ptr(), blocks, P, grad.data_ptr(), 0, 1.0, stream),
+               pre + "reduce_partials")
     return grad
 
 
@@ -157,7 +164,7 @@ class MlpJet(torch.autograd.Function):
         d, order, hidden, layers, act, n_out = spec
         n = X.shape[0]
         ld = _round_up(n, 64)
-        coords = torch.zeros(d, ld, dtype=torch.float32, device=X.device)
+        coords = torch.zeros(d, ld, dtype=X.dtype, device=X.device)
         coords[:, :n] = X.detach().t()
         flat = torch.cat([p.detach().reshape(-1) for p in params])
         jets = torch.ops.ndq.mlp_jet_fwd(coords, flat, n, order, hidden, layers, act, n_out)
@@ -195,7 +202,7 @@ class MlpJet(torch.autograd.Function):
                     if n_out > 1:
                         t = t.sum(dim=1, keepdim=True)
                     tot = t if tot is None else tot + t
-                cols.append(tot if tot is not None else torch.zeros(n, 1, dtype=torch.float32, device=coords.device))
+                cols.append(tot if tot is not None else torch.zeros(n, 1, dtype=coords.dtype, device=coords.device))
             return torch.cat(cols, dim=1)
 
         if torch.is_grad_enabled():
@@ -205,7 +212,7 @@ class MlpJet(torch.autograd.Function):
         # the final backward: parameter gradients from ONE adjoint launch over all streams
         grads = [None] * len(ctx.shapes)
         if any(ctx.needs_input_grad[2:]):
-            gbar = torch.zeros(len(streams) * n_out, ld, dtype=torch.float32, device=coords.device)
+            gbar = torch.zeros(len(streams) * n_out, ld, dtype=coords.dtype, device=coords.device)
             for s, g in enumerate(gouts):
                 if g is not None:
                     gbar[s * n_out:(s + 1) * n_out, :n] = g.t()
@@ -228,39 +235,40 @@ class MlpJet(torch.autograd.Function):
 _SPECS = weakref.WeakKeyDictionary()
 
 
-def _spec_for(net, order):
-    """(d, order, hidden, layers, act, n_out) + parameter list if the gfx950 kernels can run ``net``, else None."""
+def _spec_for(net, order, dtype=torch.float32):
+    """(d, order, hidden, layers, act, n_out) + parameter list if the gfx950 kernels can run ``net`` in ``dtype``, else
+    None."""
     cache = _SPECS.setdefault(net, {})
-    hit = cache.get(order)
+    hit = cache.get((order, dtype))
     if hit is not None:
         return hit if hit else None
-    info = describe(net)
+    info = describe(net, dtype=dtype)
     ok = info is not None and info["skip"] == 0 and 1 <= info["d"] <= 3
     if ok:
         from . import codegen
         desc = _desc(info["d"], order, info["hidden"], info["layers"], info["act"], info["n_out"])
         try:
-            ok = bool(codegen.ensure_mlp_kernels(desc))
+            ok = bool(codegen.ensure_mlp_kernels(desc, f64=(dtype == torch.float64)))
         except _lib.NdqError:
             ok = False
-    cache[order] = ((info["d"], order, info["hidden"], info["layers"], info["act"], info["n_out"]), info["params"]) \
-        if ok else False
-    return cache[order] or None
+    cache[(order, dtype)] = ((info["d"], order, info["hidden"], info["layers"], info["act"], info["n_out"]),
+                             info["params"]) if ok else False
+    return cache[(order, dtype)] or None
 
 
 def try_jet_forward(net, t):
     """``net(t)`` through the HIP stream kernels if possible, else None (the caller runs its torch forward)."""
     if not _ENABLED or not isinstance(t, torch.Tensor) or t.device.type not in _DEVICE_TYPES \
-            or t.dtype != torch.float32 or t.dim() != 2:
+            or t.dtype not in (torch.float32, torch.float64) or t.dim() != 2:
         return None
     if t.shape[0] == 0 or torch.jit.is_tracing():
         return None
     want_grad = torch.is_grad_enabled() and t.requires_grad
     order = _MAX_ORDER if want_grad else 0
-    spec = _spec_for(net, order)
+    spec = _spec_for(net, order, t.dtype)
     if spec is None or t.shape[1] != spec[0][0]:
         return None
     params = spec[1]
-    if any(p.device != t.device or p.dtype != torch.float32 for p in params):
+    if any(p.device != t.device or p.dtype != t.dtype for p in params):
         return None
     return MlpJet.apply(t, spec[0], *params)[0]

@@ -817,24 +817,26 @@ def mlp_ext_allowed(desc):
             and desc.skip in (0, 1) and (desc.skip == 0 or desc.n_out == 1))
 
 
-def mlp_ext_source(desc):
+def mlp_ext_source(desc, f64=False):
     header = os.path.join(HERE, "csrc", "ndq_launch.h")
+    record = "ndq64_mlp_kernels" if f64 else "ndq_mlp_kernels"
     return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
+{"#define NDQ_F64 1" if f64 else ""}
 #include "{header}"
 using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u>;
-extern "C" const ndq_mlp_kernels* ndq_ext_kernels(void) {{
-  static const ndq_mlp_kernels k = ndq::make_kernels<CFG>();
+extern "C" const {record}* ndq_ext_kernels(void) {{
+  static const {record} k = ndq::make_kernels<CFG>();
   return &k;
 }}
 """
 
 
-def build_mlp_ext(desc, force=False):
+def build_mlp_ext(desc, force=False, f64=False):
     os.makedirs(JIT_DIR, exist_ok=True)
-    source = mlp_ext_source(desc)
+    source = mlp_ext_source(desc, f64)
     key = _cache_key(source)
-    so = os.path.join(JIT_DIR, f"mlp_{key}.so")
-    src = os.path.join(JIT_DIR, f"mlp_{key}.hip")
+    so = os.path.join(JIT_DIR, f"mlp{'64' if f64 else ''}_{key}.so")
+    src = os.path.join(JIT_DIR, f"mlp{'64' if f64 else ''}_{key}.hip")
     if os.path.exists(so) and not force:
         return so
     with open(src, "w") as fh:
@@ -846,20 +848,23 @@ def build_mlp_ext(desc, force=False):
     return so
 
 
-def ensure_mlp_kernels(desc):
-    """True if libndq.so can serve ``desc`` -- from its table, or after building + registering an extension module."""
+def ensure_mlp_kernels(desc, f64=False):
+    """True if libndq.so (``f64``: libndq64.so) can serve ``desc`` -- from its table, or after building + registering an
+    extension module."""
     from . import _lib
-    L = _lib.lib()
-    if L.ndq_mlp_supported(ctypes.byref(desc)):
+    L = _lib.lib64() if f64 else _lib.lib()
+    supported = L.ndq64_mlp_supported if f64 else L.ndq_mlp_supported
+    register = L.ndq64_mlp_register if f64 else L.ndq_mlp_register
+    if supported(ctypes.byref(desc)):
         return True
-    if not mlp_ext_allowed(desc):
+    if not mlp_ext_allowed(desc) or (f64 and (desc.lap or desc.skip or desc.hidden > 32)):
         return False
-    key = desc.key()
+    key = desc.key() + (("f64",) if f64 else ())
     if key in _MLP_EXT:
         return _MLP_EXT[key] is not None
     _MLP_EXT[key] = None
     try:
-        ext = ctypes.CDLL(build_mlp_ext(desc))
+        ext = ctypes.CDLL(build_mlp_ext(desc, f64=f64))
     except RuntimeError as e:                     # the templates reject this combination: not a supported shape
         import warnings
         warnings.warn(f"could not build an MLP kernel extension for {key}: {str(e)[:400]}")
@@ -867,10 +872,10 @@ def ensure_mlp_kernels(desc):
     except OSError as e:                          # no hipcc / unreadable module: the native path is broken, say so
         raise _lib.NdqError(f"cannot build or load the MLP kernel extension for {key}: {e}") from e
     ext.ndq_ext_kernels.restype = ctypes.c_void_p
-    if L.ndq_mlp_register(ctypes.c_void_p(ext.ndq_ext_kernels())) != 0:
+    if register(ctypes.c_void_p(ext.ndq_ext_kernels())) != 0:
         return False                              # e.g. the shape needs more LDS than a workgroup has
     _MLP_EXT[key] = ext                           # keep the module (and its record) alive
-    return bool(L.ndq_mlp_supported(ctypes.byref(desc)))
+    return bool(supported(ctypes.byref(desc)))
 
 
 def build_fused(program: PointwiseProgram, desc, force=False, threads=None):

@@ -49,23 +49,29 @@ int launch_bwd(const MlpArgs& a, int blocks, hipStream_t s) {
 }
 
 template <class C>
-int kernels_fwd(const float* coords, int ldc, int n, const float* params, float* jets, int ldj, void* stream) {
+int kernels_fwd(const real* coords, int ldc, int n, const real* params, real* jets, int ldj, void* stream) {
   MlpArgs a{};
   a.coords = coords; a.params = params; a.jets = jets; a.n = n; a.ldc = ldc; a.ldj = ldj;
   return launch_fwd<C>(a, static_cast<hipStream_t>(stream));
 }
 
 template <class C>
-int kernels_bwd(const float* coords, int ldc, int n, const float* params, const float* gbar, int ldj, float* partials,
+int kernels_bwd(const real* coords, int ldc, int n, const real* params, const real* gbar, int ldj, real* partials,
                 int blocks, void* stream) {
   MlpArgs a{};
   a.coords = coords; a.params = params; a.gbar = gbar; a.partials = partials; a.n = n; a.ldc = ldc; a.ldj = ldj;
   return launch_bwd<C>(a, blocks, static_cast<hipStream_t>(stream));
 }
 
+#if NDQ_F64
+typedef ndq64_mlp_kernels kernels_record;      // include/ndq.h: the fp64 record (double buffers)
+#else
+typedef ndq_mlp_kernels kernels_record;
+#endif
+
 template <class C>
-ndq_mlp_kernels make_kernels() {
-  ndq_mlp_kernels k{};
+kernels_record make_kernels() {
+  kernels_record k{};
   k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::H, C::L, C::ACT, C::NOUT, C::SS::LAP, C::SKIP,
                         (int)C::SS::M3};
   k.n_streams = C::NS;

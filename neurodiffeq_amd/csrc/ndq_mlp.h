@@ -12,7 +12,7 @@
 //    SIMD with the whole 512-entry register file (the f32 MFMA shares the VALU datapath on gfx950 --
 //    scripts/ubench_mfma_valu.hip -- so a second wave per SIMD only buys the overlap of its bf16 MFMAs and stalls with
 //    the other's VALU work: ~3 % where the state fits twice, see NDQ_BWD_THREADS).
-//  * a "fragment" f32x4 frag[NB] holds, for point p, hidden units 16*b + 4*q + r (b < NB, r < 4) -- exactly the C/D
+//  * a "fragment" real4 frag[NB] holds, for point p, hidden units 16*b + 4*q + r (b < NB, r < 4) -- exactly the C/D
 //    layout of the 16x16 MFMAs with units as rows and points as columns.  The 8 values a lane holds per 32 units are
 //    ALSO a valid B operand of the next layer's MFMA if the contraction runs in the permuted order
 //    slot(kg, e) <-> unit 16*(2c + (e>>2)) + 4*kg + (e&3), so hidden activations never leave registers between
@@ -26,7 +26,7 @@
 //  * "Laplacian stream" (LAP = 1): when the residual needs second derivatives only through their sum, ONE stream
 //    carries sum_a d2/dx_a^2 instead of one stream per coordinate.
 //  * all reductions are fixed-order: DPP row rotations / lane shuffles -> per-wave LDS regions -> workgroup ->
-//    partials[block][P] in HBM -> second-stage kernel.  No float atomics across waves.
+//    partials[block][P] in HBM -> second-stage kernel.  No real atomics across waves.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <utility>
@@ -34,7 +34,33 @@
 
 namespace ndq {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// The scalar type of the kernels: fp32 (the product path, north_star) or -- NDQ_F64, built into libndq64.so for the
+// torch custom-op seam -- fp64, the reference's default precision (neurodiffeq/__init__.py:22).  In the fp64 build
+// every per-point GEMM runs on v_mfma_f64_16x16x4_f64 (same operand layout as the f32 16x16x4), the bf16x3 paths are
+// compiled out, transcendental functions come from libm.
+#ifndef NDQ_F64
+#define NDQ_F64 0
+#endif
+#if NDQ_F64
+typedef double real;
+#else
+typedef float real;
+#endif
+typedef real real4 __attribute__((ext_vector_type(4)));
+
+#if NDQ_F64
+__device__ __forceinline__ real rfma(real a, real b, real c) { return fma(a, b, c); }
+#else
+__device__ __forceinline__ real rfma(real a, real b, real c) { return fmaf(a, b, c); }
+#endif
+// D (16 x 16, 4 values per lane) += A (16 x 4) B (4 x 16): one value of A and of B per lane
+__device__ __forceinline__ real4 mfma16x16x4(real a, real b, real4 c) {
+#if NDQ_F64
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------ phase timestamps
 // Experiments only (-DNDQ_PHASE_TS via NDQ_JIT_FLAGS; scripts/phase_ts.py): thread 0 of every workgroup records the
@@ -254,59 +280,73 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 // tanh z = 1 - 2 / (2^(2 z log2 e) + 1): one v_exp_f32 + one v_rcp_f32 (both ~1 ulp).  Absolute error <= ~1.5e-7
 // over the whole range (saturates correctly: e -> inf gives 1, e -> 0 gives -1); the libm tanhf costs ~10x the
 // VALU issue slots, and the VALU is what competes with the MFMA pipe in these kernels.
-__device__ __forceinline__ float tanh_fast(float z) {
-  const float e = __builtin_amdgcn_exp2f(z * 2.88539008177792681472f);
-  return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+__device__ __forceinline__ real tanh_fast(real z) {
+#if NDQ_F64
+  return tanh(z);
+#else
+  const real e = __builtin_amdgcn_exp2f(z * 2.88539008177792681472f);
+  return rfma(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+#endif
 }
 
 template <int ACT> struct Act;
 template <> struct Act<ACT_TANH> {  // nn.Tanh, networks.py:27 default
-  static __device__ __forceinline__ void fwd(float z, float& t, float& c) {
-#if NDQ_FAST_TANH
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c) {
+#if NDQ_FAST_TANH || NDQ_F64
     t = tanh_fast(z);
 #else
     t = tanhf(z);
 #endif
     c = 0.f;
   }
-  static __device__ __forceinline__ float s1(float t, float) { return fmaf(-t, t, 1.f); }
-  static __device__ __forceinline__ float s2(float t, float, float s1v) { return -2.f * t * s1v; }
-  static __device__ __forceinline__ float s3(float t, float, float s1v) { return -2.f * s1v * fmaf(-3.f * t, t, 1.f); }
+  static __device__ __forceinline__ real s1(real t, real) { return rfma(-t, t, 1.f); }
+  static __device__ __forceinline__ real s2(real t, real, real s1v) { return -2.f * t * s1v; }
+  static __device__ __forceinline__ real s3(real t, real, real s1v) { return -2.f * s1v * rfma(-3.f * t, t, 1.f); }
   // fourth derivative: -2 s2 (1 - 3 t^2) + 12 t s1^2 with s2 = -2 t s1
-  static __device__ __forceinline__ float s4(float t, float, float s1v) {
-    return 4.f * t * s1v * fmaf(-3.f * t, t, 1.f) + 12.f * t * s1v * s1v;
+  static __device__ __forceinline__ real s4(real t, real, real s1v) {
+    return 4.f * t * s1v * rfma(-3.f * t, t, 1.f) + 12.f * t * s1v * s1v;
   }
 };
 template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
-  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { sincosf(z, &t, &c); }
-  static __device__ __forceinline__ float s1(float, float c) { return c; }
-  static __device__ __forceinline__ float s2(float t, float, float) { return -t; }
-  static __device__ __forceinline__ float s3(float, float c, float) { return -c; }
-  static __device__ __forceinline__ float s4(float t, float, float) { return t; }
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c) {
+#if NDQ_F64
+    sincos(z, &t, &c);
+#else
+    sincosf(z, &t, &c);
+#endif
+  }
+  static __device__ __forceinline__ real s1(real, real c) { return c; }
+  static __device__ __forceinline__ real s2(real t, real, real) { return -t; }
+  static __device__ __forceinline__ real s3(real, real c, real) { return -c; }
+  static __device__ __forceinline__ real s4(real t, real, real) { return t; }
 };
 
-__device__ __forceinline__ float sigmoid_fast(float z) {   // 1 / (1 + 2^(-z log2 e)); saturates cleanly to 0 / 1
+__device__ __forceinline__ real sigmoid_fast(real z) {   // 1 / (1 + 2^(-z log2 e)); saturates cleanly to 0 / 1
+#if NDQ_F64
+  return 1.0 / (1.0 + exp(-z));
+#else
   return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+#endif
 }
 template <> struct Act<ACT_SIGMOID> {  // torch.nn.Sigmoid as FCNN(actv=nn.Sigmoid): everything is a polynomial in t
-  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { t = sigmoid_fast(z); c = 0.f; }
-  static __device__ __forceinline__ float s1(float t, float) { return t * (1.f - t); }
-  static __device__ __forceinline__ float s2(float t, float, float s1v) { return s1v * fmaf(-2.f, t, 1.f); }
-  static __device__ __forceinline__ float s3(float, float, float s1v) { return s1v * fmaf(-6.f, s1v, 1.f); }
-  static __device__ __forceinline__ float s4(float t, float, float s1v) {      // s2 (1 - 12 s1)
-    return s1v * fmaf(-2.f, t, 1.f) * fmaf(-12.f, s1v, 1.f);
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c) { t = sigmoid_fast(z); c = 0.f; }
+  static __device__ __forceinline__ real s1(real t, real) { return t * (1.f - t); }
+  static __device__ __forceinline__ real s2(real t, real, real s1v) { return s1v * rfma(-2.f, t, 1.f); }
+  static __device__ __forceinline__ real s3(real, real, real s1v) { return s1v * rfma(-6.f, s1v, 1.f); }
+  static __device__ __forceinline__ real s4(real t, real, real s1v) {      // s2 (1 - 12 s1)
+    return s1v * rfma(-2.f, t, 1.f) * rfma(-12.f, s1v, 1.f);
   }
 };
 // Swish with the default fixed beta = 1 (networks.py:155-175): f = z sigma(z).  State: t = f, c = sigma(z); since
 // z sigma = t the derivatives need no z:  f1 = c + t(1-c),  f2 = (1-c)(2c + t(1-2c)),  f3 = (1-c)(3c(1-2c) + t(1-6c+6c^2))
 template <> struct Act<ACT_SWISH> {
-  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { c = sigmoid_fast(z); t = z * c; }
-  static __device__ __forceinline__ float s1(float t, float c) { return fmaf(t, 1.f - c, c); }
-  static __device__ __forceinline__ float s2(float t, float c, float) {
-    return (1.f - c) * fmaf(t, fmaf(-2.f, c, 1.f), 2.f * c);
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c) { c = sigmoid_fast(z); t = z * c; }
+  static __device__ __forceinline__ real s1(real t, real c) { return rfma(t, 1.f - c, c); }
+  static __device__ __forceinline__ real s2(real t, real c, real) {
+    return (1.f - c) * rfma(t, rfma(-2.f, c, 1.f), 2.f * c);
   }
-  static __device__ __forceinline__ float s3(float t, float c, float) {
-    return (1.f - c) * fmaf(t, fmaf(6.f * c, c - 1.f, 1.f), 3.f * c * fmaf(-2.f, c, 1.f));
+  static __device__ __forceinline__ real s3(real t, real c, real) {
+    return (1.f - c) * rfma(t, rfma(6.f * c, c - 1.f, 1.f), 3.f * c * rfma(-2.f, c, 1.f));
   }
 };
 
@@ -314,18 +354,18 @@ template <> struct Act<ACT_SWISH> {
 // State: t = f, c = z (z cannot be recovered from f and tanh z where 1 + tanh z underflows); with T = tanh z
 //   f1 = (1 + T)/2 + z (1 - T^2)/2,  f2 = (1 - T^2)(1 - z T),  f3 = (1 - T^2)(3 z T^2 - 3 T - z)
 template <> struct Act<ACT_APTX> {
-  static __device__ __forceinline__ void fwd(float z, float& t, float& c) { c = z; t = 0.5f * z * (1.f + tanh_fast(z)); }
-  static __device__ __forceinline__ float s1(float, float z) {
-    const float T = tanh_fast(z);
-    return 0.5f * fmaf(z, fmaf(-T, T, 1.f), 1.f + T);
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c) { c = z; t = 0.5f * z * (1.f + tanh_fast(z)); }
+  static __device__ __forceinline__ real s1(real, real z) {
+    const real T = tanh_fast(z);
+    return 0.5f * rfma(z, rfma(-T, T, 1.f), 1.f + T);
   }
-  static __device__ __forceinline__ float s2(float, float z, float) {
-    const float T = tanh_fast(z);
-    return fmaf(-T, T, 1.f) * fmaf(-z, T, 1.f);
+  static __device__ __forceinline__ real s2(real, real z, real) {
+    const real T = tanh_fast(z);
+    return rfma(-T, T, 1.f) * rfma(-z, T, 1.f);
   }
-  static __device__ __forceinline__ float s3(float, float z, float) {
-    const float T = tanh_fast(z);
-    return fmaf(-T, T, 1.f) * fmaf(3.f * z * T, T, fmaf(-3.f, T, -z));
+  static __device__ __forceinline__ real s3(real, real z, real) {
+    const real T = tanh_fast(z);
+    return rfma(-T, T, 1.f) * rfma(3.f * z * T, T, rfma(-3.f, T, -z));
   }
 };
 
@@ -344,7 +384,7 @@ struct Cfg {
   // workgroup sizes: 8 waves (2 per SIMD, <= 256 registers each) when the per-wave state fits, else 4 waves with the
   // whole 512-entry register file per wave
   static constexpr int BWD_THREADS =
-      (NB_ * NB_ * (L_ - 1) + NB_ * SS::NS * L_ + (NOUT_ > 1 ? NB_ * NBO : 0) > 40) ? 256 : NDQ_BWD_THREADS;
+      (NDQ_F64 || NB_ * NB_ * (L_ - 1) + NB_ * SS::NS * L_ + (NOUT_ > 1 ? NB_ * NBO : 0) > 40) ? 256 : NDQ_BWD_THREADS;
   static constexpr int FWD_THREADS = (NB_ >= 4) ? 256 : NDQ_FWD_THREADS;
   // flat parameter offsets, torch order: W1 (H,D) b1 (H) | W_l (H,H) b_l (H), l = 2..L | Wout (1,H) bout (1)
   static constexpr int offW1 = 0, offb1 = H * D;
@@ -362,7 +402,7 @@ struct Cfg {
   static constexpr int ldsW1T = 0, ldsb1 = D * H;
   static constexpr int ldsLayer0 = D * H + H;
   // hidden GEMM operand format: bf16x3 planes (3 x 2 B per weight) when the width is a multiple of 32, else f32
-  static constexpr bool BF16 = (NDQ_BF16X3 != 0) && (NB_ % 2 == 0);
+  static constexpr bool BF16 = (NDQ_BF16X3 != 0) && (NB_ % 2 == 0) && (NDQ_F64 == 0);
   static constexpr int NC = NB_ / 2;                       // K-chunks of 32 contraction slots (bf16 path)
   static constexpr int WEL = BF16 ? (H * H * 3) / 2 : H * H;   // floats of LDS per weight matrix image
   // multi-output networks: the output layer (HO x H, zero-padded rows) runs on the bf16 matrix core as well when its
@@ -403,11 +443,11 @@ struct Cfg {
 };
 
 struct MlpArgs {
-  const float* coords;   // [D][ldc]  SoA collocation coordinates
-  const float* params;   // [P] flat, torch parameter order
-  const float* gbar;     // bwd: [NS][NOUT][ldj] adjoint of every output stream
-  float* jets;           // fwd: [NS][NOUT][ldj] output streams of the raw network
-  float* partials;       // bwd: [gridDim.x][P] per-workgroup parameter-gradient partial sums
+  const real* coords;   // [D][ldc]  SoA collocation coordinates
+  const real* params;   // [P] flat, torch parameter order
+  const real* gbar;     // bwd: [NS][NOUT][ldj] adjoint of every output stream
+  real* jets;           // fwd: [NS][NOUT][ldj] output streams of the raw network
+  real* partials;       // bwd: [gridDim.x][P] per-workgroup parameter-gradient partial sums
   int n;                 // number of points
   int ldc;               // leading dimension of coords
   int ldj;               // leading dimension of jets / gbar
@@ -415,7 +455,7 @@ struct MlpArgs {
 
 // ------------------------------------------------------------------------------------------------ weight staging
 template <class C, bool BWD>
-__device__ __forceinline__ void stage_weights(float* lds, const float* __restrict__ prm) {
+__device__ __forceinline__ void stage_weights(real* lds, const real* __restrict__ prm) {
   constexpr int H = C::H, D = C::D, NB = C::NB;
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int i = tid; i < D * H; i += nt) {  // W1T[a][j] = W1[j][a]
@@ -433,14 +473,14 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
     // bf16x3 planes of the zero-padded output matrix Wo [HO][H] in bf16 fragment order (same index scheme as the
     // hidden layers below): forward image = A operand of (ob = 16-row output block, c = chunk of 32 hidden units),
     // transposed image = A operand of (kb = 16 hidden units, c = chunk of 32 output rows)
-    const float* Wo = prm + C::offWout;
+    const real* Wo = prm + C::offWout;
     __bf16* wf = reinterpret_cast<__bf16*>(lds + C::ldsWout(BWD));
     __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWoutT());
     for (int i = tid; i < C::HO * H; i += nt) {
       const int j = i / H, k = i - j * H;
-      const float w = j < C::NOUT ? Wo[i] : 0.f;
-      const __bf16 w0 = (__bf16)w; const float r1 = w - (float)w0;
-      const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (float)w1);
+      const real w = j < C::NOUT ? Wo[i] : 0.f;
+      const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
+      const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
       {
         const int blk = (j >> 4) * C::NC + (k >> 5);
         const int base = ((blk * 3) * 64 + (j & 15) + 16 * ((k & 15) >> 2)) * 8 + 4 * ((k & 31) >> 4) + (k & 3);
@@ -455,7 +495,7 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
     for (int i = tid; i < C::HO; i += nt) lds[C::ldsbout(BWD) + i] = i < C::NOUT ? prm[C::offbout + i] : 0.f;
   } else {
     constexpr int NBO = C::NBO;
-    const float* Wo = prm + C::offWout;  // [NOUT][H], rows >= NOUT are zero padding
+    const real* Wo = prm + C::offWout;  // [NOUT][H], rows >= NOUT are zero padding
     for (int i = tid; i < C::HO * H; i += nt) {
       const int lane = i & 63, t = (i >> 6) & 3, blk = i >> 8;
       {  // forward A operand of block (ob, kb): blk = ob*NB + kb:  A[i'][q'] = Wo[16 ob + i'][16 kb + 4 q' + t]
@@ -477,14 +517,14 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
     // index in bf16 units: ((((ob*NC + c)*3 + pl)*64 + lane)*8 + e
 #pragma unroll
     for (int l = 2; l <= C::L; ++l) {
-      const float* W = prm + C::offW(l);
+      const real* W = prm + C::offW(l);
       __bf16* wf = reinterpret_cast<__bf16*>(lds + C::ldsWf(l, BWD));
       __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWt(l));
       for (int i = tid; i < H * H; i += nt) {   // one coalesced pass over W[j][k] (out j, in k): split once, scatter twice
         const int j = i / H, k = i - j * H;
-        const float w = W[i];
-        const __bf16 w0 = (__bf16)w; const float r1 = w - (float)w0;
-        const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (float)w1);
+        const real w = W[i];
+        const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
+        const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
         {  // forward image: block (ob = j/16, c = k/32), lane (j%16, kg = (k%16)/4), slot e = 4*((k%32)/16) + k%4
           const int blk = (j >> 4) * C::NC + (k >> 5);
           const int base = ((blk * 3) * 64 + (j & 15) + 16 * ((k & 15) >> 2)) * 8 + 4 * ((k & 31) >> 4) + (k & 3);
@@ -501,7 +541,7 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
   } else
 #pragma unroll
   for (int l = 2; l <= C::L; ++l) {
-    const float* W = prm + C::offW(l);
+    const real* W = prm + C::offW(l);
     for (int i = tid; i < H * H; i += nt) {
       const int lane = i & 63, t = (i >> 6) & 3, blk = i >> 8;  // blk = first*NB + second
       const int b0 = blk / NB, b1 = blk - b0 * NB;
@@ -514,7 +554,7 @@ __device__ __forceinline__ void stage_weights(float* lds, const float* __restric
   }
 }
 
-__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ real4 lds4(const real* p) { return *reinterpret_cast<const real4*>(p); }
 
 // An offset of zero the optimiser cannot see through.  Added to the LDS base once per tile it keeps the (loop-invariant)
 // weight reads inside the tile loop.  Wide nets only: there the hoisted reads would occupy hundreds of registers for
@@ -530,9 +570,9 @@ __device__ __forceinline__ int opaque_zero() {
 // hidden-unit state of one layer for one tile
 template <class C>
 struct LayerState {
-  float t[C::NB][4];                 // sigma(z)
-  float c[C::NB][4];                 // second state value: cos(z) for sin, sigma(z) for swish, z for aptx; unused (dead) otherwise
-  f32x4 z[C::NS][C::NB];             // pre-activation derivative streams (index 0 unused: value is in t)
+  real t[C::NB][4];                 // sigma(z)
+  real c[C::NB][4];                 // second state value: cos(z) for sin, sigma(z) for swish, z for aptx; unused (dead) otherwise
+  real4 z[C::NS][C::NB];             // pre-activation derivative streams (index 0 unused: value is in t)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -544,15 +584,15 @@ struct Planes {
 
 // streams of h = sigma(z) from the layer state:  h0 = t, h_a = s1 z_a, h_ab = s2 z_a z_b + s1 z_ab
 template <class C>
-__device__ __forceinline__ void act_forward(const LayerState<C>& st, f32x4 (&h)[C::NS][C::NB]) {
+__device__ __forceinline__ void act_forward(const LayerState<C>& st, real4 (&h)[C::NS][C::NB]) {
   using SS = typename C::SS;
   using A = Act<C::ACT>;
 #pragma unroll
   for (int b = 0; b < C::NB; ++b)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float t = st.t[b][r], c = st.c[b][r];
-      const float s1 = A::s1(t, c);
+      const real t = st.t[b][r], c = st.c[b][r];
+      const real s1 = A::s1(t, c);
       h[0][b][r] = t;
       if constexpr (SS::FIRST) {
         sfor<C::D>([&](auto a_) {
@@ -560,29 +600,29 @@ __device__ __forceinline__ void act_forward(const LayerState<C>& st, f32x4 (&h)[
           h[1 + a][b][r] = s1 * st.z[1 + a][b][r];
         });
         if constexpr (SS::LAP) {
-          const float s2 = A::s2(t, c, s1);
-          float q2 = 0.f;
+          const real s2 = A::s2(t, c, s1);
+          real q2 = 0.f;
           sfor<C::D>([&](auto a_) {
             constexpr int a = decltype(a_)::value;
-            if constexpr (SS::in_lap(a)) q2 = fmaf(st.z[1 + a][b][r], st.z[1 + a][b][r], q2);
+            if constexpr (SS::in_lap(a)) q2 = rfma(st.z[1 + a][b][r], st.z[1 + a][b][r], q2);
           });
-          h[SS::S2][b][r] = fmaf(s2, q2, s1 * st.z[SS::S2][b][r]);
+          h[SS::S2][b][r] = rfma(s2, q2, s1 * st.z[SS::S2][b][r]);
         } else if constexpr (SS::N2 > 0) {
-          const float s2 = A::s2(t, c, s1);
+          const real s2 = A::s2(t, c, s1);
           sfor<SS::N2>([&](auto k_) {
             constexpr int s = SS::S2 + decltype(k_)::value;
             constexpr int a = SS::A(s), bb = SS::B(s);
-            h[s][b][r] = fmaf(s2 * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[s][b][r]);
+            h[s][b][r] = rfma(s2 * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[s][b][r]);
           });
           if constexpr (SS::N3 > 0) {
-            const float s3 = A::s3(t, c, s1);
+            const real s3 = A::s3(t, c, s1);
             sfor<SS::N3>([&](auto k_) {
               constexpr int s = SS::S3 + decltype(k_)::value;
               constexpr int a = SS::T(s, 0), bb = SS::T(s, 1), cc = SS::T(s, 2);
               constexpr int sab = SS::pair_stream(a, bb), sac = SS::pair_stream(a, cc), sbc = SS::pair_stream(bb, cc);
-              const float za = st.z[1 + a][b][r], zb = st.z[1 + bb][b][r], zc = st.z[1 + cc][b][r];
-              const float mix = fmaf(st.z[sab][b][r], zc, fmaf(st.z[sac][b][r], zb, st.z[sbc][b][r] * za));
-              h[s][b][r] = fmaf(s3 * za, zb * zc, fmaf(s2, mix, s1 * st.z[s][b][r]));
+              const real za = st.z[1 + a][b][r], zb = st.z[1 + bb][b][r], zc = st.z[1 + cc][b][r];
+              const real mix = rfma(st.z[sab][b][r], zc, rfma(st.z[sac][b][r], zb, st.z[sbc][b][r] * za));
+              h[s][b][r] = rfma(s3 * za, zb * zc, rfma(s2, mix, s1 * st.z[s][b][r]));
             });
           }
         }
@@ -592,110 +632,110 @@ __device__ __forceinline__ void act_forward(const LayerState<C>& st, f32x4 (&h)[
 
 // one stream of act_forward (compile-time stream index S)
 template <class C, int S>
-__device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, f32x4 (&hs)[C::NB]) {
+__device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, real4 (&hs)[C::NB]) {
   using SS = typename C::SS;
   using A = Act<C::ACT>;
 #pragma unroll
   for (int b = 0; b < C::NB; ++b)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float t = st.t[b][r], c = st.c[b][r];
+      const real t = st.t[b][r], c = st.c[b][r];
       if constexpr (S == 0) {
         hs[b][r] = t;
       } else if constexpr (S < SS::S2) {
         hs[b][r] = A::s1(t, c) * st.z[S][b][r];
       } else if constexpr (SS::LAP) {
-        const float s1 = A::s1(t, c);
-        float q2 = 0.f;
+        const real s1 = A::s1(t, c);
+        real q2 = 0.f;
         sfor<C::D>([&](auto a_) {
           constexpr int a = decltype(a_)::value;
-          if constexpr (SS::in_lap(a)) q2 = fmaf(st.z[1 + a][b][r], st.z[1 + a][b][r], q2);
+          if constexpr (SS::in_lap(a)) q2 = rfma(st.z[1 + a][b][r], st.z[1 + a][b][r], q2);
         });
-        hs[b][r] = fmaf(A::s2(t, c, s1), q2, s1 * st.z[S][b][r]);
+        hs[b][r] = rfma(A::s2(t, c, s1), q2, s1 * st.z[S][b][r]);
       } else if constexpr (S < SS::S3) {
         constexpr int a = SS::A(S), bb = SS::B(S);
-        const float s1 = A::s1(t, c);
-        hs[b][r] = fmaf(A::s2(t, c, s1) * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[S][b][r]);
+        const real s1 = A::s1(t, c);
+        hs[b][r] = rfma(A::s2(t, c, s1) * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[S][b][r]);
       } else {
         constexpr int a = SS::T(S, 0), bb = SS::T(S, 1), cc = SS::T(S, 2);
         constexpr int sab = SS::pair_stream(a, bb), sac = SS::pair_stream(a, cc), sbc = SS::pair_stream(bb, cc);
-        const float s1 = A::s1(t, c), s2 = A::s2(t, c, s1), s3 = A::s3(t, c, s1);
-        const float za = st.z[1 + a][b][r], zb = st.z[1 + bb][b][r], zc = st.z[1 + cc][b][r];
-        const float mix = fmaf(st.z[sab][b][r], zc, fmaf(st.z[sac][b][r], zb, st.z[sbc][b][r] * za));
-        hs[b][r] = fmaf(s3 * za, zb * zc, fmaf(s2, mix, s1 * st.z[S][b][r]));
+        const real s1 = A::s1(t, c), s2 = A::s2(t, c, s1), s3 = A::s3(t, c, s1);
+        const real za = st.z[1 + a][b][r], zb = st.z[1 + bb][b][r], zc = st.z[1 + cc][b][r];
+        const real mix = rfma(st.z[sab][b][r], zc, rfma(st.z[sac][b][r], zb, st.z[sbc][b][r] * za));
+        hs[b][r] = rfma(s3 * za, zb * zc, rfma(s2, mix, s1 * st.z[S][b][r]));
       }
     }
 }
 
 // adjoint of act_forward: given hbar (overwritten in place with zbar)
 template <class C>
-__device__ __forceinline__ void act_backward(const LayerState<C>& st, f32x4 (&g)[C::NS][C::NB]) {
+__device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)[C::NS][C::NB]) {
   using SS = typename C::SS;
   using A = Act<C::ACT>;
 #pragma unroll
   for (int b = 0; b < C::NB; ++b)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float t = st.t[b][r], c = st.c[b][r];
-      const float s1 = A::s1(t, c);
-      float z0 = s1 * g[0][b][r];
+      const real t = st.t[b][r], c = st.c[b][r];
+      const real s1 = A::s1(t, c);
+      real z0 = s1 * g[0][b][r];
       if constexpr (SS::FIRST) {
-        const float s2 = A::s2(t, c, s1);
-        float za[C::D];
+        const real s2 = A::s2(t, c, s1);
+        real za[C::D];
         sfor<C::D>([&](auto a_) {
           constexpr int a = decltype(a_)::value;
-          z0 = fmaf(s2 * st.z[1 + a][b][r], g[1 + a][b][r], z0);
+          z0 = rfma(s2 * st.z[1 + a][b][r], g[1 + a][b][r], z0);
           za[a] = s1 * g[1 + a][b][r];
         });
         if constexpr (SS::LAP) {
           // h_L = s2 * sum_a z_a^2 + s1 * z_L
-          const float s3 = A::s3(t, c, s1);
-          const float hb = g[SS::S2][b][r];
-          float q2 = 0.f;
+          const real s3 = A::s3(t, c, s1);
+          const real hb = g[SS::S2][b][r];
+          real q2 = 0.f;
           sfor<C::D>([&](auto a_) {
             constexpr int a = decltype(a_)::value;
             if constexpr (SS::in_lap(a)) {
-              const float zA = st.z[1 + a][b][r];
-              q2 = fmaf(zA, zA, q2);
-              za[a] = fmaf(2.f * s2 * zA, hb, za[a]);
+              const real zA = st.z[1 + a][b][r];
+              q2 = rfma(zA, zA, q2);
+              za[a] = rfma(2.f * s2 * zA, hb, za[a]);
             }
           });
-          z0 = fmaf(fmaf(s3, q2, s2 * st.z[SS::S2][b][r]), hb, z0);
+          z0 = rfma(rfma(s3, q2, s2 * st.z[SS::S2][b][r]), hb, z0);
           g[SS::S2][b][r] = s1 * hb;
         } else if constexpr (SS::N2 > 0) {
-          const float s3 = A::s3(t, c, s1);
-          float zb2[SS::N2];                 // what the third-order streams add to the second-order adjoints
+          const real s3 = A::s3(t, c, s1);
+          real zb2[SS::N2];                 // what the third-order streams add to the second-order adjoints
 #pragma unroll
           for (int k = 0; k < SS::N2; ++k) zb2[k] = 0.f;
           if constexpr (SS::N3 > 0) {
-            const float s4 = A::s4(t, c, s1);
+            const real s4 = A::s4(t, c, s1);
             sfor<SS::N3>([&](auto k_) {
               constexpr int s = SS::S3 + decltype(k_)::value;
               constexpr int a = SS::T(s, 0), bb = SS::T(s, 1), cc = SS::T(s, 2);
               constexpr int sab = SS::pair_stream(a, bb), sac = SS::pair_stream(a, cc), sbc = SS::pair_stream(bb, cc);
-              const float hb = g[s][b][r];
-              const float zA = st.z[1 + a][b][r], zB = st.z[1 + bb][b][r], zC = st.z[1 + cc][b][r];
-              const float zab = st.z[sab][b][r], zac = st.z[sac][b][r], zbc = st.z[sbc][b][r];
-              const float mix = fmaf(zab, zC, fmaf(zac, zB, zbc * zA));
-              z0 = fmaf(fmaf(s4 * zA, zB * zC, fmaf(s3, mix, s2 * st.z[s][b][r])), hb, z0);
-              za[a] = fmaf(fmaf(s3 * zB, zC, s2 * zbc), hb, za[a]);
-              za[bb] = fmaf(fmaf(s3 * zA, zC, s2 * zac), hb, za[bb]);
-              za[cc] = fmaf(fmaf(s3 * zA, zB, s2 * zab), hb, za[cc]);
-              zb2[sab - SS::S2] = fmaf(s2 * zC, hb, zb2[sab - SS::S2]);
-              zb2[sac - SS::S2] = fmaf(s2 * zB, hb, zb2[sac - SS::S2]);
-              zb2[sbc - SS::S2] = fmaf(s2 * zA, hb, zb2[sbc - SS::S2]);
+              const real hb = g[s][b][r];
+              const real zA = st.z[1 + a][b][r], zB = st.z[1 + bb][b][r], zC = st.z[1 + cc][b][r];
+              const real zab = st.z[sab][b][r], zac = st.z[sac][b][r], zbc = st.z[sbc][b][r];
+              const real mix = rfma(zab, zC, rfma(zac, zB, zbc * zA));
+              z0 = rfma(rfma(s4 * zA, zB * zC, rfma(s3, mix, s2 * st.z[s][b][r])), hb, z0);
+              za[a] = rfma(rfma(s3 * zB, zC, s2 * zbc), hb, za[a]);
+              za[bb] = rfma(rfma(s3 * zA, zC, s2 * zac), hb, za[bb]);
+              za[cc] = rfma(rfma(s3 * zA, zB, s2 * zab), hb, za[cc]);
+              zb2[sab - SS::S2] = rfma(s2 * zC, hb, zb2[sab - SS::S2]);
+              zb2[sac - SS::S2] = rfma(s2 * zB, hb, zb2[sac - SS::S2]);
+              zb2[sbc - SS::S2] = rfma(s2 * zA, hb, zb2[sbc - SS::S2]);
               g[s][b][r] = s1 * hb;
             });
           }
           sfor<SS::N2>([&](auto k_) {
             constexpr int s = SS::S2 + decltype(k_)::value;
             constexpr int a = SS::A(s), bb = SS::B(s);
-            const float hb = g[s][b][r];
-            const float zA = st.z[1 + a][b][r], zB = st.z[1 + bb][b][r];
-            z0 = fmaf(fmaf(s3 * zA, zB, s2 * st.z[s][b][r]), hb, z0);
-            za[a] = fmaf(s2 * zB, hb, za[a]);
-            za[bb] = fmaf(s2 * zA, hb, za[bb]);
-            g[s][b][r] = fmaf(s1, hb, zb2[decltype(k_)::value]);
+            const real hb = g[s][b][r];
+            const real zA = st.z[1 + a][b][r], zB = st.z[1 + bb][b][r];
+            z0 = rfma(rfma(s3 * zA, zB, s2 * st.z[s][b][r]), hb, z0);
+            za[a] = rfma(s2 * zB, hb, za[a]);
+            za[bb] = rfma(s2 * zA, hb, za[bb]);
+            g[s][b][r] = rfma(s1, hb, zb2[decltype(k_)::value]);
           });
         }
         sfor<C::D>([&](auto a_) {
@@ -707,11 +747,11 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, f32x4 (&g)
     }
 }
 
-template <class C> __device__ __forceinline__ void zero_frag(f32x4 (&z)[C::NS][C::NB]);
+template <class C> __device__ __forceinline__ void zero_frag(real4 (&z)[C::NS][C::NB]);
 
 // split the 8 fp32 values a lane holds for one K-chunk (blocks 2c, 2c+1) into three bf16x8 operands
-__device__ __forceinline__ void split3(const f32x4 a, const f32x4 b, bf16x8 (&pl)[3]) {
-  const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+__device__ __forceinline__ void split3(const real4 a, const real4 b, bf16x8 (&pl)[3]) {
+  const real x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   if constexpr ((NDQ_ABL & 32) != 0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { pl[0][e] = (__bf16)x[e]; pl[1][e] = pl[0][e]; pl[2][e] = pl[0][e]; }
@@ -720,15 +760,15 @@ __device__ __forceinline__ void split3(const f32x4 a, const f32x4 b, bf16x8 (&pl
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const __bf16 h0 = (__bf16)x[e];
-    const float r1 = x[e] - (float)h0;
+    const real r1 = x[e] - (real)h0;
     const __bf16 h1 = (__bf16)r1;
-    const __bf16 h2 = (__bf16)(r1 - (float)h1);
+    const __bf16 h2 = (__bf16)(r1 - (real)h1);
     pl[0][e] = h0; pl[1][e] = h1; pl[2][e] = h2;
   }
 }
 
 template <class C>
-__device__ __forceinline__ void split_all(const f32x4 (&h)[C::NS][C::NB], Planes<C>& P) {
+__device__ __forceinline__ void split_all(const real4 (&h)[C::NS][C::NB], Planes<C>& P) {
 #pragma unroll
   for (int s = 0; s < C::NS; ++s)
 #pragma unroll
@@ -737,8 +777,8 @@ __device__ __forceinline__ void split_all(const f32x4 (&h)[C::NS][C::NB], Planes
 
 // z[s][ob] += W h[s] with h given as bf16x3 planes
 template <class C>
-__device__ __forceinline__ void gemm_planes(const float* __restrict__ wl, int lane, const Planes<C>& P,
-                                            f32x4 (&z)[C::NS][C::NB]) {
+__device__ __forceinline__ void gemm_planes(const real* __restrict__ wl, int lane, const Planes<C>& P,
+                                            real4 (&z)[C::NS][C::NB]) {
   const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
 #pragma unroll
   for (int c = 0; c < C::NC; ++c)
@@ -757,7 +797,7 @@ __device__ __forceinline__ void gemm_planes(const float* __restrict__ wl, int la
 
 // hbar = W^T zbar in place (all streams are split first, then overwritten)
 template <class C>
-__device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl, int lane, f32x4 (&g)[C::NS][C::NB]) {
+__device__ __forceinline__ void gemm_bf16x3_inplace(const real* __restrict__ wl, int lane, real4 (&g)[C::NS][C::NB]) {
   if constexpr (C::GROUP_HBAR) {     // group by group: planes and outputs of SG streams live at a time
     constexpr int NG = (C::NS + C::SG - 1) / C::SG;
     sfor<NG>([&](auto g_) {
@@ -765,13 +805,13 @@ __device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl
       constexpr int sn = (C::NS - s0 < C::SG) ? C::NS - s0 : C::SG;
       const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
       bf16x8 pl[sn][C::NC][3];
-      f32x4 o[sn][C::NB];
+      real4 o[sn][C::NB];
 #pragma unroll
       for (int s = 0; s < sn; ++s) {
 #pragma unroll
         for (int c = 0; c < C::NC; ++c) split3(g[s0 + s][2 * c], g[s0 + s][2 * c + 1], pl[s][c]);
 #pragma unroll
-        for (int b = 0; b < C::NB; ++b) o[s][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < C::NB; ++b) o[s][b] = real4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int c = 0; c < C::NC; ++c)
@@ -793,7 +833,7 @@ __device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl
     });
     return;
   }
-  f32x4 o[C::NS][C::NB];
+  real4 o[C::NS][C::NB];
   zero_frag<C>(o);
   Planes<C> P;
   split_all<C>(g, P);
@@ -806,42 +846,42 @@ __device__ __forceinline__ void gemm_bf16x3_inplace(const float* __restrict__ wl
 
 // z[s][ib] (+)= sum_kb sum_t A(w[(ib*NB+kb)*4+t]) * B(h[s][kb][t]);  w points at a fragment-ordered H x H matrix
 template <class C>
-__device__ __forceinline__ void gemm_frag(const float* __restrict__ w, int lane, const f32x4 (&h)[C::NS][C::NB],
-                                          f32x4 (&z)[C::NS][C::NB]) {
+__device__ __forceinline__ void gemm_frag(const real* __restrict__ w, int lane, const real4 (&h)[C::NS][C::NB],
+                                          real4 (&z)[C::NS][C::NB]) {
 #pragma unroll
   for (int ib = 0; ib < C::NB; ++ib)
 #pragma unroll
     for (int kb = 0; kb < C::NB; ++kb)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float a = w[((ib * C::NB + kb) * 4 + t) * 64 + lane];
+        const real a = w[((ib * C::NB + kb) * 4 + t) * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) z[s][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, h[s][kb][t], z[s][ib], 0, 0, 0);
+        for (int s = 0; s < C::NS; ++s) z[s][ib] = mfma16x16x4(a, h[s][kb][t], z[s][ib]);
       }
 }
 
 template <class C>
-__device__ __forceinline__ void zero_frag(f32x4 (&z)[C::NS][C::NB]) {
+__device__ __forceinline__ void zero_frag(real4 (&z)[C::NS][C::NB]) {
 #pragma unroll
   for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-    for (int b = 0; b < C::NB; ++b) z[s][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < C::NB; ++b) z[s][b] = real4{0.f, 0.f, 0.f, 0.f};
 }
 
 // first layer (VALU): z = W1 x + b1; derivative streams of z are columns of W1 (second order: zero)
 template <class C, bool BWD>
-__device__ __forceinline__ void first_layer(const float* lds, int q, const float (&x)[C::D], LayerState<C>& st) {
+__device__ __forceinline__ void first_layer(const real* lds, int q, const real (&x)[C::D], LayerState<C>& st) {
   using SS = typename C::SS;
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
     const int j0 = 16 * b + 4 * q;
-    f32x4 z = lds4(lds + C::ldsb1 + j0);
-    f32x4 w[C::D];
+    real4 z = lds4(lds + C::ldsb1 + j0);
+    real4 w[C::D];
 #pragma unroll
     for (int a = 0; a < C::D; ++a) {
       w[a] = lds4(lds + C::ldsW1T + a * C::H + j0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) z[r] = fmaf(w[a][r], x[a], z[r]);
+      for (int r = 0; r < 4; ++r) z[r] = rfma(w[a][r], x[a], z[r]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[r], st.t[b][r], st.c[b][r]);
@@ -849,16 +889,16 @@ __device__ __forceinline__ void first_layer(const float* lds, int q, const float
 #pragma unroll
       for (int a = 0; a < C::D; ++a) st.z[1 + a][b] = w[a];
 #pragma unroll
-      for (int s = SS::S2; s < C::NS; ++s) st.z[s][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = SS::S2; s < C::NS; ++s) st.z[s][b] = real4{0.f, 0.f, 0.f, 0.f};
     }
   }
 }
 
 // hidden layer l (2..L): z = W_l h + b_l on every stream, then activation state
 template <class C, bool BWD>
-__device__ __forceinline__ void hidden_layer(const float* lds, int l, int lane, int q, const f32x4 (&h)[C::NS][C::NB],
+__device__ __forceinline__ void hidden_layer(const real* lds, int l, int lane, int q, const real4 (&h)[C::NS][C::NB],
                                              LayerState<C>& st) {
-  f32x4 z[C::NS][C::NB];
+  real4 z[C::NS][C::NB];
   zero_frag<C>(z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
@@ -874,9 +914,9 @@ __device__ __forceinline__ void hidden_layer(const float* lds, int l, int lane, 
 
 // same with the layer input given as bf16x3 planes
 template <class C, bool BWD>
-__device__ __forceinline__ void hidden_layer_planes(const float* lds, int l, int lane, int q, const Planes<C>& P,
+__device__ __forceinline__ void hidden_layer_planes(const real* lds, int l, int lane, int q, const Planes<C>& P,
                                                     LayerState<C>& st) {
-  f32x4 z[C::NS][C::NB];
+  real4 z[C::NS][C::NB];
   zero_frag<C>(z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
@@ -893,16 +933,23 @@ __device__ __forceinline__ void hidden_layer_planes(const float* lds, int l, int
 // cross-lane sums: the 4 lane groups are combined through ds_bpermute (v_permlane16/32_swap with both operands equal
 // did not produce the expected exchange on this toolchain and was dropped), the 16 points of a tile -- exactly one DPP
 // row -- by DPP row rotations fused into the adds.  Every lane ends up with the total.
-__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lane groups q (lanes p, p+16, p+32, p+48)
+__device__ __forceinline__ real quad_sum(real v) {  // sum over the 4 lane groups q (lanes p, p+16, p+32, p+48)
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
 }
 template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+__device__ __forceinline__ real dpp_add(real v) {
+#if NDQ_F64
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+#else
+  return v + __builtin_bit_cast(real, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+#endif
 }
-__device__ __forceinline__ float point_sum(float v) {  // sum over the 16 points of the tile (lanes with equal q)
+__device__ __forceinline__ real point_sum(real v) {  // sum over the 16 points of the tile (lanes with equal q)
   v = dpp_add<0x128>(v);  // row_ror:8
   v = dpp_add<0x124>(v);  // row_ror:4
   v = dpp_add<0x122>(v);  // row_ror:2
@@ -912,17 +959,17 @@ __device__ __forceinline__ float point_sum(float v) {  // sum over the 16 points
 
 // output layer (n_out = 1) on the VALU: out[s] = Wout . h[s] (+ bout on the value stream), identical in all 4 lane groups
 template <class C, bool BWD>
-__device__ __forceinline__ void tile_output(const float* lds, int q, const float (&x)[C::D], const f32x4 (&h)[C::NS][C::NB],
-                                            float (&out)[C::NS]) {
+__device__ __forceinline__ void tile_output(const real* lds, int q, const real (&x)[C::D], const real4 (&h)[C::NS][C::NB],
+                                            real (&out)[C::NS]) {
 #pragma unroll
   for (int s = 0; s < C::NS; ++s) out[s] = 0.f;
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
-    const f32x4 wo = lds4(lds + C::ldsWout(BWD) + 16 * b + 4 * q);
+    const real4 wo = lds4(lds + C::ldsWout(BWD) + 16 * b + 4 * q);
 #pragma unroll
     for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[s] = fmaf(wo[r], h[s][b][r], out[s]);
+      for (int r = 0; r < 4; ++r) out[s] = rfma(wo[r], h[s][b][r], out[s]);
   }
 #pragma unroll
   for (int s = 0; s < C::NS; ++s) out[s] = quad_sum(out[s]);
@@ -930,8 +977,8 @@ __device__ __forceinline__ void tile_output(const float* lds, int q, const float
   if constexpr (C::SKIP != 0) {            // + S x: value and first-order streams (second order: nothing)
 #pragma unroll
     for (int a = 0; a < C::D; ++a) {
-      const float sa = lds[C::ldsSkip(BWD) + a];
-      out[0] = fmaf(sa, x[a], out[0]);
+      const real sa = lds[C::ldsSkip(BWD) + a];
+      out[0] = rfma(sa, x[a], out[0]);
       if constexpr (C::SS::FIRST) out[1 + a] += sa;
     }
   }
@@ -939,12 +986,12 @@ __device__ __forceinline__ void tile_output(const float* lds, int q, const float
 
 // output layer with NOUT > 1 as an MFMA layer: o[s][ob] = Wo h[s] (+ bout on the value stream); rows >= NOUT are zero
 template <class C, bool BWD>
-__device__ __forceinline__ void output_layer_mfma(const float* lds, int lane, int q, const f32x4 (&h)[C::NS][C::NB],
-                                                  f32x4 (&o)[C::NS][C::NBO]) {
+__device__ __forceinline__ void output_layer_mfma(const real* lds, int lane, int q, const real4 (&h)[C::NS][C::NB],
+                                                  real4 (&o)[C::NS][C::NBO]) {
 #pragma unroll
   for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-    for (int ob = 0; ob < C::NBO; ++ob) o[s][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ob = 0; ob < C::NBO; ++ob) o[s][ob] = real4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ob = 0; ob < C::NBO; ++ob) o[0][ob] = lds4(lds + C::ldsbout(BWD) + 16 * ob + 4 * q);
   if constexpr (C::BF16O) {
@@ -966,23 +1013,23 @@ __device__ __forceinline__ void output_layer_mfma(const float* lds, int lane, in
       }
     return;
   }
-  const float* w = lds + C::ldsWout(BWD);
+  const real* w = lds + C::ldsWout(BWD);
 #pragma unroll
   for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
     for (int kb = 0; kb < C::NB; ++kb)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float a = w[((ob * C::NB + kb) * 4 + t) * 64 + lane];
+        const real a = w[((ob * C::NB + kb) * 4 + t) * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, h[s][kb][t], o[s][ob], 0, 0, 0);
+        for (int s = 0; s < C::NS; ++s) o[s][ob] = mfma16x16x4(a, h[s][kb][t], o[s][ob]);
       }
 }
 
 // forward pass of one tile keeping every layer's state; h = streams of the last hidden layer's activations
 // forward-only hidden layer on the bf16x3 path (planes are transient)
 template <class C>
-__device__ __forceinline__ void gemm_layer_bf16(const float* lds, int l, int lane, int q, const f32x4 (&h)[C::NS][C::NB],
+__device__ __forceinline__ void gemm_layer_bf16(const real* lds, int l, int lane, int q, const real4 (&h)[C::NS][C::NB],
                                                 LayerState<C>& st) {
   Planes<C> P;
   split_all<C>(h, P);
@@ -992,9 +1039,9 @@ __device__ __forceinline__ void gemm_layer_bf16(const float* lds, int l, int lan
 // hidden layer on the bf16x3 path for wide nets: SG streams at a time, each group's activations h[s] computed from the
 // input layer's state right before they are split into planes (never more than SG streams of h and of planes live)
 template <class C, bool BWD>
-__device__ __forceinline__ void hidden_layer_grouped(const float* lds, int l, int lane, int q, const LayerState<C>& st_in,
+__device__ __forceinline__ void hidden_layer_grouped(const real* lds, int l, int lane, int q, const LayerState<C>& st_in,
                                                      LayerState<C>& st) {
-  f32x4 z[C::NS][C::NB];
+  real4 z[C::NS][C::NB];
   zero_frag<C>(z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
@@ -1006,7 +1053,7 @@ __device__ __forceinline__ void hidden_layer_grouped(const float* lds, int l, in
     bf16x8 pl[sn][C::NC][3];
     sfor<sn>([&](auto s_) {
       constexpr int s = decltype(s_)::value;
-      f32x4 hs[C::NB];
+      real4 hs[C::NB];
       act_forward_stream<C, s0 + s>(st_in, hs);
 #pragma unroll
       for (int c = 0; c < C::NC; ++c) split3(hs[2 * c], hs[2 * c + 1], pl[s][c]);
@@ -1038,12 +1085,12 @@ __device__ __forceinline__ void hidden_layer_grouped(const float* lds, int l, in
 template <class C> struct KeptPlanes {
   // with one wave per SIMD there are registers to spare: the activation streams of every layer are kept from the
   // forward pass instead of being recomputed for the weight-gradient GEMMs and the output-layer gradient
-  f32x4 h[C::KEEP_H ? C::L : 1][C::NS][C::NB];
+  real4 h[C::KEEP_H ? C::L : 1][C::NS][C::NB];
 };
 
 template <class C, bool BWD>
-__device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, const float (&x)[C::D],
-                                             LayerState<C> (&st)[C::L], f32x4 (&h)[C::NS][C::NB], KeptPlanes<C>& kp) {
+__device__ __forceinline__ void tile_forward(const real* lds, int lane, int q, const real (&x)[C::D],
+                                             LayerState<C> (&st)[C::L], real4 (&h)[C::NS][C::NB], KeptPlanes<C>& kp) {
   first_layer<C, BWD>(lds, q, x, st[0]);
   sfor<C::L - 1>([&](auto li_) {
     constexpr int li = decltype(li_)::value;  // computes layer l = li + 2 from layer li + 1
@@ -1078,7 +1125,7 @@ __device__ __forceinline__ void tile_forward(const float* lds, int lane, int q, 
 // ------------------------------------------------------------------------------------------------ forward kernel
 template <class C>
 __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) real lds[];
   stage_weights<C, false>(lds, a.params);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
@@ -1087,13 +1134,13 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
   for (int tile = blockIdx.x * wavesPerBlock + wave; tile < ntiles; tile += gridDim.x * wavesPerBlock) {
     const int n = tile * 16 + p;
     const int nn = n < a.n ? n : a.n - 1;
-    float x[C::D];
+    real x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
-    const float* ldsw = lds + opaque_zero<C>();
+    const real* ldsw = lds + opaque_zero<C>();
     LayerState<C> st;                      // one state, reused layer after layer (nothing is kept for a reverse pass)
     first_layer<C, false>(ldsw, q, x, st);
-    f32x4 h[C::NS][C::NB];
+    real4 h[C::NS][C::NB];
 #pragma unroll
     for (int l = 2; l <= C::L; ++l) {
       if constexpr (C::BF16 && C::WIDE) {
@@ -1106,14 +1153,14 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
     }
     act_forward<C>(st, h);
     if constexpr (C::NOUT == 1) {
-      float out[C::NS];
+      real out[C::NS];
       tile_output<C, false>(ldsw, q, x, h, out);
       if (q == 0 && n < a.n) {
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) a.jets[(size_t)s * a.ldj + n] = out[s];
       }
     } else {
-      f32x4 o[C::NS][C::NBO];
+      real4 o[C::NS][C::NBO];
       output_layer_mfma<C, false>(ldsw, lane, q, h, o);
       if (n < a.n) {
 #pragma unroll
@@ -1135,7 +1182,7 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
 template <class C>
 constexpr int bwd_regions(int waves) {
   const int pp = (C::P + 3) & ~3;
-  const int budget = 38 * 1024 - C::ldsWeightsEnd(true) - waves * C::biasFloats;   // floats
+  const int budget = (38 * 1024 * 4) / (int)sizeof(real) - C::ldsWeightsEnd(true) - waves * C::biasFloats;   // reals (152 KB)
   int r = budget / pp;
   if (r < 1) r = 1;
   return r > waves ? waves : r;
@@ -1144,24 +1191,24 @@ constexpr int bwd_regions(int waves) {
 // per-wave gradient accumulators (registers), summed over all tiles the wave processes
 template <class C>
 struct GradAcc {
-  float w1[C::D][C::NB][4];          // dW1[j][a], j = 16b+4q+r   (needs point_sum)
-  float b1[C::NB][4];                // db1[j]                    (needs point_sum)
-  f32x4 w[C::L > 1 ? C::L - 1 : 1][C::NB][C::NB];  // dW_l[16jb+4q+r][16kb+p], MFMA accumulators (already summed)
-  float b[C::L > 1 ? C::L - 1 : 1][C::NB][4];      // db_l[j]     (needs point_sum)
-  float wout[C::NB][4];              // NOUT == 1: dWout[j]       (needs point_sum)
-  float bout;                        // NOUT == 1: dbout          (needs full wave sum)
-  float skip[C::D];                  // SKIP: dS[a]               (needs full wave sum)
-  f32x4 wo[C::NBO][C::NB];           // NOUT > 1: dWout[16ob+4q+r][16kb+p], MFMA accumulators
-  float bo[C::NBO][4];               // NOUT > 1: dbout[16ob+4q+r] (needs point_sum)
-  float* bias;                       // ACC_LDS: this wave's LDS region holding b1 / w1 / b / wout instead (already point-summed)
+  real w1[C::D][C::NB][4];          // dW1[j][a], j = 16b+4q+r   (needs point_sum)
+  real b1[C::NB][4];                // db1[j]                    (needs point_sum)
+  real4 w[C::L > 1 ? C::L - 1 : 1][C::NB][C::NB];  // dW_l[16jb+4q+r][16kb+p], MFMA accumulators (already summed)
+  real b[C::L > 1 ? C::L - 1 : 1][C::NB][4];      // db_l[j]     (needs point_sum)
+  real wout[C::NB][4];              // NOUT == 1: dWout[j]       (needs point_sum)
+  real bout;                        // NOUT == 1: dbout          (needs full wave sum)
+  real skip[C::D];                  // SKIP: dS[a]               (needs full wave sum)
+  real4 wo[C::NBO][C::NB];           // NOUT > 1: dWout[16ob+4q+r][16kb+p], MFMA accumulators
+  real bo[C::NBO][4];               // NOUT > 1: dbout[16ob+4q+r] (needs point_sum)
+  real* bias;                       // ACC_LDS: this wave's LDS region holding b1 / w1 / b / wout instead (already point-summed)
 };
 
 // ACC_LDS: add the tile's point-sum of v (one value per unit j = 16b+4q+r, per lane group) to this wave's LDS sums.
 // Only this wave touches its region and LDS operations of a wave are issued in order, so the order of additions --
 // tile after tile -- is fixed.
 template <class C>
-__device__ __forceinline__ void bias_accum(GradAcc<C>& acc, int off, int p, int q, int b, const float (&v)[4]) {
-  float s[4];
+__device__ __forceinline__ void bias_accum(GradAcc<C>& acc, int off, int p, int q, int b, const real (&v)[4]) {
+  real s[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) s[r] = point_sum(v[r]);
   if (p == 0) {
@@ -1173,7 +1220,7 @@ __device__ __forceinline__ void bias_accum(GradAcc<C>& acc, int off, int p, int 
 
 // first-layer derivative streams (columns of W1) re-read from LDS
 template <class C>
-__device__ __forceinline__ void reload_first_layer_streams(const float* lds, int q, LayerState<C>& st) {
+__device__ __forceinline__ void reload_first_layer_streams(const real* lds, int q, LayerState<C>& st) {
   if constexpr (C::SS::FIRST) {
 #pragma unroll
     for (int b = 0; b < C::NB; ++b)
@@ -1187,9 +1234,9 @@ __device__ __forceinline__ void reload_first_layer_streams(const float* lds, int
 // which makes both the b128 writes (8-lane groups: bank stride 4*(HP mod 8) ... HP = H+4 -> 16 B apart) and the b32
 // reads (32-lane groups: q*4*HP = 16 banks apart) conflict-free.
 template <class C, int NBA>
-__device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q, const f32x4 (&zb)[C::NS][NBA],
-                                            const LayerState<C>& st_in, f32x4 (&acc)[NBA][C::NB],
-                                            const f32x4 (*hkept)[C::NB] = nullptr) {
+__device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q, const real4 (&zb)[C::NS][NBA],
+                                            const LayerState<C>& st_in, real4 (&acc)[NBA][C::NB],
+                                            const real4 (*hkept)[C::NB] = nullptr) {
   constexpr int HP = C::HP, SB = C::WG_SB;
   constexpr int NR = (C::NS + SB - 1) / SB;           // barrier rounds
   if constexpr ((NDQ_ABL & 1) != 0) return;
@@ -1198,9 +1245,9 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
     constexpr int sn = (C::NS - s0 < SB) ? C::NS - s0 : SB;
     sfor<sn>([&](auto k_) {
       constexpr int s = s0 + decltype(k_)::value;
-      float* Zt = stage + decltype(k_)::value * 2 * 16 * HP;
-      float* Ht = Zt + 16 * HP;
-      f32x4 hs[C::NB];
+      real* Zt = stage + decltype(k_)::value * 2 * 16 * HP;
+      real* Ht = Zt + 16 * HP;
+      real4 hs[C::NB];
       if constexpr (C::KEEP_H) {              // stream s of the layer's input activations: kept by the forward pass ...
 #pragma unroll
         for (int b = 0; b < C::NB; ++b) hs[b] = hkept[s][b];
@@ -1209,9 +1256,9 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
       }
       if constexpr ((NDQ_ABL & 16) == 0) {
 #pragma unroll
-        for (int b = 0; b < NBA; ++b) *reinterpret_cast<f32x4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
+        for (int b = 0; b < NBA; ++b) *reinterpret_cast<real4*>(Zt + p * HP + 16 * b + 4 * q) = zb[s][b];
 #pragma unroll
-        for (int b = 0; b < C::NB; ++b) *reinterpret_cast<f32x4*>(Ht + p * HP + 16 * b + 4 * q) = hs[b];
+        for (int b = 0; b < C::NB; ++b) *reinterpret_cast<real4*>(Ht + p * HP + 16 * b + 4 * q) = hs[b];
       }
     });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1222,11 +1269,11 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
     if constexpr (C::BWD_THREADS != 256) {
       // two waves per SIMD, 256 registers each: no room for a round's operands at once -- step by step
       sfor<sn>([&](auto k_) {
-        const float* Zt = stage + decltype(k_)::value * 2 * 16 * HP;
-        const float* Ht = Zt + 16 * HP;
+        const real* Zt = stage + decltype(k_)::value * 2 * 16 * HP;
+        const real* Ht = Zt + 16 * HP;
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-          float a1[NBA], b1[C::NB];
+          real a1[NBA], b1[C::NB];
 #pragma unroll
           for (int b = 0; b < NBA; ++b) a1[b] = Zt[(4 * q + st) * HP + 16 * b + p];
 #pragma unroll
@@ -1235,7 +1282,7 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
           for (int jb = 0; jb < NBA; ++jb)
 #pragma unroll
             for (int kb = 0; kb < C::NB; ++kb)
-              acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[jb], b1[kb], acc[jb][kb], 0, 0, 0);
+              acc[jb][kb] = mfma16x16x4(a1[jb], b1[kb], acc[jb][kb]);
         }
       });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1243,11 +1290,11 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       return;
     }
-    float av[sn][4][NBA], bv[sn][4][C::NB];
+    real av[sn][4][NBA], bv[sn][4][C::NB];
     sfor<sn>([&](auto k_) {
       constexpr int k = decltype(k_)::value;
-      const float* Zt = stage + k * 2 * 16 * HP;
-      const float* Ht = Zt + 16 * HP;
+      const real* Zt = stage + k * 2 * 16 * HP;
+      const real* Ht = Zt + 16 * HP;
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
 #pragma unroll
@@ -1267,7 +1314,7 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
         for (int jb = 0; jb < NBA; ++jb)
 #pragma unroll
           for (int kb = 0; kb < C::NB; ++kb)
-            acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k][st][jb], bv[k][st][kb], acc[jb][kb], 0, 0, 0);
+            acc[jb][kb] = mfma16x16x4(av[k][st][jb], bv[k][st][kb], acc[jb][kb]);
     });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1278,19 +1325,19 @@ __device__ __forceinline__ void weight_grad(float* stage, int lane, int p, int q
 // one stream of hbar = W^T zbar in place: g[s] <- sum over (ib, t) of A(w) * B(g[s][ib][t]); stream by stream so that only
 // one extra fragment is live (the two output blocks alternate as MFMA accumulators, 64 cycles apart > 40 latency)
 template <class C>
-__device__ __forceinline__ void gemm_frag_inplace(const float* __restrict__ w, int lane, f32x4 (&g)[C::NS][C::NB]) {
+__device__ __forceinline__ void gemm_frag_inplace(const real* __restrict__ w, int lane, real4 (&g)[C::NS][C::NB]) {
 #pragma unroll
   for (int s = 0; s < C::NS; ++s) {
-    f32x4 o[C::NB];
+    real4 o[C::NB];
 #pragma unroll
-    for (int b = 0; b < C::NB; ++b) o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < C::NB; ++b) o[b] = real4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < C::NB; ++kb)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int ib = 0; ib < C::NB; ++ib)
-          o[ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[((ib * C::NB + kb) * 4 + t) * 64 + lane], g[s][kb][t], o[ib], 0, 0, 0);
+          o[ib] = mfma16x16x4(w[((ib * C::NB + kb) * 4 + t) * 64 + lane], g[s][kb][t], o[ib]);
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) g[s][b] = o[b];
   }
@@ -1314,27 +1361,27 @@ __device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
 #pragma unroll
     for (int jb = 0; jb < C::NB; ++jb)
 #pragma unroll
-      for (int kb = 0; kb < C::NB; ++kb) acc.w[l][jb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < C::NB; ++kb) acc.w[l][jb][kb] = real4{0.f, 0.f, 0.f, 0.f};
   acc.bout = 0.f;
 #pragma unroll
   for (int d = 0; d < C::D; ++d) acc.skip[d] = 0.f;
 #pragma unroll
   for (int ob = 0; ob < C::NBO; ++ob) {
 #pragma unroll
-    for (int kb = 0; kb < C::NB; ++kb) acc.wo[ob][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < C::NB; ++kb) acc.wo[ob][kb] = real4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc.bo[ob][r] = 0.f;
   }
 }
 
 // start of the per-wave bias-sum regions (ACC_LDS), behind the staging tiles / reduction regions
-template <class C> __device__ __forceinline__ float* bias_region(float* lds, int waves, int wave) {
+template <class C> __device__ __forceinline__ real* bias_region(real* lds, int waves, int wave) {
   const int pp = (C::P + 3) & ~3;
   const int stage = waves * C::stageFloatsPerWave;
   const int red = bwd_regions<C>(waves) * pp;
   return lds + C::ldsWeightsEnd(true) + (stage > red ? stage : red) + wave * C::biasFloats;
 }
-template <class C> __device__ __forceinline__ void acc_init(GradAcc<C>& acc, float* lds, int waves, int wave, int lane) {
+template <class C> __device__ __forceinline__ void acc_init(GradAcc<C>& acc, real* lds, int waves, int wave, int lane) {
   acc_zero<C>(acc);
   acc.bias = nullptr;
   if constexpr (C::ACC_LDS) {
@@ -1345,21 +1392,21 @@ template <class C> __device__ __forceinline__ void acc_init(GradAcc<C>& acc, flo
 
 
 template <class C>
-__device__ __forceinline__ void tile_backward_hidden(const float* lds, float* stage, int lane, int p, int q,
-                                                     const float (&x)[C::D], LayerState<C> (&st)[C::L],
-                                                     f32x4 (&g)[C::NS][C::NB], GradAcc<C>& acc, KeptPlanes<C>& kp);
+__device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stage, int lane, int p, int q,
+                                                     const real (&x)[C::D], LayerState<C> (&st)[C::L],
+                                                     real4 (&g)[C::NS][C::NB], GradAcc<C>& acc, KeptPlanes<C>& kp);
 
 // reverse pass of one tile, multi-output network: go[s][ob] = dLoss/d out[s][16ob+4q+r] for the tile's points
 template <class C>
-__device__ __forceinline__ void tile_backward_multi(const float* lds, float* stage, int lane, int p, int q,
-                                                    const float (&x)[C::D], const f32x4 (&go)[C::NS][C::NBO],
+__device__ __forceinline__ void tile_backward_multi(const real* lds, real* stage, int lane, int p, int q,
+                                                    const real (&x)[C::D], const real4 (&go)[C::NS][C::NBO],
                                                     LayerState<C> (&st)[C::L], GradAcc<C>& acc, KeptPlanes<C>& kp) {
 #pragma unroll
   for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc.bo[ob][r] += go[0][ob][r];
   weight_grad<C, C::NBO>(stage, lane, p, q, go, st[C::L - 1], acc.wo, kp.h[C::KEEP_H ? C::L - 1 : 0]);   // dWout += sum_s Gout[s] H_L[s]^T
-  f32x4 g[C::NS][C::NB];
+  real4 g[C::NS][C::NB];
   zero_frag<C>(g);
   if constexpr (C::BF16O) {                                                // hbar_L = Wout^T gout on the bf16 matrix core
     bf16x8 pl[C::NS][C::NCO][3];
@@ -1384,24 +1431,24 @@ __device__ __forceinline__ void tile_backward_multi(const float* lds, float* sta
     tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc, kp);
     return;
   }
-  const float* w = lds + C::ldsWoutT();
+  const real* w = lds + C::ldsWoutT();
 #pragma unroll
   for (int kb = 0; kb < C::NB; ++kb)                                       // hbar_L = Wout^T gout
 #pragma unroll
     for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float a = w[((kb * C::NBO + ob) * 4 + t) * 64 + lane];
+        const real a = w[((kb * C::NBO + ob) * 4 + t) * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) g[s][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, go[s][ob][t], g[s][kb], 0, 0, 0);
+        for (int s = 0; s < C::NS; ++s) g[s][kb] = mfma16x16x4(a, go[s][ob][t], g[s][kb]);
       }
   tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc, kp);
 }
 
 // reverse pass of one tile: gout[s] = dLoss/d out[s] for the tile's points (0 for padding lanes)
 template <class C>
-__device__ __forceinline__ void tile_backward(const float* lds, float* stage, int lane, int p, int q,
-                                              const float (&x)[C::D], const float (&gout)[C::NS],
+__device__ __forceinline__ void tile_backward(const real* lds, real* stage, int lane, int p, int q,
+                                              const real (&x)[C::D], const real (&gout)[C::NS],
                                               LayerState<C> (&st)[C::L], GradAcc<C>& acc, KeptPlanes<C>& kp) {
   // ---------------- output layer adjoint (n_out = 1): hbar = Wout * gout; dWout += sum_s gout_s h_s; dbout += gout_0
   // (h_s of the last hidden layer is recomputed per stream from its state instead of being kept live)
@@ -1413,14 +1460,14 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(st[l].t[b][r]));
   }
-  f32x4 g[C::NS][C::NB];
+  real4 g[C::NS][C::NB];
   {
-    f32x4 dw[C::NB];
+    real4 dw[C::NB];
 #pragma unroll
-    for (int b = 0; b < C::NB; ++b) dw[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < C::NB; ++b) dw[b] = real4{0.f, 0.f, 0.f, 0.f};
     sfor<C::NS>([&](auto s_) {
       constexpr int s = decltype(s_)::value;
-      f32x4 hs[C::NB];
+      real4 hs[C::NB];
       if constexpr (C::KEEP_H) {
 #pragma unroll
         for (int b = 0; b < C::NB; ++b) hs[b] = kp.h[C::L - 1][s][b];
@@ -1430,13 +1477,13 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
 #pragma unroll
       for (int b = 0; b < C::NB; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dw[b][r] = fmaf(gout[s], hs[b][r], dw[b][r]);
+        for (int r = 0; r < 4; ++r) dw[b][r] = rfma(gout[s], hs[b][r], dw[b][r]);
     });
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
-      const f32x4 wo = lds4(lds + C::ldsWout(true) + 16 * b + 4 * q);
+      const real4 wo = lds4(lds + C::ldsWout(true) + 16 * b + 4 * q);
       if constexpr (C::ACC_LDS) {
-        const float v[4] = {dw[b][0], dw[b][1], dw[b][2], dw[b][3]};
+        const real v[4] = {dw[b][0], dw[b][1], dw[b][2], dw[b][3]};
         bias_accum<C>(acc, C::biasWout, p, q, b, v);
       }
 #pragma unroll
@@ -1452,7 +1499,7 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
   if constexpr (C::SKIP != 0) {
 #pragma unroll
     for (int a = 0; a < C::D; ++a) {
-      float v = gout[0] * x[a];
+      real v = gout[0] * x[a];
       if constexpr (C::SS::FIRST) v += gout[1 + a];
       acc.skip[a] += (q == 0) ? v : 0.f;
     }
@@ -1462,9 +1509,9 @@ __device__ __forceinline__ void tile_backward(const float* lds, float* stage, in
 
 // hidden layers L .. 2 and the first layer, given g = hbar of the last hidden layer
 template <class C>
-__device__ __forceinline__ void tile_backward_hidden(const float* lds, float* stage, int lane, int p, int q,
-                                                     const float (&x)[C::D], LayerState<C> (&st)[C::L],
-                                                     f32x4 (&g)[C::NS][C::NB], GradAcc<C>& acc, KeptPlanes<C>& kp) {
+__device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stage, int lane, int p, int q,
+                                                     const real (&x)[C::D], LayerState<C> (&st)[C::L],
+                                                     real4 (&g)[C::NS][C::NB], GradAcc<C>& acc, KeptPlanes<C>& kp) {
   using SS = typename C::SS;
   // ---------------- hidden layers L .. 2
   sfor<C::L - 1>([&](auto k_) {
@@ -1475,7 +1522,7 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
       if constexpr (C::ACC_LDS) {
-        const float v[4] = {g[0][b][0], g[0][b][1], g[0][b][2], g[0][b][3]};
+        const real v[4] = {g[0][b][0], g[0][b][1], g[0][b][2], g[0][b][3]};
         bias_accum<C>(acc, C::biasBl + (l - 2) * C::H, p, q, b, v);
       } else {
 #pragma unroll
@@ -1500,11 +1547,11 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
   if constexpr (C::ACC_LDS) {
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
-      const float v0[4] = {g[0][b][0], g[0][b][1], g[0][b][2], g[0][b][3]};
+      const real v0[4] = {g[0][b][0], g[0][b][1], g[0][b][2], g[0][b][3]};
       bias_accum<C>(acc, C::biasB1, p, q, b, v0);
 #pragma unroll
       for (int d = 0; d < C::D; ++d) {
-        float v[4];
+        real v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v[r] = g[0][b][r] * x[d];
@@ -1518,11 +1565,11 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
     for (int b = 0; b < C::NB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float z0 = g[0][b][r];
+        const real z0 = g[0][b][r];
         acc.b1[b][r] += z0;
 #pragma unroll
         for (int d = 0; d < C::D; ++d) {
-          float v = z0 * x[d];
+          real v = z0 * x[d];
           if constexpr (SS::FIRST) v += g[1 + d][b][r];
           acc.w1[d][b][r] += v;
         }
@@ -1536,13 +1583,13 @@ __device__ __forceinline__ void tile_backward_hidden(const float* lds, float* st
 // touched once per wave and rounds are separated by barriers, so the summation order is fixed); finally every thread
 // adds the R regions in order and writes the workgroup's row of partials.
 template <class C, int WAVES>
-__device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, int wave, int lane, int p, int q,
-                                                   float* __restrict__ out) {
+__device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, int wave, int lane, int p, int q,
+                                                   real* __restrict__ out) {
   constexpr int PP = (C::P + 3) & ~3;
   constexpr int R = bwd_regions<C>(WAVES);
-  float* red0 = lds + C::ldsWeightsEnd(true);
-  const float bsum = point_sum(quad_sum(acc.bout));
-  float ssum[C::D];
+  real* red0 = lds + C::ldsWeightsEnd(true);
+  const real bsum = point_sum(quad_sum(acc.bout));
+  real ssum[C::D];
 #pragma unroll
   for (int a = 0; a < C::D; ++a) ssum[a] = (C::SKIP != 0) ? point_sum(quad_sum(acc.skip[a])) : 0.f;
 #pragma unroll
@@ -1573,10 +1620,10 @@ __device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, 
       for (int r = 0; r < 4; ++r) acc.bo[ob][r] = point_sum(acc.bo[ob][r]);
   }
   __syncthreads();  // every wave is done with its staging tile
-  float* red = red0 + (wave % R) * PP;
+  real* red = red0 + (wave % R) * PP;
   for (int k = 0; k * R < WAVES; ++k) {
     if (wave / R == k) {
-      auto put = [&](int idx, float v) {
+      auto put = [&](int idx, real v) {
         if (k == 0) red[idx] = v;
         else __hip_atomic_fetch_add(&red[idx], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
@@ -1628,7 +1675,7 @@ __device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, 
     __syncthreads();
   }
   for (int i = threadIdx.x; i < C::P; i += blockDim.x) {
-    float v = red0[i];
+    real v = red0[i];
 #pragma unroll
     for (int r = 1; r < R; ++r) v += red0[r * PP + i];
     out[i] = v;
@@ -1637,34 +1684,34 @@ __device__ __forceinline__ void block_reduce_store(float* lds, GradAcc<C>& acc, 
 
 template <class C>
 __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) real lds[];
   stage_weights<C, true>(lds, a.params);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   constexpr int WAVES = C::BWD_THREADS / 64;
   const int ntiles = (a.n + 15) >> 4;
-  float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
+  real* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
   GradAcc<C> acc;
   acc_init<C>(acc, lds, WAVES, wave, lane);
   for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
     const int nn = valid ? n : a.n - 1;
-    float x[C::D];
+    real x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
-    const float* ldsw = lds + opaque_zero<C>();
+    const real* ldsw = lds + opaque_zero<C>();
     LayerState<C> st[C::L];
-    f32x4 h[C::NS][C::NB];
+    real4 h[C::NS][C::NB];
     KeptPlanes<C> kp;
     tile_forward<C, true>(ldsw, lane, q, x, st, h, kp);
     if constexpr (C::NOUT == 1) {
-      float gout[C::NS];
+      real gout[C::NS];
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) gout[s] = valid ? a.gbar[(size_t)s * a.ldj + nn] : 0.f;
       tile_backward<C>(ldsw, stage, lane, p, q, x, gout, st, acc, kp);
     } else {
-      f32x4 go[C::NS][C::NBO];
+      real4 go[C::NS][C::NBO];
 #pragma unroll
       for (int s = 0; s < C::NS; ++s)
 #pragma unroll
@@ -1687,20 +1734,20 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
 // PW::apply(x, jets, seed, r, f, gj): per-point function; PW::loss(r): per-point loss term; PW::NEQ / PW::NF = number of
 // residuals / function values.
 struct FusedArgs {
-  const float* coords;     // [D][ldc]
-  const float* params;     // [P]
-  float* partials;         // TRAIN: [gridDim.x][P]
-  float* loss_partials;    // [gridDim.x] block sums of sum_e r_e^2
-  float* funcs;            // optional [NF][ldj]
-  float* resid;            // optional [NEQ][ldj]
+  const real* coords;     // [D][ldc]
+  const real* params;     // [P]
+  real* partials;         // TRAIN: [gridDim.x][P]
+  real* loss_partials;    // [gridDim.x] block sums of sum_e r_e^2
+  real* funcs;            // optional [NF][ldj]
+  real* resid;            // optional [NEQ][ldj]
   int n, ldc, ldj;
-  float seed;              // adjoint seed scale 1 / (N_global * n_eq)
+  real seed;              // adjoint seed scale 1 / (N_global * n_eq)
 };
 
 template <class C, class PW, bool TRAIN>
 __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs a) {
   static_assert(C::NOUT == 1, "the single-launch closure kernel needs a single-output network");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) real lds[];
   NDQ_TS(0);
 #ifdef NDQ_PHASE_TS
   if (threadIdx.x == 0 && blockIdx.x == 0) ndq_tile_iter = 0;
@@ -1710,7 +1757,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   const int ntiles = (a.n + 15) >> 4;
   // coordinates of a tile are fetched one tile ahead: the first tile's before the weights are staged (both global
   // latencies overlap), the next tile's while the current one is computed
-  float xn[C::D];
+  real xn[C::D];
   {
     const int n0 = (blockIdx.x * WAVES + wave) * 16 + p;
     const int nn0 = n0 < a.n ? n0 : a.n - 1;
@@ -1720,10 +1767,10 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   stage_weights<C, TRAIN>(lds, a.params);
   __syncthreads();
   NDQ_TS(1);
-  float* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
+  real* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
   GradAcc<C> acc;
   if constexpr (TRAIN) acc_init<C>(acc, lds, WAVES, wave, lane);
-  float lsum = 0.f;
+  real lsum = 0.f;
 #if NDQ_STAGGER > 0
   // two waves per SIMD run the same phases (VALU-heavy activation math, MFMA-heavy GEMMs) in lockstep and then compete for
   // the same pipe; delaying the second wave of every SIMD by a fraction of a tile lets one's MFMAs run under the
@@ -1733,7 +1780,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
-    float x[C::D];
+    real x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = xn[d];
     {
@@ -1742,14 +1789,14 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
 #pragma unroll
       for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn1];
     }
-    const float* ldsw = lds + opaque_zero<C>();
+    const real* ldsw = lds + opaque_zero<C>();
     LayerState<C> st[C::L];
-    f32x4 h[C::NS][C::NB];
+    real4 h[C::NS][C::NB];
     KeptPlanes<C> kp;
     NDQ_TT(0);
     tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp);
     NDQ_TT(1);
-    float jets[C::NS], gout[C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
+    real jets[C::NS], gout[C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
     tile_output<C, TRAIN>(ldsw, q, x, h, jets);
     NDQ_TT(2);
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
@@ -1783,11 +1830,11 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   // loss: lanes (only q == 0 lanes are non-zero) -> wave -> workgroup, fixed order
   lsum = point_sum(quad_sum(lsum));
   __syncthreads();
-  float* wl = lds + C::ldsWeightsEnd(TRAIN);
+  real* wl = lds + C::ldsWeightsEnd(TRAIN);
   if (lane == 0) wl[wave] = lsum;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float v = 0.f;
+    real v = 0.f;
     for (int w = 0; w < WAVES; ++w) v += wl[w];
     a.loss_partials[blockIdx.x] = v;
   }
@@ -1802,20 +1849,20 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
 // systems this serves are small and launch-bound, the extra per-point GEMMs are noise).  H = 32 class nets only.
 constexpr int kMaxFusedNets = 4;
 struct FusedMultiArgs {
-  const float* coords;                    // [D][ldc]
-  const float* params[kMaxFusedNets];     // K x [P]
-  float* partials[kMaxFusedNets];         // TRAIN: K x [gridDim.x][P]
-  float* loss_partials;                   // [gridDim.x]
-  float* funcs;                           // optional [NF][ldj]
-  float* resid;                           // optional [NEQ][ldj]
+  const real* coords;                    // [D][ldc]
+  const real* params[kMaxFusedNets];     // K x [P]
+  real* partials[kMaxFusedNets];         // TRAIN: K x [gridDim.x][P]
+  real* loss_partials;                   // [gridDim.x]
+  real* funcs;                           // optional [NF][ldj]
+  real* resid;                           // optional [NEQ][ldj]
   int n, ldc, ldj;
-  float seed;
+  real seed;
 };
 
 template <class C, int K, class PW, bool TRAIN>
 __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(FusedMultiArgs a) {
   static_assert(C::NOUT == 1 && !C::WIDE && K >= 2 && K <= kMaxFusedNets, "multi-network closure: n_out = 1, H <= 48, 2..4 nets");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) real lds[];
   constexpr int WS = C::ldsWeightsEnd(TRAIN);          // LDS floats per weight image
 #pragma unroll
   for (int k = 0; k < K; ++k) stage_weights<C, TRAIN>(lds + k * WS, a.params[k]);
@@ -1823,25 +1870,25 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   constexpr int WAVES = C::BWD_THREADS / 64;
   const int ntiles = (a.n + 15) >> 4;
-  float* stage = lds + K * WS + wave * C::stageFloatsPerWave;
+  real* stage = lds + K * WS + wave * C::stageFloatsPerWave;
   GradAcc<C> acc[K];
   if constexpr (TRAIN) {
 #pragma unroll
     for (int k = 0; k < K; ++k) { acc_zero<C>(acc[k]); acc[k].bias = nullptr; }
   }
-  float lsum = 0.f;
+  real lsum = 0.f;
   for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
     const int nn = valid ? n : a.n - 1;
-    float x[C::D];
+    real x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
-    float jets[K][C::NS], gout[K][C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
+    real jets[K][C::NS], gout[K][C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
     sfor<K>([&](auto k_) {
       constexpr int k = decltype(k_)::value;
       LayerState<C> st[C::L];
-      f32x4 h[C::NS][C::NB];
+      real4 h[C::NS][C::NB];
       KeptPlanes<C> kp;
       tile_forward<C, TRAIN>(lds + k * WS, lane, q, x, st, h, kp);
       tile_output<C, TRAIN>(lds + k * WS, q, x, h, jets[k]);
@@ -1864,7 +1911,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) gout[k][s] = valid ? gout[k][s] : 0.f;
         LayerState<C> st[C::L];
-        f32x4 h[C::NS][C::NB];
+        real4 h[C::NS][C::NB];
         KeptPlanes<C> kp;
         tile_forward<C, true>(lds + k * WS, lane, q, x, st, h, kp);
         tile_backward<C>(lds + k * WS, stage, lane, p, q, x, gout[k], st, acc[k], kp);
@@ -1880,11 +1927,11 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
   }
   lsum = point_sum(quad_sum(lsum));
   __syncthreads();
-  float* wl = lds + K * WS;
+  real* wl = lds + K * WS;
   if (lane == 0) wl[wave] = lsum;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float v = 0.f;
+    real v = 0.f;
     for (int w = 0; w < WAVES; ++w) v += wl[w];
     a.loss_partials[blockIdx.x] = v;
   }
@@ -1931,7 +1978,7 @@ template <class C> constexpr int group_xs() {
 template <class C, class PW, bool TRAIN>
 __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(FusedArgs a) {
   static_assert(!C::ACC_LDS && C::SKIP == 0, "grouped closure: H <= 48, no skip connection");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) real lds[];
   stage_weights<C, TRAIN>(lds, a.params);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
@@ -1939,29 +1986,29 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
   constexpr int XS = group_xs<C>();
   constexpr int G = group_tiles<C>(), GP = 16 * G;      // tiles / points per group
   const int ngroups = (a.n + GP - 1) / GP;
-  float* stage = lds + C::ldsWeightsEnd(TRAIN) + wave * C::stageFloatsPerWave;
-  float* X = lds + C::ldsWeightsEnd(TRAIN) + WAVES * C::stageFloatsPerWave + wave * (GP * XS);
+  real* stage = lds + C::ldsWeightsEnd(TRAIN) + wave * C::stageFloatsPerWave;
+  real* X = lds + C::ldsWeightsEnd(TRAIN) + WAVES * C::stageFloatsPerWave + wave * (GP * XS);
   GradAcc<C> acc;
   if constexpr (TRAIN) { acc_zero<C>(acc); acc.bias = nullptr; }
-  float lsum = 0.f;
+  real lsum = 0.f;
   for (int grp = blockIdx.x * WAVES + wave; grp < ngroups; grp += gridDim.x * WAVES) {
     const int n = grp * GP + lane;                       // this lane's point in phase 2 (lanes >= GP idle there)
     const bool valid = n < a.n && lane < GP;
     const int nn = valid ? n : a.n - 1;
-    float c[PW::NC];
+    real c[PW::NC];
 #pragma unroll
     for (int d = 0; d < PW::NC; ++d) c[d] = a.coords[(size_t)d * a.ldc + nn];
     // ---- phase 1: forward streams of the 4 tiles -> X
     NDQ_UNROLL(NDQ_GROUP_U1)
     for (int t = 0; t < G; ++t) {
-      float x[C::D];
+      real x[C::D];
       sfor<C::D>([&](auto d_) {
         constexpr int d = decltype(d_)::value;
         x[d] = __shfl(c[PW::dep(d)], 16 * t + p);
       });
       LayerState<C> st;
       first_layer<C, TRAIN>(lds, q, x, st);
-      f32x4 h[C::NS][C::NB];
+      real4 h[C::NS][C::NB];
 #pragma unroll
       for (int l = 2; l <= C::L; ++l) {
         act_forward<C>(st, h);
@@ -1974,16 +2021,16 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
         }
       }
       act_forward<C>(st, h);
-      float* row = X + (16 * t + p) * XS;
+      real* row = X + (16 * t + p) * XS;
       if constexpr (C::NOUT == 1) {
-        float out[C::NS];
+        real out[C::NS];
         tile_output<C, TRAIN>(lds, q, x, h, out);
         if (q == 0) {
 #pragma unroll
           for (int s = 0; s < C::NS; ++s) row[s] = out[s];
         }
       } else {
-        f32x4 o[C::NS][C::NBO];
+        real4 o[C::NS][C::NBO];
         output_layer_mfma<C, TRAIN>(lds, lane, q, h, o);
 #pragma unroll
         for (int s = 0; s < C::NS; ++s)
@@ -1998,8 +2045,8 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- phase 2: the per-point program, one point per lane
     {
-      float r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
-      float* row = X + (lane < GP ? lane : 0) * XS;
+      real r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
+      real* row = X + (lane < GP ? lane : 0) * XS;
       if (lane < GP) PW::apply(c, row, valid ? a.seed : 0.f, TRAIN ? 1 : 0, r, f, row);
       if (valid) {
         lsum += PW::loss(r);
@@ -2022,23 +2069,23 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
       NDQ_UNROLL(NDQ_GROUP_U3)
       for (int t = 0; t < G; ++t) {
         if ((grp * G + t) * 16 >= a.n) break;            // whole tile is padding (uniform over the wave)
-        float x[C::D];
+        real x[C::D];
         sfor<C::D>([&](auto d_) {
           constexpr int d = decltype(d_)::value;
           x[d] = __shfl(c[PW::dep(d)], 16 * t + p);
         });
         LayerState<C> st[C::L];
-        f32x4 h[C::NS][C::NB];
+        real4 h[C::NS][C::NB];
         KeptPlanes<C> kp;
         tile_forward<C, true>(lds, lane, q, x, st, h, kp);
-        const float* row = X + (16 * t + p) * XS;
+        const real* row = X + (16 * t + p) * XS;
         if constexpr (C::NOUT == 1) {
-          float gout[C::NS];
+          real gout[C::NS];
 #pragma unroll
           for (int s = 0; s < C::NS; ++s) gout[s] = row[s];
           tile_backward<C>(lds, stage, lane, p, q, x, gout, st, acc, kp);
         } else {
-          f32x4 go[C::NS][C::NBO];
+          real4 go[C::NS][C::NBO];
 #pragma unroll
           for (int s = 0; s < C::NS; ++s)
 #pragma unroll
@@ -2056,11 +2103,11 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
   if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
   lsum = point_sum(quad_sum(lsum));                      // all 64 lanes carry a point here
   __syncthreads();
-  float* wl = lds + C::ldsWeightsEnd(TRAIN);
+  real* wl = lds + C::ldsWeightsEnd(TRAIN);
   if (lane == 0) wl[wave] = lsum;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float v = 0.f;
+    real v = 0.f;
     for (int w = 0; w < WAVES; ++w) v += wl[w];
     a.loss_partials[blockIdx.x] = v;
   }
@@ -2072,20 +2119,20 @@ template <class C> constexpr size_t group_lds_bytes(bool train) {
   const int pp = (C::P + 3) & ~3;
   const int work = waves * (C::stageFloatsPerWave + 16 * group_tiles<C>() * group_xs<C>());
   const int red = train ? bwd_regions<C>(waves) * pp : 0;          // overlays the staging + exchange tiles at the end
-  return sizeof(float) * (C::ldsWeightsEnd(train) + (work > red ? work : red) + 16);
+  return sizeof(real) * (C::ldsWeightsEnd(train) + (work > red ? work : red) + 16);
 }
-template <class C> constexpr size_t fwd_lds_bytes() { return sizeof(float) * C::ldsWeightsEnd(false); }
+template <class C> constexpr size_t fwd_lds_bytes() { return sizeof(real) * C::ldsWeightsEnd(false); }
 template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock);
 template <class C> constexpr size_t fused_lds_bytes(bool train) {
-  return train ? bwd_lds_bytes<C>(C::BWD_THREADS / 64) : sizeof(float) * (C::ldsWeightsEnd(false) + 16);
+  return train ? bwd_lds_bytes<C>(C::BWD_THREADS / 64) : sizeof(real) * (C::ldsWeightsEnd(false) + 16);
 }
 template <class C> constexpr size_t fused_multi_lds_bytes(int nets, bool train) {
-  return fused_lds_bytes<C>(train) + sizeof(float) * (size_t)(nets - 1) * C::ldsWeightsEnd(train);
+  return fused_lds_bytes<C>(train) + sizeof(real) * (size_t)(nets - 1) * C::ldsWeightsEnd(train);
 }
 template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock) {
   const int pp = (C::P + 3) & ~3;
   const int stage = wavesPerBlock * C::stageFloatsPerWave;
   const int red = bwd_regions<C>(wavesPerBlock) * pp;
-  return sizeof(float) * (C::ldsWeightsEnd(true) + (stage > red ? stage : red) + wavesPerBlock * C::biasFloats);
+  return sizeof(real) * (C::ldsWeightsEnd(true) + (stage > red ? stage : red) + wavesPerBlock * C::biasFloats);
 }
 }  // namespace ndq

@@ -132,13 +132,13 @@ _ACT_IDS = {nn.Tanh: _lib.NDQ_ACT_TANH, SinActv: _lib.NDQ_ACT_SIN, nn.Sigmoid: _
             Swish: _lib.NDQ_ACT_SWISH, APTx: _lib.NDQ_ACT_APTX}
 
 
-def describe(net):
+def describe(net, dtype=torch.float32):
     """Return ``dict(d, hidden, layers, act, n_out, linears)`` if ``net`` is an FCNN the HIP kernels can run,
     else ``None`` (the solver then uses the composite autograd path for the whole system)."""
     skip = None
     if isinstance(net, Resnet):                  # FCNN branch + bias-free linear skip: out += S x, handled in-kernel
         skip, net = net.skip_connection, net.residual
-        if skip.bias is not None or skip.weight.dtype != torch.float32:
+        if skip.bias is not None or skip.weight.dtype != dtype:
             return None
     seq = getattr(net, "NN", net)
     if not isinstance(seq, nn.Sequential):
@@ -161,7 +161,7 @@ def describe(net):
         return None
     if linears[-1].in_features != hidden:
         return None
-    if any(p.dtype != torch.float32 for l in linears for p in l.parameters()):
+    if any(p.dtype != dtype for l in linears for p in l.parameters()):
         return None
     if skip is not None and (linears[-1].out_features != 1 or tuple(skip.weight.shape) != (1, linears[0].in_features)):
         return None          # the in-kernel skip connection serves single-output networks

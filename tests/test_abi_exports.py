@@ -15,6 +15,13 @@ def test_every_declared_symbol_is_exported():
     L = _lib.lib()
     for name in declared:
         assert getattr(L, name) is not None
+    declared64 = set(re.findall(r"^\s*int\s+(ndq64_\w+)\s*\(", header, flags=re.M))      # libndq64.so: the fp64 build
+    assert declared64 == set(_lib.EXPORTS64), declared64 ^ set(_lib.EXPORTS64)
+    L64 = _lib.lib64()
+    for name in declared64:
+        assert getattr(L64, name) is not None
+    d = _lib.MlpDesc(2, 1, 7, 32, 2, _lib.NDQ_ACT_TANH, 1, 0)
+    assert L64.ndq64_mlp_supported(ctypes.byref(d)) == 1 and L64.ndq64_mlp_num_streams(ctypes.byref(d)) == 6
 
 
 def test_descriptor_queries_without_gpu():

@@ -37,9 +37,9 @@ def cpu_ops():
         streams = autograd_ops._streams(d, order)
         z = J.mlp_jets(params.numpy(), dims(d, hidden, layers, n_out), ACT[act], [coords[a, :n].numpy() for a in range(d)],
                        streams)
-        jets = torch.zeros(len(streams) * n_out, coords.shape[1], dtype=torch.float32)
+        jets = torch.zeros(len(streams) * n_out, coords.shape[1], dtype=coords.dtype)
         for s, mi in enumerate(streams):
-            jets[s * n_out:(s + 1) * n_out, :n] = torch.from_numpy(z[mi].T.astype(np.float32))
+            jets[s * n_out:(s + 1) * n_out, :n] = torch.from_numpy(z[mi].T.copy()).to(coords.dtype)
         return jets
 
     def bwd(coords, params, gbar, n, order, hidden, layers, act, n_out):
@@ -48,7 +48,7 @@ def cpu_ops():
         g = {mi: gbar[s * n_out:(s + 1) * n_out, :n].numpy().T.astype(np.float64) for s, mi in enumerate(streams)}
         out = J.mlp_jets_vjp(params.numpy().astype(np.float64), dims(d, hidden, layers, n_out), ACT[act],
                              [coords[a, :n].numpy() for a in range(d)], g)
-        return torch.from_numpy(out.astype(np.float32))
+        return torch.from_numpy(out).to(coords.dtype)
 
     autograd_ops.mlp_jet_fwd.register_kernel("cpu")(fwd)
     autograd_ops.mlp_jet_bwd.register_kernel("cpu")(bwd)
@@ -56,7 +56,7 @@ def cpu_ops():
     autograd_ops._DEVICE_TYPES = ("cuda", "cpu")
     import neurodiffeq_amd.codegen as codegen
     keep = codegen.ensure_mlp_kernels
-    codegen.ensure_mlp_kernels = lambda desc: True
+    codegen.ensure_mlp_kernels = lambda desc, f64=False: True
     autograd_ops._SPECS.clear()
     yield
     autograd_ops._DEVICE_TYPES = old
@@ -134,10 +134,38 @@ def test_third_order_request_raises_and_plain_inputs_fall_back(cpu_ops):
     with torch.no_grad():
         v = net(t)
     assert torch.allclose(v, net.NN(t), atol=1e-6)
-    # fp64 nets / inputs: the plain Sequential
+    # fp64 networks have kernels of their own (libndq64.so); mixed precision is the plain Sequential's business
     net64 = FCNN(1, 1).double()
     out = net64(t.double())
-    assert "MlpJet" not in type(out.grad_fn).__name__
+    assert "MlpJet" in type(out.grad_fn).__name__
+    with pytest.raises(RuntimeError):
+        net64(t)            # fp32 input into an fp64 network: torch's own dtype error, not a kernel launch
+
+
+def test_fp64_closure_matches_reference_golden_cpu_plumbing(cpu_ops):
+    """The reference's default precision through the same seam: one closure of C2 and C1 in fp64 against the golden
+    fp64 vectors of the unmodified reference (1e-10: the oracle-backed CPU ops compute in fp64)."""
+    _fp64_closure("cpu", 1e-10)
+
+
+def _fp64_closure(device, tol):
+    for name, size in (("c2", 16), ("c1", 64)):
+        gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
+        torch.manual_seed(0)
+        cfg = configs.make(name, size)
+        nets = [n.double().to(device) for n in cfg["nets"]]
+        R.set_flat(nets, torch.from_numpy(gold["params0"]).double().to(device))
+        coords = [torch.from_numpy(c).double().reshape(-1, 1).to(device).requires_grad_(True) for c in gold["coords"]]
+        funcs = [cond.enforce(net, *coords) for net, cond in zip(nets, cfg["conds"])]
+        assert all("MlpJet" in type(n(torch.cat(coords, 1)).grad_fn).__name__ for n in nets)
+        res = torch.cat(cfg["pde"](*funcs, *coords), dim=1)
+        loss = (res ** 2).mean()
+        loss.backward()
+        grad = torch.cat([p.grad.reshape(-1) for n in nets for p in n.parameters()]).cpu().numpy()
+        assert rel_l2(torch.cat(funcs, 1).detach().cpu().numpy(), gold["funcs_f64"]) < tol
+        assert rel_l2(res.detach().cpu().numpy(), gold["residuals_f64"]) < tol
+        assert abs(loss.item() - float(gold["loss_f64"])) <= tol * abs(float(gold["loss_f64"]))
+        assert rel_l2(grad, gold["grad_f64"]) < tol, (name, rel_l2(grad, gold["grad_f64"]))
 
 
 def test_third_order_on_request(cpu_ops):
@@ -187,6 +215,39 @@ def test_hand_written_loop_on_the_hip_kernels_matches_reference_trajectory(name,
     assert calls["fwd"] == 3 * len(nets) and calls["bwd"] == 3 * len(nets), calls
     assert np.max(np.abs(losses - gold["traj_loss"]) / np.abs(gold["traj_loss"])) < 2e-5, (losses, gold["traj_loss"])
     assert rel_l2(params, gold["traj_params"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_fp64_closure_on_the_f64_mfma_kernels_matches_reference_golden():
+    """fp64 networks (the reference's default precision, neurodiffeq/__init__.py:22) on libndq64.so: the stream kernels
+    compiled for double (v_mfma_f64_16x16x4_f64).  One closure of C2 and C1 against the reference's golden fp64 vectors."""
+    _fp64_closure("cuda", 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,act,n_out,order", [(1, "tanh", 1, 2), (2, "tanh", 1, 2), (1, "sin", 1, 2), (2, "tanh", 3, 1),
+                                               (3, "tanh", 1, 2), (1, "sigmoid", 1, 3), (2, "sin", 1, 0)])
+def test_fp64_stream_kernels_match_jet_oracle(d, act, n_out, order):
+    """ndq64_mlp_jet_fwd / ndq64_mlp_jet_bwd through the dispatcher ops against the numpy jet oracle, ragged batch."""
+    from neurodiffeq_amd import codegen
+    act_id = {"tanh": 0, "sin": 1, "sigmoid": 2}[act]
+    desc = autograd_ops._desc(d, order, 32, 2, act_id, n_out)
+    assert codegen.ensure_mlp_kernels(desc, f64=True)
+    rng = np.random.default_rng(d * 100 + order)
+    dims = (d, 32, 32, n_out)
+    flat = np.concatenate([rng.uniform(-1, 1, a * b + b) / np.sqrt(a) for a, b in zip(dims[:-1], dims[1:])])
+    n, ld = 1003, 1024
+    coords = np.zeros((d, ld)); coords[:, :n] = rng.uniform(-1, 1, (d, n))
+    streams = autograd_ops._streams(d, order)
+    jets = torch.ops.ndq.mlp_jet_fwd(torch.from_numpy(coords).cuda(), torch.from_numpy(flat).cuda(), n, order, 32, 2, act_id, n_out)
+    want = J.mlp_jets(flat, dims, act, list(coords[:, :n]), streams)
+    for s, mi in enumerate(streams):
+        assert rel_l2(jets[s * n_out:(s + 1) * n_out, :n].T.cpu().numpy(), want[mi]) < 1e-12, mi
+    gbar = np.zeros((len(streams) * n_out, ld)); gbar[:, :n] = rng.standard_normal((len(streams) * n_out, n))
+    grad = torch.ops.ndq.mlp_jet_bwd(torch.from_numpy(coords).cuda(), torch.from_numpy(flat).cuda(), torch.from_numpy(gbar).cuda(),
+                                     n, order, 32, 2, act_id, n_out)
+    gb = {mi: gbar[s * n_out:(s + 1) * n_out, :n].T for s, mi in enumerate(streams)}
+    assert rel_l2(grad.cpu().numpy(), J.mlp_jets_vjp(flat, dims, act, list(coords[:, :n]), gb)) < 1e-11
 
 
 @pytest.mark.gpu
