@@ -61,6 +61,12 @@ __device__ __forceinline__ real4 mfma16x16x4(real a, real b, real4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 #endif
 }
+// Row of the A operand whose products land in "slot (q, r) = unit 4q + r" of the 16-row block a lane holds.  The f32
+// 16x16x4 MFMA puts row 4q + r of D into register r of lane group q -- the fragment layout of this file; the f64 one puts
+// row q + 4r there (measured: scripts/ubench_mfma_f64_layout.hip).  Hidden units may be numbered any way inside a block
+// as long as every use agrees, so the fp64 build keeps the fragment layout and feeds the MFMA its A rows permuted:
+// operand row i' carries unit mrow(i') = 4 (i' mod 4) + i' / 4.
+__device__ __forceinline__ constexpr int mrow(int i) { return NDQ_F64 ? 4 * (i & 3) + (i >> 2) : i; }
 
 // ------------------------------------------------------------------------------------------------ phase timestamps
 // Experiments only (-DNDQ_PHASE_TS via NDQ_JIT_FLAGS; scripts/phase_ts.py): thread 0 of every workgroup records the
@@ -500,13 +506,13 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
       const int lane = i & 63, t = (i >> 6) & 3, blk = i >> 8;
       {  // forward A operand of block (ob, kb): blk = ob*NB + kb:  A[i'][q'] = Wo[16 ob + i'][16 kb + 4 q' + t]
         const int ob = blk / NB, kb = blk - ob * NB;
-        const int o = 16 * ob + (lane & 15);
+        const int o = 16 * ob + mrow(lane & 15);
         lds[C::ldsWout(BWD) + i] = o < C::NOUT ? Wo[o * H + 16 * kb + 4 * (lane >> 4) + t] : 0.f;
       }
       if (BWD) {  // transposed A operand of block (kb, ob): blk = kb*NBO + ob:  A[i'][q'] = Wo[16 ob + 4 q' + t][16 kb + i']
         const int kb = blk / NBO, ob = blk - kb * NBO;
         const int o = 16 * ob + 4 * (lane >> 4) + t;
-        lds[C::ldsWoutT() + i] = o < C::NOUT ? Wo[o * H + 16 * kb + (lane & 15)] : 0.f;
+        lds[C::ldsWoutT() + i] = o < C::NOUT ? Wo[o * H + 16 * kb + mrow(lane & 15)] : 0.f;
       }
     }
     for (int i = tid; i < C::HO; i += nt) lds[C::ldsbout(BWD) + i] = i < C::NOUT ? prm[C::offbout + i] : 0.f;
@@ -546,9 +552,9 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
       const int lane = i & 63, t = (i >> 6) & 3, blk = i >> 8;  // blk = first*NB + second
       const int b0 = blk / NB, b1 = blk - b0 * NB;
       // forward A operand of block (ib=b0, kb=b1), step t:  A[i'][k=q'] = W[16 ib + i'][16 kb + 4 q' + t]
-      lds[C::ldsWf(l, BWD) + i] = W[(16 * b0 + (lane & 15)) * H + 16 * b1 + 4 * (lane >> 4) + t];
+      lds[C::ldsWf(l, BWD) + i] = W[(16 * b0 + mrow(lane & 15)) * H + 16 * b1 + 4 * (lane >> 4) + t];
       if (BWD)  // transposed A operand of block (kb=b0, ib=b1): A[i'][k=q'] = W[16 ib + 4 q' + t][16 kb + i']
-        lds[C::ldsWt(l) + i] = W[(16 * b1 + 4 * (lane >> 4) + t) * H + 16 * b0 + (lane & 15)];
+        lds[C::ldsWt(l) + i] = W[(16 * b1 + 4 * (lane >> 4) + t) * H + 16 * b0 + mrow(lane & 15)];
     }
     for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = prm[C::offb(l) + i];
   }
@@ -1275,7 +1281,7 @@ __device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q,
         for (int st = 0; st < 4; ++st) {
           real a1[NBA], b1[C::NB];
 #pragma unroll
-          for (int b = 0; b < NBA; ++b) a1[b] = Zt[(4 * q + st) * HP + 16 * b + p];
+          for (int b = 0; b < NBA; ++b) a1[b] = Zt[(4 * q + st) * HP + 16 * b + mrow(p)];
 #pragma unroll
           for (int b = 0; b < C::NB; ++b) b1[b] = Ht[(4 * q + st) * HP + 16 * b + p];
 #pragma unroll
@@ -1298,7 +1304,7 @@ __device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q,
 #pragma unroll
       for (int st = 0; st < 4; ++st) {
 #pragma unroll
-        for (int b = 0; b < NBA; ++b) av[k][st][b] = Zt[(4 * q + st) * HP + 16 * b + p];
+        for (int b = 0; b < NBA; ++b) av[k][st][b] = Zt[(4 * q + st) * HP + 16 * b + mrow(p)];
 #pragma unroll
         for (int b = 0; b < C::NB; ++b) bv[k][st][b] = Ht[(4 * q + st) * HP + 16 * b + p];
       }
