@@ -64,45 +64,6 @@ def time_launches(fn, iters=1000, warm=200):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def closure_in_situ(solver, system, steps):
-    """Average duration of the closure kernel INSIDE real training steps (closure -> sums/tail -> closure ...): HIP
-    events recorded by the native step right before / after the kernel on the stream it runs on, `steps` epochs."""
-    hip = ctypes.CDLL("libamdhip64.so")
-    hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
-    hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
-    hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
-    pairs = []
-    for _ in range(steps):
-        a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        assert hip.hipEventCreate(ctypes.byref(a)) == 0 and hip.hipEventCreate(ctypes.byref(b)) == 0
-        pairs.append((a.value, b.value))
-    def elapsed(a, b):
-        ms = ctypes.c_float()
-        assert hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0
-        return ms.value * 1e-3
-
-    # what an event pair costs by itself on a busy stream (two records with nothing in between)
-    hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    scratch = torch.zeros(1024, device="cuda")
-    empty = []
-    for a, b in pairs[:min(50, steps)]:
-        scratch.add_(1.0)
-        hip.hipEventRecord(a, stream), hip.hipEventRecord(b, stream)
-    torch.cuda.synchronize()
-    empty = sorted(elapsed(a, b) for a, b in pairs[:min(50, steps)])
-    overhead = empty[len(empty) // 2]
-    system.closure_events = list(pairs)
-    for _ in range(steps):
-        solver.run_train_epoch()
-    torch.cuda.synchronize()
-    assert not system.closure_events
-    raw = sum(elapsed(a, b) for a, b in pairs) / steps
-    for a, b in pairs:
-        hip.hipEventDestroy(a), hip.hipEventDestroy(b)
-    return raw - overhead, raw, overhead
-
-
 def fused_breakdown(system, batch):
     """Launch time of the single-launch fused closure kernel (forward + pointwise + reverse) on a resident batch."""
     from neurodiffeq_amd.engine import _c_vp, _ptr
@@ -482,14 +443,8 @@ def main():
         kb = kernel_breakdown(pipeline, batch)
         if system.fusedk is not None:
             kb.update(fused_breakdown(system, batch))
-            kb["fused_closure"]["back_to_back_us"] = kb["fused_closure"]["us"]
-            t_situ, t_raw, t_ev = closure_in_situ(solver, system, min(args.steps, 2000))
-            flop = (FWD_FLOP_PER_PT + BWD_FLOP_PER_PT) * N_POINTS
-            # two HIP-event measurements of the same kernel: inside real steps (event pair minus what an empty pair
-            # costs: the calibration moves by ~1 us between boxes) and 200 launches back to back between two events.
-            # The roofline is priced with the LARGER of the two.
-            t_kernel = max(t_situ, kb["fused_closure"]["back_to_back_us"] * 1e-6)
-            kb["fused_closure"].update(us=t_kernel * 1e6, tflops=flop / t_kernel / 1e12, in_situ_us=t_situ * 1e6)
+            # HIP events on the stream the kernel runs on, 1 000 launches back to back (rocprofv3's kernel trace of the same
+            # command is committed under profiles/ and must agree)
             threads = system.fused_variant(N_POINTS).threads
             out["roofline"] = {"kernel": "fused_closure_kernel<Cfg<2,1,5,2,2,tanh>, PW, train> (fwd + pointwise + bwd), "
                                          f"{threads} threads per workgroup",
@@ -497,11 +452,7 @@ def main():
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": kb["fused_closure"]["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                                "algorithmic_flop_per_point": FWD_FLOP_PER_PT + BWD_FLOP_PER_PT,
-                               # max(in situ, back to back), see above
                                "avg_launch_us": kb["fused_closure"]["us"],
-                               "in_situ_us": kb["fused_closure"]["in_situ_us"],
-                               "back_to_back_us": kb["fused_closure"]["back_to_back_us"],
-                               "event_pair_us": {"raw": t_raw * 1e6, "empty_pair": t_ev * 1e6},
                                # the kernel carries u_xx + u_yy as ONE "Laplacian" stream when the tracer proves the
                                # residual only needs the sum, i.e. it executes 4 streams instead of SURVEY's 5
                                "executed_streams": system.program.streams[0].n_streams,

@@ -158,8 +158,6 @@ typedef struct ndq_fused_step {
   float* best_flat;           /* [P] */
   ndq_allreduce_fn allreduce; /* data parallel: sums grad[0..P) and the loss slot, which must be grad[P] (one message) */
   void* comm;                 /* ncclComm_t for `allreduce` */
-  void* ev_start;             /* optional hipEvent_t recorded on `stream` right before the closure kernel ... */
-  void* ev_stop;              /* ... and right after it (in-situ kernel timing, bench.py); NULL: nothing recorded */
   /* optional prefetch of the NEXT batch of a device generator: extra workgroups of the sums + tail kernel draw
    * (next_sampler, next_seed, next_draw, next_stream) into next_coords [d][next_ldc] -- the block this step's closure
    * kernel has just finished reading -- so the sampler launch leaves the step.  NULL: nothing drawn. */

@@ -44,7 +44,6 @@ class FusedStep(ctypes.Structure):
                 ("weight_decay", ctypes.c_float),
                 ("loss_hist", ctypes.c_void_p), ("best_loss", ctypes.c_void_p), ("best_flat", ctypes.c_void_p),
                 ("allreduce", ctypes.c_void_p), ("comm", ctypes.c_void_p),
-                ("ev_start", ctypes.c_void_p), ("ev_stop", ctypes.c_void_p),
                 ("next_sampler", ctypes.c_void_p), ("next_seed", ctypes.c_ulonglong), ("next_draw", ctypes.c_ulonglong),
                 ("next_stream", ctypes.c_uint), ("next_coords", ctypes.c_void_p), ("next_ldc", ctypes.c_int)]
 

@@ -499,11 +499,9 @@ static void fill_reduce_tail(ReduceTailArgs& a, const ndq_fused_step* s, const f
 int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_step, int hist_index, int parity,
                        void* stream) {
   if (!s || !s->launch || !coords) return NDQ_EINVAL;
-  if (s->ev_start) (void)hipEventRecord(static_cast<hipEvent_t>(s->ev_start), static_cast<hipStream_t>(stream));
   int rc = s->launch(coords, s->ldc, s->n, s->params, s->partials, s->loss_partials, nullptr, nullptr, s->ldj, s->seed,
                      1, stream);
   if (rc) return rc;
-  if (s->ev_stop) (void)hipEventRecord(static_cast<hipEvent_t>(s->ev_stop), static_cast<hipStream_t>(stream));
   if (!s->adam_m)
     return ndq_reduce_grad_loss(s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks,
                                 s->loss_slot, s->seed, stream);

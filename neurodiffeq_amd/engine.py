@@ -237,7 +237,6 @@ class FusedSystem:
         self._bufs = {}
         self._resident_cache = {}
         self._static, self._static_seen = {}, {}
-        self.closure_events = []        # bench.py: (hipEvent_t start, stop) pairs, one consumed per native training step
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.loss_buf = torch.zeros(64, dtype=torch.float32, device=self.device)
 
@@ -746,7 +745,6 @@ class FusedSystem:
         stream = self._stream()
         coords = self._coord_ptr(b, 0)
         hist_index, parity = fs["pending"], fs["parity"]
-        st.ev_start, st.ev_stop = self.closure_events.pop() if self.closure_events else (None, None)
         # a prefetching DeviceGenerator: the tail kernel's extra workgroups draw the next batch into the block this
         # step's closure kernel has just read (single GPU only: the data-parallel tail is a different kernel)
         src = generators.device_source(batch) if dist is None else None

@@ -300,6 +300,54 @@ def make(name, seed=0):
           "traj =", out["traj_loss"], "->", os.path.getsize(path), "bytes")
 
 
+FULL_SIZES = {"c1": 1024, "c2": 256, "c3": 512, "c4": 131072, "c5": 1024}
+
+
+def make_full(name, seed=0, chunk=32768):
+    """The BASELINE config at its STATED size, evaluated by the unmodified reference in fp64: loss, flat parameter gradient
+    and per-column sums of the function values / squared residuals of one training closure (solvers.py:369-395).  The
+    batch is the reference generator's own draw under ``seed + 1`` (bit-exact contract: the tests regenerate it); the
+    reference's functions are called on chunks of the batch because its autograd graph for C5 at 1 048 576 points needs
+    ~43 GB -- the loss is a mean and the gradient a sum over points, so the chunk results add up exactly.  Only O(P)
+    numbers are stored (``<name>_full.npz``), not the million-point vectors."""
+    torch.manual_seed(seed)
+    cfg = CONFIGS[name](FULL_SIZES[name])
+    torch.manual_seed(seed + 1)
+    draw = cfg["gen"].get_examples()
+    coords = [c.detach().clone() for c in ([draw] if isinstance(draw, torch.Tensor) else list(draw))]
+    n = coords[0].numel()
+    nets = [net.to(torch.float64) for net in cfg["nets"]]
+    params0 = flat_params(cfg["nets"]).to(torch.float32).numpy()
+    for net in nets:
+        net.zero_grad()
+    if cfg.get("enforcer") is not None:
+        for c in cfg["conds"]:
+            c.R_0, c.R_1 = c.R_0.to(torch.float64), c.R_1.to(torch.float64)
+    loss, fsum, r2sum, n_eq = 0.0, None, None, None
+    for lo in range(0, n, chunk):
+        batch = [c[lo:lo + chunk].to(torch.float64).reshape(-1, 1).requires_grad_(True) for c in coords]
+        if cfg.get("enforcer") is not None:
+            funcs = [cfg["enforcer"](net, c, batch) for net, c in zip(nets, cfg["conds"])]
+        else:
+            funcs = [c.enforce(net, *batch) for net, c in zip(nets, cfg["conds"])]
+        res = torch.cat(cfg["pde"](*funcs, *batch), dim=1)
+        n_eq = res.shape[1]
+        part = (res ** 2).sum() / (n * n_eq)
+        part.backward()
+        loss += part.item()
+        f = torch.cat(funcs, dim=1).detach().sum(dim=0)
+        r = (res.detach() ** 2).sum(dim=0)
+        fsum, r2sum = (f if fsum is None else fsum + f), (r if r2sum is None else r2sum + r)
+    grad = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                      for net in nets for p in net.parameters()])
+    path = os.path.join(HERE, f"{name}_full.npz")
+    np.savez_compressed(path, seed=np.asarray(seed), n_points=np.asarray(n), params0=params0, loss_f64=np.asarray(loss),
+                        grad_f64=grad.numpy(), funcs_sum=fsum.numpy(), resid_sq_sum=r2sum.numpy(),
+                        coords_head=np.stack([c[:8].numpy() for c in coords]),
+                        coords_sum=np.asarray([c.double().sum().item() for c in coords]))
+    print(name, "full: N =", n, "loss64 =", loss, "|grad| =", float(grad.norm()), "->", os.path.getsize(path), "bytes")
+
+
 def make_diff_known_answers():
     """Known-answer vectors for diff()/operators on closed-form functions (mirrors the reference's
     tests/test_neurodiffeq.py:87-96 and tests/test_operators_cartesian.py:62-111), fp64."""
@@ -376,6 +424,9 @@ if __name__ == "__main__":
     for name in CONFIGS:
         if not only or name in only:
             make(name)
+    for name in FULL_SIZES:
+        if not only or name + "_full" in only:
+            make_full(name)
     if not only:
         make_diff_known_answers()
     if not only or "generators" in only:

@@ -450,6 +450,42 @@ def test_fused_closure_matches_oracle_at_size(name, size, mode):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("name,size,mode", [("c1", 1024, "1k"), ("c2", 256, "1k"), ("c2", 256, "3k"), ("c3", 512, "1k"), ("c3", 512, "3k"),
+                                            ("c4", 131072, "1k"), ("c4", 131072, "3k"), ("c5", 1024, "1k"), ("c5", 1024, "3k")])
+def test_fused_closure_matches_reference_golden_at_stated_size(golden_dir, name, size, mode):
+    """The BASELINE configs at their STATED sizes against numbers the unmodified reference produced (fp64; script:
+    tests/golden/make_golden.py make_full -> <name>_full.npz): loss, flat gradient, and the per-column sums of function
+    values and squared residuals of one closure.  The batch is regenerated here from the seed -- the generators'
+    bit-exact contract -- and checked against the head and the sum of the reference's own draw."""
+    gold = np.load(os.path.join(golden_dir, f"{name}_full.npz"))
+    cfg, system = _load_system(name, size, single_kernel=(mode == "1k"))
+    if mode == "1k" and system.fusedk is None:
+        pytest.skip("no single-launch closure kernel for this system")
+    R.set_flat(cfg["nets"], gold["params0"])
+    torch.manual_seed(int(gold["seed"]) + 1)
+    ex = cfg["gen"].get_examples()
+    coords = [ex.detach()] if isinstance(ex, torch.Tensor) else [c.detach() for c in ex]
+    assert coords[0].numel() == int(gold["n_points"])
+    assert np.array_equal(np.stack([c[:8].numpy() for c in coords]), gold["coords_head"])
+    assert np.array_equal(np.asarray([c.double().sum().item() for c in coords]), gold["coords_sum"])
+    b, n = system.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    n_eq = gold["resid_sq_sum"].shape[0]
+    fsum = b["funcs"][:, :n].double().sum(dim=1).cpu().numpy()
+    r2sum = (b["resid"][:n_eq, :n].double() ** 2).sum(dim=1).cpu().numpy()
+    grad = np.concatenate([fp.grad.cpu().numpy() for fp in system.flat])
+    loss = float(system.loss_buf[0].item())
+    errs = dict(loss=abs(loss - float(gold["loss_f64"])) / abs(float(gold["loss_f64"])),
+                grad=rel_l2(grad, gold["grad_f64"]), funcs_sum=rel_l2(fsum, gold["funcs_sum"]),
+                resid_sq_sum=rel_l2(r2sum, gold["resid_sq_sum"]))
+    off = 0
+    for k, fp in enumerate(system.flat):
+        errs[f"grad_net{k}"] = rel_l2(grad[off:off + fp.numel], gold["grad_f64"][off:off + fp.numel])
+        off += fp.numel
+    diag(f"closure_refgold_full_{name}_{mode}", errs)
+    assert max(errs.values()) < TOL, errs
+
+
 @pytest.mark.parametrize("mode", ["1k", "3k"])
 @pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide",
                                   "stokes_like", "kdv", "ode3", "poisson3d", "hessian3d", "shell", "swish_laplace", "sigmoid_mixed",

@@ -57,6 +57,27 @@ def test_closure_matches_reference(golden_dir, name, prec):
     assert rel_l2(R.get_flat_grad(cfg["nets"]).numpy(), g[f"grad_{prec}"]) < tol
 
 
+@pytest.mark.parametrize("name,size", [("c1", 1024), ("c2", 256), ("c4", 131072), ("c3", 512), ("c5", 1024)])
+def test_chunked_closure_matches_reference_at_stated_size(golden_dir, name, size):
+    """The chunked oracle walk the at-size GPU parity tests rely on (autograd_ref.closure_chunked), against what the
+    unmodified reference produced at the BASELINE size (<name>_full.npz); the batch comes from the port's generators
+    under the same seed (C5: 1 048 576 points, ~20 s here)."""
+    g = _load(golden_dir, f"{name}_full")
+    torch.manual_seed(int(g["seed"]))
+    cfg = R.build_config(name, size, dtype=torch.float64)
+    R.set_flat(cfg["nets"], torch.from_numpy(g["params0"]).double())
+    sampler = R.build_config(name, size)["sampler"]           # the draw is fp32, like the reference's generators
+    torch.manual_seed(int(g["seed"]) + 1)
+    coords = sampler()
+    assert np.array_equal(np.stack([c[:8].numpy() for c in coords]), g["coords_head"])
+    assert np.array_equal(np.asarray([c.double().sum().item() for c in coords]), g["coords_sum"])
+    out = R.closure_chunked(cfg["nets"], cfg["enforcers"], cfg["pde"], [c.double() for c in coords], chunk=16384, keep=True)
+    assert abs(out["loss"].item() - float(g["loss_f64"])) <= 1e-11 * abs(float(g["loss_f64"]))
+    assert rel_l2(R.get_flat_grad(cfg["nets"]).numpy(), g["grad_f64"]) < 1e-11
+    assert rel_l2(out["funcs"].sum(dim=0).numpy(), g["funcs_sum"]) < 1e-11
+    assert rel_l2((out["residuals"] ** 2).sum(dim=0).numpy(), g["resid_sq_sum"]) < 1e-11
+
+
 @pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5"])
 def test_adam_trajectory_matches_reference(golden_dir, name):
     g = _load(golden_dir, name)
