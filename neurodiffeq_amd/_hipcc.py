@@ -25,7 +25,7 @@ HIPCC = os.environ.get("NDQ_HIPCC", "/opt/rocm/bin/hipcc")
 LLVM_BIN = os.environ.get("NDQ_LLVM_BIN", os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))),
                                                        "lib", "llvm", "bin"))
 ARCH = "gfx950"
-BASE_FLAGS = ["-O3", "-std=c++17", "-fPIC"]
+BASE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")]
 # part of every cache key: bump when the fix-up rules change so that cached kernels are rebuilt
 FIXUP_VERSION = "pk-opsel-scalar+mfma-nop-2"
 

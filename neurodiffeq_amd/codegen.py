@@ -396,7 +396,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         for k in range(K):
             for loc in range(ns):
                 stores.append(f"    {gj(k, loc)} = {'g[%d]' % used[(k, loc)] if (k, loc) in used else '0.0f'};")
-        header = os.path.join(HERE, "csrc", "ndq_mlp.h")
+        header = "ndq_mlp.h"                 # found through -I csrc (_hipcc.BASE_FLAGS): sources and cache keys do not depend on the checkout path
         neq, nf = len(self.residuals), len(self.funcs)
         jets_t = "const float (&jets)[CFG::NS]" if K == 1 else f"const float (&jets)[{K}][CFG::NS]"
         gj_t = "float (&gj)[CFG::NS]" if K == 1 else f"float (&gj)[{K}][CFG::NS]"
@@ -514,7 +514,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
         stores = [f"    grow[{row(loc)}] = {'g[%d]' % used[loc] if loc in used else '0.0f'};" for loc in range(width)]
         deps = list(st.deps)
         dep_fn = " : ".join(f"d == {d} ? {c}" for d, c in enumerate(deps)) + " : 0"
-        header = os.path.join(HERE, "csrc", "ndq_mlp.h")
+        header = "ndq_mlp.h"                 # found through -I csrc (_hipcc.BASE_FLAGS): sources and cache keys do not depend on the checkout path
         neq, nf = len(self.residuals), len(self.funcs)
         kern = lambda train: f"ndq::fused_group_closure_kernel<CFG, PW, {train}>"
         lds = lambda train: f"ndq::group_lds_bytes<CFG>({train})"
@@ -818,7 +818,7 @@ def mlp_ext_allowed(desc):
 
 
 def mlp_ext_source(desc, f64=False):
-    header = os.path.join(HERE, "csrc", "ndq_launch.h")
+    header = "ndq_launch.h"              # -I csrc, as above
     record = "ndq64_mlp_kernels" if f64 else "ndq_mlp_kernels"
     return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
 {"#define NDQ_F64 1" if f64 else ""}

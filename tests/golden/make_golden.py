@@ -306,7 +306,8 @@ FULL_SIZES = {"c1": 1024, "c2": 256, "c3": 512, "c4": 131072, "c5": 1024}
 def make_full(name, seed=0, chunk=32768):
     """The BASELINE config at its STATED size, evaluated by the unmodified reference in fp64: loss, flat parameter gradient
     and per-column sums of the function values / squared residuals of one training closure (solvers.py:369-395).  The
-    batch is the reference generator's own draw under ``seed + 1`` (bit-exact contract: the tests regenerate it); the
+    batch is the reference generator's own draw under ``seed + 1`` (bit-exact contract: the tests regenerate it and
+    compare the first values plus an exact, order-independent checksum -- the int64 sum of the fp32 bit patterns); the
     reference's functions are called on chunks of the batch because its autograd graph for C5 at 1 048 576 points needs
     ~43 GB -- the loss is a mean and the gradient a sum over points, so the chunk results add up exactly.  Only O(P)
     numbers are stored (``<name>_full.npz``), not the million-point vectors."""
@@ -344,7 +345,7 @@ def make_full(name, seed=0, chunk=32768):
     np.savez_compressed(path, seed=np.asarray(seed), n_points=np.asarray(n), params0=params0, loss_f64=np.asarray(loss),
                         grad_f64=grad.numpy(), funcs_sum=fsum.numpy(), resid_sq_sum=r2sum.numpy(),
                         coords_head=np.stack([c[:8].numpy() for c in coords]),
-                        coords_sum=np.asarray([c.double().sum().item() for c in coords]))
+                        coords_bits_sum=np.asarray([c.view(torch.int32).to(torch.int64).sum().item() for c in coords]))
     print(name, "full: N =", n, "loss64 =", loss, "|grad| =", float(grad.norm()), "->", os.path.getsize(path), "bytes")
 
 

@@ -467,7 +467,7 @@ def test_fused_closure_matches_reference_golden_at_stated_size(golden_dir, name,
     coords = [ex.detach()] if isinstance(ex, torch.Tensor) else [c.detach() for c in ex]
     assert coords[0].numel() == int(gold["n_points"])
     assert np.array_equal(np.stack([c[:8].numpy() for c in coords]), gold["coords_head"])
-    assert np.array_equal(np.asarray([c.double().sum().item() for c in coords]), gold["coords_sum"])
+    assert np.array_equal(np.asarray([c.view(torch.int32).to(torch.int64).sum().item() for c in coords]), gold["coords_bits_sum"])
     b, n = system.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)
     torch.cuda.synchronize()
     n_eq = gold["resid_sq_sum"].shape[0]

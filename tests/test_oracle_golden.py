@@ -70,7 +70,7 @@ def test_chunked_closure_matches_reference_at_stated_size(golden_dir, name, size
     torch.manual_seed(int(g["seed"]) + 1)
     coords = sampler()
     assert np.array_equal(np.stack([c[:8].numpy() for c in coords]), g["coords_head"])
-    assert np.array_equal(np.asarray([c.double().sum().item() for c in coords]), g["coords_sum"])
+    assert np.array_equal(np.asarray([c.view(torch.int32).to(torch.int64).sum().item() for c in coords]), g["coords_bits_sum"])
     out = R.closure_chunked(cfg["nets"], cfg["enforcers"], cfg["pde"], [c.double() for c in coords], chunk=16384, keep=True)
     assert abs(out["loss"].item() - float(g["loss_f64"])) <= 1e-11 * abs(float(g["loss_f64"]))
     assert rel_l2(R.get_flat_grad(cfg["nets"]).numpy(), g["grad_f64"]) < 1e-11
