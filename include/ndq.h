@@ -19,8 +19,8 @@ extern "C" {
 #define NDQ_ACT_TANH 0 /* torch.nn.Tanh, default of FCNN (networks.py:27,52-53) */
 #define NDQ_ACT_SIN 1  /* neurodiffeq.networks.SinActv (networks.py:142-152) */
 #define NDQ_ACT_SIGMOID 2 /* torch.nn.Sigmoid passed as FCNN(actv=...) (networks.py:52-53) */
-#define NDQ_ACT_SWISH 3   /* neurodiffeq.networks.Swish with its default fixed beta = 1 (networks.py:155-175) */
-#define NDQ_ACT_APTX 4    /* neurodiffeq.networks.APTx with its default fixed alpha = 1, beta = 1, gamma = 0.5 (networks.py:177-209) */
+#define NDQ_ACT_SWISH 3   /* neurodiffeq.networks.Swish (networks.py:155-175); actp = 0: its default fixed beta = 1 */
+#define NDQ_ACT_APTX 4    /* neurodiffeq.networks.APTx (networks.py:177-209); actp = 0: default fixed alpha = 1, beta = 1, gamma = 0.5 */
 
 /* Shape of one FCNN (networks.py:59-66: Linear(d,h) actv [Linear(h,h) actv]* Linear(h,n_out)) plus the set of
  * derivative streams of its raw output that the residual needs.  Stream order in every jets/gbar array:
@@ -36,11 +36,15 @@ typedef struct ndq_mlp_desc {
   int act;     /* NDQ_ACT_* */
   int n_out;   /* output units */
   int lap;     /* 1: "Laplacian stream" -- the diagonal pairs of mask2 are carried as ONE stream holding their sum */
-  int skip;    /* 1: Resnet (networks.py:73-106): out += S x with a trainable bias-free S (n_out x d) that follows the
-                  output bias in the flat parameter vector; n_out = 1 only */
+  int skip;    /* 1: Resnet (networks.py:73-106): out += S x with a trainable bias-free S (n_out x d, row-major) that
+                  follows the output bias in the flat parameter vector */
   int mask3;   /* third-order triple mask: bit k <-> k-th triple a <= b <= c in lexicographic order; those streams follow
                   the second-order ones.  A triple needs its three pairs in mask2; lap must be 0.  (Sobolev losses of
                   second-order PDEs, losses.py:17-26; diff(u, t, order=3), neurodiffeq.py:21-34) */
+  int actp;    /* 1: trainable activation parameters (Swish(trainable=True): beta; APTx(trainable=True): alpha, beta,
+                  gamma -- one set per hidden layer, networks.py:166-169,196-203).  They sit at the END of the flat
+                  parameter vector, layer after layer, and get gradient entries like every other parameter; beta and
+                  gamma must be non-zero */
 } ndq_mlp_desc;
 
 /* One compiled kernel pair (forward streams / parameter-gradient adjoint) for ONE descriptor.  libndq.so carries a

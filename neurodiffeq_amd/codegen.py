@@ -416,7 +416,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}>;
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf}, NR = {self.n_r};
   static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
@@ -524,7 +524,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}>;
 static_assert(CFG::NS * CFG::NOUT == {width}, "stream layout of the traced program and of the kernel disagree");
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf}, NC = {self.n_coords}, NR = {self.n_r};
@@ -814,7 +814,7 @@ def mlp_ext_allowed(desc):
             and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
             and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0))
-            and desc.skip in (0, 1) and (desc.skip == 0 or desc.n_out == 1))
+            and desc.skip in (0, 1) and desc.actp in (0, 1) and (desc.actp == 0 or desc.act in (3, 4)))
 
 
 def mlp_ext_source(desc, f64=False):
@@ -823,7 +823,7 @@ def mlp_ext_source(desc, f64=False):
     return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
 {"#define NDQ_F64 1" if f64 else ""}
 #include "{header}"
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}>;
 extern "C" const {record}* ndq_ext_kernels(void) {{
   static const {record} k = ndq::make_kernels<CFG>();
   return &k;
@@ -915,7 +915,7 @@ def fuse_mode(program: PointwiseProgram, descs=None):
     if K == 1:
         st = program.streams[0]
         d0 = descs[0] if descs is not None and 0 in descs else None
-        group_ok = (d0 is not None and d0.hidden <= 48 and d0.skip == 0 and all(c < program.n_coords for c in st.deps)
+        group_ok = (d0 is not None and d0.hidden <= 48 and all(c < program.n_coords for c in st.deps)
                     and not os.environ.get("NDQ_NO_GROUP_FUSE"))
         if plain and not (group_ok and os.environ.get("NDQ_FUSE_GROUP") == "1"):
             return "tile"

@@ -297,7 +297,7 @@ __device__ __forceinline__ real tanh_fast(real z) {
 
 template <int ACT> struct Act;
 template <> struct Act<ACT_TANH> {  // nn.Tanh, networks.py:27 default
-  static __device__ __forceinline__ void fwd(real z, real& t, real& c) {
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c, real = 1.f) {
 #if NDQ_FAST_TANH || NDQ_F64
     t = tanh_fast(z);
 #else
@@ -305,7 +305,7 @@ template <> struct Act<ACT_TANH> {  // nn.Tanh, networks.py:27 default
 #endif
     c = 0.f;
   }
-  static __device__ __forceinline__ real s1(real t, real) { return rfma(-t, t, 1.f); }
+  static __device__ __forceinline__ real s1(real t, real, real = 1.f) { return rfma(-t, t, 1.f); }
   static __device__ __forceinline__ real s2(real t, real, real s1v) { return -2.f * t * s1v; }
   static __device__ __forceinline__ real s3(real t, real, real s1v) { return -2.f * s1v * rfma(-3.f * t, t, 1.f); }
   // fourth derivative: -2 s2 (1 - 3 t^2) + 12 t s1^2 with s2 = -2 t s1
@@ -314,14 +314,14 @@ template <> struct Act<ACT_TANH> {  // nn.Tanh, networks.py:27 default
   }
 };
 template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
-  static __device__ __forceinline__ void fwd(real z, real& t, real& c) {
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c, real = 1.f) {
 #if NDQ_F64
     sincos(z, &t, &c);
 #else
     sincosf(z, &t, &c);
 #endif
   }
-  static __device__ __forceinline__ real s1(real, real c) { return c; }
+  static __device__ __forceinline__ real s1(real, real c, real = 1.f) { return c; }
   static __device__ __forceinline__ real s2(real t, real, real) { return -t; }
   static __device__ __forceinline__ real s3(real, real c, real) { return -c; }
   static __device__ __forceinline__ real s4(real t, real, real) { return t; }
@@ -335,8 +335,8 @@ __device__ __forceinline__ real sigmoid_fast(real z) {   // 1 / (1 + 2^(-z log2 
 #endif
 }
 template <> struct Act<ACT_SIGMOID> {  // torch.nn.Sigmoid as FCNN(actv=nn.Sigmoid): everything is a polynomial in t
-  static __device__ __forceinline__ void fwd(real z, real& t, real& c) { t = sigmoid_fast(z); c = 0.f; }
-  static __device__ __forceinline__ real s1(real t, real) { return t * (1.f - t); }
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c, real = 1.f) { t = sigmoid_fast(z); c = 0.f; }
+  static __device__ __forceinline__ real s1(real t, real, real = 1.f) { return t * (1.f - t); }
   static __device__ __forceinline__ real s2(real t, real, real s1v) { return s1v * rfma(-2.f, t, 1.f); }
   static __device__ __forceinline__ real s3(real, real, real s1v) { return s1v * rfma(-6.f, s1v, 1.f); }
   static __device__ __forceinline__ real s4(real t, real, real s1v) {      // s2 (1 - 12 s1)
@@ -346,8 +346,8 @@ template <> struct Act<ACT_SIGMOID> {  // torch.nn.Sigmoid as FCNN(actv=nn.Sigmo
 // Swish with the default fixed beta = 1 (networks.py:155-175): f = z sigma(z).  State: t = f, c = sigma(z); since
 // z sigma = t the derivatives need no z:  f1 = c + t(1-c),  f2 = (1-c)(2c + t(1-2c)),  f3 = (1-c)(3c(1-2c) + t(1-6c+6c^2))
 template <> struct Act<ACT_SWISH> {
-  static __device__ __forceinline__ void fwd(real z, real& t, real& c) { c = sigmoid_fast(z); t = z * c; }
-  static __device__ __forceinline__ real s1(real t, real c) { return rfma(t, 1.f - c, c); }
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c, real = 1.f) { c = sigmoid_fast(z); t = z * c; }
+  static __device__ __forceinline__ real s1(real t, real c, real = 1.f) { return rfma(t, 1.f - c, c); }
   static __device__ __forceinline__ real s2(real t, real c, real) {
     return (1.f - c) * rfma(t, rfma(-2.f, c, 1.f), 2.f * c);
   }
@@ -359,11 +359,18 @@ template <> struct Act<ACT_SWISH> {
 // APTx with its default fixed parameters alpha = 1, beta = 1, gamma = 1/2 (networks.py:177-209): f = z (1 + tanh z) / 2.
 // State: t = f, c = z (z cannot be recovered from f and tanh z where 1 + tanh z underflows); with T = tanh z
 //   f1 = (1 + T)/2 + z (1 - T^2)/2,  f2 = (1 - T^2)(1 - z T),  f3 = (1 - T^2)(3 z T^2 - 3 T - z)
+//
+// Trainable parameters (Cfg::ACTP): the tile loop always evaluates the UNIT-SCALE function -- swish: u sigma(u);
+// APTx: u (al + tanh u) / 2 -- on u = beta z; the scales live in the weights.  f(z) = o g(beta z) with o = 1 / beta
+// (swish) or 2 gamma / beta (APTx), so stage_weights() loads W_l' = beta_l o_{l-1} W_l, b_l' = beta_l b_l,
+// Wout' = o_L Wout and block_reduce_store() carries the gradient back through that map (chain rule on the
+// workgroup's partial sums; beta and gamma only enter there).  alpha is a shape parameter: it is the one value the
+// activation code reads at run time (LayerState::al) and whose gradient the reverse pass accumulates (GradAcc::al).
 template <> struct Act<ACT_APTX> {
-  static __device__ __forceinline__ void fwd(real z, real& t, real& c) { c = z; t = 0.5f * z * (1.f + tanh_fast(z)); }
-  static __device__ __forceinline__ real s1(real, real z) {
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c, real al = 1.f) { c = z; t = 0.5f * z * (al + tanh_fast(z)); }
+  static __device__ __forceinline__ real s1(real, real z, real al = 1.f) {
     const real T = tanh_fast(z);
-    return 0.5f * rfma(z, rfma(-T, T, 1.f), 1.f + T);
+    return 0.5f * rfma(z, rfma(-T, T, 1.f), al + T);
   }
   static __device__ __forceinline__ real s2(real, real z, real) {
     const real T = tanh_fast(z);
@@ -377,7 +384,7 @@ template <> struct Act<ACT_APTX> {
 
 // ------------------------------------------------------------------------------------------------ config
 template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0, int SKIP_ = 0,
-          unsigned M3_ = 0>
+          unsigned M3_ = 0, int ACTP_ = 0>
 struct Cfg {
   using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
   static_assert(M3_ == 0 || ACT_ == ACT_TANH || ACT_ == ACT_SIN || ACT_ == ACT_SIGMOID,
@@ -401,9 +408,15 @@ struct Cfg {
   // SKIP: a trainable bias-free linear map from the inputs straight to the output, out += S x (networks.Resnet,
   // networks.py:73-106); its weights S (n_out x d) follow the output bias in the flat parameter vector
   static constexpr int SKIP = SKIP_;
-  static_assert(SKIP_ == 0 || NOUT_ == 1, "the skip connection is implemented for single-output networks");
   static constexpr int offS = offbout + NOUT;
-  static constexpr int P = offS + SKIP * NOUT * D;
+  // ACTP: trainable activation parameters (networks.Swish(trainable=True): beta; networks.APTx(trainable=True): alpha,
+  // beta, gamma -- networks.py:155-209), one set per hidden layer, behind everything else in the flat vector
+  static constexpr int ACTP = ACTP_;
+  static constexpr int AK = (ACT_ == ACT_SWISH) ? 1 : (ACT_ == ACT_APTX) ? 3 : 0;
+  static_assert(ACTP_ == 0 || AK > 0, "trainable activation parameters: Swish / APTx");
+  static constexpr bool ALPHA = (ACTP_ != 0) && (ACT_ == ACT_APTX);
+  static constexpr int offA = offS + SKIP * NOUT * D;
+  static constexpr int P = offA + ACTP * AK * L;
   // LDS carve (floats): W1T [D][H] | b1 [H] | per hidden-hidden layer: Wf [H*H] (+ Wt [H*H] for bwd) | b_l | Wout | bout
   static constexpr int ldsW1T = 0, ldsb1 = D * H;
   static constexpr int ldsLayer0 = D * H + H;
@@ -441,7 +454,9 @@ struct Cfg {
   static constexpr int ldsWoutT() { return ldsWout(true) + WOEL; }
   static constexpr int ldsbout(bool bwd) { return ldsWout(bwd) + (NOUT == 1 ? H : (bwd ? 2 : 1) * WOEL); }
   static constexpr int ldsSkip(bool bwd) { return ldsbout(bwd) + (NOUT == 1 ? 1 : HO); }
-  static constexpr int ldsWeightsEnd(bool bwd) { return (ldsSkip(bwd) + SKIP * NOUT * D + 3) & ~3; }
+  // skip weights: NOUT == 1: S [D];  NOUT > 1: transposed and zero-padded, St [D][HO];  then APTx's alpha per layer [L]
+  static constexpr int ldsAlpha(bool bwd) { return ldsSkip(bwd) + SKIP * D * (NOUT == 1 ? 1 : HO); }
+  static constexpr int ldsWeightsEnd(bool bwd) { return (ldsAlpha(bwd) + (ALPHA ? L : 0) + 3) & ~3; }
   // weight-gradient transposes: streams staged per barrier round (narrow nets: two at a time, so that the LDS round
   // trip of one stream hides behind the MFMAs of the other; wide nets: no LDS to spare)
   static constexpr int WG_SB = (NB_ <= 2 && SS::NS >= 2 && BWD_THREADS == 256) ? 2 : 1;
@@ -460,17 +475,51 @@ struct MlpArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ weight staging
+// Cfg::ACTP, scale factors of the trainable activation parameters (see Act<ACT_APTX>): the pre-activation of layer l
+// (1..L) is multiplied by act_pre(l) = beta_l, its activations by act_post(l) = 1 / beta_l (swish), 2 gamma_l / beta_l
+// (APTx); act_post(0) = 1 (the inputs).
+template <class C>
+__device__ __forceinline__ real act_pre(const real* __restrict__ prm, int l) {
+  if constexpr (C::ACTP == 0) return 1.f;
+  else return prm[C::offA + (l - 1) * C::AK + (C::AK == 3 ? 1 : 0)];
+}
+template <class C>
+__device__ __forceinline__ real act_post(const real* __restrict__ prm, int l) {
+  if constexpr (C::ACTP == 0) return 1.f;
+  else {
+    if (l == 0) return 1.f;
+    const real beta = act_pre<C>(prm, l);
+    if constexpr (C::AK == 3) return 2.f * prm[C::offA + (l - 1) * 3 + 2] / beta;
+    else return 1.f / beta;
+  }
+}
+template <class C>
+__device__ __forceinline__ real actp_mul(real v, real f) {
+  if constexpr (C::ACTP != 0) return v * f;
+  else return v;
+}
+
 template <class C, bool BWD>
 __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict__ prm) {
   constexpr int H = C::H, D = C::D, NB = C::NB;
   const int tid = threadIdx.x, nt = blockDim.x;
+  const real f1 = act_pre<C>(prm, 1), fo = act_post<C>(prm, C::L);
   for (int i = tid; i < D * H; i += nt) {  // W1T[a][j] = W1[j][a]
     const int a = i / H, j = i - a * H;
-    lds[C::ldsW1T + i] = prm[C::offW1 + j * D + a];
+    lds[C::ldsW1T + i] = actp_mul<C>(prm[C::offW1 + j * D + a], f1);
   }
-  for (int i = tid; i < H; i += nt) lds[C::ldsb1 + i] = prm[C::offb1 + i];
+  for (int i = tid; i < H; i += nt) lds[C::ldsb1 + i] = actp_mul<C>(prm[C::offb1 + i], f1);
+  if constexpr (C::ALPHA) {
+    if (tid < C::L) lds[C::ldsAlpha(BWD) + tid] = prm[C::offA + 3 * tid];
+  }
+  if constexpr (C::SKIP != 0 && C::NOUT > 1) {   // St[a][u] = S[u][a], rows >= NOUT zero
+    for (int i = tid; i < D * C::HO; i += nt) {
+      const int a = i / C::HO, u = i - a * C::HO;
+      lds[C::ldsSkip(BWD) + i] = u < C::NOUT ? prm[C::offS + u * D + a] : 0.f;
+    }
+  }
   if constexpr (C::NOUT == 1) {
-    for (int i = tid; i < H; i += nt) lds[C::ldsWout(BWD) + i] = prm[C::offWout + i];
+    for (int i = tid; i < H; i += nt) lds[C::ldsWout(BWD) + i] = actp_mul<C>(prm[C::offWout + i], fo);
     if (tid == 0) lds[C::ldsbout(BWD)] = prm[C::offbout];
     if constexpr (C::SKIP != 0) {
       if (tid < D) lds[C::ldsSkip(BWD) + tid] = prm[C::offS + tid];
@@ -484,7 +533,7 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
     __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWoutT());
     for (int i = tid; i < C::HO * H; i += nt) {
       const int j = i / H, k = i - j * H;
-      const real w = j < C::NOUT ? Wo[i] : 0.f;
+      const real w = j < C::NOUT ? actp_mul<C>(Wo[i], fo) : 0.f;
       const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
       const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
       {
@@ -507,12 +556,12 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
       {  // forward A operand of block (ob, kb): blk = ob*NB + kb:  A[i'][q'] = Wo[16 ob + i'][16 kb + 4 q' + t]
         const int ob = blk / NB, kb = blk - ob * NB;
         const int o = 16 * ob + mrow(lane & 15);
-        lds[C::ldsWout(BWD) + i] = o < C::NOUT ? Wo[o * H + 16 * kb + 4 * (lane >> 4) + t] : 0.f;
+        lds[C::ldsWout(BWD) + i] = o < C::NOUT ? actp_mul<C>(Wo[o * H + 16 * kb + 4 * (lane >> 4) + t], fo) : 0.f;
       }
       if (BWD) {  // transposed A operand of block (kb, ob): blk = kb*NBO + ob:  A[i'][q'] = Wo[16 ob + 4 q' + t][16 kb + i']
         const int kb = blk / NBO, ob = blk - kb * NBO;
         const int o = 16 * ob + 4 * (lane >> 4) + t;
-        lds[C::ldsWoutT() + i] = o < C::NOUT ? Wo[o * H + 16 * kb + mrow(lane & 15)] : 0.f;
+        lds[C::ldsWoutT() + i] = o < C::NOUT ? actp_mul<C>(Wo[o * H + 16 * kb + mrow(lane & 15)], fo) : 0.f;
       }
     }
     for (int i = tid; i < C::HO; i += nt) lds[C::ldsbout(BWD) + i] = i < C::NOUT ? prm[C::offbout + i] : 0.f;
@@ -526,9 +575,10 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
       const real* W = prm + C::offW(l);
       __bf16* wf = reinterpret_cast<__bf16*>(lds + C::ldsWf(l, BWD));
       __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWt(l));
+      const real fb = act_pre<C>(prm, l), fw = actp_mul<C>(fb, act_post<C>(prm, l - 1));
       for (int i = tid; i < H * H; i += nt) {   // one coalesced pass over W[j][k] (out j, in k): split once, scatter twice
         const int j = i / H, k = i - j * H;
-        const real w = W[i];
+        const real w = actp_mul<C>(W[i], fw);
         const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
         const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
         {  // forward image: block (ob = j/16, c = k/32), lane (j%16, kg = (k%16)/4), slot e = 4*((k%32)/16) + k%4
@@ -542,21 +592,22 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
           wt[base] = w0; wt[base + 512] = w1; wt[base + 1024] = w2;
         }
       }
-      for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = prm[C::offb(l) + i];
+      for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = actp_mul<C>(prm[C::offb(l) + i], fb);
     }
   } else
 #pragma unroll
   for (int l = 2; l <= C::L; ++l) {
     const real* W = prm + C::offW(l);
+    const real fb = act_pre<C>(prm, l), fw = actp_mul<C>(fb, act_post<C>(prm, l - 1));
     for (int i = tid; i < H * H; i += nt) {
       const int lane = i & 63, t = (i >> 6) & 3, blk = i >> 8;  // blk = first*NB + second
       const int b0 = blk / NB, b1 = blk - b0 * NB;
       // forward A operand of block (ib=b0, kb=b1), step t:  A[i'][k=q'] = W[16 ib + i'][16 kb + 4 q' + t]
-      lds[C::ldsWf(l, BWD) + i] = W[(16 * b0 + mrow(lane & 15)) * H + 16 * b1 + 4 * (lane >> 4) + t];
+      lds[C::ldsWf(l, BWD) + i] = actp_mul<C>(W[(16 * b0 + mrow(lane & 15)) * H + 16 * b1 + 4 * (lane >> 4) + t], fw);
       if (BWD)  // transposed A operand of block (kb=b0, ib=b1): A[i'][k=q'] = W[16 ib + 4 q' + t][16 kb + i']
-        lds[C::ldsWt(l) + i] = W[(16 * b1 + 4 * (lane >> 4) + t) * H + 16 * b0 + mrow(lane & 15)];
+        lds[C::ldsWt(l) + i] = actp_mul<C>(W[(16 * b1 + 4 * (lane >> 4) + t) * H + 16 * b0 + mrow(lane & 15)], fw);
     }
-    for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = prm[C::offb(l) + i];
+    for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = actp_mul<C>(prm[C::offb(l) + i], fb);
   }
 }
 
@@ -579,7 +630,17 @@ struct LayerState {
   real t[C::NB][4];                 // sigma(z)
   real c[C::NB][4];                 // second state value: cos(z) for sin, sigma(z) for swish, z for aptx; unused (dead) otherwise
   real4 z[C::NS][C::NB];             // pre-activation derivative streams (index 0 unused: value is in t)
+  real al;                          // Cfg::ALPHA: the layer's APTx alpha (wave-uniform); never touched otherwise
 };
+template <class C>
+__device__ __forceinline__ real layer_alpha(const LayerState<C>& st) {
+  if constexpr (C::ALPHA) return st.al;
+  else return 1.f;
+}
+template <class C, bool BWD>
+__device__ __forceinline__ void load_alpha(const real* lds, int l, LayerState<C>& st) {   // l = 1..L
+  if constexpr (C::ALPHA) st.al = lds[C::ldsAlpha(BWD) + l - 1];
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // bf16x3 planes of all streams of one fragment set: pl[s][c][k], k = 0 (high) .. 2 (low)
@@ -598,7 +659,7 @@ __device__ __forceinline__ void act_forward(const LayerState<C>& st, real4 (&h)[
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const real t = st.t[b][r], c = st.c[b][r];
-      const real s1 = A::s1(t, c);
+      const real s1 = A::s1(t, c, layer_alpha<C>(st));
       h[0][b][r] = t;
       if constexpr (SS::FIRST) {
         sfor<C::D>([&](auto a_) {
@@ -649,9 +710,9 @@ __device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, real
       if constexpr (S == 0) {
         hs[b][r] = t;
       } else if constexpr (S < SS::S2) {
-        hs[b][r] = A::s1(t, c) * st.z[S][b][r];
+        hs[b][r] = A::s1(t, c, layer_alpha<C>(st)) * st.z[S][b][r];
       } else if constexpr (SS::LAP) {
-        const real s1 = A::s1(t, c);
+        const real s1 = A::s1(t, c, layer_alpha<C>(st));
         real q2 = 0.f;
         sfor<C::D>([&](auto a_) {
           constexpr int a = decltype(a_)::value;
@@ -660,12 +721,12 @@ __device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, real
         hs[b][r] = rfma(A::s2(t, c, s1), q2, s1 * st.z[S][b][r]);
       } else if constexpr (S < SS::S3) {
         constexpr int a = SS::A(S), bb = SS::B(S);
-        const real s1 = A::s1(t, c);
+        const real s1 = A::s1(t, c, layer_alpha<C>(st));
         hs[b][r] = rfma(A::s2(t, c, s1) * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[S][b][r]);
       } else {
         constexpr int a = SS::T(S, 0), bb = SS::T(S, 1), cc = SS::T(S, 2);
         constexpr int sab = SS::pair_stream(a, bb), sac = SS::pair_stream(a, cc), sbc = SS::pair_stream(bb, cc);
-        const real s1 = A::s1(t, c), s2 = A::s2(t, c, s1), s3 = A::s3(t, c, s1);
+        const real s1 = A::s1(t, c, layer_alpha<C>(st)), s2 = A::s2(t, c, s1), s3 = A::s3(t, c, s1);
         const real za = st.z[1 + a][b][r], zb = st.z[1 + bb][b][r], zc = st.z[1 + cc][b][r];
         const real mix = rfma(st.z[sab][b][r], zc, rfma(st.z[sac][b][r], zb, st.z[sbc][b][r] * za));
         hs[b][r] = rfma(s3 * za, zb * zc, rfma(s2, mix, s1 * st.z[S][b][r]));
@@ -673,9 +734,11 @@ __device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, real
     }
 }
 
-// adjoint of act_forward: given hbar (overwritten in place with zbar)
+// adjoint of act_forward: given hbar (overwritten in place with zbar).  Cfg::ALPHA: dal += sum_s hbar_s u_s over this
+// lane's units, twice the layer's alpha gradient (alpha enters h = u (alpha + tanh u) / 2 through alpha u / 2 only, and
+// that term passes every derivative stream of u straight through)
 template <class C>
-__device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)[C::NS][C::NB]) {
+__device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)[C::NS][C::NB], real& dal) {
   using SS = typename C::SS;
   using A = Act<C::ACT>;
 #pragma unroll
@@ -683,7 +746,12 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const real t = st.t[b][r], c = st.c[b][r];
-      const real s1 = A::s1(t, c);
+      if constexpr (C::ALPHA) {
+        dal = rfma(g[0][b][r], c, dal);
+#pragma unroll
+        for (int s = 1; s < C::NS; ++s) dal = rfma(g[s][b][r], st.z[s][b][r], dal);
+      }
+      const real s1 = A::s1(t, c, layer_alpha<C>(st));
       real z0 = s1 * g[0][b][r];
       if constexpr (SS::FIRST) {
         const real s2 = A::s2(t, c, s1);
@@ -878,6 +946,7 @@ __device__ __forceinline__ void zero_frag(real4 (&z)[C::NS][C::NB]) {
 template <class C, bool BWD>
 __device__ __forceinline__ void first_layer(const real* lds, int q, const real (&x)[C::D], LayerState<C>& st) {
   using SS = typename C::SS;
+  load_alpha<C, BWD>(lds, 1, st);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
     const int j0 = 16 * b + 4 * q;
@@ -890,7 +959,7 @@ __device__ __forceinline__ void first_layer(const real* lds, int q, const real (
       for (int r = 0; r < 4; ++r) z[r] = rfma(w[a][r], x[a], z[r]);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[r], st.t[b][r], st.c[b][r]);
+    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[r], st.t[b][r], st.c[b][r], layer_alpha<C>(st));
     if constexpr (SS::FIRST) {
 #pragma unroll
       for (int a = 0; a < C::D; ++a) st.z[1 + a][b] = w[a];
@@ -909,10 +978,11 @@ __device__ __forceinline__ void hidden_layer(const real* lds, int l, int lane, i
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
   gemm_frag<C>(lds + C::ldsWf(l, BWD), lane, h, z);   // exact-f32 MFMA path (widths that are not a multiple of 32)
+  load_alpha<C, BWD>(lds, l, st);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[0][b][r], st.t[b][r], st.c[b][r]);
+    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[0][b][r], st.t[b][r], st.c[b][r], layer_alpha<C>(st));
 #pragma unroll
     for (int s = 1; s < C::NS; ++s) st.z[s][b] = z[s][b];
   }
@@ -927,10 +997,11 @@ __device__ __forceinline__ void hidden_layer_planes(const real* lds, int l, int 
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
   if constexpr ((NDQ_ABL & 4) == 0) gemm_planes<C>(lds + C::ldsWf(l, BWD), lane, P, z);
+  load_alpha<C, BWD>(lds, l, st);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[0][b][r], st.t[b][r], st.c[b][r]);
+    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[0][b][r], st.t[b][r], st.c[b][r], layer_alpha<C>(st));
 #pragma unroll
     for (int s = 1; s < C::NS; ++s) st.z[s][b] = z[s][b];
   }
@@ -987,6 +1058,24 @@ __device__ __forceinline__ void tile_output(const real* lds, int q, const real (
       out[0] = rfma(sa, x[a], out[0]);
       if constexpr (C::SS::FIRST) out[1 + a] += sa;
     }
+  }
+}
+
+// + S x on a multi-output network (networks.Resnet): value stream += S x, first-order stream a += S[:, a]
+template <class C, bool BWD>
+__device__ __forceinline__ void output_skip_multi(const real* lds, int q, const real (&x)[C::D], real4 (&o)[C::NS][C::NBO]) {
+  if constexpr (C::SKIP != 0 && C::NOUT > 1) {
+#pragma unroll
+    for (int a = 0; a < C::D; ++a)
+#pragma unroll
+      for (int ob = 0; ob < C::NBO; ++ob) {
+        const real4 sa = lds4(lds + C::ldsSkip(BWD) + a * C::HO + 16 * ob + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[0][ob][r] = rfma(sa[r], x[a], o[0][ob][r]);
+          if constexpr (C::SS::FIRST) o[1 + a][ob][r] += sa[r];
+        }
+      }
   }
 }
 
@@ -1079,10 +1168,11 @@ __device__ __forceinline__ void hidden_layer_grouped(const real* lds, int l, int
       }
   });
   // st may alias st_in (forward-only kernel): everything read from st_in is consumed above
+  load_alpha<C, BWD>(lds, l, st);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[0][b][r], st.t[b][r], st.c[b][r]);
+    for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[0][b][r], st.t[b][r], st.c[b][r], layer_alpha<C>(st));
 #pragma unroll
     for (int s = 1; s < C::NS; ++s) st.z[s][b] = z[s][b];
   }
@@ -1168,6 +1258,7 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
     } else {
       real4 o[C::NS][C::NBO];
       output_layer_mfma<C, false>(ldsw, lane, q, h, o);
+      output_skip_multi<C, false>(ldsw, q, x, o);
       if (n < a.n) {
 #pragma unroll
         for (int s = 0; s < C::NS; ++s)
@@ -1203,7 +1294,9 @@ struct GradAcc {
   real b[C::L > 1 ? C::L - 1 : 1][C::NB][4];      // db_l[j]     (needs point_sum)
   real wout[C::NB][4];              // NOUT == 1: dWout[j]       (needs point_sum)
   real bout;                        // NOUT == 1: dbout          (needs full wave sum)
-  real skip[C::D];                  // SKIP: dS[a]               (needs full wave sum)
+  real skip[C::D];                  // SKIP, NOUT == 1: dS[a]    (needs full wave sum)
+  real so[C::D][C::NBO][4];         // SKIP, NOUT > 1: dS[16ob+4q+r][a] (needs point_sum)
+  real al[C::L];                    // ALPHA: 2 d alpha_l        (needs full wave sum)
   real4 wo[C::NBO][C::NB];           // NOUT > 1: dWout[16ob+4q+r][16kb+p], MFMA accumulators
   real bo[C::NBO][4];               // NOUT > 1: dbout[16ob+4q+r] (needs point_sum)
   real* bias;                       // ACC_LDS: this wave's LDS region holding b1 / w1 / b / wout instead (already point-summed)
@@ -1377,7 +1470,13 @@ __device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
     for (int kb = 0; kb < C::NB; ++kb) acc.wo[ob][kb] = real4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc.bo[ob][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < C::D; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc.so[d][ob][r] = 0.f;
   }
+#pragma unroll
+  for (int l = 0; l < C::L; ++l) acc.al[l] = 0.f;
 }
 
 // start of the per-wave bias-sum regions (ACC_LDS), behind the staging tiles / reduction regions
@@ -1411,6 +1510,18 @@ __device__ __forceinline__ void tile_backward_multi(const real* lds, real* stage
   for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc.bo[ob][r] += go[0][ob][r];
+  if constexpr (C::SKIP != 0) {
+#pragma unroll
+    for (int a = 0; a < C::D; ++a)
+#pragma unroll
+      for (int ob = 0; ob < C::NBO; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          real v = go[0][ob][r] * x[a];
+          if constexpr (C::SS::FIRST) v += go[1 + a][ob][r];
+          acc.so[a][ob][r] += v;
+        }
+  }
   weight_grad<C, C::NBO>(stage, lane, p, q, go, st[C::L - 1], acc.wo, kp.h[C::KEEP_H ? C::L - 1 : 0]);   // dWout += sum_s Gout[s] H_L[s]^T
   real4 g[C::NS][C::NB];
   zero_frag<C>(g);
@@ -1523,7 +1634,7 @@ __device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stag
   sfor<C::L - 1>([&](auto k_) {
     constexpr int l = C::L - decltype(k_)::value;          // layer whose weights W_l (H x H) map h_{l-1} -> z_l
     constexpr int li = l - 1;             // state index of layer l
-    if constexpr ((NDQ_ABL & 8) == 0) act_backward<C>(st[li], g);           // g: hbar_l -> zbar_l
+    if constexpr ((NDQ_ABL & 8) == 0) act_backward<C>(st[li], g, acc.al[li]);           // g: hbar_l -> zbar_l
     NDQ_TT(5 + 3 * (C::L - l));
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
@@ -1549,7 +1660,7 @@ __device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stag
 
   // ---------------- first layer: z_a = W1[:,a] (constant), z_ab = 0
   if constexpr (C::WIDE && C::L == 1) reload_first_layer_streams<C>(lds, q, st[0]);
-  act_backward<C>(st[0], g);  // g[0] = zbar, g[1+a] = zbar_a
+  act_backward<C>(st[0], g, acc.al[0]);  // g[0] = zbar, g[1+a] = zbar_a
   if constexpr (C::ACC_LDS) {
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
@@ -1590,11 +1701,14 @@ __device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stag
 // adds the R regions in order and writes the workgroup's row of partials.
 template <class C, int WAVES>
 __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, int wave, int lane, int p, int q,
-                                                   real* __restrict__ out) {
+                                                   real* __restrict__ out, const real* __restrict__ prm = nullptr) {
   constexpr int PP = (C::P + 3) & ~3;
   constexpr int R = bwd_regions<C>(WAVES);
   real* red0 = lds + C::ldsWeightsEnd(true);
   const real bsum = point_sum(quad_sum(acc.bout));
+  real alsum[C::L];
+#pragma unroll
+  for (int l = 0; l < C::L; ++l) alsum[l] = C::ALPHA ? point_sum(quad_sum(acc.al[l])) : 0.f;
   real ssum[C::D];
 #pragma unroll
   for (int a = 0; a < C::D; ++a) ssum[a] = (C::SKIP != 0) ? point_sum(quad_sum(acc.skip[a])) : 0.f;
@@ -1624,6 +1738,14 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
     for (int ob = 0; ob < C::NBO; ++ob)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc.bo[ob][r] = point_sum(acc.bo[ob][r]);
+    if constexpr (C::SKIP != 0) {
+#pragma unroll
+      for (int a = 0; a < C::D; ++a)
+#pragma unroll
+        for (int ob = 0; ob < C::NBO; ++ob)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc.so[a][ob][r] = point_sum(acc.so[a][ob][r]);
+    }
   }
   __syncthreads();  // every wave is done with its staging tile
   real* red = red0 + (wave % R) * PP;
@@ -1671,20 +1793,92 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
           for (int r = 0; r < 4; ++r) {
             const int u = 16 * ob + 4 * q + r;
             if (u < C::NOUT) {
-              if (p == 0) put(C::offbout + u, acc.bo[ob][r]);
+              if (p == 0) {
+                put(C::offbout + u, acc.bo[ob][r]);
+                if constexpr (C::SKIP != 0) {
+#pragma unroll
+                  for (int a = 0; a < C::D; ++a) put(C::offS + u * C::D + a, acc.so[a][ob][r]);
+                }
+              }
 #pragma unroll
               for (int kb = 0; kb < C::NB; ++kb) put(C::offWout + u * C::H + 16 * kb + p, acc.wo[ob][kb][r]);
             }
           }
       }
+      if constexpr (C::ACTP != 0) {           // act-parameter slots: alpha's sum (APTx), zeros elsewhere (filled below)
+        if (lane == 0) {
+#pragma unroll
+          for (int l = 0; l < C::L; ++l)
+#pragma unroll
+            for (int k = 0; k < C::AK; ++k) put(C::offA + l * C::AK + k, (C::ALPHA && k == 0) ? 0.5f * alsum[l] : 0.f);
+        }
+      }
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < C::P; i += blockDim.x) {
+  auto total = [&](int i) {
     real v = red0[i];
 #pragma unroll
     for (int r = 1; r < R; ++r) v += red0[r * PP + i];
-    out[i] = v;
+    return v;
+  };
+  if constexpr (C::ACTP == 0) {
+    for (int i = threadIdx.x; i < C::P; i += blockDim.x) out[i] = total(i);
+  } else {
+    // Chain rule from the scaled weights the tile loop ran on (stage_weights: W' = f W) to the stored parameters:
+    // dW = f dW', and since every f is a product of powers of the betas / gammas their gradients follow from the sums
+    // <dW, W> = <dW', W'> -- linear in the partial sums, so each workgroup does it on its own row and the second stage
+    // adds the rows up like any other entry.  d[2(l-1)] = <dW_l, W_l>, d[2(l-1)+1] = <db_l, b_l>, d[2L] = <dWout, Wout>
+    real d[2 * C::L + 1];
+#pragma unroll
+    for (int k = 0; k < 2 * C::L + 1; ++k) d[k] = 0.f;
+    auto segment = [&](int lo, int hi, real f, real& dot) {
+      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const real v = total(i) * f;
+        out[i] = v;
+        dot = rfma(v, prm[i], dot);
+      }
+    };
+    segment(C::offW1, C::offb1, act_pre<C>(prm, 1), d[0]);
+    segment(C::offb1, C::offb1 + C::H, act_pre<C>(prm, 1), d[1]);
+    sfor<C::L - 1>([&](auto k_) {
+      constexpr int l = decltype(k_)::value + 2;
+      segment(C::offW(l), C::offb(l), act_pre<C>(prm, l) * act_post<C>(prm, l - 1), d[2 * (l - 1)]);
+      segment(C::offb(l), C::offb(l) + C::H, act_pre<C>(prm, l), d[2 * (l - 1) + 1]);
+    });
+    segment(C::offWout, C::offbout, act_post<C>(prm, C::L), d[2 * C::L]);
+    for (int i = C::offbout + threadIdx.x; i < C::offA; i += blockDim.x) out[i] = total(i);   // bout, skip weights
+    real dal[C::L];
+#pragma unroll
+    for (int l = 0; l < C::L; ++l) dal[l] = C::ALPHA ? total(C::offA + 3 * l) : 0.f;
+#pragma unroll
+    for (int k = 0; k < 2 * C::L + 1; ++k) d[k] = point_sum(quad_sum(d[k]));
+    __syncthreads();                          // everybody has read the regions: reuse them for the per-wave sums
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 2 * C::L + 1; ++k) red0[wave * (2 * C::L + 1) + k] = d[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 2 * C::L + 1; ++k) {
+        real v = 0.f;
+        for (int w = 0; w < WAVES; ++w) v += red0[w * (2 * C::L + 1) + k];
+        d[k] = v;
+      }
+#pragma unroll
+      for (int l = 1; l <= C::L; ++l) {
+        const real next = d[2 * l];           // <dW_{l+1}, W_{l+1}> (l = L: the output matrix)
+        const real dbeta = (d[2 * (l - 1)] + d[2 * (l - 1) + 1] - next) / act_pre<C>(prm, l);
+        if constexpr (C::AK == 1) {
+          out[C::offA + (l - 1)] = dbeta;
+        } else {
+          out[C::offA + 3 * (l - 1)] = dal[l - 1];
+          out[C::offA + 3 * (l - 1) + 1] = dbeta;
+          out[C::offA + 3 * (l - 1) + 2] = next / prm[C::offA + 3 * (l - 1) + 2];
+        }
+      }
+    }
   }
 }
 
@@ -1730,7 +1924,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
       tile_backward_multi<C>(ldsw, stage, lane, p, q, x, go, st, acc, kp);
     }
   }
-  block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
+  block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P, a.params);
 }
 
 // ------------------------------------------------------------------------------------------------ fused train / eval kernel
@@ -1832,7 +2026,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   __syncthreads();
   NDQ_TS(2);
 #endif
-  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
+  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P, a.params);
   // loss: lanes (only q == 0 lanes are non-zero) -> wave -> workgroup, fixed order
   lsum = point_sum(quad_sum(lsum));
   __syncthreads();
@@ -1928,7 +2122,8 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
     // block_reduce_store puts its regions right behind "the" weight image of the base it is given: hand it the last one
     sfor<K>([&](auto k_) {
       constexpr int k = decltype(k_)::value;
-      block_reduce_store<C, WAVES>(lds + (K - 1) * WS, acc[k], wave, lane, p, q, a.partials[k] + (size_t)blockIdx.x * C::P);
+      block_reduce_store<C, WAVES>(lds + (K - 1) * WS, acc[k], wave, lane, p, q, a.partials[k] + (size_t)blockIdx.x * C::P,
+                                   a.params[k]);
     });
   }
   lsum = point_sum(quad_sum(lsum));
@@ -1983,7 +2178,7 @@ template <class C> constexpr int group_xs() {
 
 template <class C, class PW, bool TRAIN>
 __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(FusedArgs a) {
-  static_assert(!C::ACC_LDS && C::SKIP == 0, "grouped closure: H <= 48, no skip connection");
+  static_assert(!C::ACC_LDS, "grouped closure: H <= 48");
   extern __shared__ __attribute__((aligned(16))) real lds[];
   stage_weights<C, TRAIN>(lds, a.params);
   __syncthreads();
@@ -2038,6 +2233,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
       } else {
         real4 o[C::NS][C::NBO];
         output_layer_mfma<C, TRAIN>(lds, lane, q, h, o);
+        output_skip_multi<C, TRAIN>(lds, q, x, o);
 #pragma unroll
         for (int s = 0; s < C::NS; ++s)
 #pragma unroll
@@ -2106,7 +2302,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
-  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P);
+  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P, a.params);
   lsum = point_sum(quad_sum(lsum));                      // all 64 lanes carry a point here
   __syncthreads();
   real* wl = lds + C::ldsWeightsEnd(TRAIN);

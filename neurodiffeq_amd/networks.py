@@ -2,9 +2,11 @@
 142-209) so existing scripts keep working; ``FCNN`` is a real ``nn.Module`` (``.NN`` is the ``Sequential``; its
 parameters are ordinary ``nn.Parameter`` objects, which the optimiser, ``deepcopy`` and checkpoints rely on).
 
-What is new is :func:`describe`: it recognises FCNN-shaped modules the gfx950 kernels can run (uniform hidden width
-multiple of 16, tanh / sin, one output unit) and :class:`FlatParams`, which re-homes the parameters as views of one
-flat fp32 buffer in torch parameter order -- the layout ``ndq_mlp_jet_fwd/bwd`` and ``ndq_adam_step`` consume.
+What is new is :func:`describe`: it recognises the modules the gfx950 kernels can run (FCNN / Resnet with a uniform
+hidden width that is a multiple of 16; tanh, sin, sigmoid, Swish, APTx -- the last two with their default or with
+trainable parameters; any number of output units) and :class:`FlatParams`, which re-homes the parameters as views of
+one flat fp32 buffer -- linear layers in torch order, then the skip weights, then the activation parameters: the
+layout ``ndq_mlp_jet_fwd/bwd`` and ``ndq_adam_step`` consume.
 """
 import warnings
 
@@ -89,7 +91,7 @@ class FCNN(nn.Module):
 class Resnet(nn.Module):
     """``FCNN(x) + W x``: a fully connected residual branch plus a trainable bias-free linear skip from input to output
     (reference: networks.py:73-106; attribute names ``residual`` / ``skip_connection`` as there, the residual branch is
-    built first).  Runs on the composite path."""
+    built first).  On the HIP path the skip is part of the output layer (``ndq_mlp_desc.skip``)."""
 
     def __init__(self, n_input_units=1, n_output_units=1, n_hidden_units=None, n_hidden_layers=None, actv=nn.Tanh,
                  hidden_units=(32, 32)):
@@ -152,10 +154,23 @@ def describe(net, dtype=torch.float32):
     act_types = {type(a) for a in acts}
     if len(act_types) != 1 or next(iter(act_types)) not in _ACT_IDS:
         return None
-    if any(isinstance(a, Swish) and (a.trainable or a.beta != 1.0) for a in acts):
-        return None          # the kernels carry Swish with its default fixed beta = 1 only
-    if any(isinstance(a, APTx) and (a.trainable or (a.alpha, a.beta, a.gamma) != (1.0, 1.0, 0.5)) for a in acts):
-        return None          # ... and APTx with its default fixed parameters
+    # Swish / APTx: either their default fixed parameters (constants in the kernels) or trainable ones on every layer
+    # (ndq_mlp_desc.actp: per-layer scalars at the end of the flat parameter vector); fixed non-default values are not
+    # covered
+    act_params = []
+    if acts and isinstance(acts[0], (Swish, APTx)):
+        trainable = {bool(a.trainable) for a in acts}
+        if len(trainable) != 1:
+            return None
+        names = ("beta",) if isinstance(acts[0], Swish) else ("alpha", "beta", "gamma")
+        if trainable == {True}:
+            act_params = [getattr(a, k) for a in acts for k in names]
+            if any(not isinstance(p, nn.Parameter) or p.dim() != 0 or p.dtype != dtype for p in act_params):
+                return None
+            if len({id(p) for p in act_params}) != len(act_params):
+                return None      # one module object used for several layers: its parameters are shared, not per layer
+        elif any(tuple(getattr(a, k) for k in names) != ((1.0,) if len(names) == 1 else (1.0, 1.0, 0.5)) for a in acts):
+            return None
     hidden = linears[0].out_features
     if hidden % 16 or any(l.in_features != hidden or l.out_features != hidden for l in linears[1:-1]):
         return None
@@ -163,11 +178,13 @@ def describe(net, dtype=torch.float32):
         return None
     if any(p.dtype != dtype for l in linears for p in l.parameters()):
         return None
-    if skip is not None and (linears[-1].out_features != 1 or tuple(skip.weight.shape) != (1, linears[0].in_features)):
-        return None          # the in-kernel skip connection serves single-output networks
-    params = [p for l in linears for p in (l.weight, l.bias)] + ([skip.weight] if skip is not None else [])
+    if skip is not None and tuple(skip.weight.shape) != (linears[-1].out_features, linears[0].in_features):
+        return None
+    # flat order the kernels read: W1 b1 ... Wout bout | skip weights (n_out x d, row-major) | activation parameters
+    params = [p for l in linears for p in (l.weight, l.bias)] + ([skip.weight] if skip is not None else []) + act_params
     return dict(d=linears[0].in_features, hidden=hidden, layers=len(acts), act=_ACT_IDS[next(iter(act_types))],
-                n_out=linears[-1].out_features, linears=linears, skip=int(skip is not None), params=params)
+                n_out=linears[-1].out_features, linears=linears, skip=int(skip is not None), params=params,
+                actp=int(bool(act_params)))
 
 
 class FlatParams:

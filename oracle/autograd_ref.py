@@ -67,7 +67,32 @@ class APTxRef(nn.Module):
         return (1.0 + torch.tanh(x)) * 0.5 * x
 
 
-ACTIVATIONS = {"tanh": nn.Tanh, "sin": Sin, "sigmoid": nn.Sigmoid, "swish": SwishRef, "aptx": APTxRef}
+class SwishTrainableRef(nn.Module):
+    """x * sigmoid(beta x) with a trainable scalar beta (networks.py:166-169)."""
+
+    def __init__(self):
+        super().__init__()
+        self.beta = nn.Parameter(torch.tensor(1.0))
+
+    def forward(self, x):
+        return x * torch.sigmoid(self.beta * x)
+
+
+class APTxTrainableRef(nn.Module):
+    """(alpha + tanh(beta x)) * gamma * x with trainable scalars, registered in that order (networks.py:196-203)."""
+
+    def __init__(self):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.tensor(1.0))
+        self.beta = nn.Parameter(torch.tensor(1.0))
+        self.gamma = nn.Parameter(torch.tensor(0.5))
+
+    def forward(self, x):
+        return (self.alpha + torch.tanh(self.beta * x)) * self.gamma * x
+
+
+ACTIVATIONS = {"tanh": nn.Tanh, "sin": Sin, "sigmoid": nn.Sigmoid, "swish": SwishRef, "aptx": APTxRef,
+               "swish-tr": SwishTrainableRef, "aptx-tr": APTxTrainableRef}
 
 
 def make_fcnn(n_in, n_out, hidden, act="tanh", dtype=torch.float32):

@@ -32,8 +32,21 @@ def act_deriv4(name, z):
     raise KeyError(f"no fourth derivative stated for {name}")
 
 
-def act_derivs(name, z):
-    """sigma(z) and its first three derivatives."""
+def act_derivs(name, z, theta=None):
+    """sigma(z) and its first three derivatives.  ``theta``: the layer's activation parameters
+    -- (beta,) for swish, (alpha, beta, gamma) for aptx (networks.py:155-209); None = their defaults."""
+    if theta is not None and name == "swish":            # z s(beta z): Leibniz with S^(k)(z) = beta^k s^(k)(beta z)
+        (beta,) = theta
+        s = 1.0 / (1.0 + np.exp(-beta * z))
+        d1 = s * (1 - s)
+        S0, S1, S2, S3 = s, beta * d1, beta ** 2 * d1 * (1 - 2 * s), beta ** 3 * d1 * (1 - 6 * d1)
+        return z * S0, S0 + z * S1, 2 * S1 + z * S2, 3 * S2 + z * S3
+    if theta is not None and name == "aptx":             # gamma z (alpha + tanh(beta z))
+        alpha, beta, gamma = theta
+        t = np.tanh(beta * z)
+        u1 = 1 - t * t
+        U0, U1, U2, U3 = alpha + t, beta * u1, beta ** 2 * (-2 * t * u1), beta ** 3 * (-2 * u1 * (1 - 3 * t * t))
+        return gamma * z * U0, gamma * (U0 + z * U1), gamma * (2 * U1 + z * U2), gamma * (3 * U2 + z * U3)
     if name == "tanh":
         t = np.tanh(z)
         s1 = 1 - t * t
@@ -88,7 +101,7 @@ def close_streams(streams):
     return sorted(s, key=lambda m: (len(m), m))
 
 
-def _forward(flat, dims, act, coords, streams):
+def _forward(flat, dims, act, coords, streams, thetas=None):
     layers = split_params(np.asarray(flat, dtype=np.float64), dims)
     x = np.stack([np.asarray(c, dtype=np.float64).reshape(-1) for c in coords], axis=1)   # (N, d)
     n, d = x.shape
@@ -104,7 +117,7 @@ def _forward(flat, dims, act, coords, streams):
         z[()] = z[()] + b
         if li == len(layers) - 1:
             return z, saved, layers
-        s0, s1, s2, s3 = act_derivs(act, z[()])
+        s0, s1, s2, s3 = act_derivs(act, z[()], None if thetas is None else thetas[li])
         hn = {(): s0}
         for m in streams:
             if len(m) == 1:
@@ -124,14 +137,26 @@ def _n_fcnn_params(dims):
     return sum(a * b + b for a, b in zip(dims[:-1], dims[1:]))
 
 
-def mlp_jets(flat, dims, act, coords, streams, skip=False):
-    """Streams of the raw network output: dict stream -> (N, n_out).  ``skip``: Resnet (networks.py:73-106) -- the flat
-    vector ends with the bias-free skip matrix S (n_out, d) and the output gains S x (value) / S[:, a] (d/dx_a)."""
+def _act_thetas(flat, dims, act, skip, actp):
+    """Per-layer activation parameters from the tail of the flat vector (include/ndq.h: ndq_mlp_desc.actp)."""
+    if not actp:
+        return None
+    k = {"swish": 1, "aptx": 3}[act]
+    off = _n_fcnn_params(dims) + (dims[-1] * dims[0] if skip else 0)
+    n_layers = len(dims) - 2
+    assert flat.size == off + k * n_layers
+    return [tuple(flat[off + k * l: off + k * (l + 1)]) for l in range(n_layers)]
+
+
+def mlp_jets(flat, dims, act, coords, streams, skip=False, actp=False):
+    """Streams of the raw network output: dict stream -> (N, n_out).  ``skip``: Resnet (networks.py:73-106) -- the
+    bias-free skip matrix S (n_out, d) follows the FCNN parameters in the flat vector and the output gains S x (value) /
+    S[:, a] (d/dx_a).  ``actp``: trainable Swish / APTx parameters, one set per hidden layer, at the end of the vector."""
     streams = close_streams(streams)
     flat = np.asarray(flat, dtype=np.float64)
-    z, _, _ = _forward(flat[:_n_fcnn_params(dims)], dims, act, coords, streams)
+    z, _, _ = _forward(flat[:_n_fcnn_params(dims)], dims, act, coords, streams, _act_thetas(flat, dims, act, skip, actp))
     if skip:
-        S = flat[_n_fcnn_params(dims):].reshape(dims[-1], dims[0])
+        S = flat[_n_fcnn_params(dims):_n_fcnn_params(dims) + dims[-1] * dims[0]].reshape(dims[-1], dims[0])
         x = np.stack([np.asarray(c, dtype=np.float64).reshape(-1) for c in coords], axis=1)
         z = dict(z)
         z[()] = z[()] + x @ S.T
@@ -141,14 +166,30 @@ def mlp_jets(flat, dims, act, coords, streams, skip=False):
     return z
 
 
-def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False):
+def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False, actp=False, thetas=None):
     """Parameter gradient sum_n sum_streams <gbar[stream][n], d out_stream[n] / d params>  (flat, torch order; with
-    ``skip`` the gradient of the skip matrix follows).
+    ``skip`` the gradient of the skip matrix follows, with ``actp`` that of the activation parameters after it).
 
     ``gbar``: dict stream -> (N, n_out) adjoints."""
+    if actp:
+        # weights: the same recurrences with the parameterised derivative table; the activation parameters themselves:
+        # central differences of the scalar <gbar, streams> in fp64 (a handful of scalars; step 1e-6 -> ~1e-10 relative)
+        flat = np.asarray(flat, dtype=np.float64)
+        th = _act_thetas(flat, dims, act, skip, True)
+        n_lin = _n_fcnn_params(dims) + (dims[-1] * dims[0] if skip else 0)
+        base = mlp_jets_vjp(flat[:n_lin], dims, act, coords, gbar, skip=skip, thetas=th)
+
+        def scalar(v):
+            out = mlp_jets(v, dims, act, coords, list(gbar.keys()), skip=skip, actp=True)
+            return sum(float(np.sum(np.asarray(g, dtype=np.float64) * out[tuple(sorted(m))])) for m, g in gbar.items())
+        dth = np.zeros(flat.size - n_lin)
+        for i in range(dth.size):
+            e = np.zeros_like(flat); e[n_lin + i] = 1e-6
+            dth[i] = (scalar(flat + e) - scalar(flat - e)) / 2e-6
+        return np.concatenate([base, dth])
     if skip:
         flat = np.asarray(flat, dtype=np.float64)
-        base = mlp_jets_vjp(flat[:_n_fcnn_params(dims)], dims, act, coords, gbar)
+        base = mlp_jets_vjp(flat[:_n_fcnn_params(dims)], dims, act, coords, gbar, thetas=thetas)
         x = np.stack([np.asarray(c, dtype=np.float64).reshape(-1) for c in coords], axis=1)
         dS = np.asarray(gbar.get((), np.zeros((x.shape[0], dims[-1]))), dtype=np.float64).T @ x      # (n_out, d)
         for m, g in gbar.items():
@@ -156,7 +197,7 @@ def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False):
                 dS[:, m[0]] += np.asarray(g, dtype=np.float64).sum(axis=0)
         return np.concatenate([base, dS.reshape(-1)])
     streams = close_streams(list(gbar.keys()))
-    zlast, saved, layers = _forward(flat, dims, act, coords, streams)
+    zlast, saved, layers = _forward(flat, dims, act, coords, streams, thetas)
     n = zlast[()].shape[0]
     zb = {m: np.asarray(gbar.get(m, np.zeros_like(zlast[()])), dtype=np.float64) for m in streams}
     grads = [None] * len(layers)
@@ -172,7 +213,7 @@ def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False):
                     hin[m][:, m[0]] = 1.0
         else:
             _, zprev, (s1, s2, s3) = saved[li - 1]
-            s0 = act_derivs(act, zprev[()])[0]
+            s0 = act_derivs(act, zprev[()], None if thetas is None else thetas[li - 1])[0]
             hin = {(): s0}
             for m in streams:
                 if len(m) == 1:

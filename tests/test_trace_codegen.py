@@ -48,14 +48,22 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     coords = np.ascontiguousarray(coords, np.float32)
     n_coords, n = coords.shape
     prog = trace(nets, conds, pde, n_coords, lap, cfv, loss, metrics)
-    dims_act, flats, off = [], [], 0
+    dims_act, flats, perms, off = [], [], [], 0
     for net in nets:
         info = describe(net)
         dims = (info["d"],) + (info["hidden"],) * info["layers"] + (info["n_out"],)
-        npar = sum(a * b + b for a, b in zip(dims[:-1], dims[1:])) + info["skip"] * info["n_out"] * info["d"]
-        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx")[info["act"]], bool(info["skip"])))
-        flats.append(np.asarray(params[off:off + npar], np.float64))
-        off += npar
+        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx")[info["act"]], bool(info["skip"]), bool(info["actp"])))
+        # ``params`` is in torch parameter order; the kernels' (and the jet oracle's) flat vector lists the linear layers,
+        # then the skip weights, then the activation parameters (networks.describe): perm maps one onto the other
+        start, at = {}, 0
+        for prm in net.parameters():
+            start[id(prm)] = at
+            at += prm.numel()
+        perm = np.concatenate([np.arange(start[id(prm)], start[id(prm)] + prm.numel()) for prm in info["params"]])
+        assert perm.size == at
+        perms.append(perm)
+        flats.append(np.asarray(params[off:off + at], np.float64)[perm])
+        off += at
     # a ("L", a, b, ..) symbol is the Laplacian stream = sum of the pure second derivatives (a,a), (b,b), ..
     parts = lambda mi: [(c, c) for c in mi[1:]] if (mi and mi[0] == "L") else [mi]
     # evaluation sites: (network, coordinate tuple) pairs; a virtual coordinate is a constant column
@@ -67,11 +75,11 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
         needed[k].add(mi)
     jets = {}
     for k in range(prog.n_sites):
-        dims, act, skip = dims_act[site_net[k]]
+        dims, act, skip, actp = dims_act[site_net[k]]
         deps = prog.streams[k].deps
         local = lambda mi: tuple(sorted(deps.index(c) for c in mi))
         want = sorted({local(m) for mi in needed[k] for m in parts(mi)})
-        js = J.mlp_jets(flats[site_net[k]], dims, act, [column(c) for c in deps], want or [()], skip=skip)
+        js = J.mlp_jets(flats[site_net[k]], dims, act, [column(c) for c in deps], want or [()], skip=skip, actp=actp)
         jets[k] = {mi: sum(js[local(m)] for m in parts(mi)) for mi in needed[k]}       # (N, n_out)
     syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]][:, prog.g.nodes[i][2]]
                      for i in prog.symbols]).astype(np.float32)
@@ -84,7 +92,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     # parameter gradient: adjoint streams through the jet oracle's VJP
     grads = [0.0] * len(nets)
     for k in range(prog.n_sites):                       # every site of a network adds into that network's gradient
-        dims, act, skip = dims_act[site_net[k]]
+        dims, act, skip, actp = dims_act[site_net[k]]
         deps = prog.streams[k].deps
         gb = {}
         for idx, i in enumerate(prog.symbols):
@@ -96,7 +104,11 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
         if not gb:
             gb = {(): np.zeros((n, dims[-1]))}
         grads[site_net[k]] = grads[site_net[k]] + J.mlp_jets_vjp(flats[site_net[k]], dims, act, [column(c) for c in deps], gb,
-                                                               skip=skip)
+                                                               skip=skip, actp=actp)
+    for j, perm in enumerate(perms):                    # back to torch parameter order
+        g = np.zeros(perm.size)
+        g[perm] = grads[j]
+        grads[j] = g
     return prog, funcs.T, resid.T, loss, np.concatenate(grads)
 
 
@@ -126,6 +138,8 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "bundle_decay": [(1, 0, 0)], "bundle_bvp": [(1, 1, 0)], "shape_64x2": [(1, 5, 1)], "shape_32x3": [(1, 5, 1)],
                "shape_48x2": [(1, 5, 1)], "shape_16x2_sin": [(1, 5, 1)], "shape_32x1": [(1, 5, 1)],
                "aptx_burgers": [(1, 1, 0)], "resnet_laplace": [(1, 5, 1)], "resnet_ode": [(1, 1, 0)],
+               "swish_tr_laplace": [(1, 5, 1)], "aptx_tr_laplace": [(1, 5, 1)], "aptx_tr_wide": [(1, 5, 1)],
+               "swish_tr_system": [(1, 1, 0), (1, 0, 0)], "aptx_tr_resnet": [(1, 1, 0)],
                # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along
                "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)]}
 

@@ -27,9 +27,19 @@ class System:
         """(nets fp32, conditions, diff_eqs) on the neurodiffeq_amd API"""
         from neurodiffeq_amd import diff
         from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx, Resnet
-        actv = {"tanh": torch.nn.Tanh, "sin": SinActv, "sigmoid": torch.nn.Sigmoid, "swish": Swish, "aptx": APTx}
+        from functools import partial
+        actv = {"tanh": torch.nn.Tanh, "sin": SinActv, "sigmoid": torch.nn.Sigmoid, "swish": Swish, "aptx": APTx,
+                "swish-tr": partial(Swish, trainable=True), "aptx-tr": partial(APTx, trainable=True)}
         nets = [(Resnet if a.startswith("resnet-") else FCNN)(i, o, hidden_units=h, actv=actv[a.replace("resnet-", "")])
                 for i, o, h, a in self.net_specs]
+        # trainable activation parameters: move them off their defaults (every layer its own values), deterministically
+        k = 0
+        for net in nets:
+            for m in net.modules():
+                if isinstance(m, (Swish, APTx)) and m.trainable:
+                    for p in m.parameters():
+                        p.data.mul_(1.0 + 0.11 * ((k % 5) - 2))
+                        k += 1
         return nets, self.conds(), self.pde(diff)
 
     def oracle(self, flat):
@@ -158,6 +168,23 @@ def build(name):
         conds = lambda: [C.IBVP1D(-1.0, 1.0, 0.0, u0, x_min_val=zero, x_max_val=zero)]
         return System(name, 2, [(2, 1, (32, 32), "aptx")], [(-1.0, 1.0), (0.0, 1.0)], pde, conds,
                       lambda D: [_R().ibvp1d_dd(-1.0, 1.0, 0.0, u0, zero, zero)])
+    if name in ("swish_tr_laplace", "aptx_tr_laplace", "aptx_tr_wide"):   # trainable activation parameters (networks.py:155-209)
+        f0 = lambda y: torch.sin(PI * y)
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + u * D(u, x) - torch.exp(-x * y)])
+        conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
+        hidden = (64, 64, 64) if name == "aptx_tr_wide" else (32, 32)
+        return System(name, 2, [(2, 1, hidden, name.split("_")[0] + "-tr")], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, zero)])
+    if name == "swish_tr_system":     # two trainable-Swish networks on one coordinate (multi-network closure kernel)
+        pde = lambda D: (lambda u, v, t: [D(u, t, order=2) + v * D(u, t) + u, D(v, t) - u * v + torch.sin(t)])
+        conds = lambda: [C.IVP(0.0, 1.0, u_0_prime=0.0), C.IVP(0.0, 0.5)]
+        enf = lambda D: [lambda net, t: 1.0 + t * 0.0 + (1 - torch.exp(-t)) ** 2 * net(t), _R().ivp(0.0, 0.5)]
+        return System(name, 1, [(1, 1, (32, 32), "swish-tr")] * 2, [(0.0, 2.0)], pde, conds, enf)
+    if name == "aptx_tr_resnet":      # Resnet with trainable APTx parameters: skip weights and activation scalars together
+        pde = lambda D: (lambda u, t: [D(u, t, order=2) + 0.5 * D(u, t) + u - torch.cos(t)])
+        conds = lambda: [C.IVP(0.0, 1.0, u_0_prime=0.5)]
+        enf = lambda D: [lambda net, t: 1.0 + t * 0.5 + (1 - torch.exp(-t)) ** 2 * net(t)]
+        return System(name, 1, [(1, 1, (32, 32), "resnet-aptx-tr")], [(0.0, 2.0)], pde, conds, enf)
     if name == "kdv":                 # Korteweg-de Vries: a third-order derivative in x (diff(u, x, order=3), neurodiffeq.py:21-34)
         u0 = lambda x: 0.5 / torch.cosh(0.5 * x) ** 2
         pde = lambda D: (lambda u, x, t: [D(u, t) + 6.0 * u * D(u, x) + D(u, x, order=3)])
@@ -201,7 +228,8 @@ def build(name):
 
 NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "kdv", "ode3", "poisson3d",
          "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
-         "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode"]
+         "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode", "swish_tr_laplace", "aptx_tr_laplace",
+         "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet"]
 
 
 def spherical_solver_problem():
