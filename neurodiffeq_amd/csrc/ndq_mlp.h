@@ -360,12 +360,17 @@ template <> struct Act<ACT_SWISH> {
 // State: t = f, c = z (z cannot be recovered from f and tanh z where 1 + tanh z underflows); with T = tanh z
 //   f1 = (1 + T)/2 + z (1 - T^2)/2,  f2 = (1 - T^2)(1 - z T),  f3 = (1 - T^2)(3 z T^2 - 3 T - z)
 //
-// Trainable parameters (Cfg::ACTP): the tile loop always evaluates the UNIT-SCALE function -- swish: u sigma(u);
-// APTx: u (al + tanh u) / 2 -- on u = beta z; the scales live in the weights.  f(z) = o g(beta z) with o = 1 / beta
+// Trainable parameters (Cfg::ACTP): the tile loop always evaluates the UNIT-SCALE function G -- swish: u sigma(u);
+// APTx: u (al + tanh u) / 2 -- on u = beta z; the scales live in the weights.  f(z) = o G(beta z) with o = 1 / beta
 // (swish) or 2 gamma / beta (APTx), so stage_weights() loads W_l' = beta_l o_{l-1} W_l, b_l' = beta_l b_l,
-// Wout' = o_L Wout and block_reduce_store() carries the gradient back through that map (chain rule on the
-// workgroup's partial sums; beta and gamma only enter there).  alpha is a shape parameter: it is the one value the
-// activation code reads at run time (LayerState::al) and whose gradient the reverse pass accumulates (GradAcc::al).
+// Wout' = o_L Wout and block_reduce_store() scales the weight gradients back (dW = f dW').  alpha is a shape
+// parameter, the one value the activation code reads at run time (LayerState::al).  The parameters' own gradients
+// come out of act_backward() as three per-layer sums over units and points of the layer's unit-scale streams h = G(u),
+// their adjoints g and the pre-activation adjoints ubar it produces (GradAcc::ap):
+//   d alpha = sum_s g_s u_s / 2        (alpha enters h through alpha u / 2 only, every stream passes straight through)
+//   d gamma = sum_s g_s h_s / gamma    (f is linear in gamma)
+//   d beta  = (sum_t ubar_t u_t - sum_s g_s h_s) / beta      (Euler: f(z; beta) = G(beta z) / beta is homogeneous)
+// accumulated element by element, so what cancels are the small per-element differences, not the layer totals.
 template <> struct Act<ACT_APTX> {
   static __device__ __forceinline__ void fwd(real z, real& t, real& c, real al = 1.f) { c = z; t = 0.5f * z * (al + tanh_fast(z)); }
   static __device__ __forceinline__ real s1(real, real z, real al = 1.f) {
@@ -734,11 +739,10 @@ __device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, real
     }
 }
 
-// adjoint of act_forward: given hbar (overwritten in place with zbar).  Cfg::ALPHA: dal += sum_s hbar_s u_s over this
-// lane's units, twice the layer's alpha gradient (alpha enters h = u (alpha + tanh u) / 2 through alpha u / 2 only, and
-// that term passes every derivative stream of u straight through)
+// adjoint of act_forward: given hbar (overwritten in place with zbar).  Cfg::ACTP: ap[0] += sum_s g_s u_s,
+// ap[1] += sum_t ubar_t u_t - sum_s g_s h_s, ap[2] += sum_s g_s h_s over this lane's units (see Act<ACT_APTX>)
 template <class C>
-__device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)[C::NS][C::NB], real& dal) {
+__device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)[C::NS][C::NB], real (&ap)[3]) {
   using SS = typename C::SS;
   using A = Act<C::ACT>;
 #pragma unroll
@@ -746,15 +750,41 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const real t = st.t[b][r], c = st.c[b][r];
-      if constexpr (C::ALPHA) {
-        dal = rfma(g[0][b][r], c, dal);
-#pragma unroll
-        for (int s = 1; s < C::NS; ++s) dal = rfma(g[s][b][r], st.z[s][b][r], dal);
-      }
       const real s1 = A::s1(t, c, layer_alpha<C>(st));
+      real u0 = 0.f, gh = 0.f, gu = 0.f;     // ACTP: pre-activation value, sum_s g_s h_s, sum_s g_s u_s of this unit
+      if constexpr (C::ACTP != 0) {
+        // swish keeps t = u sigma(u) and c = sigma(u): u = t / c (c underflows to 0 only where the contribution does too)
+        if constexpr (C::ACT == ACT_SWISH) u0 = (c > 0.f) ? t / c : 0.f;
+        else u0 = c;
+        gh = g[0][b][r] * t;
+        gu = g[0][b][r] * u0;
+      }
       real z0 = s1 * g[0][b][r];
       if constexpr (SS::FIRST) {
         const real s2 = A::s2(t, c, s1);
+        if constexpr (C::ACTP != 0) {        // h_a = s1 u_a; h_L = s2 sum u_a^2 + s1 u_L; h_ab = s2 u_a u_b + s1 u_ab
+          sfor<C::D>([&](auto a_) {
+            constexpr int a = decltype(a_)::value;
+            gh = rfma(g[1 + a][b][r], s1 * st.z[1 + a][b][r], gh);
+            gu = rfma(g[1 + a][b][r], st.z[1 + a][b][r], gu);
+          });
+          if constexpr (SS::LAP) {
+            real q2 = 0.f;
+            sfor<C::D>([&](auto a_) {
+              constexpr int a = decltype(a_)::value;
+              if constexpr (SS::in_lap(a)) q2 = rfma(st.z[1 + a][b][r], st.z[1 + a][b][r], q2);
+            });
+            gh = rfma(g[SS::S2][b][r], rfma(s2, q2, s1 * st.z[SS::S2][b][r]), gh);
+            gu = rfma(g[SS::S2][b][r], st.z[SS::S2][b][r], gu);
+          } else {
+            sfor<SS::N2>([&](auto k_) {
+              constexpr int s = SS::S2 + decltype(k_)::value;
+              constexpr int a = SS::A(s), bb = SS::B(s);
+              gh = rfma(g[s][b][r], rfma(s2 * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[s][b][r]), gh);
+              gu = rfma(g[s][b][r], st.z[s][b][r], gu);
+            });
+          }
+        }
         real za[C::D];
         sfor<C::D>([&](auto a_) {
           constexpr int a = decltype(a_)::value;
@@ -818,6 +848,14 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)
         });
       }
       g[0][b][r] = z0;
+      if constexpr (C::ACTP != 0) {
+        real uu = z0 * u0;
+#pragma unroll
+        for (int s = 1; s < C::NS; ++s) uu = rfma(g[s][b][r], st.z[s][b][r], uu);
+        ap[0] += gu;
+        ap[1] += uu - gh;
+        ap[2] += gh;
+      }
     }
 }
 
@@ -1296,7 +1334,7 @@ struct GradAcc {
   real bout;                        // NOUT == 1: dbout          (needs full wave sum)
   real skip[C::D];                  // SKIP, NOUT == 1: dS[a]    (needs full wave sum)
   real so[C::D][C::NBO][4];         // SKIP, NOUT > 1: dS[16ob+4q+r][a] (needs point_sum)
-  real al[C::L];                    // ALPHA: 2 d alpha_l        (needs full wave sum)
+  real ap[C::L][3];                 // ACTP: per layer, see act_backward (needs full wave sum)
   real4 wo[C::NBO][C::NB];           // NOUT > 1: dWout[16ob+4q+r][16kb+p], MFMA accumulators
   real bo[C::NBO][4];               // NOUT > 1: dbout[16ob+4q+r] (needs point_sum)
   real* bias;                       // ACC_LDS: this wave's LDS region holding b1 / w1 / b / wout instead (already point-summed)
@@ -1476,7 +1514,7 @@ __device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
       for (int r = 0; r < 4; ++r) acc.so[d][ob][r] = 0.f;
   }
 #pragma unroll
-  for (int l = 0; l < C::L; ++l) acc.al[l] = 0.f;
+  for (int l = 0; l < C::L; ++l) acc.ap[l][0] = acc.ap[l][1] = acc.ap[l][2] = 0.f;
 }
 
 // start of the per-wave bias-sum regions (ACC_LDS), behind the staging tiles / reduction regions
@@ -1634,7 +1672,7 @@ __device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stag
   sfor<C::L - 1>([&](auto k_) {
     constexpr int l = C::L - decltype(k_)::value;          // layer whose weights W_l (H x H) map h_{l-1} -> z_l
     constexpr int li = l - 1;             // state index of layer l
-    if constexpr ((NDQ_ABL & 8) == 0) act_backward<C>(st[li], g, acc.al[li]);           // g: hbar_l -> zbar_l
+    if constexpr ((NDQ_ABL & 8) == 0) act_backward<C>(st[li], g, acc.ap[li]);           // g: hbar_l -> zbar_l
     NDQ_TT(5 + 3 * (C::L - l));
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
@@ -1660,7 +1698,7 @@ __device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stag
 
   // ---------------- first layer: z_a = W1[:,a] (constant), z_ab = 0
   if constexpr (C::WIDE && C::L == 1) reload_first_layer_streams<C>(lds, q, st[0]);
-  act_backward<C>(st[0], g, acc.al[0]);  // g[0] = zbar, g[1+a] = zbar_a
+  act_backward<C>(st[0], g, acc.ap[0]);  // g[0] = zbar, g[1+a] = zbar_a
   if constexpr (C::ACC_LDS) {
 #pragma unroll
     for (int b = 0; b < C::NB; ++b) {
@@ -1706,9 +1744,11 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
   constexpr int R = bwd_regions<C>(WAVES);
   real* red0 = lds + C::ldsWeightsEnd(true);
   const real bsum = point_sum(quad_sum(acc.bout));
-  real alsum[C::L];
+  real apsum[C::L][3];
 #pragma unroll
-  for (int l = 0; l < C::L; ++l) alsum[l] = C::ALPHA ? point_sum(quad_sum(acc.al[l])) : 0.f;
+  for (int l = 0; l < C::L; ++l)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) apsum[l][k] = (C::ACTP != 0) ? point_sum(quad_sum(acc.ap[l][k])) : 0.f;
   real ssum[C::D];
 #pragma unroll
   for (int a = 0; a < C::D; ++a) ssum[a] = (C::SKIP != 0) ? point_sum(quad_sum(acc.skip[a])) : 0.f;
@@ -1805,12 +1845,19 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
             }
           }
       }
-      if constexpr (C::ACTP != 0) {           // act-parameter slots: alpha's sum (APTx), zeros elsewhere (filled below)
+      if constexpr (C::ACTP != 0) {           // activation parameters (formulas: Act<ACT_APTX>)
         if (lane == 0) {
 #pragma unroll
-          for (int l = 0; l < C::L; ++l)
-#pragma unroll
-            for (int k = 0; k < C::AK; ++k) put(C::offA + l * C::AK + k, (C::ALPHA && k == 0) ? 0.5f * alsum[l] : 0.f);
+          for (int l = 0; l < C::L; ++l) {
+            const real dbeta = apsum[l][1] / act_pre<C>(prm, l + 1);
+            if constexpr (C::AK == 1) {
+              put(C::offA + l, dbeta);
+            } else {
+              put(C::offA + 3 * l, 0.5f * apsum[l][0]);
+              put(C::offA + 3 * l + 1, dbeta);
+              put(C::offA + 3 * l + 2, apsum[l][2] / prm[C::offA + 3 * l + 2]);
+            }
+          }
         }
       }
     }
@@ -1825,60 +1872,18 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
   if constexpr (C::ACTP == 0) {
     for (int i = threadIdx.x; i < C::P; i += blockDim.x) out[i] = total(i);
   } else {
-    // Chain rule from the scaled weights the tile loop ran on (stage_weights: W' = f W) to the stored parameters:
-    // dW = f dW', and since every f is a product of powers of the betas / gammas their gradients follow from the sums
-    // <dW, W> = <dW', W'> -- linear in the partial sums, so each workgroup does it on its own row and the second stage
-    // adds the rows up like any other entry.  d[2(l-1)] = <dW_l, W_l>, d[2(l-1)+1] = <db_l, b_l>, d[2L] = <dWout, Wout>
-    real d[2 * C::L + 1];
-#pragma unroll
-    for (int k = 0; k < 2 * C::L + 1; ++k) d[k] = 0.f;
-    auto segment = [&](int lo, int hi, real f, real& dot) {
-      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const real v = total(i) * f;
-        out[i] = v;
-        dot = rfma(v, prm[i], dot);
-      }
+    // the tile loop ran on scaled weights (stage_weights: W' = f W): dW = f dW'
+    auto segment = [&](int lo, int hi, real f) {
+      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) out[i] = total(i) * f;
     };
-    segment(C::offW1, C::offb1, act_pre<C>(prm, 1), d[0]);
-    segment(C::offb1, C::offb1 + C::H, act_pre<C>(prm, 1), d[1]);
+    segment(C::offW1, C::offb1 + C::H, act_pre<C>(prm, 1));
     sfor<C::L - 1>([&](auto k_) {
       constexpr int l = decltype(k_)::value + 2;
-      segment(C::offW(l), C::offb(l), act_pre<C>(prm, l) * act_post<C>(prm, l - 1), d[2 * (l - 1)]);
-      segment(C::offb(l), C::offb(l) + C::H, act_pre<C>(prm, l), d[2 * (l - 1) + 1]);
+      segment(C::offW(l), C::offb(l), act_pre<C>(prm, l) * act_post<C>(prm, l - 1));
+      segment(C::offb(l), C::offb(l) + C::H, act_pre<C>(prm, l));
     });
-    segment(C::offWout, C::offbout, act_post<C>(prm, C::L), d[2 * C::L]);
-    for (int i = C::offbout + threadIdx.x; i < C::offA; i += blockDim.x) out[i] = total(i);   // bout, skip weights
-    real dal[C::L];
-#pragma unroll
-    for (int l = 0; l < C::L; ++l) dal[l] = C::ALPHA ? total(C::offA + 3 * l) : 0.f;
-#pragma unroll
-    for (int k = 0; k < 2 * C::L + 1; ++k) d[k] = point_sum(quad_sum(d[k]));
-    __syncthreads();                          // everybody has read the regions: reuse them for the per-wave sums
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 2 * C::L + 1; ++k) red0[wave * (2 * C::L + 1) + k] = d[k];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int k = 0; k < 2 * C::L + 1; ++k) {
-        real v = 0.f;
-        for (int w = 0; w < WAVES; ++w) v += red0[w * (2 * C::L + 1) + k];
-        d[k] = v;
-      }
-#pragma unroll
-      for (int l = 1; l <= C::L; ++l) {
-        const real next = d[2 * l];           // <dW_{l+1}, W_{l+1}> (l = L: the output matrix)
-        const real dbeta = (d[2 * (l - 1)] + d[2 * (l - 1) + 1] - next) / act_pre<C>(prm, l);
-        if constexpr (C::AK == 1) {
-          out[C::offA + (l - 1)] = dbeta;
-        } else {
-          out[C::offA + 3 * (l - 1)] = dal[l - 1];
-          out[C::offA + 3 * (l - 1) + 1] = dbeta;
-          out[C::offA + 3 * (l - 1) + 2] = next / prm[C::offA + 3 * (l - 1) + 2];
-        }
-      }
-    }
+    segment(C::offWout, C::offbout, act_post<C>(prm, C::L));
+    segment(C::offbout, C::P, 1.f);           // output bias, skip weights, activation parameters
   }
 }
 
