@@ -31,7 +31,8 @@ typedef struct ndq_mlp_desc {
   int d;       /* number of input coordinates (1..3) */
   int first;   /* 1: first-order streams present */
   int mask2;   /* second-order pair mask */
-  int hidden;  /* width of every hidden layer (multiple of 16) */
+  int hidden;  /* width of every hidden layer, 1..64 (kernels lay it out padded to a multiple of 16; the flat parameter
+                  vector holds the real width) */
   int layers;  /* number of hidden layers */
   int act;     /* NDQ_ACT_* */
   int n_out;   /* output units */

@@ -416,7 +416,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if desc.hidden % 16 else 0}>;
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf}, NR = {self.n_r};
   static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
@@ -524,7 +524,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if desc.hidden % 16 else 0}>;
 static_assert(CFG::NS * CFG::NOUT == {width}, "stream layout of the traced program and of the kernel disagree");
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf}, NC = {self.n_coords}, NR = {self.n_r};
@@ -810,11 +810,16 @@ def mlp_ext_allowed(desc):
             if (desc.mask3 >> k) & 1 and not all((desc.mask2 >> pair_list(desc.d).index(p)) & 1
                                                    for p in ((a, b), (a, c), (b, c))):
                 return False
-    return (1 <= desc.d <= 3 and desc.hidden % 16 == 0 and 16 <= desc.hidden <= 64 and 1 <= desc.layers <= 4
+    return (1 <= desc.d <= 3 and 1 <= desc.hidden <= 64 and 1 <= desc.layers <= 4
             and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
             and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0))
             and desc.skip in (0, 1) and desc.actp in (0, 1) and (desc.actp == 0 or desc.act in (3, 4)))
+
+
+def padded_width(hidden):
+    """Width the kernels lay a hidden layer out for: the next multiple of 16 (csrc/ndq_mlp.h: Cfg::H vs Cfg::HR)."""
+    return (hidden + 15) // 16 * 16
 
 
 def mlp_ext_source(desc, f64=False):
@@ -823,7 +828,7 @@ def mlp_ext_source(desc, f64=False):
     return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
 {"#define NDQ_F64 1" if f64 else ""}
 #include "{header}"
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.hidden // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if desc.hidden % 16 else 0}>;
 extern "C" const {record}* ndq_ext_kernels(void) {{
   static const {record} k = ndq::make_kernels<CFG>();
   return &k;
@@ -857,7 +862,7 @@ def ensure_mlp_kernels(desc, f64=False):
     register = L.ndq64_mlp_register if f64 else L.ndq_mlp_register
     if supported(ctypes.byref(desc)):
         return True
-    if not mlp_ext_allowed(desc) or (f64 and (desc.lap or desc.skip or desc.hidden > 32)):
+    if not mlp_ext_allowed(desc) or (f64 and (desc.lap or desc.skip or desc.actp or desc.hidden > 32)):
         return False
     key = desc.key() + (("f64",) if f64 else ())
     if key in _MLP_EXT:
@@ -915,14 +920,14 @@ def fuse_mode(program: PointwiseProgram, descs=None):
     if K == 1:
         st = program.streams[0]
         d0 = descs[0] if descs is not None and 0 in descs else None
-        group_ok = (d0 is not None and d0.hidden <= 48 and all(c < program.n_coords for c in st.deps)
+        group_ok = (d0 is not None and padded_width(d0.hidden) <= 48 and all(c < program.n_coords for c in st.deps)
                     and not os.environ.get("NDQ_NO_GROUP_FUSE"))
         if plain and not (group_ok and os.environ.get("NDQ_FUSE_GROUP") == "1"):
             return "tile"
         return "group" if group_ok else None
     if not plain:
         return None
-    if descs is None or len({descs[k].key() for k in range(K)}) != 1 or descs[0].hidden > 48:
+    if descs is None or len({descs[k].key() for k in range(K)}) != 1 or padded_width(descs[0].hidden) > 48:
         return None
     if os.environ.get("NDQ_NO_MULTI_FUSE"):
         return None

@@ -72,7 +72,7 @@ typedef ndq_mlp_kernels kernels_record;
 template <class C>
 kernels_record make_kernels() {
   kernels_record k{};
-  k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::H, C::L, C::ACT, C::NOUT, C::SS::LAP, C::SKIP,
+  k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::HR, C::L, C::ACT, C::NOUT, C::SS::LAP, C::SKIP,
                         (int)C::SS::M3, C::ACTP};
   k.n_streams = C::NS;
   k.n_params = C::P;

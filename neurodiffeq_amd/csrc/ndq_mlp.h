@@ -389,12 +389,18 @@ template <> struct Act<ACT_APTX> {
 
 // ------------------------------------------------------------------------------------------------ config
 template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0, int SKIP_ = 0,
-          unsigned M3_ = 0, int ACTP_ = 0>
+          unsigned M3_ = 0, int ACTP_ = 0, int HR_ = 0>
 struct Cfg {
   using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
   static_assert(M3_ == 0 || ACT_ == ACT_TANH || ACT_ == ACT_SIN || ACT_ == ACT_SIGMOID,
                 "third-order streams: tanh / sin / sigmoid networks");
   static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
+  // HR: the network's real hidden width when it is no multiple of 16 (HR_ = 0: H).  Registers, fragments and LDS images
+  // are laid out for the padded width H; the padding units have zero weights in LDS (whatever their activation value,
+  // nothing downstream sees it) and no slot in the flat parameter / gradient vectors, which are indexed with HR.
+  static constexpr int HR = HR_ > 0 ? HR_ : H;
+  static_assert(HR <= H && HR > H - 16, "real width and padded width disagree");
+  static constexpr bool RAGGED = HR != H;
   static constexpr int NOUT = NOUT_;               // output units; > 1: the output layer is an MFMA layer too
   static constexpr int NBO = (NOUT_ + 15) / 16;    // 16-row blocks of the (zero-padded) output layer
   static constexpr int HO = 16 * NBO;
@@ -405,11 +411,11 @@ struct Cfg {
       (NDQ_F64 || NB_ * NB_ * (L_ - 1) + NB_ * SS::NS * L_ + (NOUT_ > 1 ? NB_ * NBO : 0) > 40) ? 256 : NDQ_BWD_THREADS;
   static constexpr int FWD_THREADS = (NB_ >= 4) ? 256 : NDQ_FWD_THREADS;
   // flat parameter offsets, torch order: W1 (H,D) b1 (H) | W_l (H,H) b_l (H), l = 2..L | Wout (1,H) bout (1)
-  static constexpr int offW1 = 0, offb1 = H * D;
-  static constexpr int offW(int l) { return H * D + H + (l - 2) * (H * H + H); }  // l in 2..L
-  static constexpr int offb(int l) { return offW(l) + H * H; }
-  static constexpr int offWout = H * D + H + (L - 1) * (H * H + H);
-  static constexpr int offbout = offWout + NOUT * H;
+  static constexpr int offW1 = 0, offb1 = HR * D;
+  static constexpr int offW(int l) { return HR * D + HR + (l - 2) * (HR * HR + HR); }  // l in 2..L
+  static constexpr int offb(int l) { return offW(l) + HR * HR; }
+  static constexpr int offWout = HR * D + HR + (L - 1) * (HR * HR + HR);
+  static constexpr int offbout = offWout + NOUT * HR;
   // SKIP: a trainable bias-free linear map from the inputs straight to the output, out += S x (networks.Resnet,
   // networks.py:73-106); its weights S (n_out x d) follow the output bias in the flat parameter vector
   static constexpr int SKIP = SKIP_;
@@ -506,14 +512,20 @@ __device__ __forceinline__ real actp_mul(real v, real f) {
 
 template <class C, bool BWD>
 __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict__ prm) {
-  constexpr int H = C::H, D = C::D, NB = C::NB;
+  constexpr int H = C::H, D = C::D, NB = C::NB, HR = C::HR;
   const int tid = threadIdx.x, nt = blockDim.x;
   const real f1 = act_pre<C>(prm, 1), fo = act_post<C>(prm, C::L);
+  // padding units (RAGGED: j >= HR) read as zero
+  auto unit = [&](int j, int idx, real f) {
+    if constexpr (C::RAGGED) return j < HR ? actp_mul<C>(prm[idx], f) : (real)0.f;
+    else return actp_mul<C>(prm[idx], f);
+  };
+  auto real_unit = [](int j) { return !C::RAGGED || j < HR; };
   for (int i = tid; i < D * H; i += nt) {  // W1T[a][j] = W1[j][a]
     const int a = i / H, j = i - a * H;
-    lds[C::ldsW1T + i] = actp_mul<C>(prm[C::offW1 + j * D + a], f1);
+    lds[C::ldsW1T + i] = unit(j, C::offW1 + j * D + a, f1);
   }
-  for (int i = tid; i < H; i += nt) lds[C::ldsb1 + i] = actp_mul<C>(prm[C::offb1 + i], f1);
+  for (int i = tid; i < H; i += nt) lds[C::ldsb1 + i] = unit(i, C::offb1 + i, f1);
   if constexpr (C::ALPHA) {
     if (tid < C::L) lds[C::ldsAlpha(BWD) + tid] = prm[C::offA + 3 * tid];
   }
@@ -524,7 +536,7 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
     }
   }
   if constexpr (C::NOUT == 1) {
-    for (int i = tid; i < H; i += nt) lds[C::ldsWout(BWD) + i] = actp_mul<C>(prm[C::offWout + i], fo);
+    for (int i = tid; i < H; i += nt) lds[C::ldsWout(BWD) + i] = unit(i, C::offWout + i, fo);
     if (tid == 0) lds[C::ldsbout(BWD)] = prm[C::offbout];
     if constexpr (C::SKIP != 0) {
       if (tid < D) lds[C::ldsSkip(BWD) + tid] = prm[C::offS + tid];
@@ -538,7 +550,9 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
     __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWoutT());
     for (int i = tid; i < C::HO * H; i += nt) {
       const int j = i / H, k = i - j * H;
-      const real w = j < C::NOUT ? actp_mul<C>(Wo[i], fo) : 0.f;
+      real w;
+      if constexpr (C::RAGGED) w = (j < C::NOUT && k < HR) ? actp_mul<C>(Wo[j * HR + k], fo) : 0.f;
+      else w = j < C::NOUT ? actp_mul<C>(Wo[i], fo) : 0.f;
       const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
       const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
       {
@@ -561,12 +575,14 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
       {  // forward A operand of block (ob, kb): blk = ob*NB + kb:  A[i'][q'] = Wo[16 ob + i'][16 kb + 4 q' + t]
         const int ob = blk / NB, kb = blk - ob * NB;
         const int o = 16 * ob + mrow(lane & 15);
-        lds[C::ldsWout(BWD) + i] = o < C::NOUT ? actp_mul<C>(Wo[o * H + 16 * kb + 4 * (lane >> 4) + t], fo) : 0.f;
+        const int k = 16 * kb + 4 * (lane >> 4) + t;
+        lds[C::ldsWout(BWD) + i] = (o < C::NOUT && real_unit(k)) ? actp_mul<C>(Wo[o * HR + k], fo) : 0.f;
       }
       if (BWD) {  // transposed A operand of block (kb, ob): blk = kb*NBO + ob:  A[i'][q'] = Wo[16 ob + 4 q' + t][16 kb + i']
         const int kb = blk / NBO, ob = blk - kb * NBO;
         const int o = 16 * ob + 4 * (lane >> 4) + t;
-        lds[C::ldsWoutT() + i] = o < C::NOUT ? actp_mul<C>(Wo[o * H + 16 * kb + mrow(lane & 15)], fo) : 0.f;
+        const int k = 16 * kb + mrow(lane & 15);
+        lds[C::ldsWoutT() + i] = (o < C::NOUT && real_unit(k)) ? actp_mul<C>(Wo[o * HR + k], fo) : 0.f;
       }
     }
     for (int i = tid; i < C::HO; i += nt) lds[C::ldsbout(BWD) + i] = i < C::NOUT ? prm[C::offbout + i] : 0.f;
@@ -583,7 +599,9 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
       const real fb = act_pre<C>(prm, l), fw = actp_mul<C>(fb, act_post<C>(prm, l - 1));
       for (int i = tid; i < H * H; i += nt) {   // one coalesced pass over W[j][k] (out j, in k): split once, scatter twice
         const int j = i / H, k = i - j * H;
-        const real w = actp_mul<C>(W[i], fw);
+        real w;
+        if constexpr (C::RAGGED) w = (j < HR && k < HR) ? actp_mul<C>(W[j * HR + k], fw) : 0.f;
+        else w = actp_mul<C>(W[i], fw);
         const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
         const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
         {  // forward image: block (ob = j/16, c = k/32), lane (j%16, kg = (k%16)/4), slot e = 4*((k%32)/16) + k%4
@@ -597,7 +615,7 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
           wt[base] = w0; wt[base + 512] = w1; wt[base + 1024] = w2;
         }
       }
-      for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = actp_mul<C>(prm[C::offb(l) + i], fb);
+      for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = unit(i, C::offb(l) + i, fb);
     }
   } else
 #pragma unroll
@@ -608,11 +626,15 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
       const int lane = i & 63, t = (i >> 6) & 3, blk = i >> 8;  // blk = first*NB + second
       const int b0 = blk / NB, b1 = blk - b0 * NB;
       // forward A operand of block (ib=b0, kb=b1), step t:  A[i'][k=q'] = W[16 ib + i'][16 kb + 4 q' + t]
-      lds[C::ldsWf(l, BWD) + i] = actp_mul<C>(W[(16 * b0 + mrow(lane & 15)) * H + 16 * b1 + 4 * (lane >> 4) + t], fw);
+      auto weight = [&](int j, int k) {
+        if constexpr (C::RAGGED) return (j < HR && k < HR) ? actp_mul<C>(W[j * HR + k], fw) : (real)0.f;
+        else return actp_mul<C>(W[j * H + k], fw);
+      };
+      lds[C::ldsWf(l, BWD) + i] = weight(16 * b0 + mrow(lane & 15), 16 * b1 + 4 * (lane >> 4) + t);
       if (BWD)  // transposed A operand of block (kb=b0, ib=b1): A[i'][k=q'] = W[16 ib + 4 q' + t][16 kb + i']
-        lds[C::ldsWt(l) + i] = actp_mul<C>(W[(16 * b1 + 4 * (lane >> 4) + t) * H + 16 * b0 + mrow(lane & 15)], fw);
+        lds[C::ldsWt(l) + i] = weight(16 * b1 + 4 * (lane >> 4) + t, 16 * b0 + mrow(lane & 15));
     }
-    for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = actp_mul<C>(prm[C::offb(l) + i], fb);
+    for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = unit(i, C::offb(l) + i, fb);
   }
 }
 
@@ -1800,7 +1822,7 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * b + 4 * q + r;
-          if (p == 0) {
+          if (p == 0 && (!C::RAGGED || j < C::HR)) {
             put(C::offb1 + j, acc.b1[b][r]);
             if constexpr (C::NOUT == 1) put(C::offWout + j, acc.wout[b][r]);
 #pragma unroll
@@ -1816,8 +1838,10 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
 #pragma unroll
           for (int kb = 0; kb < C::NB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              put(C::offW(l + 2) + (16 * jb + 4 * q + r) * C::H + 16 * kb + p, acc.w[l][jb][kb][r]);
+            for (int r = 0; r < 4; ++r) {
+              const int j = 16 * jb + 4 * q + r, k = 16 * kb + p;
+              if (!C::RAGGED || (j < C::HR && k < C::HR)) put(C::offW(l + 2) + j * C::HR + k, acc.w[l][jb][kb][r]);
+            }
       if constexpr (C::NOUT == 1) {
         if (lane == 0) {
           put(C::offbout, bsum);
@@ -1841,7 +1865,9 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
                 }
               }
 #pragma unroll
-              for (int kb = 0; kb < C::NB; ++kb) put(C::offWout + u * C::H + 16 * kb + p, acc.wo[ob][kb][r]);
+              for (int kb = 0; kb < C::NB; ++kb) {
+                if (!C::RAGGED || 16 * kb + p < C::HR) put(C::offWout + u * C::HR + 16 * kb + p, acc.wo[ob][kb][r]);
+              }
             }
           }
       }
@@ -1876,11 +1902,11 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
     auto segment = [&](int lo, int hi, real f) {
       for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) out[i] = total(i) * f;
     };
-    segment(C::offW1, C::offb1 + C::H, act_pre<C>(prm, 1));
+    segment(C::offW1, C::offb1 + C::HR, act_pre<C>(prm, 1));
     sfor<C::L - 1>([&](auto k_) {
       constexpr int l = decltype(k_)::value + 2;
       segment(C::offW(l), C::offb(l), act_pre<C>(prm, l) * act_post<C>(prm, l - 1));
-      segment(C::offb(l), C::offb(l) + C::H, act_pre<C>(prm, l));
+      segment(C::offb(l), C::offb(l) + C::HR, act_pre<C>(prm, l));
     });
     segment(C::offWout, C::offbout, act_post<C>(prm, C::L));
     segment(C::offbout, C::P, 1.f);           // output bias, skip weights, activation parameters

@@ -163,7 +163,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         if not (2 <= K <= 4) or len(streams) != K or len(g.site_net) != K or os.environ.get("NDQ_NO_MULTI_FUSE"):
             return
         shape = {(i["d"], i["hidden"], i["layers"], i["act"], i["n_out"], i["skip"], i["actp"]) for i in infos}
-        if len(shape) != 1 or infos[0]["n_out"] != 1 or infos[0]["hidden"] > 48:
+        if len(shape) != 1 or infos[0]["n_out"] != 1 or codegen.padded_width(infos[0]["hidden"]) > 48:
             return
         if any(tuple(st.deps) != tuple(range(n_coords)) for st in streams.values()):
             return
@@ -269,7 +269,7 @@ class FusedSystem:
         if codegen.fuse_mode(self.program, self.descs) == "group":
             return os.environ.get("NDQ_GROUP_WIDE", "0") == "1"     # experiment: 8 waves with 32-point groups
         d = self.descs[0]
-        nb, layers = d.hidden // 16, d.layers
+        nb, layers = (d.hidden + 15) // 16, d.layers
         ns = self.L.ndq_mlp_num_streams(ctypes.byref(d))
         return nb * nb * (layers - 1) + nb * ns * layers <= 40
 

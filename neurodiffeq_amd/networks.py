@@ -2,8 +2,8 @@
 142-209) so existing scripts keep working; ``FCNN`` is a real ``nn.Module`` (``.NN`` is the ``Sequential``; its
 parameters are ordinary ``nn.Parameter`` objects, which the optimiser, ``deepcopy`` and checkpoints rely on).
 
-What is new is :func:`describe`: it recognises the modules the gfx950 kernels can run (FCNN / Resnet with a uniform
-hidden width that is a multiple of 16; tanh, sin, sigmoid, Swish, APTx -- the last two with their default or with
+What is new is :func:`describe`: it recognises the modules the gfx950 kernels can run (FCNN / Resnet with one hidden
+width of up to 64 units on every layer; tanh, sin, sigmoid, Swish, APTx -- the last two with their default or with
 trainable parameters; any number of output units) and :class:`FlatParams`, which re-homes the parameters as views of
 one flat fp32 buffer -- linear layers in torch order, then the skip weights, then the activation parameters: the
 layout ``ndq_mlp_jet_fwd/bwd`` and ``ndq_adam_step`` consume.
@@ -172,8 +172,8 @@ def describe(net, dtype=torch.float32):
         elif any(tuple(getattr(a, k) for k in names) != ((1.0,) if len(names) == 1 else (1.0, 1.0, 0.5)) for a in acts):
             return None
     hidden = linears[0].out_features
-    if hidden % 16 or any(l.in_features != hidden or l.out_features != hidden for l in linears[1:-1]):
-        return None
+    if any(l.in_features != hidden or l.out_features != hidden for l in linears[1:-1]):
+        return None          # one width for all hidden layers (any width: the kernels pad it to a multiple of 16)
     if linears[-1].in_features != hidden:
         return None
     if any(p.dtype != dtype for l in linears for p in l.parameters()):

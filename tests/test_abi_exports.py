@@ -35,7 +35,7 @@ def test_descriptor_queries_without_gpu():
     assert L.ndq_mlp_supported(ctypes.byref(c2lap)) == 1 and L.ndq_mlp_num_streams(ctypes.byref(c2lap)) == 4
     c3 = _lib.MlpDesc(2, 1, 1, 64, 3, _lib.NDQ_ACT_TANH, 1, 0)
     assert L.ndq_mlp_num_params(ctypes.byref(c3)) == 8577
-    bad = _lib.MlpDesc(2, 1, 5, 40, 2, 0, 1, 0)
+    bad = _lib.MlpDesc(2, 1, 5, 80, 2, 0, 1, 0)                          # wider than the kernels go
     assert L.ndq_mlp_supported(ctypes.byref(bad)) == 0
     assert L.ndq_mlp_num_params(ctypes.byref(bad)) == -1
 

@@ -30,6 +30,14 @@ CASES = {
     "res_25out": ((1, 32, 32, 25), "tanh", 1, 0),
     "res_3out_wide": ((2, 64, 64, 64, 3), "tanh", 1, 0),
     "res_aptx_tr_3out": ((2, 32, 32, 3), "aptx", 1, 1),
+    # hidden widths that are no multiple of 16 (Cfg::HR: padded in registers / LDS, real in the flat vectors)
+    "w20": ((2, 20, 20, 1), "tanh", 0, 0),
+    "w50x3": ((2, 50, 50, 50, 1), "tanh", 0, 0),
+    "w40_sigmoid": ((1, 40, 40, 1), "sigmoid", 0, 0),
+    "w24_3out_skip": ((2, 24, 24, 3), "tanh", 1, 0),
+    "w50_25out": ((1, 50, 50, 25), "tanh", 0, 0),
+    "w10x1_sin": ((2, 10, 1), "sin", 0, 0),
+    "w50_swish_tr": ((2, 50, 50, 1), "swish", 0, 1),
 }
 ACT_ID = {"tanh": 0, "sin": 1, "sigmoid": 2, "swish": 3, "aptx": 4}
 
@@ -124,8 +132,9 @@ def _grad_in_torch_order(nets, flats):
 
 
 @pytest.mark.parametrize("mode", ["1k", "3k"])
-@pytest.mark.parametrize("name", ["swish_tr_laplace", "aptx_tr_laplace", "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet"])
-def test_closure_with_trainable_activation_parameters_matches_autograd_oracle(name, mode):
+@pytest.mark.parametrize("name", ["swish_tr_laplace", "aptx_tr_laplace", "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet",
+                                  "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1"])
+def test_closure_of_networks_outside_the_template_matches_autograd_oracle(name, mode):
     """funcs / residuals / loss / gradient of one closure, the gradient compared parameter by parameter in torch order
     (activation scalars interleaved with the linear layers there, behind them in the kernels' flat vector)."""
     from tests import zoo

@@ -309,7 +309,7 @@ def test_bad_arguments_are_rejected(L):
     t = torch.zeros(64, device="cuda")
     assert L.ndq_mlp_jet_fwd(ctypes.byref(d), t.data_ptr(), 64, 0, t.data_ptr(), t.data_ptr(), 64, _stream()) == -2
     assert L.ndq_mlp_jet_fwd(ctypes.byref(d), t.data_ptr(), 8, 16, t.data_ptr(), t.data_ptr(), 64, _stream()) == -2
-    bad = _lib.MlpDesc(2, 1, 5, 40, 2, 0, 1, 0)
+    bad = _lib.MlpDesc(2, 1, 5, 80, 2, 0, 1, 0)
     assert L.ndq_mlp_supported(ctypes.byref(bad)) == 0
     assert L.ndq_mlp_jet_fwd(ctypes.byref(bad), t.data_ptr(), 64, 16, t.data_ptr(), t.data_ptr(), 64, _stream()) == -1
 

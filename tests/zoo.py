@@ -142,10 +142,13 @@ def build(name):
             return 0.0 * (1 - s) + u1 * s + (1 - torch.exp((1 - s) * s)) * net(_cat(t, u1))
         return System(name, 2, [(2, 1, (32, 32), "tanh")], [(0.0, 1.0), (-1.0, 1.0)], pde, conds, lambda D: [e])
     # ---- network shapes outside libndq.so's table: compiled on first use as extension modules (codegen.ensure_mlp_kernels)
-    if name in ("shape_64x2", "shape_32x3", "shape_48x2", "shape_16x2_sin", "shape_32x1"):
+    if name in ("shape_64x2", "shape_32x3", "shape_48x2", "shape_16x2_sin", "shape_32x1", "shape_50x2", "shape_20x3",
+                "shape_40x2_sigmoid", "shape_10x1"):
+        # widths that are no multiple of 16 run padded (csrc/ndq_mlp.h: Cfg::HR); sigmoid: the padding units output 1/2
         hidden, act = {"shape_64x2": ((64, 64), "tanh"), "shape_32x3": ((32, 32, 32), "tanh"),
                        "shape_48x2": ((48, 48), "tanh"), "shape_16x2_sin": ((16, 16), "sin"),
-                       "shape_32x1": ((32,), "tanh")}[name]
+                       "shape_32x1": ((32,), "tanh"), "shape_50x2": ((50, 50), "tanh"), "shape_20x3": ((20, 20, 20), "tanh"),
+                       "shape_40x2_sigmoid": ((40, 40), "sigmoid"), "shape_10x1": ((10,), "sin")}[name]
         f0 = lambda y: torch.sin(PI * y)
         pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + u * D(u, x) - torch.exp(-x * y)])
         conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
@@ -229,7 +232,7 @@ def build(name):
 NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "kdv", "ode3", "poisson3d",
          "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
          "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode", "swish_tr_laplace", "aptx_tr_laplace",
-         "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet"]
+         "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1"]
 
 
 def spherical_solver_problem():
