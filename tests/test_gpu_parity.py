@@ -466,8 +466,13 @@ def test_fused_closure_matches_reference_golden_at_stated_size(golden_dir, name,
     ex = cfg["gen"].get_examples()
     coords = [ex.detach()] if isinstance(ex, torch.Tensor) else [c.detach() for c in ex]
     assert coords[0].numel() == int(gold["n_points"])
-    assert np.array_equal(np.stack([c[:8].numpy() for c in coords]), gold["coords_head"])
-    assert np.array_equal(np.asarray([c.view(torch.int32).to(torch.int64).sum().item() for c in coords]), gold["coords_bits_sum"])
+    # the same draw as the reference's: first values, and the int64 sum of the fp32 bit patterns.  The spherical generator
+    # goes through acos / cbrt-type CPU kernels whose last bit depends on the host's vector ISA (build container vs GPU
+    # box: 3 of 393 216 values differ by an ulp), so the checksum gets a budget of 1/8 ulp per value -- another draw is
+    # off by ~1e6 ulp per value
+    assert np.allclose(np.stack([c[:8].numpy() for c in coords]), gold["coords_head"], rtol=3e-7, atol=0)
+    bits = np.asarray([c.view(torch.int32).to(torch.int64).sum().item() for c in coords])
+    assert np.all(np.abs(bits - gold["coords_bits_sum"]) <= coords[0].numel() // 8), (bits, gold["coords_bits_sum"])
     b, n = system.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)
     torch.cuda.synchronize()
     n_eq = gold["resid_sq_sum"].shape[0]

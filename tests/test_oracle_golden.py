@@ -69,8 +69,11 @@ def test_chunked_closure_matches_reference_at_stated_size(golden_dir, name, size
     sampler = R.build_config(name, size)["sampler"]           # the draw is fp32, like the reference's generators
     torch.manual_seed(int(g["seed"]) + 1)
     coords = sampler()
-    assert np.array_equal(np.stack([c[:8].numpy() for c in coords]), g["coords_head"])
-    assert np.array_equal(np.asarray([c.view(torch.int32).to(torch.int64).sum().item() for c in coords]), g["coords_bits_sum"])
+    # same draw as the reference's (checksum budget: 1/8 ulp per value -- the spherical generator's transcendental CPU
+    # kernels may differ in the last bit between host ISAs; a different draw is off by ~1e6 ulp per value)
+    assert np.allclose(np.stack([c[:8].numpy() for c in coords]), g["coords_head"], rtol=3e-7, atol=0)
+    bits = np.asarray([c.view(torch.int32).to(torch.int64).sum().item() for c in coords])
+    assert np.all(np.abs(bits - g["coords_bits_sum"]) <= coords[0].numel() // 8), (bits, g["coords_bits_sum"])
     out = R.closure_chunked(cfg["nets"], cfg["enforcers"], cfg["pde"], [c.double() for c in coords], chunk=16384, keep=True)
     assert abs(out["loss"].item() - float(g["loss_f64"])) <= 1e-11 * abs(float(g["loss_f64"]))
     assert rel_l2(R.get_flat_grad(cfg["nets"]).numpy(), g["grad_f64"]) < 1e-11
