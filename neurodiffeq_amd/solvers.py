@@ -357,6 +357,7 @@ class BaseSolver(ABC):
                     same = False
                 if same:
                     return sysm
+                self._flush_device_history()     # epochs the native path still holds on the device belong to the history
                 self._fused_key, self._fused_sys = key, None
                 reason = ("the loss function / additional_loss changed between epochs (it depends on solver or Python state, "
                           "which a traced kernel freezes)")
@@ -366,6 +367,7 @@ class BaseSolver(ABC):
                               "the reference's closure on torch autograd instead.", RuntimeWarning)
                 self._loss_time_dependent = True
                 return None
+        self._flush_device_history()
         self._fused_key, self._fused_sys = key, None
         if reason is None:
             try:
