@@ -45,7 +45,9 @@ typedef struct ndq_mlp_desc {
   int actp;    /* 1: trainable activation parameters (Swish(trainable=True): beta; APTx(trainable=True): alpha, beta,
                   gamma -- one set per hidden layer, networks.py:166-169,196-203).  They sit at the END of the flat
                   parameter vector, layer after layer, and get gradient entries like every other parameter; beta and
-                  gamma must be non-zero */
+                  gamma must be non-zero.
+                  2: the same scalars as fixed non-default values (Swish(beta=2.0)): the layers x {1, 3} floats FOLLOW
+                  the n_params trainable entries in the buffer `params` points to and have no gradient entries */
 } ndq_mlp_desc;
 
 /* One compiled kernel pair (forward streams / parameter-gradient adjoint) for ONE descriptor.  libndq.so carries a

@@ -814,7 +814,7 @@ def mlp_ext_allowed(desc):
             and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
             and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0))
-            and desc.skip in (0, 1) and desc.actp in (0, 1) and (desc.actp == 0 or desc.act in (3, 4)))
+            and desc.skip in (0, 1) and desc.actp in (0, 1, 2) and (desc.actp == 0 or desc.act in (3, 4)))
 
 
 def padded_width(hidden):

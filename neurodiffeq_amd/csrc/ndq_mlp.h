@@ -420,14 +420,16 @@ struct Cfg {
   // networks.py:73-106); its weights S (n_out x d) follow the output bias in the flat parameter vector
   static constexpr int SKIP = SKIP_;
   static constexpr int offS = offbout + NOUT;
-  // ACTP: trainable activation parameters (networks.Swish(trainable=True): beta; networks.APTx(trainable=True): alpha,
-  // beta, gamma -- networks.py:155-209), one set per hidden layer, behind everything else in the flat vector
+  // ACTP = 1: trainable activation parameters (networks.Swish(trainable=True): beta; networks.APTx(trainable=True):
+  // alpha, beta, gamma -- networks.py:155-209), one set per hidden layer, behind everything else in the flat vector.
+  // ACTP = 2: the same scalars as FIXED non-default values (Swish(beta=2.0)): they follow the P trainable entries in
+  // the parameter buffer and have no gradient slots.
   static constexpr int ACTP = ACTP_;
   static constexpr int AK = (ACT_ == ACT_SWISH) ? 1 : (ACT_ == ACT_APTX) ? 3 : 0;
   static_assert(ACTP_ == 0 || AK > 0, "trainable activation parameters: Swish / APTx");
   static constexpr bool ALPHA = (ACTP_ != 0) && (ACT_ == ACT_APTX);
   static constexpr int offA = offS + SKIP * NOUT * D;
-  static constexpr int P = offA + ACTP * AK * L;
+  static constexpr int P = offA + (ACTP_ == 1 ? AK * L : 0);
   // LDS carve (floats): W1T [D][H] | b1 [H] | per hidden-hidden layer: Wf [H*H] (+ Wt [H*H] for bwd) | b_l | Wout | bout
   static constexpr int ldsW1T = 0, ldsb1 = D * H;
   static constexpr int ldsLayer0 = D * H + H;
@@ -774,7 +776,7 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)
       const real t = st.t[b][r], c = st.c[b][r];
       const real s1 = A::s1(t, c, layer_alpha<C>(st));
       real u0 = 0.f, gh = 0.f, gu = 0.f;     // ACTP: pre-activation value, sum_s g_s h_s, sum_s g_s u_s of this unit
-      if constexpr (C::ACTP != 0) {
+      if constexpr (C::ACTP == 1) {
         // swish keeps t = u sigma(u) and c = sigma(u): u = t / c (c underflows to 0 only where the contribution does too)
         if constexpr (C::ACT == ACT_SWISH) u0 = (c > 0.f) ? t / c : 0.f;
         else u0 = c;
@@ -784,7 +786,7 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)
       real z0 = s1 * g[0][b][r];
       if constexpr (SS::FIRST) {
         const real s2 = A::s2(t, c, s1);
-        if constexpr (C::ACTP != 0) {        // h_a = s1 u_a; h_L = s2 sum u_a^2 + s1 u_L; h_ab = s2 u_a u_b + s1 u_ab
+        if constexpr (C::ACTP == 1) {        // h_a = s1 u_a; h_L = s2 sum u_a^2 + s1 u_L; h_ab = s2 u_a u_b + s1 u_ab
           sfor<C::D>([&](auto a_) {
             constexpr int a = decltype(a_)::value;
             gh = rfma(g[1 + a][b][r], s1 * st.z[1 + a][b][r], gh);
@@ -870,7 +872,7 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)
         });
       }
       g[0][b][r] = z0;
-      if constexpr (C::ACTP != 0) {
+      if constexpr (C::ACTP == 1) {
         real uu = z0 * u0;
 #pragma unroll
         for (int s = 1; s < C::NS; ++s) uu = rfma(g[s][b][r], st.z[s][b][r], uu);
@@ -1770,7 +1772,7 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
 #pragma unroll
   for (int l = 0; l < C::L; ++l)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) apsum[l][k] = (C::ACTP != 0) ? point_sum(quad_sum(acc.ap[l][k])) : 0.f;
+    for (int k = 0; k < 3; ++k) apsum[l][k] = (C::ACTP == 1) ? point_sum(quad_sum(acc.ap[l][k])) : 0.f;
   real ssum[C::D];
 #pragma unroll
   for (int a = 0; a < C::D; ++a) ssum[a] = (C::SKIP != 0) ? point_sum(quad_sum(acc.skip[a])) : 0.f;
@@ -1871,7 +1873,7 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
             }
           }
       }
-      if constexpr (C::ACTP != 0) {           // activation parameters (formulas: Act<ACT_APTX>)
+      if constexpr (C::ACTP == 1) {           // activation parameters (formulas: Act<ACT_APTX>)
         if (lane == 0) {
 #pragma unroll
           for (int l = 0; l < C::L; ++l) {
@@ -1909,7 +1911,7 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
       segment(C::offb(l), C::offb(l) + C::HR, act_pre<C>(prm, l));
     });
     segment(C::offWout, C::offbout, act_post<C>(prm, C::L));
-    segment(C::offbout, C::P, 1.f);           // output bias, skip weights, activation parameters
+    segment(C::offbout, C::P, 1.f);           // output bias, skip weights, (trainable) activation parameters
   }
 }
 

@@ -154,10 +154,10 @@ def describe(net, dtype=torch.float32):
     act_types = {type(a) for a in acts}
     if len(act_types) != 1 or next(iter(act_types)) not in _ACT_IDS:
         return None
-    # Swish / APTx: either their default fixed parameters (constants in the kernels) or trainable ones on every layer
-    # (ndq_mlp_desc.actp: per-layer scalars at the end of the flat parameter vector); fixed non-default values are not
-    # covered
-    act_params = []
+    # Swish / APTx: their default fixed parameters (constants in the kernels), trainable ones on every layer
+    # (ndq_mlp_desc.actp = 1: per-layer scalars at the end of the flat parameter vector) or fixed non-default values
+    # (actp = 2: the scalars follow the trainable entries in the flat buffer, no gradient slots)
+    act_params, act_frozen = [], []
     if acts and isinstance(acts[0], (Swish, APTx)):
         trainable = {bool(a.trainable) for a in acts}
         if len(trainable) != 1:
@@ -170,7 +170,9 @@ def describe(net, dtype=torch.float32):
             if len({id(p) for p in act_params}) != len(act_params):
                 return None      # one module object used for several layers: its parameters are shared, not per layer
         elif any(tuple(getattr(a, k) for k in names) != ((1.0,) if len(names) == 1 else (1.0, 1.0, 0.5)) for a in acts):
-            return None
+            act_frozen = [float(getattr(a, k)) for a in acts for k in names]
+            if any(getattr(a, "beta") == 0 or getattr(a, "gamma", 1.0) == 0 for a in acts):
+                return None
     hidden = linears[0].out_features
     if any(l.in_features != hidden or l.out_features != hidden for l in linears[1:-1]):
         return None          # one width for all hidden layers (any width: the kernels pad it to a multiple of 16)
@@ -184,7 +186,7 @@ def describe(net, dtype=torch.float32):
     params = [p for l in linears for p in (l.weight, l.bias)] + ([skip.weight] if skip is not None else []) + act_params
     return dict(d=linears[0].in_features, hidden=hidden, layers=len(acts), act=_ACT_IDS[next(iter(act_types))],
                 n_out=linears[-1].out_features, linears=linears, skip=int(skip is not None), params=params,
-                actp=int(bool(act_params)))
+                actp=1 if act_params else (2 if act_frozen else 0), frozen=act_frozen)
 
 
 class FlatParams:
@@ -196,7 +198,9 @@ class FlatParams:
     def __init__(self, net, device):
         self.net = net
         self.device = torch.device(device)
-        self.params = describe(net)["params"]
+        info = describe(net)
+        self.params = info["params"]
+        self.frozen = info["frozen"]      # fixed non-default activation scalars: behind the trainable entries of ``flat``
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
         # gradient buffer with one spare trailing slot: single-network systems keep the batch loss there so that
@@ -224,7 +228,9 @@ class FlatParams:
         if self._is_flat():
             return
         with torch.no_grad():
-            flat = torch.cat([p.detach().to(self.device, torch.float32).reshape(-1) for p in self.params]).contiguous()
+            flat = torch.cat([p.detach().to(self.device, torch.float32).reshape(-1) for p in self.params]
+                             + ([torch.tensor(self.frozen, dtype=torch.float32, device=self.device)] if self.frozen else [])
+                             ).contiguous()
             for p, off in zip(self.params, self._offsets):
                 p.data = flat[off:off + p.numel()].view(p.shape)
         self.flat = flat

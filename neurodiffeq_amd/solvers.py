@@ -29,7 +29,7 @@ from .conditions import BaseCondition
 from .generators import Generator1D, Generator2D, GeneratorSpherical, SamplerGenerator
 from . import autograd_ops
 from .losses import _losses
-from .networks import FCNN
+from .networks import FCNN, describe
 from .neurodiffeq import safe_diff as diff
 from .optim import FusedAdam
 from .symbolic import TraceUnsupported
@@ -253,7 +253,7 @@ class BaseSolver(ABC):
             with torch.no_grad():
                 for net, flat in zip(nets, self._best_flat):
                     off = 0
-                    for p in net.parameters():
+                    for p in describe(net)["params"]:      # the flat vector's order (networks.FlatParams)
                         p.copy_(flat[off:off + p.numel()].view(p.shape))
                         off += p.numel()
             self._best_nets = nets

@@ -91,8 +91,23 @@ class APTxTrainableRef(nn.Module):
         return (self.alpha + torch.tanh(self.beta * x)) * self.gamma * x
 
 
+class SwishFixedRef(nn.Module):
+    """x * sigmoid(beta x) with a fixed non-default beta = 1.7 (Swish(beta=1.7), networks.py:161-169)."""
+
+    def forward(self, x):
+        return x * torch.sigmoid(1.7 * x)
+
+
+class APTxFixedRef(nn.Module):
+    """(alpha + tanh(beta x)) * gamma * x with fixed alpha = 0.8, beta = 1.3, gamma = 0.6 (networks.py:193-209)."""
+
+    def forward(self, x):
+        return (0.8 + torch.tanh(1.3 * x)) * 0.6 * x
+
+
 ACTIVATIONS = {"tanh": nn.Tanh, "sin": Sin, "sigmoid": nn.Sigmoid, "swish": SwishRef, "aptx": APTxRef,
-               "swish-tr": SwishTrainableRef, "aptx-tr": APTxTrainableRef}
+               "swish-tr": SwishTrainableRef, "aptx-tr": APTxTrainableRef, "swish-fixed": SwishFixedRef,
+               "aptx-fixed": APTxFixedRef}
 
 
 def make_fcnn(n_in, n_out, hidden, act="tanh", dtype=torch.float32):

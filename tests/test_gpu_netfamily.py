@@ -38,6 +38,9 @@ CASES = {
     "w50_25out": ((1, 50, 50, 25), "tanh", 0, 0),
     "w10x1_sin": ((2, 10, 1), "sin", 0, 0),
     "w50_swish_tr": ((2, 50, 50, 1), "swish", 0, 1),
+    # fixed non-default activation scalars (actp = 2): behind the trainable entries of the parameter buffer, no gradients
+    "swish_fixed": ((2, 32, 32, 1), "swish", 0, 2),
+    "aptx_fixed_3out": ((2, 32, 32, 3), "aptx", 0, 2),
 }
 ACT_ID = {"tanh": 0, "sin": 1, "sigmoid": 2, "swish": 3, "aptx": 4}
 
@@ -84,7 +87,9 @@ def test_stream_kernels_match_jet_oracle(name, n):
     assert codegen.ensure_mlp_kernels(d) and L.ndq_mlp_supported(ctypes.byref(d)) == 1
     rng = np.random.default_rng(zlib.crc32(f"{name}/{n}".encode()))
     flat = _flat(name, rng)
-    assert L.ndq_mlp_num_params(ctypes.byref(d)) == flat.size and L.ndq_mlp_num_streams(ctypes.byref(d)) == len(streams)
+    n_frozen = (len(dims) - 2) * (1 if act == "swish" else 3) if actp == 2 else 0
+    P = flat.size - n_frozen
+    assert L.ndq_mlp_num_params(ctypes.byref(d)) == P and L.ndq_mlp_num_streams(ctypes.byref(d)) == len(streams)
     coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
     ld = (n + 63) // 64 * 64
     c = torch.zeros(dims[0], ld, device="cuda"); c[:, :n] = torch.from_numpy(coords)
@@ -101,20 +106,20 @@ def test_stream_kernels_match_jet_oracle(name, n):
     gbar = rng.standard_normal((len(streams), dims[-1], n)).astype(np.float32)
     g = torch.zeros(len(streams), dims[-1], ld, device="cuda"); g[:, :, :n] = torch.from_numpy(gbar)
     nb = L.ndq_mlp_bwd_blocks(ctypes.byref(d), n)
-    part = torch.full((nb, flat.size), float("nan"), device="cuda")
-    out = torch.zeros(flat.size, device="cuda")
+    part = torch.full((nb, P), float("nan"), device="cuda")
+    out = torch.zeros(P, device="cuda")
     assert L.ndq_mlp_jet_bwd(ctypes.byref(d), c.data_ptr(), ld, n, p.data_ptr(), g.data_ptr(), ld, part.data_ptr(), _stream()) == 0
-    assert L.ndq_reduce_partials(part.data_ptr(), nb, flat.size, out.data_ptr(), 0, 1.0, _stream()) == 0
+    assert L.ndq_reduce_partials(part.data_ptr(), nb, P, out.data_ptr(), 0, 1.0, _stream()) == 0
     torch.cuda.synchronize()
     grad = out.cpu().numpy()
     want_grad = J.mlp_jets_vjp(f64, dims, act, c64, {m: gbar[s].astype(np.float64).T for s, m in enumerate(streams)},
-                               skip=bool(skip), actp=bool(actp))
+                               skip=bool(skip), actp=bool(actp))[:P]
     n_lin = J._n_fcnn_params(dims)
     n_skip = dims[-1] * dims[0] if skip else 0
     errs["grad_linear"] = rel_l2(grad[:n_lin], want_grad[:n_lin])
     if skip:
         errs["grad_skip"] = rel_l2(grad[n_lin:n_lin + n_skip], want_grad[n_lin:n_lin + n_skip])
-    if actp:
+    if actp == 1:
         errs["grad_act"] = rel_l2(grad[n_lin + n_skip:], want_grad[n_lin + n_skip:])
     os.makedirs(DIAG, exist_ok=True)
     import json
@@ -133,7 +138,8 @@ def _grad_in_torch_order(nets, flats):
 
 @pytest.mark.parametrize("mode", ["1k", "3k"])
 @pytest.mark.parametrize("name", ["swish_tr_laplace", "aptx_tr_laplace", "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet",
-                                  "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1"])
+                                  "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1", "swish_fixed_laplace",
+                                  "aptx_fixed_laplace"])
 def test_closure_of_networks_outside_the_template_matches_autograd_oracle(name, mode):
     """funcs / residuals / loss / gradient of one closure, the gradient compared parameter by parameter in torch order
     (activation scalars interleaved with the linear layers there, behind them in the kernels' flat vector)."""
@@ -228,6 +234,10 @@ def test_solver_trains_activation_parameters_like_torch():
         torch.manual_seed(1)
         solver.fit(max_epochs=25)
         assert solver.fused_active == (fused == "require")
+        if fused == "require":      # best-network snapshot: a flat device copy in the kernels' parameter order, unpacked per module
+            best = solver.best_nets[0]
+            assert all(0.8 < float(best.NN[i].beta) < 1.8 for i in (1, 3)), [float(best.NN[i].beta) for i in (1, 3)]
+            assert all(torch.isfinite(v).all() for v in best.parameters())
         return np.array(solver.metrics_history["train_loss"]), {k: v.detach().cpu().double().numpy().copy() for k, v in net.named_parameters()}
 
     hist_f, par_f = run("require")

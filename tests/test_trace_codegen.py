@@ -62,7 +62,8 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
         perm = np.concatenate([np.arange(start[id(prm)], start[id(prm)] + prm.numel()) for prm in info["params"]])
         assert perm.size == at
         perms.append(perm)
-        flats.append(np.asarray(params[off:off + at], np.float64)[perm])
+        # fixed non-default activation scalars (actp = 2) follow the trainable entries; the oracle takes them like trainable ones
+        flats.append(np.concatenate([np.asarray(params[off:off + at], np.float64)[perm], np.asarray(info["frozen"], np.float64)]))
         off += at
     # a ("L", a, b, ..) symbol is the Laplacian stream = sum of the pure second derivatives (a,a), (b,b), ..
     parts = lambda mi: [(c, c) for c in mi[1:]] if (mi and mi[0] == "L") else [mi]
@@ -105,9 +106,9 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
             gb = {(): np.zeros((n, dims[-1]))}
         grads[site_net[k]] = grads[site_net[k]] + J.mlp_jets_vjp(flats[site_net[k]], dims, act, [column(c) for c in deps], gb,
                                                                skip=skip, actp=actp)
-    for j, perm in enumerate(perms):                    # back to torch parameter order
+    for j, perm in enumerate(perms):                    # back to torch parameter order (frozen scalars: no gradient entry)
         g = np.zeros(perm.size)
-        g[perm] = grads[j]
+        g[perm] = grads[j][:perm.size]
         grads[j] = g
     return prog, funcs.T, resid.T, loss, np.concatenate(grads)
 
@@ -140,6 +141,7 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "aptx_burgers": [(1, 1, 0)], "resnet_laplace": [(1, 5, 1)], "resnet_ode": [(1, 1, 0)],
                "swish_tr_laplace": [(1, 5, 1)], "aptx_tr_laplace": [(1, 5, 1)], "aptx_tr_wide": [(1, 5, 1)],
                "swish_tr_system": [(1, 1, 0), (1, 0, 0)], "aptx_tr_resnet": [(1, 1, 0)],
+               "swish_fixed_laplace": [(1, 5, 1)], "aptx_fixed_laplace": [(1, 5, 1)],
                "shape_50x2": [(1, 5, 1)], "shape_20x3": [(1, 5, 1)], "shape_40x2_sigmoid": [(1, 5, 1)], "shape_10x1": [(1, 5, 1)],
                # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along
                "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)]}

@@ -29,7 +29,8 @@ class System:
         from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx, Resnet
         from functools import partial
         actv = {"tanh": torch.nn.Tanh, "sin": SinActv, "sigmoid": torch.nn.Sigmoid, "swish": Swish, "aptx": APTx,
-                "swish-tr": partial(Swish, trainable=True), "aptx-tr": partial(APTx, trainable=True)}
+                "swish-tr": partial(Swish, trainable=True), "aptx-tr": partial(APTx, trainable=True),
+                "swish-fixed": partial(Swish, beta=1.7), "aptx-fixed": partial(APTx, alpha=0.8, beta=1.3, gamma=0.6)}
         nets = [(Resnet if a.startswith("resnet-") else FCNN)(i, o, hidden_units=h, actv=actv[a.replace("resnet-", "")])
                 for i, o, h, a in self.net_specs]
         # trainable activation parameters: move them off their defaults (every layer its own values), deterministically
@@ -171,6 +172,12 @@ def build(name):
         conds = lambda: [C.IBVP1D(-1.0, 1.0, 0.0, u0, x_min_val=zero, x_max_val=zero)]
         return System(name, 2, [(2, 1, (32, 32), "aptx")], [(-1.0, 1.0), (0.0, 1.0)], pde, conds,
                       lambda D: [_R().ibvp1d_dd(-1.0, 1.0, 0.0, u0, zero, zero)])
+    if name in ("swish_fixed_laplace", "aptx_fixed_laplace"):      # fixed non-default activation parameters
+        f0 = lambda y: torch.sin(PI * y)
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + u * D(u, x) - torch.exp(-x * y)])
+        conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
+        return System(name, 2, [(2, 1, (32, 32), name.split("_")[0] + "-fixed")], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, zero)])
     if name in ("swish_tr_laplace", "aptx_tr_laplace", "aptx_tr_wide"):   # trainable activation parameters (networks.py:155-209)
         f0 = lambda y: torch.sin(PI * y)
         pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + u * D(u, x) - torch.exp(-x * y)])
@@ -232,7 +239,8 @@ def build(name):
 NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide", "stokes_like", "kdv", "ode3", "poisson3d",
          "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
          "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode", "swish_tr_laplace", "aptx_tr_laplace",
-         "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1"]
+         "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1",
+         "swish_fixed_laplace", "aptx_fixed_laplace"]
 
 
 def spherical_solver_problem():
