@@ -236,7 +236,7 @@ def test_solver_trains_activation_parameters_like_torch():
         assert solver.fused_active == (fused == "require")
         if fused == "require":      # best-network snapshot: a flat device copy in the kernels' parameter order, unpacked per module
             best = solver.best_nets[0]
-            assert all(0.8 < float(best.NN[i].beta) < 1.8 for i in (1, 3)), [float(best.NN[i].beta) for i in (1, 3)]
+            assert all(0.8 < best.NN[i].beta.item() < 1.8 for i in (1, 3)), [best.NN[i].beta.item() for i in (1, 3)]
             assert all(torch.isfinite(v).all() for v in best.parameters())
         return np.array(solver.metrics_history["train_loss"]), {k: v.detach().cpu().double().numpy().copy() for k, v in net.named_parameters()}
 
