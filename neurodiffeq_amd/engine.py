@@ -69,9 +69,17 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             except (TypeError, ValueError, RuntimeError):
                 raise TraceUnsupported(f"an equation returned {type(r).__name__}, not a traced (N, 1) column or a scalar")
         res = [column(r) for r in res]
-        if not all(isinstance(f, Sym) for f in funcs):
-            raise TraceUnsupported("a condition returned something that is not a traced (N, 1) column (a multi-column "
-                                   "function, e.g. EnsembleCondition as a solver function, runs on the composite path)")
+        # a function is an (N, 1) column or -- EnsembleCondition on one multi-output network (conditions.py:157-202), used
+        # as ONE solver function whose columns the equations pick apart -- an (N, k) matrix: k rows of the function buffer
+        from .symbolic import SymMat
+        func_columns = []
+        for f in funcs:
+            if isinstance(f, Sym):
+                func_columns.append([f])
+            elif isinstance(f, SymMat) and all(isinstance(c, Sym) for c in f.cols):
+                func_columns.append(list(f.cols))
+            else:
+                raise TraceUnsupported(f"a condition returned {type(f).__name__}, not traced (N, k) values")
         # a custom loss: callable(residual (N, n_eq), funcs, coords) -> scalar (solvers.py:216-226; the solver passes
         # loss_fn + additional_loss as ONE callable) traced to the per-point term whose batch mean it is
         loss_term = None
@@ -181,10 +189,12 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         for st in sts:
             st.first, st.mask2, st.lap = first, mask2, lap
 
-    program = codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs] + [m.i for m in metric_terms],
+    program = codegen.PointwiseProgram(g, [r.i for r in res],
+                                       [c.i for cols in func_columns for c in cols] + [m.i for m in metric_terms],
                                        len(nets), widen=widen, allow_lap=allow_lap, unify=unify, loss=loss,
                                        loss_term=loss_term)
     program.n_metrics = len(metric_terms)        # the last n_metrics "functions" are per-point metric terms
+    program.func_widths = [len(cols) for cols in func_columns]    # columns of every solver function, in order
     program.loss_probe = loss_probe              # custom losses: "does the callable still trace to the compiled term?"
     program.unique_nets = nets                   # distinct modules, in first-appearance order: one parameter set each
     return program, descs
@@ -451,8 +461,17 @@ class FusedSystem:
             return [c[:n].view(-1, 1) for c in b["coords_rows"]]
         return [b["coords_own"][i, :n].view(-1, 1) for i in range(self.n_coords)]
 
+    def split_functions(self, rows):
+        """[n_user_funcs][n] rows of the function buffer -> one (n, k) tensor per solver function (k = 1 except for a
+        multi-column function such as EnsembleCondition on a multi-output network)."""
+        out, r = [], 0
+        for k in self.program.func_widths:
+            out.append(rows[r].reshape(-1, 1) if k == 1 else rows[r:r + k].t())
+            r += k
+        return out
+
     def func_columns(self, b, n):
-        return [b["funcs"][i, :n].view(-1, 1) for i in range(self.n_user_funcs)]
+        return self.split_functions(b["funcs"][:self.n_user_funcs, :n])
 
     def metric_sums(self, b, n):
         """Sum over the (local) points of every traced metric's per-point term: device tensor [n_metrics]."""

@@ -803,8 +803,7 @@ class BaseSolution(ABC):
                 pass
         if self._eval_sys is None:
             return None
-        vals = self._eval_sys.evaluate(coords)
-        return [vals[i].clone().reshape(-1, 1) for i in range(len(self.nets))]
+        return [v.clone() for v in self._eval_sys.split_functions(self._eval_sys.evaluate(coords))]
 
 
 class GenericSolution(BaseSolution):

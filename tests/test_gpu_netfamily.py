@@ -139,7 +139,7 @@ def _grad_in_torch_order(nets, flats):
 @pytest.mark.parametrize("mode", ["1k", "3k"])
 @pytest.mark.parametrize("name", ["swish_tr_laplace", "aptx_tr_laplace", "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet",
                                   "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1", "swish_fixed_laplace",
-                                  "aptx_fixed_laplace"])
+                                  "aptx_fixed_laplace", "ensemble_lv"])
 def test_closure_of_networks_outside_the_template_matches_autograd_oracle(name, mode):
     """funcs / residuals / loss / gradient of one closure, the gradient compared parameter by parameter in torch order
     (activation scalars interleaved with the linear layers there, behind them in the kernels' flat vector)."""
@@ -247,3 +247,37 @@ def test_solver_trains_activation_parameters_like_torch():
     assert len(betas) == 2 and all(abs(float(par_f[k]) - 1.25) > 1e-3 for k in betas)
     for k in par_f:
         assert np.linalg.norm(par_f[k] - par_c[k]) <= 2e-4 * max(np.linalg.norm(par_c[k]), 1e-2), k
+
+
+def test_ensemble_condition_as_one_solver_function_trains_on_the_fused_path():
+    """One two-output network under EnsembleCondition (conditions.py:157-202) handed to Solver1D as a SINGLE function
+    whose columns the ODE system picks apart: fused path vs the composite path (torch autograd), and the solution object
+    returns the (N, 2) function through the forward kernels."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import EnsembleCondition, IVP
+    from neurodiffeq_amd.generators import Generator1D
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.solvers import Solver1D
+
+    def lv(uv, t):
+        u, v = uv[:, 0:1], uv[:, 1:2]
+        return [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)]
+
+    def run(fused):
+        torch.manual_seed(0)
+        solver = Solver1D(lv, [EnsembleCondition(IVP(0.0, 1.5), IVP(0.0, 1.0))], t_min=0.1, t_max=4.0,
+                          nets=[FCNN(1, 2, hidden_units=(32, 32))], train_generator=Generator1D(200, 0.1, 4.0, "equally-spaced-noisy"),
+                          valid_generator=Generator1D(16, 0.1, 4.0), n_batches_valid=0)
+        solver.fused = fused
+        torch.manual_seed(1)
+        solver.fit(max_epochs=20)
+        assert solver.fused_active == (fused == "require")
+        ts = torch.linspace(0.1, 4.0, 50, device="cuda").reshape(-1, 1)
+        uv = solver.get_solution(best=False)(ts, to_numpy=False, no_reshape=True)
+        return np.array(solver.metrics_history["train_loss"]), uv.detach().cpu().numpy()
+
+    hist_f, uv_f = run("require")
+    hist_c, uv_c = run("off")
+    assert uv_f.shape == (50, 2) and uv_c.shape == (50, 2)
+    assert np.allclose(hist_f, hist_c, rtol=2e-4), (hist_f, hist_c)
+    assert np.linalg.norm(uv_f - uv_c) <= 2e-4 * np.linalg.norm(uv_c)

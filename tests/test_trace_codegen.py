@@ -38,7 +38,8 @@ def trace(nets, conds, pde, n_coords, lap=True, cfv=None, loss="l2", metrics=())
     for k, n in enumerate(nets):
         g.net_deps.setdefault(k, tuple(range(describe(n)["d"])))
         g.net_nout.setdefault(k, describe(n)["n_out"])
-    return codegen.PointwiseProgram(g, [r.i for r in res], [f.i for f in funcs] + mterms, len(nets),
+    cols = [c for f in funcs for c in (f.cols if isinstance(f, SymMat) else [f])]     # a multi-column function: one row per column
+    return codegen.PointwiseProgram(g, [r.i for r in res], [c.i for c in cols] + mterms, len(nets),
                                     allow_lap=(lambda k, coords: True) if lap else None, loss=loss, loss_term=term)
 
 
@@ -141,7 +142,7 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "aptx_burgers": [(1, 1, 0)], "resnet_laplace": [(1, 5, 1)], "resnet_ode": [(1, 1, 0)],
                "swish_tr_laplace": [(1, 5, 1)], "aptx_tr_laplace": [(1, 5, 1)], "aptx_tr_wide": [(1, 5, 1)],
                "swish_tr_system": [(1, 1, 0), (1, 0, 0)], "aptx_tr_resnet": [(1, 1, 0)],
-               "swish_fixed_laplace": [(1, 5, 1)], "aptx_fixed_laplace": [(1, 5, 1)],
+               "swish_fixed_laplace": [(1, 5, 1)], "aptx_fixed_laplace": [(1, 5, 1)], "ensemble_lv": [(1, 0, 0)],
                "shape_50x2": [(1, 5, 1)], "shape_20x3": [(1, 5, 1)], "shape_40x2_sigmoid": [(1, 5, 1)], "shape_10x1": [(1, 5, 1)],
                # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along
                "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)]}

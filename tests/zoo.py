@@ -172,6 +172,18 @@ def build(name):
         conds = lambda: [C.IBVP1D(-1.0, 1.0, 0.0, u0, x_min_val=zero, x_max_val=zero)]
         return System(name, 2, [(2, 1, (32, 32), "aptx")], [(-1.0, 1.0), (0.0, 1.0)], pde, conds,
                       lambda D: [_R().ibvp1d_dd(-1.0, 1.0, 0.0, u0, zero, zero)])
+    if name == "ensemble_lv":         # ONE two-output network, EnsembleCondition (conditions.py:157-202) as ONE solver function
+        def pde(D):
+            def f(uv, t):             # the equations pick the columns apart themselves
+                u, v = uv[:, 0:1], uv[:, 1:2]
+                return [D(u, t) - (u - u * v), D(v, t) - (u * v - v)]
+            return f
+        conds = lambda: [C.EnsembleCondition(C.IVP(0.0, 1.5), C.IVP(0.0, 1.0))]
+
+        def e(net, t):
+            out, decay = net(t), 1 - torch.exp(-t)
+            return _cat(1.5 + decay * out[:, 0:1], 1.0 + decay * out[:, 1:2])
+        return System(name, 1, [(1, 2, (32, 32), "tanh")], [(0.0, 2.0)], pde, conds, lambda D: [e])
     if name in ("swish_fixed_laplace", "aptx_fixed_laplace"):      # fixed non-default activation parameters
         f0 = lambda y: torch.sin(PI * y)
         pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + u * D(u, x) - torch.exp(-x * y)])
@@ -240,7 +252,7 @@ NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "he
          "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
          "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode", "swish_tr_laplace", "aptx_tr_laplace",
          "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1",
-         "swish_fixed_laplace", "aptx_fixed_laplace"]
+         "swish_fixed_laplace", "aptx_fixed_laplace", "ensemble_lv"]
 
 
 def spherical_solver_problem():
