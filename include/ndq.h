@@ -31,8 +31,8 @@ typedef struct ndq_mlp_desc {
   int d;       /* number of input coordinates (1..3) */
   int first;   /* 1: first-order streams present */
   int mask2;   /* second-order pair mask */
-  int hidden;  /* width of every hidden layer, 1..64 (kernels lay it out padded to a multiple of 16; the flat parameter
-                  vector holds the real width) */
+  int hidden;  /* width of the hidden layers, 1..64 -- the widest one if they differ (kernels lay every layer out padded
+                  to the next multiple of 16 of this; the flat parameter vector holds the real widths) */
   int layers;  /* number of hidden layers */
   int act;     /* NDQ_ACT_* */
   int n_out;   /* output units */
@@ -48,6 +48,8 @@ typedef struct ndq_mlp_desc {
                   gamma must be non-zero.
                   2: the same scalars as fixed non-default values (Swish(beta=2.0)): the layers x {1, 3} floats FOLLOW
                   the n_params trainable entries in the buffer `params` points to and have no gradient entries */
+  int widths;  /* 0: every hidden layer is `hidden` wide.  Otherwise the widths of layers 1..layers, 8 bits each, layer 1
+                  in the low byte (FCNN(hidden_units=(64, 32, 16)) -> 0x102040); `hidden` is their maximum */
 } ndq_mlp_desc;
 
 /* One compiled kernel pair (forward streams / parameter-gradient adjoint) for ONE descriptor.  libndq.so carries a

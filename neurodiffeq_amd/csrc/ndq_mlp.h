@@ -389,7 +389,7 @@ template <> struct Act<ACT_APTX> {
 
 // ------------------------------------------------------------------------------------------------ config
 template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0, int SKIP_ = 0,
-          unsigned M3_ = 0, int ACTP_ = 0, int HR_ = 0>
+          unsigned M3_ = 0, int ACTP_ = 0, int HR_ = 0, unsigned HRP_ = 0>
 struct Cfg {
   using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
   static_assert(M3_ == 0 || ACT_ == ACT_TANH || ACT_ == ACT_SIN || ACT_ == ACT_SIGMOID,
@@ -398,9 +398,16 @@ struct Cfg {
   // HR: the network's real hidden width when it is no multiple of 16 (HR_ = 0: H).  Registers, fragments and LDS images
   // are laid out for the padded width H; the padding units have zero weights in LDS (whatever their activation value,
   // nothing downstream sees it) and no slot in the flat parameter / gradient vectors, which are indexed with HR.
+  // HRP: hidden layers of DIFFERENT widths, 8 bits per layer (layer 1 in the low byte); 0: every layer HR wide.  All
+  // layers are laid out for the widest one.
   static constexpr int HR = HR_ > 0 ? HR_ : H;
-  static_assert(HR <= H && HR > H - 16, "real width and padded width disagree");
-  static constexpr bool RAGGED = HR != H;
+  static constexpr unsigned HRP = HRP_;
+  static constexpr int hr(int l) { return HRP_ != 0 ? (int)((HRP_ >> (8 * (l - 1))) & 255u) : HR; }    // l in 1..L
+  static constexpr int hr_max() { int m = 0; for (int l = 1; l <= L_; ++l) m = hr(l) > m ? hr(l) : m; return m; }
+  static constexpr int hr_min() { int m = 1 << 20; for (int l = 1; l <= L_; ++l) m = hr(l) < m ? hr(l) : m; return m; }
+  static_assert(hr_max() <= H && hr_max() > H - 16 && hr_min() >= 1, "real widths and padded width disagree");
+  static_assert(HRP_ == 0 || HR == hr_max(), "packed widths: HR is the widest layer");
+  static constexpr bool RAGGED = hr_min() != H;
   static constexpr int NOUT = NOUT_;               // output units; > 1: the output layer is an MFMA layer too
   static constexpr int NBO = (NOUT_ + 15) / 16;    // 16-row blocks of the (zero-padded) output layer
   static constexpr int HO = 16 * NBO;
@@ -411,11 +418,15 @@ struct Cfg {
       (NDQ_F64 || NB_ * NB_ * (L_ - 1) + NB_ * SS::NS * L_ + (NOUT_ > 1 ? NB_ * NBO : 0) > 40) ? 256 : NDQ_BWD_THREADS;
   static constexpr int FWD_THREADS = (NB_ >= 4) ? 256 : NDQ_FWD_THREADS;
   // flat parameter offsets, torch order: W1 (H,D) b1 (H) | W_l (H,H) b_l (H), l = 2..L | Wout (1,H) bout (1)
-  static constexpr int offW1 = 0, offb1 = HR * D;
-  static constexpr int offW(int l) { return HR * D + HR + (l - 2) * (HR * HR + HR); }  // l in 2..L
-  static constexpr int offb(int l) { return offW(l) + HR * HR; }
-  static constexpr int offWout = HR * D + HR + (L - 1) * (HR * HR + HR);
-  static constexpr int offbout = offWout + NOUT * HR;
+  static constexpr int offW1 = 0, offb1 = hr(1) * D;
+  static constexpr int offW(int l) {       // l in 2..L + 1 (L + 1: the output matrix)
+    int o = hr(1) * D + hr(1);
+    for (int k = 2; k < l; ++k) o += hr(k) * hr(k - 1) + hr(k);
+    return o;
+  }
+  static constexpr int offb(int l) { return offW(l) + hr(l) * hr(l - 1); }
+  static constexpr int offWout = offW(L + 1);
+  static constexpr int offbout = offWout + NOUT * hr(L);
   // SKIP: a trainable bias-free linear map from the inputs straight to the output, out += S x (networks.Resnet,
   // networks.py:73-106); its weights S (n_out x d) follow the output bias in the flat parameter vector
   static constexpr int SKIP = SKIP_;
@@ -514,20 +525,21 @@ __device__ __forceinline__ real actp_mul(real v, real f) {
 
 template <class C, bool BWD>
 __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict__ prm) {
-  constexpr int H = C::H, D = C::D, NB = C::NB, HR = C::HR;
+  constexpr int H = C::H, D = C::D, NB = C::NB;
+  constexpr int HL = C::hr(C::L);          // width of the last hidden layer (input of the output layer)
   const int tid = threadIdx.x, nt = blockDim.x;
   const real f1 = act_pre<C>(prm, 1), fo = act_post<C>(prm, C::L);
-  // padding units (RAGGED: j >= HR) read as zero
-  auto unit = [&](int j, int idx, real f) {
-    if constexpr (C::RAGGED) return j < HR ? actp_mul<C>(prm[idx], f) : (real)0.f;
+  // padding units (RAGGED: j >= the layer's real width hw) read as zero
+  auto unit = [&](int j, int hw, int idx, real f) {
+    if constexpr (C::RAGGED) return j < hw ? actp_mul<C>(prm[idx], f) : (real)0.f;
     else return actp_mul<C>(prm[idx], f);
   };
-  auto real_unit = [](int j) { return !C::RAGGED || j < HR; };
+  auto real_unit = [](int j, int hw) { return !C::RAGGED || j < hw; };
   for (int i = tid; i < D * H; i += nt) {  // W1T[a][j] = W1[j][a]
     const int a = i / H, j = i - a * H;
-    lds[C::ldsW1T + i] = unit(j, C::offW1 + j * D + a, f1);
+    lds[C::ldsW1T + i] = unit(j, C::hr(1), C::offW1 + j * D + a, f1);
   }
-  for (int i = tid; i < H; i += nt) lds[C::ldsb1 + i] = unit(i, C::offb1 + i, f1);
+  for (int i = tid; i < H; i += nt) lds[C::ldsb1 + i] = unit(i, C::hr(1), C::offb1 + i, f1);
   if constexpr (C::ALPHA) {
     if (tid < C::L) lds[C::ldsAlpha(BWD) + tid] = prm[C::offA + 3 * tid];
   }
@@ -538,7 +550,7 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
     }
   }
   if constexpr (C::NOUT == 1) {
-    for (int i = tid; i < H; i += nt) lds[C::ldsWout(BWD) + i] = unit(i, C::offWout + i, fo);
+    for (int i = tid; i < H; i += nt) lds[C::ldsWout(BWD) + i] = unit(i, HL, C::offWout + i, fo);
     if (tid == 0) lds[C::ldsbout(BWD)] = prm[C::offbout];
     if constexpr (C::SKIP != 0) {
       if (tid < D) lds[C::ldsSkip(BWD) + tid] = prm[C::offS + tid];
@@ -553,7 +565,7 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
     for (int i = tid; i < C::HO * H; i += nt) {
       const int j = i / H, k = i - j * H;
       real w;
-      if constexpr (C::RAGGED) w = (j < C::NOUT && k < HR) ? actp_mul<C>(Wo[j * HR + k], fo) : 0.f;
+      if constexpr (C::RAGGED) w = (j < C::NOUT && k < HL) ? actp_mul<C>(Wo[j * HL + k], fo) : 0.f;
       else w = j < C::NOUT ? actp_mul<C>(Wo[i], fo) : 0.f;
       const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
       const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
@@ -578,13 +590,13 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
         const int ob = blk / NB, kb = blk - ob * NB;
         const int o = 16 * ob + mrow(lane & 15);
         const int k = 16 * kb + 4 * (lane >> 4) + t;
-        lds[C::ldsWout(BWD) + i] = (o < C::NOUT && real_unit(k)) ? actp_mul<C>(Wo[o * HR + k], fo) : 0.f;
+        lds[C::ldsWout(BWD) + i] = (o < C::NOUT && real_unit(k, HL)) ? actp_mul<C>(Wo[o * HL + k], fo) : 0.f;
       }
       if (BWD) {  // transposed A operand of block (kb, ob): blk = kb*NBO + ob:  A[i'][q'] = Wo[16 ob + 4 q' + t][16 kb + i']
         const int kb = blk / NBO, ob = blk - kb * NBO;
         const int o = 16 * ob + 4 * (lane >> 4) + t;
         const int k = 16 * kb + mrow(lane & 15);
-        lds[C::ldsWoutT() + i] = (o < C::NOUT && real_unit(k)) ? actp_mul<C>(Wo[o * HR + k], fo) : 0.f;
+        lds[C::ldsWoutT() + i] = (o < C::NOUT && real_unit(k, HL)) ? actp_mul<C>(Wo[o * HL + k], fo) : 0.f;
       }
     }
     for (int i = tid; i < C::HO; i += nt) lds[C::ldsbout(BWD) + i] = i < C::NOUT ? prm[C::offbout + i] : 0.f;
@@ -602,7 +614,7 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
       for (int i = tid; i < H * H; i += nt) {   // one coalesced pass over W[j][k] (out j, in k): split once, scatter twice
         const int j = i / H, k = i - j * H;
         real w;
-        if constexpr (C::RAGGED) w = (j < HR && k < HR) ? actp_mul<C>(W[j * HR + k], fw) : 0.f;
+        if constexpr (C::RAGGED) w = (j < C::hr(l) && k < C::hr(l - 1)) ? actp_mul<C>(W[j * C::hr(l - 1) + k], fw) : 0.f;
         else w = actp_mul<C>(W[i], fw);
         const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
         const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
@@ -617,7 +629,7 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
           wt[base] = w0; wt[base + 512] = w1; wt[base + 1024] = w2;
         }
       }
-      for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = unit(i, C::offb(l) + i, fb);
+      for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = unit(i, C::hr(l), C::offb(l) + i, fb);
     }
   } else
 #pragma unroll
@@ -629,14 +641,14 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
       const int b0 = blk / NB, b1 = blk - b0 * NB;
       // forward A operand of block (ib=b0, kb=b1), step t:  A[i'][k=q'] = W[16 ib + i'][16 kb + 4 q' + t]
       auto weight = [&](int j, int k) {
-        if constexpr (C::RAGGED) return (j < HR && k < HR) ? actp_mul<C>(W[j * HR + k], fw) : (real)0.f;
+        if constexpr (C::RAGGED) return (j < C::hr(l) && k < C::hr(l - 1)) ? actp_mul<C>(W[j * C::hr(l - 1) + k], fw) : (real)0.f;
         else return actp_mul<C>(W[j * H + k], fw);
       };
       lds[C::ldsWf(l, BWD) + i] = weight(16 * b0 + mrow(lane & 15), 16 * b1 + 4 * (lane >> 4) + t);
       if (BWD)  // transposed A operand of block (kb=b0, ib=b1): A[i'][k=q'] = W[16 ib + 4 q' + t][16 kb + i']
         lds[C::ldsWt(l) + i] = weight(16 * b1 + 4 * (lane >> 4) + t, 16 * b0 + mrow(lane & 15));
     }
-    for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = unit(i, C::offb(l) + i, fb);
+    for (int i = tid; i < H; i += nt) lds[C::ldsb(l, BWD) + i] = unit(i, C::hr(l), C::offb(l) + i, fb);
   }
 }
 
@@ -1824,13 +1836,19 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * b + 4 * q + r;
-          if (p == 0 && (!C::RAGGED || j < C::HR)) {
-            put(C::offb1 + j, acc.b1[b][r]);
-            if constexpr (C::NOUT == 1) put(C::offWout + j, acc.wout[b][r]);
+          if (p == 0) {
+            if (!C::RAGGED || j < C::hr(1)) {
+              put(C::offb1 + j, acc.b1[b][r]);
 #pragma unroll
-            for (int d = 0; d < C::D; ++d) put(C::offW1 + j * C::D + d, acc.w1[d][b][r]);
+              for (int d = 0; d < C::D; ++d) put(C::offW1 + j * C::D + d, acc.w1[d][b][r]);
+            }
+            if constexpr (C::NOUT == 1) {
+              if (!C::RAGGED || j < C::hr(C::L)) put(C::offWout + j, acc.wout[b][r]);
+            }
 #pragma unroll
-            for (int l = 0; l < C::L - 1; ++l) put(C::offb(l + 2) + j, acc.b[l][b][r]);
+            for (int l = 0; l < C::L - 1; ++l) {
+              if (!C::RAGGED || j < C::hr(l + 2)) put(C::offb(l + 2) + j, acc.b[l][b][r]);
+            }
           }
         }
 #pragma unroll
@@ -1842,7 +1860,8 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int j = 16 * jb + 4 * q + r, k = 16 * kb + p;
-              if (!C::RAGGED || (j < C::HR && k < C::HR)) put(C::offW(l + 2) + j * C::HR + k, acc.w[l][jb][kb][r]);
+              if (!C::RAGGED || (j < C::hr(l + 2) && k < C::hr(l + 1)))
+                put(C::offW(l + 2) + j * C::hr(l + 1) + k, acc.w[l][jb][kb][r]);
             }
       if constexpr (C::NOUT == 1) {
         if (lane == 0) {
@@ -1868,7 +1887,7 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
               }
 #pragma unroll
               for (int kb = 0; kb < C::NB; ++kb) {
-                if (!C::RAGGED || 16 * kb + p < C::HR) put(C::offWout + u * C::HR + 16 * kb + p, acc.wo[ob][kb][r]);
+                if (!C::RAGGED || 16 * kb + p < C::hr(C::L)) put(C::offWout + u * C::hr(C::L) + 16 * kb + p, acc.wo[ob][kb][r]);
               }
             }
           }
@@ -1904,11 +1923,11 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
     auto segment = [&](int lo, int hi, real f) {
       for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) out[i] = total(i) * f;
     };
-    segment(C::offW1, C::offb1 + C::HR, act_pre<C>(prm, 1));
+    segment(C::offW1, C::offb1 + C::hr(1), act_pre<C>(prm, 1));
     sfor<C::L - 1>([&](auto k_) {
       constexpr int l = decltype(k_)::value + 2;
       segment(C::offW(l), C::offb(l), act_pre<C>(prm, l) * act_post<C>(prm, l - 1));
-      segment(C::offb(l), C::offb(l) + C::HR, act_pre<C>(prm, l));
+      segment(C::offb(l), C::offb(l) + C::hr(l), act_pre<C>(prm, l));
     });
     segment(C::offWout, C::offbout, act_post<C>(prm, C::L));
     segment(C::offbout, C::P, 1.f);           // output bias, skip weights, (trainable) activation parameters

@@ -173,11 +173,12 @@ def describe(net, dtype=torch.float32):
             act_frozen = [float(getattr(a, k)) for a in acts for k in names]
             if any(getattr(a, "beta") == 0 or getattr(a, "gamma", 1.0) == 0 for a in acts):
                 return None
-    hidden = linears[0].out_features
-    if any(l.in_features != hidden or l.out_features != hidden for l in linears[1:-1]):
-        return None          # one width for all hidden layers (any width: the kernels pad it to a multiple of 16)
-    if linears[-1].in_features != hidden:
+    # hidden widths: any (the kernels lay all layers out for the widest one, padded to a multiple of 16)
+    ws = [l.out_features for l in linears[:-1]]
+    if any(b.in_features != a for a, b in zip(ws, linears[1:])) or len(ws) > 4 or max(ws) > 255:
         return None
+    hidden = max(ws)
+    widths = 0 if len(set(ws)) == 1 else sum(w << (8 * i) for i, w in enumerate(ws))
     if any(p.dtype != dtype for l in linears for p in l.parameters()):
         return None
     if skip is not None and tuple(skip.weight.shape) != (linears[-1].out_features, linears[0].in_features):
@@ -186,7 +187,7 @@ def describe(net, dtype=torch.float32):
     params = [p for l in linears for p in (l.weight, l.bias)] + ([skip.weight] if skip is not None else []) + act_params
     return dict(d=linears[0].in_features, hidden=hidden, layers=len(acts), act=_ACT_IDS[next(iter(act_types))],
                 n_out=linears[-1].out_features, linears=linears, skip=int(skip is not None), params=params,
-                actp=1 if act_params else (2 if act_frozen else 0), frozen=act_frozen)
+                actp=1 if act_params else (2 if act_frozen else 0), frozen=act_frozen, widths=widths)
 
 
 class FlatParams:

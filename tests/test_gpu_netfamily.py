@@ -39,6 +39,11 @@ CASES = {
     "w10x1_sin": ((2, 10, 1), "sin", 0, 0),
     "w50_swish_tr": ((2, 50, 50, 1), "swish", 0, 1),
     # fixed non-default activation scalars (actp = 2): behind the trainable entries of the parameter buffer, no gradients
+    # hidden layers of different widths (ndq_mlp_desc.widths): all laid out for the widest one
+    "funnel_64_32_16": ((2, 64, 32, 16, 1), "tanh", 0, 0),
+    "funnel_50_30_3out_skip": ((2, 50, 30, 3), "tanh", 1, 0),
+    "expand_16_48_sin": ((1, 16, 48, 1), "sin", 0, 0),
+    "funnel_40_20_swish_tr": ((2, 40, 20, 1), "swish", 0, 1),
     "swish_fixed": ((2, 32, 32, 1), "swish", 0, 2),
     "aptx_fixed_3out": ((2, 32, 32, 3), "aptx", 0, 2),
 }
@@ -53,8 +58,9 @@ def rel_l2(a, b):
 def _desc(name):
     from neurodiffeq_amd import _lib
     dims, act, skip, actp = CASES[name]
-    d = dims[0]
-    return _lib.MlpDesc(d, 1, (1 << (d * (d + 1) // 2)) - 1, dims[1], len(dims) - 2, ACT_ID[act], dims[-1], 0, skip, 0, actp)
+    d, ws = dims[0], dims[1:-1]
+    widths = 0 if len(set(ws)) == 1 else sum(w << (8 * i) for i, w in enumerate(ws))
+    return _lib.MlpDesc(d, 1, (1 << (d * (d + 1) // 2)) - 1, max(ws), len(ws), ACT_ID[act], dims[-1], 0, skip, 0, actp, widths)
 
 
 def _flat(name, rng):
@@ -139,7 +145,7 @@ def _grad_in_torch_order(nets, flats):
 @pytest.mark.parametrize("mode", ["1k", "3k"])
 @pytest.mark.parametrize("name", ["swish_tr_laplace", "aptx_tr_laplace", "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet",
                                   "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1", "swish_fixed_laplace",
-                                  "aptx_fixed_laplace", "ensemble_lv"])
+                                  "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid"])
 def test_closure_of_networks_outside_the_template_matches_autograd_oracle(name, mode):
     """funcs / residuals / loss / gradient of one closure, the gradient compared parameter by parameter in torch order
     (activation scalars interleaved with the linear layers there, behind them in the kernels' flat vector)."""

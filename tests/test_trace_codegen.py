@@ -52,7 +52,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     dims_act, flats, perms, off = [], [], [], 0
     for net in nets:
         info = describe(net)
-        dims = (info["d"],) + (info["hidden"],) * info["layers"] + (info["n_out"],)
+        dims = (info["d"],) + tuple(l.out_features for l in info["linears"][:-1]) + (info["n_out"],)
         dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx")[info["act"]], bool(info["skip"]), bool(info["actp"])))
         # ``params`` is in torch parameter order; the kernels' (and the jet oracle's) flat vector lists the linear layers,
         # then the skip weights, then the activation parameters (networks.describe): perm maps one onto the other
@@ -143,6 +143,7 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "swish_tr_laplace": [(1, 5, 1)], "aptx_tr_laplace": [(1, 5, 1)], "aptx_tr_wide": [(1, 5, 1)],
                "swish_tr_system": [(1, 1, 0), (1, 0, 0)], "aptx_tr_resnet": [(1, 1, 0)],
                "swish_fixed_laplace": [(1, 5, 1)], "aptx_fixed_laplace": [(1, 5, 1)], "ensemble_lv": [(1, 0, 0)],
+               "shape_64_32": [(1, 5, 1)], "shape_24_40_12_sigmoid": [(1, 5, 1)],
                "shape_50x2": [(1, 5, 1)], "shape_20x3": [(1, 5, 1)], "shape_40x2_sigmoid": [(1, 5, 1)], "shape_10x1": [(1, 5, 1)],
                # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along
                "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)]}

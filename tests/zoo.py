@@ -144,12 +144,14 @@ def build(name):
         return System(name, 2, [(2, 1, (32, 32), "tanh")], [(0.0, 1.0), (-1.0, 1.0)], pde, conds, lambda D: [e])
     # ---- network shapes outside libndq.so's table: compiled on first use as extension modules (codegen.ensure_mlp_kernels)
     if name in ("shape_64x2", "shape_32x3", "shape_48x2", "shape_16x2_sin", "shape_32x1", "shape_50x2", "shape_20x3",
-                "shape_40x2_sigmoid", "shape_10x1"):
+                "shape_40x2_sigmoid", "shape_10x1", "shape_64_32", "shape_24_40_12_sigmoid"):
         # widths that are no multiple of 16 run padded (csrc/ndq_mlp.h: Cfg::HR); sigmoid: the padding units output 1/2
         hidden, act = {"shape_64x2": ((64, 64), "tanh"), "shape_32x3": ((32, 32, 32), "tanh"),
                        "shape_48x2": ((48, 48), "tanh"), "shape_16x2_sin": ((16, 16), "sin"),
                        "shape_32x1": ((32,), "tanh"), "shape_50x2": ((50, 50), "tanh"), "shape_20x3": ((20, 20, 20), "tanh"),
-                       "shape_40x2_sigmoid": ((40, 40), "sigmoid"), "shape_10x1": ((10,), "sin")}[name]
+                       "shape_40x2_sigmoid": ((40, 40), "sigmoid"), "shape_10x1": ((10,), "sin"),
+                       # hidden layers of different widths: laid out for the widest one (ndq_mlp_desc.widths)
+                       "shape_64_32": ((64, 32), "tanh"), "shape_24_40_12_sigmoid": ((24, 40, 12), "sigmoid")}[name]
         f0 = lambda y: torch.sin(PI * y)
         pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + u * D(u, x) - torch.exp(-x * y)])
         conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
@@ -252,7 +254,7 @@ NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "he
          "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
          "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode", "swish_tr_laplace", "aptx_tr_laplace",
          "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1",
-         "swish_fixed_laplace", "aptx_fixed_laplace", "ensemble_lv"]
+         "swish_fixed_laplace", "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid"]
 
 
 def spherical_solver_problem():
