@@ -50,6 +50,9 @@ typedef struct ndq_mlp_desc {
                   the n_params trainable entries in the buffer `params` points to and have no gradient entries */
   int widths;  /* 0: every hidden layer is `hidden` wide.  Otherwise the widths of layers 1..layers, 8 bits each, layer 1
                   in the low byte (FCNN(hidden_units=(64, 32, 16)) -> 0x102040); `hidden` is their maximum */
+  int mono;    /* != 0: a MonomialNN (networks.py:109-139) in front of the first linear layer: bit k <-> degree k + 1
+                  (ascending, 1..8).  The d coordinates become the d * n_degrees features x_a^deg, degree after degree,
+                  and the first weight matrix is (hidden x d * n_degrees); streams up to second order, hidden <= 48, no skip */
 } ndq_mlp_desc;
 
 /* One compiled kernel pair (forward streams / parameter-gradient adjoint) for ONE descriptor.  libndq.so carries a

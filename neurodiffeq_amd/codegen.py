@@ -416,7 +416,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf}, NR = {self.n_r};
   static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
@@ -524,7 +524,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
 static_assert(CFG::NS * CFG::NOUT == {width}, "stream layout of the traced program and of the kernel disagree");
 struct PW {{
   static constexpr int NEQ = {neq}, NF = {nf}, NC = {self.n_coords}, NR = {self.n_r};
@@ -815,6 +815,8 @@ def mlp_ext_allowed(desc):
         if (desc.widths >> 32) or any(w for w in ws[desc.layers:]) or min(ws[:desc.layers]) < 1 \
                 or max(ws[:desc.layers]) != desc.hidden:
             return False
+    if desc.mono and (not 0 < desc.mono < 256 or desc.mask3 or desc.skip or desc.hidden > 48):
+        return False          # monomial features: degrees 1..8, up to second order, H <= 48, no skip connection
     return (1 <= desc.d <= 3 and 1 <= desc.hidden <= 64 and 1 <= desc.layers <= 4
             and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
@@ -833,7 +835,7 @@ def mlp_ext_source(desc, f64=False):
     return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
 {"#define NDQ_F64 1" if f64 else ""}
 #include "{header}"
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
 extern "C" const {record}* ndq_ext_kernels(void) {{
   static const {record} k = ndq::make_kernels<CFG>();
   return &k;
@@ -867,7 +869,7 @@ def ensure_mlp_kernels(desc, f64=False):
     register = L.ndq64_mlp_register if f64 else L.ndq_mlp_register
     if supported(ctypes.byref(desc)):
         return True
-    if not mlp_ext_allowed(desc) or (f64 and (desc.lap or desc.skip or desc.actp or desc.widths or desc.hidden > 32)):
+    if not mlp_ext_allowed(desc) or (f64 and (desc.lap or desc.skip or desc.actp or desc.widths or desc.mono or desc.hidden > 32)):
         return False
     key = desc.key() + (("f64",) if f64 else ())
     if key in _MLP_EXT:

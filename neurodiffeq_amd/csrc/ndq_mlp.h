@@ -389,12 +389,30 @@ template <> struct Act<ACT_APTX> {
 
 // ------------------------------------------------------------------------------------------------ config
 template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0, int SKIP_ = 0,
-          unsigned M3_ = 0, int ACTP_ = 0, int HR_ = 0, unsigned HRP_ = 0>
+          unsigned M3_ = 0, int ACTP_ = 0, int HR_ = 0, unsigned HRP_ = 0, unsigned MONO_ = 0>
 struct Cfg {
   using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
   static_assert(M3_ == 0 || ACT_ == ACT_TANH || ACT_ == ACT_SIN || ACT_ == ACT_SIGMOID,
                 "third-order streams: tanh / sin / sigmoid networks");
   static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
+  // MONO: a networks.MonomialNN (networks.py:109-139) in front of the first linear layer -- the D coordinates are
+  // expanded to the features x_a^deg, degree after degree (bit k of MONO <-> degree k + 1, ascending), so the first
+  // layer takes NIN = D * NDEG inputs and its derivative streams are no longer constant columns of W1:
+  //   z = b1 + sum_f W1[:, f] x_a^deg,  z_a = sum_deg W1[:, (deg, a)] deg x_a^(deg-1),  z_aa = ... deg (deg-1) x_a^(deg-2),
+  // mixed second derivatives stay zero.
+  static constexpr unsigned MONO = MONO_;
+  static constexpr int mono_count() { int c = 0; for (int k = 0; k < 8; ++k) c += (MONO_ >> k) & 1u; return c; }
+  static constexpr int NDEG = mono_count();
+  static constexpr int NIN = MONO_ != 0 ? D_ * NDEG : D_;          // inputs of the first linear layer
+  static constexpr int mono_deg(int i) {                           // i-th degree, ascending
+    int c = 0;
+    for (int k = 0; k < 8; ++k)
+      if ((MONO_ >> k) & 1u) { if (c == i) return k + 1; ++c; }
+    return 0;
+  }
+  static constexpr int MAXDEG = MONO_ != 0 ? mono_deg(NDEG - 1) : 1;
+  static_assert(MONO_ < 256u && (MONO_ == 0 || (M3_ == 0 && SKIP_ == 0 && NB_ <= 3)),
+                "monomial features: degrees 1..8, up to second-order streams, no skip connection, H <= 48");
   // HR: the network's real hidden width when it is no multiple of 16 (HR_ = 0: H).  Registers, fragments and LDS images
   // are laid out for the padded width H; the padding units have zero weights in LDS (whatever their activation value,
   // nothing downstream sees it) and no slot in the flat parameter / gradient vectors, which are indexed with HR.
@@ -418,9 +436,9 @@ struct Cfg {
       (NDQ_F64 || NB_ * NB_ * (L_ - 1) + NB_ * SS::NS * L_ + (NOUT_ > 1 ? NB_ * NBO : 0) > 40) ? 256 : NDQ_BWD_THREADS;
   static constexpr int FWD_THREADS = (NB_ >= 4) ? 256 : NDQ_FWD_THREADS;
   // flat parameter offsets, torch order: W1 (H,D) b1 (H) | W_l (H,H) b_l (H), l = 2..L | Wout (1,H) bout (1)
-  static constexpr int offW1 = 0, offb1 = hr(1) * D;
+  static constexpr int offW1 = 0, offb1 = hr(1) * NIN;
   static constexpr int offW(int l) {       // l in 2..L + 1 (L + 1: the output matrix)
-    int o = hr(1) * D + hr(1);
+    int o = hr(1) * NIN + hr(1);
     for (int k = 2; k < l; ++k) o += hr(k) * hr(k - 1) + hr(k);
     return o;
   }
@@ -442,8 +460,8 @@ struct Cfg {
   static constexpr int offA = offS + SKIP * NOUT * D;
   static constexpr int P = offA + (ACTP_ == 1 ? AK * L : 0);
   // LDS carve (floats): W1T [D][H] | b1 [H] | per hidden-hidden layer: Wf [H*H] (+ Wt [H*H] for bwd) | b_l | Wout | bout
-  static constexpr int ldsW1T = 0, ldsb1 = D * H;
-  static constexpr int ldsLayer0 = D * H + H;
+  static constexpr int ldsW1T = 0, ldsb1 = NIN * H;
+  static constexpr int ldsLayer0 = NIN * H + H;
   // hidden GEMM operand format: bf16x3 planes (3 x 2 B per weight) when the width is a multiple of 32, else f32
   static constexpr bool BF16 = (NDQ_BF16X3 != 0) && (NB_ % 2 == 0) && (NDQ_F64 == 0);
   static constexpr int NC = NB_ / 2;                       // K-chunks of 32 contraction slots (bf16 path)
@@ -535,9 +553,9 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
     else return actp_mul<C>(prm[idx], f);
   };
   auto real_unit = [](int j, int hw) { return !C::RAGGED || j < hw; };
-  for (int i = tid; i < D * H; i += nt) {  // W1T[a][j] = W1[j][a]
+  for (int i = tid; i < C::NIN * H; i += nt) {  // W1T[a][j] = W1[j][a]  (MONO: a runs over the NIN features)
     const int a = i / H, j = i - a * H;
-    lds[C::ldsW1T + i] = unit(j, C::hr(1), C::offW1 + j * D + a, f1);
+    lds[C::ldsW1T + i] = unit(j, C::hr(1), C::offW1 + j * C::NIN + a, f1);
   }
   for (int i = tid; i < H; i += nt) lds[C::ldsb1 + i] = unit(i, C::hr(1), C::offb1 + i, f1);
   if constexpr (C::ALPHA) {
@@ -1016,11 +1034,73 @@ __device__ __forceinline__ void zero_frag(real4 (&z)[C::NS][C::NB]) {
     for (int b = 0; b < C::NB; ++b) z[s][b] = real4{0.f, 0.f, 0.f, 0.f};
 }
 
+// MONO: pw[a][k] = x_a^k, k = 0..MAXDEG
+template <class C>
+__device__ __forceinline__ void mono_powers(const real (&x)[C::D], real (&pw)[C::D][C::MAXDEG + 1]) {
+#pragma unroll
+  for (int a = 0; a < C::D; ++a) {
+    pw[a][0] = 1.f;
+#pragma unroll
+    for (int k = 1; k <= C::MAXDEG; ++k) pw[a][k] = pw[a][k - 1] * x[a];
+  }
+}
+
 // first layer (VALU): z = W1 x + b1; derivative streams of z are columns of W1 (second order: zero)
 template <class C, bool BWD>
 __device__ __forceinline__ void first_layer(const real* lds, int q, const real (&x)[C::D], LayerState<C>& st) {
   using SS = typename C::SS;
   load_alpha<C, BWD>(lds, 1, st);
+  if constexpr (C::MONO != 0) {
+    real pw[C::D][C::MAXDEG + 1];
+    mono_powers<C>(x, pw);
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b) {
+      const int j0 = 16 * b + 4 * q;
+      real4 z = lds4(lds + C::ldsb1 + j0);
+      real4 z1[C::D], z2[C::D];
+#pragma unroll
+      for (int a = 0; a < C::D; ++a) z1[a] = z2[a] = real4{0.f, 0.f, 0.f, 0.f};
+      sfor<C::NDEG>([&](auto i_) {
+        constexpr int i = decltype(i_)::value, deg = C::mono_deg(i);
+#pragma unroll
+        for (int a = 0; a < C::D; ++a) {
+          const real4 w = lds4(lds + C::ldsW1T + (i * C::D + a) * C::H + j0);
+          const real p1 = (real)deg * pw[a][deg - 1];
+          const real p2 = deg >= 2 ? (real)(deg * (deg - 1)) * pw[a][deg >= 2 ? deg - 2 : 0] : (real)0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            z[r] = rfma(w[r], pw[a][deg], z[r]);
+            z1[a][r] = rfma(w[r], p1, z1[a][r]);
+            if constexpr (deg >= 2) z2[a][r] = rfma(w[r], p2, z2[a][r]);
+          }
+        }
+      });
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Act<C::ACT>::fwd(z[r], st.t[b][r], st.c[b][r], layer_alpha<C>(st));
+      if constexpr (SS::FIRST) {
+#pragma unroll
+        for (int a = 0; a < C::D; ++a) st.z[1 + a][b] = z1[a];
+        if constexpr (SS::LAP) {
+          real4 zl = real4{0.f, 0.f, 0.f, 0.f};
+          sfor<C::D>([&](auto a_) {
+            constexpr int a = decltype(a_)::value;
+            if constexpr (SS::in_lap(a)) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) zl[r] += z2[a][r];
+            }
+          });
+          st.z[SS::S2][b] = zl;
+        } else {
+          sfor<SS::N2>([&](auto k_) {
+            constexpr int s = SS::S2 + decltype(k_)::value;
+            if constexpr (SS::A(s) == SS::B(s)) st.z[s][b] = z2[SS::A(s)];
+            else st.z[s][b] = real4{0.f, 0.f, 0.f, 0.f};
+          });
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
     const int j0 = 16 * b + 4 * q;
@@ -1362,7 +1442,7 @@ constexpr int bwd_regions(int waves) {
 // per-wave gradient accumulators (registers), summed over all tiles the wave processes
 template <class C>
 struct GradAcc {
-  real w1[C::D][C::NB][4];          // dW1[j][a], j = 16b+4q+r   (needs point_sum)
+  real w1[C::NIN][C::NB][4];        // dW1[j][a], j = 16b+4q+r   (needs point_sum; MONO: a runs over the NIN features)
   real b1[C::NB][4];                // db1[j]                    (needs point_sum)
   real4 w[C::L > 1 ? C::L - 1 : 1][C::NB][C::NB];  // dW_l[16jb+4q+r][16kb+p], MFMA accumulators (already summed)
   real b[C::L > 1 ? C::L - 1 : 1][C::NB][4];      // db_l[j]     (needs point_sum)
@@ -1523,7 +1603,7 @@ __device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-      for (int d = 0; d < C::D; ++d) acc.w1[d][b][r] = 0.f;
+      for (int d = 0; d < C::NIN; ++d) acc.w1[d][b][r] = 0.f;
       acc.b1[b][r] = 0.f;
       acc.wout[b][r] = 0.f;
 #pragma unroll
@@ -1751,6 +1831,35 @@ __device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stag
         bias_accum<C>(acc, C::biasW1 + d * C::H, p, q, b, v);
       }
     }
+  } else if constexpr (C::MONO != 0) {
+    // dW1[j][(deg, a)] += zbar x_a^deg + zbar_a deg x_a^(deg-1) + zbar_aa deg (deg-1) x_a^(deg-2)
+    real pw[C::D][C::MAXDEG + 1];
+    mono_powers<C>(x, pw);
+#pragma unroll
+    for (int b = 0; b < C::NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const real z0 = g[0][b][r];
+        acc.b1[b][r] += z0;
+        sfor<C::D>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
+          real g1 = 0.f, g2 = 0.f;
+          if constexpr (SS::FIRST) {
+            g1 = g[1 + a][b][r];
+            if constexpr (SS::LAP) {
+              if constexpr (SS::in_lap(a)) g2 = g[SS::S2][b][r];
+            } else if constexpr (SS::pair_stream(a, a) >= 0) {
+              g2 = g[SS::pair_stream(a, a)][b][r];
+            }
+          }
+          sfor<C::NDEG>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, deg = C::mono_deg(i);
+            real v = rfma(z0, pw[a][deg], g1 * ((real)deg * pw[a][deg - 1]));
+            if constexpr (deg >= 2) v = rfma(g2, (real)(deg * (deg - 1)) * pw[a][deg - 2], v);
+            acc.w1[i * C::D + a][b][r] += v;
+          });
+        });
+      }
   } else {
 #pragma unroll
     for (int b = 0; b < C::NB; ++b)
@@ -1805,7 +1914,7 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
       acc.b1[b][r] = point_sum(acc.b1[b][r]);
       if constexpr (C::NOUT == 1) acc.wout[b][r] = point_sum(acc.wout[b][r]);
 #pragma unroll
-      for (int d = 0; d < C::D; ++d) acc.w1[d][b][r] = point_sum(acc.w1[d][b][r]);
+      for (int d = 0; d < C::NIN; ++d) acc.w1[d][b][r] = point_sum(acc.w1[d][b][r]);
 #pragma unroll
       for (int l = 0; l < C::L - 1; ++l) acc.b[l][b][r] = point_sum(acc.b[l][b][r]);
     }
@@ -1840,7 +1949,7 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
             if (!C::RAGGED || j < C::hr(1)) {
               put(C::offb1 + j, acc.b1[b][r]);
 #pragma unroll
-              for (int d = 0; d < C::D; ++d) put(C::offW1 + j * C::D + d, acc.w1[d][b][r]);
+              for (int d = 0; d < C::NIN; ++d) put(C::offW1 + j * C::NIN + d, acc.w1[d][b][r]);
             }
             if constexpr (C::NOUT == 1) {
               if (!C::RAGGED || j < C::hr(C::L)) put(C::offWout + j, acc.wout[b][r]);

@@ -123,7 +123,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         for c in coords:
             a = deps.index(c)
             mask2 |= 1 << codegen.pair_list(len(deps)).index((a, a))
-        d = _lib.MlpDesc(len(deps), 1, mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1, info["skip"], 0, info["actp"], info["widths"])
+        d = _lib.MlpDesc(len(deps), 1, mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1, info["skip"], 0, info["actp"], info["widths"], info["mono"])
         return codegen.ensure_mlp_kernels(d)
 
     def widen(k, st):
@@ -131,12 +131,12 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         if st.d != info["d"]:
             raise TraceUnsupported("network input width differs from the number of coordinates fed to it")
         if st.lap:                      # allow_lap already checked that this exact kernel exists
-            descs[k] = _lib.MlpDesc(st.d, 1, st.mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1, info["skip"], 0, info["actp"], info["widths"])
+            descs[k] = _lib.MlpDesc(st.d, 1, st.mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1, info["skip"], 0, info["actp"], info["widths"], info["mono"])
             codegen.ensure_mlp_kernels(descs[k])
             return
         # exact stream set: from libndq.so's table, else compiled on first use as an extension module ...
         exact = _lib.MlpDesc(st.d, 1 if (st.first or st.mask2) else 0, st.mask2, info["hidden"], info["layers"],
-                             info["act"], info["n_out"], 0, info["skip"], st.mask3, info["actp"], info["widths"])
+                             info["act"], info["n_out"], 0, info["skip"], st.mask3, info["actp"], info["widths"], info["mono"])
         if codegen.ensure_mlp_kernels(exact):
             st.first, st.mask2 = exact.first, exact.mask2
             descs[k] = exact
@@ -152,7 +152,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
                 if (mask2 & st.mask2) != st.mask2 or (mask2 and not first):
                     continue
                 d = _lib.MlpDesc(st.d, first, mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 0,
-                                 info["skip"], 0, info["actp"], info["widths"])
+                                 info["skip"], 0, info["actp"], info["widths"], info["mono"])
                 if L.ndq_mlp_supported(ctypes.byref(d)):
                     cost = first * st.d + bin(mask2).count("1")
                     if best is None or cost < best[0]:
@@ -170,7 +170,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         K = len(nets)
         if not (2 <= K <= 4) or len(streams) != K or len(g.site_net) != K or os.environ.get("NDQ_NO_MULTI_FUSE"):
             return
-        shape = {(i["d"], i["hidden"], i["layers"], i["act"], i["n_out"], i["skip"], i["actp"], i["widths"]) for i in infos}
+        shape = {(i["d"], i["hidden"], i["layers"], i["act"], i["n_out"], i["skip"], i["actp"], i["widths"], i["mono"]) for i in infos}
         if len(shape) != 1 or infos[0]["n_out"] != 1 or codegen.padded_width(infos[0]["hidden"]) > 48:
             return
         if any(tuple(st.deps) != tuple(range(n_coords)) for st in streams.values()):

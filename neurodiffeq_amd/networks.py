@@ -145,6 +145,16 @@ def describe(net, dtype=torch.float32):
     seq = getattr(net, "NN", net)
     if not isinstance(seq, nn.Sequential):
         return None
+    # a MonomialNN feature map in front: Sequential(MonomialNN(degrees), FCNN(...)) or Sequential(MonomialNN, Linear, actv,
+    # ..., Linear) -- ascending degrees 1..8 (ndq_mlp_desc.mono: the first layer evaluates the powers and their derivatives)
+    mono = 0
+    if len(seq) >= 2 and isinstance(seq[0], MonomialNN):
+        degs = list(seq[0].degrees)
+        if skip is not None or degs != sorted(set(degs)) or degs[0] < 1 or degs[-1] > 8:
+            return None
+        mono = sum(1 << (k - 1) for k in degs)
+        rest = list(seq)[1:]
+        seq = rest[0].NN if len(rest) == 1 and isinstance(rest[0], FCNN) else nn.Sequential(*rest)
     mods = list(seq)
     if len(mods) < 3 or len(mods) % 2 == 0:
         return None
@@ -185,7 +195,13 @@ def describe(net, dtype=torch.float32):
         return None
     # flat order the kernels read: W1 b1 ... Wout bout | skip weights (n_out x d, row-major) | activation parameters
     params = [p for l in linears for p in (l.weight, l.bias)] + ([skip.weight] if skip is not None else []) + act_params
-    return dict(d=linears[0].in_features, hidden=hidden, layers=len(acts), act=_ACT_IDS[next(iter(act_types))],
+    n_in = linears[0].in_features
+    if mono:
+        n_deg = bin(mono).count("1")
+        if n_in % n_deg or hidden > 48:
+            return None
+        n_in //= n_deg
+    return dict(d=n_in, mono=mono, hidden=hidden, layers=len(acts), act=_ACT_IDS[next(iter(act_types))],
                 n_out=linears[-1].out_features, linears=linears, skip=int(skip is not None), params=params,
                 actp=1 if act_params else (2 if act_frozen else 0), frozen=act_frozen, widths=widths)
 

@@ -91,6 +91,17 @@ class APTxTrainableRef(nn.Module):
         return (self.alpha + torch.tanh(self.beta * x)) * self.gamma * x
 
 
+class MonomialRef(nn.Module):
+    """x -> [x^d for d in degrees] along dim 1 (networks.py:109-139)."""
+
+    def __init__(self, degrees):
+        super().__init__()
+        self.degrees = tuple(degrees)
+
+    def forward(self, x):
+        return torch.cat([x ** d for d in self.degrees], dim=1)
+
+
 class SwishFixedRef(nn.Module):
     """x * sigmoid(beta x) with a fixed non-default beta = 1.7 (Swish(beta=1.7), networks.py:161-169)."""
 

@@ -101,16 +101,38 @@ def close_streams(streams):
     return sorted(s, key=lambda m: (len(m), m))
 
 
-def _forward(flat, dims, act, coords, streams, thetas=None):
-    layers = split_params(np.asarray(flat, dtype=np.float64), dims)
+def _input_streams(coords, streams, mono=None):
+    """Streams of what the first linear layer sees.  Plain network: value = x, d/dx_a = e_a, higher orders 0.  ``mono``
+    (degrees of a networks.MonomialNN in front, networks.py:109-139): the features x_a^deg, degree after degree, and
+    their derivatives -- d^k/dx_a^k x_a^deg = deg!/(deg-k)! x_a^(deg-k), every mixed derivative 0."""
     x = np.stack([np.asarray(c, dtype=np.float64).reshape(-1) for c in coords], axis=1)   # (N, d)
     n, d = x.shape
-    # input "activations": value = x, d/dx_a = e_a, second = 0
-    h = {m: np.zeros((n, d)) for m in streams}
-    h[()] = x
+    if mono is None:
+        h = {m: np.zeros((n, d)) for m in streams}
+        h[()] = x
+        for m in streams:
+            if len(m) == 1:
+                h[m][:, m[0]] = 1.0
+        return h
+    h = {m: np.zeros((n, d * len(mono))) for m in streams}
     for m in streams:
-        if len(m) == 1:
-            h[m][:, m[0]] = 1.0
+        for i, deg in enumerate(mono):
+            for a in range(d):
+                if all(idx == a for idx in m) and len(m) <= deg:
+                    coef = 1.0
+                    for k in range(len(m)):
+                        coef *= deg - k
+                    h[m][:, i * d + a] = coef * x[:, a] ** (deg - len(m))
+    return h
+
+
+def _mono_dims(dims, mono):
+    return dims if mono is None else (dims[0] * len(mono),) + tuple(dims[1:])
+
+
+def _forward(flat, dims, act, coords, streams, thetas=None, mono=None):
+    layers = split_params(np.asarray(flat, dtype=np.float64), _mono_dims(dims, mono))
+    h = _input_streams(coords, streams, mono)
     saved = []
     for li, (w, b) in enumerate(layers):
         z = {m: h[m] @ w.T for m in streams}
@@ -148,12 +170,15 @@ def _act_thetas(flat, dims, act, skip, actp):
     return [tuple(flat[off + k * l: off + k * (l + 1)]) for l in range(n_layers)]
 
 
-def mlp_jets(flat, dims, act, coords, streams, skip=False, actp=False):
+def mlp_jets(flat, dims, act, coords, streams, skip=False, actp=False, mono=None):
     """Streams of the raw network output: dict stream -> (N, n_out).  ``skip``: Resnet (networks.py:73-106) -- the
     bias-free skip matrix S (n_out, d) follows the FCNN parameters in the flat vector and the output gains S x (value) /
     S[:, a] (d/dx_a).  ``actp``: trainable Swish / APTx parameters, one set per hidden layer, at the end of the vector."""
     streams = close_streams(streams)
     flat = np.asarray(flat, dtype=np.float64)
+    if mono is not None:
+        assert not skip and not actp
+        return _forward(flat, dims, act, coords, streams, None, mono)[0]
     z, _, _ = _forward(flat[:_n_fcnn_params(dims)], dims, act, coords, streams, _act_thetas(flat, dims, act, skip, actp))
     if skip:
         S = flat[_n_fcnn_params(dims):_n_fcnn_params(dims) + dims[-1] * dims[0]].reshape(dims[-1], dims[0])
@@ -166,7 +191,7 @@ def mlp_jets(flat, dims, act, coords, streams, skip=False, actp=False):
     return z
 
 
-def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False, actp=False, thetas=None):
+def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False, actp=False, thetas=None, mono=None):
     """Parameter gradient sum_n sum_streams <gbar[stream][n], d out_stream[n] / d params>  (flat, torch order; with
     ``skip`` the gradient of the skip matrix follows, with ``actp`` that of the activation parameters after it).
 
@@ -197,7 +222,7 @@ def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False, actp=False, thetas=N
                 dS[:, m[0]] += np.asarray(g, dtype=np.float64).sum(axis=0)
         return np.concatenate([base, dS.reshape(-1)])
     streams = close_streams(list(gbar.keys()))
-    zlast, saved, layers = _forward(flat, dims, act, coords, streams, thetas)
+    zlast, saved, layers = _forward(flat, dims, act, coords, streams, thetas, mono)
     n = zlast[()].shape[0]
     zb = {m: np.asarray(gbar.get(m, np.zeros_like(zlast[()])), dtype=np.float64) for m in streams}
     grads = [None] * len(layers)
@@ -205,12 +230,7 @@ def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False, actp=False, thetas=N
     for li in range(len(layers) - 1, -1, -1):
         w, _ = layers[li]
         if li == 0:
-            x = np.stack([np.asarray(c, dtype=np.float64).reshape(-1) for c in coords], axis=1)
-            hin = {m: np.zeros_like(x) for m in streams}
-            hin[()] = x
-            for m in streams:
-                if len(m) == 1:
-                    hin[m][:, m[0]] = 1.0
+            hin = _input_streams(coords, streams, mono)
         else:
             _, zprev, (s1, s2, s3) = saved[li - 1]
             s0 = act_derivs(act, zprev[()], None if thetas is None else thetas[li - 1])[0]

@@ -44,6 +44,11 @@ CASES = {
     "funnel_50_30_3out_skip": ((2, 50, 30, 3), "tanh", 1, 0),
     "expand_16_48_sin": ((1, 16, 48, 1), "sin", 0, 0),
     "funnel_40_20_swish_tr": ((2, 40, 20, 1), "swish", 0, 1),
+    # MonomialNN in front (ndq_mlp_desc.mono; 5th entry: the degrees): the first layer sees x_a^deg and its derivatives
+    "mono123_tanh": ((2, 32, 32, 1), "tanh", 0, 0, (1, 2, 3)),
+    "mono135_2out": ((1, 16, 16, 2), "sigmoid", 0, 0, (1, 3, 5)),
+    "mono1234_sin_w20": ((1, 20, 20, 1), "sin", 0, 0, (1, 2, 3, 4)),
+    "mono12_swish_tr": ((2, 32, 32, 1), "swish", 0, 1, (1, 2)),
     "swish_fixed": ((2, 32, 32, 1), "swish", 0, 2),
     "aptx_fixed_3out": ((2, 32, 32, 3), "aptx", 0, 2),
 }
@@ -57,14 +62,17 @@ def rel_l2(a, b):
 
 def _desc(name):
     from neurodiffeq_amd import _lib
-    dims, act, skip, actp = CASES[name]
+    dims, act, skip, actp = CASES[name][:4]
+    mono = sum(1 << (k - 1) for k in CASES[name][4]) if len(CASES[name]) > 4 else 0
     d, ws = dims[0], dims[1:-1]
     widths = 0 if len(set(ws)) == 1 else sum(w << (8 * i) for i, w in enumerate(ws))
-    return _lib.MlpDesc(d, 1, (1 << (d * (d + 1) // 2)) - 1, max(ws), len(ws), ACT_ID[act], dims[-1], 0, skip, 0, actp, widths)
+    return _lib.MlpDesc(d, 1, (1 << (d * (d + 1) // 2)) - 1, max(ws), len(ws), ACT_ID[act], dims[-1], 0, skip, 0, actp, widths, mono)
 
 
 def _flat(name, rng):
-    dims, act, skip, actp = CASES[name]
+    dims, act, skip, actp = CASES[name][:4]
+    if len(CASES[name]) > 4:
+        dims = (dims[0] * len(CASES[name][4]),) + tuple(dims[1:])
     parts = []
     for a, b in zip(dims[:-1], dims[1:]):
         k = 1.0 / np.sqrt(a)
@@ -87,7 +95,8 @@ def _stream():
 def test_stream_kernels_match_jet_oracle(name, n):
     from neurodiffeq_amd import _lib, codegen
     L = _lib.lib()
-    dims, act, skip, actp = CASES[name]
+    dims, act, skip, actp = CASES[name][:4]
+    mono = list(CASES[name][4]) if len(CASES[name]) > 4 else None
     streams = FULL2[dims[0]]
     d = _desc(name)
     assert codegen.ensure_mlp_kernels(d) and L.ndq_mlp_supported(ctypes.byref(d)) == 1
@@ -105,7 +114,13 @@ def test_stream_kernels_match_jet_oracle(name, n):
     torch.cuda.synchronize()
     got = jets[:, :, :n].cpu().numpy()
     f64, c64 = flat.astype(np.float64), list(coords.astype(np.float64))
-    want = J.mlp_jets(f64, dims, act, c64, streams, skip=bool(skip), actp=bool(actp))
+    if mono is not None and actp:       # the oracle states activation parameters and monomial features separately: theta by hand
+        n_lin0 = J._n_fcnn_params(J._mono_dims(dims, mono))
+        k_act = 1 if act == "swish" else 3
+        thetas = [tuple(f64[n_lin0 + k_act * l: n_lin0 + k_act * (l + 1)]) for l in range(len(dims) - 2)]
+        want = J._forward(f64[:n_lin0], dims, act, c64, J.close_streams(streams), thetas, mono)[0]
+    else:
+        want = J.mlp_jets(f64, dims, act, c64, streams, skip=bool(skip), actp=bool(actp), mono=mono)
     floor = (0.1 if n < 64 else 0.0) * np.sqrt(n * dims[-1]) * max(np.sqrt(np.mean(want[m] ** 2)) for m in streams)
     errs = {str(m): float(np.linalg.norm(got[s].T - want[m]) / max(np.linalg.norm(want[m]), floor))
             for s, m in enumerate(streams)}
@@ -118,9 +133,15 @@ def test_stream_kernels_match_jet_oracle(name, n):
     assert L.ndq_reduce_partials(part.data_ptr(), nb, P, out.data_ptr(), 0, 1.0, _stream()) == 0
     torch.cuda.synchronize()
     grad = out.cpu().numpy()
-    want_grad = J.mlp_jets_vjp(f64, dims, act, c64, {m: gbar[s].astype(np.float64).T for s, m in enumerate(streams)},
-                               skip=bool(skip), actp=bool(actp))[:P]
-    n_lin = J._n_fcnn_params(dims)
+    gb = {m: gbar[s].astype(np.float64).T for s, m in enumerate(streams)}
+    if mono is not None and actp:
+        want_grad = J.mlp_jets_vjp(f64[:n_lin0], dims, act, c64, gb, thetas=thetas, mono=mono)      # linear layers only
+        grad = grad[:n_lin0]
+        P = n_lin0
+        actp = 0
+    else:
+        want_grad = J.mlp_jets_vjp(f64, dims, act, c64, gb, skip=bool(skip), actp=bool(actp), mono=mono)[:P]
+    n_lin = J._n_fcnn_params(J._mono_dims(dims, mono))
     n_skip = dims[-1] * dims[0] if skip else 0
     errs["grad_linear"] = rel_l2(grad[:n_lin], want_grad[:n_lin])
     if skip:
@@ -145,7 +166,8 @@ def _grad_in_torch_order(nets, flats):
 @pytest.mark.parametrize("mode", ["1k", "3k"])
 @pytest.mark.parametrize("name", ["swish_tr_laplace", "aptx_tr_laplace", "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet",
                                   "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1", "swish_fixed_laplace",
-                                  "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid"])
+                                  "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid",
+                                  "mono_laplace", "mono_ode", "mono_poisson"])
 def test_closure_of_networks_outside_the_template_matches_autograd_oracle(name, mode):
     """funcs / residuals / loss / gradient of one closure, the gradient compared parameter by parameter in torch order
     (activation scalars interleaved with the linear layers there, behind them in the kernels' flat vector)."""

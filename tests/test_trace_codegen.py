@@ -53,7 +53,8 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     for net in nets:
         info = describe(net)
         dims = (info["d"],) + tuple(l.out_features for l in info["linears"][:-1]) + (info["n_out"],)
-        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx")[info["act"]], bool(info["skip"]), bool(info["actp"])))
+        mono = [k + 1 for k in range(8) if (info["mono"] >> k) & 1] or None      # MonomialNN degrees in front of the network
+        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx")[info["act"]], bool(info["skip"]), bool(info["actp"]), mono))
         # ``params`` is in torch parameter order; the kernels' (and the jet oracle's) flat vector lists the linear layers,
         # then the skip weights, then the activation parameters (networks.describe): perm maps one onto the other
         start, at = {}, 0
@@ -77,11 +78,11 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
         needed[k].add(mi)
     jets = {}
     for k in range(prog.n_sites):
-        dims, act, skip, actp = dims_act[site_net[k]]
+        dims, act, skip, actp, mono = dims_act[site_net[k]]
         deps = prog.streams[k].deps
         local = lambda mi: tuple(sorted(deps.index(c) for c in mi))
         want = sorted({local(m) for mi in needed[k] for m in parts(mi)})
-        js = J.mlp_jets(flats[site_net[k]], dims, act, [column(c) for c in deps], want or [()], skip=skip, actp=actp)
+        js = J.mlp_jets(flats[site_net[k]], dims, act, [column(c) for c in deps], want or [()], skip=skip, actp=actp, mono=mono)
         jets[k] = {mi: sum(js[local(m)] for m in parts(mi)) for mi in needed[k]}       # (N, n_out)
     syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]][:, prog.g.nodes[i][2]]
                      for i in prog.symbols]).astype(np.float32)
@@ -94,7 +95,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     # parameter gradient: adjoint streams through the jet oracle's VJP
     grads = [0.0] * len(nets)
     for k in range(prog.n_sites):                       # every site of a network adds into that network's gradient
-        dims, act, skip, actp = dims_act[site_net[k]]
+        dims, act, skip, actp, mono = dims_act[site_net[k]]
         deps = prog.streams[k].deps
         gb = {}
         for idx, i in enumerate(prog.symbols):
@@ -106,7 +107,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
         if not gb:
             gb = {(): np.zeros((n, dims[-1]))}
         grads[site_net[k]] = grads[site_net[k]] + J.mlp_jets_vjp(flats[site_net[k]], dims, act, [column(c) for c in deps], gb,
-                                                               skip=skip, actp=actp)
+                                                               skip=skip, actp=actp, mono=mono)
     for j, perm in enumerate(perms):                    # back to torch parameter order (frozen scalars: no gradient entry)
         g = np.zeros(perm.size)
         g[perm] = grads[j][:perm.size]
@@ -143,6 +144,7 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "swish_tr_laplace": [(1, 5, 1)], "aptx_tr_laplace": [(1, 5, 1)], "aptx_tr_wide": [(1, 5, 1)],
                "swish_tr_system": [(1, 1, 0), (1, 0, 0)], "aptx_tr_resnet": [(1, 1, 0)],
                "swish_fixed_laplace": [(1, 5, 1)], "aptx_fixed_laplace": [(1, 5, 1)], "ensemble_lv": [(1, 0, 0)],
+               "mono_laplace": [(1, 7, 0)], "mono_ode": [(1, 1, 0)], "mono_poisson": [(1, 5, 1)],
                "shape_64_32": [(1, 5, 1)], "shape_24_40_12_sigmoid": [(1, 5, 1)],
                "shape_50x2": [(1, 5, 1)], "shape_20x3": [(1, 5, 1)], "shape_40x2_sigmoid": [(1, 5, 1)], "shape_10x1": [(1, 5, 1)],
                # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along

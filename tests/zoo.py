@@ -31,8 +31,14 @@ class System:
         actv = {"tanh": torch.nn.Tanh, "sin": SinActv, "sigmoid": torch.nn.Sigmoid, "swish": Swish, "aptx": APTx,
                 "swish-tr": partial(Swish, trainable=True), "aptx-tr": partial(APTx, trainable=True),
                 "swish-fixed": partial(Swish, beta=1.7), "aptx-fixed": partial(APTx, alpha=0.8, beta=1.3, gamma=0.6)}
-        nets = [(Resnet if a.startswith("resnet-") else FCNN)(i, o, hidden_units=h, actv=actv[a.replace("resnet-", "")])
-                for i, o, h, a in self.net_specs]
+        from neurodiffeq_amd.networks import MonomialNN
+
+        def make(i, o, h, a):
+            if a.startswith("mono"):            # "mono3-tanh": MonomialNN(3) in front of an FCNN with 3 i inputs
+                k = int(a[4])
+                return torch.nn.Sequential(MonomialNN(k), FCNN(i * k, o, hidden_units=h, actv=actv[a[6:]]))
+            return (Resnet if a.startswith("resnet-") else FCNN)(i, o, hidden_units=h, actv=actv[a.replace("resnet-", "")])
+        nets = [make(*spec) for spec in self.net_specs]
         # trainable activation parameters: move them off their defaults (every layer its own values), deterministically
         k = 0
         for net in nets:
@@ -46,8 +52,14 @@ class System:
     def oracle(self, flat):
         """(nets fp64 carrying ``flat``, enforcers, pde) on the oracle"""
         from oracle import autograd_ref as R
-        nets = [R.ResnetRef(i, o, h, a[7:], dtype=torch.float64) if a.startswith("resnet-")
-                else R.make_fcnn(i, o, h, a, dtype=torch.float64) for i, o, h, a in self.net_specs]
+        def make(i, o, h, a):
+            if a.startswith("mono"):
+                k = int(a[4])
+                return torch.nn.Sequential(R.MonomialRef(range(1, k + 1)), R.make_fcnn(i * k, o, h, a[6:], dtype=torch.float64))
+            if a.startswith("resnet-"):
+                return R.ResnetRef(i, o, h, a[7:], dtype=torch.float64)
+            return R.make_fcnn(i, o, h, a, dtype=torch.float64)
+        nets = [make(*spec) for spec in self.net_specs]
         R.set_flat(nets, flat.double())
         return nets, self.enforcers(R.ref_diff), self.pde(R.ref_diff)
 
@@ -174,6 +186,22 @@ def build(name):
         conds = lambda: [C.IBVP1D(-1.0, 1.0, 0.0, u0, x_min_val=zero, x_max_val=zero)]
         return System(name, 2, [(2, 1, (32, 32), "aptx")], [(-1.0, 1.0), (0.0, 1.0)], pde, conds,
                       lambda D: [_R().ibvp1d_dd(-1.0, 1.0, 0.0, u0, zero, zero)])
+    if name == "mono_poisson":        # pure Laplacian -> the merged second-order stream on a monomial first layer
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) - torch.sin(PI * x) * y])
+        conds = lambda: [C.NoCondition()]
+        return System(name, 2, [(2, 1, (32, 32), "mono3-tanh")], [(-1.0, 1.0), (-1.0, 1.0)], pde, conds,
+                      lambda D: [lambda net, x, y: net(_cat(x, y))])
+    if name in ("mono_laplace", "mono_ode"):      # MonomialNN feature map in front of the network (networks.py:109-139)
+        if name == "mono_ode":
+            pde = lambda D: (lambda u, t: [D(u, t, order=2) + 0.5 * D(u, t) + u - torch.cos(t)])
+            conds = lambda: [C.IVP(0.0, 1.0, u_0_prime=0.5)]
+            enf = lambda D: [lambda net, t: 1.0 + t * 0.5 + (1 - torch.exp(-t)) ** 2 * net(t)]
+            return System(name, 1, [(1, 1, (32, 32), "mono4-sin")], [(0.0, 1.5)], pde, conds, enf)
+        f0 = lambda y: torch.sin(PI * y)
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + 0.5 * D(D(u, x), y) + u * D(u, x) - torch.exp(-x * y)])
+        conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
+        return System(name, 2, [(2, 1, (32, 32), "mono3-tanh")], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, zero)])
     if name == "ensemble_lv":         # ONE two-output network, EnsembleCondition (conditions.py:157-202) as ONE solver function
         def pde(D):
             def f(uv, t):             # the equations pick the columns apart themselves
@@ -254,7 +282,8 @@ NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "he
          "hessian3d", "shell", "swish_laplace", "sigmoid_mixed", "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
          "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode", "swish_tr_laplace", "aptx_tr_laplace",
          "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1",
-         "swish_fixed_laplace", "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid"]
+         "swish_fixed_laplace", "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid",
+         "mono_laplace", "mono_ode", "mono_poisson"]
 
 
 def spherical_solver_problem():
