@@ -12,6 +12,7 @@ The launcher it exports has the ``ndq_pointwise_fn`` signature of include/ndq.h.
 import ctypes
 import hashlib
 import os
+import re
 
 from .symbolic import Graph, TraceUnsupported
 
@@ -94,7 +95,7 @@ class NetStreams:
 def _lit(v):
     if v != v or v in (float("inf"), float("-inf")):
         raise ValueError("non-finite constant in traced expression")
-    s = "%.9g" % v
+    s = repr(float(v))          # shortest decimal that round-trips the double: exact for the fp32 and the fp64 build alike
     if "." not in s and "e" not in s and "n" not in s:
         s += ".0"
     return s + "f"
@@ -706,13 +707,13 @@ extern "C" int ndq_pw_launch(const float* coords, int ldc, int n, const float* c
 
 # ----------------------------------------------------------------------------------------------- build / load
 class PointwiseKernel:
-    def __init__(self, so_path):
+    def __init__(self, so_path, f64=False):
         self.path = so_path
         self.lib = ctypes.CDLL(so_path)
         self.lib.ndq_pw_launch.restype = ctypes.c_int
         self.lib.ndq_pw_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                           ctypes.c_float, ctypes.c_void_p]
+                                           ctypes.c_double if f64 else ctypes.c_float, ctypes.c_void_p]
         self.lib.ndq_pw_blocks.restype = ctypes.c_int
         self.lib.ndq_pw_blocks.argtypes = [ctypes.c_int]
 
@@ -720,19 +721,32 @@ class PointwiseKernel:
         return self.lib.ndq_pw_blocks(n)
 
 
-def so_path_for(program: PointwiseProgram):
-    return os.path.join(JIT_DIR, f"pw_{program.key}.so")
+def so_path_for(program: PointwiseProgram, f64=False):
+    return os.path.join(JIT_DIR, f"pw{'64' if f64 else ''}_{program.key}.so")
 
 
-def build(program: PointwiseProgram, force=False):
+_F64_FUNCS = re.compile(r"\b(pow|sin|cos|tan|exp|log|tanh|sqrt|fabs|sinh|cosh|fmax)f\(")
+_F64_LITERAL = re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?)f\b")
+
+
+def source_f64(source):
+    """The generated pointwise source in double precision (the reference's default dtype, neurodiffeq/__init__.py:22):
+    the emitter writes ``float``, ``expf(..)``-style calls and ``1.0f``-style literals only, so the fp64 build is a
+    textual rewrite of the same program -- types, math calls, literal suffixes."""
+    out = re.sub(r"\bfloat\b", "double", source)
+    out = _F64_FUNCS.sub(lambda m: m.group(1) + "(", out)
+    return _F64_LITERAL.sub(lambda m: m.group(1), out)
+
+
+def build(program: PointwiseProgram, force=False, f64=False):
     """Compile the generated source for gfx950 (in-tree cache keyed by the source hash) and return the .so path."""
     os.makedirs(JIT_DIR, exist_ok=True)
-    so = so_path_for(program)
-    src = os.path.join(JIT_DIR, f"pw_{program.key}.hip")
+    so = so_path_for(program, f64)
+    src = so[:-3] + ".hip"
     if os.path.exists(so) and not force:
         return so
     with open(src, "w") as fh:
-        fh.write(program.source)
+        fh.write(source_f64(program.source) if f64 else program.source)
     try:
         _hipcc.compile_shared(src, so)
     except RuntimeError as e:
@@ -740,8 +754,8 @@ def build(program: PointwiseProgram, force=False):
     return so
 
 
-def load(program: PointwiseProgram):
-    return PointwiseKernel(build(program))
+def load(program: PointwiseProgram, f64=False):
+    return PointwiseKernel(build(program, f64=f64), f64)
 
 
 # ----------------------------------------------------------------------------------------------- fused closure kernel

@@ -34,13 +34,24 @@ def _round_up(n, m):
     return (n + m - 1) // m * m
 
 
-def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, loss="l2", metrics=()):
+class _Lib64:
+    """libndq64.so behind libndq.so's names (``ndq_mlp_jet_fwd`` -> ``ndq64_mlp_jet_fwd`` ...): the fp64 build of the
+    stream kernels and of the fixed-order sums, which is all the three-kernel pipeline needs."""
+
+    def __init__(self):
+        self._lib = _lib.lib64()
+
+    def __getattr__(self, name):
+        return getattr(self._lib, name.replace("ndq_", "ndq64_", 1))
+
+
+def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, loss="l2", metrics=(), f64=False):
     """Trace (conditions, diff_eqs) once on symbolic columns and lower them to a pointwise program.
 
     Needs no GPU (used by ``__graft_entry__.build`` to pre-compile the generated kernels); raises
     :class:`TraceUnsupported` when the system is outside the fused scope.  Returns ``(program, descs)`` with
     ``descs[k]`` the ``ndq_mlp_desc`` of network k (stream set widened to one libndq.so has kernels for)."""
-    L = _lib.lib()
+    L = _Lib64() if f64 else _lib.lib()
     all_nets, conditions = list(nets), list(conditions)
     # one parameter set per DISTINCT module: the reference's single_net / ith_unit mode (ode.py:276-280, pde.py:301-305)
     # and EnsembleCondition share one multi-output network between several functions -- its symbols are output units
@@ -49,7 +60,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     for n in all_nets:
         if not any(n is m for m in nets):
             nets.append(n)
-    infos = [describe(n) for n in nets]
+    infos = [describe(n, dtype=torch.float64 if f64 else torch.float32) for n in nets]
     if any(i is None for i in infos):
         raise TraceUnsupported("a network is not an FCNN the gfx950 kernels support")
     g = Graph(n_coords)
@@ -124,7 +135,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             a = deps.index(c)
             mask2 |= 1 << codegen.pair_list(len(deps)).index((a, a))
         d = _lib.MlpDesc(len(deps), 1, mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1, info["skip"], 0, info["actp"], info["widths"], info["mono"])
-        return codegen.ensure_mlp_kernels(d)
+        return codegen.ensure_mlp_kernels(d, f64=f64)
 
     def widen(k, st):
         info = infos[g.site_net[k]]
@@ -132,12 +143,12 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             raise TraceUnsupported("network input width differs from the number of coordinates fed to it")
         if st.lap:                      # allow_lap already checked that this exact kernel exists
             descs[k] = _lib.MlpDesc(st.d, 1, st.mask2, info["hidden"], info["layers"], info["act"], info["n_out"], 1, info["skip"], 0, info["actp"], info["widths"], info["mono"])
-            codegen.ensure_mlp_kernels(descs[k])
+            codegen.ensure_mlp_kernels(descs[k], f64=f64)
             return
         # exact stream set: from libndq.so's table, else compiled on first use as an extension module ...
         exact = _lib.MlpDesc(st.d, 1 if (st.first or st.mask2) else 0, st.mask2, info["hidden"], info["layers"],
                              info["act"], info["n_out"], 0, info["skip"], st.mask3, info["actp"], info["widths"], info["mono"])
-        if codegen.ensure_mlp_kernels(exact):
+        if codegen.ensure_mlp_kernels(exact, f64=f64):
             st.first, st.mask2 = exact.first, exact.mask2
             descs[k] = exact
             return
@@ -202,24 +213,32 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
 
 class FusedSystem:
     def __init__(self, nets, conditions, diff_eqs, n_coords, device, compute_func_val=None, single_kernel=True,
-                 loss="l2", metrics=()):
+                 loss="l2", metrics=(), dtype=torch.float32):
         """single_kernel: for single-network systems use the one-launch fused closure kernel (forward + pointwise +
         reverse, csrc/ndq_mlp.h: fused_closure_kernel); otherwise (and for multi-network systems) the three-kernel
         pipeline through HBM streams."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.NdqError("the fused path needs an MI355X (device 'cuda'); no CPU fallback exists for it")
-        self.L = _lib.lib()
+        # dtype float64 (the reference's default precision, neurodiffeq/__init__.py:22): the three-kernel pipeline on the
+        # fp64 build of the stream kernels (libndq64.so) with the generated pointwise kernel compiled in double; the
+        # single-launch closure kernels, the native epoch and the device-side Adam are fp32 only
+        self.dt = dtype
+        self.f64 = dtype == torch.float64
+        self.esize = 8 if self.f64 else 4
+        if self.f64:
+            single_kernel = False
+        self.L = _Lib64() if self.f64 else _lib.lib()
         self.nets, self.conditions, self.n_coords = list(nets), list(conditions), n_coords
         self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val, loss,
-                                                metrics)
+                                                metrics, f64=self.f64)
         self.nets = list(self.program.unique_nets)      # a module shared by several functions is ONE parameter set
         # rows of the function-value buffer: the solver's functions, then one per-point term per traced metric
         self.n_eq, self.n_funcs = len(self.program.residuals), len(self.program.funcs)
         self.n_metrics = self.program.n_metrics
         self.n_user_funcs = self.n_funcs - self.n_metrics
         self.loss_norm = self.program.loss_norm      # loss = sum over points of the per-point term / (N * loss_norm)
-        self.kernel = codegen.load(self.program)
+        self.kernel = codegen.load(self.program, f64=self.f64)
         self.fusedk = None
         # the 8-wave build of the closure kernel (two waves per SIMD), built on first use for batches of at least
         # WIDE_MIN_POINTS points: None = not tried yet, False = not available / rejected
@@ -230,7 +249,7 @@ class FusedSystem:
             fk = codegen.FusedKernel(codegen.build_fused(self.program, self.descs[0]))
             if fk.lib.ndq_fused_lds_bytes() <= 160 * 1024:       # K weight images + staging must fit one workgroup's LDS
                 self.fusedk = fk
-        self.flat = [FlatParams(n, self.device) for n in self.nets]
+        self.flat = [FlatParams(n, self.device, dtype) for n in self.nets]
         # evaluation sites: (network, coordinate tuple) pairs; site k < n_nets is network k at its first tuple, further
         # sites (networks evaluated on a boundary as well: Neumann conditions) follow.  Stream arrays are per site.
         self.site_net = list(self.program.site_net)
@@ -248,22 +267,22 @@ class FusedSystem:
         self._resident_cache = {}
         self._static, self._static_seen = {}, {}
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self.loss_buf = torch.zeros(64, dtype=torch.float32, device=self.device)
+        self.loss_buf = torch.zeros(64, dtype=dtype, device=self.device)
 
     # ------------------------------------------------------------------------------------------ buffers
     def _resident_ld(self, batch):
         """Leading dimension if ``batch`` is rows of ONE contiguous fp32 SoA block (ResidentBatchGenerator), else 0."""
-        if any(c.dtype != torch.float32 or not c.is_contiguous() for c in batch):
+        if any(c.dtype != self.dt or not c.is_contiguous() for c in batch):
             return 0
         p0 = batch[0].data_ptr()
         if len(batch) == 1:
             return _round_up(batch[0].numel(), 64) if p0 % 16 == 0 else 0
         step = batch[1].data_ptr() - p0
-        if step <= 0 or step % 4 or step // 4 < batch[0].numel():
+        if step <= 0 or step % self.esize or step // self.esize < batch[0].numel():
             return 0
         if any(c.data_ptr() != p0 + i * step for i, c in enumerate(batch)):
             return 0
-        return step // 4
+        return step // self.esize
 
     MAX_BUFFER_SETS = 8
     # Which build serves a batch: both run "rounds" of one 16-point tile per wave over 256 workgroups -- 1 024 waves
@@ -330,7 +349,7 @@ class FusedSystem:
                     del fs["structs"][k]
             self._resident_cache = {k: v for k, v in self._resident_cache.items() if v[1] is not old}
         ld = ld or _round_up(n, 64)
-        dev, f32 = self.device, torch.float32
+        dev, f32 = self.device, self.dt              # (name kept: the working precision of this system)
         b = dict(ld=ld,
                  coords_own=torch.zeros(self.n_coords, ld, dtype=f32, device=dev),
                  # host staging ring: a pinned block may only be rewritten once its async H2D copy has completed
@@ -438,8 +457,8 @@ class FusedSystem:
             return b
         if key in self._static_seen and len(self._static) < 16:      # second sighting: promote to a resident block
             ld = _round_up(n, 64)
-            block = torch.zeros(self.n_coords, ld, dtype=torch.float32, device=self.device)
-            host = torch.stack([c.detach().reshape(-1)[lo:hi].to(torch.float32) for c in batch])
+            block = torch.zeros(self.n_coords, ld, dtype=self.dt, device=self.device)
+            host = torch.stack([c.detach().reshape(-1)[lo:hi].to(self.dt) for c in batch])
             block[:, :n].copy_(host)
             rows = [block[i] for i in range(self.n_coords)]
             self._static[key] = (list(batch), block, rows)
@@ -545,7 +564,7 @@ class FusedSystem:
 
     def reduce_loss(self, b, stream, seed, slot):
         rc = self.L.ndq_reduce_partials(_ptr(b["loss_partials"]), b["pw_blocks"], 1,
-                                        _c_vp(self.loss_buf.data_ptr() + 4 * slot), 0, seed, stream)
+                                        _c_vp(self.loss_buf.data_ptr() + self.esize * slot), 0, seed, stream)
         _lib.check(rc, "ndq_reduce_partials(loss)")
 
     def verify_fused(self, b, n, n_global=None):
@@ -642,7 +661,7 @@ class FusedSystem:
                                                 1 if accumulate else 0, 1.0, stream)
                 _lib.check(rc, "ndq_reduce_partials")
         rc = self.L.ndq_reduce_partials(_ptr(b["fused_loss_partials"]), b["fused_blocks"], 1,
-                                        _c_vp(self.loss_buf.data_ptr() + 4 * slot), 0, seed, stream)
+                                        _c_vp(self.loss_buf.data_ptr() + self.esize * slot), 0, seed, stream)
         _lib.check(rc, "ndq_reduce_partials(loss)")
 
     # ------------------------------------------------------------------------------------------ native epoch
@@ -651,7 +670,7 @@ class FusedSystem:
     def fast_ready(self, dist=None):
         """Can a whole training epoch go through one native call?  (single-launch closure; the data-parallel hook exists
         for one network only)"""
-        return self.fusedk is not None and (len(self.nets) == 1 or dist is None)
+        return self.fusedk is not None and (len(self.nets) == 1 or dist is None) and not self.f64
 
     def launches_per_step(self):
         """Kernel launches of one native training epoch with one batch (bench.py reports it per config)."""

@@ -212,17 +212,19 @@ class FlatParams:
     ``sync()`` is called before every launch: if something re-homed a parameter (``net.to(...)``, ``load_state_dict``
     on a copy, ...) the flat buffer is rebuilt from the current values, so the kernels always see what torch sees."""
 
-    def __init__(self, net, device):
+    def __init__(self, net, device, dtype=torch.float32):
         self.net = net
         self.device = torch.device(device)
-        info = describe(net)
+        self.dtype = dtype
+        self.esize = 8 if dtype == torch.float64 else 4
+        info = describe(net, dtype=dtype)
         self.params = info["params"]
         self.frozen = info["frozen"]      # fixed non-default activation scalars: behind the trainable entries of ``flat``
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
         # gradient buffer with one spare trailing slot: single-network systems keep the batch loss there so that
         # [gradient | loss] is ONE contiguous all-reduce message (parallel.py)
-        self.grad_loss = torch.zeros(self.numel + 1, dtype=torch.float32, device=self.device)
+        self.grad_loss = torch.zeros(self.numel + 1, dtype=dtype, device=self.device)
         self.grad = self.grad_loss[:self.numel]
         self._offsets = []
         self._grad_views = None
@@ -245,13 +247,13 @@ class FlatParams:
         if self._is_flat():
             return
         with torch.no_grad():
-            flat = torch.cat([p.detach().to(self.device, torch.float32).reshape(-1) for p in self.params]
-                             + ([torch.tensor(self.frozen, dtype=torch.float32, device=self.device)] if self.frozen else [])
+            flat = torch.cat([p.detach().to(self.device, self.dtype).reshape(-1) for p in self.params]
+                             + ([torch.tensor(self.frozen, dtype=self.dtype, device=self.device)] if self.frozen else [])
                              ).contiguous()
             for p, off in zip(self.params, self._offsets):
                 p.data = flat[off:off + p.numel()].view(p.shape)
         self.flat = flat
-        self._ptrs = [flat.data_ptr() + 4 * off for off in self._offsets]
+        self._ptrs = [flat.data_ptr() + self.esize * off for off in self._offsets]
 
     def attach_grads(self):
         """Expose the flat gradient buffer as ``p.grad`` views (what ``loss.backward()`` leaves behind, solvers.py:393)."""

@@ -48,6 +48,8 @@ class FusedAdam(torch.optim.Adam):
             groups = {id(group_of.get(id(p))) for p in fp.params}
             if len(groups) != 1 or None in [group_of.get(id(p)) for p in fp.params]:
                 continue                        # not (entirely) ours, or split across groups: leave to torch
+            if fp.grad.dtype != torch.float32:
+                continue                        # fp64 systems: stock Adam on the parameters (ndq_adam_step is fp32)
             group = group_of[id(fp.params[0])]
             m = torch.zeros_like(fp.grad)
             v = torch.zeros_like(fp.grad)

@@ -330,10 +330,16 @@ class BaseSolver(ABC):
             loss_kind = "custom"
         if _requires_closure(self.optimizer) and self.dist is not None:
             reason = "closure-based optimizer under data parallelism"
+        # working precision = the networks' (fp64 is the reference's default, neurodiffeq/__init__.py:22: such systems run
+        # the three-kernel pipeline on the fp64 build of the stream kernels)
+        dtypes = {p.dtype for n in self.nets for p in n.parameters()}
+        sys_dtype = torch.float64 if dtypes == {torch.float64} else torch.float32
+        if sys_dtype == torch.float64 and self.dist is not None:
+            reason = "fp64 networks under data parallelism"
         if self._loss_time_dependent:
             reason = "epoch-dependent loss function"
         key = (id(self.diff_eqs), tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions),
-               getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind,
+               getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind, sys_dtype,
                id(self.loss_fn) if loss_kind == "custom" else None,
                tuple((name, id(fn)) for name, fn in self.metrics_fn.items()))
         if key == self._fused_key:
@@ -379,7 +385,7 @@ class BaseSolver(ABC):
                     kind = lambda r, f, x: self.loss_fn(r, f, x) + self.additional_loss(r, f, x)
                 self._fused_sys = FusedSystem(self.nets, self.conditions, eqs, n_coords, self.device,
                                               compute_func_val=self.compute_func_val, loss=kind,
-                                              metrics=list(self.metrics_fn.values()))
+                                              metrics=list(self.metrics_fn.values()), dtype=sys_dtype)
                 if isinstance(self.optimizer, FusedAdam):
                     self.optimizer.bind(self._fused_sys.flat)
             except TraceUnsupported as e:
@@ -423,7 +429,7 @@ class BaseSolver(ABC):
             return
         metric_values = {name: 0.0 for name in self.metrics_fn}
         if system.loss_buf.numel() < nb:
-            system.loss_buf = torch.zeros(nb, dtype=torch.float32, device=self.device)
+            system.loss_buf = torch.zeros(nb, dtype=system.dt, device=self.device)
         closure_opt = key == "train" and _requires_closure(self.optimizer)
         if key == "train" and not closure_opt:
             self.optimizer.zero_grad()
@@ -486,7 +492,7 @@ class BaseSolver(ABC):
         through ONE native call (engine.fast_train_epoch: closure kernel + fused sums/tail kernel); every other fused
         system runs its per-batch launch sequence and then the device-side epoch tail (loss history ring, best
         snapshot, fused Adam per network).  Returns False if the general (host-synchronising) path must run."""
-        if not self._native_ok():
+        if not self._native_ok() or system.f64:
             return False
         train = key == "train"
         nb = self.n_batches[key]
@@ -528,7 +534,7 @@ class BaseSolver(ABC):
                                     n_global=shard.global_n(n_all) if shard else n_all, dist=shard)
         else:
             if system.loss_buf.numel() < nb:
-                system.loss_buf = torch.zeros(nb, dtype=torch.float32, device=self.device)
+                system.loss_buf = torch.zeros(nb, dtype=system.dt, device=self.device)
             batches = [first_batch] + [self._generate_batch(key) for _ in range(nb - 1)]
             if not train and nb > 1:
                 # a static validation set served nb times (the default: 4 x the same 'equally-spaced' grid) gives nb

@@ -253,30 +253,35 @@ def test_fp64_stream_kernels_match_jet_oracle(d, act, n_out, order):
 @pytest.mark.gpu
 def test_solver_in_the_reference_default_precision_trains_on_the_f64_kernels():
     """``set_tensor_type(device='cuda', float_bits=64)`` -- what importing the reference does (``__init__.py:22``) -- then a
-    plain Solver2D: the fused fp32 path steps aside (loudly), the reference's closure runs with the networks' forward /
-    backward on the fp64 stream kernels, and the run equals the same closure on plain torch fp64 autograd."""
+    plain Solver2D, three ways: (a) the fused fp64 pipeline (traced pointwise kernel compiled in double between the fp64
+    stream kernels of libndq64.so: engine.FusedSystem(dtype=float64)); (b) fused path off: the reference's closure with
+    the networks' forward / backward on the fp64 stream kernels through the custom-op seam; (c) the same closure on
+    plain torch fp64 autograd.  All three agree to 1e-9."""
     from neurodiffeq_amd.utils import set_tensor_type
     try:
         set_tensor_type(device="cuda", float_bits=64)
         runs = {}
-        for native in (True, False):
+        for mode in ("fused", "seam", "torch"):
             torch.manual_seed(0)
             solver, cfg = configs.make_solver("c2", 12)
             assert next(cfg["nets"][0].parameters()).dtype == torch.float64
+            solver.fused = "require" if mode == "fused" else "off"
             torch.manual_seed(5)
-            with autograd_ops.native_autograd(native):
-                with pytest.warns(RuntimeWarning, match="NOT on the fused MI355X path"):
+            with autograd_ops.native_autograd(mode != "torch"):
+                for _ in range(3):
                     solver.run_train_epoch()
-                for _ in range(2):
-                    solver.run_train_epoch()
-                if native:
+                assert solver.fused_active == (mode == "fused")
+                if mode == "fused":
+                    assert solver._fused_sys.f64 and solver._fused_sys.fusedk is None
+                if mode == "seam":
                     ex = [c.detach().to("cuda").requires_grad_(True) for c in solver._generate_batch("train")]
                     assert "MlpJet" in type(cfg["nets"][0](torch.cat(ex, 1)).grad_fn).__name__
-            runs[native] = (np.array(solver.metrics_history["train_loss"]), R.get_flat(cfg["nets"]).cpu().numpy())
+            runs[mode] = (np.array(solver.metrics_history["train_loss"]), R.get_flat(cfg["nets"]).cpu().numpy())
     finally:
         set_tensor_type(device="cpu", float_bits=32)
-    assert np.allclose(runs[True][0], runs[False][0], rtol=1e-10), (runs[True][0], runs[False][0])
-    assert rel_l2(runs[True][1], runs[False][1]) < 1e-10
+    for mode in ("fused", "seam"):
+        assert np.allclose(runs[mode][0], runs["torch"][0], rtol=1e-9), (mode, runs[mode][0], runs["torch"][0])
+        assert rel_l2(runs[mode][1], runs["torch"][1]) < 1e-9, mode
 
 
 @pytest.mark.gpu

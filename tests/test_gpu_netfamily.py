@@ -309,3 +309,56 @@ def test_ensemble_condition_as_one_solver_function_trains_on_the_fused_path():
     assert uv_f.shape == (50, 2) and uv_c.shape == (50, 2)
     assert np.allclose(hist_f, hist_c, rtol=2e-4), (hist_f, hist_c)
     assert np.linalg.norm(uv_f - uv_c) <= 2e-4 * np.linalg.norm(uv_c)
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3x", "pendulum", "helmholtz_xy", "stokes_like", "sigmoid_mixed", "kdv"])
+def test_fp64_pipeline_matches_autograd_oracle(name):
+    """engine.FusedSystem(dtype=float64): forward streams (libndq64.so, f64 MFMA) -> the generated pointwise kernel
+    compiled in double -> adjoint kernel -> fp64 sums, against the fp64 autograd oracle at 1e-9 (C1, C2, a 32-wide C3 and
+    zoo systems: first order only, full Hessian, three networks, sigmoid, third-order streams)."""
+    from tests import configs, zoo
+    from neurodiffeq_amd.engine import FusedSystem
+    torch.manual_seed(11)
+    if name in ("c1", "c2", "c3x"):
+        cfg = configs.make("c3" if name == "c3x" else name, 24 if name != "c1" else 500)
+        if name == "c3x":
+            from neurodiffeq_amd.networks import FCNN
+            cfg["nets"] = [FCNN(2, 1, hidden_units=(32, 32, 32))]
+        nets, conds, pde, n_coords = cfg["nets"], cfg["conds"], configs.fused_equations(cfg), configs.n_coords(cfg)
+        torch.manual_seed(11)
+        ocfg = R.build_config("c3" if name == "c3x" else name, 24 if name != "c1" else 500, dtype=torch.float64)
+        if name == "c3x":
+            ocfg["nets"] = [R.make_fcnn(2, 1, (32, 32, 32), "tanh", torch.float64)]
+        onets, enforcers, opde = ocfg["nets"], ocfg["enforcers"], ocfg["pde"]
+        torch.manual_seed(3)
+        ex = cfg["gen"].get_examples()
+        coords = [c.detach().double() for c in ([ex] if isinstance(ex, torch.Tensor) else ex)]
+    else:
+        system = zoo.build(name)
+        nets, conds, pde = system.product()
+        n_coords = system.n_coords
+        coords = system.sample(3001, seed=5)
+        onets, enforcers, opde = system.oracle(R.get_flat(nets))
+    for net in nets:
+        net.double()
+    # fp64 initial values of their own (not fp32 roundings): the point is double precision end to end
+    gen = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        for net in nets:
+            for prm in net.parameters():
+                prm.add_(1e-9 * torch.randn(prm.shape, generator=gen, dtype=torch.float64))
+    R.set_flat(onets, R.get_flat(nets).double())
+    want = R.closure(onets, enforcers, opde, coords)
+    want_grad = R.get_flat_grad(onets).numpy()
+    for net in nets:
+        net.to("cuda")
+    fs = FusedSystem(nets, conds, pde, n_coords, "cuda", dtype=torch.float64)
+    assert fs.f64 and fs.fusedk is None
+    b, n = fs.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    assert b["funcs"].dtype == torch.float64 and fs.flat[0].grad.dtype == torch.float64
+    errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), want["funcs"].numpy()),
+                residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy(), want["residuals"].numpy()),
+                loss=abs(fs.loss_buf[0].item() - want["loss"].item()) / abs(want["loss"].item()),
+                grad=rel_l2(_grad_in_torch_order(nets, fs.flat), want_grad))
+    assert max(errs.values()) < 1e-9, errs
