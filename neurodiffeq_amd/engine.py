@@ -354,7 +354,7 @@ class FusedSystem:
                  coords_own=torch.zeros(self.n_coords, ld, dtype=f32, device=dev),
                  # host staging ring: a pinned block may only be rewritten once its async H2D copy has completed
                  # (the native epoch path never synchronises, so the host can run several epochs ahead)
-                 pinned=[torch.zeros(self.n_coords, ld, dtype=f32).pin_memory() for _ in range(4)],
+                 pinned=[torch.zeros(self.n_coords, ld, dtype=f32, device="cpu").pin_memory() for _ in range(4)],
                  pin_events=[None] * 4, pin_next=0,
                  jets=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
                  gbar=[torch.zeros(ns, ld, dtype=f32, device=dev) for ns in self.ns],
