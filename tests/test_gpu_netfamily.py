@@ -362,3 +362,32 @@ def test_fp64_pipeline_matches_autograd_oracle(name):
                 loss=abs(fs.loss_buf[0].item() - want["loss"].item()) / abs(want["loss"].item()),
                 grad=rel_l2(_grad_in_torch_order(nets, fs.flat), want_grad))
     assert max(errs.values()) < 1e-9, errs
+
+
+def test_fused_solver_under_a_cuda_default_device():
+    """A user script that calls ``set_tensor_type(device='cuda', float_bits=32)`` (utils.py:10-41: torch's default device
+    becomes the GPU, generators sample there): the fused path -- native epochs, pinned staging, device-side Adam -- runs
+    as under the CPU default and trains to the same losses on the same batches."""
+    from tests import configs
+    from neurodiffeq_amd.utils import set_tensor_type
+
+    def run(cuda_default):
+        try:
+            if cuda_default:
+                set_tensor_type(device="cuda", float_bits=32)
+            torch.manual_seed(0)
+            solver, cfg = configs.make_solver("c2", 16)
+            solver.fused = "require"
+            # the same initial parameters and points whatever device torch's RNG lives on
+            init = np.random.default_rng(3).uniform(-0.3, 0.3, sum(p.numel() for p in cfg["nets"][0].parameters()))
+            R.set_flat(cfg["nets"], torch.from_numpy(init.astype(np.float32)).to(next(cfg["nets"][0].parameters()).device))
+            batch = [torch.linspace(0.05, 0.95, 256).reshape(-1, 1), torch.linspace(0.95, 0.05, 256).reshape(-1, 1) ** 2]
+            solver.generator["train"].get_examples = lambda: batch          # the same points whatever the RNG device
+            for _ in range(4):
+                solver.run_train_epoch()
+            assert solver.fused_active
+            return np.array(solver.metrics_history["train_loss"])
+        finally:
+            set_tensor_type(device="cpu", float_bits=32)
+    got, want = run(True), run(False)
+    assert np.allclose(got, want, rtol=1e-6), (got, want)
