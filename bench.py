@@ -240,6 +240,32 @@ def config_record(name):
                 final_loss=solver.metrics_history["train_loss"][-1])
 
 
+def fp64_record():
+    """C2 at its stated size in the reference's DEFAULT precision (neurodiffeq/__init__.py:22: float64): fp64 networks on
+    the fused three-kernel pipeline (fp64 stream kernels of libndq64.so + the traced pointwise kernel compiled in double,
+    stock torch Adam), batch resident in HBM, through run_train_epoch()."""
+    from tests import configs
+    torch.manual_seed(0)
+    solver, cfg = configs.make_solver("c2")
+    for net in cfg["nets"]:
+        net.double()
+    solver.fused = "require"
+    torch.manual_seed(1)
+    batch = [c.detach().double().cuda().reshape(-1, 1) for c in cfg["gen"].get_examples()]
+    solver.generator["train"].get_examples = lambda: batch
+    for _ in range(20):
+        solver.run_train_epoch()
+    torch.cuda.synchronize()
+    k = 20
+    times = timed_windows(solver.run_train_epoch, k, torch.cuda.synchronize)
+    dt = times[(len(times) - 1) // 2] / k
+    n = cfg["n_points"]
+    assert solver.fused_active and solver._fused_sys.f64
+    return dict(points=n, dtype="f64", ms_per_step=dt * 1e3, points_per_s=n / dt, windows=len(times), steps_per_window=k,
+                optimizer="torch.optim.Adam on .grad views (one host synchronisation per epoch)",
+                final_loss=solver.metrics_history["train_loss"][-1])
+
+
 def pointwise_large():
     """The standalone generated pointwise residual kernel (HBM-bound: reads coordinates + network streams, writes the
     adjoint streams) at sizes where HBM speed, not launch latency, decides: C2's at 1 M and 4 M points, C5's at 1 M."""
@@ -512,10 +538,13 @@ def main():
             torch.cuda.empty_cache()
             out["configs"] = {name: config_record(name) for name in ("c1", "c3", "c4", "c5")}
             out["roofline_pointwise_large"] = pointwise_large()
+            out["c2_fp64"] = fp64_record()
         if not args.no_cpu_baseline:
             cb = out["cpu_baseline"] = cpu_baseline()
             # like for like: resident inputs on both sides / generator draw inside the step on both sides (the host draw +
             # PCIe upload is then what the GPU step waits for; its numbers are the reference's bit for bit)
+            if "c2_fp64" in out:
+                out["c2_fp64"]["speedup_vs_cpu_fp64"] = out["c2_fp64"]["points_per_s"] / cb["fp64"]["value"]
             out["speedup_vs_cpu_baseline"] = {
                 "presampled_inputs_both_sides": value / cb["presampled"]["value"],
                 "host_sampling_both_sides": out["with_host_sampling"]["value"] / cb["value"],
