@@ -43,10 +43,11 @@ def trace(nets, conds, pde, n_coords, lap=True, cfv=None, loss="l2", metrics=())
                                     allow_lap=(lambda k, coords: True) if lap else None, loss=loss, loss_term=term)
 
 
-def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2", metrics=()):
+def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2", metrics=(), f64=False):
     """One training closure on the host: traced + generated pointwise code (gcc) around the jet oracle's network
     streams and VJP.  coords [d][n] fp32, params flat fp64.  Returns (program, funcs [n][nf], resid [n][neq], loss, grad)."""
-    coords = np.ascontiguousarray(coords, np.float32)
+    wdt = np.float64 if f64 else np.float32       # working precision of the generated pointwise code
+    coords = np.ascontiguousarray(coords, wdt)
     n_coords, n = coords.shape
     prog = trace(nets, conds, pde, n_coords, lap, cfv, loss, metrics)
     dims_act, flats, perms, off = [], [], [], 0
@@ -71,7 +72,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     parts = lambda mi: [(c, c) for c in mi[1:]] if (mi and mi[0] == "L") else [mi]
     # evaluation sites: (network, coordinate tuple) pairs; a virtual coordinate is a constant column
     site_net = prog.site_net
-    column = lambda c: coords[c] if c < n_coords else np.full(n, prog.g.vcoords[c], np.float32)
+    column = lambda c: coords[c] if c < n_coords else np.full(n, prog.g.vcoords[c], wdt)
     needed = {k: set() for k in range(prog.n_sites)}
     for i in prog.symbols:
         _, k, o, mi = prog.g.nodes[i]
@@ -85,10 +86,10 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
         js = J.mlp_jets(flats[site_net[k]], dims, act, [column(c) for c in deps], want or [()], skip=skip, actp=actp, mono=mono)
         jets[k] = {mi: sum(js[local(m)] for m in parts(mi)) for mi in needed[k]}       # (N, n_out)
     syms = np.stack([jets[prog.g.nodes[i][1]][prog.g.nodes[i][3]][:, prog.g.nodes[i][2]]
-                     for i in prog.symbols]).astype(np.float32)
+                     for i in prog.symbols]).astype(wdt)
     n_eq = len(prog.residuals)
     seed = 1.0 / (n * prog.loss_norm)
-    resid, funcs, gbar, lterm = run_cpu(prog, coords, syms, seed, return_loss=True)
+    resid, funcs, gbar, lterm = run_cpu(prog, coords, syms, seed, return_loss=True, f64=f64)
     r64 = resid.astype(np.float64)
     term = {"l2": lambda r: (r ** 2).sum(), "l1": lambda r: np.abs(r).sum(), "infinity": lambda r: np.abs(r).max(axis=0).sum()}
     loss = float(lterm.astype(np.float64).sum() * seed) if callable(loss) else float(term[loss](r64) * seed)
@@ -174,6 +175,38 @@ def test_zoo_on_host_matches_autograd_oracle(name):
     assert rel_l2(resid, want["residuals"].numpy()) < 1e-5
     assert abs(loss - want["loss"].item()) <= 1e-5 * abs(want["loss"].item())
     assert rel_l2(grad, want_grad) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "helmholtz_xy", "stokes_like", "sigmoid_mixed", "kdv", "shell",
+                                  "bundle_bvp", "mono_laplace", "aptx_burgers"])
+def test_zoo_fp64_build_on_host_matches_autograd_oracle(name):
+    """The fp64 build of the generated pointwise code (codegen.source_f64: types, math calls and literal suffixes of the
+    same traced program rewritten for double -- what FusedSystem(dtype=float64) compiles for gfx950) between the fp64
+    jet oracle's streams and VJP, against the fp64 autograd oracle: 1e-11, i.e. nothing in the program is left in fp32
+    (a stray ``float`` or a 9-digit literal would show at 1e-7)."""
+    from oracle import autograd_ref as R
+    torch.manual_seed(11)
+    system = zoo.build(name)
+    nets, conds, pde = system.product()
+    for net in nets:
+        net.double()
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for net in nets:
+            for prm in net.parameters():
+                prm.add_(1e-9 * torch.randn(prm.shape, generator=gen, dtype=torch.float64))
+    flat = R.get_flat(nets)
+    coords = system.sample(40, seed=5)
+    onets, enforcers, opde = system.oracle(flat)
+    want = R.closure(onets, enforcers, opde, coords)
+    want_grad = R.get_flat_grad(onets).numpy()
+    for net in nets:
+        net.float()                                   # describe() / the tracer look at fp32 modules; values come from ``flat``
+    prog, funcs, resid, loss, grad = host_closure(nets, conds, pde, np.stack([c.numpy() for c in coords]), flat.numpy(), f64=True)
+    assert rel_l2(funcs, want["funcs"].numpy()) < 1e-11
+    assert rel_l2(resid, want["residuals"].numpy()) < 1e-11
+    assert abs(loss - want["loss"].item()) <= 1e-11 * abs(want["loss"].item())
+    assert rel_l2(grad, want_grad) < 1e-11
 
 
 @pytest.mark.parametrize("name,kind", [("helmholtz_xy", "l1"), ("stokes_like", "l1"), ("stokes_like", "infinity"),
