@@ -231,6 +231,9 @@ int ndq64_mlp_jet_bwd(const ndq_mlp_desc* desc, const double* coords, int ldc, i
                       const double* gbar, int ldj, double* partials, void* stream);
 int ndq64_reduce_partials(const double* partials, int nparts, int len, double* out, int accumulate, double scale,
                           void* stream);
+/* ndq_adam_step in double (torch.optim.Adam, amsgrad = False, maximize = False) */
+int ndq64_adam_step(double* params, const double* grad, double* exp_avg, double* exp_avg_sq, int len, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, int step, void* stream);
 
 /* ---- one-shot all-reduce of the small [gradient | loss] message (data-parallel training) ------------
  * Every rank writes its vector straight into every peer's inbox (fine-grained device memory shared through HIP IPC; on

@@ -61,6 +61,22 @@ __global__ __launch_bounds__(256) void reduce_partials64_kernel(const double* __
   out[i] = accumulate ? out[i] + s : s;
 }
 
+// torch.optim.Adam (amsgrad=False, maximize=False), the fp32 kernel of ndq_api.hip in double
+__global__ __launch_bounds__(256) void adam64_kernel(double* __restrict__ p, const double* __restrict__ g,
+                                                     double* __restrict__ m, double* __restrict__ v, int len, double lr,
+                                                     double b1, double b2, double eps, double wd, double bc1, double bc2s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  double gi = g[i];
+  const double pi = p[i];
+  if (wd != 0.0) gi = fma(wd, pi, gi);
+  const double mi = fma(b1, m[i], (1.0 - b1) * gi);
+  const double vi = fma(b2, v[i], (1.0 - b2) * gi * gi);
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = pi - (lr / bc1) * (mi / (sqrt(vi) / bc2s + eps));
+}
+
 }  // namespace ndq
 
 using namespace ndq;
@@ -115,6 +131,15 @@ int ndq64_reduce_partials(const double* partials, int nparts, int len, double* o
   if (!partials || !out || nparts <= 0 || len <= 0) return NDQ_EINVAL;
   hipLaunchKernelGGL(reduce_partials64_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
                      partials, nparts, len, out, accumulate, scale);
+  return (int)hipGetLastError();
+}
+
+int ndq64_adam_step(double* params, const double* grad, double* exp_avg, double* exp_avg_sq, int len, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, int step, void* stream) {
+  if (!params || !grad || !exp_avg || !exp_avg_sq || len <= 0 || step <= 0) return NDQ_EINVAL;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2s = sqrt(1.0 - pow(beta2, (double)step));
+  hipLaunchKernelGGL(adam64_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), params, grad,
+                     exp_avg, exp_avg_sq, len, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
   return (int)hipGetLastError();
 }
 

@@ -48,8 +48,6 @@ class FusedAdam(torch.optim.Adam):
             groups = {id(group_of.get(id(p))) for p in fp.params}
             if len(groups) != 1 or None in [group_of.get(id(p)) for p in fp.params]:
                 continue                        # not (entirely) ours, or split across groups: leave to torch
-            if fp.grad.dtype != torch.float32:
-                continue                        # fp64 systems: stock Adam on the parameters (ndq_adam_step is fp32)
             group = group_of[id(fp.params[0])]
             m = torch.zeros_like(fp.grad)
             v = torch.zeros_like(fp.grad)
@@ -101,7 +99,6 @@ class FusedAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        L = _lib.lib() if self._bound else None
         fused = set()
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if self._bound else None
         for fp, m, v, group in self._bound:
@@ -110,8 +107,10 @@ class FusedAdam(torch.optim.Adam):
             self._steps[id(fp)] += 1
             step = self._steps[id(fp)]
             b1, b2 = group["betas"]
-            rc = L.ndq_adam_step(fp.flat.data_ptr(), fp.grad.data_ptr(), m.data_ptr(), v.data_ptr(), fp.numel,
-                                 float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], step, stream)
+            f64 = fp.grad.dtype == torch.float64          # fp64 systems: the same kernel in double (libndq64.so)
+            adam = _lib.lib64().ndq64_adam_step if f64 else _lib.lib().ndq_adam_step
+            rc = adam(fp.flat.data_ptr(), fp.grad.data_ptr(), m.data_ptr(), v.data_ptr(), fp.numel,
+                      float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], step, stream)
             _lib.check(rc, "ndq_adam_step")
             for p in fp.params:
                 self.state[p]["step"] += 1
