@@ -311,11 +311,13 @@ def test_ensemble_condition_as_one_solver_function_trains_on_the_fused_path():
     assert np.linalg.norm(uv_f - uv_c) <= 2e-4 * np.linalg.norm(uv_c)
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3x", "pendulum", "helmholtz_xy", "stokes_like", "sigmoid_mixed", "kdv"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3x", "pendulum", "helmholtz_xy", "stokes_like", "sigmoid_mixed", "kdv",
+                                  "resnet_laplace", "swish_tr_laplace", "aptx_tr_resnet", "shape_20x3", "mono_ode", "ensemble_lv"])
 def test_fp64_pipeline_matches_autograd_oracle(name):
     """engine.FusedSystem(dtype=float64): forward streams (libndq64.so, f64 MFMA) -> the generated pointwise kernel
     compiled in double -> adjoint kernel -> fp64 sums, against the fp64 autograd oracle at 1e-9 (C1, C2, a 32-wide C3 and
-    zoo systems: first order only, full Hessian, three networks, sigmoid, third-order streams)."""
+    zoo systems: first order only, full Hessian, three networks, sigmoid, third-order streams, Laplacian-merged stream, skip
+    connection, trainable activation parameters, a width that is no multiple of 16, monomial features, a two-column function)."""
     from tests import configs, zoo
     from neurodiffeq_amd.engine import FusedSystem
     torch.manual_seed(11)
