@@ -883,7 +883,7 @@ def ensure_mlp_kernels(desc, f64=False):
     register = L.ndq64_mlp_register if f64 else L.ndq_mlp_register
     if supported(ctypes.byref(desc)):
         return True
-    if not mlp_ext_allowed(desc) or (f64 and desc.hidden > 32):     # fp64: twice the LDS per weight -- widths up to 32
+    if not mlp_ext_allowed(desc) or (f64 and desc.hidden > 64):     # fp64: twice the LDS per weight -- ndq64_mlp_register turns down what does not fit
         return False
     key = desc.key() + (("f64",) if f64 else ())
     if key in _MLP_EXT:

@@ -312,7 +312,8 @@ def test_ensemble_condition_as_one_solver_function_trains_on_the_fused_path():
 
 
 @pytest.mark.parametrize("name", ["c1", "c2", "c3x", "pendulum", "helmholtz_xy", "stokes_like", "sigmoid_mixed", "kdv",
-                                  "resnet_laplace", "swish_tr_laplace", "aptx_tr_resnet", "shape_20x3", "mono_ode", "ensemble_lv"])
+                                  "resnet_laplace", "swish_tr_laplace", "aptx_tr_resnet", "shape_20x3", "mono_ode", "ensemble_lv",
+                                  "shape_48x2", "shape_64x2"])
 def test_fp64_pipeline_matches_autograd_oracle(name):
     """engine.FusedSystem(dtype=float64): forward streams (libndq64.so, f64 MFMA) -> the generated pointwise kernel
     compiled in double -> adjoint kernel -> fp64 sums, against the fp64 autograd oracle at 1e-9 (C1, C2, a 32-wide C3 and
