@@ -332,7 +332,8 @@ class BaseSolver(ABC):
             reason = "closure-based optimizer under data parallelism"
         # working precision = the networks' (fp64 is the reference's default, neurodiffeq/__init__.py:22: such systems run
         # the three-kernel pipeline on the fp64 build of the stream kernels)
-        dtypes = {p.dtype for n in self.nets for p in n.parameters()}
+        # (first parameter of every network: this runs every epoch; describe() checks the rest when the system is built)
+        dtypes = {next(iter(n.parameters())).dtype for n in self.nets}
         sys_dtype = torch.float64 if dtypes == {torch.float64} else torch.float32
         if sys_dtype == torch.float64 and self.dist is not None:
             reason = "fp64 networks under data parallelism"
