@@ -333,7 +333,7 @@ class BaseSolver(ABC):
         # working precision = the networks' (fp64 is the reference's default, neurodiffeq/__init__.py:22: such systems run
         # the three-kernel pipeline on the fp64 build of the stream kernels)
         # (first parameter of every network: this runs every epoch; describe() checks the rest when the system is built)
-        dtypes = {next(iter(n.parameters())).dtype for n in self.nets}
+        dtypes = {p.dtype for p in (next(iter(n.parameters()), None) for n in self.nets) if p is not None}
         sys_dtype = torch.float64 if dtypes == {torch.float64} else torch.float32
         if sys_dtype == torch.float64 and self.dist is not None:
             reason = "fp64 networks under data parallelism"
