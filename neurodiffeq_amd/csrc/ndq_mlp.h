@@ -276,6 +276,12 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 #ifndef NDQ_WIDE_LAUNDER
 #define NDQ_WIDE_LAUNDER 1
 #endif
+#ifndef NDQ_WG_BF16
+#define NDQ_WG_BF16 0     // narrow nets: weight-gradient GEMMs on the bf16 matrix core (split operands) instead of f32 MFMAs
+#endif
+#ifndef NDQ_WG32
+#define NDQ_WG32 1        // wide nets: weight-gradient GEMMs as split-operand v_mfma_f32_32x32x16_bf16 (one stream per instruction)
+#endif
 #ifndef NDQ_ABL
 #define NDQ_ABL 0
 #endif
@@ -501,7 +507,16 @@ struct Cfg {
   static constexpr int ldsWeightsEnd(bool bwd) { return (ldsAlpha(bwd) + (ALPHA ? L : 0) + 3) & ~3; }
   // weight-gradient transposes: streams staged per barrier round (narrow nets: two at a time, so that the LDS round
   // trip of one stream hides behind the MFMAs of the other; wide nets: no LDS to spare)
-  static constexpr int WG_SB = (NB_ <= 2 && SS::NS >= 2 && BWD_THREADS == 256) ? 2 : 1;
+  // WG_BF16 (narrow nets on the bf16x3 path): the weight-gradient GEMM dW += sum_s Zbar_s H_s^T runs on
+  // v_mfma_f32_16x16x32_bf16 as well -- one instruction contracts over 32 slots = 2 streams x 16 points, so two streams
+  // are staged per round; 6 split products of 16 cycles replace 16 exact-f32 MFMAs of 32 cycles per pair of 16x16 blocks
+  static constexpr bool WG_BF16 = BF16 && (NB_ <= 2) && (NDQ_WG_BF16 != 0);
+  // WG32 (wide nets, H = 64): the hidden-layer weight gradients on v_mfma_f32_32x32x16_bf16 -- K = 16 is exactly the 16
+  // points of ONE stream, so no second stream has to be staged (there is no LDS left for it); per stream 4 macro-blocks
+  // x 6 split products of 32 cycles (768) replace 64 exact-f32 MFMAs of 32 cycles (2 048); the accumulators are 32x32
+  // blocks (GradAcc::w32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+  static constexpr bool WG32 = BF16 && (NB_ == 4) && (NDQ_WG32 != 0);
+  static constexpr int WG_SB = (NB_ <= 2 && SS::NS >= 2 && (BWD_THREADS == 256 || WG_BF16)) ? 2 : 1;
   static constexpr int stageFloatsPerWave = WG_SB * 2 * 16 * HP;  // Zt and Ht tiles of WG_SB streams
 };
 
@@ -702,6 +717,7 @@ __device__ __forceinline__ void load_alpha(const real* lds, int l, LayerState<C>
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 // bf16x3 planes of all streams of one fragment set: pl[s][c][k], k = 0 (high) .. 2 (low)
 template <class C>
 struct Planes {
@@ -1445,6 +1461,7 @@ struct GradAcc {
   real w1[C::NIN][C::NB][4];        // dW1[j][a], j = 16b+4q+r   (needs point_sum; MONO: a runs over the NIN features)
   real b1[C::NB][4];                // db1[j]                    (needs point_sum)
   real4 w[C::L > 1 ? C::L - 1 : 1][C::NB][C::NB];  // dW_l[16jb+4q+r][16kb+p], MFMA accumulators (already summed)
+  f32x16 w32[C::L > 1 ? C::L - 1 : 1][2][2];       // WG32: the same as 32x32 blocks (w is then unused)
   real b[C::L > 1 ? C::L - 1 : 1][C::NB][4];      // db_l[j]     (needs point_sum)
   real wout[C::NB][4];              // NOUT == 1: dWout[j]       (needs point_sum)
   real bout;                        // NOUT == 1: dbout          (needs full wave sum)
@@ -1486,10 +1503,10 @@ __device__ __forceinline__ void reload_first_layer_streams(const real* lds, int 
 // stage: per-wave region of 2*16*HP floats.  Point <-> MFMA k mapping: k = q at step st  <->  point 4*q + st,
 // which makes both the b128 writes (8-lane groups: bank stride 4*(HP mod 8) ... HP = H+4 -> 16 B apart) and the b32
 // reads (32-lane groups: q*4*HP = 16 banks apart) conflict-free.
-template <class C, int NBA>
+template <class C, int NBA, bool HIDDEN = false>
 __device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q, const real4 (&zb)[C::NS][NBA],
                                             const LayerState<C>& st_in, real4 (&acc)[NBA][C::NB],
-                                            const real4 (*hkept)[C::NB] = nullptr) {
+                                            const real4 (*hkept)[C::NB] = nullptr, f32x16 (*acc32)[2] = nullptr) {
   constexpr int HP = C::HP, SB = C::WG_SB;
   constexpr int NR = (C::NS + SB - 1) / SB;           // barrier rounds
   if constexpr ((NDQ_ABL & 1) != 0) return;
@@ -1517,6 +1534,76 @@ __device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (C::WG32 && HIDDEN) {
+      // one stream is staged (SB = 1).  Lane (i = lane & 31, g = lane >> 5) of an operand holds unit 32 blk + i at the 8
+      // points 8 g + e: slot 8 g + e of the 16-wide contraction on both operands.
+      static_assert(SB == 1, "WG32 stages one stream per round");
+      const int i32 = lane & 31, g8 = 8 * (lane >> 5);
+      const real* Zt = stage + g8 * HP + i32;
+      const real* Ht = Zt + 16 * HP;
+      auto planes_of = [&](const real* t, int blk, bf16x8 (&pl)[3]) {
+        real x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = t[e * HP + 32 * blk];
+        split3(real4{x[0], x[1], x[2], x[3]}, real4{x[4], x[5], x[6], x[7]}, pl);
+      };
+      bf16x8 pb[2][3];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) planes_of(Ht, b, pb[b]);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        bf16x8 pa[3];
+        planes_of(Zt, jb, pa);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#define NDQ_W(I, J) acc32[jb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[I], pb[kb][J], acc32[jb][kb], 0, 0, 0);
+          NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+#undef NDQ_W
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      return;
+    }
+    if constexpr (C::WG_BF16) {
+      // contraction slot 8 kg + e of the 32-wide bf16 MFMA <-> stream s0 + (kg >> 1), point (e & 3) + 8 (e >> 2) + 4 (kg & 1)
+      // (the same map on both operands; this point order keeps the b32 reads of the two lane groups of a half-wave
+      // 16 banks apart: 4 HP = 16 mod 32).  A lane therefore reads 8 points of ONE unit of ONE stream per block,
+      // splits them into three bf16 planes, and the six significant plane products go through the matrix core.
+      const int kg = lane >> 4;
+      const bool live = sn == 2 || (kg >> 1) < sn; // a round with one stream: the upper half of the slots is zero
+      const real* Zt = stage + (live ? (kg >> 1) : 0) * 2 * 16 * HP + (4 * (kg & 1)) * HP + (lane & 15);
+      const real* Ht = Zt + 16 * HP;
+      auto planes_of = [&](const real* t, int b, bf16x8 (&pl)[3]) {
+        real x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const real v = t[((e & 3) + 8 * (e >> 2)) * HP + 16 * b];
+          if constexpr (sn == 2) x[e] = v;
+          else x[e] = live ? v : 0.f;
+        }
+        split3(real4{x[0], x[1], x[2], x[3]}, real4{x[4], x[5], x[6], x[7]}, pl);
+      };
+      bf16x8 pb[C::NB][3];
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b) planes_of(Ht, b, pb[b]);
+#pragma unroll
+      for (int jb = 0; jb < NBA; ++jb) {
+        bf16x8 pa[3];
+        planes_of(Zt, jb, pa);
+#pragma unroll
+        for (int kb = 0; kb < C::NB; ++kb) {
+#define NDQ_W(I, J) acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[I], pb[kb][J], acc[jb][kb], 0, 0, 0);
+          NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+#undef NDQ_W
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      return;
+    }
     // all operands of the round are read into registers of their own BEFORE the first MFMA: one LDS round trip per
     // round instead of one per k-step (the compiler otherwise recycles four registers and waits 16 times per stream)
     if constexpr (C::BWD_THREADS != 256) {
@@ -1615,6 +1702,16 @@ __device__ __forceinline__ void acc_zero(GradAcc<C>& acc) {
     for (int jb = 0; jb < C::NB; ++jb)
 #pragma unroll
       for (int kb = 0; kb < C::NB; ++kb) acc.w[l][jb][kb] = real4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (C::WG32) {
+#pragma unroll
+    for (int l = 0; l < C::L - 1; ++l)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc.w32[l][jb][kb][e] = 0.f;
+  }
   acc.bout = 0.f;
 #pragma unroll
   for (int d = 0; d < C::D; ++d) acc.skip[d] = 0.f;
@@ -1802,12 +1899,12 @@ __device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stag
     }
     if constexpr (C::WIDE && li == 1) reload_first_layer_streams<C>(lds, q, st[0]);   // needed from here on again
     if constexpr (C::BF16) {
-      weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);
+      weight_grad<C, C::NB, true>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0], acc.w32[l - 2]);
       NDQ_TT(6 + 3 * (C::L - l));
       if constexpr ((NDQ_ABL & 2) == 0) gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);
       NDQ_TT(7 + 3 * (C::L - l));
     } else {
-      weight_grad<C, C::NB>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0]);   // inputs of layer l
+      weight_grad<C, C::NB, true>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0], acc.w32[l - 2]);   // inputs of layer l
       gemm_frag_inplace<C>(lds + C::ldsWt(l), lane, g);
     }
   });
@@ -1960,6 +2057,20 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
             }
           }
         }
+      if constexpr (C::WG32) {
+#pragma unroll
+        for (int l = 0; l < C::L - 1; ++l)
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const int j = 32 * jb + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), k = 32 * kb + (lane & 31);
+                if (!C::RAGGED || (j < C::hr(l + 2) && k < C::hr(l + 1)))
+                  put(C::offW(l + 2) + j * C::hr(l + 1) + k, acc.w32[l][jb][kb][e]);
+              }
+      } else {
 #pragma unroll
       for (int l = 0; l < C::L - 1; ++l)
 #pragma unroll
@@ -1972,6 +2083,7 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
               if (!C::RAGGED || (j < C::hr(l + 2) && k < C::hr(l + 1)))
                 put(C::offW(l + 2) + j * C::hr(l + 1) + k, acc.w[l][jb][kb][r]);
             }
+      }
       if constexpr (C::NOUT == 1) {
         if (lane == 0) {
           put(C::offbout, bsum);
