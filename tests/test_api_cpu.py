@@ -323,3 +323,44 @@ def test_solver_plumbing_on_cpu():
     lb.optimizer = torch.optim.LBFGS(lb.nets[0].parameters(), max_iter=2)
     lb.fit(1, tqdm_file=None)                                # closure-based optimiser steps per batch
     assert len(lb.metrics_history["train_loss"]) == 1
+
+
+def test_describe_recognises_the_network_family():
+    """networks.describe(): what the gfx950 kernels are asked to run for each member of the reference's network family
+    (networks.py:26-209) -- widths, skip, activation parameters, monomial front end -- and what they turn down."""
+    from functools import partial
+    import torch.nn as nn
+    from neurodiffeq_amd.networks import FCNN, Resnet, MonomialNN, Swish, APTx, SinActv, describe, FlatParams
+    d = describe(FCNN(2, 1))
+    assert (d["d"], d["hidden"], d["layers"], d["n_out"], d["skip"], d["actp"], d["widths"], d["mono"]) == (2, 32, 2, 1, 0, 0, 0, 0)
+    d = describe(FCNN(2, 3, hidden_units=(50, 50, 50), actv=SinActv))
+    assert (d["hidden"], d["layers"], d["n_out"], d["widths"], d["act"]) == (50, 3, 3, 0, 1)
+    d = describe(FCNN(1, 1, hidden_units=(64, 32, 16)))
+    assert d["hidden"] == 64 and d["widths"] == 64 | (32 << 8) | (16 << 16)
+    d = describe(Resnet(2, 5, hidden_units=(32, 32)))
+    assert d["skip"] == 1 and d["n_out"] == 5 and d["params"][-1].shape == (5, 2)
+    net = FCNN(2, 1, actv=partial(Swish, trainable=True))
+    d = describe(net)
+    assert d["actp"] == 1 and len(d["params"]) == 6 + 2 and all(p.dim() == 0 for p in d["params"][-2:])
+    assert [id(p) for p in d["params"][-2:]] == [id(net.NN[1].beta), id(net.NN[3].beta)]       # behind the linear layers
+    d = describe(FCNN(2, 1, actv=partial(APTx, alpha=0.8, beta=1.3, gamma=0.6)))
+    assert d["actp"] == 2 and d["frozen"] == [0.8, 1.3, 0.6] * 2 and len(d["params"]) == 6
+    assert describe(FCNN(2, 1, actv=APTx))["actp"] == 0
+    d = describe(nn.Sequential(MonomialNN(3), FCNN(6, 1)))
+    assert (d["d"], d["mono"], d["hidden"]) == (2, 0b111, 32)
+    d = describe(nn.Sequential(MonomialNN([1, 3]), nn.Linear(2, 16), nn.Tanh(), nn.Linear(16, 2)))
+    assert (d["d"], d["mono"], d["hidden"], d["layers"], d["n_out"]) == (1, 0b101, 16, 1, 2)
+    # turned down: unsorted degrees, a feature count that is no multiple of the degree count, five hidden layers,
+    # mixed activations, a bias-free layer, fp64 parameters under an fp32 description
+    assert describe(nn.Sequential(MonomialNN([2, 1]), FCNN(2, 1))) is None
+    assert describe(nn.Sequential(MonomialNN(3), FCNN(5, 1))) is None
+    assert describe(FCNN(1, 1, hidden_units=(16,) * 5)) is None
+    assert describe(nn.Sequential(nn.Linear(1, 16), nn.Tanh(), nn.Linear(16, 16), nn.Sigmoid(), nn.Linear(16, 1))) is None
+    assert describe(nn.Sequential(nn.Linear(1, 16, bias=False), nn.Tanh(), nn.Linear(16, 1))) is None
+    assert describe(FCNN(1, 1).double()) is None and describe(FCNN(1, 1).double(), dtype=torch.float64) is not None
+    # FlatParams: parameters become views of ONE flat buffer in the kernels' order, fixed activation scalars behind them
+    net = FCNN(2, 1, actv=partial(Swish, beta=1.7))
+    fp = FlatParams(net, "cpu")
+    assert fp.numel == sum(p.numel() for p in net.parameters()) and fp.flat.numel() == fp.numel + 2
+    assert fp.flat[-2:].tolist() == [1.7000000476837158, 1.7000000476837158]
+    assert all(p.data_ptr() == fp.flat.data_ptr() + 4 * off for p, off in zip(fp.params, fp._offsets))
