@@ -279,6 +279,10 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 #ifndef NDQ_WG_BF16
 #define NDQ_WG_BF16 0     // narrow nets: weight-gradient GEMMs on the bf16 matrix core (split operands) instead of f32 MFMAs
 #endif
+#ifndef NDQ_SPLIT_PAIRS
+#define NDQ_SPLIT_PAIRS 0   // split3 on 2-wide vectors: 3.5 % fewer VALU instructions in C3's closure kernel, no time gained
+                            // (C3 418.4 -> 419.8 us, C2 8-wave 19.9 -> 19.7 us on MI355X): off
+#endif
 #ifndef NDQ_WG32
 #define NDQ_WG32 1        // wide nets: weight-gradient GEMMs as split-operand v_mfma_f32_32x32x16_bf16 (one stream per instruction)
 #endif
@@ -939,6 +943,23 @@ __device__ __forceinline__ void split3(const real4 a, const real4 b, bf16x8 (&pl
     for (int e = 0; e < 8; ++e) { pl[0][e] = (__bf16)x[e]; pl[1][e] = pl[0][e]; pl[2][e] = pl[0][e]; }
     return;
   }
+#if NDQ_SPLIT_PAIRS && !NDQ_F64
+  // two values at a time on 2-wide vector types: one v_cvt_pk_bf16_f32 per pair and plane, packed subtractions
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 v = {x[2 * k], x[2 * k + 1]};
+    const bf16x2 h0 = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(h0, f32x2);
+    const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(h1, f32x2);
+    const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
+    pl[0][2 * k] = h0[0]; pl[0][2 * k + 1] = h0[1];
+    pl[1][2 * k] = h1[0]; pl[1][2 * k + 1] = h1[1];
+    pl[2][2 * k] = h2[0]; pl[2][2 * k + 1] = h2[1];
+  }
+#else
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const __bf16 h0 = (__bf16)x[e];
@@ -947,6 +968,7 @@ __device__ __forceinline__ void split3(const real4 a, const real4 b, bf16x8 (&pl
     const __bf16 h2 = (__bf16)(r1 - (real)h1);
     pl[0][e] = h0; pl[1][e] = h1; pl[2][e] = h2;
   }
+#endif
 }
 
 template <class C>
