@@ -5,12 +5,13 @@ import math
 import torch
 
 from neurodiffeq_amd import diff
+from functools import partial
 from neurodiffeq_amd.conditions import (IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis, BundleIVP,
-                                        DirichletBVPSpherical, DoubleEndedBVP1D)
+                                        DirichletBVPSpherical, DoubleEndedBVP1D, EnsembleCondition)
 from neurodiffeq_amd.function_basis import RealSphericalHarmonics
 from neurodiffeq_amd.generators import Generator1D, Generator2D, GeneratorSpherical
 from neurodiffeq_amd.operators import spherical_laplacian
-from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx, Resnet
+from neurodiffeq_amd.networks import FCNN, SinActv, Swish, APTx, Resnet, MonomialNN
 
 PI = math.pi
 DEFAULT_SIZE = {"c1": 1024, "c2": 256, "c3": 512, "c5": 1024, "c4": 131072}
@@ -111,6 +112,24 @@ def make(name, size=None):
                  DoubleEndedBVP1D(0.0, 1.0, x_min_val=1.0, x_max_prime=0.5)]
         return dict(kind="1d", pde=pde, nets=nets, conds=conds, gen=Generator1D(48, 0.0, 1.0, "equally-spaced-noisy"),
                     n_points=48, dom=(0.0, 1.0))
+    if name in ("w11", "w12", "w13"):      # network family on the C2 problem (goldens w11 - w13)
+        c = make("c2", 12)
+        c["nets"] = [{"w11": lambda: FCNN(2, 1, hidden_units=(32, 32), actv=partial(Swish, beta=1.25, trainable=True)),
+                      "w12": lambda: Resnet(2, 1, hidden_units=(50, 30)),
+                      "w13": lambda: torch.nn.Sequential(MonomialNN(3), FCNN(6, 1, hidden_units=(32, 32)))}[name]()]
+        return c
+    if name == "w14":     # Lotka-Volterra on ONE two-output network under EnsembleCondition: a single two-column function
+        def ode(uv, t):
+            u, v = uv[:, 0:1], uv[:, 1:2]
+            return [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)]
+        return dict(kind="1d", pde=ode, nets=[FCNN(1, 2, hidden_units=(32, 32), actv=SinActv)],
+                    conds=[EnsembleCondition(IVP(0.0, 1.5), IVP(0.0, 1.0))],
+                    gen=Generator1D(64, 0.1, 4.0, "equally-spaced-noisy"), n_points=64, dom=(0.1, 4.0))
+    if name == "w15":     # APTx with trainable alpha, beta, gamma on a second-order ODE
+        pde = lambda u, t: [diff(u, t, order=2) + 0.5 * diff(u, t) + u - torch.cos(t)]
+        return dict(kind="1d", pde=pde, nets=[FCNN(1, 1, hidden_units=(32, 32), actv=partial(APTx, trainable=True))],
+                    conds=[IVP(0.0, 1.0, u_0_prime=0.5)], gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"),
+                    n_points=48, dom=(0.0, 2.0))
     if name == "w5":      # Resnet on the C2 problem
         c = make("c2", 12)
         c["nets"] = [Resnet(2, 1, hidden_units=(32, 32))]

@@ -28,9 +28,10 @@ import torch
 import neurodiffeq  # noqa: E402  (sets default dtype fp64 + default device as an import side effect)
 from neurodiffeq import diff
 from neurodiffeq.utils import set_tensor_type
-from neurodiffeq.networks import FCNN, SinActv, Swish, APTx, Resnet
+from functools import partial
+from neurodiffeq.networks import FCNN, SinActv, Swish, APTx, Resnet, MonomialNN
 from neurodiffeq.conditions import (IVP, DirichletBVP2D, IBVP1D, NoCondition, DirichletBVPSphericalBasis, BundleIVP,
-                                    DirichletBVPSpherical, DoubleEndedBVP1D)
+                                    DirichletBVPSpherical, DoubleEndedBVP1D, EnsembleCondition)
 from neurodiffeq.generators import Generator1D, Generator2D, GeneratorSpherical
 from neurodiffeq.solvers import Solver1D, Solver2D, SolverSpherical, BundleSolver1D
 from neurodiffeq.function_basis import RealSphericalHarmonics
@@ -203,9 +204,49 @@ def cfg_w10():
                 t=(0.0, 2.0))
 
 
+def cfg_w11():
+    """Swish with a TRAINABLE beta per layer (networks.py:166-169), started off its default, on the C2 problem."""
+    c = cfg_c2(12)
+    c["nets"] = [FCNN(2, 1, hidden_units=(32, 32), actv=partial(Swish, beta=1.25, trainable=True))]
+    return c
+
+
+def cfg_w12():
+    """Resnet with hidden layers of different widths, neither a multiple of 16, on the C2 problem."""
+    c = cfg_c2(12)
+    c["nets"] = [Resnet(2, 1, hidden_units=(50, 30))]
+    return c
+
+
+def cfg_w13():
+    """MonomialNN (networks.py:109-139) in front of an FCNN: features x, y, x^2, y^2, x^3, y^3, on the C2 problem."""
+    c = cfg_c2(12)
+    c["nets"] = [torch.nn.Sequential(MonomialNN(3), FCNN(6, 1, hidden_units=(32, 32)))]
+    return c
+
+
+def cfg_w14():
+    """Lotka-Volterra on ONE two-output network under EnsembleCondition (conditions.py:157-202): a single solver function
+    whose columns the equations pick apart."""
+    def ode(uv, t):
+        u, v = uv[:, 0:1], uv[:, 1:2]
+        return [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)]
+    nets = [FCNN(1, 2, hidden_units=(32, 32), actv=SinActv)]
+    conds = [EnsembleCondition(IVP(0.0, 1.5), IVP(0.0, 1.0))]
+    return dict(kind="1d", pde=ode, nets=nets, conds=conds, gen=Generator1D(64, 0.1, 4.0, "equally-spaced-noisy"), t=(0.1, 4.0))
+
+
+def cfg_w15():
+    """APTx with TRAINABLE alpha, beta, gamma per layer (networks.py:196-203) on a second-order ODE."""
+    ode = lambda u, t: [diff(u, t, order=2) + 0.5 * diff(u, t) + u - torch.cos(t)]
+    nets = [FCNN(1, 1, hidden_units=(32, 32), actv=partial(APTx, trainable=True))]
+    return dict(kind="1d", pde=ode, nets=nets, conds=[IVP(0.0, 1.0, u_0_prime=0.5)],
+                gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"), t=(0.0, 2.0))
+
+
 CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
            "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5, "w6": cfg_w6, "w7": cfg_w7, "w8": cfg_w8,
-           "w9": cfg_w9, "w10": cfg_w10}
+           "w9": cfg_w9, "w10": cfg_w10, "w11": cfg_w11, "w12": cfg_w12, "w13": cfg_w13, "w14": cfg_w14, "w15": cfg_w15}
 
 
 # ----------------------------------------------------------------------------- helpers

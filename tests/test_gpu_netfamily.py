@@ -394,3 +394,54 @@ def test_fused_solver_under_a_cuda_default_device():
             set_tensor_type(device="cpu", float_bits=32)
     got, want = run(True), run(False)
     assert np.allclose(got, want, rtol=1e-6), (got, want)
+
+
+# ------------------------------------------------------------------------------------------------ reference goldens
+# w11 trainable Swish, w12 Resnet with hidden widths (50, 30), w13 MonomialNN front end, w14 EnsembleCondition on one
+# two-output network, w15 trainable APTx: closures and 3-epoch trajectories produced by the UNMODIFIED reference
+# (tests/golden/make_golden.py) -- the same pinning the BASELINE configs and w1 - w10 have.
+GOLDEN_FAMILY = ["w11", "w12", "w13", "w14", "w15"]
+
+
+@pytest.mark.parametrize("mode", ["1k", "3k"])
+@pytest.mark.parametrize("name", GOLDEN_FAMILY)
+def test_network_family_closure_matches_reference_golden(golden_dir, name, mode):
+    from tests import configs
+    from neurodiffeq_amd.engine import FusedSystem
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(0)
+    cfg = configs.make(name, None)
+    for net in cfg["nets"]:
+        net.to("cuda")
+    fs = FusedSystem(cfg["nets"], cfg["conds"], configs.fused_equations(cfg), configs.n_coords(cfg), "cuda",
+                     compute_func_val=configs.func_val(cfg), single_kernel=(mode == "1k"))
+    assert (fs.fusedk is not None) == (mode == "1k")
+    R.set_flat(cfg["nets"], torch.from_numpy(gold["params0"]))
+    b, n = fs.step([torch.from_numpy(c) for c in gold["coords"]], train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), gold["funcs_f64"]),
+                residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy()[:, :gold["residuals_f64"].shape[1]], gold["residuals_f64"]),
+                loss=abs(fs.loss_buf[0].item() - float(gold["loss_f64"])) / abs(float(gold["loss_f64"])),
+                grad=rel_l2(_grad_in_torch_order(cfg["nets"], fs.flat), gold["grad_f64"]))
+    assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize("name", GOLDEN_FAMILY)
+def test_network_family_solver_trajectory_matches_reference_golden(golden_dir, name):
+    """Three epochs of Solver.run_train_epoch (CPU RNG sampling, fused step, device-side Adam over the whole flat vector --
+    activation scalars, skip weights included) against the reference solver's loss history and final parameters."""
+    from tests import configs
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    solver, cfg = configs.make_solver(name, None)
+    solver.fused = "require"
+    assert np.array_equal(R.get_flat(cfg["nets"]).cpu().numpy(), gold["params0"])
+    torch.manual_seed(int(gold["seed"]) + 2)
+    for _ in range(3):
+        solver.run_train_epoch()
+    assert solver.fused_active
+    hist = np.array(solver.metrics_history["train_loss"])
+    params = R.get_flat(cfg["nets"]).cpu().numpy()
+    errs = dict(loss=float(np.max(np.abs(hist - gold["traj_loss"]) / np.abs(gold["traj_loss"]))),
+                params=rel_l2(params, gold["traj_params"]))
+    assert errs["loss"] < 2e-5 and errs["params"] < 1e-5, (errs, hist, gold["traj_loss"])
