@@ -445,3 +445,28 @@ def test_network_family_solver_trajectory_matches_reference_golden(golden_dir, n
     errs = dict(loss=float(np.max(np.abs(hist - gold["traj_loss"]) / np.abs(gold["traj_loss"]))),
                 params=rel_l2(params, gold["traj_params"]))
     assert errs["loss"] < 2e-5 and errs["params"] < 1e-5, (errs, hist, gold["traj_loss"])
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c4", "w1", "w2", "w3", "w4", "w5", "w6", "w7", "w8", "w9", "w10", "w11", "w12", "w13",
+                                  "w14", "w15"])
+def test_fp64_pipeline_matches_reference_golden(golden_dir, name):
+    """The fp64 pipeline against numbers the unmodified reference produced IN ITS DEFAULT PRECISION: every golden file
+    holds the closure evaluated in fp64 on fp32-representable inputs (``funcs_f64`` ... ``grad_f64``).  1e-9 -- three
+    orders below what fp32 arithmetic anywhere in the pipeline would leave.  (C3 / C5: 64 x 3 layers do not fit LDS in double.)"""
+    from tests import configs
+    from neurodiffeq_amd.engine import FusedSystem
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(0)
+    cfg = configs.make(name, {"c1": 64, "c2": 16, "c4": 96}.get(name))
+    for net in cfg["nets"]:
+        net.double().to("cuda")
+    R.set_flat(cfg["nets"], torch.from_numpy(gold["params0"]).double())
+    fs = FusedSystem(cfg["nets"], cfg["conds"], configs.fused_equations(cfg), configs.n_coords(cfg), "cuda",
+                     compute_func_val=configs.func_val(cfg), dtype=torch.float64)
+    b, n = fs.step([torch.from_numpy(c).double() for c in gold["coords"]], train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), gold["funcs_f64"]),
+                residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy()[:, :gold["residuals_f64"].shape[1]], gold["residuals_f64"]),
+                loss=abs(fs.loss_buf[0].item() - float(gold["loss_f64"])) / abs(float(gold["loss_f64"])),
+                grad=rel_l2(_grad_in_torch_order(cfg["nets"], fs.flat), gold["grad_f64"]))
+    assert max(errs.values()) < 1e-9, errs
