@@ -192,6 +192,44 @@ typedef int (*ndq_fused_launch_multi_fn)(const float* coords, int ldc, int n, co
 int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_launch_multi_fn launch,
                              const float* coords, int adam_step, int hist_index, int parity, void* stream);
 
+/* ---- fit(): several epochs of (training epoch, validation epoch) from ONE native call -------------------------------
+ * The reference's fit loop (solvers.py:443-497) alternates run_train_epoch / run_valid_epoch and returns to Python after
+ * each; at its default sizes (32 .. 1 024 points, solvers.py:1083-1086, 1501-1504) that host round trip costs several
+ * times the kernels.  ndq_fused_fit_run enqueues n_epochs epochs back to back, two launches per epoch:
+ *   1. closure launch: the training closure of epoch e on train_coords[e] AND -- spare workgroups of the same launch --
+ *      the forward-only closure on the validation batch, both with the parameters epoch e starts from (= the parameters
+ *      epoch e - 1's validation epoch is defined on, solvers.py:484-485);
+ *   2. sums + tail launch: second-stage sums, training loss -> loss_hist[hist_index + e], validation loss of epoch e - 1
+ *      -> valid_hist[valid_index + e - 1], best-network snapshot of the PRE-update parameters (solvers.py:434-441), Adam.
+ * After the last epoch the validation batch is evaluated once more on its own (closure launch without training
+ * workgroups + tail without Adam).  n_epochs = 0 with a validation batch is one stand-alone validation epoch,
+ * n_epochs = 1 without one a stand-alone training epoch: the per-epoch entry points of the Solver run the SAME device
+ * code, so a loss history does not depend on how its epochs were grouped into calls (bit for bit). */
+typedef int (*ndq_fused_launch_tv_fn)(const float* coords, int ldc, int n, const float* const* params,
+                                      float* const* partials, float* loss_partials, float seed,
+                                      const float* valid_coords, int valid_ldc, int valid_n,
+                                      float* valid_loss_partials, void* stream);
+typedef struct ndq_fused_fit {
+  ndq_fused_launch_tv_fn launch;   /* exported by the generated closure kernel module as ndq_fused_launch_tv */
+  int n_nets;                      /* 1..4 networks behind the one closure launch */
+  /* per network: params, partials, grad, loss_slot, n_params, Adam state and hyper-parameters, best_flat;
+   * n / ldc / blocks / seed / loss_partials / loss_hist / best_loss are read from net[0]; launch / allreduce / comm /
+   * next_* of the entries are ignored */
+  ndq_fused_step net[4];
+  const float* valid_coords;       /* [d][valid_ldc] resident validation batch; NULL: no validation epochs */
+  int valid_n, valid_ldc, valid_blocks;
+  float valid_scale;               /* 1 / (valid_n * n_eq): validation loss = valid_scale * sum of the block partials */
+  float* valid_loss_partials;      /* [valid_blocks] */
+  float* valid_hist;               /* ring of validation-epoch losses */
+  int track_best;                  /* 0: no snapshot, 1: lowest TRAINING loss (n_batches_valid = 0, solvers.py:414-415),
+                                      2: lowest VALIDATION loss */
+} ndq_fused_fit;
+/* train_coords: HOST array of n_epochs device pointers, the [d][ldc] batch of every epoch.  adam_step: step count AFTER
+ * the first update (epoch e uses adam_step + e).  parity: slot of best_loss[2] holding the current best; every tail
+ * launch (n_epochs of them, + 1 with a validation batch) flips it. */
+int ndq_fused_fit_run(const ndq_fused_fit* f, int n_epochs, const float* const* train_coords, int adam_step,
+                      int hist_index, int valid_index, int parity, void* stream);
+
 /* Signature of a generated pointwise kernel launcher (one per traced PDE system, built by
  * neurodiffeq_amd/codegen.py with hipcc).  It evaluates the condition re-parameterisation (conditions.py
  * `parameterize`), the user's residuals (`diff_eqs`, solvers.py:380), the squared-residual partial sums

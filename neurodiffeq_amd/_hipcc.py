@@ -136,12 +136,53 @@ def _run(cmd, what):
         raise RuntimeError(f"{what} failed:\n{' '.join(cmd)}\n{proc.stderr[-6000:]}")
 
 
-def compile_shared(sources, out, extra_flags=(), verbose=False):
+_POOL = None          # (executor, [futures]) while a ``deferred`` block is active
+_JOBS = int(os.environ.get("NDQ_BUILD_JOBS", 0)) or (os.cpu_count() or 4)
+
+
+class deferred:
+    """``with _hipcc.deferred():`` -- inside the block, ``compile_shared(..., defer=True)`` only QUEUES the build on a pool
+    of NDQ_BUILD_JOBS (default: all cores) worker threads (the work happens in hipcc / clang subprocesses) and returns
+    at once; leaving the block waits for every queued build and raises the first failure.  ``__graft_entry__.build`` and
+    the first-use builds of a system's kernels (4-wave / 8-wave closure kernel, pointwise kernel) use it, so a full
+    build costs about (total compile time) / cores."""
+
+    def __enter__(self):
+        global _POOL
+        from concurrent.futures import ThreadPoolExecutor
+        self.prev = _POOL
+        _POOL = (ThreadPoolExecutor(max_workers=_JOBS), [], set())
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _POOL
+        pool, futures, _ = _POOL
+        _POOL = self.prev
+        errors = []
+        for f in futures:
+            try:
+                f.result()
+            except Exception as e:      # noqa: BLE001 -- collected, the first one is re-raised below
+                errors.append(e)
+        pool.shutdown()
+        if errors and exc_type is None:
+            raise errors[0]
+        return False
+
+
+def compile_shared(sources, out, extra_flags=(), verbose=False, defer=False):
     """Build ``out`` (a shared library holding host code + the gfx950 code object) from HIP sources.  Returns the number
-    of pk->mfma sites the fix-up pass separated.  Atomic: ``out`` is replaced only when everything succeeded."""
+    of pk->mfma sites the fix-up pass separated.  Atomic: ``out`` is replaced only when everything succeeded.
+    ``defer``: inside a ``deferred`` block, queue the build instead of running it (returns None)."""
+    if defer and _POOL is not None:
+        if out not in _POOL[2]:             # (several systems may share one generated kernel)
+            _POOL[2].add(out)
+            _POOL[1].append(_POOL[0].submit(compile_shared, sources, out, tuple(extra_flags), verbose))
+        return None
     sources = [sources] if isinstance(sources, str) else list(sources)
     flags = BASE_FLAGS + list(extra_flags)
-    work = f"{out}.build{os.getpid()}"
+    import threading
+    work = f"{out}.build{os.getpid()}_{threading.get_ident()}"
     os.makedirs(work, exist_ok=True)
     try:
         if not fixup_enabled():                       # experiments: the compiler's own output, one step

@@ -48,6 +48,14 @@ class FusedStep(ctypes.Structure):
                 ("next_stream", ctypes.c_uint), ("next_coords", ctypes.c_void_p), ("next_ldc", ctypes.c_int)]
 
 
+class FusedFit(ctypes.Structure):
+    """ndq_fused_fit of include/ndq.h"""
+    _fields_ = [("launch", ctypes.c_void_p), ("n_nets", ctypes.c_int), ("net", FusedStep * 4),
+                ("valid_coords", ctypes.c_void_p), ("valid_n", ctypes.c_int), ("valid_ldc", ctypes.c_int),
+                ("valid_blocks", ctypes.c_int), ("valid_scale", ctypes.c_float),
+                ("valid_loss_partials", ctypes.c_void_p), ("valid_hist", ctypes.c_void_p), ("track_best", ctypes.c_int)]
+
+
 class NdqError(RuntimeError):
     pass
 
@@ -82,6 +90,7 @@ def lib():
     L.ndq_epoch_tail.argtypes = [vp, vp, vp, vp, ci, cf, cf, cf, cf, cf, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp]
     L.ndq_fused_step_run.argtypes = [ctypes.POINTER(FusedStep), vp, ci, ci, ci, vp]
     L.ndq_fused_multi_step_run.argtypes = [ctypes.POINTER(FusedStep), ci, vp, vp, ci, ci, ci, vp]
+    L.ndq_fused_fit_run.argtypes = [ctypes.POINTER(FusedFit), ci, vp, ci, ci, ci, ci, vp]
     L.ndq_mlp_register.argtypes = [vp]
     L.ndq_sample.argtypes = [ctypes.POINTER(SamplerDesc), ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, vp, ci, vp]
     L.ndq_oneshot_create.argtypes = [ci, ci, ci, ctypes.POINTER(vp), ctypes.c_char_p]
@@ -92,7 +101,7 @@ def lib():
     for name in ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks",
                  "ndq_mlp_jet_fwd", "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss",
                  "ndq_epoch_tail", "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run",
-                 "ndq_oneshot_create", "ndq_oneshot_connect", "ndq_oneshot_allreduce", "ndq_oneshot_status",
+                 "ndq_fused_fit_run", "ndq_oneshot_create", "ndq_oneshot_connect", "ndq_oneshot_allreduce", "ndq_oneshot_status",
                  "ndq_oneshot_destroy"):
         getattr(L, name).restype = ci
     _LIB = L
@@ -137,8 +146,8 @@ EXPORTS64 = ("ndq64_mlp_register", "ndq64_mlp_supported", "ndq64_mlp_num_streams
 
 EXPORTS = ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks", "ndq_mlp_jet_fwd",
            "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss", "ndq_epoch_tail",
-           "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run", "ndq_oneshot_create",
-           "ndq_oneshot_connect", "ndq_oneshot_allreduce", "ndq_oneshot_status", "ndq_oneshot_destroy")
+           "ndq_fused_step_run", "ndq_sample", "ndq_mlp_register", "ndq_fused_multi_step_run", "ndq_fused_fit_run",
+           "ndq_oneshot_create", "ndq_oneshot_connect", "ndq_oneshot_allreduce", "ndq_oneshot_status", "ndq_oneshot_destroy")
 
 
 def check(rc, what):

@@ -126,6 +126,52 @@ _UN_ADJ = {
 }
 
 
+def _tv_launcher(args_t, fill, kern_tv, lds_train, lds_eval):
+    """Host launcher of the train + validation closure kernel (csrc/ndq_mlp.h: fused_*_closure_tv_kernel), emitted into
+    the anonymous namespace of every generated closure module: workgroups [0, blocks(n)) run the training closure on the
+    training batch, the next blocks(vn) the forward-only closure on the validation batch; n = 0 / vn = 0 drops a half."""
+    return f"""
+int launch_tv(const float* coords, int ldc, int n, const float* const* params, float* const* partials, float* loss_partials,
+              float seed, const float* vcoords, int vldc, int vn, float* vloss_partials, void* stream) {{
+  if (!params || n < 0 || vn < 0 || (n == 0 && vn == 0)) return -2;
+  if (n > 0 && (!coords || !partials || !loss_partials || ldc < n)) return -2;
+  if (vn > 0 && (!vcoords || !vloss_partials || vldc < vn)) return -2;
+  {args_t} t{{}}, v{{}};
+  {{
+    {args_t}& a = t;
+    a.coords = coords; a.loss_partials = loss_partials; a.n = n; a.ldc = ldc; a.ldj = ldc; a.seed = seed;
+    {fill}
+  }}
+  {{
+    {args_t}& a = v;
+    float* const* partials = nullptr;
+    a.coords = vcoords; a.loss_partials = vloss_partials; a.n = vn; a.ldc = vldc; a.ldj = vldc; a.seed = 0.f;
+    {fill}
+  }}
+  const int tb = n > 0 ? fused_blocks(n) : 0, vb = vn > 0 ? fused_blocks(vn) : 0;
+  static bool attr = false;
+  if (!attr) {{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&{kern_tv}),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int){lds_train});
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }}
+  hipLaunchKernelGGL(({kern_tv}), dim3(tb + vb), dim3(CFG::BWD_THREADS), tb > 0 ? {lds_train} : {lds_eval},
+                     static_cast<hipStream_t>(stream), t, v, tb);
+  return (int)hipGetLastError();
+}}"""
+
+
+# the ndq_fused_launch_tv_fn of include/ndq.h
+_TV_EXPORT = """
+extern "C" int ndq_fused_launch_tv(const float* coords, int ldc, int n, const float* const* params, float* const* partials,
+                                   float* loss_partials, float seed, const float* vcoords, int vldc, int vn,
+                                   float* vloss_partials, void* stream) {
+  return launch_tv(coords, ldc, n, params, partials, loss_partials, seed, vcoords, vldc, vn, vloss_partials, stream);
+}
+"""
+
+
 class PointwiseProgram:
     """A traced system lowered to straight-line fp32 code.
 
@@ -408,9 +454,12 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         if K == 1:
             args_t = "ndq::FusedArgs"
             fill = "a.params = params[0]; a.partials = partials ? partials[0] : nullptr;"
+            kern_tv = "ndq::fused_closure_tv_kernel<CFG, PW>"
         else:
             args_t = "ndq::FusedMultiArgs"
             fill = f"for (int k = 0; k < {K}; ++k) {{ a.params[k] = params[k]; a.partials[k] = partials ? partials[k] : nullptr; }}"
+            kern_tv = f"ndq::fused_multi_closure_tv_kernel<CFG, {K}, PW>"
+        tv = _tv_launcher(args_t, fill, kern_tv, lds('true'), lds('false'))
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- single-launch closure kernel (forward streams + pointwise stage +
 // reverse pass) of one PDE system with {K} network(s), gfx950.
 #include "{header}"
@@ -462,6 +511,7 @@ int launch(const float* coords, int ldc, int n, const float* const* params, floa
     hipLaunchKernelGGL(({kern('false')}), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS), {lds('false')}, s, a);
   return (int)hipGetLastError();
 }}
+{tv}
 }}  // namespace
 
 extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
@@ -495,7 +545,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
                                       float seed, int train, void* stream) {{
   return launch(coords, ldc, n, params, partials, loss_partials, funcs, resid, ldj, seed, train, stream);
 }}
-"""
+{_TV_EXPORT}"""
 
     def _group_source(self, desc):
         """Source of the grouped single-launch closure kernel (csrc/ndq_mlp.h: fused_group_closure_kernel): one network
@@ -519,6 +569,8 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
         neq, nf = len(self.residuals), len(self.funcs)
         kern = lambda train: f"ndq::fused_group_closure_kernel<CFG, PW, {train}>"
         lds = lambda train: f"ndq::group_lds_bytes<CFG>({train})"
+        tv = _tv_launcher("ndq::FusedArgs", "a.params = params[0]; a.partials = partials ? partials[0] : nullptr;",
+                          "ndq::fused_group_closure_tv_kernel<CFG, PW>", lds('true'), lds('false'))
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- grouped single-launch closure kernel (forward streams -> LDS exchange ->
 // per-point stage, one point per lane -> reverse pass) of one PDE system, gfx950.
 #include "{header}"
@@ -572,6 +624,7 @@ int launch(const float* coords, int ldc, int n, const float* const* params, floa
     hipLaunchKernelGGL(({kern('false')}), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS), {lds('false')}, s, a);
   return (int)hipGetLastError();
 }}
+{tv}
 }}  // namespace
 
 extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
@@ -593,7 +646,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
                                       float seed, int train, void* stream) {{
   return launch(coords, ldc, n, params, partials, loss_partials, funcs, resid, ldj, seed, train, stream);
 }}
-"""
+{_TV_EXPORT}"""
 
     def _emit(self):
         nsym = max(len(self.symbols), 1)
@@ -748,7 +801,7 @@ def build(program: PointwiseProgram, force=False, f64=False):
     with open(src, "w") as fh:
         fh.write(source_f64(program.source) if f64 else program.source)
     try:
-        _hipcc.compile_shared(src, so)
+        _hipcc.compile_shared(src, so, defer=True)
     except RuntimeError as e:
         raise RuntimeError(f"hipcc failed for generated pointwise kernel {src}:\n{str(e)[-4000:]}") from e
     return so
@@ -768,6 +821,8 @@ class FusedKernel:
         self.lib.ndq_fused_launch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
         self.lib.ndq_fused_launch_multi.restype = ci
         self.lib.ndq_fused_launch_multi.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
+        self.lib.ndq_fused_launch_tv.restype = ci
+        self.lib.ndq_fused_launch_tv.argtypes = [vp, ci, ci, vp, vp, vp, cf, vp, ci, ci, vp, vp]
         self.lib.ndq_fused_blocks.restype = ci
         self.lib.ndq_fused_blocks.argtypes = [ci]
         self.lib.ndq_fused_num_params.restype = ci
@@ -919,7 +974,7 @@ def build_fused(program: PointwiseProgram, desc, force=False, threads=None):
     with open(src, "w") as fh:
         fh.write(source)
     try:
-        _hipcc.compile_shared(src, so, flags)
+        _hipcc.compile_shared(src, so, flags, defer=True)
     except RuntimeError as e:
         raise RuntimeError(f"hipcc failed for generated fused kernel {src}:\n{str(e)[-4000:]}") from e
     return so

@@ -208,11 +208,17 @@ __global__ __launch_bounds__(256) void epoch_tail_kernel(TailArgs a) {
 // second-stage sums AND the epoch tail in one launch (single batch per epoch, no all-reduce in between): every
 // workgroup first adds up the loss partials itself (nlparts <= a few hundred floats), then reduces its 64 gradient
 // columns and applies best-snapshot + Adam to them.
+// loss of a validation batch evaluated by the same closure launch (ndq_fused_fit_run): block partials -> one scalar
+struct ValidArgs {
+  const float* part; int nparts; float scale; float* hist; int index;
+  int best_on_valid;          // 1: the best-network snapshot follows the validation loss instead of the training loss
+};
 struct ReduceTailArgs {
   Reduce2Args r;
   TailArgs t;
   int tail_blocks;            // workgroups [tail_blocks, gridDim.x) draw the next batch (smp), if any
   ndq::SampleArgs smp;
+  ValidArgs v;                // v.part == nullptr: no validation loss in this launch
 };
 __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
   // Latency-bound (19 workgroups at C2): every global load -- loss partials, this thread's rows of the gradient
@@ -220,11 +226,16 @@ __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
   // ONE barrier.  Summation orders are fixed (per-thread chains, then LDS slots added in index order).
   __shared__ float sm[16 * 64];
   __shared__ float smw[16];
+  __shared__ float smv[16];
   const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;
   const int i = blockIdx.x * 64 + c;
   const bool col = i < a.r.len;
-  float lp = 0.f;
+  const bool has_valid = a.v.part != nullptr;           // uniform over the launch
+  const bool has_train = a.r.nparts > 0;                // false: stand-alone validation epoch (no sums, no Adam)
+  float lp = 0.f, vp = 0.f;
   for (int r = tid; r < a.r.nlparts; r += 1024) lp += a.r.lpart[r];
+  if (has_valid)
+    for (int r = tid; r < a.v.nparts; r += 1024) vp += a.v.part[r];
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (col) {
     const float* __restrict__ part = a.r.part;
@@ -240,35 +251,54 @@ __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
   }
   const bool upd = (rg == 0) && col;
   float pi = 0.f, m0 = 0.f, v0 = 0.f;
-  if (upd) { pi = a.t.p[i]; m0 = a.t.m[i]; v0 = a.t.v[i]; }
+  if (upd) {
+    pi = a.t.p[i];
+    if (has_train) { m0 = a.t.m[i]; v0 = a.t.v[i]; }
+  }
   const float best = a.t.best_loss[a.t.parity];
   for (int off = 32; off > 0; off >>= 1) lp += __shfl_down(lp, off);
-  if (c == 0) smw[rg] = lp;
+  if (has_valid)
+    for (int off = 32; off > 0; off >>= 1) vp += __shfl_down(vp, off);
+  if (c == 0) { smw[rg] = lp; smv[rg] = vp; }
   sm[rg * 64 + c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  float loss = 0.f;
+  float loss = 0.f, vloss = 0.f;
 #pragma unroll
   for (int w = 0; w < 16; ++w) loss += smw[w];
   loss *= a.r.lscale;
-  const bool better = (a.t.best_flat != nullptr) && (loss < best);
-  if (upd) {
-    float g = 0.f;
+  if (has_valid) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) g += sm[k * 64 + c];
-    a.r.out[i] = g;
+    for (int w = 0; w < 16; ++w) vloss += smv[w];
+    vloss *= a.v.scale;
+  }
+  // what the snapshot follows: the validation loss of the parameters this epoch starts from (fit() with validation
+  // epochs), else the training loss (solvers.py:414-415: n_batches_valid = 0)
+  const bool on_valid = has_valid && a.v.best_on_valid != 0;
+  const float cmp = on_valid ? vloss : loss;
+  const bool better = (a.t.best_flat != nullptr) && (on_valid || has_train) && (cmp < best);
+  if (upd) {
     if (better) a.t.best_flat[i] = pi;
-    float gi = g;
-    if (a.t.wd != 0.f) gi = fmaf(a.t.wd, pi, gi);
-    const float mi = fmaf(a.t.b1, m0, (1.f - a.t.b1) * gi);
-    const float vi = fmaf(a.t.b2, v0, (1.f - a.t.b2) * gi * gi);
-    a.t.m[i] = mi;
-    a.t.v[i] = vi;
-    a.t.p[i] = pi - (a.t.lr / a.t.bc1) * (mi / (sqrtf(vi) / a.t.bc2s + a.t.eps));
+    if (has_train) {
+      float g = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) g += sm[k * 64 + c];
+      a.r.out[i] = g;
+      float gi = g;
+      if (a.t.wd != 0.f) gi = fmaf(a.t.wd, pi, gi);
+      const float mi = fmaf(a.t.b1, m0, (1.f - a.t.b1) * gi);
+      const float vi = fmaf(a.t.b2, v0, (1.f - a.t.b2) * gi * gi);
+      a.t.m[i] = mi;
+      a.t.v[i] = vi;
+      a.t.p[i] = pi - (a.t.lr / a.t.bc1) * (mi / (sqrtf(vi) / a.t.bc2s + a.t.eps));
+    }
   }
   if (blockIdx.x == 0 && tid == 0 && a.t.write_scalars) {
-    *a.r.lout = loss;
-    a.t.loss_hist[a.t.hist_index] = loss;
-    a.t.best_loss[a.t.parity ^ 1] = better ? loss : best;
+    if (has_train) {
+      *a.r.lout = loss;
+      a.t.loss_hist[a.t.hist_index] = loss;
+    }
+    if (has_valid) a.v.hist[a.v.index] = vloss;
+    a.t.best_loss[a.t.parity ^ 1] = better ? cmp : best;
   }
 }
 __global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) {
@@ -512,7 +542,7 @@ int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_st
       (s->n_params + 63) / 64 <= static_cast<ndq::Oneshot*>(s->comm)->dev.max_blocks) {
     // data parallel over the one-shot exchange: local sums + exchange + tail in ONE launch (reduce_tail_dp_kernel)
     ndq::Oneshot* c = static_cast<ndq::Oneshot*>(s->comm);
-    ReduceTailArgs a;
+    ReduceTailArgs a{};
     fill_reduce_tail(a, s, s->loss_partials, s->blocks, s->seed, s->loss_hist, s->best_loss, adam_step, hist_index, parity, 1);
     const unsigned step = ++c->step;
     hipLaunchKernelGGL(reduce_tail_dp_kernel, dim3((s->n_params + 63) / 64), dim3(1024), 0, static_cast<hipStream_t>(stream), a,
@@ -531,7 +561,7 @@ int ndq_fused_step_run(const ndq_fused_step* s, const float* coords, int adam_st
                           s->weight_decay, adam_step, s->loss_slot, 1, s->loss_hist, hist_index, s->best_loss, parity,
                           s->best_flat, 1, stream);
   }
-  ReduceTailArgs a;
+  ReduceTailArgs a{};
   a.r = Reduce2Args{s->partials, s->blocks, s->n_params, s->grad, 0, s->loss_partials, s->blocks, s->loss_slot, s->seed};
   a.t.p = s->params; a.t.g = s->grad; a.t.m = s->adam_m; a.t.v = s->adam_v; a.t.len = s->n_params;
   a.t.lr = s->lr; a.t.b1 = s->beta1; a.t.b2 = s->beta2; a.t.eps = s->eps; a.t.wd = s->weight_decay;
@@ -562,6 +592,7 @@ static void fill_reduce_tail(ReduceTailArgs& a, const ndq_fused_step* s, const f
   a.t.loss_slots = s->loss_slot; a.t.nb = 1; a.t.loss_hist = loss_hist; a.t.hist_index = hist_index;
   a.t.best_loss = best_loss; a.t.parity = parity; a.t.best_flat = s->best_flat; a.t.write_scalars = write_scalars;
   a.tail_blocks = 0x7fffffff;
+  a.v = ValidArgs{};
 }
 
 int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_launch_multi_fn launch,
@@ -582,7 +613,7 @@ int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_
   }
   int rc = launch(coords, s0.ldc, s0.n, params, partials, s0.loss_partials, nullptr, nullptr, s0.ldj, s0.seed, 1, stream);
   if (rc) return rc;
-  ReduceTailMultiArgs a;
+  ReduceTailMultiArgs a{};
   int max_params = 0;
   for (int k = 0; k < n_nets; ++k) {
     fill_reduce_tail(a.net[k], &steps[k], s0.loss_partials, s0.blocks, s0.seed, s0.loss_hist, s0.best_loss, adam_step,
@@ -593,6 +624,81 @@ int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_
   hipLaunchKernelGGL(reduce_tail_multi_kernel, dim3((max_params + 63) / 64, n_nets), dim3(1024), 0,
                      static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
+}
+
+// ndq_fused_fit_run: see include/ndq.h.  Per epoch ONE closure launch (training workgroups + validation workgroups) and
+// ONE sums / tail launch (blockIdx.y = network); a trailing validation-only pair closes the call.
+int ndq_fused_fit_run(const ndq_fused_fit* f, int n_epochs, const float* const* train_coords, int adam_step,
+                      int hist_index, int valid_index, int parity, void* stream) {
+  if (!f || !f->launch || f->n_nets < 1 || f->n_nets > 4 || n_epochs < 0 || (n_epochs > 0 && (!train_coords || adam_step <= 0)) ||
+      hist_index < 0 || valid_index < 0 || (parity != 0 && parity != 1) || f->track_best < 0 || f->track_best > 2)
+    return NDQ_EINVAL;
+  const ndq_fused_step& s0 = f->net[0];
+  const bool valid = f->valid_coords != nullptr;
+  if (!valid && n_epochs == 0) return NDQ_EINVAL;
+  if (!s0.best_loss || (n_epochs > 0 && (!s0.loss_hist || !s0.loss_partials || s0.n <= 0 || s0.blocks <= 0))) return NDQ_EINVAL;
+  if (valid && (!f->valid_loss_partials || !f->valid_hist || f->valid_n <= 0 || f->valid_blocks <= 0)) return NDQ_EINVAL;
+  if (f->track_best == 2 && !valid) return NDQ_EINVAL;
+  const float* params[4];
+  float* partials[4];
+  int max_params = 0;
+  for (int k = 0; k < f->n_nets; ++k) {
+    const ndq_fused_step& s = f->net[k];
+    if (!s.params || s.n_params <= 0 || (f->track_best && !s.best_flat)) return NDQ_EINVAL;
+    if (n_epochs > 0 && (!s.partials || !s.grad || !s.adam_m || !s.adam_v || !s.loss_slot)) return NDQ_EINVAL;
+    params[k] = s.params;
+    partials[k] = s.partials;
+    if (s.n_params > max_params) max_params = s.n_params;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 tail_grid((max_params + 63) / 64, f->n_nets);
+  // tail of one epoch: e < n_epochs: training epoch e (+ the validation loss of epoch e - 1 if with_valid);
+  // e == n_epochs: the trailing validation epoch alone
+  auto tail = [&](int e, bool with_train, bool with_valid, int vindex) {
+    ReduceTailMultiArgs a{};
+    for (int k = 0; k < f->n_nets; ++k) {
+      const ndq_fused_step& s = f->net[k];
+      ReduceTailArgs& t = a.net[k];
+      t.r = Reduce2Args{s.partials, with_train ? s0.blocks : 0, s.n_params, s.grad, 0, s0.loss_partials,
+                        with_train ? s0.blocks : 0, s.loss_slot, s0.seed};
+      t.t.p = s.params; t.t.g = s.grad; t.t.m = s.adam_m; t.t.v = s.adam_v; t.t.len = s.n_params;
+      t.t.lr = s.lr; t.t.b1 = s.beta1; t.t.b2 = s.beta2; t.t.eps = s.eps; t.t.wd = s.weight_decay;
+      const int step = adam_step + e;
+      t.t.bc1 = with_train ? (float)(1.0 - pow((double)s.beta1, (double)step)) : 1.f;
+      t.t.bc2s = with_train ? (float)sqrt(1.0 - pow((double)s.beta2, (double)step)) : 1.f;
+      t.t.loss_slots = s.loss_slot; t.t.nb = 1; t.t.loss_hist = s0.loss_hist; t.t.hist_index = hist_index + e;
+      t.t.best_loss = s0.best_loss; t.t.parity = parity; t.t.write_scalars = (k == 0) ? 1 : 0;
+      // the snapshot follows the training loss (track_best = 1) or the validation loss (2): a tail that does not carry
+      // that loss only hands the best value on to the other slot of the ping-pong
+      const bool track = (f->track_best == 1 && with_train) || (f->track_best == 2 && with_valid);
+      t.t.best_flat = track ? s.best_flat : nullptr;
+      t.tail_blocks = 0x7fffffff;
+      if (with_valid)
+        t.v = ValidArgs{f->valid_loss_partials, f->valid_blocks, f->valid_scale, f->valid_hist, vindex, f->track_best == 2 ? 1 : 0};
+    }
+    for (int k = f->n_nets; k < 4; ++k) a.net[k] = a.net[0];
+    hipLaunchKernelGGL(reduce_tail_multi_kernel, tail_grid, dim3(1024), 0, st, a);
+    parity ^= 1;
+    return (int)hipGetLastError();
+  };
+  for (int e = 0; e < n_epochs; ++e) {
+    if (!train_coords[e]) return NDQ_EINVAL;
+    const bool with_valid = valid && e > 0;
+    int rc = f->launch(train_coords[e], s0.ldc, s0.n, params, partials, s0.loss_partials, s0.seed,
+                       with_valid ? f->valid_coords : nullptr, f->valid_ldc, with_valid ? f->valid_n : 0,
+                       f->valid_loss_partials, stream);
+    if (rc) return rc;
+    rc = tail(e, true, with_valid, valid_index + e - 1);
+    if (rc) return rc;
+  }
+  if (valid) {
+    int rc = f->launch(nullptr, 0, 0, params, nullptr, nullptr, 0.f, f->valid_coords, f->valid_ldc, f->valid_n,
+                       f->valid_loss_partials, stream);
+    if (rc) return rc;
+    rc = tail(n_epochs, false, true, valid_index + (n_epochs > 0 ? n_epochs - 1 : 0));
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int ndq_adam_step(float* params, const float* grad, float* exp_avg, float* exp_avg_sq, int len, float lr, float beta1,

@@ -2239,10 +2239,12 @@ struct FusedArgs {
   real seed;              // adjoint seed scale 1 / (N_global * n_eq)
 };
 
+// The body works on workgroup `blk` of `nblk` (the plain kernels pass blockIdx.x / gridDim.x; the train + validation
+// launch below gives each half of its grid its own numbering, so that either half computes -- bit for bit -- what a
+// launch of its own would).
 template <class C, class PW, bool TRAIN>
-__global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs a) {
+__device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds, const int blk, const int nblk) {
   static_assert(C::NOUT == 1, "the single-launch closure kernel needs a single-output network");
-  extern __shared__ __attribute__((aligned(16))) real lds[];
   NDQ_TS(0);
 #ifdef NDQ_PHASE_TS
   if (threadIdx.x == 0 && blockIdx.x == 0) ndq_tile_iter = 0;
@@ -2254,7 +2256,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   // latencies overlap), the next tile's while the current one is computed
   real xn[C::D];
   {
-    const int n0 = (blockIdx.x * WAVES + wave) * 16 + p;
+    const int n0 = (blk * WAVES + wave) * 16 + p;
     const int nn0 = n0 < a.n ? n0 : a.n - 1;
 #pragma unroll
     for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn0];
@@ -2272,14 +2274,14 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   // other's VALU work
   if (WAVES > 4 && wave >= WAVES / 2) __builtin_amdgcn_s_sleep(NDQ_STAGGER);
 #endif
-  for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
+  for (int tile = blk * WAVES + wave; tile < ntiles; tile += nblk * WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
     real x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = xn[d];
     {
-      const int n1 = n + gridDim.x * WAVES * 16;
+      const int n1 = n + nblk * WAVES * 16;
       const int nn1 = n1 < a.n ? n1 : a.n - 1;
 #pragma unroll
       for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn1];
@@ -2321,7 +2323,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   __syncthreads();
   NDQ_TS(2);
 #endif
-  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P, a.params);
+  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blk * C::P, a.params);
   // loss: lanes (only q == 0 lanes are non-zero) -> wave -> workgroup, fixed order
   lsum = point_sum(quad_sum(lsum));
   __syncthreads();
@@ -2331,9 +2333,26 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
   if (threadIdx.x == 0) {
     real v = 0.f;
     for (int w = 0; w < WAVES; ++w) v += wl[w];
-    a.loss_partials[blockIdx.x] = v;
+    a.loss_partials[blk] = v;
   }
   NDQ_TS(3);
+}
+
+template <class C, class PW, bool TRAIN>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) real lds[];
+  fused_closure_body<C, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x);
+}
+
+// Training batch AND validation batch in ONE launch (fit(): solvers.py:443-497 runs a validation epoch after every
+// training epoch; the validation loss of the parameters a training epoch starts from is evaluated by the spare
+// workgroups of that epoch's closure launch): workgroups [0, train_blocks) run the training closure on `t`, the rest the
+// forward-only closure on `v`.  Either count may be zero.
+template <class C, class PW>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_tv_kernel(FusedArgs t, FusedArgs v, int train_blocks) {
+  extern __shared__ __attribute__((aligned(16))) real lds[];
+  if ((int)blockIdx.x < train_blocks) fused_closure_body<C, PW, true>(t, lds, blockIdx.x, train_blocks);
+  else fused_closure_body<C, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------ multi-network closure
@@ -2355,9 +2374,8 @@ struct FusedMultiArgs {
 };
 
 template <class C, int K, class PW, bool TRAIN>
-__global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(FusedMultiArgs a) {
+__device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a, real* lds, const int blk, const int nblk) {
   static_assert(C::NOUT == 1 && !C::WIDE && K >= 2 && K <= kMaxFusedNets, "multi-network closure: n_out = 1, H <= 48, 2..4 nets");
-  extern __shared__ __attribute__((aligned(16))) real lds[];
   constexpr int WS = C::ldsWeightsEnd(TRAIN);          // LDS floats per weight image
 #pragma unroll
   for (int k = 0; k < K; ++k) stage_weights<C, TRAIN>(lds + k * WS, a.params[k]);
@@ -2372,7 +2390,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
     for (int k = 0; k < K; ++k) { acc_zero<C>(acc[k]); acc[k].bias = nullptr; }
   }
   real lsum = 0.f;
-  for (int tile = blockIdx.x * WAVES + wave; tile < ntiles; tile += gridDim.x * WAVES) {
+  for (int tile = blk * WAVES + wave; tile < ntiles; tile += nblk * WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
     const int nn = valid ? n : a.n - 1;
@@ -2417,7 +2435,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
     // block_reduce_store puts its regions right behind "the" weight image of the base it is given: hand it the last one
     sfor<K>([&](auto k_) {
       constexpr int k = decltype(k_)::value;
-      block_reduce_store<C, WAVES>(lds + (K - 1) * WS, acc[k], wave, lane, p, q, a.partials[k] + (size_t)blockIdx.x * C::P,
+      block_reduce_store<C, WAVES>(lds + (K - 1) * WS, acc[k], wave, lane, p, q, a.partials[k] + (size_t)blk * C::P,
                                    a.params[k]);
     });
   }
@@ -2429,8 +2447,22 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(Fus
   if (threadIdx.x == 0) {
     real v = 0.f;
     for (int w = 0; w < WAVES; ++w) v += wl[w];
-    a.loss_partials[blockIdx.x] = v;
+    a.loss_partials[blk] = v;
   }
+}
+
+template <class C, int K, class PW, bool TRAIN>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(FusedMultiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) real lds[];
+  fused_multi_closure_body<C, K, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x);
+}
+
+// training + validation batch in one launch, as fused_closure_tv_kernel
+template <class C, int K, class PW>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_tv_kernel(FusedMultiArgs t, FusedMultiArgs v, int train_blocks) {
+  extern __shared__ __attribute__((aligned(16))) real lds[];
+  if ((int)blockIdx.x < train_blocks) fused_multi_closure_body<C, K, PW, true>(t, lds, blockIdx.x, train_blocks);
+  else fused_multi_closure_body<C, K, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------ grouped closure
@@ -2473,9 +2505,8 @@ template <class C> constexpr int group_xs() {
 #define NDQ_UNROLL(n) NDQ_PRAGMA(unroll n)
 
 template <class C, class PW, bool TRAIN>
-__global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(FusedArgs a) {
+__device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, real* lds, const int blk, const int nblk) {
   static_assert(!C::ACC_LDS, "grouped closure: H <= 48");
-  extern __shared__ __attribute__((aligned(16))) real lds[];
   stage_weights<C, TRAIN>(lds, a.params);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
@@ -2488,7 +2519,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
   GradAcc<C> acc;
   if constexpr (TRAIN) { acc_zero<C>(acc); acc.bias = nullptr; }
   real lsum = 0.f;
-  for (int grp = blockIdx.x * WAVES + wave; grp < ngroups; grp += gridDim.x * WAVES) {
+  for (int grp = blk * WAVES + wave; grp < ngroups; grp += nblk * WAVES) {
     const int n = grp * GP + lane;                       // this lane's point in phase 2 (lanes >= GP idle there)
     const bool valid = n < a.n && lane < GP;
     const int nn = valid ? n : a.n - 1;
@@ -2598,7 +2629,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
-  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blockIdx.x * C::P, a.params);
+  if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blk * C::P, a.params);
   lsum = point_sum(quad_sum(lsum));                      // all 64 lanes carry a point here
   __syncthreads();
   real* wl = lds + C::ldsWeightsEnd(TRAIN);
@@ -2607,8 +2638,22 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(Fus
   if (threadIdx.x == 0) {
     real v = 0.f;
     for (int w = 0; w < WAVES; ++w) v += wl[w];
-    a.loss_partials[blockIdx.x] = v;
+    a.loss_partials[blk] = v;
   }
+}
+
+template <class C, class PW, bool TRAIN>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) real lds[];
+  fused_group_closure_body<C, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x);
+}
+
+// training + validation batch in one launch, as fused_closure_tv_kernel
+template <class C, class PW>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_tv_kernel(FusedArgs t, FusedArgs v, int train_blocks) {
+  extern __shared__ __attribute__((aligned(16))) real lds[];
+  if ((int)blockIdx.x < train_blocks) fused_group_closure_body<C, PW, true>(t, lds, blockIdx.x, train_blocks);
+  else fused_group_closure_body<C, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------ host-side sizes

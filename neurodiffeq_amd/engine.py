@@ -470,6 +470,21 @@ class FusedSystem:
             self._static_seen.pop(next(iter(self._static_seen)))
         return None
 
+    def static_block(self, batch):
+        """(device pointer, n, ld) of a resident copy of an unchanging HOST batch (list of coordinate columns): uploaded
+        on first use, found again by storage identity + version counter (see ``_static_batch``)."""
+        n = batch[0].numel()
+        key = self.static_key(batch) + (0, n)
+        hit = self._static.get(key)
+        if hit is None:
+            while len(self._static) >= 16:
+                self._static.pop(next(iter(self._static)))
+            ld = _round_up(n, 64)
+            block = torch.zeros(self.n_coords, ld, dtype=self.dt, device=self.device)
+            block[:, :n].copy_(torch.stack([c.detach().reshape(-1).to(self.dt) for c in batch]))
+            hit = self._static[key] = (list(batch), block, [block[i] for i in range(self.n_coords)])
+        return hit[2][0].data_ptr(), n, hit[1].shape[1]
+
     def _coord_ptr(self, b, row):
         if b["coords_rows"] is not None:
             return _c_vp(b["coords_rows"][row].data_ptr())
@@ -590,6 +605,7 @@ class FusedSystem:
         for _ in range(2):
             self.fused_closure(b, n, stream, True, n_global, 0, False)
             runs.append(grads())
+        tv_same = self._tv_matches_plain(b, n, n_global, stream) if self.FIT_RUN else True
         pipe = []
         for _ in range(2):
             self.forward(b, n, stream)
@@ -605,7 +621,9 @@ class FusedSystem:
         ref = pipe[0][0].double()
         err = float((runs[0][0].double() - ref).norm() / ref.norm().clamp_min(1e-30))
         lerr = float((runs[0][1] - pipe[0][1]).abs() / pipe[0][1].abs().clamp_min(1e-30))
-        self.fused_check = dict(reproducible=same, pipeline_reproducible=pipe_same, grad_rel_l2=err, loss_rel=lerr)
+        self.fused_check = dict(reproducible=same, pipeline_reproducible=pipe_same, grad_rel_l2=err, loss_rel=lerr,
+                                train_valid_launch_identical=tv_same)
+        same = same and tv_same
         if not pipe_same:
             raise _lib.NdqError(f"the three-kernel pipeline of this system is not bit-reproducible ({self.fused_check}); "
                                 "refusing to train on it")
@@ -625,6 +643,39 @@ class FusedSystem:
         self._resident_cache.clear()
         self._fast = None
         return False
+
+    def _tv_matches_plain(self, b, n, n_global, stream):
+        """The train + validation launch of this closure-kernel build (fit(): several epochs per native call) against the
+        plain launches it stands in for, on the batch at hand, bit for bit: gradient and loss partial sums of its
+        training workgroups == the training launch (which has just run: ``b`` still holds its partial sums), loss
+        partial sums of its validation workgroups == the forward-only launch; alone and together."""
+        fk = b["fusedk"]
+        dev, f32 = self.device, torch.float32
+        seed = 1.0 / (float(n_global) * self.loss_norm)
+        params_pp = (_c_vp * len(self.flat))(*[fp.flat.data_ptr() for fp in self.flat])
+        want_parts = [t.clone() for t in b["fused_partials_all"]]
+        want_loss = b["fused_loss_partials"].clone()
+        blocks = b["fused_blocks"]
+        ev = torch.zeros(blocks, dtype=f32, device=dev)
+        rc = fk.lib.ndq_fused_launch_multi(self._coord_ptr(b, 0), b["ld"], n, params_pp, None, _ptr(ev), None, None, b["ld"],
+                                           seed, 0, stream)
+        _lib.check(rc, "ndq_fused_launch_multi")
+        ok = True
+        for with_train, with_valid in ((True, True), (True, False), (False, True)):
+            parts = [torch.full_like(t, float("nan")) for t in want_parts]
+            lp = torch.full_like(want_loss, float("nan"))
+            vp = torch.full_like(ev, float("nan"))
+            parts_pp = (_c_vp * len(parts))(*[t.data_ptr() for t in parts])
+            rc = fk.lib.ndq_fused_launch_tv(self._coord_ptr(b, 0) if with_train else None, b["ld"], n if with_train else 0,
+                                            params_pp, parts_pp if with_train else None, _ptr(lp) if with_train else None,
+                                            seed, self._coord_ptr(b, 0) if with_valid else None, b["ld"],
+                                            n if with_valid else 0, _ptr(vp) if with_valid else None, stream)
+            _lib.check(rc, "ndq_fused_launch_tv")
+            if with_train:
+                ok = ok and torch.equal(lp, want_loss) and all(torch.equal(a, w) for a, w in zip(parts, want_parts))
+            if with_valid:
+                ok = ok and torch.equal(vp, ev)
+        return bool(ok)
 
     SELF_CHECK_TOL = 1e-4
 
@@ -815,6 +866,119 @@ class FusedSystem:
             _lib.check(rc, "ndq_epoch_tail")
         fs["pending"] += 1
         fs["parity"] ^= 1
+
+    # ------------------------------------------------------------------------------------------ several epochs per call
+    FIT_RUN = os.environ.get("NDQ_FIT_RUN", "1") != "0"
+
+    def fit_ready(self):
+        """May epochs of this system go through ndq_fused_fit_run (closure launch with training + validation workgroups,
+        one sums / tail launch per epoch, any number of epochs per native call)?  Single GPU, single-launch closure."""
+        return self.FIT_RUN and self.fusedk is not None and not self.f64
+
+    def resident_ptr(self, batch):
+        """(device pointer of row 0, leading dimension) if ``batch`` -- a list of (N, 1) / (N,) coordinate columns -- is the
+        rows of ONE resident fp32 SoA block the kernels can read in place (ResidentBatchGenerator, blocks staged by
+        ``stage_batches``), else None."""
+        if batch[0].device.type != "cuda" or len(batch) != self.n_coords:
+            return None
+        ld = self._resident_ld(batch)
+        return (batch[0].data_ptr(), ld) if ld else None
+
+    def stage_batches(self, host_block, n):
+        """Host tensor [K][n_coords][n] (any float dtype) -> resident fp32 device block [K][n_coords][ld]: ONE pinned copy
+        and ONE asynchronous H2D transfer for K epochs' worth of collocation points.  Returns (block, ld).  Two pinned
+        staging blocks alternate; one is rewritten only after its previous transfer has completed."""
+        K = host_block.shape[0]
+        ld = _round_up(n, 64)
+        st = self.__dict__.setdefault("_stage", dict(pinned=[None, None], events=[None, None], next=0, dev=[None, None]))
+        i = st["next"]
+        st["next"] ^= 1
+        need = K * self.n_coords * ld
+        if st["pinned"][i] is None or st["pinned"][i].numel() < need:
+            st["pinned"][i] = torch.zeros(need, dtype=torch.float32, device="cpu").pin_memory()
+            st["dev"][i] = torch.zeros(need, dtype=torch.float32, device=self.device)
+        elif st["events"][i] is not None:
+            st["events"][i].synchronize()
+        pinned = st["pinned"][i][:need].view(K, self.n_coords, ld)
+        # (numpy: a strided / converting torch copy of this size goes through the intra-op thread pool, whose wake-up
+        # costs more than the copy)
+        import numpy as np
+        np.copyto(pinned.numpy()[:, :, :n], host_block.detach().numpy(), casting="same_kind")
+        dev = st["dev"][i][:need].view(K, self.n_coords, ld)
+        dev.copy_(pinned, non_blocking=True)
+        ev = st["events"][i] or torch.cuda.Event()
+        ev.record()
+        st["events"][i] = ev
+        return dev, ld
+
+    def fit_run(self, train_ptrs, n, ld, adam_slots, valid=None, track_best=0, n_global=None):
+        """``len(train_ptrs)`` training epochs (n_batches_train = 1; ``train_ptrs[e]`` = device pointer of epoch e's resident
+        [n_coords][ld] batch of ``n`` points) and -- ``valid = (ptr, n_valid, ld_valid)`` -- the validation epoch after each of
+        them, through ONE native call (include/ndq.h: ndq_fused_fit_run; no host synchronisation).  No training pointers
+        + ``valid``: one stand-alone validation epoch.  ``adam_slots[k]`` = (exp_avg, exp_avg_sq, group, step AFTER the
+        first update) per network; ``track_best``: 0 none, 1 lowest training loss, 2 lowest validation loss."""
+        fs = self.fast_state()
+        K = len(train_ptrs)
+        if K:
+            self._fit_last_n = n
+        # the closure-kernel build follows the TRAINING batch size; stand-alone validation epochs use the build of the
+        # training epochs around them, so that a validation loss does not depend on how epochs are grouped into calls
+        fk = self.fused_variant(n if K else (getattr(self, "_fit_last_n", None) or valid[1]))
+        key = (id(fk), n if K else 0, ld if K else 0, (valid[1], valid[2]) if valid else None)
+        cache = fs.setdefault("fit", {})
+        ent = cache.get(key)
+        if ent is None:
+            if len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            dev, f32 = self.device, torch.float32
+            ff = _lib.FusedFit()
+            ff.launch = ctypes.cast(fk.lib.ndq_fused_launch_tv, ctypes.c_void_p).value
+            ff.n_nets = len(self.flat)
+            keep = []
+            blocks = fk.blocks(n) if K else 0
+            lparts = torch.zeros(max(blocks, 1), dtype=f32, device=dev)
+            keep.append(lparts)
+            for k, fp in enumerate(self.flat):
+                st = ff.net[k]
+                st.n_params = fp.numel
+                st.n, st.ldc, st.ldj, st.blocks = (n, ld, ld, blocks) if K else (0, 0, 0, 0)
+                if K:
+                    part = torch.empty(blocks, fp.numel, dtype=f32, device=dev)
+                    keep.append(part)
+                    st.partials, st.loss_partials = part.data_ptr(), lparts.data_ptr()
+                st.grad, st.loss_slot = fp.grad.data_ptr(), fp.grad_loss.data_ptr() + 4 * fp.numel
+                st.loss_hist, st.best_loss = fs["loss_hist"].data_ptr(), fs["best_loss"].data_ptr()
+                st.best_flat = fs["best_flat"][k].data_ptr()
+            if valid is not None:
+                vparts = torch.zeros(fk.blocks(valid[1]), dtype=f32, device=dev)
+                keep.append(vparts)
+                ff.valid_n, ff.valid_ldc, ff.valid_blocks = valid[1], valid[2], vparts.numel()
+                ff.valid_scale = 1.0 / (float(valid[1]) * self.loss_norm)
+                ff.valid_loss_partials, ff.valid_hist = vparts.data_ptr(), fs["valid_hist"].data_ptr()
+            ent = cache[key] = (ff, keep, fk)
+        ff = ent[0]
+        step0 = 1
+        for k, fp in enumerate(self.flat):
+            fp.sync()
+            st = ff.net[k]
+            st.params = fp.flat.data_ptr()
+            if K:
+                m, v, group, step0 = adam_slots[k]
+                st.seed = 1.0 / (float(n if n_global is None else n_global) * self.loss_norm)
+                st.adam_m, st.adam_v = m.data_ptr(), v.data_ptr()
+                b1, b2 = group["betas"]
+                st.lr, st.beta1, st.beta2, st.eps, st.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]
+        ff.valid_coords = valid[0] if valid is not None else None
+        ff.track_best = track_best
+        coords = (_c_vp * max(K, 1))(*train_ptrs) if K else None
+        rc = self.L.ndq_fused_fit_run(ctypes.byref(ff), K, coords, step0, fs["pending"], fs["pending_valid"], fs["parity"],
+                                      self._stream())
+        _lib.check(rc, "ndq_fused_fit_run")
+        tails = K + (1 if valid is not None else 0)
+        fs["pending"] += K
+        if valid is not None:
+            fs["pending_valid"] += max(K, 1)
+        fs["parity"] ^= tails & 1
 
     def fast_flush(self):
         """Read back (ONE synchronising copy) the train / valid epoch losses recorded since the last flush and the

@@ -81,6 +81,17 @@ class FusedAdam(torch.optim.Adam):
                 return m, v, group, self._steps[id(fp)]
         return None
 
+    def fast_slots(self, fp, k):
+        """``fast_slot`` for ``k`` consecutive updates performed by one native call (ndq_fused_fit_run): the step count
+        returned is the one AFTER the first of them; the counter advances by ``k``."""
+        for f, m, v, group in self._bound:
+            if f is fp and not group.get("amsgrad") and not group.get("maximize"):
+                first = self._steps[id(fp)] + 1
+                self._steps[id(fp)] += k
+                self._dirty_steps = True
+                return m, v, group, first
+        return None
+
     def _sync_step_tensors(self):
         if getattr(self, "_dirty_steps", False):
             for fp, _, _, _ in self._bound:

@@ -26,7 +26,8 @@ import torch.nn as nn
 
 from . import _lib
 from .conditions import BaseCondition
-from .generators import Generator1D, Generator2D, GeneratorSpherical, SamplerGenerator
+from .generators import (Generator1D, Generator2D, GeneratorSpherical, SamplerGenerator, draws_are_static,
+                         draws_have_fixed_size, device_source)
 from . import autograd_ops
 from .losses import _losses
 from .networks import FCNN, describe
@@ -521,7 +522,11 @@ class BaseSolver(ABC):
                     return False
             slots = [self.optimizer.fast_slot(fp) for fp in system.flat]
         shard = self.dist
-        if train and nb == 1 and len(system.flat) > 1 and system.fast_ready(shard) and len({s[3] for s in slots}) == 1:
+        # (a static validation set served nb times -- the default: 4 x the same grid -- is nb identical losses: one batch)
+        one_batch = nb == 1 or (not train and draws_are_static(self.generator["valid"]))
+        if shard is None and one_batch and system.fit_ready() and self._fit_epoch(key, system, first_batch, slots):
+            pass        # one epoch through ndq_fused_fit_run: the device code the multi-epoch path of fit() runs
+        elif train and nb == 1 and len(system.flat) > 1 and system.fast_ready(shard) and len({s[3] for s in slots}) == 1:
             # several networks behind one closure launch, all at the same Adam step (always, unless states were edited)
             system.fast_train_epoch_multi(first_batch, slots, track_best)
         elif train and nb == 1 and len(system.flat) == 1 and system.fast_ready(shard):
@@ -560,6 +565,120 @@ class BaseSolver(ABC):
                     fp.attach_grads()
         self._phase = key
         return True
+
+    def _fit_epoch(self, key, system, batch, slots):
+        """ONE training or validation epoch (one batch) through engine.fit_run.  False: not applicable here."""
+        train = key == "train"
+        if train:
+            if len({s[3] for s in slots}) != 1:
+                return False                          # networks at different Adam steps (edited optimiser state)
+            src = device_source(batch)
+            if src is not None and src.prefetch:
+                return False                          # the prefetching device sampler rides on ndq_fused_step_run's tail
+        n_all = batch[0].shape[0]
+        if system.needs_check(n_all):
+            return False
+        b, n = system.upload(batch)
+        ptr = system._coord_ptr(b, 0).value
+        if train:
+            # fast_slot() has advanced every step counter by one already: slots[k][3] is the step after this update
+            system.fit_run([ptr], n, b["ld"], slots, None, track_best=1 if self.n_batches["valid"] == 0 else 0)
+        else:
+            system.fit_run([], 0, 0, None, (ptr, n, b["ld"]), track_best=2)
+        return True
+
+    #: epochs per native call of the multi-epoch fit path (bounded further by the device-side history ring and by 64 MiB
+    #: of staged collocation points)
+    FIT_CHUNK = 256
+
+    def _fit_chunk(self, remaining):
+        """Up to ``remaining`` epochs of (training epoch, validation epoch) with ONE native call (engine.fit_run ->
+        ndq_fused_fit_run) when nothing has to run on the host in between: the solver's default hooks, FusedAdam, one
+        training batch per epoch from a generator of the reference's own classes, a static validation set (or none),
+        no data parallelism.  The training batches of the whole chunk are drawn from torch's CPU generator in the
+        reference's call order (bit-identical points) and uploaded as one block.  Returns the number of epochs run;
+        0 = not applicable right now, the caller runs one epoch the ordinary way (solvers.py:443-497)."""
+        system = self._fused_sys
+        if system is None or self.dist is not None or self.n_batches["train"] != 1 or remaining < 2:
+            return 0
+        if not self._native_ok() or not system.fit_ready() or getattr(system.program, "loss_probe", None) is not None:
+            return 0
+        nv = self.n_batches["valid"]
+        tg, vg = self.generator["train"], self.generator["valid"]
+        if not draws_have_fixed_size(tg) or (nv > 0 and not draws_are_static(vg)):
+            return 0
+        if type(tg.generator).__name__ == "DeviceGenerator":
+            return 0
+        if self._fused_system(system.n_coords) is not system:      # something was swapped since the last epoch
+            return 0
+        n = tg.size
+        if system.needs_check(n):
+            return 0
+        if not all(self.optimizer.bound(fp) for fp in system.flat):
+            return 0
+        fs = system.fast_state()
+        if max(fs["pending"], fs["pending_valid"]) + 2 > system.HIST:
+            self._flush_device_history()
+        K = min(remaining, self.FIT_CHUNK, system.HIST - max(fs["pending"], fs["pending_valid"]),
+                max(2, (64 << 20) // (4 * system.n_coords * (n + 63))))
+        if K < 2:
+            return 0
+        if fs["pending"] == 0 and fs["pending_valid"] == 0:
+            fs["best_loss"].fill_(float("inf") if self._lowest_loss is None else float(self._lowest_loss))
+        # ---- validation set: static, resident
+        valid = None
+        if nv > 0:
+            vcols = self._generate_batch("valid")        # static: no RNG draw, the same columns every time
+            vres = system.resident_ptr(vcols)
+            if vcols[0].shape[0] < 1 or (vres is None and vcols[0].device.type == "cuda"):
+                return 0
+            valid = (vres[0], vcols[0].shape[0], vres[1]) if vres is not None else system.static_block(vcols)
+        # ---- K training batches in the generator's own draw order
+        self._phase = "train"
+        block = tg.generator.bulk_examples(K)
+        if block is not None:
+            tg._last = None
+            dev, ld = system.stage_batches(block, n)
+            stride = 4 * system.n_coords * ld
+            ptrs = [dev.data_ptr() + e * stride for e in range(K)]
+            self._batch["train"] = [block[-1, i].reshape(-1, 1).clone().requires_grad_(True) for i in range(block.shape[1])]
+        else:
+            draws = [self._generate_batch("train") for _ in range(K)]
+            if any(len(d) != system.n_coords or d[0].shape[0] != n for d in draws):
+                raise RuntimeError(f"{tg.generator!r} returned batches of different shapes although its class draws a "
+                                   "fixed number of points")
+            if all(d is draws[0] for d in draws[1:]) and draws[0][0].device.type != "cuda":
+                ptr, _, ld = system.static_block(draws[0])            # a static training set: one resident block
+                ptrs = [ptr] * K
+            elif draws[0][0].device.type == "cuda":
+                res = [system.resident_ptr(d) for d in draws]
+                if any(r is None or r[1] != res[0][1] for r in res):
+                    # device batches that are not SoA blocks: nothing was consumed that could not be served again
+                    block = torch.stack([torch.stack([c.detach().reshape(-1) for c in d]) for d in draws])
+                    dev = block.to(torch.float32)
+                    ld = (n + 63) // 64 * 64
+                    pad = torch.zeros(K, system.n_coords, ld, dtype=torch.float32, device=dev.device)
+                    pad[:, :, :n] = dev
+                    system._fit_keep = pad
+                    ptrs = [pad.data_ptr() + e * 4 * system.n_coords * ld for e in range(K)]
+                else:
+                    ld = res[0][1]
+                    ptrs = [r[0] for r in res]
+            else:
+                block = torch.stack([torch.stack([c.detach().reshape(-1) for c in d]) for d in draws])
+                dev, ld = system.stage_batches(block, n)
+                stride = 4 * system.n_coords * ld
+                ptrs = [dev.data_ptr() + e * stride for e in range(K)]
+        slots = [self.optimizer.fast_slots(fp, K) for fp in system.flat]
+        if len({s[3] for s in slots}) != 1:
+            raise RuntimeError("the networks of this solver are at different Adam step counts; call fit() with "
+                               "callbacks or run epochs one by one")
+        system.fit_run(ptrs, n, ld, slots, valid, track_best=2 if nv > 0 else 1)
+        for fp in system.flat:
+            if not fp.grads_attached():
+                fp.attach_grads()
+        self._phase = "valid" if nv > 0 else "train"
+        return K
 
     def _run_epoch_composite(self, key, first_batch):
         """The reference's closure on torch autograd, for systems outside the fused scope."""
@@ -652,21 +771,32 @@ class BaseSolver(ABC):
             callbacks = [monitor.to_callback()] + list(callbacks)
         if kwargs:
             raise ValueError(f"Unknown keyword argument(s): {list(kwargs.keys())}")
-        loop = range(max_epochs)
+        bar = None
         if tqdm_file is not None:
             try:
                 from tqdm.auto import tqdm
-                loop = tqdm(loop, desc="Training Progress", colour="blue", file=tqdm_file, dynamic_ncols=True)
+                bar = tqdm(total=max_epochs, desc="Training Progress", colour="blue", file=tqdm_file, dynamic_ncols=True)
             except ImportError:  # pragma: no cover
                 pass
-        for local_epoch in loop:
-            if self._stop_training:
-                break
-            self.local_epoch = local_epoch + 1
-            self.run_train_epoch()
-            self.run_valid_epoch()
-            for cb in callbacks:
-                cb(self)
+        done = 0
+        try:
+            while done < max_epochs and not self._stop_training:
+                # with no callback to run between epochs, whole chunks of epochs go through one native call
+                k = self._fit_chunk(max_epochs - done) if not callbacks else 0
+                if k == 0:
+                    self.local_epoch = done + 1
+                    self.run_train_epoch()
+                    self.run_valid_epoch()
+                    for cb in callbacks:
+                        cb(self)
+                    k = 1
+                done += k
+                self.local_epoch = done
+                if bar is not None:
+                    bar.update(k)
+        finally:
+            if bar is not None:
+                bar.close()
         self._flush_device_history()
 
     # ------------------------------------------------------------------------------------------ results

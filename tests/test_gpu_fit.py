@@ -1,0 +1,160 @@
+"""GPU tests of fit()'s multi-epoch native path (include/ndq.h: ndq_fused_fit_run; reference loop: solvers.py:443-497).
+
+``fit(n)`` without callbacks enqueues whole chunks of (training epoch, validation epoch) pairs with one native call; with
+a callback -- or through ``run_train_epoch()`` / ``run_valid_epoch()`` -- the same epochs run one per call.  Both routes
+execute the same device code, so everything a user can observe afterwards must be BIT-identical: loss histories,
+``lowest_loss``, ``best_nets``, the final parameters, the optimiser state, the generator's RNG stream."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import autograd_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(name, **kw):
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP, DirichletBVP2D, NoCondition
+    from neurodiffeq_amd.generators import Generator1D
+    from neurodiffeq_amd.solvers import Solver1D, Solver2D
+    if name == "ode":                       # the reference's default Solver1D set-up (32 noisy points, static validation grid)
+        return Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], t_min=0.0, t_max=2.0, **kw)
+    if name == "pde":                       # default Solver2D: 32 x 32 noisy grid
+        zero = lambda v: 0 * v
+        return Solver2D(lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2)],
+                        [DirichletBVP2D(0, lambda y: torch.sin(3.14159265 * y), 1, zero, 0, zero, 1, zero)],
+                        xy_min=(0, 0), xy_max=(1, 1), **kw)
+    if name == "system":                    # README's Lotka-Volterra system: two default networks behind one closure launch
+        return Solver1D(lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)], [IVP(0.0, 1.5), IVP(0.0, 1.0)],
+                        t_min=0.1, t_max=12.0, **kw)
+    if name == "odd":                       # 20 points per batch: no one-call bulk draw (not a multiple of 16), ragged last tile
+        return Solver1D(lambda u, t: [diff(u, t, order=2) + u], [IVP(0.0, 0.0, 1.0)],
+                        train_generator=Generator1D(20, 0.0, 2.0, method="equally-spaced-noisy"),
+                        valid_generator=Generator1D(37, 0.0, 2.0, method="equally-spaced"), **kw)
+    if name == "static_train":              # the same grid every epoch, no validation at all
+        return Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)],
+                        train_generator=Generator1D(64, 0.0, 2.0, method="equally-spaced"),
+                        valid_generator=Generator1D(64, 0.0, 2.0, method="equally-spaced"), n_batches_valid=0, **kw)
+    raise KeyError(name)
+
+
+def _state(solver):
+    h = solver.metrics_history
+    opt = solver.optimizer.state_dict()["state"]
+    return dict(train=list(h["train_loss"]), valid=list(h["valid_loss"]), lowest=solver.lowest_loss,
+                best=R.get_flat(solver.best_nets).cpu().numpy() if solver.best_nets is not None else None,
+                params=R.get_flat(solver.nets).cpu().numpy(), steps=[int(v["step"]) for v in opt.values()],
+                m=np.concatenate([v["exp_avg"].detach().cpu().numpy().ravel() for v in opt.values()]),
+                rng=torch.get_rng_state().clone(), epoch=solver.global_epoch,
+                batch=[c.detach().cpu().numpy() for c in solver._batch["train"]])
+
+
+def _same(a, b):
+    assert a["train"] == b["train"] and a["valid"] == b["valid"], (a["train"][-3:], b["train"][-3:], a["valid"][-3:], b["valid"][-3:])
+    assert a["lowest"] == b["lowest"] and a["steps"] == b["steps"] and a["epoch"] == b["epoch"]
+    assert np.array_equal(a["params"], b["params"]) and np.array_equal(a["m"], b["m"])
+    assert (a["best"] is None) == (b["best"] is None) and (a["best"] is None or np.array_equal(a["best"], b["best"]))
+    assert torch.equal(a["rng"], b["rng"])
+    assert all(np.array_equal(x, y) for x, y in zip(a["batch"], b["batch"]))
+
+
+@pytest.mark.parametrize("name", ["ode", "pde", "system", "odd", "static_train"])
+def test_multi_epoch_fit_is_bit_identical_to_epoch_by_epoch(monkeypatch, name):
+    from neurodiffeq_amd.solvers import BaseSolver
+    monkeypatch.setattr(BaseSolver, "FIT_CHUNK", 7)         # 23 epochs = 1 ordinary epoch + chunks of 7, 7, 7 and 1 single
+    epochs = 23
+
+    def run(how):
+        torch.manual_seed(0)
+        solver = _problem(name)
+        solver.fused = "require"
+        torch.manual_seed(11)
+        calls = []
+        if how == "chunks":
+            chunk = BaseSolver._fit_chunk
+            monkeypatch.setattr(BaseSolver, "_fit_chunk", lambda self, rem: calls.append(chunk(self, rem)) or calls[-1])
+            solver.fit(epochs, tqdm_file=None)
+            monkeypatch.setattr(BaseSolver, "_fit_chunk", chunk)
+        elif how == "callback":
+            solver.fit(epochs, callbacks=[lambda s: None], tqdm_file=None)
+        else:
+            for _ in range(epochs):
+                solver.run_train_epoch()
+                solver.run_valid_epoch()
+        return _state(solver), calls, solver
+
+    a, calls, sa = run("chunks")
+    assert [k for k in calls if k] == [7, 7, 7], calls      # (the first epoch runs alone: the closure kernel's self-check)
+    assert sa._fused_sys.fused_check["train_valid_launch_identical"]
+    b, _, _ = run("callback")
+    c, _, _ = run("epochs")
+    assert len(a["train"]) == epochs and len(a["valid"]) == (0 if name == "static_train" else epochs)
+    _same(a, b)
+    _same(a, c)
+    assert a["lowest"] == min(a["valid"] if a["valid"] else a["train"])
+
+
+@pytest.mark.parametrize("name", ["ode", "system"])
+def test_multi_epoch_fit_matches_the_general_host_synchronising_path(name):
+    """... and (to rounding: different summation orders of the second stage) the general path, where every epoch's loss
+    is read on the host and torch bookkeeping does the rest.  A no-op metric forces that path."""
+    def run(native):
+        torch.manual_seed(0)
+        solver = _problem(name, metrics=None if native else {"zero": lambda *a: (a[0] * 0).mean()})
+        solver.fused = "require"
+        torch.manual_seed(3)
+        solver.fit(40, tqdm_file=None)
+        return _state(solver)
+
+    a, b = run(True), run(False)
+    assert np.allclose(a["train"], b["train"], rtol=3e-5) and np.allclose(a["valid"], b["valid"], rtol=3e-5)
+    assert abs(a["lowest"] - b["lowest"]) <= 3e-5 * abs(b["lowest"])
+    assert np.linalg.norm(a["params"] - b["params"]) <= 2e-5 * np.linalg.norm(b["params"])
+    assert np.linalg.norm(a["best"] - b["best"]) <= 2e-5 * np.linalg.norm(b["best"])
+    assert torch.equal(a["rng"], b["rng"]) and a["steps"] == b["steps"]
+
+
+def test_history_ring_wraps_and_a_fit_can_be_continued(monkeypatch):
+    """The device-side history ring (engine.FusedSystem.HIST slots) is flushed between chunks; a second fit() continues
+    where the first one stopped, and epochs run one by one in between see the same optimiser state."""
+    from neurodiffeq_amd.engine import FusedSystem
+    monkeypatch.setattr(FusedSystem, "HIST", 16)
+
+    def run(split):
+        torch.manual_seed(0)
+        solver = _problem("ode")
+        solver.fused = "require"
+        torch.manual_seed(4)
+        if split:
+            solver.fit(21, tqdm_file=None)
+            solver.run_train_epoch()
+            solver.run_valid_epoch()
+            assert solver.global_epoch == 22 and len(solver.metrics_history["valid_loss"]) == 22
+            solver.fit(28, tqdm_file=None)
+        else:
+            solver.fit(50, tqdm_file=None)
+        return _state(solver)
+
+    _same(run(True), run(False))
+
+
+def test_resident_training_batches_and_no_validation():
+    """Pre-sampled batches resident in HBM (ResidentBatchGenerator) are read in place by every epoch of a chunk; without
+    validation epochs the best network follows the training loss (solvers.py:414-415)."""
+    from neurodiffeq_amd.generators import Generator2D, ResidentBatchGenerator
+    from tests import configs
+
+    def run(chunked):
+        torch.manual_seed(0)
+        solver, cfg = configs.make_solver("c2", 16, n_batches_valid=0)
+        solver.fused = "require"
+        torch.manual_seed(9)
+        gen = ResidentBatchGenerator.presample(Generator2D((16, 16), (0, 0), (1, 1), method="equally-spaced-noisy"), 5, "cuda")
+        solver.generator["train"].generator = gen
+        solver.fit(17, tqdm_file=None, callbacks=() if chunked else [lambda s: None])
+        return _state(solver)
+
+    a, b = run(True), run(False)
+    _same(a, b)
+    assert a["valid"] == [] and a["lowest"] == min(a["train"]) and a["steps"] == [17] * len(a["steps"])
