@@ -34,6 +34,7 @@ from .networks import describe
 
 _ENABLED = os.environ.get("NDQ_NATIVE_AUTOGRAD", "1") != "0"
 _MAX_ORDER = 2
+_COORD_GRADS = True             # see set_native_autograd(coordinate_grads=...)
 _DEVICE_TYPES = ("cuda",)       # tests add "cpu" after registering oracle-backed CPU kernels for the two ops
 
 
@@ -41,30 +42,40 @@ class JetOrderError(RuntimeError):
     """A derivative of the network output beyond what the HIP forward launch provided was requested."""
 
 
-def set_native_autograd(enabled=True, max_order=2):
+def set_native_autograd(enabled=True, max_order=2, coordinate_grads=True):
     """Switch the HIP path of plain ``net(x)`` calls on / off; ``max_order`` in {0, 1, 2, 3}: highest derivative of the
     network output w.r.t. its inputs the forward launch provides (lower = fewer streams = less work per call; 3 --
-    tanh / sin / sigmoid networks -- carries every third-order partial: 10 streams for two inputs, 20 for three)."""
-    global _ENABLED, _MAX_ORDER
+    tanh / sin / sigmoid networks -- carries every third-order partial: 10 streams for two inputs, 20 for three).
+
+    ``coordinate_grads``: ``loss.backward()`` of the reference also leaves d loss / d x in the ``.grad`` of the sampled
+    coordinate tensors (nobody reads it in a training step; residual-adaptive samplers might).  For a residual with
+    k-th order derivatives that gradient needs the (k + 1)-th order streams of the network: one more forward launch
+    with the larger stream set (or, where no such kernel exists, a recomputation on plain torch autograd) per backward
+    pass.  True (default): always produce it, like the reference.  False: skip it when the network input is made of
+    plain coordinate leaves only -- their ``.grad`` then stays None; gradients that flow on into trainable tensors
+    UPSTREAM of the network input (a learnable input scaling, an embedding, another network) are always exact."""
+    global _ENABLED, _MAX_ORDER, _COORD_GRADS
     if max_order not in (0, 1, 2, 3):
         raise ValueError("max_order must be 0, 1, 2 or 3")
-    _ENABLED, _MAX_ORDER = bool(enabled), int(max_order)
+    _ENABLED, _MAX_ORDER, _COORD_GRADS = bool(enabled), int(max_order), bool(coordinate_grads)
 
 
 class native_autograd:
     """Context manager: ``with native_autograd(False): ...`` runs plain torch forwards inside."""
 
-    def __init__(self, enabled=True, max_order=None):
-        self.want = (bool(enabled), _MAX_ORDER if max_order is None else int(max_order))
+    def __init__(self, enabled=True, max_order=None, coordinate_grads=None):
+        """``None`` keeps a setting as it is (``enabled=None``: only the other two change)."""
+        self.want = (_ENABLED if enabled is None else bool(enabled), _MAX_ORDER if max_order is None else int(max_order),
+                     _COORD_GRADS if coordinate_grads is None else bool(coordinate_grads))
 
     def __enter__(self):
-        global _ENABLED, _MAX_ORDER
-        self.keep = (_ENABLED, _MAX_ORDER)
-        _ENABLED, _MAX_ORDER = self.want
+        global _ENABLED, _MAX_ORDER, _COORD_GRADS
+        self.keep = (_ENABLED, _MAX_ORDER, _COORD_GRADS)
+        _ENABLED, _MAX_ORDER, _COORD_GRADS = self.want
 
     def __exit__(self, *exc):
-        global _ENABLED, _MAX_ORDER
-        _ENABLED, _MAX_ORDER = self.keep
+        global _ENABLED, _MAX_ORDER, _COORD_GRADS
+        _ENABLED, _MAX_ORDER, _COORD_GRADS = self.keep
 
 
 def _pairs(d):
@@ -156,36 +167,107 @@ def _(coords, params, gbar, n, order, hidden, layers, act, n_out):
 
 
 # ------------------------------------------------------------------------------------------------ autograd node
+def _will_run(node):
+    """Will the autograd engine execute ``node`` in the backward pass that is running?  (False for the inputs a
+    ``torch.autograd.grad(..., inputs=[x])`` sweep does not ask for.)  Unknown -> assume yes."""
+    if node is None:
+        return False
+    try:
+        return bool(torch._C._will_engine_execute_node(node))
+    except Exception:           # noqa: BLE001 -- not inside a backward pass / private API moved: be conservative
+        return True
+
+
+def _only_coordinate_leaves(node, limit=256):
+    """True if everything upstream of ``node`` ends in leaf tensors that are NOT ``nn.Parameter``s (sampled coordinates
+    and constants); False as soon as a parameter shows up or the graph is larger than ``limit`` nodes."""
+    seen, todo = set(), [node]
+    while todo:
+        n = todo.pop()
+        if n is None or id(n) in seen:
+            continue
+        seen.add(id(n))
+        if len(seen) > limit:
+            return False
+        var = getattr(n, "variable", None)              # AccumulateGrad
+        if var is not None:
+            if isinstance(var, torch.nn.Parameter):
+                return False
+            continue
+        todo.extend(fn for fn, _ in n.next_functions)
+    return True
+
+
 class MlpJet(torch.autograd.Function):
-    """outputs: one (N, n_out) tensor per stream, in kernel order; output 0 is the network output itself."""
+    """inputs: X (N, d), the network's flat parameter vector (``torch.cat`` of its parameters: ONE tensor input whose
+    producer node the engine can be asked about, see ``_will_run``); outputs: one (N, n_out) tensor per stream, in
+    kernel order; output 0 is the network output itself.
+
+    ``backward`` never drops a gradient silently: what the streams of the forward launch cannot express --
+    the input gradient of a top-order stream, parameter gradients that have to be differentiable themselves -- is
+    obtained from a forward launch with the next-higher stream set or recomputed on plain torch autograd."""
 
     @staticmethod
-    def forward(ctx, X, spec, *params):
+    def forward(ctx, X, flat_in, spec, net, params):
         d, order, hidden, layers, act, n_out = spec
         n = X.shape[0]
         ld = _round_up(n, 64)
         coords = torch.zeros(d, ld, dtype=X.dtype, device=X.device)
         coords[:, :n] = X.detach().t()
-        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        flat = flat_in.detach()
         jets = torch.ops.ndq.mlp_jet_fwd(coords, flat, n, order, hidden, layers, act, n_out)
         outs = tuple(jets[s * n_out:(s + 1) * n_out, :n].t() for s in range(len(_streams(d, order))))
-        ctx.spec, ctx.n, ctx.ld = spec, n, ld
-        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.spec, ctx.n, ctx.ld, ctx.net, ctx.params = spec, n, ld, net, params
+        ctx.coord_grads = _COORD_GRADS
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(coords, flat, *outs)
+        ctx.save_for_backward(coords, flat, X, *outs)
         return outs
+
+    @staticmethod
+    def _plain_vjp(ctx, X, gouts, want_x, want_p, create_graph):
+        """The vector-Jacobian product of this node recomputed on plain torch autograd (the reference's own cost model:
+        one nested sweep per stream): exact for every stream order, differentiable when ``create_graph``.  Returns
+        (gX or None, flat parameter gradient or None)."""
+        d, order, hidden, layers, act, n_out = ctx.spec
+        streams = _streams(d, order)
+        params = list(ctx.params)
+        with native_autograd(False), torch.enable_grad():
+            Xr = X if (create_graph and X.requires_grad) else X.detach().requires_grad_(True)
+            y = ctx.net(Xr)
+            vals = {(): [y[:, j:j + 1] for j in range(n_out)]}
+            for mi in streams[1:]:
+                parent = vals[mi[:-1]]
+                vals[mi] = [torch.autograd.grad(c, Xr, torch.ones_like(c), create_graph=True)[0][:, mi[-1]:mi[-1] + 1]
+                            for c in parent]
+            outs, gos = [], []
+            for s, g in enumerate(gouts):
+                if g is not None:
+                    outs.append(torch.cat(vals[streams[s]], dim=1))
+                    gos.append(g)
+            wrt = ([Xr] if want_x else []) + (params if want_p else [])
+            got = list(torch.autograd.grad(outs, wrt, gos, create_graph=create_graph, allow_unused=True)) if wrt else []
+        gX = got.pop(0) if want_x else None
+        gflat = None
+        if want_p:
+            gflat = torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(got, params)])
+        return gX, gflat
 
     @staticmethod
     def backward(ctx, *gouts):
         d, order, hidden, layers, act, n_out = ctx.spec
-        coords, flat, *outs = ctx.saved_tensors
+        coords, flat, X, *outs = ctx.saved_tensors
         streams = _streams(d, order)
         index = {mi: k for k, mi in enumerate(streams)}
         n, ld = ctx.n, ctx.ld
-        second = any(g is not None and len(streams[s]) == order and order >= 2 for s, g in enumerate(gouts))
+        # which gradients does THIS backward pass need?  (a diff() sweep asks for the input only, autograd.grad(loss,
+        # params) for the parameters only, loss.backward() for everything that requires grad)
+        nf = ctx.next_functions                    # one entry per TENSOR input: X, the flat parameter vector
+        want_x = bool(ctx.needs_input_grad[0]) and _will_run(nf[0][0])
+        want_p = bool(ctx.needs_input_grad[1]) and _will_run(nf[1][0])
+        top = any(g is not None and len(streams[s]) == order for s, g in enumerate(gouts))    # adjoint on a top-order stream
 
-        def input_grad():
-            """sum_s g_s * d(stream s)/dx_a for every input a, from the node's own outputs"""
+        def input_grad(values, idx):
+            """sum_s g_s * d(stream s)/dx_a for every input a, from stream values ``values`` indexed by ``idx``"""
             cols = []
             for a in range(d):
                 tot = None
@@ -193,12 +275,12 @@ class MlpJet(torch.autograd.Function):
                     if g is None:
                         continue
                     mi = tuple(sorted(streams[s] + (a,)))
-                    if mi not in index:
+                    if mi not in idx:
                         raise JetOrderError(
                             f"derivative of order {len(mi)} of a network output w.r.t. its inputs requested, but the HIP "
                             f"forward provides orders <= {order}: call neurodiffeq_amd.set_native_autograd(max_order=3) "
                             "for third order, or set_native_autograd(False) for the plain torch forward")
-                    t = g * outs[index[mi]]
+                    t = g * values[idx[mi]]
                     if n_out > 1:
                         t = t.sum(dim=1, keepdim=True)
                     tot = t if tot is None else tot + t
@@ -206,29 +288,37 @@ class MlpJet(torch.autograd.Function):
             return torch.cat(cols, dim=1)
 
         if torch.is_grad_enabled():
-            # a sweep of diff() (create_graph=True): only the input gradient matters, as a differentiable expression
-            gX = input_grad() if ctx.needs_input_grad[0] else None
-            return (gX, None) + (None,) * len(ctx.shapes)
+            # a higher-order graph is being built.  diff() sweeps (create_graph=True, inputs = coordinates) need the
+            # input gradient as a differentiable expression of this node's own outputs; parameter gradients that must be
+            # differentiable (loss.backward(create_graph=True)) cannot come from the adjoint kernel: plain torch
+            if want_p:
+                gX, gflat = MlpJet._plain_vjp(ctx, X, gouts, want_x, True, True)
+                return gX, gflat, None, None, None
+            return (input_grad(outs, index) if want_x else None), None, None, None, None
         # the final backward: parameter gradients from ONE adjoint launch over all streams
-        grads = [None] * len(ctx.shapes)
-        if any(ctx.needs_input_grad[2:]):
+        gflat = None
+        if want_p:
             gbar = torch.zeros(len(streams) * n_out, ld, dtype=coords.dtype, device=coords.device)
             for s, g in enumerate(gouts):
                 if g is not None:
                     gbar[s * n_out:(s + 1) * n_out, :n] = g.t()
             gflat = torch.ops.ndq.mlp_jet_bwd(coords, flat, gbar, n, order, hidden, layers, act, n_out)
-            off = 0
-            for k, shape in enumerate(ctx.shapes):
-                cnt = 1
-                for v in shape:
-                    cnt *= v
-                if ctx.needs_input_grad[2 + k]:
-                    grads[k] = gflat[off:off + cnt].view(shape)
-                off += cnt
-        # d loss / d inputs of the network part: available unless it needs third-order streams (a training step never
-        # reads it; the reference computes it and throws it away)
-        gX = input_grad() if (ctx.needs_input_grad[0] and not second) else None
-        return (gX, None) + tuple(grads)
+        # d loss / d inputs: from the node's own streams unless a top-order stream carries an adjoint -- then it needs
+        # the streams one order up (the reference computes this gradient in every step and nobody reads it, SURVEY.md
+        # App. A.2; it matters when trainable tensors sit upstream of the network input)
+        gX = None
+        if want_x and not top:
+            gX = input_grad(outs, index)
+        elif want_x and (ctx.coord_grads or not _only_coordinate_leaves(nf[0][0])):
+            up = _spec_for(ctx.net, order + 1, coords.dtype) if order + 1 <= 3 else None
+            if up is not None:
+                jets = torch.ops.ndq.mlp_jet_fwd(coords, flat, n, order + 1, hidden, layers, act, n_out)
+                hi = _streams(d, order + 1)
+                vals = [jets[s * n_out:(s + 1) * n_out, :n].t() for s in range(len(hi))]
+                gX = input_grad(vals, {mi: k for k, mi in enumerate(hi)})
+            else:
+                gX, _ = MlpJet._plain_vjp(ctx, X, gouts, True, False, False)
+        return gX, gflat, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ the seam
@@ -271,4 +361,6 @@ def try_jet_forward(net, t):
     params = spec[1]
     if any(p.device != t.device or p.dtype != t.dtype for p in params):
         return None
-    return MlpJet.apply(t, spec[0], *params)[0]
+    # the parameters enter as ONE flat vector (torch.cat hands its gradient back to every p.grad)
+    flat = torch.cat([p.reshape(-1) for p in params])
+    return MlpJet.apply(t, flat, spec[0], net, params)[0]

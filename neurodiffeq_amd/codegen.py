@@ -126,7 +126,7 @@ _UN_ADJ = {
 }
 
 
-def _tv_launcher(args_t, fill, kern_tv, lds_train, lds_eval):
+def _tv_launcher(args_t, fill, kern_tv, lds_train, lds_eval, threads="CFG::BWD_THREADS"):
     """Host launcher of the train + validation closure kernel (csrc/ndq_mlp.h: fused_*_closure_tv_kernel), emitted into
     the anonymous namespace of every generated closure module: workgroups [0, blocks(n)) run the training closure on the
     training batch, the next blocks(vn) the forward-only closure on the validation batch; n = 0 / vn = 0 drops a half."""
@@ -156,7 +156,7 @@ int launch_tv(const float* coords, int ldc, int n, const float* const* params, f
     if (e != hipSuccess) return (int)e;
     attr = true;
   }}
-  hipLaunchKernelGGL(({kern_tv}), dim3(tb + vb), dim3(CFG::BWD_THREADS), tb > 0 ? {lds_train} : {lds_eval},
+  hipLaunchKernelGGL(({kern_tv}), dim3(tb + vb), dim3({threads}), tb > 0 ? {lds_train} : {lds_eval},
                      static_cast<hipStream_t>(stream), t, v, tb);
   return (int)hipGetLastError();
 }}"""
@@ -450,7 +450,10 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         kern = (lambda train: f"ndq::fused_closure_kernel<CFG, PW, {train}>") if K == 1 else \
             (lambda train: f"ndq::fused_multi_closure_kernel<CFG, {K}, PW, {train}>")
         lds = (lambda train: f"ndq::fused_lds_bytes<CFG>({train})") if K == 1 else \
-            (lambda train: f"ndq::fused_multi_lds_bytes<CFG>({K}, {train})")
+            (lambda train: f"(ndq::fused_multi_lds_bytes<CFG, {K}>({train}))")
+        # workgroup shape: waves x tiles per round (multi-network closure: K x G waves, G tile slots -- csrc/ndq_mlp.h)
+        threads = "CFG::BWD_THREADS" if K == 1 else f"ndq::multi_threads<{K}>()"
+        tiles_per_block = "CFG::BWD_THREADS / 64" if K == 1 else f"ndq::multi_group<{K}>()"
         if K == 1:
             args_t = "ndq::FusedArgs"
             fill = "a.params = params[0]; a.partials = partials ? partials[0] : nullptr;"
@@ -459,7 +462,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
             args_t = "ndq::FusedMultiArgs"
             fill = f"for (int k = 0; k < {K}; ++k) {{ a.params[k] = params[k]; a.partials[k] = partials ? partials[k] : nullptr; }}"
             kern_tv = f"ndq::fused_multi_closure_tv_kernel<CFG, {K}, PW>"
-        tv = _tv_launcher(args_t, fill, kern_tv, lds('true'), lds('false'))
+        tv = _tv_launcher(args_t, fill, kern_tv, lds('true'), lds('false'), threads)
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- single-launch closure kernel (forward streams + pointwise stage +
 // reverse pass) of one PDE system with {K} network(s), gfx950.
 #include "{header}"
@@ -479,7 +482,7 @@ struct PW {{
 {chr(10).join(stores)}
   }}
 }};
-constexpr int kWaves = CFG::BWD_THREADS / 64;
+constexpr int kWaves = {tiles_per_block};        // tiles a workgroup handles per round
 int fused_blocks(int n) {{
   const int tiles = (n + 15) / 16;
   int b = (tiles + kWaves - 1) / kWaves;
@@ -506,9 +509,9 @@ int launch(const float* coords, int ldc, int n, const float* const* params, floa
     attr = true;
   }}
   if (train)
-    hipLaunchKernelGGL(({kern('true')}), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS), {lds('true')}, s, a);
+    hipLaunchKernelGGL(({kern('true')}), dim3(fused_blocks(n)), dim3({threads}), {lds('true')}, s, a);
   else
-    hipLaunchKernelGGL(({kern('false')}), dim3(fused_blocks(n)), dim3(CFG::BWD_THREADS), {lds('false')}, s, a);
+    hipLaunchKernelGGL(({kern('false')}), dim3(fused_blocks(n)), dim3({threads}), {lds('false')}, s, a);
   return (int)hipGetLastError();
 }}
 {tv}
@@ -517,7 +520,7 @@ int launch(const float* coords, int ldc, int n, const float* const* params, floa
 extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
 extern "C" int ndq_fused_num_params() {{ return CFG::P; }}
 extern "C" int ndq_fused_num_nets() {{ return {K}; }}
-extern "C" int ndq_fused_threads() {{ return CFG::BWD_THREADS; }}
+extern "C" int ndq_fused_threads() {{ return {threads}; }}
 extern "C" unsigned long ndq_fused_lds_bytes() {{ return (unsigned long){lds('true')}; }}
 
 #ifdef NDQ_PHASE_TS

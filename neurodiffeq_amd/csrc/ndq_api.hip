@@ -1,5 +1,6 @@
 // C-ABI of libndq.so (declared in include/ndq.h): descriptor dispatch onto the templated gfx950 kernels of
 // ndq_mlp.h, the second-stage reduction and the fused Adam step.
+#include <cstdlib>
 #include <vector>
 #include "ndq_launch.h"
 #include "ndq_sample.h"
@@ -318,6 +319,8 @@ __global__ __launch_bounds__(1024) void reduce_tail_dp_kernel(ReduceTailArgs a, 
   __shared__ float sm[16 * 64];
   __shared__ float smw[16];
   __shared__ float sloss;
+  __shared__ int timed_out;
+  if (threadIdx.x == 0) timed_out = 0;
   const int tid = threadIdx.x, col = tid & 63, rg = tid >> 6, blk = blockIdx.x;
   const int i = blk * 64 + col;
   const bool incol = i < a.r.len;
@@ -368,28 +371,24 @@ __global__ __launch_bounds__(1024) void reduce_tail_dp_kernel(ReduceTailArgs a, 
     unsigned* f = c.flags[tid] + ((size_t)parity * c.world + c.rank) * c.max_blocks + blk;
     __hip_atomic_store(f, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned* mine = c.flags[c.rank] + ((size_t)parity * c.world + tid) * c.max_blocks + blk;
-    unsigned spins = 0;
-    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != step) {
-      if (++spins > ndq::kOneshotSpinLimit) {
-        atomicAdd(c.status, 1u);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
+    if (!ndq::oneshot_wait(mine, step, c.spin_limit, c.status)) timed_out = 1;
   }
   __syncthreads();
+  // a peer's slice never arrived (counted in the status word, which the solver turns into an error at its next history
+  // flush): no parameter is updated with a stale inbox, and the epoch's loss is NaN
+  const bool bad = timed_out != 0;
   // ---- fixed-order sum over the ranks, then the tail on the global values
   const float* inbox = c.inbox[c.rank] + (size_t)parity * c.world * c.max_len + (size_t)blk * 65;
   if (tid == 0) {
     float loss = 0.f;
     for (int q = 0; q < c.world; ++q)
       loss += __hip_atomic_load(inbox + (size_t)q * c.max_len + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    sloss = loss;
+    sloss = bad ? __builtin_nanf("") : loss;
   }
   __syncthreads();
   const float loss = sloss;
   const bool better = (a.t.best_flat != nullptr) && (loss < best);
-  if (upd) {
+  if (upd && !bad) {
     float g = 0.f;
     for (int q = 0; q < c.world; ++q)
       g += __hip_atomic_load(inbox + (size_t)q * c.max_len + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -742,6 +741,8 @@ int ndq_oneshot_create(int rank, int world, int max_len, void** out, unsigned ch
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handles are 64 bytes");
   std::memcpy(handle64, &h, 64);
   c->dev.rank = rank; c->dev.world = world; c->dev.max_len = max_len; c->dev.max_blocks = max_blocks;
+  c->dev.spin_limit = ndq::kOneshotSpinLimit;
+  if (const char* e = std::getenv("NDQ_ONESHOT_SPIN_LIMIT")) c->dev.spin_limit = std::strtoull(e, nullptr, 10);
   c->dev.status = reinterpret_cast<unsigned*>(static_cast<char*>(c->base) + c->inbox_bytes + c->flag_bytes);
   c->step = 0;
   *out = c;

@@ -2001,11 +2001,15 @@ __device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stag
 // Round k handles waves [k*R, (k+1)*R): round 0 stores, later rounds use no-return ds_add_f32 (each address is
 // touched once per wave and rounds are separated by barriers, so the summation order is fixed); finally every thread
 // adds the R regions in order and writes the workgroup's row of partials.
-template <class C, int WAVES>
+// RR != 0: number of regions given by the caller; tid / nt: this thread's index among the nt threads that reduce
+// together (default: the whole workgroup) -- the multi-network closure reduces network by network, all at once.
+template <class C, int WAVES, int RR = 0>
 __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, int wave, int lane, int p, int q,
-                                                   real* __restrict__ out, const real* __restrict__ prm = nullptr) {
+                                                   real* __restrict__ out, const real* __restrict__ prm = nullptr,
+                                                   int tid = -1, int nt = 0) {
   constexpr int PP = (C::P + 3) & ~3;
-  constexpr int R = bwd_regions<C>(WAVES);
+  constexpr int R = RR != 0 ? RR : bwd_regions<C>(WAVES);
+  if (tid < 0) { tid = threadIdx.x; nt = blockDim.x; }
   real* red0 = lds + C::ldsWeightsEnd(true);
   const real bsum = point_sum(quad_sum(acc.bout));
   real apsum[C::L][3];
@@ -2160,11 +2164,11 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
     return v;
   };
   if constexpr (C::ACTP == 0) {
-    for (int i = threadIdx.x; i < C::P; i += blockDim.x) out[i] = total(i);
+    for (int i = tid; i < C::P; i += nt) out[i] = total(i);
   } else {
     // the tile loop ran on scaled weights (stage_weights: W' = f W): dW = f dW'
     auto segment = [&](int lo, int hi, real f) {
-      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) out[i] = total(i) * f;
+      for (int i = lo + tid; i < hi; i += nt) out[i] = total(i) * f;
     };
     segment(C::offW1, C::offb1 + C::hr(1), act_pre<C>(prm, 1));
     sfor<C::L - 1>([&](auto k_) {
@@ -2373,41 +2377,78 @@ struct FusedMultiArgs {
   real seed;
 };
 
+// Workgroup shape (round 3): the K networks of a tile run CONCURRENTLY on K waves -- wave (k, g) carries network k for
+// tile slot g of the round -- instead of one wave running K forward passes, the pointwise stage and then K times
+// (forward again + reverse).  The K waves of a tile exchange their output streams through a small LDS block (double
+// buffered: one workgroup barrier per round), every one of them evaluates the pointwise stage for the tile's points
+// (a handful of operations for systems of ODEs) and keeps the adjoint seeds of its own network, whose layer states are
+// still in its registers: no second forward pass, and the serial chain of a round is one network deep instead of K.
+// Waves per workgroup: K x G with G = 2 tile slots for K = 2, one for K = 3, 4 -- never more than one wave per SIMD,
+// so every wave has the whole register file (Cfg must be the 256-thread build: KEEP_H, no laundering).
+template <int K> constexpr int multi_group() { return K == 2 ? 2 : 1; }
+template <int K> constexpr int multi_threads() { return 64 * K * multi_group<K>(); }
+// reduction regions of one network's G waves (they overlay those waves' transpose staging tiles)
+template <class C, int K> constexpr int multi_regions() {
+  const int pp = (C::P + 3) & ~3, g = multi_group<K>();
+  int r = (g * C::stageFloatsPerWave) / pp;
+  return r < 1 ? 1 : (r > g ? g : r);
+}
+template <class C, int K> constexpr int multi_group_floats() {
+  const int pp = (C::P + 3) & ~3, st = multi_group<K>() * C::stageFloatsPerWave, red = multi_regions<C, K>() * pp;
+  return ((st > red ? st : red) + 3) & ~3;
+}
+template <class C, int K> constexpr int multi_xchg_floats() { return 2 * multi_group<K>() * K * C::NS * 16; }
+
 template <class C, int K, class PW, bool TRAIN>
 __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a, real* lds, const int blk, const int nblk) {
   static_assert(C::NOUT == 1 && !C::WIDE && K >= 2 && K <= kMaxFusedNets, "multi-network closure: n_out = 1, H <= 48, 2..4 nets");
+  static_assert(C::BWD_THREADS == 256, "multi-network closure: one wave per SIMD (build without NDQ_BWD_THREADS)");
   constexpr int WS = C::ldsWeightsEnd(TRAIN);          // LDS floats per weight image
+  constexpr int G = multi_group<K>(), WAVES = K * G;
 #pragma unroll
-  for (int k = 0; k < K; ++k) stage_weights<C, TRAIN>(lds + k * WS, a.params[k]);
+  for (int kk = 0; kk < K; ++kk) stage_weights<C, TRAIN>(lds + kk * WS, a.params[kk]);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
-  constexpr int WAVES = C::BWD_THREADS / 64;
+  const int k = wave / G, g = wave - k * G;            // this wave's network and its tile slot in a round
+  const real* ldsw = lds + k * WS;
   const int ntiles = (a.n + 15) >> 4;
-  real* stage = lds + K * WS + wave * C::stageFloatsPerWave;
-  GradAcc<C> acc[K];
-  if constexpr (TRAIN) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) { acc_zero<C>(acc[k]); acc[k].bias = nullptr; }
-  }
+  real* work = lds + K * WS;                           // per network: G staging tiles (later: its reduction regions)
+  real* stage = work + k * multi_group_floats<C, K>() + g * C::stageFloatsPerWave;
+  real* xchg = work + (TRAIN ? K * multi_group_floats<C, K>() : 0);
+  GradAcc<C> acc;
+  if constexpr (TRAIN) { acc_zero<C>(acc); acc.bias = nullptr; }
   real lsum = 0.f;
-  for (int tile = blk * WAVES + wave; tile < ntiles; tile += nblk * WAVES) {
-    const int n = tile * 16 + p;
+  int par = 0;
+  // every wave of the workgroup runs the same number of rounds (one barrier each); a slot past the last tile works on
+  // a copy of the last point with zero seeds
+  for (int tile0 = blk * G; tile0 < ntiles; tile0 += nblk * G, par ^= 1) {
+    const int n = (tile0 + g) * 16 + p;
     const bool valid = n < a.n;
     const int nn = valid ? n : a.n - 1;
     real x[C::D];
 #pragma unroll
     for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    LayerState<C> st[C::L];
+    real4 h[C::NS][C::NB];
+    KeptPlanes<C> kp;
+    tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp);
+    real* xr = xchg + (par * G + g) * (K * C::NS * 16);        // [K][NS][16 points] of this tile
+    {
+      real mine[C::NS];
+      tile_output<C, TRAIN>(ldsw, q, x, h, mine);
+      if (q == 0) {
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) xr[(k * C::NS + s) * 16 + p] = mine[s];
+      }
+    }
+    __syncthreads();
     real jets[K][C::NS], gout[K][C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
-    sfor<K>([&](auto k_) {
-      constexpr int k = decltype(k_)::value;
-      LayerState<C> st[C::L];
-      real4 h[C::NS][C::NB];
-      KeptPlanes<C> kp;
-      tile_forward<C, TRAIN>(lds + k * WS, lane, q, x, st, h, kp);
-      tile_output<C, TRAIN>(lds + k * WS, q, x, h, jets[k]);
-    });
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk)
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s) jets[kk][s] = xr[(kk * C::NS + s) * 16 + p];
     PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
-    if (valid && q == 0) {
+    if (valid && q == 0 && k == 0) {
       lsum += PW::loss(r);
       if (a.resid) {
 #pragma unroll
@@ -2419,27 +2460,25 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
       }
     }
     if constexpr (TRAIN) {
-      sfor<K>([&](auto k_) {
-        constexpr int k = decltype(k_)::value;
+      real go[C::NS];
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) gout[k][s] = valid ? gout[k][s] : 0.f;
-        LayerState<C> st[C::L];
-        real4 h[C::NS][C::NB];
-        KeptPlanes<C> kp;
-        tile_forward<C, true>(lds + k * WS, lane, q, x, st, h, kp);
-        tile_backward<C>(lds + k * WS, stage, lane, p, q, x, gout[k], st, acc[k], kp);
-      });
+      for (int s = 0; s < C::NS; ++s) {
+        real v = gout[0][s];
+#pragma unroll
+        for (int kk = 1; kk < K; ++kk) v = (k == kk) ? gout[kk][s] : v;
+        go[s] = valid ? v : 0.f;
+      }
+      tile_backward<C>(ldsw, stage, lane, p, q, x, go, st, acc, kp);
     }
   }
   if constexpr (TRAIN) {
-    // block_reduce_store puts its regions right behind "the" weight image of the base it is given: hand it the last one
-    sfor<K>([&](auto k_) {
-      constexpr int k = decltype(k_)::value;
-      block_reduce_store<C, WAVES>(lds + (K - 1) * WS, acc[k], wave, lane, p, q, a.partials[k] + (size_t)blk * C::P,
-                                   a.params[k]);
-    });
+    // the G waves of a network add up among themselves (all networks at once: same barrier sequence), regions in that
+    // network's own staging area; block_reduce_store addresses its regions behind "the" weight image of its base
+    real* base = work + k * multi_group_floats<C, K>() - C::ldsWeightsEnd(true);
+    block_reduce_store<C, G, multi_regions<C, K>()>(base, acc, g, lane, p, q, a.partials[k] + (size_t)blk * C::P, a.params[k],
+                                                     g * 64 + lane, G * 64);
   }
-  lsum = point_sum(quad_sum(lsum));
+  lsum = point_sum(quad_sum(lsum));                      // non-zero in the waves of network 0 only
   __syncthreads();
   real* wl = lds + K * WS;
   if (lane == 0) wl[wave] = lsum;
@@ -2452,14 +2491,14 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
 }
 
 template <class C, int K, class PW, bool TRAIN>
-__global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_kernel(FusedMultiArgs a) {
+__global__ __launch_bounds__(multi_threads<K>()) void fused_multi_closure_kernel(FusedMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
   fused_multi_closure_body<C, K, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x);
 }
 
 // training + validation batch in one launch, as fused_closure_tv_kernel
 template <class C, int K, class PW>
-__global__ __launch_bounds__(C::BWD_THREADS) void fused_multi_closure_tv_kernel(FusedMultiArgs t, FusedMultiArgs v, int train_blocks) {
+__global__ __launch_bounds__(multi_threads<K>()) void fused_multi_closure_tv_kernel(FusedMultiArgs t, FusedMultiArgs v, int train_blocks) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
   if ((int)blockIdx.x < train_blocks) fused_multi_closure_body<C, K, PW, true>(t, lds, blockIdx.x, train_blocks);
   else fused_multi_closure_body<C, K, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks);
@@ -2669,8 +2708,9 @@ template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock);
 template <class C> constexpr size_t fused_lds_bytes(bool train) {
   return train ? bwd_lds_bytes<C>(C::BWD_THREADS / 64) : sizeof(real) * (C::ldsWeightsEnd(false) + 16);
 }
-template <class C> constexpr size_t fused_multi_lds_bytes(int nets, bool train) {
-  return fused_lds_bytes<C>(train) + sizeof(real) * (size_t)(nets - 1) * C::ldsWeightsEnd(train);
+template <class C, int K> constexpr size_t fused_multi_lds_bytes(bool train) {
+  return sizeof(real) * ((size_t)K * C::ldsWeightsEnd(train) + (train ? K * multi_group_floats<C, K>() : 0) +
+                         multi_xchg_floats<C, K>() + 16);
 }
 template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock) {
   const int pp = (C::P + 3) & ~3;

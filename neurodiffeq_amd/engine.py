@@ -114,10 +114,13 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         # rows whose batch mean is the metric
         metric_terms = []
         for fn in metrics:
-            from .symbolic import SymScalar
-            val = fn(*funcs, *coords)
+            from .symbolic import MetricTraceUnsupported, SymScalar
+            try:
+                val = fn(*funcs, *coords)
+            except Exception as e:      # noqa: BLE001 -- whatever the metric does to a traced column that it cannot take
+                raise MetricTraceUnsupported(f"a metric could not be traced ({type(e).__name__}: {e})") from e
             if not isinstance(val, SymScalar):
-                raise TraceUnsupported(f"a metric returned {type(val).__name__}, not a batch mean of traced values")
+                raise MetricTraceUnsupported(f"a metric returned {type(val).__name__}, not a batch mean of traced values")
             metric_terms.append(val.term)
     for k, info in enumerate(infos):       # a net that never appears in an equation still needs a layout
         g.net_deps.setdefault(k, tuple(range(info["d"])))
@@ -295,7 +298,10 @@ class FusedSystem:
     def _wide_possible(self):
         """Does csrc/ndq_mlp.h give this shape an 8-wave build at all?  (Cfg::BWD_THREADS: per-wave state of more than 40
         fragment blocks keeps the whole register file, i.e. 4 waves -- no point compiling to find that out)"""
-        if codegen.fuse_mode(self.program, self.descs) == "group":
+        mode = codegen.fuse_mode(self.program, self.descs)
+        if mode == "multi":
+            return False            # K x G waves, one per SIMD, whatever the batch size (csrc/ndq_mlp.h: multi_threads)
+        if mode == "group":
             return os.environ.get("NDQ_GROUP_WIDE", "0") == "1"     # experiment: 8 waves with 32-point groups
         d = self.descs[0]
         nb, layers = (d.hidden + 15) // 16, d.layers
@@ -843,7 +849,7 @@ class FusedSystem:
             st.next_coords, st.next_ldc = src.block.data_ptr(), src.block.shape[1]
         else:
             src, st.next_sampler = None, None
-        direct = dist.direct(self.device) if dist is not None else None
+        direct = dist.direct(self.device, fp.numel + 1) if dist is not None else None
         if dist is None or direct is not None:
             # one native call; with data parallelism the RCCL all-reduce of [grad | loss] is enqueued by it, on the
             # same stream, between the local sums and the tail

@@ -106,6 +106,7 @@ class OneShot:
     def __init__(self, rank, world_size, group, device, max_len=None):
         from . import _lib
         self.ok, self.ctx, self.fn = False, None, None
+        self.max_len = int(max_len or self.MAX_LEN)
         self.L = _lib.lib()
         self.device = torch.device(device)
         err = None
@@ -162,6 +163,10 @@ class OneShot:
         elif err is not None:
             warnings.warn(f"one-shot all-reduce unavailable ({err}); using RCCL")
 
+    def fits(self, numel):
+        """Does a message of ``numel`` floats fit the inboxes?  (larger ones go through torch.distributed)"""
+        return numel <= self.max_len
+
     def all_reduce(self, tensor):
         stream = ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
         rc = self.L.ndq_oneshot_allreduce(tensor.data_ptr(), tensor.data_ptr(), tensor.numel(), 7, 0, self.ctx, stream)
@@ -195,9 +200,26 @@ class BatchSharding:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return bool(t.item() == 1.0)
 
-    def direct(self, device):
+    def check(self):
+        """Raise if the one-shot exchange ever gave up waiting for a peer (its result was poisoned with NaN and the
+        parameter update of that step skipped on this rank: the replicas are no longer in step -- a fatal condition the
+        reference's RCCL path would have shown as a hang).  Synchronises; called at every history flush of a solver."""
+        d = self._direct
+        if isinstance(d, OneShot) and d.ok:
+            n = d.status()
+            if n:
+                from . import _lib
+                raise _lib.NdqError(
+                    f"data-parallel rank {self.rank}: {n} wait(s) of the one-shot all-reduce ran into the spin limit -- a "
+                    "peer rank did not deliver its gradient slice in time (crashed or stalled for minutes).  The affected "
+                    "steps were NOT applied on this rank and their loss is NaN; the replicas have diverged.  Restart from "
+                    "a checkpoint; NDQ_ONESHOT_SPIN_LIMIT (iterations of ~1 us, 0 = wait for ever) or "
+                    "NDQ_ONESHOT_ALLREDUCE=0 (RCCL) change the behaviour.")
+
+    def direct(self, device, numel=None):
         """(address of ncclAllReduce, ncclComm_t) for the native step, or None (CPU / gloo / NDQ_RCCL_DIRECT=0 /
-        communicator unavailable -> ``torch.distributed``)."""
+        communicator unavailable / a message of ``numel`` floats does not fit the one-shot inboxes ->
+        ``torch.distributed``)."""
         if self._direct is None:
             device = torch.device(device)
             on_gpu = device.type == "cuda" and dist.is_initialized()
@@ -214,6 +236,8 @@ class BatchSharding:
                 self._direct = DirectRccl(self.rank, self.world_size, self.group, device)
         d = self._direct
         if not (d and d.ok):
+            return None
+        if numel is not None and isinstance(d, OneShot) and not d.fits(numel):
             return None
         return (d.fn, d.comm.value if hasattr(d.comm, "value") else d.comm)
 
@@ -248,7 +272,8 @@ class BatchSharding:
         self._direct = False
 
     def _sum(self, t):
-        if self.direct(t.device) is not None:
+        # (message sizes are the same on every rank, so all ranks take the same branch)
+        if self.direct(t.device, t.numel()) is not None:
             self._direct.all_reduce(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

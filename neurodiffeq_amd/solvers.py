@@ -33,7 +33,7 @@ from .losses import _losses
 from .networks import FCNN, describe
 from .neurodiffeq import safe_diff as diff
 from .optim import FusedAdam
-from .symbolic import TraceUnsupported
+from .symbolic import MetricTraceUnsupported, TraceUnsupported
 
 
 _CLOSURE_CACHE = {}
@@ -79,7 +79,9 @@ def _default_l2(residual, funcs, coords):
 
 
 class BaseSolver(ABC):
-    LOSS_PROBE_EVERY = 128      # epochs between re-probes of a traced custom loss (see _fused_system)
+    LOSS_PROBE_EVERY = 1        # epochs between re-probes of a traced custom loss (see _fused_system): every epoch -- a probe
+    #                             is one Python re-trace of the callable on a hash-consed graph, and a loss that follows
+    #                             solver state (a penalty switched on at epoch N) must never train on a stale kernel
 
     """See the module docstring; constructor arguments are the reference's (solvers.py:36-140)."""
 
@@ -210,6 +212,8 @@ class BaseSolver(ABC):
         if fs is None or (fs["pending"] == 0 and fs["pending_valid"] == 0):
             return
         losses, vlosses, best = system.fast_flush()
+        if self.dist is not None:
+            self.dist.check()       # a data-parallel exchange that gave up on a peer is an error, not a statistic
         self._history["train_loss"].extend(losses)
         self._history["valid_loss"].extend(vlosses)
         if best < float("inf") and (self._lowest_loss is None or best < self._lowest_loss):
@@ -251,10 +255,16 @@ class BaseSolver(ABC):
         self._flush_device_history()
         if self._best_flat is not None:
             nets = deepcopy(self.nets)
+            # one snapshot per DISTINCT module, in first-appearance order (engine.trace_system: a module shared by several
+            # functions -- nets = [A, A, B] -- is one parameter set; deepcopy keeps the sharing)
+            distinct = []
+            for n in nets:
+                if not any(n is m for m in distinct):
+                    distinct.append(n)
             with torch.no_grad():
-                for net, flat in zip(nets, self._best_flat):
+                for net, flat in zip(distinct, self._best_flat):
                     off = 0
-                    for p in describe(net)["params"]:      # the flat vector's order (networks.FlatParams)
+                    for p in describe(net, dtype=flat.dtype)["params"]:      # the flat vector's order (networks.FlatParams)
                         p.copy_(flat[off:off + p.numel()].view(p.shape))
                         off += p.numel()
             self._best_nets = nets
@@ -385,9 +395,20 @@ class BaseSolver(ABC):
                     eqs, kind = sobolev_equations(self.diff_eqs, len(self.nets), semi=(loss_kind == "h1 semi")), "l2"
                 elif loss_kind == "custom":
                     kind = lambda r, f, x: self.loss_fn(r, f, x) + self.additional_loss(r, f, x)
-                self._fused_sys = FusedSystem(self.nets, self.conditions, eqs, n_coords, self.device,
-                                              compute_func_val=self.compute_func_val, loss=kind,
-                                              metrics=list(self.metrics_fn.values()), dtype=sys_dtype)
+                self._host_metrics = False
+                try:
+                    self._fused_sys = FusedSystem(self.nets, self.conditions, eqs, n_coords, self.device,
+                                                  compute_func_val=self.compute_func_val, loss=kind,
+                                                  metrics=list(self.metrics_fn.values()), dtype=sys_dtype)
+                except MetricTraceUnsupported:
+                    # metrics are observers: training stays fused, the metrics are evaluated on the host from the
+                    # function values of every batch (not under data parallelism: a shard's metric is not the batch's)
+                    if self.dist is not None:
+                        raise
+                    self._fused_sys = FusedSystem(self.nets, self.conditions, eqs, n_coords, self.device,
+                                                  compute_func_val=self.compute_func_val, loss=kind, metrics=(),
+                                                  dtype=sys_dtype)
+                    self._host_metrics = True
                 if isinstance(self.optimizer, FusedAdam):
                     self.optimizer.bind(self._fused_sys.flat)
             except TraceUnsupported as e:
@@ -457,7 +478,13 @@ class BaseSolver(ABC):
                 b, n = system.step(batch, train=(key == "train"), slot=batch_id, accumulate=(batch_id > 0),
                                    n_global=shard.global_n(n_all) if shard else n_all, lo=lo, hi=hi,
                                    want_funcs=bool(self.metrics_fn))
-            if self.metrics_fn:
+            if self.metrics_fn and getattr(self, "_host_metrics", False):
+                # metrics the tracer cannot express: the reference's own evaluation (solvers.py:377-379) on the function
+                # values the kernels wrote out for this batch
+                funcs, coords = system.func_columns(b, n), system.coord_columns(b, n)
+                for name, fn in self.metrics_fn.items():
+                    metric_values[name] += float(fn(*funcs, *coords))
+            elif self.metrics_fn:
                 # traced with the system: per-point terms in extra function rows; metric = their mean over the GLOBAL
                 # batch (shard sums are added up across ranks)
                 sums = system.metric_sums(b, n)
@@ -635,7 +662,13 @@ class BaseSolver(ABC):
             valid = (vres[0], vcols[0].shape[0], vres[1]) if vres is not None else system.static_block(vcols)
         # ---- K training batches in the generator's own draw order
         self._phase = "train"
+        trace = getattr(self, "_fit_trace", None)          # diagnostics (scripts/fit_profile.py): host seconds per phase
+        if trace is not None:
+            import time
+            t0 = time.perf_counter()
         block = tg.generator.bulk_examples(K)
+        if trace is not None:
+            t1 = time.perf_counter()
         if block is not None:
             tg._last = None
             dev, ld = system.stage_batches(block, n)
@@ -673,7 +706,11 @@ class BaseSolver(ABC):
         if len({s[3] for s in slots}) != 1:
             raise RuntimeError("the networks of this solver are at different Adam step counts; call fit() with "
                                "callbacks or run epochs one by one")
+        if trace is not None:
+            t2 = time.perf_counter()
         system.fit_run(ptrs, n, ld, slots, valid, track_best=2 if nv > 0 else 1)
+        if trace is not None:
+            trace.append((K, t1 - t0, t2 - t1, time.perf_counter() - t2))
         for fp in system.flat:
             if not fp.grads_attached():
                 fp.attach_grads()
@@ -701,7 +738,9 @@ class BaseSolver(ABC):
                     with autograd_ops.native_autograd(False):
                         return closure_body(zero_grad)
                 try:
-                    return closure_body(zero_grad)
+                    # (a Solver never reads the .grad of its sampled coordinates: no extra launch for them)
+                    with autograd_ops.native_autograd(None, coordinate_grads=False):
+                        return closure_body(zero_grad)
                 except autograd_ops.JetOrderError:
                     self._composite_plain = True
                     with autograd_ops.native_autograd(False):

@@ -22,6 +22,12 @@ class TraceUnsupported(Exception):
     """Raised when user code does something the tracer cannot express; the solver then uses the composite path."""
 
 
+class MetricTraceUnsupported(TraceUnsupported):
+    """A *metric* (solvers.py:377-379) is not a batch mean of traced per-point values (``.max()``, the square root of a
+    mean, ...).  Metrics do not take part in training: the solver keeps the fused path and evaluates such metrics on
+    the host from the function values the kernels write out."""
+
+
 # op -> (arity).  Unary elementwise functions are listed in UNARY.
 UNARY = ("neg", "sin", "cos", "tan", "exp", "log", "tanh", "sqrt", "abs", "sinh", "cosh", "sigmoid", "recip", "sign")
 

@@ -190,10 +190,14 @@ def test_third_order_on_request(cpu_ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("coordinate_grads", [False, True])
 @pytest.mark.parametrize("name,size", [("c2", 16), ("c1", 64), ("c3", 12), ("c4", 96)])
-def test_hand_written_loop_on_the_hip_kernels_matches_reference_trajectory(name, size):
+def test_hand_written_loop_on_the_hip_kernels_matches_reference_trajectory(name, size, coordinate_grads):
     """enforce -> diff -> .backward() -> torch.optim.Adam, three epochs, HIP forward / adjoint
-    kernels underneath (asserted through the dispatcher ops' call counts), against tests/golden/<name>.npz."""
+    kernels underneath (asserted through the dispatcher ops' call counts), against tests/golden/<name>.npz.
+    ``coordinate_grads`` (round 3): with the default (True) ``loss.backward()`` also fills the ``.grad`` of the sampled
+    coordinates like the reference does -- for a second-order residual that is one more forward launch (third-order
+    streams) per step; False is what a Solver's composite path runs with."""
     if name == "c4":
         pytest.skip("C4's enforcer is a SolverSpherical hook; covered by the closure test below")
     calls = {"fwd": 0, "bwd": 0}
@@ -209,10 +213,13 @@ def test_hand_written_loop_on_the_hip_kernels_matches_reference_trajectory(name,
             return self.fn(*a)
     L.ndq_mlp_jet_fwd, L.ndq_mlp_jet_bwd = Counting(fwd, "fwd"), Counting(bwd, "bwd")
     try:
-        gold, losses, params, nets = hand_written_epochs(name, size, "cuda")
+        with autograd_ops.native_autograd(True, coordinate_grads=coordinate_grads):
+            gold, losses, params, nets = hand_written_epochs(name, size, "cuda")
     finally:
         L.ndq_mlp_jet_fwd, L.ndq_mlp_jet_bwd = fwd, bwd
-    assert calls["fwd"] == 3 * len(nets) and calls["bwd"] == 3 * len(nets), calls
+    second_order = name in ("c2", "c3")
+    assert calls["fwd"] == 3 * len(nets) * (2 if (coordinate_grads and second_order) else 1), calls
+    assert calls["bwd"] == 3 * len(nets), calls
     assert np.max(np.abs(losses - gold["traj_loss"]) / np.abs(gold["traj_loss"])) < 2e-5, (losses, gold["traj_loss"])
     assert rel_l2(params, gold["traj_params"]) < 1e-5
 
@@ -305,3 +312,63 @@ def test_multi_output_network_closure_on_the_hip_kernels_matches_golden():
     assert abs(loss.item() - float(gold["loss_f64"])) / abs(float(gold["loss_f64"])) < 1e-5
     assert rel_l2(grad, gold["grad_f64"]) < 1e-5
     assert rel_l2(res.detach().cpu().numpy(), gold["residuals_f64"]) < 1e-5
+
+
+def _residual(net, x, scale):
+    """u = net(scale * x); r = u'' + u (second-order: the adjoint reaches the TOP-order stream of the forward launch)"""
+    u = net(scale * x)
+    return diff(u, x, order=2) + u
+
+
+@pytest.mark.parametrize("act", [torch.nn.Tanh, torch.nn.Softplus])
+def test_gradients_flowing_through_the_network_input_are_never_dropped(cpu_ops, act):
+    """a trainable tensor UPSTREAM of the network input (learnable input scale), and the coordinate
+    gradient itself, must come out of loss.backward() exactly as torch autograd produces them -- the top-order stream's
+    input gradient needs the streams one order up (tanh: a forward launch with third-order streams; Softplus has no
+    HIP kernels at all and runs on torch either way)."""
+    torch.manual_seed(2)
+    net = FCNN(1, 1, hidden_units=(32, 32), actv=act)
+    x0 = torch.rand(13, 1)
+
+    def run(native, how):
+        x = x0.clone().requires_grad_(True)
+        scale = torch.nn.Parameter(torch.tensor(1.3))
+        for p in net.parameters():
+            p.grad = None
+        with autograd_ops.native_autograd(native):
+            loss = (_residual(net, x, scale) ** 2).mean()
+            if how == "backward":
+                loss.backward()
+                return [x.grad, scale.grad] + [p.grad for p in net.parameters()]
+            if how == "params_only":
+                return list(torch.autograd.grad(loss, list(net.parameters())))
+            loss.backward(create_graph=True)            # parameter gradients that are differentiable themselves
+            assert all(p.grad is not None for p in net.parameters())
+            return [x.grad, scale.grad] + [p.grad for p in net.parameters()]
+
+    for how in ("backward", "params_only", "create_graph"):
+        got, want = run(True, how), run(False, how)
+        assert all(g is not None for g in got), how
+        for g, w in zip(got, want):
+            assert rel_l2(g.detach().numpy(), w.detach().numpy()) < 5e-6, how
+
+
+def test_coordinate_gradients_can_be_skipped_but_upstream_parameters_cannot(cpu_ops):
+    """set_native_autograd(coordinate_grads=False): plain coordinate leaves keep .grad = None (no extra launch); with a
+    trainable tensor upstream of the network input the gradient is produced regardless."""
+    torch.manual_seed(4)
+    net = FCNN(1, 1, hidden_units=(32, 32))
+    x0 = torch.rand(9, 1)
+    with autograd_ops.native_autograd(True, coordinate_grads=False):
+        x = x0.clone().requires_grad_(True)
+        ((diff(net(x), x, order=2)) ** 2).mean().backward()
+        assert x.grad is None and all(p.grad is not None for p in net.parameters())
+        x = x0.clone().requires_grad_(True)
+        scale = torch.nn.Parameter(torch.tensor(0.7))
+        (_residual(net, x, scale) ** 2).mean().backward()
+        got = scale.grad.item()
+    with autograd_ops.native_autograd(False):
+        x = x0.clone().requires_grad_(True)
+        scale = torch.nn.Parameter(torch.tensor(0.7))
+        (_residual(net, x, scale) ** 2).mean().backward()
+    assert abs(got - scale.grad.item()) <= 5e-6 * abs(scale.grad.item())

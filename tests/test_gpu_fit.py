@@ -158,3 +158,55 @@ def test_resident_training_batches_and_no_validation():
     a, b = run(True), run(False)
     _same(a, b)
     assert a["valid"] == [] and a["lowest"] == min(a["train"]) and a["steps"] == [17] * len(a["steps"])
+
+
+def test_metric_outside_the_traced_family_is_evaluated_on_the_host_and_training_stays_fused():
+    """a metric that is not a batch mean (``.max()``, sqrt of a mean) used to push the whole solver onto the
+    composite path.  Metrics only observe: training stays on the fused kernels, the metric is evaluated on the host from
+    the function values of every batch -- same numbers as the composite path reports."""
+    import warnings
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.solvers import Solver1D
+    metrics = {"max_abs": lambda u, t: u.abs().max(), "rms": lambda u, t: torch.sqrt((u ** 2).mean())}
+
+    def run(fused):
+        torch.manual_seed(0)
+        solver = Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], t_min=0.0, t_max=2.0, metrics=dict(metrics))
+        solver.fused = fused
+        torch.manual_seed(8)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            solver.fit(5, tqdm_file=None)
+        return solver
+
+    a, b = run("require"), run("off")
+    assert a.fused_active and a._host_metrics and not b.fused_active
+    for key in ("train_loss", "valid_loss", "train__max_abs", "valid__max_abs", "train__rms", "valid__rms"):
+        assert len(a.metrics_history[key]) == 5
+        assert np.allclose(a.metrics_history[key], b.metrics_history[key], rtol=5e-5), key
+
+
+def test_loss_that_changes_with_the_epoch_is_noticed_at_the_very_next_epoch():
+    """a traced custom loss is a constant of the generated kernel; it is probed EVERY epoch now (was: every
+    128), so a penalty switched on at epoch N never trains on the stale kernel."""
+    import warnings
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.solvers import Solver1D
+
+    class Stepped(Solver1D):
+        def additional_loss(self, residual, funcs, coords):
+            weight = 0.0 if self.global_epoch < 4 else 2.0          # switched on at epoch 4
+            return weight * (funcs[0] ** 2).mean()
+
+    torch.manual_seed(0)
+    solver = Stepped(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], t_min=0.0, t_max=2.0, n_batches_valid=0)
+    seen = []
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for epoch in range(7):
+            solver.run_train_epoch()
+            seen.append(solver.fused_active)
+    assert seen == [True] * 4 + [False] * 3, seen                  # epochs 0..3 fused, from epoch 4 on the composite path
+    assert any("changed between epochs" in str(x.message) for x in w)
