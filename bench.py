@@ -116,6 +116,93 @@ def kernel_breakdown(system, batch):
     )
 
 
+def traffic_child():
+    """``bench.py --traffic-child``: the headline step a few hundred times, nothing else -- what the rocprofv3 --pmc
+    passes of ``measure_traffic`` run over."""
+    from neurodiffeq_amd.generators import Generator2D, ResidentBatchGenerator, SamplerGenerator
+    from tests import configs
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    solver, cfg = configs.make_solver("c2", GRID)
+    solver.fused = "require"
+    torch.manual_seed(1)
+    gen = Generator2D((GRID, GRID), (0, 0), (1, 1), "equally-spaced-noisy")
+    solver.generator["train"] = SamplerGenerator(ResidentBatchGenerator.presample(gen, 4, "cuda"))
+    for _ in range(300):
+        solver.run_train_epoch()
+    torch.cuda.synchronize()
+
+
+def measure_traffic(timeout_s=150):
+    """HBM-side bytes per launch of the headline closure kernel, measured IN THIS RUN: two rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE cannot share a pass -- MI355X_MICROARCH.md, PMC slots) over ``--traffic-child``, mean per
+    dispatch of the closure kernel.  Units / correction as the guide prescribes and as calibrated on this package's
+    access patterns (profiles/r02v_pmc_c2_summary.txt: counters in KiB, a streaming read reports exactly half its
+    bytes in FETCH_SIZE, a streaming write reports WRITE_SIZE exactly).  None if rocprofv3 is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ndq_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc",
+                                "--", sys.executable, os.path.abspath(__file__), "--traffic-child"],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "fused_closure" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        rows.append(float(row["Counter_Value"]))
+            if len(rows) < 40:
+                return None
+            rows = rows[len(rows) // 4:]                 # skip warm-up dispatches
+            vals[counter] = sum(rows) / len(rows)
+        except (subprocess.TimeoutExpired, OSError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return dict(FETCH_SIZE_KiB=vals["FETCH_SIZE"], WRITE_SIZE_KiB=vals["WRITE_SIZE"],
+                hbm_bytes=vals["FETCH_SIZE"] * 1024 * 2.0 + vals["WRITE_SIZE"] * 1024,
+                algorithmic_bytes=N_POINTS * 8 + 256 * 1185 * 4 + 256 * 4)
+
+
+def cold_start():
+    """Time to the first training step of a PDE this installation has never seen: trace + code generation
+    + hipcc (pointwise kernel and single-launch closure kernel, built concurrently) + first-use self-check, then the
+    second solver of the same system (everything cached).  The PDE carries a fresh constant so that no cache can know it."""
+    import random
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import NoCondition
+    from neurodiffeq_amd.generators import Generator2D
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.solvers import Solver2D
+    c = 1.0 + random.SystemRandom().random()
+    pde = lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2) - c * u * u]
+    out = {}
+    for tag in ("cold_start_s", "warm_start_s"):
+        torch.manual_seed(0)
+        t0 = time.perf_counter()
+        s = Solver2D(pde, [NoCondition()], nets=[FCNN(2, 1, hidden_units=(32, 32))],
+                     train_generator=Generator2D((32, 32), (0, 0), (1, 1)), valid_generator=Generator2D((32, 32), (0, 0), (1, 1)),
+                     n_batches_valid=0)
+        s.fused = "require"
+        s.run_train_epoch()
+        _ = s.metrics_history["train_loss"][-1]
+        torch.cuda.synchronize()
+        out[tag] = time.perf_counter() - t0
+    out["what"] = ("Solver2D of a never-seen nonlinear Poisson problem: constructor + first run_train_epoch() incl. trace, code "
+                   "generation, hipcc of the pointwise and closure kernels (concurrent), assembly fix-up, first-use self-check")
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -230,11 +317,21 @@ def config_record(name):
         torch.cuda.synchronize()
     k = 5 if name == "c5" else 50
     times = timed_windows(solver.run_train_epoch, k, torch.cuda.synchronize)
-    dt = times[(len(times) - 1) // 2] / k
+    dt_epoch = times[(len(times) - 1) // 2] / k
+    # the same training epochs the way a user runs them: fit(k) -- whole chunks of epochs per native call (solvers.fit,
+    # ndq_fused_fit_run), no Python between the epochs.  For the launch-bound configs this is the step time that counts.
+    kf = 10 if name == "c5" else 500
+    solver.fit(kf, tqdm_file=None)
+    times_fit = timed_windows(lambda: solver.fit(kf, tqdm_file=None), 1, torch.cuda.synchronize)
+    dt_fit = times_fit[(len(times_fit) - 1) // 2] / kf
+    dt = min(dt_epoch, dt_fit)
     n = cfg["n_points"]
     tf = ALGO_FLOP_PER_PT[name] * n / dt / 1e12
     sysm = solver._fused_sys
     return dict(points=n, ms_per_step=dt * 1e3, points_per_s=n / dt, algorithmic_flop_per_point=ALGO_FLOP_PER_PT[name],
+                ms_per_step_run_train_epoch=dt_epoch * 1e3, ms_per_step_in_fit=dt_fit * 1e3,
+                step_definition="one training epoch (n_batches_train = 1, no validation); ms_per_step = the faster of "
+                                "run_train_epoch() in a Python loop and fit(k) (multi-epoch native call), both listed",
                 algorithmic_tflops=tf, frac_of_fp32_mfma_peak=tf / FP32_MFMA_PEAK_TFLOPS, windows=len(times), steps_per_window=k,
                 single_launch=sysm.fusedk is not None, launches_per_step=sysm.launches_per_step(),
                 final_loss=solver.metrics_history["train_loss"][-1])
@@ -363,6 +460,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config sub-records (C1, C3, C4, C5)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes for roofline.traffic")
+    ap.add_argument("--cold-start", action="store_true", help="also time the first step of a never-seen PDE (runs hipcc)")
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE config to run (the driver's headline is c2; c3 / c5 are the sizes where strong scaling "
                          "has work to share: SURVEY.md 8e)")
@@ -370,6 +470,8 @@ def main():
                     help="weak: every rank trains the config's full batch (global batch = N x that); strong: the "
                          "config's batch is split over the ranks")
     args = ap.parse_args()
+    if args.traffic_child:
+        return traffic_child()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -461,6 +563,15 @@ def main():
         }
         if use_dist and hasattr(solver.dist._direct, "status"):
             out["allreduce_flag_timeouts"] = solver.dist._direct.status()      # one-shot exchange: must be 0
+    if world == 1 and not use_dist:
+        # the same training epochs inside fit(): whole chunks of epochs per native call (ndq_fused_fit_run), no Python in
+        # between -- at this size the step is GPU-bound either way; listed so that the two routes can be compared
+        kf = max(args.steps, 200)
+        solver.fit(kf, tqdm_file=None)
+        tf_ = timed_windows(lambda: solver.fit(kf, tqdm_file=None), 1, barrier)
+        dtf = tf_[(len(tf_) - 1) // 2] / kf
+        out["in_fit"] = {"value": N_POINTS / dtf, "ms_per_step": dtf * 1e3, "epochs_per_call": kf,
+                         "note": "fit(k) with n_batches_valid = 0: the headline's training epochs issued k per native call"}
     if rank == 0 and world == 1 and not use_dist:
         system = solver._fused_sys
         batch = solver._generate_batch("train")
@@ -497,13 +608,21 @@ def main():
                                      "frac": kb["pointwise"]["gbs"] / HBM_PEAK_GBS, "traffic": None,
                                      "algorithmic_bytes_per_point": kb["pointwise"]["bytes_per_point"]}
         tpath = os.path.join(ROOT, "profiles", "traffic_c2.json")
-        if os.path.exists(tpath):      # HBM bytes per launch from the last committed rocprofv3 --pmc pass
+        live = None if (args.no_traffic or system.fusedk is None) else measure_traffic()
+        if live is not None:           # HBM bytes per launch measured in THIS run (two rocprofv3 --pmc passes)
+            out["roofline"]["traffic"] = live["hbm_bytes"]
+            out["roofline"]["traffic_note"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+                                               "300 steps, mean per dispatch; FETCH_SIZE x 2 per the guide and this package's "
+                                               "calibration (profiles/r02v_pmc_c2_summary.txt)")
+            out["roofline"]["traffic_detail"] = live
+        if os.path.exists(tpath):      # the last committed rocprofv3 --pmc measurement (may be stale: see its source field)
             tr = json.load(open(tpath))
             key = "fused_closure" if system.fusedk is not None else None
-            if key and key in tr["kernels"]:
+            if live is None and key and key in tr["kernels"]:
                 out["roofline"]["traffic"] = tr["kernels"][key]["hbm_bytes"]
-                out["roofline"]["traffic_note"] = tr["source"]
+                out["roofline"]["traffic_note"] = "NOT measured in this run (stale-able): " + tr["source"]
             out["roofline_pointwise"]["traffic"] = tr["kernels"]["pointwise"]["hbm_bytes"]
+            out["roofline_pointwise"]["traffic_note"] = "NOT measured in this run (stale-able): " + tr["source"]
         # the same step with host sampling (CPU RNG, bit-exact with the reference) + PCIe upload inside it
         torch.manual_seed(2)
         solver.generator["train"] = SamplerGenerator(cfg["gen"])
@@ -539,6 +658,8 @@ def main():
             out["configs"] = {name: config_record(name) for name in ("c1", "c3", "c4", "c5")}
             out["roofline_pointwise_large"] = pointwise_large()
             out["c2_fp64"] = fp64_record()
+        if args.cold_start:
+            out["cold_start"] = cold_start()
         if not args.no_cpu_baseline:
             cb = out["cpu_baseline"] = cpu_baseline()
             # like for like: resident inputs on both sides / generator draw inside the step on both sides (the host draw +

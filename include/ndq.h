@@ -242,6 +242,14 @@ typedef int (*ndq_pointwise_fn)(const float* coords, int ldc, int n, const float
                                 float* const* gbar, int ldj, float* funcs, float* resid, float* loss_partials,
                                 float seed_scale, void* stream);
 typedef int (*ndq_pw_blocks_fn)(int n);
+/* Inverse problems: the reference re-evaluates the user's diff_eqs under autograd every batch (solvers.py:380), so
+ * nn.Parameter coefficients inside the equations receive gradients and (N, 1) data tensors are just operands.  In a
+ * generated module the n_theta trainable scalars are a device vector every launch reads, their gradient the fixed-order
+ * sum of per-point adjoints (block rows theta_partials [blocks][n_theta], second stage: ndq_reduce_partials), and
+ * the n_data per-point columns are rows [d, d + n_data) of the coordinate block.  Every generated module (pointwise:
+ * ndq_pw_bind_theta, closure: ndq_fused_bind_theta) exports the binder below; it is called before a launch whenever
+ * n_theta > 0 (theta_partials may be NULL for forward-only launches). */
+typedef void (*ndq_bind_theta_fn)(const float* theta, float* theta_partials);
 
 /* ---- fp64 variants (libndq64.so) ------------------------------------------------------------------------------------
  * The reference's default precision is fp64 (neurodiffeq/__init__.py:22, utils.py:10-41).  libndq64.so carries the SAME

@@ -126,6 +126,32 @@ def scalarize_pk(asm_text, which="opsel"):
     return "\n".join(out), done, skipped
 
 
+_PK_ANY_F32 = re.compile(r"^\s*v_pk_\w+_f32\s")
+STATS = {}            # output path -> dict(split=, left_alone=, nops=) of the last build through this process
+
+
+def verify_fixup(asm_text):
+    """Post-condition of the fix-up pass, checked on the assembly that is about to be assembled -- the pass FAILS CLOSED:
+    (1) no packed-fp32 instruction whose low half selects a high source half (``op_sel`` with a 1) may be left: either the
+    rewrite understood it, or the build stops (an encoding the ROCm 7.2 code generator did not emit when the rules were
+    written -- e.g. after a compiler update -- must be looked at, not waved through);
+    (2) no packed VALU instruction may be directly followed by an MFMA.  Raises RuntimeError."""
+    prev_pk = None
+    for ln, line in enumerate(asm_text.split("\n"), 1):
+        if not _is_instruction(line):
+            continue
+        s = line.strip()
+        if _PK_ANY_F32.match(line):
+            m = re.search(r"\bop_sel:\[([01,]+)\]", s)
+            if m and "1" in m.group(1):
+                raise RuntimeError(f"assembly fix-up: packed fp32 instruction with op_sel left in the output (line {ln}): {s}\n"
+                                   "-- an encoding _hipcc.scalarize_pk does not know; NDQ_NO_PK_MFMA_FIX=1 builds without the "
+                                   "pass (and without its protection)")
+        if prev_pk is not None and _MFMA.match(line):
+            raise RuntimeError(f"assembly fix-up: packed VALU instruction directly followed by an MFMA (line {ln}): {prev_pk} / {s}")
+        prev_pk = s if _PK.match(line) else None
+
+
 def fixup_enabled():
     return os.environ.get("NDQ_NO_PK_MFMA_FIX", "0") != "1"
 
@@ -191,6 +217,7 @@ def compile_shared(sources, out, extra_flags=(), verbose=False, defer=False):
             os.replace(tmp, out)
             return 0
         sites, objs = 0, []
+        STATS.pop(out, None)
         for i, src in enumerate(sources):
             asm = os.path.join(work, f"dev{i}.s")
             _run([HIPCC, f"--offload-arch={ARCH}", "--cuda-device-only", "-S"] + flags + [src, "-o", asm],
@@ -205,6 +232,13 @@ def compile_shared(sources, out, extra_flags=(), verbose=False, defer=False):
                     print(f"scalarized {n_split} packed op(s) ({split}), left {n_skip} alone", flush=True)
             text, n = fix_pk_mfma(text, rule)
             sites += n
+            if split == "opsel" and rule == "mfma":       # (experiment variants of the rules are not held to the post-condition)
+                verify_fixup(text)
+            st = STATS.setdefault(out, dict(split=0, left_alone=0, nops=0))
+            st["nops"] += n
+            if split != "none":
+                st["split"] += n_split
+                st["left_alone"] += n_skip
             with open(asm, "w") as fh:
                 fh.write(text)
             obj, co, fb = (os.path.join(work, f"dev{i}.{e}") for e in ("o", "out", "hipfb"))

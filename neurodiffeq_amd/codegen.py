@@ -140,12 +140,14 @@ int launch_tv(const float* coords, int ldc, int n, const float* const* params, f
   {{
     {args_t}& a = t;
     a.coords = coords; a.loss_partials = loss_partials; a.n = n; a.ldc = ldc; a.ldj = ldc; a.seed = seed;
+    a.theta = g_theta; a.theta_partials = g_theta_partials;
     {fill}
   }}
   {{
     {args_t}& a = v;
     float* const* partials = nullptr;
     a.coords = vcoords; a.loss_partials = vloss_partials; a.n = vn; a.ldc = vldc; a.ldj = vldc; a.seed = 0.f;
+    a.theta = g_theta;
     {fill}
   }}
   const int tb = n > 0 ? fused_blocks(n) : 0, vb = vn > 0 ? fused_blocks(vn) : 0;
@@ -211,6 +213,8 @@ class PointwiseProgram:
         self.site_net = list(getattr(graph, "site_net", None) or range(n_nets))
         self.n_sites = len(self.site_net)       # (network, coordinate tuple) pairs: stream arrays are per site
         self.n_coords = graph.n_coords
+        self.n_data = len(getattr(graph, "data", ()))       # per-point data columns: input rows behind the coordinates
+        self.n_theta = len(getattr(graph, "params", ()))    # trainable scalars of the equations: kernel arguments
         self.order = graph.reachable(self.residuals + self.funcs + ([self.loss_term] if self.loss_term is not None else []))
         self.streams = {}
         for k in range(self.n_sites):
@@ -288,6 +292,10 @@ class PointwiseProgram:
             return _lit(n[1])
         if n[0] == "coord":
             return f"c{n[1]}"
+        if n[0] == "data":
+            return f"d{n[1]}"
+        if n[0] == "param":
+            return f"t{n[1]}"
         return f"v{i}"
 
     def sym_location(self, i):
@@ -302,14 +310,14 @@ class PointwiseProgram:
         dep = {}
         for i in self.order:
             n = g.nodes[i]
-            dep[i] = n[0] == "net" or any(dep[c] for c in g.children(i))
+            dep[i] = n[0] in ("net", "param") or any(dep[c] for c in g.children(i))
         res_order = g.reachable(self.residuals)
         res_set = set(res_order)
         L.append("// ---- forward")
         for i in self.order:
             n = g.nodes[i]
             op = n[0]
-            if op in ("const", "coord"):
+            if op in ("const", "coord", "data", "param"):
                 continue
             if op == "net":
                 L.append(f"  const float v{i} = s[{self.symbols.index(i)}];")
@@ -360,7 +368,7 @@ class PointwiseProgram:
             op = n[0]
             L.append(f"  const float b{i} = {' + '.join(terms[i])};")
             b = f"b{i}"
-            if op == "net":
+            if op in ("net", "param"):
                 continue
 
             def push(child, expr):
@@ -386,6 +394,11 @@ class PointwiseProgram:
                     push(n[1], t.format(b=b, a=self._val(n[1]), v=f"v{i}"))
         for idx, i in enumerate(self.symbols):
             L.append(f"  g[{idx}] = {'b%d' % i if (i in terms and i in res_set) else '0.0f'};")
+        # per-point adjoints of the trainable scalars: behind the stream adjoints in g (summed over the points by the kernels)
+        nsym = len(self.symbols)
+        for j in range(self.n_theta):
+            i = g._ids.get(("param", j))
+            L.append(f"  g[{nsym + j}] = {'b%d' % i if (i is not None and i in terms and i in res_set) else '0.0f'};")
         return "\n".join(L)
 
     def point_fn_source(self):
@@ -402,8 +415,13 @@ class PointwiseProgram:
             term = "0.0f"
             for e in range(neq):
                 term = f"fmaxf({term}, fabsf(r[{e}]))"
-        return f"""NDQ_PW_INLINE void ndq_pw_point(const float* c, const float* s, float seed, int want_adj, float* r, float* f, float* g) {{
+        nd, nt = self.n_data, self.n_theta
+        return f"""// c: {nc} coordinate(s) | {nd} per-point data value(s) | {nt} trainable scalar(s) of the equations;  g: adjoints of the
+// {len(self.symbols)} stream symbol(s) | of the {nt} trainable scalar(s)
+NDQ_PW_INLINE void ndq_pw_point(const float* c, const float* s, float seed, int want_adj, float* r, float* f, float* g) {{
 {chr(10).join(f"  const float c{i} = c[{i}];" for i in range(nc))}
+{chr(10).join(f"  const float d{j} = c[{nc + j}];" for j in range(nd))}
+{chr(10).join(f"  const float t{j} = c[{nc + nd + j}];" for j in range(nt))}
 {chr(10).join(f"  const float c{i} = {_lit(v)};   // virtual coordinate (boundary value)" for i, v in sorted(self.g.vcoords.items()))}
 {body}
 }}
@@ -471,15 +489,23 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
 namespace {{
 using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
 struct PW {{
-  static constexpr int NEQ = {neq}, NF = {nf}, NR = {self.n_r};
+  // ND per-point data columns (rows D .. D + ND of the coordinate block), NT trainable scalars of the equations
+  static constexpr int NEQ = {neq}, NF = {nf}, NR = {self.n_r}, ND = {self.n_data}, NT = {self.n_theta};
   static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
-  static __device__ __forceinline__ void apply(const float (&x)[CFG::D], {jets_t}, float seed,
+  // xe: the point's ND data values, then the NT scalars;  gth (want_adj): per-point adjoints of the scalars
+  static __device__ __forceinline__ void apply(const float (&x)[CFG::D], const float* xe, {jets_t}, float seed,
                                                int want_adj, float (&r)[{self.n_r}], float (&f)[{max(nf, 1)}],
-                                               {gj_t}) {{
-    float s[{nsym}], g[{nsym}];
+                                               {gj_t}, float* gth) {{
+    float c[CFG::D + ND + NT], s[{nsym}], g[{nsym} + NT];
+#pragma unroll
+    for (int d = 0; d < CFG::D; ++d) c[d] = x[d];
+#pragma unroll
+    for (int j = 0; j < ND + NT; ++j) c[CFG::D + j] = xe[j];
 {chr(10).join(loads)}
-    ndq_pw_point(x, s, seed, want_adj, r, f, g);
+    ndq_pw_point(c, s, seed, want_adj, r, f, g);
 {chr(10).join(stores)}
+#pragma unroll
+    for (int j = 0; j < NT; ++j) gth[j] = g[{len(self.symbols)} + j];
   }}
 }};
 constexpr int kWaves = {tiles_per_block};        // tiles a workgroup handles per round
@@ -489,14 +515,21 @@ int fused_blocks(int n) {{
   return b > 256 ? 256 : (b < 1 ? 1 : b);
 }}
 
+// trainable scalars of the equations (PW::NT of them): values read by every launch, block sums of their adjoints written by
+// training launches -- bound by the engine before it launches (ndq_fused_bind_theta)
+const float* g_theta = nullptr;
+float* g_theta_partials = nullptr;
+
 // params / partials: host arrays of {K} device pointers (one per network)
 int launch(const float* coords, int ldc, int n, const float* const* params, float* const* partials, float* loss_partials,
            float* funcs, float* resid, int ldj, float seed, int train, void* stream) {{
   if (!coords || !params || !loss_partials || n <= 0 || ldc < n || (train && !partials)) return -2;
-  {args_t} a;
+  if (PW::NT > 0 && !g_theta) return -2;
+  {args_t} a{{}};
   a.coords = coords; a.loss_partials = loss_partials;
   {fill}
   a.funcs = funcs; a.resid = resid; a.n = n; a.ldc = ldc; a.ldj = ldj; a.seed = seed;
+  a.theta = g_theta; a.theta_partials = train ? g_theta_partials : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   static bool attr = false;
   if (!attr) {{
@@ -519,6 +552,8 @@ int launch(const float* coords, int ldc, int n, const float* const* params, floa
 
 extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
 extern "C" int ndq_fused_num_params() {{ return CFG::P; }}
+extern "C" int ndq_fused_num_theta() {{ return PW::NT; }}
+extern "C" void ndq_fused_bind_theta(const float* theta, float* theta_partials) {{ g_theta = theta; g_theta_partials = theta_partials; }}
 extern "C" int ndq_fused_num_nets() {{ return {K}; }}
 extern "C" int ndq_fused_threads() {{ return {threads}; }}
 extern "C" unsigned long ndq_fused_lds_bytes() {{ return (unsigned long){lds('true')}; }}
@@ -583,16 +618,23 @@ namespace {{
 using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
 static_assert(CFG::NS * CFG::NOUT == {width}, "stream layout of the traced program and of the kernel disagree");
 struct PW {{
-  static constexpr int NEQ = {neq}, NF = {nf}, NC = {self.n_coords}, NR = {self.n_r};
+  // NC rows of the coordinate block per point: the batch coordinates, then ND data columns; NT trainable scalars
+  static constexpr int NEQ = {neq}, NF = {nf}, ND = {self.n_data}, NT = {self.n_theta}, NC = {self.n_coords} + ND, NR = {self.n_r};
   static constexpr int dep(int d) {{ return {dep_fn}; }}     // batch coordinate fed to network input d
   static __device__ __forceinline__ float loss(const float* r) {{ return ndq_pw_loss(r); }}
-  static __device__ __forceinline__ void apply(const float (&c)[NC], const float* srow, float seed, int want_adj,
-                                               float (&r)[{self.n_r}], float (&f)[{max(nf, 1)}], float* grow) {{
-    float s[{nsym}], g[{nsym}];
+  static __device__ __forceinline__ void apply(const float (&cc)[NC], const float* th, const float* srow, float seed, int want_adj,
+                                               float (&r)[{self.n_r}], float (&f)[{max(nf, 1)}], float* grow, float* gth) {{
+    float c[NC + NT], s[{nsym}], g[{nsym} + NT];
+#pragma unroll
+    for (int d = 0; d < NC; ++d) c[d] = cc[d];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) c[NC + j] = th[j];
 {chr(10).join(loads)}
     ndq_pw_point(c, s, seed, want_adj, r, f, g);
     if (!want_adj) return;
 {chr(10).join(stores)}
+#pragma unroll
+    for (int j = 0; j < NT; ++j) gth[j] = g[{len(self.symbols)} + j];
   }}
 }};
 constexpr int kWaves = CFG::BWD_THREADS / 64;
@@ -603,13 +645,18 @@ int fused_blocks(int n) {{
   return b > 256 ? 256 : (b < 1 ? 1 : b);
 }}
 
+const float* g_theta = nullptr;          // see the tile-closure module: trainable scalars of the equations
+float* g_theta_partials = nullptr;
+
 int launch(const float* coords, int ldc, int n, const float* const* params, float* const* partials, float* loss_partials,
            float* funcs, float* resid, int ldj, float seed, int train, void* stream) {{
   if (!coords || !params || !loss_partials || n <= 0 || ldc < n || (train && !partials)) return -2;
-  ndq::FusedArgs a;
+  if (PW::NT > 0 && !g_theta) return -2;
+  ndq::FusedArgs a{{}};
   a.coords = coords; a.loss_partials = loss_partials;
   a.params = params[0]; a.partials = partials ? partials[0] : nullptr;
   a.funcs = funcs; a.resid = resid; a.n = n; a.ldc = ldc; a.ldj = ldj; a.seed = seed;
+  a.theta = g_theta; a.theta_partials = train ? g_theta_partials : nullptr;
   hipStream_t s = static_cast<hipStream_t>(stream);
   static bool attr = false;
   if (!attr) {{
@@ -632,6 +679,8 @@ int launch(const float* coords, int ldc, int n, const float* const* params, floa
 
 extern "C" int ndq_fused_blocks(int n) {{ return fused_blocks(n); }}
 extern "C" int ndq_fused_num_params() {{ return CFG::P; }}
+extern "C" int ndq_fused_num_theta() {{ return PW::NT; }}
+extern "C" void ndq_fused_bind_theta(const float* theta, float* theta_partials) {{ g_theta = theta; g_theta_partials = theta_partials; }}
 extern "C" int ndq_fused_num_nets() {{ return 1; }}
 extern "C" int ndq_fused_threads() {{ return CFG::BWD_THREADS; }}
 extern "C" unsigned long ndq_fused_lds_bytes() {{ return (unsigned long){lds('true')}; }}
@@ -680,6 +729,8 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 #endif
 
 #define NDQ_PW_NC {nc}
+#define NDQ_PW_ND {self.n_data}
+#define NDQ_PW_NT {self.n_theta}
 #define NDQ_PW_NSYM {len(self.symbols)}
 #define NDQ_PW_NEQ {neq}
 #define NDQ_PW_NR {self.n_r}
@@ -697,17 +748,26 @@ struct PwArgs {{
   float* loss_partials;
   int n, ldc, ldj, want_adj;
   float seed;
+  const float* theta;          // [NDQ_PW_NT] trainable scalars of the equations
+  float* theta_partials;       // [gridDim.x][NDQ_PW_NT] block sums of their per-point adjoints
 }};
 
 extern "C" __global__ __launch_bounds__(256) void ndq_pw_kernel(PwArgs a) {{
   const int n = blockIdx.x * 256 + threadIdx.x;
   float sq = 0.f;
+  float gt[NDQ_PW_NT > 0 ? NDQ_PW_NT : 1] = {{0.f}};
   if (n < a.n) {{
-    float c[NDQ_PW_NC], s[{nsym}], r[{self.n_r}], f[{max(nf, 1)}], g[{nsym}];
+    float c[NDQ_PW_NC + NDQ_PW_ND + NDQ_PW_NT], s[{nsym}], r[{self.n_r}], f[{max(nf, 1)}], g[{nsym} + NDQ_PW_NT];
 #pragma unroll
-    for (int i = 0; i < NDQ_PW_NC; ++i) c[i] = a.coords[(size_t)i * a.ldc + n];
+    for (int i = 0; i < NDQ_PW_NC + NDQ_PW_ND; ++i) c[i] = a.coords[(size_t)i * a.ldc + n];   // data rows follow the coordinates
+#pragma unroll
+    for (int j = 0; j < NDQ_PW_NT; ++j) c[NDQ_PW_NC + NDQ_PW_ND + j] = a.theta[j];
 {chr(10).join(loads)}
     ndq_pw_point(c, s, a.seed, a.want_adj, r, f, g);
+    if (a.want_adj) {{
+#pragma unroll
+      for (int j = 0; j < NDQ_PW_NT; ++j) gt[j] = g[NDQ_PW_NSYM + j];
+    }}
     sq += ndq_pw_loss(r);
     if (a.resid) {{
 #pragma unroll
@@ -727,14 +787,37 @@ extern "C" __global__ __launch_bounds__(256) void ndq_pw_kernel(PwArgs a) {{
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
   __syncthreads();
   if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+#if NDQ_PW_NT > 0
+  // the same fixed-order block sums for the adjoints of the trainable scalars
+  __shared__ float tsum[4][NDQ_PW_NT];
+#pragma unroll
+  for (int j = 0; j < NDQ_PW_NT; ++j) {{
+    float v = gt[j];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) tsum[threadIdx.x >> 6][j] = v;
+  }}
+  __syncthreads();
+  if (threadIdx.x < NDQ_PW_NT && a.want_adj && a.theta_partials)
+    a.theta_partials[(size_t)blockIdx.x * NDQ_PW_NT + threadIdx.x] =
+        (tsum[0][threadIdx.x] + tsum[1][threadIdx.x]) + (tsum[2][threadIdx.x] + tsum[3][threadIdx.x]);
+#endif
 }}
 
 extern "C" int ndq_pw_blocks(int n) {{ return (n + 255) / 256; }}
+extern "C" int ndq_pw_num_theta() {{ return NDQ_PW_NT; }}
+extern "C" int ndq_pw_num_data() {{ return NDQ_PW_ND; }}
+
+// trainable scalars of the equations: values read by every launch, block sums of their adjoints written by training launches
+static const float* g_theta = nullptr;
+static float* g_theta_partials = nullptr;
+extern "C" void ndq_pw_bind_theta(const float* theta, float* theta_partials) {{ g_theta = theta; g_theta_partials = theta_partials; }}
 
 extern "C" int ndq_pw_launch(const float* coords, int ldc, int n, const float* const* jets, float* const* gbar, int ldj,
                              float* funcs, float* resid, float* loss_partials, float seed_scale, void* stream) {{
   if (!coords || !jets || !loss_partials || n <= 0) return -2;
+  if (NDQ_PW_NT > 0 && !g_theta) return -2;
   PwArgs a;
+  a.theta = g_theta; a.theta_partials = g_theta_partials;
   a.coords = coords;
   for (int k = 0; k < NDQ_PW_NNETS; ++k) {{
     a.jets[k] = jets[k];
@@ -826,6 +909,8 @@ class FusedKernel:
         self.lib.ndq_fused_launch_multi.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
         self.lib.ndq_fused_launch_tv.restype = ci
         self.lib.ndq_fused_launch_tv.argtypes = [vp, ci, ci, vp, vp, vp, cf, vp, ci, ci, vp, vp]
+        self.lib.ndq_fused_bind_theta.restype = None
+        self.lib.ndq_fused_bind_theta.argtypes = [vp, vp]
         self.lib.ndq_fused_blocks.restype = ci
         self.lib.ndq_fused_blocks.argtypes = [ci]
         self.lib.ndq_fused_num_params.restype = ci

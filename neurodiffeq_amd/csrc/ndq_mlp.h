@@ -560,11 +560,13 @@ __device__ __forceinline__ real actp_mul(real v, real f) {
   else return v;
 }
 
+// tid / nt: this thread's index among the nt threads that stage the image together (default: the whole workgroup; the
+// multi-network closure lets every network's own waves stage that network's image, all images at once)
 template <class C, bool BWD>
-__device__ __forceinline__ void stage_weights(real* lds, const real* __restrict__ prm) {
+__device__ __forceinline__ void stage_weights(real* lds, const real* __restrict__ prm, int tid = -1, int nt = 0) {
   constexpr int H = C::H, D = C::D, NB = C::NB;
   constexpr int HL = C::hr(C::L);          // width of the last hidden layer (input of the output layer)
-  const int tid = threadIdx.x, nt = blockDim.x;
+  if (tid < 0) { tid = threadIdx.x; nt = blockDim.x; }
   const real f1 = act_pre<C>(prm, 1), fo = act_post<C>(prm, C::L);
   // padding units (RAGGED: j >= the layer's real width hw) read as zero
   auto unit = [&](int j, int hw, int idx, real f) {
@@ -2241,7 +2243,32 @@ struct FusedArgs {
   real* resid;            // optional [NEQ][ldj]
   int n, ldc, ldj;
   real seed;              // adjoint seed scale 1 / (N_global * n_eq)
+  const real* theta;      // PW::NT trainable scalars of the equations (inverse problems), else unused
+  real* theta_partials;   // TRAIN: [gridDim.x][PW::NT] block sums of their per-point adjoints
 };
+
+// sum over the workgroup of NT per-lane values (non-zero in the lanes that carried a point), fixed order: lanes -> wave
+// -> the waves in order; threads 0 .. NT-1 write the block's row.  `scratch`: (waves x NT) floats of LDS nobody else
+// uses any more.
+template <int NT>
+__device__ __forceinline__ void theta_block_sum(real (&t)[NT > 0 ? NT : 1], real* scratch, int waves, real* out) {
+  if constexpr (NT > 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) t[j] = point_sum(quad_sum(t[j]));
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) scratch[wave * NT + j] = t[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NT && out) {
+      real v = 0.f;
+      for (int w = 0; w < waves; ++w) v += scratch[w * NT + threadIdx.x];
+      out[threadIdx.x] = v;
+    }
+  }
+}
 
 // The body works on workgroup `blk` of `nblk` (the plain kernels pass blockIdx.x / gridDim.x; the train + validation
 // launch below gives each half of its grid its own numbering, so that either half computes -- bit for bit -- what a
@@ -2272,6 +2299,11 @@ __device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds
   GradAcc<C> acc;
   if constexpr (TRAIN) acc_init<C>(acc, lds, WAVES, wave, lane);
   real lsum = 0.f;
+  // per-point data columns (rows D .. D + ND of the coordinate block) and trainable scalars of the equations
+  constexpr int NXE = PW::ND + PW::NT;
+  real xe[NXE > 0 ? NXE : 1], tsum[PW::NT > 0 ? PW::NT : 1];
+#pragma unroll
+  for (int j = 0; j < PW::NT; ++j) { xe[PW::ND + j] = a.theta[j]; tsum[j] = 0.f; }
 #if NDQ_STAGGER > 0
   // two waves per SIMD run the same phases (VALU-heavy activation math, MFMA-heavy GEMMs) in lockstep and then compete for
   // the same pipe; delaying the second wave of every SIMD by a fraction of a tile lets one's MFMAs run under the
@@ -2297,13 +2329,22 @@ __device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds
     NDQ_TT(0);
     tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp);
     NDQ_TT(1);
-    real jets[C::NS], gout[C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
+    real jets[C::NS], gout[C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1], gth[PW::NT > 0 ? PW::NT : 1];
     tile_output<C, TRAIN>(ldsw, q, x, h, jets);
     NDQ_TT(2);
-    PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
+    if constexpr (PW::ND > 0) {
+      const int nn = valid ? n : a.n - 1;
+#pragma unroll
+      for (int j = 0; j < PW::ND; ++j) xe[j] = a.coords[(size_t)(C::D + j) * a.ldc + nn];
+    }
+    PW::apply(x, xe, jets, a.seed, TRAIN ? 1 : 0, r, f, gout, gth);
     NDQ_TT(3);
     if (valid && q == 0) {
       lsum += PW::loss(r);
+      if constexpr (TRAIN) {
+#pragma unroll
+        for (int j = 0; j < PW::NT; ++j) tsum[j] += gth[j];
+      }
       if (a.resid) {
 #pragma unroll
         for (int e = 0; e < PW::NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];
@@ -2339,6 +2380,7 @@ __device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds
     for (int w = 0; w < WAVES; ++w) v += wl[w];
     a.loss_partials[blk] = v;
   }
+  if constexpr (TRAIN) theta_block_sum<PW::NT>(tsum, wl + 16, WAVES, a.theta_partials ? a.theta_partials + (size_t)blk * PW::NT : nullptr);
   NDQ_TS(3);
 }
 
@@ -2375,6 +2417,8 @@ struct FusedMultiArgs {
   real* resid;                           // optional [NEQ][ldj]
   int n, ldc, ldj;
   real seed;
+  const real* theta;                     // see FusedArgs
+  real* theta_partials;
 };
 
 // Workgroup shape (round 3): the K networks of a tile run CONCURRENTLY on K waves -- wave (k, g) carries network k for
@@ -2405,29 +2449,49 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
   static_assert(C::BWD_THREADS == 256, "multi-network closure: one wave per SIMD (build without NDQ_BWD_THREADS)");
   constexpr int WS = C::ldsWeightsEnd(TRAIN);          // LDS floats per weight image
   constexpr int G = multi_group<K>(), WAVES = K * G;
-#pragma unroll
-  for (int kk = 0; kk < K; ++kk) stage_weights<C, TRAIN>(lds + kk * WS, a.params[kk]);
-  __syncthreads();
+  NDQ_TS(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   const int k = wave / G, g = wave - k * G;            // this wave's network and its tile slot in a round
-  const real* ldsw = lds + k * WS;
   const int ntiles = (a.n + 15) >> 4;
+  // the first tile's coordinates are fetched before the weights are staged (both global latencies overlap)
+  real xn[C::D];
+  {
+    const int n0 = (blk * G + g) * 16 + p;
+    const int nn0 = n0 < a.n ? n0 : a.n - 1;
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn0];
+  }
+  // every network's G waves stage that network's image: the K images are built at the same time (a staging pass is
+  // bound by the latency of its parameter loads -- 2.97 us for two images one after the other at C1, measured)
+  stage_weights<C, TRAIN>(lds + k * WS, a.params[k], g * 64 + lane, G * 64);
+  __syncthreads();
+  NDQ_TS(1);
+  const real* ldsw = lds + k * WS;
   real* work = lds + K * WS;                           // per network: G staging tiles (later: its reduction regions)
   real* stage = work + k * multi_group_floats<C, K>() + g * C::stageFloatsPerWave;
   real* xchg = work + (TRAIN ? K * multi_group_floats<C, K>() : 0);
   GradAcc<C> acc;
   if constexpr (TRAIN) { acc_zero<C>(acc); acc.bias = nullptr; }
   real lsum = 0.f;
+  constexpr int NXE = PW::ND + PW::NT;
+  real xe[NXE > 0 ? NXE : 1], tsum[PW::NT > 0 ? PW::NT : 1];
+#pragma unroll
+  for (int j = 0; j < PW::NT; ++j) { xe[PW::ND + j] = a.theta[j]; tsum[j] = 0.f; }
   int par = 0;
   // every wave of the workgroup runs the same number of rounds (one barrier each); a slot past the last tile works on
   // a copy of the last point with zero seeds
   for (int tile0 = blk * G; tile0 < ntiles; tile0 += nblk * G, par ^= 1) {
     const int n = (tile0 + g) * 16 + p;
     const bool valid = n < a.n;
-    const int nn = valid ? n : a.n - 1;
     real x[C::D];
 #pragma unroll
-    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    for (int d = 0; d < C::D; ++d) x[d] = xn[d];
+    {
+      const int n1 = n + nblk * G * 16;                  // next round's tile, one round ahead
+      const int nn1 = n1 < a.n ? n1 : a.n - 1;
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn1];
+    }
     LayerState<C> st[C::L];
     real4 h[C::NS][C::NB];
     KeptPlanes<C> kp;
@@ -2442,14 +2506,23 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
       }
     }
     __syncthreads();
-    real jets[K][C::NS], gout[K][C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
+    real jets[K][C::NS], gout[K][C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1], gth[PW::NT > 0 ? PW::NT : 1];
 #pragma unroll
     for (int kk = 0; kk < K; ++kk)
 #pragma unroll
       for (int s = 0; s < C::NS; ++s) jets[kk][s] = xr[(kk * C::NS + s) * 16 + p];
-    PW::apply(x, jets, a.seed, TRAIN ? 1 : 0, r, f, gout);
+    if constexpr (PW::ND > 0) {
+      const int nn = valid ? n : a.n - 1;
+#pragma unroll
+      for (int j = 0; j < PW::ND; ++j) xe[j] = a.coords[(size_t)(C::D + j) * a.ldc + nn];
+    }
+    PW::apply(x, xe, jets, a.seed, TRAIN ? 1 : 0, r, f, gout, gth);
     if (valid && q == 0 && k == 0) {
       lsum += PW::loss(r);
+      if constexpr (TRAIN) {
+#pragma unroll
+        for (int j = 0; j < PW::NT; ++j) tsum[j] += gth[j];
+      }
       if (a.resid) {
 #pragma unroll
         for (int e = 0; e < PW::NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];
@@ -2471,6 +2544,10 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
       tile_backward<C>(ldsw, stage, lane, p, q, x, go, st, acc, kp);
     }
   }
+#ifdef NDQ_PHASE_TS
+  __syncthreads();
+  NDQ_TS(2);
+#endif
   if constexpr (TRAIN) {
     // the G waves of a network add up among themselves (all networks at once: same barrier sequence), regions in that
     // network's own staging area; block_reduce_store addresses its regions behind "the" weight image of its base
@@ -2488,6 +2565,8 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
     for (int w = 0; w < WAVES; ++w) v += wl[w];
     a.loss_partials[blk] = v;
   }
+  if constexpr (TRAIN) theta_block_sum<PW::NT>(tsum, wl + 16, WAVES, a.theta_partials ? a.theta_partials + (size_t)blk * PW::NT : nullptr);
+  NDQ_TS(3);
 }
 
 template <class C, int K, class PW, bool TRAIN>
@@ -2558,6 +2637,9 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
   GradAcc<C> acc;
   if constexpr (TRAIN) { acc_zero<C>(acc); acc.bias = nullptr; }
   real lsum = 0.f;
+  real th[PW::NT > 0 ? PW::NT : 1], tsum[PW::NT > 0 ? PW::NT : 1];
+#pragma unroll
+  for (int j = 0; j < PW::NT; ++j) { th[j] = a.theta[j]; tsum[j] = 0.f; }
   for (int grp = blk * WAVES + wave; grp < ngroups; grp += nblk * WAVES) {
     const int n = grp * GP + lane;                       // this lane's point in phase 2 (lanes >= GP idle there)
     const bool valid = n < a.n && lane < GP;
@@ -2613,11 +2695,17 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- phase 2: the per-point program, one point per lane
     {
-      real r[PW::NR], f[PW::NF > 0 ? PW::NF : 1];
+      real r[PW::NR], f[PW::NF > 0 ? PW::NF : 1], gth[PW::NT > 0 ? PW::NT : 1];
+#pragma unroll
+      for (int j = 0; j < PW::NT; ++j) gth[j] = 0.f;
       real* row = X + (lane < GP ? lane : 0) * XS;
-      if (lane < GP) PW::apply(c, row, valid ? a.seed : 0.f, TRAIN ? 1 : 0, r, f, row);
+      if (lane < GP) PW::apply(c, th, row, valid ? a.seed : 0.f, TRAIN ? 1 : 0, r, f, row, gth);
       if (valid) {
         lsum += PW::loss(r);
+        if constexpr (TRAIN) {
+#pragma unroll
+          for (int j = 0; j < PW::NT; ++j) tsum[j] += gth[j];
+        }
         if (a.resid) {
 #pragma unroll
           for (int e = 0; e < PW::NEQ; ++e) a.resid[(size_t)e * a.ldj + n] = r[e];
@@ -2679,6 +2767,7 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
     for (int w = 0; w < WAVES; ++w) v += wl[w];
     a.loss_partials[blk] = v;
   }
+  if constexpr (TRAIN) theta_block_sum<PW::NT>(tsum, wl + 16, WAVES, a.theta_partials ? a.theta_partials + (size_t)blk * PW::NT : nullptr);
 }
 
 template <class C, class PW, bool TRAIN>

@@ -281,6 +281,8 @@ class BatchSharding:
     def all_reduce(self, system, n_batches, train=True):
         """Sum gradients (``system.flat[k].grad``) and the first ``n_batches`` loss slots over all ranks, in place."""
         grads = [fp.grad for fp in system.flat] if train else []
+        if train and getattr(system, "n_theta", 0):
+            grads = grads + [system.gtheta]          # trainable scalars of the equations: part of the same message
         loss = system.loss_buf[:n_batches]
         total = sum(g.numel() for g in grads) + n_batches
         if self._flat is None or self._flat.numel() != total or self._flat.device != loss.device:

@@ -471,6 +471,7 @@ class BaseSolver(ABC):
                                              want_funcs=bool(self.metrics_fn))
                     for fp in system.flat:
                         fp.attach_grads()
+                    system.attach_theta_grads()
                     return system.loss_buf[batch_id].clone()
                 self._do_optimizer_step(closure=closure)
                 b, n = last["bn"]
@@ -499,6 +500,8 @@ class BaseSolver(ABC):
                 fp.attach_grads()
         if shard:
             shard.all_reduce(system, nb, train=(key == "train"))
+        if key == "train":
+            system.attach_theta_grads()      # trainable scalars of the equations: .grad for the user's optimiser
         epoch_loss = system.loss_buf[:nb].sum().item() / nb           # the epoch's only host synchronisation
         self._update_history(epoch_loss, "loss", key)
         if key == "valid" or self.n_batches["valid"] == 0:
@@ -521,8 +524,8 @@ class BaseSolver(ABC):
         through ONE native call (engine.fast_train_epoch: closure kernel + fused sums/tail kernel); every other fused
         system runs its per-batch launch sequence and then the device-side epoch tail (loss history ring, best
         snapshot, fused Adam per network).  Returns False if the general (host-synchronising) path must run."""
-        if not self._native_ok() or system.f64:
-            return False
+        if not self._native_ok() or system.f64 or system.n_theta:
+            return False        # (trainable equation coefficients are stepped by the user's optimiser: general path)
         train = key == "train"
         nb = self.n_batches[key]
         track_best = (not train) or self.n_batches["valid"] == 0
@@ -646,8 +649,8 @@ class BaseSolver(ABC):
         fs = system.fast_state()
         if max(fs["pending"], fs["pending_valid"]) + 2 > system.HIST:
             self._flush_device_history()
-        K = min(remaining, self.FIT_CHUNK, system.HIST - max(fs["pending"], fs["pending_valid"]),
-                max(2, (64 << 20) // (4 * system.n_coords * (n + 63))))
+        k_max = min(self.FIT_CHUNK, max(2, (64 << 20) // (4 * system.n_coords * (n + 63))))
+        K = min(remaining, k_max, system.HIST - max(fs["pending"], fs["pending_valid"]))
         if K < 2:
             return 0
         if fs["pending"] == 0 and fs["pending_valid"] == 0:
@@ -671,7 +674,7 @@ class BaseSolver(ABC):
             t1 = time.perf_counter()
         if block is not None:
             tg._last = None
-            dev, ld = system.stage_batches(block, n)
+            dev, ld = system.stage_batches(block, n, reserve=k_max)
             stride = 4 * system.n_coords * ld
             ptrs = [dev.data_ptr() + e * stride for e in range(K)]
             self._batch["train"] = [block[-1, i].reshape(-1, 1).clone().requires_grad_(True) for i in range(block.shape[1])]
@@ -699,7 +702,7 @@ class BaseSolver(ABC):
                     ptrs = [r[0] for r in res]
             else:
                 block = torch.stack([torch.stack([c.detach().reshape(-1) for c in d]) for d in draws])
-                dev, ld = system.stage_batches(block, n)
+                dev, ld = system.stage_batches(block, n, reserve=k_max)
                 stride = 4 * system.n_coords * ld
                 ptrs = [dev.data_ptr() + e * stride for e in range(K)]
         slots = [self.optimizer.fast_slots(fp, K) for fp in system.flat]

@@ -28,6 +28,8 @@ class MetricTraceUnsupported(TraceUnsupported):
     the host from the function values the kernels write out."""
 
 
+LEAVES = ("const", "coord", "net", "param", "data")
+
 # op -> (arity).  Unary elementwise functions are listed in UNARY.
 UNARY = ("neg", "sin", "cos", "tan", "exp", "log", "tanh", "sqrt", "abs", "sinh", "cosh", "sigmoid", "recip", "sign")
 
@@ -51,6 +53,12 @@ class Graph:
         self.vcoords = {}        # virtual coordinate index (>= n_coords) -> its constant value
         self.site_net = []       # site -> network index (filled by register_nets / net_symbol)
         self.captured = []       # (1-element tensor baked in as a constant, its version counter at trace time)
+        # trainable scalars inside the equations (nn.Parameter coefficients of inverse problems: the reference simply
+        # re-runs diff_eqs under autograd, solvers.py:380) -- leaf ('param', j), read from a device vector at run time,
+        # its gradient one more per-point adjoint sum -- and per-point data columns ((N, 1) tensors aligned with the
+        # batch, e.g. a measured source term on a PredefinedGenerator's points) -- leaf ('data', j), one more input row
+        self.params = []
+        self.data = []
 
     # -------------------------------------------------------------- networks
     def register_nets(self, nets, n_outs):
@@ -119,6 +127,22 @@ class Graph:
         if not (mi and mi[0] == "L"):       # ("L", a, b, ..) = Laplacian stream: sum over a of d2/dx_a^2
             mi = tuple(sorted(mi))
         return self._mk(("net", int(net_idx), int(out_idx), mi))
+
+    def param(self, t):
+        """Leaf for a trainable 1-element tensor (one leaf per tensor object)."""
+        for j, p in enumerate(self.params):
+            if p is t:
+                return self._mk(("param", j))
+        self.params.append(t)
+        return self._mk(("param", len(self.params) - 1))
+
+    def datacol(self, t):
+        """Leaf for an (N, 1) column of per-point data (one leaf per tensor object)."""
+        for j, p in enumerate(self.data):
+            if p is t:
+                return self._mk(("data", j))
+        self.data.append(t)
+        return self._mk(("data", len(self.data) - 1))
 
     def cval(self, i):
         n = self.nodes[i]
@@ -227,10 +251,13 @@ class Graph:
         D = lambda x: self.diff(x, ci)
         if op == "const":
             r = self.const(0.0)
-        elif isinstance(ci, tuple) and op in ("coord", "net"):   # d/d(leaf node ("n", id)): other leaves independent
+        elif isinstance(ci, tuple) and op in LEAVES:   # d/d(leaf node ("n", id)): other leaves independent
             r = self.const(1.0 if e == ci[1] else 0.0)
         elif op == "coord":
             r = self.const(1.0 if n[1] == ci else 0.0)
+        elif op in ("param", "data"):
+            # no autograd path to a coordinate: the reference's diff() of such a tensor contributes nothing either
+            r = self.const(0.0)
         elif op == "net":
             _, k, o, mi = n
             if ci not in self.net_deps[k]:
@@ -303,7 +330,7 @@ class Graph:
         n = self.nodes[e]
         op = n[0]
         S = lambda x: self.subst(x, mapping, memo)
-        if op in ("const", "coord", "net"):
+        if op in LEAVES:
             r = e
         elif op in ("add", "sub", "mul", "div"):
             r = getattr(self, op)(S(n[1]), S(n[2]))
@@ -330,7 +357,7 @@ class Graph:
             seen.add(i)
             stack.append((i, True))
             n = self.nodes[i]
-            if n[0] in ("const", "coord", "net"):
+            if n[0] in LEAVES:
                 continue
             for a in self.children(i):
                 if a not in seen:
@@ -340,7 +367,7 @@ class Graph:
     def children(self, i):
         n = self.nodes[i]
         op = n[0]
-        if op in ("const", "coord", "net"):
+        if op in LEAVES:
             return ()
         if op in ("add", "sub", "mul", "div"):
             return (n[1], n[2])
@@ -359,25 +386,97 @@ def current_graph():
 class trace_scope:
     def __init__(self, graph):
         self.graph = graph
+        self.mode = None
 
     def __enter__(self):
         _CURRENT.append(self.graph)
+        self.mode = _TwinMode(self.graph)
+        self.mode.__enter__()
         return self.graph
 
     def __exit__(self, *exc):
+        self.mode.__exit__(*exc)
         _CURRENT.pop()
+
+
+_TWIN_BINARY = {"mul": "mul", "__mul__": "mul", "multiply": "mul", "add": "add", "__add__": "add", "sub": "sub",
+                "__sub__": "sub", "subtract": "sub", "div": "div", "__truediv__": "div", "divide": "div",
+                "true_divide": "div"}
+_TWIN_REVERSED = {"__rmul__": "mul", "__radd__": "add", "__rsub__": "sub", "__rtruediv__": "div"}
+_TWIN_UNARY = {"neg": "neg", "__neg__": "neg", "negative": "neg", "exp": "exp", "log": "log", "sin": "sin", "cos": "cos",
+               "tan": "tan", "tanh": "tanh", "sqrt": "sqrt", "abs": "abs", "__abs__": "abs", "sigmoid": "sigmoid",
+               "sinh": "sinh", "cosh": "cosh", "reciprocal": "recip"}
+_TWIN_SHAPE = ("reshape", "view", "view_as", "unsqueeze", "squeeze", "expand", "expand_as", "clone", "contiguous", "to",
+               "float", "double", "type", "flatten", "__getitem__")
+
+
+class _TwinMode(torch.overrides.TorchFunctionMode):
+    """Active while a system is traced.  An equation may combine a TRAINABLE scalar with plain tensors before any traced
+    column is involved -- ``nu * f_measured``, ``torch.exp(log_k)`` -- and what the traced column then meets is an ordinary
+    tensor with an autograd history, computed once, at trace time.  This mode watches the torch calls of the traced region:
+    every result that depends on a trainable leaf gets a symbolic *twin* (built from the twins / leaves of its operands),
+    and ``_as_node`` hands out the twin instead of refusing the tensor.  Calls it cannot mirror leave no twin: the tensor
+    is then refused as before (TraceUnsupported -> composite path), never baked in as a constant."""
+
+    def __init__(self, graph):
+        super().__init__()
+        self.g = graph
+        if not hasattr(graph, "twins"):
+            graph.twins = {}
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        out = func(*args, **kwargs)
+        if isinstance(out, torch.Tensor) and out.requires_grad and out.grad_fn is not None and id(out) not in self.g.twins:
+            try:
+                node = self._mirror(getattr(func, "__name__", ""), args, kwargs)
+            except TraceUnsupported:
+                node = None
+            if node is not None:
+                self.g.twins[id(out)] = (out, node)          # (the tensor is kept alive: ids are not reused)
+        return out
+
+    def _operand(self, v):
+        g = self.g
+        if isinstance(v, torch.Tensor):
+            tw = g.twins.get(id(v))
+            if tw is not None and tw[0] is v:
+                return tw[1]
+            if v.requires_grad and not (v.is_leaf and v.numel() == 1):
+                raise TraceUnsupported("untracked tensor with an autograd history")
+        return _as_node(g, v)
+
+    def _mirror(self, name, args, kwargs):
+        g = self.g
+        if name in _TWIN_BINARY and len(args) >= 2 and not kwargs:
+            return getattr(g, _TWIN_BINARY[name])(self._operand(args[0]), self._operand(args[1]))
+        if name in _TWIN_REVERSED and len(args) == 2:
+            return getattr(g, _TWIN_REVERSED[name])(self._operand(args[1]), self._operand(args[0]))
+        if name in _TWIN_UNARY and len(args) == 1:
+            return g.unary(_TWIN_UNARY[name], self._operand(args[0]))
+        if name in ("pow", "__pow__") and len(args) == 2 and isinstance(args[1], numbers.Number):
+            return g.powc(self._operand(args[0]), float(args[1]))
+        if name == "square" and len(args) == 1:
+            a = self._operand(args[0])
+            return g.mul(a, a)
+        if name in _TWIN_SHAPE and args and isinstance(args[0], torch.Tensor):
+            return self._operand(args[0])                    # a scalar stays a scalar, a column a column
+        return None
 
 
 def _row_values(v):
     """A constant row vector (tensor / ndarray / list with more than one element) as a list of floats, else None."""
     if isinstance(v, torch.Tensor) and v.numel() > 1:
         if v.requires_grad:
-            raise TraceUnsupported("a trainable tensor inside the equations (the traced kernel would read it once and "
-                                   "give it no gradient)")
+            if _CURRENT and getattr(_CURRENT[-1], "twins", {}).get(id(v), (None,))[0] is v:
+                return None          # torch expression of trainable scalars and data columns: _as_node returns its twin
+            raise TraceUnsupported("a trainable tensor of more than one element inside the equations (trainable SCALARS are "
+                                   "traced; a vector would need one kernel argument per entry)")
+        if v.dim() == 2 and v.shape[1] == 1:
+            return None              # an (N, 1) column of per-point data: _as_node makes it an input row of the kernel
         if not (v.dim() == 1 or (v.dim() == 2 and v.shape[0] == 1)):
-            # (N, 1) per-point data columns, matrices ...: a column is NOT a constant row
-            raise TraceUnsupported(f"a concrete tensor of shape {tuple(v.shape)} inside the equations (only scalars and "
-                                   "constant rows (k,) / (1, k) can be baked into the traced kernel)")
+            raise TraceUnsupported(f"a concrete tensor of shape {tuple(v.shape)} inside the equations (scalars, constant "
+                                   "rows (k,) / (1, k) and per-point columns (N, 1) can be traced)")
         return [float(x) for x in v.detach().reshape(-1).tolist()]
     try:
         import numpy as np
@@ -395,12 +494,20 @@ def _as_node(g, v):
         if v.g is not g:
             raise TraceUnsupported("mixing symbols of different traces")
         return v.i
+    if isinstance(v, torch.Tensor) and v.requires_grad and not v.is_leaf:
+        tw = getattr(g, "twins", {}).get(id(v))          # a torch expression of trainable scalars seen by _TwinMode
+        if tw is not None and tw[0] is v:
+            return tw[1]
     if isinstance(v, numbers.Number):
         return g.const(float(v))
+    if isinstance(v, torch.Tensor) and v.numel() > 1 and v.dim() == 2 and v.shape[1] == 1 and not v.requires_grad:
+        return g.datacol(v)
     if isinstance(v, torch.Tensor) and v.numel() == 1:
         if v.requires_grad:
-            raise TraceUnsupported("a trainable scalar (nn.Parameter / requires_grad tensor) inside the equations: the "
-                                   "traced kernel would bake its value in and give it no gradient")
+            if not v.is_leaf:
+                raise TraceUnsupported("a non-leaf tensor that requires grad inside the equations (only leaf scalars -- "
+                                       "nn.Parameter coefficients -- become trainable kernel arguments)")
+            return g.param(v)
         # baked in at trace time like a Python float; the solver re-traces when the tensor is modified in place
         g.captured.append((v, v._version))
         return g.const(float(v.item()))

@@ -152,6 +152,50 @@ def make(name, size=None):
     raise KeyError(name)
 
 
+def make_inverse(name, size=None):
+    """Inverse problems (tests/golden/make_golden.py: cfg_inv1 / cfg_inv2): trainable scalars inside the equations, a
+    per-point data column.  Same construction order as the golden script (network init, then the data draw)."""
+    from neurodiffeq_amd.conditions import DirichletBVP
+    from neurodiffeq_amd.generators import PredefinedGenerator
+    if name == "inv1":
+        g = size or 12
+        nets = [FCNN(2, 1, hidden_units=(32, 32))]
+        nu, amp = torch.nn.Parameter(torch.tensor(0.05)), torch.nn.Parameter(torch.tensor(0.8))
+        pde = lambda u, x, t: [diff(u, t) + amp * u * diff(u, x) - nu * diff(u, x, order=2)]
+        conds = [IBVP1D(x_min=-1, x_max=1, t_min=0, t_min_val=lambda x: -torch.sin(PI * x), x_min_val=lambda t: 0,
+                        x_max_val=lambda t: 0)]
+        gen = Generator2D((g, g), (-1, 0), (1, 1), "equally-spaced-noisy")
+        return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=gen, theta=[nu, amp], data=[], n_points=g * g,
+                    dom=((-1, 0), (1, 1)))
+    if name == "inv2":
+        n = size or 48
+        nets = [FCNN(1, 1, hidden_units=(32, 32), actv=SinActv)]
+        xs = torch.linspace(0.0, 1.0, n)
+        f = (-(PI ** 2) * torch.sin(PI * xs) + 0.1 * torch.rand(n)).reshape(-1, 1)
+        a, b = torch.nn.Parameter(torch.tensor(0.6)), torch.nn.Parameter(torch.tensor(0.1))
+        pde = lambda u, x: [diff(u, x, order=2) - a * f - b]
+        conds = [DirichletBVP(0.0, 0.0, 1.0, 0.0)]
+        return dict(kind="1d", pde=pde, nets=nets, conds=conds, gen=PredefinedGenerator(xs), theta=[a, b], data=[f],
+                    n_points=n, dom=(0.0, 1.0))
+    raise KeyError(name)
+
+
+def make_inverse_solver(name, size=None, **kw):
+    """The solver of an inverse problem: the coefficients sit in the optimiser next to the network's parameters (the
+    reference's default optimiser knows the networks only, solvers.py:182)."""
+    from neurodiffeq_amd.solvers import Solver1D, Solver2D
+    cfg = make_inverse(name, size)
+    opt = torch.optim.Adam([p for n in cfg["nets"] for p in n.parameters()] + cfg["theta"], lr=1e-3)
+    kw.setdefault("n_batches_valid", 0)
+    if cfg["kind"] == "2d":
+        s = Solver2D(cfg["pde"], cfg["conds"], xy_min=cfg["dom"][0], xy_max=cfg["dom"][1], nets=cfg["nets"],
+                     train_generator=cfg["gen"], valid_generator=cfg["gen"], optimizer=opt, **kw)
+    else:
+        s = Solver1D(cfg["pde"], cfg["conds"], t_min=cfg["dom"][0], t_max=cfg["dom"][1], nets=cfg["nets"],
+                     train_generator=cfg["gen"], valid_generator=cfg["gen"], optimizer=opt, **kw)
+    return s, cfg
+
+
 def n_coords(cfg):
     return {"1d": 1, "2d": 2, "sph": 3, "bundle": 3}[cfg["kind"]]
 

@@ -210,3 +210,56 @@ def test_loss_that_changes_with_the_epoch_is_noticed_at_the_very_next_epoch():
             seen.append(solver.fused_active)
     assert seen == [True] * 4 + [False] * 3, seen                  # epochs 0..3 fused, from epoch 4 on the composite path
     assert any("changed between epochs" in str(x.message) for x in w)
+
+
+# ------------------------------------------------------------------------------------------------ inverse problems
+@pytest.mark.parametrize("mode", ["1k", "3k"])
+@pytest.mark.parametrize("name", ["inv1", "inv2"])
+def test_inverse_problem_closure_matches_reference_golden(golden_dir, name, mode):
+    """trainable scalars inside the equations (kernel arguments; gradient = fixed-order sum of per-point
+    adjoints) and a per-point data column (an input row behind the coordinates) on the fused kernels -- single launch and
+    three-kernel pipeline -- against one closure of the unmodified reference (tests/golden/inv1.npz, inv2.npz)."""
+    import os
+    from neurodiffeq_amd.engine import FusedSystem
+    from tests import configs
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    cfg = configs.make_inverse(name)
+    for net in cfg["nets"]:
+        net.to("cuda")
+    system = FusedSystem(cfg["nets"], cfg["conds"], cfg["pde"], len(gold["coords"]), "cuda", single_kernel=(mode == "1k"))
+    assert (system.fusedk is not None) == (mode == "1k") and system.n_theta == 2 and system.n_data == len(cfg["data"])
+    coords = [torch.from_numpy(c) for c in gold["coords"]]
+    b, n = system.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    system.attach_theta_grads()
+    rel = lambda a, w: float(np.linalg.norm(np.asarray(a, np.float64).ravel() - np.asarray(w, np.float64).ravel())
+                             / np.linalg.norm(np.asarray(w, np.float64).ravel()))
+    errs = dict(funcs=rel(b["funcs"][:, :n].T.cpu().numpy(), gold["funcs_f64"]),
+                residuals=rel(b["resid"][:1, :n].T.cpu().numpy(), gold["residuals_f64"]),
+                loss=abs(system.loss_buf[0].item() - float(gold["loss_f64"])) / float(gold["loss_f64"]),
+                grad=rel(system.flat[0].grad.cpu().numpy(), gold["grad_f64"]),
+                grad_theta=rel([p.grad.item() for p in cfg["theta"]], gold["grad_theta_f64"]))
+    assert max(errs.values()) < 1e-5, errs
+    if mode == "1k":
+        assert system.fused_check["reproducible"] and system.fused_check["grad_rel_l2"] < system.SELF_CHECK_TOL
+
+
+@pytest.mark.parametrize("name", ["inv1", "inv2"])
+def test_inverse_problem_solver_trajectory_matches_reference_golden(golden_dir, name):
+    """Three epochs of the Solver with the coefficients in the optimiser (torch Adam over the network's parameter views
+    and the scalars): losses, final parameters and final coefficients of the reference's own run."""
+    import os
+    from tests import configs
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    solver, cfg = configs.make_inverse_solver(name)
+    solver.fused = "require"
+    torch.manual_seed(int(gold["seed"]) + 2)
+    for _ in range(3):
+        solver.run_train_epoch()
+    assert solver.fused_active and solver._fused_sys.n_theta == 2
+    assert np.allclose(solver.metrics_history["train_loss"], gold["traj_loss"], rtol=2e-5)
+    params = R.get_flat(cfg["nets"]).cpu().numpy()
+    assert np.linalg.norm(params - gold["traj_params"]) <= 1e-5 * np.linalg.norm(gold["traj_params"])
+    assert np.allclose([p.item() for p in cfg["theta"]], gold["traj_theta"], rtol=1e-5)

@@ -185,3 +185,21 @@ def test_third_order_jets_match_nested_autograd(act):
     loss.backward()
     got = J.mlp_jets_vjp(flat, (2, 16, 16, 2), act, [x.detach().numpy(), y.detach().numpy()], gb)
     assert rel_l2(got, R.get_flat_grad([net]).numpy()) < 1e-12
+
+
+@pytest.mark.parametrize("name,grid", [("c2", 64), ("c3", 48)])
+def test_closure_at_the_reference_trained_state(golden_dir, name, grid):
+    """Near convergence (tests/golden/<name>_trained.npz: the unmodified reference trained the config, then evaluated one
+    batch in fp64 and fp32): the oracle reproduces the reference's fp64 closure there as well -- the residual is a
+    cancellation of O(1) terms at this point."""
+    g = np.load(os.path.join(golden_dir, f"{name}_trained.npz"))
+    cfg = R.build_config(name, grid, dtype=torch.float64)
+    R.set_flat(cfg["nets"], torch.from_numpy(g["params"]).double())
+    coords = [torch.from_numpy(c).double() for c in g["coords"]]
+    out = R.closure(cfg["nets"], cfg["enforcers"], cfg["pde"], coords)
+    assert rel_l2(out["funcs"].numpy().ravel(), g["u_f64"]) < 1e-12
+    assert rel_l2(out["residuals"].numpy(), g["residual_f64"]) < 1e-9         # (relative to a residual ~1e-2 of its terms)
+    assert abs(out["loss"].item() - float(g["loss_f64"])) <= 1e-9 * float(g["loss_f64"])
+    assert rel_l2(R.get_flat_grad(cfg["nets"]).numpy(), g["grad_f64"]) < 1e-9
+    # how far the reference's own fp32 evaluation is from fp64 here: the yardstick of the GPU test
+    assert rel_l2(g["residual_f32"], g["residual_f64"]) > 1e-7

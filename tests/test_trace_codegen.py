@@ -10,6 +10,7 @@ import torch
 from neurodiffeq_amd import codegen
 from neurodiffeq_amd.networks import describe
 from neurodiffeq_amd.symbolic import Graph, Sym, trace_scope
+from oracle import autograd_ref as R
 from oracle import jet_ref as J
 from tests import configs, zoo
 from tests.pw_cpu import run_cpu
@@ -89,7 +90,15 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
                      for i in prog.symbols]).astype(wdt)
     n_eq = len(prog.residuals)
     seed = 1.0 / (n * prog.loss_norm)
-    resid, funcs, gbar, lterm = run_cpu(prog, coords, syms, seed, return_loss=True, f64=f64)
+    gtheta = None
+    if prog.n_theta or prog.n_data:      # trainable scalars of the equations / per-point data columns (inverse problems)
+        data = [np.asarray(t.detach().numpy(), wdt).reshape(-1) for t in prog.g.data]
+        theta = [float(t.detach()) for t in prog.g.params]
+        resid, funcs, gbar, lterm, gth = run_cpu(prog, coords, syms, seed, return_loss=True, f64=f64, data=data, theta=theta)
+        gtheta = gth.astype(np.float64).sum(axis=1)[:prog.n_theta]
+        host_closure.last_gtheta = gtheta
+    else:
+        resid, funcs, gbar, lterm = run_cpu(prog, coords, syms, seed, return_loss=True, f64=f64)
     r64 = resid.astype(np.float64)
     term = {"l2": lambda r: (r ** 2).sum(), "l1": lambda r: np.abs(r).sum(), "infinity": lambda r: np.abs(r).max(axis=0).sum()}
     loss = float(lterm.astype(np.float64).sum() * seed) if callable(loss) else float(term[loss](r64) * seed)
@@ -333,9 +342,11 @@ def test_unsupported_constructs_raise_trace_unsupported():
 
 
 def test_trainable_and_per_point_tensors_are_not_baked_into_the_kernel():
-    """an nn.Parameter coefficient (inverse problems) or an (N, 1) data column inside ``diff_eqs`` must send
-    the system to the composite path, not be frozen into / mis-broadcast by the generated kernel; a plain scalar
-    tensor is a constant of the trace and its in-place modification is visible through the version counter."""
+    """ADVICE r1 / VERDICT r2 #7: an nn.Parameter coefficient (inverse problems) or an (N, 1) data column inside
+    ``diff_eqs`` is never frozen into / mis-broadcast by the generated kernel: since round 3 a trainable SCALAR is a
+    kernel argument with a gradient (leaf 'param'), an (N, 1) column an input row (leaf 'data'), torch expressions of
+    the two get a symbolic twin; trainable vectors and other shapes still send the system to the composite path.  A plain
+    scalar tensor is a constant of the trace and its in-place modification is visible through the version counter."""
     from neurodiffeq_amd import diff
     from neurodiffeq_amd.conditions import IVP
     from neurodiffeq_amd.engine import trace_system
@@ -343,11 +354,15 @@ def test_trainable_and_per_point_tensors_are_not_baked_into_the_kernel():
     from neurodiffeq_amd.symbolic import TraceUnsupported
     net, cond = FCNN(1, 1, hidden_units=(32, 32)), IVP(0.0, 1.0)
     k = torch.nn.Parameter(torch.tensor(2.0))
-    with pytest.raises(TraceUnsupported, match="trainable"):
-        trace_system([net], [cond], lambda u, t: [diff(u, t) + k * u], 1)
     data = torch.linspace(0, 1, 7).reshape(-1, 1)
+    prog, _ = trace_system([net], [cond], lambda u, t: [diff(u, t) + k * u - torch.exp(-k) * data], 1)
+    assert prog.n_theta == 1 and prog.g.params[0] is k and prog.n_data == 1 and prog.g.data[0] is data
+    assert not prog.g.captured                      # nothing of it was baked in as a constant
+    kv = torch.nn.Parameter(torch.ones(3))
+    with pytest.raises(TraceUnsupported, match="trainable"):
+        trace_system([net], [cond], lambda u, t: [diff(u, t) + (kv * u).sum(dim=1, keepdim=True)], 1)
     with pytest.raises(TraceUnsupported, match="shape"):
-        trace_system([net], [cond], lambda u, t: [diff(u, t) - data], 1)
+        trace_system([net], [cond], lambda u, t: [diff(u, t) - torch.ones(4, 4, 2)], 1)
     with pytest.raises(TraceUnsupported):
         trace_system([net], [cond], lambda u, t: [torch.cat([u, u], dim=1)], 1)
     c = torch.tensor(3.0)
@@ -502,3 +517,43 @@ def test_scalarized_packed_ops_compute_what_the_packed_ones_do():
         assert all(x == y or (np.isnan(x) and np.isnan(y)) for x, y in zip(a, b)), (text, out)
         checked += 1
     assert checked > 2000
+
+
+@pytest.mark.parametrize("name", ["inv1", "inv2"])
+def test_inverse_problem_closure_on_host_matches_reference(golden_dir, name):
+    """nn.Parameter coefficients inside the equations become kernel arguments whose gradient is one more
+    sum of per-point adjoints; (N, 1) data tensors become input rows.  Tracer + generated code (gcc) + jet oracle against
+    what the unmodified reference computed (tests/golden/inv1.npz: Burgers with trainable viscosity and advection
+    amplitude; inv2.npz: Poisson with a measured source column and two trainable scalars)."""
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    cfg = configs.make_inverse(name)
+    assert np.array_equal(R.get_flat(cfg["nets"]).numpy(), gold["params0"])
+    if cfg["data"]:
+        assert np.array_equal(np.stack([d.numpy().reshape(-1) for d in cfg["data"]]), gold["data"])
+    prog, funcs, resid, loss, grad = host_closure(cfg["nets"], cfg["conds"], cfg["pde"], gold["coords"], gold["params0"])
+    assert prog.n_theta == 2 and prog.n_data == len(cfg["data"])
+    order = [next(j for j, t in enumerate(prog.g.params) if t is p) for p in cfg["theta"]]    # leaves are numbered by first use
+    assert rel_l2(funcs, gold["funcs_f64"]) < 1e-5 and rel_l2(resid, gold["residuals_f64"]) < 1e-5
+    assert abs(loss - float(gold["loss_f64"])) <= 1e-5 * abs(float(gold["loss_f64"]))
+    assert rel_l2(grad, gold["grad_f64"]) < 1e-5
+    assert rel_l2(host_closure.last_gtheta[order], gold["grad_theta_f64"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["inv1", "inv2"])
+def test_inverse_problem_trajectory_on_the_composite_path(golden_dir, name):
+    """The same problems through the Solver on a host without a GPU (composite path = the reference's closure): three epochs
+    of Adam over the network AND the coefficients reproduce the reference's trajectory."""
+    import warnings
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    solver, cfg = configs.make_inverse_solver(name)
+    solver.fused = "off"
+    torch.manual_seed(int(gold["seed"]) + 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(3):
+            solver.run_train_epoch()
+    assert np.allclose(solver.metrics_history["train_loss"], gold["traj_loss"], rtol=2e-5)
+    assert rel_l2(R.get_flat(cfg["nets"]).numpy(), gold["traj_params"]) < 1e-5
+    assert np.allclose([p.item() for p in cfg["theta"]], gold["traj_theta"], rtol=1e-5)
