@@ -208,7 +208,13 @@ int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_
 typedef int (*ndq_fused_launch_tv_fn)(const float* coords, int ldc, int n, const float* const* params,
                                       float* const* partials, float* loss_partials, float seed,
                                       const float* valid_coords, int valid_ldc, int valid_n,
-                                      float* valid_loss_partials, void* stream);
+                                      float* valid_loss_partials, const void* pull, void* stream);
+/* `pull` (NULL: none): an ndq::PullArgs of csrc/ndq_tail.h.  PULL MODE, for grids of up to 32 training workgroups: the
+ * closure launch of epoch e first FINISHES epoch e - 1 itself -- every workgroup adds up the partial rows of the previous
+ * launch (same summation order as the tail kernel), applies Adam to all parameters in registers and stages its weight
+ * image from the result; workgroup 0 writes the new parameters / moments / history.  One launch per epoch instead of
+ * two.  It needs a second set of buffers (a launch reads the state its predecessor wrote while writing the next one):
+ * the alt_* members below; the call's last launch is an ordinary tail that leaves everything in the primary buffers. */
 typedef struct ndq_fused_fit {
   ndq_fused_launch_tv_fn launch;   /* exported by the generated closure kernel module as ndq_fused_launch_tv */
   int n_nets;                      /* 1..4 networks behind the one closure launch */
@@ -223,6 +229,14 @@ typedef struct ndq_fused_fit {
   float* valid_hist;               /* ring of validation-epoch losses */
   int track_best;                  /* 0: no snapshot, 1: lowest TRAINING loss (n_batches_valid = 0, solvers.py:414-415),
                                       2: lowest VALIDATION loss */
+  /* pull mode: pull_ok != 0 (the closure module supports it: ndq_fused_pull_ok) and every alt_* buffer present */
+  int pull_ok;
+  float* alt_params[4];            /* [P_k] second parameter vector of network k, likewise the Adam moments */
+  float* alt_m[4];
+  float* alt_v[4];
+  float* alt_partials[4];          /* [blocks][P_k] */
+  float* alt_loss_partials;        /* [blocks] */
+  float* alt_valid_loss_partials;  /* [valid_blocks] */
 } ndq_fused_fit;
 /* train_coords: HOST array of n_epochs device pointers, the [d][ldc] batch of every epoch.  adam_step: step count AFTER
  * the first update (epoch e uses adam_step + e).  parity: slot of best_loss[2] holding the current best; every tail

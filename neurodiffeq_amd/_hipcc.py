@@ -27,7 +27,7 @@ LLVM_BIN = os.environ.get("NDQ_LLVM_BIN", os.path.join(os.path.dirname(os.path.d
 ARCH = "gfx950"
 BASE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")]
 # part of every cache key: bump when the fix-up rules change so that cached kernels are rebuilt
-FIXUP_VERSION = "pk-opsel-scalar+mfma-nop-2"
+FIXUP_VERSION = "pk-opsel-scalar+mfma-nop-3"
 
 _PK = re.compile(r"^\s*v_pk_\w+")
 _MFMA = re.compile(r"^\s*v_s?mfmac?_\w+")
@@ -118,6 +118,29 @@ def scalarize_pk(asm_text, which="opsel"):
         lo_clobbers_hi = any(x.lstrip("-") == d_lo for x in src_hi)
         hi_clobbers_lo = any(x.lstrip("-") == d_hi for x in src_lo)
         if lo_clobbers_hi and hi_clobbers_lo:
+            # each half would overwrite a source of the other.  The case the compiler emits is the pair sum / product
+            # "x.lo (op) x.hi in both halves" (v_pk_add_f32 v[a:a+1], v[a:a+1], v[a:a+1] op_sel:[0,1] op_sel_hi:[1,0]): both
+            # halves compute the SAME value from the same operands -- compute it once, copy it.  Anything else is left
+            # alone here and stopped by verify_fixup (the build fails closed).
+            commutes = sorted(src_lo[:2]) == sorted(src_hi[:2]) and (nsrc == 2 or src_lo[2] == src_hi[2])
+            if commutes:
+                out += [lo, f"{indent}v_mov_b32_e32 {d_hi}, {d_lo}"]
+                done += 1
+                continue
+            # general case: exchange the two destination registers first (v_swap_b32), rename them in the sources; the
+            # halves then stop reading each other's destination in at least one order
+            def ren(x):
+                neg, r = ("-", x[1:]) if x.startswith("-") else ("", x)
+                return neg + (d_hi if r == d_lo else d_lo if r == d_hi else r)
+            s_lo, s_hi = [ren(x) for x in src_lo], [ren(x) for x in src_hi]
+            lo2 = f"{indent}{mnem} {d_lo}, " + ", ".join(s_lo)
+            hi2 = f"{indent}{mnem} {d_hi}, " + ", ".join(s_hi)
+            lo_first_ok = not any(x.lstrip("-") == d_lo for x in s_hi)
+            hi_first_ok = not any(x.lstrip("-") == d_hi for x in s_lo)
+            if lo_first_ok or hi_first_ok:
+                out += [f"{indent}v_swap_b32 {d_lo}, {d_hi}"] + ([lo2, hi2] if lo_first_ok else [hi2, lo2])
+                done += 1
+                continue
             out.append(line)
             skipped += 1
             continue
@@ -137,6 +160,12 @@ def verify_fixup(asm_text):
     written -- e.g. after a compiler update -- must be looked at, not waved through);
     (2) no packed VALU instruction may be directly followed by an MFMA.  Raises RuntimeError."""
     prev_pk = None
+    # One kind of instruction has no two-instruction rewrite: a genuine two-in / two-out update, (L, H) <- (a L + H, b H + L),
+    # where each half reads BOTH destination registers (it would need a spare register).  What is known about the op_sel
+    # forms (DESIGN.md 4.6): the direct hazard -- such an instruction immediately before a bf16 MFMA -- is removed by the
+    # wait state fix_pk_mfma inserts; the second, unexplained failure was only ever seen in kernels that SPILL.  So such an
+    # instruction may stay in a module without scratch, and stops the build in a module with scratch.
+    spills = any(int(v) > 0 for v in re.findall(r"^; ScratchSize: (\d+)", asm_text, flags=re.M))
     for ln, line in enumerate(asm_text.split("\n"), 1):
         if not _is_instruction(line):
             continue
@@ -144,9 +173,16 @@ def verify_fixup(asm_text):
         if _PK_ANY_F32.match(line):
             m = re.search(r"\bop_sel:\[([01,]+)\]", s)
             if m and "1" in m.group(1):
-                raise RuntimeError(f"assembly fix-up: packed fp32 instruction with op_sel left in the output (line {ln}): {s}\n"
-                                   "-- an encoding _hipcc.scalarize_pk does not know; NDQ_NO_PK_MFMA_FIX=1 builds without the "
-                                   "pass (and without its protection)")
+                two_in_two_out = False
+                pm = _PK_F32.match(line)
+                if pm:
+                    ops = [o.strip() for o in _MOD.sub("", pm.group(3).split(";")[0]).strip().rstrip(",").split(",") if o.strip()]
+                    two_in_two_out = len(ops) >= 3 and ops[1:].count(ops[0]) >= 2
+                if not (two_in_two_out and not spills):
+                    raise RuntimeError(f"assembly fix-up: packed fp32 instruction with op_sel left in the output (line {ln}): {s}\n"
+                                       "-- an encoding _hipcc.scalarize_pk has no rewrite for"
+                                       + (" in a kernel module that spills registers" if two_in_two_out else "")
+                                       + "; NDQ_NO_PK_MFMA_FIX=1 builds without the pass (and without its protection)")
         if prev_pk is not None and _MFMA.match(line):
             raise RuntimeError(f"assembly fix-up: packed VALU instruction directly followed by an MFMA (line {ln}): {prev_pk} / {s}")
         prev_pk = s if _PK.match(line) else None

@@ -53,7 +53,10 @@ class FusedFit(ctypes.Structure):
     _fields_ = [("launch", ctypes.c_void_p), ("n_nets", ctypes.c_int), ("net", FusedStep * 4),
                 ("valid_coords", ctypes.c_void_p), ("valid_n", ctypes.c_int), ("valid_ldc", ctypes.c_int),
                 ("valid_blocks", ctypes.c_int), ("valid_scale", ctypes.c_float),
-                ("valid_loss_partials", ctypes.c_void_p), ("valid_hist", ctypes.c_void_p), ("track_best", ctypes.c_int)]
+                ("valid_loss_partials", ctypes.c_void_p), ("valid_hist", ctypes.c_void_p), ("track_best", ctypes.c_int),
+                ("pull_ok", ctypes.c_int), ("alt_params", ctypes.c_void_p * 4), ("alt_m", ctypes.c_void_p * 4),
+                ("alt_v", ctypes.c_void_p * 4), ("alt_partials", ctypes.c_void_p * 4),
+                ("alt_loss_partials", ctypes.c_void_p), ("alt_valid_loss_partials", ctypes.c_void_p)]
 
 
 class NdqError(RuntimeError):

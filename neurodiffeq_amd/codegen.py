@@ -132,7 +132,7 @@ def _tv_launcher(args_t, fill, kern_tv, lds_train, lds_eval, threads="CFG::BWD_T
     training batch, the next blocks(vn) the forward-only closure on the validation batch; n = 0 / vn = 0 drops a half."""
     return f"""
 int launch_tv(const float* coords, int ldc, int n, const float* const* params, float* const* partials, float* loss_partials,
-              float seed, const float* vcoords, int vldc, int vn, float* vloss_partials, void* stream) {{
+              float seed, const float* vcoords, int vldc, int vn, float* vloss_partials, const void* pull, void* stream) {{
   if (!params || n < 0 || vn < 0 || (n == 0 && vn == 0)) return -2;
   if (n > 0 && (!coords || !partials || !loss_partials || ldc < n)) return -2;
   if (vn > 0 && (!vcoords || !vloss_partials || vldc < vn)) return -2;
@@ -158,8 +158,13 @@ int launch_tv(const float* coords, int ldc, int n, const float* const* params, f
     if (e != hipSuccess) return (int)e;
     attr = true;
   }}
+  ndq::PullArgs pa{{}};        // pull prologue (csrc/ndq_tail.h): the launch finishes the previous epoch itself
+  if (pull) {{
+    if (!ndq::pull_supported<CFG>()) return -2;
+    pa = *static_cast<const ndq::PullArgs*>(pull);
+  }}
   hipLaunchKernelGGL(({kern_tv}), dim3(tb + vb), dim3({threads}), tb > 0 ? {lds_train} : {lds_eval},
-                     static_cast<hipStream_t>(stream), t, v, tb);
+                     static_cast<hipStream_t>(stream), t, v, tb, pa);
   return (int)hipGetLastError();
 }}"""
 
@@ -168,9 +173,10 @@ int launch_tv(const float* coords, int ldc, int n, const float* const* params, f
 _TV_EXPORT = """
 extern "C" int ndq_fused_launch_tv(const float* coords, int ldc, int n, const float* const* params, float* const* partials,
                                    float* loss_partials, float seed, const float* vcoords, int vldc, int vn,
-                                   float* vloss_partials, void* stream) {
-  return launch_tv(coords, ldc, n, params, partials, loss_partials, seed, vcoords, vldc, vn, vloss_partials, stream);
+                                   float* vloss_partials, const void* pull, void* stream) {
+  return launch_tv(coords, ldc, n, params, partials, loss_partials, seed, vcoords, vldc, vn, vloss_partials, pull, stream);
 }
+extern "C" int ndq_fused_pull_ok() { return ndq::pull_supported<CFG>() ? 1 : 0; }
 """
 
 
@@ -908,7 +914,8 @@ class FusedKernel:
         self.lib.ndq_fused_launch_multi.restype = ci
         self.lib.ndq_fused_launch_multi.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
         self.lib.ndq_fused_launch_tv.restype = ci
-        self.lib.ndq_fused_launch_tv.argtypes = [vp, ci, ci, vp, vp, vp, cf, vp, ci, ci, vp, vp]
+        self.lib.ndq_fused_launch_tv.argtypes = [vp, ci, ci, vp, vp, vp, cf, vp, ci, ci, vp, vp, vp]
+        self.lib.ndq_fused_pull_ok.restype = ci
         self.lib.ndq_fused_bind_theta.restype = None
         self.lib.ndq_fused_bind_theta.argtypes = [vp, vp]
         self.lib.ndq_fused_blocks.restype = ci
@@ -938,7 +945,7 @@ def _build_tag():
 
 def _header_digest():
     h = hashlib.sha1()
-    for name in ("csrc/ndq_mlp.h", "csrc/ndq_launch.h", "../include/ndq.h"):
+    for name in ("csrc/ndq_mlp.h", "csrc/ndq_tail.h", "csrc/ndq_launch.h", "../include/ndq.h"):
         with open(os.path.join(HERE, name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()

@@ -5,6 +5,7 @@
 #include "ndq_launch.h"
 #include "ndq_sample.h"
 #include "ndq_oneshot.h"
+#include "ndq_tail.h"
 
 extern "C" int ndq_oneshot_allreduce(const void* send, void* recv, size_t count, int dtype, int op, void* comm, void* stream);
 
@@ -177,6 +178,9 @@ __global__ __launch_bounds__(1024) void reduce_grad_loss_kernel(Reduce2Args a) {
 struct TailArgs {
   float* p; const float* g; float* m; float* v; int len;
   float lr, b1, b2, eps, wd, bc1, bc2s;
+  // where the parameters / moments this epoch started from live, when that is not p / m / v (fit() in pull mode keeps
+  // two sets of buffers; the tail that closes a call brings the result home): nullptr = in place
+  const float* p_in; const float* m_in; const float* v_in;
   const float* loss_slots; int nb; float* loss_hist; int hist_index; float* best_loss; int parity; float* best_flat;
   int write_scalars;
 };
@@ -191,13 +195,11 @@ __global__ __launch_bounds__(256) void epoch_tail_kernel(TailArgs a) {
     const float pi = a.p[i];
     if (better) a.best_flat[i] = pi;
     if (a.m != nullptr) {             // validation epochs pass no optimiser state: bookkeeping only
-      float gi = a.g[i];
-      if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
-      const float mi = fmaf(a.b1, a.m[i], (1.f - a.b1) * gi);
-      const float vi = fmaf(a.b2, a.v[i], (1.f - a.b2) * gi * gi);
+      float pn, mi, vi;
+      ndq::adam_value(ndq::AdamConsts{a.lr, a.b1, a.b2, a.eps, a.wd, a.bc1, a.bc2s}, pi, a.g[i], a.m[i], a.v[i], pn, mi, vi);
       a.m[i] = mi;
       a.v[i] = vi;
-      a.p[i] = pi - (a.lr / a.bc1) * (mi / (sqrtf(vi) / a.bc2s + a.eps));
+      a.p[i] = pn;
     }
   }
   if (i == 0 && a.write_scalars) {
@@ -251,10 +253,13 @@ __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
     for (; r < nparts; r += 16) s0 += part[(size_t)r * len + i];
   }
   const bool upd = (rg == 0) && col;
+  const float* p_in = a.t.p_in ? a.t.p_in : a.t.p;
+  const float* m_in = a.t.m_in ? a.t.m_in : a.t.m;
+  const float* v_in = a.t.v_in ? a.t.v_in : a.t.v;
   float pi = 0.f, m0 = 0.f, v0 = 0.f;
   if (upd) {
-    pi = a.t.p[i];
-    if (has_train) { m0 = a.t.m[i]; v0 = a.t.v[i]; }
+    pi = p_in[i];
+    if (has_train || a.t.p_in) { m0 = m_in[i]; v0 = v_in[i]; }
   }
   const float best = a.t.best_loss[a.t.parity];
   for (int off = 32; off > 0; off >>= 1) lp += __shfl_down(lp, off);
@@ -284,13 +289,13 @@ __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) g += sm[k * 64 + c];
       a.r.out[i] = g;
-      float gi = g;
-      if (a.t.wd != 0.f) gi = fmaf(a.t.wd, pi, gi);
-      const float mi = fmaf(a.t.b1, m0, (1.f - a.t.b1) * gi);
-      const float vi = fmaf(a.t.b2, v0, (1.f - a.t.b2) * gi * gi);
+      float pn, mi, vi;
+      ndq::adam_value(ndq::AdamConsts{a.t.lr, a.t.b1, a.t.b2, a.t.eps, a.t.wd, a.t.bc1, a.t.bc2s}, pi, g, m0, v0, pn, mi, vi);
       a.t.m[i] = mi;
       a.t.v[i] = vi;
-      a.t.p[i] = pi - (a.t.lr / a.t.bc1) * (mi / (sqrtf(vi) / a.t.bc2s + a.t.eps));
+      a.t.p[i] = pn;
+    } else if (a.t.p_in) {             // a validation-only tail that also brings the parameters / moments home
+      a.t.p[i] = pi; a.t.m[i] = m0; a.t.v[i] = v0;
     }
   }
   if (blockIdx.x == 0 && tid == 0 && a.t.write_scalars) {
@@ -394,13 +399,11 @@ __global__ __launch_bounds__(1024) void reduce_tail_dp_kernel(ReduceTailArgs a, 
       g += __hip_atomic_load(inbox + (size_t)q * c.max_len + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     a.r.out[i] = g;
     if (better) a.t.best_flat[i] = pi;
-    float gi = g;
-    if (a.t.wd != 0.f) gi = fmaf(a.t.wd, pi, gi);
-    const float mi = fmaf(a.t.b1, m0, (1.f - a.t.b1) * gi);
-    const float vi = fmaf(a.t.b2, v0, (1.f - a.t.b2) * gi * gi);
+    float pn, mi, vi;
+    ndq::adam_value(ndq::AdamConsts{a.t.lr, a.t.b1, a.t.b2, a.t.eps, a.t.wd, a.t.bc1, a.t.bc2s}, pi, g, m0, v0, pn, mi, vi);
     a.t.m[i] = mi;
     a.t.v[i] = vi;
-    a.t.p[i] = pi - (a.t.lr / a.t.bc1) * (mi / (sqrtf(vi) / a.t.bc2s + a.t.eps));
+    a.t.p[i] = pn;
   }
   if (blk == 0 && tid == 0 && a.t.write_scalars) {
     *a.r.lout = loss;
@@ -427,15 +430,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float b1, float b2, float eps, float wd, float bc1, float bc2s) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= len) return;
-  float gi = g[i];
-  const float pi = p[i];
-  if (wd != 0.f) gi = fmaf(wd, pi, gi);
-  const float mi = fmaf(b1, m[i], (1.f - b1) * gi);       // lerp(m, g, 1-b1)
-  const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+  float pn, mi, vi;
+  ndq::adam_value(ndq::AdamConsts{lr, b1, b2, eps, wd, bc1, bc2s}, p[i], g[i], m[i], v[i], pn, mi, vi);
   m[i] = mi;
   v[i] = vi;
-  const float denom = sqrtf(vi) / bc2s + eps;
-  p[i] = pi - (lr / bc1) * (mi / denom);
+  p[i] = pn;
 }
 
 }  // namespace ndq
@@ -511,7 +510,7 @@ int ndq_epoch_tail(float* params, const float* grad, float* exp_avg, float* exp_
   if (!params || len <= 0 || !loss_slots || n_batches <= 0 || !loss_hist || !best_loss || hist_index < 0 ||
       (parity != 0 && parity != 1) || (adam && (!grad || !exp_avg_sq || step <= 0)))
     return NDQ_EINVAL;
-  TailArgs a;
+  TailArgs a{};
   a.p = params; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.len = len;
   a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
   a.bc1 = adam ? (float)(1.0 - pow((double)beta1, (double)step)) : 1.f;
@@ -680,19 +679,100 @@ int ndq_fused_fit_run(const ndq_fused_fit* f, int n_epochs, const float* const* 
     parity ^= 1;
     return (int)hipGetLastError();
   };
+  bool pull = f->pull_ok != 0 && n_epochs >= 2 && s0.blocks <= ndq::kPullMaxRows && f->alt_loss_partials &&
+              (!valid || f->alt_valid_loss_partials);
+  for (int k = 0; k < f->n_nets && pull; ++k)
+    pull = f->alt_params[k] && f->alt_m[k] && f->alt_v[k] && f->alt_partials[k];
+  if (pull) {
+    // ---- pull mode: ONE launch per epoch.  State of epoch e (parameters, moments) lives in buffer set e & 1; launch e
+    // writes its partial rows into set e & 1 and, in its prologue, finishes epoch e - 1 from set (e - 1) & 1.
+    float* P[2][4]; float* M[2][4]; float* V[2][4]; float* PART[2][4];
+    for (int k = 0; k < f->n_nets; ++k) {
+      P[0][k] = f->net[k].params; M[0][k] = f->net[k].adam_m; V[0][k] = f->net[k].adam_v; PART[0][k] = f->net[k].partials;
+      P[1][k] = f->alt_params[k]; M[1][k] = f->alt_m[k]; V[1][k] = f->alt_v[k]; PART[1][k] = f->alt_partials[k];
+    }
+    float* LP[2] = {s0.loss_partials, f->alt_loss_partials};
+    float* VP[2] = {f->valid_loss_partials, f->alt_valid_loss_partials};
+    const int last = valid ? n_epochs : n_epochs - 1;          // index of the last closure launch
+    for (int e = 0; e <= last; ++e) {
+      ndq::PullArgs pa{};
+      if (e >= 1) {                                            // prologue: finish training epoch j = e - 1
+        const int j = e - 1, in = j & 1, out = e & 1;
+        const bool with_valid = valid && j >= 1;                // validation of epoch j - 1, evaluated by launch j
+        pa.enabled = 1; pa.n_nets = f->n_nets; pa.nparts = s0.blocks;
+        pa.lpart = LP[in]; pa.nlparts = s0.blocks; pa.lscale = s0.seed;
+        pa.loss_hist = s0.loss_hist; pa.hist_index = hist_index + j; pa.loss_slot = s0.loss_slot;
+        pa.vpart = with_valid ? VP[in] : nullptr; pa.nvparts = f->valid_blocks; pa.vscale = f->valid_scale;
+        pa.valid_hist = f->valid_hist; pa.valid_index = valid_index + j - 1; pa.best_on_valid = f->track_best == 2 ? 1 : 0;
+        pa.best_loss = s0.best_loss; pa.parity = parity;
+        const bool track = f->track_best == 1 || (f->track_best == 2 && with_valid);
+        for (int k = 0; k < f->n_nets; ++k) {
+          const ndq_fused_step& s = f->net[k];
+          ndq::PullNet& n = pa.net[k];
+          n.part = PART[in][k];
+          n.p_in = P[in][k]; n.m_in = M[in][k]; n.v_in = V[in][k];
+          n.p_out = P[out][k]; n.m_out = M[out][k]; n.v_out = V[out][k];
+          n.grad = s.grad; n.best_flat = track ? s.best_flat : nullptr; n.len = s.n_params;
+          const int step = adam_step + j;
+          n.adam = ndq::AdamConsts{s.lr, s.beta1, s.beta2, s.eps, s.weight_decay,
+                                   (float)(1.0 - pow((double)s.beta1, (double)step)),
+                                   (float)sqrt(1.0 - pow((double)s.beta2, (double)step))};
+        }
+        parity ^= 1;
+      }
+      const bool train_part = e < n_epochs, valid_part = valid && e >= 1;
+      if (train_part && !train_coords[e]) return NDQ_EINVAL;
+      const float* pp[4]; float* qq[4];
+      for (int k = 0; k < f->n_nets; ++k) { pp[k] = P[e & 1][k]; qq[k] = PART[e & 1][k]; }
+      int rc = f->launch(train_part ? train_coords[e] : nullptr, s0.ldc, train_part ? s0.n : 0, pp, train_part ? qq : nullptr,
+                         LP[e & 1], s0.seed, valid_part ? f->valid_coords : nullptr, f->valid_ldc, valid_part ? f->valid_n : 0,
+                         VP[e & 1], &pa, stream);
+      if (rc) return rc;
+    }
+    // ---- the call's last launch: an ordinary tail that leaves everything in the primary buffers
+    ReduceTailMultiArgs a{};
+    const int fin = last & 1;                                   // buffer set holding the state after the last closure launch
+    for (int k = 0; k < f->n_nets; ++k) {
+      const ndq_fused_step& s = f->net[k];
+      ReduceTailArgs& t = a.net[k];
+      t.t.p = s.params; t.t.g = s.grad; t.t.m = s.adam_m; t.t.v = s.adam_v; t.t.len = s.n_params;
+      t.t.lr = s.lr; t.t.b1 = s.beta1; t.t.b2 = s.beta2; t.t.eps = s.eps; t.t.wd = s.weight_decay;
+      t.t.loss_slots = s.loss_slot; t.t.nb = 1; t.t.loss_hist = s0.loss_hist; t.t.best_loss = s0.best_loss; t.t.parity = parity;
+      t.t.write_scalars = (k == 0) ? 1 : 0;
+      t.tail_blocks = 0x7fffffff;
+      t.t.p_in = fin ? P[fin][k] : nullptr; t.t.m_in = fin ? M[fin][k] : nullptr; t.t.v_in = fin ? V[fin][k] : nullptr;
+      if (valid) {              // validation of the last epoch (evaluated by the trailing launch); no Adam
+        t.r = Reduce2Args{PART[fin][k], 0, s.n_params, s.grad, 0, LP[fin], 0, s.loss_slot, s0.seed};
+        t.t.bc1 = 1.f; t.t.bc2s = 1.f; t.t.hist_index = hist_index + n_epochs - 1;
+        t.t.best_flat = f->track_best == 2 ? s.best_flat : nullptr;
+        t.v = ValidArgs{VP[fin], f->valid_blocks, f->valid_scale, f->valid_hist, valid_index + n_epochs - 1,
+                        f->track_best == 2 ? 1 : 0};
+      } else {                  // the last training epoch's update
+        const int step = adam_step + n_epochs - 1;
+        t.r = Reduce2Args{PART[fin][k], s0.blocks, s.n_params, s.grad, 0, LP[fin], s0.blocks, s.loss_slot, s0.seed};
+        t.t.bc1 = (float)(1.0 - pow((double)s.beta1, (double)step));
+        t.t.bc2s = (float)sqrt(1.0 - pow((double)s.beta2, (double)step));
+        t.t.hist_index = hist_index + n_epochs - 1;
+        t.t.best_flat = f->track_best == 1 ? s.best_flat : nullptr;
+      }
+    }
+    for (int k = f->n_nets; k < 4; ++k) a.net[k] = a.net[0];
+    hipLaunchKernelGGL(reduce_tail_multi_kernel, tail_grid, dim3(1024), 0, st, a);
+    return (int)hipGetLastError();
+  }
   for (int e = 0; e < n_epochs; ++e) {
     if (!train_coords[e]) return NDQ_EINVAL;
     const bool with_valid = valid && e > 0;
     int rc = f->launch(train_coords[e], s0.ldc, s0.n, params, partials, s0.loss_partials, s0.seed,
                        with_valid ? f->valid_coords : nullptr, f->valid_ldc, with_valid ? f->valid_n : 0,
-                       f->valid_loss_partials, stream);
+                       f->valid_loss_partials, nullptr, stream);
     if (rc) return rc;
     rc = tail(e, true, with_valid, valid_index + e - 1);
     if (rc) return rc;
   }
   if (valid) {
     int rc = f->launch(nullptr, 0, 0, params, nullptr, nullptr, 0.f, f->valid_coords, f->valid_ldc, f->valid_n,
-                       f->valid_loss_partials, stream);
+                       f->valid_loss_partials, nullptr, stream);
     if (rc) return rc;
     rc = tail(n_epochs, false, true, valid_index + (n_epochs > 0 ? n_epochs - 1 : 0));
     if (rc) return rc;

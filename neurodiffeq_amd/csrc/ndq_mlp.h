@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <utility>
 #include <type_traits>
+#include "ndq_tail.h"
 
 namespace ndq {
 
@@ -2273,8 +2274,15 @@ __device__ __forceinline__ void theta_block_sum(real (&t)[NT > 0 ? NT : 1], real
 // The body works on workgroup `blk` of `nblk` (the plain kernels pass blockIdx.x / gridDim.x; the train + validation
 // launch below gives each half of its grid its own numbering, so that either half computes -- bit for bit -- what a
 // launch of its own would).
+// pull (fit(), small grids; csrc/ndq_tail.h): the launch first finishes the previous epoch -- sums, Adam, history -- and
+// stages its weights from the parameters it has just computed (LDS vector behind the weight image); `writer`: this
+// workgroup writes the global state.  fp32 builds without trainable activation parameters only (Cfg::ACTP == 0).
+template <class C> constexpr bool pull_supported() { return NDQ_F64 == 0 && C::ACTP == 0; }
+template <class C> constexpr int pull_floats() { return ((C::P + 3) & ~3) + 32; }
+
 template <class C, class PW, bool TRAIN>
-__device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds, const int blk, const int nblk) {
+__device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds, const int blk, const int nblk,
+                                                   const PullArgs& pull, bool writer) {
   static_assert(C::NOUT == 1, "the single-launch closure kernel needs a single-output network");
   NDQ_TS(0);
 #ifdef NDQ_PHASE_TS
@@ -2292,7 +2300,19 @@ __device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds
 #pragma unroll
     for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn0];
   }
-  stage_weights<C, TRAIN>(lds, a.params);
+  const real* prm = a.params;
+#if !NDQ_F64
+  if constexpr (pull_supported<C>()) {
+    if (pull.enabled) {
+      float* pnew = lds + C::ldsWeightsEnd(TRAIN);
+      const bool better = pull_scalars(pull, pnew + ((C::P + 3) & ~3), writer);
+      pull_update_net(pull.net[0], pull.nparts, pnew, writer, better, threadIdx.x, blockDim.x);
+      __syncthreads();
+      prm = pnew;
+    }
+  }
+#endif
+  stage_weights<C, TRAIN>(lds, prm);
   __syncthreads();
   NDQ_TS(1);
   real* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
@@ -2387,7 +2407,8 @@ __device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds
 template <class C, class PW, bool TRAIN>
 __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
-  fused_closure_body<C, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x);
+  const PullArgs none{};
+  fused_closure_body<C, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x, none, false);
 }
 
 // Training batch AND validation batch in ONE launch (fit(): solvers.py:443-497 runs a validation epoch after every
@@ -2395,10 +2416,11 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_kernel(FusedArgs
 // workgroups of that epoch's closure launch): workgroups [0, train_blocks) run the training closure on `t`, the rest the
 // forward-only closure on `v`.  Either count may be zero.
 template <class C, class PW>
-__global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_tv_kernel(FusedArgs t, FusedArgs v, int train_blocks) {
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_tv_kernel(FusedArgs t, FusedArgs v, int train_blocks, PullArgs pull) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
-  if ((int)blockIdx.x < train_blocks) fused_closure_body<C, PW, true>(t, lds, blockIdx.x, train_blocks);
-  else fused_closure_body<C, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks);
+  const bool writer = blockIdx.x == 0;
+  if ((int)blockIdx.x < train_blocks) fused_closure_body<C, PW, true>(t, lds, blockIdx.x, train_blocks, pull, writer);
+  else fused_closure_body<C, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks, pull, writer);
 }
 
 // ------------------------------------------------------------------------------------------------ multi-network closure
@@ -2444,7 +2466,8 @@ template <class C, int K> constexpr int multi_group_floats() {
 template <class C, int K> constexpr int multi_xchg_floats() { return 2 * multi_group<K>() * K * C::NS * 16; }
 
 template <class C, int K, class PW, bool TRAIN>
-__device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a, real* lds, const int blk, const int nblk) {
+__device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a, real* lds, const int blk, const int nblk,
+                                                         const PullArgs& pull, bool writer) {
   static_assert(C::NOUT == 1 && !C::WIDE && K >= 2 && K <= kMaxFusedNets, "multi-network closure: n_out = 1, H <= 48, 2..4 nets");
   static_assert(C::BWD_THREADS == 256, "multi-network closure: one wave per SIMD (build without NDQ_BWD_THREADS)");
   constexpr int WS = C::ldsWeightsEnd(TRAIN);          // LDS floats per weight image
@@ -2463,7 +2486,23 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
   }
   // every network's G waves stage that network's image: the K images are built at the same time (a staging pass is
   // bound by the latency of its parameter loads -- 2.97 us for two images one after the other at C1, measured)
-  stage_weights<C, TRAIN>(lds + k * WS, a.params[k], g * 64 + lane, G * 64);
+  const real* prm = a.params[k];
+#if !NDQ_F64
+  if constexpr (pull_supported<C>()) {
+    if (pull.enabled) {
+      // finish the previous epoch for all K networks (every thread of the workgroup on every network), results in LDS
+      float* pn0 = lds + K * WS;
+      const bool better = pull_scalars(pull, pn0 + K * pull_floats<C>() - 32, writer);
+      sfor<K>([&](auto kk_) {           // (static indices: the argument struct must stay in the kernarg segment)
+        constexpr int kk = decltype(kk_)::value;
+        pull_update_net(pull.net[kk], pull.nparts, pn0 + kk * pull_floats<C>(), writer, better, threadIdx.x, blockDim.x);
+      });
+      __syncthreads();
+      prm = pn0 + k * pull_floats<C>();
+    }
+  }
+#endif
+  stage_weights<C, TRAIN>(lds + k * WS, prm, g * 64 + lane, G * 64);
   __syncthreads();
   NDQ_TS(1);
   const real* ldsw = lds + k * WS;
@@ -2572,15 +2611,18 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
 template <class C, int K, class PW, bool TRAIN>
 __global__ __launch_bounds__(multi_threads<K>()) void fused_multi_closure_kernel(FusedMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
-  fused_multi_closure_body<C, K, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x);
+  const PullArgs none{};
+  fused_multi_closure_body<C, K, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x, none, false);
 }
 
 // training + validation batch in one launch, as fused_closure_tv_kernel
 template <class C, int K, class PW>
-__global__ __launch_bounds__(multi_threads<K>()) void fused_multi_closure_tv_kernel(FusedMultiArgs t, FusedMultiArgs v, int train_blocks) {
+__global__ __launch_bounds__(multi_threads<K>()) void fused_multi_closure_tv_kernel(FusedMultiArgs t, FusedMultiArgs v, int train_blocks,
+                                                                                    PullArgs pull) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
-  if ((int)blockIdx.x < train_blocks) fused_multi_closure_body<C, K, PW, true>(t, lds, blockIdx.x, train_blocks);
-  else fused_multi_closure_body<C, K, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks);
+  const bool writer = blockIdx.x == 0;
+  if ((int)blockIdx.x < train_blocks) fused_multi_closure_body<C, K, PW, true>(t, lds, blockIdx.x, train_blocks, pull, writer);
+  else fused_multi_closure_body<C, K, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks, pull, writer);
 }
 
 // ------------------------------------------------------------------------------------------------ grouped closure
@@ -2623,9 +2665,22 @@ template <class C> constexpr int group_xs() {
 #define NDQ_UNROLL(n) NDQ_PRAGMA(unroll n)
 
 template <class C, class PW, bool TRAIN>
-__device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, real* lds, const int blk, const int nblk) {
+__device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, real* lds, const int blk, const int nblk,
+                                                         const PullArgs& pull, bool writer) {
   static_assert(!C::ACC_LDS, "grouped closure: H <= 48");
-  stage_weights<C, TRAIN>(lds, a.params);
+  const real* prm = a.params;
+#if !NDQ_F64
+  if constexpr (pull_supported<C>()) {
+    if (pull.enabled) {
+      float* pnew = lds + C::ldsWeightsEnd(TRAIN);
+      const bool better = pull_scalars(pull, pnew + ((C::P + 3) & ~3), writer);
+      pull_update_net(pull.net[0], pull.nparts, pnew, writer, better, threadIdx.x, blockDim.x);
+      __syncthreads();
+      prm = pnew;
+    }
+  }
+#endif
+  stage_weights<C, TRAIN>(lds, prm);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   constexpr int WAVES = C::BWD_THREADS / 64;
@@ -2773,33 +2828,41 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
 template <class C, class PW, bool TRAIN>
 __global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
-  fused_group_closure_body<C, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x);
+  const PullArgs none{};
+  fused_group_closure_body<C, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x, none, false);
 }
 
 // training + validation batch in one launch, as fused_closure_tv_kernel
 template <class C, class PW>
-__global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_tv_kernel(FusedArgs t, FusedArgs v, int train_blocks) {
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_group_closure_tv_kernel(FusedArgs t, FusedArgs v, int train_blocks, PullArgs pull) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
-  if ((int)blockIdx.x < train_blocks) fused_group_closure_body<C, PW, true>(t, lds, blockIdx.x, train_blocks);
-  else fused_group_closure_body<C, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks);
+  const bool writer = blockIdx.x == 0;
+  if ((int)blockIdx.x < train_blocks) fused_group_closure_body<C, PW, true>(t, lds, blockIdx.x, train_blocks, pull, writer);
+  else fused_group_closure_body<C, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks, pull, writer);
 }
 
 // ------------------------------------------------------------------------------------------------ host-side sizes
 template <class C> constexpr size_t group_lds_bytes(bool train) {
   const int waves = C::BWD_THREADS / 64;
   const int pp = (C::P + 3) & ~3;
-  const int work = waves * (C::stageFloatsPerWave + 16 * group_tiles<C>() * group_xs<C>());
+  int work = waves * (C::stageFloatsPerWave + 16 * group_tiles<C>() * group_xs<C>());
   const int red = train ? bwd_regions<C>(waves) * pp : 0;          // overlays the staging + exchange tiles at the end
-  return sizeof(real) * (C::ldsWeightsEnd(train) + (work > red ? work : red) + 16);
+  if (red > work) work = red;
+  if (pull_floats<C>() > work) work = pull_floats<C>();            // pull prologue: the updated parameter vector
+  return sizeof(real) * (C::ldsWeightsEnd(train) + work + 16);
 }
 template <class C> constexpr size_t fwd_lds_bytes() { return sizeof(real) * C::ldsWeightsEnd(false); }
 template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock);
 template <class C> constexpr size_t fused_lds_bytes(bool train) {
-  return train ? bwd_lds_bytes<C>(C::BWD_THREADS / 64) : sizeof(real) * (C::ldsWeightsEnd(false) + 16);
+  const size_t pulled = sizeof(real) * (C::ldsWeightsEnd(train) + pull_floats<C>() + 16);   // pull prologue's vector
+  const size_t plain = train ? bwd_lds_bytes<C>(C::BWD_THREADS / 64) : sizeof(real) * (C::ldsWeightsEnd(false) + 16);
+  return plain > pulled ? plain : pulled;
 }
 template <class C, int K> constexpr size_t fused_multi_lds_bytes(bool train) {
-  return sizeof(real) * ((size_t)K * C::ldsWeightsEnd(train) + (train ? K * multi_group_floats<C, K>() : 0) +
-                         multi_xchg_floats<C, K>() + 16);
+  const size_t work = train ? (size_t)K * multi_group_floats<C, K>() : 0;
+  const size_t plain = (size_t)K * C::ldsWeightsEnd(train) + work + multi_xchg_floats<C, K>() + 16;
+  const size_t pulled = (size_t)K * C::ldsWeightsEnd(train) + (size_t)K * pull_floats<C>() + 16;   // pull prologue's K vectors
+  return sizeof(real) * (plain > pulled ? plain : pulled);
 }
 template <class C> constexpr size_t bwd_lds_bytes(int wavesPerBlock) {
   const int pp = (C::P + 3) & ~3;

@@ -739,7 +739,7 @@ class FusedSystem:
             rc = fk.lib.ndq_fused_launch_tv(self._coord_ptr(b, 0) if with_train else None, b["ld"], n if with_train else 0,
                                             params_pp, parts_pp if with_train else None, _ptr(lp) if with_train else None,
                                             seed, self._coord_ptr(b, 0) if with_valid else None, b["ld"],
-                                            n if with_valid else 0, _ptr(vp) if with_valid else None, stream)
+                                            n if with_valid else 0, _ptr(vp) if with_valid else None, None, stream)
             _lib.check(rc, "ndq_fused_launch_tv")
             if with_train:
                 ok = ok and torch.equal(lp, want_loss) and all(torch.equal(a, w) for a, w in zip(parts, want_parts))
@@ -945,6 +945,7 @@ class FusedSystem:
 
     # ------------------------------------------------------------------------------------------ several epochs per call
     FIT_RUN = os.environ.get("NDQ_FIT_RUN", "1") != "0"
+    FIT_PULL = os.environ.get("NDQ_FIT_PULL", "1") != "0"      # one launch per epoch for small grids (pull prologue)
 
     def fit_ready(self):
         """May epochs of this system go through ndq_fused_fit_run (closure launch with training + validation workgroups,
@@ -1040,6 +1041,24 @@ class FusedSystem:
                 ff.valid_n, ff.valid_ldc, ff.valid_blocks = valid[1], valid[2], vparts.numel()
                 ff.valid_scale = 1.0 / (float(valid[1]) * self.loss_norm)
                 ff.valid_loss_partials, ff.valid_hist = vparts.data_ptr(), fs["valid_hist"].data_ptr()
+            # pull mode (small grids: the closure launch of an epoch finishes the previous one itself, one launch per epoch;
+            # include/ndq.h): a second set of state / partial buffers
+            ff.pull_ok = 0
+            if K and self.FIT_PULL and 0 < blocks <= 32 and fk.lib.ndq_fused_pull_ok():
+                ff.pull_ok = 1
+                for k, fp in enumerate(self.flat):
+                    alt = [torch.zeros(fp.numel, dtype=f32, device=dev) for _ in range(3)]
+                    apart = torch.empty(blocks, fp.numel, dtype=f32, device=dev)
+                    keep.extend(alt + [apart])
+                    ff.alt_params[k], ff.alt_m[k], ff.alt_v[k] = (t.data_ptr() for t in alt)
+                    ff.alt_partials[k] = apart.data_ptr()
+                alp = torch.zeros(max(blocks, 1), dtype=f32, device=dev)
+                keep.append(alp)
+                ff.alt_loss_partials = alp.data_ptr()
+                if valid is not None:
+                    avp = torch.zeros(ff.valid_blocks, dtype=f32, device=dev)
+                    keep.append(avp)
+                    ff.alt_valid_loss_partials = avp.data_ptr()
             ent = cache[key] = (ff, keep, fk)
         ff = ent[0]
         step0 = 1

@@ -2,8 +2,9 @@
 
 ``l2`` (= the solver default, solvers.py:218), ``l1`` and ``infinity`` are per-point terms averaged over the batch: the
 fused gfx950 path evaluates them (and their adjoint seeds) inside the generated pointwise code.  The Sobolev norms are
-the l2 loss of the residual list extended by d(sum_e r_e)/dx_a; the solver traces them that way when that extra
-derivative stays within second-order network streams (first-order systems), else they run on the composite path."""
+the l2 loss of the residual list extended by d(sum_e r_e)/dx_a; the solver traces them that way: first-order systems
+stay within second-order network streams, second-order PDEs use the third-order streams (``ndq_mlp_desc.mask3``: tanh /
+sin / sigmoid networks) -- only what would need fourth-order streams runs on the composite path."""
 import torch
 
 from .operators import grad

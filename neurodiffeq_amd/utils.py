@@ -1,9 +1,12 @@
 """Global dtype / device helpers with the reference's names (neurodiffeq/utils.py:10-68).
 
 Difference from the reference, on purpose: importing :mod:`neurodiffeq_amd` does NOT flip the process-wide default
-dtype to fp64 / device to cuda (reference ``__init__.py:22``).  The fused gfx950 path is fp32; call
-``set_tensor_type(float_bits=64)`` explicitly to get the reference's fp64 default, which runs on the composite
-(torch autograd) path."""
+dtype to fp64 / device to cuda (reference ``__init__.py:22``) -- a script that only changes its import line therefore
+trains in fp32 unless it calls ``set_tensor_type(float_bits=64)`` itself (INTEGRATION.md leads with this).  fp32
+systems run on the single-launch closure kernels and the native epochs; fp64 networks -- the reference's default
+precision -- run the fused three-kernel pipeline in double (fp64 stream kernels of libndq64.so, the traced pointwise
+kernel compiled in double, Adam in double), or, for shapes whose weights do not fit LDS in double, the
+reference's closure on torch autograd with the network forward / backward on the fp64 stream kernels."""
 import random
 import re
 

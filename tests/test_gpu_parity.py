@@ -739,10 +739,24 @@ def test_loss_outside_the_traced_family_falls_back_loudly():
     with pytest.warns(RuntimeWarning, match="NOT on the fused MI355X path"):
         solver.run_train_epoch()
     assert not solver.fused_active and len(solver.metrics_history["train_loss"]) == 1
+    # a per-point data column is an input row of the kernels since round 3: fused, and the same loss as the composite path
+    losses = {}
+    for mode in ("require", "off"):
+        torch.manual_seed(0)
+        data = torch.linspace(0, 1, 64, device="cuda").reshape(-1, 1)
+        solver, cfg = configs.make_solver("c2", 8)
+        solver.fused = mode
+        solver.diff_eqs = lambda u, x, y: [configs.diff(u, x, order=2) + configs.diff(u, y, order=2) - data]
+        torch.manual_seed(1)
+        solver.run_train_epoch()
+        assert solver.fused_active == (mode == "require")
+        losses[mode] = solver.metrics_history["train_loss"][0]
+    assert abs(losses["require"] - losses["off"]) <= 2e-5 * abs(losses["off"])
+    # ... a matrix of data is not
     torch.manual_seed(0)
-    data = torch.linspace(0, 1, 64, device="cuda").reshape(-1, 1)
+    table = torch.ones(64, 2, device="cuda")
     solver, cfg = configs.make_solver("c2", 8)
-    solver.diff_eqs = lambda u, x, y: [configs.diff(u, x, order=2) + configs.diff(u, y, order=2) - data]   # per-point data column
+    solver.diff_eqs = lambda u, x, y: [configs.diff(u, x, order=2) + (configs.diff(u, y, order=2) * table).sum(dim=1, keepdim=True)]
     with pytest.warns(RuntimeWarning, match="NOT on the fused MI355X path"):
         solver.run_train_epoch()
     assert not solver.fused_active

@@ -428,15 +428,31 @@ def test_assembly_fixup_scalarizes_packed_ops_that_cross_halves():
     ])
     out, done, skipped = _hipcc.scalarize_pk(asm, "opsel")
     lines = [l.strip() for l in out.split("\n")]
-    assert done == 4 and skipped == 1
+    assert done == 5 and skipped == 0
     assert lines[0:2] == ["v_mul_f32_e64 v2, v10, v59", "v_mul_f32_e64 v3, v11, v59"]
     assert lines[2:4] == ["v_fma_f32 v18, v19, v140, v20", "v_fma_f32 v19, v19, v141, v21"]
     assert lines[4:6] == ["v_fma_f32 v4, -v8, v47, v4", "v_fma_f32 v5, -v9, v47, v5"]
     assert lines[6].startswith("v_pk_mul_f32 v[60:61]") and lines[7].startswith("v_pk_add_f32")
     assert lines[8:10] == ["v_mul_f32_e64 v70, v33, s58", "v_mul_f32_e64 v71, v32, s58"]
-    assert lines[10].startswith("v_pk_mul_f32 v[2:3], v[2:3], v[2:3]")      # halves would clobber each other: untouched
+    # halves that would clobber each other's sources: the pair product x.lo * x.hi in both halves -> once, then a copy
+    assert lines[10:12] == ["v_mul_f32_e64 v2, v3, v2", "v_mov_b32_e32 v3, v2"]
+    # ... the general case: exchange the destination registers first
+    crossed, n_c, n_s = _hipcc.scalarize_pk("\tv_pk_mul_f32 v[2:3], v[2:3], v[4:5] op_sel:[1,0] op_sel_hi:[0,1]", "opsel")
+    assert (n_c, n_s) == (1, 0) and [l.strip() for l in crossed.split("\n")] == \
+        ["v_swap_b32 v2, v3", "v_mul_f32_e64 v2, v2, v4", "v_mul_f32_e64 v3, v3, v5"]
     every, n_all, _ = _hipcc.scalarize_pk(asm, "all")
-    assert n_all == 6 and every.count("v_pk_") == 1
+    assert n_all == 7 and every.count("v_pk_") == 0
+    # what is left over fails the build (the pass fails closed) -- with ONE exception: a genuine two-in / two-out update
+    # (each half reads both destination registers: no two-instruction rewrite exists) may stay in a module that does not
+    # spill; the only unexplained failure of op_sel forms was in spilling kernels, the direct hazard is covered by the nop
+    two = "\tv_pk_fma_f32 v[2:3], v[2:3], v[2:3], v[6:7] op_sel:[1,0,0] op_sel_hi:[0,1,1]\n"
+    _hipcc.verify_fixup(two + "; ScratchSize: 0\n")
+    with pytest.raises(RuntimeError, match="op_sel left in the output"):
+        _hipcc.verify_fixup(two + "; ScratchSize: 0\n; ScratchSize: 224\n")
+    with pytest.raises(RuntimeError, match="op_sel left in the output"):
+        _hipcc.verify_fixup("\tv_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[0,1]\n; ScratchSize: 0\n")
+    with pytest.raises(RuntimeError, match="directly followed by an MFMA"):
+        _hipcc.verify_fixup("\tv_pk_add_f32 v[2:3], v[4:5], v[6:7]\n\tv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]")
     # operands the rewrite does not understand (output modifiers, special registers) are never touched
     odd = "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0] clamp\n\tv_pk_add_f32 v[0:1], v[2:3], vcc op_sel:[0,1]"
     same, n_odd, n_skip = _hipcc.scalarize_pk(odd, "opsel")
@@ -478,6 +494,14 @@ def test_scalarized_packed_ops_compute_what_the_packed_ones_do():
         regs[dst], regs[dst + 1] = lo, hi
 
     def run_scalar(regs, line):
+        mv = re.match(r"\s*v_(mov_b32_e32|swap_b32)\s+v(\d+),\s*v(\d+)$", line)
+        if mv:
+            a_, b_ = int(mv.group(2)), int(mv.group(3))
+            if mv.group(1) == "swap_b32":
+                regs[a_], regs[b_] = regs[b_], regs[a_]
+            else:
+                regs[a_] = regs[b_]
+            return
         m = re.match(r"\s*v_(mul|add|fma)_f32(?:_e64)?\s+v(\d+),\s*(.*)$", line)
         op, d, rest = m.group(1), int(m.group(2)), [t.strip() for t in m.group(3).split(",")]
         vals = []
