@@ -209,7 +209,7 @@ typedef int (*ndq_fused_launch_tv_fn)(const float* coords, int ldc, int n, const
                                       float* const* partials, float* loss_partials, float seed,
                                       const float* valid_coords, int valid_ldc, int valid_n,
                                       float* valid_loss_partials, const void* pull, void* stream);
-/* `pull` (NULL: none): an ndq::PullArgs of csrc/ndq_tail.h.  PULL MODE, for grids of up to 32 training workgroups: the
+/* `pull` (NULL: none): an ndq::PullArgs of csrc/ndq_tail.h.  PULL MODE, used while training workgroups x networks <= 16: the
  * closure launch of epoch e first FINISHES epoch e - 1 itself -- every workgroup adds up the partial rows of the previous
  * launch (same summation order as the tail kernel), applies Adam to all parameters in registers and stages its weight
  * image from the result; workgroup 0 writes the new parameters / moments / history.  One launch per epoch instead of

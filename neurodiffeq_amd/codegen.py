@@ -568,6 +568,9 @@ extern "C" unsigned long ndq_fused_lds_bytes() {{ return (unsigned long){lds('tr
 extern "C" int ndq_fused_phase_ts(unsigned long long* out) {{    // experiments: scripts/phase_ts.py
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ndq::ndq_phase_ts), sizeof(unsigned long long) * 256 * 8);
 }}
+extern "C" int ndq_fused_pull_ts(unsigned long long* out) {{    // experiments: scripts/pull_ts.py
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ndq::ndq_pull_ts), sizeof(unsigned long long) * 8);
+}}
 extern "C" int ndq_fused_tile_ts(unsigned long long* out) {{
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ndq::ndq_tile_ts), sizeof(unsigned long long) * 48);
 }}

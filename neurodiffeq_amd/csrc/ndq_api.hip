@@ -679,7 +679,7 @@ int ndq_fused_fit_run(const ndq_fused_fit* f, int n_epochs, const float* const* 
     parity ^= 1;
     return (int)hipGetLastError();
   };
-  bool pull = f->pull_ok != 0 && n_epochs >= 2 && s0.blocks <= ndq::kPullMaxRows && f->alt_loss_partials &&
+  bool pull = f->pull_ok != 0 && n_epochs >= 2 && s0.blocks * f->n_nets <= ndq::kPullMaxWork && f->alt_loss_partials &&
               (!valid || f->alt_valid_loss_partials);
   for (int k = 0; k < f->n_nets && pull; ++k)
     pull = f->alt_params[k] && f->alt_m[k] && f->alt_v[k] && f->alt_partials[k];

@@ -89,9 +89,16 @@ __device__ int ndq_tile_iter;      // 0 while wave 0 of workgroup 0 is in its fi
     if (threadIdx.x == 0 && blockIdx.x == 0)                                                        \
       ndq_tile_ts[24 * ndq_tile_iter + (k)] = __builtin_readcyclecounter();                         \
   } while (0)
+// NDQ_PT(k): wall clock of thread 0 of workgroup 0 at point k (< 8) of the pull prologue (scripts/pull_ts.py)
+__device__ unsigned long long ndq_pull_ts[8];
+#define NDQ_PT(k)                                                                                   \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x == 0) ndq_pull_ts[(k)] = wall_clock64();                     \
+  } while (0)
 #else
 #define NDQ_TS(k)
 #define NDQ_TT(k)
+#define NDQ_PT(k)
 #endif
 
 // ------------------------------------------------------------------------------------------------ static for
@@ -2305,8 +2312,15 @@ __device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds
   if constexpr (pull_supported<C>()) {
     if (pull.enabled) {
       float* pnew = lds + C::ldsWeightsEnd(TRAIN);
-      const bool better = pull_scalars(pull, pnew + ((C::P + 3) & ~3), writer);
-      pull_update_net(pull.net[0], pull.nparts, pnew, writer, better, threadIdx.x, blockDim.x);
+      NDQ_PT(0);
+#ifdef NDQ_PHASE_TS
+      if (threadIdx.x == 0 && blockIdx.x == 0) {      // when the previous launch's workgroups 0 / 1 ended
+        ndq_pull_ts[4] = ndq_phase_ts[4 + 3];
+        ndq_pull_ts[5] = ndq_phase_ts[8 + 4 + 3];
+      }
+#endif
+      pull_prologue<C::BWD_THREADS, C::P, 1>(pull, pnew, 0, pnew + ((C::P + 3) & ~3), writer);
+      NDQ_PT(2);
       __syncthreads();
       prm = pnew;
     }
@@ -2314,6 +2328,7 @@ __device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds
 #endif
   stage_weights<C, TRAIN>(lds, prm);
   __syncthreads();
+  NDQ_PT(3);
   NDQ_TS(1);
   real* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
   GradAcc<C> acc;
@@ -2451,7 +2466,10 @@ struct FusedMultiArgs {
 // still in its registers: no second forward pass, and the serial chain of a round is one network deep instead of K.
 // Waves per workgroup: K x G with G = 2 tile slots for K = 2, one for K = 3, 4 -- never more than one wave per SIMD,
 // so every wave has the whole register file (Cfg must be the 256-thread build: KEEP_H, no laundering).
-template <int K> constexpr int multi_group() { return K == 2 ? 2 : 1; }
+#ifndef NDQ_MULTI_G2
+#define NDQ_MULTI_G2 2      // tile slots per workgroup for K = 2 (experiments: 4 = two waves per SIMD)
+#endif
+template <int K> constexpr int multi_group() { return K == 2 ? NDQ_MULTI_G2 : 1; }
 template <int K> constexpr int multi_threads() { return 64 * K * multi_group<K>(); }
 // reduction regions of one network's G waves (they overlay those waves' transpose staging tiles)
 template <class C, int K> constexpr int multi_regions() {
@@ -2492,11 +2510,7 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
     if (pull.enabled) {
       // finish the previous epoch for all K networks (every thread of the workgroup on every network), results in LDS
       float* pn0 = lds + K * WS;
-      const bool better = pull_scalars(pull, pn0 + K * pull_floats<C>() - 32, writer);
-      sfor<K>([&](auto kk_) {           // (static indices: the argument struct must stay in the kernarg segment)
-        constexpr int kk = decltype(kk_)::value;
-        pull_update_net(pull.net[kk], pull.nparts, pn0 + kk * pull_floats<C>(), writer, better, threadIdx.x, blockDim.x);
-      });
+      pull_prologue<multi_threads<K>(), C::P, K>(pull, pn0, pull_floats<C>(), pn0 + K * pull_floats<C>() - 32, writer);
       __syncthreads();
       prm = pn0 + k * pull_floats<C>();
     }
@@ -2673,8 +2687,7 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
   if constexpr (pull_supported<C>()) {
     if (pull.enabled) {
       float* pnew = lds + C::ldsWeightsEnd(TRAIN);
-      const bool better = pull_scalars(pull, pnew + ((C::P + 3) & ~3), writer);
-      pull_update_net(pull.net[0], pull.nparts, pnew, writer, better, threadIdx.x, blockDim.x);
+      pull_prologue<C::BWD_THREADS, C::P, 1>(pull, pnew, 0, pnew + ((C::P + 3) & ~3), writer);
       __syncthreads();
       prm = pnew;
     }

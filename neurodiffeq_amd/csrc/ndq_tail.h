@@ -13,7 +13,11 @@
 
 namespace ndq {
 
-constexpr int kPullMaxRows = 32;        // partial rows (closure workgroups) up to which the pull prologue is used
+constexpr int kPullMaxRows = 32;        // partial rows (closure workgroups) the pull prologue can take
+// ... and rows x networks up to which it is USED (ndq_fused_fit_run): every workgroup reads every row of every network.
+// MI355X, us per fit() epoch, one launch against two: 1 row 12.1 / 14.4 (K = 1), 14.6 / 16.5 (K = 2); 16 rows 15.5 / 16.9
+// (K = 1), 19.9 / 19.3 (K = 2, four tile slots per workgroup); 32 rows, K = 2 (C1): 23.8 / 18.8.
+constexpr int kPullMaxWork = 16;
 constexpr int kPullMaxNets = 4;
 
 // Adam, torch.optim.Adam single-tensor formula (amsgrad = False, maximize = False); bc1 = 1 - b1^t, bc2s = sqrt(1 - b2^t)
@@ -189,5 +193,154 @@ __device__ __forceinline__ bool pull_scalars(const PullArgs& a, float* scratch, 
   }
   return better;
 }
+
+// ---- batched prologue ------------------------------------------------------------------------------------------------
+// Everything the prologue reads was written by the previous launch, so every first touch is a far miss (measured on
+// MI355X: ~2 us each when one depends on the other -- a prologue of five dependent rounds cost 10 - 12 us, twice the tail
+// launch it replaces).  Here ALL loads of the prologue -- loss partials, best loss, and for every column a thread owns the
+// partial rows, parameter and moments -- are issued before the first use, the
+// arithmetic (and therefore every bit of the result) is the same as above.  NT: threads per workgroup, LEN: parameters
+// per network (both static: the loads live in registers).  Two builds: up to 2 and up to 16 partial rows.
+
+template <int NT> struct PullScalarLoads {
+  static constexpr int VW = (1024 + NT - 1) / NT;          // "virtual" waves of the tail kernel each wave plays
+  float x[VW], y[VW], best;
+};
+template <int NT>
+__device__ __forceinline__ void pull_scalars_issue(const PullArgs& a, PullScalarLoads<NT>& s) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool has_valid = a.vpart != nullptr;
+  const float* vp = has_valid ? a.vpart : a.lpart;
+  const int nv = has_valid ? a.nvparts : a.nlparts;
+#pragma unroll
+  for (int j = 0; j < PullScalarLoads<NT>::VW; ++j) {
+    const int r = 64 * (wave + j * (NT / 64)) + lane;
+    s.x[j] = a.lpart[r < a.nlparts ? r : a.nlparts - 1];
+    s.y[j] = vp[r < nv ? r : nv - 1];
+  }
+  s.best = a.best_loss[a.parity];
+}
+// n{l,v}parts <= 1024 (one term per virtual thread of tail_loss_total).  scratch: 32 floats of LDS.
+template <int NT>
+__device__ __forceinline__ bool pull_scalars_finish(const PullArgs& a, const PullScalarLoads<NT>& s, float* scratch, bool writer) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool has_valid = a.vpart != nullptr;
+#pragma unroll
+  for (int j = 0; j < PullScalarLoads<NT>::VW; ++j) {
+    const int w = wave + j * (NT / 64), r = 64 * w + lane;
+    float x = 0.f, y = 0.f;
+    if (r < a.nlparts) x += s.x[j];
+    if (has_valid && r < a.nvparts) y += s.y[j];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    for (int off = 32; off > 0; off >>= 1) y += __shfl_down(y, off);
+    if (lane == 0 && w < 16) { scratch[w] = x; scratch[16 + w] = y; }
+  }
+  __syncthreads();
+  float sl = 0.f, sv = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) sl += scratch[w];
+#pragma unroll
+  for (int w = 0; w < 16; ++w) sv += scratch[16 + w];
+  const float loss = sl * a.lscale, vloss = sv * a.vscale;
+  const bool on_valid = has_valid && a.best_on_valid != 0;
+  const float cmp = on_valid ? vloss : loss;
+  bool track = false;
+#pragma unroll
+  for (int k = 0; k < kPullMaxNets; ++k) track = track || (k < a.n_nets && a.net[k].best_flat != nullptr);   // static indices
+  const bool better = track && (cmp < s.best);
+  if (writer && threadIdx.x == 0) {
+    *a.loss_slot = loss;
+    a.loss_hist[a.hist_index] = loss;
+    if (has_valid) a.valid_hist[a.valid_index] = vloss;
+    a.best_loss[a.parity ^ 1] = better ? cmp : s.best;
+  }
+  return better;
+}
+
+template <int NT, int LEN, int R> struct PullNetLoads {
+  static constexpr int CPT = (LEN + NT - 1) / NT;          // columns per thread
+  float a[CPT][R], p[CPT], m[CPT], v[CPT];
+};
+template <int NT, int LEN, int R>
+__device__ __forceinline__ void pull_net_issue(const PullNet& n, int nparts, PullNetLoads<NT, LEN, R>& l) {
+#pragma unroll
+  for (int c = 0; c < PullNetLoads<NT, LEN, R>::CPT; ++c) {
+    const int i = (int)threadIdx.x + c * NT < LEN ? (int)threadIdx.x + c * NT : LEN - 1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) l.a[c][r] = n.part[(size_t)(r < nparts ? r : nparts - 1) * LEN + i];
+    l.p[c] = n.p_in[i];
+    l.m[c] = n.m_in[i];
+    l.v[c] = n.v_in[i];
+  }
+}
+template <int NT, int LEN, int R>
+__device__ __forceinline__ void pull_net_finish(const PullNet& n, int nparts, const PullNetLoads<NT, LEN, R>& l, float* pnew,
+                                                bool writer, bool better) {
+#pragma unroll
+  for (int c = 0; c < PullNetLoads<NT, LEN, R>::CPT; ++c) {
+    const int i = (int)threadIdx.x + c * NT;
+    if (i >= LEN) continue;
+    // tail_column_total for nparts <= R <= 32: row group rg holds the chain (0 + a[rg]) + a[rg + 16], the other three
+    // chains of the group are empty, the 16 groups are added in order
+    float g = 0.f;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      float s0 = 0.f;
+      const float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      if (rg < R && rg < nparts) s0 += l.a[c][rg < R ? rg : 0];
+      if (rg + 16 < R && rg + 16 < nparts) s0 += l.a[c][rg + 16 < R ? rg + 16 : 0];
+      g += (s0 + s1) + (s2 + s3);
+    }
+    float p, m, v;
+    adam_value(n.adam, l.p[c], g, l.m[c], l.v[c], p, m, v);
+    pnew[i] = p;
+    if (writer) {
+      n.p_out[i] = p; n.m_out[i] = m; n.v_out[i] = v;
+      if (n.grad) n.grad[i] = g;
+      if (better && n.best_flat) n.best_flat[i] = l.p[c];
+    }
+  }
+}
+
+template <int NT, int LEN, int K, int R>
+__device__ __forceinline__ void pull_prologue_batched(const PullArgs& a, float* pnew, int stride, float* scratch, bool writer) {
+  PullScalarLoads<NT> s;
+  PullNetLoads<NT, LEN, R> l[K];
+  pull_scalars_issue<NT>(a, s);
+  pull_net_issue<NT, LEN, R>(a.net[0], a.nparts, l[0]);
+  // two networks' loads in flight at a time where the registers allow it
+  constexpr bool AHEAD = 2 * PullNetLoads<NT, LEN, R>::CPT * (R + 3) <= 224;
+  if constexpr (K > 1 && AHEAD) pull_net_issue<NT, LEN, R>(a.net[1], a.nparts, l[1]);
+  const bool better = pull_scalars_finish<NT>(a, s, scratch, writer);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if constexpr (AHEAD) {
+      if (k + 2 < K) pull_net_issue<NT, LEN, R>(a.net[k + 2], a.nparts, l[k + 2]);
+    }
+    pull_net_finish<NT, LEN, R>(a.net[k], a.nparts, l[k], pnew + k * stride, writer, better);
+    if constexpr (!AHEAD) {
+      if (k + 1 < K) pull_net_issue<NT, LEN, R>(a.net[k + 1], a.nparts, l[k + 1]);
+    }
+  }
+}
+
+// The whole prologue for K networks of LEN parameters each: updated parameters of network k at pnew + k * stride (LDS),
+// scratch: 32 floats of LDS.  The caller synchronises the workgroup afterwards.
+template <int NT, int LEN, int K>
+__device__ __forceinline__ void pull_prologue(const PullArgs& a, float* pnew, int stride, float* scratch, bool writer) {
+  bool same = a.nlparts <= 1024 && a.nvparts <= 1024;
+#pragma unroll
+  for (int k = 0; k < K; ++k) same = same && a.net[k].len == LEN;
+  if (same && a.nparts <= 2) {
+    pull_prologue_batched<NT, LEN, K, 2>(a, pnew, stride, scratch, writer);
+  } else if (same && a.nparts <= 16) {
+    pull_prologue_batched<NT, LEN, K, 16>(a, pnew, stride, scratch, writer);
+  } else {                     // 17 .. 32 rows: chunks of columns (the hosts of this package never ask for it, see kPullMaxWork)
+    const bool better = pull_scalars(a, scratch, writer);
+#pragma unroll
+    for (int k = 0; k < K; ++k) pull_update_net(a.net[k], a.nparts, pnew + k * stride, writer, better, threadIdx.x, blockDim.x);
+  }
+}
+
 
 }  // namespace ndq

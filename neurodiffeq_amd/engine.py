@@ -1044,7 +1044,7 @@ class FusedSystem:
             # pull mode (small grids: the closure launch of an epoch finishes the previous one itself, one launch per epoch;
             # include/ndq.h): a second set of state / partial buffers
             ff.pull_ok = 0
-            if K and self.FIT_PULL and 0 < blocks <= 32 and fk.lib.ndq_fused_pull_ok():
+            if K and self.FIT_PULL and 0 < blocks * len(self.flat) <= 16 and fk.lib.ndq_fused_pull_ok():   # ndq_tail.h: kPullMaxWork
                 ff.pull_ok = 1
                 for k, fp in enumerate(self.flat):
                     alt = [torch.zeros(fp.numel, dtype=f32, device=dev) for _ in range(3)]

@@ -28,6 +28,14 @@ def _problem(name, **kw):
     if name == "system":                    # README's Lotka-Volterra system: two default networks behind one closure launch
         return Solver1D(lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)], [IVP(0.0, 1.5), IVP(0.0, 1.0)],
                         t_min=0.1, t_max=12.0, **kw)
+    if name == "system1k":                  # BASELINE C1's size: 32 closure workgroups (the largest one-launch-per-epoch grid)
+        return Solver1D(lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)], [IVP(0.0, 1.5), IVP(0.0, 1.0)],
+                        train_generator=Generator1D(1024, 0.1, 12.0, method="equally-spaced-noisy"),
+                        valid_generator=Generator1D(256, 0.1, 12.0, method="equally-spaced"), **kw)
+    if name == "ode300":                    # 19 tiles on 5 workgroups, the last one ragged
+        return Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)],
+                        train_generator=Generator1D(300, 0.0, 2.0, method="equally-spaced-noisy"),
+                        valid_generator=Generator1D(100, 0.0, 2.0, method="equally-spaced"), **kw)
     if name == "odd":                       # 20 points per batch: no one-call bulk draw (not a multiple of 16), ragged last tile
         return Solver1D(lambda u, t: [diff(u, t, order=2) + u], [IVP(0.0, 0.0, 1.0)],
                         train_generator=Generator1D(20, 0.0, 2.0, method="equally-spaced-noisy"),
@@ -59,7 +67,7 @@ def _same(a, b):
     assert all(np.array_equal(x, y) for x, y in zip(a["batch"], b["batch"]))
 
 
-@pytest.mark.parametrize("name", ["ode", "pde", "system", "odd", "static_train"])
+@pytest.mark.parametrize("name", ["ode", "pde", "system", "odd", "static_train", "system1k", "ode300"])
 def test_multi_epoch_fit_is_bit_identical_to_epoch_by_epoch(monkeypatch, name):
     from neurodiffeq_amd.solvers import BaseSolver
     monkeypatch.setattr(BaseSolver, "FIT_CHUNK", 7)         # 23 epochs = 1 ordinary epoch + chunks of 7, 7, 7 and 1 single
