@@ -462,7 +462,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config sub-records (C1, C3, C4, C5)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes for roofline.traffic")
-    ap.add_argument("--cold-start", action="store_true", help="also time the first step of a never-seen PDE (runs hipcc)")
+    ap.add_argument("--cold-start", action="store_true", help="(default at N = 1 since round 3; kept for old command lines)")
+    ap.add_argument("--no-cold-start", action="store_true",
+                    help="skip timing the first step of a never-seen PDE (trace + hipcc + self-check, ~1.5 s)")
     ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE config to run (the driver's headline is c2; c3 / c5 are the sizes where strong scaling "
                          "has work to share: SURVEY.md 8e)")
@@ -658,8 +660,12 @@ def main():
             out["configs"] = {name: config_record(name) for name in ("c1", "c3", "c4", "c5")}
             out["roofline_pointwise_large"] = pointwise_large()
             out["c2_fp64"] = fp64_record()
-        if args.cold_start:
-            out["cold_start"] = cold_start()
+        if world == 1 and not args.no_cold_start and (args.cold_start or not args.no_configs):
+            try:
+                out["cold_start"] = cold_start()
+                out["cold_start_s"] = out["cold_start"]["cold_start_s"]
+            except Exception as e:                      # e.g. no hipcc on the box: the figure is missing, the bench line is not
+                out["cold_start"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_cpu_baseline:
             cb = out["cpu_baseline"] = cpu_baseline()
             # like for like: resident inputs on both sides / generator draw inside the step on both sides (the host draw +

@@ -150,6 +150,11 @@ int launch_tv(const float* coords, int ldc, int n, const float* const* params, f
     a.theta = g_theta;
     {fill}
   }}
+  // a training epoch on its own is the plain training kernel (the same device code as the training half of the combined
+  // kernel -- engine.verify_fused compares the two bit for bit -- without the second body's registers: C2 -1 us, C3 -13 us)
+  static const bool always_tv = getenv("NDQ_TV_ALWAYS") != nullptr;        // measurement knob
+  if (vn == 0 && !pull && !always_tv)
+    return launch(coords, ldc, n, params, partials, loss_partials, nullptr, nullptr, ldc, seed, 1, stream);
   const int tb = n > 0 ? fused_blocks(n) : 0, vb = vn > 0 ? fused_blocks(vn) : 0;
   static bool attr = false;
   if (!attr) {{
@@ -489,6 +494,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         tv = _tv_launcher(args_t, fill, kern_tv, lds('true'), lds('false'), threads)
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- single-launch closure kernel (forward streams + pointwise stage +
 // reverse pass) of one PDE system with {K} network(s), gfx950.
+#include <cstdlib>
 #include "{header}"
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}
@@ -620,6 +626,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
                           "ndq::fused_group_closure_tv_kernel<CFG, PW>", lds('true'), lds('false'))
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- grouped single-launch closure kernel (forward streams -> LDS exchange ->
 // per-point stage, one point per lane -> reverse pass) of one PDE system, gfx950.
+#include <cstdlib>
 #include "{header}"
 #define NDQ_PW_INLINE __device__ __forceinline__
 {self.point_fn_source()}

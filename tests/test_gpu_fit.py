@@ -147,6 +147,36 @@ def test_history_ring_wraps_and_a_fit_can_be_continued(monkeypatch):
     _same(run(True), run(False))
 
 
+def test_weight_decay_and_a_changed_learning_rate_take_the_same_route():
+    """Adam hyper-parameters are read at every native call: weight decay (folded into the gradient by both the tail
+    kernel and the one-launch prologue) and a learning rate changed between two fit() calls."""
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.optim import FusedAdam
+
+    def run(chunked):
+        torch.manual_seed(0)
+        nets = [FCNN(1, 1)]
+        solver = _problem("ode", nets=nets, optimizer=FusedAdam(nets[0].parameters(), lr=2e-3, weight_decay=1e-2))
+        solver.fused = "require"
+        torch.manual_seed(5)
+        cbs = () if chunked else [lambda s: None]
+        solver.fit(30, tqdm_file=None, callbacks=cbs)
+        solver.optimizer.param_groups[0]["lr"] = 5e-4
+        solver.fit(30, tqdm_file=None, callbacks=cbs)
+        return _state(solver)
+
+    a, b = run(True), run(False)
+    _same(a, b)
+    # ... and the decay is really applied: the same run without it ends elsewhere
+    torch.manual_seed(0)
+    nets = [FCNN(1, 1)]
+    plain = _problem("ode", nets=nets, optimizer=FusedAdam(nets[0].parameters(), lr=2e-3))
+    plain.fused = "require"
+    torch.manual_seed(5)
+    plain.fit(30, tqdm_file=None)
+    assert a["train"][:30] != plain.metrics_history["train_loss"][:30]
+
+
 def test_resident_training_batches_and_no_validation():
     """Pre-sampled batches resident in HBM (ResidentBatchGenerator) are read in place by every epoch of a chunk; without
     validation epochs the best network follows the training loss (solvers.py:414-415)."""
