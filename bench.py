@@ -21,7 +21,11 @@ device-side Philox sampler every step as ``with_device_sampling``.
 
 Rank 0 prints ONE JSON line (contract in the task description) including
   roofline      -- dominant kernel (fused closure kernel): algorithmic GEMM flops / HIP-event launch time vs the fp32
-                   MFMA peak, plus the HBM bytes per launch from calibrated rocprofv3 --pmc passes (profiles/traffic_c2.json),
+                   MFMA peak, plus the HBM bytes per launch MEASURED IN THIS RUN (two child runs of this script under
+                   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, outside the timed region; when rocprofv3 is missing the last
+                   committed figure of profiles/traffic_c2.json is reported and labelled stale-able),
+  in_fit, cold_start -- the headline's epochs issued by fit(k) (one native call); seconds to the first training step of a
+                   PDE this installation has never seen (trace + hipcc + first-use self-check),
   kernels       -- the three-kernel pipeline (forward / pointwise / backward) timed the same way,
   configs       -- C1, C3, C4, C5 at their BASELINE sizes: ms per step, algorithmic TFLOP/s, fraction of the peak,
   roofline_pointwise_large -- the standalone pointwise residual kernel at 1 M / 4 M points vs the HBM roofline,
