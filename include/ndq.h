@@ -215,6 +215,14 @@ typedef int (*ndq_fused_launch_tv_fn)(const float* coords, int ldc, int n, const
  * image from the result; workgroup 0 writes the new parameters / moments / history.  One launch per epoch instead of
  * two.  It needs a second set of buffers (a launch reads the state its predecessor wrote while writing the next one):
  * the alt_* members below; the call's last launch is an ordinary tail that leaves everything in the primary buffers. */
+/* LOOP MODE (csrc/ndq_tail.h: ndq::LoopArgs), used when the training grid and the validation grid are ONE workgroup each
+ * (the reference's default ODE solvers: 32 points) and there are at most two networks: one launch of one workgroup
+ * stands for up to 64 launches of the pull-mode sequence -- prologue, validation closure, training closure, again -- with
+ * parameters, moments, gradient row and loss partials in LDS.  Exported by the closure module as ndq_fused_launch_loop
+ * (ndq_fused_loop_ok() != 0 when its kernel supports it).  Same device functions in the same order as the other two
+ * routes: the three are interchangeable bit for bit. */
+typedef int (*ndq_fused_launch_loop_fn)(const float* coords, int ldc, int n, float seed, const float* vcoords, int vldc,
+                                        int vn, const void* loop, void* stream);
 typedef struct ndq_fused_fit {
   ndq_fused_launch_tv_fn launch;   /* exported by the generated closure kernel module as ndq_fused_launch_tv */
   int n_nets;                      /* 1..4 networks behind the one closure launch */
@@ -237,6 +245,9 @@ typedef struct ndq_fused_fit {
   float* alt_partials[4];          /* [blocks][P_k] */
   float* alt_loss_partials;        /* [blocks] */
   float* alt_valid_loss_partials;  /* [valid_blocks] */
+  /* loop mode: both set by the caller when the module exports it (needs the alt_* buffers too) */
+  ndq_fused_launch_loop_fn launch_loop;
+  int loop_ok;
 } ndq_fused_fit;
 /* train_coords: HOST array of n_epochs device pointers, the [d][ldc] batch of every epoch.  adam_step: step count AFTER
  * the first update (epoch e uses adam_step + e).  parity: slot of best_loss[2] holding the current best; every tail

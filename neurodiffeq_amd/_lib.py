@@ -56,7 +56,8 @@ class FusedFit(ctypes.Structure):
                 ("valid_loss_partials", ctypes.c_void_p), ("valid_hist", ctypes.c_void_p), ("track_best", ctypes.c_int),
                 ("pull_ok", ctypes.c_int), ("alt_params", ctypes.c_void_p * 4), ("alt_m", ctypes.c_void_p * 4),
                 ("alt_v", ctypes.c_void_p * 4), ("alt_partials", ctypes.c_void_p * 4),
-                ("alt_loss_partials", ctypes.c_void_p), ("alt_valid_loss_partials", ctypes.c_void_p)]
+                ("alt_loss_partials", ctypes.c_void_p), ("alt_valid_loss_partials", ctypes.c_void_p),
+                ("launch_loop", ctypes.c_void_p), ("loop_ok", ctypes.c_int)]
 
 
 class NdqError(RuntimeError):

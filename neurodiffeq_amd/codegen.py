@@ -126,7 +126,7 @@ _UN_ADJ = {
 }
 
 
-def _tv_launcher(args_t, fill, kern_tv, lds_train, lds_eval, threads="CFG::BWD_THREADS"):
+def _tv_launcher(args_t, fill, kern_tv, lds_train, lds_eval, threads="CFG::BWD_THREADS", kern_loop=None, lds_loop=None):
     """Host launcher of the train + validation closure kernel (csrc/ndq_mlp.h: fused_*_closure_tv_kernel), emitted into
     the anonymous namespace of every generated closure module: workgroups [0, blocks(n)) run the training closure on the
     training batch, the next blocks(vn) the forward-only closure on the validation batch; n = 0 / vn = 0 drops a half."""
@@ -171,7 +171,32 @@ int launch_tv(const float* coords, int ldc, int n, const float* const* params, f
   hipLaunchKernelGGL(({kern_tv}), dim3(tb + vb), dim3({threads}), tb > 0 ? {lds_train} : {lds_eval},
                      static_cast<hipStream_t>(stream), t, v, tb, pa);
   return (int)hipGetLastError();
-}}"""
+}}""" + (f"""
+// loop mode (csrc/ndq_tail.h: LoopArgs): ONE workgroup runs a run of fit()'s launches back to back, state in LDS
+int launch_loop(const float* coords, int ldc, int n, float seed, const float* vcoords, int vldc, int vn, const void* loop,
+                void* stream) {{
+  if (!loop || !ndq::pull_supported<CFG>() || n < 0 || vn < 0 || (n > 0 && (!coords || ldc < n || fused_blocks(n) != 1)) ||
+      (vn > 0 && (!vcoords || vldc < vn || fused_blocks(vn) != 1)))
+    return -2;
+  {args_t} t{{}}, v{{}};
+  t.coords = coords; t.n = n; t.ldc = ldc; t.ldj = ldc; t.seed = seed; t.theta = g_theta;
+  v.coords = vcoords; v.n = vn; v.ldc = vldc; v.ldj = vldc; v.seed = 0.f; v.theta = g_theta;
+  static bool attr = false;
+  if (!attr) {{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&{kern_loop}),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int){lds_loop});
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }}
+  hipLaunchKernelGGL(({kern_loop}), dim3(1), dim3({threads}), {lds_loop}, static_cast<hipStream_t>(stream), t, v,
+                     *static_cast<const ndq::LoopArgs*>(loop));
+  return (int)hipGetLastError();
+}}
+int loop_ok() {{ return ndq::pull_supported<CFG>() ? 1 : 0; }}
+""" if kern_loop else """
+int launch_loop(const float*, int, int, float, const float*, int, int, const void*, void*) { return -2; }
+int loop_ok() { return 0; }
+""")
 
 
 # the ndq_fused_launch_tv_fn of include/ndq.h
@@ -182,6 +207,12 @@ extern "C" int ndq_fused_launch_tv(const float* coords, int ldc, int n, const fl
   return launch_tv(coords, ldc, n, params, partials, loss_partials, seed, vcoords, vldc, vn, vloss_partials, pull, stream);
 }
 extern "C" int ndq_fused_pull_ok() { return ndq::pull_supported<CFG>() ? 1 : 0; }
+// the ndq_fused_launch_loop_fn of include/ndq.h
+extern "C" int ndq_fused_launch_loop(const float* coords, int ldc, int n, float seed, const float* vcoords, int vldc, int vn,
+                                     const void* loop, void* stream) {
+  return launch_loop(coords, ldc, n, seed, vcoords, vldc, vn, loop, stream);
+}
+extern "C" int ndq_fused_loop_ok() { return loop_ok(); }
 """
 
 
@@ -491,12 +522,21 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
             args_t = "ndq::FusedMultiArgs"
             fill = f"for (int k = 0; k < {K}; ++k) {{ a.params[k] = params[k]; a.partials[k] = partials ? partials[k] : nullptr; }}"
             kern_tv = f"ndq::fused_multi_closure_tv_kernel<CFG, {K}, PW>"
-        tv = _tv_launcher(args_t, fill, kern_tv, lds('true'), lds('false'), threads)
+        if K == 1:
+            kern_loop, lds_loop = "ndq::fused_closure_loop_kernel<CFG, PW>", "ndq::fused_loop_lds_bytes<CFG>()"
+        elif K == 2:
+            kern_loop, lds_loop = f"ndq::fused_multi_closure_loop_kernel<CFG, {K}, PW>", f"(ndq::fused_multi_loop_lds_bytes<CFG, {K}>())"
+        else:
+            kern_loop = lds_loop = None
+        tv = _tv_launcher(args_t, fill, kern_tv, lds('true'), lds('false'), threads, kern_loop, lds_loop)
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- single-launch closure kernel (forward streams + pointwise stage +
 // reverse pass) of one PDE system with {K} network(s), gfx950.
 #include <cstdlib>
 #include "{header}"
 #define NDQ_PW_INLINE __device__ __forceinline__
+#ifndef NDQ_MAX_BLOCKS
+#define NDQ_MAX_BLOCKS 256     // closure workgroups per launch (one per CU; experiments: 512 = two 8-wave workgroups per CU)
+#endif
 {self.point_fn_source()}
 namespace {{
 using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
@@ -524,7 +564,7 @@ constexpr int kWaves = {tiles_per_block};        // tiles a workgroup handles pe
 int fused_blocks(int n) {{
   const int tiles = (n + 15) / 16;
   int b = (tiles + kWaves - 1) / kWaves;
-  return b > 256 ? 256 : (b < 1 ? 1 : b);
+  return b > NDQ_MAX_BLOCKS ? NDQ_MAX_BLOCKS : (b < 1 ? 1 : b);
 }}
 
 // trainable scalars of the equations (PW::NT of them): values read by every launch, block sums of their adjoints written by
@@ -629,6 +669,9 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 #include <cstdlib>
 #include "{header}"
 #define NDQ_PW_INLINE __device__ __forceinline__
+#ifndef NDQ_MAX_BLOCKS
+#define NDQ_MAX_BLOCKS 256     // closure workgroups per launch (one per CU; experiments: 512 = two 8-wave workgroups per CU)
+#endif
 {self.point_fn_source()}
 namespace {{
 using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
@@ -658,7 +701,7 @@ int fused_blocks(int n) {{
   constexpr int gp = 16 * ndq::group_tiles<CFG>();
   const int groups = (n + gp - 1) / gp;
   int b = (groups + kWaves - 1) / kWaves;
-  return b > 256 ? 256 : (b < 1 ? 1 : b);
+  return b > NDQ_MAX_BLOCKS ? NDQ_MAX_BLOCKS : (b < 1 ? 1 : b);
 }}
 
 const float* g_theta = nullptr;          // see the tile-closure module: trainable scalars of the equations
@@ -926,6 +969,9 @@ class FusedKernel:
         self.lib.ndq_fused_launch_tv.restype = ci
         self.lib.ndq_fused_launch_tv.argtypes = [vp, ci, ci, vp, vp, vp, cf, vp, ci, ci, vp, vp, vp]
         self.lib.ndq_fused_pull_ok.restype = ci
+        self.lib.ndq_fused_launch_loop.restype = ci
+        self.lib.ndq_fused_launch_loop.argtypes = [vp, ci, ci, cf, vp, ci, ci, vp, vp]
+        self.lib.ndq_fused_loop_ok.restype = ci
         self.lib.ndq_fused_bind_theta.restype = None
         self.lib.ndq_fused_bind_theta.argtypes = [vp, vp]
         self.lib.ndq_fused_blocks.restype = ci

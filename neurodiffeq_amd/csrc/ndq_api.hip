@@ -694,7 +694,52 @@ int ndq_fused_fit_run(const ndq_fused_fit* f, int n_epochs, const float* const* 
     float* LP[2] = {s0.loss_partials, f->alt_loss_partials};
     float* VP[2] = {f->valid_loss_partials, f->alt_valid_loss_partials};
     const int last = valid ? n_epochs : n_epochs - 1;          // index of the last closure launch
-    for (int e = 0; e <= last; ++e) {
+    int fin = last & 1;                                        // buffer set holding the state after the last closure launch
+    // ---- loop mode: training and validation grid are ONE workgroup each -> runs of up to kLoopMaxLaunches launches of the
+    // sequence below become one launch of one workgroup that keeps the state in LDS (csrc/ndq_tail.h: LoopArgs)
+    bool loop = f->loop_ok != 0 && f->launch_loop && s0.blocks == 1 && (!valid || f->valid_blocks == 1) &&
+                f->n_nets <= ndq::kLoopMaxNets;
+    long long stride = 0;
+    if (loop) {
+      if (!train_coords[0] || !train_coords[1]) return NDQ_EINVAL;
+      stride = train_coords[1] - train_coords[0];
+      for (int e = 2; e < n_epochs && loop; ++e) {
+        if (!train_coords[e]) return NDQ_EINVAL;
+        loop = train_coords[e] - train_coords[0] == stride * e;
+      }
+    }
+    if (loop) {
+      int seg = 0;
+      for (int e0 = 0; e0 <= last; e0 += ndq::kLoopMaxLaunches, ++seg) {
+        const int e1 = e0 + ndq::kLoopMaxLaunches <= last + 1 ? e0 + ndq::kLoopMaxLaunches : last + 1;
+        const int in = seg & 1, out = in ^ 1;
+        ndq::LoopArgs L{};
+        L.e0 = e0; L.e1 = e1; L.n_epochs = n_epochs; L.has_valid = valid ? 1 : 0; L.track_best = f->track_best;
+        L.hist_index = hist_index; L.valid_index = valid_index; L.parity = parity; L.coord_stride = stride;
+        L.lp_in = LP[in]; L.vp_in = VP[in]; L.lp_out = LP[out]; L.vp_out = VP[out];
+        L.lscale = s0.seed; L.vscale = f->valid_scale;
+        L.loss_hist = s0.loss_hist; L.loss_slot = s0.loss_slot; L.valid_hist = f->valid_hist; L.best_loss = s0.best_loss;
+        for (int k = 0; k < f->n_nets; ++k) {
+          const ndq_fused_step& s = f->net[k];
+          ndq::LoopNet& n = L.net[k];
+          n.p_in = P[in][k]; n.m_in = M[in][k]; n.v_in = V[in][k]; n.part_in = PART[in][k];
+          n.p_out = P[out][k]; n.m_out = M[out][k]; n.v_out = V[out][k]; n.part_out = PART[out][k];
+          n.grad = s.grad; n.best_flat = s.best_flat;
+          n.lr = s.lr; n.b1 = s.beta1; n.b2 = s.beta2; n.eps = s.eps; n.wd = s.weight_decay;
+          for (int e = e0 > 1 ? e0 : 1; e < e1; ++e) {         // launch e finishes epoch e - 1: Adam step adam_step + e - 1
+            const int step = adam_step + e - 1;
+            n.bc1[e - e0] = (float)(1.0 - pow((double)s.beta1, (double)step));
+            n.bc2s[e - e0] = (float)sqrt(1.0 - pow((double)s.beta2, (double)step));
+          }
+        }
+        int rc = f->launch_loop(train_coords[0], s0.ldc, s0.n, s0.seed, valid ? f->valid_coords : nullptr, f->valid_ldc,
+                                valid ? f->valid_n : 0, &L, stream);
+        if (rc) return rc;
+        fin = out;
+      }
+      parity ^= (last & 1);
+    }
+    for (int e = 0; e <= last && !loop; ++e) {
       ndq::PullArgs pa{};
       if (e >= 1) {                                            // prologue: finish training epoch j = e - 1
         const int j = e - 1, in = j & 1, out = e & 1;
@@ -731,7 +776,6 @@ int ndq_fused_fit_run(const ndq_fused_fit* f, int n_epochs, const float* const* 
     }
     // ---- the call's last launch: an ordinary tail that leaves everything in the primary buffers
     ReduceTailMultiArgs a{};
-    const int fin = last & 1;                                   // buffer set holding the state after the last closure launch
     for (int k = 0; k < f->n_nets; ++k) {
       const ndq_fused_step& s = f->net[k];
       ReduceTailArgs& t = a.net[k];

@@ -2438,6 +2438,93 @@ __global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_tv_kernel(FusedA
   else fused_closure_body<C, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks, pull, writer);
 }
 
+// Loop mode (csrc/ndq_tail.h): one workgroup runs launches [e0, e1) of fit()'s pull-mode sequence back to back -- state
+// in LDS behind everything the closure bodies use (loop_state_offset), the bodies themselves unchanged: they read their
+// parameters from and leave their gradient row / loss partial in LDS through generic pointers.
+template <class C> constexpr size_t fused_lds_bytes(bool train);
+template <class C> constexpr int loop_state_offset() {
+  const size_t a = fused_lds_bytes<C>(true), b = fused_lds_bytes<C>(false);
+  return (int)((((a > b ? a : b) + 15) & ~(size_t)15) / sizeof(real));
+}
+template <class C> constexpr int loop_state_floats(int nets) { return nets * 4 * ((C::P + 3) & ~3) + 64; }
+template <class C> constexpr size_t fused_loop_lds_bytes() { return sizeof(real) * (loop_state_offset<C>() + loop_state_floats<C>(1)); }
+
+// state of K networks in LDS <- global at entry, -> global at exit (all threads; the caller synchronises)
+template <int K>
+__device__ __forceinline__ void loop_state_load(const LoopArgs& L, float* state, int pp, int len, float* misc) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float* s = state + (size_t)k * 4 * pp;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+      s[i] = L.net[k].p_in[i];
+      s[pp + i] = L.net[k].m_in[i];
+      s[2 * pp + i] = L.net[k].v_in[i];
+      s[3 * pp + i] = L.e0 >= 1 ? L.net[k].part_in[i] : 0.f;
+    }
+  }
+  if (threadIdx.x == 0) {
+    misc[0] = L.e0 >= 1 ? L.lp_in[0] : 0.f;
+    misc[1] = (L.e0 >= 2 && L.has_valid) ? L.vp_in[0] : 0.f;
+    misc[2] = L.best_loss[0];
+    misc[3] = L.best_loss[1];
+  }
+}
+template <int K>
+__device__ __forceinline__ void loop_state_store(const LoopArgs& L, const float* state, int pp, int len, const float* misc) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float* s = state + (size_t)k * 4 * pp;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+      L.net[k].p_out[i] = s[i];
+      L.net[k].m_out[i] = s[pp + i];
+      L.net[k].v_out[i] = s[2 * pp + i];
+      L.net[k].part_out[i] = s[3 * pp + i];
+    }
+  }
+  if (threadIdx.x == 0) {
+    L.lp_out[0] = misc[0];
+    if (L.has_valid) L.vp_out[0] = misc[1];
+    L.best_loss[0] = misc[2];
+    L.best_loss[1] = misc[3];
+  }
+}
+
+#if !NDQ_F64
+template <class C, class PW>
+__global__ __launch_bounds__(C::BWD_THREADS) void fused_closure_loop_kernel(FusedArgs t, FusedArgs v, LoopArgs L) {
+  extern __shared__ __attribute__((aligned(16))) real lds[];
+  if constexpr (!pull_supported<C>()) return;         // (never launched: ndq_fused_loop_ok)
+  constexpr int PP = (C::P + 3) & ~3;
+  float* state = lds + loop_state_offset<C>();
+  float* misc = state + 4 * PP;                       // [0] training loss partial [1] validation loss partial [2, 3] best loss
+  const PullArgs none{};
+  loop_state_load<1>(L, state, PP, C::P, misc);
+  __syncthreads();
+  for (int e = L.e0; e < L.e1; ++e) {
+    if (e >= 1) {                                     // finish training epoch e - 1 (in place: every thread owns its columns)
+      PullArgs pa{};
+      loop_pull_args<1>(L, e, state, PP, C::P, misc, pa);
+      pull_prologue<C::BWD_THREADS, C::P, 1>(pa, state, 0, misc + 8, true);
+      __syncthreads();
+    }
+    if (L.has_valid && e >= 1) {                      // validation loss of the parameters epoch e starts from
+      FusedArgs a = v;
+      a.params = state; a.loss_partials = misc + 1;
+      fused_closure_body<C, PW, false>(a, lds, 0, 1, none, false);
+      __syncthreads();
+    }
+    if (e < L.n_epochs) {
+      FusedArgs a = t;
+      a.coords = t.coords + (size_t)e * (size_t)L.coord_stride;
+      a.params = state; a.partials = state + 3 * PP; a.loss_partials = misc;
+      fused_closure_body<C, PW, true>(a, lds, 0, 1, none, false);
+      __syncthreads();
+    }
+  }
+  loop_state_store<1>(L, state, PP, C::P, misc);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ multi-network closure
 // The same single launch for K networks of ONE shape and stream set (systems of ODEs / PDEs with one network per
 // unknown, the reference's default: solvers.py:136-140): all K weight images sit in LDS, each tile runs the K forward
@@ -2483,9 +2570,15 @@ template <class C, int K> constexpr int multi_group_floats() {
 }
 template <class C, int K> constexpr int multi_xchg_floats() { return 2 * multi_group<K>() * K * C::NS * 16; }
 
+// loop mode (fused_multi_closure_loop_kernel): buffers in LDS that replace coords / params[k] / partials[k] /
+// loss_partials of the argument struct; params_base == nullptr: unused
+struct MultiLoopView {
+  const real* coords; const real* params_base; real* partials_base; real* loss_partials; int stride;
+};
+
 template <class C, int K, class PW, bool TRAIN>
 __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a, real* lds, const int blk, const int nblk,
-                                                         const PullArgs& pull, bool writer) {
+                                                         const PullArgs& pull, bool writer, const MultiLoopView& lv) {
   static_assert(C::NOUT == 1 && !C::WIDE && K >= 2 && K <= kMaxFusedNets, "multi-network closure: n_out = 1, H <= 48, 2..4 nets");
   static_assert(C::BWD_THREADS == 256, "multi-network closure: one wave per SIMD (build without NDQ_BWD_THREADS)");
   constexpr int WS = C::ldsWeightsEnd(TRAIN);          // LDS floats per weight image
@@ -2493,6 +2586,11 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
   NDQ_TS(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   const int k = wave / G, g = wave - k * G;            // this wave's network and its tile slot in a round
+  // loop mode hands in its LDS-resident buffers through `lv` (the argument struct itself stays in the kernarg segment)
+  const real* const coords = lv.params_base ? lv.coords : a.coords;
+  const real* const prm_k = lv.params_base ? lv.params_base + k * lv.stride : a.params[k];
+  real* const part_k = lv.params_base ? lv.partials_base + k * lv.stride : a.partials[k];
+  real* const lpart = lv.params_base ? lv.loss_partials : a.loss_partials;
   const int ntiles = (a.n + 15) >> 4;
   // the first tile's coordinates are fetched before the weights are staged (both global latencies overlap)
   real xn[C::D];
@@ -2500,11 +2598,11 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
     const int n0 = (blk * G + g) * 16 + p;
     const int nn0 = n0 < a.n ? n0 : a.n - 1;
 #pragma unroll
-    for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn0];
+    for (int d = 0; d < C::D; ++d) xn[d] = coords[(size_t)d * a.ldc + nn0];
   }
   // every network's G waves stage that network's image: the K images are built at the same time (a staging pass is
   // bound by the latency of its parameter loads -- 2.97 us for two images one after the other at C1, measured)
-  const real* prm = a.params[k];
+  const real* prm = prm_k;
 #if !NDQ_F64
   if constexpr (pull_supported<C>()) {
     if (pull.enabled) {
@@ -2543,7 +2641,7 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
       const int n1 = n + nblk * G * 16;                  // next round's tile, one round ahead
       const int nn1 = n1 < a.n ? n1 : a.n - 1;
 #pragma unroll
-      for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn1];
+      for (int d = 0; d < C::D; ++d) xn[d] = coords[(size_t)d * a.ldc + nn1];
     }
     LayerState<C> st[C::L];
     real4 h[C::NS][C::NB];
@@ -2567,7 +2665,7 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
     if constexpr (PW::ND > 0) {
       const int nn = valid ? n : a.n - 1;
 #pragma unroll
-      for (int j = 0; j < PW::ND; ++j) xe[j] = a.coords[(size_t)(C::D + j) * a.ldc + nn];
+      for (int j = 0; j < PW::ND; ++j) xe[j] = coords[(size_t)(C::D + j) * a.ldc + nn];
     }
     PW::apply(x, xe, jets, a.seed, TRAIN ? 1 : 0, r, f, gout, gth);
     if (valid && q == 0 && k == 0) {
@@ -2605,7 +2703,7 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
     // the G waves of a network add up among themselves (all networks at once: same barrier sequence), regions in that
     // network's own staging area; block_reduce_store addresses its regions behind "the" weight image of its base
     real* base = work + k * multi_group_floats<C, K>() - C::ldsWeightsEnd(true);
-    block_reduce_store<C, G, multi_regions<C, K>()>(base, acc, g, lane, p, q, a.partials[k] + (size_t)blk * C::P, a.params[k],
+    block_reduce_store<C, G, multi_regions<C, K>()>(base, acc, g, lane, p, q, part_k + (size_t)blk * C::P, prm_k,
                                                      g * 64 + lane, G * 64);
   }
   lsum = point_sum(quad_sum(lsum));                      // non-zero in the waves of network 0 only
@@ -2616,7 +2714,7 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
   if (threadIdx.x == 0) {
     real v = 0.f;
     for (int w = 0; w < WAVES; ++w) v += wl[w];
-    a.loss_partials[blk] = v;
+    lpart[blk] = v;
   }
   if constexpr (TRAIN) theta_block_sum<PW::NT>(tsum, wl + 16, WAVES, a.theta_partials ? a.theta_partials + (size_t)blk * PW::NT : nullptr);
   NDQ_TS(3);
@@ -2626,7 +2724,7 @@ template <class C, int K, class PW, bool TRAIN>
 __global__ __launch_bounds__(multi_threads<K>()) void fused_multi_closure_kernel(FusedMultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
   const PullArgs none{};
-  fused_multi_closure_body<C, K, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x, none, false);
+  fused_multi_closure_body<C, K, PW, TRAIN>(a, lds, blockIdx.x, gridDim.x, none, false, MultiLoopView{});
 }
 
 // training + validation batch in one launch, as fused_closure_tv_kernel
@@ -2635,9 +2733,51 @@ __global__ __launch_bounds__(multi_threads<K>()) void fused_multi_closure_tv_ker
                                                                                     PullArgs pull) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
   const bool writer = blockIdx.x == 0;
-  if ((int)blockIdx.x < train_blocks) fused_multi_closure_body<C, K, PW, true>(t, lds, blockIdx.x, train_blocks, pull, writer);
-  else fused_multi_closure_body<C, K, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks, pull, writer);
+  if ((int)blockIdx.x < train_blocks) fused_multi_closure_body<C, K, PW, true>(t, lds, blockIdx.x, train_blocks, pull, writer, MultiLoopView{});
+  else fused_multi_closure_body<C, K, PW, false>(v, lds, (int)blockIdx.x - train_blocks, (int)gridDim.x - train_blocks, pull, writer, MultiLoopView{});
 }
+
+template <class C, int K> constexpr size_t fused_multi_lds_bytes(bool train);
+template <class C, int K> constexpr int multi_loop_state_offset() {
+  const size_t a = fused_multi_lds_bytes<C, K>(true), b = fused_multi_lds_bytes<C, K>(false);
+  return (int)((((a > b ? a : b) + 15) & ~(size_t)15) / sizeof(real));
+}
+template <class C, int K> constexpr size_t fused_multi_loop_lds_bytes() {
+  return sizeof(real) * (multi_loop_state_offset<C, K>() + loop_state_floats<C>(K));
+}
+#if !NDQ_F64
+// loop mode for K same-shape networks (see fused_closure_loop_kernel)
+template <class C, int K, class PW>
+__global__ __launch_bounds__(multi_threads<K>()) void fused_multi_closure_loop_kernel(FusedMultiArgs t, FusedMultiArgs v, LoopArgs L) {
+  static_assert(K <= kLoopMaxNets, "loop mode: up to two networks");
+  extern __shared__ __attribute__((aligned(16))) real lds[];
+  if constexpr (!pull_supported<C>()) return;
+  constexpr int PP = (C::P + 3) & ~3;
+  float* state = lds + multi_loop_state_offset<C, K>();
+  float* misc = state + K * 4 * PP;
+  const PullArgs none{};
+  loop_state_load<K>(L, state, PP, C::P, misc);
+  __syncthreads();
+  for (int e = L.e0; e < L.e1; ++e) {
+    if (e >= 1) {
+      PullArgs pa{};
+      loop_pull_args<K>(L, e, state, PP, C::P, misc, pa);
+      pull_prologue<multi_threads<K>(), C::P, K>(pa, state, 4 * PP, misc + 8, true);
+      __syncthreads();
+    }
+    if (L.has_valid && e >= 1) {
+      fused_multi_closure_body<C, K, PW, false>(v, lds, 0, 1, none, false, MultiLoopView{v.coords, state, state + 3 * PP, misc + 1, 4 * PP});
+      __syncthreads();
+    }
+    if (e < L.n_epochs) {
+      fused_multi_closure_body<C, K, PW, true>(t, lds, 0, 1, none, false,
+                                               MultiLoopView{t.coords + (size_t)e * (size_t)L.coord_stride, state, state + 3 * PP, misc, 4 * PP});
+      __syncthreads();
+    }
+  }
+  loop_state_store<K>(L, state, PP, C::P, misc);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------ grouped closure
 // Single-launch closure for systems whose pointwise stage is too heavy to run 4x redundantly on the (p, q) lanes of a

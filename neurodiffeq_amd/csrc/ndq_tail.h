@@ -343,4 +343,60 @@ __device__ __forceinline__ void pull_prologue(const PullArgs& a, float* pnew, in
 }
 
 
+// ---- loop mode: a whole run of epochs in ONE launch -----------------------------------------------------------------
+// When the training grid and the validation grid are one workgroup each (the reference's default ODE solvers: 32 points),
+// nothing of an epoch has to leave the CU: ONE workgroup runs launch after launch of the pull-mode sequence above inside
+// a loop -- prologue (finish the previous epoch), validation closure, training closure -- with parameters, moments, the
+// gradient row and the loss partials in LDS.  It reads the state the way a pull-mode launch would find it and leaves
+// what the last launch of the run would have left (in the other buffer set), so ndq_fused_fit_run can mix the two and
+// ends with the same ordinary tail.  Same device functions, same order of operations: bit-identical to both other routes.
+constexpr int kLoopMaxLaunches = 64;    // launches one loop kernel stands for (Adam's bias corrections travel as arguments)
+constexpr int kLoopMaxNets = 2;
+struct LoopNet {
+  const float* p_in; const float* m_in; const float* v_in; const float* part_in;     // state at entry (part_in: e0 >= 1)
+  float* p_out; float* m_out; float* v_out; float* part_out;                         // ... and at exit
+  float* grad; float* best_flat;
+  float lr, b1, b2, eps, wd;
+  float bc1[kLoopMaxLaunches], bc2s[kLoopMaxLaunches];     // of the epoch finished by the prologue of launch e0 + i
+};
+struct LoopArgs {
+  int e0, e1;                  // launches [e0, e1) of the call's sequence (launch e: prologue for e >= 1, training closure
+  int n_epochs;                // for e < n_epochs, validation closure for has_valid && e >= 1)
+  int has_valid, track_best;
+  int hist_index, valid_index, parity;        // as passed to ndq_fused_fit_run (values of the call's first launch)
+  long long coord_stride;      // floats between the training batches of consecutive epochs
+  const float* lp_in; const float* vp_in; float* lp_out; float* vp_out;
+  float lscale, vscale;
+  float* loss_hist; float* loss_slot; float* valid_hist; float* best_loss;
+  LoopNet net[kLoopMaxNets];
+};
+
+// The PullArgs launch e of the sequence would have been given, with every buffer of the epoch being finished in LDS:
+// state[k] = {p, m, v, row} of network k (PP floats each), misc = {training loss partial, validation loss partial,
+// best-loss ping-pong (2)}.
+template <int K>
+__device__ __forceinline__ void loop_pull_args(const LoopArgs& L, int e, float* state, int pp, int len, float* misc, PullArgs& pa) {
+  const int j = e - 1;
+  const bool with_valid = L.has_valid != 0 && j >= 1;
+  pa.enabled = 1; pa.n_nets = K; pa.nparts = 1;
+  pa.lpart = misc; pa.nlparts = 1; pa.lscale = L.lscale;
+  pa.loss_hist = L.loss_hist; pa.hist_index = L.hist_index + j; pa.loss_slot = L.loss_slot;
+  pa.vpart = with_valid ? misc + 1 : nullptr; pa.nvparts = 1; pa.vscale = L.vscale;
+  pa.valid_hist = L.valid_hist; pa.valid_index = L.valid_index + j - 1; pa.best_on_valid = L.track_best == 2 ? 1 : 0;
+  pa.best_loss = misc + 2; pa.parity = L.parity ^ (j & 1);
+  const bool track = L.track_best == 1 || (L.track_best == 2 && with_valid);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float* s = state + (size_t)k * 4 * pp;
+    PullNet& n = pa.net[k];
+    n.part = s + 3 * pp;
+    n.p_in = s; n.m_in = s + pp; n.v_in = s + 2 * pp;
+    n.p_out = s; n.m_out = s + pp; n.v_out = s + 2 * pp;
+    n.grad = L.net[k].grad; n.best_flat = track ? L.net[k].best_flat : nullptr; n.len = len;
+    n.adam = AdamConsts{L.net[k].lr, L.net[k].b1, L.net[k].b2, L.net[k].eps, L.net[k].wd, L.net[k].bc1[e - L.e0],
+                        L.net[k].bc2s[e - L.e0]};
+  }
+}
+
+
 }  // namespace ndq

@@ -946,6 +946,7 @@ class FusedSystem:
     # ------------------------------------------------------------------------------------------ several epochs per call
     FIT_RUN = os.environ.get("NDQ_FIT_RUN", "1") != "0"
     FIT_PULL = os.environ.get("NDQ_FIT_PULL", "1") != "0"      # one launch per epoch for small grids (pull prologue)
+    FIT_LOOP = os.environ.get("NDQ_FIT_LOOP", "1") != "0"      # one launch per RUN of epochs for one-workgroup grids
 
     def fit_ready(self):
         """May epochs of this system go through ndq_fused_fit_run (closure launch with training + validation workgroups,
@@ -1059,6 +1060,11 @@ class FusedSystem:
                     avp = torch.zeros(ff.valid_blocks, dtype=f32, device=dev)
                     keep.append(avp)
                     ff.alt_valid_loss_partials = avp.data_ptr()
+                # loop mode (one workgroup for the training grid, one for the validation grid: a run of epochs is one launch)
+                if self.FIT_LOOP and blocks == 1 and (valid is None or ff.valid_blocks == 1) and len(self.flat) <= 2 \
+                        and fk.lib.ndq_fused_loop_ok():
+                    ff.launch_loop = ctypes.cast(fk.lib.ndq_fused_launch_loop, ctypes.c_void_p).value
+                    ff.loop_ok = 1
             ent = cache[key] = (ff, keep, fk)
         ff = ent[0]
         step0 = 1
