@@ -192,7 +192,7 @@ int launch_loop(const float* coords, int ldc, int n, float seed, const float* vc
                      *static_cast<const ndq::LoopArgs*>(loop));
   return (int)hipGetLastError();
 }}
-int loop_ok() {{ return ndq::pull_supported<CFG>() ? 1 : 0; }}
+int loop_ok() {{ return ndq::pull_supported<CFG>() && {lds_loop} <= 160 * 1024 ? 1 : 0; }}
 """ if kern_loop else """
 int launch_loop(const float*, int, int, float, const float*, int, int, const void*, void*) { return -2; }
 int loop_ok() { return 0; }
@@ -529,10 +529,13 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         else:
             kern_loop = lds_loop = None
         tv = _tv_launcher(args_t, fill, kern_tv, lds('true'), lds('false'), threads, kern_loop, lds_loop)
+        # hidden-layer weight gradients from the bf16x3 planes through transposing LDS reads (csrc/ndq_mlp.h Cfg::WG_TR;
+        # shapes it does not cover, or whose K images would not fit the LDS, ignore the switch)
+        wg_tr = f"#ifndef NDQ_WG_TR\n#define NDQ_WG_TR 1\n#endif\n#define NDQ_WG_TR_K {K}\n"
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- single-launch closure kernel (forward streams + pointwise stage +
 // reverse pass) of one PDE system with {K} network(s), gfx950.
 #include <cstdlib>
-#include "{header}"
+{wg_tr}#include "{header}"
 #define NDQ_PW_INLINE __device__ __forceinline__
 #ifndef NDQ_MAX_BLOCKS
 #define NDQ_MAX_BLOCKS 256     // closure workgroups per launch (one per CU; experiments: 512 = two 8-wave workgroups per CU)

@@ -3,6 +3,9 @@
 // neurodiffeq_amd/codegen.py builds at run time (hipcc, one Cfg each) for network shapes / stream sets outside that
 // table, which then join the same dispatch through ndq_mlp_register().
 #pragma once
+#ifndef NDQ_WG_TR
+#define NDQ_WG_TR 1     // adjoint kernels of H = 32 networks: weight gradients from the bf16x3 planes (ndq_mlp.h Cfg::WG_TR)
+#endif
 #include "ndq_mlp.h"
 #include "../../include/ndq.h"
 

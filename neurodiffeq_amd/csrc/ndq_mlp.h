@@ -287,6 +287,18 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 #ifndef NDQ_WG_BF16
 #define NDQ_WG_BF16 0     // narrow nets: weight-gradient GEMMs on the bf16 matrix core (split operands) instead of f32 MFMAs
 #endif
+#ifndef NDQ_WG_TR
+#define NDQ_WG_TR 0       // narrow nets, single-launch closure kernels (set by codegen.py for those modules): hidden-layer
+                          // weight gradients on the bf16 matrix core from the bf16x3 planes the forward / hbar GEMMs split
+                          // anyway, transposed by ds_read_b64_tr_b16 (Cfg::WG_TR)
+#endif
+#ifndef NDQ_MULTI_G2
+#define NDQ_MULTI_G2 2      // tile slots per workgroup for K = 2 (experiments: 4 = two waves per SIMD)
+#endif
+#ifndef NDQ_WG_TR_K
+#define NDQ_WG_TR_K 1     // networks of the closure kernel the module is built for (multi-network closure: K weight images
+                          // and K x G staging regions share the workgroup's LDS)
+#endif
 #ifndef NDQ_SPLIT_PAIRS
 #define NDQ_SPLIT_PAIRS 0   // split3 on 2-wide vectors: 3.5 % fewer VALU instructions in C3's closure kernel, no time gained
                             // (C3 418.4 -> 419.8 us, C2 8-wave 19.9 -> 19.7 us on MI355X): off
@@ -529,7 +541,33 @@ struct Cfg {
   // blocks (GradAcc::w32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
   static constexpr bool WG32 = BF16 && (NB_ == 4) && (NDQ_WG32 != 0);
   static constexpr int WG_SB = (NB_ <= 2 && SS::NS >= 2 && (BWD_THREADS == 256 || WG_BF16)) ? 2 : 1;
-  static constexpr int stageFloatsPerWave = WG_SB * 2 * 16 * HP;  // Zt and Ht tiles of WG_SB streams
+  static constexpr int stageFloatsPlain = WG_SB * 2 * 16 * HP;    // Zt and Ht tiles of WG_SB streams
+  // WG_TR (H = 32 on the bf16x3 path, closure kernels built with NDQ_WG_TR): dW_l += sum_s Zbar_s H_s^T contracts over
+  // POINTS, which the fragment layout keeps in lanes -- both operands have to be transposed.  The exact-f32 route stages
+  // fp32 tiles in LDS and feeds 64 v_mfma_f32_16x16x4_f32 per tile (2 048 cycles that overlap with nothing, 4.0).  But
+  // both operands exist as bf16x3 planes already: H_s was split for the forward GEMM z = W h, Zbar_s is split for
+  // hbar = W^T zbar.  The planes go to LDS as [point][unit] images -- a lane's bf16x8 is one ds_write_b128 -- and come
+  // back through ds_read_b64_tr_b16, which hands lane i the 4 points of unit i (a 4 x 4 transpose per read, no VALU):
+  // two reads make the 8 contraction slots of a lane, one v_mfma_f32_16x16x32_bf16 contracts 2 streams x 16 points, and
+  // the six significant plane products of 16 cycles (48 per tile, hidden under VALU work like every bf16 MFMA) replace
+  // the 64 f32 MFMAs, the fp32 staging reads and -- in the 8-wave build -- the recomputation of H_s in the reverse pass.
+  // Per wave: (L - 1) H images of NS streams, kept from the forward pass of the tile, + one Zbar image of 2 streams.
+  static constexpr int trPlane = 256;                      // floats of one plane image: 16 points x 32 units x 2 B
+  static constexpr int trHimg = (L_ - 1) * SS::NS * 3 * trPlane;
+  static constexpr int trStage = trHimg + 2 * 3 * trPlane;
+  static constexpr int trWaves = NDQ_WG_TR_K == 1 ? BWD_THREADS / 64 : (NDQ_WG_TR_K == 2 ? NDQ_MULTI_G2 : 1);   // per network
+  static constexpr bool WG_TR = BF16 && (NB_ == 2) && (L_ >= 2) && (NOUT_ == 1) && (NDQ_WG_TR != 0) && !WG_BF16 &&
+                                (NDQ_WG_TR_K * (ldsWeightsEnd(true) + trWaves * trStage) +
+                                 (NDQ_WG_TR_K > 1 ? 2 * trWaves * NDQ_WG_TR_K * SS::NS * 16 : 0) + 64 <= 40 * 1024);
+  // WG_TR64 (H = 64, same switch): the 32x32x16 weight-gradient GEMM of WG32 fed the same way.  There is no LDS to keep
+  // the forward pass's H planes, so per stream the layer input is recomputed and split in the forward GEMM's operand
+  // layout (16 values per lane instead of the 2 x 16 both operands cost when they are read back as fp32 tiles), the
+  // Zbar planes are the ones hbar = W^T zbar needs anyway; one Zbar and one H image of one stream per wave.
+  static constexpr int trPlane64 = 512;                    // 16 points x 64 units x 2 B
+  static constexpr int trStage64 = 2 * 3 * trPlane64;
+  static constexpr bool WG_TR64 = WG32 && (NOUT_ == 1) && (NDQ_WG_TR != 0) && (NDQ_WG_TR_K == 1) &&
+                                  (ldsWeightsEnd(true) + (BWD_THREADS / 64) * (trStage64 + biasFloats) + 64 <= 40 * 1024);
+  static constexpr int stageFloatsPerWave = WG_TR ? trStage : WG_TR64 ? trStage64 : stageFloatsPlain;
 };
 
 struct MlpArgs {
@@ -1380,6 +1418,26 @@ __device__ __forceinline__ void hidden_layer_grouped(const real* lds, int l, int
   }
 }
 
+// Cfg::WG_TR: the three planes of one stream of one tile as LDS images.  A lane (point p, lane group q) holds units
+// 4q .. 4q+3 of block 0 and of block 1 of its point: 16 bytes, stored at chunk q (256 B apart), slot p ^ 4q (16 B each) --
+// eight consecutive lanes write 128 contiguous bytes (rows of 64 B per point 4-way conflict on the 32-bank write path:
+// measured +30 cycles per ds_write_b128), and the 4 rows x 4 chunks a 16-lane group of the transposing read gathers
+// lie in 16 different slots.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ int tr_slot(int row, int chunk) { return chunk * 64 + ((row ^ (4 * chunk)) * 4); }   // floats
+template <class C>
+__device__ __forceinline__ void tr_store(real* img, int woff, const bf16x8 (&pl)[3]) {     // woff = tr_slot(p, q)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(img + k * C::trPlane + woff) = pl[k];
+}
+// 8 contraction slots of one lane: two transposing reads (4 points each) of the same unit
+__device__ __forceinline__ bf16x8 tr_read8(const real* a0, const real* a1) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 template <class C> struct KeptPlanes {
   // with one wave per SIMD there are registers to spare: the activation streams of every layer are kept from the
   // forward pass instead of being recomputed for the weight-gradient GEMMs and the output-layer gradient
@@ -1388,7 +1446,8 @@ template <class C> struct KeptPlanes {
 
 template <class C, bool BWD>
 __device__ __forceinline__ void tile_forward(const real* lds, int lane, int q, const real (&x)[C::D],
-                                             LayerState<C> (&st)[C::L], real4 (&h)[C::NS][C::NB], KeptPlanes<C>& kp) {
+                                             LayerState<C> (&st)[C::L], real4 (&h)[C::NS][C::NB], KeptPlanes<C>& kp,
+                                             real* stage = nullptr) {
   first_layer<C, BWD>(lds, q, x, st[0]);
   sfor<C::L - 1>([&](auto li_) {
     constexpr int li = decltype(li_)::value;  // computes layer l = li + 2 from layer li + 1
@@ -1396,7 +1455,7 @@ __device__ __forceinline__ void tile_forward(const real* lds, int lane, int q, c
       hidden_layer_grouped<C, BWD>(lds, li + 2, lane, q, st[li], st[li + 1]);
     } else {
       act_forward<C>(st[li], h);
-      if constexpr (BWD && C::KEEP_H) {
+      if constexpr (BWD && C::KEEP_H && !C::WG_TR) {
 #pragma unroll
         for (int s = 0; s < C::NS; ++s)
 #pragma unroll
@@ -1405,6 +1464,10 @@ __device__ __forceinline__ void tile_forward(const real* lds, int lane, int q, c
       if constexpr (C::BF16) {
         Planes<C> P;
         split_all<C>(h, P);
+        if constexpr (BWD && C::WG_TR) {       // the reverse pass reads the planes back transposed (hbar_wgrad_tr)
+#pragma unroll
+          for (int s = 0; s < C::NS; ++s) tr_store<C>(stage + (li * C::NS + s) * 3 * C::trPlane, tr_slot(lane & 15, q), P.pl[s][0]);
+        }
         hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, P, st[li + 1]);
       } else {
         hidden_layer<C, BWD>(lds, li + 2, lane, q, h, st[li + 1]);
@@ -1694,6 +1757,205 @@ __device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q,
   });
 }
 
+// Cfg::WG_TR: hbar = W_l^T zbar and dW_l += sum_s Zbar_s H_s^T of one hidden layer, two streams per round.
+//   ds_read_b64_tr_b16 (lane map measured by scripts/ubench_tr16.hip): result j of lane l is element (l & 3) of the 8
+//   bytes addressed by lane (l & ~15) + 4 j + ((l & 15) >> 2).  Lane (i = l & 15, kg = l >> 4) points at the row of
+//   point 4 (kg & 1) + 8 h + (i >> 2), chunk i & 3, block b's half of the 16 bytes, of stream kg >> 1 of the round: it
+//   receives unit 16 b + i at the points 4 (kg & 1) + 8 h + j -- slot 8 kg + 4 h + j of the 32-wide contraction, the
+//   same map on both operands.  A round with one stream has zero planes in the second Zbar slot (its lanes read H of
+//   the first).  LDS operations of a wave execute in order, so the "barriers" below only pin the compiler's order.
+template <class C, int LI>
+__device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real* stage, int lane, int p, int q,
+                                              real4 (&g)[C::NS][C::NB], real4 (&acc)[C::NB][C::NB]) {
+  static_assert(C::NB == 2 && C::NC == 1, "WG_TR: H = 32");
+  constexpr int NS = C::NS, PL = C::trPlane, NR = (NS + 1) / 2;
+  real* zimg = stage + C::trHimg;
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+  const int kg = lane >> 4, i = lane & 15, strm = kg >> 1;
+  const int woff = tr_slot(p, q);
+  const int r0 = tr_slot(4 * (kg & 1) + (i >> 2), i & 3), r1 = tr_slot(4 * (kg & 1) + 8 + (i >> 2), i & 3);
+  sfor<NR>([&](auto r_) {
+    constexpr int s0 = 2 * decltype(r_)::value;
+    constexpr int sn = (NS - s0 < 2) ? NS - s0 : 2;
+    // H operand of the round: written by the forward pass, independent of everything below -- with the whole register
+    // file (one wave per SIMD) it is in flight first, with 256 registers only once the split planes are stored
+    constexpr bool ROOMY = C::BWD_THREADS == 256;
+    bf16x8 pb[2][3];
+    auto read_h = [&]() {
+      const real* hr = stage + (LI * NS + s0 + (sn == 2 ? strm : 0)) * 3 * PL;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pb[kb][k] = tr_read8(hr + k * PL + kb * 2 + r0, hr + k * PL + kb * 2 + r1);
+    };
+    if constexpr ((NDQ_ABL & 1) == 0 && ROOMY) read_h();
+    {
+      bf16x8 pl[sn][3];
+      real4 o[sn][2];
+#pragma unroll
+      for (int s = 0; s < sn; ++s) {
+        split3(g[s0 + s][0], g[s0 + s][1], pl[s]);
+        tr_store<C>(zimg + s * 3 * PL, woff, pl[s]);
+        o[s][0] = real4{0.f, 0.f, 0.f, 0.f};
+        o[s][1] = real4{0.f, 0.f, 0.f, 0.f};
+      }
+      if constexpr (sn == 1) {
+        bf16x8 zero[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) zero[k][e] = (__bf16)0.f;
+        tr_store<C>(zimg + 3 * PL, woff, zero);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // Zbar operand: read back right away, the hbar MFMAs run while it is on its way
+      bf16x8 pa[2][3];
+      const real* zr = zimg + strm * 3 * PL;
+      if constexpr ((NDQ_ABL & 1) == 0) {
+        if constexpr (!ROOMY) read_h();
+#pragma unroll
+        for (int jb = 0; jb < (ROOMY ? 2 : 1); ++jb)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pa[jb][k] = tr_read8(zr + k * PL + jb * 2 + r0, zr + k * PL + jb * 2 + r1);
+      }
+      if constexpr ((NDQ_ABL & 2) == 0) {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) {
+          const bf16x8 a0 = w[(ob * 3 + 0) * 64 + lane];
+          const bf16x8 a1 = w[(ob * 3 + 1) * 64 + lane];
+          const bf16x8 a2 = w[(ob * 3 + 2) * 64 + lane];
+#define NDQ_T(A, K)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
+      o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][K], o[s][ob], 0, 0, 0);
+          NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < sn; ++s) { g[s0 + s][0] = o[s][0]; g[s0 + s][1] = o[s][1]; }
+      if constexpr ((NDQ_ABL & 1) == 0 && ROOMY) {
+        // product by product over the four accumulator blocks: consecutive MFMAs never wait for one another
+#define NDQ_W(I, J)                                                                                          \
+  _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)          \
+      acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[jb][I], pb[kb][J], acc[jb][kb], 0, 0, 0);
+        NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+#undef NDQ_W
+      } else if constexpr ((NDQ_ABL & 1) == 0) {
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+          if (jb == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pa[0][k] = tr_read8(zr + k * PL + 2 + r0, zr + k * PL + 2 + r1);
+          }
+#define NDQ_W(I, J)                                                                                          \
+  _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                           \
+      acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[0][I], pb[kb][J], acc[jb][kb], 0, 0, 0);
+          NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+#undef NDQ_W
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  });
+}
+
+// Cfg::WG_TR64: hbar = W_l^T zbar and dW_l += sum_s Zbar_s H_s^T of one hidden layer of an H = 64 network, SG streams
+// per group (the weight fragments of the hbar GEMM are read once per group).  A plane image of one stream is two
+// H = 32 images side by side (units 32 c .. 32 c + 31); the 32x32x16 operand of macro-block c: lane (i = l & 31,
+// kg = l >> 5) receives unit 32 c + i at the points 8 kg + 4 h + j from the two transposing reads h = 0, 1 -- lanes
+// 0..15 and 16..31 of a half-wave gather the two 8-byte halves of the same 16-byte slots.
+template <class C>
+__device__ __forceinline__ void hbar_wgrad_tr64(const real* __restrict__ wl, real* stage, int lane, int p, int q,
+                                                const LayerState<C>& st_in, real4 (&g)[C::NS][C::NB], f32x16 (&acc32)[2][2]) {
+  static_assert(C::NB == 4 && C::NC == 2, "WG_TR64: H = 64");
+  constexpr int NS = C::NS, PL = C::trPlane64, NG = (NS + C::SG - 1) / C::SG;
+  real* zimg = stage;
+  real* himg = stage + 3 * PL;
+  const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
+  const int i16 = lane & 15, kg = lane >> 5;
+  const int woff = tr_slot(p, q);
+  const int r0 = tr_slot(8 * kg + (i16 >> 2), i16 & 3) + 2 * ((lane >> 4) & 1), r1 = tr_slot(8 * kg + 4 + (i16 >> 2), i16 & 3) + 2 * ((lane >> 4) & 1);
+  sfor<NG>([&](auto g_) {
+    constexpr int s0 = decltype(g_)::value * C::SG;
+    constexpr int sn = (NS - s0 < C::SG) ? NS - s0 : C::SG;
+    bf16x8 pl[sn][2][3];
+#pragma unroll
+    for (int s = 0; s < sn; ++s)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) split3(g[s0 + s][2 * c], g[s0 + s][2 * c + 1], pl[s][c]);
+    if constexpr ((NDQ_ABL & 1) == 0) {
+      sfor<sn>([&](auto s_) {
+        constexpr int s = decltype(s_)::value;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(zimg + k * PL + c * 256 + woff) = pl[s][c][k];
+        {
+          real4 hs[C::NB];
+          act_forward_stream<C, s0 + s>(st_in, hs);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            bf16x8 ph[3];
+            split3(hs[2 * c], hs[2 * c + 1], ph);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(himg + k * PL + c * 256 + woff) = ph[k];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bf16x8 pb[2][3];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pb[kb][k] = tr_read8(himg + k * PL + kb * 256 + r0, himg + k * PL + kb * 256 + r1);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+          bf16x8 pa[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) pa[k] = tr_read8(zimg + k * PL + jb * 256 + r0, zimg + k * PL + jb * 256 + r1);
+#define NDQ_W(I, J)                                                                                          \
+  _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                           \
+      acc32[jb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[I], pb[kb][J], acc32[jb][kb], 0, 0, 0);
+          NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+#undef NDQ_W
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      });
+    }
+    real4 o[sn][C::NB];
+#pragma unroll
+    for (int s = 0; s < sn; ++s)
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b) o[s][b] = real4{0.f, 0.f, 0.f, 0.f};
+    if constexpr ((NDQ_ABL & 2) == 0) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int ob = 0; ob < C::NB; ++ob) {
+          const bf16x8 a0 = w[((ob * 2 + c) * 3 + 0) * 64 + lane];
+          const bf16x8 a1 = w[((ob * 2 + c) * 3 + 1) * 64 + lane];
+          const bf16x8 a2 = w[((ob * 2 + c) * 3 + 2) * 64 + lane];
+#define NDQ_T(A, K)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
+      o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], o[s][ob], 0, 0, 0);
+          NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < sn; ++s)
+#pragma unroll
+      for (int b = 0; b < C::NB; ++b) g[s0 + s][b] = o[s][b];
+  });
+}
+
 // one stream of hbar = W^T zbar in place: g[s] <- sum over (ib, t) of A(w) * B(g[s][ib][t]); stream by stream so that only
 // one extra fragment is live (the two output blocks alternate as MFMA accumulators, 64 cycles apart > 40 latency)
 template <class C>
@@ -1930,7 +2192,15 @@ __device__ __forceinline__ void tile_backward_hidden(const real* lds, real* stag
       }
     }
     if constexpr (C::WIDE && li == 1) reload_first_layer_streams<C>(lds, q, st[0]);   // needed from here on again
-    if constexpr (C::BF16) {
+    if constexpr (C::WG_TR) {
+      hbar_wgrad_tr<C, li - 1>(lds + C::ldsWt(l), stage, lane, p, q, g, acc.w[l - 2]);
+      NDQ_TT(6 + 3 * (C::L - l));
+      NDQ_TT(7 + 3 * (C::L - l));
+    } else if constexpr (C::WG_TR64) {
+      hbar_wgrad_tr64<C>(lds + C::ldsWt(l), stage, lane, p, q, st[li - 1], g, acc.w32[l - 2]);
+      NDQ_TT(6 + 3 * (C::L - l));
+      NDQ_TT(7 + 3 * (C::L - l));
+    } else if constexpr (C::BF16) {
       weight_grad<C, C::NB, true>(stage, lane, p, q, g, st[li - 1], acc.w[l - 2], kp.h[C::KEEP_H ? li - 1 : 0], acc.w32[l - 2]);
       NDQ_TT(6 + 3 * (C::L - l));
       if constexpr ((NDQ_ABL & 2) == 0) gemm_bf16x3_inplace<C>(lds + C::ldsWt(l), lane, g);
@@ -2213,7 +2483,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
     LayerState<C> st[C::L];
     real4 h[C::NS][C::NB];
     KeptPlanes<C> kp;
-    tile_forward<C, true>(ldsw, lane, q, x, st, h, kp);
+    tile_forward<C, true>(ldsw, lane, q, x, st, h, kp, stage);
     if constexpr (C::NOUT == 1) {
       real gout[C::NS];
 #pragma unroll
@@ -2362,7 +2632,7 @@ __device__ __forceinline__ void fused_closure_body(const FusedArgs& a, real* lds
     real4 h[C::NS][C::NB];
     KeptPlanes<C> kp;
     NDQ_TT(0);
-    tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp);
+    tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp, stage);
     NDQ_TT(1);
     real jets[C::NS], gout[C::NS], r[PW::NR], f[PW::NF > 0 ? PW::NF : 1], gth[PW::NT > 0 ? PW::NT : 1];
     tile_output<C, TRAIN>(ldsw, q, x, h, jets);
@@ -2553,9 +2823,6 @@ struct FusedMultiArgs {
 // still in its registers: no second forward pass, and the serial chain of a round is one network deep instead of K.
 // Waves per workgroup: K x G with G = 2 tile slots for K = 2, one for K = 3, 4 -- never more than one wave per SIMD,
 // so every wave has the whole register file (Cfg must be the 256-thread build: KEEP_H, no laundering).
-#ifndef NDQ_MULTI_G2
-#define NDQ_MULTI_G2 2      // tile slots per workgroup for K = 2 (experiments: 4 = two waves per SIMD)
-#endif
 template <int K> constexpr int multi_group() { return K == 2 ? NDQ_MULTI_G2 : 1; }
 template <int K> constexpr int multi_threads() { return 64 * K * multi_group<K>(); }
 // reduction regions of one network's G waves (they overlay those waves' transpose staging tiles)
@@ -2646,7 +2913,7 @@ __device__ __forceinline__ void fused_multi_closure_body(const FusedMultiArgs& a
     LayerState<C> st[C::L];
     real4 h[C::NS][C::NB];
     KeptPlanes<C> kp;
-    tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp);
+    tile_forward<C, TRAIN>(ldsw, lane, q, x, st, h, kp, stage);
     real* xr = xchg + (par * G + g) * (K * C::NS * 16);        // [K][NS][16 points] of this tile
     {
       real mine[C::NS];

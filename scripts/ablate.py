@@ -7,9 +7,11 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = [("baseline", 0), ("no weight-grad GEMMs", 1), ("no LDS transposes", 16), ("no hbar GEMM", 2),
+VARIANTS = [("baseline", 0), ("no weight-grad GEMMs", 1), ("no hbar GEMM", 2), ("no weight-grad, no hbar GEMM", 1 | 2),
             ("no forward GEMM", 4), ("no act_backward", 8), ("no operand splitting", 32),
             ("no GEMMs at all", 1 | 2 | 4), ("no GEMMs, no split, no act_backward", 1 | 2 | 4 | 8 | 32)]
+if os.environ.get("ABLATE_F32"):      # the exact-f32 weight-gradient route (NDQ_WG_TR=0) has its LDS transposes as a piece of its own
+    VARIANTS.insert(2, ("no LDS transposes", 16))
 CHILD = r"""
 import sys, torch, ctypes
 sys.path.insert(0, %r)
