@@ -299,6 +299,10 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 #define NDQ_WG_TR_K 1     // networks of the closure kernel the module is built for (multi-network closure: K weight images
                           // and K x G staging regions share the workgroup's LDS)
 #endif
+#ifndef NDQ_QUAD_SWAP
+#define NDQ_QUAD_SWAP 0   // quad_sum through v_permlane16/32_swap instead of ds_bpermute: same bits, measured NOT faster (C2 closure
+                          // kernel 19.5 vs 19.2 us: the LDS round trip was never on the critical path) -- off
+#endif
 #ifndef NDQ_SPLIT_PAIRS
 #define NDQ_SPLIT_PAIRS 0   // split3 on 2-wide vectors: 3.5 % fewer VALU instructions in C3's closure kernel, no time gained
                             // (C3 418.4 -> 419.8 us, C2 8-wave 19.9 -> 19.7 us on MI355X): off
@@ -1247,13 +1251,28 @@ __device__ __forceinline__ void hidden_layer_planes(const real* lds, int l, int 
   }
 }
 
-// cross-lane sums: the 4 lane groups are combined through ds_bpermute (v_permlane16/32_swap with both operands equal
-// did not produce the expected exchange on this toolchain and was dropped), the 16 points of a tile -- exactly one DPP
-// row -- by DPP row rotations fused into the adds.  Every lane ends up with the total.
+// cross-lane sums: the 4 lane groups are combined through ds_bpermute (NDQ_QUAD_SWAP: v_permlane16/32_swap, an
+// experiment), the 16 points of a tile -- exactly one DPP row -- by DPP row rotations fused into the adds.  Every lane
+// ends up with the total.
 __device__ __forceinline__ real quad_sum(real v) {  // sum over the 4 lane groups q (lanes p, p+16, p+32, p+48)
+#if NDQ_QUAD_SWAP && !NDQ_F64
+  // v_permlane16_swap / v_permlane32_swap exchange rows between TWO registers; swapping a value with a copy of itself
+  // leaves (own row, partner row) in the pair, whose sum is what v + shfl_xor(v, 16 / 32) computes -- the same two
+  // operands, so the same bits (scripts/ubench_permlane_swap.hip) -- on the VALU, without the LDS round trip
+  // (inline asm: ROCm 7.2's clang folds the two results of __builtin_amdgcn_permlane16/32_swap into one register when
+  // they are added -- v_add v4, v5, v5 after the swap; the s_nop covers the VALU-write -> permlane-read hazard, which
+  // nobody pads inside an asm statement)
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  v = __builtin_bit_cast(real, a) + __builtin_bit_cast(real, b);
+  a = __builtin_bit_cast(unsigned, v); b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return __builtin_bit_cast(real, a) + __builtin_bit_cast(real, b);
+#else
   v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 32);
   return v;
+#endif
 }
 template <int CTRL>
 __device__ __forceinline__ real dpp_add(real v) {
