@@ -599,6 +599,12 @@ def main():
                                # the kernel carries u_xx + u_yy as ONE "Laplacian" stream when the tracer proves the
                                # residual only needs the sum, i.e. it executes 4 streams instead of SURVEY's 5
                                "executed_streams": system.program.streams[0].n_streams,
+                               # every GEMM of the kernel (forward, hbar, and since r03 the weight gradients too) runs as 6
+                               # bf16 plane products on the bf16 matrix core; the yardstick stays the fp32 MFMA peak the
+                               # earlier rounds were priced against, the dense bf16 peak / 6 is given beside it
+                               "peak_note": "fp32 MFMA peak (157.3 TFLOP/s); the kernel's GEMMs are bf16x3 (6 bf16 MFMA "
+                                            "products per fp32-class product): ceiling of that format 2500 / 6 = 416.7 TFLOP/s",
+                               "frac_of_bf16x3_ceiling": kb["fused_closure"]["tflops"] / (2500.0 / 6.0),
                                "executed_gemm_flop_per_point":
                                    3 * 2 * (32 * 2 + 32 * 32 * system.program.streams[0].n_streams
                                             + 32 * system.program.streams[0].n_streams)}

@@ -1017,17 +1017,22 @@ def _header_digest():
 _MLP_EXT = {}
 
 
+MAX_INPUTS = 6          # network inputs the templates are instantiated for (Streams<D, ...>: D (D + 1) / 2 pair bits)
+MAX_LAYERS = 8          # hidden layers of one width (networks.describe); the LDS footprint decides at registration
+
+
 def mlp_ext_allowed(desc):
-    """Can ndq_mlp.h express this descriptor?  (H = 16..64, 1..4 hidden layers, d <= 3; the LDS footprint is checked
-    by ndq_mlp_register once the module is built.)"""
+    """Can ndq_mlp.h express this descriptor?  (H = 1..64, 1..8 hidden layers of one width or 1..4 of different widths,
+    d <= 6; the LDS footprint is checked by ndq_mlp_register once the module is built.)"""
     if os.environ.get("NDQ_JIT_MLP", "1") == "0":
         return False
     npair = desc.d * (desc.d + 1) // 2
     diag = 0
     for a in range(desc.d):
         diag |= 1 << pair_list(desc.d).index((a, a))
-    if desc.mask3:              # third order: tanh / sin / sigmoid, every triple with its three pairs, no Laplacian stream
-        if desc.lap or desc.act not in (0, 1, 2) or desc.mask3 >> len(triple_list(desc.d)):
+    if desc.mask3:              # third order: tanh / sin / sigmoid, every triple with its three pairs, no Laplacian stream,
+        #                         d <= 4 (five inputs have more triples than the 32 mask bits)
+        if desc.lap or desc.d > 4 or desc.act not in (0, 1, 2) or desc.mask3 >> len(triple_list(desc.d)):
             return False
         for k, (a, b, c) in enumerate(triple_list(desc.d)):
             if (desc.mask3 >> k) & 1 and not all((desc.mask2 >> pair_list(desc.d).index(p)) & 1
@@ -1040,7 +1045,7 @@ def mlp_ext_allowed(desc):
             return False
     if desc.mono and (not 0 < desc.mono < 256 or desc.mask3 or desc.skip or desc.hidden > 48):
         return False          # monomial features: degrees 1..8, up to second order, H <= 48, no skip connection
-    return (1 <= desc.d <= 3 and 1 <= desc.hidden <= 64 and 1 <= desc.layers <= 4
+    return (1 <= desc.d <= MAX_INPUTS and 1 <= desc.hidden <= 64 and 1 <= desc.layers <= (4 if desc.widths else MAX_LAYERS)
             and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
             and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0))

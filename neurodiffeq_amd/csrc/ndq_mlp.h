@@ -133,7 +133,7 @@ struct Streams {
   static constexpr int NTRIP = D * (D + 1) * (D + 2) / 6;
   static constexpr int count3() {
     int c = 0;
-    for (int k = 0; k < NTRIP; ++k) c += (M3 >> k) & 1u;
+    for (int k = 0; k < NTRIP && k < 32; ++k) c += (M3 >> k) & 1u;     // (D >= 5 has more triples than mask bits: the first 32)
     return c;
   }
   static constexpr int N3 = count3();
@@ -198,7 +198,7 @@ struct Streams {
   static constexpr int B(int s) { return pair_b(pair_of(s)); }
   static constexpr int tri_of(int s) {      // s >= S3 -> triple index
     int c = S3;
-    for (int k = 0; k < NTRIP; ++k)
+    for (int k = 0; k < NTRIP && k < 32; ++k)
       if ((M3 >> k) & 1u) {
         if (c == s) return k;
         ++c;
@@ -220,7 +220,7 @@ struct Streams {
     return -1;
   }
   static constexpr bool closed3() {
-    for (int k = 0; k < NTRIP; ++k)
+    for (int k = 0; k < NTRIP && k < 32; ++k)
       if ((M3 >> k) & 1u) {
         const int a = tri_x(k, 0), b = tri_x(k, 1), c = tri_x(k, 2);
         if (pair_stream(a, b) < 0 || pair_stream(a, c) < 0 || pair_stream(b, c) < 0) return false;

@@ -575,7 +575,9 @@ def _lib_check(rc):
 @pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "heat_wide",
                                   "stokes_like", "kdv", "ode3", "poisson3d", "hessian3d", "shell", "swish_laplace", "sigmoid_mixed",
                                   "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
-                                  "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode"])
+                                  "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode",
+                                  # beyond round 2's template limits: 6 and 8 hidden layers, 4 and 5 inputs, a 3-parameter bundle
+                                  "shape_32x6", "shape_16x8_sin", "heat4d", "mix5d", "bundle_osc"])
 def test_zoo_closure_matches_autograd_oracle(name, mode):
     """Systems outside the BASELINE set (tests/zoo.py): second-order IVP, sin networks, mixed second derivatives, first
     order only, three coordinates (Laplacian-merged, diagonal and full Hessian stream sets), three networks."""

@@ -157,6 +157,9 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "mono_laplace": [(1, 7, 0)], "mono_ode": [(1, 1, 0)], "mono_poisson": [(1, 5, 1)],
                "shape_64_32": [(1, 5, 1)], "shape_24_40_12_sigmoid": [(1, 5, 1)],
                "shape_50x2": [(1, 5, 1)], "shape_20x3": [(1, 5, 1)], "shape_40x2_sigmoid": [(1, 5, 1)], "shape_10x1": [(1, 5, 1)],
+               "shape_32x6": [(1, 5, 1)], "shape_16x8_sin": [(1, 5, 1)],
+               # four / five inputs: 10 / 15 pair bits -- xx, yy, zz of (x, y, z, t) merged into one Laplacian stream; cc and ae
+               "heat4d": [(1, 145, 1)], "mix5d": [(1, 528, 0)], "bundle_osc": [(1, 1, 0)],
                # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along
                "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)]}
 

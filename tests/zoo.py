@@ -156,12 +156,14 @@ def build(name):
         return System(name, 2, [(2, 1, (32, 32), "tanh")], [(0.0, 1.0), (-1.0, 1.0)], pde, conds, lambda D: [e])
     # ---- network shapes outside libndq.so's table: compiled on first use as extension modules (codegen.ensure_mlp_kernels)
     if name in ("shape_64x2", "shape_32x3", "shape_48x2", "shape_16x2_sin", "shape_32x1", "shape_50x2", "shape_20x3",
-                "shape_40x2_sigmoid", "shape_10x1", "shape_64_32", "shape_24_40_12_sigmoid"):
+                "shape_40x2_sigmoid", "shape_10x1", "shape_64_32", "shape_24_40_12_sigmoid", "shape_32x6", "shape_16x8_sin"):
         # widths that are no multiple of 16 run padded (csrc/ndq_mlp.h: Cfg::HR); sigmoid: the padding units output 1/2
         hidden, act = {"shape_64x2": ((64, 64), "tanh"), "shape_32x3": ((32, 32, 32), "tanh"),
                        "shape_48x2": ((48, 48), "tanh"), "shape_16x2_sin": ((16, 16), "sin"),
                        "shape_32x1": ((32,), "tanh"), "shape_50x2": ((50, 50), "tanh"), "shape_20x3": ((20, 20, 20), "tanh"),
                        "shape_40x2_sigmoid": ((40, 40), "sigmoid"), "shape_10x1": ((10,), "sin"),
+                       # more than four hidden layers of one width (the reference's FCNN takes any depth, networks.py:26-66)
+                       "shape_32x6": ((32,) * 6, "tanh"), "shape_16x8_sin": ((16,) * 8, "sin"),
                        # hidden layers of different widths: laid out for the widest one (ndq_mlp_desc.widths)
                        "shape_64_32": ((64, 32), "tanh"), "shape_24_40_12_sigmoid": ((24, 40, 12), "sigmoid")}[name]
         f0 = lambda y: torch.sin(PI * y)
@@ -169,6 +171,24 @@ def build(name):
         conds = lambda: [C.DirichletBVP2D(0, f0, 1, zero, 0, zero, 1, zero)]
         return System(name, 2, [(2, 1, hidden, act)], [(0.0, 1.0), (0.0, 1.0)], pde, conds,
                       lambda D: [_R().dirichlet_bvp2d(0, f0, 1, zero, 0, zero, 1, zero)])
+    # ---- more than three network inputs (round 3: d <= 6)
+    if name == "heat4d":              # heat equation in three space dimensions + time: a Laplacian stream over 3 of 4 inputs
+        pde = lambda D: (lambda u, x, y, z, t: [D(u, t) - 0.3 * (D(u, x, order=2) + D(u, y, order=2) + D(u, z, order=2))
+                                                + u ** 2 - torch.exp(-t) * torch.sin(x + y * z)])
+        conds = lambda: [C.NoCondition()]
+        return System(name, 4, [(4, 1, (32, 32), "tanh")], [(-1.0, 1.0)] * 3 + [(0.0, 1.0)], pde, conds,
+                      lambda D: [lambda net, x, y, z, t: net(_cat(x, y, z, t))])
+    if name == "mix5d":               # five inputs: first derivatives of all, one pure and one mixed second derivative
+        pde = lambda D: (lambda u, a, b, c, d, e: [D(u, a) + u * D(u, b) - D(u, c, order=2) - D(u, d) * D(u, e)
+                                                   + 0.5 * D(D(u, a), e) - torch.cos(a * b + c) * d])
+        conds = lambda: [C.NoCondition()]
+        return System(name, 5, [(5, 1, (32, 32), "sin")], [(-1.0, 1.0)] * 5, pde, conds,
+                      lambda D: [lambda net, a, b, c, d, e: net(_cat(a, b, c, d, e))])
+    if name == "bundle_osc":          # bundle of IVPs with THREE parameters: u'' + w^2 u = 0, u(0) = u0, u'(0) = v0 (BundleSolver1D)
+        pde = lambda D: (lambda u, t, u0, v0, w: [D(u, t, order=2) + w ** 2 * u])
+        conds = lambda: [C.BundleIVP(t_0=0.0, bundle_param_lookup={"u_0": 0, "u_0_prime": 1})]
+        enf = lambda D: [lambda net, t, u0, v0, w: u0 + t * v0 + (1 - torch.exp(-t)) ** 2 * net(_cat(t, u0, v0, w))]
+        return System(name, 4, [(4, 1, (32, 32), "tanh")], [(0.0, 1.0), (0.5, 2.0), (-1.0, 1.0), (0.5, 2.0)], pde, conds, enf)
     if name == "resnet_laplace":      # Resnet (networks.py:73-106): FCNN + trainable linear skip, on the C2 problem
         f0 = lambda y: torch.sin(PI * y)
         pde = lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2)])
@@ -283,7 +303,7 @@ NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "he
          "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode", "swish_tr_laplace", "aptx_tr_laplace",
          "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1",
          "swish_fixed_laplace", "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid",
-         "mono_laplace", "mono_ode", "mono_poisson"]
+         "mono_laplace", "mono_ode", "mono_poisson", "shape_32x6", "shape_16x8_sin", "heat4d", "mix5d", "bundle_osc"]
 
 
 def spherical_solver_problem():
