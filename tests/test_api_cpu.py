@@ -350,11 +350,14 @@ def test_describe_recognises_the_network_family():
     assert (d["d"], d["mono"], d["hidden"]) == (2, 0b111, 32)
     d = describe(nn.Sequential(MonomialNN([1, 3]), nn.Linear(2, 16), nn.Tanh(), nn.Linear(16, 2)))
     assert (d["d"], d["mono"], d["hidden"], d["layers"], d["n_out"]) == (1, 0b101, 16, 1, 2)
-    # turned down: unsorted degrees, a feature count that is no multiple of the degree count, five hidden layers,
-    # mixed activations, a bias-free layer, fp64 parameters under an fp32 description
+    # turned down: unsorted degrees, a feature count that is no multiple of the degree count, nine hidden layers (five
+    # of DIFFERENT widths), mixed activations, a bias-free layer, fp64 parameters under an fp32 description
     assert describe(nn.Sequential(MonomialNN([2, 1]), FCNN(2, 1))) is None
     assert describe(nn.Sequential(MonomialNN(3), FCNN(5, 1))) is None
-    assert describe(FCNN(1, 1, hidden_units=(16,) * 5)) is None
+    d = describe(FCNN(1, 1, hidden_units=(16,) * 5))           # since round 3: up to 8 hidden layers of one width
+    assert (d["hidden"], d["layers"], d["widths"]) == (16, 5, 0)
+    assert describe(FCNN(1, 1, hidden_units=(16,) * 9)) is None
+    assert describe(FCNN(1, 1, hidden_units=(16, 32, 16, 32, 16))) is None
     assert describe(nn.Sequential(nn.Linear(1, 16), nn.Tanh(), nn.Linear(16, 16), nn.Sigmoid(), nn.Linear(16, 1))) is None
     assert describe(nn.Sequential(nn.Linear(1, 16, bias=False), nn.Tanh(), nn.Linear(16, 1))) is None
     assert describe(FCNN(1, 1).double()) is None and describe(FCNN(1, 1).double(), dtype=torch.float64) is not None
