@@ -299,6 +299,11 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 #define NDQ_WG_TR_K 1     // networks of the closure kernel the module is built for (multi-network closure: K weight images
                           // and K x G staging regions share the workgroup's LDS)
 #endif
+#ifndef NDQ_FWD_BF16X1
+#define NDQ_FWD_BF16X1 0  // opt-in (a library of its own: NDQ_LIB_FLAGS=-DNDQ_FWD_BF16X1=1): the hidden-layer GEMMs of the forward
+                          // STREAM kernel (mlp_jet_fwd_kernel, three-kernel pipeline) on single bf16 operands -- BASELINE config 5's
+                          // "bf16 fwd / fp32 grad"; the adjoint kernels recompute their forward pass in bf16x3 as always
+#endif
 #ifndef NDQ_QUAD_SWAP
 #define NDQ_QUAD_SWAP 0   // quad_sum through v_permlane16/32_swap instead of ds_bpermute: same bits, measured NOT faster (C2 closure
                           // kernel 19.5 vs 19.2 us: the LDS round trip was never on the critical path) -- off
@@ -1023,6 +1028,13 @@ __device__ __forceinline__ void split3(const real4 a, const real4 b, bf16x8 (&pl
 #endif
 }
 
+// NDQ_FWD_BF16X1: plane 0 alone (round to nearest even), the other two stay unset and unread
+__device__ __forceinline__ void split1(const real4 a, const real4 b, bf16x8 (&pl)[3]) {
+  const real x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pl[0][e] = (__bf16)x[e];
+}
+
 template <class C>
 __device__ __forceinline__ void split_all(const real4 (&h)[C::NS][C::NB], Planes<C>& P) {
 #pragma unroll
@@ -1032,7 +1044,7 @@ __device__ __forceinline__ void split_all(const real4 (&h)[C::NS][C::NB], Planes
 }
 
 // z[s][ob] += W h[s] with h given as bf16x3 planes
-template <class C>
+template <class C, bool X1 = false>
 __device__ __forceinline__ void gemm_planes(const real* __restrict__ wl, int lane, const Planes<C>& P,
                                             real4 (&z)[C::NS][C::NB]) {
   const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
@@ -1041,6 +1053,11 @@ __device__ __forceinline__ void gemm_planes(const real* __restrict__ wl, int lan
 #pragma unroll
     for (int ob = 0; ob < C::NB; ++ob) {
       const bf16x8 a0 = w[((ob * C::NC + c) * 3 + 0) * 64 + lane];
+      if constexpr (X1) {                  // NDQ_FWD_BF16X1: the leading planes only
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) z[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, P.pl[s][c][0], z[s][ob], 0, 0, 0);
+        continue;
+      }
       const bf16x8 a1 = w[((ob * C::NC + c) * 3 + 1) * 64 + lane];
       const bf16x8 a2 = w[((ob * C::NC + c) * 3 + 2) * 64 + lane];
 #define NDQ_T(A, K)                                                                                          \
@@ -1233,14 +1250,14 @@ __device__ __forceinline__ void hidden_layer(const real* lds, int l, int lane, i
 }
 
 // same with the layer input given as bf16x3 planes
-template <class C, bool BWD>
+template <class C, bool BWD, bool X1 = false>
 __device__ __forceinline__ void hidden_layer_planes(const real* lds, int l, int lane, int q, const Planes<C>& P,
                                                     LayerState<C>& st) {
   real4 z[C::NS][C::NB];
   zero_frag<C>(z);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) z[0][b] = lds4(lds + C::ldsb(l, BWD) + 16 * b + 4 * q);
-  if constexpr ((NDQ_ABL & 4) == 0) gemm_planes<C>(lds + C::ldsWf(l, BWD), lane, P, z);
+  if constexpr ((NDQ_ABL & 4) == 0) gemm_planes<C, X1>(lds + C::ldsWf(l, BWD), lane, P, z);
   load_alpha<C, BWD>(lds, l, st);
 #pragma unroll
   for (int b = 0; b < C::NB; ++b) {
@@ -1382,17 +1399,24 @@ __device__ __forceinline__ void output_layer_mfma(const real* lds, int lane, int
 
 // forward pass of one tile keeping every layer's state; h = streams of the last hidden layer's activations
 // forward-only hidden layer on the bf16x3 path (planes are transient)
-template <class C>
+template <class C, bool X1 = false>
 __device__ __forceinline__ void gemm_layer_bf16(const real* lds, int l, int lane, int q, const real4 (&h)[C::NS][C::NB],
                                                 LayerState<C>& st) {
   Planes<C> P;
-  split_all<C>(h, P);
-  hidden_layer_planes<C, false>(lds, l, lane, q, P, st);
+  if constexpr (X1) {
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+      for (int c = 0; c < C::NC; ++c) split1(h[s][2 * c], h[s][2 * c + 1], P.pl[s][c]);
+  } else {
+    split_all<C>(h, P);
+  }
+  hidden_layer_planes<C, false, X1>(lds, l, lane, q, P, st);
 }
 
 // hidden layer on the bf16x3 path for wide nets: SG streams at a time, each group's activations h[s] computed from the
 // input layer's state right before they are split into planes (never more than SG streams of h and of planes live)
-template <class C, bool BWD>
+template <class C, bool BWD, bool X1 = false>
 __device__ __forceinline__ void hidden_layer_grouped(const real* lds, int l, int lane, int q, const LayerState<C>& st_in,
                                                      LayerState<C>& st) {
   real4 z[C::NS][C::NB];
@@ -1410,13 +1434,22 @@ __device__ __forceinline__ void hidden_layer_grouped(const real* lds, int l, int
       real4 hs[C::NB];
       act_forward_stream<C, s0 + s>(st_in, hs);
 #pragma unroll
-      for (int c = 0; c < C::NC; ++c) split3(hs[2 * c], hs[2 * c + 1], pl[s][c]);
+      for (int c = 0; c < C::NC; ++c) {
+        if constexpr (X1) split1(hs[2 * c], hs[2 * c + 1], pl[s][c]);
+        else split3(hs[2 * c], hs[2 * c + 1], pl[s][c]);
+      }
     });
 #pragma unroll
     for (int c = 0; c < C::NC; ++c)
 #pragma unroll
       for (int ob = 0; ob < C::NB; ++ob) {
         const bf16x8 a0 = w[((ob * C::NC + c) * 3 + 0) * 64 + lane];
+        if constexpr (X1) {                // NDQ_FWD_BF16X1: the leading planes only
+#pragma unroll
+          for (int s = 0; s < sn; ++s)
+            z[s0 + s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, pl[s][c][0], z[s0 + s][ob], 0, 0, 0);
+          continue;
+        }
         const bf16x8 a1 = w[((ob * C::NC + c) * 3 + 1) * 64 + lane];
         const bf16x8 a2 = w[((ob * C::NC + c) * 3 + 2) * 64 + lane];
 #define NDQ_T(A, K)                                                                                          \
@@ -1523,11 +1556,12 @@ __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) 
     real4 h[C::NS][C::NB];
 #pragma unroll
     for (int l = 2; l <= C::L; ++l) {
+      constexpr bool X1 = NDQ_FWD_BF16X1 != 0;
       if constexpr (C::BF16 && C::WIDE) {
-        hidden_layer_grouped<C, false>(ldsw, l, lane, q, st, st);
+        hidden_layer_grouped<C, false, X1>(ldsw, l, lane, q, st, st);
       } else {
         act_forward<C>(st, h);
-        if constexpr (C::BF16) gemm_layer_bf16<C>(ldsw, l, lane, q, h, st);
+        if constexpr (C::BF16) gemm_layer_bf16<C, X1>(ldsw, l, lane, q, h, st);
         else hidden_layer<C, false>(ldsw, l, lane, q, h, st);
       }
     }
