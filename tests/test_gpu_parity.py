@@ -609,6 +609,38 @@ def test_zoo_closure_matches_autograd_oracle(name, mode):
     assert max(errs.values()) < TOL, errs
 
 
+@pytest.mark.parametrize("name", ["pendulum", "advection", "helmholtz_xy", "sigmoid_mixed"])
+def test_zoo_closure_on_the_eight_wave_build(name):
+    """Batches of 65 536+ points go to the 8-wave build of the closure kernel (two waves per SIMD, 256 registers each:
+    engine.fused_variant), whose weight-gradient route (csrc/ndq_mlp.h hbar_wgrad_tr, the branch without the whole register
+    file) the BASELINE configs only exercise with C2's four streams: three streams (a round with ONE stream: zero planes in
+    the second slot) and six (three full rounds) against the fp64 autograd oracle."""
+    from tests import zoo
+    from neurodiffeq_amd.engine import FusedSystem
+    torch.manual_seed(11)
+    system = zoo.build(name)
+    nets, conds, pde = system.product()
+    flat = R.get_flat(nets)
+    n_pts = 65536 - 37            # 4 094 tiles: two rounds of 2 048 waves (engine.prefers_wide), the last tile ragged
+    coords = system.sample(n_pts, seed=5)
+    onets, enforcers, opde = system.oracle(flat)
+    want = R.closure(onets, enforcers, opde, coords)
+    want_grad = R.get_flat_grad(onets).numpy()
+    for net in nets:
+        net.to("cuda")
+    fs = FusedSystem(nets, conds, pde, system.n_coords, "cuda")
+    assert fs.fusedk is not None
+    b, n = fs.step([c.float() for c in coords], train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    assert b["fusedk"].threads == 512, b["fusedk"].threads
+    errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), want["funcs"].numpy()),
+                residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy(), want["residuals"].numpy()),
+                loss=abs(fs.loss_buf[0].item() - want["loss"].item()) / abs(want["loss"].item()),
+                grad=rel_l2(np.concatenate([fp.grad.cpu().numpy() for fp in fs.flat]), want_grad))
+    diag(f"zoo8w_{name}", errs)
+    assert max(errs.values()) < TOL, errs
+
+
 @pytest.mark.parametrize("name,kind,mode", [("helmholtz_xy", "l1", "1k"), ("stokes_like", "l1", "1k"), ("stokes_like", "infinity", "1k"),
                                             ("stokes_like", "infinity", "3k"), ("pendulum", "infinity", "1k")])
 def test_l1_and_infinity_losses_match_autograd_oracle(name, kind, mode):
