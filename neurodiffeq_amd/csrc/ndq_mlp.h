@@ -20,9 +20,11 @@
 //  * per-point GEMMs (z = W h, hbar = W^T zbar; K = H) run on the bf16 matrix core with 3-way split operands
 //    ("bf16x3", fp32-class accuracy, overlaps with the activation math); widths that are not a multiple of 32 fall
 //    back to the exact f32 MFMA.
-//  * weight gradients of hidden layers contract over points with heavy cancellation and stay on the exact f32 MFMA
-//    (bitwise an fmaf chain); the operands need the point index on the MFMA k axis, i.e. a transpose of the
-//    fragments, which goes through a padded (ld = H+4) per-wave LDS tile (conflict-free b128 writes / b32 reads).
+//  * weight gradients of hidden layers contract over POINTS, so both operands need the point index on the MFMA k
+//    axis, i.e. a transpose of the fragments.  Closure / adjoint kernels of H = 32 and H = 64 networks (Cfg::WG_TR,
+//    Cfg::WG_TR64; round 3): the bf16x3 planes the forward / hbar GEMMs split anyway go to LDS and come back through
+//    ds_read_b64_tr_b16, six plane products on the bf16 matrix core.  Everything else (other widths, the grouped
+//    closure, fp64): fp32 tiles through a padded (ld = H+4) per-wave LDS tile into the exact f32 MFMA.
 //  * "Laplacian stream" (LAP = 1): when the residual needs second derivatives only through their sum, ONE stream
 //    carries sum_a d2/dx_a^2 instead of one stream per coordinate.
 //  * all reductions are fixed-order: DPP row rotations / lane shuffles -> per-wave LDS regions -> workgroup ->
@@ -254,12 +256,11 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 #ifndef NDQ_BF16X3
 #define NDQ_BF16X3 1
 #endif
-// The weight gradients stay on the exact-f32 MFMA: a bf16x3 variant (fragments transposed by MFMAs against 0/1
-// selection operands, six split products) was implemented, measured and REJECTED.  dW = sum over points of zbar * h
-// cancels heavily (|sum| << sum |terms|) and the bf16 matrix core's internal fp32 accumulation of its 32 products is
-// visibly less precise than an fmaf chain: with real PDE adjoints the gradient came out 9e-5 off (rel-L2, C2 closure)
-// although every factor was an exact bf16x3 split, versus 2e-7 with the f32 MFMA.  The per-point forward / hbar
-// GEMMs do not accumulate across points and stay at fp32-class error (4e-7).
+// Weight gradients: a first bf16x3 variant in round 1 (fragments transposed by MFMAs against 0/1 selection operands,
+// six split products) came out 9e-5 off (rel-L2, C2 closure) and was rejected -- the transposing products themselves
+// went through the bf16 matrix core.  The route of round 3 (Cfg::WG_TR / WG_TR64) transposes the bf16 PLANES through
+// LDS (ds_read_b64_tr_b16: exact) and passes the gradient goldens at the level of the f32 MFMA route (1e-7 ... 6e-6,
+// incl. the trained states of tests/golden/c2_trained.npz, c3_trained.npz).
 #ifndef NDQ_WIDE_LOWREG
 #define NDQ_WIDE_LOWREG 1
 #endif
