@@ -316,7 +316,11 @@ class FusedSystem:
     def attach_theta_grads(self):
         """``p.grad`` of every trainable scalar = its entry of ``gtheta`` (what loss.backward() leaves, solvers.py:393)."""
         for j, p in enumerate(self.theta_params):
-            p.grad = self.gtheta[j].reshape(p.shape).to(p.device, p.dtype)
+            g = self.gtheta[j].reshape(p.shape).to(p.device, p.dtype)
+            if p.grad is not None and p.grad.shape == g.shape and p.grad.data_ptr() != self.gtheta[j].data_ptr():
+                p.grad.copy_(g)
+            else:
+                p.grad = g.clone()       # never a view of the shared buffer: the next epoch rewrites gtheta in place
 
     # ------------------------------------------------------------------------------------------ buffers
     def _resident_ld(self, batch):

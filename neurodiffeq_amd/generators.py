@@ -597,6 +597,8 @@ def draws_have_fixed_size(g):
         return True
     if type(g) in (ConcatGenerator, EnsembleGenerator, MeshGenerator):
         return all(draws_have_fixed_size(x) for x in g.generators)
+    if type(g) is ResampleGenerator and not g.replacement and g.size > g.generator.size:
+        return False                  # randperm(generator.size)[:size] yields generator.size points, not `size`
     if type(g) in (ResampleGenerator, BatchGenerator):
         return draws_have_fixed_size(g.generator)
     return False

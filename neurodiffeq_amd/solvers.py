@@ -617,6 +617,10 @@ class BaseSolver(ABC):
             system.fit_run([], 0, 0, None, (ptr, n, b["ld"]), track_best=2)
         return True
 
+    #: methods the reference's fit loop goes through every epoch (solvers.py:443-497); the multi-epoch path skips them
+    _PER_EPOCH_METHODS = ("run_train_epoch", "run_valid_epoch", "_run_epoch", "_generate_batch", "_generate_train_batch",
+                          "_generate_valid_batch")
+
     #: epochs per native call of the multi-epoch fit path (bounded further by the device-side history ring and by 64 MiB
     #: of staged collocation points)
     FIT_CHUNK = 256
@@ -633,6 +637,13 @@ class BaseSolver(ABC):
             return 0
         if not self._native_ok() or not system.fit_ready() or getattr(system.program, "loss_probe", None) is not None:
             return 0
+        if system.n_data:
+            # per-point data columns ride behind the coordinates of every uploaded batch (engine.upload); the blocks this
+            # path stages hold coordinates only, so such systems run epoch by epoch
+            return 0
+        cls = type(self)
+        if any(getattr(cls, m) is not getattr(BaseSolver, m) for m in self._PER_EPOCH_METHODS):
+            return 0                      # a subclass hooks the per-epoch methods the reference's fit loop calls: keep calling them
         nv = self.n_batches["valid"]
         tg, vg = self.generator["train"], self.generator["valid"]
         if not draws_have_fixed_size(tg) or (nv > 0 and not draws_are_static(vg)):
@@ -646,6 +657,8 @@ class BaseSolver(ABC):
             return 0
         if not all(self.optimizer.bound(fp) for fp in system.flat):
             return 0
+        if len({self.optimizer._steps.get(id(fp)) for fp in system.flat}) != 1:
+            return 0                      # networks at different Adam step counts (edited optimiser state): epoch by epoch
         fs = system.fast_state()
         if max(fs["pending"], fs["pending_valid"]) + 2 > system.HIST:
             self._flush_device_history()

@@ -427,26 +427,35 @@ class _TwinMode(torch.overrides.TorchFunctionMode):
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         out = func(*args, **kwargs)
+        name = getattr(func, "__name__", "")
+        if isinstance(out, torch.Tensor) and id(out) in self.g.twins and self.g.twins[id(out)][0] is out:
+            # the call returned a tensor that already has a twin: an in-place update (a += 1.0, a.mul_(k), a[0] = v).
+            # Its twin describes the OLD value -- drop it, the tensor is refused from here on (TraceUnsupported ->
+            # composite path) instead of training a different equation
+            if out._version != self.g.twins[id(out)][2] or name.endswith("_") or name.startswith("__i"):
+                self.g.twins[id(out)] = (out, None, -1)
+            return out
         if isinstance(out, torch.Tensor) and out.requires_grad and out.grad_fn is not None and id(out) not in self.g.twins:
             try:
-                node = self._mirror(getattr(func, "__name__", ""), args, kwargs)
+                node = self._mirror(name, args, kwargs, out)
             except TraceUnsupported:
                 node = None
             if node is not None:
-                self.g.twins[id(out)] = (out, node)          # (the tensor is kept alive: ids are not reused)
+                # (the tensor is kept alive: ids are not reused; its version counter tells an in-place edit later on)
+                self.g.twins[id(out)] = (out, node, out._version)
         return out
 
     def _operand(self, v):
         g = self.g
         if isinstance(v, torch.Tensor):
             tw = g.twins.get(id(v))
-            if tw is not None and tw[0] is v:
+            if tw is not None and tw[0] is v and tw[1] is not None and tw[2] == v._version:
                 return tw[1]
             if v.requires_grad and not (v.is_leaf and v.numel() == 1):
                 raise TraceUnsupported("untracked tensor with an autograd history")
         return _as_node(g, v)
 
-    def _mirror(self, name, args, kwargs):
+    def _mirror(self, name, args, kwargs, out=None):
         g = self.g
         if name in _TWIN_BINARY and len(args) >= 2 and not kwargs:
             return getattr(g, _TWIN_BINARY[name])(self._operand(args[0]), self._operand(args[1]))
@@ -460,6 +469,8 @@ class _TwinMode(torch.overrides.TorchFunctionMode):
             a = self._operand(args[0])
             return g.mul(a, a)
         if name in _TWIN_SHAPE and args and isinstance(args[0], torch.Tensor):
+            if name == "__getitem__" and (out is None or out.numel() != args[0].numel()):
+                return None                                  # b[0:4] is not "the column b": only shape-preserving indexing is mirrored
             return self._operand(args[0])                    # a scalar stays a scalar, a column a column
         return None
 
@@ -468,7 +479,8 @@ def _row_values(v):
     """A constant row vector (tensor / ndarray / list with more than one element) as a list of floats, else None."""
     if isinstance(v, torch.Tensor) and v.numel() > 1:
         if v.requires_grad:
-            if _CURRENT and getattr(_CURRENT[-1], "twins", {}).get(id(v), (None,))[0] is v:
+            tw = getattr(_CURRENT[-1], "twins", {}).get(id(v)) if _CURRENT else None
+            if tw is not None and tw[0] is v and tw[1] is not None and tw[2] == v._version:
                 return None          # torch expression of trainable scalars and data columns: _as_node returns its twin
             raise TraceUnsupported("a trainable tensor of more than one element inside the equations (trainable SCALARS are "
                                    "traced; a vector would need one kernel argument per entry)")
@@ -496,7 +508,7 @@ def _as_node(g, v):
         return v.i
     if isinstance(v, torch.Tensor) and v.requires_grad and not v.is_leaf:
         tw = getattr(g, "twins", {}).get(id(v))          # a torch expression of trainable scalars seen by _TwinMode
-        if tw is not None and tw[0] is v:
+        if tw is not None and tw[0] is v and tw[1] is not None and tw[2] == v._version:
             return tw[1]
     if isinstance(v, numbers.Number):
         return g.const(float(v))

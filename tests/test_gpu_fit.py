@@ -301,3 +301,59 @@ def test_inverse_problem_solver_trajectory_matches_reference_golden(golden_dir, 
     params = R.get_flat(cfg["nets"]).cpu().numpy()
     assert np.linalg.norm(params - gold["traj_params"]) <= 1e-5 * np.linalg.norm(gold["traj_params"])
     assert np.allclose([p.item() for p in cfg["theta"]], gold["traj_theta"], rtol=1e-5)
+
+
+def test_fit_with_a_per_point_data_column_equals_single_epochs():
+    """a system whose equations read an (N, 1) data column must not go through the staged blocks of the
+    multi-epoch path (they hold coordinates only) -- fit(k) equals k x (run_train_epoch, run_valid_epoch) bit for bit."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.generators import Generator1D
+    from neurodiffeq_amd.solvers import Solver1D
+    runs = {}
+    for how in ("fit", "single"):
+        torch.manual_seed(3)
+        data = torch.linspace(0.0, 1.0, 64).reshape(-1, 1).to("cuda")
+        solver = Solver1D(lambda u, t: [diff(u, t) + u - data], [IVP(0.0, 1.0)],
+                          train_generator=Generator1D(64, 0.0, 2.0, method="equally-spaced"),
+                          valid_generator=Generator1D(64, 0.0, 2.0, method="equally-spaced"))
+        solver.fused = "require"
+        torch.manual_seed(4)
+        if how == "fit":
+            solver.fit(6)
+        else:
+            for _ in range(6):
+                solver.run_train_epoch()
+                solver.run_valid_epoch()
+        assert solver.fused_active
+        runs[how] = (np.array(solver.metrics_history["train_loss"]), np.array(solver.metrics_history["valid_loss"]),
+                     R.get_flat(solver.nets).cpu().numpy())
+    for a, b in zip(runs["fit"], runs["single"]):
+        assert np.array_equal(a, b)
+    # and the column really is part of the equation: without it the first loss differs
+    torch.manual_seed(3)
+    plain = Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)],
+                     train_generator=Generator1D(64, 0.0, 2.0, method="equally-spaced"),
+                     valid_generator=Generator1D(64, 0.0, 2.0, method="equally-spaced"))
+    torch.manual_seed(4)
+    plain.fit(1)
+    assert abs(plain.metrics_history["train_loss"][0] - runs["fit"][0][0]) > 1e-4
+
+
+def test_fit_keeps_calling_overridden_per_epoch_methods():
+    """a subclass that hooks run_train_epoch / _generate_batch (what the reference's fit loop calls every
+    epoch, solvers.py:443-497) is not bypassed by the multi-epoch native path."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.solvers import Solver1D
+    calls = []
+
+    class Hooked(Solver1D):
+        def run_train_epoch(self):
+            calls.append(self.global_epoch)
+            return super().run_train_epoch()
+
+    torch.manual_seed(0)
+    s = Hooked(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], t_min=0.0, t_max=2.0)
+    s.fit(5)
+    assert len(calls) == 5 and len(s.metrics_history["train_loss"]) == 5

@@ -584,3 +584,35 @@ def test_inverse_problem_trajectory_on_the_composite_path(golden_dir, name):
     assert np.allclose(solver.metrics_history["train_loss"], gold["traj_loss"], rtol=2e-5)
     assert rel_l2(R.get_flat(cfg["nets"]).numpy(), gold["traj_params"]) < 1e-5
     assert np.allclose([p.item() for p in cfg["theta"]], gold["traj_theta"], rtol=1e-5)
+
+
+def test_twin_of_a_tensor_updated_in_place_is_dropped():
+    """``a = k * f; a += 1.0`` -- the twin recorded for ``a`` describes the old value; the tensor must be refused
+    (composite path), not traced as k * f.  Slices of a twinned column are not the column."""
+    from neurodiffeq_amd.symbolic import Graph, trace_scope, TraceUnsupported, _as_node
+    g = Graph(1)
+    k = torch.nn.Parameter(torch.tensor(2.0))
+    f = torch.linspace(0, 1, 8).reshape(-1, 1)
+    with trace_scope(g):
+        a = k * f
+        assert isinstance(_as_node(g, a), int)
+        a += 1.0
+        with pytest.raises(TraceUnsupported):
+            _as_node(g, a)
+        b = k * f
+        b.mul_(3.0)
+        with pytest.raises(TraceUnsupported):
+            _as_node(g, b)
+        c = k * f
+        with pytest.raises(TraceUnsupported):
+            _as_node(g, c[0:4])
+        assert _as_node(g, c[:, 0:1]) == _as_node(g, c)
+        assert _as_node(g, (k * f).reshape(-1, 1)) == _as_node(g, k * f)
+
+
+def test_resample_generator_larger_than_its_source_is_not_fixed_size():
+    from neurodiffeq_amd.generators import Generator1D, ResampleGenerator, draws_have_fixed_size
+    g = Generator1D(16, 0.0, 1.0)
+    assert draws_have_fixed_size(ResampleGenerator(g, size=8))
+    assert not draws_have_fixed_size(ResampleGenerator(g, size=32, replacement=False))
+    assert draws_have_fixed_size(ResampleGenerator(g, size=32, replacement=True))
