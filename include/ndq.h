@@ -27,12 +27,14 @@ extern "C" {
  *   0: value | 1..d: d/dx_a (if first) | second-order pairs (a<=b) selected by mask2, enumerated
  *   (0,0),(0,1),..,(0,d-1),(1,1),..  (bit k of mask2 <-> k-th pair).
  *   With lap = 1 the second-order part is a single stream: sum over the diagonal pairs in mask2 of d2/dx_a^2.  */
+#define NDQ_MAX_HIDDEN 512   /* widest hidden layer a descriptor may name: 1..64 csrc/ndq_mlp.h (fragment kernels, weights
+                                resident in LDS), 65..512 csrc/ndq_wide.h (one hidden layer, units over lanes) */
 typedef struct ndq_mlp_desc {
   int d;       /* number of input coordinates (1..3) */
   int first;   /* 1: first-order streams present */
   int mask2;   /* second-order pair mask */
-  int hidden;  /* width of the hidden layers, 1..64 -- the widest one if they differ (kernels lay every layer out padded
-                  to the next multiple of 16 of this; the flat parameter vector holds the real widths) */
+  int hidden;  /* width of the hidden layers, 1..NDQ_MAX_HIDDEN -- the widest one if they differ (kernels lay every layer out
+                  padded; the flat parameter vector holds the real widths) */
   int layers;  /* number of hidden layers */
   int act;     /* NDQ_ACT_* */
   int n_out;   /* output units */

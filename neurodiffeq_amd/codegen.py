@@ -488,8 +488,8 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         K = self.n_nets
         mode = fuse_mode(self, {k: desc for k in range(K)})
         assert mode is not None
-        if mode == "group":
-            return self._group_source(desc)
+        if mode in ("group", "wide"):
+            return self._group_source(desc, wide=(mode == "wide"))
         ns = self.streams[0].n_streams
         nsym = max(len(self.symbols), 1)
         jet = (lambda k, loc: f"jets[{loc}]") if K == 1 else (lambda k, loc: f"jets[{k}][{loc}]")
@@ -643,13 +643,17 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 }}
 {_TV_EXPORT}"""
 
-    def _group_source(self, desc):
+    def _group_source(self, desc, wide=False):
         """Source of the grouped single-launch closure kernel (csrc/ndq_mlp.h: fused_group_closure_kernel): one network
         with any number of outputs, reading any subset of the batch coordinates; the per-point function runs on one
-        point per lane, stream values and adjoint seeds are exchanged through an LDS tile."""
+        point per lane, stream values and adjoint seeds are exchanged through an LDS tile.
+        ``wide``: the closure kernel of csrc/ndq_wide.h (one hidden layer of 65 .. 512 units) -- the same per-point
+        interface, stream rows [n_streams][n_out] without padding."""
         st = self.streams[0]
         width = st.n_streams * st.n_out
         gw = 1 if st.n_out == 1 else (st.n_out + 15) // 16 * 16      # row layout [n_streams][gw] (ndq::group_w)
+        if wide:
+            gw = st.n_out
         row = lambda loc: (loc // st.n_out) * gw + loc % st.n_out
         nsym = max(len(self.symbols), 1)
         used = {}
@@ -665,8 +669,23 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
         neq, nf = len(self.residuals), len(self.funcs)
         kern = lambda train: f"ndq::fused_group_closure_kernel<CFG, PW, {train}>"
         lds = lambda train: f"ndq::group_lds_bytes<CFG>({train})"
+        kern_tv = "ndq::fused_group_closure_tv_kernel<CFG, PW>"
+        cfg_t = (f"ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, "
+                 f"{desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, "
+                 f"{desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>")
+        blocks_body = """  constexpr int gp = 16 * ndq::group_tiles<CFG>();
+  const int groups = (n + gp - 1) / gp;
+  int b = (groups + kWaves - 1) / kWaves;"""
+        if wide:
+            header = "ndq_wide.h"
+            kern = lambda train: f"ndq::wide_closure_kernel<CFG, PW, {train}>"
+            lds = lambda train: "(ndq::wide_closure_lds_bytes<CFG, PW>())"
+            kern_tv = "ndq::wide_closure_tv_kernel<CFG, PW>"
+            cfg_t = wide_cfg(desc)
+            blocks_body = """  const int tiles = (n + 15) / 16;
+  int b = (tiles + kWaves - 1) / kWaves;"""
         tv = _tv_launcher("ndq::FusedArgs", "a.params = params[0]; a.partials = partials ? partials[0] : nullptr;",
-                          "ndq::fused_group_closure_tv_kernel<CFG, PW>", lds('true'), lds('false'))
+                          kern_tv, lds('true'), lds('false'))
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- grouped single-launch closure kernel (forward streams -> LDS exchange ->
 // per-point stage, one point per lane -> reverse pass) of one PDE system, gfx950.
 #include <cstdlib>
@@ -677,7 +696,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
 #endif
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
+using CFG = {cfg_t};
 static_assert(CFG::NS * CFG::NOUT == {width}, "stream layout of the traced program and of the kernel disagree");
 struct PW {{
   // NC rows of the coordinate block per point: the batch coordinates, then ND data columns; NT trainable scalars
@@ -701,9 +720,7 @@ struct PW {{
 }};
 constexpr int kWaves = CFG::BWD_THREADS / 64;
 int fused_blocks(int n) {{
-  constexpr int gp = 16 * ndq::group_tiles<CFG>();
-  const int groups = (n + gp - 1) / gp;
-  int b = (groups + kWaves - 1) / kWaves;
+{blocks_body}
   return b > NDQ_MAX_BLOCKS ? NDQ_MAX_BLOCKS : (b < 1 ? 1 : b);
 }}
 
@@ -1004,7 +1021,7 @@ def _build_tag():
 
 def _header_digest():
     h = hashlib.sha1()
-    for name in ("csrc/ndq_mlp.h", "csrc/ndq_tail.h", "csrc/ndq_launch.h", "../include/ndq.h"):
+    for name in ("csrc/ndq_mlp.h", "csrc/ndq_tail.h", "csrc/ndq_launch.h", "csrc/ndq_wide.h", "../include/ndq.h"):
         with open(os.path.join(HERE, name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -1045,11 +1062,34 @@ def mlp_ext_allowed(desc):
             return False
     if desc.mono and (not 0 < desc.mono < 256 or desc.mask3 or desc.skip or desc.hidden > 48):
         return False          # monomial features: degrees 1..8, up to second order, H <= 48, no skip connection
-    return (1 <= desc.d <= MAX_INPUTS and 1 <= desc.hidden <= 64 and 1 <= desc.layers <= (4 if desc.widths else MAX_LAYERS)
+    if is_wide(desc) and (desc.layers != 1 or desc.skip or desc.actp or desc.mono or desc.widths or desc.n_out > 16):
+        return False          # wider than 64 units (csrc/ndq_wide.h): one hidden layer, plain FCNN
+    return (1 <= desc.d <= MAX_INPUTS and 1 <= desc.hidden <= MAX_HIDDEN and 1 <= desc.layers <= (4 if desc.widths else MAX_LAYERS)
             and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
             and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0))
             and desc.skip in (0, 1) and desc.actp in (0, 1, 2) and (desc.actp == 0 or desc.act in (3, 4)))
+
+
+MAX_HIDDEN = 512        # include/ndq.h NDQ_MAX_HIDDEN
+
+
+def is_wide(desc):
+    """Shapes served by csrc/ndq_wide.h (units over lanes, weights in registers) instead of csrc/ndq_mlp.h (16-point MFMA
+    fragments, weights resident in LDS): hidden layers wider than 64 units."""
+    return desc.hidden > 64
+
+
+def wide_cfg(desc):
+    """The ndq::WideCfg instantiation of a descriptor (one hidden layer of 65 .. 512 units)."""
+    return (f"ndq::WideCfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.lap}, {desc.mask3}u, {desc.hidden}, {desc.act}, "
+            f"{desc.n_out}>")
+
+
+#: extra hipcc flags of modules built from csrc/ndq_wide.h: its tile code is 16 rounds x U units of independent scalar
+#: chains; the SLP vectoriser pairs them ACROSS rounds into v_pk_* (no faster on gfx950: a packed fp32 op issues like two),
+#: which drags every round's live values to the end of the tile -- 512 VGPRs + 200 .. 700 spilled against 227 without
+WIDE_FLAGS = ["-fno-slp-vectorize"]
 
 
 def padded_width(hidden):
@@ -1060,6 +1100,16 @@ def padded_width(hidden):
 def mlp_ext_source(desc, f64=False):
     header = "ndq_launch.h"              # -I csrc, as above
     record = "ndq64_mlp_kernels" if f64 else "ndq_mlp_kernels"
+    if is_wide(desc):
+        return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one single-hidden-layer FCNN wider
+// than 64 units (csrc/ndq_wide.h)
+#include "{header}"
+using CFG = {wide_cfg(desc)};
+extern "C" const {record}* ndq_ext_kernels(void) {{
+  static const {record} k = ndq::make_wide_kernels<CFG>();
+  return &k;
+}}
+"""
     return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
 {"#define NDQ_F64 1" if f64 else ""}
 #include "{header}"
@@ -1082,7 +1132,7 @@ def build_mlp_ext(desc, force=False, f64=False):
     with open(src, "w") as fh:
         fh.write(source)
     try:
-        _hipcc.compile_shared(src, so, _extra_flags())
+        _hipcc.compile_shared(src, so, _extra_flags() + (WIDE_FLAGS if is_wide(desc) else []))
     except RuntimeError as e:
         raise RuntimeError(f"hipcc failed for MLP kernel extension {src}:\n{str(e)[-4000:]}") from e
     return so
@@ -1097,7 +1147,7 @@ def ensure_mlp_kernels(desc, f64=False):
     register = L.ndq64_mlp_register if f64 else L.ndq_mlp_register
     if supported(ctypes.byref(desc)):
         return True
-    if not mlp_ext_allowed(desc) or (f64 and desc.hidden > 64):     # fp64: twice the LDS per weight -- ndq64_mlp_register turns down what does not fit
+    if not mlp_ext_allowed(desc) or (f64 and desc.hidden > 64):     # (no fp64 build of csrc/ndq_wide.h)     # fp64: twice the LDS per weight -- ndq64_mlp_register turns down what does not fit
         return False
     key = desc.key() + (("f64",) if f64 else ())
     if key in _MLP_EXT:
@@ -1124,7 +1174,7 @@ def build_fused(program: PointwiseProgram, desc, force=False, threads=None):
     per-wave state fits 256 registers; csrc/ndq_mlp.h NDQ_BWD_THREADS) the engine uses for large batches."""
     os.makedirs(JIT_DIR, exist_ok=True)
     source = program.fused_source(desc)
-    flags = _extra_flags() + ([f"-DNDQ_BWD_THREADS={int(threads)}"] if threads else [])
+    flags = _extra_flags() + ([f"-DNDQ_BWD_THREADS={int(threads)}"] if threads else []) + (WIDE_FLAGS if is_wide(desc) else [])
     key = _cache_key(source + (f"|threads={int(threads)}" if threads else ""))
     so = os.path.join(JIT_DIR, f"fused_{key}.so")
     src = os.path.join(JIT_DIR, f"fused_{key}.hip")
@@ -1155,6 +1205,11 @@ def fuse_mode(program: PointwiseProgram, descs=None):
     if K == 1:
         st = program.streams[0]
         d0 = descs[0] if descs is not None and 0 in descs else None
+        if d0 is not None and is_wide(d0):
+            # one hidden layer wider than 64 units: csrc/ndq_wide.h's closure kernel (any number of outputs, any subset of
+            # the batch coordinates as inputs)
+            return "wide" if (d0.layers == 1 and all(c < program.n_coords for c in st.deps)
+                              and not os.environ.get("NDQ_NO_WIDE_FUSE")) else None
         group_ok = (d0 is not None and padded_width(d0.hidden) <= 48 and all(c < program.n_coords for c in st.deps)
                     and not os.environ.get("NDQ_NO_GROUP_FUSE"))
         if plain and not (group_ok and os.environ.get("NDQ_FUSE_GROUP") == "1"):

@@ -76,7 +76,7 @@ static bool same_desc(const ndq_mlp_desc& a, const ndq_mlp_desc& b) {
 }
 
 static const ndq_mlp_kernels* find(const ndq_mlp_desc* d) {
-  if (!d || d->hidden < 1 || d->hidden > 64) return nullptr;
+  if (!d || d->hidden < 1 || d->hidden > NDQ_MAX_HIDDEN) return nullptr;
   for (const ndq_mlp_kernels& e : kTable)
     if (same_desc(e.desc, *d)) return &e;
   for (const ndq_mlp_kernels* e : g_registered)
@@ -446,7 +446,7 @@ extern "C" {
 int ndq_mlp_supported(const ndq_mlp_desc* desc) { return find(desc) ? 1 : 0; }
 
 int ndq_mlp_register(const ndq_mlp_kernels* k) {
-  if (!k || !k->fwd || !k->bwd || k->desc.hidden < 1 || k->desc.hidden > 64 || k->n_streams < 1 || k->n_params < 1 || k->bwd_waves < 1 ||
+  if (!k || !k->fwd || !k->bwd || k->desc.hidden < 1 || k->desc.hidden > NDQ_MAX_HIDDEN || k->n_streams < 1 || k->n_params < 1 || k->bwd_waves < 1 ||
       k->lds_bytes > 160 * 1024)
     return NDQ_EINVAL;
   if (!find(&k->desc)) g_registered.push_back(k);

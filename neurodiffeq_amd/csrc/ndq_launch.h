@@ -7,6 +7,7 @@
 #define NDQ_WG_TR 1     // adjoint kernels of H = 32 networks: weight gradients from the bf16x3 planes (ndq_mlp.h Cfg::WG_TR)
 #endif
 #include "ndq_mlp.h"
+#include "ndq_wide.h"
 #include "../../include/ndq.h"
 
 namespace ndq {
@@ -86,5 +87,59 @@ kernels_record make_kernels() {
   k.bwd = &kernels_bwd<C>;
   return k;
 }
+
+// ---- one hidden layer of 65 .. 512 units (ndq_wide.h): the same record, so ndq_mlp_register / ndq_mlp_jet_fwd / _bwd
+// serve these shapes like any other
+#if !NDQ_F64
+template <class C>
+int wide_kernels_fwd(const real* coords, int ldc, int n, const real* params, real* jets, int ldj, void* stream) {
+  MlpArgs a{};
+  a.coords = coords; a.params = params; a.jets = jets; a.n = n; a.ldc = ldc; a.ldj = ldj;
+  static bool attr = false;
+  const size_t lds = wide_lds_bytes<C>();
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_jet_fwd_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  const int tiles = (n + 15) / 16;
+  int blocks = (tiles + C::WAVES - 1) / C::WAVES;
+  if (blocks > NDQ_BWD_MAX_BLOCKS) blocks = NDQ_BWD_MAX_BLOCKS;      // every wave loads its units once: one workgroup per CU
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(wide_jet_fwd_kernel<C>, dim3(blocks), dim3(C::THREADS), lds, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}
+
+template <class C>
+int wide_kernels_bwd(const real* coords, int ldc, int n, const real* params, const real* gbar, int ldj, real* partials,
+                     int blocks, void* stream) {
+  MlpArgs a{};
+  a.coords = coords; a.params = params; a.gbar = gbar; a.partials = partials; a.n = n; a.ldc = ldc; a.ldj = ldj;
+  static bool attr = false;
+  const size_t lds = wide_lds_bytes<C>();
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_jet_bwd_kernel<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(wide_jet_bwd_kernel<C>, dim3(blocks), dim3(C::THREADS), lds, static_cast<hipStream_t>(stream), a);
+  return (int)hipGetLastError();
+}
+
+template <class C>
+kernels_record make_wide_kernels() {
+  kernels_record k{};
+  k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::W, 1, C::ACT, C::NOUT, C::SS::LAP, 0, (int)C::SS::M3, 0, 0, 0};
+  k.n_streams = C::NS;
+  k.n_params = C::P;
+  k.bwd_waves = C::WAVES;
+  k.lds_bytes = (int)wide_lds_bytes<C>();
+  k.fwd = &wide_kernels_fwd<C>;
+  k.bwd = &wide_kernels_bwd<C>;
+  return k;
+}
+#endif
 
 }  // namespace ndq

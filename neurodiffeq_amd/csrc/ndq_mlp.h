@@ -2608,7 +2608,9 @@ __device__ __forceinline__ void theta_block_sum(real (&t)[NT > 0 ? NT : 1], real
 // pull (fit(), small grids; csrc/ndq_tail.h): the launch first finishes the previous epoch -- sums, Adam, history -- and
 // stages its weights from the parameters it has just computed (LDS vector behind the weight image); `writer`: this
 // workgroup writes the global state.  fp32 builds without trainable activation parameters only (Cfg::ACTP == 0).
-template <class C> constexpr bool pull_supported() { return NDQ_F64 == 0 && C::ACTP == 0; }
+template <class C, class = void> struct no_pull_marker : std::false_type {};          // a Cfg may opt out: static constexpr bool NO_PULL
+template <class C> struct no_pull_marker<C, std::void_t<decltype(C::NO_PULL)>> : std::true_type {};
+template <class C> constexpr bool pull_supported() { return NDQ_F64 == 0 && C::ACTP == 0 && !no_pull_marker<C>::value; }
 template <class C> constexpr int pull_floats() { return ((C::P + 3) & ~3) + 32; }
 
 template <class C, class PW, bool TRAIN>

@@ -137,6 +137,7 @@ _ACT_IDS = {nn.Tanh: _lib.NDQ_ACT_TANH, SinActv: _lib.NDQ_ACT_SIN, nn.Sigmoid: _
 # hidden layers the kernel templates take: any number the LDS holds when all have one width (up to MAX_LAYERS are offered),
 # up to four when the widths differ (ndq_mlp_desc.widths packs 8 bits per layer)
 MAX_LAYERS = 8
+MAX_HIDDEN = 512       # widest hidden layer (include/ndq.h NDQ_MAX_HIDDEN; wider than 64: csrc/ndq_wide.h)
 
 
 def describe(net, dtype=torch.float32):
@@ -190,7 +191,8 @@ def describe(net, dtype=torch.float32):
                 return None
     # hidden widths: any (the kernels lay all layers out for the widest one, padded to a multiple of 16)
     ws = [l.out_features for l in linears[:-1]]
-    if any(b.in_features != a for a, b in zip(ws, linears[1:])) or len(ws) > (MAX_LAYERS if len(set(ws)) == 1 else 4) or max(ws) > 255:
+    if any(b.in_features != a for a, b in zip(ws, linears[1:])) or len(ws) > (MAX_LAYERS if len(set(ws)) == 1 else 4) \
+            or max(ws) > (MAX_HIDDEN if len(set(ws)) == 1 else 255):
         return None
     hidden = max(ws)
     widths = 0 if len(set(ws)) == 1 else sum(w << (8 * i) for i, w in enumerate(ws))

@@ -130,6 +130,35 @@ def make(name, size=None):
         return dict(kind="1d", pde=pde, nets=[FCNN(1, 1, hidden_units=(32, 32), actv=partial(APTx, trainable=True))],
                     conds=[IVP(0.0, 1.0, u_0_prime=0.5)], gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"),
                     n_points=48, dom=(0.0, 2.0))
+    if name == "w16":     # README.md:125 -- FCNN(2, 1, hidden_units=(512,)) on the C2 problem
+        c = make("c2", size or 12)
+        c["nets"] = [FCNN(n_input_units=2, n_output_units=1, hidden_units=(512,))]
+        return c
+    if name == "w18":     # 128 x 3 on the Burgers problem of C3
+        c = make("c3", size or 12)
+        c["nets"] = [FCNN(2, 1, hidden_units=(128, 128, 128))]
+        return c
+    if name in ("w17", "w19"):     # lid-driven cavity on ONE three-output network (EnsembleCondition): 2 -> 512 -> 3 and the
+        #                            RE100 notebook's FCNN(n_hidden_units=256, n_hidden_layers=1) = 2 -> 256 -> 256 -> 3
+        re = 400.0 if name == "w17" else 100.0
+
+        def pde(uvp, x, y):
+            u, v, p = uvp[:, 0:1], uvp[:, 1:2], uvp[:, 2:3]
+            mx = u * diff(u, x) + v * diff(u, y) + diff(p, x) - 1 / re * (diff(u, x, order=2) + diff(u, y, order=2))
+            my = u * diff(v, x) + v * diff(v, y) + diff(p, y) - 1 / re * (diff(v, x, order=2) + diff(v, y, order=2))
+            return [mx, my, diff(u, x) + diff(v, y)]
+        if name == "w17":
+            net = FCNN(n_input_units=2, n_output_units=3, hidden_units=(512,))
+        else:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", FutureWarning)
+                net = FCNN(n_input_units=2, n_hidden_units=256, n_hidden_layers=1, n_output_units=3, actv=torch.nn.Tanh)
+        conds = [EnsembleCondition(DirichletBVP2D(0, zero, 1, zero, 0, zero, 1, lid),
+                                   DirichletBVP2D(0, zero, 1, zero, 0, zero, 1, zero), NoCondition())]
+        g = size or 8
+        return dict(kind="2d", pde=pde, nets=[net], conds=conds, gen=Generator2D((g, g), (0, 0), (1, 1), "equally-spaced-noisy"),
+                    n_points=g * g, dom=((0, 0), (1, 1)))
     if name == "w5":      # Resnet on the C2 problem
         c = make("c2", 12)
         c["nets"] = [Resnet(2, 1, hidden_units=(32, 32))]

@@ -244,7 +244,52 @@ def cfg_w15():
                 gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"), t=(0.0, 2.0))
 
 
-CONFIGS = {"c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
+# ---- round 4: networks WIDER than 64 units -- the reference's own headline shapes
+def cfg_w16():
+    """README.md:125 -- the Laplace example's network, FCNN(2, 1, hidden_units=(512,)), on the C2 problem."""
+    c = cfg_c2(12)
+    c["nets"] = [FCNN(n_input_units=2, n_output_units=1, hidden_units=(512,))]
+    return c
+
+
+def _ns_single(net, g=8, re=400.0):
+    """Lid-driven cavity (experiments/lid-driven-cavity-RE400.ipynb) on ONE three-output network: u, v, p are the columns of a
+    single solver function under EnsembleCondition (the current API's form of the notebook's single_network)."""
+    def pde(uvp, x, y):
+        u, v, p = uvp[:, 0:1], uvp[:, 1:2], uvp[:, 2:3]
+        mx = u * diff(u, x) + v * diff(u, y) + diff(p, x) - 1 / re * (diff(u, x, order=2) + diff(u, y, order=2))
+        my = u * diff(v, x) + v * diff(v, y) + diff(p, y) - 1 / re * (diff(v, x, order=2) + diff(v, y, order=2))
+        return [mx, my, diff(u, x) + diff(v, y)]
+    zero = lambda s: 0
+    conds = [EnsembleCondition(DirichletBVP2D(0, zero, 1, zero, 0, zero, 1, lid), DirichletBVP2D(0, zero, 1, zero, 0, zero, 1, zero),
+                               NoCondition())]
+    gen = Generator2D((g, g), (0, 0), (1, 1), "equally-spaced-noisy")
+    return dict(kind="2d", pde=pde, nets=[net], conds=conds, gen=gen)
+
+
+def cfg_w17():
+    """2 -> 512 -> 3: one hidden layer of the RE400 notebook's width, three outputs."""
+    return _ns_single(FCNN(n_input_units=2, n_output_units=3, hidden_units=(512,)))
+
+
+def cfg_w18():
+    """FCNN(2, 1, hidden_units=(128, 128, 128)) on the Burgers problem of C3."""
+    c = cfg_c3(12)
+    c["nets"] = [FCNN(2, 1, hidden_units=(128, 128, 128))]
+    return c
+
+
+def cfg_w19():
+    """experiments/lid-driven-cavity-RE100.ipynb:72-78 -- FCNN(n_input_units=2, n_hidden_units=256, n_hidden_layers=1,
+    n_output_units=3), which networks.py:41 turns into hidden_units=(256, 256): 2 -> 256 -> 256 -> 3."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)
+        net = FCNN(n_input_units=2, n_hidden_units=256, n_hidden_layers=1, n_output_units=3, actv=torch.nn.Tanh)
+    return _ns_single(net, re=100.0)
+
+
+CONFIGS = {"w16": cfg_w16, "w17": cfg_w17, "w18": cfg_w18, "w19": cfg_w19, "c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
            "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5, "w6": cfg_w6, "w7": cfg_w7, "w8": cfg_w8,
            "w9": cfg_w9, "w10": cfg_w10, "w11": cfg_w11, "w12": cfg_w12, "w13": cfg_w13, "w14": cfg_w14, "w15": cfg_w15}
 
