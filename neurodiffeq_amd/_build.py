@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libndq.so")
 SOURCES = [os.path.join(CSRC, "ndq_api.hip")]
-HEADERS = [os.path.join(CSRC, h) for h in ("ndq_mlp.h", "ndq_tail.h", "ndq_launch.h", "ndq_wide.h", "ndq_sample.h", "ndq_oneshot.h")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("ndq_mlp.h", "ndq_tail.h", "ndq_launch.h", "ndq_wide.h", "ndq_deep.h", "ndq_sample.h", "ndq_oneshot.h")] + \
     [os.path.join(HERE, "..", "include", "ndq.h"), os.path.join(HERE, "_hipcc.py")]
 # libndq64.so = csrc/ndq_api64.hip: the same stream kernels compiled for fp64 (ndq64_* entry points of include/ndq.h)
 LIB64 = os.path.join(HERE, "libndq64.so")

@@ -1021,7 +1021,7 @@ def _build_tag():
 
 def _header_digest():
     h = hashlib.sha1()
-    for name in ("csrc/ndq_mlp.h", "csrc/ndq_tail.h", "csrc/ndq_launch.h", "csrc/ndq_wide.h", "../include/ndq.h"):
+    for name in ("csrc/ndq_mlp.h", "csrc/ndq_tail.h", "csrc/ndq_launch.h", "csrc/ndq_wide.h", "csrc/ndq_deep.h", "../include/ndq.h"):
         with open(os.path.join(HERE, name), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -1062,8 +1062,8 @@ def mlp_ext_allowed(desc):
             return False
     if desc.mono and (not 0 < desc.mono < 256 or desc.mask3 or desc.skip or desc.hidden > 48):
         return False          # monomial features: degrees 1..8, up to second order, H <= 48, no skip connection
-    if is_wide(desc) and (desc.layers != 1 or desc.skip or desc.actp or desc.mono or desc.widths or desc.n_out > 16):
-        return False          # wider than 64 units (csrc/ndq_wide.h): one hidden layer, plain FCNN
+    if is_wide(desc) and (desc.skip or desc.actp or desc.mono or desc.widths or desc.n_out > 16):
+        return False          # wider than 64 units (csrc/ndq_wide.h: one hidden layer; csrc/ndq_deep.h: 2 .. 8): plain FCNN
     return (1 <= desc.d <= MAX_INPUTS and 1 <= desc.hidden <= MAX_HIDDEN and 1 <= desc.layers <= (4 if desc.widths else MAX_LAYERS)
             and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
@@ -1078,6 +1078,12 @@ def is_wide(desc):
     """Shapes served by csrc/ndq_wide.h (units over lanes, weights in registers) instead of csrc/ndq_mlp.h (16-point MFMA
     fragments, weights resident in LDS): hidden layers wider than 64 units."""
     return desc.hidden > 64
+
+
+def deep_cfg(desc):
+    """The ndq::DeepCfg instantiation of a descriptor (2 .. 8 hidden layers of 65 .. 512 units, csrc/ndq_deep.h)."""
+    return (f"ndq::DeepCfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.lap}, {desc.mask3}u, {desc.hidden}, {desc.layers}, "
+            f"{desc.act}, {desc.n_out}>")
 
 
 def wide_cfg(desc):
@@ -1100,6 +1106,16 @@ def padded_width(hidden):
 def mlp_ext_source(desc, f64=False):
     header = "ndq_launch.h"              # -I csrc, as above
     record = "ndq64_mlp_kernels" if f64 else "ndq_mlp_kernels"
+    if is_wide(desc) and desc.layers >= 2:
+        return f"""// GENERATED by neurodiffeq_amd/codegen.py -- layer-by-layer forward / adjoint kernels of one deep FCNN wider than 64
+// units (csrc/ndq_deep.h)
+#include "{header}"
+using CFG = {deep_cfg(desc)};
+extern "C" const {record}* ndq_ext_kernels(void) {{
+  static const {record} k = ndq::make_deep_kernels<CFG>();
+  return &k;
+}}
+"""
     if is_wide(desc):
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one single-hidden-layer FCNN wider
 // than 64 units (csrc/ndq_wide.h)
@@ -1132,7 +1148,7 @@ def build_mlp_ext(desc, force=False, f64=False):
     with open(src, "w") as fh:
         fh.write(source)
     try:
-        _hipcc.compile_shared(src, so, _extra_flags() + (WIDE_FLAGS if is_wide(desc) else []))
+        _hipcc.compile_shared(src, so, _extra_flags() + (WIDE_FLAGS if is_wide(desc) and desc.layers == 1 else []))
     except RuntimeError as e:
         raise RuntimeError(f"hipcc failed for MLP kernel extension {src}:\n{str(e)[-4000:]}") from e
     return so

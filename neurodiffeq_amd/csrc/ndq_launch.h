@@ -8,6 +8,7 @@
 #endif
 #include "ndq_mlp.h"
 #include "ndq_wide.h"
+#include "ndq_deep.h"
 #include "../../include/ndq.h"
 
 namespace ndq {
@@ -138,6 +139,156 @@ kernels_record make_wide_kernels() {
   k.lds_bytes = (int)wide_lds_bytes<C>();
   k.fwd = &wide_kernels_fwd<C>;
   k.bwd = &wide_kernels_bwd<C>;
+  return k;
+}
+
+// ---- two or more hidden layers of 65 .. 512 units (ndq_deep.h): layer by layer through a workspace in HBM.  The module
+// owns that workspace (hipMalloc on first use, grown when a larger batch arrives, never inside a timed steady state); the
+// adjoint entry recomputes the forward layers like every ndq_mlp_jet_bwd and writes ONE row of "partials" -- the gradient
+// itself, its own reductions being fixed-order already (bwd_waves is set so that ndq_mlp_bwd_blocks() == 1).
+struct DeepPlan {
+  int np, blocks_max;
+  size_t X, z0, zb0, wp, wt, pw, pb, pw1, pwo, pbo, total;
+};
+template <class C>
+DeepPlan deep_plan(int n) {
+  DeepPlan q{};
+  q.np = (n + 15) & ~15;
+  q.blocks_max = 256;
+  const size_t HP = C::HP, nwmax = (size_t)q.blocks_max * C::WAVES;
+  q.X = (size_t)C::NS * q.np * HP;
+  size_t o = 0;
+  q.z0 = o; o += (size_t)(C::L - 1) * q.X;            // Z_2 .. Z_L
+  q.zb0 = o; o += 2 * q.X;                            // Zbar ping-pong
+  q.wp = o; o += (size_t)(C::L - 1) * HP * HP;
+  q.wt = o; o += (size_t)(C::L - 1) * HP * HP;
+  q.pw = o; o += (nwmax / (C::NT * C::NT) + 1) * HP * HP;
+  q.pb = o; o += nwmax * HP;
+  q.pw1 = o; o += nwmax * HP * C::D;
+  q.pwo = o; o += nwmax * C::NOUT * HP;
+  q.pbo = o; o += nwmax * C::NOUT;
+  q.total = o + 64;
+  return q;
+}
+inline real* deep_workspace(size_t floats) {
+  static real* base = nullptr;
+  static size_t have = 0;
+  if (floats > have) {
+    if (base) { (void)hipDeviceSynchronize(); (void)hipFree(base); base = nullptr; have = 0; }
+    const size_t want = floats + floats / 8;
+    if (hipMalloc(reinterpret_cast<void**>(&base), want * sizeof(real)) != hipSuccess) { base = nullptr; return nullptr; }
+    have = want;
+  }
+  return base;
+}
+inline int deep_blocks(long waves, int min_waves, int cap) {
+  long w = waves > min_waves ? waves : min_waves;
+  long b = (w + 3) / 4;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+// forward layers 2 .. L into the workspace (shared by the two entry points)
+template <class C>
+int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc, int n, const real* params, hipStream_t st) {
+  hipLaunchKernelGGL(deep_prep<C>, dim3(64, C::L - 1), dim3(256), 0, st, params, ws + q.wp, ws + q.wt);
+  const int ntiles = q.np / 16;
+  const int blocks = deep_blocks((long)ntiles * C::NCH, C::NCH, q.blocks_max);
+  for (int l = 2; l <= C::L; ++l) {
+    DeepArgs a{};
+    a.coords = coords; a.prm = params; a.n = n; a.np = q.np; a.ldc = ldc;
+    a.wmat = ws + q.wp + (size_t)(l - 2) * C::HP * C::HP;
+    a.bias = params + C::offb(l);
+    a.zin = l > 2 ? ws + q.z0 + (size_t)(l - 3) * q.X : nullptr;
+    a.zout = ws + q.z0 + (size_t)(l - 2) * q.X;
+    if (l == 2) hipLaunchKernelGGL((deep_fwd_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+    else hipLaunchKernelGGL((deep_fwd_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+  }
+  return (int)hipGetLastError();
+}
+
+template <class C>
+int deep_kernels_fwd(const real* coords, int ldc, int n, const real* params, real* jets, int ldj, void* stream) {
+  const DeepPlan q = deep_plan<C>(n);
+  real* ws = deep_workspace(q.total);
+  if (!ws) return (int)hipErrorOutOfMemory;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = deep_forward_layers<C>(q, ws, coords, ldc, n, params, st);
+  if (rc) return rc;
+  DeepHeadArgs h{};
+  h.prm = params; h.z = ws + q.z0 + (size_t)(C::L - 2) * q.X; h.jets = jets; h.n = n; h.np = q.np; h.ldj = ldj;
+  hipLaunchKernelGGL(deep_head_fwd<C>, dim3(deep_blocks(q.np / 16, 1, q.blocks_max)), dim3(C::THREADS), 0, st, h);
+  return (int)hipGetLastError();
+}
+
+template <class C>
+int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, const real* gbar, int ldj, real* grad,
+                     int /*blocks == 1*/, void* stream) {
+  const DeepPlan q = deep_plan<C>(n);
+  real* ws = deep_workspace(q.total);
+  if (!ws) return (int)hipErrorOutOfMemory;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = deep_forward_layers<C>(q, ws, coords, ldc, n, params, st);
+  if (rc) return rc;
+  auto reduce = [&](const real* src, int nparts, int rows_p, int cols_p, int rows, int cols, real* dst) {
+    hipLaunchKernelGGL(deep_reduce2d, dim3((rows * cols + 255) / 256), dim3(256), 0, st, src, nparts, rows_p, cols_p, rows, cols, dst);
+  };
+  constexpr int UG = (C::HP + 63) / 64;
+  {
+    DeepHeadArgs h{};
+    h.prm = params; h.z = ws + q.z0 + (size_t)(C::L - 2) * q.X; h.gbar = gbar; h.zbar = ws + q.zb0;
+    h.pwo = ws + q.pwo; h.pb = ws + q.pb; h.pbo = ws + q.pbo; h.n = n; h.np = q.np; h.ldj = ldj;
+    const int blocks = deep_blocks((long)UG * q.np, UG, q.blocks_max);
+    const int stripes = blocks * C::WAVES / UG;
+    hipLaunchKernelGGL(deep_head_bwd<C>, dim3(blocks), dim3(C::THREADS), 0, st, h);
+    reduce(ws + q.pwo, stripes, C::NOUT, C::HP, C::NOUT, C::W, grad + C::offWout);
+    reduce(ws + q.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb(C::L));
+    reduce(ws + q.pbo, stripes, 1, C::NOUT, 1, C::NOUT, grad + C::offbout);
+  }
+  int cur = 0;
+  const int ntiles = q.np / 16;
+  for (int l = C::L; l >= 2; --l) {
+    DeepArgs a{};
+    a.coords = coords; a.prm = params; a.n = n; a.np = q.np; a.ldc = ldc;
+    a.zin = ws + q.zb0 + (size_t)cur * q.X;                               // Zbar_l
+    a.zprev = l > 2 ? ws + q.z0 + (size_t)(l - 3) * q.X : nullptr;        // Z_{l-1}
+    {   // dW_l
+      a.pw = ws + q.pw;
+      const int blocks = deep_blocks((long)C::NT * C::NT * (q.np / 4), C::NT * C::NT, q.blocks_max);
+      const int KS = blocks * C::WAVES / (C::NT * C::NT);
+      if (l == 2) hipLaunchKernelGGL((deep_wgrad_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+      else hipLaunchKernelGGL((deep_wgrad_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+      reduce(ws + q.pw, KS, C::HP, C::HP, C::W, C::W, grad + C::offW(l));
+    }
+    a.wmat = ws + q.wt + (size_t)(l - 2) * C::HP * C::HP;
+    a.pb = ws + q.pb;
+    if (l > 2) {
+      a.zout = ws + q.zb0 + (size_t)(cur ^ 1) * q.X;
+      const int blocks = deep_blocks((long)ntiles * C::NCH, C::NCH, q.blocks_max);
+      hipLaunchKernelGGL((deep_bwd_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+      reduce(ws + q.pb, blocks * C::WAVES / C::NCH, 1, C::HP, 1, C::W, grad + C::offb(l - 1));
+      cur ^= 1;
+    } else {
+      a.pw1 = ws + q.pw1;
+      const int blocks = deep_blocks((long)ntiles * C::NCHF, C::NCHF, q.blocks_max);
+      const int stripes = blocks * C::WAVES / C::NCHF;
+      hipLaunchKernelGGL((deep_bwd_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+      reduce(ws + q.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb1);
+      reduce(ws + q.pw1, stripes, C::HP, C::D, C::W, C::D, grad + C::offW1);
+    }
+  }
+  return (int)hipGetLastError();
+}
+
+template <class C>
+kernels_record make_deep_kernels() {
+  kernels_record k{};
+  k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::W, C::L, C::ACT, C::NOUT, C::SS::LAP, 0, (int)C::SS::M3, 0, 0, 0};
+  k.n_streams = C::NS;
+  k.n_params = C::P;
+  k.bwd_waves = 1 << 24;              // ndq_mlp_bwd_blocks() == 1: the adjoint entry writes the gradient row itself
+  k.lds_bytes = 0;
+  k.fwd = &deep_kernels_fwd<C>;
+  k.bwd = &deep_kernels_bwd<C>;
   return k;
 }
 #endif

@@ -39,6 +39,10 @@ def _streams(d, kind):
     if kind == "lap":
         m = sum(1 << k for k, (a, b) in enumerate(pairs) if a == b)
         return [()] + first + ["lap"], 1, m, 1, 0
+    if kind == "first+xx":      # value, gradient, d2/dx0^2
+        return [()] + first + [(0, 0)], 1, 1, 0, 0
+    if kind == "lap3":          # three-output network with a Laplacian stream is not offered by the tracer (lap needs n_out = 1): full2
+        return [()] + first + pairs, 1, (1 << len(pairs)) - 1, 0, 0
     if kind == "full3":
         return [()] + first + pairs + trips, 1, (1 << len(pairs)) - 1, 0, (1 << len(trips)) - 1
     raise KeyError(kind)
@@ -61,7 +65,20 @@ SHAPES = [
     (4, 80, 1, "tanh", "value"),
     (2, 65, 8, "tanh", "full2"),         # 48 stream x output rows per point: four-point reduction passes
 ]
-IDS = [f"{d}-{w}-{o}-{a}-{k}" for d, w, o, a, k in SHAPES]
+# deep networks wider than 64 units (csrc/ndq_deep.h: layer by layer through HBM): (d, width, n_out, activation, stream set, layers)
+DEEP_SHAPES = [
+    (2, 128, 1, "tanh", "first+xx", 3),  # w18's shape and stream set (Burgers: u_t, u_x, u_xx)
+    (2, 256, 3, "tanh", "full2", 2),     # the RE100 notebook's network as FCNN builds it
+    (2, 100, 1, "tanh", "lap", 2),       # tests/test_pde.py:377's (100, 100)
+    (2, 512, 3, "tanh", "lap3", 2),      # the RE400 notebook's network
+    (1, 65, 1, "sin", "full3", 2),
+    (3, 80, 2, "sigmoid", "full2", 4),
+    (2, 144, 1, "swish", "diag2", 2),
+    (2, 96, 1, "aptx", "first", 5),
+    (4, 72, 1, "tanh", "value", 2),
+]
+SHAPES = SHAPES + DEEP_SHAPES
+IDS = ["-".join(map(str, sh)) for sh in SHAPES]
 
 
 def rel_l2(a, b):
@@ -86,14 +103,15 @@ def _oracle_streams(flat64, dims, act, c64, streams):
 @pytest.mark.parametrize("shape", SHAPES, ids=IDS)
 def test_wide_stream_kernels_match_jet_oracle(shape, n):
     from neurodiffeq_amd import _lib, codegen
-    d, w, n_out, act, kind = shape
-    if n not in (17, 1000) and shape not in SHAPES[:3] + SHAPES[6:7] + SHAPES[9:10]:
+    d, w, n_out, act, kind = shape[:5]
+    layers = shape[5] if len(shape) > 5 else 1
+    if n not in (17, 1000) and shape not in SHAPES[:3] + SHAPES[6:7] + SHAPES[9:10] + DEEP_SHAPES[:3]:
         pytest.skip("edge sizes on a subset of the shapes")
     L = _lib.lib()
     streams, first, mask2, lap, mask3 = _streams(d, kind)
-    desc = _lib.MlpDesc(d, first, mask2, w, 1, ACT_ID[act], n_out, lap, 0, mask3)
+    desc = _lib.MlpDesc(d, first, mask2, w, layers, ACT_ID[act], n_out, lap, 0, mask3)
     assert codegen.ensure_mlp_kernels(desc) and L.ndq_mlp_supported(ctypes.byref(desc)) == 1
-    dims = (d, w, n_out)
+    dims = (d,) + (w,) * layers + (n_out,)
     rng = np.random.default_rng(zlib.crc32(f"{shape}/{n}".encode()))
     parts = []
     for a, b in zip(dims[:-1], dims[1:]):
@@ -131,8 +149,8 @@ def test_wide_stream_kernels_match_jet_oracle(shape, n):
             gb[mm] = gb.get(mm, 0) + gbar[s].astype(np.float64).T
     want_grad = J.mlp_jets_vjp(f64, dims, act, c64, gb)[:P]
     errs["grad"] = rel_l2(grad, want_grad)
-    for name, lo, hi in (("dW1", 0, d * w), ("db1", d * w, d * w + w), ("dWout", d * w + w, d * w + w + n_out * w),
-                         ("dbout", P - n_out, P)):
+    for name, lo, hi in (("dW1", 0, d * w), ("db1", d * w, d * w + w), ("dWhidden", d * w + w, P - n_out * w - n_out),
+                         ("dWout", P - n_out * w - n_out, P - n_out), ("dbout", P - n_out, P)):
         errs[name] = float(np.linalg.norm(grad[lo:hi] - want_grad[lo:hi]) / max(np.linalg.norm(want_grad), 1e-300))
     # bit-reproducible: a second launch gives the same bits
     part2 = torch.full((nb, P), float("nan"), device="cuda")
@@ -153,7 +171,8 @@ def _grad_in_torch_order(nets, flats):
     return torch.cat([where[id(prm)].reshape(-1) for net in nets for prm in net.parameters()]).cpu().numpy()
 
 
-GOLDEN_WIDE = ["w16", "w17"]
+GOLDEN_WIDE = ["w16", "w17", "w18", "w19"]
+GOLDEN_DEEP = ("w18", "w19")       # layer-by-layer kernels: no single-launch closure
 
 
 @pytest.mark.parametrize("mode", ["1k", "3k"])
@@ -164,6 +183,8 @@ def test_wide_closure_matches_reference_golden(golden_dir, name, mode):
     pointwise kernel / wide_jet_bwd)."""
     from tests import configs
     from neurodiffeq_amd.engine import FusedSystem
+    if name in GOLDEN_DEEP and mode == "1k":
+        pytest.skip("deep wide networks run layer by layer (csrc/ndq_deep.h): pipeline mode only")
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
     cfg = configs.make(name, None)
