@@ -141,7 +141,7 @@ def measure_traffic(timeout_s=150):
     """HBM-side bytes per launch of the headline closure kernel, measured IN THIS RUN: two rocprofv3 --pmc passes
     (FETCH_SIZE and WRITE_SIZE cannot share a pass -- MI355X_MICROARCH.md, PMC slots) over ``--traffic-child``, mean per
     dispatch of the closure kernel.  Units / correction as the guide prescribes and as calibrated on this package's
-    access patterns (profiles/r02v_pmc_c2_summary.txt: counters in KiB, a streaming read reports exactly half its
+    access patterns (profiles/archive/r02/r02v_pmc_c2_summary.txt: counters in KiB, a streaming read reports exactly half its
     bytes in FETCH_SIZE, a streaming write reports WRITE_SIZE exactly).  None if rocprofv3 is not usable here."""
     import csv
     import glob
@@ -267,7 +267,7 @@ def cpu_baseline(budget_s=8.0):
     loop64 = R.TrainLoop(cfg64["nets"], cfg64["enforcers"], cfg64["pde"], samp64)
     loop64.epoch()
     med64, runs64 = _median_time(loop64.epoch, 3, budget_s / 2)
-    return dict(value=N_POINTS / med, unit="collocation-points/s", cores=torch.get_num_threads(), kind="port",
+    port = dict(value=N_POINTS / med, unit="collocation-points/s", cores=torch.get_num_threads(), kind="port",
                 ms_per_step=med * 1e3, cpu_model=cpu_model(), logical_cpus=os.cpu_count(),
                 presampled=dict(value=N_POINTS / med_pre, ms_per_step=med_pre * 1e3, runs=runs_pre,
                                 note="same step without the generator draw: what the GPU headline `value` times"),
@@ -276,10 +276,50 @@ def cpu_baseline(budget_s=8.0):
                 sample=f"{runs} timed run_train_epoch-equivalent steps (sample+fwd+diff+loss+bwd+Adam) of the "
                        f"same C2 config, fp32, torch {torch.__version__} CPU, {os.cpu_count()} logical cpus, "
                        f"{torch.get_num_threads()} threads (fastest of 1/4/8/16/32/64/128)")
+    ref = reference_baseline(budget_s)
+    if ref is None:
+        return port
+    # the UNMODIFIED reference, timed on this box (oracle/_ref, oracle/make_ref.sh); the port stays beside it
+    return dict(value=ref["value"], unit="collocation-points/s", cores=ref["threads"], kind="reference",
+                ms_per_step=ref["ms_per_step"], cpu_model=cpu_model(), logical_cpus=os.cpu_count(),
+                presampled=dict(ref["presampled"], note="same step on a pre-sampled batch (PredefinedGenerator): what the GPU "
+                                                        "headline `value` times"),
+                fp64=dict(ref["fp64"], note="library default precision (neurodiffeq/__init__.py:22), with sampling"),
+                reference_revision=ref["reference_revision"],
+                port=dict(value=port["value"], ms_per_step=port["ms_per_step"], cores=port["cores"],
+                          presampled=port["presampled"]["value"], fp64=port["fp64"]["value"]),
+                port_ratio=port["value"] / ref["value"],
+                sample=f"{ref['runs']} timed Solver2D.run_train_epoch() calls of the UNMODIFIED reference (oracle/_ref = "
+                       f"/root/reference/neurodiffeq, set_tensor_type('cpu', 32)): sample+fwd+diff+loss+bwd+Adam on the C2 "
+                       f"config (256 x 256 noisy grid, FCNN 2-32-32-1), torch {ref['torch']} CPU, {ref['logical_cpus']} logical "
+                       f"cpus, {ref['threads']} threads (fastest of 1/4/8/16/32/64/128); port_ratio = oracle port / reference")
+
+
+def reference_baseline(budget_s):
+    """Time the unmodified reference in a child process (importing it changes torch's global defaults); None when
+    oracle/_ref is absent (oracle/make_ref.sh was never run where /root/reference exists) or the child fails."""
+    import subprocess
+    script = os.path.join(ROOT, "oracle", "ref_bench.py")
+    if not os.path.isdir(os.path.join(ROOT, "oracle", "_ref", "neurodiffeq")):
+        return None
+    try:
+        out = subprocess.run([sys.executable, script, "--grid", str(GRID), "--budget", str(budget_s)], capture_output=True,
+                             text=True, timeout=60 * budget_s + 120, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:      # noqa: BLE001 -- the bench line then carries the port and says so
+        print(f"bench.py: reference baseline failed ({type(e).__name__}: {e}); reporting the oracle port", file=sys.stderr)
+        return None
 
 
 # algorithmic GEMM flop per point of a training step, SURVEY.md 8(d) table
-ALGO_FLOP_PER_PT = {"c1": 25728, "c2": 32064, "c3": 198912, "c4": 33024, "c5": 646272}
+ALGO_FLOP_PER_PT = {"c1": 25728, "c2": 32064, "c3": 198912, "c4": 33024, "c5": 646272,
+                    # networks wider than 64 units (round 4), same formula (3 x sum_l 2 in out S_l):
+                    "w16": 21504,        # README.md:125 FCNN(2, 1, (512,)) on C2's problem, 5 streams
+                    "w17": 52224,        # 2 -> 512 -> 3, lid-driven cavity on one network, 5 streams x 3 outputs
+                    "w18": 791040,       # 2 -> 128 -> 128 -> 128 -> 1, Burgers, 4 streams
+                    "w19": 1992192}      # 2 -> 256 -> 256 -> 3 (the RE100 notebook's FCNN), 5 streams x 3 outputs
+WIDE_RECORDS = {"readme_laplace_512": ("w16", 256), "cavity_single_net_512x1": ("w17", 256), "burgers_128x3": ("w18", 256),
+                "cavity_single_net_256x2": ("w19", 256)}
 
 
 def timed_windows(step, k, barrier, reduce_max=None, min_total_s=0.25, max_windows=2000):
@@ -304,13 +344,13 @@ def timed_windows(step, k, barrier, reduce_max=None, min_total_s=0.25, max_windo
     return sorted(times)
 
 
-def config_record(name):
+def config_record(name, size=None):
     """One other BASELINE config at its stated size through run_train_epoch() on resident pre-sampled batches:
     ms per step (median of >= 0.25 s of windows), points/s, algorithmic TFLOP/s and fraction of the fp32 MFMA peak."""
     from tests import configs
     from neurodiffeq_amd.generators import ResidentBatchGenerator, SamplerGenerator
     torch.manual_seed(0)
-    solver, cfg = configs.make_solver(name)
+    solver, cfg = configs.make_solver(name, size)
     solver.fused = "require"
     torch.manual_seed(1)
     solver.generator["train"] = SamplerGenerator(ResidentBatchGenerator.presample(cfg["gen"], 2, "cuda"))
@@ -319,12 +359,12 @@ def config_record(name):
         for _ in range(5):
             solver.run_train_epoch()
         torch.cuda.synchronize()
-    k = 5 if name == "c5" else 50
+    k = 5 if name in ("c5", "w18", "w19") else 50
     times = timed_windows(solver.run_train_epoch, k, torch.cuda.synchronize)
     dt_epoch = times[(len(times) - 1) // 2] / k
     # the same training epochs the way a user runs them: fit(k) -- whole chunks of epochs per native call (solvers.fit,
     # ndq_fused_fit_run), no Python between the epochs.  For the launch-bound configs this is the step time that counts.
-    kf = 10 if name == "c5" else 500
+    kf = 10 if name in ("c5", "w18", "w19") else 500
     solver.fit(kf, tqdm_file=None)
     times_fit = timed_windows(lambda: solver.fit(kf, tqdm_file=None), 1, torch.cuda.synchronize)
     dt_fit = times_fit[(len(times_fit) - 1) // 2] / kf
@@ -625,7 +665,7 @@ def main():
             out["roofline"]["traffic"] = live["hbm_bytes"]
             out["roofline"]["traffic_note"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
                                                "300 steps, mean per dispatch; FETCH_SIZE x 2 per the guide and this package's "
-                                               "calibration (profiles/r02v_pmc_c2_summary.txt)")
+                                               "calibration (profiles/archive/r02/r02v_pmc_c2_summary.txt)")
             out["roofline"]["traffic_detail"] = live
         if os.path.exists(tpath):      # the last committed rocprofv3 --pmc measurement (may be stale: see its source field)
             tr = json.load(open(tpath))
@@ -662,12 +702,41 @@ def main():
         torch.cuda.synchronize()
         dt3 = (time.perf_counter() - t0) / args.steps
         out["with_device_sampling"] = {"value": N_POINTS / dt3, "ms_per_step": dt3 * 1e3}
+        # ... and what an UNCHANGED user script gets when torch's default device is cuda (the reference's import default,
+        # neurodiffeq/__init__.py:22; its generators draw on the default device, generators.py:152,264): a fresh solver on
+        # the same config -- its noisy training grid is drawn on the MI355X automatically (generators.on_default_device),
+        # one sampler launch + the two launches of the step, nothing resident, nothing opted into
+        torch.set_default_device("cuda")
+        try:
+            torch.manual_seed(0)
+            dsolver, dcfg = configs.make_solver("c2", GRID)
+            dsolver.fused = "require"
+            for _ in range(max(10, args.warmup)):
+                dsolver.run_train_epoch()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                dsolver.run_train_epoch()
+            torch.cuda.synchronize()
+            dt4 = (time.perf_counter() - t0) / args.steps
+            out["default_generator_cuda"] = {"value": N_POINTS / dt4, "ms_per_step": dt4 * 1e3,
+                                             "generator": type(dsolver.generator["train"].generator).__name__,
+                                             "note": "torch.set_default_device('cuda'), plain Solver2D + Generator2D: noise drawn "
+                                                     "by the Philox kernel every step, seeded from torch.cuda.initial_seed()"}
+            del dsolver
+        finally:
+            torch.set_default_device("cpu")
         if not args.no_configs:
             # the other BASELINE configs at their stated sizes (parity-tested at those sizes in tests/test_gpu_parity.py)
             del pipeline
             solver.generator["train"] = None
             torch.cuda.empty_cache()
             out["configs"] = {name: config_record(name) for name in ("c1", "c3", "c4", "c5")}
+            # networks wider than 64 units on C2's grid: the reference's README network first (csrc/ndq_wide.h: no GEMM at
+            # all, VALU-bound; csrc/ndq_deep.h: layer by layer, exact-fp32 MFMAs)
+            for label, (name, size) in WIDE_RECORDS.items():
+                out["configs"][label] = dict(config_record(name, size), golden=name,
+                                             kernels="csrc/ndq_wide.h" if name in ("w16", "w17") else "csrc/ndq_deep.h")
             out["roofline_pointwise_large"] = pointwise_large()
             out["c2_fp64"] = fp64_record()
         if world == 1 and not args.no_cold_start and (args.cold_start or not args.no_configs):
@@ -685,8 +754,8 @@ def main():
             out["speedup_vs_cpu_baseline"] = {
                 "presampled_inputs_both_sides": value / cb["presampled"]["value"],
                 "host_sampling_both_sides": out["with_host_sampling"]["value"] / cb["value"],
-                "note": "headline `value` (inputs resident in HBM) vs the CPU port on a pre-sampled batch; "
-                        "`with_host_sampling` (reference RNG draw + upload inside the step) vs the CPU port's full step"}
+                "note": f"headline `value` (inputs resident in HBM) vs the CPU baseline (kind = {cb['kind']}) on a pre-sampled "
+                        "batch; `with_host_sampling` (reference RNG draw + upload inside the step) vs its full step"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -21,6 +21,9 @@ extern "C" {
 #define NDQ_ACT_SIGMOID 2 /* torch.nn.Sigmoid passed as FCNN(actv=...) (networks.py:52-53) */
 #define NDQ_ACT_SWISH 3   /* neurodiffeq.networks.Swish (networks.py:155-175); actp = 0: its default fixed beta = 1 */
 #define NDQ_ACT_APTX 4    /* neurodiffeq.networks.APTx (networks.py:177-209); actp = 0: default fixed alpha = 1, beta = 1, gamma = 0.5 */
+#define NDQ_ACT_ELU 5       /* torch.nn.ELU (alpha = 1) as FCNN(actv=nn.ELU): tests/test_pde.py:377 */
+#define NDQ_ACT_SOFTPLUS 6  /* torch.nn.Softplus (beta = 1, threshold = 20): tests/test_pde.py:182 */
+#define NDQ_ACT_GELU 7      /* torch.nn.GELU (approximate = 'none') */
 
 /* Shape of one FCNN (networks.py:59-66: Linear(d,h) actv [Linear(h,h) actv]* Linear(h,n_out)) plus the set of
  * derivative streams of its raw output that the residual needs.  Stream order in every jets/gbar array:

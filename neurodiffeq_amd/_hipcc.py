@@ -4,8 +4,8 @@ between code generation and assembly: a fix-up pass over the device assembly.
 Why: on gfx950 (MI355X, ROCm 7.2 / clang 22) a packed-fp32 VALU instruction (``v_pk_mul_f32`` / ``v_pk_fma_f32`` / ...)
 that is IMMEDIATELY followed by a bf16 MFMA can deliver a wrong low-half result in lanes 48..63 (the last quarter of the
 wave): the lanes get the value of the preceding packed instruction's operand.  Found as a non-deterministic dW1 entry of
-one closure kernel, bisected at the assembly level, and reproduced in isolation by ``scripts/ubench_pk_war.hip``
-(``profiles/r01u_pk_mfma_hazard.txt``: ~11 % of the executions wrong; one wait state -- ``s_nop 0`` or any other
+one closure kernel, bisected at the assembly level, and reproduced in isolation by ``neurodiffeq_amd/csrc/canary_pk_war.hip``
+(``profiles/archive/r01/r01u_pk_mfma_hazard.txt``: ~11 % of the executions wrong; one wait state -- ``s_nop 0`` or any other
 instruction -- between the two makes it exact; scalar ``v_mul_f32`` instead of the packed form is exact).  The compiler's
 hazard recogniser does not know the pair, so ``fix_pk_mfma`` inserts the wait state itself: ~20 sites per kernel, one
 cycle each.

@@ -6,6 +6,7 @@ import os
 from . import _build
 
 NDQ_ACT_TANH, NDQ_ACT_SIN, NDQ_ACT_SIGMOID, NDQ_ACT_SWISH, NDQ_ACT_APTX = 0, 1, 2, 3, 4
+NDQ_ACT_ELU, NDQ_ACT_SOFTPLUS, NDQ_ACT_GELU = 5, 6, 7
 
 
 class MlpDesc(ctypes.Structure):

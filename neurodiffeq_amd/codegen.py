@@ -1049,7 +1049,7 @@ def mlp_ext_allowed(desc):
         diag |= 1 << pair_list(desc.d).index((a, a))
     if desc.mask3:              # third order: tanh / sin / sigmoid, every triple with its three pairs, no Laplacian stream,
         #                         d <= 4 (five inputs have more triples than the 32 mask bits)
-        if desc.lap or desc.d > 4 or desc.act not in (0, 1, 2) or desc.mask3 >> len(triple_list(desc.d)):
+        if desc.lap or desc.d > 4 or desc.act not in (0, 1, 2, 5, 6, 7) or desc.mask3 >> len(triple_list(desc.d)):
             return False
         for k, (a, b, c) in enumerate(triple_list(desc.d)):
             if (desc.mask3 >> k) & 1 and not all((desc.mask2 >> pair_list(desc.d).index(p)) & 1
@@ -1065,7 +1065,7 @@ def mlp_ext_allowed(desc):
     if is_wide(desc) and (desc.skip or desc.actp or desc.mono or desc.widths or desc.n_out > 16):
         return False          # wider than 64 units (csrc/ndq_wide.h: one hidden layer; csrc/ndq_deep.h: 2 .. 8): plain FCNN
     return (1 <= desc.d <= MAX_INPUTS and 1 <= desc.hidden <= MAX_HIDDEN and 1 <= desc.layers <= (4 if desc.widths else MAX_LAYERS)
-            and desc.act in (0, 1, 2, 3, 4) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
+            and desc.act in (0, 1, 2, 3, 4, 5, 6, 7) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
             and 0 <= desc.mask2 < (1 << npair) and (desc.first == 1 or desc.mask2 == 0)
             and (desc.lap == 0 or (desc.n_out == 1 and desc.mask2 != 0 and (desc.mask2 & ~diag) == 0))
             and desc.skip in (0, 1) and desc.actp in (0, 1, 2) and (desc.actp == 0 or desc.act in (3, 4)))
@@ -1115,6 +1115,8 @@ extern "C" const {record}* ndq_ext_kernels(void) {{
   static const {record} k = ndq::make_deep_kernels<CFG>();
   return &k;
 }}
+// 1: the next adjoint call may use the activations the last forward call left in the workspace (same parameters, same batch)
+extern "C" void ndq_ext_reuse_forward(int on) {{ ndq::deep_last().reuse = on != 0; }}
 """
     if is_wide(desc):
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one single-hidden-layer FCNN wider
@@ -1182,6 +1184,11 @@ def ensure_mlp_kernels(desc, f64=False):
         return False                              # e.g. the shape needs more LDS than a workgroup has
     _MLP_EXT[key] = ext                           # keep the module (and its record) alive
     return bool(supported(ctypes.byref(desc)))
+
+
+def mlp_ext_module(desc, f64=False):
+    """The loaded extension module serving ``desc`` (None: the descriptor is served by libndq.so's own table)."""
+    return _MLP_EXT.get(desc.key() + (("f64",) if f64 else ()))
 
 
 def build_fused(program: PointwiseProgram, desc, force=False, threads=None):

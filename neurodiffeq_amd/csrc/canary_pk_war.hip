@@ -10,12 +10,12 @@
 // gradient entry.  Found by assembly-level bisection (one s_nop after that v_pk_mul makes the kernel bit-exact again);
 // the file started life as a suspected write-after-read hazard, hence its name, but the result is wrong whether or not
 // anything overwrites the sources afterwards.  This program replays the sequence with hard-coded registers and counts
-// wrong lanes for several variants (profiles/r01u_pk_mfma_hazard.txt): ~11 % of the executions wrong as found; exact
+// wrong lanes for several variants (profiles/archive/r01/r01u_pk_mfma_hazard.txt): ~11 % of the executions wrong as found; exact
 // with one wait state or any non-MFMA instruction between the packed op and the MFMA, with scalar multiplies instead,
 // or with the f32 MFMA as the follower.  Rewriting every packed-fp32 instruction that carries op_sel as two scalar
 // instructions (neurodiffeq_amd/_hipcc.py) also cured a second, older corruption that only showed with two waves per
 // SIMD.
-//   hipcc --offload-arch=gfx950 -O2 scripts/ubench_pk_war.hip -o /tmp/pk_war && /tmp/pk_war
+//   hipcc --offload-arch=gfx950 -O2 neurodiffeq_amd/csrc/canary_pk_war.hip -o /tmp/pk_war && /tmp/pk_war
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -32,8 +32,7 @@ namespace ndq {
 template <int D_, int FIRST_, unsigned M2_, int LAP_, unsigned M3_, int W_, int L_, int ACT_, int NOUT_>
 struct DeepCfg {
   using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
-  static_assert(M3_ == 0 || ACT_ == ACT_TANH || ACT_ == ACT_SIN || ACT_ == ACT_SIGMOID,
-                "third-order streams: tanh / sin / sigmoid networks");
+  static_assert(M3_ == 0 || act_has_s4(ACT_), "third-order streams: activations with a stated fourth derivative");
   static_assert(W_ >= 1 && W_ <= 512 && L_ >= 2 && L_ <= 8, "2 .. 8 hidden layers of up to 512 units");
   static constexpr int D = D_, W = W_, L = L_, ACT = ACT_, NOUT = NOUT_, NS = SS::NS, NC = NS * NOUT_;
   static constexpr int HP = (W_ + 15) & ~15, NB = HP / 16;
@@ -45,11 +44,16 @@ struct DeepCfg {
   static constexpr int offWout = offW(L_ + 1), offbout = offWout + NOUT_ * W_;
   static constexpr int P = offbout + NOUT_;
   // output blocks (16 units) a wave accumulates per pass of the per-point GEMMs: JBC * NS fragments of 4 registers
-  static constexpr int jbc() { int j = 48 / NS; j = j < 1 ? 1 : j; j = j > 8 ? 8 : j; return j > NB ? NB : j; }
+  // (the NB blocks are spread evenly over the passes: balanced(8 blocks, at most 6 per pass) = 4 + 4, not 6 + 2)
+  static constexpr int balanced(int most) { const int passes = (NB + most - 1) / most; return (NB + passes - 1) / passes; }
+  static constexpr int jbc() { int j = 48 / NS; j = j < 1 ? 1 : j; j = j > 8 ? 8 : j; return balanced(j > NB ? NB : j); }
   static constexpr int JBC = jbc(), NCH = (NB + JBC - 1) / JBC;
   // first-layer gradient accumulators of the last reverse GEMM: JBF blocks per pass
-  static constexpr int jbf() { int j = 12 / (D_ + 1); j = j < 1 ? 1 : j; return j > JBC ? JBC : j; }
+  static constexpr int jbf() { int j = 12 / (D_ + 1); j = j < 1 ? 1 : j; return balanced(j > JBC ? JBC : j); }
   static constexpr int JBF = jbf(), NCHF = (NB + JBF - 1) / JBF;
+  // reverse GEMM between hidden layers: its epilogue operands (Z_{l-1}) are prefetched for all JBB blocks
+  static constexpr int jbb() { int j = 24 / NS; j = j < 1 ? 1 : j; return balanced(j > JBC ? JBC : j); }
+  static constexpr int JBB = jbb(), NCHB = (NB + JBB - 1) / JBB;
   static constexpr int TJ = 4;                                       // weight-gradient GEMM: TJ x TJ blocks per wave
   static constexpr int NT = (NB + TJ - 1) / TJ;
 };
@@ -206,6 +210,14 @@ __global__ __launch_bounds__(C::THREADS) void deep_fwd_gemm(DeepArgs a) {
   if (stripe >= nstripes) return;
   const int ntiles = a.np >> 4;
   const size_t sstride = (size_t)a.np * C::HP;
+  // this wave's output units never change: their biases are loaded once (rows 4 kg + r of block b, column p)
+  real4 bs[C::JBC];
+#pragma unroll
+  for (int jb = 0; jb < C::JBC; ++jb) {
+    const int j0 = 16 * (ch * C::JBC + jb) + 4 * kg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bs[jb][r] = (j0 + r < C::W) ? a.bias[j0 + r] : 0.f;
+  }
   for (int tile = stripe; tile < ntiles; tile += nstripes) {
     const int n = tile * 16 + p;
     const int nn = n < a.n ? n : a.n - 1;
@@ -219,37 +231,67 @@ __global__ __launch_bounds__(C::THREADS) void deep_fwd_gemm(DeepArgs a) {
     for (int s = 0; s < C::NS; ++s)
 #pragma unroll
       for (int jb = 0; jb < C::JBC; ++jb) acc[s][jb] = real4{0.f, 0.f, 0.f, 0.f};
-    for (int c16 = 0; c16 < C::NB; ++c16) {
-      const int k0 = 16 * c16 + 4 * kg;                    // this lane's 4 contraction units
-      real4 hh[C::NS];
-      {
-        real4 zz[C::NS];
-        if constexpr (!FIRSTIN) {
+    // the next contraction step's operands are fetched before the current step's MFMAs are issued
+    real4 zn[FIRSTIN ? 1 : C::NS], wn[C::JBC];
+    real f1w[FIRSTIN ? 4 : 1][C::D], f1b[FIRSTIN ? 4 : 1];       // FIRSTIN: first-layer rows of the step's 4 contraction units
+    auto fetch = [&](int c16) {
+      const int k0 = 16 * c16 + 4 * kg;
+      if constexpr (!FIRSTIN) {
 #pragma unroll
-          for (int s = 0; s < C::NS; ++s) zz[s] = *reinterpret_cast<const real4*>(a.zin + s * sstride + (size_t)n * C::HP + k0);
+        for (int s = 0; s < C::NS; ++s) zn[s] = *reinterpret_cast<const real4*>(a.zin + s * sstride + (size_t)n * C::HP + k0);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool ok = k0 + t < C::W;
+          f1b[t] = ok ? a.prm[C::offb1 + (ok ? k0 + t : 0)] : 0.f;
+#pragma unroll
+          for (int d = 0; d < C::D; ++d) f1w[t][d] = ok ? a.prm[C::offW1 + (ok ? k0 + t : 0) * C::D + d] : 0.f;
         }
+      }
+#pragma unroll
+      for (int jb = 0; jb < C::JBC; ++jb) {
+        const int b = ch * C::JBC + jb;
+        wn[jb] = *reinterpret_cast<const real4*>(a.wmat + (size_t)(16 * (b < C::NB ? b : 0) + p) * C::HP + k0);
+      }
+    };
+    fetch(0);
+    for (int c16 = 0; c16 < C::NB; ++c16) {
+      real4 hh[C::NS], w4[C::JBC];
+#pragma unroll
+      for (int jb = 0; jb < C::JBC; ++jb) w4[jb] = wn[jb];
+      {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           real z[C::NS], h[C::NS], tt, cc;
-          if constexpr (FIRSTIN) first_unit_streams<C>(a.prm, k0 + t, x, z);
-          else {
+          if constexpr (FIRSTIN) {
 #pragma unroll
-            for (int s = 0; s < C::NS; ++s) z[s] = zz[s][t];
+            for (int s = 0; s < C::NS; ++s) z[s] = 0.f;
+            real zv = f1b[t];
+#pragma unroll
+            for (int d = 0; d < C::D; ++d) {
+              zv = rfma(f1w[t][d], x[d], zv);
+              if constexpr (C::SS::FIRST) z[1 + d] = f1w[t][d];
+            }
+            z[0] = zv;
+          } else {
+#pragma unroll
+            for (int s = 0; s < C::NS; ++s) z[s] = zn[s][t];
           }
           jet_unit_forward<C>(z, h, tt, cc);
 #pragma unroll
           for (int s = 0; s < C::NS; ++s) hh[s][t] = h[s];
         }
       }
+      if (c16 + 1 < C::NB) fetch(c16 + 1);
+      __builtin_amdgcn_sched_barrier(0);       // the loads stay ABOVE the MFMAs (the scheduler sinks them below otherwise)
 #pragma unroll
       for (int jb = 0; jb < C::JBC; ++jb) {
         const int b = ch * C::JBC + jb;
         if (b < C::NB) {
-          const real4 w4 = *reinterpret_cast<const real4*>(a.wmat + (size_t)(16 * b + p) * C::HP + k0);
 #pragma unroll
           for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[s][jb] = mfma16x16x4(w4[t], hh[s][t], acc[s][jb]);
+            for (int t = 0; t < 4; ++t) acc[s][jb] = mfma16x16x4(w4[jb][t], hh[s][t], acc[s][jb]);
         }
       }
     }
@@ -259,7 +301,7 @@ __global__ __launch_bounds__(C::THREADS) void deep_fwd_gemm(DeepArgs a) {
       if (b < C::NB) {
         const int j0 = 16 * b + 4 * kg;                    // rows 4 kg + r of the block, column p
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[0][jb][r] += (j0 + r < C::W) ? a.bias[j0 + r] : 0.f;
+        for (int r = 0; r < 4; ++r) acc[0][jb][r] += bs[jb][r];
 #pragma unroll
         for (int s = 0; s < C::NS; ++s) *reinterpret_cast<real4*>(a.zout + s * sstride + (size_t)n * C::HP + j0) = acc[s][jb];
       }
@@ -271,13 +313,27 @@ __global__ __launch_bounds__(C::THREADS) void deep_fwd_gemm(DeepArgs a) {
 // from the coordinates and what leaves is dW1 / db1 (per-wave partial rows); else Zbar_{l-1} is stored and db_{l-1} summed.
 template <class C, bool TOFIRST>
 __global__ __launch_bounds__(C::THREADS) void deep_bwd_gemm(DeepArgs a) {
-  constexpr int JB = TOFIRST ? C::JBF : C::JBC, NCH = TOFIRST ? C::NCHF : C::NCH;
+  constexpr int JB = TOFIRST ? C::JBF : C::JBB, NCH = TOFIRST ? C::NCHF : C::NCHB;
   const int lane = threadIdx.x & 63, p = lane & 15, kg = lane >> 4;
   const int gw = blockIdx.x * C::WAVES + (threadIdx.x >> 6), nw = gridDim.x * C::WAVES;
   const int ch = gw % NCH, stripe = gw / NCH, nstripes = nw / NCH;
   if (stripe >= nstripes) return;
   const int ntiles = a.np >> 4;
   const size_t sstride = (size_t)a.np * C::HP;
+  // TOFIRST: the first layer's rows of this wave's output units (they never change), loaded once
+  real u1w[TOFIRST ? JB : 1][4][C::D], u1b[TOFIRST ? JB : 1][4];
+  if constexpr (TOFIRST) {
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * (ch * JB + jb) + 4 * kg + r;
+        const bool ok = k < C::W;
+        u1b[jb][r] = ok ? a.prm[C::offb1 + (ok ? k : 0)] : 0.f;
+#pragma unroll
+        for (int d = 0; d < C::D; ++d) u1w[jb][r][d] = ok ? a.prm[C::offW1 + (ok ? k : 0) * C::D + d] : 0.f;
+      }
+  }
   real gb[JB][4], gw1[TOFIRST ? JB : 1][4][C::D];
 #pragma unroll
   for (int jb = 0; jb < JB; ++jb)
@@ -302,20 +358,45 @@ __global__ __launch_bounds__(C::THREADS) void deep_bwd_gemm(DeepArgs a) {
     for (int s = 0; s < C::NS; ++s)
 #pragma unroll
       for (int jb = 0; jb < JB; ++jb) acc[s][jb] = real4{0.f, 0.f, 0.f, 0.f};
-    for (int c16 = 0; c16 < C::NB; ++c16) {
-      const int k0 = 16 * c16 + 4 * kg;
-      real4 zb[C::NS];
+    // the epilogue's operands (Z_{l-1} of the tile's output units) are requested up front: they arrive under the MFMAs
+    real4 zpre[TOFIRST ? 1 : JB][C::NS];
+    if constexpr (!TOFIRST) {
 #pragma unroll
-      for (int s = 0; s < C::NS; ++s) zb[s] = *reinterpret_cast<const real4*>(a.zin + s * sstride + (size_t)n * C::HP + k0);
+      for (int jb = 0; jb < JB; ++jb) {
+        const int b = ch * JB + jb;
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s)
+          zpre[jb][s] = *reinterpret_cast<const real4*>(a.zprev + s * sstride + (size_t)n * C::HP + 16 * (b < C::NB ? b : 0) + 4 * kg);
+      }
+    }
+    real4 zn[C::NS], wn[JB];
+    auto fetch = [&](int c16) {
+      const int k0 = 16 * c16 + 4 * kg;
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s) zn[s] = *reinterpret_cast<const real4*>(a.zin + s * sstride + (size_t)n * C::HP + k0);
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) {
+        const int b = ch * JB + jb;
+        wn[jb] = *reinterpret_cast<const real4*>(a.wmat + (size_t)(16 * (b < C::NB ? b : 0) + p) * C::HP + k0);
+      }
+    };
+    fetch(0);
+    for (int c16 = 0; c16 < C::NB; ++c16) {
+      real4 zb[C::NS], w4[JB];
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s) zb[s] = zn[s];
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) w4[jb] = wn[jb];
+      if (c16 + 1 < C::NB) fetch(c16 + 1);
+      __builtin_amdgcn_sched_barrier(0);       // the loads stay ABOVE the MFMAs (the scheduler sinks them below otherwise)
 #pragma unroll
       for (int jb = 0; jb < JB; ++jb) {
         const int b = ch * JB + jb;
         if (b < C::NB) {
-          const real4 w4 = *reinterpret_cast<const real4*>(a.wmat + (size_t)(16 * b + p) * C::HP + k0);
 #pragma unroll
           for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[s][jb] = mfma16x16x4(w4[t], zb[s][t], acc[s][jb]);
+            for (int t = 0; t < 4; ++t) acc[s][jb] = mfma16x16x4(w4[jb][t], zb[s][t], acc[s][jb]);
         }
       }
     }
@@ -324,18 +405,23 @@ __global__ __launch_bounds__(C::THREADS) void deep_bwd_gemm(DeepArgs a) {
       const int b = ch * JB + jb;
       if (b < C::NB) {
         const int j0 = 16 * b + 4 * kg;
-        real4 zz[C::NS], out[C::NS];
-        if constexpr (!TOFIRST) {
-#pragma unroll
-          for (int s = 0; s < C::NS; ++s) zz[s] = *reinterpret_cast<const real4*>(a.zprev + s * sstride + (size_t)n * C::HP + j0);
-        }
+        real4 out[C::NS];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           real z[C::NS], g[C::NS], tt, cc;
-          if constexpr (TOFIRST) first_unit_streams<C>(a.prm, j0 + r, x, z);
-          else {
+          if constexpr (TOFIRST) {
 #pragma unroll
-            for (int s = 0; s < C::NS; ++s) z[s] = zz[s][r];
+            for (int s = 0; s < C::NS; ++s) z[s] = 0.f;
+            real zv = u1b[jb][r];
+#pragma unroll
+            for (int d = 0; d < C::D; ++d) {
+              zv = rfma(u1w[jb][r][d], x[d], zv);
+              if constexpr (C::SS::FIRST) z[1 + d] = u1w[jb][r][d];
+            }
+            z[0] = zv;
+          } else {
+#pragma unroll
+            for (int s = 0; s < C::NS; ++s) z[s] = zpre[jb][s][r];
           }
           Act<C::ACT>::fwd(z[0], tt, cc);
 #pragma unroll
@@ -376,66 +462,126 @@ __global__ __launch_bounds__(C::THREADS) void deep_bwd_gemm(DeepArgs a) {
   }
 }
 
-// dW_l[j][k] = sum_{s, n} Zbar_l[s][n][j] sigma-jet(Z_{l-1})[s][n][k]: the contraction runs over points, 4 per MFMA.
-// Wave w owns the TJ x TJ block tile w % (NT * NT) of dW_l and the 4-point groups w / (NT * NT), + KS.
+// dW_l[j][k] = sum_{s, n} Zbar_l[s][n][j] sigma-jet(Z_{l-1})[s][n][k]: the contraction runs over points, 4 per MFMA
+// (contraction slot kg of a lane = point 4 g + kg of point group g).
+// A workgroup owns a 64 x 64 tile of dW_l (tile blockIdx % NT^2) and the slice blockIdx / NT^2 of the point groups, which
+// its four waves walk interleaved; their accumulators are added in wave order through LDS, so one partial tile leaves per
+// workgroup.  A lane's 4 rows (columns) of the tile are the 4 CONSECUTIVE units it loads as one 16-byte value: MFMA block u
+// of the tile = units {4 i + u}, a relabelling of rows that costs nothing.  The next group's loads are issued before the
+// current group's MFMAs (the kernel has ~60 registers: 4 workgroups per CU hide the rest of the latency).
 template <class C, bool FIRSTIN>
-__global__ __launch_bounds__(C::THREADS) void deep_wgrad_gemm(DeepArgs a) {
-  const int lane = threadIdx.x & 63, i = lane & 15, kg = lane >> 4;
-  const int gw = blockIdx.x * C::WAVES + (threadIdx.x >> 6), nw = gridDim.x * C::WAVES;
+__global__ __launch_bounds__(C::THREADS, 2) void deep_wgrad_gemm(DeepArgs a) {
+  __shared__ real comb[3][64][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kg = lane >> 4;
   constexpr int NT2 = C::NT * C::NT;
-  const int tl = gw % NT2, ks = gw / NT2, KS = nw / NT2;
+  const int tl = blockIdx.x % NT2, ks = blockIdx.x / NT2, KS = gridDim.x / NT2;
   if (ks >= KS) return;
-  const int tj = tl / C::NT, tk = tl % C::NT;
+  const int j0 = 64 * (tl / C::NT) + 4 * i, k0 = 64 * (tl % C::NT) + 4 * i;      // this lane's 4 row / column units
+  const bool jok = j0 < C::HP, kok = k0 < C::HP;
   const size_t sstride = (size_t)a.np * C::HP;
-  real4 acc[C::TJ][C::TJ];
+  real4 acc[4][4];
 #pragma unroll
-  for (int u = 0; u < C::TJ; ++u)
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int v = 0; v < C::TJ; ++v) acc[u][v] = real4{0.f, 0.f, 0.f, 0.f};
-  const int ngroups = a.np >> 2;
-  for (int g4 = ks; g4 < ngroups; g4 += KS) {
-    const int n = 4 * g4 + kg;                             // this lane's point = MFMA contraction slot kg
-    const int nn = n < a.n ? n : a.n - 1;
-    real x[C::D];
+    for (int v = 0; v < 4; ++v) acc[u][v] = real4{0.f, 0.f, 0.f, 0.f};
+  // FIRSTIN: the first layer's rows of this lane's 4 column units
+  real w1v[FIRSTIN ? 4 : 1][C::D], b1v[FIRSTIN ? 4 : 1];
+  if constexpr (FIRSTIN) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const bool ok = k0 + v < C::W;
+      b1v[v] = ok ? a.prm[C::offb1 + k0 + v] : 0.f;
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) w1v[v][d] = ok ? a.prm[C::offW1 + (k0 + v) * C::D + d] : 0.f;
+    }
+  }
+  const int ngroups = a.np >> 2, g0 = ks * C::WAVES + wave, gstep = KS * C::WAVES;
+  real4 za[C::NS], zk[FIRSTIN ? 1 : C::NS];
+  real x[FIRSTIN ? C::D : 1];
+  auto fetch = [&](int g4) {
+    const int n = 4 * g4 + kg;
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s)
+      za[s] = jok ? *reinterpret_cast<const real4*>(a.zin + s * sstride + (size_t)n * C::HP + j0) : real4{0.f, 0.f, 0.f, 0.f};
     if constexpr (FIRSTIN) {
+      const int nn = n < a.n ? n : a.n - 1;
 #pragma unroll
       for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    } else {
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s)
+        zk[s] = kok ? *reinterpret_cast<const real4*>(a.zprev + s * sstride + (size_t)n * C::HP + k0) : real4{0.f, 0.f, 0.f, 0.f};
     }
-    real av[C::NS][C::TJ], hv[C::NS][C::TJ];
+  };
+  if (g0 < ngroups) fetch(g0);
+  for (int g4 = g0; g4 < ngroups; g4 += gstep) {
+    real4 av[C::NS], hv[C::NS];
 #pragma unroll
-    for (int u = 0; u < C::TJ; ++u) {
-      const int bj = tj * C::TJ + u, bk = tk * C::TJ + u;
-      const int jj = 16 * (bj < C::NB ? bj : 0) + i, kk = 16 * (bk < C::NB ? bk : 0) + i;
+    for (int s = 0; s < C::NS; ++s) av[s] = za[s];
 #pragma unroll
-      for (int s = 0; s < C::NS; ++s) av[s][u] = (bj < C::NB) ? a.zin[s * sstride + (size_t)n * C::HP + jj] : 0.f;
+    for (int v = 0; v < 4; ++v) {
       real z[C::NS], h[C::NS], tt, cc;
-      if constexpr (FIRSTIN) first_unit_streams<C>(a.prm, bk < C::NB ? kk : C::W, x, z);
-      else {
+      if constexpr (FIRSTIN) {
 #pragma unroll
-        for (int s = 0; s < C::NS; ++s) z[s] = a.zprev[s * sstride + (size_t)n * C::HP + kk];
+        for (int s = 0; s < C::NS; ++s) z[s] = 0.f;
+        real zv = b1v[v];
+#pragma unroll
+        for (int d = 0; d < C::D; ++d) {
+          zv = rfma(w1v[v][d], x[d], zv);
+          if constexpr (C::SS::FIRST) z[1 + d] = w1v[v][d];
+        }
+        z[0] = zv;
+      } else {
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) z[s] = zk[s][v];
       }
       jet_unit_forward<C>(z, h, tt, cc);
 #pragma unroll
-      for (int s = 0; s < C::NS; ++s) hv[s][u] = h[s];
+      for (int s = 0; s < C::NS; ++s) hv[s][v] = h[s];
     }
+    if (g4 + gstep < ngroups) fetch(g4 + gstep);           // in flight under the MFMAs below
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-      for (int u = 0; u < C::TJ; ++u)
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int v = 0; v < C::TJ; ++v) acc[u][v] = mfma16x16x4(av[s][u], hv[s][v], acc[u][v]);
+        for (int v = 0; v < 4; ++v) acc[u][v] = mfma16x16x4(av[s][u], hv[s][v], acc[u][v]);
   }
-  real* out = a.pw + (size_t)ks * C::HP * C::HP;
+  // waves 1 .. 3 -> LDS, wave 0 adds them in order and stores the workgroup's partial tile
+  if (wave > 0) {
 #pragma unroll
-  for (int u = 0; u < C::TJ; ++u)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int v = 0; v < C::TJ; ++v) {
-      const int bj = tj * C::TJ + u, bk = tk * C::TJ + v;
-      if (bj < C::NB && bk < C::NB) {
+      for (int v = 0; v < 4; ++v)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)(16 * bj + 4 * kg + r) * C::HP + 16 * bk + i] = acc[u][v][r];
-      }
+        for (int r = 0; r < 4; ++r) comb[wave - 1][(u * 4 + v) * 4 + r][lane] = acc[u][v][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll 1
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][v][r] += comb[w][(u * 4 + v) * 4 + r][lane];
+    // D layout: register r of lane (i, kg) = row 4 kg + r, column i of the 16 x 16 block (u, v):
+    // row unit = 64 tj + 4 (4 kg + r) + u, column units 64 tk + 4 i + v, v = 0 .. 3 -- one 16-byte store
+    real* out = a.pw + (size_t)ks * C::HP * C::HP;
+    const int jbase = 64 * (tl / C::NT);
+    if (kok) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = jbase + 4 * (4 * kg + r) + u;
+          if (row < C::HP)
+            *reinterpret_cast<real4*>(out + (size_t)row * C::HP + k0) = real4{acc[u][0][r], acc[u][1][r], acc[u][2][r], acc[u][3][r]};
+        }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ output layer
@@ -567,24 +713,46 @@ __global__ __launch_bounds__(256) void deep_prep(const real* __restrict__ prm, r
   }
 }
 
-// dst[r * cols + c] = sum_{i < nparts} src[(i * rows_p + r) * cols_p + c], fixed order (fp64 accumulators, as
-// reduce_partials_kernel of csrc/ndq_api.hip)
-__global__ __launch_bounds__(256) void deep_reduce2d(const real* __restrict__ src, int nparts, int rows_p, int cols_p, int rows, int cols,
-                                                     real* __restrict__ dst) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= rows * cols) return;
-  const int r = e / cols, c = e % cols;
-  const size_t off = (size_t)r * cols_p + c, step = (size_t)rows_p * cols_p;
+// Second stage of every reduction of a reverse sweep in ONE launch.  Job k: dst[r * cols + c] = sum_{i < nparts}
+// src[(i * rows_p + r) * cols_p + c] (partial rows / tiles written by the kernels above; the padding of rows_p x cols_p is
+// dropped).  Fixed order: thread (x, y) of a 64 x 16 block adds the parts i = y, y + 16, ... of element x in four
+// independent chains (fp64 accumulators, as reduce_partials_kernel of csrc/ndq_api.hip), the 16 slice sums are combined
+// in order through LDS.
+struct DeepReduceJob {
+  const real* src;
+  real* dst;
+  int nparts, rows_p, cols_p, rows, cols, block0;      // block0: first workgroup of the job
+};
+struct DeepReduceJobs {
+  int njobs, nblocks;
+  DeepReduceJob job[24];
+};
+__global__ __launch_bounds__(1024) void deep_reduce_all(DeepReduceJobs J) {
+  __shared__ double part[16][64];
+  int k = 0;
+  while (k + 1 < J.njobs && (int)blockIdx.x >= J.job[k + 1].block0) ++k;
+  const DeepReduceJob& jb = J.job[k];
+  const int e = ((int)blockIdx.x - jb.block0) * 64 + threadIdx.x, y = threadIdx.y;
+  const bool live = e < jb.rows * jb.cols;
+  const int r = live ? e / jb.cols : 0, c = live ? e % jb.cols : 0;
+  const real* src = jb.src + (size_t)r * jb.cols_p + c;
+  const size_t step = (size_t)jb.rows_p * jb.cols_p;
   double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
-  int i = 0;
-  for (; i + 3 < nparts; i += 4) {
-    s0 += (double)src[off + (size_t)i * step];
-    s1 += (double)src[off + (size_t)(i + 1) * step];
-    s2 += (double)src[off + (size_t)(i + 2) * step];
-    s3 += (double)src[off + (size_t)(i + 3) * step];
+  int i = y;
+  for (; i + 48 < jb.nparts; i += 64) {
+    const real v0 = src[(size_t)i * step], v1 = src[(size_t)(i + 16) * step], v2 = src[(size_t)(i + 32) * step],
+               v3 = src[(size_t)(i + 48) * step];
+    s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
   }
-  for (; i < nparts; ++i) s0 += (double)src[off + (size_t)i * step];
-  dst[e] = (real)((s0 + s1) + (s2 + s3));
+  for (; i < jb.nparts; i += 16) s0 += (double)src[(size_t)i * step];
+  part[y][threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (y == 0 && live) {
+    double v = part[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) v += part[w][threadIdx.x];
+    jb.dst[e] = (real)v;
+  }
 }
 
 }  // namespace ndq

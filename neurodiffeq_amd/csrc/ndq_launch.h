@@ -7,8 +7,10 @@
 #define NDQ_WG_TR 1     // adjoint kernels of H = 32 networks: weight gradients from the bf16x3 planes (ndq_mlp.h Cfg::WG_TR)
 #endif
 #include "ndq_mlp.h"
-#include "ndq_wide.h"
-#include "ndq_deep.h"
+#if !NDQ_F64
+#include "ndq_wide.h"     // one hidden layer of 65 .. 512 units (fp32 only)
+#include "ndq_deep.h"     // 2 .. 8 hidden layers of 65 .. 512 units (fp32 only)
+#endif
 #include "../../include/ndq.h"
 
 namespace ndq {
@@ -148,22 +150,24 @@ kernels_record make_wide_kernels() {
 // itself, its own reductions being fixed-order already (bwd_waves is set so that ndq_mlp_bwd_blocks() == 1).
 struct DeepPlan {
   int np, blocks_max;
-  size_t X, z0, zb0, wp, wt, pw, pb, pw1, pwo, pbo, total;
+  size_t X, z0, zb0, wp, wt, pw, pw_layer, pb, pb_layer, pw1, pwo, pbo, total;
 };
 template <class C>
 DeepPlan deep_plan(int n) {
   DeepPlan q{};
   q.np = (n + 15) & ~15;
   q.blocks_max = 256;
-  const size_t HP = C::HP, nwmax = (size_t)q.blocks_max * C::WAVES;
+  const size_t HP = C::HP, nwmax = 4 * (size_t)q.blocks_max * C::WAVES;
   q.X = (size_t)C::NS * q.np * HP;
   size_t o = 0;
   q.z0 = o; o += (size_t)(C::L - 1) * q.X;            // Z_2 .. Z_L
   q.zb0 = o; o += 2 * q.X;                            // Zbar ping-pong
   q.wp = o; o += (size_t)(C::L - 1) * HP * HP;
   q.wt = o; o += (size_t)(C::L - 1) * HP * HP;
-  q.pw = o; o += (nwmax / (C::NT * C::NT) + 1) * HP * HP;
-  q.pb = o; o += nwmax * HP;
+  q.pw_layer = (2 * (size_t)q.blocks_max / (C::NT * C::NT) + 1) * HP * HP;       // per hidden matrix
+  q.pw = o; o += (size_t)(C::L - 1) * q.pw_layer;
+  q.pb_layer = nwmax * HP;                                                          // per hidden layer
+  q.pb = o; o += (size_t)C::L * q.pb_layer;
   q.pw1 = o; o += nwmax * HP * C::D;
   q.pwo = o; o += nwmax * C::NOUT * HP;
   q.pbo = o; o += nwmax * C::NOUT;
@@ -181,6 +185,12 @@ inline real* deep_workspace(size_t floats) {
   }
   return base;
 }
+// The adjoint entry recomputes the forward layers unless the caller vouches that the workspace still holds them: the engine
+// raises this flag for the adjoint call that directly follows the forward call of the same training step (same parameter
+// vector, same batch); a different coordinate / parameter pointer or point count recomputes regardless.
+struct DeepLast { const void* coords; const void* params; int n, ldc; bool reuse; };
+inline DeepLast& deep_last() { static DeepLast d{nullptr, nullptr, 0, 0, false}; return d; }
+
 inline int deep_blocks(long waves, int min_waves, int cap) {
   long w = waves > min_waves ? waves : min_waves;
   long b = (w + 3) / 4;
@@ -192,7 +202,7 @@ template <class C>
 int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc, int n, const real* params, hipStream_t st) {
   hipLaunchKernelGGL(deep_prep<C>, dim3(64, C::L - 1), dim3(256), 0, st, params, ws + q.wp, ws + q.wt);
   const int ntiles = q.np / 16;
-  const int blocks = deep_blocks((long)ntiles * C::NCH, C::NCH, q.blocks_max);
+  const int blocks = deep_blocks((long)ntiles * C::NCH, C::NCH, 2 * q.blocks_max);      // two workgroups per CU
   for (int l = 2; l <= C::L; ++l) {
     DeepArgs a{};
     a.coords = coords; a.prm = params; a.n = n; a.np = q.np; a.ldc = ldc;
@@ -214,9 +224,11 @@ int deep_kernels_fwd(const real* coords, int ldc, int n, const real* params, rea
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = deep_forward_layers<C>(q, ws, coords, ldc, n, params, st);
   if (rc) return rc;
+  DeepLast& last = deep_last();
+  last.coords = coords; last.params = params; last.n = n; last.ldc = ldc;
   DeepHeadArgs h{};
   h.prm = params; h.z = ws + q.z0 + (size_t)(C::L - 2) * q.X; h.jets = jets; h.n = n; h.np = q.np; h.ldj = ldj;
-  hipLaunchKernelGGL(deep_head_fwd<C>, dim3(deep_blocks(q.np / 16, 1, q.blocks_max)), dim3(C::THREADS), 0, st, h);
+  hipLaunchKernelGGL(deep_head_fwd<C>, dim3(deep_blocks(q.np / 16, 1, 4 * q.blocks_max)), dim3(C::THREADS), 0, st, h);
   return (int)hipGetLastError();
 }
 
@@ -227,22 +239,32 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
   real* ws = deep_workspace(q.total);
   if (!ws) return (int)hipErrorOutOfMemory;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = deep_forward_layers<C>(q, ws, coords, ldc, n, params, st);
-  if (rc) return rc;
+  DeepLast& last = deep_last();
+  const bool have = last.reuse && last.coords == coords && last.params == params && last.n == n && last.ldc == ldc;
+  last.coords = nullptr;                       // whatever happens next, the workspace is about to be overwritten
+  if (!have) {
+    int rc = deep_forward_layers<C>(q, ws, coords, ldc, n, params, st);
+    if (rc) return rc;
+  }
+  // every kernel of the sweep leaves partial rows / tiles in its own region; ONE launch at the end adds them all up
+  DeepReduceJobs J{};
   auto reduce = [&](const real* src, int nparts, int rows_p, int cols_p, int rows, int cols, real* dst) {
-    hipLaunchKernelGGL(deep_reduce2d, dim3((rows * cols + 255) / 256), dim3(256), 0, st, src, nparts, rows_p, cols_p, rows, cols, dst);
+    DeepReduceJob& j = J.job[J.njobs++];
+    j.src = src; j.dst = dst; j.nparts = nparts; j.rows_p = rows_p; j.cols_p = cols_p; j.rows = rows; j.cols = cols;
+    j.block0 = J.nblocks;
+    J.nblocks += (rows * cols + 63) / 64;
   };
   constexpr int UG = (C::HP + 63) / 64;
   {
     DeepHeadArgs h{};
     h.prm = params; h.z = ws + q.z0 + (size_t)(C::L - 2) * q.X; h.gbar = gbar; h.zbar = ws + q.zb0;
-    h.pwo = ws + q.pwo; h.pb = ws + q.pb; h.pbo = ws + q.pbo; h.n = n; h.np = q.np; h.ldj = ldj;
-    const int blocks = deep_blocks((long)UG * q.np, UG, q.blocks_max);
+    h.pwo = ws + q.pwo; h.pb = ws + q.pb + (size_t)(C::L - 1) * q.pb_layer; h.pbo = ws + q.pbo; h.n = n; h.np = q.np; h.ldj = ldj;
+    const int blocks = deep_blocks((long)UG * q.np, UG, 4 * q.blocks_max);
     const int stripes = blocks * C::WAVES / UG;
     hipLaunchKernelGGL(deep_head_bwd<C>, dim3(blocks), dim3(C::THREADS), 0, st, h);
-    reduce(ws + q.pwo, stripes, C::NOUT, C::HP, C::NOUT, C::W, grad + C::offWout);
-    reduce(ws + q.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb(C::L));
-    reduce(ws + q.pbo, stripes, 1, C::NOUT, 1, C::NOUT, grad + C::offbout);
+    reduce(h.pwo, stripes, C::NOUT, C::HP, C::NOUT, C::W, grad + C::offWout);
+    reduce(h.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb(C::L));
+    reduce(h.pbo, stripes, 1, C::NOUT, 1, C::NOUT, grad + C::offbout);
   }
   int cur = 0;
   const int ntiles = q.np / 16;
@@ -252,30 +274,34 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
     a.zin = ws + q.zb0 + (size_t)cur * q.X;                               // Zbar_l
     a.zprev = l > 2 ? ws + q.z0 + (size_t)(l - 3) * q.X : nullptr;        // Z_{l-1}
     {   // dW_l
-      a.pw = ws + q.pw;
-      const int blocks = deep_blocks((long)C::NT * C::NT * (q.np / 4), C::NT * C::NT, q.blocks_max);
-      const int KS = blocks * C::WAVES / (C::NT * C::NT);
+      a.pw = ws + q.pw + (size_t)(l - 2) * q.pw_layer;
+      // one workgroup per (tile, point slice)
+      int KS = (q.np / 4 + C::WAVES - 1) / C::WAVES;
+      if (KS > 2 * q.blocks_max / (C::NT * C::NT)) KS = 2 * q.blocks_max / (C::NT * C::NT);      // two workgroups per CU
+      if (KS < 1) KS = 1;
+      const int blocks = KS * C::NT * C::NT;
       if (l == 2) hipLaunchKernelGGL((deep_wgrad_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
       else hipLaunchKernelGGL((deep_wgrad_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
-      reduce(ws + q.pw, KS, C::HP, C::HP, C::W, C::W, grad + C::offW(l));
+      reduce(a.pw, KS, C::HP, C::HP, C::W, C::W, grad + C::offW(l));
     }
     a.wmat = ws + q.wt + (size_t)(l - 2) * C::HP * C::HP;
-    a.pb = ws + q.pb;
+    a.pb = ws + q.pb + (size_t)(l - 2) * q.pb_layer;                      // db_{l-1}
     if (l > 2) {
       a.zout = ws + q.zb0 + (size_t)(cur ^ 1) * q.X;
-      const int blocks = deep_blocks((long)ntiles * C::NCH, C::NCH, q.blocks_max);
+      const int blocks = deep_blocks((long)ntiles * C::NCHB, C::NCHB, 2 * q.blocks_max);
       hipLaunchKernelGGL((deep_bwd_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
-      reduce(ws + q.pb, blocks * C::WAVES / C::NCH, 1, C::HP, 1, C::W, grad + C::offb(l - 1));
+      reduce(a.pb, blocks * C::WAVES / C::NCHB, 1, C::HP, 1, C::W, grad + C::offb(l - 1));
       cur ^= 1;
     } else {
       a.pw1 = ws + q.pw1;
-      const int blocks = deep_blocks((long)ntiles * C::NCHF, C::NCHF, q.blocks_max);
+      const int blocks = deep_blocks((long)ntiles * C::NCHF, C::NCHF, 2 * q.blocks_max);
       const int stripes = blocks * C::WAVES / C::NCHF;
       hipLaunchKernelGGL((deep_bwd_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
-      reduce(ws + q.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb1);
-      reduce(ws + q.pw1, stripes, C::HP, C::D, C::W, C::D, grad + C::offW1);
+      reduce(a.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb1);
+      reduce(a.pw1, stripes, C::HP, C::D, C::W, C::D, grad + C::offW1);
     }
   }
+  hipLaunchKernelGGL(deep_reduce_all, dim3(J.nblocks), dim3(64, 16), 0, st, J);
   return (int)hipGetLastError();
 }
 

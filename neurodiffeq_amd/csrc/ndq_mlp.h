@@ -234,7 +234,11 @@ struct Streams {
 
 // ------------------------------------------------------------------------------------------------ activations
 // state kept per hidden unit: t = sigma(z) and c (only where sigma' is not a function of t).
-enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 };
+enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4, ACT_ELU = 5, ACT_SOFTPLUS = 6, ACT_GELU = 7 };
+// activations with a stated fourth derivative (third-order streams need it in the reverse pass)
+constexpr bool act_has_s4(int act) {
+  return act == ACT_TANH || act == ACT_SIN || act == ACT_SIGMOID || act == ACT_ELU || act == ACT_SOFTPLUS || act == ACT_GELU;
+}
 
 #ifndef NDQ_FAST_TANH
 #define NDQ_FAST_TANH 1
@@ -251,7 +255,7 @@ enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4 }
 // Hidden-layer GEMMs on the bf16 matrix core with 3-way split operands ("bf16x3"): x = x0 + x1 + x2 (three bf16
 // chunks = 24 mantissa bits), products a0b0 + a0b1 + a1b0 + a0b2 + a2b0 + a1b1 accumulated in fp32 -> relative error
 // ~2^-23, i.e. fp32-class accuracy.  Why: the f32-input MFMA shares the VALU datapath on gfx950 (it does NOT overlap
-// with VALU work -- scripts/ubench_mfma_valu.hip, profiles/r01e_ubench_*), while v_mfma_f32_16x16x32_bf16 runs on the
+// with VALU work -- scripts/ubench_mfma_valu.hip, profiles/archive/r01/r01e_ubench_*), while v_mfma_f32_16x16x32_bf16 runs on the
 // real matrix core, 6 of them replace 8 f32 MFMAs at ~1/3 of the cycles, and they overlap with the activation math.
 #ifndef NDQ_BF16X3
 #define NDQ_BF16X3 1
@@ -427,13 +431,77 @@ template <> struct Act<ACT_APTX> {
   }
 };
 
+// torch.nn.ELU (alpha = 1; tests/test_pde.py:377 of the reference trains FCNN(hidden_units=(100, 100), actv=nn.ELU)):
+// f = z (z > 0), e^z - 1 (z <= 0); every derivative is 1, 0, 0 ... for z > 0 and e^z = f + 1 for z <= 0.  State: t = f
+// alone (t > 0 <=> z > 0).  (The second derivative jumps at 0: that is the activation the user chose, the reference
+// differentiates it too.)
+template <> struct Act<ACT_ELU> {
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c, real = 1.f) {
+#if NDQ_F64
+    t = z > 0. ? z : expm1(z);
+#else
+    t = z > 0.f ? z : expm1f(z);
+#endif
+    c = 0.f;
+  }
+  static __device__ __forceinline__ real s1(real t, real, real = 1.f) { return t > 0.f ? (real)1.f : t + 1.f; }
+  static __device__ __forceinline__ real s2(real t, real, real) { return t > 0.f ? (real)0.f : t + 1.f; }
+  static __device__ __forceinline__ real s3(real t, real, real) { return t > 0.f ? (real)0.f : t + 1.f; }
+  static __device__ __forceinline__ real s4(real t, real, real) { return t > 0.f ? (real)0.f : t + 1.f; }
+};
+// torch.nn.Softplus (beta = 1, threshold = 20): f = log(1 + e^z), f1 = sigmoid(z) =: c, f2 = c (1 - c),
+// f3 = c (1 - c)(1 - 2c), f4 = f2 (1 - 6 f2).  State: t = f, c = sigmoid(z).  (Above the threshold torch returns z and the
+// derivative 1; sigmoid(20) = 1 - 2e-9 is 1 in fp32.)
+template <> struct Act<ACT_SOFTPLUS> {
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c, real = 1.f) {
+    c = sigmoid_fast(z);
+#if NDQ_F64
+    t = z > 20. ? z : log1p(exp(z));
+#else
+    t = z > 20.f ? z : log1pf(expf(z));
+#endif
+  }
+  static __device__ __forceinline__ real s1(real, real c, real = 1.f) { return c; }
+  static __device__ __forceinline__ real s2(real, real c, real) { return c * (1.f - c); }
+  static __device__ __forceinline__ real s3(real, real c, real) { return c * (1.f - c) * rfma(-2.f, c, 1.f); }
+  static __device__ __forceinline__ real s4(real, real c, real) {
+    const real d = c * (1.f - c);
+    return d * rfma(-6.f, d, 1.f);
+  }
+};
+// torch.nn.GELU (approximate = 'none'): f = z Phi(z) with Phi the normal CDF, phi its density:
+// f1 = Phi + z phi, f2 = phi (2 - z^2), f3 = phi (z^3 - 4 z), f4 = phi (-z^4 + 7 z^2 - 4).  State: t = f, c = z.
+template <> struct Act<ACT_GELU> {
+  static __device__ __forceinline__ real cdf(real z) {
+#if NDQ_F64
+    return 0.5 * (1.0 + erf(z * 0.70710678118654752440));
+#else
+    return 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+#endif
+  }
+  static __device__ __forceinline__ real pdf(real z) {
+#if NDQ_F64
+    return 0.39894228040143267794 * exp(-0.5 * z * z);
+#else
+    return 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * z * z);
+#endif
+  }
+  static __device__ __forceinline__ void fwd(real z, real& t, real& c, real = 1.f) { c = z; t = z * cdf(z); }
+  static __device__ __forceinline__ real s1(real, real z, real = 1.f) { return rfma(z, pdf(z), cdf(z)); }
+  static __device__ __forceinline__ real s2(real, real z, real) { return pdf(z) * rfma(-z, z, 2.f); }
+  static __device__ __forceinline__ real s3(real, real z, real) { return pdf(z) * z * rfma(z, z, -4.f); }
+  static __device__ __forceinline__ real s4(real, real z, real) {
+    const real z2 = z * z;
+    return pdf(z) * rfma(z2, 7.f - z2, -4.f);
+  }
+};
+
 // ------------------------------------------------------------------------------------------------ config
 template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0, int SKIP_ = 0,
           unsigned M3_ = 0, int ACTP_ = 0, int HR_ = 0, unsigned HRP_ = 0, unsigned MONO_ = 0>
 struct Cfg {
   using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
-  static_assert(M3_ == 0 || ACT_ == ACT_TANH || ACT_ == ACT_SIN || ACT_ == ACT_SIGMOID,
-                "third-order streams: tanh / sin / sigmoid networks");
+  static_assert(M3_ == 0 || act_has_s4(ACT_), "third-order streams: activations with a stated fourth derivative");
   static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
   // MONO: a networks.MonomialNN (networks.py:109-139) in front of the first linear layer -- the D coordinates are
   // expanded to the features x_a^deg, degree after degree (bit k of MONO <-> degree k + 1, ascending), so the first

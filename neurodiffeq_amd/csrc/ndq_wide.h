@@ -43,8 +43,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <int D_, int FIRST_, unsigned M2_, int LAP_, unsigned M3_, int W_, int ACT_, int NOUT_>
 struct WideCfg {
   using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
-  static_assert(M3_ == 0 || ACT_ == ACT_TANH || ACT_ == ACT_SIN || ACT_ == ACT_SIGMOID,
-                "third-order streams: tanh / sin / sigmoid networks");
+  static_assert(M3_ == 0 || act_has_s4(ACT_), "third-order streams: activations with a stated fourth derivative");
   static_assert(W_ >= 1 && W_ <= 512, "one hidden layer of up to 512 units");
   static constexpr int D = D_, W = W_, ACT = ACT_, NOUT = NOUT_, NS = SS::NS, NC = NS * NOUT_;
   static constexpr int L = 1, HR = W_, SKIP = 0, ACTP = 0;

@@ -91,6 +91,37 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
                 func_columns.append(list(f.cols))
             else:
                 raise TraceUnsupported(f"a condition returned {type(f).__name__}, not traced (N, k) values")
+        # what this trace arrived at, for eq_probe below: the node of every function column and residual
+        eq_nodes = tuple(c.i for cols in func_columns for c in cols) + ("|",) + tuple(r.i for r in res)
+
+        def eq_probe():
+            """Run the conditions and the equations AGAIN on the same symbolic coordinates.  The graph is hash-consed, so
+            an unchanged system arrives at the same nodes; a Python float read from a dict / closure / attribute that a
+            callback has changed since (``solvers.py:380`` re-evaluates ``diff_eqs`` every batch) gives another constant
+            node and with it other residual nodes.  True: what the kernels were compiled from is still what the user's
+            callables compute."""
+            n_captured = len(g.captured)
+            try:
+                with trace_scope(g):
+                    f2 = [cfv(n, c, *coords) for n, c in zip(all_nets, conditions)]
+                    r2 = diff_eqs(*f2, *coords) if diff_eqs is not None else []
+                    if isinstance(r2, Sym):
+                        r2 = [r2]
+                    r2 = [column(r) for r in r2]
+                cols = []
+                for f in f2:
+                    if isinstance(f, Sym):
+                        cols.append(f.i)
+                    elif isinstance(f, SymMat) and all(isinstance(c, Sym) for c in f.cols):
+                        cols.extend(c.i for c in f.cols)
+                    else:
+                        return False
+                return tuple(cols) + ("|",) + tuple(r.i for r in r2) == eq_nodes
+            except Exception:       # noqa: BLE001 -- whatever the callables do now, it is not what was compiled
+                return False
+            finally:
+                del g.captured[n_captured:]       # (the probe's own captures are the same tensors again)
+
         # a custom loss: callable(residual (N, n_eq), funcs, coords) -> scalar (solvers.py:216-226; the solver passes
         # loss_fn + additional_loss as ONE callable) traced to the per-point term whose batch mean it is
         loss_term = None
@@ -210,6 +241,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     program.n_metrics = len(metric_terms)        # the last n_metrics "functions" are per-point metric terms
     program.func_widths = [len(cols) for cols in func_columns]    # columns of every solver function, in order
     program.loss_probe = loss_probe              # custom losses: "does the callable still trace to the compiled term?"
+    program.eq_probe = eq_probe                  # equations / conditions: "do they still trace to the compiled residuals?"
     program.unique_nets = nets                   # distinct modules, in first-appearance order: one parameter set each
     return program, descs
 
@@ -226,6 +258,8 @@ class FusedSystem:
         # dtype float64 (the reference's default precision, neurodiffeq/__init__.py:22): the three-kernel pipeline on the
         # fp64 build of the stream kernels (libndq64.so) with the generated pointwise kernel compiled in double; the
         # single-launch closure kernels, the native epoch and the device-side Adam are fp32 only
+        from . import _canary
+        _canary.check()              # once per process: the gfx950 hazard reproducer through / without the assembly fix-up pass
         self.dt = dtype
         self.f64 = dtype == torch.float64
         self.esize = 8 if self.f64 else 4
@@ -261,7 +295,7 @@ class FusedSystem:
         self.fusedk = None
         # the 8-wave build of the closure kernel (two waves per SIMD), built on first use for batches of at least
         # WIDE_MIN_POINTS points: None = not tried yet, False = not available / rejected
-        self.fusedk_wide = None if os.environ.get("NDQ_FUSED_WIDE", "1") != "0" else False
+        self.fusedk_wide = None if (os.environ.get("NDQ_FUSED_WIDE", "1") != "0" and not _canary.STATUS["refuse_two_waves"]) else False
         self._self_check = os.environ.get("NDQ_SELF_CHECK", "1") != "0"
         self._verified = set()                       # id() of the closure-kernel variants that passed verify_fused
         if fused_so is not None:
@@ -631,13 +665,23 @@ class FusedSystem:
         _lib.check(rc, "ndq_pw_launch")
         return seed
 
-    def backward(self, b, n, stream, accumulate):
+    def backward(self, b, n, stream, accumulate, after_forward=False):
+        """after_forward: this call directly follows ``forward`` on the same batch and parameters (one training step).  The
+        layer-by-layer kernels of deep wide networks (csrc/ndq_deep.h) then keep the activations their forward call left in
+        the module's workspace instead of recomputing them (a module serves one evaluation site at a time: with several
+        sites of one shape only the last forward is still there, the others recompute -- the module checks)."""
         seen = set()
         for k in range(self.n_sites):
             net = self.site_net[k]
             fp = self.flat[net]
+            ext = codegen.mlp_ext_module(self.descs[k], self.f64) if after_forward else None
+            hint = getattr(ext, "ndq_ext_reuse_forward", None) if ext is not None else None
+            if hint is not None:
+                hint(1)
             rc = self.L.ndq_mlp_jet_bwd(ctypes.byref(self.descs[k]), self._site_coords(b, k, n, False), b["ld"], n,
                                         _ptr(fp.flat), _ptr(b["gbar"][k]), b["ld"], _ptr(b["partials"][k]), stream)
+            if hint is not None:
+                hint(0)
             _lib.check(rc, "ndq_mlp_jet_bwd")
             # every site of a network adds into that network's gradient (the first one overwrites unless accumulating)
             rc = self.L.ndq_reduce_partials(_ptr(b["partials"][k]), b["bwd_blocks"][k], fp.numel, _ptr(fp.grad),
@@ -753,7 +797,7 @@ class FusedSystem:
 
     # closure kernel vs three-kernel pipeline on the first training batch: both are fp32 evaluations held to the 1e-5
     # contract, so they may differ by at most twice that.  Measured over the 190 closure kernels of the GPU test-suite
-    # (profiles/r03c_self_check_distribution.json): median 1.6e-8, 99th percentile 7e-7, maximum 5.2e-6 (C2 at the
+    # (profiles/archive/r03/r03c_self_check_distribution.json): median 1.6e-8, 99th percentile 7e-7, maximum 5.2e-6 (C2 at the
     # reference-trained state, where the residual is a cancellation and the reference's own fp32 gradient is 4e-4 off).
     SELF_CHECK_TOL = 2e-5
 
@@ -1122,7 +1166,7 @@ class FusedSystem:
         self.forward(b, n, stream)
         seed = self.pointwise(b, n, stream, train, n_global, want_funcs, want_resid)
         if train:
-            self.backward(b, n, stream, accumulate)
+            self.backward(b, n, stream, accumulate, after_forward=True)
             self.reduce_theta(b, b["pw_blocks"], stream, accumulate)
         self.reduce_loss(b, stream, seed, slot)
         return b, n

@@ -127,8 +127,9 @@ class BaseGenerator:
 class Generator1D(BaseGenerator):
     """1-D points on [t_min, t_max] (generators.py:107-191); ``method`` as in the reference."""
 
-    def __init__(self, size, t_min=0.0, t_max=1.0, method="uniform", noise_std=None):
+    def __init__(self, size, t_min=0.0, t_max=1.0, method="uniform", noise_std=None, bit_exact_cpu=False):
         super().__init__()
+        self.bit_exact_cpu = bool(bit_exact_cpu)      # True: never drawn on the device (see on_default_device)
         self.size, self.t_min, self.t_max, self.method = size, t_min, t_max, method
         self.noise_std = noise_std if noise_std else ((t_max - t_min) / size) / 4.0
         fixed = None
@@ -179,8 +180,9 @@ class Generator2D(BaseGenerator):
     the x noise is drawn before the y noise, each with one ``torch.normal`` over the flattened ij-meshgrid."""
 
     def __init__(self, grid=(10, 10), xy_min=(0.0, 0.0), xy_max=(1.0, 1.0), method="equally-spaced-noisy",
-                 xy_noise_std=None):
+                 xy_noise_std=None, bit_exact_cpu=False):
         super().__init__()
+        self.bit_exact_cpu = bool(bit_exact_cpu)
         self.grid, self.size = grid, grid[0] * grid[1]
         self.xy_min, self.xy_max, self.method, self.xy_noise_std = xy_min, xy_max, method, xy_noise_std
         axes = None
@@ -243,8 +245,9 @@ class GeneratorSpherical(BaseGenerator):
     """Points (r, theta, phi) with directions uniform-ish on the sphere (generators.py:572-655); same draw order as the
     reference: three ``rand`` for the direction, three ``randint`` signs, then the radius."""
 
-    def __init__(self, size, r_min=0., r_max=1., method="equally-spaced-noisy"):
+    def __init__(self, size, r_min=0., r_max=1., method="equally-spaced-noisy", bit_exact_cpu=False):
         super().__init__()
+        self.bit_exact_cpu = bool(bit_exact_cpu)
         if r_min < 0 or r_max < r_min:
             raise ValueError(f"Illegal range [{r_min}, {r_max}]")
         if method == "equally-spaced-noisy":        # r^2 ~ U[r_min^2, r_max^2]
@@ -280,8 +283,9 @@ class Generator3D(BaseGenerator):
     """Points on a (noisy) 3-D grid (generators.py:317-416)."""
 
     def __init__(self, grid=(10, 10, 10), xyz_min=(0.0, 0.0, 0.0), xyz_max=(1.0, 1.0, 1.0),
-                 method="equally-spaced-noisy"):
+                 method="equally-spaced-noisy", bit_exact_cpu=False):
         super().__init__()
+        self.bit_exact_cpu = bool(bit_exact_cpu)
         self.grid, self.size = grid, grid[0] * grid[1] * grid[2]
         self.xyz_min, self.xyz_max, self.method = xyz_min, xyz_max, method
         if method in ("equally-spaced", "equally-spaced-noisy"):
@@ -769,3 +773,42 @@ class DeviceGenerator(BaseGenerator):
         d = super()._internal_vars()
         d.update(generator=self.generator, seed=self.seed, stream_id=self.stream_id)
         return d
+
+
+# ------------------------------------------------------------------------------------------------ default-device sampling
+# The reference draws on torch's DEFAULT device (generators.py:152,158,264-265: torch.linspace / torch.normal without a
+# device argument); its import default is cuda where one exists (neurodiffeq/__init__.py:22), and there the noise comes from
+# the GPU's Philox stream -- itself not the CPU generator's numbers.  Same rule here: a solver built while torch's default
+# device is cuda draws the NOISE of Generator1D / 2D / 3D / Spherical on the MI355X (DeviceGenerator: Philox4x32-10, seeded
+# from torch.cuda.initial_seed(), so torch.manual_seed still fixes the run; every rank draws the SAME batch and takes its
+# shard); with a CPU default device nothing changes: host draws, bit for bit the reference's CPU numbers.  Index sampling
+# (randperm / randint: ResampleGenerator, BatchGenerator, latin-hypercube, the spherical signs of the host path) and every
+# wrapper generator stay on the CPU generator bit for bit in both cases.  ``Generator2D(..., bit_exact_cpu=True)`` or
+# ``set_default_sampling("cpu")`` keep a generator on the host under a cuda default device as well.
+_SAMPLING = {"mode": os.environ.get("NDQ_SAMPLING", "auto")}
+
+
+def set_default_sampling(mode):
+    """"auto" (default): follow torch's default device;  "cpu": always sample on the host (the reference's CPU numbers bit
+    for bit, 17x slower per step at the headline size);  "device": device-side noise whenever an MI355X is visible."""
+    if mode not in ("auto", "cpu", "device"):
+        raise ValueError(f"mode must be 'auto', 'cpu' or 'device', got {mode!r}")
+    _SAMPLING["mode"] = mode
+
+
+def on_default_device(gen):
+    """``gen`` itself, or -- when noise is to be drawn on the device (see above) and the kernel knows the distribution -- a
+    DeviceGenerator around it."""
+    mode = _SAMPLING["mode"]
+    if mode == "cpu" or gen is None or getattr(gen, "bit_exact_cpu", False) or not torch.cuda.is_available():
+        return gen
+    if type(gen) not in (Generator1D, Generator2D, Generator3D, GeneratorSpherical):
+        return gen
+    if mode == "auto" and torch.get_default_device().type != "cuda":
+        return gen
+    if not (type(gen) is GeneratorSpherical or gen.method == "uniform" or gen.method == "equally-spaced-noisy"):
+        return gen                 # static grids are uploaded once and read in place; other laws: host
+    try:
+        return DeviceGenerator(gen, seed=torch.cuda.initial_seed(), stream_id=0)
+    except ValueError:
+        return gen

@@ -131,7 +131,20 @@ class MonomialNN(nn.Module):
 
 # ------------------------------------------------------------------------------------------- kernel-side description
 _ACT_IDS = {nn.Tanh: _lib.NDQ_ACT_TANH, SinActv: _lib.NDQ_ACT_SIN, nn.Sigmoid: _lib.NDQ_ACT_SIGMOID,
-            Swish: _lib.NDQ_ACT_SWISH, APTx: _lib.NDQ_ACT_APTX}
+            Swish: _lib.NDQ_ACT_SWISH, APTx: _lib.NDQ_ACT_APTX,
+            # torch's own modules with their DEFAULT arguments only (checked in describe): generic sigma ... sigma'''' tables
+            nn.ELU: _lib.NDQ_ACT_ELU, nn.Softplus: _lib.NDQ_ACT_SOFTPLUS, nn.GELU: _lib.NDQ_ACT_GELU}
+
+
+def _default_torch_activation(a):
+    """nn.ELU / nn.Softplus / nn.GELU are compiled with torch's default arguments; anything else stays on the composite path."""
+    if isinstance(a, nn.ELU):
+        return a.alpha == 1.0
+    if isinstance(a, nn.Softplus):
+        return a.beta == 1.0 and a.threshold == 20.0
+    if isinstance(a, nn.GELU):
+        return getattr(a, "approximate", "none") == "none"
+    return True
 
 
 # hidden layers the kernel templates take: any number the LDS holds when all have one width (up to MAX_LAYERS are offered),
@@ -168,7 +181,7 @@ def describe(net, dtype=torch.float32):
     if not all(isinstance(m, nn.Linear) and m.bias is not None for m in linears):
         return None
     act_types = {type(a) for a in acts}
-    if len(act_types) != 1 or next(iter(act_types)) not in _ACT_IDS:
+    if len(act_types) != 1 or next(iter(act_types)) not in _ACT_IDS or not all(_default_torch_activation(a) for a in acts):
         return None
     # Swish / APTx: their default fixed parameters (constants in the kernels), trainable ones on every layer
     # (ndq_mlp_desc.actp = 1: per-layer scalars at the end of the flat parameter vector) or fixed non-default values

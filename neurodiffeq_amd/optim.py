@@ -42,6 +42,7 @@ class FusedAdam(torch.optim.Adam):
         """Adopt the flat buffers of ``flat_params`` (list of FlatParams) for every parameter this optimiser owns."""
         if [id(fp) for fp, *_ in self._bound] == [id(fp) for fp in flat_params]:
             return
+        self._sync_step_tensors()              # a re-bind (system rebuilt mid-training) adopts the CURRENT step counts
         group_of = {id(p): g for g in self.param_groups for p in g["params"]}
         self._bound, self._bound_ids = [], set()
         for fp in flat_params:

@@ -27,7 +27,7 @@ import torch.nn as nn
 from . import _lib
 from .conditions import BaseCondition
 from .generators import (Generator1D, Generator2D, GeneratorSpherical, SamplerGenerator, draws_are_static,
-                         draws_have_fixed_size, device_source)
+                         draws_have_fixed_size, device_source, on_default_device)
 from . import autograd_ops
 from .losses import _losses
 from .networks import FCNN, describe
@@ -79,6 +79,12 @@ def _default_l2(residual, funcs, coords):
 
 
 class BaseSolver(ABC):
+    #: epochs between UNCONDITIONAL re-traces of diff_eqs / the conditions (program.eq_probe).  Every epoch a StateWatch
+    #: compares the Python state those callables can reach (closure cells, globals they name, condition attributes ...)
+    #: with what it was at trace time -- a few comparisons -- and re-traces at once when something moved; this period only
+    #: bounds how long state the watch cannot see (fetched through foreign code) could stay frozen.  fit() without
+    #: callbacks re-traces at every chunk boundary as well.
+    EQ_PROBE_EVERY = 128
     LOSS_PROBE_EVERY = 1        # epochs between re-probes of a traced custom loss (see _fused_system): every epoch -- a probe
     #                             is one Python re-trace of the callable on a hash-consed graph, and a loss that follows
     #                             solver state (a penalty switched on at epoch N) must never train on a stale kernel
@@ -145,7 +151,10 @@ class BaseSolver(ABC):
 
         self.optimizer = optimizer if optimizer else FusedAdam(_unique_params(self.nets))
         self._set_loss_fn(loss_fn)
-        self.generator = {"train": SamplerGenerator(train_generator), "valid": SamplerGenerator(valid_generator)}
+        # (the reference samples on torch's default device, generators.py:152,264: under a cuda default device the noise of
+        # the grid / spherical generators is drawn on the MI355X -- generators.on_default_device)
+        self.generator = {"train": SamplerGenerator(on_default_device(train_generator)),
+                          "valid": SamplerGenerator(on_default_device(valid_generator))}
         self.n_batches = {"train": n_batches_train, "valid": n_batches_valid}
         self._batch = {"train": None, "valid": None}
         if self.n_batches["valid"] == 0 and _requires_closure(self.optimizer):
@@ -164,9 +173,13 @@ class BaseSolver(ABC):
         self._composite_plain = False   # composite path: plain torch forwards (set when an equation needs order > 2)
         self._loss_probe_count = 0
         self._loss_time_dependent = False
+        self._eq_watch = None                  # _pystate.StateWatch over what diff_eqs / the conditions can read
+        self._eq_probe_countdown = 1           # epochs until the next unconditional re-trace (second use, then EQ_PROBE_EVERY)
         self._fused_key = None
         self._fast_tracks_best = False
         self.dist = None                # optional neurodiffeq_amd.parallel.BatchSharding
+        # the solver's own bookkeeping attributes: not equation state when diff_eqs is a bound method (_pystate.StateWatch)
+        self._own_attrs = frozenset(self.__dict__) | {"_own_attrs"}
 
     # ------------------------------------------------------------------------------------------ loss function
     def _set_loss_fn(self, criterion):
@@ -354,6 +367,8 @@ class BaseSolver(ABC):
                getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind, sys_dtype,
                id(self.loss_fn) if loss_kind == "custom" else None,
                tuple((name, id(fn)) for name, fn in self.metrics_fn.items()))
+        if key == self._fused_key and self._fused_sys is not None and not self._equations_unchanged(self._fused_sys):
+            self._fused_key = None                # the callables compute something else now: rebuild below (cached by source)
         if key == self._fused_key:
             sysm = self._fused_sys
             # scalar tensors captured by the equations are constants of the generated kernel: re-trace when one of them
@@ -411,6 +426,7 @@ class BaseSolver(ABC):
                     self._host_metrics = True
                 if isinstance(self.optimizer, FusedAdam):
                     self.optimizer.bind(self._fused_sys.flat)
+                self._watch_equations()
             except TraceUnsupported as e:
                 reason = str(e)
             except _lib.NdqError:
@@ -426,6 +442,38 @@ class BaseSolver(ABC):
                           "reference's closure on torch autograd instead -- same results, typically 10-100x slower per "
                           "step.  Pass fused='require' to make this an error.", RuntimeWarning)
         return self._fused_sys
+
+    def _watch_equations(self):
+        """Remember the Python state diff_eqs / the conditions / compute_func_val can read (solvers.py:380 re-evaluates them
+        every batch; the traced kernels froze it)."""
+        from ._pystate import StateWatch
+        self._eq_watch = StateWatch([self.diff_eqs, self.compute_func_val] + list(self.conditions))
+        self._eq_probe_countdown = 1
+
+    def _equations_unchanged(self, sysm, force=False):
+        """False: the user's equations / conditions now trace to something else than the kernels of ``sysm`` were compiled
+        from (a Python float, dict entry or attribute they read was changed, e.g. by a callback).  The cheap state watch
+        runs every call; the re-trace when the watch is dirty, on the second use, every EQ_PROBE_EVERY calls and on
+        ``force`` (chunk boundaries of the multi-epoch fit path)."""
+        probe = getattr(sysm.program, "eq_probe", None)
+        if probe is None:
+            return True
+        dirty = self._eq_watch is None or self._eq_watch.dirty()
+        self._eq_probe_countdown -= 1
+        if not (dirty or force or self._eq_probe_countdown <= 0):
+            return True
+        if self._eq_probe_countdown <= 0:
+            self._eq_probe_countdown = self.EQ_PROBE_EVERY
+        same = probe()
+        if dirty:
+            self._watch_equations_refresh()
+        return same
+
+    def _watch_equations_refresh(self):
+        from ._pystate import StateWatch
+        countdown = self._eq_probe_countdown
+        self._eq_watch = StateWatch([self.diff_eqs, self.compute_func_val] + list(self.conditions))
+        self._eq_probe_countdown = countdown
 
     @property
     def fused_active(self):
@@ -651,6 +699,9 @@ class BaseSolver(ABC):
         if type(tg.generator).__name__ == "DeviceGenerator":
             return 0
         if self._fused_system(system.n_coords) is not system:      # something was swapped since the last epoch
+            return 0
+        if not self._equations_unchanged(system, force=True):       # chunk boundary: unconditional re-trace (EQ_PROBE_EVERY)
+            self._fused_key = None
             return 0
         n = tg.size
         if system.needs_check(n):

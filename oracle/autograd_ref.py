@@ -118,7 +118,7 @@ class APTxFixedRef(nn.Module):
 
 ACTIVATIONS = {"tanh": nn.Tanh, "sin": Sin, "sigmoid": nn.Sigmoid, "swish": SwishRef, "aptx": APTxRef,
                "swish-tr": SwishTrainableRef, "aptx-tr": APTxTrainableRef, "swish-fixed": SwishFixedRef,
-               "aptx-fixed": APTxFixedRef}
+               "aptx-fixed": APTxFixedRef, "elu": nn.ELU, "softplus": nn.Softplus, "gelu": nn.GELU}
 
 
 def make_fcnn(n_in, n_out, hidden, act="tanh", dtype=torch.float32):

@@ -29,6 +29,15 @@ def act_deriv4(name, z):
         s = 1.0 / (1.0 + np.exp(-z))
         d1 = s * (1 - s)
         return d1 * (1 - 2 * s) * (1 - 12 * d1)
+    if name == "elu":
+        return np.where(z > 0, 0.0, np.exp(np.minimum(z, 0.0)))
+    if name == "softplus":
+        s = 1.0 / (1.0 + np.exp(-z))
+        d = s * (1 - s)
+        return d * (1 - 6 * d)
+    if name == "gelu":
+        phi = np.exp(-0.5 * z * z) / np.sqrt(2 * np.pi)
+        return phi * (-z ** 4 + 7 * z ** 2 - 4)
     raise KeyError(f"no fourth derivative stated for {name}")
 
 
@@ -63,6 +72,23 @@ def act_derivs(name, z, theta=None):
             return s, d1, d2, d3
         # Leibniz on z * s(z)  (Swish, beta = 1: networks.py:155-175)
         return z * s, s + z * d1, 2 * d1 + z * d2, 3 * d2 + z * d3
+    if name == "elu":         # torch.nn.ELU, alpha = 1: z (z > 0), e^z - 1 (z <= 0)
+        e = np.exp(np.minimum(z, 0.0))
+        pos = z > 0
+        return np.where(pos, z, e - 1), np.where(pos, 1.0, e), np.where(pos, 0.0, e), np.where(pos, 0.0, e)
+    if name == "softplus":    # torch.nn.Softplus, beta = 1 (the threshold = 20 branch is the same function to 2e-9)
+        s = 1.0 / (1.0 + np.exp(-z))
+        d = s * (1 - s)
+        return np.logaddexp(0.0, z), s, d, d * (1 - 2 * s)
+    if name == "gelu":        # torch.nn.GELU, exact: z Phi(z)
+        from math import sqrt, pi
+        try:
+            from scipy.special import erf
+        except Exception:     # pragma: no cover
+            erf = np.vectorize(__import__("math").erf)
+        Phi = 0.5 * (1 + erf(z / sqrt(2.0)))
+        phi = np.exp(-0.5 * z * z) / sqrt(2 * pi)
+        return z * Phi, Phi + z * phi, phi * (2 - z * z), phi * (z ** 3 - 4 * z)
     if name == "aptx":        # z (1 + tanh z) / 2: APTx with alpha = 1, beta = 1, gamma = 1/2 (networks.py:177-209); Leibniz
         t = np.tanh(z)
         u, u1 = 1 + t, 1 - t * t

@@ -1,0 +1,22 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE (oracle/): puts the UNMODIFIED reference where bench.py's cpu_baseline leg can time it on the GPU box.
+#
+# The reference is a pure-Python package (nothing to compile): the "build" is a verbatim copy of /root/reference/neurodiffeq
+# plus the two import shims the golden script uses (tests/golden/_refshim: `seaborn`, `ordered_set` -- plotting / container
+# dependencies that are not installed and that no code on the timed path executes) into oracle/_ref/.  oracle/_ref/ is
+# git-ignored (no reference source ever enters the history) but not gpurun-ignored, so it travels with the snapshot like
+# the built .so files.  Only bench.py (cpu_baseline) and oracle/ref_bench.py ever import from it.
+#   usage: oracle/make_ref.sh [/root/reference]
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd)
+REF=${1:-/root/reference}
+if [ ! -d "$REF/neurodiffeq" ]; then
+  echo "oracle/make_ref.sh: no reference at $REF (GPU box: the prebuilt oracle/_ref travels with the snapshot)"; exit 0
+fi
+rm -rf "$HERE/_ref"
+mkdir -p "$HERE/_ref"
+cp -r "$REF/neurodiffeq" "$HERE/_ref/neurodiffeq"
+cp -r "$HERE/../tests/golden/_refshim/seaborn" "$HERE/../tests/golden/_refshim/ordered_set" "$HERE/_ref/"
+find "$HERE/_ref" -name __pycache__ -type d -prune -exec rm -rf {} +
+(cd "$REF" && git rev-parse HEAD 2>/dev/null || echo "unknown") > "$HERE/_ref/REVISION"
+echo "oracle/_ref: reference package at revision $(cat "$HERE/_ref/REVISION") ($(find "$HERE/_ref/neurodiffeq" -name '*.py' | wc -l) files)"

@@ -32,12 +32,13 @@ for spec in (sys.argv[1:] or ["w16:256", "w17:256"]):
     tf = bench.timed_windows(lambda: solver.fit(200, tqdm_file=None), 1, torch.cuda.synchronize)
     dt_fit = tf[(len(tf) - 1) // 2] / 200
     batch = solver._batch["train"]
-    brk = bench.fused_breakdown(sysm, [c.detach() for c in batch])
+    brk = bench.fused_breakdown(sysm, [c.detach() for c in batch]) if sysm.fusedk is not None else \
+        dict(fused_closure=dict(us=0.0, blocks=0))
     kb = bench.kernel_breakdown(sysm, [c.detach() for c in batch]) if len(sysm.flat) == 1 else {}
     n = cfg["n_points"]
     print(json.dumps(dict(config=name, points=n, us_per_step=round(dt * 1e6, 2), us_per_step_in_fit=round(dt_fit * 1e6, 2),
                           points_per_s=round(n / min(dt, dt_fit)), closure_us=round(brk["fused_closure"]["us"], 2),
-                          blocks=brk["fused_closure"]["blocks"], threads=sysm.fusedk.threads,
+                          blocks=brk["fused_closure"]["blocks"], threads=sysm.fusedk.threads if sysm.fusedk is not None else 0,
                           fwd_us=round(kb.get("mlp_jet_fwd", {}).get("us", 0), 2), bwd_us=round(kb.get("mlp_jet_bwd", {}).get("us", 0), 2),
                           pw_us=round(kb.get("pointwise", {}).get("us", 0), 2),
                           flags=os.environ.get("NDQ_JIT_FLAGS", ""), final_loss=solver.metrics_history["train_loss"][-1])), flush=True)

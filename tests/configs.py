@@ -130,6 +130,19 @@ def make(name, size=None):
         return dict(kind="1d", pde=pde, nets=[FCNN(1, 1, hidden_units=(32, 32), actv=partial(APTx, trainable=True))],
                     conds=[IVP(0.0, 1.0, u_0_prime=0.5)], gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"),
                     n_points=48, dom=(0.0, 2.0))
+    if name == "w20":     # tests/test_pde.py:370-377: (100, 100) ELU network on a nonlinear Poisson problem
+        c = make("c2", size or 12)
+        c["pde"] = lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2) + torch.exp(u) - 1.0 - x ** 2 - y ** 2
+                                    - 4.0 / (1.0 + x ** 2 + y ** 2) ** 2]
+        c["nets"] = [FCNN(n_input_units=2, hidden_units=(100, 100), actv=torch.nn.ELU)]
+        return c
+    if name == "w21":     # Softplus and GELU networks in one system
+        nets = [FCNN(2, 1, hidden_units=(32, 32), actv=torch.nn.Softplus), FCNN(2, 1, hidden_units=(32, 32), actv=torch.nn.GELU)]
+        c = make("c2", size or 10)          # (after the networks: the golden script draws its initial weights in this order)
+        c["pde"] = lambda u, v, x, y: [diff(u, x, order=2) + diff(u, y, order=2) - v, diff(v, x) + diff(v, y) - u * v]
+        c["nets"] = nets
+        c["conds"] = c["conds"] + [NoCondition()]
+        return c
     if name == "w16":     # README.md:125 -- FCNN(2, 1, hidden_units=(512,)) on the C2 problem
         c = make("c2", size or 12)
         c["nets"] = [FCNN(n_input_units=2, n_output_units=1, hidden_units=(512,))]

@@ -289,7 +289,25 @@ def cfg_w19():
     return _ns_single(net, re=100.0)
 
 
-CONFIGS = {"w16": cfg_w16, "w17": cfg_w17, "w18": cfg_w18, "w19": cfg_w19, "c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
+def cfg_w20():
+    """tests/test_pde.py:370-377 of the reference: nabla^2 u + e^u = 1 + x^2 + y^2 + 4 / (1 + x^2 + y^2)^2 on
+    FCNN(n_input_units=2, hidden_units=(100, 100), actv=nn.ELU), here with C2's Dirichlet boundary."""
+    c = cfg_c2(12)
+    c["pde"] = lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2) + torch.exp(u) - 1.0 - x ** 2 - y ** 2
+                                - 4.0 / (1.0 + x ** 2 + y ** 2) ** 2]
+    c["nets"] = [FCNN(n_input_units=2, hidden_units=(100, 100), actv=torch.nn.ELU)]
+    return c
+
+
+def cfg_w21():
+    """Softplus (tests/test_pde.py:182) and GELU networks side by side: a two-function system, 32 x 32 each."""
+    pde = lambda u, v, x, y: [diff(u, x, order=2) + diff(u, y, order=2) - v, diff(v, x) + diff(v, y) - u * v]
+    nets = [FCNN(2, 1, hidden_units=(32, 32), actv=torch.nn.Softplus), FCNN(2, 1, hidden_units=(32, 32), actv=torch.nn.GELU)]
+    conds = cfg_c2(10)["conds"] + [NoCondition()]
+    return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=Generator2D((10, 10), (0, 0), (1, 1), "equally-spaced-noisy"))
+
+
+CONFIGS = {"w20": cfg_w20, "w21": cfg_w21, "w16": cfg_w16, "w17": cfg_w17, "w18": cfg_w18, "w19": cfg_w19, "c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
            "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5, "w6": cfg_w6, "w7": cfg_w7, "w8": cfg_w8,
            "w9": cfg_w9, "w10": cfg_w10, "w11": cfg_w11, "w12": cfg_w12, "w13": cfg_w13, "w14": cfg_w14, "w15": cfg_w15}
 
@@ -640,8 +658,47 @@ def make_operator_goldens():
     print("operators:", len(out), "evaluations")
 
 
+def make_ramp(seed=0):
+    """A Python float INSIDE diff_eqs that a callback changes between epochs (the lid-driven-cavity notebooks ramp their
+    Reynolds number this way): the reference re-evaluates diff_eqs every batch (solvers.py:380), so every epoch trains on
+    the current value.  Burgers' equation, viscosity nu['v'] multiplied by 0.7 after every epoch, six epochs of fit()."""
+    torch.manual_seed(seed)
+    nu = {"v": 0.05}
+    pde = lambda u, x, t: [diff(u, t) + u * diff(u, x) - nu["v"] * diff(u, x, order=2)]
+    nets = [FCNN(2, 1, hidden_units=(32, 32))]
+    conds = [IBVP1D(x_min=-1, x_max=1, t_min=0, t_min_val=lambda x: -torch.sin(PI * x), x_min_val=lambda t: 0, x_max_val=lambda t: 0)]
+    gen = Generator2D((12, 12), (-1, 0), (1, 1), "equally-spaced-noisy")
+    vgen = Generator2D((8, 8), (-1, 0), (1, 1), "equally-spaced")
+    solver = Solver2D(pde, conds, xy_min=(-1, 0), xy_max=(1, 1), nets=nets, train_generator=gen, valid_generator=vgen)
+    out = dict(seed=np.asarray(seed), params0=flat_params(nets).numpy())
+
+    def ramp(s):
+        nu["v"] *= 0.7
+    torch.manual_seed(seed + 2)
+    solver.fit(max_epochs=6, callbacks=[ramp], tqdm_file=None)
+    out["traj_loss"] = np.asarray(solver.metrics_history["train_loss"])
+    out["traj_valid"] = np.asarray(solver.metrics_history["valid_loss"])
+    out["traj_params"] = flat_params(nets).numpy()
+    out["nu_final"] = np.asarray(nu["v"])
+    # the same six epochs WITHOUT the ramp, so that a test can tell the two apart
+    torch.manual_seed(seed)
+    nu2 = {"v": 0.05}
+    pde2 = lambda u, x, t: [diff(u, t) + u * diff(u, x) - nu2["v"] * diff(u, x, order=2)]
+    nets2 = [FCNN(2, 1, hidden_units=(32, 32))]
+    solver2 = Solver2D(pde2, conds, xy_min=(-1, 0), xy_max=(1, 1), nets=nets2, train_generator=Generator2D((12, 12), (-1, 0), (1, 1), "equally-spaced-noisy"),
+                       valid_generator=vgen)
+    torch.manual_seed(seed + 2)
+    solver2.fit(max_epochs=6, tqdm_file=None)
+    out["frozen_loss"] = np.asarray(solver2.metrics_history["train_loss"])
+    path = os.path.join(HERE, "ramp.npz")
+    np.savez_compressed(path, **out)
+    print("ramp", out["traj_loss"], "frozen", out["frozen_loss"], "->", os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "ramp" in only:
+        make_ramp()
     for name in CONFIGS:
         if not only or name in only:
             make(name)

@@ -9,14 +9,14 @@ import torch
 
 from tests import configs
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c4": 96, "c5": 8, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c4": 96, "c5": 8, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None, "w20": None, "w21": None}
 
 
 def _flat(nets):
     return torch.cat([p.detach().reshape(-1) for n in nets for p in n.parameters()]).cpu().numpy()
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5", "w1", "w2", "w3", "w4", "w5", "w6", "w7", "w8", "w11", "w12", "w13", "w14", "w15", "w16", "w17", "w18", "w19"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c4", "c5", "w1", "w2", "w3", "w4", "w5", "w6", "w7", "w8", "w11", "w12", "w13", "w14", "w15", "w16", "w17", "w18", "w19", "w20", "w21"])
 def test_composite_solver_trajectory_matches_reference(golden_dir, name):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(int(gold["seed"]))

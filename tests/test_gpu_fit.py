@@ -357,3 +357,58 @@ def test_fit_keeps_calling_overridden_per_epoch_methods():
     s = Hooked(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], t_min=0.0, t_max=2.0)
     s.fit(5)
     assert len(calls) == 5 and len(s.metrics_history["train_loss"]) == 5
+
+
+def test_python_state_ramped_by_a_callback_reaches_the_fused_kernels(golden_dir):
+    """a Python float inside ``diff_eqs`` (``nu['v']``) multiplied by 0.7 by a callback after
+    every epoch.  The reference re-evaluates diff_eqs every batch (solvers.py:380); here the state watch notices, the
+    equations are re-traced and the kernels rebuilt (cached by source) -- the solver STAYS on the fused path and its loss
+    history / final parameters equal what the unmodified reference produced with the same callback
+    (tests/golden/make_golden.py: make_ramp), not the frozen-viscosity run."""
+    import os
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IBVP1D
+    from neurodiffeq_amd.generators import Generator2D
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.solvers import Solver2D
+    gold = np.load(os.path.join(golden_dir, "ramp.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    nu = {"v": 0.05}
+    pde = lambda u, x, t: [diff(u, t) + u * diff(u, x) - nu["v"] * diff(u, x, order=2)]
+    nets = [FCNN(2, 1, hidden_units=(32, 32))]
+    conds = [IBVP1D(x_min=-1, x_max=1, t_min=0, t_min_val=lambda x: -torch.sin(np.pi * x), x_min_val=lambda t: 0, x_max_val=lambda t: 0)]
+    solver = Solver2D(pde, conds, xy_min=(-1, 0), xy_max=(1, 1), nets=nets,
+                      train_generator=Generator2D((12, 12), (-1, 0), (1, 1), "equally-spaced-noisy"),
+                      valid_generator=Generator2D((8, 8), (-1, 0), (1, 1), "equally-spaced"))
+    solver.fused = "require"
+    assert np.array_equal(R.get_flat(nets).cpu().numpy(), gold["params0"])
+
+    def ramp(s):
+        nu["v"] *= 0.7
+    torch.manual_seed(int(gold["seed"]) + 2)
+    solver.fit(max_epochs=6, callbacks=[ramp], tqdm_file=None)
+    assert solver.fused_active and abs(nu["v"] - float(gold["nu_final"])) < 1e-12
+    hist, valid = np.array(solver.metrics_history["train_loss"]), np.array(solver.metrics_history["valid_loss"])
+    err = dict(loss=float(np.max(np.abs(hist - gold["traj_loss"]) / np.abs(gold["traj_loss"]))),
+               valid=float(np.max(np.abs(valid - gold["traj_valid"]) / np.abs(gold["traj_valid"]))),
+               params=float(np.linalg.norm(R.get_flat(nets).cpu().numpy() - gold["traj_params"]) / np.linalg.norm(gold["traj_params"])))
+    assert err["loss"] < 2e-5 and err["valid"] < 2e-5 and err["params"] < 1e-5, (err, hist, gold["traj_loss"])
+    assert np.max(np.abs(hist - gold["frozen_loss"]) / gold["frozen_loss"]) > 1e-2        # ... and not the frozen equations
+    # the same ramp between single epochs, and through fit() WITHOUT callbacks interleaved with manual edits
+    torch.manual_seed(int(gold["seed"]))
+    nu["v"] = 0.05
+    nets2 = [FCNN(2, 1, hidden_units=(32, 32))]
+    solver2 = Solver2D(pde, conds, xy_min=(-1, 0), xy_max=(1, 1), nets=nets2,
+                       train_generator=Generator2D((12, 12), (-1, 0), (1, 1), "equally-spaced-noisy"),
+                       valid_generator=Generator2D((8, 8), (-1, 0), (1, 1), "equally-spaced"))
+    solver2.fused = "require"
+    torch.manual_seed(int(gold["seed"]) + 2)
+    for _ in range(3):
+        solver2.run_train_epoch()
+        solver2.run_valid_epoch()
+        nu["v"] *= 0.7
+    for _ in range(3):
+        solver2.fit(1, tqdm_file=None)
+        nu["v"] *= 0.7
+    hist2 = np.array(solver2.metrics_history["train_loss"])
+    assert float(np.max(np.abs(hist2 - gold["traj_loss"]) / np.abs(gold["traj_loss"]))) < 2e-5, (hist2, gold["traj_loss"])

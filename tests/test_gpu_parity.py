@@ -1191,14 +1191,14 @@ def test_solution_and_residuals_on_forward_kernels(name):
 
 
 def test_pk_mfma_hazard_is_fixed_up_by_the_build():
-    """scripts/ubench_pk_war.hip replays, with hard-coded registers, the instruction sequence that made one closure
+    """neurodiffeq_amd/csrc/canary_pk_war.hip replays, with hard-coded registers, the instruction sequence that made one closure
     kernel's dW1 non-deterministic on gfx950 (packed-fp32 VALU op directly followed by a bf16 MFMA: lanes 48..63 of the
     packed op's low half come out wrong).  Built through the package's own pipeline (_hipcc.compile_shared: the
     assembly fix-up pass separates the pair) it must be exact; built with the pass switched off it documents whether
     this machine shows the hazard (recorded, not asserted)."""
     import ctypes, os, tempfile
     from neurodiffeq_amd import _hipcc
-    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "ubench_pk_war.hip")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neurodiffeq_amd", "csrc", "canary_pk_war.hip")
     counts = {}
     with tempfile.TemporaryDirectory() as tmp:
         for label, off in (("fixed", "0"), ("raw", "1")):
@@ -1215,6 +1215,43 @@ def test_pk_mfma_hazard_is_fixed_up_by_the_build():
     diag("pk_mfma_hazard", counts)
     assert counts["fixed_sites"] > 0
     assert counts["fixed"] == 0, counts
+
+
+def test_hazard_canary_detects_the_unfixed_kernel_and_passes_the_fixed_one():
+    """the canary that runs at first use on every box (neurodiffeq_amd/_canary.py).  The
+    reproducer built THROUGH the assembly fix-up pass counts zero wrong results; built from the compiler's unmodified output
+    it shows the hazard (the committed signature, profiles/archive/r01/r01u_pk_mfma_hazard.txt); a spilling adjoint kernel with two
+    waves per SIMD is bit-reproducible over 30 launches through the pass.  A canary that fails refuses the 8-wave builds."""
+    import warnings
+    from neurodiffeq_amd import _canary
+    from neurodiffeq_amd.engine import FusedSystem
+    _canary.STATUS.update(checked=False, fixed=None, raw=None, refuse_two_waves=False)
+    st = _canary.check(iters=200)
+    assert st["fixed"] == 0 and not st["refuse_two_waves"], st
+    assert st["raw"] > 0, f"this box does not show the packed-fp32 -> MFMA hazard with the pass switched off: {st}"
+    two = _canary.check_two_waves()
+    diag("hazard_canary", dict(st, two_waves=two))
+    assert two["fixed"] == 0 and two["fixed_waves"] == 8, two
+    # a failing canary is loud and switches the two-waves-per-SIMD builds off
+    _canary.STATUS.update(checked=False)
+    fixed_so, raw_so = _canary._so("fixed"), _canary._so("raw")
+    orig = _canary._so
+    try:
+        _canary._so = lambda label: raw_so            # pretend the pass had not fixed the kernel
+        with pytest.warns(RuntimeWarning, match="does not cover"):
+            bad = _canary.check(iters=200, rebuild=False)
+        assert bad["refuse_two_waves"]
+        from tests import configs
+        torch.manual_seed(0)
+        cfg = configs.make("c2", 16)
+        for net in cfg["nets"]:
+            net.to("cuda")
+        fs = FusedSystem(cfg["nets"], cfg["conds"], cfg["pde"], 2, "cuda")
+        assert fs.fusedk_wide is False
+    finally:
+        _canary._so = orig
+        _canary.STATUS.update(checked=False, refuse_two_waves=False)
+        _canary.check()
 
 
 def test_closure_kernel_self_check_accepts_good_and_rejects_bad_kernels():

@@ -1,0 +1,118 @@
+"""Sampling follows torch's default device (VERDICT r3 missing #3 / next #4).
+
+The reference draws on the default device (``generators.py:152,158,264-265``); under its import default ``cuda``
+(``__init__.py:22``) the noise comes from the GPU's Philox stream.  Here a solver built under a cuda default device draws
+the noise of Generator1D / 2D / 3D / Spherical on the MI355X (DeviceGenerator), seeded from ``torch.cuda.initial_seed()``;
+index sampling and everything under a CPU default device stay on the CPU generator bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def cuda_default():
+    torch.set_default_device("cuda")
+    try:
+        yield
+    finally:
+        torch.set_default_device("cpu")
+
+
+def _laplace(**kw):
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import DirichletBVP2D
+    from neurodiffeq_amd.solvers import Solver2D
+    zero = lambda v: 0 * v
+    return Solver2D(lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2)],
+                    [DirichletBVP2D(0, lambda y: torch.sin(np.pi * y), 1, zero, 0, zero, 1, zero)], xy_min=(0, 0), xy_max=(1, 1), **kw)
+
+
+def test_solver_under_a_cuda_default_device_samples_on_the_device(cuda_default):
+    from neurodiffeq_amd.generators import (DeviceGenerator, Generator1D, Generator2D, ResampleGenerator, on_default_device,
+                                            set_default_sampling)
+    runs = []
+    for seed in (0, 0, 1):
+        torch.manual_seed(seed)
+        solver = _laplace()
+        solver.fused = "require"
+        assert isinstance(solver.generator["train"].generator, DeviceGenerator)          # noisy 32 x 32 grid: device
+        assert not isinstance(solver.generator["valid"].generator, DeviceGenerator)      # static grid: uploaded once
+        solver.fit(5, tqdm_file=None)
+        assert solver.fused_active and solver._batch["train"][0].device.type == "cuda"
+        runs.append((np.array(solver.metrics_history["train_loss"]), solver._batch["train"][0].detach().cpu().numpy().copy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])     # torch.manual_seed fixes the run
+    assert not np.array_equal(runs[0][1], runs[2][1])
+    assert runs[0][0][-1] < runs[0][0][0]
+    # opting out: per generator, globally; index sampling never moves
+    g = Generator2D((8, 8), bit_exact_cpu=True)
+    assert on_default_device(g) is g
+    r = ResampleGenerator(Generator1D(16, method="equally-spaced-noisy"), size=8)
+    assert on_default_device(r) is r
+    set_default_sampling("cpu")
+    try:
+        assert on_default_device(Generator2D((8, 8))).__class__ is Generator2D
+    finally:
+        set_default_sampling("auto")
+
+
+def test_cpu_default_device_keeps_the_reference_cpu_numbers():
+    """Nothing changes without a cuda default device: host draws, the reference's CPU stream bit for bit (golden-tested
+    elsewhere); here: the generator is not wrapped."""
+    from neurodiffeq_amd.generators import Generator2D
+    torch.manual_seed(0)
+    solver = _laplace()
+    assert type(solver.generator["train"].generator) is Generator2D
+
+
+CASES = {
+    "1d-uniform": lambda G: G.Generator1D(4096, 0.5, 2.5, method="uniform"),
+    "1d-noisy": lambda G: G.Generator1D(4096, 0.0, 2.0, method="equally-spaced-noisy"),
+    "2d-noisy": lambda G: G.Generator2D((64, 64), (0.0, -1.0), (1.0, 1.0), method="equally-spaced-noisy"),
+    "2d-noisy-std": lambda G: G.Generator2D((64, 64), (0.0, 0.0), (1.0, 1.0), method="equally-spaced-noisy", xy_noise_std=(0.02, 0.005)),
+    "3d-noisy": lambda G: G.Generator3D((16, 16, 16), (0.0, 0.0, 0.0), (1.0, 2.0, 3.0), method="equally-spaced-noisy"),
+    "sph-r2": lambda G: G.GeneratorSpherical(4096, 0.1, 3.0, method="equally-spaced-noisy"),
+    "sph-r": lambda G: G.GeneratorSpherical(4096, 0.1, 3.0, method="equally-radius-noisy"),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_device_draws_follow_the_host_generators_distribution(name):
+    """Every distribution the device sampler draws against the host generator it stands in for: two-sample
+    Kolmogorov-Smirnov per coordinate (for the jittered grids: of the jitter, i.e. sample minus grid node), first two
+    moments, and the range."""
+    from scipy import stats
+    from neurodiffeq_amd import generators as G
+    torch.manual_seed(5)
+    host = CASES[name](G)
+    dev = G.DeviceGenerator(CASES[name](G), seed=11, stream_id=0)
+    def cols(g, k):
+        out = []
+        for _ in range(k):
+            ex = g.get_examples()
+            ex = [ex] if isinstance(ex, torch.Tensor) else list(ex)
+            out.append(np.stack([c.detach().cpu().numpy().reshape(-1) for c in ex]).astype(np.float64))
+        return np.concatenate(out, axis=1)
+    h, d = cols(host, 4), cols(dev, 4)
+    assert h.shape == d.shape
+    if "noisy" in name and not name.startswith("sph"):
+        # subtract the grid nodes (the mean over many draws of the host generator's own noiseless grid)
+        node = np.stack([c.detach().cpu().numpy().reshape(-1) for c in _grid_nodes(G, name)]).astype(np.float64)
+        node = np.tile(node, (1, 4))
+        h, d = h - node, d - node
+    for i in range(h.shape[0]):
+        ks = stats.ks_2samp(h[i], d[i])
+        scale = max(np.std(h[i]), 1e-12)
+        assert ks.pvalue > 1e-4, (name, i, ks)
+        assert abs(np.mean(h[i]) - np.mean(d[i])) < 0.05 * scale + 1e-9, (name, i)
+        assert abs(np.std(h[i]) - np.std(d[i])) < 0.05 * scale, (name, i)
+
+
+def _grid_nodes(G, name):
+    spec = {"1d-noisy": lambda: G.Generator1D(4096, 0.0, 2.0, method="equally-spaced"),
+            "2d-noisy": lambda: G.Generator2D((64, 64), (0.0, -1.0), (1.0, 1.0), method="equally-spaced"),
+            "2d-noisy-std": lambda: G.Generator2D((64, 64), (0.0, 0.0), (1.0, 1.0), method="equally-spaced"),
+            "3d-noisy": lambda: G.Generator3D((16, 16, 16), (0.0, 0.0, 0.0), (1.0, 2.0, 3.0), method="equally-spaced")}[name]()
+    ex = spec.get_examples()
+    return [ex] if isinstance(ex, torch.Tensor) else list(ex)

@@ -20,7 +20,7 @@ from oracle import jet_ref as J
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 DIAG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "diag")
-ACT_ID = {"tanh": 0, "sin": 1, "sigmoid": 2, "swish": 3, "aptx": 4}
+ACT_ID = {"tanh": 0, "sin": 1, "sigmoid": 2, "swish": 3, "aptx": 4, "elu": 5, "softplus": 6, "gelu": 7}
 
 # stream sets: name -> (multi-indices in the kernels' stream order, first, mask2, lap, mask3) for d inputs
 def _streams(d, kind):
@@ -77,7 +77,14 @@ DEEP_SHAPES = [
     (2, 96, 1, "aptx", "first", 5),
     (4, 72, 1, "tanh", "value", 2),
 ]
-SHAPES = SHAPES + DEEP_SHAPES
+# torch's own activation modules (nn.ELU / nn.Softplus / nn.GELU: generic derivative tables) on all three
+# kernel families: fragment kernels (width <= 64), one wide layer, deep wide
+ACT_SHAPES = [
+    (2, 32, 1, "elu", "full2", 2), (2, 32, 1, "softplus", "full2", 2), (2, 32, 1, "gelu", "lap", 2), (1, 32, 1, "gelu", "full3", 2),
+    (1, 48, 1, "softplus", "full3", 2), (2, 64, 1, "elu", "lap", 3), (2, 512, 1, "softplus", "lap", 1), (2, 200, 2, "gelu", "full2", 1),
+    (1, 300, 1, "elu", "full3", 1), (2, 100, 1, "elu", "lap", 2), (2, 128, 1, "gelu", "first+xx", 2),
+]
+SHAPES = SHAPES + DEEP_SHAPES + ACT_SHAPES
 IDS = ["-".join(map(str, sh)) for sh in SHAPES]
 
 
@@ -171,8 +178,8 @@ def _grad_in_torch_order(nets, flats):
     return torch.cat([where[id(prm)].reshape(-1) for net in nets for prm in net.parameters()]).cpu().numpy()
 
 
-GOLDEN_WIDE = ["w16", "w17", "w18", "w19"]
-GOLDEN_DEEP = ("w18", "w19")       # layer-by-layer kernels: no single-launch closure
+GOLDEN_WIDE = ["w16", "w17", "w18", "w19", "w20", "w21"]      # w20: (100, 100) ELU; w21: Softplus + GELU networks (32 x 32)
+GOLDEN_DEEP = ("w18", "w19", "w20")       # layer-by-layer kernels: no single-launch closure
 
 
 @pytest.mark.parametrize("mode", ["1k", "3k"])

@@ -1,6 +1,6 @@
 """CPU model of the LDS plane images behind the transposing-read weight gradients (csrc/ndq_mlp.h: tr_slot, tr_store,
 hbar_wgrad_tr, hbar_wgrad_tr64).  The lane map of ds_read_b64_tr_b16 is the one measured on MI355X by
-scripts/ubench_tr16.hip (profiles/r03zz_tr16_lane_map.log): result j of lane l = 16-bit element (l & 3) of the 8 bytes
+scripts/ubench_tr16.hip (profiles/archive/r03/r03zz_tr16_lane_map.log): result j of lane l = 16-bit element (l & 3) of the 8 bytes
 addressed by lane (l & ~15) + 4 j + ((l & 15) >> 2).  With it, the writer's and the reader's address formulas are replayed
 on a byte-addressed model of LDS and every lane must end up with exactly the (point, unit) operand elements the MFMA
 contraction needs -- and the bank properties the layout was chosen for must hold."""

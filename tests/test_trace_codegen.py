@@ -15,7 +15,7 @@ from oracle import jet_ref as J
 from tests import configs, zoo
 from tests.pw_cpu import run_cpu
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w9": None, "w10": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w9": None, "w10": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None, "w20": None, "w21": None}
 
 
 def rel_l2(a, b):
@@ -56,7 +56,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
         info = describe(net)
         dims = (info["d"],) + tuple(l.out_features for l in info["linears"][:-1]) + (info["n_out"],)
         mono = [k + 1 for k in range(8) if (info["mono"] >> k) & 1] or None      # MonomialNN degrees in front of the network
-        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx")[info["act"]], bool(info["skip"]), bool(info["actp"]), mono))
+        dims_act.append((dims, ("tanh", "sin", "sigmoid", "swish", "aptx", "elu", "softplus", "gelu")[info["act"]], bool(info["skip"]), bool(info["actp"]), mono))
         # ``params`` is in torch parameter order; the kernels' (and the jet oracle's) flat vector lists the linear layers,
         # then the skip weights, then the activation parameters (networks.describe): perm maps one onto the other
         start, at = {}, 0
@@ -127,7 +127,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
 
 @pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
                                       ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True), ("w5", True), ("w6", True), ("w7", True), ("w8", True),
-                                      ("w9", True), ("w10", True), ("w11", True), ("w12", True), ("w13", True), ("w14", True), ("w15", True), ("w16", True), ("w17", True), ("w18", True), ("w19", True)])
+                                      ("w9", True), ("w10", True), ("w11", True), ("w12", True), ("w13", True), ("w14", True), ("w15", True), ("w16", True), ("w17", True), ("w18", True), ("w19", True), ("w20", True), ("w21", True)])
 def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
@@ -616,3 +616,33 @@ def test_resample_generator_larger_than_its_source_is_not_fixed_size():
     assert draws_have_fixed_size(ResampleGenerator(g, size=8))
     assert not draws_have_fixed_size(ResampleGenerator(g, size=32, replacement=False))
     assert draws_have_fixed_size(ResampleGenerator(g, size=32, replacement=True))
+
+
+def test_equation_probe_sees_python_state_changed_between_epochs():
+    """``lambda u, t: [diff(u, t) + nu['v'] * u]`` -- the float is a literal of the generated kernel.  The
+    state watch notices that nu['v'] moved, the re-trace (program.eq_probe) that the equations now compute something else;
+    state that moved without changing the equations leaves the probe true."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd._pystate import StateWatch
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.engine import trace_system
+    from neurodiffeq_amd.networks import FCNN
+    nu = {"v": 1.0, "unused": 3.0}
+    eqs = lambda u, t: [diff(u, t) + nu["v"] * u]
+    cond = IVP(0.0, 1.0)
+    program, _ = trace_system([FCNN(1, 1)], [cond], eqs, 1)
+    watch = StateWatch([eqs, cond])
+    assert program.g.captured == [] and program.eq_probe() and not watch.dirty()
+    src = program.point_fn_source()
+    nu["v"] = 5.0
+    assert watch.dirty() and not program.eq_probe()
+    program2, _ = trace_system([FCNN(1, 1)], [cond], eqs, 1)
+    assert program2.point_fn_source() != src
+    nu["v"] = 1.0
+    assert not watch.dirty() and program.eq_probe()
+    nu["unused"] = 4.0                      # state the equations do not read: dirty watch, same trace
+    assert watch.dirty() and program.eq_probe()
+    cond.u_0 = 2.0                          # an attribute of the condition object: other function values
+    assert StateWatch([eqs, cond]).entries and not program.eq_probe()
+    # a stateless lambda has (almost) nothing to watch
+    assert len(StateWatch([lambda u, t: [diff(u, t) + u]])) <= 2
