@@ -13,9 +13,11 @@ REF=${1:-/root/reference}
 if [ ! -d "$REF/neurodiffeq" ]; then
   echo "oracle/make_ref.sh: no reference at $REF (GPU box: the prebuilt oracle/_ref travels with the snapshot)"; exit 0
 fi
+[ -d "$HERE/_ref" ] && chmod -R u+w "$HERE/_ref"
 rm -rf "$HERE/_ref"
 mkdir -p "$HERE/_ref"
 cp -r "$REF/neurodiffeq" "$HERE/_ref/neurodiffeq"
+chmod -R u+w "$HERE/_ref"
 cp -r "$HERE/../tests/golden/_refshim/seaborn" "$HERE/../tests/golden/_refshim/ordered_set" "$HERE/_ref/"
 find "$HERE/_ref" -name __pycache__ -type d -prune -exec rm -rf {} +
 (cd "$REF" && git rev-parse HEAD 2>/dev/null || echo "unknown") > "$HERE/_ref/REVISION"

@@ -18,7 +18,7 @@ from oracle import autograd_ref as R
 from oracle import jet_ref as J
 from tests import configs
 
-ACT = {0: "tanh", 1: "sin", 2: "sigmoid", 3: "swish", 4: "aptx"}
+ACT = {0: "tanh", 1: "sin", 2: "sigmoid", 3: "swish", 4: "aptx", 5: "elu", 6: "softplus", 7: "gelu"}
 
 
 def rel_l2(a, b):
@@ -320,11 +320,11 @@ def _residual(net, x, scale):
     return diff(u, x, order=2) + u
 
 
-@pytest.mark.parametrize("act", [torch.nn.Tanh, torch.nn.Softplus])
+@pytest.mark.parametrize("act", [torch.nn.Tanh, torch.nn.Softplus, torch.nn.ReLU])
 def test_gradients_flowing_through_the_network_input_are_never_dropped(cpu_ops, act):
     """a trainable tensor UPSTREAM of the network input (learnable input scale), and the coordinate
     gradient itself, must come out of loss.backward() exactly as torch autograd produces them -- the top-order stream's
-    input gradient needs the streams one order up (tanh: a forward launch with third-order streams; Softplus has no
+    input gradient needs the streams one order up (tanh, Softplus: a forward launch with third-order streams; ReLU has no
     HIP kernels at all and runs on torch either way)."""
     torch.manual_seed(2)
     net = FCNN(1, 1, hidden_units=(32, 32), actv=act)
