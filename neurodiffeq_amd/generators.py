@@ -806,6 +806,8 @@ def on_default_device(gen):
         return gen
     if mode == "auto" and torch.get_default_device().type != "cuda":
         return gen
+    if torch.get_default_dtype() != torch.float32:
+        return gen                 # the Philox kernel draws fp32 points; an fp64 default (the reference's) samples on the host in fp64
     if not (type(gen) is GeneratorSpherical or gen.method == "uniform" or gen.method == "equally-spaced-noisy"):
         return gen                 # static grids are uploaded once and read in place; other laws: host
     try:
