@@ -179,7 +179,8 @@ def _grad_in_torch_order(nets, flats):
 
 
 GOLDEN_WIDE = ["w16", "w17", "w18", "w19", "w20", "w21"]      # w20: (100, 100) ELU; w21: Softplus + GELU networks (32 x 32)
-GOLDEN_DEEP = ("w18", "w19", "w20")       # layer-by-layer kernels: no single-launch closure
+GOLDEN_DEEP = ("w18", "w19", "w20", "w21")    # layer-by-layer kernels (w18 - w20) / two networks with different activations (w21):
+#                                                 three-kernel pipeline, no single-launch closure
 
 
 @pytest.mark.parametrize("mode", ["1k", "3k"])
@@ -191,7 +192,7 @@ def test_wide_closure_matches_reference_golden(golden_dir, name, mode):
     from tests import configs
     from neurodiffeq_amd.engine import FusedSystem
     if name in GOLDEN_DEEP and mode == "1k":
-        pytest.skip("deep wide networks run layer by layer (csrc/ndq_deep.h): pipeline mode only")
+        pytest.skip("no single-launch closure for this system (layer-by-layer kernels / networks of different shapes): pipeline mode only")
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
     cfg = configs.make(name, None)
