@@ -725,7 +725,7 @@ def main():
                                                      "by the Philox kernel every step, seeded from torch.cuda.initial_seed()"}
             del dsolver
         finally:
-            torch.set_default_device("cpu")
+            torch.set_default_device(None)       # (None removes torch's global device mode; "cpu" would leave one installed)
         if not args.no_configs:
             # the other BASELINE configs at their stated sizes (parity-tested at those sizes in tests/test_gpu_parity.py)
             del pipeline

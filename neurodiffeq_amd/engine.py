@@ -45,6 +45,25 @@ class _Lib64:
         return getattr(self._lib, name.replace("ndq_", "ndq64_", 1))
 
 
+class library_code:
+    """``with library_code():`` around host code of this package that names the device of everything it creates.  A global
+    TorchFunctionMode -- torch.set_default_device('cuda'), the reference's import default, installs one -- intercepts every
+    tensor method call (``data_ptr``, ``shape``, ``device`` ...: ~1 us each, ~40 of them per native epoch, more than the
+    epoch's 26 us of kernels); user callables (conditions, equations, generators, callbacks) are never run under this."""
+    __slots__ = ("ctx",)
+
+    def __enter__(self):
+        self.ctx = torch._C.DisableTorchFunction() if torch._C._len_torch_function_stack() else None
+        if self.ctx is not None:
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, loss="l2", metrics=(), f64=False):
     """Trace (conditions, diff_eqs) once on symbolic columns and lower them to a pointwise program.
 

@@ -756,6 +756,12 @@ class DeviceGenerator(BaseGenerator):
         return d
 
     def get_examples(self):
+        if torch._C._len_torch_function_stack():          # a global default-device mode: see engine.library_code
+            with torch._C.DisableTorchFunction():
+                return self._get_examples()
+        return self._get_examples()
+
+    def _get_examples(self):
         if self.prefetched == self.draw:          # a tail kernel has drawn this batch already
             self.prefetched = None
         else:

@@ -496,7 +496,10 @@ class BaseSolver(ABC):
             # the largest shard decides which closure-kernel build serves the batch: the same on every rank
             system.select_n = n_all if self.dist.presharded else -(-n_all // self.dist.world_size)
         nb = self.n_batches[key]
-        if self._run_epoch_native(key, system, first_batch):
+        from .engine import library_code
+        with library_code():               # (no user code below: see engine.library_code)
+            done = self._run_epoch_native(key, system, first_batch)
+        if done:
             return
         metric_values = {name: 0.0 for name in self.metrics_fn}
         if system.loss_buf.numel() < nb:

@@ -28,7 +28,9 @@ def set_tensor_type(device=None, float_bits=32):
     if device != "cpu" and not re.fullmatch(r"cuda(?::\d+)?", device):
         raise ValueError(f"Unknown device '{device}'; device must be either 'cuda', 'cuda:x' where x is the device "
                          f"number, 'cpu'")
-    torch.set_default_device(device)
+    # (torch.set_default_device installs a process-wide TorchFunctionMode that intercepts EVERY tensor method call, ~1 us
+    # each -- also for 'cpu', where it changes nothing: the CPU default is restored by removing the mode instead)
+    torch.set_default_device(None if device == "cpu" else device)
 
 
 def set_seed(seed_value, ignore_numpy=False, ignore_torch=False, ignore_random=False):

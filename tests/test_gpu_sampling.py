@@ -17,7 +17,7 @@ def cuda_default():
     try:
         yield
     finally:
-        torch.set_default_device("cpu")
+        torch.set_default_device(None)
 
 
 def _laplace(**kw):
