@@ -351,11 +351,10 @@ template <> struct Act<ACT_TANH> {  // nn.Tanh, networks.py:27 default
   }
   static __device__ __forceinline__ real s1(real t, real, real = 1.f) { return rfma(-t, t, 1.f); }
   static __device__ __forceinline__ real s2(real t, real, real s1v) { return -2.f * t * s1v; }
-  static __device__ __forceinline__ real s3(real t, real, real s1v) { return -2.f * s1v * rfma(-3.f * t, t, 1.f); }
-  // fourth derivative: -2 s2 (1 - 3 t^2) + 12 t s1^2 with s2 = -2 t s1
-  static __device__ __forceinline__ real s4(real t, real, real s1v) {
-    return 4.f * t * s1v * rfma(-3.f * t, t, 1.f) + 12.f * t * s1v * s1v;
-  }
+  // third derivative -2 s1 (1 - 3 t^2); with t^2 = 1 - s1 that is s1 (4 - 6 s1): two instructions instead of four
+  static __device__ __forceinline__ real s3(real, real, real s1v) { return s1v * rfma(-6.f, s1v, 4.f); }
+  // fourth derivative: -2 s2 (1 - 3 t^2) + 12 t s1^2 with s2 = -2 t s1, i.e. t s1 (24 s1 - 8)
+  static __device__ __forceinline__ real s4(real t, real, real s1v) { return t * s1v * rfma(24.f, s1v, -8.f); }
 };
 template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
   static __device__ __forceinline__ void fwd(real z, real& t, real& c, real = 1.f) {

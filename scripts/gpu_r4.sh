@@ -40,10 +40,12 @@ if has pmc; then
     done
   done
   python scripts/pmc_summary.py $OUT > $OUT/pmc_wide_summary.txt 2>/dev/null; head -n 40 $OUT/pmc_wide_summary.txt | cut -c1-200
+  rm -rf $OUT/pmc_w16_* $OUT/pmc_w18_*            # (the raw counter csv files are hundreds of MB; the summary is what is kept)
   bash scripts/gpu_pmc.sh ${TAG}_pmc_c2 > $OUT/pmc_c2.log 2>&1; tail -n 12 $OUT/pmc_c2.log
 fi
 if has dryrun; then
   bash scripts/scale_dryrun.sh $OUT/scale_dryrun
 fi
-find $OUT -name "*.db" -size +20M -delete
+find $OUT gpurun_out/${TAG}_pmc_c2 -name "*.db" -delete 2>/dev/null
+find $OUT gpurun_out/${TAG}_pmc_c2 -name "*.csv" -size +2M -delete 2>/dev/null
 du -sh $OUT
