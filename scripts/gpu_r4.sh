@@ -11,7 +11,7 @@ REPO=$(pwd)
 has() { [[ " $WHAT " == *" $1 "* ]]; }
 (rocminfo | grep -E "Marketing|gfx" | head -4; nproc; lscpu | grep "Model name") > $OUT/env.log 2>&1
 if has tests; then
-  timeout 3000 python -m pytest tests -m gpu -q -p no:cacheprovider -x > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 5 $OUT/pytest_gpu.log
+  timeout 3000 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 5 $OUT/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $OUT/smoke.log
 fi
 if has bench; then
@@ -47,5 +47,6 @@ if has dryrun; then
   bash scripts/scale_dryrun.sh $OUT/scale_dryrun
 fi
 find $OUT gpurun_out/${TAG}_pmc_c2 -name "*.db" -delete 2>/dev/null
+rm -rf $OUT/prof $OUT/prof_w16 $OUT/prof_w18 $OUT/prof_w19
 find $OUT gpurun_out/${TAG}_pmc_c2 -name "*.csv" -size +2M -delete 2>/dev/null
 du -sh $OUT
