@@ -455,12 +455,13 @@ class BaseSolver(ABC):
         from (a Python float, dict entry or attribute they read was changed, e.g. by a callback).  The cheap state watch
         runs every call; the re-trace when the watch is dirty, on the second use, every EQ_PROBE_EVERY calls and on
         ``force`` (chunk boundaries of the multi-epoch fit path)."""
-        probe = getattr(sysm.program, "eq_probe", None)
-        if probe is None:
-            return True
-        dirty = self._eq_watch is None or self._eq_watch.dirty()
+        watch = self._eq_watch
+        dirty = watch is None or watch.dirty()
         self._eq_probe_countdown -= 1
         if not (dirty or force or self._eq_probe_countdown <= 0):
+            return True                       # (the per-epoch cost: one compiled chain of comparisons, _pystate.StateWatch)
+        probe = getattr(sysm.program, "eq_probe", None)
+        if probe is None:
             return True
         if self._eq_probe_countdown <= 0:
             self._eq_probe_countdown = self.EQ_PROBE_EVERY
