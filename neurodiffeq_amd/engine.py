@@ -430,6 +430,15 @@ class FusedSystem:
         if self.fusedk is None:
             return None
         n = self.select_n or n
+        memo = self.__dict__.get("_variant_memo")
+        if memo is not None and memo[0] == n and memo[1] is self.fusedk_wide:
+            return memo[2]                    # (asked three times per epoch)
+        fk = self._fused_variant(n)
+        if self.fusedk_wide is not None:      # the 8-wave build has been tried: the answer for this n is final
+            self._variant_memo = (n, self.fusedk_wide, fk)
+        return fk
+
+    def _fused_variant(self, n):
         if n >= self.WIDE_MIN_POINTS and self.prefers_wide(n) and self.fusedk_wide is not False:
             if self.fusedk_wide is None and not self._wide_possible():
                 self.fusedk_wide = False
@@ -1132,23 +1141,40 @@ class FusedSystem:
                         and fk.lib.ndq_fused_loop_ok():
                     ff.launch_loop = ctypes.cast(fk.lib.ndq_fused_launch_loop, ctypes.c_void_p).value
                     ff.loop_ok = 1
-            ent = cache[key] = (ff, keep, fk)
+            ent = cache[key] = (ff, keep, fk, {}, (_c_vp * 1)(), ctypes.byref(ff))
         ff = ent[0]
         step0 = 1
+        # (this runs once per epoch on the per-epoch path, where the HOST is the bottleneck at the headline size: ctypes
+        # struct fields are rewritten only when their values changed)
+        last = ent[3]
         for k, fp in enumerate(self.flat):
             fp.sync()
-            st = ff.net[k]
-            st.params = fp.flat.data_ptr()
             if K:
                 m, v, group, step0 = adam_slots[k]
-                st.seed = 1.0 / (float(n if n_global is None else n_global) * self.loss_norm)
-                st.adam_m, st.adam_v = m.data_ptr(), v.data_ptr()
-                b1, b2 = group["betas"]
-                st.lr, st.beta1, st.beta2, st.eps, st.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]
-        ff.valid_coords = valid[0] if valid is not None else None
-        ff.track_best = track_best
-        coords = (_c_vp * max(K, 1))(*train_ptrs) if K else None
-        rc = self.L.ndq_fused_fit_run(ctypes.byref(ff), K, coords, step0, fs["pending"], fs["pending_valid"], fs["parity"],
+                now = (fp.flat.data_ptr(), n if n_global is None else n_global, m.data_ptr(), v.data_ptr(), group["lr"],
+                       group["betas"], group["eps"], group["weight_decay"])
+            else:
+                now = (fp.flat.data_ptr(),)
+            if last.get(k) != now:
+                last[k] = now
+                st = ff.net[k]
+                st.params = now[0]
+                if K:
+                    st.seed = 1.0 / (float(now[1]) * self.loss_norm)
+                    st.adam_m, st.adam_v = now[2], now[3]
+                    b1, b2 = group["betas"]
+                    st.lr, st.beta1, st.beta2, st.eps, st.weight_decay = group["lr"], b1, b2, group["eps"], group["weight_decay"]
+        vc = valid[0] if valid is not None else None
+        if last.get("v") != (vc, track_best):
+            last["v"] = (vc, track_best)
+            ff.valid_coords = vc
+            ff.track_best = track_best
+        if K == 1:
+            coords = ent[4]
+            coords[0] = train_ptrs[0]
+        else:
+            coords = (_c_vp * max(K, 1))(*train_ptrs) if K else None
+        rc = self.L.ndq_fused_fit_run(ent[5], K, coords, step0, fs["pending"], fs["pending_valid"], fs["parity"],
                                       self._stream())
         _lib.check(rc, "ndq_fused_fit_run")
         tails = K + (1 if valid is not None else 0)

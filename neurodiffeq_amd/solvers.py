@@ -84,7 +84,7 @@ class BaseSolver(ABC):
     #: with what it was at trace time -- a few comparisons -- and re-traces at once when something moved; this period only
     #: bounds how long state the watch cannot see (fetched through foreign code) could stay frozen.  fit() without
     #: callbacks re-traces at every chunk boundary as well.
-    EQ_PROBE_EVERY = 128
+    EQ_PROBE_EVERY = 1024
     LOSS_PROBE_EVERY = 1        # epochs between re-probes of a traced custom loss (see _fused_system): every epoch -- a probe
     #                             is one Python re-trace of the callable on a hash-consed graph, and a loss that follows
     #                             solver state (a penalty switched on at epoch N) must never train on a stale kernel
@@ -357,13 +357,19 @@ class BaseSolver(ABC):
         # working precision = the networks' (fp64 is the reference's default, neurodiffeq/__init__.py:22: such systems run
         # the three-kernel pipeline on the fp64 build of the stream kernels)
         # (first parameter of every network: this runs every epoch; describe() checks the rest when the system is built)
-        dtypes = {p.dtype for p in (next(iter(n.parameters()), None) for n in self.nets) if p is not None}
+        # (nn.Module.parameters() walks the module tree: ~3 us per network and epoch; the first parameter of every network
+        # is looked up once per set of network objects)
+        net_ids = tuple(id(n) for n in self.nets)
+        probe = self.__dict__.get("_dtype_probe")
+        if probe is None or probe[0] != net_ids:
+            probe = self._dtype_probe = (net_ids, [p for p in (next(iter(n.parameters()), None) for n in self.nets) if p is not None])
+        dtypes = {p.dtype for p in probe[1]}
         sys_dtype = torch.float64 if dtypes == {torch.float64} else torch.float32
         if sys_dtype == torch.float64 and self.dist is not None:
             reason = "fp64 networks under data parallelism"
         if self._loss_time_dependent:
             reason = "epoch-dependent loss function"
-        key = (id(self.diff_eqs), tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions),
+        key = (id(self.diff_eqs), net_ids, tuple(id(c) for c in self.conditions),
                getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind, sys_dtype,
                id(self.loss_fn) if loss_kind == "custom" else None,
                tuple((name, id(fn)) for name, fn in self.metrics_fn.items()))

@@ -16,7 +16,7 @@ torch.manual_seed(0)
 solver, cfg = configs.make_solver("c2", 256)
 solver.fused = "require"
 solver.generator["train"] = SamplerGenerator(ResidentBatchGenerator.presample(cfg["gen"], 8, "cuda"))
-for _ in range(50):
+for _ in range(600):
     solver.run_train_epoch()
 torch.cuda.synchronize()
 n = 3000
@@ -33,4 +33,4 @@ for _ in range(n):
     solver.run_train_epoch()
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+pstats.Stats(pr).sort_stats("tottime").print_stats(30)
