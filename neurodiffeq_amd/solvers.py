@@ -492,7 +492,14 @@ class BaseSolver(ABC):
         if self.n_batches[key] <= 0:
             return
         self._phase = key
-        first_batch = self._generate_batch(key)
+        from .engine import library_code
+        inner = getattr(self.generator[key], "generator", None)
+        if type(inner).__module__ == "neurodiffeq_amd.generators" and type(inner).__name__ in ("DeviceGenerator", "ResidentBatchGenerator") \
+                and type(self)._generate_batch is BaseSolver._generate_batch:
+            with library_code():           # device-side / resident batches: library code end to end (engine.library_code)
+                first_batch = self._generate_batch(key)
+        else:
+            first_batch = self._generate_batch(key)
         system = self._fused_system(len(first_batch))
         if system is None:
             return self._run_epoch_composite(key, first_batch)
@@ -503,7 +510,6 @@ class BaseSolver(ABC):
             # the largest shard decides which closure-kernel build serves the batch: the same on every rank
             system.select_n = n_all if self.dist.presharded else -(-n_all // self.dist.world_size)
         nb = self.n_batches[key]
-        from .engine import library_code
         with library_code():               # (no user code below: see engine.library_code)
             done = self._run_epoch_native(key, system, first_batch)
         if done:
