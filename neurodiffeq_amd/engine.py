@@ -992,7 +992,8 @@ class FusedSystem:
         if src is not None and src.prefetch and b["coords_rows"] is not None:
             st.next_sampler = ctypes.addressof(src.desc)
             st.next_seed, st.next_draw, st.next_stream = src.seed, src.draw, src.stream_id
-            st.next_coords, st.next_ldc = src.block.data_ptr(), src.block.shape[1]
+            nxt = src.block_of(src.draw)              # (src.draw is the NEXT draw number: the other block of the pair)
+            st.next_coords, st.next_ldc = nxt.data_ptr(), nxt.shape[1]
         else:
             src, st.next_sampler = None, None
         direct = dist.direct(self.device, fp.numel + 1) if dist is not None else None

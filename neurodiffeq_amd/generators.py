@@ -681,7 +681,7 @@ _DEVICE_SOURCES = {}
 def device_source(batch):
     """The DeviceGenerator that handed out ``batch`` (its own list of views), or None."""
     g = _DEVICE_SOURCES.get(id(batch))
-    return g if (g is not None and g._views is batch) else None
+    return g if (g is not None and any(v is batch for v in g._views_all)) else None
 
 
 class DeviceGenerator(BaseGenerator):
@@ -716,16 +716,18 @@ class DeviceGenerator(BaseGenerator):
         self.desc = self.describe(generator)
         self._L = _lib.lib()
         ld = (self.size + 63) // 64 * 64
-        self.block = torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device)
-        self._views = [self.block[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)]
         # prefetch=True: a solver on the single-launch native path lets the extra workgroups of its sums + tail kernel
         # draw the NEXT batch (ndq_fused_step.next_sampler) -- the sampler launch leaves the step.  The points are the
-        # same (draw k is a function of (seed, k, stream_id) only); the one visible difference: once an epoch has run,
-        # the tensors handed out for it already hold the next batch.
+        # same (draw k is a function of (seed, k, stream_id) only).  Two blocks alternate (draw k lives in block k & 1), so
+        # the tensors handed out for an epoch keep that epoch's points until the END of the following epoch.
         self.prefetch = bool(prefetch)
-        self.prefetched = None       # draw number already sitting in the block, drawn ahead by a tail kernel
+        self.blocks = [torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device) for _ in range(2 if self.prefetch else 1)]
+        self._views_all = [[blk[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)] for blk in self.blocks]
+        self.block, self._views = self.blocks[0], self._views_all[0]
+        self.prefetched = None       # draw number already sitting in its block, drawn ahead by a tail kernel
         self.launches = 0            # sampler kernels this generator launched itself (diagnostics / tests)
-        _DEVICE_SOURCES[id(self._views)] = self
+        for views in self._views_all:
+            _DEVICE_SOURCES[id(views)] = self
 
     @staticmethod
     def describe(g):
@@ -761,19 +763,26 @@ class DeviceGenerator(BaseGenerator):
                 return self._get_examples()
         return self._get_examples()
 
+    def block_of(self, draw):
+        """The block draw number ``draw`` lives in."""
+        return self.blocks[draw & 1] if self.prefetch else self.blocks[0]
+
     def _get_examples(self):
+        block = self.block_of(self.draw)
         if self.prefetched == self.draw:          # a tail kernel has drawn this batch already
             self.prefetched = None
         else:
             stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, self.draw, self.stream_id, self.block.data_ptr(),
-                                    self.block.shape[1], stream)
+            rc = self._L.ndq_sample(ctypes.byref(self.desc), self.seed, self.draw, self.stream_id, block.data_ptr(),
+                                    block.shape[1], stream)
             if rc != 0:
                 from . import _lib
                 raise _lib.NdqError(f"ndq_sample failed with code {rc}")
             self.launches += 1
+        views = self._views_all[self.draw & 1] if self.prefetch else self._views_all[0]
+        self.block, self._views = block, views
         self.draw += 1
-        return self._views
+        return views
 
     def _internal_vars(self):
         d = super()._internal_vars()
@@ -817,6 +826,8 @@ def on_default_device(gen):
     if not (type(gen) is GeneratorSpherical or gen.method == "uniform" or gen.method == "equally-spaced-noisy"):
         return gen                 # static grids are uploaded once and read in place; other laws: host
     try:
-        return DeviceGenerator(gen, seed=torch.cuda.initial_seed(), stream_id=0)
+        # prefetch: on the single-launch native path the next batch is drawn by spare workgroups of the epoch's own sums /
+        # tail launch (no sampler launch); the handed-out tensors keep an epoch's points until the end of the next epoch
+        return DeviceGenerator(gen, seed=torch.cuda.initial_seed(), stream_id=0, prefetch=True)
     except ValueError:
         return gen

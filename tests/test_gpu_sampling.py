@@ -43,6 +43,20 @@ def test_solver_under_a_cuda_default_device_samples_on_the_device(cuda_default):
         assert solver.fused_active and solver._batch["train"][0].device.type == "cuda"
         runs.append((np.array(solver.metrics_history["train_loss"]), solver._batch["train"][0].detach().cpu().numpy().copy()))
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])     # torch.manual_seed fixes the run
+    # the auto-wrapped generator prefetches (the next batch is drawn by the epoch's own tail launch) into ALTERNATING blocks:
+    # after epoch e, solver._batch still holds epoch e's points -- what a generator with its own launches draws as batch e
+    torch.manual_seed(3)
+    solver = _laplace()
+    solver.fused = "require"
+    gen = solver.generator["train"].generator
+    assert gen.prefetch and len(gen.blocks) == 2
+    ref = DeviceGenerator(Generator2D((32, 32), (0, 0), (1, 1), method="equally-spaced-noisy"), seed=gen.seed, stream_id=0)
+    for e in range(5):
+        solver.run_train_epoch()
+        have = [c.detach().clone() for c in solver._batch["train"]]
+        want = [c.clone() for c in ref.get_examples()]
+        assert all(torch.equal(a, b) for a, b in zip(have, want)), e
+    assert gen.launches == 1                       # only the very first batch had a sampler launch of its own
     assert not np.array_equal(runs[0][1], runs[2][1])
     assert runs[0][0][-1] < runs[0][0][0]
     # opting out: per generator, globally; index sampling never moves
