@@ -197,13 +197,17 @@ struct DeepArgs {
   real* pb;               // reverse: partial rows of db_{l-1} [stripes][HP]
   real* pw1;              // reverse into the first layer: partial rows of dW1 [stripes][HP][D]
   real* pw;               // weight gradient: partial tiles [KS][HP][HP]
+  const void* wpl;        // bf16x3 route: the layer's weight planes in MFMA A-operand order (deep_prep_planes)
 };
 
 // ------------------------------------------------------------------------------------------------ per-point GEMMs
 // FIRSTIN: the layer input is the first layer's sigma-jet, evaluated from the coordinates; else sigma-jet(zin).
 // Wave w of the grid owns output chunk w % NCH (JBC blocks of 16 units) and walks the 16-point tiles w / NCH, + stripes.
+#ifndef NDQ_DEEP_OCC
+#define NDQ_DEEP_OCC 1             // workgroups per CU the per-point GEMMs are compiled for (experiments: 2 = 256 registers per wave)
+#endif
 template <class C, bool FIRSTIN>
-__global__ __launch_bounds__(C::THREADS) void deep_fwd_gemm(DeepArgs a) {
+__global__ __launch_bounds__(C::THREADS, NDQ_DEEP_OCC) void deep_fwd_gemm(DeepArgs a) {
   const int lane = threadIdx.x & 63, p = lane & 15, kg = lane >> 4;
   const int gw = blockIdx.x * C::WAVES + (threadIdx.x >> 6), nw = gridDim.x * C::WAVES;
   const int ch = gw % C::NCH, stripe = gw / C::NCH, nstripes = nw / C::NCH;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(C::THREADS) void deep_fwd_gemm(DeepArgs a) {
 // Hbar_{l-1} = W_l^T Zbar_l, then the act-backward of layer l - 1 in the epilogue.  TOFIRST (l == 2): layer 1's streams come
 // from the coordinates and what leaves is dW1 / db1 (per-wave partial rows); else Zbar_{l-1} is stored and db_{l-1} summed.
 template <class C, bool TOFIRST>
-__global__ __launch_bounds__(C::THREADS) void deep_bwd_gemm(DeepArgs a) {
+__global__ __launch_bounds__(C::THREADS, NDQ_DEEP_OCC) void deep_bwd_gemm(DeepArgs a) {
   constexpr int JB = TOFIRST ? C::JBF : C::JBB, NCH = TOFIRST ? C::NCHF : C::NCHB;
   const int lane = threadIdx.x & 63, p = lane & 15, kg = lane >> 4;
   const int gw = blockIdx.x * C::WAVES + (threadIdx.x >> 6), nw = gridDim.x * C::WAVES;
@@ -459,6 +463,277 @@ __global__ __launch_bounds__(C::THREADS) void deep_bwd_gemm(DeepArgs a) {
         }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ per-point GEMMs, bf16x3
+// The same products as deep_fwd_gemm / deep_bwd_gemm on the REAL matrix core: v_mfma_f32_16x16x32_bf16 with 3-way split
+// operands (x = x0 + x1 + x2, six significant plane products accumulated in fp32, smallest first: fp32-class accuracy,
+// csrc/ndq_mlp.h) -- 6 MFMAs of 16 cycles per 32-deep contraction chunk against 8 exact-f32 MFMAs of 32 cycles, and they
+// overlap with the VALU work of the operand prologue (the f32 MFMA shares the VALU datapath).
+//   weights   deep_prep writes every hidden matrix (and its transpose) as bf16x3 planes in MFMA A-operand order:
+//             element ((b * NCK + c) * 3 + plane) * 64 + lane = the 8 bf16 of row 16 b + (lane & 15), columns
+//             32 c + 8 (lane >> 4) ... + 7.  A workgroup keeps the planes of ITS output chunk (JBR blocks x all NCK
+//             contraction chunks, <= 96 KB) resident in LDS for the whole launch: staged once, read by all four waves.
+//   operand   a lane's 8 contraction units of its point are two 16-byte loads per stream; sigma-jet (SRC 0 / 1) and the
+//             3-way split of step c + 1 are computed while the MFMAs of step c are in flight.
+// SRC: 0 = sigma-jet of the first layer, from the coordinates; 1 = sigma-jet(zin); 2 = zin as it is (reverse GEMM).
+// EPI: 0 = + bias, store Z_l; 1 = act-backward with Z_{l-1}, store Zbar_{l-1}, sum db_{l-1}; 2 = act-backward into the
+//      first layer (dW1, db1 partial rows).
+#ifndef NDQ_DEEP_BF_LDS_KB
+#define NDQ_DEEP_BF_LDS_KB 96      // LDS a workgroup spends on its resident weight planes (48: two workgroups per CU)
+#endif
+constexpr int kDeepBfOcc = NDQ_DEEP_BF_LDS_KB <= 48 ? 2 : 1;
+template <class C, int EPI> constexpr int deep_bf_jb() {
+  constexpr int NCK = (C::HP + 31) / 32;
+  int j = (NDQ_DEEP_BF_LDS_KB / 3) / NCK;                  // planes of the chunk: 3 KB per (block, contraction chunk)
+  const int most = EPI == 0 ? C::JBC : (EPI == 1 ? C::JBB : C::JBF);
+  j = j > most ? most : j;
+  j = j < 1 ? 1 : j;
+  return C::balanced(j);
+}
+
+template <class C, int SRC, int EPI>
+__global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs a) {
+  constexpr int JB = deep_bf_jb<C, EPI>(), NCH = (C::NB + JB - 1) / JB, NCK = (C::HP + 31) / 32, NS = C::NS;
+  extern __shared__ __attribute__((aligned(16))) bf16x8 wl[];          // [JB][NCK][3][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, kg = lane >> 4;
+  const int ch = blockIdx.x % NCH, bstripe = blockIdx.x / NCH, nbstripes = gridDim.x / NCH;
+  if (bstripe >= nbstripes) return;                        // (whole workgroups: no barrier is missed)
+  // ---- this workgroup's weight planes -> LDS, once
+  {
+    const bf16x8* src = static_cast<const bf16x8*>(a.wpl);
+    for (int e = threadIdx.x; e < JB * NCK * 3 * 64; e += C::THREADS) {
+      const int jb = e / (NCK * 3 * 64), rest = e % (NCK * 3 * 64);
+      const int b = ch * JB + jb;
+      bf16x8 v;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = (__bf16)0.f;
+      if (b < C::NB) v = src[(size_t)b * (NCK * 3 * 64) + rest];
+      wl[e] = v;
+    }
+  }
+  const int ntiles = a.np >> 4;
+  const size_t sstride = (size_t)a.np * C::HP;
+  // per-wave constants of the epilogue
+  real4 bs[EPI == 0 ? JB : 1];
+  real u1w[EPI == 2 ? JB : 1][4][C::D], u1b[EPI == 2 ? JB : 1][4];
+  real gb[EPI != 0 ? JB : 1][4], gw1[EPI == 2 ? JB : 1][4][C::D];
+#pragma unroll
+  for (int jb = 0; jb < JB; ++jb) {
+    const int j0 = 16 * (ch * JB + jb) + 4 * kg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = j0 + r < C::W;
+      if constexpr (EPI == 0) bs[jb][r] = ok ? a.bias[ok ? j0 + r : 0] : 0.f;
+      if constexpr (EPI != 0) gb[jb][r] = 0.f;
+      if constexpr (EPI == 2) {
+        u1b[jb][r] = ok ? a.prm[C::offb1 + (ok ? j0 + r : 0)] : 0.f;
+#pragma unroll
+        for (int d = 0; d < C::D; ++d) {
+          u1w[jb][r][d] = ok ? a.prm[C::offW1 + (ok ? j0 + r : 0) * C::D + d] : 0.f;
+          gw1[jb][r][d] = 0.f;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int tile = bstripe * C::WAVES + wave; tile < ntiles; tile += nbstripes * C::WAVES) {
+    const int n = tile * 16 + p;
+    const int nn = n < a.n ? n : a.n - 1;
+    real x[C::D];
+    if constexpr (SRC == 0 || EPI == 2) {
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    }
+    real4 acc[NS][JB];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) acc[s][jb] = real4{0.f, 0.f, 0.f, 0.f};
+    real4 zpre[EPI == 1 ? JB : 1][NS];
+    if constexpr (EPI == 1) {
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) {
+        const int b = ch * JB + jb;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          zpre[jb][s] = *reinterpret_cast<const real4*>(a.zprev + s * sstride + (size_t)n * C::HP + 16 * (b < C::NB ? b : 0) + 4 * kg);
+      }
+    }
+    // operand of contraction step c: this lane's units 32 c + 8 kg ... + 7 of its point
+    real4 vlo[SRC == 0 ? 1 : NS], vhi[SRC == 0 ? 1 : NS];
+    real f1w[SRC == 0 ? 8 : 1][C::D], f1b[SRC == 0 ? 8 : 1];
+    auto fetch = [&](int c) {
+      const int k0 = 32 * c + 8 * kg;
+      if constexpr (SRC == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool ok = k0 + e < C::W;
+          f1b[e] = ok ? a.prm[C::offb1 + (ok ? k0 + e : 0)] : 0.f;
+#pragma unroll
+          for (int d = 0; d < C::D; ++d) f1w[e][d] = ok ? a.prm[C::offW1 + (ok ? k0 + e : 0) * C::D + d] : 0.f;
+        }
+      } else {
+        const real4 zero = real4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const real* row = a.zin + s * sstride + (size_t)n * C::HP;
+          vlo[s] = k0 < C::HP ? *reinterpret_cast<const real4*>(row + k0) : zero;
+          vhi[s] = k0 + 4 < C::HP ? *reinterpret_cast<const real4*>(row + k0 + 4) : zero;
+        }
+      }
+    };
+    bf16x8 pl[NS][3];
+    auto planes = [&]() {
+      real4 hlo[NS], hhi[NS];
+      if constexpr (SRC == 2) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { hlo[s] = vlo[s]; hhi[s] = vhi[s]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          real z[NS], h[NS], tt, cc;
+          if constexpr (SRC == 0) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) z[s] = 0.f;
+            real zv = f1b[e];
+#pragma unroll
+            for (int d = 0; d < C::D; ++d) {
+              zv = rfma(f1w[e][d], x[d], zv);
+              if constexpr (C::SS::FIRST) z[1 + d] = f1w[e][d];
+            }
+            z[0] = zv;
+          } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) z[s] = e < 4 ? vlo[s][e & 3] : vhi[s][e & 3];
+          }
+          jet_unit_forward<C>(z, h, tt, cc);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            if (e < 4) hlo[s][e & 3] = h[s];
+            else hhi[s][e & 3] = h[s];
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) split3(hlo[s], hhi[s], pl[s]);
+    };
+    fetch(0);
+    planes();
+    for (int c = 0; c < NCK; ++c) {
+      if (c + 1 < NCK) fetch(c + 1);
+      __builtin_amdgcn_sched_barrier(0);                   // the loads stay above the MFMAs
+#pragma unroll
+      for (int jb = 0; jb < JB; ++jb) {
+        const bf16x8* w = wl + ((jb * NCK + c) * 3) * 64 + lane;
+        const bf16x8 a0 = w[0], a1 = w[64], a2 = w[128];
+#define NDQ_T(A, K)                                                                                          \
+  _Pragma("unroll") for (int s = 0; s < NS; ++s)                                                             \
+      acc[s][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][K], acc[s][jb], 0, 0, 0);
+        NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+#undef NDQ_T
+      }
+      if (c + 1 < NCK) planes();                           // VALU work of the next step, under the MFMAs in flight
+    }
+    // ---- epilogue
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+      const int b = ch * JB + jb;
+      if (b < C::NB) {
+        const int j0 = 16 * b + 4 * kg;
+        if constexpr (EPI == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[0][jb][r] += bs[jb][r];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) *reinterpret_cast<real4*>(a.zout + s * sstride + (size_t)n * C::HP + j0) = acc[s][jb];
+        } else {
+          real4 out[NS];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            real z[NS], g[NS], tt, cc;
+            if constexpr (EPI == 2) {
+#pragma unroll
+              for (int s = 0; s < NS; ++s) z[s] = 0.f;
+              real zv = u1b[jb][r];
+#pragma unroll
+              for (int d = 0; d < C::D; ++d) {
+                zv = rfma(u1w[jb][r][d], x[d], zv);
+                if constexpr (C::SS::FIRST) z[1 + d] = u1w[jb][r][d];
+              }
+              z[0] = zv;
+            } else {
+#pragma unroll
+              for (int s = 0; s < NS; ++s) z[s] = zpre[jb][s][r];
+            }
+            Act<C::ACT>::fwd(z[0], tt, cc);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) g[s] = acc[s][jb][r];
+            jet_unit_backward<C>(z, tt, cc, g);
+            gb[jb][r] += g[0];
+            if constexpr (EPI == 2) {
+#pragma unroll
+              for (int d = 0; d < C::D; ++d) gw1[jb][r][d] += C::SS::FIRST ? rfma(g[0], x[d], g[C::SS::FIRST ? 1 + d : 0]) : g[0] * x[d];
+            } else {
+#pragma unroll
+              for (int s = 0; s < NS; ++s) out[s][r] = g[s];
+            }
+          }
+          if constexpr (EPI == 1) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) *reinterpret_cast<real4*>(a.zout + s * sstride + (size_t)n * C::HP + j0) = out[s];
+          }
+        }
+      }
+    }
+  }
+  if constexpr (EPI != 0) {
+    // partial rows: one per WAVE (row index = workgroup stripe x 4 + wave), every chunk fills its own units
+    const int row = bstripe * C::WAVES + wave;
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) {
+      const int b = ch * JB + jb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const real v = point_sum(gb[jb][r]);
+        if (b < C::NB && p == 0) a.pb[(size_t)row * C::HP + 16 * b + 4 * kg + r] = v;
+        if constexpr (EPI == 2) {
+#pragma unroll
+          for (int d = 0; d < C::D; ++d) {
+            const real u = point_sum(gw1[jb][r][d]);
+            if (b < C::NB && p == 0) a.pw1[((size_t)row * C::HP + 16 * b + 4 * kg + r) * C::D + d] = u;
+          }
+        }
+      }
+    }
+  }
+}
+template <class C, int EPI> constexpr size_t deep_bf_lds_bytes() { return (size_t)deep_bf_jb<C, EPI>() * ((C::HP + 31) / 32) * 3 * 64 * 16; }
+
+// bf16x3 planes of the padded hidden matrices in MFMA A-operand order (see deep_gemm_bf): wpl[l - 2] = W_l, wtl[l - 2] = W_l^T
+template <class C>
+__global__ __launch_bounds__(256) void deep_prep_planes(const real* __restrict__ prm, bf16x8* __restrict__ wpl, bf16x8* __restrict__ wtl) {
+  constexpr int NCK = (C::HP + 31) / 32, PER = C::NB * NCK * 64;     // lane-elements per matrix and plane set
+  const int l = 2 + blockIdx.y;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * PER; e += gridDim.x * blockDim.x) {
+    const bool tr = e >= PER;
+    const int f = tr ? e - PER : e;
+    const int lane = f & 63, c = (f >> 6) % NCK, b = (f >> 6) / NCK;
+    const int row = 16 * b + (lane & 15), k0 = 32 * c + 8 * (lane >> 4);
+    real4 lo, hi;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = k0 + t;
+      // element (row, k) of W_l, or of its transpose
+      const int j = tr ? k : row, kk = tr ? row : k;
+      const real v = (j < C::W && kk < C::W) ? prm[C::offW(l) + j * C::W + kk] : 0.f;
+      if (t < 4) lo[t] = v; else hi[t - 4] = v;
+    }
+    bf16x8 pl[3];
+    split3(lo, hi, pl);
+    bf16x8* dst = (tr ? wtl : wpl) + (size_t)(l - 2) * (C::NB * NCK * 3 * 64);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dst[((size_t)(b * NCK + c) * 3 + q) * 64 + lane] = pl[q];
   }
 }
 

@@ -148,16 +148,23 @@ kernels_record make_wide_kernels() {
 // owns that workspace (hipMalloc on first use, grown when a larger batch arrives, never inside a timed steady state); the
 // adjoint entry recomputes the forward layers like every ndq_mlp_jet_bwd and writes ONE row of "partials" -- the gradient
 // itself, its own reductions being fixed-order already (bwd_waves is set so that ndq_mlp_bwd_blocks() == 1).
+#ifndef NDQ_DEEP_BF16X3
+#define NDQ_DEEP_BF16X3 1          // per-point GEMMs of the deep wide networks on the bf16 matrix core with 3-way split operands
+#endif                             // (0: the exact-f32 MFMA kernels -- A/B runs, and the fallback the first version shipped with)
 struct DeepPlan {
   int np, blocks_max;
-  size_t X, z0, zb0, wp, wt, pw, pw_layer, pb, pb_layer, pw1, pwo, pbo, total;
+  size_t X, z0, zb0, wp, wt, pw, pw_layer, pb, pb_layer, pw1, pwo, pbo, wpl, wtl, planes_layer, total;
 };
+template <class K>
+int deep_set_lds(K kernel, size_t bytes) {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 template <class C>
 DeepPlan deep_plan(int n) {
   DeepPlan q{};
   q.np = (n + 15) & ~15;
   q.blocks_max = 256;
-  const size_t HP = C::HP, nwmax = 4 * (size_t)q.blocks_max * C::WAVES;
+  const size_t HP = C::HP, nwmax = 4 * (size_t)q.blocks_max * C::WAVES;      // most partial rows any kernel writes
   q.X = (size_t)C::NS * q.np * HP;
   size_t o = 0;
   q.z0 = o; o += (size_t)(C::L - 1) * q.X;            // Z_2 .. Z_L
@@ -171,6 +178,9 @@ DeepPlan deep_plan(int n) {
   q.pw1 = o; o += nwmax * HP * C::D;
   q.pwo = o; o += nwmax * C::NOUT * HP;
   q.pbo = o; o += nwmax * C::NOUT;
+  q.planes_layer = (size_t)C::NB * ((C::HP + 31) / 32) * 3 * 64 * 4;             // floats per matrix: bf16x8 elements of 16 B
+  q.wpl = o; o += (size_t)(C::L - 1) * q.planes_layer;
+  q.wtl = o; o += (size_t)(C::L - 1) * q.planes_layer;
   q.total = o + 64;
   return q;
 }
@@ -200,18 +210,40 @@ inline int deep_blocks(long waves, int min_waves, int cap) {
 // forward layers 2 .. L into the workspace (shared by the two entry points)
 template <class C>
 int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc, int n, const real* params, hipStream_t st) {
-  hipLaunchKernelGGL(deep_prep<C>, dim3(64, C::L - 1), dim3(256), 0, st, params, ws + q.wp, ws + q.wt);
   const int ntiles = q.np / 16;
+#if NDQ_DEEP_BF16X3
+  hipLaunchKernelGGL(deep_prep_planes<C>, dim3(64, C::L - 1), dim3(256), 0, st, params, reinterpret_cast<bf16x8*>(ws + q.wpl),
+                     reinterpret_cast<bf16x8*>(ws + q.wtl));
+  constexpr int NCHB0 = (C::NB + deep_bf_jb<C, 0>() - 1) / deep_bf_jb<C, 0>();
+  static bool attr = false;
+  if (!attr) {
+    int e = deep_set_lds(&deep_gemm_bf<C, 0, 0>, deep_bf_lds_bytes<C, 0>());
+    if (!e) e = deep_set_lds(&deep_gemm_bf<C, 1, 0>, deep_bf_lds_bytes<C, 0>());
+    if (e) return e;
+    attr = true;
+  }
+  int stripes = (ntiles + C::WAVES - 1) / C::WAVES;                                        // one workgroup per CU: its weight planes fill the LDS
+  if (stripes > kDeepBfOcc * q.blocks_max / NCHB0) stripes = kDeepBfOcc * q.blocks_max / NCHB0;
+  if (stripes < 1) stripes = 1;
+#else
+  hipLaunchKernelGGL(deep_prep<C>, dim3(64, C::L - 1), dim3(256), 0, st, params, ws + q.wp, ws + q.wt);
   const int blocks = deep_blocks((long)ntiles * C::NCH, C::NCH, 2 * q.blocks_max);      // two workgroups per CU
+#endif
   for (int l = 2; l <= C::L; ++l) {
     DeepArgs a{};
     a.coords = coords; a.prm = params; a.n = n; a.np = q.np; a.ldc = ldc;
     a.wmat = ws + q.wp + (size_t)(l - 2) * C::HP * C::HP;
+    a.wpl = ws + q.wpl + (size_t)(l - 2) * q.planes_layer;
     a.bias = params + C::offb(l);
     a.zin = l > 2 ? ws + q.z0 + (size_t)(l - 3) * q.X : nullptr;
     a.zout = ws + q.z0 + (size_t)(l - 2) * q.X;
+#if NDQ_DEEP_BF16X3
+    if (l == 2) hipLaunchKernelGGL((deep_gemm_bf<C, 0, 0>), dim3(stripes * NCHB0), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
+    else hipLaunchKernelGGL((deep_gemm_bf<C, 1, 0>), dim3(stripes * NCHB0), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
+#else
     if (l == 2) hipLaunchKernelGGL((deep_fwd_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
     else hipLaunchKernelGGL((deep_fwd_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+#endif
   }
   return (int)hipGetLastError();
 }
@@ -285,7 +317,39 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       reduce(a.pw, KS, C::HP, C::HP, C::W, C::W, grad + C::offW(l));
     }
     a.wmat = ws + q.wt + (size_t)(l - 2) * C::HP * C::HP;
+    a.wpl = ws + q.wtl + (size_t)(l - 2) * q.planes_layer;               // planes of W_l^T
     a.pb = ws + q.pb + (size_t)(l - 2) * q.pb_layer;                      // db_{l-1}
+#if NDQ_DEEP_BF16X3
+    {
+      static bool attr = false;
+      if (!attr) {
+        int e = deep_set_lds(&deep_gemm_bf<C, 2, 1>, deep_bf_lds_bytes<C, 1>());
+        if (!e) e = deep_set_lds(&deep_gemm_bf<C, 2, 2>, deep_bf_lds_bytes<C, 2>());
+        if (e) return e;
+        attr = true;
+      }
+    }
+    auto bf_stripes = [&](int nch) {
+      int s = (ntiles + C::WAVES - 1) / C::WAVES;
+      if (s > kDeepBfOcc * q.blocks_max / nch) s = kDeepBfOcc * q.blocks_max / nch;
+      return s < 1 ? 1 : s;
+    };
+    if (l > 2) {
+      constexpr int NCHB1 = (C::NB + deep_bf_jb<C, 1>() - 1) / deep_bf_jb<C, 1>();
+      a.zout = ws + q.zb0 + (size_t)(cur ^ 1) * q.X;
+      const int stripes = bf_stripes(NCHB1);
+      hipLaunchKernelGGL((deep_gemm_bf<C, 2, 1>), dim3(stripes * NCHB1), dim3(C::THREADS), (deep_bf_lds_bytes<C, 1>()), st, a);
+      reduce(a.pb, stripes * C::WAVES, 1, C::HP, 1, C::W, grad + C::offb(l - 1));
+      cur ^= 1;
+    } else {
+      constexpr int NCHB2 = (C::NB + deep_bf_jb<C, 2>() - 1) / deep_bf_jb<C, 2>();
+      a.pw1 = ws + q.pw1;
+      const int stripes = bf_stripes(NCHB2);
+      hipLaunchKernelGGL((deep_gemm_bf<C, 2, 2>), dim3(stripes * NCHB2), dim3(C::THREADS), (deep_bf_lds_bytes<C, 2>()), st, a);
+      reduce(a.pb, stripes * C::WAVES, 1, C::HP, 1, C::W, grad + C::offb1);
+      reduce(a.pw1, stripes * C::WAVES, C::HP, C::D, C::W, C::D, grad + C::offW1);
+    }
+#else
     if (l > 2) {
       a.zout = ws + q.zb0 + (size_t)(cur ^ 1) * q.X;
       const int blocks = deep_blocks((long)ntiles * C::NCHB, C::NCHB, 2 * q.blocks_max);
@@ -300,6 +364,7 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       reduce(a.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb1);
       reduce(a.pw1, stripes, C::HP, C::D, C::W, C::D, grad + C::offW1);
     }
+#endif
   }
   hipLaunchKernelGGL(deep_reduce_all, dim3(J.nblocks), dim3(64, 16), 0, st, J);
   return (int)hipGetLastError();
