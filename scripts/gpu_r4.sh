@@ -21,6 +21,7 @@ fi
 if has trace; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/$OUT/prof" -o trace -- python "$REPO/bench.py" --steps 2000 --warmup 200 --no-cpu-baseline --no-traffic > "$REPO/$OUT/prof_bench.json" 2> "$REPO/$OUT/prof.err"); echo "rocprof rc=$?"
   python scripts/rocpd_stats.py $OUT/prof/trace_results.db > $OUT/bench_kernel_stats.md 2>/dev/null; head -n 8 $OUT/bench_kernel_stats.md | cut -c1-220
+  python scripts/step_timeline.py $OUT/prof/trace_results.db > $OUT/step_timeline.json 2>$OUT/step_timeline.err; cat $OUT/step_timeline.json
 fi
 if has wide; then
   timeout 600 python scripts/wide_bench.py w16:256 w17:256 w18:256 w19:256 w20:256 w16:1024 > $OUT/wide.jsonl 2> $OUT/wide.err; cat $OUT/wide.jsonl | cut -c1-330
