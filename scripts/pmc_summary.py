@@ -18,9 +18,11 @@ def short(k):
     m = re.search(r"(wide_closure_tv|wide_closure|wide_jet_fwd|wide_jet_bwd)_kernel<ndq::WideCfg<([^>]*)>", k)
     if m:
         return f"{m.group(1)}<{m.group(2).replace(' ', '')}>"
-    m = re.search(r"(deep_fwd_gemm|deep_bwd_gemm|deep_wgrad_gemm|deep_head_fwd|deep_head_bwd)<ndq::DeepCfg<([^>]*)>(, \w+)?", k)
+    m = re.search(r"(deep_gemm_bf|deep_fwd_gemm|deep_bwd_gemm|deep_wgrad_gemm|deep_head_fwd|deep_head_bwd)<ndq::DeepCfg<([^>]*)>((?:, \w+)*)", k)
     if m:
         return f"{m.group(1)}<{m.group(2).replace(' ', '')}>{(m.group(3) or '').replace(', ', '/')}"
+    if "deep_prep_planes" in k:
+        return "deep_prep_planes"
     for name in ("deep_reduce_all", "deep_prep", "reduce_tail_multi", "reduce_tail", "reduce_partials", "reduce_grad_loss", "epoch_tail", "ndq_pw_kernel",
                  "sample_kernel", "calib_read4", "calib_read16", "calib_write4"):
         if name in k:
