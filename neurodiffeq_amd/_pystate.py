@@ -5,7 +5,7 @@ held in a dict, a Reynolds number ramped by a callback or a boundary value store
 next epoch.  The fused path executes those callables ONCE, on symbolic columns: every Python float they read becomes a
 literal of the generated kernel.  ``StateWatch`` records, at trace time, the leaves of Python state the callables can
 reach -- closure cells, the module globals their code names, default arguments, attributes of bound ``self`` objects and
-of the condition objects, up to three container levels deep -- as (where, expected stamp) entries and compiles them into
+of the condition objects (and the plain class attributes behind them), up to six container levels deep -- as (where, expected stamp) entries and compiles them into
 ONE checker function (a chain of ``and``-ed comparisons, ~0.05 us per entry: the native epoch is host-bound at the headline
 size, a microsecond here is 4 % of the step).  ``dirty()`` runs it: nothing for the usual stateless lambda.  A dirty watch
 is not yet a changed equation; the solver then re-traces (``program.eq_probe``: the graph is hash-consed, so an unchanged
@@ -27,12 +27,18 @@ _MISSING = object()
 _OPAQUE = (torch.Tensor, torch.nn.Module, torch.optim.Optimizer, types.ModuleType, type)
 
 
+def _user_class(k):
+    """A class whose plain attributes can be equation state: not a builtin, not library code, not a torch module."""
+    return (isinstance(k, type) and (getattr(k, "__module__", "") or "").split(".")[0] not in _LIBRARY_ROOTS + ("builtins", "abc", "typing", "collections", "types")
+            and not issubclass(k, (torch.nn.Module, torch.optim.Optimizer, BaseException)))
+
+
 def _is_leaf(v):
     return isinstance(v, _LEAF_TYPES) and not isinstance(v, torch.Tensor)
 
 
 class StateWatch:
-    def __init__(self, roots, max_depth=3, max_items=64):
+    def __init__(self, roots, max_depth=6, max_items=64):
         self.entries = []          # (expression template over O[...] / M, kind, payload)
         self.objs = []             # objects the expressions index: they stay alive, an id() can never come back as another object
         self._index = {}
@@ -75,8 +81,12 @@ class StateWatch:
         self._visit(value, depth + 1)
 
     def _visit(self, v, depth):
+        if isinstance(v, type) and depth <= self.max_depth and id(v) not in self._seen:
+            self._seen.add(id(v))
+            self._class(v, self._ref(v), depth)         # `class Cfg: nu = 0.1` used as a namespace
+            return
         if depth > self.max_depth or id(v) in self._seen or _is_leaf(v) or isinstance(v, _OPAQUE):
-            return                 # (tensors are stamped where they are referenced; modules / classes are not state)
+            return                 # (tensors are stamped where they are referenced; modules are not state)
         self._seen.add(id(v))
         if isinstance(v, types.MethodType):
             self._visit(v.__func__, depth)
@@ -128,8 +138,10 @@ class StateWatch:
             codes.extend(c for c in co.co_consts if isinstance(c, types.CodeType))
         g = fn.__globals__
         for name in sorted(names):
-            if name in g and not isinstance(g[name], (types.ModuleType, type, types.BuiltinFunctionType)):
+            if name in g and not isinstance(g[name], (types.ModuleType, types.BuiltinFunctionType)):
                 value = g[name]
+                if isinstance(value, type) and not _user_class(value):
+                    continue
                 if isinstance(value, types.FunctionType) and (getattr(value, "__module__", "") or "").split(".")[0] in _LIBRARY_ROOTS:
                     continue       # `diff`, `torch.sin` ...: library functions are not user state
                 self._add(f"{self._ref(g)}.get({name!r}, M)", value, depth)
@@ -153,6 +165,22 @@ class StateWatch:
             if name in own or name == "_own_attrs" or not name.isidentifier():
                 continue
             self._add(f"getattr({r}, {name!r}, M)", d[name], depth)
+        # plain values defined on the class and read through the instance (`class Eq: nu = 0.1`): watched THROUGH the
+        # instance, so that an instance attribute set later, shadowing the class value, is seen as well
+        self._class(type(obj), r, depth, skip=set(d) | set(own))
+
+    def _class(self, cls, via, depth, skip=()):
+        n = 0
+        for k in cls.__mro__:
+            if not _user_class(k):
+                continue
+            for name, value in list(vars(k).items()):
+                if name.startswith("__") or name in skip or not name.isidentifier() or n >= self.max_items:
+                    continue
+                if _is_leaf(value) or isinstance(value, (dict, list, tuple, torch.Tensor)) or type(value).__module__ == "numpy":
+                    n += 1
+                    skip = set(skip) | {name}
+                    self._add(f"getattr({via}, {name!r}, M)", value, depth)
 
     def _compile(self):
         if not self.entries:

@@ -99,6 +99,7 @@ class BaseSolver(ABC):
                  analytic_solutions=None, optimizer=None, loss_fn=None, n_batches_train=1, n_batches_valid=4,
                  metrics=None, n_input_units=None, n_output_units=None, shuffle=None, batch_size=None,
                  criterion=None):
+        attrs_of_the_subclass = frozenset(self.__dict__)       # set before super().__init__(): possibly equation state
         if criterion is not None:
             warnings.warn("`criterion` is deprecated; use `loss_fn`", FutureWarning)
             loss_fn = criterion if loss_fn is None else loss_fn
@@ -179,7 +180,8 @@ class BaseSolver(ABC):
         self._fast_tracks_best = False
         self.dist = None                # optional neurodiffeq_amd.parallel.BatchSharding
         # the solver's own bookkeeping attributes: not equation state when diff_eqs is a bound method (_pystate.StateWatch)
-        self._own_attrs = frozenset(self.__dict__) | {"_own_attrs"}
+        self._own_attrs = (frozenset(self.__dict__) - attrs_of_the_subclass) | {"_own_attrs", "_best_nets_from_device", "_dtype_probe", "_eq_watch_warned",
+                                                       "_eval_key", "_eval_sys", "_host_metrics", "_resid_key", "_resid_sys"}
 
     # ------------------------------------------------------------------------------------------ loss function
     def _set_loss_fn(self, criterion):
@@ -452,8 +454,7 @@ class BaseSolver(ABC):
     def _watch_equations(self):
         """Remember the Python state diff_eqs / the conditions / compute_func_val can read (solvers.py:380 re-evaluates them
         every batch; the traced kernels froze it)."""
-        from ._pystate import StateWatch
-        self._eq_watch = StateWatch([self.diff_eqs, self.compute_func_val] + list(self.conditions))
+        self._eq_watch = self._new_state_watch()
         self._eq_probe_countdown = 1
 
     def _equations_unchanged(self, sysm, force=False):
@@ -477,10 +478,20 @@ class BaseSolver(ABC):
         return same
 
     def _watch_equations_refresh(self):
-        from ._pystate import StateWatch
         countdown = self._eq_probe_countdown
-        self._eq_watch = StateWatch([self.diff_eqs, self.compute_func_val] + list(self.conditions))
+        self._eq_watch = self._new_state_watch()
         self._eq_probe_countdown = countdown
+
+    def _new_state_watch(self):
+        from ._pystate import StateWatch
+        try:
+            return StateWatch([self.diff_eqs, self.compute_func_val] + list(self.conditions))
+        except Exception as e:       # noqa: BLE001 -- an object the walk cannot read: no watch = re-trace every epoch (slow, never stale)
+            if not self.__dict__.get("_eq_watch_warned"):
+                self._eq_watch_warned = True
+                warnings.warn(f"neurodiffeq_amd: the Python state read by the equations could not be indexed ({type(e).__name__}: "
+                              f"{e}); the equations are re-traced every epoch instead.", RuntimeWarning)
+            return None
 
     @property
     def fused_active(self):
