@@ -384,7 +384,7 @@ def config_record(name, size=None):
 def fp64_record():
     """C2 at its stated size in the reference's DEFAULT precision (neurodiffeq/__init__.py:22: float64): fp64 networks on
     the fused three-kernel pipeline (fp64 stream kernels of libndq64.so + the traced pointwise kernel compiled in double,
-    device-side Adam in double), batch resident in HBM, through run_train_epoch()."""
+    device-side epoch tail in double), batch resident in HBM, through run_train_epoch()."""
     from tests import configs
     torch.manual_seed(0)
     solver, cfg = configs.make_solver("c2")
@@ -403,7 +403,7 @@ def fp64_record():
     n = cfg["n_points"]
     assert solver.fused_active and solver._fused_sys.f64
     return dict(points=n, dtype="f64", ms_per_step=dt * 1e3, points_per_s=n / dt, windows=len(times), steps_per_window=k,
-                optimizer="FusedAdam: ndq64_adam_step on the flat fp64 vector (one host synchronisation per epoch)",
+                optimizer="FusedAdam on the device: ndq64_epoch_tail (history, best snapshot, Adam in double; no host synchronisation per epoch)",
                 final_loss=solver.metrics_history["train_loss"][-1])
 
 

@@ -311,6 +311,14 @@ int ndq64_reduce_partials(const double* partials, int nparts, int len, double* o
 int ndq64_adam_step(double* params, const double* grad, double* exp_avg, double* exp_avg_sq, int len, double lr,
                     double beta1, double beta2, double eps, double weight_decay, int step, void* stream);
 
+/* ndq_epoch_tail in double: the device-side end of an epoch of an fp64 system (loss slots -> history ring, best snapshot,
+ * Adam with ndq64_adam_step's arithmetic) -- with it an fp64 Solver epoch needs no host synchronisation either
+ * (solvers.py:407-419, 434-441 of the reference). */
+int ndq64_epoch_tail(double* params, const double* grad, double* exp_avg, double* exp_avg_sq, int len, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, int step, const double* loss_slots,
+                     int n_batches, double* loss_hist, int hist_index, double* best_loss, int parity, double* best_flat,
+                     int write_scalars, void* stream);
+
 /* ---- one-shot all-reduce of the small [gradient | loss] message (data-parallel training) ------------
  * Every rank writes its vector straight into every peer's inbox (fine-grained device memory shared through HIP IPC; on
  * MI355X one xGMI hop to each of the 7 peers) and adds up the world_size vectors it received, in rank order: ONE

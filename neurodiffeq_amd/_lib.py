@@ -140,6 +140,7 @@ def lib64():
     L.ndq64_mlp_register.argtypes = [vp]
     cd = ctypes.c_double
     L.ndq64_adam_step.argtypes = [vp, vp, vp, vp, ci, cd, cd, cd, cd, cd, ci, vp]
+    L.ndq64_epoch_tail.argtypes = [vp, vp, vp, vp, ci, cd, cd, cd, cd, cd, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp]
     for name in EXPORTS64:
         getattr(L, name).restype = ci
     _LIB64 = L
@@ -147,7 +148,8 @@ def lib64():
 
 
 EXPORTS64 = ("ndq64_mlp_register", "ndq64_mlp_supported", "ndq64_mlp_num_streams", "ndq64_mlp_num_params",
-             "ndq64_mlp_bwd_blocks", "ndq64_mlp_jet_fwd", "ndq64_mlp_jet_bwd", "ndq64_reduce_partials", "ndq64_adam_step")
+             "ndq64_mlp_bwd_blocks", "ndq64_mlp_jet_fwd", "ndq64_mlp_jet_bwd", "ndq64_reduce_partials", "ndq64_adam_step",
+             "ndq64_epoch_tail")
 
 EXPORTS = ("ndq_mlp_supported", "ndq_mlp_num_streams", "ndq_mlp_num_params", "ndq_mlp_bwd_blocks", "ndq_mlp_jet_fwd",
            "ndq_mlp_jet_bwd", "ndq_reduce_partials", "ndq_adam_step", "ndq_reduce_grad_loss", "ndq_epoch_tail",

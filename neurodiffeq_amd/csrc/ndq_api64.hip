@@ -43,22 +43,35 @@ static int bwd_blocks64(const ndq64_mlp_kernels* e, int n) {
   return blocks < 1 ? 1 : blocks;
 }
 
-// out[i] = (acc ? out[i] : 0) + scale * sum_r partials[r*len + i]; rows in fixed order, 4 independent chains per thread
-__global__ __launch_bounds__(256) void reduce_partials64_kernel(const double* __restrict__ part, int nparts, int len,
-                                                                double* __restrict__ out, int accumulate, double scale) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= len) return;
+// out[i] = (acc ? out[i] : 0) + scale * sum_r partials[r*len + i], rows in fixed order.  A workgroup owns 64 columns; its
+// 16 row groups each add up every 16th row in four independent chains, the 16 group sums are added in index order (the
+// layout of ndq_api.hip's column_sum_1024).  An fp64 adjoint launch leaves up to 1 024 partial rows: with one thread per
+// column walking all of them this sum took 15 us of a 130 us epoch, and the loss sum (len = 1) was a single thread.
+__global__ __launch_bounds__(1024) void reduce_partials64_kernel(const double* __restrict__ part, int nparts, int len,
+                                                                 double* __restrict__ out, int accumulate, double scale) {
+  __shared__ double sm[16 * 64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
   double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
-  int r = 0;
-  for (; r + 3 < nparts; r += 4) {
-    s0 += part[(size_t)r * len + i];
-    s1 += part[(size_t)(r + 1) * len + i];
-    s2 += part[(size_t)(r + 2) * len + i];
-    s3 += part[(size_t)(r + 3) * len + i];
+  if (i < len) {
+    int r = rg;
+    for (; r + 48 < nparts; r += 64) {
+      s0 += part[(size_t)r * len + i];
+      s1 += part[(size_t)(r + 16) * len + i];
+      s2 += part[(size_t)(r + 32) * len + i];
+      s3 += part[(size_t)(r + 48) * len + i];
+    }
+    for (; r < nparts; r += 16) s0 += part[(size_t)r * len + i];
   }
-  for (; r < nparts; ++r) s0 += part[(size_t)r * len + i];
-  const double s = ((s0 + s1) + (s2 + s3)) * scale;
-  out[i] = accumulate ? out[i] + s : s;
+  sm[rg * 64 + c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && i < len) {
+    double s = 0.;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += sm[k * 64 + c];
+    s *= scale;
+    out[i] = accumulate ? out[i] + s : s;
+  }
 }
 
 // torch.optim.Adam (amsgrad=False, maximize=False), the fp32 kernel of ndq_api.hip in double
@@ -75,6 +88,41 @@ __global__ __launch_bounds__(256) void adam64_kernel(double* __restrict__ p, con
   m[i] = mi;
   v[i] = vi;
   p[i] = pi - (lr / bc1) * (mi / (sqrt(vi) / bc2s + eps));
+}
+
+// Device-side end of an fp64 epoch, the double twin of ndq_api.hip's epoch_tail_kernel: mean of the per-batch losses ->
+// history ring, best-loss ping-pong + snapshot of the parameters the epoch was evaluated on, Adam (the arithmetic of
+// adam64_kernel, operation for operation: an epoch through this kernel and one through ndq64_adam_step agree bit for bit).
+struct Tail64Args {
+  double* p; const double* g; double* m; double* v; int len;
+  double lr, b1, b2, eps, wd, bc1, bc2s;
+  const double* loss_slots; int nb; double* loss_hist; int hist_index; double* best_loss; int parity; double* best_flat;
+  int write_scalars;
+};
+__global__ __launch_bounds__(256) void epoch_tail64_kernel(Tail64Args a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double loss = 0.;
+  for (int k = 0; k < a.nb; ++k) loss += a.loss_slots[k];
+  loss /= (double)a.nb;
+  const double best = a.best_loss[a.parity];
+  const bool better = (a.best_flat != nullptr) && (loss < best);   // false for NaN, like the reference's comparison
+  if (i < a.len) {
+    const double pi = a.p[i];
+    if (better) a.best_flat[i] = pi;
+    if (a.m != nullptr) {             // validation epochs pass no optimiser state: bookkeeping only
+      double gi = a.g[i];
+      if (a.wd != 0.0) gi = fma(a.wd, pi, gi);
+      const double mi = fma(a.b1, a.m[i], (1.0 - a.b1) * gi);
+      const double vi = fma(a.b2, a.v[i], (1.0 - a.b2) * gi * gi);
+      a.m[i] = mi;
+      a.v[i] = vi;
+      a.p[i] = pi - (a.lr / a.bc1) * (mi / (sqrt(vi) / a.bc2s + a.eps));
+    }
+  }
+  if (i == 0 && a.write_scalars) {
+    a.loss_hist[a.hist_index] = loss;
+    a.best_loss[a.parity ^ 1] = better ? loss : best;
+  }
 }
 
 }  // namespace ndq
@@ -129,7 +177,7 @@ int ndq64_mlp_jet_bwd(const ndq_mlp_desc* desc, const double* coords, int ldc, i
 int ndq64_reduce_partials(const double* partials, int nparts, int len, double* out, int accumulate, double scale,
                           void* stream) {
   if (!partials || !out || nparts <= 0 || len <= 0) return NDQ_EINVAL;
-  hipLaunchKernelGGL(reduce_partials64_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(reduce_partials64_kernel, dim3((len + 63) / 64), dim3(1024), 0, static_cast<hipStream_t>(stream),
                      partials, nparts, len, out, accumulate, scale);
   return (int)hipGetLastError();
 }
@@ -140,6 +188,25 @@ int ndq64_adam_step(double* params, const double* grad, double* exp_avg, double*
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2s = sqrt(1.0 - pow(beta2, (double)step));
   hipLaunchKernelGGL(adam64_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), params, grad,
                      exp_avg, exp_avg_sq, len, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+  return (int)hipGetLastError();
+}
+
+int ndq64_epoch_tail(double* params, const double* grad, double* exp_avg, double* exp_avg_sq, int len, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, int step, const double* loss_slots,
+                     int n_batches, double* loss_hist, int hist_index, double* best_loss, int parity, double* best_flat,
+                     int write_scalars, void* stream) {
+  const bool adam = exp_avg != nullptr;
+  if (!params || len <= 0 || !loss_slots || n_batches <= 0 || !loss_hist || !best_loss || hist_index < 0 ||
+      (parity != 0 && parity != 1) || (adam && (!grad || !exp_avg_sq || step <= 0)))
+    return NDQ_EINVAL;
+  Tail64Args a{};
+  a.p = params; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.len = len;
+  a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
+  a.bc1 = adam ? 1.0 - pow(beta1, (double)step) : 1.0;
+  a.bc2s = adam ? sqrt(1.0 - pow(beta2, (double)step)) : 1.0;
+  a.loss_slots = loss_slots; a.nb = n_batches; a.loss_hist = loss_hist; a.hist_index = hist_index;
+  a.best_loss = best_loss; a.parity = parity; a.best_flat = best_flat; a.write_scalars = write_scalars;
+  hipLaunchKernelGGL(epoch_tail64_kernel, dim3((len + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return (int)hipGetLastError();
 }
 

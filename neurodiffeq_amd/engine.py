@@ -885,7 +885,7 @@ class FusedSystem:
     def fast_state(self):
         """Device-side epoch bookkeeping of the native fast path: loss ring, best-loss ping-pong, best snapshot."""
         if getattr(self, "_fast", None) is None:
-            dev, f32 = self.device, torch.float32
+            dev, f32 = self.device, self.dt        # (fp64 systems keep their bookkeeping in double: ndq64_epoch_tail)
             self._fast = dict(loss_hist=torch.zeros(self.HIST, dtype=f32, device=dev),
                               valid_hist=torch.zeros(self.HIST, dtype=f32, device=dev),
                               best_loss=torch.full((2,), float("inf"), dtype=f32, device=dev),

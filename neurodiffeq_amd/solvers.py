@@ -599,8 +599,10 @@ class BaseSolver(ABC):
         through ONE native call (engine.fast_train_epoch: closure kernel + fused sums/tail kernel); every other fused
         system runs its per-batch launch sequence and then the device-side epoch tail (loss history ring, best
         snapshot, fused Adam per network).  Returns False if the general (host-synchronising) path must run."""
-        if not self._native_ok() or system.f64 or system.n_theta:
+        if not self._native_ok() or system.n_theta:
             return False        # (trainable equation coefficients are stepped by the user's optimiser: general path)
+        # (fp64 systems -- the reference's default precision -- have no closure kernel and no multi-epoch call: they run
+        # their three-kernel sequence per batch and then the device-side epoch tail in double, ndq64_epoch_tail)
         train = key == "train"
         nb = self.n_batches[key]
         track_best = (not train) or self.n_batches["valid"] == 0

@@ -1113,6 +1113,42 @@ def test_native_epoch_path_bookkeeping_matches_general_path():
 
 
 @pytest.mark.parametrize("name", ["c2", "c1"])
+def test_fp64_epochs_stay_on_the_device_and_match_the_general_path(name):
+    """fp64 networks (the reference's default precision, neurodiffeq/__init__.py:22): the three-kernel pipeline in double
+    followed by the device-side epoch tail in double (ndq64_epoch_tail) -- no host synchronisation per epoch -- against the
+    general path (host-side history, FusedAdam.step through ndq64_adam_step) on the same seeds.  Same kernels, same Adam
+    arithmetic: histories, best snapshot, parameters and step counts agree to rounding of the loss mean."""
+    from tests import configs
+
+    def run(native):
+        torch.manual_seed(0)
+        solver, cfg = configs.make_solver(name, SIZES[name], n_batches_train=2, n_batches_valid=2,
+                                          metrics=None if native else {"zero": lambda *a: (a[0] * 0).mean()})
+        for net in cfg["nets"]:
+            net.double()
+        solver.fused = "require"
+        torch.manual_seed(5)
+        solver.run_train_epoch()
+        solver.run_valid_epoch()
+        solver.fit(3, tqdm_file=None)
+        assert solver.fused_active and solver._fused_sys.f64
+        h = solver.metrics_history
+        return (solver, list(h["train_loss"]), list(h["valid_loss"]), solver.lowest_loss,
+                R.get_flat(solver.best_nets).cpu().numpy(), R.get_flat(cfg["nets"]).cpu().numpy())
+
+    s1, t1, v1, l1, b1, p1 = run(True)
+    s2, t2, v2, l2, b2, p2 = run(False)
+    assert getattr(s1._fused_sys, "_fast", None) is not None and getattr(s2._fused_sys, "_fast", None) is None
+    assert s1._fused_sys._fast["loss_hist"].dtype == torch.float64
+    assert len(t1) == len(v1) == 4 and s1.global_epoch == 4
+    assert np.allclose(t1, t2, rtol=1e-13, atol=0) and np.allclose(v1, v2, rtol=1e-13, atol=0)
+    assert abs(l1 - min(v1)) <= 1e-15 * abs(l1) and abs(l1 - l2) <= 1e-13 * abs(l2)
+    assert b1.dtype == np.float64 and rel_l2(b1, b2) < 1e-13 and rel_l2(p1, p2) < 1e-13
+    steps = {int(st["step"]) for st in s1.optimizer.state_dict()["state"].values()}
+    assert steps == {4}
+
+
+@pytest.mark.parametrize("name", ["c2", "c1"])
 def test_native_fit_with_validation_matches_general_path(name):
     """fit() with validation epochs (best network chosen by the validation loss, solvers.py:414-415) on the zero-sync
     path -- single-launch (c2) and multi-network pipeline (c1) -- against the general host-synchronising path."""
