@@ -383,7 +383,7 @@ def config_record(name, size=None):
 
 def fp64_record():
     """C2 at its stated size in the reference's DEFAULT precision (neurodiffeq/__init__.py:22: float64): fp64 networks on
-    the fused three-kernel pipeline (fp64 stream kernels of libndq64.so + the traced pointwise kernel compiled in double,
+    the fused path in double (the closure kernel compiled for fp64 on the f64 MFMA, fixed-order fp64 sums,
     device-side epoch tail in double), batch resident in HBM, through run_train_epoch()."""
     from tests import configs
     torch.manual_seed(0)

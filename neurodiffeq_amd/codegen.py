@@ -481,13 +481,20 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         """length of the per-point ``r`` array: residuals (+ the loss term of a traced custom loss)"""
         return max(len(self.residuals) + (1 if self.loss == "custom" else 0), 1)
 
-    def fused_source(self, desc):
+    def fused_source(self, desc, f64=False):
         """Source of the single-launch closure kernel (csrc/ndq_mlp.h: fused_closure_kernel for one network,
         fused_multi_closure_kernel for 2..4 networks of one shape and stream set) specialised with this program's
-        per-point function.  desc: the ndq_mlp_desc shared by all networks."""
+        per-point function.  desc: the ndq_mlp_desc shared by all networks.
+        f64: the same module in double (csrc/ndq_mlp.h under NDQ_F64: per-point GEMMs on the f64 MFMA, no bf16 planes, no
+        pull / loop mode) -- one network, plain closure only (``can_fuse_f64``)."""
+        if f64:
+            return "#define NDQ_F64 1\n" + source_f64(self._fused_source(desc, True))
+        return self._fused_source(desc, False)
+
+    def _fused_source(self, desc, f64):
         K = self.n_nets
         mode = fuse_mode(self, {k: desc for k in range(K)})
-        assert mode is not None
+        assert mode is not None and not (f64 and (mode != "tile" or K != 1))
         if mode in ("group", "wide"):
             return self._group_source(desc, wide=(mode == "wide"))
         ns = self.streams[0].n_streams
@@ -522,7 +529,9 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
             args_t = "ndq::FusedMultiArgs"
             fill = f"for (int k = 0; k < {K}; ++k) {{ a.params[k] = params[k]; a.partials[k] = partials ? partials[k] : nullptr; }}"
             kern_tv = f"ndq::fused_multi_closure_tv_kernel<CFG, {K}, PW>"
-        if K == 1:
+        if f64:
+            kern_loop = lds_loop = None          # (loop / pull mode: fp32 only, csrc/ndq_tail.h)
+        elif K == 1:
             kern_loop, lds_loop = "ndq::fused_closure_loop_kernel<CFG, PW>", "ndq::fused_loop_lds_bytes<CFG>()"
         elif K == 2:
             kern_loop, lds_loop = f"ndq::fused_multi_closure_loop_kernel<CFG, {K}, PW>", f"(ndq::fused_multi_loop_lds_bytes<CFG, {K}>())"
@@ -978,10 +987,10 @@ def load(program: PointwiseProgram, f64=False):
 
 # ----------------------------------------------------------------------------------------------- fused closure kernel
 class FusedKernel:
-    def __init__(self, so_path):
+    def __init__(self, so_path, f64=False):
         self.path = so_path
         self.lib = ctypes.CDLL(so_path)
-        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, (ctypes.c_double if f64 else ctypes.c_float)
         self.lib.ndq_fused_launch.restype = ci
         self.lib.ndq_fused_launch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, ci, cf, ci, vp]
         self.lib.ndq_fused_launch_multi.restype = ci
@@ -1191,12 +1200,18 @@ def mlp_ext_module(desc, f64=False):
     return _MLP_EXT.get(desc.key() + (("f64",) if f64 else ()))
 
 
-def build_fused(program: PointwiseProgram, desc, force=False, threads=None):
+def can_fuse_f64(program, descs):
+    """fp64 systems: the single-launch closure exists for ONE network on the plain closure kernel (no grouped / wide /
+    multi-network variant in double)."""
+    return program.n_nets == 1 and can_fuse(program, descs) and fuse_mode(program, descs) == "tile" and descs[0].hidden <= 64
+
+
+def build_fused(program: PointwiseProgram, desc, force=False, threads=None, f64=False):
     """Compile the fused closure kernel of a single-network system for gfx950 (in-tree cache keyed by the generated
     source AND the kernel header it instantiates).  ``threads=512``: the 8-wave build (two waves per SIMD where the
     per-wave state fits 256 registers; csrc/ndq_mlp.h NDQ_BWD_THREADS) the engine uses for large batches."""
     os.makedirs(JIT_DIR, exist_ok=True)
-    source = program.fused_source(desc)
+    source = program.fused_source(desc, f64=f64)
     flags = _extra_flags() + ([f"-DNDQ_BWD_THREADS={int(threads)}"] if threads else []) + (WIDE_FLAGS if is_wide(desc) else [])
     key = _cache_key(source + (f"|threads={int(threads)}" if threads else ""))
     so = os.path.join(JIT_DIR, f"fused_{key}.so")

@@ -274,16 +274,15 @@ class FusedSystem:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.NdqError("the fused path needs an MI355X (device 'cuda'); no CPU fallback exists for it")
-        # dtype float64 (the reference's default precision, neurodiffeq/__init__.py:22): the three-kernel pipeline on the
-        # fp64 build of the stream kernels (libndq64.so) with the generated pointwise kernel compiled in double; the
-        # single-launch closure kernels, the native epoch and the device-side Adam are fp32 only
+        # dtype float64 (the reference's default precision, neurodiffeq/__init__.py:22): the fp64 build of the stream kernels
+        # (libndq64.so) with the generated pointwise kernel compiled in double; single-network systems on the plain closure
+        # kernel get that kernel compiled in double as well (codegen.can_fuse_f64); the epoch tail runs on the device
+        # (ndq64_epoch_tail); pull / loop mode, the multi-epoch fit() call and the 8-wave build are fp32 only
         from . import _canary
         _canary.check()              # once per process: the gfx950 hazard reproducer through / without the assembly fix-up pass
         self.dt = dtype
         self.f64 = dtype == torch.float64
         self.esize = 8 if self.f64 else 4
-        if self.f64:
-            single_kernel = False
         self.L = _Lib64() if self.f64 else _lib.lib()
         self.nets, self.conditions, self.n_coords = list(nets), list(conditions), n_coords
         self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val, loss,
@@ -306,19 +305,22 @@ class FusedSystem:
         # first use of a system: its pointwise kernel and its single-launch closure kernel are compiled CONCURRENTLY (two
         # hipcc pipelines side by side; cached in-tree afterwards)
         from . import _hipcc
-        want_fused = single_kernel and not self.f64 and codegen.can_fuse(self.program, self.descs)
+        # (fp64: one network on the plain closure kernel compiled in double; NDQ_F64_CLOSURE=0: three-kernel pipeline only)
+        want_fused = single_kernel and (codegen.can_fuse_f64(self.program, self.descs) and os.environ.get("NDQ_F64_CLOSURE", "1") != "0"
+                                        if self.f64 else codegen.can_fuse(self.program, self.descs))
         with _hipcc.deferred():
             pw_so = codegen.build(self.program, f64=self.f64)
-            fused_so = codegen.build_fused(self.program, self.descs[0]) if want_fused else None
+            fused_so = codegen.build_fused(self.program, self.descs[0], f64=self.f64) if want_fused else None
         self.kernel = codegen.PointwiseKernel(pw_so, self.f64)
         self.fusedk = None
         # the 8-wave build of the closure kernel (two waves per SIMD), built on first use for batches of at least
         # WIDE_MIN_POINTS points: None = not tried yet, False = not available / rejected
-        self.fusedk_wide = None if (os.environ.get("NDQ_FUSED_WIDE", "1") != "0" and not _canary.STATUS["refuse_two_waves"]) else False
+        self.fusedk_wide = None if (os.environ.get("NDQ_FUSED_WIDE", "1") != "0" and not _canary.STATUS["refuse_two_waves"]
+                                    and not self.f64) else False
         self._self_check = os.environ.get("NDQ_SELF_CHECK", "1") != "0"
         self._verified = set()                       # id() of the closure-kernel variants that passed verify_fused
         if fused_so is not None:
-            fk = codegen.FusedKernel(fused_so)
+            fk = codegen.FusedKernel(fused_so, self.f64)
             if fk.lib.ndq_fused_lds_bytes() <= 160 * 1024:       # K weight images + staging must fit one workgroup's LDS
                 self.fusedk = fk
         self.flat = [FlatParams(n, self.device, dtype) for n in self.nets]
@@ -746,7 +748,7 @@ class FusedSystem:
         for _ in range(2):
             self.fused_closure(b, n, stream, True, n_global, 0, False)
             runs.append(grads())
-        tv_same = self._tv_matches_plain(b, n, n_global, stream) if (self.FIT_RUN and not self.n_theta) else True
+        tv_same = self._tv_matches_plain(b, n, n_global, stream) if (self.FIT_RUN and not self.n_theta and not self.f64) else True
         pipe = []
         for _ in range(2):
             self.forward(b, n, stream)
@@ -877,6 +879,8 @@ class FusedSystem:
 
     def launches_per_step(self):
         """Kernel launches of one native training epoch with one batch (bench.py reports it per config)."""
+        if self.fusedk is not None and self.f64:
+            return 4                                     # closure kernel, gradient sum, loss sum, epoch tail (in double)
         if self.fusedk is not None:
             return 2                                     # closure kernel + ONE sums/tail kernel (all networks)
         # pipeline: forward per site, pointwise, (adjoint + sums) per site, loss sum, epoch tail per network

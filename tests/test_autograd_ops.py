@@ -279,7 +279,7 @@ def test_solver_in_the_reference_default_precision_trains_on_the_f64_kernels():
                     solver.run_train_epoch()
                 assert solver.fused_active == (mode == "fused")
                 if mode == "fused":
-                    assert solver._fused_sys.f64 and solver._fused_sys.fusedk is None
+                    assert solver._fused_sys.f64 and solver._fused_sys.fusedk is not None     # the closure kernel in double
                 if mode == "seam":
                     ex = [c.detach().to("cuda").requires_grad_(True) for c in solver._generate_batch("train")]
                     assert "MlpJet" in type(cfg["nets"][0](torch.cat(ex, 1)).grad_fn).__name__

@@ -314,7 +314,8 @@ def test_ensemble_condition_as_one_solver_function_trains_on_the_fused_path():
 @pytest.mark.parametrize("name", ["c1", "c2", "c3x", "pendulum", "helmholtz_xy", "stokes_like", "sigmoid_mixed", "kdv",
                                   "resnet_laplace", "swish_tr_laplace", "aptx_tr_resnet", "shape_20x3", "mono_ode", "ensemble_lv",
                                   "shape_48x2", "shape_64x2"])
-def test_fp64_pipeline_matches_autograd_oracle(name):
+@pytest.mark.parametrize("mode", ["3k", "1k"])
+def test_fp64_pipeline_matches_autograd_oracle(name, mode):
     """engine.FusedSystem(dtype=float64): forward streams (libndq64.so, f64 MFMA) -> the generated pointwise kernel
     compiled in double -> adjoint kernel -> fp64 sums, against the fp64 autograd oracle at 1e-9 (C1, C2, a 32-wide C3 and
     zoo systems: first order only, full Hessian, three networks, sigmoid, third-order streams, Laplacian-merged stream, skip
@@ -355,9 +356,13 @@ def test_fp64_pipeline_matches_autograd_oracle(name):
     want_grad = R.get_flat_grad(onets).numpy()
     for net in nets:
         net.to("cuda")
-    fs = FusedSystem(nets, conds, pde, n_coords, "cuda", dtype=torch.float64)
-    assert fs.f64 and fs.fusedk is None
+    # "1k": the single-launch closure kernel compiled in double (one network on the plain closure kernel); "3k": pipeline
+    fs = FusedSystem(nets, conds, pde, n_coords, "cuda", dtype=torch.float64, single_kernel=(mode == "1k"))
+    assert fs.f64 and (mode == "1k" or fs.fusedk is None)
+    if mode == "1k" and fs.fusedk is None:
+        pytest.skip("no fp64 closure kernel for this system (several networks / grouped kernel / LDS)")
     b, n = fs.step(coords, train=True, slot=0, want_funcs=True, want_resid=True)
+    assert mode == "3k" or (fs.fusedk is not None and fs.fused_check["reproducible"] and fs.fused_check["grad_rel_l2"] < 1e-12)
     torch.cuda.synchronize()
     assert b["funcs"].dtype == torch.float64 and fs.flat[0].grad.dtype == torch.float64
     errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), want["funcs"].numpy()),
@@ -449,7 +454,8 @@ def test_network_family_solver_trajectory_matches_reference_golden(golden_dir, n
 
 @pytest.mark.parametrize("name", ["c1", "c2", "c4", "w1", "w2", "w3", "w4", "w5", "w6", "w7", "w8", "w9", "w10", "w11", "w12", "w13",
                                   "w14", "w15"])
-def test_fp64_pipeline_matches_reference_golden(golden_dir, name):
+@pytest.mark.parametrize("mode", ["3k", "1k"])
+def test_fp64_pipeline_matches_reference_golden(golden_dir, name, mode):
     """The fp64 pipeline against numbers the unmodified reference produced IN ITS DEFAULT PRECISION: every golden file
     holds the closure evaluated in fp64 on fp32-representable inputs (``funcs_f64`` ... ``grad_f64``).  1e-9 -- three
     orders below what fp32 arithmetic anywhere in the pipeline would leave.  (C3 / C5: 64 x 3 layers do not fit LDS in double.)"""
@@ -462,7 +468,10 @@ def test_fp64_pipeline_matches_reference_golden(golden_dir, name):
         net.double().to("cuda")
     R.set_flat(cfg["nets"], torch.from_numpy(gold["params0"]).double())
     fs = FusedSystem(cfg["nets"], cfg["conds"], configs.fused_equations(cfg), configs.n_coords(cfg), "cuda",
-                     compute_func_val=configs.func_val(cfg), dtype=torch.float64)
+                     compute_func_val=configs.func_val(cfg), dtype=torch.float64, single_kernel=(mode == "1k"))
+    if mode == "1k" and fs.fusedk is None:
+        pytest.skip("no fp64 closure kernel for this system (several networks / grouped kernel / LDS)")
+    assert (fs.fusedk is not None) == (mode == "1k")
     b, n = fs.step([torch.from_numpy(c).double() for c in gold["coords"]], train=True, slot=0, want_funcs=True, want_resid=True)
     torch.cuda.synchronize()
     errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), gold["funcs_f64"]),
