@@ -61,6 +61,31 @@ class library_code:
     def __exit__(self, *exc):
         if self.ctx is not None:
             self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+    def user_code(self):
+        """``with lc.user_code():`` inside the block, around a call into user code (a generator's ``get_examples``): the
+        global modes are back in force for its duration."""
+        return _UserCode(self)
+
+
+class _UserCode:
+    __slots__ = ("lc", "was")
+
+    def __init__(self, lc):
+        self.lc = lc
+
+    def __enter__(self):
+        self.was = self.lc.ctx is not None
+        if self.was:
+            self.lc.ctx.__exit__(None, None, None)
+            self.lc.ctx = None
+
+    def __exit__(self, *exc):
+        if self.was:
+            self.lc.ctx = torch._C.DisableTorchFunction()
+            self.lc.ctx.__enter__()
         return False
 
 

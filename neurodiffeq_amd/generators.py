@@ -9,6 +9,7 @@ HBM as one SoA block.  Two additions without a reference counterpart keep the pr
 distributions drawn by a Philox kernel on the MI355X, a fresh batch per epoch with no PCIe hand-off)."""
 import ctypes
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -680,7 +681,8 @@ _DEVICE_SOURCES = {}
 
 def device_source(batch):
     """The DeviceGenerator that handed out ``batch`` (its own list of views), or None."""
-    g = _DEVICE_SOURCES.get(id(batch))
+    ref = _DEVICE_SOURCES.get(id(batch))
+    g = ref() if ref is not None else None
     return g if (g is not None and any(v is batch for v in g._views_all)) else None
 
 
@@ -726,8 +728,11 @@ class DeviceGenerator(BaseGenerator):
         self.block, self._views = self.blocks[0], self._views_all[0]
         self.prefetched = None       # draw number already sitting in its block, drawn ahead by a tail kernel
         self.launches = 0            # sampler kernels this generator launched itself (diagnostics / tests)
+        # (weak: the registry must not keep a generator -- two device blocks -- alive after its solver is gone; the entries go
+        # with it, before the ids of its view lists can be reused)
         for views in self._views_all:
-            _DEVICE_SOURCES[id(views)] = self
+            _DEVICE_SOURCES[id(views)] = weakref.ref(self)
+            weakref.finalize(self, _DEVICE_SOURCES.pop, id(views), None)
 
     @staticmethod
     def describe(g):

@@ -180,7 +180,7 @@ class BaseSolver(ABC):
         self._fast_tracks_best = False
         self.dist = None                # optional neurodiffeq_amd.parallel.BatchSharding
         # the solver's own bookkeeping attributes: not equation state when diff_eqs is a bound method (_pystate.StateWatch)
-        self._own_attrs = (frozenset(self.__dict__) - attrs_of_the_subclass) | {"_own_attrs", "_best_nets_from_device", "_dtype_probe", "_eq_watch_warned",
+        self._own_attrs = (frozenset(self.__dict__) - attrs_of_the_subclass) | {"_own_attrs", "_best_nets_from_device", "_dtype_probe", "_eq_watch_warned", "_lc",
                                                        "_eval_key", "_eval_sys", "_host_metrics", "_resid_key", "_resid_sys"}
 
     # ------------------------------------------------------------------------------------------ loss function
@@ -521,7 +521,8 @@ class BaseSolver(ABC):
             # the largest shard decides which closure-kernel build serves the batch: the same on every rank
             system.select_n = n_all if self.dist.presharded else -(-n_all // self.dist.world_size)
         nb = self.n_batches[key]
-        with library_code():               # (no user code below: see engine.library_code)
+        with library_code() as lc:         # (user code below -- further batches -- runs inside lc.user_code())
+            self._lc = lc
             done = self._run_epoch_native(key, system, first_batch)
         if done:
             return
@@ -601,8 +602,9 @@ class BaseSolver(ABC):
         snapshot, fused Adam per network).  Returns False if the general (host-synchronising) path must run."""
         if not self._native_ok() or system.n_theta:
             return False        # (trainable equation coefficients are stepped by the user's optimiser: general path)
-        # (fp64 systems -- the reference's default precision -- have no closure kernel and no multi-epoch call: they run
-        # their three-kernel sequence per batch and then the device-side epoch tail in double, ndq64_epoch_tail)
+        # (fp64 systems -- the reference's default precision -- have no multi-epoch call: they run their per-batch launch
+        # sequence (closure kernel in double, or the three-kernel pipeline) and then the device-side epoch tail in double,
+        # ndq64_epoch_tail)
         train = key == "train"
         nb = self.n_batches[key]
         track_best = (not train) or self.n_batches["valid"] == 0
@@ -648,7 +650,10 @@ class BaseSolver(ABC):
         else:
             if system.loss_buf.numel() < nb:
                 system.loss_buf = torch.zeros(nb, dtype=system.dt, device=self.device)
-            batches = [first_batch] + [self._generate_batch(key) for _ in range(nb - 1)]
+            batches = [first_batch]
+            if nb > 1:
+                with self._lc.user_code():           # the generators are user code: torch's global modes apply to them
+                    batches += [self._generate_batch(key) for _ in range(nb - 1)]
             if not train and nb > 1:
                 # a static validation set served nb times (the default: 4 x the same 'equally-spaced' grid) gives nb
                 # identical losses under unchanged parameters: evaluate it once, the mean is that value
