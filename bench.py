@@ -407,6 +407,35 @@ def fp64_record():
                 final_loss=solver.metrics_history["train_loss"][-1])
 
 
+def reference_defaults_record():
+    """What importing the reference sets up -- cuda default device AND float64 default dtype (neurodiffeq/__init__.py:22,
+    utils.py:10-41) -- then a plain Solver2D with its noisy 256 x 256 generator, nothing else changed: a fresh batch every
+    epoch from the Philox kernel (fp32 draws handed out as doubles), the closure kernel in double, bookkeeping on the device."""
+    from tests import configs
+    from neurodiffeq_amd.utils import set_tensor_type
+    try:
+        set_tensor_type(device="cuda", float_bits=64)
+        torch.manual_seed(0)
+        solver, cfg = configs.make_solver("c2")
+        solver.fused = "require"
+        assert next(cfg["nets"][0].parameters()).dtype == torch.float64
+        for _ in range(20):
+            solver.run_train_epoch()
+        torch.cuda.synchronize()
+        k = 20
+        times = timed_windows(solver.run_train_epoch, k, torch.cuda.synchronize)
+        dt = times[(len(times) - 1) // 2] / k
+        n = cfg["n_points"]
+        assert solver.fused_active and solver._fused_sys.f64
+        return dict(points=n, dtype="f64", ms_per_step=dt * 1e3, points_per_s=n / dt, windows=len(times), steps_per_window=k,
+                    generator=type(solver.generator["train"].generator).__name__,
+                    note="set_tensor_type('cuda', 64) as `import neurodiffeq` does, plain Solver2D + Generator2D: sampling, "
+                         "closure in double, Adam and history all on the device",
+                    final_loss=solver.metrics_history["train_loss"][-1])
+    finally:
+        set_tensor_type(device="cpu", float_bits=32)
+
+
 def pointwise_large():
     """The standalone generated pointwise residual kernel (HBM-bound: reads coordinates + network streams, writes the
     adjoint streams) at sizes where HBM speed, not launch latency, decides: C2's at 1 M and 4 M points, C5's at 1 M."""
@@ -739,6 +768,7 @@ def main():
                                              kernels="csrc/ndq_wide.h" if name in ("w16", "w17") else "csrc/ndq_deep.h")
             out["roofline_pointwise_large"] = pointwise_large()
             out["c2_fp64"] = fp64_record()
+            out["c2_reference_defaults_cuda_float64"] = reference_defaults_record()
         if world == 1 and not args.no_cold_start and (args.cold_start or not args.no_configs):
             try:
                 out["cold_start"] = cold_start()

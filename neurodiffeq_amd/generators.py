@@ -704,9 +704,13 @@ class DeviceGenerator(BaseGenerator):
     streams cost more than the 4 us kernel they hide -- 41 us per step instead of 33 -- and it was dropped.)
     """
 
-    def __init__(self, generator, device=None, seed=None, stream_id=None, prefetch=False):
+    def __init__(self, generator, device=None, seed=None, stream_id=None, prefetch=False, dtype=torch.float32):
+        """dtype: torch.float32, or torch.float64 for fp64 solvers (the reference's default precision): the kernel draws fp32
+        points, the handed-out tensors are their exact images in double (one device-side copy per draw)."""
         super().__init__()
         from . import _lib
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError(f"dtype must be torch.float32 or torch.float64, got {dtype}")
         if not torch.cuda.is_available():
             raise _lib.NdqError("DeviceGenerator samples with a gfx950 kernel and needs an MI355X; use the wrapped "
                                 "generator itself for host sampling")
@@ -724,7 +728,10 @@ class DeviceGenerator(BaseGenerator):
         # the tensors handed out for an epoch keep that epoch's points until the END of the following epoch.
         self.prefetch = bool(prefetch)
         self.blocks = [torch.zeros(self.desc.d, ld, dtype=torch.float32, device=self.device) for _ in range(2 if self.prefetch else 1)]
-        self._views_all = [[blk[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)] for blk in self.blocks]
+        self.dtype = dtype
+        # fp64: the tensors handed out are views of double blocks the fp32 draws are copied into
+        self._out_blocks = self.blocks if dtype == torch.float32 else [torch.zeros_like(b, dtype=dtype) for b in self.blocks]
+        self._views_all = [[blk[i, :self.size].reshape(-1, 1) for i in range(self.desc.d)] for blk in self._out_blocks]
         self.block, self._views = self.blocks[0], self._views_all[0]
         self.prefetched = None       # draw number already sitting in its block, drawn ahead by a tail kernel
         self.launches = 0            # sampler kernels this generator launched itself (diagnostics / tests)
@@ -784,7 +791,10 @@ class DeviceGenerator(BaseGenerator):
                 from . import _lib
                 raise _lib.NdqError(f"ndq_sample failed with code {rc}")
             self.launches += 1
-        views = self._views_all[self.draw & 1] if self.prefetch else self._views_all[0]
+        slot = (self.draw & 1) if self.prefetch else 0
+        if self.dtype != torch.float32:
+            self._out_blocks[slot].copy_(block)          # (stream-ordered behind the draw)
+        views = self._views_all[slot]
         self.block, self._views = block, views
         self.draw += 1
         return views
@@ -826,13 +836,15 @@ def on_default_device(gen):
         return gen
     if mode == "auto" and torch.get_default_device().type != "cuda":
         return gen
-    if torch.get_default_dtype() != torch.float32:
-        return gen                 # the Philox kernel draws fp32 points; an fp64 default (the reference's) samples on the host in fp64
+    dtype = torch.get_default_dtype()
+    if dtype not in (torch.float32, torch.float64):
+        return gen
     if not (type(gen) is GeneratorSpherical or gen.method == "uniform" or gen.method == "equally-spaced-noisy"):
         return gen                 # static grids are uploaded once and read in place; other laws: host
     try:
         # prefetch: on the single-launch native path the next batch is drawn by spare workgroups of the epoch's own sums /
         # tail launch (no sampler launch); the handed-out tensors keep an epoch's points until the end of the next epoch
-        return DeviceGenerator(gen, seed=torch.cuda.initial_seed(), stream_id=0, prefetch=True)
+        # (an fp64 default dtype -- the reference's import default is cuda + float64 -- gets the fp32 draws as doubles)
+        return DeviceGenerator(gen, seed=torch.cuda.initial_seed(), stream_id=0, prefetch=True, dtype=dtype)
     except ValueError:
         return gen

@@ -71,6 +71,56 @@ def test_solver_under_a_cuda_default_device_samples_on_the_device(cuda_default):
         set_default_sampling("auto")
 
 
+def test_the_reference_import_default_cuda_float64_samples_on_the_device_in_double():
+    """``set_tensor_type(device='cuda', float_bits=64)`` is what importing the reference does (``__init__.py:22``): the noisy
+    grid is drawn by the Philox kernel (fp32 points) and handed out as their exact images in double; the solver trains on the
+    fp64 kernels with the epoch's bookkeeping on the device.  The same points fed back explicitly give the same losses."""
+    from neurodiffeq_amd.generators import DeviceGenerator, Generator2D
+    from neurodiffeq_amd.utils import set_tensor_type
+    try:
+        set_tensor_type(device="cuda", float_bits=64)
+        torch.manual_seed(0)
+        solver = _laplace()
+        solver.fused = "require"
+        gen = solver.generator["train"].generator
+        assert isinstance(gen, DeviceGenerator) and gen.dtype == torch.float64
+        batches = []
+        for _ in range(4):
+            solver.run_train_epoch()
+            batches.append([c.detach().clone() for c in solver._batch["train"]])
+        assert solver.fused_active and solver._fused_sys.f64 and getattr(solver._fused_sys, "_fast", None) is not None
+        assert all(c.dtype == torch.float64 and c.device.type == "cuda" for b in batches for c in b)
+        # exact images of fp32 draws, batch after batch what a generator with its own launches draws
+        ref = DeviceGenerator(Generator2D((32, 32), (0, 0), (1, 1), method="equally-spaced-noisy"), seed=gen.seed, stream_id=0)
+        for b in batches:
+            want = ref.get_examples()
+            assert all(torch.equal(a, w.double()) for a, w in zip(b, want))
+        assert not torch.equal(batches[0][0], batches[1][0])
+        losses = np.array(solver.metrics_history["train_loss"])
+        # the same four batches replayed by a plain generator: same system, same kernels -> the same losses
+        assert len(batches[0][0]) == 1024
+        from neurodiffeq_amd.generators import BaseGenerator
+        torch.manual_seed(0)
+
+        class Replay(BaseGenerator):
+            def __init__(self):
+                super().__init__()
+                self.size, self.k = 1024, 0
+
+            def get_examples(self):
+                b = batches[self.k]
+                self.k += 1
+                return b
+        again = _laplace(train_generator=Replay())
+        again.fused = "require"
+        for _ in range(4):
+            again.run_train_epoch()
+        assert np.allclose(losses, np.array(again.metrics_history["train_loss"]), rtol=1e-12, atol=0)
+        assert losses[-1] < losses[0]
+    finally:
+        set_tensor_type(device="cpu", float_bits=32)
+
+
 def test_cpu_default_device_keeps_the_reference_cpu_numbers():
     """Nothing changes without a cuda default device: host draws, the reference's CPU stream bit for bit (golden-tested
     elsewhere); here: the generator is not wrapped."""
