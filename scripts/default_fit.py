@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Wall time of solver.fit() in the reference's default configuration (README-style script: default networks, default
 generators -- 32 noisy points for training (32 x 32 in 2-D), 4 static validation batches per epoch).
-usage: scripts/default_fit.py [epochs]
+usage: scripts/default_fit.py [epochs] [--f64]
 
 Per problem: 'fit' = fit(n) as a user calls it (whole chunks of epochs per native call), 'per_epoch' = the same epochs
 with a no-op callback (one training + one validation epoch per call: the round-2 behaviour of the host loop), 'off' =
@@ -20,6 +20,9 @@ from neurodiffeq_amd.conditions import IVP, DirichletBVP2D  # noqa: E402
 from neurodiffeq_amd.solvers import Solver1D, Solver2D  # noqa: E402
 
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+if "--f64" in sys.argv:       # the reference's import defaults as well: cuda default device AND float64 (neurodiffeq/__init__.py:22)
+    from neurodiffeq_amd.utils import set_tensor_type
+    set_tensor_type(device="cuda", float_bits=64)
 zero = lambda v: 0 * v
 PROBLEMS = {
     "ode": lambda: Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], t_min=0.0, t_max=2.0),
