@@ -4,9 +4,10 @@ Difference from the reference, on purpose: importing :mod:`neurodiffeq_amd` does
 dtype to fp64 / device to cuda (reference ``__init__.py:22``) -- a script that only changes its import line therefore
 trains in fp32 unless it calls ``set_tensor_type(float_bits=64)`` itself (INTEGRATION.md leads with this).  fp32
 systems run on the single-launch closure kernels and the native epochs; fp64 networks -- the reference's default
-precision -- run the fused three-kernel pipeline in double (fp64 stream kernels of libndq64.so, the traced pointwise
-kernel compiled in double, Adam in double), or, for shapes whose weights do not fit LDS in double, the
-reference's closure on torch autograd with the network forward / backward on the fp64 stream kernels."""
+precision -- run fused in double as well (single-network systems on the closure kernel compiled for fp64, the others on the
+three-kernel pipeline: fp64 stream kernels of libndq64.so around the traced pointwise kernel compiled in double; epoch
+bookkeeping and Adam on the device), or, for shapes whose weights do not fit LDS in double, the reference's
+closure on torch autograd with the network forward / backward on the fp64 stream kernels."""
 import random
 import re
 
