@@ -757,7 +757,7 @@ def main():
             torch.cuda.empty_cache()
             out["configs"] = {name: config_record(name) for name in ("c1", "c3", "c4", "c5")}
             # networks wider than 64 units on C2's grid: the reference's README network first (csrc/ndq_wide.h: no GEMM at
-            # all, VALU-bound; csrc/ndq_deep.h: layer by layer, exact-fp32 MFMAs)
+            # all, VALU-bound; csrc/ndq_deep.h: layer by layer through HBM, per-point GEMMs as bf16x3 on the bf16 matrix core)
             for label, (name, size) in WIDE_RECORDS.items():
                 out["configs"][label] = dict(config_record(name, size), golden=name,
                                              kernels="csrc/ndq_wide.h" if name in ("w16", "w17") else "csrc/ndq_deep.h")

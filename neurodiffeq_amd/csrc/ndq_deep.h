@@ -10,19 +10,22 @@
 //   Z_l [NS][NP][HP] fp32, point-major rows of HP = ceil16(W) units -- a lane's 4 consecutive units of one point are ONE
 //   16-byte load / store, which is exactly the C/D fragment of the 16x16x4 MFMA (units = rows, points = columns).
 //
-//   forward   deep_fwd_gemm   Z_l = W_l sigma-jet(Z_{l-1}) + b_l      (l = 2: sigma-jet of the first layer, from the coordinates)
-//             deep_head_fwd   u_s = Wout sigma-jet(Z_L)_s + bout -> output streams
-//   reverse   deep_head_bwd   seeds -> Zbar_L, dWout, db_L, dbout     (one unit per thread, seeds are wave-uniform)
-//             deep_wgrad_gemm dW_l = sum_{s, n} Zbar_l^T sigma-jet(Z_{l-1})   (split over points, partials summed in fixed order)
-//             deep_bwd_gemm   Hbar_{l-1} = W_l^T Zbar_l, act-backward in the epilogue -> Zbar_{l-1}, db_{l-1}
-//                             (l = 2: the first layer's dW1 / db1 instead of a store)
+//   forward   deep_gemm_bf<SRC 0 | 1, EPI 0>   Z_l = W_l sigma-jet(Z_{l-1}) + b_l   (l = 2: sigma-jet of the first layer, from the
+//                                               coordinates)
+//             deep_head_fwd                     u_s = Wout sigma-jet(Z_L)_s + bout -> output streams
+//   reverse   deep_head_bwd                     seeds -> Zbar_L, dWout, db_L, dbout   (one unit per thread, seeds are wave-uniform)
+//             deep_wgrad_gemm                   dW_l = sum_{s, n} Zbar_l^T sigma-jet(Z_{l-1})   (split over points, partial tiles)
+//             deep_gemm_bf<SRC 2, EPI 1 | 2>    Hbar_{l-1} = W_l^T Zbar_l, act-backward in the epilogue -> Zbar_{l-1}, db_{l-1}
+//                                               (l = 2: the first layer's dW1 / db1 instead of a store)
+//             deep_reduce_all                   every second-stage sum of the sweep in ONE launch (job table, fixed order)
 //
-// All three GEMMs run on v_mfma_f32_16x16x4_f32 -- EXACT fp32 products, no operand splitting, and both operands of every
-// product load straight from the point-major layout (the weight-gradient GEMM contracts over points: its A and B operands
-// are "one value per lane" of 4 consecutive points, no transposes).  That pipe peaks at 157 TFLOP/s on MI355X; the bf16x3
-// route of csrc/ndq_mlp.h (417 TFLOP/s effective) is the next step for these kernels, not taken yet -- at W = 128 the
-// layer round trips through HBM cost as much as the arithmetic.
-// Reductions are fixed-order everywhere (per-wave partial rows -> deep_reduce2d), results are bit-reproducible.
+// The two per-point GEMMs run on the bf16 matrix core as bf16x3 products (v_mfma_f32_16x16x32_bf16, six significant plane
+// products, fp32-class accuracy: csrc/ndq_mlp.h), the layer's weight planes resident in LDS for the whole launch; at W = 128
+// they are bound by the HBM round trips of Z, from W = 256 on by the MFMAs.  The weight-gradient GEMM contracts over POINTS and
+// stays on v_mfma_f32_16x16x4_f32 (exact fp32; both operands are "one value per lane" of 4 consecutive points straight from
+// the point-major layout, no transposes).  deep_fwd_gemm / deep_bwd_gemm are the exact-f32 versions of the per-point GEMMs,
+// kept behind -DNDQ_DEEP_BF16X3=0 as the A/B baseline.
+// Reductions are fixed-order everywhere (per-wave partial rows / partial tiles -> deep_reduce_all): bit-reproducible results.
 // Reference restated: networks.py:59-70 (forward), neurodiffeq.py:21-34 (diff sweeps), solvers.py:393 (backward).
 #pragma once
 #include "ndq_mlp.h"
