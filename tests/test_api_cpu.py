@@ -367,3 +367,28 @@ def test_describe_recognises_the_network_family():
     assert fp.numel == sum(p.numel() for p in net.parameters()) and fp.flat.numel() == fp.numel + 2
     assert fp.flat[-2:].tolist() == [1.7000000476837158, 1.7000000476837158]
     assert all(p.data_ptr() == fp.flat.data_ptr() + 4 * off for p, off in zip(fp.params, fp._offsets))
+
+
+def test_library_code_suspends_global_torch_modes_and_user_code_restores_them():
+    """engine.library_code: package host code runs without torch's global TorchFunctionMode (a default device installs one:
+    ~1 us per tensor method call); user callables inside such a block -- further batches of a multi-batch epoch -- run with
+    the modes back in force (``user_code``), i.e. with the default device the user set."""
+    import torch
+    from neurodiffeq_amd.engine import library_code
+    assert torch.empty(1).device.type == "cpu"
+    with library_code() as lc:                       # nothing installed: a no-op
+        assert lc.ctx is None
+        with lc.user_code():
+            assert torch.empty(1).device.type == "cpu"
+    torch.set_default_device("meta")
+    try:
+        assert torch.empty(1).device.type == "meta"
+        with library_code() as lc:
+            assert torch.empty(1).device.type == "cpu"        # the global mode is off for package code
+            with lc.user_code():
+                assert torch.empty(1).device.type == "meta"   # ... and back for the user's generator
+            assert torch.empty(1).device.type == "cpu"
+        assert torch.empty(1).device.type == "meta"
+    finally:
+        torch.set_default_device(None)
+    assert torch.empty(1).device.type == "cpu"
