@@ -646,3 +646,32 @@ def test_equation_probe_sees_python_state_changed_between_epochs():
     assert StateWatch([eqs, cond]).entries and not program.eq_probe()
     # a stateless lambda has (almost) nothing to watch
     assert len(StateWatch([lambda u, t: [diff(u, t) + u]])) <= 2
+
+
+def test_fp64_closure_source_is_the_fp32_module_rewritten_for_double():
+    """codegen.can_fuse_f64 / fused_source(f64=True): single-network systems on the plain closure kernel get the SAME generated
+    module under NDQ_F64 -- types, math calls and literal suffixes rewritten, no loop / pull launcher (fp32 only) --, other
+    systems keep the fp64 three-kernel pipeline."""
+    import re
+    from neurodiffeq_amd import codegen, engine
+    from tests import configs
+
+    def traced(name):
+        torch.manual_seed(0)
+        cfg = configs.make(name, None)
+        for net in cfg["nets"]:
+            net.double()
+        return engine.trace_system(cfg["nets"], cfg["conds"], configs.fused_equations(cfg), configs.n_coords(cfg),
+                                   compute_func_val=configs.func_val(cfg), f64=True)
+    program, descs = traced("c2")
+    assert codegen.can_fuse_f64(program, descs)
+    src = program.fused_source(descs[0], f64=True)
+    assert src.startswith("#define NDQ_F64 1\n")
+    assert not re.search(r"\bfloat\b", src) and "double" in src
+    assert not re.search(r"\d\.\d+f\b", src) and "expf(" not in src and "tanhf(" not in src
+    assert "fused_closure_loop_kernel" not in src and "ndq_fused_launch_tv" in src
+    assert src != program.fused_source(descs[0])                      # (and the fp32 module is untouched by the flag)
+    assert "#define NDQ_F64" not in program.fused_source(descs[0])
+    for name in ("c1", "c4"):                                         # two networks / the grouped closure: pipeline in double
+        program, descs = traced(name)
+        assert not codegen.can_fuse_f64(program, descs)
