@@ -4,20 +4,31 @@ The reference re-evaluates the user's ``diff_eqs`` and the conditions every batc
 held in a dict, a Reynolds number ramped by a callback or a boundary value stored on a condition object take effect at the
 next epoch.  The fused path executes those callables ONCE, on symbolic columns: every Python float they read becomes a
 literal of the generated kernel.  ``StateWatch`` records, at trace time, the leaves of Python state the callables can
-reach -- closure cells, the module globals their code names, default arguments, attributes of bound ``self`` objects and
-of the condition objects (and the plain class attributes behind them), up to six container levels deep -- as (where, expected stamp) entries and compiles them into
-ONE checker function (a chain of ``and``-ed comparisons, ~0.05 us per entry: the native epoch is host-bound at the headline
-size, a microsecond here is 4 % of the step).  ``dirty()`` runs it: nothing for the usual stateless lambda.  A dirty watch
-is not yet a changed equation; the solver then re-traces (``program.eq_probe``: the graph is hash-consed, so an unchanged
-system returns the same node ids) and only a different trace makes it rebuild the kernels (the build cache is keyed by
-generated source).
+reach -- closure cells, the module globals their code names, attributes of the user modules they name, default arguments,
+attributes (``__dict__`` and ``__slots__``) of bound ``self`` objects and of the condition objects, the plain class
+attributes and the methods behind them, dicts / lists / tuples / deques / sets, small ndarrays by content and larger ones
+by CRC -- as (where, expected stamp) entries and compiles them into ONE checker function (a chain of ``and``-ed
+comparisons, ~0.05 us per entry: the native epoch is host-bound at the headline size, a microsecond here is 4 % of the
+step).  ``dirty()`` runs it: nothing for the usual stateless lambda.  A dirty watch is not yet a changed equation; the
+solver then re-traces (``program.eq_probe``: the graph is hash-consed, so an unchanged system returns the same node ids)
+and only a different trace makes it rebuild the kernels (the build cache is keyed by generated source).
 
-The walk is a heuristic with bounded depth: state it cannot see (a value fetched through another module's function, a
-container nested deeper than ``max_depth``) is covered by the solver's periodic unconditional re-trace.
+**Fail-closed.**  The walk is a bounded heuristic, so it keeps a second answer next to ``dirty()``: ``complete``.  Whenever
+it meets something it cannot stamp -- an object with neither ``__dict__`` nor ``__slots__``, an unknown container or
+iterator, a dict / list beyond ``max_items``, nesting beyond ``max_depth``, an ndarray too large to hash every epoch, a
+callable of a compiled non-library module, code that names a source of values outside Python state (``time``, ``random``,
+``os.environ`` ...), or code that names the solver's own bookkeeping (``local_epoch``, ``global_epoch``,
+``metrics_history``, ``lowest_loss`` ...) while a solver object is reachable -- the reason is appended to ``incomplete``.
+The solver treats an incomplete watch as "re-trace every time Python ran between two epochs" (one ``eq_probe`` per epoch,
+93 - 685 us on the BASELINE systems) and keeps such a system off the multi-epoch native call; a complete watch keeps the
+fast path.  Never a silently stale equation.
 """
+import collections
 import functools
 import numbers
+import sys
 import types
+import zlib
 
 import torch
 
@@ -25,11 +36,29 @@ _LEAF_TYPES = (numbers.Number, str, bytes, type(None))
 _LIBRARY_ROOTS = ("neurodiffeq_amd", "torch", "numpy", "math", "functools", "operator", "scipy")
 _MISSING = object()
 _OPAQUE = (torch.Tensor, torch.nn.Module, torch.optim.Optimizer, types.ModuleType, type)
+_STDLIB = frozenset(getattr(sys, "stdlib_module_names", ())) | {"builtins"}
+#: modules whose functions return values that are not Python state (a clock, an RNG, the environment): code naming one of
+#: them can change what it computes with nothing for a watch to see
+_VOLATILE_MODULES = frozenset({"time", "random", "os", "datetime", "secrets", "uuid", "socket", "subprocess", "threading"})
+#: attribute / function names of the same kind reached through a library module (``np.random.rand``, ``torch.rand`` ...)
+_VOLATILE_NAMES = frozenset({"random", "rand", "randn", "randint", "normal", "uniform", "rand_like", "randn_like", "time",
+                             "perf_counter", "monotonic", "environ", "getenv", "now", "today"})
+#: the solver's own bookkeeping (solvers.py:36-140 of the reference: counters and histories the fit loop advances by itself,
+#: with no user code running): equations that read one of these through a reachable solver follow the epoch
+SOLVER_BOOKKEEPING = frozenset({"local_epoch", "global_epoch", "_max_local_epoch", "metrics_history", "_history", "lowest_loss",
+                                "_lowest_loss", "best_nets", "_best_nets", "_stop_training", "_phase", "_batch", "n_batches"})
+#: names that read a tensor's VALUE into Python (a trainable scalar read this way is a literal of the kernel, not an argument)
+_VALUE_READS = frozenset({"item", "tolist", "numpy", "float", "int", "bool"})
+_CRC_BYTES = 64 << 10        # ndarrays up to this size are stamped by CRC-32 every epoch (~30 us at the limit); larger: incomplete
+
+
+def _root(module_name):
+    return (module_name or "").split(".")[0]
 
 
 def _user_class(k):
     """A class whose plain attributes can be equation state: not a builtin, not library code, not a torch module."""
-    return (isinstance(k, type) and (getattr(k, "__module__", "") or "").split(".")[0] not in _LIBRARY_ROOTS + ("builtins", "abc", "typing", "collections", "types")
+    return (isinstance(k, type) and _root(getattr(k, "__module__", "")) not in _LIBRARY_ROOTS + ("builtins", "abc", "typing", "collections", "types")
             and not issubclass(k, (torch.nn.Module, torch.optim.Optimizer, BaseException)))
 
 
@@ -37,16 +66,40 @@ def _is_leaf(v):
     return isinstance(v, _LEAF_TYPES) and not isinstance(v, torch.Tensor)
 
 
+def _crc(a):
+    import numpy as np
+    return zlib.crc32(np.ascontiguousarray(a).view(np.uint8).reshape(-1)) if a.dtype != object else None
+
+
 class StateWatch:
     def __init__(self, roots, max_depth=6, max_items=64):
         self.entries = []          # (expression template over O[...] / M, kind, payload)
         self.objs = []             # objects the expressions index: they stay alive, an id() can never come back as another object
+        self.incomplete = []       # reasons the walk could not stamp everything the callables can read (fail-closed, module docstring)
         self._index = {}
         self._seen = set()
+        self._names = set()        # every name the walked code objects mention
+        self._solver_seen = False
+        self._trainable = []       # (expression, tensor) of requires_grad leaves: stamped by identity (their values are kernel arguments)
         self.max_depth, self.max_items = max_depth, max_items
         for r in roots:
             self._visit(r, 0)
+        if self._solver_seen and self._names & SOLVER_BOOKKEEPING:
+            self._fail("the equations name solver bookkeeping (" + ", ".join(sorted(self._names & SOLVER_BOOKKEEPING)) +
+                       ") with a solver object in reach")
+        for expr, t in self._trainable:
+            if self._names & _VALUE_READS:
+                # a trainable scalar the code may read by VALUE (.item(), float(...)): every optimiser step changes it
+                self.entries.append(f"{expr}._version == {t._version}")
         self._check = self._compile()
+
+    @property
+    def complete(self):
+        return not self.incomplete
+
+    def _fail(self, why):
+        if why not in self.incomplete and len(self.incomplete) < 8:
+            self.incomplete.append(why)
 
     # ------------------------------------------------------------------ building
     def _ref(self, obj):
@@ -65,15 +118,25 @@ class StateWatch:
                 self.entries.append(f"((v := {expr}) == {self._ref(value)} and type(v) is {self._ref(type(value))})")
             return
         if isinstance(value, torch.Tensor):
-            self.entries.append(f"((v := {expr}) is {self._ref(value)} and v._version == {value._version})")
+            if value.requires_grad and value.is_leaf:
+                # nn.Parameter coefficients (inverse problems): kernel ARGUMENTS, bumped by every optimiser step -- pinned by
+                # identity only, or every epoch would re-trace for nothing
+                self.entries.append(f"({expr}) is {self._ref(value)}")
+                self._trainable.append((self._ref(value), value))
+            else:
+                self.entries.append(f"((v := {expr}) is {self._ref(value)} and v._version == {value._version})")
             return
         try:
             import numpy as np
             if isinstance(value, np.ndarray):
-                if value.size <= 64:
+                if value.size <= 64 and value.dtype != object:
                     self.entries.append(f"((v := {expr}) is {self._ref(value)} and v.tobytes() == {self._ref(value.tobytes())})")
+                elif value.nbytes <= _CRC_BYTES and value.dtype != object:
+                    self.entries.append(f"((v := {expr}) is {self._ref(value)} and v.shape == {self._ref(value.shape)} "
+                                        f"and CRC(v) == {_crc(value)})")
                 else:
                     self.entries.append(f"({expr}) is {self._ref(value)}")
+                    self._fail(f"an ndarray of {value.nbytes} bytes (dtype {value.dtype}) is too large to compare every epoch")
                 return
         except Exception:  # pragma: no cover
             pass
@@ -85,14 +148,17 @@ class StateWatch:
             self._seen.add(id(v))
             self._class(v, self._ref(v), depth)         # `class Cfg: nu = 0.1` used as a namespace
             return
-        if depth > self.max_depth or id(v) in self._seen or _is_leaf(v) or isinstance(v, _OPAQUE):
+        if id(v) in self._seen or _is_leaf(v) or isinstance(v, _OPAQUE):
             return                 # (tensors are stamped where they are referenced; modules are not state)
+        if depth > self.max_depth:
+            self._fail(f"state nested deeper than {self.max_depth} levels")
+            return
         self._seen.add(id(v))
         if isinstance(v, types.MethodType):
             self._visit(v.__func__, depth)
             self._object(v.__self__, depth)
         elif isinstance(v, types.FunctionType):
-            if (getattr(v, "__module__", "") or "").split(".")[0] not in _LIBRARY_ROOTS:      # library code is not user state
+            if _root(getattr(v, "__module__", "")) not in _LIBRARY_ROOTS:      # library code is not user state
                 self._function(v, depth)
         elif isinstance(v, functools.partial):
             self._visit(v.func, depth)
@@ -101,17 +167,20 @@ class StateWatch:
         elif isinstance(v, dict):
             r = self._ref(v)
             self.entries.append(f"len({r}) == {len(v)}")
+            if len(v) > self.max_items:
+                self._fail(f"a dict of {len(v)} entries (more than {self.max_items})")
             for i, k in enumerate(list(v)):
                 if i >= self.max_items:
                     break
-                if _is_leaf(k):
-                    self._add(f"{r}.get({self._ref(k)}, M)", v[k], depth)
-        elif isinstance(v, list):
+                self._add(f"{r}.get({self._ref(k)}, M)", v[k], depth)       # (any hashable key: looked up through the kept object)
+        elif isinstance(v, (list, collections.deque)):
             r = self._ref(v)
             self.entries.append(f"len({r}) == {len(v)}")
             if len(v) <= self.max_items:
                 for i in range(len(v)):
                     self._add(f"{r}[{i}]", v[i], depth)
+            else:
+                self._fail(f"a {type(v).__name__} of {len(v)} items (more than {self.max_items})")
         elif isinstance(v, tuple):
             # immutable: its leaves cannot change (the reference to the tuple is pinned by identity where it was read);
             # mutable members are state
@@ -119,8 +188,26 @@ class StateWatch:
                 for i in range(len(v)):
                     if not _is_leaf(v[i]) and not isinstance(v[i], _OPAQUE):
                         self._visit(v[i], depth + 1)
-        elif callable(v) and not hasattr(v, "__dict__"):
-            return                 # builtins
+            elif not all(_is_leaf(x) for x in v):
+                self._fail(f"a tuple of {len(v)} items (more than {self.max_items})")
+        elif isinstance(v, (set, frozenset)):
+            if all(_is_leaf(x) for x in v) and len(v) <= 16 * self.max_items:
+                if isinstance(v, set):
+                    self.entries.append(f"{self._ref(v)} == {self._ref(frozenset(v))}")
+            else:
+                self._fail("a set with non-scalar members")
+        elif isinstance(v, (types.GeneratorType, types.CoroutineType, types.AsyncGeneratorType)) or \
+                (hasattr(v, "__next__") and not hasattr(v, "__dict__")):
+            self._fail(f"an iterator ({type(v).__name__}): what it yields next cannot be compared")
+        elif callable(v) and not hasattr(v, "__dict__") and not hasattr(type(v), "__slots__"):
+            # builtins and compiled callables: library / standard-library ones are not user state; a compiled extension
+            # function of any other module computes from state this walk cannot read
+            mod = _root(getattr(v, "__module__", None) or getattr(getattr(v, "__self__", None), "__module__", None)
+                        or type(v).__module__ or "builtins")
+            if mod in _VOLATILE_MODULES:
+                self._fail(f"a function of module '{mod}' (values that are not Python state)")
+            elif mod not in _LIBRARY_ROOTS and mod not in _STDLIB:
+                self._fail(f"a compiled callable of module '{mod}'")
         else:
             self._object(v, depth)
 
@@ -136,38 +223,83 @@ class StateWatch:
             co = codes.pop()
             names.update(co.co_names)
             codes.extend(c for c in co.co_consts if isinstance(c, types.CodeType))
+        self._names |= names
         g = fn.__globals__
         for name in sorted(names):
-            if name in g and not isinstance(g[name], (types.ModuleType, types.BuiltinFunctionType)):
-                value = g[name]
-                if isinstance(value, type) and not _user_class(value):
-                    continue
-                if isinstance(value, types.FunctionType) and (getattr(value, "__module__", "") or "").split(".")[0] in _LIBRARY_ROOTS:
-                    continue       # `diff`, `torch.sin` ...: library functions are not user state
-                self._add(f"{self._ref(g)}.get({name!r}, M)", value, depth)
+            if name not in g:
+                continue
+            value = g[name]
+            if isinstance(value, types.ModuleType):
+                self._module(value, names, depth)
+                continue
+            if isinstance(value, types.BuiltinFunctionType):
+                self._visit(value, depth)
+                continue
+            if isinstance(value, type) and not _user_class(value):
+                continue
+            if isinstance(value, types.FunctionType) and _root(getattr(value, "__module__", "")) in _LIBRARY_ROOTS:
+                continue       # `diff`, `torch.sin` ...: library functions are not user state
+            self._add(f"{self._ref(g)}.get({name!r}, M)", value, depth)
         if fn.__defaults__:
             self._add(f"{self._ref(fn)}.__defaults__", fn.__defaults__, depth)
         if fn.__kwdefaults__:
             self._add(f"{self._ref(fn)}.__kwdefaults__", fn.__kwdefaults__, depth)
 
+    def _module(self, mod, names, depth):
+        """``import cfg`` ... ``cfg.nu * u``: the attributes of a USER module that the code names are state (the attribute
+        names sit in ``co_names`` next to the module's own); library and standard-library modules are code, except the
+        ones that hand out values from outside Python state."""
+        root = _root(getattr(mod, "__name__", ""))
+        if root in _VOLATILE_MODULES:
+            self._fail(f"the equations name module '{root}' (values that are not Python state)")
+            return
+        if root in _LIBRARY_ROOTS or root in _STDLIB:
+            hot = names & _VOLATILE_NAMES
+            if hot:
+                self._fail(f"the equations name {sorted(hot)} of module '{root}' (values that are not Python state)")
+            return
+        ns, r = vars(mod), self._ref(mod)
+        for name in sorted(names):
+            if name in ns and not name.startswith("__"):
+                value = ns[name]
+                if isinstance(value, types.ModuleType):
+                    if id(value) not in self._seen:
+                        self._seen.add(id(value))
+                        self._module(value, names, depth)
+                    continue
+                self._add(f"getattr({r}, {name!r}, M)", value, depth)
+
     def _object(self, obj, depth):
         if isinstance(obj, _OPAQUE) or _is_leaf(obj):
             return
         d = getattr(obj, "__dict__", None)
-        if not isinstance(d, dict):
+        slots = []
+        for k in type(obj).__mro__:
+            ks = vars(k).get("__slots__", ())
+            slots += [s for s in ((ks,) if isinstance(ks, str) else tuple(ks)) if s not in ("__dict__", "__weakref__")]
+        if not isinstance(d, dict) and not slots:
+            self._fail(f"an object of type {type(obj).__module__}.{type(obj).__qualname__} with neither __dict__ nor __slots__")
             return
         self._seen.add(id(obj))
         own = getattr(obj, "_own_attrs", ())     # a solver's own bookkeeping (epoch counters, histories ...) is not equation state
+        if own:
+            self._solver_seen = True             # ... unless the code NAMES it: checked once the walk is over (module docstring)
         r = self._ref(obj)
+        d = d if isinstance(d, dict) else {}
+        if len(d) > 4 * self.max_items:
+            self._fail(f"an object with {len(d)} attributes")
         for i, name in enumerate(list(d)):
             if i >= 4 * self.max_items:
                 break
             if name in own or name == "_own_attrs" or not name.isidentifier():
                 continue
             self._add(f"getattr({r}, {name!r}, M)", d[name], depth)
+        for name in slots:
+            if name.isidentifier() and name not in d:
+                self._add(f"getattr({r}, {name!r}, M)", getattr(obj, name, _MISSING), depth)
         # plain values defined on the class and read through the instance (`class Eq: nu = 0.1`): watched THROUGH the
         # instance, so that an instance attribute set later, shadowing the class value, is seen as well
-        self._class(type(obj), r, depth, skip=set(d) | set(own))
+        self._class(type(obj), r, depth, skip=set(d) | set(own) | set(slots))
 
     def _class(self, cls, via, depth, skip=()):
         n = 0
@@ -175,9 +307,18 @@ class StateWatch:
             if not _user_class(k):
                 continue
             for name, value in list(vars(k).items()):
-                if name.startswith("__") or name in skip or not name.isidentifier() or n >= self.max_items:
+                # methods (and what property / staticmethod / classmethod wrap): code the equations may run -- their closure
+                # cells and the globals they name are state like the entry function's
+                fn = value.fget if isinstance(value, property) else getattr(value, "__func__", value) if isinstance(value, (staticmethod, classmethod)) else value
+                if isinstance(fn, types.FunctionType):
+                    self._visit(fn, depth)
                     continue
-                if _is_leaf(value) or isinstance(value, (dict, list, tuple, torch.Tensor)) or type(value).__module__ == "numpy":
+                if name.startswith("__") or name in skip or not name.isidentifier():
+                    continue
+                if _is_leaf(value) or isinstance(value, (dict, list, tuple, set, collections.deque, torch.Tensor)) or type(value).__module__ == "numpy":
+                    if n >= self.max_items:
+                        self._fail(f"class {k.__qualname__} has more than {self.max_items} plain attributes")
+                        break
                     n += 1
                     skip = set(skip) | {name}
                     self._add(f"getattr({via}, {name!r}, M)", value, depth)
@@ -185,7 +326,7 @@ class StateWatch:
     def _compile(self):
         if not self.entries:
             return None
-        src = "def _check(O, M):\n    return (" + "\n            and ".join(self.entries) + ")\n"
+        src = "def _check(O, M, CRC):\n    return (" + "\n            and ".join(self.entries) + ")\n"
         ns = {}
         exec(compile(src, "<neurodiffeq_amd._pystate>", "exec"), ns)     # noqa: S102 -- source built from indices into self.objs only
         return ns["_check"]
@@ -195,7 +336,7 @@ class StateWatch:
         if self._check is None:
             return False
         try:
-            return not self._check(self.objs, _MISSING)
+            return not self._check(self.objs, _MISSING, _crc)
         except Exception:   # noqa: BLE001 -- state that can no longer be read has changed
             return True
 

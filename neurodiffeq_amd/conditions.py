@@ -11,6 +11,7 @@ import warnings
 
 import torch
 
+from ._version_utils import deprecated_alias
 from .neurodiffeq import safe_diff as diff
 from .symbolic import Sym, SymMat, TraceUnsupported, current_graph
 
@@ -97,16 +98,9 @@ class EnsembleCondition(BaseCondition):
 class IVP(BaseCondition):
     """u(t0) = u0, optionally u'(t0) = u0'  (conditions.py:225-267)."""
 
-    def __init__(self, t_0, u_0=None, u_0_prime=None, **deprecated):
+    @deprecated_alias(x_0="u_0", x_0_prime="u_0_prime")      # (conditions.py:242; both spellings at once: KeyError)
+    def __init__(self, t_0, u_0=None, u_0_prime=None):
         super().__init__()
-        if "x_0" in deprecated:
-            warnings.warn("`x_0` is deprecated; use `u_0`", FutureWarning)
-            u_0 = deprecated.pop("x_0")
-        if "x_0_prime" in deprecated:
-            warnings.warn("`x_0_prime` is deprecated; use `u_0_prime`", FutureWarning)
-            u_0_prime = deprecated.pop("x_0_prime")
-        if deprecated:
-            raise TypeError(f"unexpected arguments {list(deprecated)}")
         self.t_0, self.u_0, self.u_0_prime = t_0, u_0, u_0_prime
 
     def parameterize(self, output_tensor, t):
@@ -137,25 +131,11 @@ class _BundleConditionMixin:
         return getattr(self, override_name or param_name)
 
 
-def _bundle_kwargs(kw, names):
-    """deprecated keyword aliases of the bundle conditions (conditions.py:293, 365)"""
-    out = {}
-    for old, new_name in names.items():
-        if old in kw:
-            warnings.warn(f"`{old}` is deprecated; use `{new_name}`", FutureWarning)
-            out[new_name] = kw.pop(old)
-    if kw:
-        raise TypeError(f"unexpected arguments {list(kw)}")
-    return out
-
-
 class BundleIVP(BaseCondition, _BundleConditionMixin):
     """IVP whose t_0 / u_0 / u_0' may be bundle inputs (conditions.py:270-345)."""
 
-    def __init__(self, t_0=None, u_0=None, u_0_prime=None, bundle_param_lookup=None, **deprecated):
-        alias = _bundle_kwargs(deprecated, {"x_0": "u_0", "x_0_prime": "u_0_prime", "bundle_conditions": "bundle_param_lookup"})
-        u_0, u_0_prime = alias.get("u_0", u_0), alias.get("u_0_prime", u_0_prime)
-        bundle_param_lookup = alias.get("bundle_param_lookup", bundle_param_lookup)
+    @deprecated_alias(x_0="u_0", x_0_prime="u_0_prime", bundle_conditions="bundle_param_lookup")     # (conditions.py:295)
+    def __init__(self, t_0=None, u_0=None, u_0_prime=None, bundle_param_lookup=None):
         BaseCondition.__init__(self)
         _BundleConditionMixin.__init__(self, bundle_param_lookup, allowed_params=["t_0", "u_0", "u_0_prime"])
         self.t_0, self.u_0, self.u_0_prime = t_0, u_0, u_0_prime
@@ -173,9 +153,8 @@ class BundleIVP(BaseCondition, _BundleConditionMixin):
 class BundleDirichletBVP(BaseCondition, _BundleConditionMixin):
     """Two-point Dirichlet condition whose ends / end values may be bundle inputs (conditions.py:348-395)."""
 
-    def __init__(self, t_0, u_0, t_1, u_1, bundle_param_lookup=None, **deprecated):
-        alias = _bundle_kwargs(deprecated, {"bundle_conditions": "bundle_param_lookup"})
-        bundle_param_lookup = alias.get("bundle_param_lookup", bundle_param_lookup)
+    @deprecated_alias(bundle_conditions="bundle_param_lookup")                                        # (conditions.py:363)
+    def __init__(self, t_0, u_0, t_1, u_1, bundle_param_lookup=None):
         BaseCondition.__init__(self)
         _BundleConditionMixin.__init__(self, bundle_param_lookup, allowed_params=["t_0", "u_0", "t_1", "u_1"])
         self.t_0, self.u_0, self.t_1, self.u_1 = t_0, u_0, t_1, u_1
@@ -190,6 +169,7 @@ class BundleDirichletBVP(BaseCondition, _BundleConditionMixin):
 class DirichletBVP(BaseCondition):
     """u(t0) = u0, u(t1) = u1  (conditions.py:398-435)."""
 
+    @deprecated_alias(x_0="u_0", x_1="u_1")                                                          # (conditions.py:412)
     def __init__(self, t_0, u_0, t_1, u_1):
         super().__init__()
         self.t_0, self.u_0, self.t_1, self.u_1 = t_0, u_0, t_1, u_1

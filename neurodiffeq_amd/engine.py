@@ -145,6 +145,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             node and with it other residual nodes.  True: what the kernels were compiled from is still what the user's
             callables compute."""
             n_captured = len(g.captured)
+            twins_before = set(getattr(g, "twins", ()))
             try:
                 with trace_scope(g):
                     f2 = [cfv(n, c, *coords) for n, c in zip(all_nets, conditions)]
@@ -161,10 +162,18 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
                     else:
                         return False
                 return tuple(cols) + ("|",) + tuple(r.i for r in r2) == eq_nodes
-            except Exception:       # noqa: BLE001 -- whatever the callables do now, it is not what was compiled
+            except Exception as e:       # noqa: BLE001 -- whatever the callables do now, it is not what was compiled
+                if not getattr(eq_probe, "warned", False):
+                    eq_probe.warned = True       # said once: an unexpected kernel rebuild can be traced back to this
+                    import warnings
+                    warnings.warn(f"neurodiffeq_amd: re-tracing the equations raised {type(e).__name__}: {e}; the system is "
+                                  "rebuilt from a fresh trace.  (On the fused path diff_eqs / the conditions run on symbolic "
+                                  "columns, once per re-trace: they should be free of side effects.)", RuntimeWarning)
                 return False
             finally:
                 del g.captured[n_captured:]       # (the probe's own captures are the same tensors again)
+                for key in [k for k in getattr(g, "twins", ()) if k not in twins_before]:
+                    del g.twins[key]              # (twins of the tensors this probe created: they would pile up)
 
         # a custom loss: callable(residual (N, n_eq), funcs, coords) -> scalar (solvers.py:216-226; the solver passes
         # loss_fn + additional_loss as ONE callable) traced to the per-point term whose batch mean it is

@@ -19,7 +19,8 @@ def _cos(x):
 
 
 def _ones(x):
-    return Sym(x.g, x.g.const(1.0)) if isinstance(x, Sym) else torch.ones_like(x)
+    # (function_basis.py:18-19: P_0 of a column that requires grad is itself attached -- callers differentiate it)
+    return Sym(x.g, x.g.const(1.0)) if isinstance(x, Sym) else torch.ones_like(x, requires_grad=x.requires_grad)
 
 
 def _cat(cols):

@@ -811,7 +811,7 @@ class DeviceGenerator(BaseGenerator):
 # device argument); its import default is cuda where one exists (neurodiffeq/__init__.py:22), and there the noise comes from
 # the GPU's Philox stream -- itself not the CPU generator's numbers.  Same rule here: a solver built while torch's default
 # device is cuda draws the NOISE of Generator1D / 2D / 3D / Spherical on the MI355X (DeviceGenerator: Philox4x32-10, seeded
-# from torch.cuda.initial_seed(), so torch.manual_seed still fixes the run; every rank draws the SAME batch and takes its
+# from torch's cuda generator (one draw per wrapped generator), so torch.manual_seed still fixes the run; every rank draws the SAME batch and takes its
 # shard); with a CPU default device nothing changes: host draws, bit for bit the reference's CPU numbers.  Index sampling
 # (randperm / randint: ResampleGenerator, BatchGenerator, latin-hypercube, the spherical signs of the host path) and every
 # wrapper generator stay on the CPU generator bit for bit in both cases.  ``Generator2D(..., bit_exact_cpu=True)`` or
@@ -825,6 +825,11 @@ def set_default_sampling(mode):
     if mode not in ("auto", "cpu", "device"):
         raise ValueError(f"mode must be 'auto', 'cpu' or 'device', got {mode!r}")
     _SAMPLING["mode"] = mode
+
+
+def _seed_from_torch_cuda_rng():
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64, device=dev).item())
 
 
 def on_default_device(gen):
@@ -846,6 +851,11 @@ def on_default_device(gen):
         # prefetch: on the single-launch native path the next batch is drawn by spare workgroups of the epoch's own sums /
         # tail launch (no sampler launch); the handed-out tensors keep an epoch's points until the end of the next epoch
         # (an fp64 default dtype -- the reference's import default is cuda + float64 -- gets the fp32 draws as doubles)
-        return DeviceGenerator(gen, seed=torch.cuda.initial_seed(), stream_id=0, prefetch=True, dtype=dtype)
+        # the Philox key is (seed, draw number, stream id): every wrapped generator needs a seed of its OWN, or two generators
+        # of one law -- the default train / valid pair of SolverSpherical, every solver of a process -- would replay the same
+        # points.  The reference's generators all consume the one global RNG of the default device; here each
+        # takes its seed from that RNG once, at construction: torch.manual_seed still fixes the run, data-parallel ranks
+        # seeded alike still draw the same batches, and no two generators share a stream.
+        return DeviceGenerator(gen, seed=_seed_from_torch_cuda_rng(), stream_id=0, prefetch=True, dtype=dtype)
     except ValueError:
         return gen

@@ -10,20 +10,11 @@ from functools import wraps
 
 import torch
 
+from ._version_utils import deprecated_alias
 from .symbolic import Sym, sym_diff
 
 
-def _alias_x_to_u(fn):
-    """``x=`` is the deprecated name of the first argument (reference: _version_utils.py:21-48)."""
-    @wraps(fn)
-    def wrapped(*args, **kwargs):
-        if "x" in kwargs:
-            if "u" in kwargs:
-                raise KeyError("deprecated alias `x` and new name `u` cannot be passed together")
-            warnings.warn("The argument `x` is deprecated for `%s`; use `u` instead." % fn.__name__, FutureWarning)
-            kwargs["u"] = kwargs.pop("x")
-        return fn(*args, **kwargs)
-    return wrapped
+_alias_x_to_u = deprecated_alias(x="u")       # ``x=``: the deprecated name of the first argument (neurodiffeq.py:6,37,63)
 
 
 @_alias_x_to_u

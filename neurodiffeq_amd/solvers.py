@@ -460,22 +460,34 @@ class BaseSolver(ABC):
     def _equations_unchanged(self, sysm, force=False):
         """False: the user's equations / conditions now trace to something else than the kernels of ``sysm`` were compiled
         from (a Python float, dict entry or attribute they read was changed, e.g. by a callback).  The cheap state watch
-        runs every call; the re-trace when the watch is dirty, on the second use, every EQ_PROBE_EVERY calls and on
-        ``force`` (chunk boundaries of the multi-epoch fit path)."""
+        runs every call; the re-trace when the watch is dirty, on the second use, every EQ_PROBE_EVERY calls, on ``force``
+        (chunk boundaries of the multi-epoch fit path) -- and on EVERY call when the watch is incomplete (the walk met state
+        it cannot stamp, _pystate.StateWatch: fail-closed, the reference re-evaluates every batch, solvers.py:380)."""
         watch = self._eq_watch
         dirty = watch is None or watch.dirty()
+        blind = watch is not None and not watch.complete
         self._eq_probe_countdown -= 1
-        if not (dirty or force or self._eq_probe_countdown <= 0):
+        if not (dirty or blind or force or self._eq_probe_countdown <= 0):
             return True                       # (the per-epoch cost: one compiled chain of comparisons, _pystate.StateWatch)
         probe = getattr(sysm.program, "eq_probe", None)
         if probe is None:
             return True
+        if blind and not self.__dict__.get("_eq_watch_warned"):
+            self._eq_watch_warned = True
+            warnings.warn("neurodiffeq_amd: the equations / conditions read state that cannot be compared between epochs ("
+                          + "; ".join(watch.incomplete) + "). They are re-traced every epoch instead (about 0.1 - 0.7 ms of host "
+                          "time per epoch) and fit() runs epoch by epoch; results are unaffected.", RuntimeWarning)
         if self._eq_probe_countdown <= 0:
             self._eq_probe_countdown = self.EQ_PROBE_EVERY
         same = probe()
         if dirty:
             self._watch_equations_refresh()
         return same
+
+    def _eq_watch_blocks_chunks(self):
+        """The multi-epoch native call runs K epochs with no Python in between: only when everything the equations can read
+        is stamped (a complete watch) is "nothing ran, nothing changed" a safe conclusion."""
+        return self._eq_watch is None or not self._eq_watch.complete
 
     def _watch_equations_refresh(self):
         countdown = self._eq_probe_countdown
@@ -734,6 +746,8 @@ class BaseSolver(ABC):
             return 0
         if self._fused_system(system.n_coords) is not system:      # something was swapped since the last epoch
             return 0
+        if self._eq_watch_blocks_chunks():
+            return 0                      # equations that may follow the epoch counter / unstampable state: epoch by epoch
         if not self._equations_unchanged(system, force=True):       # chunk boundary: unconditional re-trace (EQ_PROBE_EVERY)
             self._fused_key = None
             return 0

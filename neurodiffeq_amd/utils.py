@@ -34,6 +34,12 @@ def set_tensor_type(device=None, float_bits=32):
     torch.set_default_device(None if device == "cpu" else device)
 
 
+def safe_mkdir(path):
+    """``mkdir -p`` (utils.py:44-45; the reference's callbacks / monitors call it)."""
+    import os
+    os.makedirs(path, exist_ok=True)
+
+
 def set_seed(seed_value, ignore_numpy=False, ignore_torch=False, ignore_random=False):
     if not ignore_numpy:
         np.random.seed(seed_value)

