@@ -116,6 +116,7 @@ _UN_FWD = {
     "log": "logf({a})", "tanh": "tanhf({a})", "sqrt": "sqrtf({a})", "abs": "fabsf({a})", "sinh": "sinhf({a})",
     "cosh": "coshf({a})", "sigmoid": "(1.0f/(1.0f+expf(-{a})))", "recip": "(1.0f/{a})",
     "sign": "(({a}>0.0f)-({a}<0.0f))",
+    "log1p": "log1pf({a})", "expm1": "expm1f({a})", "erf": "erff({a})", "atan": "atanf({a})",
 }
 # adjoint factor of the single child: child_adj += b * factor ; {a} child value, {v} node value
 _UN_ADJ = {
@@ -123,6 +124,8 @@ _UN_ADJ = {
     "exp": "{b}*{v}", "log": "{b}/{a}", "tanh": "{b}*(1.0f-{v}*{v})", "sqrt": "{b}/(2.0f*{v})",
     "abs": "{b}*(({a}>0.0f)-({a}<0.0f))", "sinh": "{b}*coshf({a})", "cosh": "{b}*sinhf({a})",
     "sigmoid": "{b}*{v}*(1.0f-{v})", "recip": "-{b}*{v}*{v}", "sign": None,
+    "log1p": "{b}/(1.0f+{a})", "expm1": "{b}*({v}+1.0f)", "erf": "{b}*1.1283791670955126f*expf(-{a}*{a})",
+    "atan": "{b}/(1.0f+{a}*{a})",
 }
 
 
@@ -352,7 +355,8 @@ class PointwiseProgram:
         dep = {}
         for i in self.order:
             n = g.nodes[i]
-            dep[i] = n[0] in ("net", "param") or any(dep[c] for c in g.children(i))
+            # (runtime constants -- frozen 'param' leaves, symbolic.Graph.external -- carry no adjoint)
+            dep[i] = n[0] == "net" or (n[0] == "param" and n[1] not in getattr(g, "frozen", ())) or any(dep[c] for c in g.children(i))
         res_order = g.reachable(self.residuals)
         res_set = set(res_order)
         L.append("// ---- forward")
@@ -371,6 +375,12 @@ class PointwiseProgram:
                 e = _powi_expr(self._val(n[1]), n[2])
             elif op == "powc":
                 e = f"powf({self._val(n[1])}, {_lit(n[2])})"
+            elif op == "atan2":
+                e = f"atan2f({self._val(n[1])}, {self._val(n[2])})"
+            elif op in ("gt", "ge"):          # masks: 1.0f / 0.0f
+                e = f"(({self._val(n[1])} {'>' if op == 'gt' else '>='} {self._val(n[2])}) ? 1.0f : 0.0f)"
+            elif op == "where":               # a select, not a blend (symbolic.BINARY)
+                e = f"(({self._val(n[1])} != 0.0f) ? {self._val(n[2])} : {self._val(n[3])})"
             else:
                 e = _UN_FWD[op].format(a=self._val(n[1]))
             L.append(f"  const float v{i} = {e};")
@@ -426,6 +436,14 @@ class PointwiseProgram:
             elif op == "div":
                 push(n[1], f"{b}/{self._val(n[2])}")
                 push(n[2], f"-{b}*v{i}/{self._val(n[2])}")
+            elif op == "atan2":
+                L.append(f"  const float q{i} = {b}/({self._val(n[1])}*{self._val(n[1])} + {self._val(n[2])}*{self._val(n[2])});")
+                push(n[1], f"q{i}*{self._val(n[2])}"); push(n[2], f"-q{i}*{self._val(n[1])}")
+            elif op in ("gt", "ge"):
+                pass                          # piecewise constant: nothing flows through a mask
+            elif op == "where":
+                push(n[2], f"(({self._val(n[1])} != 0.0f) ? {b} : 0.0f)")
+                push(n[3], f"(({self._val(n[1])} != 0.0f) ? 0.0f : {b})")
             elif op == "powi":
                 push(n[1], f"{b}*{float(n[2])}f*{_powi_expr(self._val(n[1]), n[2] - 1)}")
             elif op == "powc":
@@ -952,7 +970,7 @@ def so_path_for(program: PointwiseProgram, f64=False):
     return os.path.join(JIT_DIR, f"pw{'64' if f64 else ''}_{program.key}.so")
 
 
-_F64_FUNCS = re.compile(r"\b(pow|sin|cos|tan|exp|log|tanh|sqrt|fabs|sinh|cosh|fmax)f\(")
+_F64_FUNCS = re.compile(r"\b(pow|sin|cos|tan|exp|log|tanh|sqrt|fabs|sinh|cosh|fmax|log1p|expm1|erf|atan|atan2)f\(")
 _F64_LITERAL = re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?)f\b")
 
 

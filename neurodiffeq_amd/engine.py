@@ -89,12 +89,18 @@ class _UserCode:
         return False
 
 
-def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, loss="l2", metrics=(), f64=False):
+def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, loss="l2", metrics=(), f64=False,
+                 volatile=frozenset()):
     """Trace (conditions, diff_eqs) once on symbolic columns and lower them to a pointwise program.
 
     Needs no GPU (used by ``__graft_entry__.build`` to pre-compile the generated kernels); raises
     :class:`TraceUnsupported` when the system is outside the fused scope.  Returns ``(program, descs)`` with
-    ``descs[k]`` the ``ndq_mlp_desc`` of network k (stream set widened to one libndq.so has kernels for)."""
+    ``descs[k]`` the ``ndq_mlp_desc`` of network k (stream set widened to one libndq.so has kernels for).
+
+    volatile: positions (in the order the callables hand them to the trace, ``symbolic.Graph.external``) of outside numbers
+    that become RUNTIME constants of the generated kernels instead of literals -- what ``program.suggest_volatile()`` of an
+    earlier trace of the same callables returned after a re-trace that differed in such numbers only (a coefficient ramped
+    by a callback: one rebuild, then every further value is an argument update).  fp32 only."""
     L = _Lib64() if f64 else _lib.lib()
     all_nets, conditions = list(nets), list(conditions)
     # one parameter set per DISTINCT module: the reference's single_net / ith_unit mode (ode.py:276-280, pde.py:301-305)
@@ -108,6 +114,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     if any(i is None for i in infos):
         raise TraceUnsupported("a network is not an FCNN the gfx950 kernels support")
     g = Graph(n_coords)
+    g.volatile = frozenset() if f64 else frozenset(volatile)      # (the fp64 pipeline has no scalar arguments)
     g.register_nets(nets, [i["n_out"] for i in infos])
     cfv = compute_func_val or (lambda net, cond, *coords: cond.enforce(net, *coords))
     with trace_scope(g):
@@ -124,6 +131,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             except (TypeError, ValueError, RuntimeError):
                 raise TraceUnsupported(f"an equation returned {type(r).__name__}, not a traced (N, 1) column or a scalar")
         res = [column(r) for r in res]
+        eq_ext = list(g.ext_log)         # the outside numbers the conditions and equations read, in order (suggest_volatile)
         # a function is an (N, 1) column or -- EnsembleCondition on one multi-output network (conditions.py:157-202), used
         # as ONE solver function whose columns the equations pick apart -- an (N, k) matrix: k rows of the function buffer
         from .symbolic import SymMat
@@ -146,6 +154,8 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             callables compute."""
             n_captured = len(g.captured)
             twins_before = set(getattr(g, "twins", ()))
+            g.ext_log = []
+            eq_probe.last_ext = None
             try:
                 with trace_scope(g):
                     f2 = [cfv(n, c, *coords) for n, c in zip(all_nets, conditions)]
@@ -161,6 +171,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
                         cols.extend(c.i for c in f.cols)
                     else:
                         return False
+                eq_probe.last_ext = list(g.ext_log)
                 return tuple(cols) + ("|",) + tuple(r.i for r in r2) == eq_nodes
             except Exception as e:       # noqa: BLE001 -- whatever the callables do now, it is not what was compiled
                 if not getattr(eq_probe, "warned", False):
@@ -174,6 +185,15 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
                 del g.captured[n_captured:]       # (the probe's own captures are the same tensors again)
                 for key in [k for k in getattr(g, "twins", ()) if k not in twins_before]:
                     del g.twins[key]              # (twins of the tensors this probe created: they would pile up)
+
+        def suggest_volatile():
+            """After an ``eq_probe()`` that returned False: the positions to trace as runtime constants next time -- the
+            current ones plus every outside number whose value differs from the compiled trace's (same count of numbers
+            in both: the callables took the same path).  Any set is safe (module symbolic: Graph.external)."""
+            last = getattr(eq_probe, "last_ext", None)
+            if last is None or len(last) != len(eq_ext):
+                return frozenset(g.volatile)
+            return frozenset(g.volatile) | {i for i, (a, b) in enumerate(zip(eq_ext, last)) if a != b and (a == a or b == b)}
 
         # a custom loss: callable(residual (N, n_eq), funcs, coords) -> scalar (solvers.py:216-226; the solver passes
         # loss_fn + additional_loss as ONE callable) traced to the per-point term whose batch mean it is
@@ -295,13 +315,14 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     program.func_widths = [len(cols) for cols in func_columns]    # columns of every solver function, in order
     program.loss_probe = loss_probe              # custom losses: "does the callable still trace to the compiled term?"
     program.eq_probe = eq_probe                  # equations / conditions: "do they still trace to the compiled residuals?"
+    program.suggest_volatile = suggest_volatile  # ... and if not: which outside numbers moved (-> runtime constants)
     program.unique_nets = nets                   # distinct modules, in first-appearance order: one parameter set each
     return program, descs
 
 
 class FusedSystem:
     def __init__(self, nets, conditions, diff_eqs, n_coords, device, compute_func_val=None, single_kernel=True,
-                 loss="l2", metrics=(), dtype=torch.float32):
+                 loss="l2", metrics=(), dtype=torch.float32, volatile=frozenset()):
         """single_kernel: for single-network systems use the one-launch fused closure kernel (forward + pointwise +
         reverse, csrc/ndq_mlp.h: fused_closure_kernel); otherwise (and for multi-network systems) the three-kernel
         pipeline through HBM streams."""
@@ -320,7 +341,7 @@ class FusedSystem:
         self.L = _Lib64() if self.f64 else _lib.lib()
         self.nets, self.conditions, self.n_coords = list(nets), list(conditions), n_coords
         self.program, self.descs = trace_system(self.nets, self.conditions, diff_eqs, n_coords, compute_func_val, loss,
-                                                metrics, f64=self.f64)
+                                                metrics, f64=self.f64, volatile=volatile)
         self.nets = list(self.program.unique_nets)      # a module shared by several functions is ONE parameter set
         # rows of the function-value buffer: the solver's functions, then one per-point term per traced metric
         self.n_eq, self.n_funcs = len(self.program.residuals), len(self.program.funcs)
@@ -331,6 +352,11 @@ class FusedSystem:
         # under autograd every batch, solvers.py:380): kernel arguments whose gradient is one more fixed-order sum of
         # per-point adjoints; per-point data columns ((N, 1) tensors aligned with the batch): input rows behind the coordinates
         self.theta_params = list(self.program.g.params)
+        # ... and the RUNTIME constants among them (symbolic.Graph.external: outside numbers that change between epochs --
+        # frozen host scalars the re-trace refills; no gradient, no optimiser)
+        self.theta_frozen = sorted(self.program.g.frozen)
+        self._theta_trainable = [j for j in range(len(self.theta_params)) if j not in self.program.g.frozen]
+        self._theta_frozen_seen = None
         self.data_cols = list(self.program.g.data)
         self.n_theta, self.n_data = len(self.theta_params), len(self.data_cols)
         self.n_rows = n_coords + self.n_data
@@ -387,7 +413,16 @@ class FusedSystem:
         """Current values of the equations' trainable scalars -> the device vector the kernels read."""
         if self.n_theta:
             with torch.no_grad():
-                self.theta_buf.copy_(torch.stack([p.detach().reshape(()).to(self.device, self.dt) for p in self.theta_params]))
+                if not self.theta_frozen:
+                    self.theta_buf.copy_(torch.stack([p.detach().reshape(()).to(self.device, self.dt) for p in self.theta_params]))
+                    return
+                if self._theta_trainable:
+                    live = torch.stack([self.theta_params[j].detach().reshape(()).to(self.device, self.dt) for j in self._theta_trainable])
+                    self.theta_buf[self._theta_trainable] = live
+                values = tuple(float(self.theta_params[j]) for j in self.theta_frozen)
+                if values != self._theta_frozen_seen:          # (one small H2D copy when a re-trace brought new values)
+                    self._theta_frozen_seen = values
+                    self.theta_buf[self.theta_frozen] = torch.tensor(values, dtype=self.dt).to(self.device)
 
     def _bind_theta(self, b, lib, fused):
         """Hand a kernel module the scalars' vector and the block-partial rows of this buffer set."""
@@ -405,6 +440,8 @@ class FusedSystem:
     def attach_theta_grads(self):
         """``p.grad`` of every trainable scalar = its entry of ``gtheta`` (what loss.backward() leaves, solvers.py:393)."""
         for j, p in enumerate(self.theta_params):
+            if j in self.program.g.frozen:
+                continue
             g = self.gtheta[j].reshape(p.shape).to(p.device, p.dtype)
             if p.grad is not None and p.grad.shape == g.shape and p.grad.data_ptr() != self.gtheta[j].data_ptr():
                 p.grad.copy_(g)

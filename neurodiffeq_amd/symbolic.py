@@ -31,7 +31,13 @@ class MetricTraceUnsupported(TraceUnsupported):
 LEAVES = ("const", "coord", "net", "param", "data")
 
 # op -> (arity).  Unary elementwise functions are listed in UNARY.
-UNARY = ("neg", "sin", "cos", "tan", "exp", "log", "tanh", "sqrt", "abs", "sinh", "cosh", "sigmoid", "recip", "sign")
+UNARY = ("neg", "sin", "cos", "tan", "exp", "log", "tanh", "sqrt", "abs", "sinh", "cosh", "sigmoid", "recip", "sign",
+         "log1p", "expm1", "erf", "atan")
+# further binary nodes: atan2(a, b) and the MASKS gt(a, b) = [a > b], ge(a, b) = [a >= b] -- per-point 0.0 / 1.0 columns with
+# zero derivative, what a comparison of traced columns gives (`x > 0.5`); ternary: where(m, a, b) = m != 0 ? a : b, which
+# selects (it does not blend: an inf / nan in the branch not taken stays out of the value AND of the gradient, like
+# torch.where).  relu / clamp / maximum / minimum are written in these (Sym.relu ...), with torch's own subgradients at ties.
+BINARY = ("add", "sub", "mul", "div", "atan2", "gt", "ge")
 
 
 class Graph:
@@ -59,6 +65,34 @@ class Graph:
         # batch, e.g. a measured source term on a PredefinedGenerator's points) -- leaf ('data', j), one more input row
         self.params = []
         self.data = []
+        # numbers that enter the trace from OUTSIDE it (Python floats read from a closure / dict / attribute, 1-element
+        # tensors baked in as constants), in the order the callables hand them over.  The reference re-evaluates the user's
+        # callables every batch (solvers.py:380), so such a number may differ from one epoch to the next -- a viscosity ramp, a
+        # curriculum on ``solver.local_epoch``; as a literal of the generated kernel every new value would be a new hipcc run.
+        # Positions listed in ``volatile`` become RUNTIME constants instead: leaves ('param', j) backed by a frozen host
+        # scalar (``frozen``: their indices; no adjoint, no optimiser), read from the same device vector as the trainable
+        # scalars.  Which positions are volatile is found out by the solver when a re-trace differs from the compiled
+        # one in nothing but such numbers (engine.trace_system: eq_probe / suggest_volatile); any choice of positions gives
+        # a faithful program -- the set only decides what is a literal and what an argument.
+        self.ext_log = []
+        self.volatile = frozenset()
+        self.frozen = set()
+        self._rtensors = {}      # external position -> its frozen scalar
+
+    def external(self, v):
+        """Node of a number coming from outside the trace (see ``ext_log`` above)."""
+        v = float(v)
+        pos = len(self.ext_log)
+        self.ext_log.append(v)
+        if pos in self.volatile:
+            t = self._rtensors.get(pos)
+            if t is None:
+                t = self._rtensors[pos] = torch.zeros((), dtype=torch.float64)
+            t.fill_(v)
+            i = self.param(t)
+            self.frozen.add(self.nodes[i][1])
+            return i
+        return self.const(v)
 
     # -------------------------------------------------------------- networks
     def register_nets(self, nets, n_outs):
@@ -229,6 +263,7 @@ class Graph:
         "tanh": math.tanh, "sqrt": math.sqrt, "abs": abs, "sinh": math.sinh, "cosh": math.cosh,
         "sigmoid": lambda v: 1.0 / (1.0 + math.exp(-v)), "recip": lambda v: 1.0 / v,
         "sign": lambda v: (v > 0) - (v < 0),
+        "log1p": math.log1p, "expm1": math.expm1, "erf": math.erf, "atan": math.atan,
     }
 
     def unary(self, op, a):
@@ -238,6 +273,34 @@ class Graph:
         if op == "neg" and self.nodes[a][0] == "neg":
             return self.nodes[a][1]
         return self._mk((op, a))
+
+    def atan2(self, a, b):
+        ca, cb = self.cval(a), self.cval(b)
+        if ca is not None and cb is not None:
+            return self.const(math.atan2(ca, cb))
+        return self._mk(("atan2", a, b))
+
+    def gt(self, a, b):
+        ca, cb = self.cval(a), self.cval(b)
+        if ca is not None and cb is not None:
+            return self.const(1.0 if ca > cb else 0.0)
+        if a == b:
+            return self.const(0.0)
+        return self._mk(("gt", a, b))
+
+    def ge(self, a, b):
+        ca, cb = self.cval(a), self.cval(b)
+        if ca is not None and cb is not None:
+            return self.const(1.0 if ca >= cb else 0.0)
+        return self._mk(("ge", a, b))
+
+    def where(self, m, a, b):
+        cm = self.cval(m)
+        if cm is not None:
+            return a if cm != 0.0 else b
+        if a == b:
+            return a
+        return self._mk(("where", m, a, b))
 
     # -------------------------------------------------------------- differentiation
     def diff(self, e, ci):
@@ -277,6 +340,13 @@ class Graph:
             a, b = n[1], n[2]
             # (a/b)' = a'/b - (a/b) b'/b
             r = self.sub(self.div(D(a), b), self.mul(e, self.div(D(b), b)))
+        elif op in ("gt", "ge"):
+            r = self.const(0.0)              # a mask: piecewise constant
+        elif op == "where":
+            r = self.where(n[1], D(n[2]), D(n[3]))
+        elif op == "atan2":
+            a, b = n[1], n[2]                # d atan2(a, b) = (b da - a db) / (a^2 + b^2)
+            r = self.div(self.sub(self.mul(b, D(a)), self.mul(a, D(b))), self.add(self.mul(a, a), self.mul(b, b)))
         elif op == "powi":
             a, k = n[1], n[2]
             r = self.mul(self.mul(self.const(k), self.powi(a, k - 1)), D(a))
@@ -314,6 +384,14 @@ class Graph:
                 r = self.mul(self.mul(e, self.sub(self.const(1.0), e)), da)
             elif op == "recip":
                 r = self.unary("neg", self.mul(self.mul(e, e), da))
+            elif op == "log1p":
+                r = self.div(da, self.add(self.const(1.0), a))
+            elif op == "expm1":
+                r = self.mul(self.add(e, self.const(1.0)), da)
+            elif op == "erf":                # 2 / sqrt(pi) * exp(-a^2)
+                r = self.mul(self.mul(self.const(2.0 / math.sqrt(math.pi)), self.unary("exp", self.unary("neg", self.mul(a, a)))), da)
+            elif op == "atan":
+                r = self.div(da, self.add(self.const(1.0), self.mul(a, a)))
             else:  # pragma: no cover
                 raise TraceUnsupported(f"no derivative rule for {op}")
         self._dcache[key] = r
@@ -332,8 +410,10 @@ class Graph:
         S = lambda x: self.subst(x, mapping, memo)
         if op in LEAVES:
             r = e
-        elif op in ("add", "sub", "mul", "div"):
+        elif op in BINARY:
             r = getattr(self, op)(S(n[1]), S(n[2]))
+        elif op == "where":
+            r = self.where(S(n[1]), S(n[2]), S(n[3]))
         elif op == "powi":
             r = self.powi(S(n[1]), n[2])
         elif op == "powc":
@@ -369,8 +449,10 @@ class Graph:
         op = n[0]
         if op in LEAVES:
             return ()
-        if op in ("add", "sub", "mul", "div"):
+        if op in BINARY:
             return (n[1], n[2])
+        if op == "where":
+            return (n[1], n[2], n[3])
         return (n[1],)
 
 
@@ -501,7 +583,9 @@ def _row_values(v):
     return None
 
 
-def _as_node(g, v):
+def _as_node(g, v, literal=False):
+    """literal: the number is needed as a compile-time constant (an exponent): never a runtime constant (Graph.external)."""
+    ext = g.const if literal else g.external
     if isinstance(v, Sym):
         if v.g is not g:
             raise TraceUnsupported("mixing symbols of different traces")
@@ -511,7 +595,7 @@ def _as_node(g, v):
         if tw is not None and tw[0] is v and tw[1] is not None and tw[2] == v._version:
             return tw[1]
     if isinstance(v, numbers.Number):
-        return g.const(float(v))
+        return ext(v)
     if isinstance(v, torch.Tensor) and v.numel() > 1 and v.dim() == 2 and v.shape[1] == 1 and not v.requires_grad:
         return g.datacol(v)
     if isinstance(v, torch.Tensor) and v.numel() == 1:
@@ -522,11 +606,11 @@ def _as_node(g, v):
             return g.param(v)
         # baked in at trace time like a Python float; the solver re-traces when the tensor is modified in place
         g.captured.append((v, v._version))
-        return g.const(float(v.item()))
+        return ext(v.item())
     try:
         import numpy as np
         if isinstance(v, np.ndarray) and v.size == 1:
-            return g.const(float(v.reshape(-1)[0]))
+            return ext(v.reshape(-1)[0])
     except Exception:  # pragma: no cover
         pass
     raise TraceUnsupported(f"cannot mix a traced value with {type(v).__name__} of more than one element")
@@ -630,12 +714,12 @@ class Sym:
             # a ** b = exp(b log a)
             g = self.g
             return Sym(g, g.unary("exp", g.mul(e.i, g.unary("log", self.i))))
-        c = self.g.cval(_as_node(self.g, e))
+        c = self.g.cval(_as_node(self.g, e, literal=True))
         return Sym(self.g, self.g.powc(self.i, c))
 
     def __rpow__(self, base):
         g = self.g
-        c = g.cval(_as_node(g, base))
+        c = g.cval(_as_node(g, base, literal=True))
         return Sym(g, g.unary("exp", g.mul(self.i, g.const(math.log(c)))))
 
     # methods mirroring torch.Tensor
@@ -657,6 +741,58 @@ class Sym:
     def square(self): return self * self
     def pow(self, e): return self ** e
     def mean(self, dim=None, keepdim=False, **k): return _batch_mean(self, dim, keepdim)
+    def sign(self): return self._un("sign")
+    def sgn(self): return self._un("sign")
+    def log1p(self): return self._un("log1p")
+    def expm1(self): return self._un("expm1")
+    def erf(self): return self._un("erf")
+    def atan(self): return self._un("atan")
+    def arctan(self): return self._un("atan")
+    def atan2(self, other): return _tf_atan2(self, other)
+    def arctan2(self, other): return _tf_atan2(self, other)
+
+    # ---- comparisons -> masks (0.0 / 1.0 columns, zero derivative); piecewise functions in torch's own subgradients
+    def _cmp(self, other, op, swap):
+        g = self.g
+        try:
+            o = _as_node(g, other)
+        except TraceUnsupported:
+            return NotImplemented
+        a, b = (o, self.i) if swap else (self.i, o)
+        return Sym(g, getattr(g, op)(a, b))
+
+    def __gt__(self, o): return self._cmp(o, "gt", False)
+    def __lt__(self, o): return self._cmp(o, "gt", True)
+    def __ge__(self, o): return self._cmp(o, "ge", False)
+    def __le__(self, o): return self._cmp(o, "ge", True)
+    def gt(self, o): return self > o
+    def lt(self, o): return self < o
+    def ge(self, o): return self >= o
+    def le(self, o): return self <= o
+    def greater(self, o): return self > o
+    def less(self, o): return self < o
+    def __invert__(self): return 1.0 - self                      # of a mask
+    def logical_not(self): return 1.0 - self
+    def __and__(self, o): return self * o                        # of two masks
+    def __rand__(self, o): return self * o
+    def logical_and(self, o): return self * o
+    def __or__(self, o): return self + o - self * o
+    def __ror__(self, o): return self + o - self * o
+    def logical_or(self, o): return self + o - self * o
+    def float(self): return self
+    def double(self): return self
+    def bool(self): return self
+    def to(self, *a, **k): return self
+    def type(self, *a, **k): return self
+    def type_as(self, other): return self
+    def where(self, condition, other): return _tf_where(condition, self, other)
+    def relu(self): return _tf_where(self > 0.0, self, 0.0)
+    def clamp(self, min=None, max=None): return _tf_clamp(self, min, max)
+    def clip(self, min=None, max=None): return _tf_clamp(self, min, max)
+    def clamp_min(self, min): return _tf_clamp(self, min, None)
+    def clamp_max(self, max): return _tf_clamp(self, None, max)
+    def maximum(self, other): return _tf_maximum(self, other)
+    def minimum(self, other): return _tf_minimum(self, other)
 
     # ---- torch.* functions
     @classmethod
@@ -1013,7 +1149,117 @@ def _tf_pow(a, b):
     return b.__rpow__(a)
 
 
+def _columns(x, k, g):
+    """``x`` (traced column / matrix, number, 1-element tensor) as k traced columns."""
+    if isinstance(x, SymMat):
+        if len(x.cols) != k:
+            raise TraceUnsupported("traced matrices of different widths")
+        return list(x.cols)
+    if isinstance(x, Sym):
+        return [x] * k
+    return [Sym(g, _as_node(g, x))] * k
+
+
+def _elementwise(fn, *operands):
+    """Apply ``fn(*columns)`` column by column over traced columns / matrices / scalars (broadcast to the widest)."""
+    s = _first_sym(*operands)
+    k = max((len(x.cols) for x in operands if isinstance(x, SymMat)), default=0)
+    if k == 0:
+        return fn(*[x if isinstance(x, Sym) else Sym(s.g, _as_node(s.g, x)) for x in operands])
+    cols = [_columns(x, k, s.g) for x in operands]
+    return SymMat([fn(*[c[j] for c in cols]) for j in range(k)])
+
+
+def _where1(m, a, b):
+    return Sym(m.g, m.g.where(m.i, a.i, b.i))
+
+
+def _tf_where(condition, input=None, other=None, **k):
+    if input is None or other is None:
+        raise TraceUnsupported("torch.where(condition) without the two branches inside the traced region")
+    if isinstance(condition, torch.Tensor):
+        if condition.numel() != 1:
+            raise TraceUnsupported("torch.where on a concrete mask of more than one element")
+        return input if bool(condition) else other
+    if not isinstance(condition, (Sym, SymMat)):
+        return input if condition else other
+    return _elementwise(_where1, condition, input, other)
+
+
+def _tf_clamp(x, min=None, max=None, **k):
+    """torch.clamp: the value inside [min, max] (derivative 1, bounds included), the bound outside (derivative 0)."""
+    def one(col, *bounds):
+        bounds = list(bounds)
+        lo = bounds.pop(0) if min is not None else None
+        hi = bounds.pop(0) if max is not None else None
+        out = col
+        if hi is not None:
+            out = _where1(col > hi, hi, out)
+        if lo is not None:
+            out = _where1(col < lo, lo, out)       # (min wins where min > max, as in torch)
+        return out
+    return _elementwise(one, x, *[b for b in (min, max) if b is not None])
+
+
+def _tf_maximum(a, b, **k):
+    """torch.maximum / torch.max(a, b): the gradient is split evenly where the operands tie."""
+    return _elementwise(lambda x, y: _where1(x > y, x, _where1(y > x, y, 0.5 * (x + y))), a, b)
+
+
+def _tf_minimum(a, b, **k):
+    return _elementwise(lambda x, y: _where1(x < y, x, _where1(y < x, y, 0.5 * (x + y))), a, b)
+
+
+def _tf_max(a, b=None, *rest, **k):
+    if b is None or rest or k or not isinstance(b, (Sym, SymMat, torch.Tensor, numbers.Number)) or isinstance(b, bool) or (isinstance(b, int) and not isinstance(a, numbers.Number)):
+        raise TraceUnsupported("torch.max over a dimension of traced values")
+    return _tf_maximum(a, b)
+
+
+def _tf_min(a, b=None, *rest, **k):
+    if b is None or rest or k or not isinstance(b, (Sym, SymMat, torch.Tensor, numbers.Number)) or isinstance(b, bool) or (isinstance(b, int) and not isinstance(a, numbers.Number)):
+        raise TraceUnsupported("torch.min over a dimension of traced values")
+    return _tf_minimum(a, b)
+
+
+def _tf_atan2(a, b, **k):
+    return _elementwise(lambda y, x: Sym(y.g, y.g.atan2(y.i, x.i)), a, b)
+
+
+def _tf_relu(x, inplace=False, **k):
+    return _elementwise(lambda c: _where1(c > 0.0, c, Sym(c.g, c.g.const(0.0))), x)
+
+
+def _tf_leaky_relu(x, negative_slope=0.01, inplace=False, **k):
+    return _elementwise(lambda c: _where1(c > 0.0, c, c * float(negative_slope)), x)
+
+
+def _tf_heaviside(x, values, **k):
+    return _elementwise(lambda c, v: _where1(c > 0.0, Sym(c.g, c.g.const(1.0)), _where1(c < 0.0, Sym(c.g, c.g.const(0.0)), v)), x, values)
+
+
+def _tf_cmp(op, swap):
+    def f(a, b, **k):
+        return _elementwise(lambda x, y: Sym(x.g, getattr(x.g, op)(*((y.i, x.i) if swap else (x.i, y.i)))), a, b)
+    return f
+
+
+def _tf_map(op):
+    def f(x, *a, **k):
+        return _elementwise(lambda c: c._un(op), x)
+    return f
+
+
 _TORCH_FUNCS = {
+    "where": _tf_where, "clamp": _tf_clamp, "clip": _tf_clamp,
+    "clamp_min": lambda x, min, **k: _tf_clamp(x, min, None), "clamp_max": lambda x, max, **k: _tf_clamp(x, None, max),
+    "relu": _tf_relu, "leaky_relu": _tf_leaky_relu, "heaviside": _tf_heaviside,
+    "maximum": _tf_maximum, "minimum": _tf_minimum, "max": _tf_max, "min": _tf_min, "fmax": _tf_maximum, "fmin": _tf_minimum,
+    "sign": _tf_map("sign"), "sgn": _tf_map("sign"), "log1p": _tf_map("log1p"), "expm1": _tf_map("expm1"), "erf": _tf_map("erf"),
+    "atan": _tf_map("atan"), "arctan": _tf_map("atan"), "atan2": _tf_atan2, "arctan2": _tf_atan2,
+    "gt": _tf_cmp("gt", False), "greater": _tf_cmp("gt", False), "lt": _tf_cmp("gt", True), "less": _tf_cmp("gt", True),
+    "ge": _tf_cmp("ge", False), "greater_equal": _tf_cmp("ge", False), "le": _tf_cmp("ge", True), "less_equal": _tf_cmp("ge", True),
+    "logical_not": lambda x, **k: 1.0 - x, "logical_and": lambda a, b, **k: a * b, "logical_or": lambda a, b, **k: a + b - a * b,
     "sin": _tf_unary("sin"), "cos": _tf_unary("cos"), "tan": _tf_unary("tan"), "exp": _tf_unary("exp"),
     "log": _tf_unary("log"), "tanh": _tf_unary("tanh"), "sqrt": _tf_unary("sqrt"), "abs": _tf_unary("abs"),
     "sinh": _tf_unary("sinh"), "cosh": _tf_unary("cosh"), "sigmoid": _tf_unary("sigmoid"),

@@ -383,11 +383,17 @@ def test_python_state_ramped_by_a_callback_reaches_the_fused_kernels(golden_dir)
     solver.fused = "require"
     assert np.array_equal(R.get_flat(nets).cpu().numpy(), gold["params0"])
 
+    systems = []
+
     def ramp(s):
         nu["v"] *= 0.7
+        systems.append(s._fused_sys)
     torch.manual_seed(int(gold["seed"]) + 2)
     solver.fit(max_epochs=6, callbacks=[ramp], tqdm_file=None)
     assert solver.fused_active and abs(nu["v"] - float(gold["nu_final"])) < 1e-12
+    # the first new value rebuilds the kernels with the viscosity as a RUNTIME constant (symbolic.Graph.external); every
+    # further value is an argument update: two builds for six values, not six
+    assert len({id(x) for x in systems}) == 2 and systems[-1].theta_frozen and not systems[0].theta_frozen
     hist, valid = np.array(solver.metrics_history["train_loss"]), np.array(solver.metrics_history["valid_loss"])
     err = dict(loss=float(np.max(np.abs(hist - gold["traj_loss"]) / np.abs(gold["traj_loss"]))),
                valid=float(np.max(np.abs(valid - gold["traj_valid"]) / np.abs(gold["traj_valid"]))),
@@ -410,5 +416,62 @@ def test_python_state_ramped_by_a_callback_reaches_the_fused_kernels(golden_dir)
     for _ in range(3):
         solver2.fit(1, tqdm_file=None)
         nu["v"] *= 0.7
+    hist2 = np.array(solver2.metrics_history["train_loss"])
+    assert float(np.max(np.abs(hist2 - gold["traj_loss"]) / np.abs(gold["traj_loss"]))) < 2e-5, (hist2, gold["traj_loss"])
+
+
+def test_equations_following_solver_local_epoch_train_on_the_current_value_every_epoch(golden_dir):
+    """``diff_eqs`` reads ``solver.local_epoch`` through a captured solver -- the curriculum
+    idiom; the fit loop advances the counter itself (solvers.py:443-497), nothing a state watch could stamp.  The watch is
+    INCOMPLETE for such equations (_pystate: they name solver bookkeeping), so they are re-traced every epoch; the first value
+    that differs from the compiled literal rebuilds the kernels with that number as a runtime constant, later values are
+    argument updates.  Loss history and final parameters equal what the unmodified reference produced
+    (tests/golden/make_golden.py: make_curriculum) -- not the frozen-at-epoch-0 equation."""
+    import os
+    import warnings
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IBVP1D
+    from neurodiffeq_amd.generators import Generator2D
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.solvers import Solver2D
+    gold = np.load(os.path.join(golden_dir, "curriculum.npz"))
+    torch.manual_seed(int(gold["seed"]))
+    holder = {}
+    pde = lambda u, x, t: [diff(u, t) + u * diff(u, x) - (0.05 * 0.7 ** holder["solver"].local_epoch) * diff(u, x, order=2)]
+    nets = [FCNN(2, 1, hidden_units=(32, 32))]
+    conds = [IBVP1D(x_min=-1, x_max=1, t_min=0, t_min_val=lambda x: -torch.sin(np.pi * x), x_min_val=lambda t: 0, x_max_val=lambda t: 0)]
+    solver = Solver2D(pde, conds, xy_min=(-1, 0), xy_max=(1, 1), nets=nets,
+                      train_generator=Generator2D((12, 12), (-1, 0), (1, 1), "equally-spaced-noisy"),
+                      valid_generator=Generator2D((8, 8), (-1, 0), (1, 1), "equally-spaced"))
+    holder["solver"] = solver
+    solver.fused = "require"
+    assert np.array_equal(R.get_flat(nets).cpu().numpy(), gold["params0"])
+    systems, seen = [], []
+
+    def observe(s):
+        seen.append(s.local_epoch)
+        systems.append(s._fused_sys)
+    torch.manual_seed(int(gold["seed"]) + 2)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        solver.fit(max_epochs=6, callbacks=[observe], tqdm_file=None)
+    assert solver.fused_active and seen == list(gold["epochs_seen"])
+    assert sum("re-traced every epoch" in str(x.message) for x in w) == 1 and not solver._eq_watch.complete
+    hist, valid = np.array(solver.metrics_history["train_loss"]), np.array(solver.metrics_history["valid_loss"])
+    err = dict(loss=float(np.max(np.abs(hist - gold["traj_loss"]) / np.abs(gold["traj_loss"]))),
+               valid=float(np.max(np.abs(valid - gold["traj_valid"]) / np.abs(gold["traj_valid"]))),
+               params=float(np.linalg.norm(R.get_flat(nets).cpu().numpy() - gold["traj_params"]) / np.linalg.norm(gold["traj_params"])))
+    assert err["loss"] < 2e-5 and err["valid"] < 2e-5 and err["params"] < 1e-5, (err, hist, gold["traj_loss"])
+    assert len({id(x) for x in systems}) == 2 and systems[-1].theta_frozen         # one rebuild, then argument updates
+    # the same through fit() WITHOUT callbacks (the multi-epoch native call must not swallow the counter): epoch by epoch
+    torch.manual_seed(int(gold["seed"]))
+    nets2 = [FCNN(2, 1, hidden_units=(32, 32))]
+    solver2 = Solver2D(pde, conds, xy_min=(-1, 0), xy_max=(1, 1), nets=nets2,
+                       train_generator=Generator2D((12, 12), (-1, 0), (1, 1), "equally-spaced-noisy"),
+                       valid_generator=Generator2D((8, 8), (-1, 0), (1, 1), "equally-spaced"))
+    holder["solver"] = solver2
+    solver2.fused = "require"
+    torch.manual_seed(int(gold["seed"]) + 2)
+    solver2.fit(max_epochs=6, tqdm_file=None)
     hist2 = np.array(solver2.metrics_history["train_loss"])
     assert float(np.max(np.abs(hist2 - gold["traj_loss"]) / np.abs(gold["traj_loss"]))) < 2e-5, (hist2, gold["traj_loss"])

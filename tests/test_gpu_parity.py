@@ -577,7 +577,9 @@ def _lib_check(rc):
                                   "swish_ode", "bundle_decay", "bundle_bvp", "shape_64x2", "shape_32x3", "shape_48x2",
                                   "shape_16x2_sin", "shape_32x1", "aptx_burgers", "resnet_laplace", "resnet_ode",
                                   # beyond round 2's template limits: 6 and 8 hidden layers, 4 and 5 inputs, a 3-parameter bundle
-                                  "shape_32x6", "shape_16x8_sin", "heat4d", "mix5d", "bundle_osc"])
+                                  "shape_32x6", "shape_16x8_sin", "heat4d", "mix5d", "bundle_osc",
+                                  # piecewise / clipped equations: masks, where, clamp, relu, maximum, sign, log1p, atan2, erf
+                                  "piecewise_source", "relu_ode", "atan2_adv"])
 def test_zoo_closure_matches_autograd_oracle(name, mode):
     """Systems outside the BASELINE set (tests/zoo.py): second-order IVP, sin networks, mixed second derivatives, first
     order only, three coordinates (Laplacian-merged, diagonal and full Hessian stream sets), three networks."""

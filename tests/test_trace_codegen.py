@@ -160,6 +160,7 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "shape_32x6": [(1, 5, 1)], "shape_16x8_sin": [(1, 5, 1)],
                # four / five inputs: 10 / 15 pair bits -- xx, yy, zz of (x, y, z, t) merged into one Laplacian stream; cc and ae
                "heat4d": [(1, 145, 1)], "mix5d": [(1, 528, 0)], "bundle_osc": [(1, 1, 0)],
+               "piecewise_source": [(1, 5, 1)], "relu_ode": [(1, 0, 0)], "atan2_adv": [(1, 0, 0)],
                # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along
                "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)]}
 
@@ -190,7 +191,7 @@ def test_zoo_on_host_matches_autograd_oracle(name):
 
 
 @pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "helmholtz_xy", "stokes_like", "sigmoid_mixed", "kdv", "shell",
-                                  "bundle_bvp", "mono_laplace", "aptx_burgers"])
+                                  "bundle_bvp", "mono_laplace", "aptx_burgers", "piecewise_source", "relu_ode", "atan2_adv"])
 def test_zoo_fp64_build_on_host_matches_autograd_oracle(name):
     """The fp64 build of the generated pointwise code (codegen.source_f64: types, math calls and literal suffixes of the
     same traced program rewritten for double -- what FusedSystem(dtype=float64) compiles for gfx950) between the fp64
@@ -646,6 +647,59 @@ def test_equation_probe_sees_python_state_changed_between_epochs():
     assert StateWatch([eqs, cond]).entries and not program.eq_probe()
     # a stateless lambda has (almost) nothing to watch
     assert len(StateWatch([lambda u, t: [diff(u, t) + u]])) <= 2
+
+
+def test_outside_numbers_that_move_become_runtime_constants_of_the_generated_kernel():
+    """symbolic.Graph.external / engine.trace_system(volatile=...): a number the equations read from Python state is a literal of
+    the first build; once a re-trace differs in such numbers only, ``suggest_volatile()`` names their positions and the next
+    trace takes them as frozen 'param' leaves -- same per-point values as the literal program, no adjoint, and every later
+    value is absorbed by ``eq_probe()`` (it refills the frozen scalars) without another build."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.engine import trace_system
+    from neurodiffeq_amd.networks import FCNN
+    nu = {"v": 0.05}
+    k = torch.tensor(2.0)                                       # a captured 1-element tensor is an outside number as well
+    cond = IVP(0.0, 1.5)
+    eqs = lambda u, t: [diff(u, t) + nu["v"] * u ** 2 - k * torch.sin(t) + 3.0]
+    net = FCNN(1, 1)
+    lit, _ = trace_system([net], [cond], eqs, 1)
+    assert lit.n_theta == 0 and lit.eq_probe() and lit.suggest_volatile() == frozenset()
+    nu["v"] = 0.035
+    k.mul_(1.5)
+    assert not lit.eq_probe()
+    vol = lit.suggest_volatile()
+    assert len(vol) == 2                                        # nu['v'] and k; the IVP's 1.5, the literal 3.0 stay literals
+    run, _ = trace_system([net], [cond], eqs, 1, volatile=vol)
+    assert run.n_theta == 2 and run.g.frozen == {0, 1} and run.eq_probe()
+    lit2, _ = trace_system([net], [cond], eqs, 1)              # the literal program of the CURRENT values
+    rng = np.random.default_rng(0)
+    n = 257
+    coords = rng.uniform(0.1, 2.0, (1, n)).astype(np.float32)
+    syms = rng.normal(size=(len(lit2.symbols), n)).astype(np.float32)
+    assert [lit2.g.nodes[i] for i in lit2.symbols] == [run.g.nodes[i] for i in run.symbols]
+    theta = [float(p) for p in run.g.params]
+    assert theta == [0.035, 3.0]
+    r0, f0, g0 = run_cpu(lit2, coords, syms, 1.0 / n)
+    r1, f1, g1, gth = run_cpu(run, coords, syms, 1.0 / n, theta=theta)
+    assert np.allclose(r0, r1, rtol=2e-6, atol=1e-6) and np.array_equal(f0, f1) and np.allclose(g0, g1, rtol=2e-6, atol=1e-7)
+    assert not gth.any()                                        # runtime constants carry no adjoint
+    # a further change: absorbed by the probe, no new program
+    nu["v"] = 0.0245
+    assert run.eq_probe() and [float(p) for p in run.g.params] == [0.0245, 3.0]
+    # a change of a number that is NOT volatile is still a different program ... whose suggestion adds that position
+    cond.u_0 = 1.75
+    assert not run.eq_probe() and len(run.suggest_volatile()) == 3
+    cond.u_0 = 1.5
+    # exponents stay compile-time constants: never promoted, a new value is a new program
+    p = {"e": 2.0}
+    eqs2 = lambda u, t: [diff(u, t) + u ** p["e"]]
+    a, _ = trace_system([net], [cond], eqs2, 1)
+    p["e"] = 3.0
+    assert not a.eq_probe() and a.suggest_volatile() == frozenset()
+    # fp64 programs have no scalar arguments: the hint is ignored, the numbers stay literals
+    d, _ = trace_system([FCNN(1, 1).double()], [cond], eqs, 1, f64=True, volatile=vol)
+    assert d.n_theta == 0
 
 
 def test_fp64_closure_source_is_the_fp32_module_rewritten_for_double():
