@@ -746,7 +746,7 @@ def main():
             out["default_generator_cuda"] = {"value": N_POINTS / dt4, "ms_per_step": dt4 * 1e3, "windows": len(w4),
                                              "generator": type(dsolver.generator["train"].generator).__name__,
                                              "note": "torch.set_default_device('cuda'), plain Solver2D + Generator2D: noise drawn "
-                                                     "by the Philox kernel every step, seeded from torch.cuda.initial_seed()"}
+                                                     "by the Philox kernel every step, each generator seeded from torch's cuda generator"}
             del dsolver
         finally:
             torch.set_default_device(None)       # (None removes torch's global device mode; "cpu" would leave one installed)
@@ -785,6 +785,11 @@ def main():
                 "note": f"headline `value` (inputs resident in HBM) vs the CPU baseline (kind = {cb['kind']}) on a pre-sampled "
                         "batch; `with_host_sampling` (reference RNG draw + upload inside the step) vs its full step"}
     if rank == 0:
+        # ONE JSON line; the bulky side records first, the contract keys and the compact headline figures (roofline,
+        # cpu_baseline, in_fit, with_*_sampling, default_generator_cuda) LAST: whoever keeps only the tail of this process's
+        # stdout still sees the headline
+        bulky = ("kernels", "configs", "cold_start", "roofline_pointwise_large", "c2_fp64", "c2_reference_defaults_cuda_float64")
+        out = {**{k: out[k] for k in bulky if k in out}, **{k: v for k, v in out.items() if k not in bulky}}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -224,10 +224,16 @@ class BatchSharding:
             device = torch.device(device)
             on_gpu = device.type == "cuda" and dist.is_initialized()
             self._direct = False
-            # the [gradient | loss] message is a few KB: first choice is the one-shot exchange through IPC-shared inboxes
-            # (NDQ_ONESHOT_ALLREDUCE=0 skips it; up to 16 ranks of one node; works under gloo as well as nccl), then a RCCL
-            # communicator of our own driven from the native step, else torch.distributed
-            if on_gpu and os.environ.get("NDQ_ONESHOT_ALLREDUCE", "1") != "0" and 1 < self.world_size <= 16:
+            # the [gradient | loss] message is a few KB.  Default: the RCCL all-reduce north_star names, on a communicator of
+            # our own that the native step drives on the compute stream; torch.distributed if that cannot be set up.  The
+            # one-shot exchange through IPC-shared inboxes (csrc/ndq_oneshot.h; up to 16 ranks of one node; works under gloo as
+            # well as nccl) is OPT-IN (NDQ_ONESHOT_ALLREDUCE=1): it has only ever run between ranks sharing one device, never
+            # across an xGMI link -- it becomes the default under nccl once a node run has validated it
+            # (unset: under a process group that is NOT nccl -- the single-device dry runs and tests over gloo, where RCCL
+            # cannot run at all -- the one-shot exchange stays the choice)
+            choice = os.environ.get("NDQ_ONESHOT_ALLREDUCE")
+            want_oneshot = choice == "1" or (choice is None and dist.get_backend(self.group) != "nccl")
+            if on_gpu and want_oneshot and 1 < self.world_size <= 16:
                 one = OneShot(self.rank, self.world_size, self.group, device)
                 if one.ok:
                     self._direct = one
@@ -273,7 +279,8 @@ class BatchSharding:
 
     def _sum(self, t):
         # (message sizes are the same on every rank, so all ranks take the same branch)
-        if self.direct(t.device, t.numel()) is not None:
+        # (the native collectives move fp32; the fp64 pipeline's [gradient | loss] vector goes through torch.distributed)
+        if t.dtype == torch.float32 and self.direct(t.device, t.numel()) is not None:
             self._direct.all_reduce(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -285,8 +292,8 @@ class BatchSharding:
             grads = grads + [system.gtheta]          # trainable scalars of the equations: part of the same message
         loss = system.loss_buf[:n_batches]
         total = sum(g.numel() for g in grads) + n_batches
-        if self._flat is None or self._flat.numel() != total or self._flat.device != loss.device:
-            self._flat = torch.empty(total, dtype=torch.float32, device=loss.device)
+        if self._flat is None or self._flat.numel() != total or self._flat.device != loss.device or self._flat.dtype != loss.dtype:
+            self._flat = torch.empty(total, dtype=loss.dtype, device=loss.device)
         off = 0
         for t in grads + [loss]:
             self._flat[off:off + t.numel()].copy_(t.reshape(-1))

@@ -367,8 +367,8 @@ class BaseSolver(ABC):
             probe = self._dtype_probe = (net_ids, [p for p in (next(iter(n.parameters()), None) for n in self.nets) if p is not None])
         dtypes = {p.dtype for p in probe[1]}
         sys_dtype = torch.float64 if dtypes == {torch.float64} else torch.float32
-        if sys_dtype == torch.float64 and self.dist is not None:
-            reason = "fp64 networks under data parallelism"
+        # (fp64 under data parallelism: the per-batch launch sequence in double on every rank's shard, one all-reduce of the
+        # [gradient | loss] vector in double through torch.distributed, the device-side tail in double -- parallel.py)
         if self._loss_time_dependent:
             reason = "epoch-dependent loss function"
         key = (id(self.diff_eqs), net_ids, tuple(id(c) for c in self.conditions),

@@ -1,13 +1,20 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 (ROCm 7.2 rocpd sqlite) kernel trace as a per-kernel stats table (markdown/CSV-ish).
-usage: scripts/rocpd_stats.py <trace_results.db> [> profiles/xxx_kernel_stats.md]"""
+usage: scripts/rocpd_stats.py <trace_results.db> [> profiles/xxx_kernel_stats.md]
+
+One row per kernel VARIANT: the generated closure modules all instantiate templates whose pointwise program ``PW`` sits in an
+anonymous namespace, so the demangled name alone is the same for every generated closure of one ``Cfg`` (4- / 8-wave builds,
+other PDEs, other batch sizes).  Rows are therefore keyed on (name, workgroup size, grid, LDS bytes, scratch bytes, VGPRs,
+AGPRs): the headline launch -- 65 536 points, its own grid and register allocation -- gets a row of its own and
+``frac`` can be recomputed from this table alone."""
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
-                  "max(vgpr_count), max(accum_vgpr_count), max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x) "
-                  "from kernels group by name order by sum(duration) desc").fetchall()
+                  "vgpr_count, accum_vgpr_count, lds_size, scratch_size, grid_x, workgroup_x "
+                  "from kernels group by name, workgroup_x, grid_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count "
+                  "order by sum(duration) desc").fetchall()
 total = sum(r[2] for r in rows) or 1
 print("| kernel | calls | total_us | avg_us | min_us | max_us | % | vgpr | agpr | lds_B | scratch_B | grid_x | wg_x |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")

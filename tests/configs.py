@@ -151,6 +151,12 @@ def make(name, size=None):
         c = make("c3", size or 12)
         c["nets"] = [FCNN(2, 1, hidden_units=(128, 128, 128))]
         return c
+    if name == "w18r":    # w18 on a ragged batch: 251 x 261 = 65 511 points (tests/golden/make_golden.py: cfg_w18r)
+        c = make("w18", 12)
+        g = size or (251, 261)
+        c["gen"] = Generator2D(tuple(g), (-1, 0), (1, 1), "equally-spaced-noisy")
+        c["n_points"] = g[0] * g[1]
+        return c
     if name in ("w17", "w19"):     # lid-driven cavity on ONE three-output network (EnsembleCondition): 2 -> 512 -> 3 and the
         #                            RE100 notebook's FCNN(n_hidden_units=256, n_hidden_layers=1) = 2 -> 256 -> 256 -> 3
         re = 400.0 if name == "w17" else 100.0

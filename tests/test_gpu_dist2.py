@@ -18,7 +18,11 @@ def _train(name, size, epochs, sharding, info=None):
     from tests import configs
     from neurodiffeq_amd.parallel import BatchSharding
     torch.manual_seed(0)
-    solver, cfg = configs.make_solver(name, size)
+    f64 = name.endswith("/f64")               # fp64 networks: the reference's default precision
+    solver, cfg = configs.make_solver(name.split("/")[0], size)
+    if f64:
+        for net in cfg["nets"]:
+            net.double()
     solver.fused = "require"
     if sharding:
         solver.dist = BatchSharding()
@@ -123,6 +127,24 @@ def _worker_oneshot_raw(rank, world, port, out):
     if ok:
         one.close()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,size,world", [("c2/f64", 24, 2), ("c1/f64", 100, 3)])
+def test_fp64_ranks_equal_one_process_on_the_whole_batch(tmp_path, name, size, world):
+    """fp64 networks (neurodiffeq/__init__.py:22: the reference's import default) under data parallelism (VERDICT r4 missing
+    #2 / next #9): shards through the fp64 kernels, ONE all-reduce of the [gradient | loss] vector in double, the device-side
+    tail in double; replicas bit-identical, the run equals one process on the whole batch to fp64 rounding of the sums."""
+    epochs = 4
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "dp64")
+    mp.spawn(_worker, args=(world, port, name, size, epochs, out), nprocs=world, join=True)
+    rs = [np.load(out + f".{r}.npz") for r in range(world)]
+    for r in rs[1:]:
+        assert np.array_equal(rs[0]["params"], r["params"]) and np.array_equal(rs[0]["hist"], r["hist"])
+    assert rs[0]["params"].dtype == np.float64
+    hist, params = _train(name, size, epochs, sharding=False)
+    assert np.allclose(rs[0]["hist"], hist, rtol=1e-11), (rs[0]["hist"], hist)
+    assert np.linalg.norm(rs[0]["params"] - params) <= 1e-9 * np.linalg.norm(params)
 
 
 @pytest.mark.parametrize("world", [2, 4])
