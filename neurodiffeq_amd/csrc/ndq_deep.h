@@ -30,6 +30,13 @@
 #pragma once
 #include "ndq_mlp.h"
 
+#ifndef NDQ_DEEP_XCD_REMAP
+#define NDQ_DEEP_XCD_REMAP 1       // 0: plain blockIdx (A/B runs of the XCD-aware workgroup mapping, xcd_block_id below)
+#endif
+#ifndef NDQ_DEEP_HEAD_FUSED
+#define NDQ_DEEP_HEAD_FUSED 1      // 0: deep_head_bwd materialises Zbar_L (round 4); 1: its consumers form it from Z_L and the seeds
+#endif
+
 namespace ndq {
 
 template <int D_, int FIRST_, unsigned M2_, int LAP_, unsigned M3_, int W_, int L_, int ACT_, int NOUT_>
@@ -188,6 +195,23 @@ __device__ __forceinline__ void first_unit_streams(const real* __restrict__ prm,
   }
 }
 
+// XCD-aware workgroup id.  The dispatcher places block b on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"; a
+// pure speed assumption: any placement computes the same thing) and every XCD has its own 4 MiB L2.  The kernels below have
+// GROUPS of workgroups that read the same rows of a Z tensor at the same time -- the NT x NT output tiles of one point slice
+// in the weight-gradient GEMM, the NCH output chunks of one stripe of tiles in the per-point GEMMs.  With the plain id those
+// neighbours sit on different XCDs and every one of them pulls the rows from HBM (measured, round 4: 545 MB per
+// weight-gradient launch at 128 x 3 against 268 MB of operands).  The remapped id hands every XCD a CONTIGUOUS range of
+// virtual ids, so a group lands on one XCD, is dispatched within a few ids of each other, and its common rows come out of
+// that XCD's L2.  Bijective for any grid size (q = n / 8, r = n % 8: XCD x owns q + (x < r) ids).
+__device__ __forceinline__ int xcd_block_id() {
+#if NDQ_DEEP_XCD_REMAP
+  const int b = (int)blockIdx.x, n = (int)gridDim.x, x = b & 7, q = n >> 3, r = n & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+#else
+  return (int)blockIdx.x;
+#endif
+}
+
 struct DeepArgs {
   const real* coords;     // [D][ldc]
   const real* prm;        // [P]
@@ -201,6 +225,13 @@ struct DeepArgs {
   real* pw1;              // reverse into the first layer: partial rows of dW1 [stripes][HP][D]
   real* pw;               // weight gradient: partial tiles [KS][HP][HP]
   const void* wpl;        // bf16x3 route: the layer's weight planes in MFMA A-operand order (deep_prep_planes)
+  // head fused into its consumers (NDQ_DEEP_HEAD_FUSED): Zbar_L = act-backward(Z_L, Wout^T seeds) is never written -- zin is
+  // Z_L, and the kernels form Zbar_L from it and the seeds as they load
+  const real* gbar;       // [NS][NOUT][ldj] seeds of the output streams
+  int ldj;
+  real* pwo;              // partial rows of dWout [rows][NOUT][HP]   (weight-gradient GEMM of layer L, tiles of column block 0)
+  real* pbh;              // partial rows of db_L  [rows][HP]
+  real* pbo;              // partial rows of dbout [rows][NOUT]
 };
 
 // ------------------------------------------------------------------------------------------------ per-point GEMMs
@@ -480,7 +511,9 @@ __global__ __launch_bounds__(C::THREADS, NDQ_DEEP_OCC) void deep_bwd_gemm(DeepAr
 //             contraction chunks, <= 96 KB) resident in LDS for the whole launch: staged once, read by all four waves.
 //   operand   a lane's 8 contraction units of its point are two 16-byte loads per stream; sigma-jet (SRC 0 / 1) and the
 //             3-way split of step c + 1 are computed while the MFMAs of step c are in flight.
-// SRC: 0 = sigma-jet of the first layer, from the coordinates; 1 = sigma-jet(zin); 2 = zin as it is (reverse GEMM).
+// SRC: 0 = sigma-jet of the first layer, from the coordinates; 1 = sigma-jet(zin); 2 = zin as it is (reverse GEMM);
+//      3 = reverse GEMM of the LAST hidden layer with the head folded in: zin is Z_L, the operand Zbar_L =
+//          act-backward(Z_L, Wout^T seeds) is formed in registers (no deep_head_bwd pass, no Zbar_L tensor in HBM).
 // EPI: 0 = + bias, store Z_l; 1 = act-backward with Z_{l-1}, store Zbar_{l-1}, sum db_{l-1}; 2 = act-backward into the
 //      first layer (dW1, db1 partial rows).
 #ifndef NDQ_DEEP_BF_LDS_KB
@@ -501,7 +534,8 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
   constexpr int JB = deep_bf_jb<C, EPI>(), NCH = (C::NB + JB - 1) / JB, NCK = (C::HP + 31) / 32, NS = C::NS;
   extern __shared__ __attribute__((aligned(16))) bf16x8 wl[];          // [JB][NCK][3][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, kg = lane >> 4;
-  const int ch = blockIdx.x % NCH, bstripe = blockIdx.x / NCH, nbstripes = gridDim.x / NCH;
+  const int vid = xcd_block_id();                          // (the NCH chunks of a stripe share its operand rows: one XCD)
+  const int ch = vid % NCH, bstripe = vid / NCH, nbstripes = gridDim.x / NCH;
   if (bstripe >= nbstripes) return;                        // (whole workgroups: no barrier is missed)
   // ---- this workgroup's weight planes -> LDS, once
   {
@@ -567,8 +601,21 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
     // operand of contraction step c: this lane's units 32 c + 8 kg ... + 7 of its point
     real4 vlo[SRC == 0 ? 1 : NS], vhi[SRC == 0 ? 1 : NS];
     real f1w[SRC == 0 ? 8 : 1][C::D], f1b[SRC == 0 ? 8 : 1];
+    real wo8[SRC == 3 ? 8 : 1][C::NOUT], gs[SRC == 3 ? C::NC : 1];
+    if constexpr (SRC == 3) {                              // the point's seeds (padding points: zero -> Zbar_L = 0)
+#pragma unroll
+      for (int cc = 0; cc < C::NC; ++cc) gs[cc] = n < a.n ? a.gbar[(size_t)cc * a.ldj + nn] : 0.f;
+    }
     auto fetch = [&](int c) {
       const int k0 = 32 * c + 8 * kg;
+      if constexpr (SRC == 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool ok = k0 + e < C::W;
+#pragma unroll
+          for (int o = 0; o < C::NOUT; ++o) wo8[e][o] = ok ? a.prm[C::offWout + o * C::W + (ok ? k0 + e : 0)] : 0.f;
+        }
+      }
       if constexpr (SRC == 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -593,6 +640,26 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
       if constexpr (SRC == 2) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) { hlo[s] = vlo[s]; hhi[s] = vhi[s]; }
+      } else if constexpr (SRC == 3) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          real z[NS], g[NS], tt, cc;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            z[s] = e < 4 ? vlo[s][e & 3] : vhi[s][e & 3];
+            real v = 0.f;
+#pragma unroll
+            for (int o = 0; o < C::NOUT; ++o) v = rfma(wo8[e][o], gs[s * C::NOUT + o], v);
+            g[s] = v;
+          }
+          Act<C::ACT>::fwd(z[0], tt, cc);
+          jet_unit_backward<C>(z, tt, cc, g);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            if (e < 4) hlo[s][e & 3] = g[s];
+            else hhi[s][e & 3] = g[s];
+          }
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -747,12 +814,16 @@ __global__ __launch_bounds__(256) void deep_prep_planes(const real* __restrict__
 // workgroup.  A lane's 4 rows (columns) of the tile are the 4 CONSECUTIVE units it loads as one 16-byte value: MFMA block u
 // of the tile = units {4 i + u}, a relabelling of rows that costs nothing.  The next group's loads are issued before the
 // current group's MFMAs (the kernel has ~60 registers: 4 workgroups per CU hide the rest of the latency).
-template <class C, bool FIRSTIN>
+// HEAD (layer L with the head folded in, NDQ_DEEP_HEAD_FUSED): zin is Z_L; the row operand Zbar_L = act-backward(Z_L, Wout^T
+// seeds) is formed per lane from its 4 units of its point, and the tiles of column block 0 also leave what deep_head_bwd used
+// to: partial rows of dWout (seeds x sigma-jet(Z_L)), db_L (value stream of Zbar_L) and -- tile 0 -- dbout, one per wave.
+template <class C, bool FIRSTIN, bool HEAD = false>
 __global__ __launch_bounds__(C::THREADS, 2) void deep_wgrad_gemm(DeepArgs a) {
   __shared__ real comb[3][64][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kg = lane >> 4;
   constexpr int NT2 = C::NT * C::NT;
-  const int tl = blockIdx.x % NT2, ks = blockIdx.x / NT2, KS = gridDim.x / NT2;
+  const int vid = xcd_block_id();                          // (the NT x NT tiles of a point slice share its rows: one XCD)
+  const int tl = vid % NT2, ks = vid / NT2, KS = gridDim.x / NT2;
   if (ks >= KS) return;
   const int j0 = 64 * (tl / C::NT) + 4 * i, k0 = 64 * (tl % C::NT) + 4 * i;      // this lane's 4 row / column units
   const bool jok = j0 < C::HP, kok = k0 < C::HP;
@@ -776,8 +847,30 @@ __global__ __launch_bounds__(C::THREADS, 2) void deep_wgrad_gemm(DeepArgs a) {
   const int ngroups = a.np >> 2, g0 = ks * C::WAVES + wave, gstep = KS * C::WAVES;
   real4 za[C::NS], zk[FIRSTIN ? 1 : C::NS];
   real x[FIRSTIN ? C::D : 1];
+  // HEAD: Wout columns of this lane's 4 row units, the point's seeds (prefetched with the rows), the by-products
+  const bool side = HEAD && (tl % C::NT) == 0;
+  real wov[HEAD ? 4 : 1][C::NOUT], gsn[HEAD ? C::NC : 1], dwo[HEAD ? 4 : 1][C::NOUT], dbl[HEAD ? 4 : 1], gbo[HEAD ? C::NOUT : 1];
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const bool ok = j0 + v < C::W;
+      dbl[v] = 0.f;
+#pragma unroll
+      for (int o = 0; o < C::NOUT; ++o) {
+        wov[v][o] = ok ? a.prm[C::offWout + o * C::W + (ok ? j0 + v : 0)] : 0.f;
+        dwo[v][o] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < C::NOUT; ++o) gbo[o] = 0.f;
+  }
   auto fetch = [&](int g4) {
     const int n = 4 * g4 + kg;
+    if constexpr (HEAD) {
+      const int ns = n < a.n ? n : a.n - 1;
+#pragma unroll
+      for (int cc = 0; cc < C::NC; ++cc) gsn[cc] = n < a.n ? a.gbar[(size_t)cc * a.ldj + ns] : 0.f;
+    }
 #pragma unroll
     for (int s = 0; s < C::NS; ++s)
       za[s] = jok ? *reinterpret_cast<const real4*>(a.zin + s * sstride + (size_t)n * C::HP + j0) : real4{0.f, 0.f, 0.f, 0.f};
@@ -794,8 +887,38 @@ __global__ __launch_bounds__(C::THREADS, 2) void deep_wgrad_gemm(DeepArgs a) {
   if (g0 < ngroups) fetch(g0);
   for (int g4 = g0; g4 < ngroups; g4 += gstep) {
     real4 av[C::NS], hv[C::NS];
+    if constexpr (HEAD) {
 #pragma unroll
-    for (int s = 0; s < C::NS; ++s) av[s] = za[s];
+      for (int o = 0; o < C::NOUT; ++o) gbo[o] += gsn[o];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        real z[C::NS], g[C::NS], h[C::NS], tt, cc;
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+          z[s] = za[s][v];
+          real w = 0.f;
+#pragma unroll
+          for (int o = 0; o < C::NOUT; ++o) w = rfma(wov[v][o], gsn[s * C::NOUT + o], w);
+          g[s] = w;
+        }
+        if (side) {                                        // (workgroup-uniform)
+          jet_unit_forward<C>(z, h, tt, cc);
+#pragma unroll
+          for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+            for (int o = 0; o < C::NOUT; ++o) dwo[v][o] = rfma(gsn[s * C::NOUT + o], h[s], dwo[v][o]);
+        } else {
+          Act<C::ACT>::fwd(z[0], tt, cc);
+        }
+        jet_unit_backward<C>(z, tt, cc, g);
+        dbl[v] += g[0];
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) av[s][v] = g[s];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s) av[s] = za[s];
+    }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       real z[C::NS], h[C::NS], tt, cc;
@@ -825,6 +948,25 @@ __global__ __launch_bounds__(C::THREADS, 2) void deep_wgrad_gemm(DeepArgs a) {
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[u][v] = mfma16x16x4(av[s][u], hv[s][v], acc[u][v]);
+  }
+  if constexpr (HEAD) {
+    // by-products: one partial row per WAVE; a lane's sums run over the points with contraction slot kg -> + the 4 slots
+    const int row = ks * C::WAVES + wave;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const real db = quad_sum(dbl[v]);
+      if (side && kg == 0 && j0 + v < C::HP) a.pbh[(size_t)row * C::HP + j0 + v] = db;
+#pragma unroll
+      for (int o = 0; o < C::NOUT; ++o) {
+        const real dw = quad_sum(dwo[v][o]);
+        if (side && kg == 0 && j0 + v < C::HP) a.pwo[((size_t)row * C::NOUT + o) * C::HP + j0 + v] = dw;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < C::NOUT; ++o) {
+      const real gb = quad_sum(gbo[o]);
+      if (tl == 0 && lane == 0) a.pbo[(size_t)row * C::NOUT + o] = gb;
+    }
   }
   // waves 1 .. 3 -> LDS, wave 0 adds them in order and stores the workgroup's partial tile
   if (wave > 0) {

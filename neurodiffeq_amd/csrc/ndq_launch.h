@@ -287,6 +287,7 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
     J.nblocks += (rows * cols + 63) / 64;
   };
   constexpr int UG = (C::HP + 63) / 64;
+#if !NDQ_DEEP_HEAD_FUSED
   {
     DeepHeadArgs h{};
     h.prm = params; h.z = ws + q.z0 + (size_t)(C::L - 2) * q.X; h.gbar = gbar; h.zbar = ws + q.zb0;
@@ -298,6 +299,9 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
     reduce(h.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb(C::L));
     reduce(h.pbo, stripes, 1, C::NOUT, 1, C::NOUT, grad + C::offbout);
   }
+#else
+  (void)UG;
+#endif
   int cur = 0;
   const int ntiles = q.np / 16;
   for (int l = C::L; l >= 2; --l) {
@@ -305,6 +309,17 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
     a.coords = coords; a.prm = params; a.n = n; a.np = q.np; a.ldc = ldc;
     a.zin = ws + q.zb0 + (size_t)cur * q.X;                               // Zbar_l
     a.zprev = l > 2 ? ws + q.z0 + (size_t)(l - 3) * q.X : nullptr;        // Z_{l-1}
+#if NDQ_DEEP_HEAD_FUSED
+    // layer L with the head folded in: no deep_head_bwd pass, no Zbar_L in HBM -- both consumers read Z_L and the seeds
+    const bool head = l == C::L;
+    if (head) {
+      a.zin = ws + q.z0 + (size_t)(C::L - 2) * q.X;                       // Z_L
+      a.gbar = gbar; a.ldj = ldj;
+      a.pwo = ws + q.pwo; a.pbh = ws + q.pb + (size_t)(C::L - 1) * q.pb_layer; a.pbo = ws + q.pbo;
+    }
+#else
+    constexpr bool head = false;
+#endif
     {   // dW_l
       a.pw = ws + q.pw + (size_t)(l - 2) * q.pw_layer;
       // one workgroup per (tile, point slice)
@@ -312,7 +327,13 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       if (KS > 2 * q.blocks_max / (C::NT * C::NT)) KS = 2 * q.blocks_max / (C::NT * C::NT);      // two workgroups per CU
       if (KS < 1) KS = 1;
       const int blocks = KS * C::NT * C::NT;
-      if (l == 2) hipLaunchKernelGGL((deep_wgrad_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+      if (head) {
+        if (l == 2) hipLaunchKernelGGL((deep_wgrad_gemm<C, true, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+        else hipLaunchKernelGGL((deep_wgrad_gemm<C, false, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+        reduce(a.pwo, KS * C::WAVES, C::NOUT, C::HP, C::NOUT, C::W, grad + C::offWout);
+        reduce(a.pbh, KS * C::WAVES, 1, C::HP, 1, C::W, grad + C::offb(C::L));
+        reduce(a.pbo, KS * C::WAVES, 1, C::NOUT, 1, C::NOUT, grad + C::offbout);
+      } else if (l == 2) hipLaunchKernelGGL((deep_wgrad_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
       else hipLaunchKernelGGL((deep_wgrad_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
       reduce(a.pw, KS, C::HP, C::HP, C::W, C::W, grad + C::offW(l));
     }
@@ -325,6 +346,10 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       if (!attr) {
         int e = deep_set_lds(&deep_gemm_bf<C, 2, 1>, deep_bf_lds_bytes<C, 1>());
         if (!e) e = deep_set_lds(&deep_gemm_bf<C, 2, 2>, deep_bf_lds_bytes<C, 2>());
+#if NDQ_DEEP_HEAD_FUSED
+        if (!e) e = deep_set_lds(&deep_gemm_bf<C, 3, 1>, deep_bf_lds_bytes<C, 1>());
+        if (!e) e = deep_set_lds(&deep_gemm_bf<C, 3, 2>, deep_bf_lds_bytes<C, 2>());
+#endif
         if (e) return e;
         attr = true;
       }
@@ -338,14 +363,16 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       constexpr int NCHB1 = (C::NB + deep_bf_jb<C, 1>() - 1) / deep_bf_jb<C, 1>();
       a.zout = ws + q.zb0 + (size_t)(cur ^ 1) * q.X;
       const int stripes = bf_stripes(NCHB1);
-      hipLaunchKernelGGL((deep_gemm_bf<C, 2, 1>), dim3(stripes * NCHB1), dim3(C::THREADS), (deep_bf_lds_bytes<C, 1>()), st, a);
+      if (head) hipLaunchKernelGGL((deep_gemm_bf<C, 3, 1>), dim3(stripes * NCHB1), dim3(C::THREADS), (deep_bf_lds_bytes<C, 1>()), st, a);
+      else hipLaunchKernelGGL((deep_gemm_bf<C, 2, 1>), dim3(stripes * NCHB1), dim3(C::THREADS), (deep_bf_lds_bytes<C, 1>()), st, a);
       reduce(a.pb, stripes * C::WAVES, 1, C::HP, 1, C::W, grad + C::offb(l - 1));
       cur ^= 1;
     } else {
       constexpr int NCHB2 = (C::NB + deep_bf_jb<C, 2>() - 1) / deep_bf_jb<C, 2>();
       a.pw1 = ws + q.pw1;
       const int stripes = bf_stripes(NCHB2);
-      hipLaunchKernelGGL((deep_gemm_bf<C, 2, 2>), dim3(stripes * NCHB2), dim3(C::THREADS), (deep_bf_lds_bytes<C, 2>()), st, a);
+      if (head) hipLaunchKernelGGL((deep_gemm_bf<C, 3, 2>), dim3(stripes * NCHB2), dim3(C::THREADS), (deep_bf_lds_bytes<C, 2>()), st, a);
+      else hipLaunchKernelGGL((deep_gemm_bf<C, 2, 2>), dim3(stripes * NCHB2), dim3(C::THREADS), (deep_bf_lds_bytes<C, 2>()), st, a);
       reduce(a.pb, stripes * C::WAVES, 1, C::HP, 1, C::W, grad + C::offb1);
       reduce(a.pw1, stripes * C::WAVES, C::HP, C::D, C::W, C::D, grad + C::offW1);
     }
