@@ -407,7 +407,7 @@ def fp64_record():
                 final_loss=solver.metrics_history["train_loss"][-1])
 
 
-def reference_defaults_record():
+def reference_defaults_record(name="c2", size=None):
     """What importing the reference sets up -- cuda default device AND float64 default dtype (neurodiffeq/__init__.py:22,
     utils.py:10-41) -- then a plain Solver2D with its noisy 256 x 256 generator, nothing else changed: a fresh batch every
     epoch from the Philox kernel (fp32 draws handed out as doubles), the closure kernel in double, bookkeeping on the device."""
@@ -416,7 +416,7 @@ def reference_defaults_record():
     try:
         set_tensor_type(device="cuda", float_bits=64)
         torch.manual_seed(0)
-        solver, cfg = configs.make_solver("c2")
+        solver, cfg = configs.make_solver(name, size)
         solver.fused = "require"
         assert next(cfg["nets"][0].parameters()).dtype == torch.float64
         for _ in range(20):
@@ -429,6 +429,7 @@ def reference_defaults_record():
         assert solver.fused_active and solver._fused_sys.f64
         return dict(points=n, dtype="f64", ms_per_step=dt * 1e3, points_per_s=n / dt, windows=len(times), steps_per_window=k,
                     generator=type(solver.generator["train"].generator).__name__,
+                    single_launch=solver._fused_sys.fusedk is not None,
                     note="set_tensor_type('cuda', 64) as `import neurodiffeq` does, plain Solver2D + Generator2D: sampling, "
                          "closure in double, Adam and history all on the device",
                     final_loss=solver.metrics_history["train_loss"][-1])
@@ -767,6 +768,10 @@ def main():
                 out["c2_reference_defaults_cuda_float64"] = reference_defaults_record()
             except Exception as e:                      # a side figure must not cost the bench line
                 out["c2_reference_defaults_cuda_float64"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:        # ... and the same two import defaults with the README's own network, FCNN(2, 1, hidden_units=(512,))
+                out["readme_512_reference_defaults_cuda_float64"] = reference_defaults_record("w16", GRID)
+            except Exception as e:
+                out["readme_512_reference_defaults_cuda_float64"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cold_start and (args.cold_start or not args.no_configs):
             try:
                 out["cold_start"] = cold_start()
@@ -788,7 +793,8 @@ def main():
         # ONE JSON line; the bulky side records first, the contract keys and the compact headline figures (roofline,
         # cpu_baseline, in_fit, with_*_sampling, default_generator_cuda) LAST: whoever keeps only the tail of this process's
         # stdout still sees the headline
-        bulky = ("kernels", "configs", "cold_start", "roofline_pointwise_large", "c2_fp64", "c2_reference_defaults_cuda_float64")
+        bulky = ("kernels", "configs", "cold_start", "roofline_pointwise_large", "c2_fp64", "c2_reference_defaults_cuda_float64",
+                 "readme_512_reference_defaults_cuda_float64")
         out = {**{k: out[k] for k in bulky if k in out}, **{k: v for k, v in out.items() if k not in bulky}}
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -1148,6 +1148,7 @@ extern "C" void ndq_ext_reuse_forward(int on) {{ ndq::deep_last().reuse = on != 
     if is_wide(desc):
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one single-hidden-layer FCNN wider
 // than 64 units (csrc/ndq_wide.h)
+{"#define NDQ_F64 1" if f64 else ""}
 #include "{header}"
 using CFG = {wide_cfg(desc)};
 extern "C" const {record}* ndq_ext_kernels(void) {{
@@ -1192,7 +1193,9 @@ def ensure_mlp_kernels(desc, f64=False):
     register = L.ndq64_mlp_register if f64 else L.ndq_mlp_register
     if supported(ctypes.byref(desc)):
         return True
-    if not mlp_ext_allowed(desc) or (f64 and desc.hidden > 64):     # (no fp64 build of csrc/ndq_wide.h)     # fp64: twice the LDS per weight -- ndq64_mlp_register turns down what does not fit
+    # fp64: twice the LDS per weight -- ndq64_mlp_register turns down what does not fit; wider than 64 units only ONE hidden
+    # layer (csrc/ndq_wide.h compiled in double: forward-stream and adjoint kernels; csrc/ndq_deep.h is fp32 only)
+    if not mlp_ext_allowed(desc) or (f64 and desc.hidden > 64 and desc.layers != 1):
         return False
     key = desc.key() + (("f64",) if f64 else ())
     if key in _MLP_EXT:

@@ -28,7 +28,8 @@ static bool same_desc(const ndq_mlp_desc& a, const ndq_mlp_desc& b) {
 }
 
 static const ndq64_mlp_kernels* find64(const ndq_mlp_desc* d) {
-  if (!d || d->hidden < 1 || d->hidden > 64) return nullptr;
+  // (hidden > 64: ONE hidden layer of up to 512 units -- csrc/ndq_wide.h compiled in double, registered extension modules only)
+  if (!d || d->hidden < 1 || d->hidden > (d->layers == 1 ? 512 : 64)) return nullptr;
   for (const ndq64_mlp_kernels& e : kTable64)
     if (same_desc(e.desc, *d)) return &e;
   for (const ndq64_mlp_kernels* e : g_registered64)
@@ -134,7 +135,7 @@ extern "C" {
 int ndq64_mlp_supported(const ndq_mlp_desc* desc) { return find64(desc) ? 1 : 0; }
 
 int ndq64_mlp_register(const ndq64_mlp_kernels* k) {
-  if (!k || !k->fwd || !k->bwd || k->desc.hidden < 1 || k->desc.hidden > 64 || k->n_streams < 1 || k->n_params < 1 || k->bwd_waves < 1 ||
+  if (!k || !k->fwd || !k->bwd || k->desc.hidden < 1 || k->desc.hidden > (k->desc.layers == 1 ? 512 : 64) || k->n_streams < 1 || k->n_params < 1 || k->bwd_waves < 1 ||
       k->lds_bytes > 160 * 1024)
     return NDQ_EINVAL;
   if (!find64(&k->desc)) g_registered64.push_back(k);

@@ -232,6 +232,7 @@ struct DeepArgs {
   real* pwo;              // partial rows of dWout [rows][NOUT][HP]   (weight-gradient GEMM of layer L, tiles of column block 0)
   real* pbh;              // partial rows of db_L  [rows][HP]
   real* pbo;              // partial rows of dbout [rows][NOUT]
+  real* jets;             // EPI 3 (last forward GEMM with the head folded in): output streams [NS][NOUT][ldj]
 };
 
 // ------------------------------------------------------------------------------------------------ per-point GEMMs
@@ -515,7 +516,9 @@ __global__ __launch_bounds__(C::THREADS, NDQ_DEEP_OCC) void deep_bwd_gemm(DeepAr
 //      3 = reverse GEMM of the LAST hidden layer with the head folded in: zin is Z_L, the operand Zbar_L =
 //          act-backward(Z_L, Wout^T seeds) is formed in registers (no deep_head_bwd pass, no Zbar_L tensor in HBM).
 // EPI: 0 = + bias, store Z_l; 1 = act-backward with Z_{l-1}, store Zbar_{l-1}, sum db_{l-1}; 2 = act-backward into the
-//      first layer (dW1, db1 partial rows).
+//      first layer (dW1, db1 partial rows); 3 = EPI 0 of the LAST hidden layer with the output layer folded in (one chunk
+//      holds all units, NCH == 1: W <= 128): u_s = Wout sigma-jet(Z_L)_s + bout from the accumulators -- no deep_head_fwd
+//      pass re-reading Z_L.
 #ifndef NDQ_DEEP_BF_LDS_KB
 #define NDQ_DEEP_BF_LDS_KB 96      // LDS a workgroup spends on its resident weight planes (48: two workgroups per CU)
 #endif
@@ -523,7 +526,7 @@ constexpr int kDeepBfOcc = NDQ_DEEP_BF_LDS_KB <= 48 ? 2 : 1;
 template <class C, int EPI> constexpr int deep_bf_jb() {
   constexpr int NCK = (C::HP + 31) / 32;
   int j = (NDQ_DEEP_BF_LDS_KB / 3) / NCK;                  // planes of the chunk: 3 KB per (block, contraction chunk)
-  const int most = EPI == 0 ? C::JBC : (EPI == 1 ? C::JBB : C::JBF);
+  const int most = (EPI == 0 || EPI == 3) ? C::JBC : (EPI == 1 ? C::JBB : C::JBF);
   j = j > most ? most : j;
   j = j < 1 ? 1 : j;
   return C::balanced(j);
@@ -553,17 +556,24 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
   const int ntiles = a.np >> 4;
   const size_t sstride = (size_t)a.np * C::HP;
   // per-wave constants of the epilogue
-  real4 bs[EPI == 0 ? JB : 1];
+  constexpr bool STORE = EPI == 0 || EPI == 3;             // forward GEMM: + bias, store Z_l
+  static_assert(EPI != 3 || NCH == 1, "the folded output layer needs all units of a point in one workgroup");
+  real4 bs[STORE ? JB : 1];
   real u1w[EPI == 2 ? JB : 1][4][C::D], u1b[EPI == 2 ? JB : 1][4];
-  real gb[EPI != 0 ? JB : 1][4], gw1[EPI == 2 ? JB : 1][4][C::D];
+  real gb[!STORE ? JB : 1][4], gw1[EPI == 2 ? JB : 1][4][C::D];
+  real wout[EPI == 3 ? JB : 1][4][C::NOUT];
 #pragma unroll
   for (int jb = 0; jb < JB; ++jb) {
     const int j0 = 16 * (ch * JB + jb) + 4 * kg;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool ok = j0 + r < C::W;
-      if constexpr (EPI == 0) bs[jb][r] = ok ? a.bias[ok ? j0 + r : 0] : 0.f;
-      if constexpr (EPI != 0) gb[jb][r] = 0.f;
+      if constexpr (STORE) bs[jb][r] = ok ? a.bias[ok ? j0 + r : 0] : 0.f;
+      if constexpr (EPI == 3) {
+#pragma unroll
+        for (int o = 0; o < C::NOUT; ++o) wout[jb][r][o] = ok ? a.prm[C::offWout + o * C::W + (ok ? j0 + r : 0)] : 0.f;
+      }
+      if constexpr (!STORE) gb[jb][r] = 0.f;
       if constexpr (EPI == 2) {
         u1b[jb][r] = ok ? a.prm[C::offb1 + (ok ? j0 + r : 0)] : 0.f;
 #pragma unroll
@@ -707,16 +717,34 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
       if (c + 1 < NCK) planes();                           // VALU work of the next step, under the MFMAs in flight
     }
     // ---- epilogue
+    real uo[EPI == 3 ? C::NC : 1];
+    if constexpr (EPI == 3) {
+#pragma unroll
+      for (int cc = 0; cc < C::NC; ++cc) uo[cc] = 0.f;
+    }
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
       const int b = ch * JB + jb;
       if (b < C::NB) {
         const int j0 = 16 * b + 4 * kg;
-        if constexpr (EPI == 0) {
+        if constexpr (STORE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[0][jb][r] += bs[jb][r];
 #pragma unroll
           for (int s = 0; s < NS; ++s) *reinterpret_cast<real4*>(a.zout + s * sstride + (size_t)n * C::HP + j0) = acc[s][jb];
+          if constexpr (EPI == 3) {                        // output layer on the accumulators (deep_head_fwd's arithmetic)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              real z[NS], h[NS], tt, cc;
+#pragma unroll
+              for (int s = 0; s < NS; ++s) z[s] = acc[s][jb][r];
+              jet_unit_forward<C>(z, h, tt, cc);
+#pragma unroll
+              for (int o = 0; o < C::NOUT; ++o)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) uo[s * C::NOUT + o] = rfma(wout[jb][r][o], h[s], uo[s * C::NOUT + o]);
+            }
+          }
         } else {
           real4 out[NS];
 #pragma unroll
@@ -756,8 +784,16 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
         }
       }
     }
+    if constexpr (EPI == 3) {
+#pragma unroll
+      for (int cc = 0; cc < C::NC; ++cc) {
+        real v = quad_sum(uo[cc]);
+        if (cc < C::NOUT) v += a.prm[C::offbout + cc];
+        if (n < a.n && (cc & 3) == kg) a.jets[(size_t)cc * a.ldj + n] = v;
+      }
+    }
   }
-  if constexpr (EPI != 0) {
+  if constexpr (!STORE) {
     // partial rows: one per WAVE (row index = workgroup stripe x 4 + wave), every chunk fills its own units
     const int row = bstripe * C::WAVES + wave;
 #pragma unroll

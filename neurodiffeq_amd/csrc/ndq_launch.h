@@ -7,8 +7,8 @@
 #define NDQ_WG_TR 1     // adjoint kernels of H = 32 networks: weight gradients from the bf16x3 planes (ndq_mlp.h Cfg::WG_TR)
 #endif
 #include "ndq_mlp.h"
+#include "ndq_wide.h"     // one hidden layer of 65 .. 512 units (fp32; fp64: the forward-stream / adjoint kernels, round 5)
 #if !NDQ_F64
-#include "ndq_wide.h"     // one hidden layer of 65 .. 512 units (fp32 only)
 #include "ndq_deep.h"     // 2 .. 8 hidden layers of 65 .. 512 units (fp32 only)
 #endif
 #include "../../include/ndq.h"
@@ -93,7 +93,6 @@ kernels_record make_kernels() {
 
 // ---- one hidden layer of 65 .. 512 units (ndq_wide.h): the same record, so ndq_mlp_register / ndq_mlp_jet_fwd / _bwd
 // serve these shapes like any other
-#if !NDQ_F64
 template <class C>
 int wide_kernels_fwd(const real* coords, int ldc, int n, const real* params, real* jets, int ldj, void* stream) {
   MlpArgs a{};
@@ -144,6 +143,7 @@ kernels_record make_wide_kernels() {
   return k;
 }
 
+#if !NDQ_F64
 // ---- two or more hidden layers of 65 .. 512 units (ndq_deep.h): layer by layer through a workspace in HBM.  The module
 // owns that workspace (hipMalloc on first use, grown when a larger batch arrives, never inside a timed steady state); the
 // adjoint entry recomputes the forward layers like every ndq_mlp_jet_bwd and writes ONE row of "partials" -- the gradient
@@ -208,9 +208,16 @@ inline int deep_blocks(long waves, int min_waves, int cap) {
 }
 
 // forward layers 2 .. L into the workspace (shared by the two entry points)
+// jets != nullptr (forward entry point): when one output chunk holds all units (NCH == 1: W <= 128) the LAST layer's GEMM
+// also computes the output streams (deep_gemm_bf EPI 3) and the caller skips deep_head_fwd; returns 1 in *head_done then.
+#ifndef NDQ_DEEP_HEAD_FWD_FUSED
+#define NDQ_DEEP_HEAD_FWD_FUSED 1
+#endif
 template <class C>
-int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc, int n, const real* params, hipStream_t st) {
+int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc, int n, const real* params, hipStream_t st,
+                        real* jets = nullptr, int ldj = 0, int* head_done = nullptr) {
   const int ntiles = q.np / 16;
+  if (head_done) *head_done = 0;
 #if NDQ_DEEP_BF16X3
   hipLaunchKernelGGL(deep_prep_planes<C>, dim3(64, C::L - 1), dim3(256), 0, st, params, reinterpret_cast<bf16x8*>(ws + q.wpl),
                      reinterpret_cast<bf16x8*>(ws + q.wtl));
@@ -219,6 +226,10 @@ int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc
   if (!attr) {
     int e = deep_set_lds(&deep_gemm_bf<C, 0, 0>, deep_bf_lds_bytes<C, 0>());
     if (!e) e = deep_set_lds(&deep_gemm_bf<C, 1, 0>, deep_bf_lds_bytes<C, 0>());
+    if constexpr (NCHB0 == 1 && NDQ_DEEP_HEAD_FWD_FUSED) {
+      if (!e) e = deep_set_lds(&deep_gemm_bf<C, 0, 3>, deep_bf_lds_bytes<C, 0>());
+      if (!e) e = deep_set_lds(&deep_gemm_bf<C, 1, 3>, deep_bf_lds_bytes<C, 0>());
+    }
     if (e) return e;
     attr = true;
   }
@@ -238,6 +249,17 @@ int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc
     a.zin = l > 2 ? ws + q.z0 + (size_t)(l - 3) * q.X : nullptr;
     a.zout = ws + q.z0 + (size_t)(l - 2) * q.X;
 #if NDQ_DEEP_BF16X3
+    bool folded = false;
+    if constexpr (NCHB0 == 1 && NDQ_DEEP_HEAD_FWD_FUSED) {
+      if (jets && l == C::L) {
+        a.jets = jets; a.ldj = ldj;
+        if (l == 2) hipLaunchKernelGGL((deep_gemm_bf<C, 0, 3>), dim3(stripes), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
+        else hipLaunchKernelGGL((deep_gemm_bf<C, 1, 3>), dim3(stripes), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
+        folded = true;
+        if (head_done) *head_done = 1;
+      }
+    }
+    if (folded) continue;
     if (l == 2) hipLaunchKernelGGL((deep_gemm_bf<C, 0, 0>), dim3(stripes * NCHB0), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
     else hipLaunchKernelGGL((deep_gemm_bf<C, 1, 0>), dim3(stripes * NCHB0), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
 #else
@@ -254,10 +276,12 @@ int deep_kernels_fwd(const real* coords, int ldc, int n, const real* params, rea
   real* ws = deep_workspace(q.total);
   if (!ws) return (int)hipErrorOutOfMemory;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  int rc = deep_forward_layers<C>(q, ws, coords, ldc, n, params, st);
+  int head_done = 0;
+  int rc = deep_forward_layers<C>(q, ws, coords, ldc, n, params, st, jets, ldj, &head_done);
   if (rc) return rc;
   DeepLast& last = deep_last();
   last.coords = coords; last.params = params; last.n = n; last.ldc = ldc;
+  if (head_done) return (int)hipGetLastError();          // (the last layer's GEMM wrote the output streams itself)
   DeepHeadArgs h{};
   h.prm = params; h.z = ws + q.z0 + (size_t)(C::L - 2) * q.X; h.jets = jets; h.n = n; h.np = q.np; h.ldj = ldj;
   hipLaunchKernelGGL(deep_head_fwd<C>, dim3(deep_blocks(q.np / 16, 1, 4 * q.blocks_max)), dim3(C::THREADS), 0, st, h);
@@ -287,8 +311,7 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
     J.nblocks += (rows * cols + 63) / 64;
   };
   constexpr int UG = (C::HP + 63) / 64;
-#if !NDQ_DEEP_HEAD_FUSED
-  {
+  if (!NDQ_DEEP_HEAD_FUSED || C::HP > 128) {
     DeepHeadArgs h{};
     h.prm = params; h.z = ws + q.z0 + (size_t)(C::L - 2) * q.X; h.gbar = gbar; h.zbar = ws + q.zb0;
     h.pwo = ws + q.pwo; h.pb = ws + q.pb + (size_t)(C::L - 1) * q.pb_layer; h.pbo = ws + q.pbo; h.n = n; h.np = q.np; h.ldj = ldj;
@@ -299,9 +322,6 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
     reduce(h.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb(C::L));
     reduce(h.pbo, stripes, 1, C::NOUT, 1, C::NOUT, grad + C::offbout);
   }
-#else
-  (void)UG;
-#endif
   int cur = 0;
   const int ntiles = q.np / 16;
   for (int l = C::L; l >= 2; --l) {
@@ -310,8 +330,11 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
     a.zin = ws + q.zb0 + (size_t)cur * q.X;                               // Zbar_l
     a.zprev = l > 2 ? ws + q.z0 + (size_t)(l - 3) * q.X : nullptr;        // Z_{l-1}
 #if NDQ_DEEP_HEAD_FUSED
-    // layer L with the head folded in: no deep_head_bwd pass, no Zbar_L in HBM -- both consumers read Z_L and the seeds
-    const bool head = l == C::L;
+    // layer L with the head folded in: no deep_head_bwd pass, no Zbar_L in HBM -- both consumers read Z_L and the seeds.
+    // Only where every consumer forms a unit's Zbar_L ONCE (HP <= 128: one output chunk in the reverse GEMM, 2 x 2 tiles in the
+    // weight-gradient GEMM); at W = 256 the same arithmetic would be repeated by 4 chunks and 4 tile columns -- measured
+    // (profiles/r05b_deep_ab.md): 128 x 3 602 -> 585 us per step, 256 x 2 1112 -> 1171 us, so the wider shapes keep the pass
+    const bool head = l == C::L && C::HP <= 128;
     if (head) {
       a.zin = ws + q.z0 + (size_t)(C::L - 2) * q.X;                       // Z_L
       a.gbar = gbar; a.ldj = ldj;

@@ -310,12 +310,23 @@ __device__ __forceinline__ void wide_round_backward(const WideUnits<C>& un, cons
   }
 }
 
+// (wave-uniform read of one lane's value; fp64: two 32-bit halves)
+__device__ __forceinline__ real readlane_real(real v, int lane) {
+#if NDQ_F64
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+#else
+  return __builtin_bit_cast(real, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+#endif
+}
+
 // coordinates of this lane's point in round r: lane l < 16 of xv holds point l of the tile
 template <class C>
 __device__ __forceinline__ void wide_round_coords(const real (&xv)[C::D], int r, int pl, real (&x)[C::D]) {
 #pragma unroll
   for (int a = 0; a < C::D; ++a) {
-    if constexpr (C::PL == 1) x[a] = __builtin_bit_cast(real, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[a]), r));
+    if constexpr (C::PL == 1) x[a] = readlane_real(xv[a], r);
     else x[a] = __shfl(xv[a], r * C::PL + pl);
   }
 }

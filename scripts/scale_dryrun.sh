@@ -17,8 +17,8 @@ for n in ${GPUS:-2 4 8}; do
     --master-addr 127.0.0.1 --master-port $port bench.py --gpus $n --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-traffic \
     > "$OUT/dryrun_$n.out" 2> "$OUT/dryrun_$n.err"
   rc=$?
-  grep "^{" "$OUT/dryrun_$n.out" | tail -n 1 > "$OUT/r04_scale_dryrun_$n.json"
-  python - "$OUT/r04_scale_dryrun_$n.json" $n $rc <<'PY'
+  grep "^{" "$OUT/dryrun_$n.out" | tail -n 1 > "$OUT/scale_dryrun_$n.json"
+  python - "$OUT/scale_dryrun_$n.json" $n $rc <<'PY'
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
@@ -28,3 +28,9 @@ except Exception as e:
     print(f"n={sys.argv[2]} rc={sys.argv[3]} NO JSON LINE ({e})")
 PY
 done
+# ... and the strong-scaling form of a big config (bench.py --config c3 --scaling strong: 262 144 points cut into 8 shards)
+port=$((port + 1))
+NDQ_BENCH_DEVICE=0 NDQ_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+  --master-addr 127.0.0.1 --master-port $port bench.py --gpus 8 --config c3 --scaling strong --steps 10 --warmup 3 --no-cpu-baseline \
+  > "$OUT/dryrun_c3_strong_8.out" 2> "$OUT/dryrun_c3_strong_8.err"
+echo "c3 strong 8 ranks rc=$?"; grep "^{" "$OUT/dryrun_c3_strong_8.out" | tail -n 1 | tee "$OUT/scale_dryrun_c3_strong_8.json" | cut -c1-400

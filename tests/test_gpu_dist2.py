@@ -82,7 +82,8 @@ def test_direct_rccl_communicator_world_size_one(tmp_path):
     assert np.allclose(r["hist"], hist, rtol=2e-5) and np.linalg.norm(r["params"] - params) <= 2e-5 * np.linalg.norm(params)
 
 
-@pytest.mark.parametrize("name,size,world", [("c2", 32, 2), ("c1", 250, 2), ("c2", 33, 3), ("c2", 32, 4), ("c5", 8, 4)])
+@pytest.mark.parametrize("name,size,world", [("c2", 32, 2), ("c1", 250, 2), ("c2", 33, 3), ("c2", 32, 4), ("c5", 8, 4),
+                                             ("c3", 40, 8)])        # (8 ranks: the node size the driver's scaling run uses)
 def test_ranks_equal_one_process_on_the_whole_batch(tmp_path, name, size, world):
     """2 .. 4 ranks (processes sharing cuda:0).  The [gradient | loss] exchange is the ONE-SHOT all-reduce
     (csrc/ndq_oneshot.h: every rank writes into every peer's HIP-IPC-shared inbox, fixed-order local sum -- IPC handles

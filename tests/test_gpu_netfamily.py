@@ -453,7 +453,7 @@ def test_network_family_solver_trajectory_matches_reference_golden(golden_dir, n
 
 
 @pytest.mark.parametrize("name", ["c1", "c2", "c4", "w1", "w2", "w3", "w4", "w5", "w6", "w7", "w8", "w9", "w10", "w11", "w12", "w13",
-                                  "w14", "w15"])
+                                  "w14", "w15", "w16", "w17"])      # (w16 / w17: one hidden layer of 512 units, csrc/ndq_wide.h in double)
 @pytest.mark.parametrize("mode", ["3k", "1k"])
 def test_fp64_pipeline_matches_reference_golden(golden_dir, name, mode):
     """The fp64 pipeline against numbers the unmodified reference produced IN ITS DEFAULT PRECISION: every golden file
