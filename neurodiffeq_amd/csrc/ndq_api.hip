@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   // measured 5e-6 off at C5; the adds are nothing next to the loads
   double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
   int r = 0;
+#pragma unroll 4                      // (16 loads in flight per thread instead of 4: the chains stay in order)
   for (; r + 3 < nparts; r += 4) {
     s0 += (double)part[(size_t)r * len + i];
     s1 += (double)part[(size_t)(r + 1) * len + i];
@@ -122,23 +123,65 @@ struct Reduce2Args {
   const float* lpart; int nlparts; float* lout; float lscale;
 };
 
+// ---- the per-thread part of a column sum with EVERY load in flight before the first add (round 5).
+// The loops "for (r = rg; r + 48 < nparts; r += 64) { s0 += ..; s1 += ..; s2 += ..; s3 += ..; }" below compile to four
+// loads, s_waitcnt vmcnt(0), four adds, branch: with the closure kernel's 256 partial rows that is FOUR dependent round
+// trips to memory written by the previous launch (i.e. HBM / another XCD's L2, ~0.7 us each) inside a kernel whose whole
+// duration is 5 us -- and the loss-partial loop in front of it and the parameter / moment loads behind it add three more.
+// ColumnRows issues the first 16 rows of a thread (rows rg, rg + 16, ..., rg + 240: all of them for nparts <= 256, the
+// closure kernels' maximum) as straight-line clamped loads; finish() adds them in EXACTLY the order of the loops it
+// replaces (rows beyond nparts contribute +0.0f), then walks any further rows the old way.
+struct ColumnRows {
+  float v[16];
+  // UNCONDITIONAL clamped loads: a load whose value is only selected under "row < nparts" gets sunk into that branch by the
+  // compiler (one load + s_waitcnt per row -- seen in the ISA), so the raw values are pinned by one empty asm statement in
+  // finish(), where all sixteen must be live at once; the selection happens after it.
+  __device__ __forceinline__ void issue(const float* __restrict__ part, int nparts, int len, int col, int rg) {
+    const int cc = col < len ? col : len - 1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int r = rg + 16 * j;
+      v[j] = part[(size_t)(r < nparts ? r : nparts - 1) * len + cc];
+    }
+  }
+  // (s0 + s1) + (s2 + s3) of: for (r = rg; r + 48 < nparts; r += 64) {s0 += row r; s1 += row r+16; s2 += row r+32; s3 += row r+48;}
+  //                           for (; r < nparts; r += 16) s0 += row r;
+  __device__ __forceinline__ float finish(const float* __restrict__ part, int nparts, int len, int col, int rg) const {
+    float x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = v[j];
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+                      "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = (rg + 16 * j < nparts && col < len) ? x[j] : 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (rg + 64 * it + 48 < nparts) { s0 += x[4 * it]; s1 += x[4 * it + 1]; s2 += x[4 * it + 2]; s3 += x[4 * it + 3]; }
+      else { s0 += x[4 * it]; s0 += x[4 * it + 1]; s0 += x[4 * it + 2]; s0 += x[4 * it + 3]; }
+    }
+    if (nparts > 256 && col < len) {                     // (larger partial sets: the remaining rows, same scheme)
+      int r = rg + 256;
+      for (; r + 48 < nparts; r += 64) {
+        s0 += part[(size_t)r * len + col];
+        s1 += part[(size_t)(r + 16) * len + col];
+        s2 += part[(size_t)(r + 32) * len + col];
+        s3 += part[(size_t)(r + 48) * len + col];
+      }
+      for (; r < nparts; r += 16) s0 += part[(size_t)r * len + col];
+    }
+    return (s0 + s1) + (s2 + s3);
+  }
+};
+
 // column sums of partials[nparts][len] for the 64 columns of this workgroup: 16 row groups x 64 columns, every thread
 // keeps 4 independent chains (rows rg, rg+16, ...), then the 16 group sums are added in fixed order.  Returns the
 // column total in the threads of row group 0 (valid where col < len).
 __device__ __forceinline__ float column_sum_1024(const float* __restrict__ part, int nparts, int len, int col, int rg,
                                                  float* sm /* [16*64] */) {
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (col < len) {
-    int r = rg;
-    for (; r + 48 < nparts; r += 64) {
-      s0 += part[(size_t)r * len + col];
-      s1 += part[(size_t)(r + 16) * len + col];
-      s2 += part[(size_t)(r + 32) * len + col];
-      s3 += part[(size_t)(r + 48) * len + col];
-    }
-    for (; r < nparts; r += 16) s0 += part[(size_t)r * len + col];
-  }
-  sm[rg * 64 + (threadIdx.x & 63)] = (s0 + s1) + (s2 + s3);
+  ColumnRows rows;
+  rows.issue(part, nparts, len, col, rg);
+  sm[rg * 64 + (threadIdx.x & 63)] = rows.finish(part, nparts, len, col, rg);
   __syncthreads();
   float s = 0.f;
   if (rg == 0) {
@@ -235,23 +278,12 @@ __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
   const bool col = i < a.r.len;
   const bool has_valid = a.v.part != nullptr;           // uniform over the launch
   const bool has_train = a.r.nparts > 0;                // false: stand-alone validation epoch (no sums, no Adam)
-  float lp = 0.f, vp = 0.f;
-  for (int r = tid; r < a.r.nlparts; r += 1024) lp += a.r.lpart[r];
-  if (has_valid)
-    for (int r = tid; r < a.v.nparts; r += 1024) vp += a.v.part[r];
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (col) {
-    const float* __restrict__ part = a.r.part;
-    const int len = a.r.len, nparts = a.r.nparts;
-    int r = rg;
-    for (; r + 48 < nparts; r += 64) {
-      s0 += part[(size_t)r * len + i];
-      s1 += part[(size_t)(r + 16) * len + i];
-      s2 += part[(size_t)(r + 32) * len + i];
-      s3 += part[(size_t)(r + 48) * len + i];
-    }
-    for (; r < nparts; r += 16) s0 += part[(size_t)r * len + i];
-  }
+  // ---- issue: gradient-partial rows, first loss / validation partial, parameter + moments, best loss -- straight-line
+  // (see ColumnRows: the loops these replace serialised seven memory round trips)
+  ColumnRows rows;
+  if (has_train) rows.issue(a.r.part, a.r.nparts, a.r.len, i, rg);
+  const float lp0 = tid < a.r.nlparts ? a.r.lpart[tid] : 0.f;
+  const float vp0 = has_valid && tid < a.v.nparts ? a.v.part[tid] : 0.f;
   const bool upd = (rg == 0) && col;
   const float* p_in = a.t.p_in ? a.t.p_in : a.t.p;
   const float* m_in = a.t.m_in ? a.t.m_in : a.t.m;
@@ -262,11 +294,17 @@ __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
     if (has_train || a.t.p_in) { m0 = m_in[i]; v0 = v_in[i]; }
   }
   const float best = a.t.best_loss[a.t.parity];
+  // ---- use
+  float lp = lp0, vp = vp0;
+  for (int r = tid + 1024; r < a.r.nlparts; r += 1024) lp += a.r.lpart[r];
+  if (has_valid)
+    for (int r = tid + 1024; r < a.v.nparts; r += 1024) vp += a.v.part[r];
+  const float colsum = has_train ? rows.finish(a.r.part, a.r.nparts, a.r.len, i, rg) : 0.f;
   for (int off = 32; off > 0; off >>= 1) lp += __shfl_down(lp, off);
   if (has_valid)
     for (int off = 32; off > 0; off >>= 1) vp += __shfl_down(vp, off);
   if (c == 0) { smw[rg] = lp; smv[rg] = vp; }
-  sm[rg * 64 + c] = (s0 + s1) + (s2 + s3);
+  sm[rg * 64 + c] = colsum;
   __syncthreads();
   float loss = 0.f, vloss = 0.f;
 #pragma unroll
@@ -329,28 +367,19 @@ __global__ __launch_bounds__(1024) void reduce_tail_dp_kernel(ReduceTailArgs a, 
   const int tid = threadIdx.x, col = tid & 63, rg = tid >> 6, blk = blockIdx.x;
   const int i = blk * 64 + col;
   const bool incol = i < a.r.len;
-  float lp = 0.f;
-  for (int r = tid; r < a.r.nlparts; r += 1024) lp += a.r.lpart[r];
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (incol) {
-    const float* __restrict__ part = a.r.part;
-    const int len = a.r.len, nparts = a.r.nparts;
-    int r = rg;
-    for (; r + 48 < nparts; r += 64) {
-      s0 += part[(size_t)r * len + i];
-      s1 += part[(size_t)(r + 16) * len + i];
-      s2 += part[(size_t)(r + 32) * len + i];
-      s3 += part[(size_t)(r + 48) * len + i];
-    }
-    for (; r < nparts; r += 16) s0 += part[(size_t)r * len + i];
-  }
+  ColumnRows rows;                                        // (every load in flight before the first add: see ColumnRows)
+  rows.issue(a.r.part, a.r.nparts, a.r.len, i, rg);
+  const float lp0 = tid < a.r.nlparts ? a.r.lpart[tid] : 0.f;
   const bool upd = (rg == 0) && incol;
   float pi = 0.f, m0 = 0.f, v0 = 0.f;
   if (upd) { pi = a.t.p[i]; m0 = a.t.m[i]; v0 = a.t.v[i]; }
   const float best = a.t.best_loss[a.t.parity];
+  float lp = lp0;
+  for (int r = tid + 1024; r < a.r.nlparts; r += 1024) lp += a.r.lpart[r];
+  const float colsum = rows.finish(a.r.part, a.r.nparts, a.r.len, i, rg);
   for (int off = 32; off > 0; off >>= 1) lp += __shfl_down(lp, off);
   if (col == 0) smw[rg] = lp;
-  sm[rg * 64 + col] = (s0 + s1) + (s2 + s3);
+  sm[rg * 64 + col] = colsum;
   __syncthreads();
   // ---- push this workgroup's slice [64 local column sums | local loss] to every rank
   const int parity = step & 1u;

@@ -184,22 +184,29 @@ DeepPlan deep_plan(int n) {
   q.total = o + 64;
   return q;
 }
+// One workspace per DEVICE and module (it used to be one per module, allocated on whichever device was current at
+// first use -- a second FusedSystem on another GPU of the same process would have been handed that device's memory).  Still
+// one STREAM at a time per device: growing it synchronises the device and frees the old block, and the forward-reuse hint
+// below is per device too; concurrent streams of one process must not share a deep network's module.
+constexpr int kDeepMaxDevices = 16;
+inline int deep_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kDeepMaxDevices) d = 0; return d; }
 inline real* deep_workspace(size_t floats) {
-  static real* base = nullptr;
-  static size_t have = 0;
-  if (floats > have) {
-    if (base) { (void)hipDeviceSynchronize(); (void)hipFree(base); base = nullptr; have = 0; }
+  static real* base[kDeepMaxDevices] = {};
+  static size_t have[kDeepMaxDevices] = {};
+  const int d = deep_device();
+  if (floats > have[d]) {
+    if (base[d]) { (void)hipDeviceSynchronize(); (void)hipFree(base[d]); base[d] = nullptr; have[d] = 0; }
     const size_t want = floats + floats / 8;
-    if (hipMalloc(reinterpret_cast<void**>(&base), want * sizeof(real)) != hipSuccess) { base = nullptr; return nullptr; }
-    have = want;
+    if (hipMalloc(reinterpret_cast<void**>(&base[d]), want * sizeof(real)) != hipSuccess) { base[d] = nullptr; return nullptr; }
+    have[d] = want;
   }
-  return base;
+  return base[d];
 }
 // The adjoint entry recomputes the forward layers unless the caller vouches that the workspace still holds them: the engine
 // raises this flag for the adjoint call that directly follows the forward call of the same training step (same parameter
 // vector, same batch); a different coordinate / parameter pointer or point count recomputes regardless.
 struct DeepLast { const void* coords; const void* params; int n, ldc; bool reuse; };
-inline DeepLast& deep_last() { static DeepLast d{nullptr, nullptr, 0, 0, false}; return d; }
+inline DeepLast& deep_last() { static DeepLast d[kDeepMaxDevices] = {}; return d[deep_device()]; }
 
 inline int deep_blocks(long waves, int min_waves, int cap) {
   long w = waves > min_waves ? waves : min_waves;

@@ -1020,12 +1020,20 @@ class BaseSolver(ABC):
         if nets is None:
             return None
         key = (tuple(id(n) for n in nets), id(self.diff_eqs), tuple(id(c) for c in self.conditions), len(coords))
+        # the reference evaluates diff_eqs / the conditions afresh on every call (solvers.py:606-646): a cached trace is used
+        # again only if a re-trace on the same symbols still arrives at it (program.eq_probe: ~0.1 - 0.7 ms, this is not the
+        # training loop); numbers that moved since become runtime constants of the rebuild (symbolic.Graph.external)
+        volatile = frozenset()
+        held = self._resid_sys if getattr(self, "_resid_key", None) == key else None
+        if held is not None and not held.program.eq_probe():
+            volatile = held.program.suggest_volatile()
+            self._resid_key = None
         if getattr(self, "_resid_key", None) != key:
             self._resid_key, self._resid_sys = key, None
             try:
                 from .engine import FusedSystem
                 self._resid_sys = FusedSystem(nets, self.conditions, self.diff_eqs, len(coords), self.device,
-                                              compute_func_val=self.compute_func_val, single_kernel=False)
+                                              compute_func_val=self.compute_func_val, single_kernel=False, volatile=volatile)
             except TraceUnsupported:
                 pass
         if self._resid_sys is None:
@@ -1106,12 +1114,19 @@ class BaseSolution(ABC):
                 or len(set(id(n) for n in self.nets)) != len(self.nets):
             return None
         key = (tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions), len(coords))
+        # (a boundary value stored on a condition object may have been changed since the cached trace: re-probed on every
+        # call like _fused_residuals -- the reference's solutions call cond.enforce afresh, solvers.py:682-720)
+        volatile = frozenset()
+        held = self._eval_sys if getattr(self, "_eval_key", None) == key else None
+        if held is not None and not held.program.eq_probe():
+            volatile = held.program.suggest_volatile()
+            self._eval_key = None
         if getattr(self, "_eval_key", None) != key:
             self._eval_key, self._eval_sys = key, None
             try:
                 from .engine import FusedSystem
                 self._eval_sys = FusedSystem(self.nets, self.conditions, None, len(coords), coords[0].device,
-                                             compute_func_val=self._compute_u, single_kernel=False)
+                                             compute_func_val=self._compute_u, single_kernel=False, volatile=volatile)
             except (TraceUnsupported, _lib.NdqError):
                 pass
         if self._eval_sys is None:

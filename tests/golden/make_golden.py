@@ -425,10 +425,13 @@ def make_default_precision(name, base, seed=0):
         coords = [d.detach().clone() for d in gen.get_examples()]
         assert coords[0].dtype == torch.float64 and next(cfg["nets"][0].parameters()).dtype == torch.float64
         out = dict(seed=np.asarray(seed), params0=flat_params(cfg["nets"]).numpy(), coords=np.stack([c.numpy() for c in coords]))
+        keep = [{k: v.clone() for k, v in n.state_dict().items()} for n in cfg["nets"]]
         for k, v in closure_once(cfg, coords, torch.float64).items():
             out[f"{k}_f64"] = v
-        for n in cfg["nets"]:
-            n.double()                       # (closure_once hands the networks back in fp32)
+        for n, sd in zip(cfg["nets"], keep):   # (closure_once hands the networks back in fp32: restore the double weights exactly)
+            n.double()
+            n.load_state_dict(sd)
+        assert np.array_equal(flat_params(cfg["nets"]).numpy(), out["params0"])
         solver = Solver2D(cfg["pde"], cfg["conds"], nets=cfg["nets"], train_generator=gen, valid_generator=gen, n_batches_valid=0,
                           xy_min=(0, 0), xy_max=(1, 1))
         torch.manual_seed(seed + 2)
