@@ -1194,7 +1194,29 @@ __global__ __launch_bounds__(1024) void deep_reduce_all(DeepReduceJobs J) {
   const real* src = jb.src + (size_t)r * jb.cols_p + c;
   const size_t step = (size_t)jb.rows_p * jb.cols_p;
   double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
-  int i = y;
+  // the first 256 parts of this thread (parts y, y + 16, ..., y + 240) as straight-line clamped loads, all in flight before the
+  // first add -- the loop form below compiles to "four loads, s_waitcnt vmcnt(0), four adds, branch", one memory round trip per
+  // 64 parts (csrc/ndq_api.hip ColumnRows has the story); same order of additions
+  real pv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int q = y + 16 * j;
+    pv[j] = src[(size_t)(q < jb.nparts ? q : jb.nparts - 1) * step];
+  }
+  asm volatile("" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]), "+v"(pv[8]),
+                    "+v"(pv[9]), "+v"(pv[10]), "+v"(pv[11]), "+v"(pv[12]), "+v"(pv[13]), "+v"(pv[14]), "+v"(pv[15]));
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int q = y + 64 * it;
+    if (q + 48 < jb.nparts) {
+      s0 += (double)pv[4 * it]; s1 += (double)pv[4 * it + 1]; s2 += (double)pv[4 * it + 2]; s3 += (double)pv[4 * it + 3];
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        if (q + 16 * kk < jb.nparts) s0 += (double)pv[4 * it + kk];
+    }
+  }
+  int i = y + 256;
   for (; i + 48 < jb.nparts; i += 64) {
     const real v0 = src[(size_t)i * step], v1 = src[(size_t)(i + 16) * step], v2 = src[(size_t)(i + 32) * step],
                v3 = src[(size_t)(i + 48) * step];

@@ -323,6 +323,9 @@ constexpr bool act_has_s4(int act) {
 #ifndef NDQ_ABL
 #define NDQ_ABL 0
 #endif
+#ifndef NDQ_STAGE_INFLIGHT
+#define NDQ_STAGE_INFLIGHT 1   // 0: weight staging array by array (rounds 1 - 4; A/B of stage_weights' in-flight pass)
+#endif
 #ifndef NDQ_STAGGER
 #define NDQ_STAGGER 0       // s_sleep argument (x 64 cycles) by which waves WAVES/2.. start their tile loop late
 #endif
@@ -697,6 +700,62 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
     else return actp_mul<C>(prm[idx], f);
   };
   auto real_unit = [](int j, int hw) { return !C::RAGGED || j < hw; };
+#if NDQ_STAGE_INFLIGHT
+  // ---- plain FCNNs on the bf16x3 path (the BASELINE shapes): ONE pass over the flat parameter vector in torch order with the
+  // loads of a pass all in flight (round 5).  The loops below stage array by array -- W1, b1, Wout, bout, W_l, b_l -- and every
+  // loop compiles to "load, s_waitcnt vmcnt(0), ds_write, branch": five (C2) dependent round trips to memory that the previous
+  // step's tail launch wrote on other XCDs, 1.35 us of every launch.  Here a thread loads its elements e = base + tid + k nt,
+  // k < KP, unconditionally (clamped), one empty asm statement keeps all KP values live at once, and place() puts element e
+  // where the loops below would have put it (same LDS images, bit for bit).
+  if constexpr (C::ACTP == 0 && !C::RAGGED && C::MONO == 0 && C::SKIP == 0 && C::NOUT == 1 && C::BF16) {
+    constexpr int KP = 8, P = C::P, LS = H * H + H;          // LS: flat stride of one hidden layer (matrix + bias)
+    auto place = [&](int e, real w) {
+      if (e < C::offb1) {                                    // W1[j][a] -> W1T[a][j]
+        const int j = e / C::NIN, a = e - j * C::NIN;
+        lds[C::ldsW1T + a * H + j] = w;
+      } else if (e < C::offW(2)) {
+        lds[C::ldsb1 + (e - C::offb1)] = w;
+      } else if (e < C::offWout) {
+        const int l = 2 + (e - C::offW(2)) / LS, r = (e - C::offW(2)) % LS;
+        if (r >= H * H) { lds[C::ldsb(l, BWD) + (r - H * H)] = w; return; }
+        const int j = r / H, k = r - j * H;
+        __bf16* wf = reinterpret_cast<__bf16*>(lds + C::ldsWf(l, BWD));
+        __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWt(l));
+        const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
+        const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
+        {
+          const int blk = (j >> 4) * C::NC + (k >> 5);
+          const int base = ((blk * 3) * 64 + (j & 15) + 16 * ((k & 15) >> 2)) * 8 + 4 * ((k & 31) >> 4) + (k & 3);
+          wf[base] = w0; wf[base + 512] = w1; wf[base + 1024] = w2;
+        }
+        if (BWD) {
+          const int blk = (k >> 4) * C::NC + (j >> 5);
+          const int base = ((blk * 3) * 64 + (k & 15) + 16 * ((j & 15) >> 2)) * 8 + 4 * ((j & 31) >> 4) + (j & 3);
+          wt[base] = w0; wt[base + 512] = w1; wt[base + 1024] = w2;
+        }
+      } else if (e < C::offbout) {
+        lds[C::ldsWout(BWD) + (e - C::offWout)] = w;
+      } else {
+        lds[C::ldsbout(BWD)] = w;
+      }
+    };
+    for (int base = 0; base < P; base += KP * nt) {
+      real v[KP];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const int e = base + tid + k * nt;
+        v[k] = prm[e < P ? e : P - 1];
+      }
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const int e = base + tid + k * nt;
+        if (e < P) place(e, v[k]);
+      }
+    }
+    return;
+  }
+#endif
   for (int i = tid; i < C::NIN * H; i += nt) {  // W1T[a][j] = W1[j][a]  (MONO: a runs over the NIN features)
     const int a = i / H, j = i - a * H;
     lds[C::ldsW1T + i] = unit(j, C::hr(1), C::offW1 + j * C::NIN + a, f1);
