@@ -333,7 +333,7 @@ def _spec_for(net, order, dtype=torch.float32):
     if hit is not None:
         return hit if hit else None
     info = describe(net, dtype=dtype)
-    ok = info is not None and info["skip"] == 0 and info["actp"] == 0 and info["widths"] == 0 and info["mono"] == 0 and 1 <= info["d"] <= 3
+    ok = info is not None and info["skip"] == 0 and info.get("skip_sym") is None and info["actp"] == 0 and info["widths"] == 0 and info["mono"] == 0 and 1 <= info["d"] <= 3
     if ok:
         from . import codegen
         desc = _desc(info["d"], order, info["hidden"], info["layers"], info["act"], info["n_out"])

@@ -115,7 +115,9 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         raise TraceUnsupported("a network is not an FCNN the gfx950 kernels support")
     g = Graph(n_coords)
     g.volatile = frozenset() if f64 else frozenset(volatile)      # (the fp64 pipeline has no scalar arguments)
-    g.register_nets(nets, [i["n_out"] for i in infos])
+    if f64 and any(i.get("skip_sym") is not None for i in infos):
+        raise TraceUnsupported("a skip connection above 64 hidden units on the fp64 pipeline (its weights are kernel arguments: fp32 only)")
+    g.register_nets(nets, [i["n_out"] for i in infos], skips=[i.get("skip_sym") for i in infos])
     cfv = compute_func_val or (lambda net, cond, *coords: cond.enforce(net, *coords))
     with trace_scope(g):
         coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
@@ -413,11 +415,14 @@ class FusedSystem:
         """Current values of the equations' trainable scalars -> the device vector the kernels read."""
         if self.n_theta:
             with torch.no_grad():
+                def value(p):      # a 1-element tensor, or entry k of a tensor (symbolic.Graph.param_elem)
+                    v = p[0].detach().reshape(-1)[p[1]] if isinstance(p, tuple) else p.detach().reshape(())
+                    return v.to(self.device, self.dt)
                 if not self.theta_frozen:
-                    self.theta_buf.copy_(torch.stack([p.detach().reshape(()).to(self.device, self.dt) for p in self.theta_params]))
+                    self.theta_buf.copy_(torch.stack([value(p) for p in self.theta_params]))
                     return
                 if self._theta_trainable:
-                    live = torch.stack([self.theta_params[j].detach().reshape(()).to(self.device, self.dt) for j in self._theta_trainable])
+                    live = torch.stack([value(self.theta_params[j]) for j in self._theta_trainable])
                     self.theta_buf[self._theta_trainable] = live
                 values = tuple(float(self.theta_params[j]) for j in self.theta_frozen)
                 if values != self._theta_frozen_seen:          # (one small H2D copy when a re-trace brought new values)
@@ -441,6 +446,12 @@ class FusedSystem:
         """``p.grad`` of every trainable scalar = its entry of ``gtheta`` (what loss.backward() leaves, solvers.py:393)."""
         for j, p in enumerate(self.theta_params):
             if j in self.program.g.frozen:
+                continue
+            if isinstance(p, tuple):             # entry k of a tensor (a symbolic skip connection's weight matrix)
+                t, k = p
+                if t.grad is None:
+                    t.grad = torch.zeros_like(t)
+                t.grad.reshape(-1)[k] = self.gtheta[j].to(t.device, t.dtype)
                 continue
             g = self.gtheta[j].reshape(p.shape).to(p.device, p.dtype)
             if p.grad is not None and p.grad.shape == g.shape and p.grad.data_ptr() != self.gtheta[j].data_ptr():

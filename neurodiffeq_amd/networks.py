@@ -214,6 +214,14 @@ def describe(net, dtype=torch.float32):
     if skip is not None and tuple(skip.weight.shape) != (linears[-1].out_features, linears[0].in_features):
         return None
     # flat order the kernels read: W1 b1 ... Wout bout | skip weights (n_out x d, row-major) | activation parameters
+    # wider than 64 units the kernels serve plain FCNNs (csrc/ndq_wide.h, csrc/ndq_deep.h): a Resnet's skip connection is then
+    # handled by the TRACER -- out += S x as a symbolic term whose entries are trainable kernel arguments
+    # (symbolic.Graph.register_nets) -- and stays outside the flat parameter vector of the kernels
+    skip_sym = None
+    if skip is not None and hidden > 64:
+        if act_params or act_frozen or widths or mono:
+            return None
+        skip_sym, skip = skip, None
     params = [p for l in linears for p in (l.weight, l.bias)] + ([skip.weight] if skip is not None else []) + act_params
     n_in = linears[0].in_features
     if mono:
@@ -223,7 +231,7 @@ def describe(net, dtype=torch.float32):
         n_in //= n_deg
     return dict(d=n_in, mono=mono, hidden=hidden, layers=len(acts), act=_ACT_IDS[next(iter(act_types))],
                 n_out=linears[-1].out_features, linears=linears, skip=int(skip is not None), params=params,
-                actp=1 if act_params else (2 if act_frozen else 0), frozen=act_frozen, widths=widths)
+                actp=1 if act_params else (2 if act_frozen else 0), frozen=act_frozen, widths=widths, skip_sym=skip_sym)
 
 
 class FlatParams:

@@ -929,12 +929,17 @@ class BaseSolver(ABC):
         current_loss = self.metrics_history[key + "_loss"][-1]
         if (self._lowest_loss is None) or current_loss < self._lowest_loss:
             self._lowest_loss = current_loss
-            if self._fused_sys is not None:
+            outside = self._fused_sys is not None and any(isinstance(p, tuple) for p in self._fused_sys.theta_params)
+            if self._fused_sys is not None and not outside:
                 for fp in self._fused_sys.flat:
                     fp.sync()
                 self._best_flat = [fp.flat.clone() for fp in self._fused_sys.flat]
                 self._best_nets = None
             else:
+                # (a symbolic skip connection's weights live outside the kernels' flat vectors: snapshot the modules themselves)
+                if self._fused_sys is not None:
+                    for fp in self._fused_sys.flat:
+                        fp.sync()
                 self.best_nets = deepcopy(self.nets)
 
     def fit(self, max_epochs, callbacks=(), tqdm_file=sys.stderr, **kwargs):

@@ -95,9 +95,13 @@ class Graph:
         return self.const(v)
 
     # -------------------------------------------------------------- networks
-    def register_nets(self, nets, n_outs):
+    def register_nets(self, nets, n_outs, skips=None):
+        """skips[k]: the bias-free ``nn.Linear`` skip connection of network k when it is handled SYMBOLICALLY (networks wider
+        than 64 units: the kernels of csrc/ndq_wide.h / ndq_deep.h serve plain FCNNs, so ``Resnet``'s ``out += S x``
+        (networks.py:73-106) is added here, every entry of S a trainable kernel argument -- ``param_elem``), else None."""
         self._net_ids = {id(n): k for k, n in enumerate(nets)}
         self._net_nouts = list(n_outs)
+        self._net_skips = list(skips) if skips is not None else [None] * len(nets)
         self.site_net = list(range(len(nets)))
         self._sites = {}         # (network index, deps) -> site
 
@@ -131,12 +135,21 @@ class Graph:
             self.net_deps[site] = deps
         n_out = self._net_nouts[k]
         self.net_nout[site] = n_out
+        skip = self._net_skips[k]
         k = site
+
+        def output(o):
+            u = Sym(self, self.net(k, o))
+            if skip is not None:                 # + sum_a S[o][a] x_a: derivatives w.r.t. the coordinates come out of diff()
+                d = len(coords)
+                for a, c in enumerate(coords):
+                    u = u + Sym(self, self.param_elem(skip.weight, o * d + a)) * c
+            return u
         if ith_unit is not None:
-            return Sym(self, self.net(k, ith_unit))
+            return output(ith_unit)
         if n_out == 1:
-            return Sym(self, self.net(k, 0))
-        return SymMat([Sym(self, self.net(k, o)) for o in range(n_out)])
+            return output(0)
+        return SymMat([output(o) for o in range(n_out)])
 
     # -------------------------------------------------------------- construction
     def _mk(self, key):
@@ -168,6 +181,15 @@ class Graph:
             if p is t:
                 return self._mk(("param", j))
         self.params.append(t)
+        return self._mk(("param", len(self.params) - 1))
+
+    def param_elem(self, t, k):
+        """Leaf for ENTRY k (flat index) of a trainable tensor: ``params`` holds the pair (tensor, k); read from the same device
+        vector as the scalars, its gradient lands in ``t.grad`` at k (engine.attach_theta_grads)."""
+        for j, p in enumerate(self.params):
+            if isinstance(p, tuple) and p[0] is t and p[1] == k:
+                return self._mk(("param", j))
+        self.params.append((t, int(k)))
         return self._mk(("param", len(self.params) - 1))
 
     def datacol(self, t):

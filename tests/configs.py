@@ -151,6 +151,15 @@ def make(name, size=None):
         c = make("c3", size or 12)
         c["nets"] = [FCNN(2, 1, hidden_units=(128, 128, 128))]
         return c
+    if name == "w24":     # Resnet 128 x 2 on the C2 problem: skip connection above 64 units (handled by the tracer)
+        c = make("c2", size or 12)
+        c["nets"] = [Resnet(2, 1, hidden_units=(128, 128))]
+        return c
+    if name == "w25":     # Resnet 2 -> 512 -> 3 on the single-network cavity problem
+        net = Resnet(n_input_units=2, n_output_units=3, hidden_units=(512,))     # (first: the golden script's RNG order)
+        c = make("w17", size)
+        c["nets"] = [net]
+        return c
     if name == "w18r":    # w18 on a ragged batch: 251 x 261 = 65 511 points (tests/golden/make_golden.py: cfg_w18r)
         c = make("w18", 12)
         g = size or (251, 261)

@@ -175,11 +175,14 @@ def _grad_in_torch_order(nets, flats):
     for fp in flats:
         for prm, off in zip(fp.params, fp._offsets):
             where[id(prm)] = fp.grad[off:off + prm.numel()]
-    return torch.cat([where[id(prm)].reshape(-1) for net in nets for prm in net.parameters()]).cpu().numpy()
+    # (parameters outside the kernels' flat vectors -- a symbolic skip connection's weights -- carry their gradient in .grad)
+    return torch.cat([(where[id(prm)] if id(prm) in where else prm.grad).reshape(-1).to("cuda")
+                      for net in nets for prm in net.parameters()]).cpu().numpy()
 
 
-GOLDEN_WIDE = ["w16", "w17", "w18", "w19", "w20", "w21"]      # w20: (100, 100) ELU; w21: Softplus + GELU networks (32 x 32)
-GOLDEN_DEEP = ("w18", "w19", "w20", "w21")    # layer-by-layer kernels (w18 - w20) / two networks with different activations (w21):
+GOLDEN_WIDE = ["w16", "w17", "w18", "w19", "w20", "w21", "w24", "w25"]      # w20: (100, 100) ELU; w21: Softplus + GELU networks (32 x 32);
+#                                                 w24 / w25: Resnet 128 x 2 and 2 -> 512 -> 3 (skip connection above 64 units: symbolic, round 5)
+GOLDEN_DEEP = ("w18", "w19", "w20", "w21", "w24")    # layer-by-layer kernels (w18 - w20) / two networks with different activations (w21):
 #                                                 three-kernel pipeline, no single-launch closure
 
 
@@ -203,6 +206,7 @@ def test_wide_closure_matches_reference_golden(golden_dir, name, mode):
     assert (fs.fusedk is not None) == (mode == "1k")
     R.set_flat(cfg["nets"], torch.from_numpy(gold["params0"]))
     b, n = fs.step([torch.from_numpy(c) for c in gold["coords"]], train=True, slot=0, want_funcs=True, want_resid=True)
+    fs.attach_theta_grads()                    # (w24 / w25: the skip connection's weights are kernel arguments; their .grad)
     torch.cuda.synchronize()
     errs = dict(funcs=rel_l2(b["funcs"][:, :n].T.cpu().numpy(), gold["funcs_f64"]),
                 residuals=rel_l2(b["resid"][:, :n].T.cpu().numpy()[:, :gold["residuals_f64"].shape[1]], gold["residuals_f64"]),

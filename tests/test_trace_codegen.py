@@ -15,7 +15,7 @@ from oracle import jet_ref as J
 from tests import configs, zoo
 from tests.pw_cpu import run_cpu
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w9": None, "w10": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None, "w20": None, "w21": None}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w9": None, "w10": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None, "w20": None, "w21": None, "w24": None, "w25": None}
 
 
 def rel_l2(a, b):
@@ -26,7 +26,7 @@ def rel_l2(a, b):
 def trace(nets, conds, pde, n_coords, lap=True, cfv=None, loss="l2", metrics=()):
     from neurodiffeq_amd.symbolic import SymMat
     g = Graph(n_coords)
-    g.register_nets(nets, [describe(n)["n_out"] for n in nets])
+    g.register_nets(nets, [describe(n)["n_out"] for n in nets], skips=[describe(n).get("skip_sym") for n in nets])
     cfv = cfv or (lambda net, cond, *coords: cond.enforce(net, *coords))
     term, mterms = None, []
     with trace_scope(g):
@@ -64,8 +64,10 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
             start[id(prm)] = at
             at += prm.numel()
         perm = np.concatenate([np.arange(start[id(prm)], start[id(prm)] + prm.numel()) for prm in info["params"]])
-        assert perm.size == at
-        perms.append(perm)
+        # (a symbolic skip connection -- networks wider than 64 units -- keeps its weights outside the kernels' flat vector:
+        # they are trainable scalars of the traced program, handled with the other theta entries below)
+        assert perm.size == at or info.get("skip_sym") is not None
+        perms.append((perm, at))
         # fixed non-default activation scalars (actp = 2) follow the trainable entries; the oracle takes them like trainable ones
         flats.append(np.concatenate([np.asarray(params[off:off + at], np.float64)[perm], np.asarray(info["frozen"], np.float64)]))
         off += at
@@ -93,7 +95,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     gtheta = None
     if prog.n_theta or prog.n_data:      # trainable scalars of the equations / per-point data columns (inverse problems)
         data = [np.asarray(t.detach().numpy(), wdt).reshape(-1) for t in prog.g.data]
-        theta = [float(t.detach()) for t in prog.g.params]
+        theta = [float(t[0].detach().reshape(-1)[t[1]]) if isinstance(t, tuple) else float(t.detach()) for t in prog.g.params]
         resid, funcs, gbar, lterm, gth = run_cpu(prog, coords, syms, seed, return_loss=True, f64=f64, data=data, theta=theta)
         gtheta = gth.astype(np.float64).sum(axis=1)[:prog.n_theta]
         host_closure.last_gtheta = gtheta
@@ -118,16 +120,25 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
             gb = {(): np.zeros((n, dims[-1]))}
         grads[site_net[k]] = grads[site_net[k]] + J.mlp_jets_vjp(flats[site_net[k]], dims, act, [column(c) for c in deps], gb,
                                                                skip=skip, actp=actp, mono=mono)
-    for j, perm in enumerate(perms):                    # back to torch parameter order (frozen scalars: no gradient entry)
-        g = np.zeros(perm.size)
+    for j, (perm, at) in enumerate(perms):              # back to torch parameter order (frozen scalars: no gradient entry)
+        g = np.zeros(at)
         g[perm] = grads[j][:perm.size]
+        # entries of tensors that are trainable scalars of the program (symbolic skip weights): their per-point adjoint sums
+        start, pos = {}, 0
+        for prm in nets[j].parameters():
+            start[id(prm)] = pos
+            pos += prm.numel()
+        for jt, t in enumerate(prog.g.params):
+            if isinstance(t, tuple) and id(t[0]) in start:
+                g[start[id(t[0])] + t[1]] = gtheta[jt]
         grads[j] = g
     return prog, funcs.T, resid.T, loss, np.concatenate(grads)
 
 
 @pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
                                       ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True), ("w5", True), ("w6", True), ("w7", True), ("w8", True),
-                                      ("w9", True), ("w10", True), ("w11", True), ("w12", True), ("w13", True), ("w14", True), ("w15", True), ("w16", True), ("w17", True), ("w18", True), ("w19", True), ("w20", True), ("w21", True)])
+                                      ("w9", True), ("w10", True), ("w11", True), ("w12", True), ("w13", True), ("w14", True), ("w15", True), ("w16", True), ("w17", True), ("w18", True), ("w19", True), ("w20", True), ("w21", True),
+                                      ("w24", True), ("w25", True)])       # w24 / w25: Resnets above 64 units (symbolic skip connection)
 def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
