@@ -53,18 +53,37 @@ __global__ __launch_bounds__(1024) void reduce_partials64_kernel(const double* _
   __shared__ double sm[16 * 64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + c;
+  // Sixteen rows of a thread at a time as straight-line clamped loads, pinned by one empty asm statement, then added in
+  // EXACTLY the order of the loops they replace:
+  //     for (r = rg; r + 48 < nparts; r += 64) { s0 += row r; s1 += row r + 16; s2 += row r + 32; s3 += row r + 48; }
+  //     for (; r < nparts; r += 16) s0 += row r;
+  // which compile to "four loads, s_waitcnt vmcnt(0), four adds, branch" -- one memory round trip per 64 rows, sixteen of them
+  // behind an fp64 adjoint launch's 1 024 partial rows (round 5; csrc/ndq_api.hip ColumnRows has the fp32 story).
   double s0 = 0., s1 = 0., s2 = 0., s3 = 0.;
-  if (i < len) {
-    int r = rg;
-    for (; r + 48 < nparts; r += 64) {
-      s0 += part[(size_t)r * len + i];
-      s1 += part[(size_t)(r + 16) * len + i];
-      s2 += part[(size_t)(r + 32) * len + i];
-      s3 += part[(size_t)(r + 48) * len + i];
+  const bool live = i < len;
+  const int cc = live ? i : len - 1;
+  for (int base = 0; base < nparts; base += 256) {
+    double x[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int r = base + rg + 16 * j;
+      x[j] = part[(size_t)(r < nparts ? r : nparts - 1) * len + cc];
     }
-    for (; r < nparts; r += 16) s0 += part[(size_t)r * len + i];
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]),
+                      "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r0 = base + rg + 64 * it;
+      if (r0 + 48 < nparts) {
+        s0 += x[4 * it]; s1 += x[4 * it + 1]; s2 += x[4 * it + 2]; s3 += x[4 * it + 3];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (r0 + 16 * k < nparts) s0 += x[4 * it + k];
+      }
+    }
   }
-  sm[rg * 64 + c] = (s0 + s1) + (s2 + s3);
+  sm[rg * 64 + c] = live ? (s0 + s1) + (s2 + s3) : 0.;
   __syncthreads();
   if (rg == 0 && i < len) {
     double s = 0.;
