@@ -326,6 +326,9 @@ constexpr bool act_has_s4(int act) {
 #ifndef NDQ_STAGE_INFLIGHT
 #define NDQ_STAGE_INFLIGHT 1   // 0: weight staging array by array (rounds 1 - 4; A/B of stage_weights' in-flight pass)
 #endif
+#ifndef NDQ_GROUP_PREFETCH
+#define NDQ_GROUP_PREFETCH 1   // 0: grouped closure kernel loads a group's coordinates at the top of the group loop (A/B)
+#endif
 #ifndef NDQ_STAGGER
 #define NDQ_STAGGER 0       // s_sleep argument (x 64 cycles) by which waves WAVES/2.. start their tile loop late
 #endif
@@ -707,8 +710,30 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
   // step's tail launch wrote on other XCDs, 1.35 us of every launch.  Here a thread loads its elements e = base + tid + k nt,
   // k < KP, unconditionally (clamped), one empty asm statement keeps all KP values live at once, and place() puts element e
   // where the loops below would have put it (same LDS images, bit for bit).
-  if constexpr (C::ACTP == 0 && !C::RAGGED && C::MONO == 0 && C::SKIP == 0 && C::NOUT == 1 && C::BF16) {
+  if constexpr (C::ACTP == 0 && !C::RAGGED && C::MONO == 0 && C::SKIP == 0 && C::BF16 && (C::NOUT == 1 || C::BF16O)) {
     constexpr int KP = 8, P = C::P, LS = H * H + H;          // LS: flat stride of one hidden layer (matrix + bias)
+    // multi-output networks on the bf16 matrix core (BF16O): planes of the zero-padded output matrix Wo [HO][H], forward and
+    // transposed image, index scheme of the loop further down
+    auto place_wout = [&](int j, int k, real w) {
+      __bf16* wf = reinterpret_cast<__bf16*>(lds + C::ldsWout(BWD));
+      __bf16* wt = reinterpret_cast<__bf16*>(lds + C::ldsWoutT());
+      const __bf16 w0 = (__bf16)w; const real r1 = w - (real)w0;
+      const __bf16 w1 = (__bf16)r1; const __bf16 w2 = (__bf16)(r1 - (real)w1);
+      {
+        const int blk = (j >> 4) * C::NC + (k >> 5);
+        const int base = ((blk * 3) * 64 + (j & 15) + 16 * ((k & 15) >> 2)) * 8 + 4 * ((k & 31) >> 4) + (k & 3);
+        wf[base] = w0; wf[base + 512] = w1; wf[base + 1024] = w2;
+      }
+      if (BWD) {
+        const int blk = (k >> 4) * C::NCO + (j >> 5);
+        const int base = ((blk * 3) * 64 + (k & 15) + 16 * ((j & 15) >> 2)) * 8 + 4 * ((j & 31) >> 4) + (j & 3);
+        wt[base] = w0; wt[base + 512] = w1; wt[base + 1024] = w2;
+      }
+    };
+    if constexpr (C::NOUT > 1) {                             // padding rows NOUT .. HO - 1 of Wo and of bout: exact zeros
+      for (int i = C::NOUT * H + tid; i < C::HO * H; i += nt) place_wout(i / H, i % H, (real)0.f);
+      for (int i = C::NOUT + tid; i < C::HO; i += nt) lds[C::ldsbout(BWD) + i] = 0.f;
+    }
     auto place = [&](int e, real w) {
       if (e < C::offb1) {                                    // W1[j][a] -> W1T[a][j]
         const int j = e / C::NIN, a = e - j * C::NIN;
@@ -734,9 +759,10 @@ __device__ __forceinline__ void stage_weights(real* lds, const real* __restrict_
           wt[base] = w0; wt[base + 512] = w1; wt[base + 1024] = w2;
         }
       } else if (e < C::offbout) {
-        lds[C::ldsWout(BWD) + (e - C::offWout)] = w;
+        if constexpr (C::NOUT == 1) lds[C::ldsWout(BWD) + (e - C::offWout)] = w;
+        else place_wout((e - C::offWout) / H, (e - C::offWout) % H, w);
       } else {
-        lds[C::ldsbout(BWD)] = w;
+        lds[C::ldsbout(BWD) + (e - C::offbout)] = w;
       }
     };
     for (int base = 0; base < P; base += KP * nt) {
@@ -3282,13 +3308,22 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
     }
   }
 #endif
-  stage_weights<C, TRAIN>(lds, prm);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   constexpr int WAVES = C::BWD_THREADS / 64;
   constexpr int XS = group_xs<C>();
   constexpr int G = group_tiles<C>(), GP = 16 * G;      // tiles / points per group
   const int ngroups = (a.n + GP - 1) / GP;
+  // the first group's coordinates are requested before the weights are staged, every later group's one group ahead (round 5:
+  // the load sat at the top of the group loop, its HBM latency exposed once per group -- the tile kernels always prefetched)
+  real cn[PW::NC];
+  {
+    const int n0 = (blk * WAVES + wave) * GP + lane;
+    const int nn0 = (n0 < a.n && lane < GP) ? n0 : a.n - 1;
+#pragma unroll
+    for (int d = 0; d < PW::NC; ++d) cn[d] = a.coords[(size_t)d * a.ldc + nn0];
+  }
+  stage_weights<C, TRAIN>(lds, prm);
+  __syncthreads();
   real* stage = lds + C::ldsWeightsEnd(TRAIN) + wave * C::stageFloatsPerWave;
   real* X = lds + C::ldsWeightsEnd(TRAIN) + WAVES * C::stageFloatsPerWave + wave * (GP * XS);
   GradAcc<C> acc;
@@ -3300,10 +3335,23 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
   for (int grp = blk * WAVES + wave; grp < ngroups; grp += nblk * WAVES) {
     const int n = grp * GP + lane;                       // this lane's point in phase 2 (lanes >= GP idle there)
     const bool valid = n < a.n && lane < GP;
-    const int nn = valid ? n : a.n - 1;
     real c[PW::NC];
 #pragma unroll
-    for (int d = 0; d < PW::NC; ++d) c[d] = a.coords[(size_t)d * a.ldc + nn];
+    for (int d = 0; d < PW::NC; ++d) c[d] = cn[d];
+    {
+      const int n1 = (grp + nblk * WAVES) * GP + lane;
+      const int nn1 = (n1 < a.n && lane < GP) ? n1 : a.n - 1;
+#pragma unroll
+      for (int d = 0; d < PW::NC; ++d) cn[d] = a.coords[(size_t)d * a.ldc + nn1];
+    }
+#if !NDQ_GROUP_PREFETCH      // (A/B: the load at the top of the group loop, as in rounds 2 - 4)
+    {
+      const int nn = valid ? n : a.n - 1;
+#pragma unroll
+      for (int d = 0; d < PW::NC; ++d) c[d] = a.coords[(size_t)d * a.ldc + nn];
+      asm volatile("" : "+v"(c[0]));
+    }
+#endif
     // ---- phase 1: forward streams of the 4 tiles -> X
     NDQ_UNROLL(NDQ_GROUP_U1)
     for (int t = 0; t < G; ++t) {
