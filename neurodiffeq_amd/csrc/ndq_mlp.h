@@ -1692,17 +1692,32 @@ __device__ __forceinline__ void tile_forward(const real* lds, int lane, int q, c
 template <class C>
 __global__ __launch_bounds__(C::FWD_THREADS) void mlp_jet_fwd_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
-  stage_weights<C, false>(lds, a.params);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   const int wavesPerBlock = blockDim.x >> 6;
   const int ntiles = (a.n + 15) >> 4;
+  // the first tile's coordinates are requested before the weights are staged, every later tile's one tile ahead (round 5:
+  // the load sat at the top of the tile loop -- one exposed HBM round trip per tile on a SIMD that runs a single wave; the
+  // closure kernels always prefetched)
+  real xn[C::D];
+  {
+    const int n0 = (blockIdx.x * wavesPerBlock + wave) * 16 + p;
+    const int nn0 = n0 < a.n ? n0 : a.n - 1;
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn0];
+  }
+  stage_weights<C, false>(lds, a.params);
+  __syncthreads();
   for (int tile = blockIdx.x * wavesPerBlock + wave; tile < ntiles; tile += gridDim.x * wavesPerBlock) {
     const int n = tile * 16 + p;
-    const int nn = n < a.n ? n : a.n - 1;
     real x[C::D];
 #pragma unroll
-    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    for (int d = 0; d < C::D; ++d) x[d] = xn[d];
+    {
+      const int n1 = n + gridDim.x * wavesPerBlock * 16;
+      const int nn1 = n1 < a.n ? n1 : a.n - 1;
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn1];
+    }
     const real* ldsw = lds + opaque_zero<C>();
     LayerState<C> st;                      // one state, reused layer after layer (nothing is kept for a reverse pass)
     first_layer<C, false>(ldsw, q, x, st);
@@ -2670,11 +2685,24 @@ __device__ __forceinline__ void block_reduce_store(real* lds, GradAcc<C>& acc, i
 template <class C>
 __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) real lds[];
-  stage_weights<C, true>(lds, a.params);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, q = lane >> 4;
   constexpr int WAVES = C::BWD_THREADS / 64;
   const int ntiles = (a.n + 15) >> 4;
+  // coordinates and (single-output networks) seeds of the first tile before the weights are staged, of every later tile one tile
+  // ahead: loop-carried registers, so the loads cannot be sunk to their use (round 5; see mlp_jet_fwd_kernel)
+  real xn[C::D], gn[C::NOUT == 1 ? C::NS : 1];
+  {
+    const int n0 = (blockIdx.x * WAVES + wave) * 16 + p;
+    const int nn0 = n0 < a.n ? n0 : a.n - 1;
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn0];
+    if constexpr (C::NOUT == 1) {
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s) gn[s] = a.gbar[(size_t)s * a.ldj + nn0];
+    }
+  }
+  stage_weights<C, true>(lds, a.params);
+  __syncthreads();
   real* stage = lds + C::ldsWeightsEnd(true) + wave * C::stageFloatsPerWave;
   GradAcc<C> acc;
   acc_init<C>(acc, lds, WAVES, wave, lane);
@@ -2682,9 +2710,23 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
     const int nn = valid ? n : a.n - 1;
-    real x[C::D];
+    real x[C::D], gcur[C::NOUT == 1 ? C::NS : 1];
 #pragma unroll
-    for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+    for (int d = 0; d < C::D; ++d) x[d] = xn[d];
+    if constexpr (C::NOUT == 1) {
+#pragma unroll
+      for (int s = 0; s < C::NS; ++s) gcur[s] = gn[s];
+    }
+    {
+      const int n1 = n + gridDim.x * WAVES * 16;
+      const int nn1 = n1 < a.n ? n1 : a.n - 1;
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nn1];
+      if constexpr (C::NOUT == 1) {
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) gn[s] = a.gbar[(size_t)s * a.ldj + nn1];
+      }
+    }
     const real* ldsw = lds + opaque_zero<C>();
     LayerState<C> st[C::L];
     real4 h[C::NS][C::NB];
@@ -2693,7 +2735,7 @@ __global__ __launch_bounds__(C::BWD_THREADS) void mlp_jet_bwd_kernel(MlpArgs a) 
     if constexpr (C::NOUT == 1) {
       real gout[C::NS];
 #pragma unroll
-      for (int s = 0; s < C::NS; ++s) gout[s] = valid ? a.gbar[(size_t)s * a.ldj + nn] : 0.f;
+      for (int s = 0; s < C::NS; ++s) gout[s] = valid ? gcur[s] : 0.f;
       tile_backward<C>(ldsw, stage, lane, p, q, x, gout, st, acc, kp);
     } else {
       real4 go[C::NS][C::NBO];

@@ -473,13 +473,25 @@ __global__ __launch_bounds__(C::THREADS) void wide_jet_fwd_kernel(MlpArgs a) {
   WideUnits<C> un;
   wide_load_units<C>(a.params, ul, un);
   const int ntiles = (a.n + 15) >> 4;
+  real xvn[C::D];                              // coordinates one tile ahead (see wide_closure_body)
+  {
+    const int n0 = (blockIdx.x * C::WAVES + wave) * 16 + p;
+    const int nn0 = n0 < a.n ? n0 : a.n - 1;
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) xvn[d] = a.coords[(size_t)d * a.ldc + nn0];
+  }
   for (int tile = blockIdx.x * C::WAVES + wave; tile < ntiles; tile += gridDim.x * C::WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
-    const int nn = valid ? n : a.n - 1;
     real xv[C::D];
 #pragma unroll
-    for (int d = 0; d < C::D; ++d) xv[d] = a.coords[(size_t)d * a.ldc + nn];
+    for (int d = 0; d < C::D; ++d) xv[d] = xvn[d];
+    {
+      const int n1 = n + gridDim.x * C::WAVES * 16;
+      const int nn1 = n1 < a.n ? n1 : a.n - 1;
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) xvn[d] = a.coords[(size_t)d * a.ldc + nn1];
+    }
     WideKept<C> kept;
     wide_tile_forward<C, false, true>(un, xv, wl, a.params + C::offbout, lane, ul, pl, kept);
     if (valid) {
@@ -503,13 +515,26 @@ __global__ __launch_bounds__(C::THREADS) void wide_jet_bwd_kernel(MlpArgs a) {
 #pragma unroll
   for (int o = 0; o < C::NOUT; ++o) gbo[o] = 0.f;
   const int ntiles = (a.n + 15) >> 4;
+  real xvn[C::D];                              // coordinates one tile ahead (see wide_closure_body)
+  {
+    const int n0 = (blockIdx.x * C::WAVES + wave) * 16 + p;
+    const int nn0 = n0 < a.n ? n0 : a.n - 1;
+#pragma unroll
+    for (int d = 0; d < C::D; ++d) xvn[d] = a.coords[(size_t)d * a.ldc + nn0];
+  }
   for (int tile = blockIdx.x * C::WAVES + wave; tile < ntiles; tile += gridDim.x * C::WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
     const int nn = valid ? n : a.n - 1;
     real xv[C::D];
 #pragma unroll
-    for (int d = 0; d < C::D; ++d) xv[d] = a.coords[(size_t)d * a.ldc + nn];
+    for (int d = 0; d < C::D; ++d) xv[d] = xvn[d];
+    {
+      const int n1 = n + gridDim.x * C::WAVES * 16;
+      const int nn1 = n1 < a.n ? n1 : a.n - 1;
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) xvn[d] = a.coords[(size_t)d * a.ldc + nn1];
+    }
     // seeds of point p: lane group q stores components q, q + 4, ...
 #pragma unroll
     for (int k = 0; k < C::NCP / 4; ++k) {
@@ -549,13 +574,27 @@ __device__ __forceinline__ void wide_closure_body(const FusedArgs& a, real* lds,
 #pragma unroll
   for (int j = 0; j < PW::NT; ++j) { th[j] = a.theta[j]; tsum[j] = 0.f; }
   const int ntiles = (a.n + 15) >> 4;
+  // coordinates one tile ahead (round 5: the load at the top of the tile loop was one exposed HBM round trip per tile -- a wave
+  // has the SIMD to itself; the first tile's load overlaps what is left of the prologue)
+  real ccn[PW::NC];
+  {
+    const int n0 = (blk * C::WAVES + wave) * 16 + p;
+    const int nn0 = n0 < a.n ? n0 : a.n - 1;
+#pragma unroll
+    for (int d = 0; d < PW::NC; ++d) ccn[d] = a.coords[(size_t)d * a.ldc + nn0];
+  }
   for (int tile = blk * C::WAVES + wave; tile < ntiles; tile += nblk * C::WAVES) {
     const int n = tile * 16 + p;
     const bool valid = n < a.n;
-    const int nn = valid ? n : a.n - 1;
     real cc[PW::NC];
 #pragma unroll
-    for (int d = 0; d < PW::NC; ++d) cc[d] = a.coords[(size_t)d * a.ldc + nn];
+    for (int d = 0; d < PW::NC; ++d) cc[d] = ccn[d];
+    {
+      const int n1 = n + nblk * C::WAVES * 16;
+      const int nn1 = n1 < a.n ? n1 : a.n - 1;
+#pragma unroll
+      for (int d = 0; d < PW::NC; ++d) ccn[d] = a.coords[(size_t)d * a.ldc + nn1];
+    }
     real xv[C::D];
     sfor<C::D>([&](auto d_) {
       constexpr int d = decltype(d_)::value;
