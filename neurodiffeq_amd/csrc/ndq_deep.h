@@ -540,17 +540,27 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
   const int vid = xcd_block_id();                          // (the NCH chunks of a stripe share its operand rows: one XCD)
   const int ch = vid % NCH, bstripe = vid / NCH, nbstripes = gridDim.x / NCH;
   if (bstripe >= nbstripes) return;                        // (whole workgroups: no barrier is missed)
-  // ---- this workgroup's weight planes -> LDS, once
+  // ---- this workgroup's weight planes -> LDS, once.  Eight 16-byte loads of a thread in flight per pass (round 5): the plain
+  // copy loop compiled to "global_load_dwordx4, s_waitcnt vmcnt(0), ds_write_b128" per element -- 24 dependent round trips for
+  // the 96 KB of a 128-unit layer, ~10 us of every launch of this kernel.
   {
-    const bf16x8* src = static_cast<const bf16x8*>(a.wpl);
-    for (int e = threadIdx.x; e < JB * NCK * 3 * 64; e += C::THREADS) {
-      const int jb = e / (NCK * 3 * 64), rest = e % (NCK * 3 * 64);
-      const int b = ch * JB + jb;
-      bf16x8 v;
+    const real4* src = static_cast<const real4*>(a.wpl);            // (a bf16x8 element is 16 bytes)
+    real4* dst = reinterpret_cast<real4*>(wl);
+    constexpr int TOT = JB * NCK * 3 * 64, PER = NCK * 3 * 64, KP = 8;
+    for (int e0 = 0; e0 < TOT; e0 += KP * C::THREADS) {
+      real4 v[KP];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) v[t] = (__bf16)0.f;
-      if (b < C::NB) v = src[(size_t)b * (NCK * 3 * 64) + rest];
-      wl[e] = v;
+      for (int k = 0; k < KP; ++k) {
+        const int e = e0 + threadIdx.x + k * C::THREADS, ec = e < TOT ? e : TOT - 1;
+        const int b = ch * JB + ec / PER;
+        v[k] = src[(size_t)(b < C::NB ? b : C::NB - 1) * PER + ec % PER];
+      }
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const int e = e0 + threadIdx.x + k * C::THREADS;
+        if (e < TOT) dst[e] = (ch * JB + e / PER < C::NB) ? v[k] : real4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
   const int ntiles = a.np >> 4;
@@ -585,13 +595,45 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
     }
   }
   __syncthreads();
-  for (int tile = bstripe * C::WAVES + wave; tile < ntiles; tile += nbstripes * C::WAVES) {
-    const int n = tile * 16 + p;
-    const int nn = n < a.n ? n : a.n - 1;
-    real x[C::D];
+  // ---- carried from one tile to the next (round 5): the rows of contraction step 0, the point's coordinates and seeds of the
+  // NEXT tile are requested during the last contraction step of the current one -- the loads at the top of the tile loop were one
+  // exposed HBM round trip per tile (a wave has its SIMD to itself)
+  real4 vlon[SRC == 0 ? 1 : NS], vhin[SRC == 0 ? 1 : NS];
+  real xn[(SRC == 0 || EPI == 2) ? C::D : 1], gsn[SRC == 3 ? C::NC : 1];
+  auto fetch_next = [&](int t) {
+    const int nr = t * 16 + p, nnr = nr < a.n ? nr : a.n - 1;
     if constexpr (SRC == 0 || EPI == 2) {
 #pragma unroll
-      for (int d = 0; d < C::D; ++d) x[d] = a.coords[(size_t)d * a.ldc + nn];
+      for (int d = 0; d < C::D; ++d) xn[d] = a.coords[(size_t)d * a.ldc + nnr];
+    }
+    if constexpr (SRC == 3) {
+#pragma unroll
+      for (int cc = 0; cc < C::NC; ++cc) {
+        const real v = a.gbar[(size_t)cc * a.ldj + nnr];
+        gsn[cc] = nr < a.n ? v : 0.f;                       // (padding points: zero -> Zbar_L = 0)
+      }
+    }
+    if constexpr (SRC != 0) {
+      const real4 zero = real4{0.f, 0.f, 0.f, 0.f};
+      const int k0 = 8 * kg;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const real* row = a.zin + s * sstride + (size_t)nr * C::HP;
+        vlon[s] = k0 < C::HP ? *reinterpret_cast<const real4*>(row + k0) : zero;
+        vhin[s] = k0 + 4 < C::HP ? *reinterpret_cast<const real4*>(row + k0 + 4) : zero;
+      }
+    }
+  };
+  {
+    const int t0 = bstripe * C::WAVES + wave;
+    if (t0 < ntiles) fetch_next(t0);
+  }
+  for (int tile = bstripe * C::WAVES + wave; tile < ntiles; tile += nbstripes * C::WAVES) {
+    const int n = tile * 16 + p;
+    real x[(SRC == 0 || EPI == 2) ? C::D : 1];
+    if constexpr (SRC == 0 || EPI == 2) {
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) x[d] = xn[d];
     }
     real4 acc[NS][JB];
 #pragma unroll
@@ -612,11 +654,12 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
     real4 vlo[SRC == 0 ? 1 : NS], vhi[SRC == 0 ? 1 : NS];
     real f1w[SRC == 0 ? 8 : 1][C::D], f1b[SRC == 0 ? 8 : 1];
     real wo8[SRC == 3 ? 8 : 1][C::NOUT], gs[SRC == 3 ? C::NC : 1];
-    if constexpr (SRC == 3) {                              // the point's seeds (padding points: zero -> Zbar_L = 0)
+    if constexpr (SRC == 3) {                              // the point's seeds
 #pragma unroll
-      for (int cc = 0; cc < C::NC; ++cc) gs[cc] = n < a.n ? a.gbar[(size_t)cc * a.ldj + nn] : 0.f;
+      for (int cc = 0; cc < C::NC; ++cc) gs[cc] = gsn[cc];
     }
-    auto fetch = [&](int c) {
+    // rows: also load this lane's rows of Z (false for step 0: they were prefetched into vlon / vhin)
+    auto fetch = [&](int c, bool rows) {
       const int k0 = 32 * c + 8 * kg;
       if constexpr (SRC == 3) {
 #pragma unroll
@@ -634,7 +677,7 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
 #pragma unroll
           for (int d = 0; d < C::D; ++d) f1w[e][d] = ok ? a.prm[C::offW1 + (ok ? k0 + e : 0) * C::D + d] : 0.f;
         }
-      } else {
+      } else if (rows) {
         const real4 zero = real4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -699,10 +742,18 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
 #pragma unroll
       for (int s = 0; s < NS; ++s) split3(hlo[s], hhi[s], pl[s]);
     };
-    fetch(0);
+    fetch(0, false);
+    if constexpr (SRC != 0) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { vlo[s] = vlon[s]; vhi[s] = vhin[s]; }
+    }
     planes();
     for (int c = 0; c < NCK; ++c) {
-      if (c + 1 < NCK) fetch(c + 1);
+      if (c + 1 < NCK) fetch(c + 1, true);
+      else {                                               // last step: the next tile's first rows / point data
+        const int tn = tile + nbstripes * C::WAVES;
+        fetch_next(tn < ntiles ? tn : tile);
+      }
       __builtin_amdgcn_sched_barrier(0);                   // the loads stay above the MFMAs
 #pragma unroll
       for (int jb = 0; jb < JB; ++jb) {
