@@ -33,6 +33,9 @@
 #ifndef NDQ_DEEP_XCD_REMAP
 #define NDQ_DEEP_XCD_REMAP 1       // 0: plain blockIdx (A/B runs of the XCD-aware workgroup mapping, xcd_block_id below)
 #endif
+#ifndef NDQ_DEEP_WGRAD_BF
+#define NDQ_DEEP_WGRAD_BF 1        // 0: weight gradients as exact-f32 MFMA products (deep_wgrad_gemm, rounds 4 - 5a); 1: bf16x3 (deep_wgrad_bf)
+#endif
 #ifndef NDQ_DEEP_HEAD_FUSED
 #define NDQ_DEEP_HEAD_FUSED 1      // 0: deep_head_bwd materialises Zbar_L (round 4); 1: its consumers form it from Z_L and the seeds
 #endif
@@ -523,6 +526,15 @@ __global__ __launch_bounds__(C::THREADS, NDQ_DEEP_OCC) void deep_bwd_gemm(DeepAr
 #define NDQ_DEEP_BF_LDS_KB 96      // LDS a workgroup spends on its resident weight planes (48: two workgroups per CU)
 #endif
 constexpr int kDeepBfOcc = NDQ_DEEP_BF_LDS_KB <= 48 ? 2 : 1;
+// Waves per workgroup of the per-point GEMMs.  The resident weight planes allow ONE workgroup per CU, i.e. one wave per SIMD
+// with 4 waves.  8 waves sharing the planes (two per SIMD: better VALU throughput on the dependent chains of the jets, as
+// the weight-gradient kernel shows between one and two workgroups per CU) were measured in round 5 and lose: the variants
+// need 312 - 472 registers, the 256 of an 8-wave workgroup cost 184 - 556 bytes of scratch per lane (128 x 3: 611 against
+// 502 us per step, 256 x 2: 1 021 against 1 003; profiles/r05n_bf_waves_ab.jsonl).  Kept as a build option.
+#ifndef NDQ_DEEP_BF_WAVES
+#define NDQ_DEEP_BF_WAVES 4
+#endif
+constexpr int kDeepBfWaves = NDQ_DEEP_BF_WAVES, kDeepBfThreads = 64 * kDeepBfWaves;
 template <class C, int EPI> constexpr int deep_bf_jb() {
   constexpr int NCK = (C::HP + 31) / 32;
   int j = (NDQ_DEEP_BF_LDS_KB / 3) / NCK;                  // planes of the chunk: 3 KB per (block, contraction chunk)
@@ -533,7 +545,7 @@ template <class C, int EPI> constexpr int deep_bf_jb() {
 }
 
 template <class C, int SRC, int EPI>
-__global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs a) {
+__global__ __launch_bounds__(kDeepBfThreads, kDeepBfOcc) void deep_gemm_bf(DeepArgs a) {
   constexpr int JB = deep_bf_jb<C, EPI>(), NCH = (C::NB + JB - 1) / JB, NCK = (C::HP + 31) / 32, NS = C::NS;
   extern __shared__ __attribute__((aligned(16))) bf16x8 wl[];          // [JB][NCK][3][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, kg = lane >> 4;
@@ -547,18 +559,18 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
     const real4* src = static_cast<const real4*>(a.wpl);            // (a bf16x8 element is 16 bytes)
     real4* dst = reinterpret_cast<real4*>(wl);
     constexpr int TOT = JB * NCK * 3 * 64, PER = NCK * 3 * 64, KP = 8;
-    for (int e0 = 0; e0 < TOT; e0 += KP * C::THREADS) {
+    for (int e0 = 0; e0 < TOT; e0 += KP * kDeepBfThreads) {
       real4 v[KP];
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
-        const int e = e0 + threadIdx.x + k * C::THREADS, ec = e < TOT ? e : TOT - 1;
+        const int e = e0 + threadIdx.x + k * kDeepBfThreads, ec = e < TOT ? e : TOT - 1;
         const int b = ch * JB + ec / PER;
         v[k] = src[(size_t)(b < C::NB ? b : C::NB - 1) * PER + ec % PER];
       }
       asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
-        const int e = e0 + threadIdx.x + k * C::THREADS;
+        const int e = e0 + threadIdx.x + k * kDeepBfThreads;
         if (e < TOT) dst[e] = (ch * JB + e / PER < C::NB) ? v[k] : real4{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -625,10 +637,10 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
     }
   };
   {
-    const int t0 = bstripe * C::WAVES + wave;
+    const int t0 = bstripe * kDeepBfWaves + wave;
     if (t0 < ntiles) fetch_next(t0);
   }
-  for (int tile = bstripe * C::WAVES + wave; tile < ntiles; tile += nbstripes * C::WAVES) {
+  for (int tile = bstripe * kDeepBfWaves + wave; tile < ntiles; tile += nbstripes * kDeepBfWaves) {
     const int n = tile * 16 + p;
     real x[(SRC == 0 || EPI == 2) ? C::D : 1];
     if constexpr (SRC == 0 || EPI == 2) {
@@ -751,7 +763,7 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
     for (int c = 0; c < NCK; ++c) {
       if (c + 1 < NCK) fetch(c + 1, true);
       else {                                               // last step: the next tile's first rows / point data
-        const int tn = tile + nbstripes * C::WAVES;
+        const int tn = tile + nbstripes * kDeepBfWaves;
         fetch_next(tn < ntiles ? tn : tile);
       }
       __builtin_amdgcn_sched_barrier(0);                   // the loads stay above the MFMAs
@@ -846,7 +858,7 @@ __global__ __launch_bounds__(C::THREADS, kDeepBfOcc) void deep_gemm_bf(DeepArgs 
   }
   if constexpr (!STORE) {
     // partial rows: one per WAVE (row index = workgroup stripe x 4 + wave), every chunk fills its own units
-    const int row = bstripe * C::WAVES + wave;
+    const int row = bstripe * kDeepBfWaves + wave;
 #pragma unroll
     for (int jb = 0; jb < JB; ++jb) {
       const int b = ch * JB + jb;
@@ -1076,6 +1088,270 @@ __global__ __launch_bounds__(C::THREADS, 2) void deep_wgrad_gemm(DeepArgs a) {
           for (int r = 0; r < 4; ++r) acc[u][v][r] += comb[w][(u * 4 + v) * 4 + r][lane];
     // D layout: register r of lane (i, kg) = row 4 kg + r, column i of the 16 x 16 block (u, v):
     // row unit = 64 tj + 4 (4 kg + r) + u, column units 64 tk + 4 i + v, v = 0 .. 3 -- one 16-byte store
+    real* out = a.pw + (size_t)ks * C::HP * C::HP;
+    const int jbase = 64 * (tl / C::NT);
+    if (kok) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = jbase + 4 * (4 * kg + r) + u;
+          if (row < C::HP)
+            *reinterpret_cast<real4*>(out + (size_t)row * C::HP + k0) = real4{acc[u][0][r], acc[u][1][r], acc[u][2][r], acc[u][3][r]};
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradients, bf16x3
+// dW_l on the bf16 matrix core (round 5).  Same tiling, same loads and the same per-lane arithmetic in front of the products as
+// deep_wgrad_gemm; what changes is the product: v_mfma_f32_16x16x32_bf16 contracts 32 slots per instruction, 8 per lane.  The
+// contraction index of dW_l = sum_{s, n} Zbar_l[s][n][j] H_{l-1}[s][n][k] is the PAIR (point, stream), and any order of it
+// serves as long as both operands agree -- so a lane's 8 slots of a chunk are simply the next 8 (group, stream) values it
+// produces: point group g hands every lane (i, kg) the NS stream values of point 4 g + kg for its 4 row units and its 4 column
+// units (two 16-byte loads per stream, as before), they are split two at a time into three bf16 planes (x = x0 + x1 + x2) and
+// written into the chunk's next two slots; a full chunk issues the six significant plane products for the 4 x 4 blocks of the
+// tile.  U = 8 / gcd(8, NS) groups (at least 2) fill whole chunks: a ROUND of U groups is straight-line code, so every slot
+// index is a compile-time constant and nothing is transposed anywhere.  6 products of 16 cycles per 8 slots against 8
+// exact-f32 products of 32 cycles (product and VALU time add up for either format: DESIGN.md 4.0).  A wave's last round is
+// padded with groups whose row operand is zero.
+// Accuracy: fp32-class, as for the per-point GEMMs (csrc/ndq_mlp.h); sums in fixed order (per wave, then waves in order).
+template <int E>
+__device__ __forceinline__ void split3_pair_into(real x0, real x1, bf16x8 (&pl)[3]) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {x0, x1};
+  const bf16x2 h0 = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = v - __builtin_convertvector(h0, f32x2);
+  const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(h1, f32x2);
+  const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
+  pl[0][E] = h0[0]; pl[0][E + 1] = h0[1];
+  pl[1][E] = h1[0]; pl[1][E + 1] = h1[1];
+  pl[2][E] = h2[0]; pl[2][E + 1] = h2[1];
+}
+constexpr int deep_wgbf_groups(int ns) {
+  int g = 8, a = ns;
+  while (a) { const int t = g % a; g = a; a = t; }         // gcd(8, ns)
+  const int u = 8 / g;
+  return u < 2 ? 2 : u;
+}
+// workgroups per CU: two where a round is ONE chunk (NS = 1, 2, 4: <= 256 registers; measured at 128 x 3: 477 against 512 us
+// per step with one), else one (NS = 5: 320 - 340 registers, forcing 256 spills)
+#ifndef NDQ_DEEP_WGBF_OCC
+#define NDQ_DEEP_WGBF_OCC 0        // 0: by stream count (above); 1 / 2: forced (A/B runs)
+#endif
+constexpr int deep_wgbf_occ(int ns) {
+  return NDQ_DEEP_WGBF_OCC ? NDQ_DEEP_WGBF_OCC : (ns * deep_wgbf_groups(ns) == 8 ? 2 : 1);
+}
+// groups whose rows are in flight per wave (a group is 2 NS 16-byte loads per lane).  Measured at 256 x 2 (one workgroup per
+// CU): 1 / 2 / 4 groups ahead 1 006 / 1 004 / 1 015 us per step -- the kernel is not waiting for memory; 2 costs nothing.
+#ifndef NDQ_DEEP_WGBF_PF
+#define NDQ_DEEP_WGBF_PF 0         // 0: 1 with two workgroups per CU, else 2; 1 / 2 / 4: forced (A/B runs)
+#endif
+constexpr int deep_wgbf_pf(int ns) { return NDQ_DEEP_WGBF_PF ? NDQ_DEEP_WGBF_PF : (deep_wgbf_occ(ns) == 2 ? 1 : 2); }
+
+template <class C, bool FIRSTIN, bool HEAD = false>
+__global__ __launch_bounds__(C::THREADS, deep_wgbf_occ(C::NS)) void deep_wgrad_bf(DeepArgs a) {
+  __shared__ real comb[3][64][64];
+  constexpr int NS = C::NS, U = deep_wgbf_groups(NS), PF = deep_wgbf_pf(NS), G = U > PF ? U : PF;     // groups per loop iteration
+  static_assert((NS * U) % 8 == 0 && G % U == 0 && G % PF == 0, "whole chunks per round, whole rounds and buffer turns per iteration");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kg = lane >> 4;
+  constexpr int NT2 = C::NT * C::NT;
+  const int vid = xcd_block_id();
+  const int tl = vid % NT2, ks = vid / NT2, KS = gridDim.x / NT2;
+  if (ks >= KS) return;
+  const int j0 = 64 * (tl / C::NT) + 4 * i, k0 = 64 * (tl % C::NT) + 4 * i;
+  const bool jok = j0 < C::HP, kok = k0 < C::HP;
+  const int j0c = jok ? j0 : 0, k0c = kok ? k0 : 0;        // (clamped: every load below is unconditional)
+  const size_t sstride = (size_t)a.np * C::HP;
+  real4 acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = real4{0.f, 0.f, 0.f, 0.f};
+  real w1v[FIRSTIN ? 4 : 1][C::D], b1v[FIRSTIN ? 4 : 1];
+  if constexpr (FIRSTIN) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const bool ok = k0 + v < C::W;
+      b1v[v] = ok ? a.prm[C::offb1 + (ok ? k0 + v : 0)] : 0.f;
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) w1v[v][d] = ok ? a.prm[C::offW1 + (ok ? k0 + v : 0) * C::D + d] : 0.f;
+    }
+  }
+  const int ngroups = a.np >> 2, g0 = ks * C::WAVES + wave, gstep = KS * C::WAVES;
+  const bool side = HEAD && (tl % C::NT) == 0;
+  real wov[HEAD ? 4 : 1][C::NOUT], dwo[HEAD ? 4 : 1][C::NOUT], dbl[HEAD ? 4 : 1], gbo[HEAD ? C::NOUT : 1];
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const bool ok = j0 + v < C::W;
+      dbl[v] = 0.f;
+#pragma unroll
+      for (int o = 0; o < C::NOUT; ++o) {
+        wov[v][o] = ok ? a.prm[C::offWout + o * C::W + (ok ? j0 + v : 0)] : 0.f;
+        dwo[v][o] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < C::NOUT; ++o) gbo[o] = 0.f;
+  }
+  // the rows of the NEXT PF groups, requested while the current group is being worked on (PF buffers taken in turn; group index
+  // clamped, `live` = the group exists)
+  real4 zab[PF][NS], zkb[PF][FIRSTIN ? 1 : NS];
+  real xb[PF][FIRSTIN ? C::D : 1], gsb[PF][HEAD ? C::NC : 1];
+  bool liveb[PF];
+  auto fetch = [&](auto b_, int g4) {
+    constexpr int b = decltype(b_)::value;
+    const bool live = g4 < ngroups;
+    liveb[b] = live;
+    const int n = 4 * (live ? g4 : ngroups - 1) + kg, ns = n < a.n ? n : a.n - 1;
+    if constexpr (HEAD) {
+#pragma unroll
+      for (int cc = 0; cc < C::NC; ++cc) {
+        const real v = a.gbar[(size_t)cc * a.ldj + ns];
+        gsb[b][cc] = (live && n < a.n) ? v : 0.f;          // (padding points and padding groups: Zbar_L = 0)
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) zab[b][s] = *reinterpret_cast<const real4*>(a.zin + s * sstride + (size_t)n * C::HP + j0c);
+    if constexpr (FIRSTIN) {
+#pragma unroll
+      for (int d = 0; d < C::D; ++d) xb[b][d] = a.coords[(size_t)d * a.ldc + ns];
+    } else {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) zkb[b][s] = *reinterpret_cast<const real4*>(a.zprev + s * sstride + (size_t)n * C::HP + k0c);
+    }
+  };
+  sfor<PF>([&](auto b_) { fetch(b_, g0 + decltype(b_)::value * gstep); });
+  bf16x8 cA[4][3], cB[4][3];
+  real pa[4], pb[4];
+  for (int gr = g0; gr < ngroups; gr += G * gstep) {
+    sfor<G>([&](auto gi_) {
+      constexpr int gi = decltype(gi_)::value, bi = gi % PF;
+      // ---- this group's values: rows av = Zbar_l (HEAD: formed here), columns hv = sigma-jet(Z_{l-1})
+      real4 av[NS], hv[NS];
+      const bool rows = liveb[bi] && jok;
+      real4 (&za)[NS] = zab[bi];
+      real4 (&zk)[FIRSTIN ? 1 : NS] = zkb[bi];
+      real (&x)[FIRSTIN ? C::D : 1] = xb[bi];
+      real (&gsn)[HEAD ? C::NC : 1] = gsb[bi];
+      if constexpr (HEAD) {
+#pragma unroll
+        for (int o = 0; o < C::NOUT; ++o) gbo[o] += gsn[o];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          real z[NS], g[NS], h[NS], tt, cc;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            z[s] = jok ? za[s][v] : 0.f;
+            real w = 0.f;
+#pragma unroll
+            for (int o = 0; o < C::NOUT; ++o) w = rfma(wov[v][o], gsn[s * C::NOUT + o], w);
+            g[s] = w;
+          }
+          if (side) {                                        // (workgroup-uniform)
+            jet_unit_forward<C>(z, h, tt, cc);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+              for (int o = 0; o < C::NOUT; ++o) dwo[v][o] = rfma(gsn[s * C::NOUT + o], h[s], dwo[v][o]);
+          } else {
+            Act<C::ACT>::fwd(z[0], tt, cc);
+          }
+          jet_unit_backward<C>(z, tt, cc, g);
+          dbl[v] += g[0];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) av[s][v] = g[s];
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) av[s] = rows ? za[s] : real4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        real z[NS], h[NS], tt, cc;
+        if constexpr (FIRSTIN) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) z[s] = 0.f;
+          real zv = b1v[v];
+#pragma unroll
+          for (int d = 0; d < C::D; ++d) {
+            zv = rfma(w1v[v][d], x[d], zv);
+            if constexpr (C::SS::FIRST) z[1 + d] = w1v[v][d];
+          }
+          z[0] = zv;
+        } else {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) z[s] = kok ? zk[s][v] : 0.f;
+        }
+        jet_unit_forward<C>(z, h, tt, cc);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) hv[s][v] = h[s];
+      }
+      fetch(std::integral_constant<int, bi>{}, gr + (gi + PF) * gstep);      // this buffer's next group, PF groups ahead
+      __builtin_amdgcn_sched_barrier(0);                     // (the loads are issued before the splits / products below)
+      // ---- the group's NS values per unit -> the next NS slots of the chunk
+      sfor<NS>([&](auto s_) {
+        constexpr int s = decltype(s_)::value, q = (gi % U) * NS + s, e = q % 8;
+        if constexpr (e % 2 == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { pa[u] = av[s][u]; pb[u] = hv[s][u]; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            split3_pair_into<e - 1>(pa[u], av[s][u], cA[u]);
+            split3_pair_into<e - 1>(pb[u], hv[s][u], cB[u]);
+          }
+        }
+        if constexpr (e == 7) {
+#define NDQ_WG(QA, QB)                                                                                       \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                              \
+  _Pragma("unroll") for (int v = 0; v < 4; ++v)                                                              \
+      acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cA[u][QA], cB[v][QB], acc[u][v], 0, 0, 0);
+          NDQ_WG(1, 1) NDQ_WG(2, 0) NDQ_WG(0, 2) NDQ_WG(1, 0) NDQ_WG(0, 1) NDQ_WG(0, 0)
+#undef NDQ_WG
+        }
+      });
+    });
+  }
+  if constexpr (HEAD) {
+    const int row = ks * C::WAVES + wave;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const real db = quad_sum(dbl[v]);
+      if (side && kg == 0 && j0 + v < C::HP) a.pbh[(size_t)row * C::HP + j0 + v] = db;
+#pragma unroll
+      for (int o = 0; o < C::NOUT; ++o) {
+        const real dw = quad_sum(dwo[v][o]);
+        if (side && kg == 0 && j0 + v < C::HP) a.pwo[((size_t)row * C::NOUT + o) * C::HP + j0 + v] = dw;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < C::NOUT; ++o) {
+      const real gb = quad_sum(gbo[o]);
+      if (tl == 0 && lane == 0) a.pbo[(size_t)row * C::NOUT + o] = gb;
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) comb[wave - 1][(u * 4 + v) * 4 + r][lane] = acc[u][v][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll 1
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][v][r] += comb[w][(u * 4 + v) * 4 + r][lane];
     real* out = a.pw + (size_t)ks * C::HP * C::HP;
     const int jbase = 64 * (tl / C::NT);
     if (kok) {

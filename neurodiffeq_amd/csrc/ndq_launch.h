@@ -240,7 +240,7 @@ int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc
     if (e) return e;
     attr = true;
   }
-  int stripes = (ntiles + C::WAVES - 1) / C::WAVES;                                        // one workgroup per CU: its weight planes fill the LDS
+  int stripes = (ntiles + kDeepBfWaves - 1) / kDeepBfWaves;                              // one workgroup per CU: its weight planes fill the LDS
   if (stripes > kDeepBfOcc * q.blocks_max / NCHB0) stripes = kDeepBfOcc * q.blocks_max / NCHB0;
   if (stripes < 1) stripes = 1;
 #else
@@ -260,15 +260,15 @@ int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc
     if constexpr (NCHB0 == 1 && NDQ_DEEP_HEAD_FWD_FUSED) {
       if (jets && l == C::L) {
         a.jets = jets; a.ldj = ldj;
-        if (l == 2) hipLaunchKernelGGL((deep_gemm_bf<C, 0, 3>), dim3(stripes), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
-        else hipLaunchKernelGGL((deep_gemm_bf<C, 1, 3>), dim3(stripes), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
+        if (l == 2) hipLaunchKernelGGL((deep_gemm_bf<C, 0, 3>), dim3(stripes), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 0>()), st, a);
+        else hipLaunchKernelGGL((deep_gemm_bf<C, 1, 3>), dim3(stripes), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 0>()), st, a);
         folded = true;
         if (head_done) *head_done = 1;
       }
     }
     if (folded) continue;
-    if (l == 2) hipLaunchKernelGGL((deep_gemm_bf<C, 0, 0>), dim3(stripes * NCHB0), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
-    else hipLaunchKernelGGL((deep_gemm_bf<C, 1, 0>), dim3(stripes * NCHB0), dim3(C::THREADS), (deep_bf_lds_bytes<C, 0>()), st, a);
+    if (l == 2) hipLaunchKernelGGL((deep_gemm_bf<C, 0, 0>), dim3(stripes * NCHB0), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 0>()), st, a);
+    else hipLaunchKernelGGL((deep_gemm_bf<C, 1, 0>), dim3(stripes * NCHB0), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 0>()), st, a);
 #else
     if (l == 2) hipLaunchKernelGGL((deep_fwd_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
     else hipLaunchKernelGGL((deep_fwd_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
@@ -354,17 +354,25 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       a.pw = ws + q.pw + (size_t)(l - 2) * q.pw_layer;
       // one workgroup per (tile, point slice)
       int KS = (q.np / 4 + C::WAVES - 1) / C::WAVES;
-      if (KS > 2 * q.blocks_max / (C::NT * C::NT)) KS = 2 * q.blocks_max / (C::NT * C::NT);      // two workgroups per CU
+#if NDQ_DEEP_WGRAD_BF
+      constexpr int kWgOcc = deep_wgbf_occ(C::NS);         // bf16x3 products (deep_wgrad_bf)
+#define NDQ_WGRAD_KERNEL deep_wgrad_bf
+#else
+      constexpr int kWgOcc = 2;                            // exact-f32 products (deep_wgrad_gemm): two workgroups per CU
+#define NDQ_WGRAD_KERNEL deep_wgrad_gemm
+#endif
+      if (KS > kWgOcc * q.blocks_max / (C::NT * C::NT)) KS = kWgOcc * q.blocks_max / (C::NT * C::NT);
       if (KS < 1) KS = 1;
       const int blocks = KS * C::NT * C::NT;
       if (head) {
-        if (l == 2) hipLaunchKernelGGL((deep_wgrad_gemm<C, true, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
-        else hipLaunchKernelGGL((deep_wgrad_gemm<C, false, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+        if (l == 2) hipLaunchKernelGGL((NDQ_WGRAD_KERNEL<C, true, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+        else hipLaunchKernelGGL((NDQ_WGRAD_KERNEL<C, false, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
         reduce(a.pwo, KS * C::WAVES, C::NOUT, C::HP, C::NOUT, C::W, grad + C::offWout);
         reduce(a.pbh, KS * C::WAVES, 1, C::HP, 1, C::W, grad + C::offb(C::L));
         reduce(a.pbo, KS * C::WAVES, 1, C::NOUT, 1, C::NOUT, grad + C::offbout);
-      } else if (l == 2) hipLaunchKernelGGL((deep_wgrad_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
-      else hipLaunchKernelGGL((deep_wgrad_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+      } else if (l == 2) hipLaunchKernelGGL((NDQ_WGRAD_KERNEL<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+      else hipLaunchKernelGGL((NDQ_WGRAD_KERNEL<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
+#undef NDQ_WGRAD_KERNEL
       reduce(a.pw, KS, C::HP, C::HP, C::W, C::W, grad + C::offW(l));
     }
     a.wmat = ws + q.wt + (size_t)(l - 2) * C::HP * C::HP;
@@ -385,7 +393,7 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       }
     }
     auto bf_stripes = [&](int nch) {
-      int s = (ntiles + C::WAVES - 1) / C::WAVES;
+      int s = (ntiles + kDeepBfWaves - 1) / kDeepBfWaves;
       if (s > kDeepBfOcc * q.blocks_max / nch) s = kDeepBfOcc * q.blocks_max / nch;
       return s < 1 ? 1 : s;
     };
@@ -393,18 +401,18 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       constexpr int NCHB1 = (C::NB + deep_bf_jb<C, 1>() - 1) / deep_bf_jb<C, 1>();
       a.zout = ws + q.zb0 + (size_t)(cur ^ 1) * q.X;
       const int stripes = bf_stripes(NCHB1);
-      if (head) hipLaunchKernelGGL((deep_gemm_bf<C, 3, 1>), dim3(stripes * NCHB1), dim3(C::THREADS), (deep_bf_lds_bytes<C, 1>()), st, a);
-      else hipLaunchKernelGGL((deep_gemm_bf<C, 2, 1>), dim3(stripes * NCHB1), dim3(C::THREADS), (deep_bf_lds_bytes<C, 1>()), st, a);
-      reduce(a.pb, stripes * C::WAVES, 1, C::HP, 1, C::W, grad + C::offb(l - 1));
+      if (head) hipLaunchKernelGGL((deep_gemm_bf<C, 3, 1>), dim3(stripes * NCHB1), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 1>()), st, a);
+      else hipLaunchKernelGGL((deep_gemm_bf<C, 2, 1>), dim3(stripes * NCHB1), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 1>()), st, a);
+      reduce(a.pb, stripes * kDeepBfWaves, 1, C::HP, 1, C::W, grad + C::offb(l - 1));
       cur ^= 1;
     } else {
       constexpr int NCHB2 = (C::NB + deep_bf_jb<C, 2>() - 1) / deep_bf_jb<C, 2>();
       a.pw1 = ws + q.pw1;
       const int stripes = bf_stripes(NCHB2);
-      if (head) hipLaunchKernelGGL((deep_gemm_bf<C, 3, 2>), dim3(stripes * NCHB2), dim3(C::THREADS), (deep_bf_lds_bytes<C, 2>()), st, a);
-      else hipLaunchKernelGGL((deep_gemm_bf<C, 2, 2>), dim3(stripes * NCHB2), dim3(C::THREADS), (deep_bf_lds_bytes<C, 2>()), st, a);
-      reduce(a.pb, stripes * C::WAVES, 1, C::HP, 1, C::W, grad + C::offb1);
-      reduce(a.pw1, stripes * C::WAVES, C::HP, C::D, C::W, C::D, grad + C::offW1);
+      if (head) hipLaunchKernelGGL((deep_gemm_bf<C, 3, 2>), dim3(stripes * NCHB2), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 2>()), st, a);
+      else hipLaunchKernelGGL((deep_gemm_bf<C, 2, 2>), dim3(stripes * NCHB2), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 2>()), st, a);
+      reduce(a.pb, stripes * kDeepBfWaves, 1, C::HP, 1, C::W, grad + C::offb1);
+      reduce(a.pw1, stripes * kDeepBfWaves, C::HP, C::D, C::W, C::D, grad + C::offW1);
     }
 #else
     if (l > 2) {

@@ -22,6 +22,9 @@ with _hipcc.deferred():
         program, descs = trace_system(cfg["nets"], cfg["conds"], configs.fused_equations(cfg), configs.n_coords(cfg),
                                       compute_func_val=configs.func_val(cfg))
         print(name, "pointwise:", codegen.build(program), flush=True)
+        for d in descs.values():   # wide / deep networks: the extension module with their stream / adjoint kernels
+            if d.hidden > 64 and codegen.mlp_ext_allowed(d):
+                print(name, "mlp ext:", codegen.build_mlp_ext(d), flush=True)
         if codegen.can_fuse(program, descs):
             print(name, "closure:", codegen.build_fused(program, descs[0]), flush=True)
             if os.environ.get("PREBUILD_WIDE"):
