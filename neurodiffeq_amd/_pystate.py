@@ -7,7 +7,8 @@ literal of the generated kernel.  ``StateWatch`` records, at trace time, the lea
 reach -- closure cells, the module globals their code names, attributes of the user modules they name, default arguments,
 attributes (``__dict__`` and ``__slots__``) of bound ``self`` objects and of the condition objects, the plain class
 attributes and the methods behind them, dicts / lists / tuples / deques / sets, small ndarrays by content and larger ones
-by CRC -- as (where, expected stamp) entries and compiles them into ONE checker function (a chain of ``and``-ed
+by CRC, the buffers / parameters / attributes / submodules of the user's own ``torch.nn.Module`` objects, the referents of
+weak references -- as (where, expected stamp) entries and compiles them into ONE checker function (a chain of ``and``-ed
 comparisons, ~0.05 us per entry: the native epoch is host-bound at the headline size, a microsecond here is 4 % of the
 step).  ``dirty()`` runs it: nothing for the usual stateless lambda.  A dirty watch is not yet a changed equation; the
 solver then re-traces (``program.eq_probe``: the graph is hash-consed, so an unchanged system returns the same node ids)
@@ -16,18 +17,23 @@ and only a different trace makes it rebuild the kernels (the build cache is keye
 **Fail-closed.**  The walk is a bounded heuristic, so it keeps a second answer next to ``dirty()``: ``complete``.  Whenever
 it meets something it cannot stamp -- an object with neither ``__dict__`` nor ``__slots__``, an unknown container or
 iterator, a dict / list beyond ``max_items``, nesting beyond ``max_depth``, an ndarray too large to hash every epoch, a
-callable of a compiled non-library module, code that names a source of values outside Python state (``time``, ``random``,
-``os.environ`` ...), or code that names the solver's own bookkeeping (``local_epoch``, ``global_epoch``,
-``metrics_history``, ``lowest_loss`` ...) while a solver object is reachable -- the reason is appended to ``incomplete``.
+callable of a compiled non-library module, an object whose inspection raises, code that names a module outside a WHITELIST
+of pure ones (the library roots and ``math``, ``operator``, ``collections`` ...: so ``time``, ``random``, ``os``, ``sys``,
+``json``, any third-party package), a builtin outside a whitelist of pure ones (``open``, ``globals``, ``eval``, ``input`` ...),
+a library function that hands out values from outside Python state (``torch.rand``, ``np.loadtxt`` ...), or code that names
+the solver's own bookkeeping (``local_epoch``, ``global_epoch``, ``metrics_history``, ``lowest_loss`` ...) while a solver
+object is reachable -- the reason is appended to ``incomplete``.
 The solver treats an incomplete watch as "re-trace every time Python ran between two epochs" (one ``eq_probe`` per epoch,
 93 - 685 us on the BASELINE systems) and keeps such a system off the multi-epoch native call; a complete watch keeps the
 fast path.  Never a silently stale equation.
 """
+import builtins
 import collections
 import functools
 import numbers
 import sys
 import types
+import weakref
 import zlib
 
 import torch
@@ -37,12 +43,39 @@ _LIBRARY_ROOTS = ("neurodiffeq_amd", "torch", "numpy", "math", "functools", "ope
 _MISSING = object()
 _OPAQUE = (torch.Tensor, torch.nn.Module, torch.optim.Optimizer, types.ModuleType, type)
 _STDLIB = frozenset(getattr(sys, "stdlib_module_names", ())) | {"builtins"}
-#: modules whose functions return values that are not Python state (a clock, an RNG, the environment): code naming one of
-#: them can change what it computes with nothing for a watch to see
-_VOLATILE_MODULES = frozenset({"time", "random", "os", "datetime", "secrets", "uuid", "socket", "subprocess", "threading"})
-#: attribute / function names of the same kind reached through a library module (``np.random.rand``, ``torch.rand`` ...)
-_VOLATILE_NAMES = frozenset({"random", "rand", "randn", "randint", "normal", "uniform", "rand_like", "randn_like", "time",
-                             "perf_counter", "monotonic", "environ", "getenv", "now", "today"})
+#: standard-library modules that compute from their arguments alone.  Code naming ANY other standard-library or third-party
+#: module (a clock, an RNG, the environment, files, sockets, a database, another framework ...) can change what it computes
+#: with nothing for a watch to see: a whitelist, because the list of ways to reach the outside world has no end
+_PURE_STDLIB = frozenset({"math", "cmath", "operator", "functools", "itertools", "collections", "numbers", "fractions", "decimal",
+                          "typing", "dataclasses", "enum", "abc", "copy", "string", "re", "warnings", "types", "statistics", "bisect",
+                          "heapq", "contextlib", "builtins", "textwrap", "pprint", "reprlib", "array", "struct", "weakref"})
+#: attribute / function names that hand out values from outside Python state when reached through a library module
+#: (``np.random.rand``, ``torch.rand``, ``np.loadtxt``, ``torch.load`` ...) or through an object (``fh.read()``)
+_VOLATILE_NAMES = frozenset({"random", "rand", "randn", "randint", "normal", "uniform", "rand_like", "randn_like", "randperm",
+                             "multinomial", "bernoulli", "poisson", "choice", "shuffle", "permutation", "default_rng", "seed",
+                             "manual_seed", "time", "perf_counter", "monotonic", "environ", "getenv", "now", "today", "load", "loadtxt",
+                             "fromfile", "genfromtxt", "memmap", "read", "readline", "readlines", "recv"})
+#: builtins that compute from their arguments alone; a callable's code naming any OTHER builtin function (``open``, ``input``,
+#: ``globals``, ``locals``, ``vars``, ``eval``, ``exec``, ``__import__``, ``compile``, ``id``, ``hash`` ...) reads state this walk cannot see
+_PURE_BUILTINS = frozenset({"abs", "all", "any", "bool", "callable", "complex", "dict", "divmod", "enumerate", "filter", "float",
+                            "format", "frozenset", "getattr", "hasattr", "int", "isinstance", "issubclass", "iter", "len", "list",
+                            "map", "max", "min", "next", "pow", "print", "range", "repr", "reversed", "round", "set", "slice", "sorted",
+                            "str", "sum", "tuple", "type", "zip", "object", "super", "property", "staticmethod", "classmethod",
+                            "bytes", "bytearray", "chr", "ord", "bin", "hex", "oct", "ascii", "setattr", "delattr", "memoryview",
+                            "NotImplemented", "Ellipsis", "True", "False", "None", "__build_class__", "__debug__", "id", "hash"})
+#: methods the arithmetic of an equation never runs (object housekeeping: printing, construction, pickling, copying); what
+#: `dataclasses` generates for them names `_thread`, `id` ... and would make every dataclass of coefficients "incomplete"
+_HOUSEKEEPING = frozenset({"__repr__", "__str__", "__init__", "__post_init__", "__new__", "__del__", "__setattr__", "__delattr__",
+                           "__getstate__", "__setstate__", "__reduce__", "__reduce_ex__", "__init_subclass__", "__format__",
+                           "__dir__", "__copy__", "__deepcopy__", "__sizeof__", "__class_getitem__", "__set_name__"})
+_IMPURE_BUILTINS = frozenset(n for n in dir(builtins) if callable(getattr(builtins, n)) and n not in _PURE_BUILTINS
+                             and not (isinstance(getattr(builtins, n), type) and issubclass(getattr(builtins, n), BaseException)))
+#: attributes torch.nn.Module keeps in an instance's __dict__ for its own machinery (module.py): not equation state
+_MODULE_INTERNALS = frozenset({"_backward_hooks", "_backward_pre_hooks", "_forward_hooks", "_forward_hooks_with_kwargs",
+                               "_forward_hooks_always_called", "_forward_pre_hooks", "_forward_pre_hooks_with_kwargs",
+                               "_is_full_backward_hook", "_non_persistent_buffers_set", "_state_dict_hooks",
+                               "_state_dict_pre_hooks", "_load_state_dict_pre_hooks", "_load_state_dict_post_hooks",
+                               "_compiled_call_impl", "_version", "_parameters", "_buffers", "_modules", "call_super_init"})
 #: the solver's own bookkeeping (solvers.py:36-140 of the reference: counters and histories the fit loop advances by itself,
 #: with no user code running): equations that read one of these through a reachable solver follow the epoch
 SOLVER_BOOKKEEPING = frozenset({"local_epoch", "global_epoch", "_max_local_epoch", "metrics_history", "_history", "lowest_loss",
@@ -57,9 +90,16 @@ def _root(module_name):
 
 
 def _user_class(k):
-    """A class whose plain attributes can be equation state: not a builtin, not library code, not a torch module."""
+    """A class whose plain attributes and methods can be equation state: not a builtin, not library code (a user's own
+    torch.nn.Module subclass counts: its ``forward`` is code the equations run)."""
     return (isinstance(k, type) and _root(getattr(k, "__module__", "")) not in _LIBRARY_ROOTS + ("builtins", "abc", "typing", "collections", "types")
-            and not issubclass(k, (torch.nn.Module, torch.optim.Optimizer, BaseException)))
+            and not issubclass(k, (torch.optim.Optimizer, BaseException)))
+
+
+def _third_party(mod):
+    """An installed package (site-packages / dist-packages) as opposed to the user's own modules."""
+    f = getattr(mod, "__file__", None) or ""
+    return "site-packages" in f or "dist-packages" in f
 
 
 def _is_leaf(v):
@@ -144,6 +184,20 @@ class StateWatch:
         self._visit(value, depth + 1)
 
     def _visit(self, v, depth):
+        try:
+            self._visit_unguarded(v, depth)
+        except Exception as e:   # noqa: BLE001 -- e.g. a __getattr__ that raises something else than AttributeError
+            self._fail(f"an object of type {type(v).__module__}.{type(v).__qualname__} could not be inspected ({type(e).__name__})")
+
+    def _visit_unguarded(self, v, depth):
+        if isinstance(v, torch.nn.Module) and _root(type(v).__module__) not in _LIBRARY_ROOTS:
+            if id(v) not in self._seen:
+                if depth > self.max_depth:
+                    self._fail(f"state nested deeper than {self.max_depth} levels")
+                else:
+                    self._seen.add(id(v))
+                    self._torch_module(v, depth)
+            return
         if isinstance(v, type) and depth <= self.max_depth and id(v) not in self._seen:
             self._seen.add(id(v))
             self._class(v, self._ref(v), depth)         # `class Cfg: nu = 0.1` used as a namespace
@@ -199,12 +253,19 @@ class StateWatch:
         elif isinstance(v, (types.GeneratorType, types.CoroutineType, types.AsyncGeneratorType)) or \
                 (hasattr(v, "__next__") and not hasattr(v, "__dict__")):
             self._fail(f"an iterator ({type(v).__name__}): what it yields next cannot be compared")
+        elif isinstance(v, weakref.ReferenceType):
+            target = v()
+            if target is not None:
+                self._add(f"{self._ref(v)}()", target, depth)
         elif callable(v) and not hasattr(v, "__dict__") and not hasattr(type(v), "__slots__"):
-            # builtins and compiled callables: library / standard-library ones are not user state; a compiled extension
-            # function of any other module computes from state this walk cannot read
+            # builtins and compiled callables: library ones and the pure part of the standard library are not user state; any
+            # other compiled function computes from state this walk cannot read
             mod = _root(getattr(v, "__module__", None) or getattr(getattr(v, "__self__", None), "__module__", None)
                         or type(v).__module__ or "builtins")
-            if mod in _VOLATILE_MODULES:
+            name = getattr(v, "__name__", "")
+            if mod == "builtins" and name in _IMPURE_BUILTINS:
+                self._fail(f"the builtin {name}() (reads state that is not the equations')")
+            elif mod in _STDLIB and mod not in _PURE_STDLIB:
                 self._fail(f"a function of module '{mod}' (values that are not Python state)")
             elif mod not in _LIBRARY_ROOTS and mod not in _STDLIB:
                 self._fail(f"a compiled callable of module '{mod}'")
@@ -225,6 +286,9 @@ class StateWatch:
             codes.extend(c for c in co.co_consts if isinstance(c, types.CodeType))
         self._names |= names
         g = fn.__globals__
+        hot = sorted(n for n in names & _IMPURE_BUILTINS if n not in g and n not in fn.__code__.co_varnames)
+        if hot:
+            self._fail(f"the equations call the builtin(s) {hot} (state that is not the equations')")
         for name in sorted(names):
             if name not in g:
                 continue
@@ -250,13 +314,13 @@ class StateWatch:
         names sit in ``co_names`` next to the module's own); library and standard-library modules are code, except the
         ones that hand out values from outside Python state."""
         root = _root(getattr(mod, "__name__", ""))
-        if root in _VOLATILE_MODULES:
-            self._fail(f"the equations name module '{root}' (values that are not Python state)")
-            return
-        if root in _LIBRARY_ROOTS or root in _STDLIB:
+        if root in _LIBRARY_ROOTS or root in _PURE_STDLIB:
             hot = names & _VOLATILE_NAMES
             if hot:
                 self._fail(f"the equations name {sorted(hot)} of module '{root}' (values that are not Python state)")
+            return
+        if root in _STDLIB or _third_party(mod):
+            self._fail(f"the equations name module '{root}' (values that are not Python state)")
             return
         ns, r = vars(mod), self._ref(mod)
         for name in sorted(names):
@@ -269,7 +333,36 @@ class StateWatch:
                     continue
                 self._add(f"getattr({r}, {name!r}, M)", value, depth)
 
+    def _torch_module(self, m, depth):
+        """A user's own torch.nn.Module the callables reach (an operator object used as ``diff_eqs``, a coefficient model
+        in a closure): its buffers and parameters (tensors: identity + version, trainable leaves by identity), its plain
+        attributes, its submodules, and the methods of its class."""
+        r = self._ref(m)
+        d = vars(m)
+        for kind in ("_parameters", "_buffers"):
+            store = d.get(kind) or {}
+            self.entries.append(f"len(vars({r})[{kind!r}]) == {len(store)}")
+            for name, t in list(store.items())[:self.max_items]:
+                self._add(f"vars({r})[{kind!r}].get({name!r}, M)", t, depth)
+            if len(store) > self.max_items:
+                self._fail(f"a module with {len(store)} {kind[1:]}")
+        for name, child in list((d.get("_modules") or {}).items())[:self.max_items]:
+            self.entries.append(f"vars({r})['_modules'].get({name!r}, M) is {self._ref(child)}")
+            if isinstance(child, torch.nn.Module) and id(child) not in self._seen:
+                self._seen.add(id(child))
+                if depth + 1 > self.max_depth:
+                    self._fail(f"state nested deeper than {self.max_depth} levels")
+                else:
+                    self._torch_module(child, depth + 1)
+        for name, value in list(d.items()):
+            if name in _MODULE_INTERNALS or not name.isidentifier():
+                continue
+            self._add(f"getattr({r}, {name!r}, M)", value, depth)
+        self._class(type(m), r, depth, skip=set(d))
+
     def _object(self, obj, depth):
+        if isinstance(obj, torch.nn.Module) and _root(type(obj).__module__) not in _LIBRARY_ROOTS:
+            return self._visit(obj, depth)
         if isinstance(obj, _OPAQUE) or _is_leaf(obj):
             return
         d = getattr(obj, "__dict__", None)
@@ -311,7 +404,8 @@ class StateWatch:
                 # cells and the globals they name are state like the entry function's
                 fn = value.fget if isinstance(value, property) else getattr(value, "__func__", value) if isinstance(value, (staticmethod, classmethod)) else value
                 if isinstance(fn, types.FunctionType):
-                    self._visit(fn, depth)
+                    if name not in _HOUSEKEEPING:
+                        self._visit(fn, depth)
                     continue
                 if name.startswith("__") or name in skip or not name.isidentifier():
                     continue

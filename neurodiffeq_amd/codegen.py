@@ -117,6 +117,7 @@ _UN_FWD = {
     "cosh": "coshf({a})", "sigmoid": "(1.0f/(1.0f+expf(-{a})))", "recip": "(1.0f/{a})",
     "sign": "(({a}>0.0f)-({a}<0.0f))",
     "log1p": "log1pf({a})", "expm1": "expm1f({a})", "erf": "erff({a})", "atan": "atanf({a})",
+    "floor": "floorf({a})", "ceil": "ceilf({a})", "round": "rintf({a})", "trunc": "truncf({a})",       # (rint: half to even, like torch.round)
 }
 # adjoint factor of the single child: child_adj += b * factor ; {a} child value, {v} node value
 _UN_ADJ = {
@@ -126,6 +127,7 @@ _UN_ADJ = {
     "sigmoid": "{b}*{v}*(1.0f-{v})", "recip": "-{b}*{v}*{v}", "sign": None,
     "log1p": "{b}/(1.0f+{a})", "expm1": "{b}*({v}+1.0f)", "erf": "{b}*1.1283791670955126f*expf(-{a}*{a})",
     "atan": "{b}/(1.0f+{a}*{a})",
+    "floor": None, "ceil": None, "round": None, "trunc": None,
 }
 
 
@@ -970,7 +972,7 @@ def so_path_for(program: PointwiseProgram, f64=False):
     return os.path.join(JIT_DIR, f"pw{'64' if f64 else ''}_{program.key}.so")
 
 
-_F64_FUNCS = re.compile(r"\b(pow|sin|cos|tan|exp|log|tanh|sqrt|fabs|sinh|cosh|fmax|log1p|expm1|erf|atan|atan2)f\(")
+_F64_FUNCS = re.compile(r"\b(pow|sin|cos|tan|exp|log|tanh|sqrt|fabs|sinh|cosh|fmax|log1p|expm1|erf|atan|atan2|floor|ceil|rint|trunc)f\(")
 _F64_LITERAL = re.compile(r"(?<![\w.])((?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?)f\b")
 
 

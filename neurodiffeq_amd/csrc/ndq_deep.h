@@ -14,17 +14,18 @@
 //                                               coordinates)
 //             deep_head_fwd                     u_s = Wout sigma-jet(Z_L)_s + bout -> output streams
 //   reverse   deep_head_bwd                     seeds -> Zbar_L, dWout, db_L, dbout   (one unit per thread, seeds are wave-uniform)
-//             deep_wgrad_gemm                   dW_l = sum_{s, n} Zbar_l^T sigma-jet(Z_{l-1})   (split over points, partial tiles)
+//             deep_wgrad_bf                     dW_l = sum_{s, n} Zbar_l^T sigma-jet(Z_{l-1})   (split over points, partial tiles)
 //             deep_gemm_bf<SRC 2, EPI 1 | 2>    Hbar_{l-1} = W_l^T Zbar_l, act-backward in the epilogue -> Zbar_{l-1}, db_{l-1}
 //                                               (l = 2: the first layer's dW1 / db1 instead of a store)
 //             deep_reduce_all                   every second-stage sum of the sweep in ONE launch (job table, fixed order)
 //
 // The two per-point GEMMs run on the bf16 matrix core as bf16x3 products (v_mfma_f32_16x16x32_bf16, six significant plane
 // products, fp32-class accuracy: csrc/ndq_mlp.h), the layer's weight planes resident in LDS for the whole launch; at W = 128
-// they are bound by the HBM round trips of Z, from W = 256 on by the MFMAs.  The weight-gradient GEMM contracts over POINTS and
-// stays on v_mfma_f32_16x16x4_f32 (exact fp32; both operands are "one value per lane" of 4 consecutive points straight from
-// the point-major layout, no transposes).  deep_fwd_gemm / deep_bwd_gemm are the exact-f32 versions of the per-point GEMMs,
-// kept behind -DNDQ_DEEP_BF16X3=0 as the A/B baseline.
+// they are bound by the instructions they issue (jets, operand splits, products: profiles/r05b_deep_ab.md).  The weight-gradient
+// GEMM contracts over (point, stream) PAIRS, since round 5 on the same bf16x3 products (deep_wgrad_bf: a lane's 8 slots of a
+// chunk are the next 8 pair values it produces, no transposes); deep_wgrad_gemm (exact-f32 v_mfma_f32_16x16x4_f32, 4 points
+// per product) and deep_fwd_gemm / deep_bwd_gemm (exact-f32 per-point GEMMs) are kept behind -DNDQ_DEEP_WGRAD_BF=0 /
+// -DNDQ_DEEP_BF16X3=0 as the A/B baselines.
 // Reductions are fixed-order everywhere (per-wave partial rows / partial tiles -> deep_reduce_all): bit-reproducible results.
 // Reference restated: networks.py:59-70 (forward), neurodiffeq.py:21-34 (diff sweeps), solvers.py:393 (backward).
 #pragma once

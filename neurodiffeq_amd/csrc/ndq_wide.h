@@ -29,7 +29,8 @@
 #include "ndq_mlp.h"
 
 #ifndef NDQ_WIDE_THREADS
-#define NDQ_WIDE_THREADS 256       // one wave per SIMD (experiments: 512 = two, 256 registers each)
+#define NDQ_WIDE_THREADS 256       // one wave per SIMD.  512 (two, 256 registers each: 80 - 220 B of scratch per lane) measured in
+                                   // round 5: README (512,) 51.9 -> 51.9 us per step, 2 -> 512 -> 3 110.6 -> 105.0 (profiles/r05o_wide_threads_ab.jsonl)
 #endif
 
 namespace ndq {
@@ -65,7 +66,7 @@ struct WideCfg {
   static constexpr int NCP = (NC + 3) & ~3;
   static constexpr int rp() {
     int r = 16;
-    while (r > PL && r * NC * RS * 4 > 20 * 1024) r >>= 1;
+    while (r > PL && r * NC * RS * 4 > 20 * 1024 * 4 / WAVES) r >>= 1;
     return r;
   }
   static constexpr int RP = rp();                                     // points per reduction pass (PL <= RP <= 16)

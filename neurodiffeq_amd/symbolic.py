@@ -10,6 +10,7 @@ fused HIP kernel by :mod:`neurodiffeq_amd.codegen`.
 
 Every traced value has the reference's ``(N, 1)`` column semantics.
 """
+import functools
 import math
 import numbers
 
@@ -32,7 +33,7 @@ LEAVES = ("const", "coord", "net", "param", "data")
 
 # op -> (arity).  Unary elementwise functions are listed in UNARY.
 UNARY = ("neg", "sin", "cos", "tan", "exp", "log", "tanh", "sqrt", "abs", "sinh", "cosh", "sigmoid", "recip", "sign",
-         "log1p", "expm1", "erf", "atan")
+         "log1p", "expm1", "erf", "atan", "floor", "ceil", "round", "trunc")
 # further binary nodes: atan2(a, b) and the MASKS gt(a, b) = [a > b], ge(a, b) = [a >= b] -- per-point 0.0 / 1.0 columns with
 # zero derivative, what a comparison of traced columns gives (`x > 0.5`); ternary: where(m, a, b) = m != 0 ? a : b, which
 # selects (it does not blend: an inf / nan in the branch not taken stays out of the value AND of the gradient, like
@@ -286,6 +287,8 @@ class Graph:
         "sigmoid": lambda v: 1.0 / (1.0 + math.exp(-v)), "recip": lambda v: 1.0 / v,
         "sign": lambda v: (v > 0) - (v < 0),
         "log1p": math.log1p, "expm1": math.expm1, "erf": math.erf, "atan": math.atan,
+        "floor": lambda v: float(math.floor(v)), "ceil": lambda v: float(math.ceil(v)), "round": lambda v: float(round(v)),   # (half to even, like torch.round)
+        "trunc": lambda v: float(math.trunc(v)),
     }
 
     def unary(self, op, a):
@@ -396,8 +399,8 @@ class Graph:
                 r = self.div(da, self.mul(self.const(2.0), e))
             elif op == "abs":
                 r = self.mul(self.unary("sign", a), da)
-            elif op == "sign":
-                r = self.const(0.0)
+            elif op in ("sign", "floor", "ceil", "round", "trunc"):
+                r = self.const(0.0)          # piecewise constant (torch: zero gradient)
             elif op == "sinh":
                 r = self.mul(self.unary("cosh", a), da)
             elif op == "cosh":
@@ -641,12 +644,35 @@ def _as_node(g, v, literal=False):
 class _Shape(tuple):
     pass
 
+def _const_size(size):
+    """Size of a constant made from a traced column (u.new_ones(1), u.new_zeros(1, 1)): one element -- it enters the trace as a
+    number; a per-point constant column is torch.ones_like(u)."""
+    if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+        size = tuple(size[0])
+    n = 1
+    for k in size:
+        n *= int(k)
+    if n != 1:
+        raise TraceUnsupported("a constant of more than one element made from a traced column (use torch.ones_like / zeros_like)")
+    return tuple(int(k) for k in size)
+
+
 def _no_such_method(kind):
     def __getattr__(self, name):
         if name.startswith("__") or name in ("g", "i", "cols", "term", "items"):
             raise AttributeError(name)
+        # x.f(...) is torch.f(x, ...) for the elementwise functions of the table below (x.mul(y), x.floor(), x.softplus ...)
+        h = _TORCH_FUNCS.get(name[:-1] if name.endswith("_") and not name.endswith("__") else name) if kind == "column" else None
+        if h is not None and name not in _NOT_METHODS:
+            if name.endswith("_"):
+                raise TraceUnsupported(f"in-place Tensor.{name} on a traced {kind}")
+            return functools.partial(h, self)
         raise TraceUnsupported(f"Tensor.{name} is not supported on a traced {kind}")
     return __getattr__
+
+
+_NOT_METHODS = frozenset({"cat", "concat", "stack", "ones_like", "zeros_like", "full_like", "mse_loss", "l1_loss", "where",
+                          "sum", "mean", "max", "min"})
 
 
 
@@ -696,7 +722,31 @@ class Sym:
         raise TraceUnsupported("detach() inside the traced region")
 
     def __getitem__(self, idx):
+        # the whole (N, 1) column under another spelling: u[:, 0:1], u[:, [0]], u[:, :], u[...]
+        # (u[:, 0] would be an (N,) vector: the column semantics of the trace do not carry that shape)
+        full = slice(None)
+        if idx is Ellipsis or idx == full:
+            return self
+        if isinstance(idx, tuple) and len(idx) == 2 and (idx[0] == full or idx[0] is Ellipsis):
+            j = idx[1]
+            if j == full or j == slice(0, 1) or j == slice(0, None) or j == slice(None, 1) or j == [0] or j is Ellipsis:
+                return self
         raise TraceUnsupported("indexing a traced column")
+
+    @property
+    def dtype(self):
+        return torch.get_default_dtype()
+
+    @property
+    def device(self):
+        return torch.device("cpu")           # (constants built "on u.device" are folded into the trace as numbers)
+
+    def new_tensor(self, data, **k): return torch.as_tensor(data, dtype=torch.get_default_dtype())
+    def new_full(self, size, fill_value, **k): return torch.full(_const_size(size), float(fill_value))
+    def new_ones(self, *size, **k): return torch.ones(_const_size(size))
+    def new_zeros(self, *size, **k): return torch.zeros(_const_size(size))
+    def expand_as(self, other): return self
+    def contiguous(self, *a, **k): return self
 
     def __bool__(self):
         raise TraceUnsupported("data-dependent control flow on a traced value")
@@ -1272,7 +1322,115 @@ def _tf_map(op):
     return f
 
 
+def _safe_den(x):
+    """x where x != 0, else 1: the denominator of a quotient whose x = 0 case is selected away (no nan in value or gradient)."""
+    return _where1(abs(x) > 0.0, x, Sym(x.g, x.g.const(1.0)))
+
+
+def _tf_softplus(x, beta=1.0, threshold=20.0, **k):
+    beta, threshold = float(beta), float(threshold)
+    # torch: x where beta x > threshold, log1p(exp(beta x)) / beta elsewhere (the argument of exp is clipped so that the branch
+    # not taken stays finite)
+    return _elementwise(lambda c: _where1(c * beta > threshold, c, (_where1(c * beta > threshold, c * 0.0, c * beta).exp()).log1p() / beta), x)
+
+
+def _tf_elu(x, alpha=1.0, inplace=False, **k):
+    return _elementwise(lambda c: _where1(c > 0.0, c, _where1(c > 0.0, c * 0.0, c).expm1() * float(alpha)), x)
+
+
+def _tf_selu(x, inplace=False, **k):
+    return _tf_elu(x, 1.6732632423543772848170429916717) * 1.0507009873554804934193349852946
+
+
+def _tf_celu(x, alpha=1.0, inplace=False, **k):
+    a = float(alpha)
+    return _elementwise(lambda c: _where1(c > 0.0, c, (_where1(c > 0.0, c * 0.0, c) / a).expm1() * a), x)
+
+
+def _tf_gelu(x, approximate="none", **k):
+    if approximate == "tanh":
+        return _elementwise(lambda c: 0.5 * c * (1.0 + (0.7978845608028654 * (c + 0.044715 * c * c * c)).tanh()), x)
+    return _elementwise(lambda c: 0.5 * c * (1.0 + (c * 0.7071067811865476).erf()), x)
+
+
+def _tf_hardtanh(x, min_val=-1.0, max_val=1.0, inplace=False, **k):
+    return _tf_clamp(x, float(min_val), float(max_val))
+
+
+def _tf_threshold(x, threshold, value, inplace=False, **k):
+    return _elementwise(lambda c: _where1(c > float(threshold), c, Sym(c.g, c.g.const(float(value)))), x)
+
+
+def _tf_logaddexp(a, b, **k):
+    return _elementwise(lambda x, y: _tf_maximum(x, y) + (-(abs(x - y))).exp().log1p(), a, b)
+
+
+def _tf_sinc(x, **k):
+    def one(c):
+        d = _safe_den(c) * math.pi
+        return _where1(abs(c) > 0.0, d.sin() / d, Sym(c.g, c.g.const(1.0)))
+    return _elementwise(one, x)
+
+
+def _tf_fmod(a, b, **k):
+    return _elementwise(lambda x, y: x - y * (x / y)._un("trunc"), a, b)
+
+
+def _tf_remainder(a, b, **k):
+    return _elementwise(lambda x, y: x - y * (x / y)._un("floor"), a, b)
+
+
+def _tf_round(x, decimals=0, **k):
+    if decimals:
+        s = 10.0 ** int(decimals)
+        return _elementwise(lambda c: (c * s)._un("round") / s, x)
+    return _elementwise(lambda c: c._un("round"), x)
+
+
+def _tf_lerp(a, b, weight, **k):
+    return _elementwise(lambda x, y, w: x + w * (y - x), a, b, weight)
+
+
+def _tf_addcmul(x, t1, t2, value=1.0, **k):
+    return _elementwise(lambda c, p, q: c + float(value) * p * q, x, t1, t2)
+
+
+def _tf_addcdiv(x, t1, t2, value=1.0, **k):
+    return _elementwise(lambda c, p, q: c + float(value) * p / q, x, t1, t2)
+
+
+def _tf_elem(fn):
+    return lambda x, *a, **k: _elementwise(fn, x)
+
+
+def _tf_xlogy(a, b, **k):
+    # x log y with 0 where x == 0 (whatever y is)
+    return _elementwise(lambda x, y: _where1(abs(x) > 0.0, x * _where1(abs(x) > 0.0, y, y * 0.0 + 1.0).log(), x * 0.0), a, b)
+
+
+def _tf_xlog1py(a, b, **k):
+    return _elementwise(lambda x, y: _where1(abs(x) > 0.0, x * _where1(abs(x) > 0.0, y, y * 0.0).log1p(), x * 0.0), a, b)
+
+
 _TORCH_FUNCS = {
+    "xlogy": _tf_xlogy, "xlog1py": _tf_xlog1py, "logit": _tf_elem(lambda c: (c / (1.0 - c)).log()), "expit": _tf_unary("sigmoid"),
+    "floor": _tf_map("floor"), "ceil": _tf_map("ceil"), "trunc": _tf_map("trunc"), "fix": _tf_map("trunc"), "round": _tf_round,
+    "frac": _tf_elem(lambda c: c - c._un("trunc")), "fmod": _tf_fmod, "remainder": _tf_remainder,
+    "asin": _tf_elem(lambda c: _tf_atan2(c, (1.0 - c * c).sqrt())), "arcsin": _tf_elem(lambda c: _tf_atan2(c, (1.0 - c * c).sqrt())),
+    "acos": _tf_elem(lambda c: _tf_atan2((1.0 - c * c).sqrt(), c)), "arccos": _tf_elem(lambda c: _tf_atan2((1.0 - c * c).sqrt(), c)),
+    "asinh": _tf_elem(lambda c: (c + (c * c + 1.0).sqrt()).log()), "arcsinh": _tf_elem(lambda c: (c + (c * c + 1.0).sqrt()).log()),
+    "acosh": _tf_elem(lambda c: (c + (c * c - 1.0).sqrt()).log()), "arccosh": _tf_elem(lambda c: (c + (c * c - 1.0).sqrt()).log()),
+    "atanh": _tf_elem(lambda c: 0.5 * ((1.0 + c) / (1.0 - c)).log()), "arctanh": _tf_elem(lambda c: 0.5 * ((1.0 + c) / (1.0 - c)).log()),
+    "rsqrt": _tf_elem(lambda c: c ** -0.5), "log10": _tf_elem(lambda c: c.log() * (1.0 / math.log(10.0))),
+    "log2": _tf_elem(lambda c: c.log() * (1.0 / math.log(2.0))), "exp2": _tf_elem(lambda c: (c * math.log(2.0)).exp()),
+    "erfc": _tf_elem(lambda c: 1.0 - c.erf()), "sinc": _tf_sinc, "hypot": lambda a, b, **k: _elementwise(lambda x, y: (x * x + y * y).sqrt(), a, b),
+    "logaddexp": _tf_logaddexp, "lerp": _tf_lerp, "addcmul": _tf_addcmul, "addcdiv": _tf_addcdiv,
+    "softplus": _tf_softplus, "elu": _tf_elu, "selu": _tf_selu, "celu": _tf_celu, "gelu": _tf_gelu,
+    "silu": _tf_elem(lambda c: c * c.sigmoid()), "mish": lambda x, **k: _elementwise(lambda c: c * _tf_softplus(c).tanh(), x),
+    "softsign": _tf_elem(lambda c: c / (1.0 + abs(c))), "hardtanh": _tf_hardtanh, "relu6": _tf_elem(lambda c: _tf_clamp(c, 0.0, 6.0)),
+    "hardsigmoid": _tf_elem(lambda c: _tf_clamp(c / 6.0 + 0.5, 0.0, 1.0)), "hardswish": _tf_elem(lambda c: c * _tf_clamp(c / 6.0 + 0.5, 0.0, 1.0)),
+    "log_sigmoid": _tf_elem(lambda c: -_tf_softplus(-c)), "logsigmoid": _tf_elem(lambda c: -_tf_softplus(-c)),
+    "threshold": _tf_threshold, "_threshold": _tf_threshold, "tanhshrink": _tf_elem(lambda c: c - c.tanh()),
     "where": _tf_where, "clamp": _tf_clamp, "clip": _tf_clamp,
     "clamp_min": lambda x, min, **k: _tf_clamp(x, min, None), "clamp_max": lambda x, max, **k: _tf_clamp(x, None, max),
     "relu": _tf_relu, "leaky_relu": _tf_leaky_relu, "heaviside": _tf_heaviside,
@@ -1296,6 +1454,12 @@ _TORCH_FUNCS = {
     "cat": _tf_cat, "concat": _tf_cat, "sum": _tf_sum, "mean": _batch_mean,
     "mse_loss": _tf_mse_loss, "l1_loss": _tf_l1_loss,
 }
+
+
+# torch.special.* arrives as "special_<name>"
+for _n in ("expit", "erf", "erfc", "log1p", "expm1", "sinc", "exp2", "xlogy", "xlog1py", "logit", "round", "softmax_none"):
+    if _n in _TORCH_FUNCS:
+        _TORCH_FUNCS["special_" + _n] = _TORCH_FUNCS[_n]
 
 
 def is_sym(x):

@@ -579,7 +579,9 @@ def _lib_check(rc):
                                   # beyond round 2's template limits: 6 and 8 hidden layers, 4 and 5 inputs, a 3-parameter bundle
                                   "shape_32x6", "shape_16x8_sin", "heat4d", "mix5d", "bundle_osc",
                                   # piecewise / clipped equations: masks, where, clamp, relu, maximum, sign, log1p, atan2, erf
-                                  "piecewise_source", "relu_ode", "atan2_adv"])
+                                  "piecewise_source", "relu_ode", "atan2_adv",
+                                  # round 5, second batch: rounding functions, torch.nn.functional activations, inverse / special functions
+                                  "rounding_ode", "activations_ode", "special_2d"])
 def test_zoo_closure_matches_autograd_oracle(name, mode):
     """Systems outside the BASELINE set (tests/zoo.py): second-order IVP, sin networks, mixed second derivatives, first
     order only, three coordinates (Laplacian-merged, diagonal and full Hessian stream sets), three networks."""

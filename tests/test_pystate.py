@@ -2,14 +2,21 @@
 solvers.py:380 re-evaluates the user's callables every batch, so ANY Python state they read takes effect at the next epoch).
 Every case builds an equation callable that reads a value from somewhere, checks that a fresh watch is clean, changes the
 value the way a callback would, and checks that the watch is dirty."""
+import array
+import collections
+import dataclasses
+import enum
 import functools
 import os
+import sys
 import time
 import types
+import weakref
 
 import numpy as np
 import pytest
 import torch
+import yaml
 
 from neurodiffeq_amd._pystate import StateWatch
 
@@ -267,6 +274,136 @@ CASES = [_global, _through_helper_function, _closure_cell, _dict_entry, _nested_
          _large_numpy_array_in_place, _method_reading_a_global, _property_reading_a_closure, _tuple_keyed_dict]
 
 
+# ---- round 5, second batch: more places a coefficient can live (each one found by probing the watch, not by reading it)
+def _ordered_dict():
+    d = collections.OrderedDict(a=1.0)
+    return (lambda u, t: [u * d["a"]]), (lambda: d.__setitem__("a", 2.0))
+
+
+def _default_dict():
+    d = collections.defaultdict(float)
+    d["a"] = 1.0
+    return (lambda u, t: [u * d["a"]]), (lambda: d.__setitem__("a", 2.0))
+
+
+@dataclasses.dataclass
+class _Params:
+    nu: float = 1.0
+
+
+def _dataclass_field():
+    p = _Params()
+    return (lambda u, t: [u * p.nu]), (lambda: setattr(p, "nu", 2.0))
+
+
+def _namedtuple_replaced():
+    P = collections.namedtuple("P", "nu")
+    box = {"p": P(1.0)}
+    return (lambda u, t: [u * box["p"].nu]), (lambda: box.__setitem__("p", P(2.0)))
+
+
+def _attribute_read_by_a_computed_name():
+    b = _Box()
+    b.nu = 1.0
+    name = "nu"
+    return (lambda u, t: [u * getattr(b, name)]), (lambda: setattr(b, "nu", 2.0))
+
+
+class _Operator(torch.nn.Module):
+    """The user's own torch module used as the equation callable (a buffer as coefficient)."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("nu", torch.tensor(1.0))
+        self.scale = 1.0
+
+    def forward(self, u, t):
+        return [u * self.nu * self.scale]
+
+
+def _module_buffer_in_place():
+    e = _Operator()
+    return e, (lambda: e.nu.mul_(2.0))
+
+
+def _module_buffer_replaced():
+    e = _Operator()
+    return e, (lambda: setattr(e, "nu", torch.tensor(3.0)))
+
+
+def _module_plain_attribute():
+    e = _Operator()
+    return e, (lambda: setattr(e, "scale", 3.0))
+
+
+def _module_in_a_closure():
+    e = _Operator()
+    return (lambda u, t: e(u, t)), (lambda: e.nu.add_(1.0))
+
+
+def _length_of_a_list():
+    items = [1, 2]
+    return (lambda u, t: [u * len(items)]), (lambda: items.append(3))
+
+
+def _weak_reference():
+    b = _Box()
+    b.nu = 1.0
+    r = weakref.ref(b)
+    return (lambda u, t: [u * r().nu]), (lambda: setattr(b, "nu", 2.0))
+
+
+class _Mode(enum.Enum):
+    A = 1.0
+    B = 2.0
+
+
+def _enum_member_switched():
+    box = {"m": _Mode.A}
+    return (lambda u, t: [u * box["m"].value]), (lambda: box.__setitem__("m", _Mode.B))
+
+
+def _cached_helper():
+    k = [1.0]
+
+    @functools.lru_cache(None)
+    def f():
+        return k[0]
+    return (lambda u, t: [u * f()]), (lambda: (k.__setitem__(0, 2.0), f.cache_clear()))
+
+
+def _numpy_view_changed_through_its_base():
+    base = np.ones(10)
+    v = base[2:4]
+    return (lambda u, t: [u * v[0]]), (lambda: base.__setitem__(2, 7.0))
+
+
+def _tensor_view_changed_through_its_base():
+    base = torch.ones(10)
+    v = base[2:4]
+    return (lambda u, t: [u * v[0]]), (lambda: base.__setitem__(2, 7.0))
+
+
+def _condition_attribute():
+    from neurodiffeq_amd.conditions import IVP
+    c = IVP(0.0, 1.0)
+    return c, (lambda: setattr(c, "u_0", 2.0))
+
+
+def _condition_boundary_function_state():
+    from neurodiffeq_amd.conditions import DirichletBVP2D
+    k = {"v": 1.0}
+    zero = lambda v: 0 * v
+    c = DirichletBVP2D(0, lambda y: k["v"] * y, 1, zero, 0, zero, 1, zero)
+    return c, (lambda: k.__setitem__("v", 3.0))
+
+
+CASES += [_ordered_dict, _default_dict, _dataclass_field, _namedtuple_replaced, _attribute_read_by_a_computed_name,
+          _module_buffer_in_place, _module_buffer_replaced, _module_plain_attribute, _module_in_a_closure, _length_of_a_list,
+          _weak_reference, _enum_member_switched, _cached_helper, _numpy_view_changed_through_its_base,
+          _tensor_view_changed_through_its_base, _condition_attribute, _condition_boundary_function_state]
+
+
 @pytest.mark.parametrize("make", CASES, ids=[c.__name__.strip("_") for c in CASES])
 def test_state_watch_sees_the_change(make):
     f, mutate = make()
@@ -396,6 +533,61 @@ def _mapping_proxy():
 
 INCOMPLETE = [_huge_array, _opaque_object, _environment, _clock, _clock_function_in_a_closure, _numpy_rng, _iterator_state, _generator_state, _long_list,
               _big_dict, _set_of_objects, _too_deep, _mapping_proxy]
+
+
+class _RaisingGetattr:
+    def __init__(self):
+        self.store = {"nu": 1.0}
+
+    def __getattr__(self, k):
+        return self.__dict__["store"][k]          # KeyError, not AttributeError, for anything it does not hold
+
+
+def _globals_call():
+    return (lambda u, t: [u * globals()["NU"]]), "globals"
+
+
+def _file_read():
+    return (lambda u, t: [u * float(open("/tmp/nu.txt").read())]), "open"
+
+
+def _eval_call():
+    return (lambda u, t: [u * eval("NU")]), "eval"
+
+
+def _getattr_that_raises_something_else():
+    b = _RaisingGetattr()
+    return (lambda u, t: [u * b.nu]), "could not be inspected"
+
+
+def _array_module_array():
+    a = array.array("d", [1.0, 2.0])
+    return (lambda u, t: [u * a[0]]), "neither __dict__ nor __slots__"
+
+
+def _bytearray_entry():
+    a = bytearray(b"\x01\x02")
+    return (lambda u, t: [u * a[0]]), "neither __dict__ nor __slots__"
+
+
+def _torch_rng():
+    return (lambda u, t: [u * torch.rand(1)]), "rand"
+
+
+def _file_loaded_through_numpy():
+    return (lambda u, t: [u * np.loadtxt("/tmp/nu.txt")]), "loadtxt"
+
+
+def _interpreter_state():
+    return (lambda u, t: [u * len(sys.argv)]), "module 'sys'"
+
+
+def _third_party_package():
+    return (lambda u, t: [u * yaml.safe_load("1.0")]), "module 'yaml'"
+
+
+INCOMPLETE += [_globals_call, _file_read, _eval_call, _getattr_that_raises_something_else, _array_module_array, _bytearray_entry,
+               _torch_rng, _file_loaded_through_numpy, _interpreter_state, _third_party_package]
 
 
 @pytest.mark.parametrize("make", INCOMPLETE, ids=[c.__name__.strip("_") for c in INCOMPLETE])

@@ -317,6 +317,38 @@ def build(name):
         conds = lambda: [C.NoCondition()]
         return System(name, 2, [(2, 1, (32, 32), "tanh")], [(-1.0, 1.0), (-1.0, 1.0)], pde, conds,
                       lambda D: [lambda net, x, y: net(_cat(x, y))])
+    if name == "rounding_ode":        # floor / ceil / round / trunc / frac / fmod / remainder (zero gradient, exact on dyadic arguments)
+        pde = lambda D: (lambda u, t: [D(u, t) + torch.floor(4.0 * t) * u - torch.ceil(2.0 * t) * torch.sin(u) + torch.round(8.0 * t) * 0.1 * u ** 2
+                                       - torch.trunc(2.0 * t - 1.0) * D(u, t) + torch.frac(2.0 * t) * u + torch.fmod(t, 0.25) * u
+                                       + torch.remainder(t - 1.0, 0.5) * torch.cos(u) + (4.0 * t).floor() * 0.05 + torch.round(t, decimals=1) * 0.0])
+        conds = lambda: [C.IVP(0.0, 1.0)]
+        enf = lambda D: [lambda net, t: 1.0 + (1 - torch.exp(-t)) * net(t)]
+        return System(name, 1, [(1, 1, (32, 32), "tanh")], [(0.0, 2.0)], pde, conds, enf)
+    if name == "activations_ode":     # torch.nn.functional activations applied to the solution inside the equation
+        # (F.hardsigmoid traces too, but torch's own double-precision backward of it multiplies by float(1 / 6): 8e-9 off, so it
+        # cannot sit in a system the fp64 oracle is compared with at 1e-11)
+        F = torch.nn.functional
+        pde = lambda D: (lambda u, t: [D(u, t) + F.softplus(u) - F.softplus(3.0 * u, beta=2.0, threshold=4.0) + F.elu(u - 1.0, alpha=0.7)
+                                       + F.selu(u - 1.1) + F.celu(u - 0.9, alpha=1.3) + F.gelu(u) - F.gelu(u - 0.5, approximate="tanh")
+                                       + F.silu(u) + F.mish(u - 1.0) + F.softsign(u) + F.hardtanh(u, -0.3, 0.7) + F.relu6(5.0 * u)
+                                       + F.hardswish(u + 1.5) + F.logsigmoid(u) + F.threshold(u, 1.05, -0.2)
+                                       + F.tanhshrink(u) + torch.sigmoid(D(u, t))])
+        conds = lambda: [C.IVP(0.0, 1.0)]
+        enf = lambda D: [lambda net, t: 1.0 + (1 - torch.exp(-t)) * net(t)]
+        return System(name, 1, [(1, 1, (32, 32), "tanh")], [(0.0, 2.0)], pde, conds, enf)
+    if name == "special_2d":          # inverse trigonometric / hyperbolic functions, logarithms, two-operand functions, Tensor methods
+        pde = lambda D: (lambda u, x, y: [D(u, x) + 2.0 * D(u, y) + torch.asin(0.5 * torch.tanh(u)) - torch.acos(0.4 * x) + torch.asinh(u * y)
+                                          + torch.acosh(2.0 + u ** 2) - torch.atanh(0.5 * torch.tanh(u + x)) + torch.rsqrt(1.0 + u ** 2)
+                                          + torch.log10(2.0 + x) * u - torch.log2(3.0 + y * u) + torch.exp2(0.5 * u) + torch.erfc(u)
+                                          + torch.sinc(u) + torch.sinc(0.0 * x) + torch.hypot(u, 1.0 + x) - torch.logaddexp(u, y) + torch.lerp(u, x, 0.3)
+                                          + torch.addcmul(u, x, y, value=0.5) - torch.addcdiv(u, x, 2.0 + y, value=0.25) + u.mul(x).add(y, alpha=2.0)
+                                          - u.sub(x).div(3.0 + y) + (1.0 + u * u).rsqrt() * 0.1 + u.floor() * 0.0 + u.clamp_min(-0.2).erfc() * 0.1 + (2.0 * x).exp2() * 0.01
+                                          + torch.special.xlogy(u * u, 2.0 + x) * 0.1 + torch.logit(0.5 + 0.2 * torch.tanh(u)) * 0.1
+                                          + u[:, 0:1] * x.new_tensor(0.25) + torch.special.expit(u) * 0.1 + u * y.new_ones(1)
+                                          + u * torch.zeros(1, dtype=u.dtype, device=u.device)])
+        conds = lambda: [C.NoCondition()]
+        return System(name, 2, [(2, 1, (32, 32), "tanh")], [(-1.0, 1.0), (-1.0, 1.0)], pde, conds,
+                      lambda D: [lambda net, x, y: net(_cat(x, y))])
     raise KeyError(name)
 
 
@@ -326,7 +358,7 @@ NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "he
          "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1",
          "swish_fixed_laplace", "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid",
          "mono_laplace", "mono_ode", "mono_poisson", "shape_32x6", "shape_16x8_sin", "heat4d", "mix5d", "bundle_osc",
-         "piecewise_source", "relu_ode", "atan2_adv"]
+         "piecewise_source", "relu_ode", "atan2_adv", "rounding_ode", "activations_ode", "special_2d"]
 
 
 def spherical_solver_problem():
