@@ -54,7 +54,8 @@ typedef struct ndq_mlp_desc {
                   2: the same scalars as fixed non-default values (Swish(beta=2.0)): the layers x {1, 3} floats FOLLOW
                   the n_params trainable entries in the buffer `params` points to and have no gradient entries */
   int widths;  /* 0: every hidden layer is `hidden` wide.  Otherwise the widths of layers 1..layers, 8 bits each, layer 1
-                  in the low byte (FCNN(hidden_units=(64, 32, 16)) -> 0x102040); `hidden` is their maximum */
+                  in the low byte (FCNN(hidden_units=(64, 32, 16)) -> 0x102040); `hidden` is their maximum.  Networks wider
+                  than 64 units (hidden > 64): 10 bits each, two or three layers (hidden_units=(128, 64) -> 64 << 10 | 128) */
   int mono;    /* != 0: a MonomialNN (networks.py:109-139) in front of the first linear layer: bit k <-> degree k + 1
                   (ascending, 1..8).  The d coordinates become the d * n_degrees features x_a^deg, degree after degree,
                   and the first weight matrix is (hidden x d * n_degrees); streams up to second order, hidden <= 48, no skip */

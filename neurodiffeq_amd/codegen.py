@@ -1085,13 +1085,14 @@ def mlp_ext_allowed(desc):
                                                    for p in ((a, b), (a, c), (b, c))):
                 return False
     if desc.widths:           # per-layer widths: 1..hidden each, the widest equal to `hidden`, nothing beyond `layers`
-        ws = [(desc.widths >> (8 * l)) & 255 for l in range(4)]
-        if (desc.widths >> 32) or any(w for w in ws[desc.layers:]) or min(ws[:desc.layers]) < 1 \
-                or max(ws[:desc.layers]) != desc.hidden:
+        bits, most = (10, 3) if is_wide(desc) else (8, 4)      # (csrc/ndq_deep.h: 10 bits x 2 .. 3 layers; csrc/ndq_mlp.h: 8 x 4)
+        ws = [(desc.widths >> (bits * l)) & ((1 << bits) - 1) for l in range(most)]
+        if (desc.widths >> (bits * most)) or desc.layers > most or any(w for w in ws[desc.layers:]) or min(ws[:desc.layers]) < 1 \
+                or max(ws[:desc.layers]) != desc.hidden or (is_wide(desc) and desc.layers < 2):
             return False
     if desc.mono and (not 0 < desc.mono < 256 or desc.mask3 or desc.skip or desc.hidden > 48):
         return False          # monomial features: degrees 1..8, up to second order, H <= 48, no skip connection
-    if is_wide(desc) and (desc.skip or desc.actp or desc.mono or desc.widths or desc.n_out > 16):
+    if is_wide(desc) and (desc.skip or desc.actp or desc.mono or desc.n_out > 16):
         return False          # wider than 64 units (csrc/ndq_wide.h: one hidden layer; csrc/ndq_deep.h: 2 .. 8): plain FCNN
     return (1 <= desc.d <= MAX_INPUTS and 1 <= desc.hidden <= MAX_HIDDEN and 1 <= desc.layers <= (4 if desc.widths else MAX_LAYERS)
             and desc.act in (0, 1, 2, 3, 4, 5, 6, 7) and 1 <= desc.n_out <= 64 and desc.first in (0, 1)
@@ -1112,7 +1113,7 @@ def is_wide(desc):
 def deep_cfg(desc):
     """The ndq::DeepCfg instantiation of a descriptor (2 .. 8 hidden layers of 65 .. 512 units, csrc/ndq_deep.h)."""
     return (f"ndq::DeepCfg<{desc.d}, {desc.first}, {desc.mask2}u, {desc.lap}, {desc.mask3}u, {desc.hidden}, {desc.layers}, "
-            f"{desc.act}, {desc.n_out}>")
+            f"{desc.act}, {desc.n_out}" + (f", {desc.widths}u>" if desc.widths else ">"))
 
 
 def wide_cfg(desc):

@@ -43,19 +43,38 @@
 
 namespace ndq {
 
-template <int D_, int FIRST_, unsigned M2_, int LAP_, unsigned M3_, int W_, int L_, int ACT_, int NOUT_>
+// WP_: per-layer widths (hidden_units = (128, 64), (256, 128, 64) ...: networks.py:26-66 takes any list), 10 bits per layer,
+// layer 1 lowest, for 2 .. 3 layers; 0 = every layer W_ wide.  Everything is laid out for the WIDEST layer (W_ = max): a
+// narrower layer's missing units are padding -- zero rows / columns in the weight planes, zero bias, so their
+// pre-activations are 0, whatever sigma(0) is meets zero weights downstream and nothing flows back into them -- and only
+// the real rows / columns of a gradient are copied out (the flat vector holds the real shapes, torch order).
+template <int D_, int FIRST_, unsigned M2_, int LAP_, unsigned M3_, int W_, int L_, int ACT_, int NOUT_, unsigned WP_ = 0u>
 struct DeepCfg {
   using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
   static_assert(M3_ == 0 || act_has_s4(ACT_), "third-order streams: activations with a stated fourth derivative");
   static_assert(W_ >= 1 && W_ <= 512 && L_ >= 2 && L_ <= 8, "2 .. 8 hidden layers of up to 512 units");
+  static_assert(WP_ == 0 || L_ <= 3, "per-layer widths: up to three hidden layers");
   static constexpr int D = D_, W = W_, L = L_, ACT = ACT_, NOUT = NOUT_, NS = SS::NS, NC = NS * NOUT_;
+  static constexpr unsigned WP = WP_;
   static constexpr int HP = (W_ + 15) & ~15, NB = HP / 16;
   static constexpr int THREADS = 256, WAVES = 4;
-  // flat parameter vector, torch order: W1 (W, D) b1 (W) | W_l (W, W) b_l (W), l = 2..L | Wout (NOUT, W) bout (NOUT)
-  static constexpr int offW1 = 0, offb1 = W_ * D_;
-  static constexpr int offW(int l) { return W_ * D_ + W_ + (l - 2) * (W_ * W_ + W_); }     // l in 2 .. L + 1
-  static constexpr int offb(int l) { return offW(l) + W_ * W_; }
-  static constexpr int offWout = offW(L_ + 1), offbout = offWout + NOUT_ * W_;
+  // real width of hidden layer l (1 .. L); wl(0) = the network's inputs
+  static constexpr int wl(int l) { return l == 0 ? D_ : (WP_ == 0 ? W_ : (int)((WP_ >> (10 * (l - 1))) & 1023u)); }
+  static constexpr bool widths_ok() {
+    int mx = 0;
+    for (int l = 1; l <= L_; ++l) { if (wl(l) < 1 || wl(l) > W_) return false; mx = wl(l) > mx ? wl(l) : mx; }
+    return mx == W_;
+  }
+  static_assert(widths_ok(), "per-layer widths: 1 .. W each, the widest equal to W");
+  // flat parameter vector, torch order: W1 (w1, D) b1 (w1) | W_l (w_l, w_{l-1}) b_l (w_l), l = 2..L | Wout (NOUT, w_L) bout (NOUT)
+  static constexpr int offW1 = 0, offb1 = wl(1) * D_;
+  static constexpr int offW(int l) {                                                           // l in 2 .. L + 1
+    int o = wl(1) * D_ + wl(1);
+    for (int k = 2; k < l; ++k) o += wl(k) * wl(k - 1) + wl(k);
+    return o;
+  }
+  static constexpr int offb(int l) { return offW(l) + wl(l) * wl(l - 1); }
+  static constexpr int offWout = offW(L_ + 1), offbout = offWout + NOUT_ * wl(L_);
   static constexpr int P = offbout + NOUT_;
   // output blocks (16 units) a wave accumulates per pass of the per-point GEMMs: JBC * NS fragments of 4 registers
   // (the NB blocks are spread evenly over the passes: balanced(8 blocks, at most 6 per pass) = 4 + 4, not 6 + 2)
@@ -187,7 +206,7 @@ template <class C>
 __device__ __forceinline__ void first_unit_streams(const real* __restrict__ prm, int k, const real (&x)[C::D], real (&z)[C::NS]) {
 #pragma unroll
   for (int s = 0; s < C::NS; ++s) z[s] = 0.f;
-  if (k < C::W) {
+  if (k < C::wl(1)) {
     real v = prm[C::offb1 + k];
 #pragma unroll
     for (int a = 0; a < C::D; ++a) {
@@ -237,6 +256,7 @@ struct DeepArgs {
   real* pbh;              // partial rows of db_L  [rows][HP]
   real* pbo;              // partial rows of dbout [rows][NOUT]
   real* jets;             // EPI 3 (last forward GEMM with the head folded in): output streams [NS][NOUT][ldj]
+  int ow;                 // forward GEMMs: real width of the layer being computed (its bias has that many entries; DeepCfg::WP)
 };
 
 // ------------------------------------------------------------------------------------------------ per-point GEMMs
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(C::THREADS, NDQ_DEEP_OCC) void deep_fwd_gemm(DeepAr
   for (int jb = 0; jb < C::JBC; ++jb) {
     const int j0 = 16 * (ch * C::JBC + jb) + 4 * kg;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bs[jb][r] = (j0 + r < C::W) ? a.bias[j0 + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bs[jb][r] = (j0 + r < a.ow) ? a.bias[j0 + r < a.ow ? j0 + r : 0] : 0.f;
   }
   for (int tile = stripe; tile < ntiles; tile += nstripes) {
     const int n = tile * 16 + p;
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(C::THREADS, NDQ_DEEP_OCC) void deep_fwd_gemm(DeepAr
       } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const bool ok = k0 + t < C::W;
+          const bool ok = k0 + t < C::wl(1);
           f1b[t] = ok ? a.prm[C::offb1 + (ok ? k0 + t : 0)] : 0.f;
 #pragma unroll
           for (int d = 0; d < C::D; ++d) f1w[t][d] = ok ? a.prm[C::offW1 + (ok ? k0 + t : 0) * C::D + d] : 0.f;
@@ -371,7 +391,7 @@ __global__ __launch_bounds__(C::THREADS, NDQ_DEEP_OCC) void deep_bwd_gemm(DeepAr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = 16 * (ch * JB + jb) + 4 * kg + r;
-        const bool ok = k < C::W;
+        const bool ok = k < C::wl(1);
         u1b[jb][r] = ok ? a.prm[C::offb1 + (ok ? k : 0)] : 0.f;
 #pragma unroll
         for (int d = 0; d < C::D; ++d) u1w[jb][r][d] = ok ? a.prm[C::offW1 + (ok ? k : 0) * C::D + d] : 0.f;
@@ -590,11 +610,12 @@ __global__ __launch_bounds__(kDeepBfThreads, kDeepBfOcc) void deep_gemm_bf(DeepA
     const int j0 = 16 * (ch * JB + jb) + 4 * kg;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool ok = j0 + r < C::W;
+      // (real widths: STORE / EPI 3 -- the layer being computed, a.ow (EPI 3: the last one); EPI 2 -- the first layer)
+      const bool ok = j0 + r < (STORE ? a.ow : C::wl(1));
       if constexpr (STORE) bs[jb][r] = ok ? a.bias[ok ? j0 + r : 0] : 0.f;
       if constexpr (EPI == 3) {
 #pragma unroll
-        for (int o = 0; o < C::NOUT; ++o) wout[jb][r][o] = ok ? a.prm[C::offWout + o * C::W + (ok ? j0 + r : 0)] : 0.f;
+        for (int o = 0; o < C::NOUT; ++o) wout[jb][r][o] = ok ? a.prm[C::offWout + o * C::wl(C::L) + (ok ? j0 + r : 0)] : 0.f;
       }
       if constexpr (!STORE) gb[jb][r] = 0.f;
       if constexpr (EPI == 2) {
@@ -677,15 +698,15 @@ __global__ __launch_bounds__(kDeepBfThreads, kDeepBfOcc) void deep_gemm_bf(DeepA
       if constexpr (SRC == 3) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const bool ok = k0 + e < C::W;
+          const bool ok = k0 + e < C::wl(C::L);
 #pragma unroll
-          for (int o = 0; o < C::NOUT; ++o) wo8[e][o] = ok ? a.prm[C::offWout + o * C::W + (ok ? k0 + e : 0)] : 0.f;
+          for (int o = 0; o < C::NOUT; ++o) wo8[e][o] = ok ? a.prm[C::offWout + o * C::wl(C::L) + (ok ? k0 + e : 0)] : 0.f;
         }
       }
       if constexpr (SRC == 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const bool ok = k0 + e < C::W;
+          const bool ok = k0 + e < C::wl(1);
           f1b[e] = ok ? a.prm[C::offb1 + (ok ? k0 + e : 0)] : 0.f;
 #pragma unroll
           for (int d = 0; d < C::D; ++d) f1w[e][d] = ok ? a.prm[C::offW1 + (ok ? k0 + e : 0) * C::D + d] : 0.f;
@@ -896,7 +917,7 @@ __global__ __launch_bounds__(256) void deep_prep_planes(const real* __restrict__
       const int k = k0 + t;
       // element (row, k) of W_l, or of its transpose
       const int j = tr ? k : row, kk = tr ? row : k;
-      const real v = (j < C::W && kk < C::W) ? prm[C::offW(l) + j * C::W + kk] : 0.f;
+      const real v = (j < C::wl(l) && kk < C::wl(l - 1)) ? prm[C::offW(l) + j * C::wl(l - 1) + kk] : 0.f;
       if (t < 4) lo[t] = v; else hi[t - 4] = v;
     }
     bf16x8 pl[3];
@@ -938,10 +959,10 @@ __global__ __launch_bounds__(C::THREADS, 2) void deep_wgrad_gemm(DeepArgs a) {
   if constexpr (FIRSTIN) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const bool ok = k0 + v < C::W;
-      b1v[v] = ok ? a.prm[C::offb1 + k0 + v] : 0.f;
+      const bool ok = k0 + v < C::wl(1);
+      b1v[v] = ok ? a.prm[C::offb1 + (ok ? k0 + v : 0)] : 0.f;
 #pragma unroll
-      for (int d = 0; d < C::D; ++d) w1v[v][d] = ok ? a.prm[C::offW1 + (k0 + v) * C::D + d] : 0.f;
+      for (int d = 0; d < C::D; ++d) w1v[v][d] = ok ? a.prm[C::offW1 + (ok ? k0 + v : 0) * C::D + d] : 0.f;
     }
   }
   const int ngroups = a.np >> 2, g0 = ks * C::WAVES + wave, gstep = KS * C::WAVES;
@@ -953,11 +974,11 @@ __global__ __launch_bounds__(C::THREADS, 2) void deep_wgrad_gemm(DeepArgs a) {
   if constexpr (HEAD) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const bool ok = j0 + v < C::W;
+      const bool ok = j0 + v < C::wl(C::L);
       dbl[v] = 0.f;
 #pragma unroll
       for (int o = 0; o < C::NOUT; ++o) {
-        wov[v][o] = ok ? a.prm[C::offWout + o * C::W + (ok ? j0 + v : 0)] : 0.f;
+        wov[v][o] = ok ? a.prm[C::offWout + o * C::wl(C::L) + (ok ? j0 + v : 0)] : 0.f;
         dwo[v][o] = 0.f;
       }
     }
@@ -1175,7 +1196,7 @@ __global__ __launch_bounds__(C::THREADS, deep_wgbf_occ(C::NS)) void deep_wgrad_b
   if constexpr (FIRSTIN) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const bool ok = k0 + v < C::W;
+      const bool ok = k0 + v < C::wl(1);
       b1v[v] = ok ? a.prm[C::offb1 + (ok ? k0 + v : 0)] : 0.f;
 #pragma unroll
       for (int d = 0; d < C::D; ++d) w1v[v][d] = ok ? a.prm[C::offW1 + (ok ? k0 + v : 0) * C::D + d] : 0.f;
@@ -1187,11 +1208,11 @@ __global__ __launch_bounds__(C::THREADS, deep_wgbf_occ(C::NS)) void deep_wgrad_b
   if constexpr (HEAD) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const bool ok = j0 + v < C::W;
+      const bool ok = j0 + v < C::wl(C::L);
       dbl[v] = 0.f;
 #pragma unroll
       for (int o = 0; o < C::NOUT; ++o) {
-        wov[v][o] = ok ? a.prm[C::offWout + o * C::W + (ok ? j0 + v : 0)] : 0.f;
+        wov[v][o] = ok ? a.prm[C::offWout + o * C::wl(C::L) + (ok ? j0 + v : 0)] : 0.f;
         dwo[v][o] = 0.f;
       }
     }
@@ -1406,7 +1427,7 @@ __global__ __launch_bounds__(C::THREADS) void deep_head_fwd(DeepHeadArgs a) {
         jet_unit_forward<C>(z, h, tt, cc);
 #pragma unroll
         for (int o = 0; o < C::NOUT; ++o) {
-          const real wo = (j0 + r < C::W) ? a.prm[C::offWout + o * C::W + j0 + r] : 0.f;
+          const real wo = (j0 + r < C::wl(C::L)) ? a.prm[C::offWout + o * C::wl(C::L) + j0 + r] : 0.f;
 #pragma unroll
           for (int s = 0; s < C::NS; ++s) acc[s * C::NOUT + o] = rfma(wo, h[s], acc[s * C::NOUT + o]);
         }
@@ -1436,7 +1457,7 @@ __global__ __launch_bounds__(C::THREADS) void deep_head_bwd(DeepHeadArgs a) {
   real wo[C::NOUT], dwo[C::NOUT], gbo[C::NOUT];
 #pragma unroll
   for (int o = 0; o < C::NOUT; ++o) {
-    wo[o] = (j < C::W) ? a.prm[C::offWout + o * C::W + jj] : 0.f;
+    wo[o] = (j < C::wl(C::L)) ? a.prm[C::offWout + o * C::wl(C::L) + (j < C::wl(C::L) ? jj : 0)] : 0.f;
     dwo[o] = 0.f;
     gbo[o] = 0.f;
   }
@@ -1491,7 +1512,7 @@ __global__ __launch_bounds__(256) void deep_prep(const real* __restrict__ prm, r
   const size_t base = (size_t)(l - 2) * C::HP * C::HP;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < C::HP * C::HP; e += gridDim.x * blockDim.x) {
     const int j = e / C::HP, k = e % C::HP;
-    const real v = (j < C::W && k < C::W) ? prm[C::offW(l) + j * C::W + k] : 0.f;
+    const real v = (j < C::wl(l) && k < C::wl(l - 1)) ? prm[C::offW(l) + j * C::wl(l - 1) + k] : 0.f;
     wp[base + e] = v;
     wt[base + (size_t)k * C::HP + j] = v;
   }

@@ -253,6 +253,7 @@ int deep_forward_layers(const DeepPlan& q, real* ws, const real* coords, int ldc
     a.wmat = ws + q.wp + (size_t)(l - 2) * C::HP * C::HP;
     a.wpl = ws + q.wpl + (size_t)(l - 2) * q.planes_layer;
     a.bias = params + C::offb(l);
+    a.ow = C::wl(l);
     a.zin = l > 2 ? ws + q.z0 + (size_t)(l - 3) * q.X : nullptr;
     a.zout = ws + q.z0 + (size_t)(l - 2) * q.X;
 #if NDQ_DEEP_BF16X3
@@ -325,8 +326,8 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
     const int blocks = deep_blocks((long)UG * q.np, UG, 4 * q.blocks_max);
     const int stripes = blocks * C::WAVES / UG;
     hipLaunchKernelGGL(deep_head_bwd<C>, dim3(blocks), dim3(C::THREADS), 0, st, h);
-    reduce(h.pwo, stripes, C::NOUT, C::HP, C::NOUT, C::W, grad + C::offWout);
-    reduce(h.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb(C::L));
+    reduce(h.pwo, stripes, C::NOUT, C::HP, C::NOUT, C::wl(C::L), grad + C::offWout);
+    reduce(h.pb, stripes, 1, C::HP, 1, C::wl(C::L), grad + C::offb(C::L));
     reduce(h.pbo, stripes, 1, C::NOUT, 1, C::NOUT, grad + C::offbout);
   }
   int cur = 0;
@@ -367,13 +368,13 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       if (head) {
         if (l == 2) hipLaunchKernelGGL((NDQ_WGRAD_KERNEL<C, true, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
         else hipLaunchKernelGGL((NDQ_WGRAD_KERNEL<C, false, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
-        reduce(a.pwo, KS * C::WAVES, C::NOUT, C::HP, C::NOUT, C::W, grad + C::offWout);
-        reduce(a.pbh, KS * C::WAVES, 1, C::HP, 1, C::W, grad + C::offb(C::L));
+        reduce(a.pwo, KS * C::WAVES, C::NOUT, C::HP, C::NOUT, C::wl(C::L), grad + C::offWout);
+        reduce(a.pbh, KS * C::WAVES, 1, C::HP, 1, C::wl(C::L), grad + C::offb(C::L));
         reduce(a.pbo, KS * C::WAVES, 1, C::NOUT, 1, C::NOUT, grad + C::offbout);
       } else if (l == 2) hipLaunchKernelGGL((NDQ_WGRAD_KERNEL<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
       else hipLaunchKernelGGL((NDQ_WGRAD_KERNEL<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
 #undef NDQ_WGRAD_KERNEL
-      reduce(a.pw, KS, C::HP, C::HP, C::W, C::W, grad + C::offW(l));
+      reduce(a.pw, KS, C::HP, C::HP, C::wl(l), C::wl(l - 1), grad + C::offW(l));
     }
     a.wmat = ws + q.wt + (size_t)(l - 2) * C::HP * C::HP;
     a.wpl = ws + q.wtl + (size_t)(l - 2) * q.planes_layer;               // planes of W_l^T
@@ -403,7 +404,7 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       const int stripes = bf_stripes(NCHB1);
       if (head) hipLaunchKernelGGL((deep_gemm_bf<C, 3, 1>), dim3(stripes * NCHB1), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 1>()), st, a);
       else hipLaunchKernelGGL((deep_gemm_bf<C, 2, 1>), dim3(stripes * NCHB1), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 1>()), st, a);
-      reduce(a.pb, stripes * kDeepBfWaves, 1, C::HP, 1, C::W, grad + C::offb(l - 1));
+      reduce(a.pb, stripes * kDeepBfWaves, 1, C::HP, 1, C::wl(l - 1), grad + C::offb(l - 1));
       cur ^= 1;
     } else {
       constexpr int NCHB2 = (C::NB + deep_bf_jb<C, 2>() - 1) / deep_bf_jb<C, 2>();
@@ -411,23 +412,23 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
       const int stripes = bf_stripes(NCHB2);
       if (head) hipLaunchKernelGGL((deep_gemm_bf<C, 3, 2>), dim3(stripes * NCHB2), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 2>()), st, a);
       else hipLaunchKernelGGL((deep_gemm_bf<C, 2, 2>), dim3(stripes * NCHB2), dim3(kDeepBfThreads), (deep_bf_lds_bytes<C, 2>()), st, a);
-      reduce(a.pb, stripes * kDeepBfWaves, 1, C::HP, 1, C::W, grad + C::offb1);
-      reduce(a.pw1, stripes * kDeepBfWaves, C::HP, C::D, C::W, C::D, grad + C::offW1);
+      reduce(a.pb, stripes * kDeepBfWaves, 1, C::HP, 1, C::wl(1), grad + C::offb1);
+      reduce(a.pw1, stripes * kDeepBfWaves, C::HP, C::D, C::wl(1), C::D, grad + C::offW1);
     }
 #else
     if (l > 2) {
       a.zout = ws + q.zb0 + (size_t)(cur ^ 1) * q.X;
       const int blocks = deep_blocks((long)ntiles * C::NCHB, C::NCHB, 2 * q.blocks_max);
       hipLaunchKernelGGL((deep_bwd_gemm<C, false>), dim3(blocks), dim3(C::THREADS), 0, st, a);
-      reduce(a.pb, blocks * C::WAVES / C::NCHB, 1, C::HP, 1, C::W, grad + C::offb(l - 1));
+      reduce(a.pb, blocks * C::WAVES / C::NCHB, 1, C::HP, 1, C::wl(l - 1), grad + C::offb(l - 1));
       cur ^= 1;
     } else {
       a.pw1 = ws + q.pw1;
       const int blocks = deep_blocks((long)ntiles * C::NCHF, C::NCHF, 2 * q.blocks_max);
       const int stripes = blocks * C::WAVES / C::NCHF;
       hipLaunchKernelGGL((deep_bwd_gemm<C, true>), dim3(blocks), dim3(C::THREADS), 0, st, a);
-      reduce(a.pb, stripes, 1, C::HP, 1, C::W, grad + C::offb1);
-      reduce(a.pw1, stripes, C::HP, C::D, C::W, C::D, grad + C::offW1);
+      reduce(a.pb, stripes, 1, C::HP, 1, C::wl(1), grad + C::offb1);
+      reduce(a.pw1, stripes, C::HP, C::D, C::wl(1), C::D, grad + C::offW1);
     }
 #endif
   }
@@ -438,7 +439,7 @@ int deep_kernels_bwd(const real* coords, int ldc, int n, const real* params, con
 template <class C>
 kernels_record make_deep_kernels() {
   kernels_record k{};
-  k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::W, C::L, C::ACT, C::NOUT, C::SS::LAP, 0, (int)C::SS::M3, 0, 0, 0};
+  k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::W, C::L, C::ACT, C::NOUT, C::SS::LAP, 0, (int)C::SS::M3, 0, (int)C::WP, 0};
   k.n_streams = C::NS;
   k.n_params = C::P;
   k.bwd_waves = 1 << 24;              // ndq_mlp_bwd_blocks() == 1: the adjoint entry writes the gradient row itself

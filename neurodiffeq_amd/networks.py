@@ -204,11 +204,21 @@ def describe(net, dtype=torch.float32):
                 return None
     # hidden widths: any (the kernels lay all layers out for the widest one, padded to a multiple of 16)
     ws = [l.out_features for l in linears[:-1]]
-    if any(b.in_features != a for a, b in zip(ws, linears[1:])) or len(ws) > (MAX_LAYERS if len(set(ws)) == 1 else 4) \
-            or max(ws) > (MAX_HIDDEN if len(set(ws)) == 1 else 255):
+    if any(b.in_features != a for a, b in zip(ws, linears[1:])):
         return None
     hidden = max(ws)
-    widths = 0 if len(set(ws)) == 1 else sum(w << (8 * i) for i, w in enumerate(ws))
+    if len(set(ws)) == 1:
+        if len(ws) > MAX_LAYERS or hidden > MAX_HIDDEN:
+            return None
+        widths = 0
+    elif hidden <= 64:
+        if len(ws) > 4:
+            return None
+        widths = sum(w << (8 * i) for i, w in enumerate(ws))          # csrc/ndq_mlp.h: 8 bits per layer, up to four
+    else:
+        if len(ws) > 3 or hidden > MAX_HIDDEN:
+            return None
+        widths = sum(w << (10 * i) for i, w in enumerate(ws))         # csrc/ndq_deep.h: 10 bits per layer, two or three
     if any(p.dtype != dtype for l in linears for p in l.parameters()):
         return None
     if skip is not None and tuple(skip.weight.shape) != (linears[-1].out_features, linears[0].in_features):

@@ -151,6 +151,14 @@ def make(name, size=None):
         c = make("c3", size or 12)
         c["nets"] = [FCNN(2, 1, hidden_units=(128, 128, 128))]
         return c
+    if name == "w26":     # per-layer widths above 64 units: (128, 64) on the Burgers problem of C3
+        c = make("c3", size or 12)
+        c["nets"] = [FCNN(2, 1, hidden_units=(128, 64))]
+        return c
+    if name == "w27":     # (96, 200, 40) with nn.Sigmoid on the C2 problem (sigma(0) != 0 in the padding units)
+        c = make("c2", size or 12)
+        c["nets"] = [FCNN(2, 1, hidden_units=(96, 200, 40), actv=torch.nn.Sigmoid)]
+        return c
     if name == "w24":     # Resnet 128 x 2 on the C2 problem: skip connection above 64 units (handled by the tracer)
         c = make("c2", size or 12)
         c["nets"] = [Resnet(2, 1, hidden_units=(128, 128))]

@@ -76,6 +76,12 @@ DEEP_SHAPES = [
     (2, 144, 1, "swish", "diag2", 2),
     (2, 96, 1, "aptx", "first", 5),
     (4, 72, 1, "tanh", "value", 2),
+    # per-layer widths (hidden_units = (128, 64) ...: laid out for the widest layer, DeepCfg::WP): the width entry is the tuple
+    (2, (128, 64), 1, "tanh", "first+xx", 2),
+    (2, (64, 128), 1, "tanh", "lap", 2),
+    (2, (96, 200, 40), 3, "sigmoid", "full2", 3),       # sigma(0) != 0 in the padding units
+    (1, (256, 128, 72), 1, "sin", "full3", 3),
+    (3, (100, 80), 2, "swish", "full2", 2),
 ]
 # torch's own activation modules (nn.ELU / nn.Softplus / nn.GELU: generic derivative tables) on all three
 # kernel families: fragment kernels (width <= 64), one wide layer, deep wide
@@ -86,6 +92,17 @@ ACT_SHAPES = [
 ]
 SHAPES = SHAPES + DEEP_SHAPES + ACT_SHAPES
 IDS = ["-".join(map(str, sh)) for sh in SHAPES]
+
+
+def shape_desc(shape):
+    """(ndq_mlp_desc, widths of the hidden layers) of a SHAPES entry (the width entry is an int, or the tuple of per-layer widths)"""
+    from neurodiffeq_amd import _lib
+    d, w, n_out, act, kind = shape[:5]
+    layers = shape[5] if len(shape) > 5 else 1
+    ws = tuple(w) if isinstance(w, tuple) else (w,) * layers
+    packed = sum(v << (10 * i) for i, v in enumerate(ws)) if isinstance(w, tuple) else 0
+    _, first, mask2, lap, mask3 = _streams(d, kind)
+    return _lib.MlpDesc(d, first, mask2, max(ws), layers, ACT_ID[act], n_out, lap, 0, mask3, 0, packed), ws
 
 
 def rel_l2(a, b):
@@ -111,14 +128,14 @@ def _oracle_streams(flat64, dims, act, c64, streams):
 def test_wide_stream_kernels_match_jet_oracle(shape, n):
     from neurodiffeq_amd import _lib, codegen
     d, w, n_out, act, kind = shape[:5]
-    layers = shape[5] if len(shape) > 5 else 1
+    desc, ws = shape_desc(shape)                                        # (ws: widths of the hidden layers)
+    w = max(ws)
     if n not in (17, 1000) and shape not in SHAPES[:3] + SHAPES[6:7] + SHAPES[9:10] + DEEP_SHAPES[:3]:
         pytest.skip("edge sizes on a subset of the shapes")
     L = _lib.lib()
     streams, first, mask2, lap, mask3 = _streams(d, kind)
-    desc = _lib.MlpDesc(d, first, mask2, w, layers, ACT_ID[act], n_out, lap, 0, mask3)
     assert codegen.ensure_mlp_kernels(desc) and L.ndq_mlp_supported(ctypes.byref(desc)) == 1
-    dims = (d,) + (w,) * layers + (n_out,)
+    dims = (d,) + ws + (n_out,)
     rng = np.random.default_rng(zlib.crc32(f"{shape}/{n}".encode()))
     parts = []
     for a, b in zip(dims[:-1], dims[1:]):
@@ -156,8 +173,9 @@ def test_wide_stream_kernels_match_jet_oracle(shape, n):
             gb[mm] = gb.get(mm, 0) + gbar[s].astype(np.float64).T
     want_grad = J.mlp_jets_vjp(f64, dims, act, c64, gb)[:P]
     errs["grad"] = rel_l2(grad, want_grad)
-    for name, lo, hi in (("dW1", 0, d * w), ("db1", d * w, d * w + w), ("dWhidden", d * w + w, P - n_out * w - n_out),
-                         ("dWout", P - n_out * w - n_out, P - n_out), ("dbout", P - n_out, P)):
+    w1, wL = ws[0], ws[-1]
+    for name, lo, hi in (("dW1", 0, d * w1), ("db1", d * w1, d * w1 + w1), ("dWhidden", d * w1 + w1, P - n_out * wL - n_out),
+                         ("dWout", P - n_out * wL - n_out, P - n_out), ("dbout", P - n_out, P)):
         errs[name] = float(np.linalg.norm(grad[lo:hi] - want_grad[lo:hi]) / max(np.linalg.norm(want_grad), 1e-300))
     # bit-reproducible: a second launch gives the same bits
     part2 = torch.full((nb, P), float("nan"), device="cuda")
@@ -180,9 +198,10 @@ def _grad_in_torch_order(nets, flats):
                       for net in nets for prm in net.parameters()]).cpu().numpy()
 
 
-GOLDEN_WIDE = ["w16", "w17", "w18", "w19", "w20", "w21", "w24", "w25"]      # w20: (100, 100) ELU; w21: Softplus + GELU networks (32 x 32);
+GOLDEN_WIDE = ["w16", "w17", "w18", "w19", "w20", "w21", "w24", "w25", "w26", "w27"]      # w20: (100, 100) ELU; w21: Softplus + GELU networks (32 x 32);
 #                                                 w24 / w25: Resnet 128 x 2 and 2 -> 512 -> 3 (skip connection above 64 units: symbolic, round 5)
-GOLDEN_DEEP = ("w18", "w19", "w20", "w21", "w24")    # layer-by-layer kernels (w18 - w20) / two networks with different activations (w21):
+GOLDEN_DEEP = ("w18", "w19", "w20", "w21", "w24", "w26", "w27")     # (w26 / w27: per-layer widths above 64 units, (128, 64) and (96, 200, 40) sigmoid)
+#      # layer-by-layer kernels (w18 - w20) / two networks with different activations (w21):
 #                                                 three-kernel pipeline, no single-launch closure
 
 
