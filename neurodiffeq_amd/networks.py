@@ -229,7 +229,7 @@ def describe(net, dtype=torch.float32):
     # (symbolic.Graph.register_nets) -- and stays outside the flat parameter vector of the kernels
     skip_sym = None
     if skip is not None and hidden > 64:
-        if act_params or act_frozen or widths or mono:
+        if act_params or act_frozen or mono:
             return None
         skip_sym, skip = skip, None
     params = [p for l in linears for p in (l.weight, l.bias)] + ([skip.weight] if skip is not None else []) + act_params

@@ -159,6 +159,10 @@ def make(name, size=None):
         c = make("c2", size or 12)
         c["nets"] = [FCNN(2, 1, hidden_units=(96, 200, 40), actv=torch.nn.Sigmoid)]
         return c
+    if name == "w28":     # Resnet (128, 64) on the C2 problem: symbolic skip connection + per-layer widths
+        c = make("c2", size or 12)
+        c["nets"] = [Resnet(2, 1, hidden_units=(128, 64))]
+        return c
     if name == "w24":     # Resnet 128 x 2 on the C2 problem: skip connection above 64 units (handled by the tracer)
         c = make("c2", size or 12)
         c["nets"] = [Resnet(2, 1, hidden_units=(128, 128))]

@@ -319,6 +319,13 @@ def cfg_w27():
     return c
 
 
+def cfg_w28():
+    """Resnet(2, 1, hidden_units=(128, 64)) on the C2 problem: skip connection AND per-layer widths above 64 units."""
+    c = cfg_c2(12)
+    c["nets"] = [Resnet(2, 1, hidden_units=(128, 64))]
+    return c
+
+
 def cfg_w25():
     """Resnet(2, 3, hidden_units=(512,)) on the single-network cavity problem: skip connection, one wide layer, three outputs."""
     return _ns_single(Resnet(n_input_units=2, n_output_units=3, hidden_units=(512,)))
@@ -342,7 +349,7 @@ def cfg_w21():
     return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=Generator2D((10, 10), (0, 0), (1, 1), "equally-spaced-noisy"))
 
 
-CONFIGS = {"w26": cfg_w26, "w27": cfg_w27, "w24": cfg_w24, "w25": cfg_w25, "w18r": cfg_w18r, "w20": cfg_w20, "w21": cfg_w21, "w16": cfg_w16, "w17": cfg_w17, "w18": cfg_w18, "w19": cfg_w19, "c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
+CONFIGS = {"w26": cfg_w26, "w27": cfg_w27, "w28": cfg_w28, "w24": cfg_w24, "w25": cfg_w25, "w18r": cfg_w18r, "w20": cfg_w20, "w21": cfg_w21, "w16": cfg_w16, "w17": cfg_w17, "w18": cfg_w18, "w19": cfg_w19, "c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
            "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5, "w6": cfg_w6, "w7": cfg_w7, "w8": cfg_w8,
            "w9": cfg_w9, "w10": cfg_w10, "w11": cfg_w11, "w12": cfg_w12, "w13": cfg_w13, "w14": cfg_w14, "w15": cfg_w15}
 

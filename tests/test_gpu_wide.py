@@ -198,9 +198,9 @@ def _grad_in_torch_order(nets, flats):
                       for net in nets for prm in net.parameters()]).cpu().numpy()
 
 
-GOLDEN_WIDE = ["w16", "w17", "w18", "w19", "w20", "w21", "w24", "w25", "w26", "w27"]      # w20: (100, 100) ELU; w21: Softplus + GELU networks (32 x 32);
+GOLDEN_WIDE = ["w16", "w17", "w18", "w19", "w20", "w21", "w24", "w25", "w26", "w27", "w28"]      # w20: (100, 100) ELU; w21: Softplus + GELU networks (32 x 32);
 #                                                 w24 / w25: Resnet 128 x 2 and 2 -> 512 -> 3 (skip connection above 64 units: symbolic, round 5)
-GOLDEN_DEEP = ("w18", "w19", "w20", "w21", "w24", "w26", "w27")     # (w26 / w27: per-layer widths above 64 units, (128, 64) and (96, 200, 40) sigmoid)
+GOLDEN_DEEP = ("w18", "w19", "w20", "w21", "w24", "w26", "w27", "w28")     # (w26 / w27: per-layer widths above 64 units, (128, 64) and (96, 200, 40) sigmoid)
 #      # layer-by-layer kernels (w18 - w20) / two networks with different activations (w21):
 #                                                 three-kernel pipeline, no single-launch closure
 

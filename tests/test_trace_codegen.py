@@ -15,7 +15,7 @@ from oracle import jet_ref as J
 from tests import configs, zoo
 from tests.pw_cpu import run_cpu
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w9": None, "w10": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None, "w20": None, "w21": None, "w24": None, "w25": None, "w26": None, "w27": None}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w9": None, "w10": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None, "w20": None, "w21": None, "w24": None, "w25": None, "w26": None, "w27": None, "w28": None}
 
 
 def rel_l2(a, b):
@@ -139,7 +139,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
                                       ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True), ("w5", True), ("w6", True), ("w7", True), ("w8", True),
                                       ("w9", True), ("w10", True), ("w11", True), ("w12", True), ("w13", True), ("w14", True), ("w15", True), ("w16", True), ("w17", True), ("w18", True), ("w19", True), ("w20", True), ("w21", True),
                                       ("w24", True), ("w25", True),       # w24 / w25: Resnets above 64 units (symbolic skip connection)
-                                      ("w26", True), ("w27", True)])       # w26 / w27: per-layer widths above 64 units
+                                      ("w26", True), ("w27", True), ("w28", True)])       # w26 / w27: per-layer widths above 64 units
 def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     torch.manual_seed(0)
