@@ -331,10 +331,10 @@ def cfg_w25():
     return _ns_single(Resnet(n_input_units=2, n_output_units=3, hidden_units=(512,)))
 
 
-def cfg_w20():
+def cfg_w20(g=12):
     """tests/test_pde.py:370-377 of the reference: nabla^2 u + e^u = 1 + x^2 + y^2 + 4 / (1 + x^2 + y^2)^2 on
     FCNN(n_input_units=2, hidden_units=(100, 100), actv=nn.ELU), here with C2's Dirichlet boundary."""
-    c = cfg_c2(12)
+    c = cfg_c2(g)
     c["pde"] = lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2) + torch.exp(u) - 1.0 - x ** 2 - y ** 2
                                 - 4.0 / (1.0 + x ** 2 + y ** 2) ** 2]
     c["nets"] = [FCNN(n_input_units=2, hidden_units=(100, 100), actv=torch.nn.ELU)]
@@ -488,7 +488,7 @@ DEFAULT_PRECISION = {"w22": "w16", "w23": "w17"}
 
 # (w17 / w18 / w19: the wide networks bench.py times at 65 536 points -- VERDICT r4 weak #2; w18r: a ragged batch through the
 # layer-by-layer kernels)
-FULL_SIZES = {"c1": 1024, "c2": 256, "c3": 512, "c4": 131072, "c5": 1024, "w17": 256, "w18": 256, "w19": 256, "w18r": (251, 261)}
+FULL_SIZES = {"c1": 1024, "c2": 256, "c3": 512, "c4": 131072, "c5": 1024, "w17": 256, "w18": 256, "w19": 256, "w18r": (251, 261), "w20": 256, "w26": 256}
 
 
 def make_full(name, seed=0, chunk=None):

@@ -264,7 +264,7 @@ def test_wide_solver_trajectory_matches_reference_golden(golden_dir, name):
 
 
 @pytest.mark.parametrize("name,size,mode", [("w17", 256, "1k"), ("w17", 256, "3k"), ("w18", 256, "3k"), ("w19", 256, "3k"),
-                                            ("w18r", (251, 261), "3k")])
+                                            ("w18r", (251, 261), "3k"), ("w20", 256, "3k"), ("w26", 256, "3k")])
 def test_wide_closure_matches_reference_golden_at_the_size_the_bench_times(golden_dir, name, size, mode):
     """VERDICT r4 weak #2 / next #2a: bench.py times the wide legs (cavity 512 x 1, Burgers 128 x 3, cavity 256 x 2) at 65 536
     points; the stripe / tile / reduction job tables of the layer-by-layer kernels depend on the batch size, so parity is
