@@ -18,7 +18,7 @@ def short(k):
     m = re.search(r"(wide_closure_tv|wide_closure|wide_jet_fwd|wide_jet_bwd)_kernel<ndq::WideCfg<([^>]*)>", k)
     if m:
         return f"{m.group(1)}<{m.group(2).replace(' ', '')}>"
-    m = re.search(r"(deep_gemm_bf|deep_fwd_gemm|deep_bwd_gemm|deep_wgrad_gemm|deep_head_fwd|deep_head_bwd)<ndq::DeepCfg<([^>]*)>((?:, \w+)*)", k)
+    m = re.search(r"(deep_gemm_bf|deep_fwd_gemm|deep_bwd_gemm|deep_wgrad_gemm|deep_wgrad_bf|deep_head_fwd|deep_head_bwd)<ndq::DeepCfg<([^>]*)>((?:, \w+)*)", k)
     if m:
         return f"{m.group(1)}<{m.group(2).replace(' ', '')}>{(m.group(3) or '').replace(', ', '/')}"
     if "deep_prep_planes" in k:
