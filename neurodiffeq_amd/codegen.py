@@ -118,6 +118,7 @@ _UN_FWD = {
     "sign": "(({a}>0.0f)-({a}<0.0f))",
     "log1p": "log1pf({a})", "expm1": "expm1f({a})", "erf": "erff({a})", "atan": "atanf({a})",
     "floor": "floorf({a})", "ceil": "ceilf({a})", "round": "rintf({a})", "trunc": "truncf({a})",       # (rint: half to even, like torch.round)
+    "detach": "{a}",
 }
 # adjoint factor of the single child: child_adj += b * factor ; {a} child value, {v} node value
 _UN_ADJ = {
@@ -127,7 +128,7 @@ _UN_ADJ = {
     "sigmoid": "{b}*{v}*(1.0f-{v})", "recip": "-{b}*{v}*{v}", "sign": None,
     "log1p": "{b}/(1.0f+{a})", "expm1": "{b}*({v}+1.0f)", "erf": "{b}*1.1283791670955126f*expf(-{a}*{a})",
     "atan": "{b}/(1.0f+{a}*{a})",
-    "floor": None, "ceil": None, "round": None, "trunc": None,
+    "floor": None, "ceil": None, "round": None, "trunc": None, "detach": None,      # (no adjoint flows into the child)
 }
 
 

@@ -33,7 +33,7 @@ LEAVES = ("const", "coord", "net", "param", "data")
 
 # op -> (arity).  Unary elementwise functions are listed in UNARY.
 UNARY = ("neg", "sin", "cos", "tan", "exp", "log", "tanh", "sqrt", "abs", "sinh", "cosh", "sigmoid", "recip", "sign",
-         "log1p", "expm1", "erf", "atan", "floor", "ceil", "round", "trunc")
+         "log1p", "expm1", "erf", "atan", "floor", "ceil", "round", "trunc", "detach")
 # further binary nodes: atan2(a, b) and the MASKS gt(a, b) = [a > b], ge(a, b) = [a >= b] -- per-point 0.0 / 1.0 columns with
 # zero derivative, what a comparison of traced columns gives (`x > 0.5`); ternary: where(m, a, b) = m != 0 ? a : b, which
 # selects (it does not blend: an inf / nan in the branch not taken stays out of the value AND of the gradient, like
@@ -289,6 +289,7 @@ class Graph:
         "log1p": math.log1p, "expm1": math.expm1, "erf": math.erf, "atan": math.atan,
         "floor": lambda v: float(math.floor(v)), "ceil": lambda v: float(math.ceil(v)), "round": lambda v: float(round(v)),   # (half to even, like torch.round)
         "trunc": lambda v: float(math.trunc(v)),
+        "detach": lambda v: v,
     }
 
     def unary(self, op, a):
@@ -401,6 +402,8 @@ class Graph:
                 r = self.mul(self.unary("sign", a), da)
             elif op in ("sign", "floor", "ceil", "round", "trunc"):
                 r = self.const(0.0)          # piecewise constant (torch: zero gradient)
+            elif op == "detach":
+                r = self.const(0.0)          # a constant as far as autograd is concerned (x.detach() inside a product / sum)
             elif op == "sinh":
                 r = self.mul(self.unary("cosh", a), da)
             elif op == "cosh":
@@ -719,7 +722,9 @@ class Sym:
         return self
 
     def detach(self):
-        raise TraceUnsupported("detach() inside the traced region")
+        """x.detach(): the value, with no gradient flowing through it (stop-gradient weights inside an equation or a loss):
+        a node of its own whose derivative and adjoint are zero."""
+        return self._un("detach")
 
     def __getitem__(self, idx):
         # the whole (N, 1) column under another spelling: u[:, 0:1], u[:, [0]], u[:, :], u[...]
@@ -1413,6 +1418,7 @@ def _tf_xlog1py(a, b, **k):
 
 
 _TORCH_FUNCS = {
+    "detach": _tf_map("detach"),
     "xlogy": _tf_xlogy, "xlog1py": _tf_xlog1py, "logit": _tf_elem(lambda c: (c / (1.0 - c)).log()), "expit": _tf_unary("sigmoid"),
     "floor": _tf_map("floor"), "ceil": _tf_map("ceil"), "trunc": _tf_map("trunc"), "fix": _tf_map("trunc"), "round": _tf_round,
     "frac": _tf_elem(lambda c: c - c._un("trunc")), "fmod": _tf_fmod, "remainder": _tf_remainder,
@@ -1478,6 +1484,8 @@ def sym_diff(u, t, order=1):
     if not isinstance(u, Sym):
         # a python scalar / constant: derivative is zero, like the reference's "unused" branch (neurodiffeq.py:23-24)
         return Sym(g, g.const(0.0))
+    if g.nodes[u.i][0] == "detach":
+        raise TraceUnsupported("diff() of a detached value (torch.autograd.grad has no path to differentiate along)")
     e = u.i
     for _ in range(int(order)):
         e = g.diff(e, nt[1])

@@ -359,7 +359,7 @@ def test_unsupported_constructs_raise_trace_unsupported():
         assert g.cval(diff(t ** 2, t, order=2).i) == 2.0
         # round 5: what stays outside the traced family says so -- operations across points, shapes the column semantics do
         # not carry, in-place methods, multi-element constants made from a column
-        for bad in (lambda: t - t.mean(), lambda: torch.roll(t, 1, 0), lambda: t.flatten(), lambda: t.squeeze(1), lambda: t.detach(),
+        for bad in (lambda: t - t.mean(), lambda: torch.roll(t, 1, 0), lambda: t.flatten(), lambda: t.squeeze(1), lambda: diff(t.detach(), t),
                     lambda: torch.stack([t, t]), lambda: t.floor_(), lambda: t.new_ones(5), lambda: t[:, 0], lambda: t[3],
                     lambda: torch.lgamma(t), lambda: torch.nan_to_num(t)):
             with pytest.raises(TraceUnsupported):
@@ -369,6 +369,7 @@ def test_unsupported_constructs_raise_trace_unsupported():
         assert float(t.new_ones(1)) == 1.0 and float(t.new_zeros(1, 1)) == 0.0 and float(t.new_tensor(2.5)) == 2.5
         assert t.dtype == torch.get_default_dtype() and t.floor().i != t.i and torch.frac(t).i == (t - torch.trunc(t)).i
         assert g.cval(diff(torch.floor(t) * 2.0, t).i) == 0.0        # piecewise constant: zero derivative
+        assert g.cval(diff(t * t.detach(), t).i) is None and diff(t * t.detach(), t).i == t.detach().i      # d/dt [t sg(t)] = sg(t)
 
 
 def test_trainable_and_per_point_tensors_are_not_baked_into_the_kernel():

@@ -345,7 +345,8 @@ def build(name):
                                           - u.sub(x).div(3.0 + y) + (1.0 + u * u).rsqrt() * 0.1 + u.floor() * 0.0 + u.clamp_min(-0.2).erfc() * 0.1 + (2.0 * x).exp2() * 0.01
                                           + torch.special.xlogy(u * u, 2.0 + x) * 0.1 + torch.logit(0.5 + 0.2 * torch.tanh(u)) * 0.1
                                           + u[:, 0:1] * x.new_tensor(0.25) + torch.special.expit(u) * 0.1 + u * y.new_ones(1)
-                                          + u * torch.zeros(1, dtype=u.dtype, device=u.device)])
+                                          + u * torch.zeros(1, dtype=u.dtype, device=u.device)
+                                          + u * torch.tanh(u).detach() * 0.3 + (u * x).detach() * D(u, y) * 0.1 + torch.detach(u) ** 2 * 0.05])
         conds = lambda: [C.NoCondition()]
         return System(name, 2, [(2, 1, (32, 32), "tanh")], [(-1.0, 1.0), (-1.0, 1.0)], pde, conds,
                       lambda D: [lambda net, x, y: net(_cat(x, y))])
