@@ -1417,7 +1417,32 @@ def _tf_xlog1py(a, b, **k):
     return _elementwise(lambda x, y: _where1(abs(x) > 0.0, x * _where1(abs(x) > 0.0, y, y * 0.0).log1p(), x * 0.0), a, b)
 
 
+def _tf_autograd_grad(outputs, inputs, grad_outputs=None, retain_graph=None, create_graph=False, only_inputs=True,
+                      allow_unused=None, is_grads_batched=False, materialize_grads=False):
+    """torch.autograd.grad on traced columns -- what `diff` wraps (neurodiffeq.py:21-34), written out by hand in user code.  Every
+    point's value depends on that point's coordinates only, so the vector-Jacobian product with ``grad_outputs`` is
+    grad_outputs * d output / d input, point by point; several outputs add up."""
+    if is_grads_batched:
+        raise TraceUnsupported("torch.autograd.grad(is_grads_batched=True) inside the traced region")
+    outs = list(outputs) if isinstance(outputs, (list, tuple)) else [outputs]
+    ins = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+    if grad_outputs is None:
+        raise TraceUnsupported("torch.autograd.grad of a per-point column without grad_outputs")
+    gos = list(grad_outputs) if isinstance(grad_outputs, (list, tuple)) else [grad_outputs]
+    if len(gos) != len(outs) or not all(isinstance(o, Sym) for o in outs) or not all(isinstance(i, Sym) for i in ins):
+        raise TraceUnsupported("torch.autograd.grad: traced (N, 1) columns with one grad_outputs entry per output")
+    res = []
+    for x in ins:
+        total = None
+        for o, go in zip(outs, gos):
+            term = sym_diff(o, x) * go
+            total = term if total is None else total + term
+        res.append(total)
+    return tuple(res)
+
+
 _TORCH_FUNCS = {
+    "grad": _tf_autograd_grad,
     "detach": _tf_map("detach"),
     "xlogy": _tf_xlogy, "xlog1py": _tf_xlog1py, "logit": _tf_elem(lambda c: (c / (1.0 - c)).log()), "expit": _tf_unary("sigmoid"),
     "floor": _tf_map("floor"), "ceil": _tf_map("ceil"), "trunc": _tf_map("trunc"), "fix": _tf_map("trunc"), "round": _tf_round,

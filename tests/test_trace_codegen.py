@@ -173,7 +173,7 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                # four / five inputs: 10 / 15 pair bits -- xx, yy, zz of (x, y, z, t) merged into one Laplacian stream; cc and ae
                "heat4d": [(1, 145, 1)], "mix5d": [(1, 528, 0)], "bundle_osc": [(1, 1, 0)],
                "piecewise_source": [(1, 5, 1)], "relu_ode": [(1, 0, 0)], "atan2_adv": [(1, 0, 0)],
-               "rounding_ode": [(1, 0, 0)], "activations_ode": [(1, 0, 0)], "special_2d": [(1, 0, 0)],
+               "rounding_ode": [(1, 0, 0)], "activations_ode": [(1, 0, 0)], "special_2d": [(1, 0, 0)], "autograd_grad_ode": [(1, 1, 0)],
                # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along
                "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)]}
 
@@ -205,7 +205,7 @@ def test_zoo_on_host_matches_autograd_oracle(name):
 
 @pytest.mark.parametrize("name", ["pendulum", "coupled_sin", "helmholtz_xy", "stokes_like", "sigmoid_mixed", "kdv", "shell",
                                   "bundle_bvp", "mono_laplace", "aptx_burgers", "piecewise_source", "relu_ode", "atan2_adv",
-                                  "rounding_ode", "activations_ode", "special_2d"])
+                                  "rounding_ode", "activations_ode", "special_2d", "autograd_grad_ode"])
 def test_zoo_fp64_build_on_host_matches_autograd_oracle(name):
     """The fp64 build of the generated pointwise code (codegen.source_f64: types, math calls and literal suffixes of the
     same traced program rewritten for double -- what FusedSystem(dtype=float64) compiles for gfx950) between the fp64

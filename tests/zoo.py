@@ -350,6 +350,17 @@ def build(name):
         conds = lambda: [C.NoCondition()]
         return System(name, 2, [(2, 1, (32, 32), "tanh")], [(-1.0, 1.0), (-1.0, 1.0)], pde, conds,
                       lambda D: [lambda net, x, y: net(_cat(x, y))])
+    if name == "autograd_grad_ode":   # derivatives taken with torch.autograd.grad by hand (what `diff` wraps), nested for the second order
+        def pde(D):
+            def f(u, t):
+                ones = torch.ones_like(u)
+                ut, = torch.autograd.grad(u, t, grad_outputs=ones, create_graph=True)
+                utt = torch.autograd.grad(ut, [t], [torch.ones_like(t)], create_graph=True)[0]
+                return [utt + 0.5 * ut + torch.sin(u) - torch.cos(t) + 0.1 * torch.autograd.grad([u, ut], t, [2.0 * ones, ones], create_graph=True)[0]]
+            return f
+        conds = lambda: [C.IVP(0.0, 1.0, u_0_prime=0.5)]
+        enf = lambda D: [lambda net, t: 1.0 + 0.5 * t + (1 - torch.exp(-t)) ** 2 * net(t)]
+        return System(name, 1, [(1, 1, (32, 32), "tanh")], [(0.0, 2.0)], pde, conds, enf)
     raise KeyError(name)
 
 
@@ -359,7 +370,7 @@ NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "he
          "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1",
          "swish_fixed_laplace", "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid",
          "mono_laplace", "mono_ode", "mono_poisson", "shape_32x6", "shape_16x8_sin", "heat4d", "mix5d", "bundle_osc",
-         "piecewise_source", "relu_ode", "atan2_adv", "rounding_ode", "activations_ode", "special_2d"]
+         "piecewise_source", "relu_ode", "atan2_adv", "rounding_ode", "activations_ode", "special_2d", "autograd_grad_ode"]
 
 
 def spherical_solver_problem():
