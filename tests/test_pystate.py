@@ -673,3 +673,82 @@ def test_an_incomplete_watch_re_probes_every_epoch_and_a_complete_one_does_not()
         assert s._equations_unchanged(sysm)
     assert sysm.program.calls == 1                                                # the second-use probe only
     assert not s._eq_watch_blocks_chunks()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# compositions: a coefficient behind a RANDOM access path (dict key / list index / tuple member / attribute / __slots__ member /
+# deque entry / closure cell), read by the equation through that path, then changed either at the leaf or by swapping a node
+# on the way -- the watch must come out dirty, or have said beforehand that it cannot see everything
+class _Slotted:
+    __slots__ = ("v",)
+
+
+def _random_path_case(seed):
+    import random
+    rng = random.Random(seed)
+    depth = rng.randint(1, 5)
+    kinds = [rng.choice(["dict", "list", "tuple", "attr", "slots", "deque"]) for _ in range(depth)]
+    leaf = {"value": 1.0}                                   # innermost mutable holder: the equation reads leaf["value"]
+    node, steps = leaf, ['["value"]']
+    holders = [leaf]
+    for k in reversed(kinds):
+        if k == "dict":
+            node, step = {"k": node, "other": 3}, '["k"]'
+        elif k == "list":
+            node, step = [0.0, node], "[1]"
+        elif k == "tuple":
+            node, step = (node, 2.0), "[0]"
+        elif k == "attr":
+            b = _Box()
+            b.child = node
+            node, step = b, ".child"
+        elif k == "slots":
+            s_ = _Slotted()
+            s_.v = node
+            node, step = s_, ".v"
+        else:
+            node, step = collections.deque([node, 5.0]), "[0]"
+        steps.insert(0, step)
+        holders.insert(0, node)
+    root = node
+    path = "".join(steps)
+    f = eval(f"lambda u, t: [u * root{path}]", {"root": root})       # noqa: S307 -- built from the fixed fragments above
+    how = rng.choice(["leaf", "swap"])
+
+    def mutate():
+        if how == "leaf" or len(holders) < 2:
+            leaf["value"] = 2.0
+            return
+        # replace a node on the path by an equal-looking copy holding a different value
+        i = rng.randrange(0, len(holders) - 1)
+        parent, k = holders[i], kinds[i]
+        import copy
+        new_child = copy.deepcopy(holders[i + 1])
+        probe = new_child
+        for st in steps[i + 1:-1]:
+            probe = eval("x" + st, {"x": probe})                      # noqa: S307
+        probe["value"] = 7.0
+        if k == "dict":
+            parent["k"] = new_child
+        elif k == "list":
+            parent[1] = new_child
+        elif k == "attr":
+            parent.child = new_child
+        elif k == "slots":
+            parent.v = new_child
+        elif k == "deque":
+            parent[0] = new_child
+        else:                                                        # a tuple cannot be changed: change the leaf instead
+            leaf["value"] = 2.0
+    return f, mutate, path, how
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_state_behind_a_random_access_path_is_seen_or_declared_unseen(seed):
+    f, mutate, path, how = _random_path_case(seed)
+    watch = StateWatch([f])
+    assert not watch.dirty(), path
+    assert float(f(1.0, 0.0)[0]) == 1.0
+    mutate()
+    assert float(f(1.0, 0.0)[0]) != 1.0, (path, how)              # (the change is visible to the equation ...)
+    assert watch.dirty() or not watch.complete, (path, how, watch.incomplete)      # ... so it must be visible to the watch
