@@ -112,7 +112,8 @@ def _crc(a):
 
 
 class StateWatch:
-    def __init__(self, roots, max_depth=6, max_items=64):
+    def __init__(self, roots, max_depth=6, max_items=64, skip_modules=()):
+        """skip_modules: the solver's own networks -- their parameters are kernel arguments, re-read every launch."""
         self.entries = []          # (expression template over O[...] / M, kind, payload)
         self.objs = []             # objects the expressions index: they stay alive, an id() can never come back as another object
         self.incomplete = []       # reasons the walk could not stamp everything the callables can read (fail-closed, module docstring)
@@ -121,9 +122,24 @@ class StateWatch:
         self._names = set()        # every name the walked code objects mention
         self._solver_seen = False
         self._trainable = []       # (expression, tensor) of requires_grad leaves: stamped by identity (their values are kernel arguments)
+        self._optimizers = []      # optimisers in reach: their hyper-parameters are state iff the code names them (below)
+        self._skip_modules = {id(m) for m in skip_modules}
         self.max_depth, self.max_items = max_depth, max_items
         for r in roots:
             self._visit(r, 0)
+        for opt in self._optimizers:
+            # `opt.param_groups[0]['lr']` read by the equations: the hyper-parameters of every group are stamped (a scheduler
+            # then makes the watch dirty every epoch: re-trace, value -> runtime constant).  The per-parameter STATE (Adam's
+            # moments, step counts: tensors the optimiser rewrites every step) cannot be stamped: incomplete
+            if self._names & {"param_groups", "defaults", "state_dict"}:
+                r = self._ref(opt)
+                self.entries.append(f"len({r}.param_groups) == {len(opt.param_groups)}")
+                for i, group in enumerate(opt.param_groups[:self.max_items]):
+                    for k, val in group.items():
+                        if k != "params":
+                            self._add(f"{r}.param_groups[{i}].get({k!r}, M)", val, 1)
+            if self._names & {"state", "state_dict"}:
+                self._fail("the equations name an optimiser's per-parameter state (rewritten by every step)")
         if self._solver_seen and self._names & SOLVER_BOOKKEEPING:
             self._fail("the equations name solver bookkeeping (" + ", ".join(sorted(self._names & SOLVER_BOOKKEEPING)) +
                        ") with a solver object in reach")
@@ -164,7 +180,7 @@ class StateWatch:
                 self.entries.append(f"({expr}) is {self._ref(value)}")
                 self._trainable.append((self._ref(value), value))
             else:
-                self.entries.append(f"((v := {expr}) is {self._ref(value)} and v._version == {value._version})")
+                self._tensor(expr, value)
             return
         try:
             import numpy as np
@@ -182,6 +198,34 @@ class StateWatch:
             pass
         self.entries.append(f"({expr}) is {self._ref(value)}")
         self._visit(value, depth + 1)
+
+    def _tensor(self, expr, t):
+        """A tensor that is not a trainable leaf: the equations read its VALUE (a one-element tensor is a literal of the
+        kernel).  The version counter misses the usual ways a callback changes one -- ``nu.data.mul_(0.7)``, ``nu.data =
+        ...``, writing through a ``.numpy()`` view or the ndarray the tensor was made from -- so small
+        tensors are stamped by CONTENT (as small ndarrays are), larger host tensors by CRC, and what is too large to read
+        every epoch makes the watch incomplete.  Per-point data columns ((N, 1), kernel INPUTS re-read every batch:
+        symbolic.Graph.datacol) are pinned by identity alone."""
+        r = self._ref(t)
+        try:
+            n, dev = t.numel(), t.device.type
+            if t.dim() == 2 and t.shape[1] == 1 and n > 1 and not t.requires_grad:
+                self.entries.append(f"(v := {expr}) is {r} and v.shape == {self._ref(t.shape)}")
+                return
+            if n <= 64 and t.layout == torch.strided:
+                # (a device tensor costs a synchronising copy per check: the price of reading a coefficient the way the
+                # reference does every batch; keep coefficients on the host or make them nn.Parameters to avoid it)
+                self.entries.append(f"((v := {expr}) is {r} and v.shape == {self._ref(t.shape)} and v.tolist() == {self._ref(t.tolist())})")
+                return
+            if dev == "cpu" and t.layout == torch.strided and n * t.element_size() <= _CRC_BYTES and \
+                    t.dtype in (torch.float32, torch.float64, torch.int64, torch.int32, torch.uint8, torch.bool, torch.int16, torch.int8):
+                crc = _crc(t.detach().numpy())
+                self.entries.append(f"((v := {expr}) is {r} and v.shape == {self._ref(t.shape)} and CRC(v.detach().numpy()) == {crc})")
+                return
+        except Exception:  # noqa: BLE001 -- a tensor subclass / layout that cannot be read: identity + version + said so
+            pass
+        self.entries.append(f"((v := {expr}) is {r} and v._version == {t._version})")
+        self._fail(f"a {t.device.type} tensor of {t.numel()} elements (dtype {t.dtype}) cannot be compared by content every epoch")
 
     def _visit(self, v, depth):
         try:
@@ -202,6 +246,20 @@ class StateWatch:
             self._seen.add(id(v))
             self._class(v, self._ref(v), depth)         # `class Cfg: nu = 0.1` used as a namespace
             return
+        if isinstance(v, torch.optim.Optimizer):
+            if id(v) not in self._seen:
+                self._seen.add(id(v))
+                self._optimizers.append(v)           # stamped once the walk knows which names the code mentions (_finish)
+            return
+        if isinstance(v, torch.nn.Module) and id(v) not in self._seen and id(v) not in self._skip_modules:
+            # a LIBRARY module (nn.BatchNorm1d, an FCNN that is not one of the solver's networks): its code is not user state,
+            # its numbers are -- `bn.eps`, `bn.running_mean`, a frozen weight the equations read
+            self._seen.add(id(v))
+            if depth > self.max_depth:
+                self._fail(f"state nested deeper than {self.max_depth} levels")
+            else:
+                self._torch_module(v, depth, methods=False)
+            return
         if id(v) in self._seen or _is_leaf(v) or isinstance(v, _OPAQUE):
             return                 # (tensors are stamped where they are referenced; modules are not state)
         if depth > self.max_depth:
@@ -218,6 +276,9 @@ class StateWatch:
             self._visit(v.func, depth)
             self._add(f"{self._ref(v)}.args", v.args, depth)
             self._add(f"{self._ref(v)}.keywords", v.keywords, depth)
+            for name, value in list((getattr(v, "__dict__", None) or {}).items()):
+                if name.isidentifier():
+                    self._add(f"getattr({self._ref(v)}, {name!r}, M)", value, depth)
         elif isinstance(v, dict):
             r = self._ref(v)
             self.entries.append(f"len({r}) == {len(v)}")
@@ -240,7 +301,9 @@ class StateWatch:
             # mutable members are state
             if len(v) <= self.max_items:
                 for i in range(len(v)):
-                    if not _is_leaf(v[i]) and not isinstance(v[i], _OPAQUE):
+                    if isinstance(v[i], (torch.Tensor, torch.nn.Module, torch.optim.Optimizer)):
+                        self._add(f"{self._ref(v)}[{i}]", v[i], depth)      # (a tensor's CONTENT is state wherever it sits)
+                    elif not _is_leaf(v[i]) and not isinstance(v[i], _OPAQUE):
                         self._visit(v[i], depth + 1)
             elif not all(_is_leaf(x) for x in v):
                 self._fail(f"a tuple of {len(v)} items (more than {self.max_items})")
@@ -285,6 +348,12 @@ class StateWatch:
             names.update(co.co_names)
             codes.extend(c for c in co.co_consts if isinstance(c, types.CodeType))
         self._names |= names
+        for name, value in list(vars(fn).items()):           # function attributes: `eq.nu = 0.1; def eq(u, t): return eq.nu * u`
+            if name != "__wrapped__" and name.isidentifier():
+                self._add(f"getattr({self._ref(fn)}, {name!r}, M)", value, depth)
+        wrapped = vars(fn).get("__wrapped__")
+        if wrapped is not None:
+            self._visit(wrapped, depth)
         g = fn.__globals__
         hot = sorted(n for n in names & _IMPURE_BUILTINS if n not in g and n not in fn.__code__.co_varnames)
         if hot:
@@ -333,7 +402,7 @@ class StateWatch:
                     continue
                 self._add(f"getattr({r}, {name!r}, M)", value, depth)
 
-    def _torch_module(self, m, depth):
+    def _torch_module(self, m, depth, methods=True):
         """A user's own torch.nn.Module the callables reach (an operator object used as ``diff_eqs``, a coefficient model
         in a closure): its buffers and parameters (tensors: identity + version, trainable leaves by identity), its plain
         attributes, its submodules, and the methods of its class."""
@@ -353,15 +422,16 @@ class StateWatch:
                 if depth + 1 > self.max_depth:
                     self._fail(f"state nested deeper than {self.max_depth} levels")
                 else:
-                    self._torch_module(child, depth + 1)
+                    self._torch_module(child, depth + 1, methods and _root(type(child).__module__) not in _LIBRARY_ROOTS)
         for name, value in list(d.items()):
             if name in _MODULE_INTERNALS or not name.isidentifier():
                 continue
             self._add(f"getattr({r}, {name!r}, M)", value, depth)
-        self._class(type(m), r, depth, skip=set(d))
+        if methods:
+            self._class(type(m), r, depth, skip=set(d))
 
     def _object(self, obj, depth):
-        if isinstance(obj, torch.nn.Module) and _root(type(obj).__module__) not in _LIBRARY_ROOTS:
+        if isinstance(obj, (torch.nn.Module, torch.optim.Optimizer)):
             return self._visit(obj, depth)
         if isinstance(obj, _OPAQUE) or _is_leaf(obj):
             return

@@ -32,7 +32,7 @@ def _boundary_column(x, value):
     leaf tensor (conditions.py:577-579), or -- while tracing -- a virtual coordinate of the graph, which makes the
     network call on it a further evaluation site of the same parameters."""
     if isinstance(x, Sym):
-        return Sym(x.g, x.g.vcoord(value))
+        return Sym(x.g, x.g.vcoord(value), leaf=True)
     return value * torch.ones_like(x, requires_grad=True)
 
 

@@ -114,13 +114,14 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     if any(i is None for i in infos):
         raise TraceUnsupported("a network is not an FCNN the gfx950 kernels support")
     g = Graph(n_coords)
+    g.f64 = bool(f64)                # (Sym.dtype: constants made "like" a traced column keep the kernels' precision)
     g.volatile = frozenset() if f64 else frozenset(volatile)      # (the fp64 pipeline has no scalar arguments)
     if f64 and any(i.get("skip_sym") is not None for i in infos):
         raise TraceUnsupported("a skip connection above 64 hidden units on the fp64 pipeline (its weights are kernel arguments: fp32 only)")
     g.register_nets(nets, [i["n_out"] for i in infos], skips=[i.get("skip_sym") for i in infos])
     cfv = compute_func_val or (lambda net, cond, *coords: cond.enforce(net, *coords))
     with trace_scope(g):
-        coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
+        coords = [Sym(g, g.coord(i), leaf=True) for i in range(n_coords)]
         funcs = [cfv(n, c, *coords) for n, c in zip(all_nets, conditions)]
         res = diff_eqs(*funcs, *coords) if diff_eqs is not None else []     # None: evaluation of the functions only
         if isinstance(res, Sym):

@@ -232,7 +232,9 @@ class BatchSharding:
             # (unset: under a process group that is NOT nccl -- the single-device dry runs and tests over gloo, where RCCL
             # cannot run at all -- the one-shot exchange stays the choice)
             choice = os.environ.get("NDQ_ONESHOT_ALLREDUCE")
-            want_oneshot = choice == "1" or (choice is None and dist.get_backend(self.group) != "nccl")
+            # (asked only with a process group on a GPU: a BatchSharding built from an explicit rank / world_size without one,
+            # or on the CPU, answers None -- ADVICE r5)
+            want_oneshot = on_gpu and (choice == "1" or (choice is None and dist.get_backend(self.group) != "nccl"))
             if on_gpu and want_oneshot and 1 < self.world_size <= 16:
                 one = OneShot(self.rank, self.world_size, self.group, device)
                 if one.ok:

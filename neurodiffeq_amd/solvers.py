@@ -385,13 +385,14 @@ class BaseSolver(ABC):
             sysm = self._fused_sys
             # scalar tensors captured by the equations are constants of the generated kernel: re-trace when one of them
             # was modified in place since (callbacks annealing a coefficient between epochs)
-            if sysm is not None and not all(t._version == v for t, v in sysm.program.g.captured):
+            from .symbolic import captured_unchanged
+            if sysm is not None and not captured_unchanged(sysm.program.g):
                 if self._equations_unchanged(sysm, force=True):
                     # same program: every tensor that moved is a runtime constant by now and the re-trace refreshed its value
-                    sysm.program.g.captured[:] = [(t, t._version) for t, _ in sysm.program.g.captured]
+                    sysm.program.g.captured[:] = [(t, t._version, t.item()) for t, _, _ in sysm.program.g.captured]
                 else:
                     self._note_volatile(sysm)
-            if sysm is None or all(t._version == v for t, v in sysm.program.g.captured):
+            if sysm is None or captured_unchanged(sysm.program.g):
                 # a traced loss_fn / additional_loss is frozen into the generated kernel; callables that follow solver
                 # state (a penalty weight annealed with self.global_epoch, ...) are re-probed on their second use and
                 # then every LOSS_PROBE_EVERY epochs: if they now trace to a different term, the solver leaves the fused
@@ -519,7 +520,7 @@ class BaseSolver(ABC):
     def _new_state_watch(self):
         from ._pystate import StateWatch
         try:
-            return StateWatch([self.diff_eqs, self.compute_func_val] + list(self.conditions))
+            return StateWatch([self.diff_eqs, self.compute_func_val] + list(self.conditions), skip_modules=self.nets)
         except Exception as e:       # noqa: BLE001 -- an object the walk cannot read: no watch = re-trace every epoch (slow, never stale)
             if not self.__dict__.get("_eq_watch_warned"):
                 self._eq_watch_warned = True

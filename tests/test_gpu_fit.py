@@ -420,6 +420,50 @@ def test_python_state_ramped_by_a_callback_reaches_the_fused_kernels(golden_dir)
     assert float(np.max(np.abs(hist2 - gold["traj_loss"]) / np.abs(gold["traj_loss"]))) < 2e-5, (hist2, gold["traj_loss"])
 
 
+@pytest.mark.parametrize("where", ["cpu", "cuda"])
+def test_a_coefficient_tensor_changed_through_data_reaches_the_fused_kernels(golden_dir, where):
+    """the viscosity is a one-element TENSOR and the callback edits it through ``.data``
+    (``nu.data.mul_(0.7)``), which does not bump the version counter.  The reference re-reads the tensor every batch
+    (solvers.py:380); the state watch stamps small tensors by CONTENT (host and device), so the equations are re-traced, the
+    value becomes a runtime constant after the first rebuild, and loss history / final parameters equal the unmodified
+    reference's run with the same callback (tests/golden/make_golden.py: make_ramp_data)."""
+    import os
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IBVP1D
+    from neurodiffeq_amd.generators import Generator2D
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.solvers import Solver2D
+    gold = np.load(os.path.join(golden_dir, "ramp_data.npz"))
+    frozen = np.load(os.path.join(golden_dir, "ramp.npz"))["frozen_loss"]
+    torch.manual_seed(int(gold["seed"]))
+    nu = torch.tensor(0.05, device=where)
+    pde = lambda u, x, t: [diff(u, t) + u * diff(u, x) - nu * diff(u, x, order=2)]
+    nets = [FCNN(2, 1, hidden_units=(32, 32))]
+    conds = [IBVP1D(x_min=-1, x_max=1, t_min=0, t_min_val=lambda x: -torch.sin(np.pi * x), x_min_val=lambda t: 0, x_max_val=lambda t: 0)]
+    solver = Solver2D(pde, conds, xy_min=(-1, 0), xy_max=(1, 1), nets=nets,
+                      train_generator=Generator2D((12, 12), (-1, 0), (1, 1), "equally-spaced-noisy"),
+                      valid_generator=Generator2D((8, 8), (-1, 0), (1, 1), "equally-spaced"))
+    solver.fused = "require"
+    assert np.array_equal(R.get_flat(nets).cpu().numpy(), gold["params0"])
+    systems, versions = [], []
+
+    def ramp(s):
+        nu.data.mul_(0.7)
+        systems.append(s._fused_sys)
+        versions.append(nu._version)
+    torch.manual_seed(int(gold["seed"]) + 2)
+    solver.fit(max_epochs=6, callbacks=[ramp], tqdm_file=None)
+    assert len(set(versions)) == 1 and solver._eq_watch.complete, solver._eq_watch.incomplete
+    assert solver.fused_active and abs(nu.item() - float(gold["nu_final"])) < 1e-9
+    assert len({id(x) for x in systems}) == 2 and systems[-1].theta_frozen       # one rebuild, then argument updates
+    hist, valid = np.array(solver.metrics_history["train_loss"]), np.array(solver.metrics_history["valid_loss"])
+    err = dict(loss=float(np.max(np.abs(hist - gold["traj_loss"]) / np.abs(gold["traj_loss"]))),
+               valid=float(np.max(np.abs(valid - gold["traj_valid"]) / np.abs(gold["traj_valid"]))),
+               params=float(np.linalg.norm(R.get_flat(nets).cpu().numpy() - gold["traj_params"]) / np.linalg.norm(gold["traj_params"])))
+    assert err["loss"] < 2e-5 and err["valid"] < 2e-5 and err["params"] < 1e-5, (err, hist, gold["traj_loss"])
+    assert np.max(np.abs(hist - frozen) / frozen) > 1e-2                         # ... and not the frozen equations
+
+
 def test_equations_following_solver_local_epoch_train_on_the_current_value_every_epoch(golden_dir):
     """``diff_eqs`` reads ``solver.local_epoch`` through a captured solver -- the curriculum
     idiom; the fit loop advances the counter itself (solvers.py:443-497), nothing a state watch could stamp.  The watch is

@@ -114,6 +114,15 @@ def test_bounds_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_sharding_without_a_process_group_has_no_native_all_reduce():
+    """a BatchSharding built from an explicit rank / world size with no process group initialised answers
+    "torch.distributed" / None instead of raising out of dist.get_backend()."""
+    assert not dist.is_initialized()
+    sh = BatchSharding(rank=0, world_size=2)
+    assert sh.direct("cpu") is None and sh.direct("cuda") is None
+    assert sh.allreduce_kind("cuda") == "torch.distributed"
+
+
 def _agree_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

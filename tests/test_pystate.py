@@ -752,3 +752,225 @@ def test_state_behind_a_random_access_path_is_seen_or_declared_unseen(seed):
     mutate()
     assert float(f(1.0, 0.0)[0]) != 1.0, (path, how)              # (the change is visible to the equation ...)
     assert watch.dirty() or not watch.complete, (path, how, watch.incomplete)      # ... so it must be visible to the watch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 6: state the version counter does not see -- tensors changed through `.data`, through a
+# numpy view or the ndarray they share storage with; optimiser hyper-parameters; numbers of library modules; function attributes
+def _tensor_data_mul():
+    nu = torch.tensor(1.0)
+    return (lambda u, t: [u * nu]), (lambda: nu.data.mul_(0.5))
+
+
+def _tensor_data_assigned():
+    nu = torch.tensor(1.0)
+
+    def m():
+        nu.data = torch.tensor(0.25)
+    return (lambda u, t: [u * nu]), m
+
+
+def _tensor_data_fill():
+    nu = torch.tensor([1.0])
+    return (lambda u, t: [u * nu]), (lambda: nu.data.fill_(3.0))
+
+
+def _tensor_through_numpy_view():
+    nu = torch.tensor([1.0, 2.0])
+    view = nu.numpy()
+
+    def m():
+        view[1] = 5.0
+    return (lambda u, t: [u * nu[1]]), m
+
+
+def _tensor_sharing_an_ndarray():
+    base = np.array([1.0, 2.0, 3.0])
+    nu = torch.from_numpy(base)
+
+    def m():
+        base[0] = 9.0
+    return (lambda u, t: [u * nu[0]]), m
+
+
+def _frozen_parameter_through_data():
+    k = torch.nn.Parameter(torch.tensor(1.0), requires_grad=False)
+    return (lambda u, t: [u * k]), (lambda: k.data.mul_(2.0))
+
+
+def _larger_tensor_through_data():
+    table = torch.linspace(0.0, 1.0, 1000)
+    return (lambda u, t: [u * table[17]]), (lambda: table.data.mul_(2.0))
+
+
+def _optimizer_learning_rate():
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([p], lr=0.1)
+
+    def m():
+        opt.param_groups[0]["lr"] = 0.05
+    return (lambda u, t: [u * opt.param_groups[0]["lr"]]), m
+
+
+def _library_module_attribute():
+    bn = torch.nn.BatchNorm1d(1)
+
+    def m():
+        bn.eps = 1e-3
+    return (lambda u, t: [u * bn.eps]), m
+
+
+def _library_module_buffer():
+    bn = torch.nn.BatchNorm1d(1)
+    return (lambda u, t: [u * bn.running_var]), (lambda: bn.running_var.data.mul_(2.0))
+
+
+def _library_module_frozen_weight():
+    lin = torch.nn.Linear(1, 1)
+    lin.weight.requires_grad_(False)
+    return (lambda u, t: [u * lin.weight]), (lambda: lin.weight.data.add_(1.0))
+
+
+def _function_attribute():
+    def eq(u, t):
+        return [eq.nu * u]
+    eq.nu = 0.1
+
+    def m():
+        eq.nu = 0.2
+    return eq, m
+
+
+def _function_attribute_holder():
+    def eq(u, t):
+        return [eq.cfg["nu"] * u]
+    eq.cfg = {"nu": 0.1}
+    return eq, (lambda: eq.cfg.__setitem__("nu", 0.2))
+
+
+def _attribute_of_a_partial():
+    def eq(scale, u, t):
+        return [scale * u]
+    p = functools.partial(eq, 2.0)
+    p.note = 1.0
+
+    def m():
+        p.note = 2.0
+    return p, m
+
+
+def _bound_method_of_a_library_module():
+    bn = torch.nn.BatchNorm1d(1)
+
+    class Eq:
+        def __init__(self):
+            self.bn = bn
+
+        def __call__(self, u, t):
+            return [u * self.bn.momentum]
+    e = Eq()
+
+    def m():
+        bn.momentum = 0.5
+    return e, m
+
+
+ROUND6 = [_tensor_data_mul, _tensor_data_assigned, _tensor_data_fill, _tensor_through_numpy_view, _tensor_sharing_an_ndarray,
+          _frozen_parameter_through_data, _larger_tensor_through_data, _optimizer_learning_rate, _library_module_attribute,
+          _library_module_buffer, _library_module_frozen_weight, _function_attribute, _function_attribute_holder,
+          _attribute_of_a_partial, _bound_method_of_a_library_module]
+
+
+@pytest.mark.parametrize("make", ROUND6, ids=[c.__name__.strip("_") for c in ROUND6])
+def test_state_the_version_counter_does_not_see(make):
+    f, mutate = make()
+    watch = StateWatch([f])
+    assert len(watch) > 0 and watch.complete, watch.incomplete
+    assert not watch.dirty() and not watch.dirty()
+    mutate()
+    assert watch.dirty()
+
+
+def test_optimizer_state_and_unreadable_tensors_fail_closed():
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.Adam([p], lr=0.1)
+    w = StateWatch([lambda u, t: [u * opt.state[p]["step"]]])
+    assert not w.complete and "per-parameter state" in w.incomplete[0]
+    # an optimiser in reach whose hyper-parameters the code does not name costs nothing and stays complete
+    w = StateWatch([lambda u, t: [u + (0.0 if opt is None else 1.0)]])
+    assert w.complete and not w.dirty()
+    opt.param_groups[0]["lr"] = 0.5
+    assert not w.dirty()
+    big = torch.zeros(1 << 16)
+    w = StateWatch([lambda u, t: [u * big[3]]])
+    assert not w.complete and "cannot be compared by content" in w.incomplete[0]
+
+
+def test_data_columns_and_the_solvers_networks_stay_cheap():
+    """An (N, 1) column of per-point data is a kernel INPUT, re-read every batch (symbolic.Graph.datacol): identity only;
+    the solver's own networks are kernel arguments: not walked at all."""
+    col = torch.rand(5000, 1)
+    w = StateWatch([lambda u, t: [u - col]])
+    assert w.complete and len(w) <= 2
+    col.data.mul_(2.0)
+    assert not w.dirty()
+    net = torch.nn.Linear(1, 1)
+    w = StateWatch([lambda u, t: [u * (net is not None)]], skip_modules=[net])
+    assert w.complete and len(w) <= 1
+    net.weight.data.add_(1.0)
+    assert not w.dirty()
+
+
+def _random_tensor_path_case(seed):
+    """tests' random access paths with a TENSOR leaf mutated the ways a version counter misses."""
+    import random
+    rng = random.Random(5000 + seed)
+    leaf = torch.tensor([1.0, 2.0]) if rng.random() < 0.5 else torch.tensor(1.0)
+    index = "[0]" if leaf.dim() else ""
+    node, steps = leaf, []
+    for _ in range(rng.randint(1, 4)):
+        k = rng.choice(["dict", "list", "tuple", "attr", "slots", "deque"])
+        if k == "dict":
+            node, step = {"k": node, "other": 3}, '["k"]'
+        elif k == "list":
+            node, step = [0.0, node], "[1]"
+        elif k == "tuple":
+            node, step = (node, 2.0), "[0]"
+        elif k == "attr":
+            b = _Box()
+            b.child = node
+            node, step = b, ".child"
+        elif k == "slots":
+            s_ = _Slotted()
+            s_.v = node
+            node, step = s_, ".v"
+        else:
+            node, step = collections.deque([node, 5.0]), "[0]"
+        steps.insert(0, step)
+    path = "".join(steps) + index
+    f = eval(f"lambda u, t: [u * root{path}]", {"root": node})       # noqa: S307 -- built from the fixed fragments above
+    how = rng.choice(["data_mul", "data_fill", "data_assign", "numpy_view", "in_place"])
+
+    def mutate():
+        if how == "data_mul":
+            leaf.data.mul_(0.5)
+        elif how == "data_fill":
+            leaf.data.fill_(7.0)
+        elif how == "data_assign":
+            leaf.data = leaf.data * 3.0
+        elif how == "numpy_view":
+            leaf.numpy()[...] = 4.0
+        else:
+            leaf.mul_(0.25)
+    return f, mutate, path, how
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_tensor_leaf_behind_a_random_access_path_changed_through_data(seed):
+    f, mutate, path, how = _random_tensor_path_case(seed)
+    watch = StateWatch([f])
+    assert watch.complete and not watch.dirty(), (path, watch.incomplete)
+    assert float(f(1.0, 0.0)[0]) == 1.0
+    mutate()
+    assert float(f(1.0, 0.0)[0]) != 1.0, (path, how)
+    assert watch.dirty(), (path, how)

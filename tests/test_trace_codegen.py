@@ -30,7 +30,7 @@ def trace(nets, conds, pde, n_coords, lap=True, cfv=None, loss="l2", metrics=())
     cfv = cfv or (lambda net, cond, *coords: cond.enforce(net, *coords))
     term, mterms = None, []
     with trace_scope(g):
-        coords = [Sym(g, g.coord(i)) for i in range(n_coords)]
+        coords = [Sym(g, g.coord(i), leaf=True) for i in range(n_coords)]
         funcs = [cfv(n, c, *coords) for n, c in zip(nets, conds)]
         res = pde(*funcs, *coords)
         if callable(loss):              # custom loss_fn(residual, funcs, coords) -> batch mean (engine.trace_system)
@@ -350,7 +350,7 @@ def test_unsupported_constructs_raise_trace_unsupported():
     from neurodiffeq_amd.symbolic import TraceUnsupported
     g = Graph(1)
     with trace_scope(g):
-        t = Sym(g, g.coord(0))
+        t = Sym(g, g.coord(0), leaf=True)
         with pytest.raises(TraceUnsupported):
             torch.cumsum(t, 0)
         with pytest.raises(TraceUnsupported):
@@ -365,7 +365,13 @@ def test_unsupported_constructs_raise_trace_unsupported():
             with pytest.raises(TraceUnsupported):
                 bad()
         # ... and the spellings of "the whole column" / one-element constants that are inside it
-        assert t[:, 0:1] is t and t[...] is t and t[:, :] is t and t.expand_as(t) is t and t.contiguous() is t
+        # (views are NEW tensors in torch: the same node, but not the coordinate itself as a diff() target -- round 6)
+        assert t[:, 0:1].i == t.i and t[...].i == t.i and t[:, :].i == t.i and t.expand_as(t).i == t.i and t.contiguous() is t
+        assert t.leaf and not t[...].leaf and not t.clone().leaf and not (t + 0.0).leaf and not t.view(-1, 1).leaf
+        for derived in (t + 0.0, t * 1.0, t.clone(), t.view(-1, 1), t[:, 0:1], t.reshape(t.shape[0], 1)):
+            assert derived.i == t.i
+            with pytest.raises(TraceUnsupported, match="derived from a batch coordinate"):
+                diff(t * t, derived)
         assert float(t.new_ones(1)) == 1.0 and float(t.new_zeros(1, 1)) == 0.0 and float(t.new_tensor(2.5)) == 2.5
         assert t.dtype == torch.get_default_dtype() and t.floor().i != t.i and torch.frac(t).i == (t - torch.trunc(t)).i
         assert g.cval(diff(torch.floor(t) * 2.0, t).i) == 0.0        # piecewise constant: zero derivative
@@ -398,7 +404,13 @@ def test_trainable_and_per_point_tensors_are_not_baked_into_the_kernel():
         trace_system([net], [cond], lambda u, t: [torch.cat([u, u], dim=1)], 1)
     c = torch.tensor(3.0)
     prog, _ = trace_system([net], [cond], lambda u, t: [diff(u, t) + c * u], 1)
-    assert [(t is c, v) for t, v in prog.g.captured] == [(True, c._version)]
+    assert [(t is c, v, val) for t, v, val in prog.g.captured] == [(True, c._version, c.item())]
+    from neurodiffeq_amd.symbolic import captured_unchanged
+    assert captured_unchanged(prog.g)
+    c.data.mul_(0.5)                                 # (no version bump: seen by value)
+    assert not captured_unchanged(prog.g)
+    c.data.mul_(2.0)
+    assert captured_unchanged(prog.g)
     c.mul_(2.0)
     assert prog.g.captured[0][1] != c._version
 
