@@ -265,6 +265,41 @@ constexpr bool act_has_s4(int act) {
 // went through the bf16 matrix core.  The route of round 3 (Cfg::WG_TR / WG_TR64) transposes the bf16 PLANES through
 // LDS (ds_read_b64_tr_b16: exact) and passes the gradient goldens at the level of the f32 MFMA route (1e-7 ... 6e-6,
 // incl. the trained states of tests/golden/c2_trained.npz, c3_trained.npz).
+// Experiments (profiles/r06_headline_ab.md): how many of the bf16 partial products of a "weights (planes a0, a1, a2) x
+// per-point operand (planes 0, 1, 2)" GEMM are issued -- the forward `z = W h` and the reverse `hbar = W^T zbar` GEMMs only; the
+// weight-gradient GEMMs, which sum over points with cancellation, always take all six.  6 = bf16x3 (fp32 class, the default);
+// 5 drops a0 x plane 2 (the per-point operand is then exact to 2^-18 instead of 2^-27), 4 drops a1 x plane 1 as well, 3 is
+// "bf16x2": hi*hi + hi*lo + lo*hi.  Smallest products first.
+#ifndef NDQ_BF16_NPROD
+#define NDQ_BF16_NPROD 6
+#endif
+#if NDQ_BF16_NPROD == 6
+#define NDQ_PRODUCTS(T) T(a1, 1) T(a2, 0) T(a0, 2) T(a1, 0) T(a0, 1) T(a0, 0)
+#elif NDQ_BF16_NPROD == 5
+#define NDQ_PRODUCTS(T) T(a1, 1) T(a2, 0) T(a1, 0) T(a0, 1) T(a0, 0)
+#elif NDQ_BF16_NPROD == 4
+#define NDQ_PRODUCTS(T) T(a2, 0) T(a1, 0) T(a0, 1) T(a0, 0)
+#elif NDQ_BF16_NPROD == 3
+#define NDQ_PRODUCTS(T) T(a1, 0) T(a0, 1) T(a0, 0)
+#else
+#error "NDQ_BF16_NPROD must be 3, 4, 5 or 6"
+#endif
+// ... and of the weight-gradient GEMMs dW = sum over points of Zbar (planes I) x H (planes J): 6 (default), 4 (no third planes)
+// or 3.  With NDQ_BF16_NPROD < 6 and NDQ_WG_NPROD < 6 nobody reads the third plane of a per-point operand: split3 makes two
+// planes (NDQ_PT_PLANES), a third less splitting work and LDS traffic of the transposed images.
+#ifndef NDQ_WG_NPROD
+#define NDQ_WG_NPROD 6
+#endif
+#if NDQ_WG_NPROD == 6
+#define NDQ_WPRODUCTS(W) W(1, 1) W(2, 0) W(0, 2) W(1, 0) W(0, 1) W(0, 0)
+#elif NDQ_WG_NPROD == 4
+#define NDQ_WPRODUCTS(W) W(1, 1) W(1, 0) W(0, 1) W(0, 0)
+#elif NDQ_WG_NPROD == 3
+#define NDQ_WPRODUCTS(W) W(1, 0) W(0, 1) W(0, 0)
+#else
+#error "NDQ_WG_NPROD must be 3, 4 or 6"
+#endif
+#define NDQ_PT_PLANES ((NDQ_BF16_NPROD == 6 || NDQ_WG_NPROD == 6) ? 3 : 2)
 #ifndef NDQ_WIDE_LOWREG
 #define NDQ_WIDE_LOWREG 1
 #endif
@@ -1175,8 +1210,8 @@ __device__ __forceinline__ void split3(const real4 a, const real4 b, bf16x8 (&pl
     const __bf16 h0 = (__bf16)x[e];
     const real r1 = x[e] - (real)h0;
     const __bf16 h1 = (__bf16)r1;
-    const __bf16 h2 = (__bf16)(r1 - (real)h1);
-    pl[0][e] = h0; pl[1][e] = h1; pl[2][e] = h2;
+    pl[0][e] = h0; pl[1][e] = h1;
+    if constexpr (NDQ_PT_PLANES == 3) pl[2][e] = (__bf16)(r1 - (real)h1);
   }
 #endif
 }
@@ -1216,7 +1251,7 @@ __device__ __forceinline__ void gemm_planes(const real* __restrict__ wl, int lan
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
       z[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, P.pl[s][c][K], z[s][ob], 0, 0, 0);
-      NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+      NDQ_PRODUCTS(NDQ_T)
 #undef NDQ_T
     }
 }
@@ -1249,7 +1284,7 @@ __device__ __forceinline__ void gemm_bf16x3_inplace(const real* __restrict__ wl,
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
       o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], o[s][ob], 0, 0, 0);
-          NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+          NDQ_PRODUCTS(NDQ_T)
 #undef NDQ_T
         }
 #pragma unroll
@@ -1532,7 +1567,7 @@ __device__ __forceinline__ void output_layer_mfma(const real* lds, int lane, int
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
       o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, P.pl[s][c][K], o[s][ob], 0, 0, 0);
-        NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+        NDQ_PRODUCTS(NDQ_T)
 #undef NDQ_T
       }
     return;
@@ -1608,7 +1643,7 @@ __device__ __forceinline__ void hidden_layer_grouped(const real* lds, int l, int
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
       z[s0 + s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], z[s0 + s][ob], 0, 0, 0);
-        NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+        NDQ_PRODUCTS(NDQ_T)
 #undef NDQ_T
       }
   });
@@ -1634,7 +1669,7 @@ __device__ __forceinline__ int tr_slot(int row, int chunk) { return chunk * 64 +
 template <class C>
 __device__ __forceinline__ void tr_store(real* img, int woff, const bf16x8 (&pl)[3]) {     // woff = tr_slot(p, q)
 #pragma unroll
-  for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(img + k * C::trPlane + woff) = pl[k];
+  for (int k = 0; k < NDQ_PT_PLANES; ++k) *reinterpret_cast<bf16x8*>(img + k * C::trPlane + woff) = pl[k];
 }
 // 8 contraction slots of one lane: two transposing reads (4 points each) of the same unit
 __device__ __forceinline__ bf16x8 tr_read8(const real* a0, const real* a1) {
@@ -1873,7 +1908,7 @@ __device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q,
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #define NDQ_W(I, J) acc32[jb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[I], pb[kb][J], acc32[jb][kb], 0, 0, 0);
-          NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+          NDQ_WPRODUCTS(NDQ_W)
 #undef NDQ_W
         }
       }
@@ -1911,7 +1946,7 @@ __device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q,
 #pragma unroll
         for (int kb = 0; kb < C::NB; ++kb) {
 #define NDQ_W(I, J) acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[I], pb[kb][J], acc[jb][kb], 0, 0, 0);
-          NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+          NDQ_WPRODUCTS(NDQ_W)
 #undef NDQ_W
         }
       }
@@ -2007,7 +2042,7 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pb[kb][k] = tr_read8(hr + k * PL + kb * 2 + r0, hr + k * PL + kb * 2 + r1);
+        for (int k = 0; k < NDQ_PT_PLANES; ++k) pb[kb][k] = tr_read8(hr + k * PL + kb * 2 + r0, hr + k * PL + kb * 2 + r1);
     };
     if constexpr ((NDQ_ABL & 1) == 0 && ROOMY) read_h();
     {
@@ -2039,7 +2074,7 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
 #pragma unroll
         for (int jb = 0; jb < (ROOMY ? 2 : 1); ++jb)
 #pragma unroll
-          for (int k = 0; k < 3; ++k) pa[jb][k] = tr_read8(zr + k * PL + jb * 2 + r0, zr + k * PL + jb * 2 + r1);
+          for (int k = 0; k < NDQ_PT_PLANES; ++k) pa[jb][k] = tr_read8(zr + k * PL + jb * 2 + r0, zr + k * PL + jb * 2 + r1);
       }
       if constexpr ((NDQ_ABL & 2) == 0) {
 #pragma unroll
@@ -2050,7 +2085,7 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
       o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][K], o[s][ob], 0, 0, 0);
-          NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+          NDQ_PRODUCTS(NDQ_T)
 #undef NDQ_T
         }
       }
@@ -2061,19 +2096,19 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
 #define NDQ_W(I, J)                                                                                          \
   _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)          \
       acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[jb][I], pb[kb][J], acc[jb][kb], 0, 0, 0);
-        NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+        NDQ_WPRODUCTS(NDQ_W)
 #undef NDQ_W
       } else if constexpr ((NDQ_ABL & 1) == 0) {
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
           if (jb == 1) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) pa[0][k] = tr_read8(zr + k * PL + 2 + r0, zr + k * PL + 2 + r1);
+            for (int k = 0; k < NDQ_PT_PLANES; ++k) pa[0][k] = tr_read8(zr + k * PL + 2 + r0, zr + k * PL + 2 + r1);
           }
 #define NDQ_W(I, J)                                                                                          \
   _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                           \
       acc[jb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[0][I], pb[kb][J], acc[jb][kb], 0, 0, 0);
-          NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+          NDQ_WPRODUCTS(NDQ_W)
 #undef NDQ_W
         }
       }
@@ -2114,7 +2149,7 @@ __device__ __forceinline__ void hbar_wgrad_tr64(const real* __restrict__ wl, rea
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(zimg + k * PL + c * 256 + woff) = pl[s][c][k];
+          for (int k = 0; k < NDQ_PT_PLANES; ++k) *reinterpret_cast<bf16x8*>(zimg + k * PL + c * 256 + woff) = pl[s][c][k];
         {
           real4 hs[C::NB];
           act_forward_stream<C, s0 + s>(st_in, hs);
@@ -2123,7 +2158,7 @@ __device__ __forceinline__ void hbar_wgrad_tr64(const real* __restrict__ wl, rea
             bf16x8 ph[3];
             split3(hs[2 * c], hs[2 * c + 1], ph);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(himg + k * PL + c * 256 + woff) = ph[k];
+            for (int k = 0; k < NDQ_PT_PLANES; ++k) *reinterpret_cast<bf16x8*>(himg + k * PL + c * 256 + woff) = ph[k];
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2133,16 +2168,16 @@ __device__ __forceinline__ void hbar_wgrad_tr64(const real* __restrict__ wl, rea
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int k = 0; k < 3; ++k) pb[kb][k] = tr_read8(himg + k * PL + kb * 256 + r0, himg + k * PL + kb * 256 + r1);
+          for (int k = 0; k < NDQ_PT_PLANES; ++k) pb[kb][k] = tr_read8(himg + k * PL + kb * 256 + r0, himg + k * PL + kb * 256 + r1);
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
           bf16x8 pa[3];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) pa[k] = tr_read8(zimg + k * PL + jb * 256 + r0, zimg + k * PL + jb * 256 + r1);
+          for (int k = 0; k < NDQ_PT_PLANES; ++k) pa[k] = tr_read8(zimg + k * PL + jb * 256 + r0, zimg + k * PL + jb * 256 + r1);
 #define NDQ_W(I, J)                                                                                          \
   _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                           \
       acc32[jb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[I], pb[kb][J], acc32[jb][kb], 0, 0, 0);
-          NDQ_W(1, 1) NDQ_W(2, 0) NDQ_W(0, 2) NDQ_W(1, 0) NDQ_W(0, 1) NDQ_W(0, 0)
+          NDQ_WPRODUCTS(NDQ_W)
 #undef NDQ_W
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2166,7 +2201,7 @@ __device__ __forceinline__ void hbar_wgrad_tr64(const real* __restrict__ wl, rea
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
       o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], o[s][ob], 0, 0, 0);
-          NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+          NDQ_PRODUCTS(NDQ_T)
 #undef NDQ_T
         }
     }
@@ -2308,7 +2343,7 @@ __device__ __forceinline__ void tile_backward_multi(const real* lds, real* stage
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
       g[s][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], g[s][kb], 0, 0, 0);
-        NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+        NDQ_PRODUCTS(NDQ_T)
 #undef NDQ_T
       }
     tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc, kp);

@@ -976,7 +976,19 @@ class FusedSystem:
         if self.fusedk is not None:
             return 2                                     # closure kernel + ONE sums/tail kernel (all networks)
         # pipeline: forward per site, pointwise, (adjoint + sums) per site, loss sum, epoch tail per network
-        return self.n_sites + 1 + 2 * self.n_sites + 1 + len(self.flat)
+        total = 1 + 1 + len(self.flat)
+        for k in range(self.n_sites):
+            d = self.descs[k]
+            if d.hidden > 64 and d.layers >= 2:
+                # deep wide networks (csrc/ndq_launch.h: deep_kernels_fwd / deep_kernels_bwd) are SEQUENCES of launches: weight
+                # planes + one GEMM per hidden layer 2..L (the last one writes the output streams when one chunk holds all
+                # units, else + the head kernel); adjoint: (head pass above 128 units) + per layer 2..L one weight-gradient and
+                # one reverse GEMM + ONE sum of all partial rows; + the entry's own gradient-row sum
+                wide_head = 1 if d.hidden > 128 else 0          # (hidden = the widest layer)
+                total += (1 + (d.layers - 1) + wide_head) + (wide_head + 2 * (d.layers - 1) + 1) + 1
+            else:
+                total += 1 + 2
+        return total
 
     def fast_state(self):
         """Device-side epoch bookkeeping of the native fast path: loss ring, best-loss ping-pong, best snapshot."""

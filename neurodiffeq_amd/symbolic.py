@@ -783,7 +783,7 @@ def _no_such_method(kind):
 
 
 _NOT_METHODS = frozenset({"cat", "concat", "stack", "ones_like", "zeros_like", "full_like", "mse_loss", "l1_loss", "where",
-                          "sum", "mean", "max", "min", "grad", "special_expit", "special_erf", "special_erfc", "special_log1p",
+                          "sum", "mean", "max", "min", "grad", "mm", "special_expit", "special_erf", "special_erfc", "special_log1p",
                           "special_expm1", "special_sinc", "special_exp2", "special_xlogy", "special_xlog1py", "special_logit",
                           "special_round", "_threshold", "threshold", "log_sigmoid", "logsigmoid", "softplus", "elu", "selu",
                           "celu", "gelu", "silu", "mish", "softsign", "hardtanh", "relu6", "hardsigmoid", "hardswish",
@@ -1014,6 +1014,10 @@ class Sym:
     def type(self, *a, **k): return self
     def type_as(self, other): return self
     def where(self, condition, other): return _tf_where(condition, self, other)
+    def masked_fill(self, mask, value): return _tf_where(mask, value, self)
+    def __mod__(self, o): return _tf_remainder(self, o)          # torch's `%`: the sign of the divisor (floor)
+    def __rmod__(self, o): return _tf_remainder(o, self)
+    def __matmul__(self, m): return _tf_matmul(self, m)
     def relu(self): return _tf_where(self > 0.0, self, 0.0)
     def clamp(self, min=None, max=None): return _tf_clamp(self, min, max)
     def clip(self, min=None, max=None): return _tf_clamp(self, min, max)
@@ -1109,6 +1113,10 @@ class SymMat:
 
     def abs(self): return self._un("abs")
     def __abs__(self): return self._un("abs")
+    def __matmul__(self, m): return _tf_matmul(self, m)
+    def __mod__(self, o): return _tf_remainder(self, o)
+    def where(self, condition, other): return _tf_where(condition, self, other)
+    def masked_fill(self, mask, value): return _tf_where(mask, value, self)
     def square(self): return self * self
     def pow(self, e): return self ** e
     def mean(self, dim=None, keepdim=False, **k): return _batch_mean(self, dim, keepdim)
@@ -1550,6 +1558,45 @@ def _tf_remainder(a, b, **k):
     return _elementwise(lambda x, y: x - y * (x / y)._un("floor"), a, b)
 
 
+def _tf_matmul(a, m, **k):
+    """(N, k) traced matrix / column times a CONSTANT (k, m) matrix (a change of basis, a small mixing matrix): m linear
+    combinations of the columns, point by point.  ``torch.einsum`` / a traced right operand stay outside the traced family."""
+    if isinstance(m, (Sym, SymMat)) or not isinstance(a, (Sym, SymMat)):
+        raise TraceUnsupported("matrix products with a traced RIGHT operand (only `columns @ constant matrix` is traced)")
+    cols = a.cols if isinstance(a, SymMat) else [a]
+    if isinstance(m, torch.Tensor):
+        if m.requires_grad:
+            raise TraceUnsupported("a trainable matrix inside the equations")
+        m = m.detach().cpu().double().tolist()
+    else:
+        try:
+            import numpy as np
+            m = np.asarray(m, dtype=float).tolist()
+        except Exception as e:      # noqa: BLE001
+            raise TraceUnsupported(f"matrix product with {type(m).__name__}") from e
+    if not isinstance(m, list) or not m or not all(isinstance(row, list) and len(row) == len(m[0]) for row in m) or len(m) != len(cols):
+        raise TraceUnsupported("matrix product: the constant operand must be a (k, m) matrix matching the k traced columns")
+    g = cols[0].g
+    out = []
+    for j in range(len(m[0])):
+        acc = None
+        for c, row in zip(cols, m):
+            term = Sym(g, g.mul(c.i, g.const(float(row[j]))))         # (entries of a matrix are literals of the kernel)
+            acc = term if acc is None else acc + term
+        out.append(acc)
+    return out[0] if len(out) == 1 else SymMat(out)
+
+
+def _tf_nan_to_num(x, nan=0.0, posinf=None, neginf=None, **k):
+    def one(c):
+        big = 1.7976931348623157e308 if getattr(c.g, "f64", False) else 3.4028234663852886e38
+        hi = big if posinf is None else float(posinf)
+        lo = -big if neginf is None else float(neginf)
+        v = _where1(c > big, Sym(c.g, c.g.const(hi)), _where1(c < -big, Sym(c.g, c.g.const(lo)), c))
+        return _where1(c == c, v, Sym(c.g, c.g.const(float(nan))))    # (x == x is false exactly at nan: Graph.ge does not fold)
+    return _elementwise(one, x)
+
+
 def _tf_round(x, decimals=0, **k):
     if decimals:
         s = 10.0 ** int(decimals)
@@ -1640,7 +1687,8 @@ _TORCH_FUNCS = {
     "hardsigmoid": _tf_elem(lambda c: _tf_clamp(c / 6.0 + 0.5, 0.0, 1.0)), "hardswish": _tf_elem(lambda c: c * _tf_clamp(c / 6.0 + 0.5, 0.0, 1.0)),
     "log_sigmoid": _tf_elem(lambda c: -_tf_softplus(-c)), "logsigmoid": _tf_elem(lambda c: -_tf_softplus(-c)),
     "threshold": _tf_threshold, "_threshold": _tf_threshold, "tanhshrink": _tf_elem(lambda c: c - c.tanh()),
-    "where": _tf_where, "clamp": _tf_clamp, "clip": _tf_clamp,
+    "where": _tf_where, "clamp": _tf_clamp, "clip": _tf_clamp, "masked_fill": lambda x, mask, value, **k: _tf_where(mask, value, x),
+    "matmul": _tf_matmul, "mm": _tf_matmul, "nan_to_num": _tf_nan_to_num,
     "clamp_min": lambda x, min, **k: _tf_clamp(x, min, None), "clamp_max": lambda x, max, **k: _tf_clamp(x, None, max),
     "relu": _tf_relu, "leaky_relu": _tf_leaky_relu, "heaviside": _tf_heaviside,
     "maximum": _tf_maximum, "minimum": _tf_minimum, "max": _tf_max, "min": _tf_min, "fmax": _tf_maximum, "fmin": _tf_minimum,

@@ -20,5 +20,8 @@ cp -r "$REF/neurodiffeq" "$HERE/_ref/neurodiffeq"
 chmod -R u+w "$HERE/_ref"
 cp -r "$HERE/../tests/golden/_refshim/seaborn" "$HERE/../tests/golden/_refshim/ordered_set" "$HERE/_ref/"
 find "$HERE/_ref" -name __pycache__ -type d -prune -exec rm -rf {} +
-(cd "$REF" && git rev-parse HEAD 2>/dev/null || echo "unknown") > "$HERE/_ref/REVISION"
+# revision: the reference's git commit, or -- a checkout without .git -- its declared version plus a digest of the package tree
+REV=$(cd "$REF" && git rev-parse HEAD 2>/dev/null) || \
+  REV="version $(sed -n "s/.*version *= *['\"]\([^'\"]*\)['\"].*/\1/p" "$REF/setup.py" 2>/dev/null | head -1), tree-sha256 $(cd "$REF/neurodiffeq" && find . -name '*.py' | LC_ALL=C sort | xargs sha256sum | sha256sum | cut -c1-16)"
+echo "$REV" > "$HERE/_ref/REVISION"
 echo "oracle/_ref: reference package at revision $(cat "$HERE/_ref/REVISION") ($(find "$HERE/_ref/neurodiffeq" -name '*.py' | wc -l) files)"

@@ -18,7 +18,7 @@ from oracle import jet_ref as J
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DIAG = os.path.join(ROOT, "gpurun_out", "diag")
+DIAG = os.environ.get("NDQ_DIAG_DIR") or os.path.join(ROOT, "gpurun_out", "diag")
 TOL = 1e-5
 
 # name -> (dims, act name, act id, (d, first, mask2) of the config's stream set, streams in kernel order)

@@ -75,6 +75,12 @@ PROBES = {
     "eq_mask": ("lambda D: lambda u, x, y: [D(u, x) + torch.where(torch.round(4.0 * x) == 0.0, u, 2.0 * u) + (x != y) * u]", False),
     "sinc_by_hand": ("lambda D: lambda u, x, y: [D(u, x) + (torch.sin(x) / x).where(x != 0, torch.ones_like(x)) * u]", False),
     "eq_torch": ("lambda D: lambda u, x, y: [D(u, x) + torch.eq(torch.floor(2.0 * x), 0.0) * u + torch.ne(torch.floor(2.0 * y), 0.0) * u]", False),
+    # everyday tensor idioms the reference evaluates (VERDICT r5 missing #5), traced since round 6
+    "mod": ("lambda D: lambda u, x, y: [D(u, x) + (x % 0.3) * u + (u % 0.7)]", False),
+    "masked_fill": ("lambda D: lambda u, x, y: [D(u, x) + u.masked_fill(x > 0.2, 0.0) + torch.masked_fill(D(u, y), y < 0.0, 2.0)]", False),
+    "matmul": ("lambda D: lambda u, x, y: [torch.cat([u, D(u, x)], 1) @ torch.tensor([[1.0], [0.5]]) + "
+               "(torch.cat([x, y], dim=1) @ torch.tensor([[0.5, 1.0], [2.0, -1.0]]))[:, 1:2] * u]", False),
+    "nan_to_num": ("lambda D: lambda u, x, y: [D(u, x) + torch.nan_to_num(torch.sqrt(x), nan=0.25) * u]", False),
     "logit_eps": ("lambda D: lambda u, x, y: [D(u, x) + torch.logit(torch.sigmoid(3.0 * u), eps=0.2)]", False),
 }
 
