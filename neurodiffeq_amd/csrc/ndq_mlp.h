@@ -265,30 +265,39 @@ constexpr bool act_has_s4(int act) {
 // went through the bf16 matrix core.  The route of round 3 (Cfg::WG_TR / WG_TR64) transposes the bf16 PLANES through
 // LDS (ds_read_b64_tr_b16: exact) and passes the gradient goldens at the level of the f32 MFMA route (1e-7 ... 6e-6,
 // incl. the trained states of tests/golden/c2_trained.npz, c3_trained.npz).
-// Experiments (profiles/r06_headline_ab.md): how many of the bf16 partial products of a "weights (planes a0, a1, a2) x
-// per-point operand (planes 0, 1, 2)" GEMM are issued -- the forward `z = W h` and the reverse `hbar = W^T zbar` GEMMs only; the
-// weight-gradient GEMMs, which sum over points with cancellation, always take all six.  6 = bf16x3 (fp32 class, the default);
-// 5 drops a0 x plane 2 (the per-point operand is then exact to 2^-18 instead of 2^-27), 4 drops a1 x plane 1 as well, 3 is
-// "bf16x2": hi*hi + hi*lo + lo*hi.  Smallest products first.
-#ifndef NDQ_BF16_NPROD
-#define NDQ_BF16_NPROD 6
+// How many of the bf16 partial products of a "weights (planes a0, a1, a2) x per-point operand (planes 0, 1, 2)" GEMM are
+// issued, smallest first (profiles/r06_headline_ab.md).  6 = bf16x3 (fp32 class); 5 drops a0 x plane 2 (the per-point operand
+// is then exact to 2^-18 instead of 2^-27), 4 drops a1 x plane 1 as well, 3 is "bf16x2": hi*hi + hi*lo + lo*hi.
+//   NDQ_FWD_NPROD   the forward GEMMs z = W h (and the multi-output layer): what the derivative STREAMS are made of.  Stays 6:
+//                   with 5 the reference's trained C3 state has u_xx off by 3.2e-5 (1e-5 contract; 3.2e-6 with 6).
+//   NDQ_HBAR_NPROD  the reverse GEMMs hbar = W^T zbar: gradients only.
+//   NDQ_WG_NPROD    the weight-gradient GEMMs dW = sum over points of Zbar (planes I) x H (planes J): 6, 4 (no third planes), 3.
+// An operand none of whose consumers reads its third plane is split into TWO planes (a third less splitting work and, for
+// the transposed LDS images of the weight-gradient GEMM, a third less LDS traffic): NDQ_H_PLANES (forward activations),
+// NDQ_HTR_PLANES (their transposed images), NDQ_Z_PLANES (the adjoint operand).
+#ifdef NDQ_BF16_NPROD              // (round-6 experiments: one number for forward and reverse)
+#define NDQ_FWD_NPROD NDQ_BF16_NPROD
+#define NDQ_HBAR_NPROD NDQ_BF16_NPROD
 #endif
-#if NDQ_BF16_NPROD == 6
-#define NDQ_PRODUCTS(T) T(a1, 1) T(a2, 0) T(a0, 2) T(a1, 0) T(a0, 1) T(a0, 0)
-#elif NDQ_BF16_NPROD == 5
-#define NDQ_PRODUCTS(T) T(a1, 1) T(a2, 0) T(a1, 0) T(a0, 1) T(a0, 0)
-#elif NDQ_BF16_NPROD == 4
-#define NDQ_PRODUCTS(T) T(a2, 0) T(a1, 0) T(a0, 1) T(a0, 0)
-#elif NDQ_BF16_NPROD == 3
-#define NDQ_PRODUCTS(T) T(a1, 0) T(a0, 1) T(a0, 0)
-#else
-#error "NDQ_BF16_NPROD must be 3, 4, 5 or 6"
+#ifndef NDQ_FWD_NPROD
+#define NDQ_FWD_NPROD 6
 #endif
-// ... and of the weight-gradient GEMMs dW = sum over points of Zbar (planes I) x H (planes J): 6 (default), 4 (no third planes)
-// or 3.  With NDQ_BF16_NPROD < 6 and NDQ_WG_NPROD < 6 nobody reads the third plane of a per-point operand: split3 makes two
-// planes (NDQ_PT_PLANES), a third less splitting work and LDS traffic of the transposed images.
+#ifndef NDQ_HBAR_NPROD
+#define NDQ_HBAR_NPROD 6
+#endif
 #ifndef NDQ_WG_NPROD
 #define NDQ_WG_NPROD 6
+#endif
+#define NDQ_PRODUCTS_6(T) T(a1, 1) T(a2, 0) T(a0, 2) T(a1, 0) T(a0, 1) T(a0, 0)
+#define NDQ_PRODUCTS_5(T) T(a1, 1) T(a2, 0) T(a1, 0) T(a0, 1) T(a0, 0)
+#define NDQ_PRODUCTS_4(T) T(a2, 0) T(a1, 0) T(a0, 1) T(a0, 0)
+#define NDQ_PRODUCTS_3(T) T(a1, 0) T(a0, 1) T(a0, 0)
+#define NDQ_CAT_(a, b) a##b
+#define NDQ_CAT(a, b) NDQ_CAT_(a, b)
+#define NDQ_PRODUCTS_FWD(T) NDQ_CAT(NDQ_PRODUCTS_, NDQ_FWD_NPROD)(T)
+#define NDQ_PRODUCTS_BWD(T) NDQ_CAT(NDQ_PRODUCTS_, NDQ_HBAR_NPROD)(T)
+#if NDQ_FWD_NPROD < 3 || NDQ_FWD_NPROD > 6 || NDQ_HBAR_NPROD < 3 || NDQ_HBAR_NPROD > 6
+#error "NDQ_FWD_NPROD / NDQ_HBAR_NPROD must be 3, 4, 5 or 6"
 #endif
 #if NDQ_WG_NPROD == 6
 #define NDQ_WPRODUCTS(W) W(1, 1) W(2, 0) W(0, 2) W(1, 0) W(0, 1) W(0, 0)
@@ -299,7 +308,9 @@ constexpr bool act_has_s4(int act) {
 #else
 #error "NDQ_WG_NPROD must be 3, 4 or 6"
 #endif
-#define NDQ_PT_PLANES ((NDQ_BF16_NPROD == 6 || NDQ_WG_NPROD == 6) ? 3 : 2)
+#define NDQ_HTR_PLANES ((NDQ_WG_NPROD == 6) ? 3 : 2)
+#define NDQ_H_PLANES ((NDQ_FWD_NPROD == 6 || NDQ_WG_NPROD == 6) ? 3 : 2)
+#define NDQ_Z_PLANES ((NDQ_HBAR_NPROD == 6 || NDQ_WG_NPROD == 6) ? 3 : 2)
 #ifndef NDQ_WIDE_LOWREG
 #define NDQ_WIDE_LOWREG 1
 #endif
@@ -1181,6 +1192,8 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)
 template <class C> __device__ __forceinline__ void zero_frag(real4 (&z)[C::NS][C::NB]);
 
 // split the 8 fp32 values a lane holds for one K-chunk (blocks 2c, 2c+1) into three bf16x8 operands
+// (NP = 2: the third plane is left unset -- for operands nobody reads it of, see NDQ_H_PLANES / NDQ_Z_PLANES above)
+template <int NP = 3>
 __device__ __forceinline__ void split3(const real4 a, const real4 b, bf16x8 (&pl)[3]) {
   const real x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
   if constexpr ((NDQ_ABL & 32) != 0) {
@@ -1211,7 +1224,7 @@ __device__ __forceinline__ void split3(const real4 a, const real4 b, bf16x8 (&pl
     const real r1 = x[e] - (real)h0;
     const __bf16 h1 = (__bf16)r1;
     pl[0][e] = h0; pl[1][e] = h1;
-    if constexpr (NDQ_PT_PLANES == 3) pl[2][e] = (__bf16)(r1 - (real)h1);
+    if constexpr (NP == 3) pl[2][e] = (__bf16)(r1 - (real)h1);
   }
 #endif
 }
@@ -1223,16 +1236,16 @@ __device__ __forceinline__ void split1(const real4 a, const real4 b, bf16x8 (&pl
   for (int e = 0; e < 8; ++e) pl[0][e] = (__bf16)x[e];
 }
 
-template <class C>
+template <class C, int NP = NDQ_H_PLANES>
 __device__ __forceinline__ void split_all(const real4 (&h)[C::NS][C::NB], Planes<C>& P) {
 #pragma unroll
   for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-    for (int c = 0; c < C::NC; ++c) split3(h[s][2 * c], h[s][2 * c + 1], P.pl[s][c]);
+    for (int c = 0; c < C::NC; ++c) split3<NP>(h[s][2 * c], h[s][2 * c + 1], P.pl[s][c]);
 }
 
 // z[s][ob] += W h[s] with h given as bf16x3 planes
-template <class C, bool X1 = false>
+template <class C, bool X1 = false, bool REV = false>
 __device__ __forceinline__ void gemm_planes(const real* __restrict__ wl, int lane, const Planes<C>& P,
                                             real4 (&z)[C::NS][C::NB]) {
   const bf16x8* w = reinterpret_cast<const bf16x8*>(wl);
@@ -1251,7 +1264,7 @@ __device__ __forceinline__ void gemm_planes(const real* __restrict__ wl, int lan
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
       z[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, P.pl[s][c][K], z[s][ob], 0, 0, 0);
-      NDQ_PRODUCTS(NDQ_T)
+      if constexpr (REV) { NDQ_PRODUCTS_BWD(NDQ_T) } else { NDQ_PRODUCTS_FWD(NDQ_T) }
 #undef NDQ_T
     }
 }
@@ -1270,7 +1283,7 @@ __device__ __forceinline__ void gemm_bf16x3_inplace(const real* __restrict__ wl,
 #pragma unroll
       for (int s = 0; s < sn; ++s) {
 #pragma unroll
-        for (int c = 0; c < C::NC; ++c) split3(g[s0 + s][2 * c], g[s0 + s][2 * c + 1], pl[s][c]);
+        for (int c = 0; c < C::NC; ++c) split3<NDQ_Z_PLANES>(g[s0 + s][2 * c], g[s0 + s][2 * c + 1], pl[s][c]);
 #pragma unroll
         for (int b = 0; b < C::NB; ++b) o[s][b] = real4{0.f, 0.f, 0.f, 0.f};
       }
@@ -1284,7 +1297,7 @@ __device__ __forceinline__ void gemm_bf16x3_inplace(const real* __restrict__ wl,
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
       o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], o[s][ob], 0, 0, 0);
-          NDQ_PRODUCTS(NDQ_T)
+          NDQ_PRODUCTS_BWD(NDQ_T)
 #undef NDQ_T
         }
 #pragma unroll
@@ -1297,8 +1310,8 @@ __device__ __forceinline__ void gemm_bf16x3_inplace(const real* __restrict__ wl,
   real4 o[C::NS][C::NB];
   zero_frag<C>(o);
   Planes<C> P;
-  split_all<C>(g, P);
-  gemm_planes<C>(wl, lane, P, o);
+  split_all<C, NDQ_Z_PLANES>(g, P);
+  gemm_planes<C, false, true>(wl, lane, P, o);
 #pragma unroll
   for (int s = 0; s < C::NS; ++s)
 #pragma unroll
@@ -1567,7 +1580,7 @@ __device__ __forceinline__ void output_layer_mfma(const real* lds, int lane, int
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
       o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, P.pl[s][c][K], o[s][ob], 0, 0, 0);
-        NDQ_PRODUCTS(NDQ_T)
+        NDQ_PRODUCTS_FWD(NDQ_T)
 #undef NDQ_T
       }
     return;
@@ -1624,7 +1637,7 @@ __device__ __forceinline__ void hidden_layer_grouped(const real* lds, int l, int
 #pragma unroll
       for (int c = 0; c < C::NC; ++c) {
         if constexpr (X1) split1(hs[2 * c], hs[2 * c + 1], pl[s][c]);
-        else split3(hs[2 * c], hs[2 * c + 1], pl[s][c]);
+        else split3<NDQ_H_PLANES>(hs[2 * c], hs[2 * c + 1], pl[s][c]);
       }
     });
 #pragma unroll
@@ -1643,7 +1656,7 @@ __device__ __forceinline__ void hidden_layer_grouped(const real* lds, int l, int
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
       z[s0 + s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], z[s0 + s][ob], 0, 0, 0);
-        NDQ_PRODUCTS(NDQ_T)
+        NDQ_PRODUCTS_FWD(NDQ_T)
 #undef NDQ_T
       }
   });
@@ -1666,10 +1679,10 @@ __device__ __forceinline__ void hidden_layer_grouped(const real* lds, int l, int
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 __device__ __forceinline__ int tr_slot(int row, int chunk) { return chunk * 64 + ((row ^ (4 * chunk)) * 4); }   // floats
-template <class C>
+template <class C, int NP>
 __device__ __forceinline__ void tr_store(real* img, int woff, const bf16x8 (&pl)[3]) {     // woff = tr_slot(p, q)
 #pragma unroll
-  for (int k = 0; k < NDQ_PT_PLANES; ++k) *reinterpret_cast<bf16x8*>(img + k * C::trPlane + woff) = pl[k];
+  for (int k = 0; k < NP; ++k) *reinterpret_cast<bf16x8*>(img + k * C::trPlane + woff) = pl[k];
 }
 // 8 contraction slots of one lane: two transposing reads (4 points each) of the same unit
 __device__ __forceinline__ bf16x8 tr_read8(const real* a0, const real* a1) {
@@ -1706,7 +1719,7 @@ __device__ __forceinline__ void tile_forward(const real* lds, int lane, int q, c
         split_all<C>(h, P);
         if constexpr (BWD && C::WG_TR) {       // the reverse pass reads the planes back transposed (hbar_wgrad_tr)
 #pragma unroll
-          for (int s = 0; s < C::NS; ++s) tr_store<C>(stage + (li * C::NS + s) * 3 * C::trPlane, tr_slot(lane & 15, q), P.pl[s][0]);
+          for (int s = 0; s < C::NS; ++s) tr_store<C, NDQ_HTR_PLANES>(stage + (li * C::NS + s) * 3 * C::trPlane, tr_slot(lane & 15, q), P.pl[s][0]);
         }
         hidden_layer_planes<C, BWD>(lds, li + 2, lane, q, P, st[li + 1]);
       } else {
@@ -1896,7 +1909,7 @@ __device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q,
         real x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = t[e * HP + 32 * blk];
-        split3(real4{x[0], x[1], x[2], x[3]}, real4{x[4], x[5], x[6], x[7]}, pl);
+        split3<NDQ_HTR_PLANES>(real4{x[0], x[1], x[2], x[3]}, real4{x[4], x[5], x[6], x[7]}, pl);
       };
       bf16x8 pb[2][3];
 #pragma unroll
@@ -1934,7 +1947,7 @@ __device__ __forceinline__ void weight_grad(real* stage, int lane, int p, int q,
           if constexpr (sn == 2) x[e] = v;
           else x[e] = live ? v : 0.f;
         }
-        split3(real4{x[0], x[1], x[2], x[3]}, real4{x[4], x[5], x[6], x[7]}, pl);
+        split3<NDQ_HTR_PLANES>(real4{x[0], x[1], x[2], x[3]}, real4{x[4], x[5], x[6], x[7]}, pl);
       };
       bf16x8 pb[C::NB][3];
 #pragma unroll
@@ -2042,7 +2055,7 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int k = 0; k < NDQ_PT_PLANES; ++k) pb[kb][k] = tr_read8(hr + k * PL + kb * 2 + r0, hr + k * PL + kb * 2 + r1);
+        for (int k = 0; k < NDQ_HTR_PLANES; ++k) pb[kb][k] = tr_read8(hr + k * PL + kb * 2 + r0, hr + k * PL + kb * 2 + r1);
     };
     if constexpr ((NDQ_ABL & 1) == 0 && ROOMY) read_h();
     {
@@ -2050,8 +2063,8 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
       real4 o[sn][2];
 #pragma unroll
       for (int s = 0; s < sn; ++s) {
-        split3(g[s0 + s][0], g[s0 + s][1], pl[s]);
-        tr_store<C>(zimg + s * 3 * PL, woff, pl[s]);
+        split3<NDQ_Z_PLANES>(g[s0 + s][0], g[s0 + s][1], pl[s]);
+        tr_store<C, NDQ_HTR_PLANES>(zimg + s * 3 * PL, woff, pl[s]);
         o[s][0] = real4{0.f, 0.f, 0.f, 0.f};
         o[s][1] = real4{0.f, 0.f, 0.f, 0.f};
       }
@@ -2061,7 +2074,7 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
         for (int k = 0; k < 3; ++k)
 #pragma unroll
           for (int e = 0; e < 8; ++e) zero[k][e] = (__bf16)0.f;
-        tr_store<C>(zimg + 3 * PL, woff, zero);
+        tr_store<C, NDQ_HTR_PLANES>(zimg + 3 * PL, woff, zero);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -2074,7 +2087,7 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
 #pragma unroll
         for (int jb = 0; jb < (ROOMY ? 2 : 1); ++jb)
 #pragma unroll
-          for (int k = 0; k < NDQ_PT_PLANES; ++k) pa[jb][k] = tr_read8(zr + k * PL + jb * 2 + r0, zr + k * PL + jb * 2 + r1);
+          for (int k = 0; k < NDQ_HTR_PLANES; ++k) pa[jb][k] = tr_read8(zr + k * PL + jb * 2 + r0, zr + k * PL + jb * 2 + r1);
       }
       if constexpr ((NDQ_ABL & 2) == 0) {
 #pragma unroll
@@ -2085,7 +2098,7 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
       o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][K], o[s][ob], 0, 0, 0);
-          NDQ_PRODUCTS(NDQ_T)
+          NDQ_PRODUCTS_BWD(NDQ_T)
 #undef NDQ_T
         }
       }
@@ -2103,7 +2116,7 @@ __device__ __forceinline__ void hbar_wgrad_tr(const real* __restrict__ wl, real*
         for (int jb = 0; jb < 2; ++jb) {
           if (jb == 1) {
 #pragma unroll
-            for (int k = 0; k < NDQ_PT_PLANES; ++k) pa[0][k] = tr_read8(zr + k * PL + 2 + r0, zr + k * PL + 2 + r1);
+            for (int k = 0; k < NDQ_HTR_PLANES; ++k) pa[0][k] = tr_read8(zr + k * PL + 2 + r0, zr + k * PL + 2 + r1);
           }
 #define NDQ_W(I, J)                                                                                          \
   _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                           \
@@ -2142,23 +2155,23 @@ __device__ __forceinline__ void hbar_wgrad_tr64(const real* __restrict__ wl, rea
 #pragma unroll
     for (int s = 0; s < sn; ++s)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) split3(g[s0 + s][2 * c], g[s0 + s][2 * c + 1], pl[s][c]);
+      for (int c = 0; c < 2; ++c) split3<NDQ_Z_PLANES>(g[s0 + s][2 * c], g[s0 + s][2 * c + 1], pl[s][c]);
     if constexpr ((NDQ_ABL & 1) == 0) {
       sfor<sn>([&](auto s_) {
         constexpr int s = decltype(s_)::value;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int k = 0; k < NDQ_PT_PLANES; ++k) *reinterpret_cast<bf16x8*>(zimg + k * PL + c * 256 + woff) = pl[s][c][k];
+          for (int k = 0; k < NDQ_HTR_PLANES; ++k) *reinterpret_cast<bf16x8*>(zimg + k * PL + c * 256 + woff) = pl[s][c][k];
         {
           real4 hs[C::NB];
           act_forward_stream<C, s0 + s>(st_in, hs);
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             bf16x8 ph[3];
-            split3(hs[2 * c], hs[2 * c + 1], ph);
+            split3<NDQ_HTR_PLANES>(hs[2 * c], hs[2 * c + 1], ph);
 #pragma unroll
-            for (int k = 0; k < NDQ_PT_PLANES; ++k) *reinterpret_cast<bf16x8*>(himg + k * PL + c * 256 + woff) = ph[k];
+            for (int k = 0; k < NDQ_HTR_PLANES; ++k) *reinterpret_cast<bf16x8*>(himg + k * PL + c * 256 + woff) = ph[k];
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2168,12 +2181,12 @@ __device__ __forceinline__ void hbar_wgrad_tr64(const real* __restrict__ wl, rea
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int k = 0; k < NDQ_PT_PLANES; ++k) pb[kb][k] = tr_read8(himg + k * PL + kb * 256 + r0, himg + k * PL + kb * 256 + r1);
+          for (int k = 0; k < NDQ_HTR_PLANES; ++k) pb[kb][k] = tr_read8(himg + k * PL + kb * 256 + r0, himg + k * PL + kb * 256 + r1);
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
           bf16x8 pa[3];
 #pragma unroll
-          for (int k = 0; k < NDQ_PT_PLANES; ++k) pa[k] = tr_read8(zimg + k * PL + jb * 256 + r0, zimg + k * PL + jb * 256 + r1);
+          for (int k = 0; k < NDQ_HTR_PLANES; ++k) pa[k] = tr_read8(zimg + k * PL + jb * 256 + r0, zimg + k * PL + jb * 256 + r1);
 #define NDQ_W(I, J)                                                                                          \
   _Pragma("unroll") for (int kb = 0; kb < 2; ++kb)                                                           \
       acc32[jb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[I], pb[kb][J], acc32[jb][kb], 0, 0, 0);
@@ -2201,7 +2214,7 @@ __device__ __forceinline__ void hbar_wgrad_tr64(const real* __restrict__ wl, rea
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < sn; ++s)                                                             \
       o[s][ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], o[s][ob], 0, 0, 0);
-          NDQ_PRODUCTS(NDQ_T)
+          NDQ_PRODUCTS_BWD(NDQ_T)
 #undef NDQ_T
         }
     }
@@ -2331,7 +2344,7 @@ __device__ __forceinline__ void tile_backward_multi(const real* lds, real* stage
 #pragma unroll
     for (int s = 0; s < C::NS; ++s)
 #pragma unroll
-      for (int c = 0; c < C::NCO; ++c) split3(go[s][2 * c], go[s][2 * c + 1], pl[s][c]);
+      for (int c = 0; c < C::NCO; ++c) split3<(NDQ_HBAR_NPROD == 6 ? 3 : 2)>(go[s][2 * c], go[s][2 * c + 1], pl[s][c]);
     const bf16x8* wb = reinterpret_cast<const bf16x8*>(lds + C::ldsWoutT());
 #pragma unroll
     for (int c = 0; c < C::NCO; ++c)
@@ -2343,7 +2356,7 @@ __device__ __forceinline__ void tile_backward_multi(const real* lds, real* stage
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < C::NS; ++s)                                                          \
       g[s][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][c][K], g[s][kb], 0, 0, 0);
-        NDQ_PRODUCTS(NDQ_T)
+        NDQ_PRODUCTS_BWD(NDQ_T)
 #undef NDQ_T
       }
     tile_backward_hidden<C>(lds, stage, lane, p, q, x, st, g, acc, kp);

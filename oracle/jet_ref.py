@@ -12,7 +12,10 @@ so the kernels can be checked stage by stage:
 Parity status: PINNED via ``tests/test_oracle_golden.py`` -- streams are compared with ``ref_diff`` of
 ``oracle/autograd_ref.py`` (itself pinned to the reference's golden vectors) and the VJP with torch autograd.
 
-A stream is a tuple of coordinate indices: ``()`` value, ``(a,)`` d/dx_a, ``(a, b)`` d2/dx_a dx_b (a <= b).
+A stream is a tuple of coordinate indices: ``()`` value, ``(a,)`` d/dx_a, ``(a, b)`` d2/dx_a dx_b (a <= b), up to four
+indices (round 6: ``diff(u, x, order=4)`` -- beam / biharmonic equations; neurodiffeq.py:21-34 has no order limit).  Orders 3
+and 4 are stated through the general Faa di Bruno sum over the set partitions of the index POSITIONS (``_partitions``), which
+handles repeated indices by itself; orders 1 and 2 keep their written-out formulas.
 """
 import numpy as np
 
@@ -39,6 +42,36 @@ def act_deriv4(name, z):
         phi = np.exp(-0.5 * z * z) / np.sqrt(2 * np.pi)
         return phi * (-z ** 4 + 7 * z ** 2 - 4)
     raise KeyError(f"no fourth derivative stated for {name}")
+
+
+def act_deriv5(name, z):
+    """Fifth derivative of the activation (the adjoint of a fourth-order stream needs it)."""
+    if name == "tanh":       # d/dz = (1 - t^2) d/dt:  P5 = (1 - t^2)(16 - 120 t^2 + 120 t^4)
+        t = np.tanh(z)
+        return (1 - t * t) * (16 - 120 * t ** 2 + 120 * t ** 4)
+    if name == "sin":
+        return np.cos(z)
+    if name == "sigmoid":    # d/dz = (s - s^2) d/ds applied to Q4 = (s - s^2)(1 - 14 s + 36 s^2 - 24 s^3)
+        s = 1.0 / (1.0 + np.exp(-z))
+        d1 = s * (1 - s)
+        return d1 * ((1 - 2 * s) * (1 - 14 * s + 36 * s ** 2 - 24 * s ** 3) + d1 * (-14 + 72 * s - 72 * s ** 2))
+    raise KeyError(f"no fifth derivative stated for {name}")
+
+
+def _partitions(k):
+    """Set partitions of the positions 0 .. k-1 (1, 2, 5, 15 of them for k = 1 .. 4), each a tuple of sorted blocks."""
+    if k == 0:
+        return [()]
+    out = []
+    for part in _partitions(k - 1):
+        out.append(part + ((k - 1,),))
+        for i in range(len(part)):
+            out.append(part[:i] + (part[i] + (k - 1,),) + part[i + 1:])
+    return out
+
+
+def _sub(m, block):
+    return tuple(sorted(m[i] for i in block))
 
 
 def act_derivs(name, z, theta=None):
@@ -114,16 +147,15 @@ def _pairs_of(m):
 
 def close_streams(streams):
     """A second-order stream needs both of its first-order streams, a third-order one also its three second-order
-    sub-streams (Faa di Bruno); the value stream is always present."""
+    sub-streams, a fourth-order one its six pairs and four triples (Faa di Bruno: every sub-multi-index); the value stream
+    is always present."""
     s = {()}
     for m in streams:
         m = tuple(sorted(m))
-        assert len(m) <= 3, "order > 3 is outside the fused path"
-        s.add(m)
-        for a in m:
-            s.add((a,))
-        if len(m) == 3:
-            s.update(_pairs_of(m))
+        assert len(m) <= 4, "order > 4 is outside the fused path"
+        for part in _partitions(len(m)):
+            for block in part:
+                s.add(_sub(m, block))
     return sorted(s, key=lambda m: (len(m), m))
 
 
@@ -172,10 +204,18 @@ def _forward(flat, dims, act, coords, streams, thetas=None, mono=None):
                 hn[m] = s1 * z[m]
             elif len(m) == 2:
                 hn[m] = s2 * z[(m[0],)] * z[(m[1],)] + s1 * z[m]
-            elif len(m) == 3:       # h_abc = s3 z_a z_b z_c + s2 (z_ab z_c + z_ac z_b + z_bc z_a) + s1 z_abc
-                a, b, c = (m[0],), (m[1],), (m[2],)
-                pab, pac, pbc = _pairs_of(m)
-                hn[m] = s3 * z[a] * z[b] * z[c] + s2 * (z[pab] * z[c] + z[pac] * z[b] + z[pbc] * z[a]) + s1 * z[m]
+            elif len(m) >= 3:
+                # h_abc = s3 z_a z_b z_c + s2 (z_ab z_c + z_ac z_b + z_bc z_a) + s1 z_abc;  h_abcd = s4 z_a z_b z_c z_d
+                # + s3 (6 terms z_pair z z) + s2 (3 terms z_pair z_pair + 4 terms z_triple z) + s1 z_abcd: one term per set
+                # partition of the positions, sigma^(number of blocks) times the product of the blocks' streams
+                sig = {1: s1, 2: s2, 3: s3, 4: act_deriv4(act, z[()]) if len(m) == 4 else None}
+                acc = 0.0
+                for part in _partitions(len(m)):
+                    term = sig[len(part)]
+                    for block in part:
+                        term = term * z[_sub(m, block)]
+                    acc = acc + term
+                hn[m] = acc
         saved.append((h, z, (s1, s2, s3)))
         h = hn
     raise AssertionError
@@ -266,11 +306,15 @@ def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False, actp=False, thetas=N
                     hin[m] = s1 * zprev[m]
                 elif len(m) == 2:
                     hin[m] = s2 * zprev[(m[0],)] * zprev[(m[1],)] + s1 * zprev[m]
-                elif len(m) == 3:
-                    a, b, c = (m[0],), (m[1],), (m[2],)
-                    pab, pac, pbc = _pairs_of(m)
-                    hin[m] = s3 * zprev[a] * zprev[b] * zprev[c] \
-                        + s2 * (zprev[pab] * zprev[c] + zprev[pac] * zprev[b] + zprev[pbc] * zprev[a]) + s1 * zprev[m]
+                elif len(m) >= 3:
+                    sig = {1: s1, 2: s2, 3: s3, 4: act_deriv4(act, zprev[()]) if len(m) == 4 else None}
+                    acc = 0.0
+                    for part in _partitions(len(m)):
+                        term = sig[len(part)]
+                        for block in part:
+                            term = term * zprev[_sub(m, block)]
+                        acc = acc + term
+                    hin[m] = acc
         dw = sum(zb[m].T @ hin[m] for m in streams)
         db = zb[()].sum(axis=0)
         grads[li] = (dw, db)
@@ -291,9 +335,26 @@ def mlp_jets_vjp(flat, dims, act, coords, gbar, skip=False, actp=False, thetas=N
                 nzb[a] += s2 * zprev[b] * hb[m]
                 nzb[b] += s2 * zprev[a] * hb[m]
                 nzb[m] += s1 * hb[m]
-        if any(len(m) == 3 for m in streams):
+        if any(len(m) >= 3 for m in streams):
             s4 = act_deriv4(act, zprev[()])
         for m in streams:
+            if len(m) == 4:
+                # adjoint of the fourth-order recurrence, partition by partition: a term sigma^(r) prod_B z_B gives
+                # sigma^(r+1) prod_B z_B to the value stream's adjoint and sigma^(r) prod_{B' != B} z_B' to block B's
+                sig = {1: s1, 2: s2, 3: s3, 4: s4, 5: act_deriv5(act, zprev[()])}
+                for part in _partitions(4):
+                    r = len(part)
+                    zs = [zprev[_sub(m, block)] for block in part]
+                    prod = 1.0
+                    for v in zs:
+                        prod = prod * v
+                    nzb[()] += sig[r + 1] * prod * hb[m]
+                    for i, block in enumerate(part):
+                        rest = sig[r]
+                        for j, v in enumerate(zs):
+                            if j != i:
+                                rest = rest * v
+                        nzb[_sub(m, block)] += rest * hb[m]
             if len(m) == 3:         # adjoint of the third-order recurrence, position by position
                 a, b, c = (m[0],), (m[1],), (m[2],)
                 pab, pac, pbc = _pairs_of(m)

@@ -187,6 +187,40 @@ def test_third_order_jets_match_nested_autograd(act):
     assert rel_l2(got, R.get_flat_grad([net]).numpy()) < 1e-12
 
 
+@pytest.mark.parametrize("act", ["tanh", "sin", "sigmoid"])
+def test_fourth_order_jets_match_nested_autograd(act):
+    """Round 6: the fourth-order recurrences (general Faa di Bruno over the set partitions of the index positions, forward
+    AND the adjoint with the fifth activation derivative) against four nested autograd sweeps in fp64 -- all five
+    quadruples of two coordinates (xxxx, xxxy, xxyy, xyyy, yyyy) with every sub-stream they need, two outputs."""
+    from oracle import jet_ref as J
+    torch.manual_seed(0)
+    net = R.make_fcnn(2, 2, (12, 12), act, torch.float64)
+    flat = R.get_flat([net]).numpy()
+    x, y = [torch.rand(6, 1, dtype=torch.float64, requires_grad=True) for _ in range(2)]
+    out = net(torch.cat([x, y], 1))
+    d = R.ref_diff
+    quads = [(0, 0, 0, 0), (0, 0, 0, 1), (0, 0, 1, 1), (0, 1, 1, 1), (1, 1, 1, 1)]
+    z = J.mlp_jets(flat, (2, 12, 12, 2), act, [x.detach().numpy(), y.detach().numpy()], quads)
+    assert len(z) == 1 + 2 + 3 + 4 + 5
+    rng = np.random.default_rng(0)
+    gb = {m: rng.standard_normal((6, 2)) for m in z}
+    loss = 0
+    coords = (x, y)
+    for o in range(2):
+        u = out[:, o:o + 1]
+        for m in z:
+            col = u
+            for a in m:
+                col = d(col, coords[a])
+            assert rel_l2(z[m][:, o], col.detach().numpy()) < 1e-10, (act, m)
+            loss = loss + (torch.from_numpy(gb[m][:, o:o + 1]) * col).sum()
+    loss.backward()
+    got = J.mlp_jets_vjp(flat, (2, 12, 12, 2), act, [x.detach().numpy(), y.detach().numpy()], gb)
+    assert rel_l2(got, R.get_flat_grad([net]).numpy()) < 1e-11
+    # the beam case: one coordinate, pure fourth derivative -- exactly the streams (), (0,), (0,0), (0,0,0), (0,0,0,0)
+    assert J.close_streams([(0, 0, 0, 0)]) == [(), (0,), (0, 0), (0, 0, 0), (0, 0, 0, 0)]
+
+
 @pytest.mark.parametrize("name,grid", [("c2", 64), ("c3", 48)])
 def test_closure_at_the_reference_trained_state(golden_dir, name, grid):
     """Near convergence (tests/golden/<name>_trained.npz: the unmodified reference trained the config, then evaluated one
