@@ -59,6 +59,10 @@ typedef struct ndq_mlp_desc {
   int mono;    /* != 0: a MonomialNN (networks.py:109-139) in front of the first linear layer: bit k <-> degree k + 1
                   (ascending, 1..8).  The d coordinates become the d * n_degrees features x_a^deg, degree after degree,
                   and the first weight matrix is (hidden x d * n_degrees); streams up to second order, hidden <= 48, no skip */
+  int mask4;   /* fourth-order quadruple mask (round 6): bit k <-> k-th quadruple a <= b <= c <= d in lexicographic order; those
+                  streams follow the third-order ones.  A quadruple needs its six pairs in mask2 and its four triples in mask3;
+                  lap, actp and mono must be 0; tanh / sin / sigmoid.  (diff(u, x, order=4), neurodiffeq.py:21-34: beam and
+                  biharmonic equations) */
 } ndq_mlp_desc;
 
 /* One compiled kernel pair (forward streams / parameter-gradient adjoint) for ONE descriptor.  libndq.so carries a

@@ -12,11 +12,12 @@ NDQ_ACT_ELU, NDQ_ACT_SOFTPLUS, NDQ_ACT_GELU = 5, 6, 7
 class MlpDesc(ctypes.Structure):
     _fields_ = [("d", ctypes.c_int), ("first", ctypes.c_int), ("mask2", ctypes.c_int), ("hidden", ctypes.c_int),
                 ("layers", ctypes.c_int), ("act", ctypes.c_int), ("n_out", ctypes.c_int), ("lap", ctypes.c_int),
-                ("skip", ctypes.c_int), ("mask3", ctypes.c_int), ("actp", ctypes.c_int), ("widths", ctypes.c_int), ("mono", ctypes.c_int)]
+                ("skip", ctypes.c_int), ("mask3", ctypes.c_int), ("actp", ctypes.c_int), ("widths", ctypes.c_int), ("mono", ctypes.c_int),
+                ("mask4", ctypes.c_int)]
 
     def key(self):
         return (self.d, self.first, self.mask2, self.hidden, self.layers, self.act, self.n_out, self.lap, self.skip,
-                self.mask3, self.actp, self.widths, self.mono)
+                self.mask3, self.actp, self.widths, self.mono, self.mask4)
 
 
 NDQ_SAMPLE_UNIFORM, NDQ_SAMPLE_GRID, NDQ_SAMPLE_SPHERICAL = 0, 1, 2

@@ -35,6 +35,16 @@ def triple_list(d):
     return [(a, b, c) for a in range(d) for b in range(a, d) for c in range(b, d)]
 
 
+def quad_list(d):
+    return [(a, b, c, e) for a in range(d) for b in range(a, d) for c in range(b, d) for e in range(c, d)]
+
+
+def _m4_arg(desc):
+    """Trailing template argument of ndq::Cfg for fourth-order streams -- appended only when there are any, so that the
+    generated source (and with it the build cache key) of every other module stays what it was."""
+    return f", {desc.mask4}u" if getattr(desc, "mask4", 0) else ""
+
+
 class NetStreams:
     """Which derivative streams of net ``k`` the residual needs, closed to a set the MLP kernels provide.
 
@@ -47,6 +57,7 @@ class NetStreams:
         self.first = 0
         self.mask2 = 0
         self.mask3 = 0          # third-order triples (include/ndq.h: ndq_mlp_desc.mask3)
+        self.mask4 = 0          # fourth-order quadruples (ndq_mlp_desc.mask4; round 6)
         self.lap = 0            # 1: the diagonal pairs of mask2 travel as ONE stream holding their sum
 
     def need(self, mi):
@@ -66,12 +77,22 @@ class NetStreams:
             self.mask3 |= 1 << triple_list(self.d).index(loc)
             for pair in ((loc[0], loc[1]), (loc[0], loc[2]), (loc[1], loc[2])):
                 self.mask2 |= 1 << pair_list(self.d).index(pair)
-        if len(loc) > 3:
-            raise TraceUnsupported("derivatives of network outputs beyond third order are outside the fused path")
+        if len(loc) == 4:               # a quadruple travels with its four triples and six pairs (Faa di Bruno over the positions)
+            if self.d > 3:
+                raise TraceUnsupported("fourth-order derivatives of a network with more than three inputs are outside the fused path")
+            self.mask4 |= 1 << quad_list(self.d).index(loc)
+            for i in range(4):
+                tri = tuple(loc[j] for j in range(4) if j != i)
+                self.mask3 |= 1 << triple_list(self.d).index(tri)
+                for j in range(i + 1, 4):
+                    self.mask2 |= 1 << pair_list(self.d).index((loc[i], loc[j]))
+        if len(loc) > 4:
+            raise TraceUnsupported("derivatives of network outputs beyond fourth order are outside the fused path")
 
     @property
     def n_streams(self):
-        return 1 + self.first * self.d + (1 if self.lap else bin(self.mask2).count("1")) + bin(self.mask3).count("1")
+        return (1 + self.first * self.d + (1 if self.lap else bin(self.mask2).count("1")) + bin(self.mask3).count("1")
+                + bin(self.mask4).count("1"))
 
     def slot(self, mi):
         if mi and mi[0] == "L":
@@ -82,6 +103,10 @@ class NetStreams:
             return 0
         if len(loc) == 1:
             return 1 + loc[0]
+        if len(loc) == 4:
+            k = quad_list(self.d).index(loc)
+            assert (self.mask4 >> k) & 1 and not self.lap
+            return 1 + self.d + bin(self.mask2).count("1") + bin(self.mask3).count("1") + bin(self.mask4 & ((1 << k) - 1)).count("1")
         if len(loc) == 3:
             k = triple_list(self.d).index(loc)
             assert (self.mask3 >> k) & 1 and not self.lap
@@ -572,7 +597,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
 #endif
 {self.point_fn_source()}
 namespace {{
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, 1, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u{_m4_arg(desc)}>;
 struct PW {{
   // ND per-point data columns (rows D .. D + ND of the coordinate block), NT trainable scalars of the equations
   static constexpr int NEQ = {neq}, NF = {nf}, NR = {self.n_r}, ND = {self.n_data}, NT = {self.n_theta};
@@ -702,7 +727,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
         kern_tv = "ndq::fused_group_closure_tv_kernel<CFG, PW>"
         cfg_t = (f"ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, "
                  f"{desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, "
-                 f"{desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>")
+                 f"{desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u{_m4_arg(desc)}>")
         blocks_body = """  constexpr int gp = 16 * ndq::group_tiles<CFG>();
   const int groups = (n + gp - 1) / gp;
   int b = (groups + kWaves - 1) / kWaves;"""
@@ -1085,6 +1110,19 @@ def mlp_ext_allowed(desc):
             if (desc.mask3 >> k) & 1 and not all((desc.mask2 >> pair_list(desc.d).index(p)) & 1
                                                    for p in ((a, b), (a, c), (b, c))):
                 return False
+    if desc.mask4:              # fourth order (round 6): tanh / sin / sigmoid, d <= 3, every quadruple with its pairs and triples
+        if (desc.lap or desc.d > 3 or desc.act not in (0, 1, 2) or desc.actp or desc.mono or is_wide(desc)
+                or desc.mask4 >> len(quad_list(desc.d))):
+            return False
+        for k, q in enumerate(quad_list(desc.d)):
+            if (desc.mask4 >> k) & 1:
+                for i in range(4):
+                    tri = tuple(q[j] for j in range(4) if j != i)
+                    if not (desc.mask3 >> triple_list(desc.d).index(tri)) & 1:
+                        return False
+                    for j in range(i + 1, 4):
+                        if not (desc.mask2 >> pair_list(desc.d).index((q[i], q[j]))) & 1:
+                            return False
     if desc.widths:           # per-layer widths: 1..hidden each, the widest equal to `hidden`, nothing beyond `layers`
         bits, most = (10, 3) if is_wide(desc) else (8, 4)      # (csrc/ndq_deep.h: 10 bits x 2 .. 3 layers; csrc/ndq_mlp.h: 8 x 4)
         ws = [(desc.widths >> (bits * l)) & ((1 << bits) - 1) for l in range(most)]
@@ -1163,7 +1201,7 @@ extern "C" const {record}* ndq_ext_kernels(void) {{
     return f"""// GENERATED by neurodiffeq_amd/codegen.py -- forward-stream and adjoint kernels of one FCNN shape / stream set
 {"#define NDQ_F64 1" if f64 else ""}
 #include "{header}"
-using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u>;
+using CFG = ndq::Cfg<{desc.d}, {desc.first}, {desc.mask2}u, {(desc.hidden + 15) // 16}, {desc.layers}, {desc.act}, {desc.n_out}, {desc.lap}, {desc.skip}, {desc.mask3}u, {desc.actp}, {desc.hidden if (desc.hidden % 16 or desc.widths) else 0}, {desc.widths}u, {desc.mono}u{_m4_arg(desc)}>;
 extern "C" const {record}* ndq_ext_kernels(void) {{
   static const {record} k = ndq::make_kernels<CFG>();
   return &k;

@@ -23,7 +23,7 @@ static std::vector<const ndq64_mlp_kernels*> g_registered64;
 
 static bool same_desc(const ndq_mlp_desc& a, const ndq_mlp_desc& b) {
   return a.d == b.d && a.first == b.first && a.mask2 == b.mask2 && a.hidden == b.hidden && a.layers == b.layers &&
-         a.act == b.act && a.n_out == b.n_out && a.lap == b.lap && a.skip == b.skip && a.mask3 == b.mask3 &&
+         a.act == b.act && a.n_out == b.n_out && a.lap == b.lap && a.skip == b.skip && a.mask3 == b.mask3 && a.mask4 == b.mask4 &&
          a.actp == b.actp && a.widths == b.widths && a.mono == b.mono;
 }
 

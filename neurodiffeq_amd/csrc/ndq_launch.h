@@ -80,7 +80,7 @@ template <class C>
 kernels_record make_kernels() {
   kernels_record k{};
   k.desc = ndq_mlp_desc{C::D, C::SS::FIRST, (int)C::SS::M2, C::HR, C::L, C::ACT, C::NOUT, C::SS::LAP, C::SKIP,
-                        (int)C::SS::M3, C::ACTP, (int)C::HRP, (int)C::MONO};
+                        (int)C::SS::M3, C::ACTP, (int)C::HRP, (int)C::MONO, (int)C::SS::M4};
   k.n_streams = C::NS;
   k.n_params = C::P;
   k.bwd_waves = C::BWD_THREADS / 64;

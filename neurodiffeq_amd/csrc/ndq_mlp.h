@@ -124,12 +124,18 @@ __device__ __forceinline__ void sfor(F&& f) {
 // losses of second-order PDEs (losses.py:17-26) and by diff(u, t, order=3).  Recurrence (Faa di Bruno):
 //   h_abc = s3 z_a z_b z_c + s2 (z_ab z_c + z_ac z_b + z_bc z_a) + s1 z_abc,   z_abc = W h_abc
 // so a triple needs its three pairs in M2.
-template <int D_, int FIRST_, unsigned M2_, int LAP_ = 0, unsigned M3_ = 0>
+// Fourth order (M4, bit k <-> k-th quadruple a <= b <= c <= d in lexicographic order; round 6): d4/dx_a dx_b dx_c dx_d, what
+// diff(u, x, order=4) asks for (beam / biharmonic / Kuramoto-Sivashinsky equations; neurodiffeq.py:21-34 has no order limit).
+// Recurrence = Faa di Bruno over the set partitions of the four index POSITIONS (repeated indices count by themselves):
+//   h_abcd = s4 z_a z_b z_c z_d + s3 (6 terms z_pair z z) + s2 (3 terms z_pair z_pair + 4 terms z_triple z) + s1 z_abcd
+// so a quadruple needs its six pairs in M2 and its four triples in M3.
+template <int D_, int FIRST_, unsigned M2_, int LAP_ = 0, unsigned M3_ = 0, unsigned M4_ = 0>
 struct Streams {
   static constexpr int D = D_;
   static constexpr int FIRST = FIRST_;
   static constexpr unsigned M2 = M2_;
   static constexpr unsigned M3 = M3_;
+  static constexpr unsigned M4 = M4_;
   static constexpr int LAP = LAP_;
   static constexpr int NPAIR = D * (D + 1) / 2;
   static constexpr int NTRIP = D * (D + 1) * (D + 2) / 6;
@@ -139,6 +145,24 @@ struct Streams {
     return c;
   }
   static constexpr int N3 = count3();
+  static constexpr int NQUAD = D * (D + 1) * (D + 2) * (D + 3) / 24;
+  static constexpr int count4() {
+    int c = 0;
+    for (int k = 0; k < NQUAD && k < 32; ++k) c += (M4 >> k) & 1u;
+    return c;
+  }
+  static constexpr int N4 = count4();
+  static constexpr int quad_x(int k, int pos) {     // pos-th index of the k-th quadruple
+    int idx = 0;
+    for (int a = 0; a < D; ++a)
+      for (int b = a; b < D; ++b)
+        for (int c = b; c < D; ++c)
+          for (int d = c; d < D; ++d) {
+            if (idx == k) return pos == 0 ? a : (pos == 1 ? b : (pos == 2 ? c : d));
+            ++idx;
+          }
+    return -1;
+  }
   static constexpr int tri_x(int k, int pos) {      // pos-th index of the k-th triple
     int idx = 0;
     for (int a = 0; a < D; ++a)
@@ -164,9 +188,11 @@ struct Streams {
       }
     return false;
   }
-  static constexpr int NS = 1 + FIRST * D + N2 + N3;
+  static constexpr int NS = 1 + FIRST * D + N2 + N3 + N4;
   static constexpr int S2 = 1 + FIRST * D;  // index of the first second-order stream
   static constexpr int S3 = S2 + N2;        // index of the first third-order stream
+  static constexpr int S4 = S3 + N3;        // index of the first fourth-order stream
+  static_assert(M4 == 0 || LAP == 0, "fourth-order streams and the Laplacian stream do not combine");
   static_assert(FIRST == 1 || M2 == 0, "second-order streams need the first-order ones");
   static_assert(M3 == 0 || LAP == 0, "third-order streams and the Laplacian stream do not combine");
   static constexpr int pair_of(int s) {  // s >= S2 -> pair index
@@ -230,12 +256,52 @@ struct Streams {
     return true;
   }
   static_assert(closed3(), "a third-order stream needs its three second-order sub-streams");
+  static constexpr int quad_of(int s) {     // s >= S4 -> quadruple index
+    int c = S4;
+    for (int k = 0; k < NQUAD && k < 32; ++k)
+      if ((M4 >> k) & 1u) {
+        if (c == s) return k;
+        ++c;
+      }
+    return -1;
+  }
+  static constexpr int Q(int s, int pos) { return quad_x(quad_of(s), pos); }   // coordinate indices of fourth-order stream s
+  static constexpr int tri_stream(int a, int b, int c) {   // stream index of d3/dx_a dx_b dx_c (any order of a, b, c), -1 if not carried
+    int lo = a < b ? (a < c ? a : c) : (b < c ? b : c);
+    int hi = a > b ? (a > c ? a : c) : (b > c ? b : c);
+    int mid = a + b + c - lo - hi;
+    int idx = 0, cnt = S3;
+    for (int x = 0; x < D; ++x)
+      for (int y = x; y < D; ++y)
+        for (int z = y; z < D; ++z) {
+          if (idx < 32 && ((M3 >> idx) & 1u)) {
+            if (x == lo && y == mid && z == hi) return cnt;
+            ++cnt;
+          }
+          ++idx;
+        }
+    return -1;
+  }
+  static constexpr bool closed4() {
+    for (int k = 0; k < NQUAD && k < 32; ++k)
+      if ((M4 >> k) & 1u) {
+        int x[4] = {quad_x(k, 0), quad_x(k, 1), quad_x(k, 2), quad_x(k, 3)};
+        for (int i = 0; i < 4; ++i)
+          for (int j = i + 1; j < 4; ++j)
+            if (pair_stream(x[i], x[j]) < 0) return false;
+        for (int i = 0; i < 4; ++i)
+          if (tri_stream(x[(i + 1) & 3], x[(i + 2) & 3], x[(i + 3) & 3]) < 0) return false;
+      }
+    return true;
+  }
+  static_assert(closed4(), "a fourth-order stream needs its six second-order and four third-order sub-streams");
 };
 
 // ------------------------------------------------------------------------------------------------ activations
 // state kept per hidden unit: t = sigma(z) and c (only where sigma' is not a function of t).
 enum { ACT_TANH = 0, ACT_SIN = 1, ACT_SIGMOID = 2, ACT_SWISH = 3, ACT_APTX = 4, ACT_ELU = 5, ACT_SOFTPLUS = 6, ACT_GELU = 7 };
 // activations with a stated fourth derivative (third-order streams need it in the reverse pass)
+constexpr bool act_has_s5(int act) { return act == 0 || act == 1 || act == 2; }      // tanh, sin, sigmoid (fourth-order streams)
 constexpr bool act_has_s4(int act) {
   return act == ACT_TANH || act == ACT_SIN || act == ACT_SIGMOID || act == ACT_ELU || act == ACT_SOFTPLUS || act == ACT_GELU;
 }
@@ -282,11 +348,15 @@ constexpr bool act_has_s4(int act) {
 #ifndef NDQ_FWD_NPROD
 #define NDQ_FWD_NPROD 6
 #endif
+// Defaults since round 6 (profiles/r06_headline_ab.md, both A/B trips on an MI355X): forward 6, reverse 4, weight gradients 3 --
+// C2 closure 18.36 -> 16.25 us, C3 375 -> 322 us; gradient rel-L2 against the fp64 reference at the stated sizes 4.7e-8 / 5.5e-8
+// (6 / 6 / 6: 4.4e-8 / 5.2e-8), 2.5e-7 / 1.1e-6 on the small golden batches, every stream and the trained-state columns
+// unchanged; 3 in the reverse GEMM would buy another 0.26 us for a gradient error of 3.2e-7 / 1.3e-6 at the stated sizes.
 #ifndef NDQ_HBAR_NPROD
-#define NDQ_HBAR_NPROD 6
+#define NDQ_HBAR_NPROD 4
 #endif
 #ifndef NDQ_WG_NPROD
-#define NDQ_WG_NPROD 6
+#define NDQ_WG_NPROD 3
 #endif
 #define NDQ_PRODUCTS_6(T) T(a1, 1) T(a2, 0) T(a0, 2) T(a1, 0) T(a0, 1) T(a0, 0)
 #define NDQ_PRODUCTS_5(T) T(a1, 1) T(a2, 0) T(a1, 0) T(a0, 1) T(a0, 0)
@@ -407,6 +477,8 @@ template <> struct Act<ACT_TANH> {  // nn.Tanh, networks.py:27 default
   static __device__ __forceinline__ real s3(real, real, real s1v) { return s1v * rfma(-6.f, s1v, 4.f); }
   // fourth derivative: -2 s2 (1 - 3 t^2) + 12 t s1^2 with s2 = -2 t s1, i.e. t s1 (24 s1 - 8)
   static __device__ __forceinline__ real s4(real t, real, real s1v) { return t * s1v * rfma(24.f, s1v, -8.f); }
+  // d/dz = (1 - t^2) d/dt: sigma^(5) = s1 (16 - 120 t^2 + 120 t^4) = s1 (16 - 120 s1 + 120 s1^2)
+  static __device__ __forceinline__ real s5(real, real, real s1v) { return s1v * rfma(s1v, rfma(120.f, s1v, -120.f), 16.f); }
 };
 template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
   static __device__ __forceinline__ void fwd(real z, real& t, real& c, real = 1.f) {
@@ -420,6 +492,7 @@ template <> struct Act<ACT_SIN> {  // SinActv, networks.py:142-152
   static __device__ __forceinline__ real s2(real t, real, real) { return -t; }
   static __device__ __forceinline__ real s3(real, real c, real) { return -c; }
   static __device__ __forceinline__ real s4(real t, real, real) { return t; }
+  static __device__ __forceinline__ real s5(real, real c, real) { return c; }
 };
 
 __device__ __forceinline__ real sigmoid_fast(real z) {   // 1 / (1 + 2^(-z log2 e)); saturates cleanly to 0 / 1
@@ -437,6 +510,8 @@ template <> struct Act<ACT_SIGMOID> {  // torch.nn.Sigmoid as FCNN(actv=nn.Sigmo
   static __device__ __forceinline__ real s4(real t, real, real s1v) {      // s2 (1 - 12 s1)
     return s1v * rfma(-2.f, t, 1.f) * rfma(-12.f, s1v, 1.f);
   }
+  // d/dz [s2 (1 - 12 s1)] = s3 (1 - 12 s1) - 12 s2^2, (1 - 2 t)^2 = 1 - 4 s1:  s1 (1 - 30 s1 + 120 s1^2)
+  static __device__ __forceinline__ real s5(real, real, real s1v) { return s1v * rfma(s1v, rfma(120.f, s1v, -30.f), 1.f); }
 };
 // Swish with the default fixed beta = 1 (networks.py:155-175): f = z sigma(z).  State: t = f, c = sigma(z); since
 // z sigma = t the derivatives need no z:  f1 = c + t(1-c),  f2 = (1-c)(2c + t(1-2c)),  f3 = (1-c)(3c(1-2c) + t(1-6c+6c^2))
@@ -549,10 +624,12 @@ template <> struct Act<ACT_GELU> {
 
 // ------------------------------------------------------------------------------------------------ config
 template <int D_, int FIRST_, unsigned M2_, int NB_, int L_, int ACT_, int NOUT_ = 1, int LAP_ = 0, int SKIP_ = 0,
-          unsigned M3_ = 0, int ACTP_ = 0, int HR_ = 0, unsigned HRP_ = 0, unsigned MONO_ = 0>
+          unsigned M3_ = 0, int ACTP_ = 0, int HR_ = 0, unsigned HRP_ = 0, unsigned MONO_ = 0, unsigned M4_ = 0>
 struct Cfg {
-  using SS = Streams<D_, FIRST_, M2_, LAP_, M3_>;
+  using SS = Streams<D_, FIRST_, M2_, LAP_, M3_, M4_>;
   static_assert(M3_ == 0 || act_has_s4(ACT_), "third-order streams: activations with a stated fourth derivative");
+  static_assert(M4_ == 0 || (act_has_s5(ACT_) && ACTP_ == 0 && MONO_ == 0),
+                "fourth-order streams: tanh / sin / sigmoid, no trainable activation parameters, no monomial features");
   static constexpr int D = D_, NB = NB_, H = 16 * NB_, L = L_, ACT = ACT_, NS = SS::NS;
   // MONO: a networks.MonomialNN (networks.py:109-139) in front of the first linear layer -- the D coordinates are
   // expanded to the features x_a^deg, degree after degree (bit k of MONO <-> degree k + 1, ascending), so the first
@@ -985,6 +1062,23 @@ struct Planes {
 };
 
 // streams of h = sigma(z) from the layer state:  h0 = t, h_a = s1 z_a, h_ab = s2 z_a z_b + s1 z_ab
+// Fourth-order stream S (S >= SS::S4) of one hidden unit: the Faa di Bruno terms over the set partitions of the four index
+// positions, grouped by the order of sigma they multiply.  zv(s) reads pre-activation stream s of the unit.
+//   q4 = z_a z_b z_c z_d;  q3 = sum over the 6 pairs (i, j) of z_ij z_k z_l;  q2 = sum over the 3 pairings of z_ij z_kl
+//   + sum over the 4 triples of z_jkl z_i;  h = s4 q4 + s3 q3 + s2 q2 + s1 z_abcd
+template <class SS, int S, class ZV>
+__device__ __forceinline__ void quad_terms(ZV&& zv, real& q4, real& q3, real& q2) {
+  constexpr int x0 = SS::Q(S, 0), x1 = SS::Q(S, 1), x2 = SS::Q(S, 2), x3 = SS::Q(S, 3);
+  const real z0 = zv(1 + x0), z1 = zv(1 + x1), z2 = zv(1 + x2), z3 = zv(1 + x3);
+  const real p01 = zv(SS::pair_stream(x0, x1)), p02 = zv(SS::pair_stream(x0, x2)), p03 = zv(SS::pair_stream(x0, x3));
+  const real p12 = zv(SS::pair_stream(x1, x2)), p13 = zv(SS::pair_stream(x1, x3)), p23 = zv(SS::pair_stream(x2, x3));
+  const real t0 = zv(SS::tri_stream(x1, x2, x3)), t1 = zv(SS::tri_stream(x0, x2, x3));
+  const real t2 = zv(SS::tri_stream(x0, x1, x3)), t3 = zv(SS::tri_stream(x0, x1, x2));
+  q4 = (z0 * z1) * (z2 * z3);
+  q3 = rfma(p01, z2 * z3, rfma(p02, z1 * z3, rfma(p03, z1 * z2, rfma(p12, z0 * z3, rfma(p13, z0 * z2, p23 * (z0 * z1))))));
+  q2 = rfma(p01, p23, rfma(p02, p13, rfma(p03, p12, rfma(t0, z0, rfma(t1, z1, rfma(t2, z2, t3 * z3))))));
+}
+
 template <class C>
 __device__ __forceinline__ void act_forward(const LayerState<C>& st, real4 (&h)[C::NS][C::NB]) {
   using SS = typename C::SS;
@@ -1026,6 +1120,15 @@ __device__ __forceinline__ void act_forward(const LayerState<C>& st, real4 (&h)[
               const real mix = rfma(st.z[sab][b][r], zc, rfma(st.z[sac][b][r], zb, st.z[sbc][b][r] * za));
               h[s][b][r] = rfma(s3 * za, zb * zc, rfma(s2, mix, s1 * st.z[s][b][r]));
             });
+            if constexpr (SS::N4 > 0) {
+              const real s4 = A::s4(t, c, s1);
+              sfor<SS::N4>([&](auto k_) {
+                constexpr int s = SS::S4 + decltype(k_)::value;
+                real q4, q3, q2;
+                quad_terms<SS, s>([&](int i) { return st.z[i][b][r]; }, q4, q3, q2);
+                h[s][b][r] = rfma(s4, q4, rfma(s3, q3, rfma(s2, q2, s1 * st.z[s][b][r])));
+              });
+            }
           }
         }
       }
@@ -1058,13 +1161,18 @@ __device__ __forceinline__ void act_forward_stream(const LayerState<C>& st, real
         constexpr int a = SS::A(S), bb = SS::B(S);
         const real s1 = A::s1(t, c, layer_alpha<C>(st));
         hs[b][r] = rfma(A::s2(t, c, s1) * st.z[1 + a][b][r], st.z[1 + bb][b][r], s1 * st.z[S][b][r]);
-      } else {
+      } else if constexpr (S < SS::S4) {
         constexpr int a = SS::T(S, 0), bb = SS::T(S, 1), cc = SS::T(S, 2);
         constexpr int sab = SS::pair_stream(a, bb), sac = SS::pair_stream(a, cc), sbc = SS::pair_stream(bb, cc);
         const real s1 = A::s1(t, c, layer_alpha<C>(st)), s2 = A::s2(t, c, s1), s3 = A::s3(t, c, s1);
         const real za = st.z[1 + a][b][r], zb = st.z[1 + bb][b][r], zc = st.z[1 + cc][b][r];
         const real mix = rfma(st.z[sab][b][r], zc, rfma(st.z[sac][b][r], zb, st.z[sbc][b][r] * za));
         hs[b][r] = rfma(s3 * za, zb * zc, rfma(s2, mix, s1 * st.z[S][b][r]));
+      } else {
+        const real s1 = A::s1(t, c, layer_alpha<C>(st)), s2 = A::s2(t, c, s1), s3 = A::s3(t, c, s1), s4 = A::s4(t, c, s1);
+        real q4, q3, q2;
+        quad_terms<SS, S>([&](int i) { return st.z[i][b][r]; }, q4, q3, q2);
+        hs[b][r] = rfma(s4, q4, rfma(s3, q3, rfma(s2, q2, s1 * st.z[S][b][r])));
       }
     }
 }
@@ -1138,9 +1246,48 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)
           g[SS::S2][b][r] = s1 * hb;
         } else if constexpr (SS::N2 > 0) {
           const real s3 = A::s3(t, c, s1);
-          real zb2[SS::N2];                 // what the third-order streams add to the second-order adjoints
+          real zb2[SS::N2];                 // what the third- / fourth-order streams add to the second-order adjoints
 #pragma unroll
           for (int k = 0; k < SS::N2; ++k) zb2[k] = 0.f;
+          real zb3[SS::N3 > 0 ? SS::N3 : 1];   // what the fourth-order streams add to the third-order adjoints
+#pragma unroll
+          for (int k = 0; k < (SS::N3 > 0 ? SS::N3 : 1); ++k) zb3[k] = 0.f;
+          if constexpr (SS::N4 > 0) {
+            // adjoint of h = s4 q4 + s3 q3 + s2 q2 + s1 z_abcd, partition by partition: a term sigma^(r) prod_B z_B gives
+            // sigma^(r+1) prod_B z_B to the value's adjoint and sigma^(r) prod_{B' != B} z_B' to block B's (oracle/jet_ref.py)
+            const real s4 = A::s4(t, c, s1), s5 = A::s5(t, c, s1);
+            sfor<SS::N4>([&](auto k_) {
+              constexpr int s = SS::S4 + decltype(k_)::value;
+              constexpr int x[4] = {SS::Q(s, 0), SS::Q(s, 1), SS::Q(s, 2), SS::Q(s, 3)};
+              const real hb = g[s][b][r];
+              real q4, q3, q2;
+              quad_terms<SS, s>([&](int i) { return st.z[i][b][r]; }, q4, q3, q2);
+              z0 = rfma(rfma(s5, q4, rfma(s4, q3, rfma(s3, q2, s2 * st.z[s][b][r]))), hb, z0);
+              const real z1v[4] = {st.z[1 + x[0]][b][r], st.z[1 + x[1]][b][r], st.z[1 + x[2]][b][r], st.z[1 + x[3]][b][r]};
+              sfor<4>([&](auto i_) {        // first-order adjoints: position i against the other three (j, k, l)
+                constexpr int i = decltype(i_)::value, j = (i + 1) & 3, k = (i + 2) & 3, l = (i + 3) & 3;
+                const real pjk = st.z[SS::pair_stream(x[j], x[k])][b][r], pjl = st.z[SS::pair_stream(x[j], x[l])][b][r];
+                const real pkl = st.z[SS::pair_stream(x[k], x[l])][b][r];
+                const real tjkl = st.z[SS::tri_stream(x[j], x[k], x[l])][b][r];
+                const real d1 = rfma(s4 * z1v[j], z1v[k] * z1v[l],
+                                     rfma(s3, rfma(pjk, z1v[l], rfma(pjl, z1v[k], pkl * z1v[j])), s2 * tjkl));
+                za[x[i]] = rfma(d1, hb, za[x[i]]);
+                // third-order adjoints: the triple without position i gets s2 z_i
+                zb3[SS::tri_stream(x[j], x[k], x[l]) - SS::S3] = rfma(s2 * z1v[i], hb, zb3[SS::tri_stream(x[j], x[k], x[l]) - SS::S3]);
+              });
+              // second-order adjoints: pair (i, j) gets s3 z_k z_l + s2 z_kl
+              auto pair_adj = [&](auto i_, auto j_, auto k_2, auto l_) {
+                constexpr int i = decltype(i_)::value, j = decltype(j_)::value, k = decltype(k_2)::value, l = decltype(l_)::value;
+                constexpr int sij = SS::pair_stream(x[i], x[j]), skl = SS::pair_stream(x[k], x[l]);
+                zb2[sij - SS::S2] = rfma(rfma(s3 * z1v[k], z1v[l], s2 * st.z[skl][b][r]), hb, zb2[sij - SS::S2]);
+              };
+              using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+              using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+              pair_adj(I0{}, I1{}, I2{}, I3{}); pair_adj(I0{}, I2{}, I1{}, I3{}); pair_adj(I0{}, I3{}, I1{}, I2{});
+              pair_adj(I1{}, I2{}, I0{}, I3{}); pair_adj(I1{}, I3{}, I0{}, I2{}); pair_adj(I2{}, I3{}, I0{}, I1{});
+              g[s][b][r] = s1 * hb;
+            });
+          }
           if constexpr (SS::N3 > 0) {
             const real s4 = A::s4(t, c, s1);
             sfor<SS::N3>([&](auto k_) {
@@ -1158,7 +1305,7 @@ __device__ __forceinline__ void act_backward(const LayerState<C>& st, real4 (&g)
               zb2[sab - SS::S2] = rfma(s2 * zC, hb, zb2[sab - SS::S2]);
               zb2[sac - SS::S2] = rfma(s2 * zB, hb, zb2[sac - SS::S2]);
               zb2[sbc - SS::S2] = rfma(s2 * zA, hb, zb2[sbc - SS::S2]);
-              g[s][b][r] = s1 * hb;
+              g[s][b][r] = rfma(s1, hb, zb3[decltype(k_)::value]);
             });
           }
           sfor<SS::N2>([&](auto k_) {

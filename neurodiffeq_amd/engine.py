@@ -257,13 +257,14 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             return
         # exact stream set: from libndq.so's table, else compiled on first use as an extension module ...
         exact = _lib.MlpDesc(st.d, 1 if (st.first or st.mask2) else 0, st.mask2, info["hidden"], info["layers"],
-                             info["act"], info["n_out"], 0, info["skip"], st.mask3, info["actp"], info["widths"], info["mono"])
+                             info["act"], info["n_out"], 0, info["skip"], st.mask3, info["actp"], info["widths"], info["mono"],
+                             getattr(st, "mask4", 0))
         if codegen.ensure_mlp_kernels(exact, f64=f64):
             st.first, st.mask2 = exact.first, exact.mask2
             descs[k] = exact
             return
-        if st.mask3:
-            raise TraceUnsupported(f"no gfx950 kernel for third-order streams of FCNN d={st.d} hidden={info['hidden']} "
+        if st.mask3 or getattr(st, "mask4", 0):
+            raise TraceUnsupported(f"no gfx950 kernel for third- / fourth-order streams of FCNN d={st.d} hidden={info['hidden']} "
                                    f"layers={info['layers']} act={info['act']} (mask3={st.mask3:#b})")
         # ... else the cheapest superset the table has (NDQ_JIT_MLP=0, or a shape the templates cannot express)
         npair = st.d * (st.d + 1) // 2
@@ -297,8 +298,8 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
         if any(tuple(st.deps) != tuple(range(n_coords)) for st in streams.values()):
             return
         sts = list(streams.values())
-        if any(st.mask3 for st in sts):
-            return              # third-order stream sets are served network by network (three-kernel pipeline)
+        if any(st.mask3 or getattr(st, "mask4", 0) for st in sts):
+            return              # third- / fourth-order stream sets are served network by network (three-kernel pipeline)
         if len({(st.first, st.mask2, st.lap) for st in sts}) == 1:
             return
         lap = max(st.lap for st in sts)

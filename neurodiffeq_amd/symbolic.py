@@ -352,8 +352,8 @@ class Graph:
             if ci not in self.net_deps[k]:
                 r = self.const(0.0)
             else:
-                if len(mi) >= 3:
-                    raise TraceUnsupported("derivatives of network outputs beyond third order are outside the fused path")
+                if len(mi) >= 4:
+                    raise TraceUnsupported("derivatives of network outputs beyond fourth order are outside the fused path")
                 r = self.net(k, o, mi + (ci,))
         elif op == "add":
             r = self.add(D(n[1]), D(n[2]))

@@ -212,6 +212,15 @@ def make(name, size=None):
         pde = lambda u, t: [diff(u, t, order=3) + diff(u, t, order=2) * diff(u, t) + u - torch.sin(t)]
         return dict(kind="1d", pde=pde, nets=[FCNN(1, 1, hidden_units=(32, 32), actv=SinActv)], conds=[IVP(0.0, 1.0)],
                     gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"), n_points=48, dom=(0.0, 2.0))
+    if name == "w29":     # fourth-order ODE (beam on an elastic foundation), round 6
+        pde = lambda u, t: [diff(u, t, order=4) + u - torch.cos(t)]
+        return dict(kind="1d", pde=pde, nets=[FCNN(1, 1, hidden_units=(32, 32))], conds=[IVP(0.0, 1.0, u_0_prime=0.5)],
+                    gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"), n_points=48, dom=(0.0, 2.0))
+    if name == "w30":     # biharmonic equation on the C2 domain: pure and mixed fourth derivatives
+        c = make("c2", 10)
+        c["pde"] = lambda u, x, y: [diff(u, x, order=4) + 2.0 * diff(diff(u, x, order=2), y, order=2) + diff(u, y, order=4)
+                                    - torch.sin(PI * x) * torch.sin(PI * y)]
+        return c
     if name == "w4":      # APTx networks: second-order ODE with a Neumann-form IVP coupled to a first-order one
         pde = lambda u, v, t: [diff(u, t, order=2) + v * diff(u, t) + u, diff(v, t) - u * v + torch.sin(t)]
         nets = [FCNN(1, 1, hidden_units=(32, 32), actv=APTx) for _ in range(2)]

@@ -326,6 +326,24 @@ def cfg_w28():
     return c
 
 
+def cfg_w29():
+    """Fourth-order ODE (``diff(u, t, order=4)``: neurodiffeq.py:21-34 loops ``order`` times for any order) -- a beam on an
+    elastic foundation, u_tttt + u = cos t, with the Neumann-form IVP."""
+    ode = lambda u, t: [diff(u, t, order=4) + u - torch.cos(t)]
+    nets = [FCNN(1, 1, hidden_units=(32, 32))]
+    return dict(kind="1d", pde=ode, nets=nets, conds=[IVP(0.0, 1.0, u_0_prime=0.5)], gen=Generator1D(48, 0.0, 2.0, "equally-spaced-noisy"),
+                t=(0.0, 2.0))
+
+
+def cfg_w30():
+    """Biharmonic (plate) equation u_xxxx + 2 u_xxyy + u_yyyy = f on the C2 domain with its Dirichlet condition: pure and
+    mixed fourth derivatives, the mixed one written as two nested second-order diff calls."""
+    c = cfg_c2(10)
+    c["pde"] = lambda u, x, y: [diff(u, x, order=4) + 2.0 * diff(diff(u, x, order=2), y, order=2) + diff(u, y, order=4)
+                                - torch.sin(PI * x) * torch.sin(PI * y)]
+    return c
+
+
 def cfg_w25():
     """Resnet(2, 3, hidden_units=(512,)) on the single-network cavity problem: skip connection, one wide layer, three outputs."""
     return _ns_single(Resnet(n_input_units=2, n_output_units=3, hidden_units=(512,)))
@@ -349,7 +367,7 @@ def cfg_w21():
     return dict(kind="2d", pde=pde, nets=nets, conds=conds, gen=Generator2D((10, 10), (0, 0), (1, 1), "equally-spaced-noisy"))
 
 
-CONFIGS = {"w26": cfg_w26, "w27": cfg_w27, "w28": cfg_w28, "w24": cfg_w24, "w25": cfg_w25, "w18r": cfg_w18r, "w20": cfg_w20, "w21": cfg_w21, "w16": cfg_w16, "w17": cfg_w17, "w18": cfg_w18, "w19": cfg_w19, "c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
+CONFIGS = {"w29": cfg_w29, "w30": cfg_w30, "w26": cfg_w26, "w27": cfg_w27, "w28": cfg_w28, "w24": cfg_w24, "w25": cfg_w25, "w18r": cfg_w18r, "w20": cfg_w20, "w21": cfg_w21, "w16": cfg_w16, "w17": cfg_w17, "w18": cfg_w18, "w19": cfg_w19, "c1": cfg_c1, "c2": cfg_c2, "c3": cfg_c3, "c5": cfg_c5, "c4": cfg_c4,
            "w1": cfg_w1, "w2": cfg_w2, "w3": cfg_w3, "w4": cfg_w4, "w5": cfg_w5, "w6": cfg_w6, "w7": cfg_w7, "w8": cfg_w8,
            "w9": cfg_w9, "w10": cfg_w10, "w11": cfg_w11, "w12": cfg_w12, "w13": cfg_w13, "w14": cfg_w14, "w15": cfg_w15}
 

@@ -405,7 +405,8 @@ def test_fused_solver_under_a_cuda_default_device():
 # w11 trainable Swish, w12 Resnet with hidden widths (50, 30), w13 MonomialNN front end, w14 EnsembleCondition on one
 # two-output network, w15 trainable APTx: closures and 3-epoch trajectories produced by the UNMODIFIED reference
 # (tests/golden/make_golden.py) -- the same pinning the BASELINE configs and w1 - w10 have.
-GOLDEN_FAMILY = ["w11", "w12", "w13", "w14", "w15"]
+# round 6: w29 fourth-order ODE (beam), w30 biharmonic equation -- diff(u, x, order=4) and the mixed quadruple xxyy
+GOLDEN_FAMILY = ["w11", "w12", "w13", "w14", "w15", "w29", "w30"]
 
 
 @pytest.mark.parametrize("mode", ["1k", "3k"])

@@ -65,6 +65,23 @@ ARCH_T3 = {
 }
 
 
+# fourth-order streams (round 6; (d, first, mask2, mask3, mask4)): the beam set of one input (tanh, sin with three layers,
+# sigmoid with two outputs), the biharmonic set of two inputs (every pair and triple; quadruples xxxx, xxyy, yyyy), the
+# Kuramoto-Sivashinsky set (x-derivatives only of a 2-D network) and the FULL set of two inputs (all five quadruples)
+ARCH_T4 = {
+    "t4beam": ((1, 32, 32, 1), "tanh", 0, (1, 1, 1, 1, 1), [(), (0,), (0, 0), (0, 0, 0), (0, 0, 0, 0)]),
+    "t4sin3": ((1, 32, 32, 32, 1), "sin", 1, (1, 1, 1, 1, 1), [(), (0,), (0, 0), (0, 0, 0), (0, 0, 0, 0)]),
+    "t4sig2out": ((1, 32, 32, 2), "sigmoid", 2, (1, 1, 1, 1, 1), [(), (0,), (0, 0), (0, 0, 0), (0, 0, 0, 0)]),
+    "t4ks": ((2, 32, 32, 1), "tanh", 0, (2, 1, 1, 1, 1), [(), (0,), (1,), (0, 0), (0, 0, 0), (0, 0, 0, 0)]),
+    "t4biharm": ((2, 32, 32, 1), "tanh", 0, (2, 1, 7, 15, 21),
+                 [(), (0,), (1,), (0, 0), (0, 1), (1, 1), (0, 0, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1),
+                  (0, 0, 0, 0), (0, 0, 1, 1), (1, 1, 1, 1)]),
+    "t4full2": ((2, 16, 16, 1), "sin", 1, (2, 1, 7, 15, 31),
+                [(), (0,), (1,), (0, 0), (0, 1), (1, 1), (0, 0, 0), (0, 0, 1), (0, 1, 1), (1, 1, 1),
+                 (0, 0, 0, 0), (0, 0, 0, 1), (0, 0, 1, 1), (0, 1, 1, 1), (1, 1, 1, 1)]),
+}
+
+
 def _parts(m):
     """oracle streams making up kernel stream m"""
     return [(c, c) for c in m[1:]] if (m and m[0] == "L") else [m]
@@ -108,7 +125,8 @@ def _desc(name):
     dims, _, act, spec, _ = ARCH[name]
     d, first, mask2 = spec[:3]
     lap = int(any(m and m[0] == "L" for m in ARCH[name][4]))
-    return _lib.MlpDesc(d, first, mask2, dims[1], len(dims) - 2, act, dims[-1], lap, 0, spec[3] if len(spec) > 3 else 0)
+    return _lib.MlpDesc(d, first, mask2, dims[1], len(dims) - 2, act, dims[-1], lap, 0, spec[3] if len(spec) > 3 else 0,
+                        0, 0, 0, spec[4] if len(spec) > 4 else 0)
 
 
 def _stream():
@@ -219,6 +237,38 @@ def test_third_order_stream_kernels_match_jet_oracle(L, name, n):
         assert max(errs.values()) < TOL, errs
     finally:
         for k in ARCH_T3:
+            ARCH.pop(k, None)
+
+
+@pytest.mark.parametrize("name", list(ARCH_T4))
+@pytest.mark.parametrize("n", [17, 1000])
+def test_fourth_order_stream_kernels_match_jet_oracle(L, name, n):
+    """Fourth-order derivative streams (ndq_mlp_desc.mask4; VERDICT r5 missing #2: diff(u, x, order=4) -- beam, biharmonic,
+    Kuramoto-Sivashinsky): forward values of every stream and the parameter gradient given adjoints of ALL streams (so the
+    adjoint contributions of a quadruple to its triples, pairs and first-order streams are exercised), against the numpy jet
+    oracle (general Faa di Bruno over set partitions; itself checked against four nested autograd sweeps on the CPU)."""
+    from neurodiffeq_amd import codegen
+    ARCH.update(ARCH_T4)
+    try:
+        d = _desc(name)
+        assert d.mask4 == ARCH[name][3][4]
+        assert codegen.ensure_mlp_kernels(d) and L.ndq_mlp_supported(ctypes.byref(d)) == 1
+        dims, act, _, _, streams = ARCH[name]
+        assert L.ndq_mlp_num_streams(ctypes.byref(d)) == len(streams)
+        rng = np.random.default_rng(zlib.crc32(f"{name}/{n}".encode()))
+        flat = _params(name, rng)
+        coords = rng.uniform(-1.0, 1.0, (dims[0], n)).astype(np.float32)
+        got = _fwd(L, name, coords, flat)
+        want = _oracle_jets(flat, dims, act, coords, streams)
+        floor = (0.1 if n < 64 else 0.0) * np.sqrt(n * dims[-1]) * max(np.sqrt(np.mean(want[m] ** 2)) for m in streams)
+        errs = {str(m): float(np.linalg.norm(got[s].T - want[m]) / max(np.linalg.norm(want[m]), floor))
+                for s, m in enumerate(streams)}
+        gbar = rng.standard_normal((len(streams), dims[-1], n)).astype(np.float32)
+        errs["grad"] = rel_l2(_bwd(L, name, coords, flat, gbar), _oracle_vjp(flat, dims, act, coords, streams, gbar))
+        diag(f"t4_{name}_{n}", errs)
+        assert max(errs.values()) < TOL, errs
+    finally:
+        for k in ARCH_T4:
             ARCH.pop(k, None)
 
 
@@ -582,7 +632,9 @@ def _lib_check(rc):
                                   "piecewise_source", "relu_ode", "atan2_adv",
                                   # round 5, second batch: rounding functions, torch.nn.functional activations, inverse / special functions
                                   "rounding_ode", "activations_ode", "special_2d",
-                                  "autograd_grad_ode"])       # torch.autograd.grad written out by hand in the equation
+                                  "autograd_grad_ode",        # torch.autograd.grad written out by hand in the equation
+                                  # round 6: fourth-order streams -- diff(u, x, order=4)
+                                  "beam", "beam_sigmoid", "biharmonic", "kuramoto"])
 def test_zoo_closure_matches_autograd_oracle(name, mode):
     """Systems outside the BASELINE set (tests/zoo.py): second-order IVP, sin networks, mixed second derivatives, first
     order only, three coordinates (Laplacian-merged, diagonal and full Hessian stream sets), three networks."""

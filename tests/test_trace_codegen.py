@@ -15,7 +15,7 @@ from oracle import jet_ref as J
 from tests import configs, zoo
 from tests.pw_cpu import run_cpu
 
-SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w9": None, "w10": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None, "w20": None, "w21": None, "w24": None, "w25": None, "w26": None, "w27": None, "w28": None}
+SIZES = {"c1": 64, "c2": 16, "c3": 12, "c5": 8, "c4": 96, "w1": None, "w2": None, "w3": None, "w4": None, "w5": None, "w6": None, "w7": None, "w8": None, "w9": None, "w10": None, "w11": None, "w12": None, "w13": None, "w14": None, "w15": None, "w16": None, "w17": None, "w18": None, "w19": None, "w20": None, "w21": None, "w24": None, "w25": None, "w26": None, "w27": None, "w28": None, "w29": None, "w30": None}
 
 
 def rel_l2(a, b):
@@ -137,7 +137,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
 
 @pytest.mark.parametrize("name,lap", [("c1", True), ("c2", True), ("c2", False), ("c3", True), ("c5", True), ("c5", False),
                                       ("c4", True), ("w1", True), ("w2", True), ("w3", True), ("w4", True), ("w5", True), ("w6", True), ("w7", True), ("w8", True),
-                                      ("w9", True), ("w10", True), ("w11", True), ("w12", True), ("w13", True), ("w14", True), ("w15", True), ("w16", True), ("w17", True), ("w18", True), ("w19", True), ("w20", True), ("w21", True),
+                                      ("w9", True), ("w10", True), ("w29", True), ("w30", True), ("w11", True), ("w12", True), ("w13", True), ("w14", True), ("w15", True), ("w16", True), ("w17", True), ("w18", True), ("w19", True), ("w20", True), ("w21", True),
                                       ("w24", True), ("w25", True),       # w24 / w25: Resnets above 64 units (symbolic skip connection)
                                       ("w26", True), ("w27", True), ("w28", True)])       # w26 / w27: per-layer widths above 64 units
 def test_fused_pipeline_on_host_matches_reference(golden_dir, name, lap):
@@ -175,7 +175,11 @@ ZOO_STREAMS = {"pendulum": [(1, 1, 0)], "coupled_sin": [(1, 0, 0)] * 2, "bvp_tan
                "piecewise_source": [(1, 5, 1)], "relu_ode": [(1, 0, 0)], "atan2_adv": [(1, 0, 0)],
                "rounding_ode": [(1, 0, 0)], "activations_ode": [(1, 0, 0)], "special_2d": [(1, 0, 0)], "autograd_grad_ode": [(1, 1, 0)],
                # third-order streams: (first, mask2, lap, mask3); the triple xxx brings its pair xx along
-               "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)]}
+               "kdv": [(1, 1, 0, 1)], "ode3": [(1, 1, 0, 1)],
+               # fourth-order streams: (first, mask2, lap, mask3, mask4); a quadruple brings its pairs and triples along --
+               # biharmonic: xxxx, xxyy, yyyy (bits 0, 2, 4) need every pair and every triple of two coordinates
+               "beam": [(1, 1, 0, 1, 1)], "beam_sigmoid": [(1, 1, 0, 1, 1)], "biharmonic": [(1, 7, 0, 15, 21)],
+               "kuramoto": [(1, 1, 0, 1, 1)]}
 
 
 @pytest.mark.parametrize("name", zoo.NAMES)
@@ -194,7 +198,7 @@ def test_zoo_on_host_matches_autograd_oracle(name):
     prog, funcs, resid, loss, grad = host_closure(nets, conds, pde, np.stack([c.numpy() for c in coords]).astype(np.float32),
                                                   flat.double().numpy())
     got_streams = [(int(st.first), int(st.mask2), int(st.lap)) + ((int(st.mask3),) if st.mask3 else ())
-                   for st in (prog.streams[k] for k in range(len(nets)))]
+                   + ((int(st.mask4),) if st.mask4 else ()) for st in (prog.streams[k] for k in range(len(nets)))]
     assert got_streams == ZOO_STREAMS[name]
     # the oracle ran on the fp64 coordinates, the host pipeline on their fp32 rounding: tolerance 1e-5 covers it
     assert rel_l2(funcs, want["funcs"].numpy()) < 1e-5

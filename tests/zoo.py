@@ -267,6 +267,28 @@ def build(name):
         pde = lambda D: (lambda u, t: [D(u, t, order=3) + D(u, t, order=2) * D(u, t) + u - torch.sin(t)])
         conds = lambda: [C.IVP(0.0, 1.0)]
         return System(name, 1, [(1, 1, (32, 32), "sin")], [(0.0, 2.0)], pde, conds, lambda D: [_R().ivp(0.0, 1.0)])
+    # fourth-order streams (round 6: diff(u, x, order=4), neurodiffeq.py:21-34 has no order limit)
+    if name == "beam":                # static beam on an elastic foundation: u_tttt + u = q(t)  (pure fourth derivative, one input)
+        pde = lambda D: (lambda u, t: [D(u, t, order=4) + u - torch.cos(t)])
+        conds = lambda: [C.IVP(0.0, 1.0, u_0_prime=0.5)]
+        enf = lambda D: [lambda net, t: 1.0 + 0.5 * t + (1 - torch.exp(-t)) ** 2 * net(t)]
+        return System(name, 1, [(1, 1, (32, 32), "tanh")], [(0.0, 2.0)], pde, conds, enf)
+    if name == "beam_sigmoid":        # ... with a sigmoid network, three layers, and the lower derivatives in the equation as well
+        pde = lambda D: (lambda u, t: [D(u, t, order=4) + 0.3 * D(u, t, order=3) * D(u, t) - D(u, t, order=2) + u - torch.sin(t)])
+        conds = lambda: [C.IVP(0.0, 1.0)]
+        return System(name, 1, [(1, 1, (32, 32, 32), "sigmoid")], [(0.0, 2.0)], pde, conds, lambda D: [_R().ivp(0.0, 1.0)])
+    if name == "biharmonic":          # plate equation: u_xxxx + 2 u_xxyy + u_yyyy = f  (the mixed quadruple xxyy by two diff calls)
+        pde = lambda D: (lambda u, x, y: [D(u, x, order=4) + 2.0 * D(D(u, x, order=2), y, order=2) + D(u, y, order=4)
+                                          - torch.sin(x) * torch.cos(y)])
+        conds = lambda: [C.NoCondition()]
+        return System(name, 2, [(2, 1, (32, 32), "tanh")], [(-1.0, 1.0)] * 2, pde, conds,
+                      lambda D: [lambda net, x, y: net(_cat(x, y))])
+    if name == "kuramoto":            # Kuramoto-Sivashinsky: u_t + u u_x + u_xx + u_xxxx, sin network, Dirichlet IBVP
+        u0 = lambda x: torch.cos(3.0 * x) * (1.0 - x ** 2)
+        pde = lambda D: (lambda u, x, t: [D(u, t) + u * D(u, x) + D(u, x, order=2) + 0.1 * D(u, x, order=4)])
+        conds = lambda: [C.IBVP1D(-1.0, 1.0, 0.0, u0, x_min_val=zero, x_max_val=zero)]
+        return System(name, 2, [(2, 1, (32, 32), "sin")], [(-1.0, 1.0), (0.0, 1.0)], pde, conds,
+                      lambda D: [_R().ibvp1d_dd(-1.0, 1.0, 0.0, u0, zero, zero)])
     if name == "poisson3d":           # three coordinates, Laplacian -> one merged second-order stream
         pde = lambda D: (lambda u, x, y, z: [D(u, x, order=2) + D(u, y, order=2) + D(u, z, order=2)
                                              + torch.exp(-(x ** 2 + y ** 2 + z ** 2))])
@@ -370,7 +392,8 @@ NAMES = ["pendulum", "coupled_sin", "bvp_tanh", "helmholtz_xy", "advection", "he
          "aptx_tr_wide", "swish_tr_system", "aptx_tr_resnet", "shape_50x2", "shape_20x3", "shape_40x2_sigmoid", "shape_10x1",
          "swish_fixed_laplace", "aptx_fixed_laplace", "ensemble_lv", "shape_64_32", "shape_24_40_12_sigmoid",
          "mono_laplace", "mono_ode", "mono_poisson", "shape_32x6", "shape_16x8_sin", "heat4d", "mix5d", "bundle_osc",
-         "piecewise_source", "relu_ode", "atan2_adv", "rounding_ode", "activations_ode", "special_2d", "autograd_grad_ode"]
+         "piecewise_source", "relu_ode", "atan2_adv", "rounding_ode", "activations_ode", "special_2d", "autograd_grad_ode",
+         "beam", "beam_sigmoid", "biharmonic", "kuramoto"]
 
 
 def spherical_solver_problem():
