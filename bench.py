@@ -713,12 +713,15 @@ def main():
                                # the kernel carries u_xx + u_yy as ONE "Laplacian" stream when the tracer proves the
                                # residual only needs the sum, i.e. it executes 4 streams instead of SURVEY's 5
                                "executed_streams": system.program.streams[0].n_streams,
-                               # every GEMM of the kernel (forward, hbar, and since r03 the weight gradients too) runs as 6
-                               # bf16 plane products on the bf16 matrix core; the yardstick stays the fp32 MFMA peak the
-                               # earlier rounds were priced against, the dense bf16 peak / 6 is given beside it
-                               "peak_note": "fp32 MFMA peak (157.3 TFLOP/s); the kernel's GEMMs are bf16x3 (6 bf16 MFMA "
-                                            "products per fp32-class product): ceiling of that format 2500 / 6 = 416.7 TFLOP/s",
-                               "frac_of_bf16x3_ceiling": kb["fused_closure"]["tflops"] / (2500.0 / 6.0),
+                               # every GEMM of the kernel runs as bf16 plane products on the bf16 matrix core: 6 per
+                               # fp32-class product in the forward GEMMs, 4 in the reverse ones, 3 in the weight gradients
+                               # since round 6 (profiles/r06_headline_ab.md); the yardstick stays the fp32 MFMA peak the
+                               # earlier rounds were priced against, the dense bf16 peak over the average 13 / 3 products
+                               # is given beside it
+                               "peak_note": "fp32 MFMA peak (157.3 TFLOP/s); the kernel's GEMMs are split-bf16 (6 / 4 / 3 bf16 MFMA "
+                                            "products per fp32-class product in the forward / reverse / weight-gradient GEMMs): "
+                                            "ceiling of that mix 2500 / (13 / 3) = 576.9 TFLOP/s",
+                               "frac_of_bf16x3_ceiling": kb["fused_closure"]["tflops"] / (2500.0 * 3.0 / 13.0),
                                "executed_gemm_flop_per_point":
                                    3 * 2 * (32 * 2 + 32 * 32 * system.program.streams[0].n_streams
                                             + 32 * system.program.streams[0].n_streams)}
@@ -741,7 +744,7 @@ def main():
             rf["avg_launch_us_back_to_back_hip_events"], rf["frac_back_to_back"] = rf["avg_launch_us"], rf["frac"]
             tfl = (FWD_FLOP_PER_PT + BWD_FLOP_PER_PT) * N_POINTS / (situ["closure_us"] * 1e-6) / 1e12
             rf.update(achieved=tfl, frac=tfl / FP32_MFMA_PEAK_TFLOPS, avg_launch_us=situ["closure_us"],
-                      frac_of_bf16x3_ceiling=tfl / (2500.0 / 6.0), in_situ=situ,
+                      frac_of_bf16x3_ceiling=tfl / (2500.0 * 3.0 / 13.0), in_situ=situ,
                       timing_note="avg_launch_us / achieved / frac: rocprofv3 --kernel-trace of THIS run over 300 training "
                                   "steps (the kernel between the tails of successive epochs); *_back_to_back: HIP events "
                                   "around 1 000 launches of the kernel alone")

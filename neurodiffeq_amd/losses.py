@@ -4,7 +4,7 @@
 fused gfx950 path evaluates them (and their adjoint seeds) inside the generated pointwise code.  The Sobolev norms are
 the l2 loss of the residual list extended by d(sum_e r_e)/dx_a; the solver traces them that way: first-order systems
 stay within second-order network streams, second-order PDEs use the third-order streams (``ndq_mlp_desc.mask3``: tanh /
-sin / sigmoid networks) -- only what would need fourth-order streams runs on the composite path."""
+sin / sigmoid networks) -- third-order equations use the fourth-order streams (round 6); only what would need fifth-order streams runs on the composite path."""
 import torch
 
 from .operators import grad

@@ -365,7 +365,7 @@ def test_unsupported_constructs_raise_trace_unsupported():
         # not carry, in-place methods, multi-element constants made from a column
         for bad in (lambda: t - t.mean(), lambda: torch.roll(t, 1, 0), lambda: t.flatten(), lambda: t.squeeze(1), lambda: diff(t.detach(), t),
                     lambda: torch.stack([t, t]), lambda: t.floor_(), lambda: t.new_ones(5), lambda: t[:, 0], lambda: t[3],
-                    lambda: torch.lgamma(t), lambda: torch.nan_to_num(t)):
+                    lambda: torch.lgamma(t), lambda: torch.einsum("ij->i", t), lambda: diff(t ** 5, t, order=1) @ t):
             with pytest.raises(TraceUnsupported):
                 bad()
         # ... and the spellings of "the whole column" / one-element constants that are inside it
