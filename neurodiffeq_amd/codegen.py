@@ -35,6 +35,14 @@ def triple_list(d):
     return [(a, b, c) for a in range(d) for b in range(a, d) for c in range(b, d)]
 
 
+#: bf16 plane products of the single-launch closure kernels' GEMMs (csrc/ndq_mlp.h: NDQ_FWD_NPROD / NDQ_HBAR_NPROD / NDQ_WG_NPROD):
+#: forward 6 (the derivative streams keep fp32 class: 5 puts u_xx of the reference's trained C3 state at 3.2e-5), reverse 4,
+#: weight gradients 3 -- measured against the unmodified reference's fp64 numbers in profiles/r06_headline_ab.md.  The generic
+#: adjoint kernels behind the C-ABI keep all six (arbitrary seeds).  NDQ_JIT_FLAGS may override (A/B runs).
+CLOSURE_PRODUCTS = ("#ifndef NDQ_HBAR_NPROD\n#define NDQ_HBAR_NPROD 4\n#endif\n"
+                    "#ifndef NDQ_WG_NPROD\n#define NDQ_WG_NPROD 3\n#endif\n")
+
+
 def quad_list(d):
     return [(a, b, c, e) for a in range(d) for b in range(a, d) for c in range(b, d) for e in range(c, d)]
 
@@ -586,7 +594,7 @@ NDQ_PW_INLINE float ndq_pw_loss(const float* r) {{ return {term}; }}
         tv = _tv_launcher(args_t, fill, kern_tv, lds('true'), lds('false'), threads, kern_loop, lds_loop)
         # hidden-layer weight gradients from the bf16x3 planes through transposing LDS reads (csrc/ndq_mlp.h Cfg::WG_TR;
         # shapes it does not cover, or whose K images would not fit the LDS, ignore the switch)
-        wg_tr = f"#ifndef NDQ_WG_TR\n#define NDQ_WG_TR 1\n#endif\n#define NDQ_WG_TR_K {K}\n"
+        wg_tr = f"#ifndef NDQ_WG_TR\n#define NDQ_WG_TR 1\n#endif\n#define NDQ_WG_TR_K {K}\n" + CLOSURE_PRODUCTS
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- single-launch closure kernel (forward streams + pointwise stage +
 // reverse pass) of one PDE system with {K} network(s), gfx950.
 #include <cstdlib>
@@ -744,7 +752,7 @@ extern "C" int ndq_fused_launch_multi(const float* coords, int ldc, int n, const
         return f"""// GENERATED by neurodiffeq_amd/codegen.py -- grouped single-launch closure kernel (forward streams -> LDS exchange ->
 // per-point stage, one point per lane -> reverse pass) of one PDE system, gfx950.
 #include <cstdlib>
-#include "{header}"
+{CLOSURE_PRODUCTS}#include "{header}"
 #define NDQ_PW_INLINE __device__ __forceinline__
 #ifndef NDQ_MAX_BLOCKS
 #define NDQ_MAX_BLOCKS 256     // closure workgroups per launch (one per CU; experiments: 512 = two 8-wave workgroups per CU)

@@ -568,6 +568,7 @@ template <class C, int EPI> constexpr int deep_bf_jb() {
 template <class C, int SRC, int EPI>
 __global__ __launch_bounds__(kDeepBfThreads, kDeepBfOcc) void deep_gemm_bf(DeepArgs a) {
   constexpr int JB = deep_bf_jb<C, EPI>(), NCH = (C::NB + JB - 1) / JB, NCK = (C::HP + 31) / 32, NS = C::NS;
+  constexpr int kPlanes = SRC >= 2 ? (NDQ_HBAR_NPROD == 6 ? 3 : 2) : (NDQ_FWD_NPROD == 6 ? 3 : 2);    // planes of the per-point operand
   extern __shared__ __attribute__((aligned(16))) bf16x8 wl[];          // [JB][NCK][3][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, kg = lane >> 4;
   const int vid = xcd_block_id();                          // (the NCH chunks of a stripe share its operand rows: one XCD)
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(kDeepBfThreads, kDeepBfOcc) void deep_gemm_bf(DeepA
         }
       }
 #pragma unroll
-      for (int s = 0; s < NS; ++s) split3(hlo[s], hhi[s], pl[s]);
+      for (int s = 0; s < NS; ++s) split3<kPlanes>(hlo[s], hhi[s], pl[s]);
     };
     fetch(0, false);
     if constexpr (SRC != 0) {
@@ -796,7 +797,9 @@ __global__ __launch_bounds__(kDeepBfThreads, kDeepBfOcc) void deep_gemm_bf(DeepA
 #define NDQ_T(A, K)                                                                                          \
   _Pragma("unroll") for (int s = 0; s < NS; ++s)                                                             \
       acc[s][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, pl[s][K], acc[s][jb], 0, 0, 0);
-        NDQ_T(a1, 1) NDQ_T(a2, 0) NDQ_T(a0, 2) NDQ_T(a1, 0) NDQ_T(a0, 1) NDQ_T(a0, 0)
+        // forward layers: all six plane products (they make the derivative streams); reverse layers: NDQ_HBAR_NPROD of them,
+        // their per-point operand split into two planes (csrc/ndq_mlp.h, profiles/r06_headline_ab.md)
+        if constexpr (SRC >= 2) { NDQ_PRODUCTS_BWD(NDQ_T) } else { NDQ_PRODUCTS_FWD(NDQ_T) }
 #undef NDQ_T
       }
       if (c + 1 < NCK) planes();                           // VALU work of the next step, under the MFMAs in flight
@@ -1138,7 +1141,7 @@ __global__ __launch_bounds__(C::THREADS, 2) void deep_wgrad_gemm(DeepArgs a) {
 // exact-f32 products of 32 cycles (product and VALU time add up for either format: DESIGN.md 4.0).  A wave's last round is
 // padded with groups whose row operand is zero.
 // Accuracy: fp32-class, as for the per-point GEMMs (csrc/ndq_mlp.h); sums in fixed order (per wave, then waves in order).
-template <int E>
+template <int E, int NP = NDQ_HTR_PLANES>
 __device__ __forceinline__ void split3_pair_into(real x0, real x1, bf16x8 (&pl)[3]) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -1146,11 +1149,13 @@ __device__ __forceinline__ void split3_pair_into(real x0, real x1, bf16x8 (&pl)[
   const bf16x2 h0 = __builtin_convertvector(v, bf16x2);
   const f32x2 r1 = v - __builtin_convertvector(h0, f32x2);
   const bf16x2 h1 = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(h1, f32x2);
-  const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
   pl[0][E] = h0[0]; pl[0][E + 1] = h0[1];
   pl[1][E] = h1[0]; pl[1][E + 1] = h1[1];
-  pl[2][E] = h2[0]; pl[2][E + 1] = h2[1];
+  if constexpr (NP == 3) {              // (two planes where no product of the weight-gradient GEMM reads the third: NDQ_WG_NPROD < 6)
+    const f32x2 r2 = r1 - __builtin_convertvector(h1, f32x2);
+    const bf16x2 h2 = __builtin_convertvector(r2, bf16x2);
+    pl[2][E] = h2[0]; pl[2][E + 1] = h2[1];
+  }
 }
 constexpr int deep_wgbf_groups(int ns) {
   int g = 8, a = ns;
@@ -1332,7 +1337,7 @@ __global__ __launch_bounds__(C::THREADS, deep_wgbf_occ(C::NS)) void deep_wgrad_b
   _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                              \
   _Pragma("unroll") for (int v = 0; v < 4; ++v)                                                              \
       acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cA[u][QA], cB[v][QB], acc[u][v], 0, 0, 0);
-          NDQ_WG(1, 1) NDQ_WG(2, 0) NDQ_WG(0, 2) NDQ_WG(1, 0) NDQ_WG(0, 1) NDQ_WG(0, 0)
+          NDQ_WPRODUCTS(NDQ_WG)
 #undef NDQ_WG
         }
       });

@@ -411,3 +411,82 @@ def test_wide_network_fit_is_bit_identical_to_epoch_by_epoch():
     for a, b in zip(runs["fit"], runs["single"]):
         assert np.array_equal(a, b)
     assert runs["fit"][0][-1] < runs["fit"][0][0]
+
+
+@pytest.mark.gpu
+def test_deep_wide_network_at_c5_size_matches_its_shards_and_the_oracle():
+    """the layer-by-layer kernels (csrc/ndq_deep.h) keep Z_l in an HBM workspace whose stripe /
+    tile / reduction tables depend on the batch size, and nothing above 65 536 points pinned them.  The RE100 notebook's
+    network (FCNN(n_hidden_units=256, n_hidden_layers=1) = 2 -> 256 -> 256 -> 3, lid-driven cavity on one network) at BASELINE C5's
+    1 048 576 points: (1) size-independent property -- loss and gradient are sums over points, so the full batch must equal the
+    sum of its sixteen 65 536-point shards evaluated one by one (each with the GLOBAL normalisation, accumulated in fp64 on the
+    host); (2) the function values / residuals of the full launch, point by point, and (3) loss + gradient of one shard
+    against the fp64 autograd oracle on that shard.  (The whole batch through the CPU oracle would cost ~10 minutes of host
+    autograd; the property covers what the sample does not.)"""
+    from tests import configs
+    from neurodiffeq_amd.engine import FusedSystem
+    g = 1024
+    torch.manual_seed(0)
+    cfg = configs.make("w19", g)
+    flat0 = R.get_flat(cfg["nets"]).clone()
+    torch.manual_seed(1)
+    coords = [c.detach() for c in cfg["gen"].get_examples()]
+    n_all = coords[0].numel()
+    assert n_all == 1 << 20
+    for net in cfg["nets"]:
+        net.to("cuda")
+    fs = FusedSystem(cfg["nets"], cfg["conds"], configs.fused_equations(cfg), 2, "cuda", compute_func_val=configs.func_val(cfg),
+                     single_kernel=False)
+    dev = [c.cuda() for c in coords]
+    b, n = fs.step(dev, train=True, slot=0, want_funcs=True, want_resid=True)
+    torch.cuda.synchronize()
+    assert n == n_all
+    loss_full = float(fs.loss_buf[0].item())
+    grad_full = _grad_in_torch_order(cfg["nets"], fs.flat).astype(np.float64)
+    funcs_full = b["funcs"][:, :n].clone()
+    resid_full = b["resid"][:, :n].clone()
+    # (1) the sixteen shards, one launch sequence each, normalised by the global batch size
+    shard = 1 << 16
+    loss_sum, grad_sum = 0.0, np.zeros_like(grad_full)
+    for k in range(n_all // shard):
+        fs.step(dev, train=True, slot=0, n_global=n_all, lo=k * shard, hi=(k + 1) * shard)
+        torch.cuda.synchronize()
+        loss_sum += float(fs.loss_buf[0].item())
+        grad_sum += _grad_in_torch_order(cfg["nets"], fs.flat).astype(np.float64)
+    errs = dict(loss_vs_shards=abs(loss_full - loss_sum) / abs(loss_sum), grad_vs_shards=rel_l2(grad_full, grad_sum))
+    # (2), (3) the fp64 autograd oracle on shard 11
+    k = 11
+    sl = slice(k * shard, (k + 1) * shard)
+    # the oracle's restatement of the single-network cavity (oracle/autograd_ref.py primitives: C5's conditions and equations,
+    # experiments/lid-driven-cavity-RE400.ipynb cell 3, on the three output columns of ONE network; Re = 100 as in tests/configs.py w19)
+    d, zero = R.ref_diff, (lambda s: 0)
+    onet = R.make_fcnn(2, 3, (256, 256), "tanh", torch.float64)
+    R.set_flat([onet], flat0.double())
+    cu, cv = R.dirichlet_bvp2d(0, zero, 1, zero, 0, zero, 1, R.lid_profile), R.dirichlet_bvp2d(0, zero, 1, zero, 0, zero, 1, zero)
+
+    class _Col(torch.nn.Module):          # column k of the shared network as a "network" of its own for the oracle's enforcers
+        def __init__(self, k):
+            super().__init__()
+            self.k = k
+
+        def forward(self, xy):
+            return onet(xy)[:, self.k:self.k + 1]
+    enforcers = [lambda net, x, y: torch.cat([cu(_Col(0), x, y), cv(_Col(1), x, y), _Col(2)(torch.cat([x, y], 1))], 1)]
+
+    def opde(uvp, x, y):
+        u, v, p = uvp[:, 0:1], uvp[:, 1:2], uvp[:, 2:3]
+        mx = u * d(u, x) + v * d(u, y) + d(p, x) - 1 / 100.0 * (d(u, x, 2) + d(u, y, 2))
+        my = u * d(v, x) + v * d(v, y) + d(p, y) - 1 / 100.0 * (d(v, x, 2) + d(v, y, 2))
+        return [mx, my, d(u, x) + d(v, y)]
+    want = R.closure_chunked([onet], enforcers, opde, [c[sl].double() for c in coords], chunk=16384, keep=True)
+    want_grad = R.get_flat_grad([onet]).numpy()
+    fs.step(dev, train=True, slot=0, lo=k * shard, hi=(k + 1) * shard)
+    torch.cuda.synchronize()
+    errs["loss_shard"] = abs(float(fs.loss_buf[0].item()) - want["loss"].item()) / abs(want["loss"].item())
+    errs["grad_shard"] = rel_l2(_grad_in_torch_order(cfg["nets"], fs.flat), want_grad)
+    errs["funcs_full_run"] = rel_l2(funcs_full[:, sl].T.cpu().numpy(), want["funcs"].numpy())
+    errs["resid_full_run"] = rel_l2(resid_full[:, sl].T.cpu().numpy(), want["residuals"].numpy())
+    os.makedirs(DIAG, exist_ok=True)
+    with open(os.path.join(DIAG, "deep_wide_1m.json"), "w") as fh:
+        json.dump(errs, fh, indent=1)
+    assert max(errs.values()) < TOL, errs
