@@ -43,9 +43,10 @@ class JetOrderError(RuntimeError):
 
 
 def set_native_autograd(enabled=True, max_order=2, coordinate_grads=True):
-    """Switch the HIP path of plain ``net(x)`` calls on / off; ``max_order`` in {0, 1, 2, 3}: highest derivative of the
+    """Switch the HIP path of plain ``net(x)`` calls on / off; ``max_order`` in {0, 1, 2, 3, 4}: highest derivative of the
     network output w.r.t. its inputs the forward launch provides (lower = fewer streams = less work per call; 3 --
-    tanh / sin / sigmoid networks -- carries every third-order partial: 10 streams for two inputs, 20 for three).
+    tanh / sin / sigmoid networks -- carries every third-order partial: 10 streams for two inputs, 20 for three; 4 -- the
+    same activations, networks of one or two inputs -- every fourth-order partial as well: 5 / 15 streams).
 
     ``coordinate_grads``: ``loss.backward()`` of the reference also leaves d loss / d x in the ``.grad`` of the sampled
     coordinate tensors (nobody reads it in a training step; residual-adaptive samplers might).  For a residual with
@@ -55,8 +56,8 @@ def set_native_autograd(enabled=True, max_order=2, coordinate_grads=True):
     plain coordinate leaves only -- their ``.grad`` then stays None; gradients that flow on into trainable tensors
     UPSTREAM of the network input (a learnable input scaling, an embedding, another network) are always exact."""
     global _ENABLED, _MAX_ORDER, _COORD_GRADS
-    if max_order not in (0, 1, 2, 3):
-        raise ValueError("max_order must be 0, 1, 2 or 3")
+    if max_order not in (0, 1, 2, 3, 4):
+        raise ValueError("max_order must be 0, 1, 2, 3 or 4")
     _ENABLED, _MAX_ORDER, _COORD_GRADS = bool(enabled), int(max_order), bool(coordinate_grads)
 
 
@@ -91,6 +92,8 @@ def _streams(d, order):
         s += _pairs(d)
     if order >= 3:
         s += [(a, b, c) for a in range(d) for b in range(a, d) for c in range(b, d)]
+    if order >= 4:
+        s += [(a, b, c, e) for a in range(d) for b in range(a, d) for c in range(b, d) for e in range(c, d)]
     return s
 
 
@@ -112,7 +115,8 @@ def _entry(dtype):
 def _desc(d, order, hidden, layers, act, n_out, skip=0):
     mask2 = (1 << (d * (d + 1) // 2)) - 1 if order >= 2 else 0
     mask3 = (1 << (d * (d + 1) * (d + 2) // 6)) - 1 if order >= 3 else 0
-    return _lib.MlpDesc(d, 1 if order >= 1 else 0, mask2, hidden, layers, act, n_out, 0, skip, mask3)
+    mask4 = (1 << (d * (d + 1) * (d + 2) * (d + 3) // 24)) - 1 if order >= 4 else 0
+    return _lib.MlpDesc(d, 1 if order >= 1 else 0, mask2, hidden, layers, act, n_out, 0, skip, mask3, 0, 0, 0, mask4)
 
 
 # ------------------------------------------------------------------------------------------------ dispatcher ops
@@ -279,7 +283,8 @@ class MlpJet(torch.autograd.Function):
                         raise JetOrderError(
                             f"derivative of order {len(mi)} of a network output w.r.t. its inputs requested, but the HIP "
                             f"forward provides orders <= {order}: call neurodiffeq_amd.set_native_autograd(max_order=3) "
-                            "for third order, or set_native_autograd(False) for the plain torch forward")
+                            "for third order (4: fourth, networks of one or two inputs), or set_native_autograd(False) for "
+                            "the plain torch forward")
                     t = g * values[idx[mi]]
                     if n_out > 1:
                         t = t.sum(dim=1, keepdim=True)
@@ -310,7 +315,7 @@ class MlpJet(torch.autograd.Function):
         if want_x and not top:
             gX = input_grad(outs, index)
         elif want_x and (ctx.coord_grads or not _only_coordinate_leaves(nf[0][0])):
-            up = _spec_for(ctx.net, order + 1, coords.dtype) if order + 1 <= 3 else None
+            up = _spec_for(ctx.net, order + 1, coords.dtype) if order + 1 <= 4 else None
             if up is not None:
                 jets = torch.ops.ndq.mlp_jet_fwd(coords, flat, n, order + 1, hidden, layers, act, n_out)
                 hi = _streams(d, order + 1)
@@ -333,7 +338,8 @@ def _spec_for(net, order, dtype=torch.float32):
     if hit is not None:
         return hit if hit else None
     info = describe(net, dtype=dtype)
-    ok = info is not None and info["skip"] == 0 and info.get("skip_sym") is None and info["actp"] == 0 and info["widths"] == 0 and info["mono"] == 0 and 1 <= info["d"] <= 3
+    ok = info is not None and info["skip"] == 0 and info.get("skip_sym") is None and info["actp"] == 0 and info["widths"] == 0 and info["mono"] == 0 and 1 <= info["d"] <= 3 \
+        and (order < 4 or info["d"] <= 2)          # (every fourth-order partial of three inputs would be 35 streams)
     if ok:
         from . import codegen
         desc = _desc(info["d"], order, info["hidden"], info["layers"], info["act"], info["n_out"])

@@ -189,6 +189,52 @@ def test_third_order_on_request(cpu_ops):
     assert rel_l2(torch.cat([g.reshape(-1) for g in g1]).numpy(), torch.cat([g.reshape(-1) for g in g2]).numpy()) < 2e-6
 
 
+def test_fourth_order_on_request(cpu_ops):
+    """set_native_autograd(max_order=4) (round 6): every fourth-order partial of a one- or two-input network travels with the
+    forward launch; the biharmonic operator written with diff() and the parameter gradient of a loss built on it equal
+    torch autograd through the plain Sequential."""
+    torch.manual_seed(6)
+    net = FCNN(2, 1, hidden_units=(16, 16))
+    x, y = [torch.rand(7, 1, requires_grad=True) for _ in range(2)]
+
+    def build():
+        u = net(torch.cat([x, y], dim=1)) * (1.0 + x * y)
+        return diff(u, x, order=4) + 2.0 * diff(diff(u, x, order=2), y, order=2) + diff(u, y, order=4) + u
+    with autograd_ops.native_autograd(True, max_order=4):
+        r = build()
+        assert "MlpJet" in type(net(torch.cat([x, y], dim=1)).grad_fn).__name__
+        g1 = torch.autograd.grad((r ** 2).mean(), list(net.parameters()))
+    with autograd_ops.native_autograd(False):
+        r2 = build()
+        g2 = torch.autograd.grad((r2 ** 2).mean(), list(net.parameters()))
+    assert rel_l2(r.detach().numpy(), r2.detach().numpy()) < 5e-6
+    assert rel_l2(torch.cat([g.reshape(-1) for g in g1]).numpy(), torch.cat([g.reshape(-1) for g in g2]).numpy()) < 5e-6
+    assert autograd_ops._spec_for(FCNN(3, 1, hidden_units=(16, 16)), 4) is None       # three inputs: order 4 stays on plain torch
+
+
+@pytest.mark.gpu
+def test_fourth_order_on_the_hip_kernels():
+    """The same biharmonic expression on the MI355X: forward + nested diff() sweeps served by the fourth-order stream kernels
+    (an extension module: every partial up to order four of a 2 -> 32 -> 32 -> 1 tanh network, 15 streams), the parameter
+    gradient by ONE adjoint launch; against plain torch autograd on the same device."""
+    torch.manual_seed(6)
+    net = FCNN(2, 1, hidden_units=(32, 32)).to("cuda")
+    x, y = [torch.rand(500, 1, device="cuda", requires_grad=True) for _ in range(2)]
+
+    def build():
+        u = net(torch.cat([x, y], dim=1)) * (1.0 + x * y)
+        return diff(u, x, order=4) + 2.0 * diff(diff(u, x, order=2), y, order=2) + diff(u, y, order=4) + u
+    with autograd_ops.native_autograd(True, max_order=4):
+        r = build()
+        assert "MlpJet" in type(net(torch.cat([x, y], dim=1)).grad_fn).__name__
+        g1 = torch.autograd.grad((r ** 2).mean(), list(net.parameters()))
+    with autograd_ops.native_autograd(False):
+        r2 = build()
+        g2 = torch.autograd.grad((r2 ** 2).mean(), list(net.parameters()))
+    assert rel_l2(r.detach().cpu().numpy(), r2.detach().cpu().numpy()) < 1e-5
+    assert rel_l2(torch.cat([g.reshape(-1) for g in g1]).cpu().numpy(), torch.cat([g.reshape(-1) for g in g2]).cpu().numpy()) < 1e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("coordinate_grads", [False, True])
 @pytest.mark.parametrize("name,size", [("c2", 16), ("c1", 64), ("c3", 12), ("c4", 96)])
