@@ -500,6 +500,8 @@ class trace_scope:
 
     def __enter__(self):
         _CURRENT.append(self.graph)
+        self._grad = torch.enable_grad()           # (a deterministic autograd mode for every trace and re-trace: Sym.__init__)
+        self._grad.__enter__()
         self.mode = _TwinMode(self.graph)
         self.mode.__enter__()
         # torch's factories parse their size arguments BEFORE any __torch_function__ mode is asked, so a _BatchDim token
@@ -518,6 +520,7 @@ class trace_scope:
         for name, fn in self._saved.items():
             setattr(torch, name, fn)
         self.mode.__exit__(*exc)
+        self._grad.__exit__(*exc)
         _CURRENT.pop()
 
 
@@ -783,7 +786,7 @@ def _no_such_method(kind):
 
 
 _NOT_METHODS = frozenset({"cat", "concat", "stack", "ones_like", "zeros_like", "full_like", "mse_loss", "l1_loss", "where",
-                          "sum", "mean", "max", "min", "grad", "mm", "special_expit", "special_erf", "special_erfc", "special_log1p",
+                          "sum", "mean", "max", "min", "grad", "mm", "linalg_norm", "linalg_vector_norm", "linalg_cross", "special_expit", "special_erf", "special_erfc", "special_log1p",
                           "special_expm1", "special_sinc", "special_exp2", "special_xlogy", "special_xlog1py", "special_logit",
                           "special_round", "_threshold", "threshold", "log_sigmoid", "logsigmoid", "softplus", "elu", "selu",
                           "celu", "gelu", "silu", "mish", "softsign", "hardtanh", "relu6", "hardsigmoid", "hardswish",
@@ -801,6 +804,11 @@ class Sym:
         # reference samples and differentiates with respect to, neurodiffeq.py:22).  Everything an operation returns is a
         # NEW tensor in torch -- also when the arithmetic folds it back to the same node (x + 0.0, x * 1.0, x.clone(),
         # x.view(-1, 1)) -- and `diff(u, <new tensor>)` is not `diff(u, x)` (sym_diff)
+        if not leaf and not torch.is_grad_enabled() and g.nodes[i][0] not in ("const", "detach"):
+            # the operation ran inside the user's `with torch.no_grad():` (or set_grad_enabled(False) / inference_mode): torch
+            # records no graph for its result -- a constant as far as autograd is concerned, exactly what x.detach() is (the
+            # tracer itself runs the callables under torch.enable_grad(): trace_scope)
+            i = g.unary("detach", i)
         self.g, self.i, self.leaf = g, i, leaf
 
     # ---- tensor-ish surface used by reference-style code
@@ -1009,9 +1017,25 @@ class Sym:
     def logical_or(self, o): return self + o - self * o
     def float(self): return self
     def double(self): return self
-    def bool(self): return self
-    def to(self, *a, **k): return self
-    def type(self, *a, **k): return self
+
+    def bool(self):
+        # of a mask: itself; of any other column: [x != 0] (arithmetic on the result must see 0 / 1, not the value)
+        return self if self.g.nodes[self.i][0] in ("gt", "ge") else (self != 0.0)
+
+    def _cast(self, args, kwargs):
+        """x.to(...) / x.type(...): float32 <-> float64 is the precision of the build either way (the contract is 1e-5 /
+        1e-9 against fp64); a cast to a NARROWER or integer type rounds the values in the reference -- refused."""
+        for v in list(args) + list(kwargs.values()):
+            if isinstance(v, torch.dtype) and v not in (torch.float32, torch.float64):
+                raise TraceUnsupported(f"cast of a traced column to {v}")
+            if isinstance(v, str) and "Float" not in v and "Double" not in v and v not in ("cpu", "cuda") and not v.startswith("cuda:"):
+                raise TraceUnsupported(f"cast of a traced column to {v!r}")
+            if isinstance(v, type) and issubclass(v, torch.Tensor) and v not in (torch.FloatTensor, torch.DoubleTensor, torch.Tensor):
+                raise TraceUnsupported(f"cast of a traced column to {v.__name__}")
+        return self
+
+    def to(self, *a, **k): return self._cast(a, k)
+    def type(self, *a, **k): return self._cast(a, k)
     def type_as(self, other): return self
     def where(self, condition, other): return _tf_where(condition, self, other)
     def masked_fill(self, mask, value): return _tf_where(mask, value, self)
@@ -1587,6 +1611,41 @@ def _tf_matmul(a, m, **k):
     return out[0] if len(out) == 1 else SymMat(out)
 
 
+def _tf_norm(x, p=None, dim=None, keepdim=False, ord=None, **k):
+    """Row norms of a traced matrix (``torch.norm(torch.cat([ux, uy], 1), dim=1, keepdim=True)``: |grad u| point by point);
+    p / ord in {2 (default), 1, inf}.  A norm over the batch (dim=0 / no dim) is an operation ACROSS points: refused."""
+    ord_ = ord if ord is not None else (2 if p is None else p)
+    if isinstance(dim, (list, tuple)) and len(dim) == 1:
+        dim = dim[0]
+    if dim not in (1, -1):
+        raise TraceUnsupported("a norm over the batch inside the traced region (only row norms, dim=1, are per-point)")
+    cols = x.cols if isinstance(x, SymMat) else [x]
+    if ord_ in (2, 2.0, "fro"):
+        acc = None
+        for c in cols:
+            acc = c * c if acc is None else acc + c * c
+        return acc.sqrt()
+    if ord_ in (1, 1.0):
+        acc = None
+        for c in cols:
+            acc = abs(c) if acc is None else acc + abs(c)
+        return acc
+    if ord_ in (float("inf"), math.inf):
+        acc = None
+        for c in cols:
+            acc = abs(c) if acc is None else _tf_maximum(acc, abs(c))
+        return acc
+    raise TraceUnsupported(f"norm of order {ord_!r} of a traced matrix")
+
+
+def _tf_cross(a, b, dim=None, **k):
+    """torch.cross / torch.linalg.cross of two traced (N, 3) matrices along dim 1."""
+    if not (isinstance(a, SymMat) and isinstance(b, SymMat) and len(a.cols) == 3 and len(b.cols) == 3) or dim not in (None, 1, -1):
+        raise TraceUnsupported("torch.cross: two traced (N, 3) matrices, dim=1")
+    (a0, a1, a2), (b0, b1, b2) = a.cols, b.cols
+    return SymMat([a1 * b2 - a2 * b1, a2 * b0 - a0 * b2, a0 * b1 - a1 * b0])
+
+
 def _tf_nan_to_num(x, nan=0.0, posinf=None, neginf=None, **k):
     def one(c):
         big = 1.7976931348623157e308 if getattr(c.g, "f64", False) else 3.4028234663852886e38
@@ -1689,6 +1748,7 @@ _TORCH_FUNCS = {
     "threshold": _tf_threshold, "_threshold": _tf_threshold, "tanhshrink": _tf_elem(lambda c: c - c.tanh()),
     "where": _tf_where, "clamp": _tf_clamp, "clip": _tf_clamp, "masked_fill": lambda x, mask, value, **k: _tf_where(mask, value, x),
     "matmul": _tf_matmul, "mm": _tf_matmul, "nan_to_num": _tf_nan_to_num,
+    "norm": _tf_norm, "linalg_norm": _tf_norm, "linalg_vector_norm": _tf_norm, "cross": _tf_cross, "linalg_cross": _tf_cross,
     "clamp_min": lambda x, min, **k: _tf_clamp(x, min, None), "clamp_max": lambda x, max, **k: _tf_clamp(x, None, max),
     "relu": _tf_relu, "leaky_relu": _tf_leaky_relu, "heaviside": _tf_heaviside,
     "maximum": _tf_maximum, "minimum": _tf_minimum, "max": _tf_max, "min": _tf_min, "fmax": _tf_maximum, "fmin": _tf_minimum,

@@ -20,8 +20,13 @@ from tests.test_tracer_fuzz import BINARY, UNARY, _expr
 F = torch.nn.functional
 
 
+def _ng(f):
+    with torch.no_grad():
+        return f()
+
+
 def _pde_system(name, src):
-    pde = eval(src, {"torch": torch, "F": F, "np": np})          # noqa: S307 -- fixed templates below
+    pde = eval(src, {"torch": torch, "F": F, "np": np, "_ng": _ng})          # noqa: S307 -- fixed templates below
     return zoo.System(name, 2, [(2, 1, (32, 32), "tanh")], [(-1.0, 1.0), (-1.0, 1.0)], pde,
                       lambda: [C.NoCondition()], lambda D: [lambda net, x, y: net(zoo._cat(x, y))])
 
@@ -81,6 +86,14 @@ PROBES = {
     "matmul": ("lambda D: lambda u, x, y: [torch.cat([u, D(u, x)], 1) @ torch.tensor([[1.0], [0.5]]) + "
                "(torch.cat([x, y], dim=1) @ torch.tensor([[0.5, 1.0], [2.0, -1.0]]))[:, 1:2] * u]", False),
     "nan_to_num": ("lambda D: lambda u, x, y: [D(u, x) + torch.nan_to_num(torch.sqrt(x), nan=0.25) * u]", False),
+    "row_norm": ("lambda D: lambda u, x, y: [D(u, x) + torch.norm(torch.cat([D(u, x), D(u, y)], 1), dim=1, keepdim=True) "
+                 "+ torch.linalg.norm(torch.cat([u, x], 1), ord=1, dim=1, keepdim=True)]", False),
+    "cross": ("lambda D: lambda u, x, y: [D(u, x) + torch.cross(torch.cat([u, x, y], 1), torch.cat([y, u, x], 1), dim=1)[:, 1:2]]", False),
+    # a torch.no_grad() block inside the equations: its results are constants for autograd (round 6: Sym.__init__)
+    "no_grad_block": ("lambda D: lambda u, x, y: [D(u, x) + u * _ng(lambda: torch.sigmoid(3.0 * u))]", False),
+    "bool_of_a_value": ("lambda D: lambda u, x, y: [D(u, x) + (torch.round(2.0 * x)).bool() * u]", False),
+    "cast_to_half": ("lambda D: lambda u, x, y: [D(u, x) + u.to(torch.float16).to(u.dtype)]", True),
+    "cast_to_long": ("lambda D: lambda u, x, y: [D(u, x) + (3.0 * x).long() * u]", True),
     "logit_eps": ("lambda D: lambda u, x, y: [D(u, x) + torch.logit(torch.sigmoid(3.0 * u), eps=0.2)]", False),
 }
 
