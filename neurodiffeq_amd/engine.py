@@ -413,6 +413,14 @@ class FusedSystem:
             self.kernel.lib.ndq_pw_bind_theta.restype = None
 
     # ------------------------------------------------------------------------------------------ trainable scalars
+    def set_batch_size(self, n_global):
+        """The batch size as a number of the equations (`u / x.shape[0]`: symbolic.Graph.nbatch): the GLOBAL batch's point
+        count -- what x.shape[0] is in the reference's closure (solvers.py:369-395) -- goes into its frozen kernel argument;
+        refresh_theta uploads it when it changed."""
+        t = getattr(self.program.g, "_nbatch_t", None)
+        if t is not None:
+            t.fill_(float(n_global))
+
     def refresh_theta(self):
         """Current values of the equations' trainable scalars -> the device vector the kernels read."""
         if self.n_theta:
@@ -762,6 +770,7 @@ class FusedSystem:
         (solvers.py:682-725)."""
         b, n = self.upload([c.reshape(-1) for c in coords])
         stream = self._stream()
+        self.set_batch_size(n)
         self.refresh_theta()
         self.forward(b, n, stream)
         self.pointwise(b, n, stream, False, n, want_funcs=True)
@@ -772,6 +781,7 @@ class FusedSystem:
         solvers.py:606-646, without building an autograd graph)."""
         b, n = self.upload([c.reshape(-1) for c in coords])
         stream = self._stream()
+        self.set_batch_size(n)
         self.refresh_theta()
         self.forward(b, n, stream)
         self.pointwise(b, n, stream, False, n, want_resid=True)
@@ -1312,6 +1322,7 @@ class FusedSystem:
         b, n = self.upload(batch, lo, hi)
         n_global = n if n_global is None else n_global
         stream = self._stream()
+        self.set_batch_size(n_global)
         self.refresh_theta()
         if train and not accumulate and not self.verify_fused(b, n, n_global):
             b, n = self.upload(batch, lo, hi)            # a closure-kernel build was rejected: fresh buffer set

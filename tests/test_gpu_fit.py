@@ -464,6 +464,40 @@ def test_a_coefficient_tensor_changed_through_data_reaches_the_fused_kernels(gol
     assert np.max(np.abs(hist - frozen) / frozen) > 1e-2                         # ... and not the frozen equations
 
 
+def test_batch_size_inside_the_equations_is_a_kernel_argument():
+    """VERDICT r5 weak #1 ("or better make N a runtime kernel argument"): `t.shape[0] ** 0.5` inside diff_eqs.  The training
+    generator draws 64 points, the validation generator 16 -- ONE traced program serves both, the batch size travels as a
+    frozen kernel argument the engine refills per launch sequence (symbolic.Graph.nbatch).  Had the trace baked in either
+    size, the other phase's losses would be off by a factor of 4; both histories follow the composite path (the reference's
+    closure on torch autograd, which reads t.shape[0] every batch: solvers.py:380)."""
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.generators import Generator1D
+    from neurodiffeq_amd.solvers import Solver1D
+
+    def run(mode):
+        torch.manual_seed(0)
+        s = Solver1D(lambda u, t: [(diff(u, t) + u) * (t.shape[0] ** 0.5) / 8.0 + u / t.numel()], [IVP(0.0, 1.0)],
+                     t_min=0.0, t_max=2.0, train_generator=Generator1D(64, 0.0, 2.0), valid_generator=Generator1D(16, 0.0, 2.0),
+                     n_batches_valid=1)
+        s.fused = mode
+        torch.manual_seed(1)
+        s.fit(6, tqdm_file=None)
+        return s
+    a, b = run("require"), run("off")
+    assert a.fused_active and not b.fused_active
+    assert a._fused_sys.theta_frozen and getattr(a._fused_sys.program.g, "_nbatch_t", None) is not None
+    for key in ("train_loss", "valid_loss"):
+        ha, hb = np.array(a.metrics_history[key]), np.array(b.metrics_history[key])
+        assert len(ha) == 6 and np.allclose(ha, hb, rtol=3e-4), (key, ha, hb)
+    # evaluation on an arbitrary number of points: x.shape[0] is THAT number (get_residuals, solvers.py:606-646)
+    ts = torch.linspace(0.1, 1.9, 37, device="cuda").reshape(-1, 1)
+    ra = a.get_residuals(ts.clone(), best=False)
+    rb = b.get_residuals(ts.clone(), best=False)
+    ra, rb = [r if isinstance(r, torch.Tensor) else r[0] for r in (ra, rb)]
+    assert np.allclose(ra.detach().cpu().numpy().reshape(-1), rb.detach().cpu().numpy().reshape(-1), rtol=1e-3, atol=1e-5)
+
+
 def test_equations_following_solver_local_epoch_train_on_the_current_value_every_epoch(golden_dir):
     """``diff_eqs`` reads ``solver.local_epoch`` through a captured solver -- the curriculum
     idiom; the fit loop advances the counter itself (solvers.py:443-497), nothing a state watch could stamp.  The watch is

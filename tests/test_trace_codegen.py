@@ -51,6 +51,8 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     coords = np.ascontiguousarray(coords, wdt)
     n_coords, n = coords.shape
     prog = trace(nets, conds, pde, n_coords, lap, cfv, loss, metrics)
+    if getattr(prog.g, "_nbatch_t", None) is not None:        # the batch size as a kernel argument (symbolic.Graph.nbatch)
+        prog.g._nbatch_t.fill_(float(n))
     dims_act, flats, perms, off = [], [], [], 0
     for net in nets:
         info = describe(net)

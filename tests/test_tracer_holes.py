@@ -54,10 +54,10 @@ def _run(system, seed=0, n=48):
 
 # (source, must it refuse?)  -- the reference evaluates all of them (solvers.py:380)
 PROBES = {
-    "inv_shape0": ("lambda D: lambda u, x, y: [D(u, x) * (1.0 / x.shape[0])]", True),
+    "inv_shape0": ("lambda D: lambda u, x, y: [D(u, x) * (1.0 / x.shape[0])]", False),
     "div_len": ("lambda D: lambda u, x, y: [D(u, x) + u / len(x)]", True),
-    "size0_sqrt": ("lambda D: lambda u, x, y: [(D(u, x) + u) / x.size(0) ** 0.5]", True),
-    "numel": ("lambda D: lambda u, x, y: [D(u, x) + u / u.numel()]", True),
+    "size0_sqrt": ("lambda D: lambda u, x, y: [(D(u, x) + u) / x.size(0) ** 0.5]", False),
+    "numel": ("lambda D: lambda u, x, y: [D(u, x) + u / u.numel()]", False),
     "float_shape0": ("lambda D: lambda u, x, y: [D(u, x) + u * float(x.shape[0])]", True),
     "linspace": ("lambda D: lambda u, x, y: [D(u, x) + torch.linspace(0, 1, x.shape[0]).reshape(-1, 1) * u]", True),
     "arange_len": ("lambda D: lambda u, x, y: [D(u, x) + torch.arange(len(x)).reshape(-1, 1) * u]", True),
@@ -65,6 +65,8 @@ PROBES = {
     "np_ones": ("lambda D: lambda u, x, y: [D(u, x) + torch.as_tensor(np.ones((x.shape[0], 1))) * u]", True),
     "ones_vector": ("lambda D: lambda u, x, y: [D(u, x) + torch.ones(x.shape[0]) * u]", True),
     "shape_compare_number": ("lambda D: lambda u, x, y: [D(u, x) + (u if x.shape[0] == 48 else 2.0 * u)]", True),
+    "shape_eq_mask": ("lambda D: lambda u, x, y: [D(u, x) + (x.shape[0] == 48) * u + (x.shape[0] > 100) * u]", False),
+    "full_of_inverse_n": ("lambda D: lambda u, x, y: [D(u, x) + torch.full((x.shape[0], 1), 1.0) / x.shape[0] * u - u * x.size(0) ** -1]", False),
     "diff_x_plus_0": ("lambda D: lambda u, x, y: [D(u, x + 0.0) + u]", True),
     "diff_x_times_1": ("lambda D: lambda u, x, y: [D(u, x * 1.0) + u]", True),
     "diff_clone": ("lambda D: lambda u, x, y: [D(u, x.clone()) + u]", True),
@@ -113,25 +115,32 @@ def test_probe_matches_autograd_or_refuses(name):
 
 
 def test_batch_size_never_reaches_the_trace_as_a_number():
-    """Whatever a callable does with x.shape[0] / len(x) / x.numel(): no Python number comes out of it."""
+    """Whatever a callable does with x.shape[0] / len(x) / x.numel(): no Python number comes out of it -- arithmetic gives a
+    traced value backed by a kernel ARGUMENT (Graph.nbatch: a frozen parameter the engine refills with the global batch size),
+    everything that needs a number refuses."""
     from neurodiffeq_amd.symbolic import Graph, Sym, SymMat, trace_scope
     g = Graph(2)
     with trace_scope(g):
         x, y = Sym(g, g.coord(0), leaf=True), Sym(g, g.coord(1), leaf=True)
         m = SymMat([x, y])
         n = x.shape[0]
-        for f in (lambda: len(x), lambda: len(m), lambda: int(n), lambda: float(n), lambda: n + 1, lambda: 1 + n, lambda: n * 2.0,
-                  lambda: 1.0 / n, lambda: n / 2, lambda: n // 2, lambda: n ** 0.5, lambda: 2 ** n, lambda: -n, lambda: abs(n),
-                  lambda: n < 5, lambda: n >= 5, lambda: n == 5, lambda: n != 5, lambda: bool(n), lambda: range(n), lambda: [0] * n,
-                  lambda: np.sqrt(n), lambda: x.numel() * 1.0, lambda: m.shape[0] + 0, lambda: x.size(0) - 1,
-                  lambda: x.size()[0] % 2, lambda: divmod(n, 2), lambda: round(n), lambda: x * n, lambda: x / n, lambda: x ** n,
-                  lambda: torch.sin(x) * n, lambda: m * n, lambda: x[:n], lambda: x[n - 1]):
+        for f in (lambda: len(x), lambda: len(m), lambda: int(n), lambda: float(n), lambda: bool(n), lambda: range(n), lambda: [0] * n,
+                  lambda: np.sqrt(n), lambda: n // 2, lambda: x.size()[0] % 2, lambda: divmod(n, 2), lambda: round(n),
+                  lambda: x ** n, lambda: x[:n], lambda: x[n - 1], lambda: (1 if n > 5 else 2), lambda: (1 if n == 48 else 2),
+                  lambda: torch.linspace(0, 1, n), lambda: torch.arange(n), lambda: torch.rand(n, 1), lambda: torch.ones(n)):
             with pytest.raises((TraceUnsupported, TypeError)):
                 f()
+        node = g.nbatch()
+        assert g.nodes[node][0] == "param" and g.nodes[node][1] in g.frozen          # a frozen kernel argument, no adjoint
+        for f in (lambda: n + 1, lambda: 1 + n, lambda: n * 2.0, lambda: 1.0 / n, lambda: n / 2, lambda: n ** 0.5, lambda: 2 ** n,
+                  lambda: -n, lambda: abs(n), lambda: x.numel() * 1.0, lambda: m.shape[0] + 0, lambda: x.size(0) - 1, lambda: x * n,
+                  lambda: x / n, lambda: torch.sin(x) * n, lambda: n < 5, lambda: n >= 5, lambda: n == 5, lambda: n != 5):
+            r = f()
+            assert isinstance(r, Sym) and node in g.reachable([r.i]), r
+        assert isinstance(m * n, SymMat)
         assert x.shape == y.shape and x.shape[1] == 1 and m.shape[1] == 2 and x.dim() == 2 and len(x.shape) == 2
         assert (n == y.shape[0]) is True and (n != m.size(0)) is False
-    assert torch.ones is torch.ones.__wrapped__ if hasattr(torch.ones, "__wrapped__") else True      # (factories restored)
-    assert not hasattr(torch.ones, "__wrapped__") and not hasattr(torch.linspace, "__wrapped__")
+    assert not hasattr(torch.ones, "__wrapped__") and not hasattr(torch.linspace, "__wrapped__")      # (factories restored)
 
 
 def test_constants_keep_the_precision_of_the_build():
@@ -166,9 +175,9 @@ def test_autograd_grad_without_create_graph_is_a_constant_of_the_trace():
 
 
 # ------------------------------------------------------------------ fuzz: shape-dependent leaves and derived diff targets
-REFUSING = ["(u / x.shape[0])", "(u * (1.0 / len(x)))", "(x.size(0) ** 0.5 * u)", "torch.linspace(0, 1, x.shape[0]).reshape(-1, 1)",
-            "D(u, x + 0.0)", "D(u * x, y * 1.0)", "(u / u.numel())"]
-TRACING = ["torch.ones(x.shape[0], 1)", "(0.3 * torch.ones(x.shape))", "x.new_tensor(0.3)", "torch.full((y.shape[0], 1), -0.5)",
+REFUSING = ["(u * (1.0 / len(x)))", "(u * float(x.shape[0]))", "torch.linspace(0, 1, x.shape[0]).reshape(-1, 1)",
+            "D(u, x + 0.0)", "D(u * x, y * 1.0)", "(u + torch.arange(x.shape[0]).reshape(-1, 1))"]
+TRACING = ["(u / x.shape[0])", "(x.size(0) ** 0.5 * u)", "(u / u.numel())", "(x * (1.0 / x.shape[0]))","torch.ones(x.shape[0], 1)", "(0.3 * torch.ones(x.shape))", "x.new_tensor(0.3)", "torch.full((y.shape[0], 1), -0.5)",
            "u.reshape(x.shape[0], 1)", "((x == y) * 1.0)", "((torch.round(2.0 * x) != 0.0) * 1.0)"]
 
 
