@@ -942,6 +942,8 @@ class FusedSystem:
 
     def verify_on(self, batch, n_global=None, lo=0, hi=None):
         b, n = self.upload(batch, lo, hi)
+        self.set_batch_size(n if n_global is None else n_global)      # (scalar arguments of the equations: as step() does)
+        self.refresh_theta()
         ok = self.verify_fused(b, n, n_global)
         if batch[0].device.type != "cuda":       # the epoch uploads this batch again: not a sign of a static generator
             self._static_seen.pop(self.static_key(batch) + (lo, batch[0].numel() if hi is None else hi), None)

@@ -635,8 +635,11 @@ class BaseSolver(ABC):
         through ONE native call (engine.fast_train_epoch: closure kernel + fused sums/tail kernel); every other fused
         system runs its per-batch launch sequence and then the device-side epoch tail (loss history ring, best
         snapshot, fused Adam per network).  Returns False if the general (host-synchronising) path must run."""
-        if not self._native_ok() or system.n_theta:
+        if not self._native_ok() or system._theta_trainable:
             return False        # (trainable equation coefficients are stepped by the user's optimiser: general path)
+        # (FROZEN scalar arguments -- runtime constants of a ramped coefficient, the batch size in the arithmetic: symbolic.Graph
+        # .external / .nbatch -- need no optimiser: such systems keep the device-side epoch; step() refreshes the arguments.
+        # fast_ready() / fit_ready() stay False for them, so they take the per-batch launch sequence + epoch_tail below)
         # (fp64 systems -- the reference's default precision -- have no multi-epoch call: they run their per-batch launch
         # sequence (closure kernel in double, or the three-kernel pipeline) and then the device-side epoch tail in double,
         # ndq64_epoch_tail)
