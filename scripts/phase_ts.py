@@ -68,3 +68,12 @@ for which, t in zip(("FIRST tile of wave 0 / workgroup 0", "a LATER tile (the la
             print(f"  {names[k]:28s} +{t[k] - prev:6d} cycles")
             prev = t[k]
     print("  tile total", t[12] - t[0], "cycles")
+    # epilogue of workgroup 0 (block_reduce_store + loss sums), thread 0: 13 entry | 14 lane sums done | 15 barrier | 16 LDS
+    # deposits | 17 barrier | 18 region sums + global stores issued | 19 loss / theta sums
+    ep = {13: "epilogue entry", 14: "lane (DPP) sums", 15: "barrier 1", 16: "LDS deposits", 17: "barrier 2",
+          18: "region sums + stores", 19: "loss sums"}
+    if t[13] and t[19]:
+        prev = t[12]
+        for k in sorted(ep):
+            print(f"  {ep[k]:28s} +{t[k] - prev:6d} cycles")
+            prev = t[k]
