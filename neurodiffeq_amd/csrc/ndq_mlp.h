@@ -430,8 +430,10 @@ constexpr bool act_has_s4(int act) {
                           // "bf16 fwd / fp32 grad"; the adjoint kernels recompute their forward pass in bf16x3 as always
 #endif
 #ifndef NDQ_QUAD_SWAP
-#define NDQ_QUAD_SWAP 0   // quad_sum through v_permlane16/32_swap instead of ds_bpermute: same bits, measured NOT faster (C2 closure
-                          // kernel 19.5 vs 19.2 us: the LDS round trip was never on the critical path) -- off
+#define NDQ_QUAD_SWAP 1   // quad_sum through v_permlane16/32_swap instead of ds_bpermute: same bits.  Round 5 measured it NOT faster
+                          // (C2 closure 19.5 vs 19.2 us: the LDS round trip was not on the critical path then); with the reverse
+                          // pass's products and planes cut down (round 6) it is: 17.52 -> 17.03 us on one box, 16.23 -> 16.09 on
+                          // another (profiles/r06h_flags_ab_c2.txt, r06j_own_tile_ab.txt) -- on.  0: the ds_bpermute route.
 #endif
 #ifndef NDQ_SPLIT_PAIRS
 #define NDQ_SPLIT_PAIRS 0   // split3 on 2-wide vectors: 3.5 % fewer VALU instructions in C3's closure kernel, no time gained
