@@ -29,6 +29,7 @@ fast path.  Never a silently stale equation.
 """
 import builtins
 import collections
+import dis
 import functools
 import numbers
 import sys
@@ -85,6 +86,19 @@ _VALUE_READS = frozenset({"item", "tolist", "numpy", "float", "int", "bool"})
 _CRC_BYTES = 64 << 10        # ndarrays up to this size are stamped by CRC-32 every epoch (~30 us at the limit); larger: incomplete
 
 
+_BUILTIN_NAMES = frozenset(dir(builtins))
+
+
+def _opnames(co, _cache={}):
+    """Opcode names of a code object (cached: `dis` is slow and the same lambdas are walked again at every re-trace)."""
+    r = _cache.get(co)
+    if r is None:
+        if len(_cache) > 512:
+            _cache.clear()
+        r = _cache[co] = frozenset(i.opname for i in dis.get_instructions(co))
+    return r
+
+
 def _root(module_name):
     return (module_name or "").split(".")[0]
 
@@ -120,13 +134,18 @@ class StateWatch:
         self._index = {}
         self._seen = set()
         self._names = set()        # every name the walked code objects mention
+        self._class_sizes = set()
         self._solver_seen = False
         self._trainable = []       # (expression, tensor) of requires_grad leaves: stamped by identity (their values are kernel arguments)
         self._optimizers = []      # optimisers in reach: their hyper-parameters are state iff the code names them (below)
         self._skip_modules = {id(m) for m in skip_modules}
+        self._late_modules = []    # modules met as VALUES (a closure cell, an attribute, `import m` inside the function): walked
+        #                            once every code object has been seen, with all the names the code mentions
         self.max_depth, self.max_items = max_depth, max_items
         for r in roots:
             self._visit(r, 0)
+        for mod in self._late_modules:
+            self._module(mod, self._names, 1)
         for opt in self._optimizers:
             # `opt.param_groups[0]['lr']` read by the equations: the hyper-parameters of every group are stamped (a scheduler
             # then makes the watch dirty every epoch: re-trace, value -> runtime constant).  The per-parameter STATE (Adam's
@@ -260,6 +279,13 @@ class StateWatch:
             else:
                 self._torch_module(v, depth, methods=False)
             return
+        if isinstance(v, types.ModuleType):
+            # `import time` in the enclosing function, `self.np = numpy`, a dict of modules: the module is code, but WHICH
+            # module it is decides whether the values it hands out are Python state (_module, after the walk)
+            if id(v) not in self._seen:
+                self._seen.add(id(v))
+                self._late_modules.append(v)
+            return
         if id(v) in self._seen or _is_leaf(v) or isinstance(v, _OPAQUE):
             return                 # (tensors are stamped where they are referenced; modules are not state)
         if depth > self.max_depth:
@@ -326,6 +352,10 @@ class StateWatch:
             mod = _root(getattr(v, "__module__", None) or getattr(getattr(v, "__self__", None), "__module__", None)
                         or type(v).__module__ or "builtins")
             name = getattr(v, "__name__", "")
+            owner = getattr(v, "__self__", None)
+            if owner is not None and not isinstance(owner, (types.ModuleType, type)):
+                # `get = cfg.get`, `at = values.__getitem__`: a bound builtin method reads its owner
+                self._add(f"{self._ref(v)}.__self__", owner, depth)
             if mod == "builtins" and name in _IMPURE_BUILTINS:
                 self._fail(f"the builtin {name}() (reads state that is not the equations')")
             elif mod in _STDLIB and mod not in _PURE_STDLIB:
@@ -342,12 +372,25 @@ class StateWatch:
             except ValueError:     # empty cell
                 continue
             self._add(f"{self._ref(cell)}.cell_contents", value, depth)
-        names, codes = set(), [fn.__code__]
+        names, codes, imports = set(), [fn.__code__], set()
+        # (fn.__code__ = other.__code__; a function attribute set later)
+        self.entries.append(f"((v := {self._ref(fn)}).__code__ is {self._ref(fn.__code__)} and len(v.__dict__) == {len(vars(fn))})")
         while codes:               # the function's own code and the code of lambdas / comprehensions nested in it
             co = codes.pop()
             names.update(co.co_names)
             codes.extend(c for c in co.co_consts if isinstance(c, types.CodeType))
+            if "IMPORT_NAME" in _opnames(co):
+                imports.update(i.argval for i in dis.get_instructions(co) if i.opname == "IMPORT_NAME" and isinstance(i.argval, str))
         self._names |= names
+        for modname in sorted(imports):                      # `import cfg` INSIDE the function: sys.modules is where it comes from
+            mod = sys.modules.get(modname)
+            if mod is None:
+                self._fail(f"the equations import module '{modname}' when they run")
+            else:
+                self._visit(mod, depth)
+                top = sys.modules.get(_root(modname))
+                if top is not None:
+                    self._visit(top, depth)
         for name, value in list(vars(fn).items()):           # function attributes: `eq.nu = 0.1; def eq(u, t): return eq.nu * u`
             if name != "__wrapped__" and name.isidentifier():
                 self._add(f"getattr({self._ref(fn)}, {name!r}, M)", value, depth)
@@ -358,8 +401,18 @@ class StateWatch:
         hot = sorted(n for n in names & _IMPURE_BUILTINS if n not in g and n not in fn.__code__.co_varnames)
         if hot:
             self._fail(f"the equations call the builtin(s) {hot} (state that is not the equations')")
+        extra = 0
         for name in sorted(names):
             if name not in g:
+                # not a global NOW: an attribute / method name (most), a standard builtin -- or a name somebody put into the
+                # builtins module, or a global a callback defines later (hasattr-style switches): pinned as "absent" / by value
+                if name not in _BUILTIN_NAMES and extra < 32 and name.isidentifier() and not name.startswith("__"):
+                    extra += 1
+                    patched = vars(builtins).get(name, _MISSING)
+                    if patched is not _MISSING:
+                        self._add(f"vars({self._ref(builtins)}).get({name!r}, M)", patched, depth)
+                    else:
+                        self.entries.append(f"{self._ref(g)}.get({name!r}, M) is M and vars({self._ref(builtins)}).get({name!r}, M) is M")
                 continue
             value = g[name]
             if isinstance(value, types.ModuleType):
@@ -392,6 +445,10 @@ class StateWatch:
             self._fail(f"the equations name module '{root}' (values that are not Python state)")
             return
         ns, r = vars(mod), self._ref(mod)
+        self.entries.append(f"len(vars({r})) == {len(ns)}")        # (`getattr(cfg, "late", 1.0)`: the name is a string constant)
+        absent = [n for n in sorted(names) if n not in ns and n.isidentifier() and not n.startswith("__")][:32]
+        if absent:                 # `getattr(cfg, "nu", 1.0)` / `hasattr(cfg, "nu")`: an attribute a callback sets later
+            self.entries.append("(" + " and ".join(f"getattr({r}, {n!r}, M) is M" for n in absent) + ")")
         for name in sorted(names):
             if name in ns and not name.startswith("__"):
                 value = ns[name]
@@ -448,6 +505,10 @@ class StateWatch:
         if own:
             self._solver_seen = True             # ... unless the code NAMES it: checked once the walk is over (module docstring)
         r = self._ref(obj)
+        if isinstance(d, dict) and not own:
+            # `getattr(cfg, "nu", 1.0)` / `hasattr(cfg, "nu")` / `vars(cfg)`: an attribute that does not exist yet (a solver adds
+            # attributes of its own as it runs: its bookkeeping is handled by name, above)
+            self.entries.append(f"len(vars({r})) == {len(d)}")
         d = d if isinstance(d, dict) else {}
         if len(d) > 4 * self.max_items:
             self._fail(f"an object with {len(d)} attributes")
@@ -469,15 +530,24 @@ class StateWatch:
         for k in cls.__mro__:
             if not _user_class(k):
                 continue
+            if id(k) not in self._class_sizes:
+                self._class_sizes.add(id(k))
+                self.entries.append(f"len(vars({self._ref(k)})) == {len(vars(k))}")     # (a class attribute / method added later)
             for name, value in list(vars(k).items()):
                 # methods (and what property / staticmethod / classmethod wrap): code the equations may run -- their closure
                 # cells and the globals they name are state like the entry function's
                 fn = value.fget if isinstance(value, property) else getattr(value, "__func__", value) if isinstance(value, (staticmethod, classmethod)) else value
                 if isinstance(fn, types.FunctionType):
                     if name not in _HOUSEKEEPING:
+                        # (the method the class holds NOW: `Eq.__call__ = other` by a callback is a change)
+                        self.entries.append(f"vars({self._ref(k)}).get({name!r}, M) is {self._ref(value)}")
                         self._visit(fn, depth)
                     continue
                 if name.startswith("__") or name in skip or not name.isidentifier():
+                    continue
+                if hasattr(type(value), "__get__") and _user_class(type(value)):
+                    # a user's descriptor object: read through the instance it computes from ITS state
+                    self._add(f"vars({self._ref(k)}).get({name!r}, M)", value, depth)
                     continue
                 if _is_leaf(value) or isinstance(value, (dict, list, tuple, set, collections.deque, torch.Tensor)) or type(value).__module__ == "numpy":
                     if n >= self.max_items:

@@ -444,9 +444,10 @@ class BaseSolver(ABC):
                                                   compute_func_val=self.compute_func_val, loss=kind, metrics=(),
                                                   dtype=sys_dtype, volatile=self._volatile_for(key))
                     self._host_metrics = True
+                self._watch_equations()
+                self._refuse_self_mutating_equations()
                 if isinstance(self.optimizer, FusedAdam):
                     self.optimizer.bind(self._fused_sys.flat)
-                self._watch_equations()
             except TraceUnsupported as e:
                 reason = str(e)
             except _lib.NdqError:
@@ -479,6 +480,26 @@ class BaseSolver(ABC):
         every batch; the traced kernels froze it)."""
         self._eq_watch = self._new_state_watch()
         self._eq_probe_countdown = 1
+
+    def _refuse_self_mutating_equations(self):
+        """Callables that CHANGE the state they read whenever they run -- a call counter (``eq.calls += 1``), a list they append
+        to, ``next()`` on something -- compute something else at every evaluation, and the reference evaluates them once per
+        batch (solvers.py:380).  A traced kernel evaluates them never again, a re-trace per epoch not as often as the reference
+        does: only the reference's own closure is faithful.  Found by running them once more (``eq_probe``) right after the
+        watch was taken: a watch that is dirty after that was dirtied by the callables themselves."""
+        watch, sysm = self._eq_watch, self._fused_sys
+        probe = getattr(sysm.program, "eq_probe", None) if sysm is not None else None
+        if watch is None or probe is None or len(watch) == 0:
+            return
+        try:
+            probe()
+        except Exception:       # noqa: BLE001 -- a callable that fails on its second evaluation is not one to trace either
+            pass
+        if watch.dirty():
+            self._fused_sys, self._eq_watch = None, None
+            raise TraceUnsupported("the equations / conditions change the Python state they read every time they are evaluated "
+                                   "(a call counter, a list they append to, ...); only the reference's own closure evaluates "
+                                   "them as often as the reference does")
 
     def _equations_unchanged(self, sysm, force=False):
         """False: the user's equations / conditions now trace to something else than the kernels of ``sysm`` were compiled

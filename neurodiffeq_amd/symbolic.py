@@ -878,7 +878,32 @@ class Sym:
         return True
 
     def requires_grad_(self, flag=True):
+        if not flag:      # on a coordinate this switches the leaf off IN PLACE (diff(u, x) raises in the reference afterwards)
+            raise TraceUnsupported("Tensor.requires_grad_(False) inside the traced region")
         return self
+
+    # ---- dtype of the value in torch's terms, as far as it changes what the arithmetic MEANS
+    # isbool: a torch.bool tensor (comparisons, ~ & | ^ of them, logical_*, .bool()): `a + b` of two of those is a logical OR
+    # in torch, `a * b` an AND, `a - b` / `-a` raise -- not the arithmetic of the 0.0 / 1.0 columns the trace represents them by.
+    isbool = False
+
+    def _as_bool(self):
+        self.isbool = True
+        return self
+
+    def _plain(self):
+        """The same values as an ordinary floating-point column (a NEW object: the flags belong to the object)."""
+        return Sym(self.g, self.i)
+
+    def _narrowed(self, what):
+        """`.float()` / `.to(torch.float32)` / `.half()` ...: the precision of the build in the fp32 build; in the fp64 build the
+        reference ROUNDS here (and every later operation with a Python number or another float32 value happens in float32):
+        only values that are exact in float32 -- masks -- pass, as a _NarrowSym that can do nothing but meet a double column."""
+        if not getattr(self.g, "f64", False):
+            return self._plain()
+        if self.isbool or self.g.nodes[self.i][0] in ("gt", "ge"):
+            return _NarrowSym(self.g, self.i)
+        raise TraceUnsupported(f"{what} of a traced value in the fp64 build (the reference rounds to float32 there)")
 
     def view(self, *shape):
         return self._reshape(shape)
@@ -951,6 +976,16 @@ class Sym:
         g = self.g
         if isinstance(other, SymMat):
             return other._bin(self, op, rev=not rev)
+        if isinstance(other, _NarrowSym):
+            return other._bin(self, op, rev=not rev)
+        if self.isbool and _is_boolish(other):
+            # torch.bool (op) torch.bool: + is OR, * is AND (both stay bool); - raises; / is the float quotient
+            if op == "sub":
+                raise TraceUnsupported("subtraction of two bool tensors (torch raises; use ^ or logical_xor)")
+            if op in ("add", "mul"):
+                o = other.i if isinstance(other, Sym) else g.const(1.0 if bool(other) else 0.0)
+                r = g.mul(self.i, o) if op == "mul" else g.sub(g.add(self.i, o), g.mul(self.i, o))
+                return Sym(g, r)._as_bool()
         row = _row_values(other)
         if row is not None:          # column (N,1) with a constant row (k,) broadcasts to an (N,k) matrix
             return SymMat([self] * len(row))._bin(other, op, rev)
@@ -969,7 +1004,10 @@ class Sym:
     def __rmul__(self, o): return self._bin(o, "mul", True)
     def __truediv__(self, o): return self._bin(o, "div")
     def __rtruediv__(self, o): return self._bin(o, "div", True)
-    def __neg__(self): return Sym(self.g, self.g.unary("neg", self.i))
+    def __neg__(self):
+        if self.isbool:
+            raise TraceUnsupported("negation of a bool tensor (torch raises; use ~ or logical_not)")
+        return Sym(self.g, self.g.unary("neg", self.i))
     def __pos__(self): return self
     def __abs__(self): return Sym(self.g, self.g.unary("abs", self.i))
 
@@ -1023,18 +1061,18 @@ class Sym:
         except TraceUnsupported:
             return NotImplemented
         a, b = (o, self.i) if swap else (self.i, o)
-        return Sym(g, getattr(g, op)(a, b))
+        return Sym(g, getattr(g, op)(a, b))._as_bool()
 
     def _eq(self, o):
         ge, le = self._cmp(o, "ge", False), self._cmp(o, "ge", True)
-        return NotImplemented if ge is NotImplemented else ge * le          # [a >= b] [b >= a]: 0 where either is nan
+        return NotImplemented if ge is NotImplemented else ge * le          # [a >= b] [b >= a]: 0 where either is nan (bool * bool: bool)
 
     def __eq__(self, o):                 # masks like the other comparisons (`t == 0`; a Python bool here would pick ONE
         return self._eq(o)               # branch of a torch.where for every point)
 
     def __ne__(self, o):
         m = self._eq(o)
-        return NotImplemented if m is NotImplemented else 1.0 - m
+        return NotImplemented if m is NotImplemented else (1.0 - m)._as_bool()
 
     def eq(self, o): return self == o
     def ne(self, o): return self != o
@@ -1049,20 +1087,38 @@ class Sym:
     def le(self, o): return self <= o
     def greater(self, o): return self > o
     def less(self, o): return self < o
-    def __invert__(self): return 1.0 - self                      # of a mask
-    def logical_not(self): return 1.0 - self
-    def __and__(self, o): return self * o                        # of two masks
-    def __rand__(self, o): return self * o
-    def logical_and(self, o): return self * o
-    def __or__(self, o): return self + o - self * o
-    def __ror__(self, o): return self + o - self * o
-    def logical_or(self, o): return self + o - self * o
-    def float(self): return self
-    def double(self): return self
+    # ~ & | ^ : torch implements them for bool (and integer) tensors only -- on float columns it raises
+    def _bits(self, o, what):
+        if not self.isbool or not _is_boolish(o):
+            raise TraceUnsupported(f"{what} of traced values that are not bool masks (torch raises for floating-point tensors)")
+        return o._plain() if isinstance(o, Sym) else (1.0 if bool(o) else 0.0)
+
+    def __invert__(self):
+        self._bits(True, "~")
+        return (1.0 - self._plain())._as_bool()
+    def __and__(self, o): return (self._plain() * self._bits(o, "&"))._as_bool()
+    __rand__ = __and__
+    def __or__(self, o):
+        b = self._bits(o, "|")
+        a = self._plain()
+        return (a + b - a * b)._as_bool()
+    __ror__ = __or__
+    def __xor__(self, o):
+        b = self._bits(o, "^")
+        a = self._plain()
+        return (a + b - 2.0 * (a * b))._as_bool()
+    __rxor__ = __xor__
+    # logical_*: any dtype, "non-zero is True"
+    def logical_not(self): return _tf_logical("not", self)
+    def logical_and(self, o): return _tf_logical("and", self, o)
+    def logical_or(self, o): return _tf_logical("or", self, o)
+    def logical_xor(self, o): return _tf_logical("xor", self, o)
+    def float(self): return self._narrowed("Tensor.float()")
+    def double(self): return self._plain()
 
     def bool(self):
         # of a mask: itself; of any other column: [x != 0] (arithmetic on the result must see 0 / 1, not the value)
-        return self if self.g.nodes[self.i][0] in ("gt", "ge") else (self != 0.0)
+        return Sym(self.g, self.i)._as_bool() if (self.isbool or self.g.nodes[self.i][0] in ("gt", "ge")) else (self != 0.0)
 
     def _cast(self, args, kwargs):
         """x.to(...) / x.type(...): float32 <-> float64 is the precision of the build either way (the contract is 1e-5 /
@@ -1074,11 +1130,17 @@ class Sym:
                 raise TraceUnsupported(f"cast of a traced column to {v!r}")
             if isinstance(v, type) and issubclass(v, torch.Tensor) and v not in (torch.FloatTensor, torch.DoubleTensor, torch.Tensor):
                 raise TraceUnsupported(f"cast of a traced column to {v.__name__}")
-        return self
+        for v in list(args) + list(kwargs.values()):
+            if v is torch.float32 or v is torch.FloatTensor or (isinstance(v, str) and "Float" in v) or \
+                    (isinstance(v, torch.Tensor) and v.dtype == torch.float32) or isinstance(v, _NarrowSym):
+                return self._narrowed("a cast to float32")
+            if isinstance(v, Sym) and v.isbool:
+                return self.bool()
+        return self._plain()
 
     def to(self, *a, **k): return self._cast(a, k)
     def type(self, *a, **k): return self._cast(a, k)
-    def type_as(self, other): return self
+    def type_as(self, other): return self._cast((other,), {})
     def where(self, condition, other): return _tf_where(condition, self, other)
     def masked_fill(self, mask, value): return _tf_where(mask, value, self)
     def __mod__(self, o): return _tf_remainder(self, o)          # torch's `%`: the sign of the divisor (floor)
@@ -1106,6 +1168,115 @@ class Sym:
         return f"Sym#{self.i}{self.g.nodes[self.i]}"
 
     __getattr__ = _no_such_method("column")
+
+
+def _is_boolish(v):
+    return (isinstance(v, Sym) and v.isbool) or isinstance(v, bool) or (isinstance(v, torch.Tensor) and v.dtype == torch.bool and v.numel() == 1)
+
+
+class _NarrowSym(Sym):
+    """A float32-typed mask in the fp64 build (``(x > 0).float()``, ``torch.ones_like(u, dtype=torch.float32)``): values that
+    are exact in float32.  torch's type promotion makes everything it meets FIRST decide what happens next: with a double column
+    the result is an ordinary double column (exact: that is all this class allows, besides sums / products / comparisons among
+    its own kind); with a Python number, a 0-dim tensor or a function the reference computes in float32 -- ``m.float() * 0.1``
+    is 0.1f -- which the fp64 kernels do not reproduce: TraceUnsupported -> the loud composite path.  Reading ``.i`` raises, so no
+    consumer of the trace can take the value for a double by accident."""
+
+    def __init__(self, g, i):
+        self.g, self._node, self.leaf = g, i, False
+
+    @property
+    def i(self):
+        raise TraceUnsupported("a float32 value inside the fp64 build meets something other than a double column (the reference "
+                               "computes that in float32)")
+
+    def _plain(self):
+        return Sym(self.g, self._node)
+
+    def _narrowed(self, what):
+        return self
+
+    def double(self):
+        return self._plain()
+
+    def _cast(self, args, kwargs):
+        for v in list(args) + list(kwargs.values()):
+            if v is torch.float64 or v is torch.DoubleTensor or (isinstance(v, Sym) and not isinstance(v, _NarrowSym) and not v.isbool):
+                return self._plain()
+            if v is torch.float32 or v is torch.FloatTensor or isinstance(v, _NarrowSym):
+                return self
+        raise TraceUnsupported("cast of a float32 value inside the fp64 build")
+
+    def bool(self):
+        return (self._plain() != 0.0)
+
+    def _bin(self, other, op, rev=False):
+        g = self.g
+        if isinstance(other, _NarrowSym):
+            if op in ("add", "sub", "mul"):              # small integers: exact in float32, and float32 again
+                a, b = (other._node, self._node) if rev else (self._node, other._node)
+                return _NarrowSym(g, getattr(g, op)(a, b))
+            raise TraceUnsupported("a quotient of float32 values inside the fp64 build")
+        if isinstance(other, Sym) and not other.isbool:
+            a, b = (other.i, self._node) if rev else (self._node, other.i)
+            return Sym(g, getattr(g, op)(a, b))
+        if isinstance(other, SymMat):
+            return other._bin(self, op, rev=not rev)
+        if _is_boolish(other) and op in ("mul",):
+            o = other.i if isinstance(other, Sym) else g.const(1.0 if bool(other) else 0.0)
+            return _NarrowSym(g, g.mul(self._node, o))
+        raise TraceUnsupported("a float32 value inside the fp64 build combined with a number / tensor that is not a double column "
+                               "(float32 arithmetic in the reference)")
+
+    def _cmp(self, other, op, swap):
+        if isinstance(other, _NarrowSym):
+            other = other._plain()
+        return self._plain()._cmp(other, op, swap)
+
+    def __neg__(self): return _NarrowSym(self.g, self.g.unary("neg", self._node))
+    def __pow__(self, e): self.i
+    def __rpow__(self, e): self.i
+    def __abs__(self): return _NarrowSym(self.g, self.g.unary("abs", self._node))
+    def _un(self, op): self.i
+    def detach(self): return self
+    def clone(self, *a, **k): return _NarrowSym(self.g, self._node)
+    def _reshape(self, shape):
+        Sym._reshape(self._plain(), shape)
+        return _NarrowSym(self.g, self._node)
+    def __getitem__(self, idx):
+        Sym.__getitem__(self._plain(), idx)
+        return _NarrowSym(self.g, self._node)
+    def _bits(self, o, what):
+        raise TraceUnsupported(f"{what} of a float32 value (torch raises for floating-point tensors)")
+
+
+def _truth(g, v):
+    """``v`` as a bool column in torch's sense (non-zero is True): a traced column, a number, a one-element tensor."""
+    if isinstance(v, _NarrowSym):
+        v = v._plain()
+    if isinstance(v, Sym):
+        return v.bool()
+    if isinstance(v, SymMat):
+        raise TraceUnsupported("logical_* of a traced matrix")
+    if isinstance(v, (bool, numbers.Number)):
+        return Sym(g, g.const(1.0 if v else 0.0))._as_bool()
+    if isinstance(v, torch.Tensor) and v.numel() == 1 and not v.requires_grad:
+        return Sym(g, g.const(1.0 if bool(v) else 0.0))._as_bool()
+    raise TraceUnsupported(f"logical_* with {type(v).__name__}")
+
+
+def _tf_logical(kind, a, b=None, **k):
+    if k.get("out") is not None:
+        raise TraceUnsupported("out= inside the traced region")
+    if isinstance(a, SymMat) or isinstance(b, SymMat):
+        return _elementwise((lambda x: _tf_logical(kind, x)) if b is None else (lambda x, y: _tf_logical(kind, x, y)),
+                            *([a] if b is None else [a, b]))
+    g = _first_sym(a, b).g
+    x = _truth(g, a)
+    if kind == "not":
+        return ~x
+    y = _truth(g, b)
+    return x & y if kind == "and" else (x | y if kind == "or" else x ^ y)
 
 
 class SymMat:
@@ -1155,13 +1326,23 @@ class SymMat:
         return [n] * k
 
     def _bin(self, other, op, rev=False):
-        try:
-            oc = self._operand_cols(other)
-        except TraceUnsupported:
-            return NotImplemented
-        g = self.g
-        f = getattr(g, op)
-        return SymMat([Sym(g, f(o, c.i) if rev else f(c.i, o)) for c, o in zip(self.cols, oc)])
+        k = len(self.cols)
+        if isinstance(other, SymMat):
+            if len(other.cols) != k:
+                return NotImplemented                    # (traced matrices of different widths)
+            others = other.cols
+        else:
+            row = _row_values(other)
+            if row is not None and len(row) != k:
+                return NotImplemented                    # (constant row of the wrong width)
+            others = row if row is not None else [other] * k
+        out = []
+        for c, o in zip(self.cols, others):              # column by column: the dtype rules of Sym._bin hold per column
+            r = c._bin(o, op, rev)
+            if r is NotImplemented:
+                return NotImplemented
+            out.append(r)
+        return SymMat(out)
 
     def __add__(self, o): return self._bin(o, "add")
     def __radd__(self, o): return self._bin(o, "add", True)
@@ -1192,7 +1373,7 @@ class SymMat:
             keepdim = keepdims
         if dim not in (1, -1):
             raise TraceUnsupported("only row sums (dim=1) of a traced matrix are supported")
-        acc = self.cols[0]
+        acc = self.cols[0]._plain()                     # (of bool columns: the COUNT, an integer -- not the OR that `+` is)
         for c in self.cols[1:]:
             acc = acc + c
         return acc                                      # (N,) and (N,1) are the same traced column
@@ -1410,19 +1591,44 @@ def _tf_bin(op):
             if alpha is not None:
                 b = b * alpha
             return s._bin(b, op) if s is a else s._bin(a, op, True)
-        g = s.g
-        nb = _as_node(g, b)
         if alpha is not None:
-            nb = g.mul(g.const(alpha), nb)
-        return Sym(g, getattr(g, op)(_as_node(g, a), nb))
+            b = b * alpha
+        if isinstance(a, Sym):
+            r = a._bin(b, op)
+        else:
+            r = b._bin(a, op, True)
+        if r is NotImplemented:
+            raise TraceUnsupported(f"torch.{op} of a traced column and {type(b if isinstance(a, Sym) else a).__name__}")
+        return r
     return f
+
+
+def _const_like(x, value, k):
+    """A per-point constant made "like" the traced column x: its dtype is x's unless dtype= says otherwise."""
+    g = x.g
+    dt = k.get("dtype")
+    if dt is torch.bool or (dt is None and isinstance(x, Sym) and x.isbool):
+        return Sym(g, g.const(1.0 if value else 0.0))._as_bool()
+    if dt in (torch.float16, torch.bfloat16) or (dt is torch.float32 and getattr(g, "f64", False)) or \
+            (dt is None and isinstance(x, _NarrowSym)):
+        v32 = float(torch.tensor(float(value), dtype=torch.float32 if dt is None else dt))
+        if not getattr(g, "f64", False):
+            if dt in (torch.float16, torch.bfloat16):
+                raise TraceUnsupported(f"a constant of dtype {dt} inside the traced region")
+            return Sym(g, g.const(v32))
+        if dt in (torch.float16, torch.bfloat16):
+            raise TraceUnsupported(f"a constant of dtype {dt} inside the traced region")
+        return _NarrowSym(g, g.const(v32))               # (the float32 value, and float32 arithmetic with whatever it meets)
+    if dt is not None and dt not in (torch.float32, torch.float64) and float(value) != int(value):
+        raise TraceUnsupported(f"a constant of dtype {dt} inside the traced region")
+    return Sym(g, g.const(value) if isinstance(value, numbers.Number) else _as_node(g, value))
 
 
 def _tf_like(value):
     def f(x, *a, **k):
         if isinstance(x, SymMat):
-            return SymMat([Sym(x.g, x.g.const(value)) for _ in x.cols])
-        return Sym(x.g, x.g.const(value))
+            return SymMat([_const_like(c, value, k) for c in x.cols])
+        return _const_like(x, value, k)
     return f
 
 
@@ -1451,7 +1657,9 @@ def _tf_sum(x, dim=None, keepdim=False, **k):
 
 
 def _tf_full_like(x, fill_value, **k):
-    return Sym(x.g, x.g.const(fill_value))
+    if isinstance(x, SymMat):
+        return SymMat([_const_like(c, fill_value, k) for c in x.cols])
+    return _const_like(x, fill_value, k)
 
 
 def _tf_pow(a, b):
@@ -1482,7 +1690,10 @@ def _elementwise(fn, *operands):
 
 
 def _where1(m, a, b):
-    return Sym(m.g, m.g.where(m.i, a.i, b.i))
+    if isinstance(m, _NarrowSym):
+        raise TraceUnsupported("torch.where with a float32 condition (torch wants a bool mask)")
+    r = Sym(m.g, m.g.where(m.i, a.i, b.i))
+    return r._as_bool() if (a.isbool and b.isbool) else r
 
 
 def _tf_where(condition, input=None, other=None, **k):
@@ -1518,11 +1729,21 @@ def _tf_clamp(x, min=None, max=None, **k):
 
 def _tf_maximum(a, b, **k):
     """torch.maximum / torch.max(a, b): the gradient is split evenly where the operands tie."""
-    return _elementwise(lambda x, y: _where1(x > y, x, _where1(y > x, y, 0.5 * (x + y))), a, b)
+    def one(x, y):
+        if x.isbool and y.isbool:
+            return x | y                                 # (of two bool masks: the OR, a bool again)
+        x, y = Sym(x.g, x.i), Sym(y.g, y.i)              # (the numbers, whatever torch dtype flags the operands carried)
+        return _where1(x > y, x, _where1(y > x, y, 0.5 * (x + y)))
+    return _elementwise(one, a, b)
 
 
 def _tf_minimum(a, b, **k):
-    return _elementwise(lambda x, y: _where1(x < y, x, _where1(y < x, y, 0.5 * (x + y))), a, b)
+    def one(x, y):
+        if x.isbool and y.isbool:
+            return x & y
+        x, y = Sym(x.g, x.i), Sym(y.g, y.i)
+        return _where1(x < y, x, _where1(y < x, y, 0.5 * (x + y)))
+    return _elementwise(one, a, b)
 
 
 def _tf_max(a, b=None, *rest, **k):
@@ -1555,7 +1776,7 @@ def _tf_heaviside(x, values, **k):
 
 def _tf_cmp(op, swap):
     def f(a, b, **k):
-        return _elementwise(lambda x, y: Sym(x.g, getattr(x.g, op)(*((y.i, x.i) if swap else (x.i, y.i)))), a, b)
+        return _elementwise(lambda x, y: x._cmp(y, op, swap), a, b)
     return f
 
 
@@ -1588,7 +1809,28 @@ def _tf_selu(x, inplace=False, **k):
 
 def _tf_celu(x, alpha=1.0, inplace=False, **k):
     a = float(alpha)
-    return _elementwise(lambda c: _where1(c > 0.0, c, (_where1(c > 0.0, c * 0.0, c) / a).expm1() * a), x)
+    # torch DIFFERENTIATES celu with the inverse of alpha rounded through float32 (derivatives.yaml: elu_backward(grad, alpha, 1,
+    # 1.0 / alpha.toFloat(), ...)) while the value uses the double: in the fp64 build that is a 1e-8 difference in every gradient
+    # through it.  Value from the exact branch, derivatives (all orders) from the one torch differentiates.
+    k32 = 1.0 / float(torch.tensor(a, dtype=torch.float32))
+
+    def one(c):
+        neg = _where1(c > 0.0, c * 0.0, c)
+        val = (neg / a).expm1() * a
+        if k32 == 1.0 / a:
+            return _where1(c > 0.0, c, val)
+        dv = (neg * k32).expm1() * a
+        return _where1(c > 0.0, c, dv + (val - dv).detach())
+    return _elementwise(one, x)
+
+
+def _hardsigmoid(c):
+    # value clamp(c / 6 + 1 / 2, 0, 1); torch's backward multiplies by 1.0f / 6.0f inside (-3, 3) whatever the dtype
+    # (hardsigmoid_backward: `one_sixth`), zero second derivative -- value from the exact formula, derivatives from that one
+    val = _tf_clamp(c / 6.0 + 0.5, 0.0, 1.0)
+    inside = (c > -3.0) & (c < 3.0)
+    dv = _where1(inside, c * 0.1666666716337204, c * 0.0)
+    return dv + (val - dv).detach()
 
 
 def _tf_gelu(x, approximate="none", **k):
@@ -1785,7 +2027,7 @@ _TORCH_FUNCS = {
     "softplus": _tf_softplus, "elu": _tf_elu, "selu": _tf_selu, "celu": _tf_celu, "gelu": _tf_gelu,
     "silu": _tf_elem(lambda c: c * c.sigmoid()), "mish": lambda x, **k: _elementwise(lambda c: c * _tf_softplus(c).tanh(), x),
     "softsign": _tf_elem(lambda c: c / (1.0 + abs(c))), "hardtanh": _tf_hardtanh, "relu6": _tf_elem(lambda c: _tf_clamp(c, 0.0, 6.0)),
-    "hardsigmoid": _tf_elem(lambda c: _tf_clamp(c / 6.0 + 0.5, 0.0, 1.0)), "hardswish": _tf_elem(lambda c: c * _tf_clamp(c / 6.0 + 0.5, 0.0, 1.0)),
+    "hardsigmoid": _tf_elem(_hardsigmoid), "hardswish": _tf_elem(lambda c: c * _tf_clamp(c / 6.0 + 0.5, 0.0, 1.0)),
     "log_sigmoid": _tf_elem(lambda c: -_tf_softplus(-c)), "logsigmoid": _tf_elem(lambda c: -_tf_softplus(-c)),
     "threshold": _tf_threshold, "_threshold": _tf_threshold, "tanhshrink": _tf_elem(lambda c: c - c.tanh()),
     "where": _tf_where, "clamp": _tf_clamp, "clip": _tf_clamp, "masked_fill": lambda x, mask, value, **k: _tf_where(mask, value, x),
@@ -1800,7 +2042,8 @@ _TORCH_FUNCS = {
     "not_equal": lambda a, b, **k: _elementwise(lambda x, y: x != y, a, b),
     "gt": _tf_cmp("gt", False), "greater": _tf_cmp("gt", False), "lt": _tf_cmp("gt", True), "less": _tf_cmp("gt", True),
     "ge": _tf_cmp("ge", False), "greater_equal": _tf_cmp("ge", False), "le": _tf_cmp("ge", True), "less_equal": _tf_cmp("ge", True),
-    "logical_not": lambda x, **k: 1.0 - x, "logical_and": lambda a, b, **k: a * b, "logical_or": lambda a, b, **k: a + b - a * b,
+    "logical_not": functools.partial(_tf_logical, "not"), "logical_and": functools.partial(_tf_logical, "and"),
+    "logical_or": functools.partial(_tf_logical, "or"), "logical_xor": functools.partial(_tf_logical, "xor"),
     "sin": _tf_unary("sin"), "cos": _tf_unary("cos"), "tan": _tf_unary("tan"), "exp": _tf_unary("exp"),
     "log": _tf_unary("log"), "tanh": _tf_unary("tanh"), "sqrt": _tf_unary("sqrt"), "abs": _tf_unary("abs"),
     "sinh": _tf_unary("sinh"), "cosh": _tf_unary("cosh"), "sigmoid": _tf_unary("sigmoid"),

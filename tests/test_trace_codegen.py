@@ -23,9 +23,10 @@ def rel_l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def trace(nets, conds, pde, n_coords, lap=True, cfv=None, loss="l2", metrics=()):
+def trace(nets, conds, pde, n_coords, lap=True, cfv=None, loss="l2", metrics=(), f64=False):
     from neurodiffeq_amd.symbolic import SymMat
     g = Graph(n_coords)
+    g.f64 = bool(f64)                   # (as engine.trace_system does: the precision of the build the trace is for)
     g.register_nets(nets, [describe(n)["n_out"] for n in nets], skips=[describe(n).get("skip_sym") for n in nets])
     cfv = cfv or (lambda net, cond, *coords: cond.enforce(net, *coords))
     term, mterms = None, []
@@ -50,7 +51,7 @@ def host_closure(nets, conds, pde, coords, params, lap=True, cfv=None, loss="l2"
     wdt = np.float64 if f64 else np.float32       # working precision of the generated pointwise code
     coords = np.ascontiguousarray(coords, wdt)
     n_coords, n = coords.shape
-    prog = trace(nets, conds, pde, n_coords, lap, cfv, loss, metrics)
+    prog = trace(nets, conds, pde, n_coords, lap, cfv, loss, metrics, f64=f64)
     if getattr(prog.g, "_nbatch_t", None) is not None:        # the batch size as a kernel argument (symbolic.Graph.nbatch)
         prog.g._nbatch_t.fill_(float(n))
     dims_act, flats, perms, off = [], [], [], 0

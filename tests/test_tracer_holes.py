@@ -97,6 +97,34 @@ PROBES = {
     "cast_to_half": ("lambda D: lambda u, x, y: [D(u, x) + u.to(torch.float16).to(u.dtype)]", True),
     "cast_to_long": ("lambda D: lambda u, x, y: [D(u, x) + (3.0 * x).long() * u]", True),
     "logit_eps": ("lambda D: lambda u, x, y: [D(u, x) + torch.logit(torch.sigmoid(3.0 * u), eps=0.2)]", False),
+    # torch.bool semantics (round 6, second half): `mask + mask` is a logical OR in torch, `&` / `|` / `~` exist for bool masks
+    # only, logical_* take any dtype ("non-zero is True"), a row sum of masks COUNTS
+    "mask_plus_mask": ("lambda D: lambda u, x, y: [D(u, x) + ((x > 0) + (y > 0)) * u + ((x > 0) + (y > 0) + (x > y)) * u]", False),
+    "not_mask_plus_mask": ("lambda D: lambda u, x, y: [D(u, x) + ((~(x > 0)) + (y > 0)) * u + ((x > 0) + True) * u]", False),
+    "mask_plus_int": ("lambda D: lambda u, x, y: [D(u, x) + ((x > 0) + 1) * u + ((x > 0) / 2) * u + ((x > 0) ** 2) * u]", False),
+    "mask_float_sum": ("lambda D: lambda u, x, y: [D(u, x) + ((x > 0).float() + (y > 0).float()) * u]", False),
+    "mask_xor": ("lambda D: lambda u, x, y: [D(u, x) + ((x > 0) ^ (y > 0)) * u + torch.logical_xor(x > 0, y > 0) * u]", False),
+    "mask_maximum": ("lambda D: lambda u, x, y: [D(u, x) + torch.maximum(x > 0, y > 0) * u + torch.minimum(x > 0, y > 0) * u]", False),
+    "mask_row_count": ("lambda D: lambda u, x, y: [D(u, x) + torch.cat([x > 0, y > 0], 1).sum(dim=1, keepdim=True) * u]", False),
+    "mask_where_of_masks": ("lambda D: lambda u, x, y: [D(u, x) + (torch.where(x > 0, y > 0, x > y) + (x > 0.5)) * u]", False),
+    "logical_of_floats": ("lambda D: lambda u, x, y: [D(u, x) + torch.logical_and(torch.round(2 * x), torch.round(2 * y)) * u "
+                          "+ torch.logical_or(torch.round(2 * x), torch.round(2 * y)) * u + torch.logical_not(torch.round(2 * x)) * u]", False),
+    "mask_minus_mask": ("lambda D: lambda u, x, y: [D(u, x) + ((x > 0) - (y > 0)) * u]", "torch raises"),        # torch raises
+    "minus_mask": ("lambda D: lambda u, x, y: [D(u, x) + (-(x > 0)) * u]", "torch raises"),
+    "invert_a_float": ("lambda D: lambda u, x, y: [D(u, x) + (~x) * u]", "torch raises"),
+    "and_of_floats": ("lambda D: lambda u, x, y: [D(u, x) + (x & y) * u]", "torch raises"),
+    "or_float_mask": ("lambda D: lambda u, x, y: [D(u, x) + (x | (y > 0)) * u]", "torch raises"),
+    "coordinate_switched_off": ("lambda D: lambda u, x, y: [D(u, x.requires_grad_(False)) + u]", "torch raises"),
+    # float32 values inside the fp64 build (the probes run the fp64 host pipeline): the reference rounds / computes in float32
+    "float_of_a_value": ("lambda D: lambda u, x, y: [D(u, x) + u.float() * x]", True),
+    "to_float32": ("lambda D: lambda u, x, y: [D(u, x) + u.to(torch.float32) * x + y.type(torch.float32) * u]", True),
+    "mask_float_times_number": ("lambda D: lambda u, x, y: [D(u, x) + (x > 0).float() * 0.1 * u]", True),
+    "ones_float32_times_number": ("lambda D: lambda u, x, y: [D(u, x) + 0.1 * torch.ones_like(u, dtype=torch.float32) * u]", True),
+    "mask_float_times_column": ("lambda D: lambda u, x, y: [D(u, x) + (x > 0).float() * u + u * (y > 0).to(torch.float32) "
+                                "+ torch.ones_like(u, dtype=torch.float32) * u + (x > 0).to(u.dtype) * u + (x > 0).type_as(u) * u]", False),
+    "double_of_a_value": ("lambda D: lambda u, x, y: [D(u, x) + u.double() * x + u.to(torch.float64) * y]", False),
+    # torch differentiates these two with float32 constants whatever the dtype (derivatives.yaml / hardsigmoid_backward)
+    "celu_hardsigmoid": ("lambda D: lambda u, x, y: [D(u, x) + F.celu(u, alpha=0.7) + F.hardsigmoid(u) + F.celu(D(u, y)) + F.hardswish(u)]", False),
 }
 
 
@@ -104,6 +132,16 @@ PROBES = {
 def test_probe_matches_autograd_or_refuses(name):
     src, must_refuse = PROBES[name]
     system = _pde_system(name, src)
+    if must_refuse == "torch raises":
+        # the reference itself fails on these (bool - bool, ~float, float & float ...): the trace must not quietly compute
+        # something instead -- whatever it raises sends the solver to the reference's closure, which raises torch's error
+        from tests.test_trace_codegen import trace
+        nets, conds, pde = system.product()
+        with pytest.raises(Exception):                   # noqa: B017, PT011
+            trace(nets, conds, pde, 2, f64=True)
+        with pytest.raises(Exception):                   # noqa: B017, PT011
+            _run(system)
+        return
     if must_refuse:
         with pytest.raises((TraceUnsupported, TypeError)) as e:       # (TypeError: torch's own argument parser met the token)
             _run(system)
