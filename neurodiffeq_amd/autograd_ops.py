@@ -334,9 +334,15 @@ def _spec_for(net, order, dtype=torch.float32):
     """(d, order, hidden, layers, act, n_out) + parameter list if the gfx950 kernels can run ``net`` in ``dtype``, else
     None."""
     cache = _SPECS.setdefault(net, {})
+    from .networks import STRUCTURE, track_structure
+    if cache.get("structure") != STRUCTURE[0]:           # a layer / parameter / hook of some tracked network changed: ask again
+        cache.clear()
+        cache["structure"] = STRUCTURE[0]
     hit = cache.get((order, dtype))
     if hit is not None:
         return hit if hit else None
+    track_structure(net)
+    cache["structure"] = STRUCTURE[0]
     info = describe(net, dtype=dtype)
     ok = info is not None and info["skip"] == 0 and info.get("skip_sym") is None and info["actp"] == 0 and info["widths"] == 0 and info["mono"] == 0 and 1 <= info["d"] <= 3 \
         and (order < 4 or info["d"] <= 2)          # (every fourth-order partial of three inputs would be 35 streams)

@@ -110,6 +110,9 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     for n in all_nets:
         if not any(n is m for m in nets):
             nets.append(n)
+    from .networks import track_structure
+    for n in nets:
+        track_structure(n)           # (from here on a replaced layer / re-assigned weight / new hook re-keys the solver's system)
     infos = [describe(n, dtype=torch.float64 if f64 else torch.float32) for n in nets]
     if any(i is None for i in infos):
         raise TraceUnsupported("a network is not an FCNN the gfx950 kernels support")

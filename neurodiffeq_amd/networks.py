@@ -8,12 +8,107 @@ trainable parameters; any number of output units) and :class:`FlatParams`, which
 one flat fp32 buffer -- linear layers in torch order, then the skip weights, then the activation parameters: the
 layout ``ndq_mlp_jet_fwd/bwd`` and ``ndq_adam_step`` consume.
 """
+import collections
 import warnings
+import weakref
 
 import torch
 import torch.nn as nn
 
 from . import _lib
+
+# ---- what a network IS can change between epochs (solvers.py:496-497 runs callbacks there): a layer replaced, a weight
+# re-assigned, a weight-norm / parametrization registered, a forward hook added.  The kernels read a flat copy of the parameters
+# describe() listed when the system was built, so every such change has to reach the solver.  Checking module trees every epoch
+# would cost microseconds of a 20 us step; instead the change itself raises a flag: torch's global registration hooks (a
+# parameter / submodule / buffer set on a tracked module) and hook dictionaries that count their own edits bump
+# STRUCTURE[0], which is part of the solver's system key and of the custom-op seam's cache key.
+STRUCTURE = [0]
+_tracked = weakref.WeakSet()
+_HOOK_DICTS = ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")
+
+
+class _NotifyingHooks(collections.OrderedDict):
+    """A module's hook dictionary that bumps STRUCTURE[0] whenever a hook is added or removed."""
+
+    def __setitem__(self, k, v):
+        STRUCTURE[0] += 1
+        super().__setitem__(k, v)
+
+    def __delitem__(self, k):
+        STRUCTURE[0] += 1
+        super().__delitem__(k)
+
+    def pop(self, *a, **k):
+        STRUCTURE[0] += 1
+        return super().pop(*a, **k)
+
+    def popitem(self, *a, **k):
+        STRUCTURE[0] += 1
+        return super().popitem(*a, **k)
+
+    def clear(self):
+        STRUCTURE[0] += 1
+        super().clear()
+
+    def update(self, *a, **k):
+        STRUCTURE[0] += 1
+        super().update(*a, **k)
+
+    def setdefault(self, *a, **k):
+        STRUCTURE[0] += 1
+        return super().setdefault(*a, **k)
+
+    def __reduce__(self):           # copies and pickles are plain dictionaries (nothing outside this process names the class)
+        return (collections.OrderedDict, (), None, None, iter(list(self.items())))
+
+
+def _on_registration(module, name, value):
+    if module in _tracked:
+        STRUCTURE[0] += 1
+    return None
+
+
+def track_structure(net):
+    """From now on a structural change of ``net`` (any module of its tree) bumps STRUCTURE[0]."""
+    if not _tracked:
+        from torch.nn.modules import module as M
+        if not getattr(M, "_ndq_registration_hooks", False):
+            M.register_module_parameter_registration_hook(_on_registration)
+            M.register_module_module_registration_hook(_on_registration)
+            M.register_module_buffer_registration_hook(_on_registration)
+            M._ndq_registration_hooks = True
+    for m in net.modules():
+        if m not in _tracked:
+            _tracked.add(m)
+        for name in _HOOK_DICTS:
+            d = m.__dict__.get(name)
+            if d is not None and not isinstance(d, _NotifyingHooks):
+                nd = _NotifyingHooks()
+                collections.OrderedDict.update(nd, d)
+                m.__dict__[name] = nd
+
+
+def _hooked(*modules):
+    for m in modules:
+        d = m.__dict__
+        for name in _HOOK_DICTS:
+            if d.get(name):
+                return True
+    return False
+
+
+def _forward_is(m, *owners):
+    """Does ``m`` run the forward of one of ``owners`` (classes of this package, of torch, or the reference package's class of the
+    same name)?  A subclass that overrides forward computes something the kernels do not."""
+    f = type(m).forward
+    for o in owners:
+        if f is o.forward:
+            return True
+        if o.__module__ == __name__ and getattr(f, "__module__", "") == "neurodiffeq.networks" and \
+                getattr(f, "__qualname__", "") == o.__name__ + ".forward":
+            return True
+    return False
 
 
 class SinActv(nn.Module):
@@ -157,12 +252,22 @@ def describe(net, dtype=torch.float32):
     """Return ``dict(d, hidden, layers, act, n_out, linears)`` if ``net`` is an FCNN the HIP kernels can run,
     else ``None`` (the solver then uses the composite autograd path for the whole system)."""
     skip = None
+    outer = net
     if isinstance(net, Resnet):                  # FCNN branch + bias-free linear skip: out += S x, handled in-kernel
+        if not _forward_is(net, Resnet) or _hooked(net):
+            return None
         skip, net = net.skip_connection, net.residual
-        if skip.bias is not None or skip.weight.dtype != dtype:
+        if type(skip) is not nn.Linear or skip.bias is not None or skip.weight.dtype != dtype or _hooked(skip):
             return None
     seq = getattr(net, "NN", net)
-    if not isinstance(seq, nn.Sequential):
+    if not isinstance(seq, nn.Sequential) or not _forward_is(seq, nn.Sequential):
+        return None
+    # the module the solver calls must compute exactly "its Sequential": an FCNN (not a subclass with a forward of its own, not
+    # some other module that happens to keep a Sequential under .NN), or the Sequential itself; and nobody listens in -- a
+    # forward (pre-)hook may replace inputs / outputs, a backward hook gradients, and the kernels would never call it
+    if seq is not net and not _forward_is(net, FCNN):
+        return None
+    if _hooked(net, seq):
         return None
     # a MonomialNN feature map in front: Sequential(MonomialNN(degrees), FCNN(...)) or Sequential(MonomialNN, Linear, actv,
     # ..., Linear) -- ascending degrees 1..8 (ndq_mlp_desc.mono: the first layer evaluates the powers and their derivatives)
@@ -172,13 +277,25 @@ def describe(net, dtype=torch.float32):
         if skip is not None or degs != sorted(set(degs)) or degs[0] < 1 or degs[-1] > 8:
             return None
         mono = sum(1 << (k - 1) for k in degs)
+        if not _forward_is(seq[0], MonomialNN) or _hooked(seq[0]):
+            return None
         rest = list(seq)[1:]
-        seq = rest[0].NN if len(rest) == 1 and isinstance(rest[0], FCNN) else nn.Sequential(*rest)
+        if len(rest) == 1 and isinstance(rest[0], FCNN):
+            if not _forward_is(rest[0], FCNN) or not _forward_is(rest[0].NN, nn.Sequential) or _hooked(rest[0], rest[0].NN):
+                return None
+            seq = rest[0].NN
+        else:
+            seq = nn.Sequential(*rest)
     mods = list(seq)
     if len(mods) < 3 or len(mods) % 2 == 0:
         return None
     linears, acts = mods[0::2], mods[1::2]
     if not all(isinstance(m, nn.Linear) and m.bias is not None for m in linears):
+        return None
+    # plain linear layers with their own trainable nn.Parameters: no weight_norm / spectral_norm / parametrization (the weight is
+    # then COMPUTED from other parameters), no subclass forward, no hooks on layers or activations
+    if not all(_forward_is(m, nn.Linear) and isinstance(m._parameters.get("weight"), nn.Parameter)
+               and isinstance(m._parameters.get("bias"), nn.Parameter) for m in linears) or _hooked(*mods):
         return None
     act_types = {type(a) for a in acts}
     if len(act_types) != 1 or next(iter(act_types)) not in _ACT_IDS or not all(_default_torch_activation(a) for a in acts):
@@ -233,6 +350,11 @@ def describe(net, dtype=torch.float32):
             return None
         skip_sym, skip = skip, None
     params = [p for l in linears for p in (l.weight, l.bias)] + ([skip.weight] if skip is not None else []) + act_params
+    every = params + ([skip_sym.weight] if skip_sym is not None else [])
+    if len({id(p) for p in every}) != len(every):
+        return None              # one parameter in two places (tied weights): one gradient in torch, two slots in the flat vector
+    if not all(p.requires_grad for p in every):
+        return None              # a frozen layer: torch leaves it alone (no gradient, the optimiser skips it); the fused step would not
     n_in = linears[0].in_features
     if mono:
         n_deg = bin(mono).count("1")
@@ -292,6 +414,14 @@ class FlatParams:
                 p.data = flat[off:off + p.numel()].view(p.shape)
         self.flat = flat
         self._ptrs = [flat.data_ptr() + self.esize * off for off in self._offsets]
+
+    def all_trainable(self):
+        """Does every parameter still ask for a gradient?  (``layer.requires_grad_(False)`` by a callback: the reference stops
+        updating that layer -- cheap enough to ask every epoch)"""
+        for p in self.params:
+            if not p.requires_grad:
+                return False
+        return True
 
     def attach_grads(self):
         """Expose the flat gradient buffer as ``p.grad`` views (what ``loss.backward()`` leaves behind, solvers.py:393)."""

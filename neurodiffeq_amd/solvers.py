@@ -34,6 +34,7 @@ from .networks import FCNN, describe
 from .neurodiffeq import safe_diff as diff
 from .optim import FusedAdam
 from .symbolic import MetricTraceUnsupported, TraceUnsupported
+from .networks import STRUCTURE as _net_structure
 
 
 _CLOSURE_CACHE = {}
@@ -371,10 +372,14 @@ class BaseSolver(ABC):
         # [gradient | loss] vector in double through torch.distributed, the device-side tail in double -- parallel.py)
         if self._loss_time_dependent:
             reason = "epoch-dependent loss function"
+        # (STRUCTURE[0]: bumped by a layer / parameter / hook set on any network the kernels serve -- networks.track_structure)
         key = (id(self.diff_eqs), net_ids, tuple(id(c) for c in self.conditions),
                getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind, sys_dtype,
                id(self.loss_fn) if loss_kind == "custom" else None,
-               tuple((name, id(fn)) for name, fn in self.metrics_fn.items()))
+               tuple((name, id(fn)) for name, fn in self.metrics_fn.items()), _net_structure[0])
+        if key == self._fused_key and self._fused_sys is not None and not all(fp.all_trainable() for fp in self._fused_sys.flat):
+            self._flush_device_history()
+            self._fused_key = None              # a layer frozen by a callback: describe() sends the system to the composite path
         if key == self._fused_key and self._fused_sys is not None and not self._equations_unchanged(self._fused_sys):
             # the callables compute something else now: rebuild below (cached by source) -- with the outside numbers that
             # moved since the compiled trace as RUNTIME constants (symbolic.Graph.external): a coefficient ramped every epoch

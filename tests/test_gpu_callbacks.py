@@ -1,0 +1,235 @@
+"""Callbacks that change the SOLVER between epochs (the reference runs them after every epoch and re-reads everything at the
+next batch: solvers.py:369-395, 496-497).  Every scenario trains twice from the same seed -- on the fused MI355X path, and as
+the reference does it (``fused="off"`` with the custom-op seam switched off: plain torch modules under torch autograd) -- with
+the same callback firing at the same epochs; loss histories and final parameters have to agree to fp32 accuracy.  A change the
+fused path did not notice shows as a trajectory that splits at the callback's epoch."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import autograd_ref as R
+
+pytestmark = pytest.mark.gpu
+
+EPOCHS, AT = 8, (3, 5)
+
+
+def _solver(fused, kind="ode"):
+    s = _make(kind)
+    s.fused = fused
+    return s
+
+
+def _make(kind):
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP, DirichletBVP2D
+    from neurodiffeq_amd.generators import Generator1D, Generator2D
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.solvers import Solver1D, Solver2D
+    torch.manual_seed(11)
+    if kind == "ode":
+        nets = [FCNN(1, 1, hidden_units=(32, 32)).cuda()]
+        return Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], nets=nets,
+                        train_generator=Generator1D(64, 0.0, 2.0, method="equally-spaced"),
+                        valid_generator=Generator1D(32, 0.0, 2.0, method="equally-spaced"))
+    if kind == "system":
+        nets = [FCNN(1, 1, hidden_units=(32, 32)).cuda() for _ in range(2)]
+        return Solver1D(lambda u, v, t: [diff(u, t) - (u - u * v), diff(v, t) - (u * v - v)], [IVP(0.0, 1.5), IVP(0.0, 1.0)], nets=nets,
+                        train_generator=Generator1D(64, 0.1, 4.0, method="equally-spaced"),
+                        valid_generator=Generator1D(32, 0.1, 4.0, method="equally-spaced"))
+    zero = lambda v: 0 * v
+    nets = [FCNN(2, 1, hidden_units=(32, 32)).cuda()]
+    return Solver2D(lambda u, x, y: [diff(u, x, order=2) + diff(u, y, order=2)],
+                    [DirichletBVP2D(0, lambda y: torch.sin(3.14159265 * y), 1, zero, 0, zero, 1, zero)], nets=nets,
+                    train_generator=Generator2D((12, 12), (0, 0), (1, 1), method="equally-spaced"),
+                    valid_generator=Generator2D((8, 8), (0, 0), (1, 1), method="equally-spaced"))
+
+
+def _lr(s):
+    s.optimizer.param_groups[0]["lr"] *= 0.3
+
+
+def _scale_weights_no_grad(s):
+    with torch.no_grad():
+        s.nets[0].NN[0].weight.mul_(0.9)
+
+
+def _shift_bias_through_data(s):
+    s.nets[0].NN[2].bias.data.add_(0.05)
+
+
+def _load_state_dict(s):
+    sd = {k: 0.95 * v for k, v in s.nets[0].state_dict().items()}
+    s.nets[0].load_state_dict(sd)
+
+
+def _replace_a_layer(s):
+    torch.manual_seed(99)
+    old = s.nets[0].NN[2]
+    new = nn.Linear(old.in_features, old.out_features).cuda()
+    s.nets[0].NN[2] = new
+    # (the optimiser has to learn about the new parameters as any torch user would tell it)
+    s.optimizer = torch.optim.Adam(itertools.chain.from_iterable(n.parameters() for n in s.nets), lr=1e-3)
+
+
+def _reassign_a_weight(s):
+    layer = s.nets[0].NN[0]
+    layer.weight = nn.Parameter(0.5 * layer.weight.detach().clone())
+    s.optimizer = torch.optim.Adam(itertools.chain.from_iterable(n.parameters() for n in s.nets), lr=1e-3)
+
+
+def _new_optimizer_sgd(s):
+    s.optimizer = torch.optim.SGD(itertools.chain.from_iterable(n.parameters() for n in s.nets), lr=1e-2, momentum=0.5)
+
+
+def _freeze_first_layer(s):
+    s.nets[0].NN[0].weight.requires_grad_(False)
+    s.nets[0].NN[0].bias.requires_grad_(False)
+
+
+def _freeze_whole_second_net(s):
+    s.nets[-1].requires_grad_(False)
+
+
+def _doubling_hook(s):
+    if not getattr(s, "_hooked_once", False):
+        s._hooked_once = True
+        s.nets[0].NN[1].register_forward_hook(lambda m, i, o: 1.5 * o)
+
+
+def _hook_on_the_network(s):
+    if not getattr(s, "_hooked_once", False):
+        s._hooked_once = True
+        s.nets[0].register_forward_hook(lambda m, i, o: o + 0.1)
+
+
+def _swap_activation(s):
+    s.nets[0].NN[1] = nn.Sigmoid()
+
+
+def _new_equations(s):
+    from neurodiffeq_amd import diff
+    if len(s.nets) == 1 and s.diff_eqs.__code__.co_argcount == 2:
+        s.diff_eqs = lambda u, t: [diff(u, t) + 2.0 * u]
+
+
+def _new_initial_value(s):
+    s.conditions[0].u_0 = 1.0 + 0.25 * s.global_epoch
+    if hasattr(s.conditions[0], "u0"):
+        s.conditions[0].u0 = s.conditions[0].u_0
+
+
+def _more_batches(s):
+    s.n_batches["train"] = 2
+
+
+def _new_generator(s):
+    from neurodiffeq_amd.generators import Generator1D, SamplerGenerator
+    s.generator["train"] = SamplerGenerator(Generator1D(48, 0.0, 1.5, method="equally-spaced"))      # (solvers.py:148-149 wraps them so)
+
+
+def _weight_decay(s):
+    s.optimizer.param_groups[0]["weight_decay"] = 0.01
+
+
+def _zero_the_moments(s):
+    for st in s.optimizer.state.values():
+        st["exp_avg"].zero_()
+
+
+def _clip_weights(s):
+    with torch.no_grad():
+        for p in s.nets[0].parameters():
+            p.clamp_(-0.5, 0.5)
+
+
+def _betas_and_eps(s):
+    s.optimizer.param_groups[0]["betas"] = (0.8, 0.9)
+    s.optimizer.param_groups[0]["eps"] = 1e-6
+
+
+def _replace_the_network(s):
+    from neurodiffeq_amd.networks import FCNN
+    torch.manual_seed(123)
+    s.nets[0] = FCNN(s.nets[0].NN[0].in_features, 1, hidden_units=(16, 16)).cuda()
+    s.optimizer = torch.optim.Adam(itertools.chain.from_iterable(n.parameters() for n in s.nets), lr=1e-3)
+
+
+def _replace_the_condition(s):
+    from neurodiffeq_amd.conditions import IVP
+    s.conditions[0] = IVP(0.0, 0.5)
+
+
+def _new_loss(s):
+    s.loss_fn = lambda r, f, x: (r.abs()).mean()
+
+
+def _add_param_group(s):
+    if len(s.optimizer.param_groups) == 1:
+        extra = nn.Parameter(torch.zeros(1, device="cuda"))
+        s.optimizer.add_param_group({"params": [extra], "lr": 1e-2})
+
+
+def _perturb_under_inference_mode(s):
+    with torch.inference_mode():
+        s.nets[0].NN[4].weight.add_(0.01)
+
+
+SCENARIOS = {
+    "lr": ("ode", _lr), "scale_weights_no_grad": ("ode", _scale_weights_no_grad), "bias_through_data": ("pde", _shift_bias_through_data),
+    "load_state_dict": ("ode", _load_state_dict), "replace_a_layer": ("ode", _replace_a_layer), "reassign_a_weight": ("pde", _reassign_a_weight),
+    "new_optimizer_sgd": ("ode", _new_optimizer_sgd), "freeze_first_layer": ("ode", _freeze_first_layer),
+    "freeze_second_net": ("system", _freeze_whole_second_net), "hook_on_an_activation": ("ode", _doubling_hook),
+    "hook_on_the_network": ("pde", _hook_on_the_network), "swap_activation": ("ode", _swap_activation), "new_equations": ("ode", _new_equations),
+    "new_initial_value": ("ode", _new_initial_value), "more_batches": ("ode", _more_batches), "new_generator": ("ode", _new_generator),
+    "betas_and_eps": ("pde", _betas_and_eps), "replace_the_network": ("ode", _replace_the_network),
+    "replace_the_condition": ("ode", _replace_the_condition), "new_loss": ("ode", _new_loss), "add_param_group": ("ode", _add_param_group),
+    "perturb_under_inference_mode": ("ode", _perturb_under_inference_mode),
+    "weight_decay": ("pde", _weight_decay), "zero_the_moments": ("system", _zero_the_moments), "clip_weights": ("pde", _clip_weights),
+}
+
+
+def _train(fused, kind, change):
+    from neurodiffeq_amd import autograd_ops
+    s = _solver(fused, kind)
+
+    def cb(solver):
+        if solver.global_epoch in AT:
+            change(solver)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if fused == "off":
+            with autograd_ops.native_autograd(False):
+                s.fit(EPOCHS, callbacks=[cb])
+        else:
+            s.fit(EPOCHS, callbacks=[cb])
+    return (np.array(s.metrics_history["train_loss"]), np.array(s.metrics_history["valid_loss"]),
+            R.get_flat(s.nets).double().cpu().numpy(), s)
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_a_callback_that_changes_the_solver_takes_effect_as_in_the_reference(name):
+    kind, change = SCENARIOS[name]
+    ft, fv, fp, fs = _train("auto", kind, change)
+    pt, pv, pp, ps = _train("off", kind, change)
+    assert len(ft) == len(pt) == EPOCHS
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12)))
+    assert rel(ft, pt) < 2e-4, (name, "train", ft, pt)
+    assert rel(fv, pv) < 2e-4, (name, "valid", fv, pv)
+    assert np.linalg.norm(fp - pp) <= 2e-4 * np.linalg.norm(pp), (name, "parameters")
+
+
+def test_the_fused_path_is_used_until_the_change_and_left_loudly_when_it_must():
+    kind, change = SCENARIOS["hook_on_an_activation"]
+    from neurodiffeq_amd import autograd_ops          # noqa: F401
+    s = _solver("auto", kind)
+    s.fit(2)
+    assert s.fused_active
+    change(s)
+    with pytest.warns(RuntimeWarning, match="NOT on the fused MI355X path"):
+        s.fit(1)
+    assert not s.fused_active
