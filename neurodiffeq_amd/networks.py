@@ -143,6 +143,18 @@ class APTx(nn.Module):
         return (self.alpha + torch.tanh(self.beta * x)) * self.gamma * x
 
 
+def _traced_call(net, t):
+    """``net(torch.cat([x, y], 1))`` written out by hand inside a condition's ``enforce`` (or a ``compute_func_val``) while the
+    solver traces the system: the network's symbol at those coordinate columns, exactly what ``BaseCondition.enforce`` arrives
+    at (conditions.py:52-55).  Anything but the solver's own network at plain coordinate columns raises TraceUnsupported."""
+    from .symbolic import Sym, SymMat, current_graph
+    if isinstance(t, Sym):
+        return current_graph().net_symbol(net, [t])
+    if isinstance(t, SymMat):
+        return current_graph().net_symbol(net, list(t.cols))
+    return None
+
+
 class FCNN(nn.Module):
     """Fully connected network ``Linear -> actv -> ... -> Linear`` (reference: networks.py:26-70).
 
@@ -178,6 +190,10 @@ class FCNN(nn.Module):
         # CUDA fp32 inputs go through the gfx950 stream kernels (autograd_ops.MlpJet: the output comes back together
         # with its input derivatives, so diff() / operators / loss.backward() of ANY caller run on the HIP path);
         # everything else -- CPU, fp64, shapes the kernels do not cover -- is the reference's plain Sequential
+        if not isinstance(t, torch.Tensor):
+            sym = _traced_call(self, t)          # a custom `enforce` / `compute_func_val` calling the network while the solver traces
+            if sym is not None:
+                return sym
         from .autograd_ops import try_jet_forward
         out = try_jet_forward(self, t)
         return self.NN(t) if out is None else out
@@ -196,6 +212,10 @@ class Resnet(nn.Module):
         self.skip_connection = nn.Linear(n_input_units, n_output_units, bias=False)
 
     def forward(self, t):
+        if not isinstance(t, torch.Tensor):
+            sym = _traced_call(self, t)
+            if sym is not None:
+                return sym
         return self.skip_connection(t) + self.residual(t)
 
 

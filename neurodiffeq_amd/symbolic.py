@@ -125,6 +125,9 @@ class Graph:
                 raise TraceUnsupported("network evaluated at something other than coordinate columns")
             deps.append(node[1])
         deps = tuple(deps)
+        if len(set(deps)) != len(deps):
+            # net(cat([x, x], 1)): d/dx is the SUM of two input derivatives -- the stream sets are per coordinate
+            raise TraceUnsupported("network evaluated with one coordinate column in two of its inputs")
         site = self._sites.get((k, deps))
         if site is None:
             if k not in self.net_deps:           # the network's first site keeps the network's own index

@@ -247,3 +247,42 @@ def test_the_fuzzer_exercises_both_outcomes():
     refusing = sum(any(leaf in s for leaf in REFUSING) for s in srcs)
     shaped = sum(any(leaf in s for leaf in TRACING) and not any(leaf in s for leaf in REFUSING) for s in srcs)
     assert refusing >= 6 and shaped >= 12, (refusing, shaped)
+
+
+# ---- a condition that overrides `enforce` and calls the network itself (hard constraints written by hand, conditions.py:52-55)
+class _ByHand(C.BaseCondition):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def enforce(self, net, *coords):
+        return self.fn(net, *coords)
+
+
+BY_HAND = {
+    "plain": ("lambda net, x, y: net(torch.cat([x, y], 1))", False),
+    "swapped": ("lambda net, x, y: net(torch.cat((y, x), dim=-1))", False),
+    "hard_constraint": ("lambda net, x, y: (1 - x ** 2) * (1 - y ** 2) * net(torch.cat([x, y], 1)) + torch.sin(3.0 * x)", False),
+    "forward_spelled_out": ("lambda net, x, y: 1.0 + (1 - torch.exp(-(x + 1.0))) * net.forward(torch.cat([x, y], 1))", False),
+    "detached_copy": ("lambda net, x, y: net(torch.cat([x, y], 1)).detach() * x + net(torch.cat([x, y], 1))", False),
+    # the network somewhere else than at the coordinate columns: derivative streams are per coordinate -- refused
+    "one_column_twice": ("lambda net, x, y: net(torch.cat([x, x], 1))", True),
+    "scaled_input": ("lambda net, x, y: net(torch.cat([2.0 * x - 1.0, y], 1))", True),
+    "reflected": ("lambda net, x, y: 0.5 * (net(torch.cat([x, y], 1)) + net(torch.cat([-x, y], 1)))", True),
+    "detached_input": ("lambda net, x, y: net(torch.cat([x.detach(), y], 1))", True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BY_HAND))
+def test_network_called_by_hand_inside_enforce(name):
+    src, must_refuse = BY_HAND[name]
+    fn = eval(src, {"torch": torch})          # noqa: S307 -- fixed templates above
+    system = zoo.System(name, 2, [(2, 1, (32, 32), "tanh")], [(-1.0, 1.0), (-1.0, 1.0)],
+                        lambda D: (lambda u, x, y: [D(u, x, order=2) + D(u, y, order=2) + u * D(u, x)]),
+                        lambda: [_ByHand(fn)], lambda D: [fn])
+    if must_refuse:
+        with pytest.raises(TraceUnsupported):
+            _run(system)
+        return
+    r, l, g = _run(system)
+    assert r < 1e-10 and l < 1e-10 and g < 1e-9, (name, r, l, g)
