@@ -35,6 +35,8 @@ from .neurodiffeq import safe_diff as diff
 from .optim import FusedAdam
 from .symbolic import MetricTraceUnsupported, TraceUnsupported
 from .networks import STRUCTURE as _net_structure
+import os as _os
+_QUICK_KEY = _os.environ.get("NDQ_QUICK_KEY", "1") != "0"        # (A/B switch of the per-epoch identity check in _fused_system)
 
 
 _CLOSURE_CACHE = {}
@@ -178,6 +180,8 @@ class BaseSolver(ABC):
         self._eq_watch = None                  # _pystate.StateWatch over what diff_eqs / the conditions can read
         self._eq_probe_countdown = 1           # epochs until the next unconditional re-trace (second use, then EQ_PROBE_EVERY)
         self._fused_key = None
+        self._fused_quick = None               # what _fused_key was made of, object by object (the per-epoch identity check)
+        self._fused_quick_parts = None
         self._fast_tracks_best = False
         self.dist = None                # optional neurodiffeq_amd.parallel.BatchSharding
         # the solver's own bookkeeping attributes: not equation state when diff_eqs is a bound method (_pystate.StateWatch)
@@ -337,13 +341,8 @@ class BaseSolver(ABC):
         return self._generate_batch("valid")
 
     # ------------------------------------------------------------------------------------------ fused system
-    def _fused_system(self, n_coords):
-        """The compiled fused step for the current (diff_eqs, nets, conditions, loss), or None -> composite path.
-        Re-keyed every epoch because callbacks may swap any of these between epochs (solvers.py:496-497)."""
-        if self.fused == "off" or self.device.type != "cuda":
-            if self.fused == "require":
-                raise _lib.NdqError("fused='require' but no MI355X is visible")
-            return None
+    def _fused_system_key(self, cfv):
+        """(key, reason, loss_kind, working dtype) of the fused system the solver's current objects ask for."""
         reason = None
         loss_kind = "l2" if self.loss_fn is _default_l2 else \
             next((k for k in ("l2", "l1", "infinity", "h1", "h1 semi") if self.loss_fn is _losses[k]), None)
@@ -374,9 +373,39 @@ class BaseSolver(ABC):
             reason = "epoch-dependent loss function"
         # (STRUCTURE[0]: bumped by a layer / parameter / hook set on any network the kernels serve -- networks.track_structure)
         key = (id(self.diff_eqs), net_ids, tuple(id(c) for c in self.conditions),
-               getattr(self.compute_func_val, "__func__", self.compute_func_val), reason, loss_kind, sys_dtype,
+               cfv, reason, loss_kind, sys_dtype,
                id(self.loss_fn) if loss_kind == "custom" else None,
                tuple((name, id(fn)) for name, fn in self.metrics_fn.items()), _net_structure[0])
+        self._fused_quick_parts = (self.diff_eqs, list(self.nets), list(self.conditions), cfv, self.loss_fn, self.optimizer,
+                                   dict(self.metrics_fn), _net_structure[0], self._loss_time_dependent, self.dist, type(self),
+                                   [(p, p.dtype) for p in probe[1]])
+        return key, reason, loss_kind, sys_dtype
+
+    def _fused_system(self, n_coords):
+        """The compiled fused step for the current (diff_eqs, nets, conditions, loss), or None -> composite path.
+        Re-keyed every epoch because callbacks may swap any of these between epochs (solvers.py:496-497)."""
+        if self.fused == "off" or self.device.type != "cuda":
+            if self.fused == "require":
+                raise _lib.NdqError("fused='require' but no MI355X is visible")
+            return None
+        # (this runs every epoch and the host is the bottleneck of the headline step: when every OBJECT the key below is made of
+        # is the one it was made of last time, the key is last time's -- one chain of identity comparisons instead of five
+        # generator expressions)
+        q = self.__dict__.get("_fused_quick") if _QUICK_KEY else None
+        cfv = getattr(self.compute_func_val, "__func__", self.compute_func_val)
+        if q is not None and self.diff_eqs is q[0] and self.nets == q[1] and self.conditions == q[2] and cfv is q[3] \
+                and self.loss_fn is q[4] and self.optimizer is q[5] and self.metrics_fn == q[6] and _net_structure[0] == q[7] \
+                and self._loss_time_dependent is q[8] and self.dist is q[9] and type(self) is q[10] and self._fused_key is q[11] \
+                and all(p.dtype is dt for p, dt in q[12]):
+            key = q[11]
+            reason, loss_kind, sys_dtype = key[4], key[5], key[6]
+        else:
+            key, reason, loss_kind, sys_dtype = self._fused_system_key(cfv)
+            self._fused_quick = None
+            if key == self._fused_key:
+                key = self._fused_key            # (the same system as last epoch: from the next epoch on the quick check serves it)
+                parts = self._fused_quick_parts
+                self._fused_quick = parts[:11] + (key, parts[11])
         if key == self._fused_key and self._fused_sys is not None and not all(fp.all_trainable() for fp in self._fused_sys.flat):
             self._flush_device_history()
             self._fused_key = None              # a layer frozen by a callback: describe() sends the system to the composite path

@@ -1153,3 +1153,17 @@ def test_equations_that_change_the_state_they_read_leave_the_fused_path():
 class _FakeColumn:
     def __mul__(self, o): return self
     __rmul__ = __add__ = __radd__ = __mul__
+
+
+def test_every_private_attribute_the_solver_sets_is_declared_its_own():
+    """A bookkeeping attribute the solver adds while it runs (a cache, a flag) must not look like equation state to the walk:
+    one that holds a torch.dtype or a device tensor would make every watch through a bound method incomplete -- a 10x slower
+    epoch, silently (found on the GPU when `_fused_quick` was added)."""
+    import re
+    import neurodiffeq_amd.solvers as S
+    src = open(S.__file__).read()
+    names = set(re.findall(r"self\.(_[a-z][a-z_0-9]*) = ", src)) | set(re.findall(r"self\.__dict__\.get\(\"(_[a-z_0-9]+)\"", src))
+    from tests import configs
+    solver, _ = configs.make_solver("c2", 8)
+    missing = sorted(n for n in names if n not in solver._own_attrs)
+    assert not missing, missing
