@@ -266,15 +266,24 @@ struct ReduceTailArgs {
   ndq::SampleArgs smp;
   ValidArgs v;                // v.part == nullptr: no validation loss in this launch
 };
+// TC: gradient columns per workgroup (TC x 16 threads).  64 (1024 threads) is the layout of rounds 2 - 5; narrower workgroups
+// spread the 1.2 MB of partial rows over more CUs / XCDs and launch faster (NDQ_TAIL_COLS; profiles/r06p_tail_cols_ab.txt).  The
+// per-column order (16 row groups of 16 rows) and the loss order (64-lane tree per wave, waves in index order) do not depend on
+// TC as long as the loss partials fit one per thread -- the launchers fall back to 64 columns otherwise.
+#ifndef NDQ_TAIL_COLS
+#define NDQ_TAIL_COLS 64
+#endif
+template <int TC>
 __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
   // Latency-bound (19 workgroups at C2): every global load -- loss partials, this thread's rows of the gradient
   // partials, the parameter / moment values it will update -- is issued before the first reduction step, and there is
   // ONE barrier.  Summation orders are fixed (per-thread chains, then LDS slots added in index order).
-  __shared__ float sm[16 * 64];
+  constexpr int TT = TC * 16, WAVES = TT / 64;
+  __shared__ float sm[16 * TC];
   __shared__ float smw[16];
   __shared__ float smv[16];
-  const int tid = threadIdx.x, c = tid & 63, rg = tid >> 6;
-  const int i = blockIdx.x * 64 + c;
+  const int tid = threadIdx.x, c = tid % TC, rg = tid / TC, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * TC + c;
   const bool col = i < a.r.len;
   const bool has_valid = a.v.part != nullptr;           // uniform over the launch
   const bool has_train = a.r.nparts > 0;                // false: stand-alone validation epoch (no sums, no Adam)
@@ -296,23 +305,23 @@ __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
   const float best = a.t.best_loss[a.t.parity];
   // ---- use
   float lp = lp0, vp = vp0;
-  for (int r = tid + 1024; r < a.r.nlparts; r += 1024) lp += a.r.lpart[r];
+  for (int r = tid + TT; r < a.r.nlparts; r += TT) lp += a.r.lpart[r];       // (TC < 64: never taken, see the launchers)
   if (has_valid)
-    for (int r = tid + 1024; r < a.v.nparts; r += 1024) vp += a.v.part[r];
+    for (int r = tid + TT; r < a.v.nparts; r += TT) vp += a.v.part[r];
   const float colsum = has_train ? rows.finish(a.r.part, a.r.nparts, a.r.len, i, rg) : 0.f;
   for (int off = 32; off > 0; off >>= 1) lp += __shfl_down(lp, off);
   if (has_valid)
     for (int off = 32; off > 0; off >>= 1) vp += __shfl_down(vp, off);
-  if (c == 0) { smw[rg] = lp; smv[rg] = vp; }
-  sm[rg * 64 + c] = colsum;
+  if (lane == 0) { smw[wave] = lp; smv[wave] = vp; }
+  sm[rg * TC + c] = colsum;
   __syncthreads();
   float loss = 0.f, vloss = 0.f;
 #pragma unroll
-  for (int w = 0; w < 16; ++w) loss += smw[w];
+  for (int w = 0; w < WAVES; ++w) loss += smw[w];      // (the 16 - WAVES waves a 1024-thread workgroup would add hold exact zeros)
   loss *= a.r.lscale;
   if (has_valid) {
 #pragma unroll
-    for (int w = 0; w < 16; ++w) vloss += smv[w];
+    for (int w = 0; w < WAVES; ++w) vloss += smv[w];
     vloss *= a.v.scale;
   }
   // what the snapshot follows: the validation loss of the parameters this epoch starts from (fit() with validation
@@ -325,7 +334,7 @@ __device__ __forceinline__ void reduce_tail_body(const ReduceTailArgs& a) {
     if (has_train) {
       float g = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) g += sm[k * 64 + c];
+      for (int k = 0; k < 16; ++k) g += sm[k * TC + c];
       a.r.out[i] = g;
       float pn, mi, vi;
       ndq::adam_value(ndq::AdamConsts{a.t.lr, a.t.b1, a.t.b2, a.t.eps, a.t.wd, a.t.bc1, a.t.bc2s}, pi, g, m0, v0, pn, mi, vi);
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(1024) void reduce_tail_kernel(ReduceTailArgs a) {
     ndq::sample_point_store(a.smp, ((int)blockIdx.x - a.tail_blocks) * 1024 + (int)threadIdx.x);
     return;
   }
-  reduce_tail_body(a);
+  reduce_tail_body<64>(a);
 }
 
 // Data parallel with the one-shot exchange (ndq_oneshot.h): the SAME launch also carries the all-reduce.  Every
@@ -445,10 +454,19 @@ __global__ __launch_bounds__(1024) void reduce_tail_dp_kernel(ReduceTailArgs a, 
 struct ReduceTailMultiArgs {
   ReduceTailArgs net[4];
 };
-__global__ __launch_bounds__(1024) void reduce_tail_multi_kernel(ReduceTailMultiArgs a) {
+template <int TC>
+__global__ __launch_bounds__(TC * 16) void reduce_tail_multi_kernel(ReduceTailMultiArgs a) {
   const ReduceTailArgs& mine = a.net[blockIdx.y];
-  if ((int)blockIdx.x * 64 >= mine.r.len) return;          // networks of one shape: never taken, kept for safety
-  reduce_tail_body(mine);
+  if ((int)blockIdx.x * TC >= mine.r.len) return;          // networks of one shape: never taken, kept for safety
+  reduce_tail_body<TC>(mine);
+}
+// the sums / tail launch of all networks of a system: narrow workgroups where every loss partial has a thread of its own
+static void launch_tail_multi(const ReduceTailMultiArgs& a, int max_params, int n_nets, int max_lparts, hipStream_t st) {
+  if (NDQ_TAIL_COLS < 64 && max_lparts <= NDQ_TAIL_COLS * 16)
+    hipLaunchKernelGGL(reduce_tail_multi_kernel<NDQ_TAIL_COLS>, dim3((max_params + NDQ_TAIL_COLS - 1) / NDQ_TAIL_COLS, n_nets),
+                       dim3(NDQ_TAIL_COLS * 16), 0, st, a);
+  else
+    hipLaunchKernelGGL(reduce_tail_multi_kernel<64>, dim3((max_params + 63) / 64, n_nets), dim3(1024), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------- Adam
@@ -648,8 +666,7 @@ int ndq_fused_multi_step_run(const ndq_fused_step* steps, int n_nets, ndq_fused_
     if (steps[k].n_params > max_params) max_params = steps[k].n_params;
   }
   for (int k = n_nets; k < 4; ++k) a.net[k] = a.net[0];
-  hipLaunchKernelGGL(reduce_tail_multi_kernel, dim3((max_params + 63) / 64, n_nets), dim3(1024), 0,
-                     static_cast<hipStream_t>(stream), a);
+  launch_tail_multi(a, max_params, n_nets, s0.blocks, static_cast<hipStream_t>(stream));
   return (int)hipGetLastError();
 }
 
@@ -678,7 +695,7 @@ int ndq_fused_fit_run(const ndq_fused_fit* f, int n_epochs, const float* const* 
     if (s.n_params > max_params) max_params = s.n_params;
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 tail_grid((max_params + 63) / 64, f->n_nets);
+  const int max_lparts = s0.blocks > f->valid_blocks ? s0.blocks : f->valid_blocks;
   // tail of one epoch: e < n_epochs: training epoch e (+ the validation loss of epoch e - 1 if with_valid);
   // e == n_epochs: the trailing validation epoch alone
   auto tail = [&](int e, bool with_train, bool with_valid, int vindex) {
@@ -704,7 +721,7 @@ int ndq_fused_fit_run(const ndq_fused_fit* f, int n_epochs, const float* const* 
         t.v = ValidArgs{f->valid_loss_partials, f->valid_blocks, f->valid_scale, f->valid_hist, vindex, f->track_best == 2 ? 1 : 0};
     }
     for (int k = f->n_nets; k < 4; ++k) a.net[k] = a.net[0];
-    hipLaunchKernelGGL(reduce_tail_multi_kernel, tail_grid, dim3(1024), 0, st, a);
+    launch_tail_multi(a, max_params, f->n_nets, max_lparts, st);
     parity ^= 1;
     return (int)hipGetLastError();
   };
@@ -830,7 +847,7 @@ int ndq_fused_fit_run(const ndq_fused_fit* f, int n_epochs, const float* const* 
       }
     }
     for (int k = f->n_nets; k < 4; ++k) a.net[k] = a.net[0];
-    hipLaunchKernelGGL(reduce_tail_multi_kernel, tail_grid, dim3(1024), 0, st, a);
+    launch_tail_multi(a, max_params, f->n_nets, max_lparts, st);
     return (int)hipGetLastError();
   }
   for (int e = 0; e < n_epochs; ++e) {

@@ -1,0 +1,95 @@
+"""Solver set-ups a user of the reference builds from its parts -- every wrapper generator, the stock torch optimisers, the named
+losses, several batches per epoch -- trained on the fused MI355X path and as the reference does it (plain torch modules under
+torch autograd, ``fused="off"``) from one seed: loss histories and final parameters agree to fp32 accuracy.  The generators draw
+from torch's CPU generator in the reference's call order, so both runs see the same points bit for bit (generators.py)."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import autograd_ref as R
+
+pytestmark = pytest.mark.gpu
+EPOCHS = 6
+
+
+def _generators():
+    from neurodiffeq_amd import generators as G
+    g1 = lambda n=48, m="equally-spaced-noisy": G.Generator1D(n, 0.0, 2.0, method=m)
+    return {
+        "uniform": lambda: g1(48, "uniform"),
+        "log_spaced_noisy": lambda: G.Generator1D(40, 0.1, 2.0, method="log-spaced-noisy"),
+        "chebyshev": lambda: g1(33, "chebyshev"),
+        "concat": lambda: g1(24) + g1(16, "uniform"),
+        "static": lambda: G.StaticGenerator(g1(40)),
+        "predefined": lambda: G.PredefinedGenerator(torch.linspace(0.0, 2.0, 37)),
+        "transform": lambda: G.TransformGenerator(g1(32), transforms=[lambda t: 2.0 * torch.sin(t) ** 2]),
+        "filter": lambda: G.FilterGenerator(g1(64, "uniform"), filter_fn=lambda xs: xs[0] > 0.4),
+        "resample": lambda: G.ResampleGenerator(g1(64), size=40, replacement=False),
+        "batch": lambda: G.BatchGenerator(g1(64), batch_size=24),
+        "nd": lambda: G.GeneratorND(grid=(36,), r_min=(0.0,), r_max=(2.0,), methods=["equally-spaced"], noisy=True),
+    }
+
+
+def _solver(gen_name, optimizer, loss, n_batches, fused):
+    from neurodiffeq_amd import diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.generators import Generator1D
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.solvers import Solver1D
+    torch.manual_seed(3)
+    nets = [FCNN(1, 1, hidden_units=(32, 32)).cuda()]
+    params = list(itertools.chain.from_iterable(n.parameters() for n in nets))
+    opt = {None: None,
+           "sgd": lambda: torch.optim.SGD(params, lr=1e-2, momentum=0.9, nesterov=True),
+           "rmsprop": lambda: torch.optim.RMSprop(params, lr=1e-3),
+           "adamw": lambda: torch.optim.AdamW(params, lr=1e-3, weight_decay=0.05),
+           "adam_amsgrad": lambda: torch.optim.Adam(params, lr=1e-3, amsgrad=True),
+           "adagrad": lambda: torch.optim.Adagrad(params, lr=1e-2),
+           "nadam": lambda: torch.optim.NAdam(params, lr=1e-3),
+           "lbfgs": lambda: torch.optim.LBFGS(params, lr=0.5, max_iter=4, history_size=5)}[optimizer]
+    kw = {}
+    if opt is not None:
+        kw["optimizer"] = opt()
+    if loss is not None:
+        kw["loss_fn"] = loss
+    s = Solver1D(lambda u, t: [diff(u, t, order=2) + 0.3 * diff(u, t) + u - torch.cos(t)], [IVP(0.0, 1.0, 0.5)], nets=nets,
+                 train_generator=_generators()[gen_name](), valid_generator=Generator1D(32, 0.0, 2.0, method="equally-spaced"),
+                 n_batches_train=n_batches, **kw)
+    s.fused = fused
+    return s
+
+
+def _train(fused, *spec):
+    from neurodiffeq_amd import autograd_ops
+    import warnings
+    torch.manual_seed(17)
+    s = _solver(*spec, fused)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if fused == "off":
+            with autograd_ops.native_autograd(False):
+                s.fit(EPOCHS)
+        else:
+            s.fit(EPOCHS)
+    h = s.metrics_history
+    return np.array(h["train_loss"]), np.array(h["valid_loss"]), R.get_flat(s.nets).double().cpu().numpy(), s
+
+
+CASES = [(g, None, None, 1) for g in sorted(_generators())] + \
+        [("uniform", o, None, 1) for o in ("sgd", "rmsprop", "adamw", "adam_amsgrad", "adagrad", "nadam", "lbfgs")] + \
+        [("uniform", None, l, 1) for l in ("l1", "infinity", "h1", "h1 semi")] + \
+        [("concat", None, None, 3), ("filter", "sgd", "l1", 2), ("batch", "adamw", None, 2)]
+
+
+@pytest.mark.parametrize("gen,optimizer,loss,n_batches", CASES, ids=["-".join(str(x) for x in c if x not in (None, 1)) for c in CASES])
+def test_solver_set_up_trains_like_plain_torch(gen, optimizer, loss, n_batches):
+    ft, fv, fp, fs = _train("auto", gen, optimizer, loss, n_batches)
+    pt, pv, pp, ps = _train("off", gen, optimizer, loss, n_batches)
+    assert len(ft) == len(pt) == EPOCHS and fs.fused_active, "the set-up left the fused path"
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12)))
+    tol = 2e-3 if optimizer == "lbfgs" else 3e-4          # (line searches amplify fp32 differences of the closure)
+    assert rel(ft, pt) < tol, (ft, pt)
+    assert rel(fv, pv) < tol, (fv, pv)
+    assert np.linalg.norm(fp - pp) <= tol * np.linalg.norm(pp)
