@@ -24,7 +24,7 @@ from . import _lib
 # parameter / submodule / buffer set on a tracked module) and hook dictionaries that count their own edits bump
 # STRUCTURE[0], which is part of the solver's system key and of the custom-op seam's cache key.
 STRUCTURE = [0]
-_tracked = weakref.WeakSet()
+_tracked = {}               # id(module) -> weak reference (by id: a user's module may define __eq__ and be unhashable)
 _HOOK_DICTS = ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")
 
 
@@ -63,24 +63,29 @@ class _NotifyingHooks(collections.OrderedDict):
         return (collections.OrderedDict, (), None, None, iter(list(self.items())))
 
 
+def _is_tracked(module):
+    ref = _tracked.get(id(module))
+    return ref is not None and ref() is module
+
+
 def _on_registration(module, name, value):
-    if module in _tracked:
+    if _is_tracked(module):
         STRUCTURE[0] += 1
     return None
 
 
 def track_structure(net):
     """From now on a structural change of ``net`` (any module of its tree) bumps STRUCTURE[0]."""
-    if not _tracked:
-        from torch.nn.modules import module as M
-        if not getattr(M, "_ndq_registration_hooks", False):
-            M.register_module_parameter_registration_hook(_on_registration)
-            M.register_module_module_registration_hook(_on_registration)
-            M.register_module_buffer_registration_hook(_on_registration)
-            M._ndq_registration_hooks = True
+    from torch.nn.modules import module as M
+    if not getattr(M, "_ndq_registration_hooks", False):
+        M.register_module_parameter_registration_hook(_on_registration)
+        M.register_module_module_registration_hook(_on_registration)
+        M.register_module_buffer_registration_hook(_on_registration)
+        M._ndq_registration_hooks = True
     for m in net.modules():
-        if m not in _tracked:
-            _tracked.add(m)
+        if not _is_tracked(m):
+            key = id(m)
+            _tracked[key] = weakref.ref(m, lambda _, key=key: _tracked.pop(key, None))
         for name in _HOOK_DICTS:
             d = m.__dict__.get(name)
             if d is not None and not isinstance(d, _NotifyingHooks):

@@ -171,3 +171,4 @@ def test_the_custom_op_seam_asks_again_after_a_structural_change():
         want = net.NN[2](torch.tanh(2.0 * net.NN[0]._conv_forward(x) if False else 2.0 * torch.nn.functional.linear(x, net.NN[0].weight, net.NN[0].bias)))
         want = net.NN[4](torch.tanh(want))
         assert torch.allclose(net(x), want)
+
