@@ -218,9 +218,9 @@ def test_a_callback_that_changes_the_solver_takes_effect_as_in_the_reference(nam
     pt, pv, pp, ps = _train("off", kind, change)
     assert len(ft) == len(pt) == EPOCHS
     rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12)))
-    assert rel(ft, pt) < 2e-4, (name, "train", ft, pt)
-    assert rel(fv, pv) < 2e-4, (name, "valid", fv, pv)
-    assert np.linalg.norm(fp - pp) <= 2e-4 * np.linalg.norm(pp), (name, "parameters")
+    assert rel(ft, pt) < 2e-5, (name, "train", ft, pt)          # (measured: <= 2e-6; north_star: 1e-5 per closure)
+    assert rel(fv, pv) < 2e-5, (name, "valid", fv, pv)
+    assert np.linalg.norm(fp - pp) <= 2e-5 * np.linalg.norm(pp), (name, "parameters")
 
 
 def test_the_fused_path_is_used_until_the_change_and_left_loudly_when_it_must():

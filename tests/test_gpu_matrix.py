@@ -89,7 +89,7 @@ def test_solver_set_up_trains_like_plain_torch(gen, optimizer, loss, n_batches):
     pt, pv, pp, ps = _train("off", gen, optimizer, loss, n_batches)
     assert len(ft) == len(pt) == EPOCHS and fs.fused_active, "the set-up left the fused path"
     rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12)))
-    tol = 2e-3 if optimizer == "lbfgs" else 3e-4          # (line searches amplify fp32 differences of the closure)
+    tol = 5e-4 if optimizer == "lbfgs" else 1e-5          # (measured: 4e-5 / <= 3e-7; line searches amplify fp32 differences)
     assert rel(ft, pt) < tol, (ft, pt)
     assert rel(fv, pv) < tol, (fv, pv)
     assert np.linalg.norm(fp - pp) <= tol * np.linalg.norm(pp)
