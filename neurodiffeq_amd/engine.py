@@ -232,6 +232,18 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
             if not isinstance(val, SymScalar):
                 raise MetricTraceUnsupported(f"a metric returned {type(val).__name__}, not a batch mean of traced values")
             metric_terms.append(val.term)
+        metric_fns = list(metrics)
+
+        def metric_probe():
+            """Run the metric callables again on the same traced columns: True iff every one still arrives at the per-point term
+            that was compiled (a metric that reads Python state -- the amplitude of an analytic solution a callback changes --
+            is a constant of the kernel otherwise; the reference re-evaluates metrics every batch, solvers.py:377-379)."""
+            with trace_scope(g):
+                for fn, term in zip(metric_fns, metric_terms):
+                    again = fn(*funcs, *coords)
+                    if not (isinstance(again, SymScalar) and again.term.i == term.i):
+                        return False
+            return True
     for k, info in enumerate(infos):       # a net that never appears in an equation still needs a layout
         g.net_deps.setdefault(k, tuple(range(info["d"])))
         g.net_nout.setdefault(k, info["n_out"])
@@ -321,6 +333,7 @@ def trace_system(nets, conditions, diff_eqs, n_coords, compute_func_val=None, lo
     program.n_metrics = len(metric_terms)        # the last n_metrics "functions" are per-point metric terms
     program.func_widths = [len(cols) for cols in func_columns]    # columns of every solver function, in order
     program.loss_probe = loss_probe              # custom losses: "does the callable still trace to the compiled term?"
+    program.metric_probe = metric_probe if metric_terms else None
     program.eq_probe = eq_probe                  # equations / conditions: "do they still trace to the compiled residuals?"
     program.suggest_volatile = suggest_volatile  # ... and if not: which outside numbers moved (-> runtime constants)
     program.unique_nets = nets                   # distinct modules, in first-appearance order: one parameter set each

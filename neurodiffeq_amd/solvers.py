@@ -180,6 +180,7 @@ class BaseSolver(ABC):
         self._eq_watch = None                  # _pystate.StateWatch over what diff_eqs / the conditions can read
         self._eq_probe_countdown = 1           # epochs until the next unconditional re-trace (second use, then EQ_PROBE_EVERY)
         self._fused_key = None
+        self._metrics_follow_state = False     # a traced metric changed between epochs: metrics on the host from then on
         self._fused_quick = None               # what _fused_key was made of, object by object (the per-epoch identity check)
         self._fused_quick_parts = None
         self._fast_tracks_best = False
@@ -431,6 +432,20 @@ class BaseSolver(ABC):
                 # state (a penalty weight annealed with self.global_epoch, ...) are re-probed on their second use and
                 # then every LOSS_PROBE_EVERY epochs: if they now trace to a different term, the solver leaves the fused
                 # path (loudly) rather than train on a stale loss
+                # traced metrics are per-point terms of the same kernels: re-probed every epoch they are evaluated (a solver
+                # with metrics synchronises every epoch anyway); one that follows Python state is evaluated on the host from
+                # then on, as the reference does it (solvers.py:377-379) -- training stays fused
+                mprobe = getattr(sysm.program, "metric_probe", None) if sysm is not None else None
+                if mprobe is not None:
+                    try:
+                        same = mprobe()
+                    except Exception:       # noqa: BLE001
+                        same = False
+                    if not same:
+                        self._metrics_follow_state = True
+                        self._flush_device_history()
+                        self._fused_key = None
+                        return self._fused_system(n_coords)
                 probe = getattr(sysm.program, "loss_probe", None) if sysm is not None else None
                 if probe is None:
                     return sysm
@@ -465,6 +480,8 @@ class BaseSolver(ABC):
                     kind = lambda r, f, x: self.loss_fn(r, f, x) + self.additional_loss(r, f, x)
                 self._host_metrics = False
                 try:
+                    if self._metrics_follow_state and self.metrics_fn:
+                        raise MetricTraceUnsupported("a metric reads Python state that changes between epochs")
                     self._fused_sys = FusedSystem(self.nets, self.conditions, eqs, n_coords, self.device,
                                                   compute_func_val=self.compute_func_val, loss=kind,
                                                   metrics=list(self.metrics_fn.values()), dtype=sys_dtype,

@@ -233,3 +233,43 @@ def test_the_fused_path_is_used_until_the_change_and_left_loudly_when_it_must():
     with pytest.warns(RuntimeWarning, match="NOT on the fused MI355X path"):
         s.fit(1)
     assert not s.fused_active
+
+
+def test_a_metric_that_reads_python_state_follows_it():
+    """Metrics are re-evaluated every batch by the reference (solvers.py:377-379); traced into the kernels they would freeze the
+    numbers they read.  They are re-probed every epoch; one that changed is evaluated on the host from then on, training stays
+    fused."""
+    from neurodiffeq_amd import autograd_ops, diff
+    from neurodiffeq_amd.conditions import IVP
+    from neurodiffeq_amd.generators import Generator1D
+    from neurodiffeq_amd.networks import FCNN
+    from neurodiffeq_amd.solvers import Solver1D
+    import warnings
+
+    def run(fused):
+        ref = {"amp": 1.0}
+        torch.manual_seed(5)
+        s = Solver1D(lambda u, t: [diff(u, t) + u], [IVP(0.0, 1.0)], nets=[FCNN(1, 1, hidden_units=(32, 32)).cuda()],
+                     train_generator=Generator1D(64, 0.0, 2.0, method="equally-spaced"),
+                     valid_generator=Generator1D(32, 0.0, 2.0, method="equally-spaced"),
+                     metrics={"err": lambda u, t: ((u - ref["amp"] * torch.exp(-t)) ** 2).mean()})
+        s.fused = fused
+
+        def cb(solver):
+            if solver.global_epoch in AT:
+                ref["amp"] *= 1.5
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if fused == "off":
+                with autograd_ops.native_autograd(False):
+                    s.fit(EPOCHS, callbacks=[cb])
+            else:
+                s.fit(EPOCHS, callbacks=[cb])
+        h = s.metrics_history
+        return np.array(h["train_loss"]), np.array(h["train__err"]), np.array(h["valid__err"]), s
+    ft, fm, fv, fs = run("auto")
+    pt, pm, pv, ps = run("off")
+    assert fs.fused_active and fs._metrics_follow_state
+    rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12)))
+    assert rel(ft, pt) < 2e-5 and rel(fm, pm) < 2e-5 and rel(fv, pv) < 2e-5, (fm, pm)
+    assert pm[AT[0]] != pytest.approx(pm[AT[0] - 1], rel=0.05)          # (the metric did move when the callback fired)
