@@ -879,6 +879,13 @@ class FusedSystem:
         for fp, g in zip(self.flat, keep[0]):
             fp.grad_loss.copy_(g)
         self.loss_buf[:1].copy_(keep[1])
+        if not all(bool(torch.isfinite(x).all()) for pair in runs + pipe for x in pair):
+            # inf / nan on this batch (points far outside the domain, a diverged state): nan != nan, nothing can be compared.
+            # The reference trains on -- to nan (solvers.py:369-395) --, and so does this path; the build stays unverified and
+            # the next finite batch checks it
+            self._verified.discard(id(fk))
+            self.fused_check = dict(inconclusive="non-finite gradients / loss on the batch at hand")
+            return True
         same = bool(torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]))
         pipe_same = bool(torch.equal(pipe[0][0], pipe[1][0]) and torch.equal(pipe[0][1], pipe[1][1]))
         ref = pipe[0][0].double()

@@ -619,7 +619,9 @@ class BaseSolver(ABC):
         else:
             first_batch = self._generate_batch(key)
         system = self._fused_system(len(first_batch))
-        if system is None:
+        if system is None or first_batch[0].shape[0] == 0:
+            # (a batch with no points at all -- a FilterGenerator that kept nothing: the reference's mean over nothing is nan and
+            # so is everything after it, solvers.py:369-395; the kernels have no such launch)
             return self._run_epoch_composite(key, first_batch)
         if self.dist is not None:
             n_all = first_batch[0].shape[0]
@@ -1100,7 +1102,7 @@ class BaseSolver(ABC):
         nets = self.best_nets if best else self.nets
         if nets is None:
             return None
-        key = (tuple(id(n) for n in nets), id(self.diff_eqs), tuple(id(c) for c in self.conditions), len(coords))
+        key = (tuple(id(n) for n in nets), id(self.diff_eqs), tuple(id(c) for c in self.conditions), len(coords), _net_structure[0])
         # the reference evaluates diff_eqs / the conditions afresh on every call (solvers.py:606-646): a cached trace is used
         # again only if a re-trace on the same symbols still arrives at it (program.eq_probe: ~0.1 - 0.7 ms, this is not the
         # training loop); numbers that moved since become runtime constants of the rebuild (symbolic.Graph.external)
@@ -1194,7 +1196,7 @@ class BaseSolution(ABC):
         if coords[0].device.type != "cuda" or coords[0].dtype != torch.float32 or coords[0].requires_grad \
                 or len(set(id(n) for n in self.nets)) != len(self.nets):
             return None
-        key = (tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions), len(coords))
+        key = (tuple(id(n) for n in self.nets), tuple(id(c) for c in self.conditions), len(coords), _net_structure[0])
         # (a boundary value stored on a condition object may have been changed since the cached trace: re-probed on every
         # call like _fused_residuals -- the reference's solutions call cond.enforce afresh, solvers.py:682-720)
         volatile = frozenset()
