@@ -33,10 +33,20 @@ from .losses import _losses
 from .networks import FCNN, describe
 from .neurodiffeq import safe_diff as diff
 from .optim import FusedAdam
-from .symbolic import MetricTraceUnsupported, TraceUnsupported
+from .symbolic import MetricTraceUnsupported, TraceUnsupported, captured_unchanged
 from .networks import STRUCTURE as _net_structure
 import os as _os
 _QUICK_KEY = _os.environ.get("NDQ_QUICK_KEY", "1") != "0"        # (A/B switch of the per-epoch identity check in _fused_system)
+_LC = []
+
+
+def _library_code():
+    """engine.library_code, imported once (engine imports this module's siblings: a function-level `from .engine import` costs
+    half a microsecond of importlib bookkeeping per epoch)."""
+    if not _LC:
+        from .engine import library_code
+        _LC.append(library_code)
+    return _LC[0]
 
 
 _CLOSURE_CACHE = {}
@@ -420,7 +430,6 @@ class BaseSolver(ABC):
             sysm = self._fused_sys
             # scalar tensors captured by the equations are constants of the generated kernel: re-trace when one of them
             # was modified in place since (callbacks annealing a coefficient between epochs)
-            from .symbolic import captured_unchanged
             if sysm is not None and not captured_unchanged(sysm.program.g):
                 if self._equations_unchanged(sysm, force=True):
                     # same program: every tensor that moved is a runtime constant by now and the re-trace refreshed its value
@@ -610,7 +619,7 @@ class BaseSolver(ABC):
         if self.n_batches[key] <= 0:
             return
         self._phase = key
-        from .engine import library_code
+        library_code = _library_code()
         inner = getattr(self.generator[key], "generator", None)
         if type(inner).__module__ == "neurodiffeq_amd.generators" and type(inner).__name__ in ("DeviceGenerator", "ResidentBatchGenerator") \
                 and type(self)._generate_batch is BaseSolver._generate_batch:
