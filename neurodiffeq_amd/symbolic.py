@@ -981,10 +981,11 @@ class Sym:
             return other._bin(self, op, rev=not rev)
         if isinstance(other, _NarrowSym):
             return other._bin(self, op, rev=not rev)
+        if op == "sub" and (self.isbool or (isinstance(other, Sym) and other.isbool)):
+            # `u - mask`, `1 - mask`, `mask - mask`: torch raises for ANY subtraction with a bool tensor (use ~mask, mask.float())
+            raise TraceUnsupported("subtraction with a bool tensor (torch raises; use ~, ^, logical_xor or mask.float())")
         if self.isbool and _is_boolish(other):
-            # torch.bool (op) torch.bool: + is OR, * is AND (both stay bool); - raises; / is the float quotient
-            if op == "sub":
-                raise TraceUnsupported("subtraction of two bool tensors (torch raises; use ^ or logical_xor)")
+            # torch.bool (op) torch.bool: + is OR, * is AND (both stay bool); / is the float quotient
             if op in ("add", "mul"):
                 o = other.i if isinstance(other, Sym) else g.const(1.0 if bool(other) else 0.0)
                 r = g.mul(self.i, o) if op == "mul" else g.sub(g.add(self.i, o), g.mul(self.i, o))
@@ -1012,7 +1013,10 @@ class Sym:
             raise TraceUnsupported("negation of a bool tensor (torch raises; use ~ or logical_not)")
         return Sym(self.g, self.g.unary("neg", self.i))
     def __pos__(self): return self
-    def __abs__(self): return Sym(self.g, self.g.unary("abs", self.i))
+    def __abs__(self):
+        if self.isbool:
+            raise TraceUnsupported("abs of a bool tensor (torch has no such kernel)")
+        return Sym(self.g, self.g.unary("abs", self.i))
 
     def __pow__(self, e):
         if isinstance(e, Sym):
@@ -1075,7 +1079,7 @@ class Sym:
 
     def __ne__(self, o):
         m = self._eq(o)
-        return NotImplemented if m is NotImplemented else (1.0 - m)._as_bool()
+        return NotImplemented if m is NotImplemented else (1.0 - m._plain())._as_bool()
 
     def eq(self, o): return self == o
     def ne(self, o): return self != o
@@ -1577,10 +1581,19 @@ def _no_options(a, k):
         raise TraceUnsupported(f"unsupported arguments {tuple(a) + tuple(sorted(k))} of an elementwise function on a traced column")
 
 
+def _floaty(x):
+    """A bool mask handed to a MATH function (torch.sin(mask), torch.exp(mask)): torch promotes it to the default float dtype first."""
+    if isinstance(x, Sym) and x.isbool:
+        return x._plain()
+    if isinstance(x, SymMat) and any(c.isbool for c in x.cols):
+        return SymMat([c._plain() if c.isbool else c for c in x.cols])
+    return x
+
+
 def _tf_unary(op):
     def f(x, *a, **k):
         _no_options(a, k)
-        return x._un(op)
+        return _floaty(x)._un(op)
     return f
 
 
@@ -1712,6 +1725,10 @@ def _tf_where(condition, input=None, other=None, **k):
             # identity instead of point by point -- one branch for every point would be a silently different equation
             raise TraceUnsupported("torch.where with a Python bool as the condition of traced branches")
         return input if condition else other
+    for c in ([condition] if isinstance(condition, Sym) else condition.cols):
+        if not c.isbool and c.g.nodes[c._node if isinstance(c, _NarrowSym) else c.i][0] not in ("gt", "ge"):
+            # torch: "where expected condition to be a boolean tensor" -- a float column (also 1 - mask, mask.float()) raises there
+            raise TraceUnsupported("torch.where / masked_fill with a condition that is not a bool mask (torch raises)")
     return _elementwise(_where1, condition, input, other)
 
 
@@ -1786,7 +1803,7 @@ def _tf_cmp(op, swap):
 def _tf_map(op):
     def f(x, *a, **k):
         _no_options(a, k)
-        return _elementwise(lambda c: c._un(op), x)
+        return _elementwise(lambda c: c._un(op), _floaty(x))
     return f
 
 
@@ -1965,7 +1982,7 @@ def _tf_addcdiv(x, t1, t2, value=1.0, **k):
 def _tf_elem(fn):
     def f(x, *a, **k):
         _no_options(a, k)            # (torch.logit(x, eps=...) has a handler of its own)
-        return _elementwise(fn, x)
+        return _elementwise(fn, _floaty(x))
     return f
 
 

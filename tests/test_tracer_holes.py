@@ -114,6 +114,17 @@ PROBES = {
     "invert_a_float": ("lambda D: lambda u, x, y: [D(u, x) + (~x) * u]", "torch raises"),
     "and_of_floats": ("lambda D: lambda u, x, y: [D(u, x) + (x & y) * u]", "torch raises"),
     "or_float_mask": ("lambda D: lambda u, x, y: [D(u, x) + (x | (y > 0)) * u]", "torch raises"),
+    "column_minus_mask": ("lambda D: lambda u, x, y: [D(u, x) + (u - (x > 0))]", "torch raises"),
+    "one_minus_mask": ("lambda D: lambda u, x, y: [D(u, x) + (1 - (x > 0)) * u]", "torch raises"),
+    "mask_minus_number": ("lambda D: lambda u, x, y: [D(u, x) + ((x > 0) - 0.5) * u]", "torch raises"),
+    "abs_of_a_mask": ("lambda D: lambda u, x, y: [D(u, x) + abs(x > 0) * u]", "torch raises"),
+    "where_on_a_float_condition": ("lambda D: lambda u, x, y: [D(u, x) + torch.where(x, u, y)]", "torch raises"),
+    "where_on_a_float32_mask": ("lambda D: lambda u, x, y: [D(u, x) + torch.where((x > 0).float(), u, y)]", "torch raises"),
+    "masked_fill_on_a_float_mask": ("lambda D: lambda u, x, y: [D(u, x) + u.masked_fill(x, 0.0)]", "torch raises"),
+    "math_functions_of_masks": ("lambda D: lambda u, x, y: [D(u, x) + torch.sin(x > 0) * u + torch.exp(y > 0) * u "
+                                "+ torch.asin((x > 0) * (y > 0)) * u + torch.sqrt(x > 0) * u + (1 - (x > 0).double()) * u]", False),
+    "where_on_composed_masks": ("lambda D: lambda u, x, y: [D(u, x) + torch.where((x > 0) & (y > 0), u, y) + torch.where(~(x > 0), u, y) "
+                                "+ u.masked_fill((x > 0) | (y < 0), 0.5) + torch.where(torch.round(2 * x).bool(), u, y)]", False),
     "coordinate_switched_off": ("lambda D: lambda u, x, y: [D(u, x.requires_grad_(False)) + u]", "torch raises"),
     # float32 values inside the fp64 build (the probes run the fp64 host pipeline): the reference rounds / computes in float32
     "float_of_a_value": ("lambda D: lambda u, x, y: [D(u, x) + u.float() * x]", True),
