@@ -383,7 +383,14 @@ class Graph:
         elif op in ("gt", "ge"):
             r = self.const(0.0)              # a mask: piecewise constant
         elif op == "where":
-            r = self.where(n[1], D(n[2]), D(n[3]))
+            # m a' + (1 - m) b', not where(m, a', b'): autograd sends an exact 0.0 into the branch that was not taken and MULTIPLIES
+            # it by that branch's local derivative -- 0 * inf = nan.  `torch.where(x > 0, torch.sqrt(x), 0.0)` differentiated with
+            # respect to x is nan at x <= 0 in the reference (the well-known pitfall); a select would hand back a clean 0 there
+            m, da, db = n[1], D(n[2]), D(n[3])
+            if self.cval(da) == 0.0 and self.cval(db) == 0.0:
+                r = self.const(0.0)
+            else:
+                r = self.add(self.mul(m, da), self.mul(self.sub(self.const(1.0), m), db))
         elif op == "atan2":
             a, b = n[1], n[2]                # d atan2(a, b) = (b da - a db) / (a^2 + b^2)
             r = self.div(self.sub(self.mul(b, D(a)), self.mul(a, D(b))), self.add(self.mul(a, a), self.mul(b, b)))

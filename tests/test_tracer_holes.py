@@ -297,3 +297,39 @@ def test_network_called_by_hand_inside_enforce(name):
         return
     r, l, g = _run(system)
     assert r < 1e-10 and l < 1e-10 and g < 1e-9, (name, r, l, g)
+
+
+@pytest.mark.parametrize("src,resid_nan,grad_nan", [
+    # the well-known pitfall: autograd multiplies an exact 0.0 by the local derivative of the branch NOT taken
+    ("lambda D: lambda u, x, y: [D(u * torch.where(x > 0, torch.sqrt(x), 0.0 * x), x)]", True, True),
+    ("lambda D: lambda u, x, y: [D(u, x) + torch.where(u > 0, torch.sqrt(u), 0.0 * u)]", False, True),
+    # ... and the same masks where every branch has a finite derivative stay clean
+    ("lambda D: lambda u, x, y: [D(u * torch.where(x > 0, torch.sqrt(torch.where(x > 0, x, 1.0 + 0.0 * x)), 0.0 * x), x)]", False, False),
+    ("lambda D: lambda u, x, y: [D(torch.relu(u) * torch.clamp(x, min=0.0), x) + torch.where(x > 0, u / (x + 2.0), u)]", False, False),
+])
+def test_nan_of_a_branch_not_taken_is_the_references_nan(src, resid_nan, grad_nan):
+    """`torch.where(x > 0, torch.sqrt(x), 0)` differentiated where x <= 0: nan in the reference (0 * inf), so nan here -- a
+    traced select that returned a clean 0 there would train on where the reference stops (Graph.diff, rule for `where`)."""
+    from oracle import autograd_ref as R
+    from tests.test_trace_codegen import host_closure
+    system = _pde_system("nan", src)
+    torch.manual_seed(100)
+    nets, conds, pde = system.product()
+    flat = R.get_flat(nets)
+    coords = system.sample(48, seed=0)
+    onets, enforcers, opde = system.oracle(flat)
+    was = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        want = R.closure(onets, enforcers, opde, coords)
+        wg = R.get_flat_grad(onets).numpy()
+        prog, funcs, resid, loss, grad = host_closure(nets, conds, pde, np.stack([c.numpy() for c in coords]), flat.double().numpy(), f64=True)
+    finally:
+        torch.set_default_dtype(was)
+    wr = want["residuals"].numpy()
+    assert np.isnan(wr).any() == resid_nan and np.isnan(wg).any() == grad_nan          # (what the reference does)
+    assert np.array_equal(np.isnan(resid), np.isnan(wr)) and np.array_equal(np.isnan(grad), np.isnan(wg))
+    ok = ~np.isnan(wr)
+    assert np.allclose(resid[ok], wr[ok], rtol=1e-10, atol=1e-12)
+    if not grad_nan:
+        assert rel_l2(grad, wg) < 1e-9
