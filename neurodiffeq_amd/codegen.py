@@ -827,6 +827,15 @@ extern "C" int ndq_fused_num_nets() {{ return 1; }}
 extern "C" int ndq_fused_threads() {{ return CFG::BWD_THREADS; }}
 extern "C" unsigned long ndq_fused_lds_bytes() {{ return (unsigned long){lds('true')}; }}
 
+#ifdef NDQ_PHASE_TS
+extern "C" int ndq_fused_phase_ts(unsigned long long* out) {{    // experiments: scripts/phase_ts_group.py
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ndq::ndq_phase_ts), sizeof(unsigned long long) * 256 * 8);
+}}
+extern "C" int ndq_fused_tile_ts(unsigned long long* out) {{
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ndq::ndq_tile_ts), sizeof(unsigned long long) * 48);
+}}
+#endif
+
 extern "C" int ndq_fused_launch(const float* coords, int ldc, int n, const float* params, float* partials,
                                 float* loss_partials, float* funcs, float* resid, int ldj, float seed, int train,
                                 void* stream) {{

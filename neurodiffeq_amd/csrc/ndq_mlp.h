@@ -3540,6 +3540,7 @@ template <class C, class PW, bool TRAIN>
 __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, real* lds, const int blk, const int nblk,
                                                          const PullArgs& pull, bool writer) {
   static_assert(!C::ACC_LDS, "grouped closure: H <= 48");
+  NDQ_TS(0);
   const real* prm = a.params;
 #if !NDQ_F64
   if constexpr (pull_supported<C>()) {
@@ -3567,6 +3568,7 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
   }
   stage_weights<C, TRAIN>(lds, prm);
   __syncthreads();
+  NDQ_TS(1);
   real* stage = lds + C::ldsWeightsEnd(TRAIN) + wave * C::stageFloatsPerWave;
   real* X = lds + C::ldsWeightsEnd(TRAIN) + WAVES * C::stageFloatsPerWave + wave * (GP * XS);
   GradAcc<C> acc;
@@ -3596,6 +3598,7 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
     }
 #endif
     // ---- phase 1: forward streams of the 4 tiles -> X
+    NDQ_TT(0);
     NDQ_UNROLL(NDQ_GROUP_U1)
     for (int t = 0; t < G; ++t) {
       real x[C::D];
@@ -3642,6 +3645,7 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- phase 2: the per-point program, one point per lane
+    NDQ_TT(1);
     {
       real r[PW::NR], f[PW::NF > 0 ? PW::NF : 1], gth[PW::NT > 0 ? PW::NT : 1];
 #pragma unroll
@@ -3670,6 +3674,7 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       // ---- phase 3: forward with kept states + reverse pass, tile by tile (seed = 0 for padding points: their rows
       // hold zero adjoints)
+      NDQ_TT(2);
       NDQ_UNROLL(NDQ_GROUP_U3)
       for (int t = 0; t < G; ++t) {
         if ((grp * G + t) * 16 >= a.n) break;            // whole tile is padding (uniform over the wave)
@@ -3702,8 +3707,10 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      NDQ_TT(3);
     }
   }
+  NDQ_TS(2);
   if constexpr (TRAIN) block_reduce_store<C, WAVES>(lds, acc, wave, lane, p, q, a.partials + (size_t)blk * C::P, a.params);
   lsum = point_sum(quad_sum(lsum));                      // all 64 lanes carry a point here
   __syncthreads();
@@ -3716,6 +3723,7 @@ __device__ __forceinline__ void fused_group_closure_body(const FusedArgs& a, rea
     a.loss_partials[blk] = v;
   }
   if constexpr (TRAIN) theta_block_sum<PW::NT>(tsum, wl + 16, WAVES, a.theta_partials ? a.theta_partials + (size_t)blk * PW::NT : nullptr);
+  NDQ_TS(3);
 }
 
 template <class C, class PW, bool TRAIN>
