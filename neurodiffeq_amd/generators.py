@@ -9,6 +9,7 @@ HBM as one SoA block.  Two additions without a reference counterpart keep the pr
 distributions drawn by a Philox kernel on the MI355X, a fresh batch per epoch with no PCIe hand-off)."""
 import ctypes
 import os
+import warnings
 import weakref
 
 import numpy as np
@@ -59,6 +60,39 @@ def _rows_inplace(z, scale, shift):
     return z
 
 
+#: attributes a generator of the reference reads WHEN IT DRAWS (generators.py:107-416: the getters are lambdas over ``self``), i.e.
+#: what a callback can change between epochs with effect -- the grid tensors, the noise widths, the getter itself.  (t_min / t_max /
+#: grid are consumed by __init__: changing them later has no effect in the reference either.)
+_LIVE = ("getter", "get_r", "examples", "grid_x", "grid_y", "grid_z", "noise_std", "noise_xstd", "noise_ystd", "size", "shape", "method")
+
+
+def live_stamp(gen, names=_LIVE):
+    """What ``gen`` would draw from right now, cheaply comparable: (attribute, value) for numbers, (attribute, id, version) for
+    tensors / callables.  A shortcut that was derived from the generator's state (one-call bulk draws, a device-side sampler's
+    descriptor) is only valid while this stamp is what it was."""
+    out = [type(gen).get_examples]
+    d = gen.__dict__
+    for name in names:
+        v = d.get(name)
+        if isinstance(v, torch.Tensor):
+            out.append((id(v), v._version))
+        elif isinstance(v, (list, tuple)):
+            out.append(tuple(v))
+        else:
+            out.append(v)
+    return out
+
+
+def _bulk_validate(gen):
+    """First use, or a callback has changed what the generator draws from (noise width, grid tensors, the getter): whatever was
+    cached or proven for the old state is void."""
+    stamp = live_stamp(gen)
+    if gen.__dict__.get("_bulk_stamp") != stamp:
+        gen.__dict__.pop("_bulk_rows", None)
+        gen._bulk_ok = None
+        gen._bulk_stamp = stamp
+
+
 def _checked_bulk(gen, k, draw):
     """``draw(k)`` -> host tensor [k][d][size] holding what ``k`` consecutive ``gen.get_examples()`` calls would return,
     drawn with ONE call into torch's CPU generator (the multi-epoch fit path of the solvers draws the batches of a whole
@@ -66,6 +100,7 @@ def _checked_bulk(gen, k, draw):
     reproduces a sequence of short ones exactly when every short one is a whole number of blocks -- but that is a
     property of torch's kernels, not of its API: the first use on a generator proves it (two batches drawn both ways
     from the same RNG state, which is restored) and the generator falls back to one call per batch if it does not hold."""
+    _bulk_validate(gen)
     ok = gen.__dict__.get("_bulk_ok")
     if ok is None:
         state = torch.get_rng_state()
@@ -226,12 +261,10 @@ class Generator2D(BaseGenerator):
         # (torch.normal(mean=m, std=s) = normal_(0, s) + add_(m), and normal_(0, s) is the standard normal draw times s in
         # one rounding: one standard normal_ over [k][x | y][size], then the scale and the shift per row)
         if self.method == "equally-spaced-noisy" and self.size % 16 == 0:
-            cache = self.__dict__.get("_bulk_rows")
-            if cache is None:
-                mean = torch.stack([self.grid_x.detach(), self.grid_y.detach()]).unsqueeze(0)
-                std = torch.tensor([self.noise_xstd, self.noise_ystd], dtype=mean.dtype, device=_CPU).view(1, 2, 1)
-                cache = self._bulk_rows = (mean, std)
-            mean, std = cache
+            # (built from the generator's CURRENT grid tensors and noise widths on every call -- once per chunk of epochs: a copy
+            # kept across calls would miss `g.grid_y.data.mul_(2.0)`, which no version counter sees)
+            mean = torch.stack([self.grid_x.detach(), self.grid_y.detach()]).unsqueeze(0)
+            std = torch.tensor([self.noise_xstd, self.noise_ystd], dtype=mean.dtype, device=_CPU).view(1, 2, 1)
             return _checked_bulk(self, k, lambda kk: _rows_inplace(
                 torch.empty(kk, 2, self.size, dtype=mean.dtype, device=_CPU).normal_(), std, mean))
         return None
@@ -721,6 +754,11 @@ class DeviceGenerator(BaseGenerator):
         self.stream_id = int(os.environ.get("RANK", "0")) if stream_id is None else int(stream_id)
         self.draw = 0
         self.desc = self.describe(generator)
+        # the descriptor froze what the wrapped generator draws from; the reference reads it at every draw (generators.py:107-416),
+        # so a callback that changes a noise width / replaces a grid tensor or the getter has to be seen: live_stamp per draw
+        self._live_names = tuple(n for n in _LIVE if n in vars(generator))
+        self._stamp = live_stamp(generator, self._live_names)
+        self._on_host = False
         self._L = _lib.lib()
         ld = (self.size + 63) // 64 * 64
         # prefetch=True: a solver on the single-launch native path lets the extra workgroups of its sums + tail kernel
@@ -780,7 +818,49 @@ class DeviceGenerator(BaseGenerator):
         """The block draw number ``draw`` lives in."""
         return self.blocks[draw & 1] if self.prefetch else self.blocks[0]
 
+    def _wrapped_changed(self):
+        """The wrapped generator no longer draws what the descriptor says.  Noise widths alone: a new descriptor.  Anything else (grid
+        tensors replaced / edited in place, another getter, another size): the wrapped generator's own host draw from now on,
+        copied into the resident block -- what the reference would train on."""
+        g = self.generator
+        try:
+            new = self.describe(g)
+            same_shape = new.kind == self.desc.kind and new.d == self.desc.d and list(new.n) == list(self.desc.n) and g.size == self.size
+        except Exception:       # noqa: BLE001
+            new, same_shape = None, False
+        numbers_only = same_shape and all(
+            a == b for n, a, b in zip(("type",) + self._live_names, self._stamp, live_stamp(g, self._live_names))
+            if not n.startswith("noise"))
+        if numbers_only:
+            self.desc = new
+            self.prefetched = None              # (a batch drawn ahead by a tail kernel used the old widths)
+        else:
+            self._on_host, self.prefetch, self.prefetched = True, False, None
+            warnings.warn("neurodiffeq_amd: a generator wrapped by DeviceGenerator was changed in a way the device sampler cannot "
+                          "follow (grid tensors / getter / size); its own host draw is used from now on (the reference's numbers, "
+                          "uploaded every epoch).", RuntimeWarning)
+        self._stamp = live_stamp(g, self._live_names)
+
+    def _host_examples(self):
+        ex = self.generator.get_examples()
+        ex = [ex] if isinstance(ex, torch.Tensor) else list(ex)
+        if len(ex) != self.desc.d or ex[0].numel() != self.size:
+            self.size = ex[0].numel()
+            return [e.detach().reshape(-1, 1).to(self.device, self.dtype) for e in ex]      # (another shape altogether: plain tensors)
+        block, views = self._out_blocks[0], self._views_all[0]
+        for i, e in enumerate(ex):
+            block[i, :self.size].copy_(e.detach().reshape(-1))
+        self.block, self._views = self.blocks[0], views
+        self.draw += 1
+        return views
+
     def _get_examples(self):
+        if self._on_host:
+            return self._host_examples()
+        if live_stamp(self.generator, self._live_names) != self._stamp:
+            self._wrapped_changed()
+            if self._on_host:
+                return self._host_examples()
         block = self.block_of(self.draw)
         if self.prefetched == self.draw:          # a tail kernel has drawn this batch already
             self.prefetched = None

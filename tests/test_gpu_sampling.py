@@ -208,3 +208,38 @@ def _grid_nodes(G, name):
             "3d-noisy": lambda: G.Generator3D((16, 16, 16), (0.0, 0.0, 0.0), (1.0, 2.0, 3.0), method="equally-spaced")}[name]()
     ex = spec.get_examples()
     return [ex] if isinstance(ex, torch.Tensor) else list(ex)
+
+
+def test_device_generator_follows_what_a_callback_changes_on_the_wrapped_generator():
+    """The reference's generators read their grid tensors, noise widths and getter WHEN THEY DRAW (generators.py:107-416): a noise
+    width annealed by a callback, a grid replaced for a curriculum.  The device sampler froze them in its descriptor; it re-reads a
+    cheap stamp of those attributes every draw -- new widths: new descriptor, anything else: the wrapped generator's own host draw."""
+    import warnings
+    from neurodiffeq_amd.generators import DeviceGenerator, Generator1D, Generator2D
+    torch.manual_seed(0)
+    g = Generator1D(4096, 0.0, 2.0, method="equally-spaced-noisy")
+    grid = torch.linspace(0.0, 2.0, 4096)
+    dg = DeviceGenerator(g, seed=3)
+    spread = lambda: float((dg.get_examples()[0].reshape(-1).cpu() - grid).std())
+    s0 = spread()
+    assert abs(s0 / g.noise_std - 1.0) < 0.1
+    g.noise_std = 20.0 * g.noise_std                                   # a callback widening the jitter
+    s1 = spread()
+    assert abs(s1 / g.noise_std - 1.0) < 0.1 and not dg._on_host, (s0, s1)
+    launches = dg.launches
+    g.examples = torch.linspace(5.0, 6.0, 4096)                        # a curriculum moving the grid: no descriptor for that
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        x = dg.get_examples()[0].reshape(-1).cpu()
+    assert dg._on_host and any("host draw" in str(m.message) for m in w)
+    assert x.shape == (4096,) and abs(float(x.mean()) - 5.5) < 0.5 and dg.launches == launches      # drawn by the wrapped generator
+    x2 = dg.get_examples()[0].reshape(-1).cpu()
+    assert not torch.equal(x, x2) and abs(float(x2.mean()) - 5.5) < 0.5
+    # a prefetching 2-D generator: the batch a tail kernel may have drawn ahead with the old widths is not served
+    g2 = Generator2D((64, 64), (0, 0), (1, 1), method="equally-spaced-noisy")
+    d2 = DeviceGenerator(g2, seed=5, prefetch=True)
+    d2.get_examples()
+    g2.noise_xstd = 10.0 * g2.noise_xstd
+    ex = d2.get_examples()
+    gx = g2.grid_x.detach()
+    assert abs(float((ex[0].reshape(-1).cpu() - gx).std()) / g2.noise_xstd - 1.0) < 0.1 and not d2._on_host
