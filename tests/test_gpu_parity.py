@@ -1033,6 +1033,15 @@ def test_static_host_batches_are_cached_and_invalidated():
     edited = loss_of(system, [x, y])
     _, fresh = _load_system("c2", 16)
     assert edited != first[0] and edited == loss_of(fresh, [x.clone(), y.clone()])
+    # ... and an edit through `.data` / a numpy view, which bumps no version counter (a callback shifting or rescaling a static
+    # grid in place): seen by the first / last value that are part of a batch's identity
+    assert loss_of(system, [x, y]) == edited
+    v = y._version
+    y.data.mul_(0.5)
+    x.numpy()[:] += 0.25
+    assert y._version == v
+    again = loss_of(system, [x, y])
+    assert again != edited and again == loss_of(fresh, [x.clone(), y.clone()])
 
 
 def test_bundle_solver_trains_fused_and_matches_autograd_path():
