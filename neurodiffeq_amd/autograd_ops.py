@@ -338,12 +338,21 @@ def _spec_for(net, order, dtype=torch.float32):
     if cache.get("structure") != STRUCTURE[0]:           # a layer / parameter / hook of some tracked network changed: ask again
         cache.clear()
         cache["structure"] = STRUCTURE[0]
+    state = cache.get("act_state")
+    if state:                                            # plain numbers of the activation modules (ELU.alpha, Swish.beta ...)
+        for a, k, v in state:
+            if getattr(a, k, None) != v:
+                cache.clear()
+                cache["structure"] = STRUCTURE[0]
+                break
     hit = cache.get((order, dtype))
     if hit is not None:
         return hit if hit else None
     track_structure(net)
     cache["structure"] = STRUCTURE[0]
     info = describe(net, dtype=dtype)
+    if info is not None:
+        cache["act_state"] = info["act_state"]
     ok = info is not None and info["skip"] == 0 and info.get("skip_sym") is None and info["actp"] == 0 and info["widths"] == 0 and info["mono"] == 0 and 1 <= info["d"] <= 3 \
         and (order < 4 or info["d"] <= 2)          # (every fourth-order partial of three inputs would be 35 streams)
     if ok:

@@ -386,9 +386,14 @@ def describe(net, dtype=torch.float32):
         if n_in % n_deg or hidden > 48:
             return None
         n_in //= n_deg
+    # plain (non-parameter) numbers of the activation modules the kernels were specialised for: `act.beta = 2.0` by a callback
+    # registers nothing with torch -- FlatParams.act_unchanged() re-reads them every epoch (nothing to read for Tanh / Sigmoid / sin)
+    act_state = [(a, k, getattr(a, k)) for a in acts for k in ("alpha", "beta", "gamma", "threshold", "approximate", "trainable")
+                 if hasattr(a, k) and not isinstance(getattr(a, k), torch.Tensor)]
     return dict(d=n_in, mono=mono, hidden=hidden, layers=len(acts), act=_ACT_IDS[next(iter(act_types))],
                 n_out=linears[-1].out_features, linears=linears, skip=int(skip is not None), params=params,
-                actp=1 if act_params else (2 if act_frozen else 0), frozen=act_frozen, widths=widths, skip_sym=skip_sym)
+                actp=1 if act_params else (2 if act_frozen else 0), frozen=act_frozen, widths=widths, skip_sym=skip_sym,
+                act_state=act_state)
 
 
 class FlatParams:
@@ -405,6 +410,7 @@ class FlatParams:
         info = describe(net, dtype=dtype)
         self.params = info["params"]
         self.frozen = info["frozen"]      # fixed non-default activation scalars: behind the trainable entries of ``flat``
+        self.act_state = info["act_state"]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
         # gradient buffer with one spare trailing slot: single-network systems keep the batch loss there so that
@@ -439,6 +445,13 @@ class FlatParams:
                 p.data = flat[off:off + p.numel()].view(p.shape)
         self.flat = flat
         self._ptrs = [flat.data_ptr() + self.esize * off for off in self._offsets]
+
+    def act_unchanged(self):
+        """Are the plain numbers of the activation modules (Swish.beta, ELU.alpha, ...) still what the kernels were built for?"""
+        for a, k, v in self.act_state:
+            if getattr(a, k, None) != v:
+                return False
+        return True
 
     def all_trainable(self):
         """Does every parameter still ask for a gradient?  (``layer.requires_grad_(False)`` by a callback: the reference stops

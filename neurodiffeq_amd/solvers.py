@@ -417,9 +417,11 @@ class BaseSolver(ABC):
                 key = self._fused_key            # (the same system as last epoch: from the next epoch on the quick check serves it)
                 parts = self._fused_quick_parts
                 self._fused_quick = parts[:11] + (key, parts[11])
-        if key == self._fused_key and self._fused_sys is not None and not all(fp.all_trainable() for fp in self._fused_sys.flat):
+        if key == self._fused_key and self._fused_sys is not None and \
+                not all(fp.all_trainable() and (not fp.act_state or fp.act_unchanged()) for fp in self._fused_sys.flat):
             self._flush_device_history()
-            self._fused_key = None              # a layer frozen by a callback: describe() sends the system to the composite path
+            self._fused_key = None              # a layer frozen by a callback (describe() sends the system to the composite path) / a number
+            #                                     of an activation module changed (Swish.beta, ELU.alpha: rebuilt for the new value, or left)
         if key == self._fused_key and self._fused_sys is not None and not self._equations_unchanged(self._fused_sys):
             # the callables compute something else now: rebuild below (cached by source) -- with the outside numbers that
             # moved since the compiled trace as RUNTIME constants (symbolic.Graph.external): a coefficient ramped every epoch
