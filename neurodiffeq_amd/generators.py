@@ -757,7 +757,7 @@ class DeviceGenerator(BaseGenerator):
         # the descriptor froze what the wrapped generator draws from; the reference reads it at every draw (generators.py:107-416),
         # so a callback that changes a noise width / replaces a grid tensor or the getter has to be seen: live_stamp per draw
         self._live_names = tuple(n for n in _LIVE if n in vars(generator))
-        self._stamp = live_stamp(generator, self._live_names)
+        self._restamp()
         self._on_host = False
         self._L = _lib.lib()
         ld = (self.size + 63) // 64 * 64
@@ -818,6 +818,26 @@ class DeviceGenerator(BaseGenerator):
         """The block draw number ``draw`` lives in."""
         return self.blocks[draw & 1] if self.prefetch else self.blocks[0]
 
+    def _restamp(self):
+        g = self.generator
+        self._stamp = live_stamp(g, self._live_names)
+        d = vars(g)
+        # the per-draw form of the same stamp: object identity of every live attribute + the version counters of the tensors
+        self._quick = tuple((n, d.get(n)) for n in self._live_names)
+        self._quick_t = tuple((v, v._version) for _, v in self._quick if isinstance(v, torch.Tensor))
+        self._quick_f = type(g).get_examples
+
+    def _unchanged(self):
+        g = self.generator
+        d = g.__dict__
+        for n, v in self._quick:
+            if d.get(n) is not v:
+                return False
+        for t, ver in self._quick_t:
+            if t._version != ver:
+                return False
+        return type(g).get_examples is self._quick_f
+
     def _wrapped_changed(self):
         """The wrapped generator no longer draws what the descriptor says.  Noise widths alone: a new descriptor.  Anything else (grid
         tensors replaced / edited in place, another getter, another size): the wrapped generator's own host draw from now on,
@@ -839,7 +859,7 @@ class DeviceGenerator(BaseGenerator):
             warnings.warn("neurodiffeq_amd: a generator wrapped by DeviceGenerator was changed in a way the device sampler cannot "
                           "follow (grid tensors / getter / size); its own host draw is used from now on (the reference's numbers, "
                           "uploaded every epoch).", RuntimeWarning)
-        self._stamp = live_stamp(g, self._live_names)
+        self._restamp()
 
     def _host_examples(self):
         ex = self.generator.get_examples()
@@ -857,7 +877,7 @@ class DeviceGenerator(BaseGenerator):
     def _get_examples(self):
         if self._on_host:
             return self._host_examples()
-        if live_stamp(self.generator, self._live_names) != self._stamp:
+        if not self._unchanged():
             self._wrapped_changed()
             if self._on_host:
                 return self._host_examples()

@@ -630,9 +630,7 @@ class BaseSolver(ABC):
         else:
             first_batch = self._generate_batch(key)
         system = self._fused_system(len(first_batch))
-        if system is None or first_batch[0].shape[0] == 0:
-            # (a batch with no points at all -- a FilterGenerator that kept nothing: the reference's mean over nothing is nan and
-            # so is everything after it, solvers.py:369-395; the kernels have no such launch)
+        if system is None:
             return self._run_epoch_composite(key, first_batch)
         if self.dist is not None:
             n_all = first_batch[0].shape[0]
@@ -643,7 +641,13 @@ class BaseSolver(ABC):
         nb = self.n_batches[key]
         with library_code() as lc:         # (user code below -- further batches -- runs inside lc.user_code())
             self._lc = lc
-            done = self._run_epoch_native(key, system, first_batch)
+            # (a batch with no points at all -- a FilterGenerator that kept nothing: the reference's mean over nothing is nan and
+            # so is everything after it, solvers.py:369-395; the kernels have no such launch.  Asked in here: under a global
+            # TorchFunctionMode every tensor attribute read outside library_code costs ~0.6 us)
+            empty = first_batch[0].shape[0] == 0
+            done = False if empty else self._run_epoch_native(key, system, first_batch)
+        if empty:
+            return self._run_epoch_composite(key, first_batch)
         if done:
             return
         metric_values = {name: 0.0 for name in self.metrics_fn}
