@@ -372,8 +372,8 @@ def try_jet_forward(net, t):
     if not _ENABLED or not isinstance(t, torch.Tensor) or t.device.type not in _DEVICE_TYPES \
             or t.dtype not in (torch.float32, torch.float64) or t.dim() != 2:
         return None
-    if t.shape[0] == 0 or torch.jit.is_tracing():
-        return None
+    if t.shape[0] == 0 or torch.jit.is_tracing() or torch.is_autocast_enabled():
+        return None                      # (under autocast the plain forward runs its layers in half precision, as the user asked)
     want_grad = torch.is_grad_enabled() and t.requires_grad
     order = _MAX_ORDER if want_grad else 0
     spec = _spec_for(net, order, t.dtype)

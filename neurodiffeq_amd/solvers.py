@@ -197,7 +197,7 @@ class BaseSolver(ABC):
         self.dist = None                # optional neurodiffeq_amd.parallel.BatchSharding
         # the solver's own bookkeeping attributes: not equation state when diff_eqs is a bound method (_pystate.StateWatch)
         self._own_attrs = (frozenset(self.__dict__) - attrs_of_the_subclass) | {"_own_attrs", "_best_nets_from_device", "_dtype_probe", "_eq_watch_warned", "_lc", "_volatile",
-                                                       "_eval_key", "_eval_sys", "_host_metrics", "_resid_key", "_resid_sys"}
+                                                       "_eval_key", "_eval_sys", "_host_metrics", "_resid_key", "_resid_sys", "_autocast_warned"}
 
     # ------------------------------------------------------------------------------------------ loss function
     def _set_loss_fn(self, criterion):
@@ -398,6 +398,17 @@ class BaseSolver(ABC):
         if self.fused == "off" or self.device.type != "cuda":
             if self.fused == "require":
                 raise _lib.NdqError("fused='require' but no MI355X is visible")
+            return None
+        if torch.is_autocast_enabled():
+            # `with torch.autocast("cuda"): solver.fit(...)`: the reference's linear layers then run in half precision and its
+            # results carry that (1e-3); the kernels have one precision.  The reference's closure it is, said once
+            if self.fused == "require":
+                raise _lib.NdqError("fused='require' but torch.autocast is enabled: the fused kernels do not change precision with it")
+            if not self.__dict__.get("_autocast_warned"):
+                self._autocast_warned = True
+                warnings.warn("neurodiffeq_amd: torch.autocast is enabled; this solver runs the reference's closure on torch autograd "
+                              "while it is (the fused MI355X kernels compute in the networks' own precision).", RuntimeWarning)
+            self._flush_device_history()
             return None
         # (this runs every epoch and the host is the bottleneck of the headline step: when every OBJECT the key below is made of
         # is the one it was made of last time, the key is last time's -- one chain of identity comparisons instead of five

@@ -296,3 +296,30 @@ def test_a_metric_that_reads_python_state_follows_it():
     rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-12)))
     assert rel(ft, pt) < 2e-5 and rel(fm, pm) < 2e-5 and rel(fv, pv) < 2e-5, (fm, pm)
     assert pm[AT[0]] != pytest.approx(pm[AT[0] - 1], rel=0.05)          # (the metric did move when the callback fired)
+
+
+def test_autocast_sends_the_solver_to_the_references_closure():
+    """`with torch.autocast("cuda"): solver.fit(...)`: the reference's layers run in half precision there; the fused kernels have one
+    precision, so the solver runs the reference's closure while autocast is on (same numbers as plain torch modules) and returns to
+    the fused path afterwards."""
+    from neurodiffeq_amd import autograd_ops
+    import warnings
+
+    def run(fused):
+        s = _solver(fused, "ode")
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ctx = autograd_ops.native_autograd(False) if fused == "off" else autograd_ops.native_autograd(None)
+            with ctx:
+                s.fit(2)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    s.fit(3)
+                    inside = s._fused_system(1)
+                s.fit(2)
+                after = s._fused_system(1)
+        said = any("torch.autocast is enabled" in str(m.message) for m in w)
+        return np.array(s.metrics_history["train_loss"]), inside, after, said
+    a, inside, after, said = run("auto")
+    b, _, _, _ = run("off")
+    assert inside is None and after is not None and said
+    assert np.allclose(a[:2], b[:2], rtol=2e-5) and np.allclose(a, b, rtol=5e-2)      # (bf16 layers: the two runs round alike, not equal)
